@@ -1,0 +1,189 @@
+/*
+ * metafast_hip.h -- C-ABI of the MI355X-native MetaFast hot path
+ * (libmetafast_hip.so; hand-written HIP for gfx950 behind plain C entry points).
+ *
+ * The reference (ctlab/metafast) is pure Java and has NO FFI: its seams for this
+ * path are Java static methods called from Tool.runImpl on the main thread.  Each
+ * entry point below replaces one of those seams and cites it.  The reference-side
+ * binding a maintainer would add (JNI natives forwarding 1:1) is in INTEGRATION.md.
+ *
+ * Citations:  src/...  = /root/reference/src/...
+ *             itmo!/.. = /root/reference/lib/itmo-assembler-src.jar!/ru/ifmo/genetics/..
+ *
+ * Conventions
+ *  - every call returns int: 0 = ok, <0 = error; mf_last_error() returns a
+ *    thread-local message (mirrors the Java side's checked ExecutionFailedException,
+ *    itmo!/utils/tool/Tool.java:450-463).
+ *  - handles are opaque and CALLER-OWNED; free with the matching *_destroy.
+ *  - calls are made from one host thread, block until the result is complete and
+ *    parallelise internally on the GPU (reference: callee spawns P threads and joins
+ *    on a latch, src/io/IOUtils.java:846-862).
+ *  - "d_" pointers are device (HBM) pointers valid on the ctx's device; everything
+ *    else is host memory.  No torch / C++ types cross this boundary.
+ *  - there is NO CPU fallback: without a usable GPU mf_ctx_create fails.
+ *
+ * k-mer encoding (itmo!/dna/DnaTools.java:31,46-64; itmo!/dna/kmers/ShortKmer.java:54-71):
+ *   A=0 G=1 C=2 T=3, first base in the most significant used bits, canonical =
+ *   min(forward, reverse-complement); k in [1,31]; counts saturate at 32767.
+ */
+#ifndef METAFAST_HIP_H
+#define METAFAST_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MF_OK 0
+#define MF_ERR (-1)
+#define MF_MAX_COUNT 32767        /* itmo!/utils/NumUtils.java:21-26 (short saturation) */
+
+typedef struct mf_ctx   mf_ctx;    /* device + stream + workspace                           */
+typedef struct mf_table mf_table;  /* canonical k-mer -> saturating count (BigLong2ShortHashMap) */
+typedef struct mf_seqs  mf_seqs;   /* unitigs with weights (Deque<Sequence>)                */
+typedef struct mf_comps mf_comps;  /* connected components (List<ConnectedComponent>)       */
+
+const char *mf_last_error(void);
+const char *mf_version(void);
+
+/* ---- context ---------------------------------------------------------------------- */
+/* host_threads plays the role of -p/--available-processors (Tool.java:61-143) for the host
+ * side parsers; GPU parallelism is fixed by the device. */
+int  mf_ctx_create(int device, int host_threads, mf_ctx **out);
+void mf_ctx_destroy(mf_ctx *ctx);
+/* Use an existing HIP stream (hipStream_t as void*) for all launches; NULL = ctx-owned stream. */
+int  mf_ctx_set_stream(mf_ctx *ctx, void *hip_stream);
+/* Tuning / test knobs, e.g. "l1_bits", "l2_bits", "part_target", "scatter_staged", "profile". */
+int  mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t value);
+int  mf_ctx_synchronize(mf_ctx *ctx);
+/* Release cached workspace back to the driver. */
+int  mf_ctx_trim(mf_ctx *ctx);
+/* Per-kernel HIP-event timings accumulated while option "profile"=1.
+ * Returns number of launches of `kernel` since the last reset; *total_ms = summed duration. */
+int64_t mf_ctx_kernel_time(mf_ctx *ctx, const char *kernel, double *total_ms);
+/* Writes "name\tlaunches\ttotal_ms\n" lines for every timed kernel into buf (NUL-terminated). */
+int  mf_ctx_kernel_report(mf_ctx *ctx, char *buf, uint64_t cap);
+int  mf_ctx_reset_timers(mf_ctx *ctx);
+
+/* ---- A1-A4  reads -> canonical k-mer counts ---------------------------------------- */
+/* replaces IOUtils.loadReads (src/io/IOUtils.java:772-803), called from
+ * KmersCounterMain.runImpl (src/tools/KmersCounterMain.java:77) with min_read_len=0 and from
+ * ComponentCutterMain.runImpl (src/tools/ComponentCutterMain.java:81) with min_read_len=l.
+ * Files are FASTA/FASTQ by extension (itmo!/io/ReadersUtils.java:27-54); reads with N (FASTA)
+ * or any phred-0 base (FASTQ) are dropped (FastaReader.java:53-76, FastaReaderFromXQSource.java:66-70).
+ * All files go into ONE table (paired files are summed). */
+int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len,
+                   mf_table **out);
+/* Same, for reads already resident in HBM: d_bases = concatenated ASCII bases (ACGT, either case,
+ * no N), d_offsets = uint64[n_reads+1] with offsets[0]=0, offsets[n_reads]=n_bases.  d_bases must
+ * be 16-byte aligned and readable up to the next multiple of 16 bytes.  This is the device half of
+ * ReadsLoadWorker.process (src/io/IOUtils.java:756-768). */
+int mf_count_device(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads,
+                    uint64_t n_bases, int k, int min_read_len, mf_table **out);
+void mf_table_destroy(mf_table *t);
+/* BigLong2ShortHashMap.size() and the sum of all (saturated) values */
+int mf_table_stats(const mf_table *t, uint64_t *n_distinct, uint64_t *n_total);
+/* k-mer occurrences fed into the table by the call that built it (N_occ) */
+int mf_table_occurrences(const mf_table *t, uint64_t *n_occ);
+/* Copies entries with count > threshold to host arrays in ASCENDING KEY order (the reference's
+ * iteration order is thread-count dependent, BigLong2ShortHashMap.java:216-253, so callers must
+ * not rely on it).  Call with cap=0 to get *n only. */
+int mf_table_export(const mf_table *t, int threshold, uint64_t *keys, uint16_t *counts,
+                    uint64_t cap, uint64_t *n);
+/* Device view (unsorted, dense): uint64 keys[n], uint16 counts[n]. */
+int mf_table_device_view(const mf_table *t, const void **d_keys, const void **d_counts, uint64_t *n);
+/* Long2ShortHashMap.get (itmo!/structures/map/Long2ShortHashMap.java:160-175) for a batch of host
+ * keys: values[i] = count or -1.  Builds the HBM open-addressed index on first use. */
+int mf_table_lookup(mf_table *t, const uint64_t *keys, uint64_t n, int32_t *values);
+
+/* ---- A5/A6  .kmers.bin / .stat.txt --------------------------------------------------- */
+/* replaces IOUtils.printKmers (src/io/IOUtils.java:45-71; KmersCounterMain.java:99): 10-byte
+ * big-endian records (int64 k-mer, int16 count) for count > threshold, ascending key order;
+ * histogram of ALL counts to stat_txt (may be NULL). */
+int mf_table_write_kmers(const mf_table *t, int threshold, const char *kmers_bin,
+                         const char *stat_txt, uint64_t *n_good);
+/* replaces IOUtils.loadKmers (src/io/IOUtils.java:369-401; SeqBuilderMain.java:80): keeps records
+ * with freq > freq_threshold; duplicate k-mers across files are summed with saturation. */
+int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nfiles, int freq_threshold, int k,
+                        mf_table **out);
+/* In-HBM equivalent of write_kmers + load_kmers: new table with the entries whose count > threshold. */
+int mf_table_filter(const mf_table *t, int threshold, mf_table **out);
+/* Build a table from host (key,count) arrays (insert-or-add with saturation). */
+int mf_table_from_host(mf_ctx *ctx, const uint64_t *keys, const uint16_t *counts, uint64_t n, int k,
+                       mf_table **out);
+
+/* ---- A7/A8  unitigs ---------------------------------------------------------------- */
+/* replaces SequencesFinders.thresholdStrategy (src/algo/SequencesFinders.java:13-31 ->
+ * AddSequencesShiftingRightTask.java:40-123) over k-mers with count > freq_threshold, keeping
+ * sequences with length >= min_len, including the reference's start/end emission rule
+ * (:101-121) under which a path may be emitted 0, 1 or 2 times. */
+int  mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_threshold, int min_len, mf_seqs **out);
+void mf_seqs_destroy(mf_seqs *s);
+int  mf_seqs_stats(const mf_seqs *s, uint64_t *n_seqs, uint64_t *total_len);
+/* Device view: ASCII bases concatenated + uint64 offsets[n+1] (same layout mf_count_device takes),
+ * int32 avg/min/max weights per sequence. */
+int  mf_seqs_device_view(const mf_seqs *s, const void **d_bases, const void **d_offsets,
+                         const void **d_avg, const void **d_min, const void **d_max,
+                         uint64_t *n_seqs, uint64_t *n_bases);
+/* Host copy: bases[total_len], offsets[n+1], avg/min/max[n]; sequences ordered by
+ * (canonical start k-mer, strand) for reproducibility (reference order is a thread race). */
+int  mf_seqs_export(const mf_seqs *s, uint8_t *bases, uint64_t *offsets, int32_t *avg, int32_t *mn,
+                    int32_t *mx);
+/* Sequence.printSequences (src/structures/Sequence.java:26-37): ">i length=L av_weight=A
+ * min_weight=m max_weight=M", 70 columns (FastaDedicatedWriter.java:15,33-49). */
+int  mf_seqs_write_fasta(const mf_seqs *s, const char *seq_fasta);
+/* One call = SeqBuilderMain.runImpl (src/tools/SeqBuilderMain.java:78-160): histogram file
+ * `distribution` (:84-98,170-176; may be NULL) + unitigs to seq_fasta. */
+int  mf_build_unitigs(mf_ctx *ctx, mf_table *t, int k, int freq_threshold, int min_len,
+                      const char *seq_fasta, const char *distribution, uint64_t *n_seq);
+
+/* ---- A9-A11  component cutter ------------------------------------------------------- */
+/* replaces ComponentsBuilder.splitStrategy (src/algo/ComponentsBuilder.java:24-32,58-270) on the
+ * cutter table (k-mers of every emitted unitig of every sample): connected components over the 8
+ * canonical neighbours (src/algo/KmerOperations.java:9-26), size window [b1,b2], oversize
+ * components re-split on value >= thr+1.  Components are ordered by (thr asc, weight desc,
+ * size desc, min k-mer asc); k-mers inside a component ascending. */
+int  mf_cut_components_device(mf_ctx *ctx, mf_table *cutter, int b1, int b2, mf_comps **out);
+void mf_comps_destroy(mf_comps *c);
+int  mf_comps_stats(const mf_comps *c, uint64_t *n_comp, uint64_t *n_kmers);
+/* Host copy: sizes[n], weights[n], thr[n], kmer_offsets[n+1], kmers[n_kmers]. */
+int  mf_comps_export(const mf_comps *c, uint64_t *sizes, int64_t *weights, int32_t *thr,
+                     uint64_t *kmer_offsets, uint64_t *kmers);
+/* ConnectedComponent.saveComponents (src/structures/ConnectedComponent.java:80-93) +
+ * components-stat file (ComponentsBuilder.java:146-152; may be NULL). */
+int  mf_comps_write(const mf_comps *c, const char *components_bin, const char *stat_txt);
+/* ConnectedComponent.loadComponents (:95-122) */
+int  mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps **out);
+/* One call = ComponentCutterMain.runImpl :92-108 */
+int  mf_cut_components(mf_ctx *ctx, mf_table *cutter, int k, int b1, int b2,
+                       const char *components_bin, const char *stat_txt, uint64_t *n_comp);
+
+/* ---- A12  features ------------------------------------------------------------------ */
+/* replaces FeaturesCalculatorMain: hm.put(kmer,0) for component k-mers (:97-103), presence pass
+ * over the sample's records (IOUtils.calculatePresenceForKmers, src/io/IOUtils.java:577-597) and
+ * buildAndPrintVector (:169-236): vec[c] = sum of counts > threshold, breadth[c] = found/size. */
+int  mf_features_device(mf_ctx *ctx, mf_comps *c, const mf_table *sample, int threshold,
+                        int64_t *vec, double *breadth);
+/* File form: components.bin + <name>.kmers.bin -> <name>.vec / <name>.breadth (either may be NULL) */
+int  mf_features(mf_ctx *ctx, const char *components_bin, const char *kmers_bin, int k, int threshold,
+                 const char *vec_path, const char *breadth_path);
+
+/* ---- A13  Bray-Curtis ---------------------------------------------------------------- */
+/* replaces DistanceMatrixCalculatorMain.brayCurtisDistance (src/tools/DistanceMatrixCalculatorMain.java:
+ * 140-152): d = sum|a-b| / sum(|a|+|b|) on raw vectors; vecs is row-major [n_samples][n_comp]. */
+int  mf_bray_curtis(const int64_t *vecs, int n_samples, int n_comp, double *out_matrix);
+
+/* ---- synthetic reads (bench / tests) ---------------------------------- */
+/* Fills d_bases[n_reads*read_len] (ASCII) and d_offsets[n_reads+1] with the deterministic,
+ * integer-only generator described in DESIGN.md (128-genome pool with shared repeats, log-normal
+ * abundances, strand flips, 0.5 % substitutions, no N).  The host mirror mf_synth_reads_host
+ * produces the identical bytes on the CPU. */
+int  mf_synth_reads_device(mf_ctx *ctx, uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads,
+                           int read_len, uint64_t genome_scale_bp, void *d_bases, void *d_offsets);
+int  mf_synth_reads_host(uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads, int read_len,
+                         uint64_t genome_scale_bp, uint8_t *bases, uint64_t *offsets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

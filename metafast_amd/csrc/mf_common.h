@@ -1,0 +1,252 @@
+// mf_common.h -- internal declarations shared by the HIP translation units of libmetafast_hip.so.
+// gfx950 (MI355X) only: wave = 64 lanes, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/metafast_hip.h"
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+int mf_set_error(const char *fmt, ...);   // returns MF_ERR
+
+#define MF_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess)                                                                    \
+            return mf_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, \
+                                __LINE__);                                                        \
+    } while (0)
+#define MF_TRY(call)                  \
+    do {                              \
+        int r__ = (call);             \
+        if (r__ < 0) return r__;      \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// constants
+// ---------------------------------------------------------------------------------------------
+#define MF_WAVE 64
+static constexpr uint64_t MF_EMPTY = 0xFFFFFFFFFFFFFFFFull;  // unreachable key: k<=31 keys are < 2^62
+static constexpr int MF_MAX_DIGIT_BITS = 11;                 // 2048 staging lines of 64 B = 128 KiB LDS
+static constexpr int MF_LINE = 8;                            // k-mers per 64-byte staging line
+static constexpr int MF_COUNT_SLOTS = 8192;                  // LDS count table slots (64 KiB keys + 32 KiB counts)
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct mf_timer_rec {
+    hipEvent_t a, b;
+    std::string name;
+};
+struct mf_ctx {
+    int device = 0;
+    int host_threads = 1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int n_cu = 256;
+    // options
+    int64_t opt_l1_bits = -1;      // -1 = auto
+    int64_t opt_l2_bits = -1;
+    int64_t opt_part_target = 3072;  // mean k-mer occurrences per final partition
+    int64_t opt_scatter_staged = 1;
+    int64_t opt_profile = 0;
+    int64_t opt_l1_blocks = 0;     // 0 = auto
+    int64_t opt_verbose = 0;
+    // workspace cache
+    struct blk { void *p; size_t sz; };
+    std::vector<blk> free_list;
+    size_t cached_bytes = 0;
+    // timers
+    std::vector<mf_timer_rec> pending;
+    std::vector<hipEvent_t> event_pool;
+    std::map<std::string, std::pair<int64_t, double>> timings;
+};
+
+int  mf_alloc(mf_ctx *ctx, size_t bytes, void **out);   // cached hipMalloc
+void mf_release(mf_ctx *ctx, void *p, size_t bytes);     // back to the cache
+int  mf_collect_timers(mf_ctx *ctx);
+
+// RAII HIP-event timer around one kernel launch on ctx->stream (only when option profile=1)
+struct mf_ktimer {
+    mf_ctx *ctx; int idx;
+    mf_ktimer(mf_ctx *c, const char *name);
+    ~mf_ktimer();
+};
+
+template <typename T> struct mf_buf {   // RAII workspace buffer
+    mf_ctx *ctx = nullptr; T *p = nullptr; size_t n = 0;
+    mf_buf() {}
+    mf_buf(const mf_buf &) = delete;
+    mf_buf &operator=(const mf_buf &) = delete;
+    ~mf_buf() { reset(); }
+    int alloc(mf_ctx *c, size_t count) {
+        reset(); ctx = c; n = count;
+        void *q = nullptr;
+        int r = mf_alloc(c, (count ? count : 1) * sizeof(T), &q);
+        p = (T *)q;
+        return r;
+    }
+    void reset() { if (p) mf_release(ctx, p, (n ? n : 1) * sizeof(T)); p = nullptr; n = 0; }
+    T *take() { T *q = p; p = nullptr; return q; }   // ownership moves to the caller (who releases with mf_release)
+    size_t bytes() const { return (n ? n : 1) * sizeof(T); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// opaque handle layouts
+// ---------------------------------------------------------------------------------------------
+struct mf_index {                 // open-addressed table in HBM: 16-byte slots {key, idx, val}
+    void *slots = nullptr;        // ulonglong2-like: .x = key, .y = (uint64)idx | (uint64)val << 32
+    uint64_t cap = 0;             // power of two
+};
+struct mf_table {
+    mf_ctx *ctx = nullptr;
+    int k = 0;
+    uint64_t n = 0;               // distinct k-mers
+    uint64_t n_occ = 0;           // occurrences fed in
+    uint64_t *d_keys = nullptr;   // [n]
+    uint16_t *d_counts = nullptr; // [n]
+    size_t keys_bytes = 0, counts_bytes = 0;
+    mf_index index;               // built lazily
+    size_t index_bytes = 0;
+};
+struct mf_seqs {
+    mf_ctx *ctx = nullptr;
+    int k = 0;
+    uint64_t n = 0, n_bases = 0;
+    uint8_t *d_bases = nullptr;   // ASCII
+    uint64_t *d_offsets = nullptr;  // [n+1]
+    int32_t *d_avg = nullptr, *d_min = nullptr, *d_max = nullptr;
+    uint64_t *d_startkey = nullptr;  // oriented start k-mer per sequence (for deterministic ordering)
+    size_t bases_bytes = 0, offsets_bytes = 0, w_bytes = 0, sk_bytes = 0;
+};
+struct mf_comps {
+    mf_ctx *ctx = nullptr;
+    int k = 0;
+    uint64_t n = 0, n_kmers = 0;
+    // host copies (component lists are small relative to the tables; ordering is done on the host)
+    std::vector<uint64_t> sizes; std::vector<int64_t> weights; std::vector<int32_t> thr;
+    std::vector<uint64_t> offsets; std::vector<uint64_t> kmers;
+    // device: component k-mers + component id per k-mer, and an index over them (for features)
+    uint64_t *d_kmers = nullptr; uint32_t *d_comp = nullptr;
+    size_t kmers_bytes = 0, comp_bytes = 0;
+    mf_index index; size_t index_bytes = 0;
+};
+
+int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, mf_index *out,
+                   size_t *bytes);
+int mf_table_ensure_index(mf_table *t);
+int mf_table_adopt(mf_ctx *ctx, int k, uint64_t n, uint64_t n_occ, uint64_t *d_keys, size_t kb, uint16_t *d_counts,
+                   size_t cb, mf_table **out);
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#ifdef __HIPCC__
+
+// 64-bit finaliser (murmur3 fmix64).  Partition digits come from the TOP bits, LDS / HBM table
+// slots from the LOW bits, so the two are independent.
+__host__ __device__ __forceinline__ uint64_t mf_hash64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL;
+    x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL;
+    x ^= x >> 33;
+    return x;
+}
+
+// reverse complement of a 2-bit packed k-mer (A0 G1 C2 T3 -> complement = 3-n), k in [1,31]
+__host__ __device__ __forceinline__ uint64_t mf_revcomp(uint64_t x, int k) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __brevll(x);                                                          // reverse all 64 bits
+    x = ((x & 0x5555555555555555ULL) << 1) | ((x >> 1) & 0x5555555555555555ULL);  // restore bit order inside each pair
+#else
+    x = ((x & 0x3333333333333333ULL) << 2) | ((x & 0xccccccccccccccccULL) >> 2);
+    x = ((x & 0x0f0f0f0f0f0f0f0fULL) << 4) | ((x & 0xf0f0f0f0f0f0f0f0ULL) >> 4);
+    x = ((x & 0x00ff00ff00ff00ffULL) << 8) | ((x & 0xff00ff00ff00ff00ULL) >> 8);
+    x = ((x & 0x0000ffff0000ffffULL) << 16) | ((x & 0xffff0000ffff0000ULL) >> 16);
+    x = (x << 32) | (x >> 32);
+#endif
+    return (~x) >> (64 - 2 * k);
+}
+__host__ __device__ __forceinline__ uint64_t mf_canon(uint64_t x, int k) {
+    uint64_t r = mf_revcomp(x, k);
+    return x < r ? x : r;
+}
+
+__device__ __forceinline__ int mf_lane() { return (int)(threadIdx.x & 63); }
+
+// exclusive prefix sum of v over the wave; *total = wave sum
+__device__ __forceinline__ uint32_t mf_wave_excl_scan(uint32_t v, uint32_t *total) {
+    uint32_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d, 64);
+        if (mf_lane() >= d) x += y;
+    }
+    *total = __shfl(x, 63, 64);
+    return x - v;
+}
+
+// Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024).
+// `scratch` must hold 17 uint32 in LDS.  Returns exclusive prefix; *block_total = sum.
+__device__ __forceinline__ uint32_t mf_block_excl_scan(uint32_t v, uint32_t *scratch, uint32_t *block_total) {
+    uint32_t wtot;
+    uint32_t ex = mf_wave_excl_scan(v, &wtot);
+    int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (mf_lane() == 0) scratch[wave] = wtot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int i = 0; i < nw; i++) { uint32_t t = scratch[i]; scratch[i] = acc; acc += t; }
+        scratch[16] = acc;
+    }
+    __syncthreads();
+    uint32_t r = ex + scratch[wave];
+    *block_total = scratch[16];
+    return r;
+}
+
+// ---- HBM open-addressed index lookup (16-byte slots) ----
+struct mf_slot { uint64_t key; uint32_t idx; uint32_t val; };
+__device__ __forceinline__ bool mf_index_find(const mf_slot *__restrict__ slots, uint64_t mask, uint64_t key,
+                                              uint32_t *idx, uint32_t *val) {
+    uint64_t s = mf_hash64(key) & mask;
+    for (;;) {
+        const ulonglong2 raw = *reinterpret_cast<const ulonglong2 *>(&slots[s]);
+        if (raw.x == key) { *idx = (uint32_t)raw.y; *val = (uint32_t)(raw.y >> 32); return true; }
+        if (raw.x == MF_EMPTY) return false;
+        s = (s + 1) & mask;
+    }
+}
+// =============================================================================================
+// single-block exclusive scan (u32 in -> u64 out); PAD8 rounds every item up to a multiple of 8
+// =============================================================================================
+template <bool PAD8>
+static __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
+                                               uint64_t n, uint64_t *__restrict__ total) {
+    __shared__ uint64_t sums[1024];
+    uint64_t per = (n + 1023) / 1024;
+    uint64_t lo = (uint64_t)threadIdx.x * per;
+    uint64_t hi = lo + per < n ? lo + per : n;
+    uint64_t s = 0;
+    for (uint64_t i = lo; i < hi; i++) { uint64_t v = in[i]; if (PAD8) v = (v + 7) & ~7ull; s += v; }
+    sums[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t acc = 0;
+        for (int i = 0; i < 1024; i++) { uint64_t t = sums[i]; sums[i] = acc; acc += t; }
+        *total = acc;
+        out[n] = acc;
+    }
+    __syncthreads();
+    uint64_t base = sums[threadIdx.x];
+    for (uint64_t i = lo; i < hi; i++) { uint64_t v = in[i]; if (PAD8) v = (v + 7) & ~7ull; out[i] = base; base += v; }
+}
+
+#endif  // __HIPCC__

@@ -1,0 +1,325 @@
+// mf_table.hip -- table handle (dense (key,count) arrays in HBM) + the open-addressed index in HBM.
+//
+// The index stands in for BigLong2ShortHashMap's random-access role (get / contains / addAndBound,
+// itmo!/structures/map/Long2ShortHashMap.java:119-175): 16-byte slots {key, idx, val}, linear probing,
+// load <= 0.5, empty marker = all-ones key (key 0 = poly-A is a legal k-mer, the reference side-cars it).
+#include "mf_common.h"
+#include <algorithm>
+#include <numeric>
+
+int mf_sum_counts(mf_ctx *ctx, const uint16_t *d_counts, uint64_t n, uint64_t *total);
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void k_index_init(mf_slot *__restrict__ slots, uint64_t cap) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < cap; i += stride) {
+        ulonglong2 v; v.x = MF_EMPTY; v.y = 0;
+        *reinterpret_cast<ulonglong2 *>(&slots[i]) = v;
+    }
+}
+
+// distinct keys: claim a slot with one 64-bit CAS, then store {idx,val}
+__global__ void k_index_insert(mf_slot *__restrict__ slots, uint64_t mask, const uint64_t *__restrict__ keys,
+                               const uint16_t *__restrict__ vals, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint64_t key = keys[i];
+        uint64_t s = mf_hash64(key) & mask;
+        for (;;) {
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[s].key),
+                                               (unsigned long long)MF_EMPTY, (unsigned long long)key);
+            if (old == MF_EMPTY) {
+                uint64_t aux = (uint64_t)(uint32_t)i | ((uint64_t)(vals ? vals[i] : 0) << 32);
+                *reinterpret_cast<uint64_t *>(&slots[s].idx) = aux;
+                break;
+            }
+            s = (s + 1) & mask;
+        }
+    }
+}
+
+// insert-or-add (duplicates allowed): val accumulates in 32 bits, clamped to 32767 on extraction
+__global__ void k_index_insert_add(mf_slot *__restrict__ slots, uint64_t mask, const uint64_t *__restrict__ keys,
+                                   const uint16_t *__restrict__ vals, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint64_t key = keys[i];
+        uint64_t s = mf_hash64(key) & mask;
+        for (;;) {
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&slots[s].key),
+                                               (unsigned long long)MF_EMPTY, (unsigned long long)key);
+            if (old == MF_EMPTY || old == key) { atomicAdd(&slots[s].val, (uint32_t)vals[i]); break; }
+            s = (s + 1) & mask;
+        }
+    }
+}
+
+__global__ void k_index_lookup(const mf_slot *__restrict__ slots, uint64_t mask, const uint64_t *__restrict__ keys,
+                               uint64_t n, int32_t *__restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t idx, val;
+    out[i] = mf_index_find(slots, mask, keys[i], &idx, &val) ? (int32_t)val : -1;
+}
+
+// ---- stable stream compaction in two passes: select entries with pred(i) ----
+// MODE 0: table entries with count > thr.   MODE 1: non-empty index slots (val clamped to 32767).
+template <int MODE>
+__device__ __forceinline__ bool mf_sel_pred(const uint64_t *keys, const uint16_t *cnts, const mf_slot *slots, uint64_t i,
+                                            int thr) {
+    if (MODE == 0) return (int)cnts[i] > thr;
+    return slots[i].key != MF_EMPTY;
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_select_count(const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnts,
+                                                        const mf_slot *__restrict__ slots, uint64_t n, uint64_t per_block,
+                                                        int thr, uint32_t *__restrict__ bcount) {
+    __shared__ uint32_t scratch[17];
+    uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
+    uint32_t c = 0;
+    for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) c += mf_sel_pred<MODE>(keys, cnts, slots, i, thr);
+    uint32_t tot;
+    mf_block_excl_scan(c, scratch, &tot);
+    if (threadIdx.x == 0) bcount[blockIdx.x] = tot;
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_select_write(const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnts,
+                                                        const mf_slot *__restrict__ slots, uint64_t n, uint64_t per_block,
+                                                        int thr, const uint64_t *__restrict__ boff,
+                                                        uint64_t *__restrict__ ok, uint16_t *__restrict__ oc) {
+    __shared__ uint32_t scratch[17];
+    uint64_t lo = (uint64_t)blockIdx.x * per_block, hi = lo + per_block < n ? lo + per_block : n;
+    uint64_t base = boff[blockIdx.x];
+    for (uint64_t i0 = lo; i0 < hi; i0 += blockDim.x) {   // uniform trip count (barriers inside)
+        uint64_t i = i0 + threadIdx.x;
+        bool sel = i < hi && mf_sel_pred<MODE>(keys, cnts, slots, i, thr);
+        uint32_t tot;
+        uint32_t ex = mf_block_excl_scan(sel ? 1u : 0u, scratch, &tot);
+        if (sel) {
+            if (MODE == 0) { ok[base + ex] = keys[i]; oc[base + ex] = cnts[i]; }
+            else {
+                uint32_t v = slots[i].val;
+                ok[base + ex] = slots[i].key;
+                oc[base + ex] = (uint16_t)(v > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : v);
+            }
+        }
+        base += tot;
+    }
+}
+
+// histogram of counts (0..32767) -- LDS-privatised low bins, global atomics for the rest
+__global__ __launch_bounds__(256) void k_count_hist(const uint16_t *__restrict__ c, uint64_t n,
+                                                    unsigned long long *__restrict__ hist) {
+    __shared__ uint32_t lo[1024];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) lo[i] = 0;
+    __syncthreads();
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t v = c[i];
+        if (v < 1024) atomicAdd(&lo[v], 1u);
+        else atomicAdd(&hist[v], 1ull);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < 1024; j += blockDim.x)
+        if (lo[j]) atomicAdd(&hist[j], (unsigned long long)lo[j]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static uint64_t pow2_at_least(uint64_t x) { uint64_t p = 1; while (p < x) p <<= 1; return p; }
+
+int mf_table_adopt(mf_ctx *ctx, int k, uint64_t n, uint64_t n_occ, uint64_t *d_keys, size_t kb, uint16_t *d_counts,
+                   size_t cb, mf_table **out) {
+    mf_table *t = new mf_table();
+    t->ctx = ctx; t->k = k; t->n = n; t->n_occ = n_occ;
+    t->d_keys = d_keys; t->keys_bytes = kb;
+    t->d_counts = d_counts; t->counts_bytes = cb;
+    *out = t;
+    return MF_OK;
+}
+
+extern "C" void mf_table_destroy(mf_table *t) {
+    if (!t) return;
+    if (t->d_keys) mf_release(t->ctx, t->d_keys, t->keys_bytes);
+    if (t->d_counts) mf_release(t->ctx, t->d_counts, t->counts_bytes);
+    if (t->index.slots) mf_release(t->ctx, t->index.slots, t->index_bytes);
+    delete t;
+}
+
+int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, mf_index *out, size_t *bytes) {
+    uint64_t cap = pow2_at_least(std::max<uint64_t>(2 * n, 1024));
+    void *p = nullptr;
+    MF_TRY(mf_alloc(ctx, cap * sizeof(mf_slot), &p));
+    unsigned grid = (unsigned)std::min<uint64_t>((cap + 255) / 256, 65536);
+    {
+        mf_ktimer t(ctx, "k_index_init");
+        k_index_init<<<grid, 256, 0, ctx->stream>>>((mf_slot *)p, cap);
+    }
+    if (n) {
+        unsigned g2 = (unsigned)std::min<uint64_t>((n + 255) / 256, 65536);
+        mf_ktimer t(ctx, "k_index_insert");
+        k_index_insert<<<g2, 256, 0, ctx->stream>>>((mf_slot *)p, cap - 1, d_keys, d_vals, n);
+    }
+    out->slots = p; out->cap = cap;
+    *bytes = cap * sizeof(mf_slot);
+    return MF_OK;
+}
+
+int mf_table_ensure_index(mf_table *t) {
+    if (t->index.slots) return MF_OK;
+    if (t->n >= 0xFFFFFFFFull) return mf_set_error("index supports < 2^32 entries");
+    return mf_index_build(t->ctx, t->d_keys, t->d_counts, t->n, &t->index, &t->index_bytes);
+}
+
+extern "C" int mf_table_stats(const mf_table *t, uint64_t *n_distinct, uint64_t *n_total) {
+    if (!t) return mf_set_error("table is NULL");
+    if (n_distinct) *n_distinct = t->n;
+    if (n_total) MF_TRY(mf_sum_counts(t->ctx, t->d_counts, t->n, n_total));
+    return MF_OK;
+}
+extern "C" int mf_table_occurrences(const mf_table *t, uint64_t *n_occ) {
+    if (!t || !n_occ) return mf_set_error("NULL argument");
+    *n_occ = t->n_occ;
+    return MF_OK;
+}
+extern "C" int mf_table_device_view(const mf_table *t, const void **d_keys, const void **d_counts, uint64_t *n) {
+    if (!t) return mf_set_error("table is NULL");
+    if (d_keys) *d_keys = t->d_keys;
+    if (d_counts) *d_counts = t->d_counts;
+    if (n) *n = t->n;
+    return MF_OK;
+}
+
+// device-side selection into fresh dense arrays
+template <int MODE>
+static int select_entries(mf_ctx *ctx, const uint64_t *keys, const uint16_t *cnts, const mf_slot *slots, uint64_t n, int thr,
+                          mf_buf<uint64_t> &ok, mf_buf<uint16_t> &oc, uint64_t *n_out) {
+    *n_out = 0;
+    if (!n) { MF_TRY(ok.alloc(ctx, 0)); MF_TRY(oc.alloc(ctx, 0)); return MF_OK; }
+    uint64_t nb = std::min<uint64_t>((n + 1023) / 1024, 2048);
+    uint64_t per = ((n + nb - 1) / nb + 1023) / 1024 * 1024;
+    nb = (n + per - 1) / per;
+    mf_buf<uint32_t> bcount; MF_TRY(bcount.alloc(ctx, nb));
+    mf_buf<uint64_t> boff; MF_TRY(boff.alloc(ctx, nb + 1));
+    mf_buf<uint64_t> tot; MF_TRY(tot.alloc(ctx, 1));
+    {
+        mf_ktimer t(ctx, "k_select");
+        k_select_count<MODE><<<(unsigned)nb, 1024, 0, ctx->stream>>>(keys, cnts, slots, n, per, thr, bcount.p);
+        k_scan<false><<<1, 1024, 0, ctx->stream>>>(bcount.p, boff.p, nb, tot.p);
+    }
+    uint64_t m = 0;
+    MF_HIP(hipMemcpyAsync(&m, tot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    MF_TRY(ok.alloc(ctx, m)); MF_TRY(oc.alloc(ctx, m));
+    if (m) {
+        mf_ktimer t(ctx, "k_select");
+        k_select_write<MODE><<<(unsigned)nb, 1024, 0, ctx->stream>>>(keys, cnts, slots, n, per, thr, boff.p, ok.p, oc.p);
+    }
+    *n_out = m;
+    return MF_OK;
+}
+
+extern "C" int mf_table_filter(const mf_table *t, int threshold, mf_table **out) {
+    if (!t || !out) return mf_set_error("NULL argument");
+    *out = nullptr;
+    mf_ctx *ctx = t->ctx;
+    MF_HIP(hipSetDevice(ctx->device));
+    mf_buf<uint64_t> ok; mf_buf<uint16_t> oc; uint64_t m = 0;
+    MF_TRY(select_entries<0>(ctx, t->d_keys, t->d_counts, nullptr, t->n, threshold, ok, oc, &m));
+    size_t kb = ok.bytes(), cb = oc.bytes();
+    return mf_table_adopt(ctx, t->k, m, 0, ok.take(), kb, oc.take(), cb, out);
+}
+
+// host arrays -> table (insert-or-add with saturation through the HBM index)
+int mf_table_from_device_pairs(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, int k, mf_table **out) {
+    uint64_t cap = pow2_at_least(std::max<uint64_t>(2 * n, 1024));
+    mf_buf<mf_slot> slots; MF_TRY(slots.alloc(ctx, cap));
+    unsigned grid = (unsigned)std::min<uint64_t>((cap + 255) / 256, 65536);
+    k_index_init<<<grid, 256, 0, ctx->stream>>>(slots.p, cap);
+    if (n) {
+        unsigned g2 = (unsigned)std::min<uint64_t>((n + 255) / 256, 65536);
+        mf_ktimer t(ctx, "k_index_insert_add");
+        k_index_insert_add<<<g2, 256, 0, ctx->stream>>>(slots.p, cap - 1, d_keys, d_vals, n);
+    }
+    mf_buf<uint64_t> ok; mf_buf<uint16_t> oc; uint64_t m = 0;
+    MF_TRY(select_entries<1>(ctx, nullptr, nullptr, slots.p, cap, 0, ok, oc, &m));
+    size_t kb = ok.bytes(), cb = oc.bytes();
+    return mf_table_adopt(ctx, k, m, 0, ok.take(), kb, oc.take(), cb, out);
+}
+
+extern "C" int mf_table_from_host(mf_ctx *ctx, const uint64_t *keys, const uint16_t *counts, uint64_t n, int k, mf_table **out) {
+    if (!ctx || !out || (n && (!keys || !counts))) return mf_set_error("NULL argument");
+    *out = nullptr;
+    if (k < 1 || k > 31) return mf_set_error("k must be in [1,31]");
+    MF_HIP(hipSetDevice(ctx->device));
+    mf_buf<uint64_t> dk; MF_TRY(dk.alloc(ctx, n));
+    mf_buf<uint16_t> dc; MF_TRY(dc.alloc(ctx, n));
+    if (n) {
+        MF_HIP(hipMemcpyAsync(dk.p, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
+        MF_HIP(hipMemcpyAsync(dc.p, counts, n * 2, hipMemcpyHostToDevice, ctx->stream));
+    }
+    int r = mf_table_from_device_pairs(ctx, dk.p, dc.p, n, k, out);
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    return r;
+}
+
+extern "C" int mf_table_export(const mf_table *t, int threshold, uint64_t *keys, uint16_t *counts, uint64_t cap, uint64_t *n) {
+    if (!t || !n) return mf_set_error("NULL argument");
+    mf_ctx *ctx = t->ctx;
+    MF_HIP(hipSetDevice(ctx->device));
+    mf_buf<uint64_t> ok; mf_buf<uint16_t> oc; uint64_t m = 0;
+    MF_TRY(select_entries<0>(ctx, t->d_keys, t->d_counts, nullptr, t->n, threshold, ok, oc, &m));
+    *n = m;
+    if (cap == 0 || !keys || !counts) return MF_OK;
+    if (cap < m) return mf_set_error("mf_table_export: capacity %llu < %llu", (unsigned long long)cap, (unsigned long long)m);
+    std::vector<uint64_t> hk(m); std::vector<uint16_t> hc(m);
+    if (m) {
+        MF_HIP(hipMemcpyAsync(hk.data(), ok.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipMemcpyAsync(hc.data(), oc.p, m * 2, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<uint64_t> order(m);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return hk[a] < hk[b]; });
+    for (uint64_t i = 0; i < m; i++) { keys[i] = hk[order[i]]; counts[i] = hc[order[i]]; }
+    return MF_OK;
+}
+
+extern "C" int mf_table_lookup(mf_table *t, const uint64_t *keys, uint64_t n, int32_t *values) {
+    if (!t || (n && (!keys || !values))) return mf_set_error("NULL argument");
+    mf_ctx *ctx = t->ctx;
+    MF_HIP(hipSetDevice(ctx->device));
+    MF_TRY(mf_table_ensure_index(t));
+    if (!n) return MF_OK;
+    mf_buf<uint64_t> dk; MF_TRY(dk.alloc(ctx, n));
+    mf_buf<int32_t> dv; MF_TRY(dv.alloc(ctx, n));
+    MF_HIP(hipMemcpyAsync(dk.p, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
+    k_index_lookup<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>((const mf_slot *)t->index.slots, t->index.cap - 1, dk.p, n, dv.p);
+    MF_HIP(hipMemcpyAsync(values, dv.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    return MF_OK;
+}
+
+// histogram of all counts -> host vector[32768]
+int mf_table_count_hist(const mf_table *t, std::vector<uint64_t> &hist) {
+    mf_ctx *ctx = t->ctx;
+    hist.assign(MF_MAX_COUNT + 1, 0);
+    if (!t->n) return MF_OK;
+    mf_buf<unsigned long long> dh; MF_TRY(dh.alloc(ctx, MF_MAX_COUNT + 1));
+    MF_HIP(hipMemsetAsync(dh.p, 0, dh.bytes(), ctx->stream));
+    unsigned grid = (unsigned)std::min<uint64_t>((t->n + 255) / 256, 2048);
+    {
+        mf_ktimer tm(ctx, "k_count_hist");
+        k_count_hist<<<grid, 256, 0, ctx->stream>>>(t->d_counts, t->n, dh.p);
+    }
+    MF_HIP(hipMemcpyAsync(hist.data(), dh.p, (MF_MAX_COUNT + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    return MF_OK;
+}

@@ -1,0 +1,375 @@
+"""ctypes binding of libmetafast_hip.so (the C-ABI in include/metafast_hip.h).
+
+This is the host-side mirror of the reference's seams for the hot path
+(IOUtils.loadReads / printKmers / loadKmers, SequencesFinders.thresholdStrategy,
+ComponentsBuilder.splitStrategy, FeaturesCalculatorMain.buildAndPrintVector,
+DistanceMatrixCalculatorMain.brayCurtisDistance).  There is no CPU fallback: if the
+HIP library is missing or no GPU is present, calls fail loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmetafast_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "metafast_hip.h")
+_lib = None
+
+u64, i64, i32, vp, cp = C.c_uint64, C.c_int64, C.c_int, C.c_void_p, C.c_char_p
+pu64, pvp = C.POINTER(C.c_uint64), C.POINTER(C.c_void_p)
+
+_SIGS = {
+    "mf_last_error": (cp, []),
+    "mf_version": (cp, []),
+    "mf_ctx_create": (i32, [i32, i32, pvp]),
+    "mf_ctx_destroy": (None, [vp]),
+    "mf_ctx_set_stream": (i32, [vp, vp]),
+    "mf_ctx_set_option": (i32, [vp, cp, i64]),
+    "mf_ctx_synchronize": (i32, [vp]),
+    "mf_ctx_trim": (i32, [vp]),
+    "mf_ctx_kernel_time": (i64, [vp, cp, C.POINTER(C.c_double)]),
+    "mf_ctx_kernel_report": (i32, [vp, cp, u64]),
+    "mf_ctx_reset_timers": (i32, [vp]),
+    "mf_count_reads": (i32, [vp, C.POINTER(cp), i32, i32, i32, pvp]),
+    "mf_count_device": (i32, [vp, vp, vp, u64, u64, i32, i32, pvp]),
+    "mf_table_destroy": (None, [vp]),
+    "mf_table_stats": (i32, [vp, pu64, pu64]),
+    "mf_table_occurrences": (i32, [vp, pu64]),
+    "mf_table_export": (i32, [vp, i32, vp, vp, u64, pu64]),
+    "mf_table_device_view": (i32, [vp, pvp, pvp, pu64]),
+    "mf_table_lookup": (i32, [vp, vp, u64, vp]),
+    "mf_table_write_kmers": (i32, [vp, i32, cp, cp, pu64]),
+    "mf_table_load_kmers": (i32, [vp, C.POINTER(cp), i32, i32, i32, pvp]),
+    "mf_table_filter": (i32, [vp, i32, pvp]),
+    "mf_table_from_host": (i32, [vp, vp, vp, u64, i32, pvp]),
+    "mf_build_unitigs_device": (i32, [vp, vp, i32, i32, pvp]),
+    "mf_seqs_destroy": (None, [vp]),
+    "mf_seqs_stats": (i32, [vp, pu64, pu64]),
+    "mf_seqs_device_view": (i32, [vp, pvp, pvp, pvp, pvp, pvp, pu64, pu64]),
+    "mf_seqs_export": (i32, [vp, vp, vp, vp, vp, vp]),
+    "mf_seqs_write_fasta": (i32, [vp, cp]),
+    "mf_build_unitigs": (i32, [vp, vp, i32, i32, i32, cp, cp, pu64]),
+    "mf_cut_components_device": (i32, [vp, vp, i32, i32, pvp]),
+    "mf_comps_destroy": (None, [vp]),
+    "mf_comps_stats": (i32, [vp, pu64, pu64]),
+    "mf_comps_export": (i32, [vp, vp, vp, vp, vp, vp]),
+    "mf_comps_write": (i32, [vp, cp, cp]),
+    "mf_comps_load": (i32, [vp, cp, pvp]),
+    "mf_cut_components": (i32, [vp, vp, i32, i32, i32, cp, cp, pu64]),
+    "mf_features_device": (i32, [vp, vp, vp, i32, vp, vp]),
+    "mf_features": (i32, [vp, cp, cp, i32, i32, cp, cp]),
+    "mf_bray_curtis": (i32, [vp, i32, i32, vp]),
+    "mf_synth_reads_device": (i32, [vp, u64, i32, u64, u64, i32, u64, vp, vp]),
+    "mf_synth_reads_host": (i32, [u64, i32, u64, u64, i32, u64, vp, vp]),
+}
+
+
+class MetafastError(RuntimeError):
+    """Mirrors ExecutionFailedException (itmo!/utils/tool/Tool.java:450-463)."""
+
+
+def exported_symbols():
+    """Every entry point declared in include/metafast_hip.h."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MetafastError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            f = getattr(L, name)          # AttributeError if the .so does not export a declared symbol
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc < 0:
+        raise MetafastError(lib().mf_last_error().decode(errors="replace"))
+    return rc
+
+
+def _cfiles(files):
+    return (C.c_char_p * len(files))(*[os.fsencode(f) for f in files])
+
+
+def _opt(path):
+    return os.fsencode(path) if path else None
+
+
+class Context:
+    def __init__(self, device=0, host_threads=0, stream=None):
+        h = C.c_void_p()
+        _check(lib().mf_ctx_create(device, host_threads or (os.cpu_count() or 1), C.byref(h)))
+        self.h = h
+        self.device = device
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mf_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def set_stream(self, stream):
+        """stream: a raw hipStream_t (int), or a torch.cuda.Stream"""
+        raw = getattr(stream, "cuda_stream", stream)
+        _check(lib().mf_ctx_set_stream(self.h, C.c_void_p(int(raw) if raw else None)))
+
+    def set_option(self, name, value):
+        _check(lib().mf_ctx_set_option(self.h, name.encode(), int(value)))
+
+    def synchronize(self):
+        _check(lib().mf_ctx_synchronize(self.h))
+
+    def trim(self):
+        _check(lib().mf_ctx_trim(self.h))
+
+    def reset_timers(self):
+        _check(lib().mf_ctx_reset_timers(self.h))
+
+    def kernel_time(self, name):
+        ms = C.c_double()
+        n = lib().mf_ctx_kernel_time(self.h, name.encode(), C.byref(ms))
+        return int(n), float(ms.value)
+
+    def kernel_report(self):
+        buf = C.create_string_buffer(1 << 16)
+        _check(lib().mf_ctx_kernel_report(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split("\t")
+            out[name] = (int(n), float(ms))
+        return out
+
+    # ---- A1-A4 ----
+    def count_reads(self, files, k, min_read_len=0):
+        """IOUtils.loadReads (src/io/IOUtils.java:772-803)"""
+        t = C.c_void_p()
+        _check(lib().mf_count_reads(self.h, _cfiles(files), len(files), k, min_read_len, C.byref(t)))
+        return Table(self, t)
+
+    def count_device(self, d_bases, d_offsets, n_reads, n_bases, k, min_read_len=0):
+        """d_bases / d_offsets: raw device pointers (int) -- e.g. torch tensor.data_ptr()"""
+        t = C.c_void_p()
+        _check(lib().mf_count_device(self.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k,
+                                     min_read_len, C.byref(t)))
+        return Table(self, t)
+
+    def load_kmers(self, files, freq_threshold, k):
+        """IOUtils.loadKmers (src/io/IOUtils.java:369-401)"""
+        t = C.c_void_p()
+        _check(lib().mf_table_load_kmers(self.h, _cfiles(files), len(files), freq_threshold, k, C.byref(t)))
+        return Table(self, t)
+
+    def table_from_host(self, keys, counts, k):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        counts = np.ascontiguousarray(counts, dtype=np.uint16)
+        t = C.c_void_p()
+        _check(lib().mf_table_from_host(self.h, keys.ctypes.data, counts.ctypes.data, len(keys), k, C.byref(t)))
+        return Table(self, t)
+
+    # ---- A7 ----
+    def build_unitigs(self, table, freq_threshold, min_len):
+        """SequencesFinders.thresholdStrategy (src/algo/SequencesFinders.java:13-31)"""
+        s = C.c_void_p()
+        _check(lib().mf_build_unitigs_device(self.h, table.h, freq_threshold, min_len, C.byref(s)))
+        return Seqs(self, s)
+
+    # ---- A10 ----
+    def cut_components(self, cutter_table, b1, b2):
+        """ComponentsBuilder.splitStrategy (src/algo/ComponentsBuilder.java:24-32)"""
+        c = C.c_void_p()
+        _check(lib().mf_cut_components_device(self.h, cutter_table.h, b1, b2, C.byref(c)))
+        return Comps(self, c)
+
+    def load_components(self, path):
+        c = C.c_void_p()
+        _check(lib().mf_comps_load(self.h, os.fsencode(path), C.byref(c)))
+        return Comps(self, c)
+
+    # ---- A12 ----
+    def features(self, comps, sample_table, threshold=0):
+        n = comps.stats()[0]
+        vec = np.zeros(n, dtype=np.int64)
+        br = np.zeros(n, dtype=np.float64)
+        _check(lib().mf_features_device(self.h, comps.h, sample_table.h, threshold, vec.ctypes.data, br.ctypes.data))
+        return vec, br
+
+    def features_files(self, components_bin, kmers_bin, k, threshold, vec_path, breadth_path):
+        _check(lib().mf_features(self.h, os.fsencode(components_bin), os.fsencode(kmers_bin), k, threshold,
+                                 _opt(vec_path), _opt(breadth_path)))
+
+    # ---- synthetic reads ----
+    def synth_reads_device(self, seed, sample, first_read, n_reads, read_len, genome_scale_bp, d_bases, d_offsets):
+        _check(lib().mf_synth_reads_device(self.h, seed, sample, first_read, n_reads, read_len, genome_scale_bp,
+                                           C.c_void_p(d_bases), C.c_void_p(d_offsets)))
+
+
+class Table:
+    """BigLong2ShortHashMap stand-in: canonical k-mer -> saturating count, resident in HBM."""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mf_table_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().mf_table_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def __len__(self):
+        a = C.c_uint64()
+        _check(lib().mf_table_stats(self.h, C.byref(a), None))
+        return a.value
+
+    def occurrences(self):
+        a = C.c_uint64()
+        _check(lib().mf_table_occurrences(self.h, C.byref(a)))
+        return a.value
+
+    def export(self, threshold=-1):
+        """-> (keys uint64[n] ascending, counts uint16[n]) with count > threshold"""
+        n = C.c_uint64()
+        _check(lib().mf_table_export(self.h, threshold, None, None, 0, C.byref(n)))
+        keys = np.empty(n.value, dtype=np.uint64)
+        cnts = np.empty(n.value, dtype=np.uint16)
+        if n.value:
+            _check(lib().mf_table_export(self.h, threshold, keys.ctypes.data, cnts.ctypes.data, n.value, C.byref(n)))
+        return keys, cnts
+
+    def device_view(self):
+        k, c, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
+        _check(lib().mf_table_device_view(self.h, C.byref(k), C.byref(c), C.byref(n)))
+        return k.value, c.value, n.value
+
+    def lookup(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        out = np.empty(len(keys), dtype=np.int32)
+        _check(lib().mf_table_lookup(self.h, keys.ctypes.data, len(keys), out.ctypes.data))
+        return out
+
+    def write_kmers(self, threshold, kmers_bin, stat_txt=None):
+        """IOUtils.printKmers (src/io/IOUtils.java:45-71)"""
+        g = C.c_uint64()
+        _check(lib().mf_table_write_kmers(self.h, threshold, os.fsencode(kmers_bin), _opt(stat_txt), C.byref(g)))
+        return g.value
+
+    def filter(self, threshold):
+        t = C.c_void_p()
+        _check(lib().mf_table_filter(self.h, threshold, C.byref(t)))
+        return Table(self.ctx, t)
+
+
+class Seqs:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mf_seqs_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().mf_seqs_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def __len__(self):
+        return self.stats()[0]
+
+    def device_view(self):
+        p = [C.c_void_p() for _ in range(5)]
+        n, nb = C.c_uint64(), C.c_uint64()
+        _check(lib().mf_seqs_device_view(self.h, *[C.byref(x) for x in p], C.byref(n), C.byref(nb)))
+        return dict(bases=p[0].value, offsets=p[1].value, avg=p[2].value, min=p[3].value, max=p[4].value,
+                    n=n.value, n_bases=nb.value)
+
+    def export(self):
+        """-> list of (sequence str, avg, min, max)"""
+        n, nb = self.stats()
+        bases = np.empty(max(nb, 1), dtype=np.uint8)
+        off = np.empty(n + 1, dtype=np.uint64)
+        a = np.empty(max(n, 1), dtype=np.int32)
+        mn = np.empty(max(n, 1), dtype=np.int32)
+        mx = np.empty(max(n, 1), dtype=np.int32)
+        _check(lib().mf_seqs_export(self.h, bases.ctypes.data, off.ctypes.data, a.ctypes.data, mn.ctypes.data,
+                                    mx.ctypes.data))
+        raw = bases.tobytes()
+        return [(raw[int(off[i]):int(off[i + 1])].decode(), int(a[i]), int(mn[i]), int(mx[i])) for i in range(n)]
+
+    def write_fasta(self, path):
+        _check(lib().mf_seqs_write_fasta(self.h, os.fsencode(path)))
+
+
+class Comps:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().mf_comps_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
+
+    def stats(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().mf_comps_stats(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def __len__(self):
+        return self.stats()[0]
+
+    def export(self):
+        """-> list of (size, weight, thr, kmers uint64[] ascending)"""
+        n, nk = self.stats()
+        sizes = np.empty(max(n, 1), dtype=np.uint64)
+        w = np.empty(max(n, 1), dtype=np.int64)
+        thr = np.empty(max(n, 1), dtype=np.int32)
+        off = np.empty(n + 1, dtype=np.uint64)
+        km = np.empty(max(nk, 1), dtype=np.uint64)
+        _check(lib().mf_comps_export(self.h, sizes.ctypes.data, w.ctypes.data, thr.ctypes.data, off.ctypes.data,
+                                     km.ctypes.data))
+        return [(int(sizes[i]), int(w[i]), int(thr[i]), km[int(off[i]):int(off[i + 1])].copy()) for i in range(n)]
+
+    def write(self, components_bin, stat_txt=None):
+        _check(lib().mf_comps_write(self.h, os.fsencode(components_bin), _opt(stat_txt)))
+
+
+def bray_curtis(vecs):
+    """DistanceMatrixCalculatorMain.brayCurtisDistance (:140-152) for all sample pairs."""
+    vecs = np.ascontiguousarray(vecs, dtype=np.int64)
+    s, c = vecs.shape
+    out = np.zeros((s, s), dtype=np.float64)
+    _check(lib().mf_bray_curtis(vecs.ctypes.data, s, c, out.ctypes.data))
+    return out
+
+
+def synth_reads_host(seed, sample, first_read, n_reads, read_len, genome_scale_bp):
+    bases = np.empty(n_reads * read_len, dtype=np.uint8)
+    off = np.empty(n_reads + 1, dtype=np.uint64)
+    _check(lib().mf_synth_reads_host(seed, sample, first_read, n_reads, read_len, genome_scale_bp,
+                                     bases.ctypes.data, off.ctypes.data))
+    return bases, off

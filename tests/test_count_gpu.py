@@ -1,0 +1,138 @@
+"""GPU parity: HIP counting path (through the C-ABI) vs the CPU oracle, bit-exact sorted (k-mer, count) lists."""
+import numpy as np
+import pytest
+
+from util import gpu_count, genome_reads, pack_reads, random_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def _check(ctx, oracle, bases, off, k, min_len=0, thr=-1):
+    t = gpu_count(ctx, bases, off, k, min_len)
+    gk, gc = t.export(thr)
+    ok, ov = oracle.Table().count_buffer(bases, off, k, min_len).export(thr)
+    assert len(gk) == len(ok), (len(gk), len(ok))
+    assert np.array_equal(gk, ok)
+    assert np.array_equal(gc.astype(np.int32), ov)
+    lens = np.diff(off.astype(np.int64))
+    occ = int(np.maximum(lens - k + 1, 0)[lens >= max(min_len, k)].sum())
+    assert t.occurrences() == occ
+    n, total = t.stats()
+    assert n == len(oracle.Table().count_buffer(bases, off, k, min_len))
+    return t
+
+
+def _reset(ctx):
+    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0)):
+        ctx.set_option(name, v)
+
+
+def test_reference_fasta(gpu_ctx, oracle, ref_files):
+    _reset(gpu_ctx)
+    for f, (nd, ng) in zip(ref_files, [(17063, 16918), (8176, 7321), (14042, 11351)]):
+        b, o = oracle.read_file(f)
+        t = _check(gpu_ctx, oracle, b, o, 31)
+        assert len(t) == nd
+        assert len(t.export(1)[0]) == ng
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 15, 16, 21, 30, 31])
+def test_ragged_reads_all_k(gpu_ctx, oracle, k):
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(100 + k)
+    b, o = random_reads(rng, 3000, 0, 90)        # includes empty reads and reads shorter than k
+    _check(gpu_ctx, oracle, b, o, k)
+    _check(gpu_ctx, oracle, b, o, k, min_len=40)
+
+
+def test_lowercase_and_boundaries(gpu_ctx, oracle):
+    _reset(gpu_ctx)
+    reads = ["acgtACGTacgtACGTacgtACGTacgtACGTa", "A" * 31, "C" * 30, "G", "", "T" * 64, "ACGT" * 16 + "A"]
+    b, o = pack_reads(reads)
+    _check(gpu_ctx, oracle, b, o, 31)
+    _check(gpu_ctx, oracle, b, o, 4)
+
+
+def test_polya_saturation(gpu_ctx, oracle):
+    _reset(gpu_ctx)
+    b, o = pack_reads(["A" * 40000, "T" * 100, "ACGTTGCA" * 20])
+    t = _check(gpu_ctx, oracle, b, o, 31)
+    k, c = t.export()
+    assert k[0] == 0 and c[0] == 32767           # key 0 legal, count saturates (NumUtils.java:21-26)
+
+
+def test_empty_inputs(gpu_ctx, oracle):
+    _reset(gpu_ctx)
+    b, o = pack_reads([])
+    t = gpu_count(gpu_ctx, b, o, 31)
+    assert len(t) == 0 and t.occurrences() == 0
+    b, o = pack_reads(["ACGT", "AC"])
+    t = gpu_count(gpu_ctx, b, o, 31)
+    assert len(t) == 0
+
+
+@pytest.mark.parametrize("l1,l2,staged,blocks", [(0, 0, 1, 0), (3, 0, 1, 0), (3, 4, 1, 2), (5, 5, 0, 3), (11, 0, 1, 0),
+                                                 (6, 6, 1, 0), (2, 11, 1, 5)])
+def test_partition_plans(gpu_ctx, oracle, l1, l2, staged, blocks):
+    """every partition plan / scatter flavour must give the same table"""
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(7)
+    b, o = genome_reads(rng, 20000, 4000, 100, err=0.01)
+    gpu_ctx.set_option("l1_bits", l1)
+    gpu_ctx.set_option("l2_bits", l2)
+    gpu_ctx.set_option("scatter_staged", staged)
+    gpu_ctx.set_option("l1_blocks", blocks)
+    try:
+        _check(gpu_ctx, oracle, b, o, 31)
+        _check(gpu_ctx, oracle, b, o, 11)
+    finally:
+        _reset(gpu_ctx)
+
+
+def test_auto_plan_medium(gpu_ctx, oracle):
+    """2.4e7 occurrences: auto plan uses two partition levels; compare everything with the oracle"""
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(11)
+    b, o = genome_reads(rng, 2_000_000, 200_000, 150, err=0.005)
+    gpu_ctx.set_option("part_target", 256)       # forces 17 partition bits on this size
+    try:
+        _check(gpu_ctx, oracle, b, o, 31)
+    finally:
+        _reset(gpu_ctx)
+    _check(gpu_ctx, oracle, b, o, 31)
+
+
+def test_lookup_and_filter(gpu_ctx, oracle, ref_files):
+    _reset(gpu_ctx)
+    b, o = oracle.read_file(ref_files[2])
+    t = gpu_count(gpu_ctx, b, o, 31)
+    keys, cnts = t.export()
+    probe = np.concatenate([keys[:100], keys[-100:], np.array([1, 2, 3, 2 ** 61 + 5], dtype=np.uint64)])
+    got = t.lookup(probe)
+    ot = oracle.Table().count_buffer(b, o, 31)
+    want = np.array([ot.get(int(x)) for x in probe], dtype=np.int32)
+    assert np.array_equal(got, want)
+    f = t.filter(1)
+    fk, fc = f.export()
+    m = cnts > 1
+    assert np.array_equal(fk, keys[m]) and np.array_equal(fc, cnts[m])
+
+
+def test_from_host_insert_or_add(gpu_ctx):
+    keys = np.array([5, 9, 5, 0, 9, 5, 77], dtype=np.uint64)
+    cnts = np.array([30000, 1, 30000, 4, 2, 7, 65535 // 2], dtype=np.uint16)
+    t = gpu_ctx.table_from_host(keys, cnts, 31)
+    k, c = t.export()
+    assert k.tolist() == [0, 5, 9, 77] and c.tolist() == [4, 32767, 3, 32767]
+
+
+def test_synth_generator_matches_host(gpu_ctx):
+    import torch
+    from metafast_amd import lib as L
+    n, rl = 5000, 150
+    tb = torch.zeros(n * rl + 64, dtype=torch.uint8, device="cuda")
+    to = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    gpu_ctx.synth_reads_device(0x4D45544146415354, 3, 1000, n, rl, 20000, tb.data_ptr(), to.data_ptr())
+    hb, ho = L.synth_reads_host(0x4D45544146415354, 3, 1000, n, rl, 20000)
+    assert np.array_equal(tb[: n * rl].cpu().numpy(), hb)
+    assert np.array_equal(to.cpu().numpy().astype(np.uint64), ho)
