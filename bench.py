@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- k-mers/s counted + graphed at k=31 on synthetic 150 bp reads (BASELINE.json metric).
+
+A step = one pass of the hot path over one synthetic sample that is already resident in HBM:
+  count (mask -> LDS-staged radix partition -> LDS hash-count) -> unitigs -> [all-gather unitigs] ->
+  cutter table -> connected components -> features -> [all-gather vectors] -> Bray-Curtis.
+One process per GPU, one sample (100 M reads) per GPU (weak scaling).  Rank 0 prints ONE JSON line.
+
+  python bench.py --gpus 1 --steps 3 --warmup 1
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus 8 --steps 3 --warmup 1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+SEED = 0x4D45544146415354      # "METAFAST"
+
+
+def algorithmic_bytes(kernel, s):
+    """Algorithmic HBM bytes of ONE full pass of `kernel` over the sample."""
+    occ, dist_, good, nb = s["n_occ"], s["n_distinct"], s["n_good"], s["n_bases"]
+    return {
+        "k_mask": nb / 8 * 2 + s["n_reads"] * 8,
+        "k_l1_hist": nb + nb / 8,                       # ASCII bases + valid-start bitmap
+        "k_l1_scatter": nb + nb / 8 + 8 * occ,          # + one 8-byte k-mer written per occurrence
+        "k_split": 16 * occ + 8 * occ,                  # histogram read + scatter read + write
+        "k_count": 8 * occ + 10 * dist_,                # stream read + (8 B key + 2 B count) per distinct k-mer
+        "k_gather": 20 * dist_,
+        "k_ut_flags": 105 * good,
+    }.get(kernel)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU (BASELINE config: 100 M)")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("-k", type=int, default=31)
+    ap.add_argument("--genome-scale", type=int, default=1_000_000, help="pool genome length scale in bp")
+    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--b1", type=int, default=1000)
+    ap.add_argument("--b2", type=int, default=10000)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
+
+    from metafast_amd import lib as L
+    from metafast_amd import pipeline as P
+
+    ctx = L.Context(local_rank, stream=torch.cuda.current_stream())
+    ctx.set_option("profile", 1)
+
+    # ---- synthetic sample of this rank, generated in HBM (untimed) ----
+    n_reads, rl, k = args.reads, args.read_len, args.k
+    n_bases = n_reads * rl
+    bases = torch.zeros(n_bases + 64, dtype=torch.uint8, device=device)
+    offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
+    ctx.synth_reads_device(SEED, rank, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr())
+    torch.cuda.synchronize()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(timings=None):
+        r = P.run_sample(ctx, bases, offsets, n_reads, n_bases, k=k, b=1, l=100, b1=args.b1, b2=args.b2, device=device,
+                         timings=timings)
+        stats = dict(n_occ=r["n_occ"], n_distinct=len(r["table"]), n_good=len(r["good"]), n_unitigs=len(r["seqs"]),
+                     n_cutter=len(r["cutter"]), n_components=len(r["comps"]), n_reads=n_reads, n_bases=n_bases)
+        for key in ("table", "good", "seqs", "cutter", "comps"):
+            r[key].close()
+        return stats, r["matrix"]
+
+    for _ in range(args.warmup):
+        stats, _m = step()
+    ctx.reset_timers()
+    stage_t = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats, matrix = step(stage_t)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    occ = torch.tensor([float(stats["n_occ"])], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(occ, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    total_occ = float(occ.item())
+
+    if rank == 0:
+        rep = ctx.kernel_report()          # name -> (launches, total ms) from HIP events on the launch stream
+        kern = {}
+        for name, (n, ms) in rep.items():
+            per_step_ms = ms / max(args.steps, 1)
+            ab = algorithmic_bytes(name, stats)
+            kern[name] = dict(launches=n, ms_per_step=round(per_step_ms, 4))
+            if ab:
+                kern[name]["algorithmic_GB"] = round(ab / 1e9, 4)
+                kern[name]["GBps"] = round(ab / 1e9 / (per_step_ms / 1e3), 1) if per_step_ms > 0 else None
+        cands = [kn for kn in kern if "GBps" in kern[kn]]
+        dom = max(cands, key=lambda kn: kern[kn]["ms_per_step"]) if cands else None
+
+        def roof(name):
+            if not name or name not in kern or not kern[name].get("GBps"):
+                return None
+            launches_per_step = kern[name]["launches"] / max(args.steps, 1)
+            return dict(kernel=name, bound="hbm", achieved=kern[name]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(kern[name]["GBps"] / HBM_PEAK_GBS, 4),
+                        avg_launch_ms=round(kern[name]["ms_per_step"] / max(launches_per_step, 1), 4),
+                        traffic=None)
+
+        cpu = None
+        if not args.no_cpu_baseline:
+            from oracle import oracle as O          # checker only: CPU baseline leg
+            m = min(args.cpu_sample_reads, n_reads)
+            hb = bases[: m * rl].cpu().numpy()
+            ho = offsets[: m + 1].cpu().numpy().astype(np.uint64)
+            cores = os.cpu_count() or 1
+            c0 = time.perf_counter()
+            d, o = O.cpu_baseline_count(hb, ho, k, cores)
+            cdt = time.perf_counter() - c0
+            cpu = dict(value=round(o / cdt, 1), unit="k-mers/s", cores=cores, kind="port",
+                       sample=f"counting stage only (multi-threaded restatement of IOUtils.loadReads) on the first {m} reads "
+                              f"of the same sample, reads already parsed in memory; {o} k-mer occurrences, {d} distinct, {cdt:.2f} s")
+        out = {
+            "metric": "k-mers/s counted+graphed at k=31, 150 bp reads",
+            "value": round(total_occ * args.steps / elapsed, 1),
+            "unit": "k-mers/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": f"{world} sample(s) x {n_reads} synthetic {rl} bp reads, k={k}, one sample per GPU, "
+                                   f"count+unitigs+components+features (b=1 l=100 b1={args.b1} b2={args.b2})",
+                       "reads_per_gpu": n_reads, "read_len": rl, "k": k, "genome_scale_bp": args.genome_scale},
+            "roofline": roof(dom),
+            "roofline_hash_count": roof("k_count"),
+            "cpu_baseline": cpu,
+            "stats": stats,
+            "stage_ms_per_step": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in stage_t.items()},
+            "kernels": kern,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,352 @@
+// mf_cc.hip -- connected components of the implicit de Bruijn neighbour graph + features + Bray-Curtis.
+//
+// Replaces ComponentsBuilder.splitStrategy (src/algo/ComponentsBuilder.java:24-32, run :58-153,
+// findAllComponents :198-213, bfs :220-270, Task.run :162-179).  The reference runs one sequential BFS
+// over the whole map; here:
+//
+//   C1 k_cc_adjacency  per vertex (cutter k-mer): the 8 canonical neighbours of KmerOperations.possibleNeighbours
+//                      (src/algo/KmerOperations.java:9-26) looked up in the HBM index -> 8 vertex ids
+//   C2 k_cc_hook       lock-free union-find: hook the larger root under the smaller with atomicCAS,
+//                      path halving on the way (so the root of a component is its smallest vertex id)
+//   C3 k_cc_flatten    parent[v] = root(v)
+//   C4 k_cc_stats      size / weight per root by atomics
+//   C5 k_cc_classify   size < b1 dropped | b1 <= size <= b2 kept | size > b2: vertices with value >= thr+1 stay
+//                      alive for the next round with thr+1 (bfs :245-262 builds nextHM the same way)
+//
+// A round at threshold t is ONE global pass over all still-alive vertices: different oversize components
+// are disconnected, so splitting them together is the same as the reference's per-component Tasks.
+#include "mf_common.h"
+#include <algorithm>
+#include <numeric>
+
+#define CC_NONE 0xFFFFFFFFu
+
+__global__ void k_cc_adjacency(const mf_slot *__restrict__ slots, uint64_t mask, const uint64_t *__restrict__ keys, uint64_t n,
+                               int k, uint32_t *__restrict__ nbr) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    const uint64_t x = keys[v];
+    uint32_t out[8];
+#pragma unroll
+    for (uint32_t nuc = 0; nuc < 4; nuc++) {
+        uint32_t idx, val;
+        uint64_t y = ((x << 2) | nuc) & kmask;
+        out[2 * nuc] = mf_index_find(slots, mask, mf_canon(y, k), &idx, &val) ? idx : CC_NONE;
+        y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2));
+        out[2 * nuc + 1] = mf_index_find(slots, mask, mf_canon(y, k), &idx, &val) ? idx : CC_NONE;
+    }
+    uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
+    o[0] = make_uint4(out[0], out[1], out[2], out[3]);
+    o[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+__global__ void k_cc_init(uint32_t *__restrict__ parent, uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight,
+                          uint64_t n) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    parent[v] = (uint32_t)v; csize[v] = 0; cweight[v] = 0;
+}
+
+__device__ __forceinline__ uint32_t cc_find(uint32_t *parent, uint32_t x) {
+    // path halving; plain (relaxed) loads/stores: any stale value is still an ancestor
+    for (;;) {
+        uint32_t p = __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p == x) return x;
+        uint32_t gp = __hip_atomic_load(&parent[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = gp;
+    }
+}
+__global__ void k_cc_hook(const uint32_t *__restrict__ nbr, const uint8_t *__restrict__ alive, uint32_t *parent, uint64_t n) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || !alive[v]) return;
+    const uint4 *q = reinterpret_cast<const uint4 *>(nbr + v * 8);
+    uint4 a = q[0], b = q[1];
+    uint32_t nb[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        uint32_t u = nb[j];
+        if (u == CC_NONE || u >= (uint32_t)v || !alive[u]) continue;    // each undirected edge once (adjacency is symmetric)
+        uint32_t ra = (uint32_t)v, rb = u;
+        for (;;) {
+            ra = cc_find(parent, ra); rb = cc_find(parent, rb);
+            if (ra == rb) break;
+            if (ra < rb) { uint32_t t = ra; ra = rb; rb = t; }
+            if (atomicCAS(&parent[ra], ra, rb) == ra) break;            // hook larger root under smaller
+        }
+    }
+}
+__global__ void k_cc_flatten_stats(const uint8_t *__restrict__ alive, uint32_t *parent, const uint16_t *__restrict__ vals,
+                                   uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight, uint64_t n) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || !alive[v]) return;
+    uint32_t r = cc_find(parent, (uint32_t)v);
+    parent[v] = r;
+    atomicAdd(&csize[r], 1u);
+    atomicAdd(&cweight[r], (unsigned long long)vals[v]);
+}
+// per root: classify; kept roots get a slot in the kept list
+struct cc_kept { uint32_t root; uint32_t size; unsigned long long weight; };
+__global__ void k_cc_classify(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ parent,
+                              const uint32_t *__restrict__ csize, const unsigned long long *__restrict__ cweight, uint64_t n,
+                              uint32_t b1, uint32_t b2, uint32_t *__restrict__ keptslot, cc_kept *__restrict__ kept,
+                              unsigned int *__restrict__ counters /* [0]=kept comps [1]=kept kmers [2]=big comps */) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || !alive[v] || parent[v] != (uint32_t)v) return;
+    uint32_t s = csize[v];
+    if (s < b1) return;
+    if (s <= b2) {
+        uint32_t slot = atomicAdd(&counters[0], 1u);
+        atomicAdd(&counters[1], s);
+        keptslot[v] = slot;
+        kept[slot].root = (uint32_t)v; kept[slot].size = s; kept[slot].weight = cweight[v];
+    } else atomicAdd(&counters[2], 1u);
+}
+// per vertex: members of kept components are appended to the member list; vertices of oversize components with
+// value >= thr+1 stay alive, everything else dies
+__global__ void k_cc_members(uint8_t *__restrict__ alive, const uint32_t *__restrict__ parent, const uint32_t *__restrict__ csize,
+                             const uint16_t *__restrict__ vals, const uint64_t *__restrict__ keys, uint64_t n, uint32_t b1,
+                             uint32_t b2, uint32_t next_thr, const uint32_t *__restrict__ keptslot,
+                             const uint64_t *__restrict__ slot_off, uint32_t *__restrict__ slot_fill,
+                             uint64_t *__restrict__ members) {
+    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || !alive[v]) return;
+    uint32_t r = parent[v];
+    uint32_t s = csize[r];
+    if (s > b2) { if ((uint32_t)vals[v] < next_thr) alive[v] = 0; return; }
+    alive[v] = 0;
+    if (s < b1) return;
+    uint32_t slot = keptslot[r];
+    uint32_t pos = atomicAdd(&slot_fill[slot], 1u);
+    members[slot_off[slot] + pos] = keys[v];
+}
+
+// ---- features: one thread per sample record ----
+__global__ void k_features(const mf_slot *__restrict__ slots, uint64_t mask, const uint32_t *__restrict__ comp_of,
+                           const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnts, uint64_t n, int threshold,
+                           unsigned long long *__restrict__ vec, unsigned int *__restrict__ found) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        int c = (int)cnts[i];
+        if (c <= threshold) continue;                       // value > threshold (buildAndPrintVector :196-199)
+        uint32_t idx, val;
+        if (!mf_index_find(slots, mask, keys[i], &idx, &val)) continue;   // hm.contains(kmer) (KmersPresenceWorker :583-587)
+        uint32_t comp = comp_of[idx];
+        atomicAdd(&vec[comp], (unsigned long long)c);
+        atomicAdd(&found[comp], 1u);
+    }
+}
+
+static inline unsigned cgrid(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+// builds d_kmers / d_comp / index from the host vectors of a finished mf_comps
+static int comps_upload(mf_comps *C) {
+    mf_ctx *ctx = C->ctx;
+    const uint64_t nk = C->kmers.size();
+    C->n_kmers = nk;
+    if (nk >= 0xFFFFFFFFull) return mf_set_error("components: too many k-mers");
+    void *p = nullptr;
+    MF_TRY(mf_alloc(ctx, (nk ? nk : 1) * 8, &p)); C->d_kmers = (uint64_t *)p; C->kmers_bytes = (nk ? nk : 1) * 8;
+    MF_TRY(mf_alloc(ctx, (nk ? nk : 1) * 4, &p)); C->d_comp = (uint32_t *)p; C->comp_bytes = (nk ? nk : 1) * 4;
+    if (nk) {
+        std::vector<uint32_t> comp(nk);
+        for (uint64_t c = 0; c < C->n; c++)
+            for (uint64_t j = C->offsets[c]; j < C->offsets[c + 1]; j++) comp[j] = (uint32_t)c;
+        MF_HIP(hipMemcpyAsync(C->d_kmers, C->kmers.data(), nk * 8, hipMemcpyHostToDevice, ctx->stream));
+        MF_HIP(hipMemcpyAsync(C->d_comp, comp.data(), nk * 4, hipMemcpyHostToDevice, ctx->stream));
+        MF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    MF_TRY(mf_index_build(ctx, C->d_kmers, nullptr, nk, &C->index, &C->index_bytes));
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    return MF_OK;
+}
+
+struct host_comp { uint64_t size; int64_t weight; int32_t thr; std::vector<uint64_t> kmers; };
+
+// final order: ConnectedComponent.compareTo (src/structures/ConnectedComponent.java:125-136): thr asc, weight desc,
+// size desc; ties (discovery order in the reference = hash / race dependent) broken by the smallest k-mer
+static void comps_finalize(mf_comps *C, std::vector<host_comp> &hc) {
+    for (auto &c : hc) std::sort(c.kmers.begin(), c.kmers.end());
+    std::sort(hc.begin(), hc.end(), [](const host_comp &a, const host_comp &b) {
+        if (a.thr != b.thr) return a.thr < b.thr;
+        if (a.weight != b.weight) return a.weight > b.weight;
+        if (a.size != b.size) return a.size > b.size;
+        uint64_t ka = a.kmers.empty() ? 0 : a.kmers[0], kb = b.kmers.empty() ? 0 : b.kmers[0];
+        return ka < kb;
+    });
+    C->n = hc.size();
+    C->sizes.clear(); C->weights.clear(); C->thr.clear(); C->offsets.assign(1, 0); C->kmers.clear();
+    for (auto &c : hc) {
+        C->sizes.push_back(c.size); C->weights.push_back(c.weight); C->thr.push_back(c.thr);
+        C->kmers.insert(C->kmers.end(), c.kmers.begin(), c.kmers.end());
+        C->offsets.push_back(C->kmers.size());
+    }
+}
+
+extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2, mf_comps **out) {
+    if (!ctx || !t || !out) return mf_set_error("mf_cut_components_device: NULL argument");
+    *out = nullptr;
+    MF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t n = t->n;
+    const int k = t->k;
+    if (n >= 0xFFFFFFFFull) return mf_set_error("components: more than 2^32 vertices is not supported");
+    if (b1 < 0) b1 = 0;
+    std::vector<host_comp> hc;
+    if (n) {
+        MF_TRY(mf_table_ensure_index(t));
+        mf_buf<uint32_t> nbr, parent, csize, keptslot, slot_fill; mf_buf<unsigned long long> cweight; mf_buf<uint8_t> alive;
+        mf_buf<unsigned int> counters; mf_buf<cc_kept> kept;
+        MF_TRY(nbr.alloc(ctx, n * 8)); MF_TRY(parent.alloc(ctx, n)); MF_TRY(csize.alloc(ctx, n)); MF_TRY(keptslot.alloc(ctx, n));
+        MF_TRY(cweight.alloc(ctx, n)); MF_TRY(alive.alloc(ctx, n)); MF_TRY(counters.alloc(ctx, 4));
+        {
+            mf_ktimer tm(ctx, "k_cc_adjacency");
+            k_cc_adjacency<<<cgrid(n), 256, 0, st>>>((const mf_slot *)t->index.slots, t->index.cap - 1, t->d_keys, n, k, nbr.p);
+        }
+        MF_HIP(hipMemsetAsync(alive.p, 1, n, st));
+        for (int thr = 1;; thr++) {
+            MF_HIP(hipMemsetAsync(counters.p, 0, 16, st));
+            {
+                mf_ktimer tm(ctx, "k_cc_hook");
+                k_cc_init<<<cgrid(n), 256, 0, st>>>(parent.p, csize.p, cweight.p, n);
+                k_cc_hook<<<cgrid(n), 256, 0, st>>>(nbr.p, alive.p, parent.p, n);
+            }
+            {
+                mf_ktimer tm(ctx, "k_cc_stats");
+                k_cc_flatten_stats<<<cgrid(n), 256, 0, st>>>(alive.p, parent.p, t->d_counts, csize.p, cweight.p, n);
+            }
+            // number of kept components is bounded by n / max(b1,1); size the list by a first counting pass
+            unsigned int cnt[4];
+            MF_TRY(kept.alloc(ctx, n / (uint64_t)std::max(b1, 1) + 1));
+            k_cc_classify<<<cgrid(n), 256, 0, st>>>(alive.p, parent.p, csize.p, cweight.p, n, (uint32_t)b1, (uint32_t)b2, keptslot.p,
+                                                    kept.p, counters.p);
+            MF_HIP(hipMemcpyAsync(cnt, counters.p, 16, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            const uint32_t nkept = cnt[0], nkm = cnt[1], nbig = cnt[2];
+            std::vector<cc_kept> hk(nkept);
+            std::vector<uint64_t> soff(nkept + 1, 0);
+            if (nkept) {
+                MF_HIP(hipMemcpyAsync(hk.data(), kept.p, nkept * sizeof(cc_kept), hipMemcpyDeviceToHost, st));
+                MF_HIP(hipStreamSynchronize(st));
+                for (uint32_t i = 0; i < nkept; i++) soff[i + 1] = soff[i] + hk[i].size;
+            }
+            mf_buf<uint64_t> d_soff, members;
+            MF_TRY(d_soff.alloc(ctx, nkept + 1)); MF_TRY(members.alloc(ctx, nkm)); MF_TRY(slot_fill.alloc(ctx, nkept));
+            MF_HIP(hipMemcpyAsync(d_soff.p, soff.data(), (nkept + 1) * 8, hipMemcpyHostToDevice, st));
+            MF_HIP(hipMemsetAsync(slot_fill.p, 0, slot_fill.bytes(), st));
+            {
+                mf_ktimer tm(ctx, "k_cc_members");
+                k_cc_members<<<cgrid(n), 256, 0, st>>>(alive.p, parent.p, csize.p, t->d_counts, t->d_keys, n, (uint32_t)b1, (uint32_t)b2,
+                                                       (uint32_t)(thr + 1), keptslot.p, d_soff.p, slot_fill.p, members.p);
+            }
+            std::vector<uint64_t> hm(nkm);
+            if (nkm) MF_HIP(hipMemcpyAsync(hm.data(), members.p, (size_t)nkm * 8, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            for (uint32_t i = 0; i < nkept; i++) {
+                host_comp c; c.size = hk[i].size; c.weight = (int64_t)hk[i].weight; c.thr = thr;
+                c.kmers.assign(hm.begin() + soff[i], hm.begin() + soff[i + 1]);
+                hc.push_back(std::move(c));
+            }
+            if (ctx->opt_verbose)
+                fprintf(stderr, "[mf] components: thr=%d kept=%u (%u k-mers) big=%u\n", thr, nkept, nkm, nbig);
+            if (!nbig) break;
+            if (thr > MF_MAX_COUNT) return mf_set_error("components: threshold loop did not terminate");
+        }
+    }
+    mf_comps *C = new mf_comps();
+    C->ctx = ctx; C->k = k;
+    comps_finalize(C, hc);
+    int rc = comps_upload(C);
+    if (rc < 0) { mf_comps_destroy(C); return rc; }
+    *out = C;
+    return MF_OK;
+}
+
+extern "C" void mf_comps_destroy(mf_comps *c) {
+    if (!c) return;
+    if (c->d_kmers) mf_release(c->ctx, c->d_kmers, c->kmers_bytes);
+    if (c->d_comp) mf_release(c->ctx, c->d_comp, c->comp_bytes);
+    if (c->index.slots) mf_release(c->ctx, c->index.slots, c->index_bytes);
+    delete c;
+}
+extern "C" int mf_comps_stats(const mf_comps *c, uint64_t *n_comp, uint64_t *n_kmers) {
+    if (!c) return mf_set_error("comps is NULL");
+    if (n_comp) *n_comp = c->n;
+    if (n_kmers) *n_kmers = c->kmers.size();
+    return MF_OK;
+}
+extern "C" int mf_comps_export(const mf_comps *c, uint64_t *sizes, int64_t *weights, int32_t *thr, uint64_t *kmer_offsets,
+                               uint64_t *kmers) {
+    if (!c) return mf_set_error("comps is NULL");
+    if (sizes && c->n) memcpy(sizes, c->sizes.data(), c->n * 8);
+    if (weights && c->n) memcpy(weights, c->weights.data(), c->n * 8);
+    if (thr && c->n) memcpy(thr, c->thr.data(), c->n * 4);
+    if (kmer_offsets) memcpy(kmer_offsets, c->offsets.data(), (c->n + 1) * 8);
+    if (kmers && !c->kmers.empty()) memcpy(kmers, c->kmers.data(), c->kmers.size() * 8);
+    return MF_OK;
+}
+
+// used by mf_comps_load (mf_io.hip)
+int mf_comps_from_host(mf_ctx *ctx, int k, const std::vector<uint64_t> &sizes, const std::vector<int64_t> &weights,
+                       const std::vector<int32_t> &thr, const std::vector<uint64_t> &offsets, const std::vector<uint64_t> &kmers,
+                       mf_comps **out) {
+    mf_comps *C = new mf_comps();
+    C->ctx = ctx; C->k = k; C->n = sizes.size();
+    C->sizes = sizes; C->weights = weights; C->thr = thr; C->offsets = offsets; C->kmers = kmers;
+    int rc = comps_upload(C);
+    if (rc < 0) { mf_comps_destroy(C); return rc; }
+    *out = C;
+    return MF_OK;
+}
+
+extern "C" int mf_features_device(mf_ctx *ctx, mf_comps *c, const mf_table *sample, int threshold, int64_t *vec, double *breadth) {
+    if (!ctx || !c || !sample || !vec) return mf_set_error("mf_features_device: NULL argument");
+    MF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t nc = c->n;
+    if (!nc) return MF_OK;
+    mf_buf<unsigned long long> dvec; mf_buf<unsigned int> dfound;
+    MF_TRY(dvec.alloc(ctx, nc)); MF_TRY(dfound.alloc(ctx, nc));
+    MF_HIP(hipMemsetAsync(dvec.p, 0, nc * 8, st));
+    MF_HIP(hipMemsetAsync(dfound.p, 0, nc * 4, st));
+    if (sample->n) {
+        unsigned grid = (unsigned)std::min<uint64_t>((sample->n + 255) / 256, 65536);
+        mf_ktimer tm(ctx, "k_features");
+        k_features<<<grid, 256, 0, st>>>((const mf_slot *)c->index.slots, c->index.cap - 1, c->d_comp, sample->d_keys,
+                                         sample->d_counts, sample->n, threshold, dvec.p, dfound.p);
+    }
+    std::vector<unsigned int> hf(nc);
+    MF_HIP(hipMemcpyAsync(vec, dvec.p, nc * 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemcpyAsync(hf.data(), dfound.p, nc * 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    if (breadth)
+        for (uint64_t i = 0; i < nc; i++) {
+            uint64_t cnt = c->offsets[i + 1] - c->offsets[i];
+            // a negative threshold makes absent k-mers (value 0) count as found (value > threshold)
+            double f = threshold < 0 ? (double)cnt : (double)hf[i];
+            breadth[i] = f / (double)cnt;                    // ((double) kmersFound) / kmersCount :203
+        }
+    return MF_OK;
+}
+
+// DistanceMatrixCalculatorMain.brayCurtisDistance :140-152.  Both sums are exact integers < 2^53 in double
+// arithmetic for realistic inputs, so one IEEE division reproduces the Java result bit for bit.
+extern "C" int mf_bray_curtis(const int64_t *vecs, int n_samples, int n_comp, double *out) {
+    if (!vecs || !out || n_samples < 0 || n_comp < 0) return mf_set_error("mf_bray_curtis: bad argument");
+    for (int i = 0; i < n_samples; i++) {
+        out[(size_t)i * n_samples + i] = 0.0;
+        for (int j = i + 1; j < n_samples; j++) {
+            double sumdiff = 0, sum = 0;
+            const int64_t *a = vecs + (size_t)i * n_comp, *b = vecs + (size_t)j * n_comp;
+            for (int p = 0; p < n_comp; p++) {
+                double x = (double)a[p], y = (double)b[p];
+                sumdiff += x > y ? x - y : y - x;
+                sum += (x < 0 ? -x : x) + (y < 0 ? -y : y);
+            }
+            out[(size_t)i * n_samples + j] = out[(size_t)j * n_samples + i] = sumdiff / sum;
+        }
+    }
+    return MF_OK;
+}

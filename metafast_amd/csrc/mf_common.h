@@ -72,6 +72,9 @@ struct mf_ctx {
 int  mf_alloc(mf_ctx *ctx, size_t bytes, void **out);   // cached hipMalloc
 void mf_release(mf_ctx *ctx, void *p, size_t bytes);     // back to the cache
 int  mf_collect_timers(mf_ctx *ctx);
+// debugging aid (option verbose >= 2): synchronise after a launch and report which kernel failed / hung
+int  mf_debug_sync(mf_ctx *ctx, const char *what);
+#define MF_DBG(ctx, what) do { if ((ctx)->opt_verbose >= 2) MF_TRY(mf_debug_sync((ctx), (what))); } while (0)
 
 // RAII HIP-event timer around one kernel launch on ctx->stream (only when option profile=1)
 struct mf_ktimer {

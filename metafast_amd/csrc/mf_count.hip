@@ -144,32 +144,41 @@ struct mf_stage {
 #define MF_WG __HIP_MEMORY_SCOPE_WORKGROUP
 
 // Lock-free within the workgroup: reserve a slot, write it, commit; the 8th committer flushes the
-// line to HBM with four 16-byte stores and reopens it.  Lanes that find the line full spin (the
-// flusher never waits, so the wave always makes progress).
+// line to HBM with four 16-byte stores and reopens it.  Lanes that find the line full retry.
+//
+// The retry loop is WAVE-UNIFORM (ballot): every lane of the wave stays in the loop until the whole
+// wave has placed its element, and the write + commit + flush of a successful lane happen INSIDE the
+// iteration.  A per-lane `while (!done)` loop is wrong here: hipcc sinks the success path below the
+// loop, so the lane holding slot 7 would wait at the loop exit for a same-wave lane that spins on the
+// full line forever (SIMT deadlock, observed on gfx950).
 __device__ __forceinline__ void mf_stage_insert(const mf_stage &L, uint64_t *__restrict__ out, uint32_t d, uint64_t key,
                                                 bool active) {
-    bool done = !active;
-    while (!done) {
-        uint32_t w = __hip_atomic_load(&L.ctr[d], __ATOMIC_RELAXED, MF_WG);
-        if ((w & 0xFFFFu) < (uint32_t)MF_LINE) {
-            uint32_t old = __hip_atomic_fetch_add(&L.ctr[d], 1u, __ATOMIC_RELAXED, MF_WG);
-            uint32_t r = old & 0xFFFFu;
-            if (r < (uint32_t)MF_LINE) {
-                L.line[d * MF_LINE + r] = key;
-                uint32_t old2 = __hip_atomic_fetch_add(&L.ctr[d], 0x10000u, __ATOMIC_ACQ_REL, MF_WG);
-                if ((old2 >> 16) == (uint32_t)(MF_LINE - 1)) {
-                    uint64_t pos = L.cur[d];
-                    L.cur[d] = pos + MF_LINE;
-                    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(&L.line[d * MF_LINE]);
-                    ulonglong2 a = s[0], b = s[1], c = s[2], e = s[3];
-                    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + pos);
-                    o[0] = a; o[1] = b; o[2] = c; o[3] = e;
-                    __hip_atomic_store(&L.ctr[d], 0u, __ATOMIC_RELEASE, MF_WG);
+    bool pending = active;
+    while (__ballot(pending) != 0ull) {
+        if (pending) {
+            uint32_t w = __hip_atomic_load(&L.ctr[d], __ATOMIC_RELAXED, MF_WG);
+            if ((w & 0xFFFFu) < (uint32_t)MF_LINE) {
+                uint32_t old = __hip_atomic_fetch_add(&L.ctr[d], 1u, __ATOMIC_RELAXED, MF_WG);
+                uint32_t r = old & 0xFFFFu;
+                if (r < (uint32_t)MF_LINE) {
+                    L.line[d * MF_LINE + r] = key;
+                    uint32_t old2 = __hip_atomic_fetch_add(&L.ctr[d], 0x10000u, __ATOMIC_ACQ_REL, MF_WG);
+                    if ((old2 >> 16) == (uint32_t)(MF_LINE - 1)) {
+                        uint64_t pos = L.cur[d];
+                        L.cur[d] = pos + MF_LINE;
+                        const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(&L.line[d * MF_LINE]);
+                        ulonglong2 a = s[0], b = s[1], c = s[2], e = s[3];
+                        ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + pos);
+                        o[0] = a; o[1] = b; o[2] = c; o[3] = e;
+                        __hip_atomic_store(&L.ctr[d], 0u, __ATOMIC_RELEASE, MF_WG);
+                    }
+                    pending = false;
                 }
-                done = true;
             }
         }
-        if (!done) __builtin_amdgcn_s_sleep(1);
+        // keep every memory operation of this iteration inside it
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 // after a barrier: write every partly filled line, padding with the sentinel
@@ -421,6 +430,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         k_mask_init<<<(unsigned)((n_words + 255) / 256), 256, 0, st>>>(vmask.p, n_words, n_bases);
         k_mask_reads<<<(unsigned)((n_reads + 255) / 256), 256, 0, st>>>(d_offsets, n_reads, k, min_len, vmask.p, &scal.p[0]);
     }
+    MF_DBG(ctx, "k_mask");
     unsigned long long n_occ = 0;
     MF_HIP(hipMemcpyAsync(&n_occ, &scal.p[0], 8, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
@@ -457,10 +467,12 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         mf_ktimer t(ctx, "k_l1_hist");
         k_l1_hist<<<G, 1024, 0, st>>>(d_bases, n_bases, vmask.p, n_words, wpb, k, bits1, blockhist.p, G);
     }
+    MF_DBG(ctx, "k_l1_hist");
     {
         mf_ktimer t(ctx, "k_scan");
         k_scan<true><<<1, 1024, 0, st>>>(blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal.p[1]);
     }
+    MF_DBG(ctx, "k_scan");
     uint64_t cap = n_occ + (uint64_t)MF_LINE * nd1 * G;    // upper bound of the padded total
     mf_buf<uint64_t> bufA; MF_TRY(bufA.alloc(ctx, cap));
     const bool staged = ctx->opt_scatter_staged != 0;
@@ -475,6 +487,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
             k_l1_scatter<false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask.p, n_words, wpb, k, bits1, blockstart.p, G, bufA.p);
         }
     }
+    MF_DBG(ctx, "k_l1_scatter");
     uint32_t np = (uint32_t)nd1;
     mf_buf<uint64_t> pstart; MF_TRY(pstart.alloc(ctx, np));
     mf_buf<uint32_t> plen; MF_TRY(plen.alloc(ctx, np));
@@ -503,6 +516,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
                 k_split<false><<<grid, 1024, lds, st>>>(bufA.p, pstart.p, plen.p, np, bits_used, bits, bufB.p, ostart.p, olen.p);
             }
         }
+        MF_DBG(ctx, "k_split");
         // swap
         std::swap(bufA.p, bufB.p); std::swap(bufA.n, bufB.n);
         std::swap(pstart.p, ostart.p); std::swap(pstart.n, ostart.n);
@@ -520,11 +534,13 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         mf_ktimer t(ctx, "k_count");
         k_count<<<grid, 1024, lds, st>>>(bufA.p, cnt.p, pstart.p, plen.p, np, dcount.p, (unsigned int *)&scal.p[2]);
     }
+    MF_DBG(ctx, "k_count");
     mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));
     {
         mf_ktimer t(ctx, "k_scan");
         k_scan<false><<<1, 1024, 0, st>>>(dcount.p, doff.p, np, (uint64_t *)&scal.p[3]);
     }
+    MF_DBG(ctx, "k_scan");
     unsigned long long res[4];
     MF_HIP(hipMemcpyAsync(res, scal.p, 32, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
@@ -538,6 +554,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         mf_ktimer t(ctx, "k_gather");
         k_gather<<<grid, 256, 0, st>>>(bufA.p, cnt.p, pstart.p, dcount.p, doff.p, np, dk.p, dc.p);
     }
+    MF_DBG(ctx, "k_gather");
     if (ctx->opt_verbose)
         fprintf(stderr, "[mf] count: n_occ=%llu levels=%zu bits=%d np=%u distinct=%llu\n", (unsigned long long)n_occ,
                 lv.size(), total_bits, np, (unsigned long long)n_dist);

@@ -177,3 +177,12 @@ extern "C" int mf_ctx_reset_timers(mf_ctx *ctx) {
     ctx->timings.clear();
     return MF_OK;
 }
+
+int mf_debug_sync(mf_ctx *ctx, const char *what) {
+    fprintf(stderr, "[mf] launched %s ...", what); fflush(stderr);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipGetLastError();
+    fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); fflush(stderr);
+    if (e != hipSuccess) return mf_set_error("%s failed: %s", what, hipGetErrorString(e));
+    return MF_OK;
+}

@@ -1,0 +1,407 @@
+// mf_io.hip -- host side of the C-ABI: readers, writers and the file-level entry points.
+// Plain C++ (no kernels); formats follow SURVEY.md Appendix A, each function cites the reference it replaces.
+#include "mf_common.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k,
+                  int min_len, mf_table **out);
+int mf_table_count_hist(const mf_table *t, std::vector<uint64_t> &hist);
+int mf_seqs_to_host(const mf_seqs *s, std::vector<uint8_t> &bases, std::vector<uint64_t> &off, std::vector<int32_t> &avg,
+                    std::vector<int32_t> &mn, std::vector<int32_t> &mx);
+int mf_comps_from_host(mf_ctx *ctx, int k, const std::vector<uint64_t> &sizes, const std::vector<int64_t> &weights,
+                       const std::vector<int32_t> &thr, const std::vector<uint64_t> &offsets, const std::vector<uint64_t> &kmers,
+                       mf_comps **out);
+
+// ---------------------------------------------------------------------------------------------
+// small file helpers
+// ---------------------------------------------------------------------------------------------
+static int read_whole_file(const char *path, std::vector<char> &buf) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return mf_set_error("can't open '%s'", path);
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    buf.resize((size_t)sz);
+    if (sz && fread(buf.data(), 1, (size_t)sz, f) != (size_t)sz) { fclose(f); return mf_set_error("short read on '%s'", path); }
+    fclose(f);
+    return MF_OK;
+}
+static bool ends_with_nocase(const std::string &s, const char *suf) {
+    size_t m = strlen(suf);
+    if (m > s.size()) return false;
+    for (size_t i = 0; i < m; i++) if (tolower((unsigned char)s[s.size() - m + i]) != suf[i]) return false;
+    return true;
+}
+static void be_put(uint8_t *p, uint64_t v, int nb) { for (int i = 0; i < nb; i++) p[i] = (uint8_t)(v >> (8 * (nb - 1 - i))); }
+static uint64_t be_get(const uint8_t *p, int nb) { uint64_t v = 0; for (int i = 0; i < nb; i++) v = (v << 8) | p[i]; return v; }
+
+// ---------------------------------------------------------------------------------------------
+// A1 readers
+// ---------------------------------------------------------------------------------------------
+struct read_batch {
+    std::vector<uint8_t> bases;      // upper-case ACGT
+    std::vector<uint64_t> offsets;   // [n+1]
+    read_batch() { offsets.push_back(0); }
+    void end_read() { offsets.push_back(bases.size()); }
+    void drop_read() { bases.resize(offsets.back()); }
+};
+// one text line at a time; BufferedReader.readLine semantics (\n, \r or \r\n)
+struct line_reader {
+    const char *b; size_t n, pos;
+    bool next(const char **ln, size_t *len) {
+        if (pos >= n) return false;
+        size_t s = pos, e = s;
+        while (e < n && b[e] != '\n' && b[e] != '\r') e++;
+        *ln = b + s; *len = e - s;
+        if (e < n) e += (b[e] == '\r' && e + 1 < n && b[e + 1] == '\n') ? 2 : 1;
+        pos = e;
+        return true;
+    }
+};
+// DnaTools.fromChar (itmo!/dna/DnaTools.java:46-64).  IUPAC codes: the reference picks one of the allowed bases at RANDOM
+// (:66-117); this implementation takes the first one listed there, which is one of the reference's possible outcomes.
+static int nucleotide_of(int c) {
+    switch (c) {
+    case 'A': case 'a': return 'A'; case 'C': case 'c': return 'C'; case 'G': case 'g': return 'G'; case 'T': case 't': return 'T';
+    case 'R': case 'r': return 'G'; case 'Y': case 'y': return 'T'; case 'M': case 'm': return 'A'; case 'K': case 'k': return 'G';
+    case 'S': case 's': return 'G'; case 'W': case 'w': return 'A'; case 'H': case 'h': return 'A'; case 'B': case 'b': return 'G';
+    case 'V': case 'v': return 'A'; case 'D': case 'd': return 'A';
+    default: return -1;
+    }
+}
+// FastaReader (itmo!/io/readers/FastaReader.java:53-104): records = concatenation of the non-comment lines between
+// '>'/';' lines; a record containing N/n is skipped
+static int parse_fasta(const std::vector<char> &buf, const char *path, read_batch &rb) {
+    line_reader lr{buf.data(), buf.size(), 0};
+    const char *ln; size_t len;
+    bool have = false, has_n = false;
+    int bad = -1;
+    for (;;) {
+        bool got = lr.next(&ln, &len);
+        bool comment = got && len > 0 && (ln[0] == '>' || ln[0] == ';');
+        if (!got || comment) {
+            if (have) {
+                if (has_n) rb.drop_read();
+                else if (bad >= 0) return mf_set_error("Incorrect nucleotide char: \"%c\" (%s)", bad, path);
+                else rb.end_read();
+            }
+            have = has_n = false; bad = -1;
+            if (!got) break;
+            continue;
+        }
+        for (size_t i = 0; i < len; i++) {
+            int c = (unsigned char)ln[i];
+            if (c == 'N' || c == 'n') { has_n = true; continue; }
+            int b = nucleotide_of(c);
+            if (b < 0) { if (bad < 0) bad = c; continue; }
+            rb.bases.push_back((uint8_t)b);
+        }
+        if (len) have = true;
+    }
+    return MF_OK;
+}
+// FastqReader (itmo!/io/readers/FastqReader.java:53-115) + quality sniffing (ReadersUtils.java:63-77: Illumina +64 on the
+// first 1000 records, any char outside [64,126] -> Sanger +33) + phred-0 drop (FastaReaderFromXQSource.java:66-70)
+static int fastq_line(line_reader &lr, const char *path, const char **ln, size_t *len) {   // 1 = line, 0 = EOF
+    do { if (!lr.next(ln, len)) return 0; } while (*len == 0);
+    if ((*ln)[0] != '@' && (*ln)[0] != '+') return mf_set_error("Unknown structure of fastq file! (%s)", path);
+    if (!lr.next(ln, len)) return mf_set_error("Unexpected end of file. File is corrupted/Format mismatch. (%s)", path);
+    return 1;
+}
+static int parse_fastq(const std::vector<char> &buf, const char *path, read_batch &rb) {
+    int offset = 64;
+    for (int pass = 0; pass < 2; pass++) {
+        line_reader lr{buf.data(), buf.size(), 0};
+        const char *d, *q; size_t dl, ql;
+        long rec = 0;
+        for (;;) {
+            int g = fastq_line(lr, path, &d, &dl);
+            if (g < 0) return g;
+            if (!g) break;
+            g = fastq_line(lr, path, &q, &ql);
+            if (g < 0) return g;
+            if (!g) return mf_set_error("Unexpected end of file. File is corrupted/Format mismatch. (%s)", path);
+            if (dl != ql) return mf_set_error("Bad DnaQ record: length of chars and quality is not the same. (%s)", path);
+            bool good = true;
+            for (size_t i = 0; i < dl; i++) {
+                int c = (unsigned char)d[i];
+                if (c == 'N' || c == 'n' || c == '.') { good = false; continue; }
+                int b = nucleotide_of(c);
+                if (b < 0) return mf_set_error("Incorrect nucleotide char: \"%c\" (%s)", c, path);
+                int qc = (unsigned char)q[i];
+                if (pass == 0) { if (qc < 64 || qc > 126) { offset = 33; goto sniffed; } }
+                else {
+                    if (qc < offset || qc > 126) return mf_set_error("Invalid quality code char: \"%c\" char code = %d (%s)", qc, qc, path);
+                    if (qc == offset) good = false;
+                    rb.bases.push_back((uint8_t)b);
+                }
+            }
+            if (pass == 1) { if (good) rb.end_read(); else rb.drop_read(); }
+            if (pass == 0 && ++rec >= 1000) break;
+        }
+    sniffed:;
+    }
+    return MF_OK;
+}
+// ReadersUtils.detectFileFormat (itmo!/io/ReadersUtils.java:27-54); compressed / binq inputs are not supported yet
+static int parse_reads_file(const char *path, read_batch &rb) {
+    std::string p(path);
+    int fmt = 0;
+    if (ends_with_nocase(p, ".gz") || ends_with_nocase(p, ".bz2") || ends_with_nocase(p, ".binq"))
+        return mf_set_error("compressed / binq input is not supported by the HIP path yet: '%s'", path);
+    if (ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq")) fmt = 2;
+    else if (ends_with_nocase(p, ".fasta") || ends_with_nocase(p, ".fa") || ends_with_nocase(p, ".fn") || ends_with_nocase(p, ".fna")) fmt = 1;
+    if (!fmt) return mf_set_error("Can't detect file format for file '%s'", path);
+    std::vector<char> buf;
+    MF_TRY(read_whole_file(path, buf));
+    return fmt == 1 ? parse_fasta(buf, path, rb) : parse_fastq(buf, path, rb);
+}
+
+// IOUtils.loadReads (src/io/IOUtils.java:772-803): all files into one table
+extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, mf_table **out) {
+    if (!ctx || !out || (nfiles && !files)) return mf_set_error("mf_count_reads: NULL argument");
+    *out = nullptr;
+    if (k < 1) return mf_set_error("The size of k-mer must be at least 1.");
+    if (k > 31) return mf_set_error("The size of k-mer must be no more than 31.");
+    read_batch rb;
+    for (int i = 0; i < nfiles; i++) MF_TRY(parse_reads_file(files[i], rb));
+    MF_HIP(hipSetDevice(ctx->device));
+    const uint64_t nb = rb.bases.size(), nr = rb.offsets.size() - 1;
+    mf_buf<uint8_t> db; mf_buf<uint64_t> doff;
+    MF_TRY(db.alloc(ctx, nb + 64)); MF_TRY(doff.alloc(ctx, nr + 1));
+    if (nb) MF_HIP(hipMemcpyAsync(db.p, rb.bases.data(), nb, hipMemcpyHostToDevice, ctx->stream));
+    MF_HIP(hipMemcpyAsync(doff.p, rb.offsets.data(), (nr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    return mf_count_core(ctx, db.p, doff.p, nr, nb, k, min_read_len, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A5 / A6
+// ---------------------------------------------------------------------------------------------
+// IOUtils.printKmers (src/io/IOUtils.java:45-71) + QuickQuantitativeStatistics.printToFile (:65-72)
+extern "C" int mf_table_write_kmers(const mf_table *t, int threshold, const char *kmers_bin, const char *stat_txt, uint64_t *n_good) {
+    if (!t || !kmers_bin) return mf_set_error("mf_table_write_kmers: NULL argument");
+    uint64_t n = 0;
+    MF_TRY(mf_table_export(t, threshold, nullptr, nullptr, 0, &n));
+    std::vector<uint64_t> keys(n); std::vector<uint16_t> cnts(n);
+    if (n) MF_TRY(mf_table_export(t, threshold, keys.data(), cnts.data(), n, &n));
+    FILE *f = fopen(kmers_bin, "wb");
+    if (!f) return mf_set_error("can't write '%s'", kmers_bin);
+    std::vector<uint8_t> rec(10 * (size_t)std::min<uint64_t>(n ? n : 1, 1 << 20));
+    for (uint64_t i = 0; i < n;) {
+        uint64_t m = std::min<uint64_t>(n - i, 1 << 20);
+        for (uint64_t j = 0; j < m; j++) { be_put(&rec[10 * j], keys[i + j], 8); be_put(&rec[10 * j + 8], cnts[i + j], 2); }
+        fwrite(rec.data(), 10, m, f);
+        i += m;
+    }
+    fclose(f);
+    if (stat_txt) {
+        std::vector<uint64_t> hist;
+        MF_TRY(mf_table_count_hist(t, hist));
+        f = fopen(stat_txt, "w");
+        if (!f) return mf_set_error("can't write '%s'", stat_txt);
+        fprintf(f, "# k-mer frequency\tnumber of such k-mers\n");
+        for (size_t v = 0; v < hist.size(); v++) if (hist[v]) fprintf(f, "%zu\t%llu\n", v, (unsigned long long)hist[v]);
+        fprintf(f, "\n");
+        fclose(f);
+    }
+    if (n_good) *n_good = n;
+    return MF_OK;
+}
+// IOUtils.loadKmers (src/io/IOUtils.java:369-401), Kmers2HMWorker.processKmer (:249-257), KmersLoadWorker (src/io/KmersLoadWorker.java:16-34)
+extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nfiles, int freq_threshold, int k, mf_table **out) {
+    if (!ctx || !out || (nfiles && !files)) return mf_set_error("mf_table_load_kmers: NULL argument");
+    *out = nullptr;
+    std::vector<uint64_t> keys; std::vector<uint16_t> cnts;
+    for (int i = 0; i < nfiles; i++) {
+        std::vector<char> buf;
+        MF_TRY(read_whole_file(files[i], buf));
+        if (buf.size() % 10) return mf_set_error("Can't load k-mers file '%s': size is not a multiple of the 10-byte record", files[i]);
+        const uint8_t *p = (const uint8_t *)buf.data();
+        for (size_t o = 0; o < buf.size(); o += 10) {
+            int freq = (int16_t)be_get(p + o + 8, 2);
+            if (freq > freq_threshold) { keys.push_back(be_get(p + o, 8)); cnts.push_back((uint16_t)freq); }
+        }
+    }
+    return mf_table_from_host(ctx, keys.data(), cnts.data(), keys.size(), k, out);
+}
+
+// ---------------------------------------------------------------------------------------------
+// A8 unitig files
+// ---------------------------------------------------------------------------------------------
+// Sequence.printSequences (src/structures/Sequence.java:26-37), FastaDedicatedWriter.writeData (:33-49),
+// TextUtils.printWithLineLimit (itmo!/utils/TextUtils.java:35-45): 70 columns
+extern "C" int mf_seqs_write_fasta(const mf_seqs *s, const char *path) {
+    if (!s || !path) return mf_set_error("mf_seqs_write_fasta: NULL argument");
+    std::vector<uint8_t> b; std::vector<uint64_t> o; std::vector<int32_t> a, lo, hi;
+    MF_TRY(mf_seqs_to_host(s, b, o, a, lo, hi));
+    FILE *f = fopen(path, "w");
+    if (!f) return mf_set_error("can't write '%s'", path);
+    for (uint64_t i = 0; i < s->n; i++) {
+        uint64_t len = o[i + 1] - o[i];
+        fprintf(f, ">%llu length=%llu av_weight=%d min_weight=%d max_weight=%d\n", (unsigned long long)(i + 1), (unsigned long long)len,
+                a[i], lo[i], hi[i]);
+        const uint8_t *q = b.data() + o[i];
+        uint64_t j = 0;
+        while ((j + 1) * 70 < len) { fwrite(q + j * 70, 1, 70, f); fputc('\n', f); j++; }
+        fwrite(q + j * 70, 1, len - j * 70, f); fputc('\n', f);
+    }
+    fclose(f);
+    return MF_OK;
+}
+// SeqBuilderMain.runImpl (src/tools/SeqBuilderMain.java:78-160)
+extern "C" int mf_build_unitigs(mf_ctx *ctx, mf_table *t, int k, int freq_threshold, int min_len, const char *seq_fasta,
+                                const char *distribution, uint64_t *n_seq) {
+    if (!ctx || !t || !seq_fasta) return mf_set_error("mf_build_unitigs: NULL argument");
+    if (k != t->k) return mf_set_error("mf_build_unitigs: k=%d but the table was built with k=%d", k, t->k);
+    if (distribution) {                                         // stat[min(value,1023)]++, lines "i stat[i]" for i=1..1023 (:84-98,170-176)
+        std::vector<uint64_t> hist;
+        MF_TRY(mf_table_count_hist(t, hist));
+        uint64_t stat[1024] = {0};
+        for (size_t v = 0; v < hist.size(); v++) stat[v >= 1024 ? 1023 : v] += hist[v];
+        FILE *f = fopen(distribution, "w");
+        if (!f) return mf_set_error("can't write '%s'", distribution);
+        for (int i = 1; i < 1024; i++) fprintf(f, "%d %llu\n", i, (unsigned long long)stat[i]);
+        fclose(f);
+    }
+    mf_seqs *s = nullptr;
+    MF_TRY(mf_build_unitigs_device(ctx, t, freq_threshold, min_len, &s));
+    int rc = mf_seqs_write_fasta(s, seq_fasta);
+    if (n_seq) *n_seq = s->n;
+    mf_seqs_destroy(s);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A11 components files
+// ---------------------------------------------------------------------------------------------
+// ConnectedComponent.saveComponents (src/structures/ConnectedComponent.java:80-93); stat file ComponentsBuilder.java:146-152
+extern "C" int mf_comps_write(const mf_comps *c, const char *components_bin, const char *stat_txt) {
+    if (!c || !components_bin) return mf_set_error("mf_comps_write: NULL argument");
+    FILE *f = fopen(components_bin, "wb");
+    if (!f) return mf_set_error("can't write '%s'", components_bin);
+    uint8_t b[12];
+    be_put(b, c->n, 4); fwrite(b, 1, 4, f);
+    std::vector<uint8_t> buf;
+    for (uint64_t i = 0; i < c->n; i++) {
+        be_put(b, c->sizes[i], 4); be_put(b + 4, (uint64_t)c->weights[i], 8); fwrite(b, 1, 12, f);
+        uint64_t lo = c->offsets[i], hi = c->offsets[i + 1];
+        buf.resize((hi - lo) * 8);
+        for (uint64_t j = lo; j < hi; j++) be_put(&buf[(j - lo) * 8], c->kmers[j], 8);
+        if (hi > lo) fwrite(buf.data(), 1, buf.size(), f);
+    }
+    fclose(f);
+    if (stat_txt) {
+        f = fopen(stat_txt, "w");
+        if (!f) return mf_set_error("can't write '%s'", stat_txt);
+        fprintf(f, "# component.no\tcomponent.size\tcomponent.weight\tusedFreqThreshold\n");
+        for (uint64_t i = 0; i < c->n; i++)
+            fprintf(f, "%llu\t%llu\t%lld\t%d\n", (unsigned long long)(i + 1), (unsigned long long)c->sizes[i], (long long)c->weights[i], c->thr[i]);
+        fclose(f);
+    }
+    return MF_OK;
+}
+// ConnectedComponent.loadComponents (:95-122)
+extern "C" int mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps **out) {
+    if (!ctx || !components_bin || !out) return mf_set_error("mf_comps_load: NULL argument");
+    *out = nullptr;
+    std::vector<char> buf;
+    if (read_whole_file(components_bin, buf) < 0) return mf_set_error("Can't load components: file not found (%s)", components_bin);
+    const uint8_t *p = (const uint8_t *)buf.data();
+    size_t n = buf.size(), pos = 4;
+    if (n < 4) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
+    uint64_t cnt = be_get(p, 4);
+    std::vector<uint64_t> sizes, offsets(1, 0), kmers; std::vector<int64_t> weights; std::vector<int32_t> thr;
+    for (uint64_t i = 0; i < cnt; i++) {
+        if (pos + 12 > n) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
+        uint64_t sz = be_get(p + pos, 4);
+        weights.push_back((int64_t)be_get(p + pos + 4, 8));
+        pos += 12;
+        if (pos + 8 * sz > n) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
+        for (uint64_t j = 0; j < sz; j++) kmers.push_back(be_get(p + pos + 8 * j, 8));
+        pos += 8 * sz;
+        sizes.push_back(sz); thr.push_back(0); offsets.push_back(kmers.size());
+    }
+    MF_HIP(hipSetDevice(ctx->device));
+    return mf_comps_from_host(ctx, 0, sizes, weights, thr, offsets, kmers, out);
+}
+// ComponentCutterMain.runImpl :92-108
+extern "C" int mf_cut_components(mf_ctx *ctx, mf_table *cutter, int k, int b1, int b2, const char *components_bin,
+                                 const char *stat_txt, uint64_t *n_comp) {
+    if (!ctx || !cutter || !components_bin) return mf_set_error("mf_cut_components: NULL argument");
+    if (k != cutter->k) return mf_set_error("mf_cut_components: k=%d but the table was built with k=%d", k, cutter->k);
+    if (cutter->n == 0)                                                          // ComponentCutterMain.java:84-86
+        return mf_set_error("No sequences were found in input files! The following steps will be useless");
+    mf_comps *c = nullptr;
+    MF_TRY(mf_cut_components_device(ctx, cutter, b1, b2, &c));
+    int rc = mf_comps_write(c, components_bin, stat_txt);
+    if (n_comp) *n_comp = c->n;
+    mf_comps_destroy(c);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// A12 feature files
+// ---------------------------------------------------------------------------------------------
+// java.lang.Double.toString: shortest digits that round-trip; plain decimal for 1e-3 <= |d| < 1e7, else d.dddE[-]n
+static std::string java_double(double d) {
+    if (std::isnan(d)) return "NaN";
+    if (std::isinf(d)) return d > 0 ? "Infinity" : "-Infinity";
+    if (d == 0) return std::signbit(d) ? "-0.0" : "0.0";
+    char buf[64];
+    int prec = 1;
+    for (; prec <= 17; prec++) { snprintf(buf, sizeof buf, "%.*e", prec - 1, d); if (strtod(buf, nullptr) == d) break; }
+    std::string s(buf);                       // [-]d.ddde[+-]xx
+    bool neg = s[0] == '-';
+    if (neg) s = s.substr(1);
+    size_t epos = s.find('e');
+    std::string mant = s.substr(0, epos);
+    int ex = atoi(s.c_str() + epos + 1);
+    std::string digits;
+    for (char ch : mant) if (ch != '.') digits.push_back(ch);
+    std::string out;
+    double ad = std::fabs(d);
+    if (ad >= 1e-3 && ad < 1e7) {
+        if (ex >= 0) {
+            std::string ip = digits.substr(0, std::min<size_t>(digits.size(), (size_t)ex + 1));
+            while ((int)ip.size() < ex + 1) ip.push_back('0');
+            std::string fp = digits.size() > (size_t)ex + 1 ? digits.substr(ex + 1) : "0";
+            out = ip + "." + fp;
+        } else out = "0." + std::string((size_t)(-ex - 1), '0') + digits;
+    } else {
+        out = digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : "0") + "E" + std::to_string(ex);
+    }
+    return neg ? "-" + out : out;
+}
+// FeaturesCalculatorMain.runImpl kmers-file branch (:137-162) + buildAndPrintVector output (:217-230)
+extern "C" int mf_features(mf_ctx *ctx, const char *components_bin, const char *kmers_bin, int k, int threshold,
+                           const char *vec_path, const char *breadth_path) {
+    if (!ctx || !components_bin || !kmers_bin) return mf_set_error("mf_features: NULL argument");
+    mf_comps *c = nullptr;
+    MF_TRY(mf_comps_load(ctx, components_bin, &c));
+    if (c->n == 0) { mf_comps_destroy(c); return mf_set_error("No components were found in input files! Can't continue the calculations."); }
+    mf_table *t = nullptr;
+    const char *files[1] = {kmers_bin};
+    // calculatePresenceForKmers streams EVERY record of the file (no threshold on load): freq_threshold = -1 keeps all
+    int rc = mf_table_load_kmers(ctx, files, 1, -1, k, &t);
+    if (rc < 0) { mf_comps_destroy(c); return rc; }
+    std::vector<int64_t> vec(c->n); std::vector<double> br(c->n);
+    rc = mf_features_device(ctx, c, t, threshold, vec.data(), br.data());
+    if (rc == MF_OK && vec_path) {
+        FILE *f = fopen(vec_path, "w");
+        if (!f) rc = mf_set_error("Can't write vector to file %s", vec_path);
+        else { for (int64_t v : vec) fprintf(f, "%lld\n", (long long)v); fclose(f); }
+    }
+    if (rc == MF_OK && breadth_path) {
+        FILE *f = fopen(breadth_path, "w");
+        if (!f) rc = mf_set_error("Can't write vector to file %s", breadth_path);
+        else { for (double v : br) fprintf(f, "%s\n", java_double(v).c_str()); fclose(f); }
+    }
+    mf_table_destroy(t);
+    mf_comps_destroy(c);
+    return rc;
+}

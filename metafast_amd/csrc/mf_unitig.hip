@@ -1,0 +1,397 @@
+// mf_unitig.hip -- unitigs (non-branching paths of the implicit de Bruijn graph) on the GPU.
+//
+// Replaces SequencesFinders.thresholdStrategy (src/algo/SequencesFinders.java:13-31), i.e. one
+// AddSequencesShiftingRightTask per shard (src/algo/AddSequencesShiftingRightTask.java:40-123).  The
+// reference walks every path sequentially (8 hash probes per step); here the walk is replaced by
+//
+//   U1 k_ut_flags   per good k-mer: getRightNucleotide / getLeftNucleotide (HashMapOperations.java:13-47) for the
+//                   canonical orientation (the other orientation follows by symmetry) + the unique neighbours' indices
+//   U2 k_ut_links   per ORIENTED k-mer (node = 2*index + strand): link f->g exists iff R(f) is unique and L(g) is
+//                   unique; a node without an incoming link is a start (task.run :52-69)
+//   U3 k_ut_jump    pointer jumping (Wyllie list ranking) to the path start: start id + distance, O(log len) rounds
+//   U4 k_ut_ends    per path end: length filter and the reference's emission rule canon(start) <= canon(end k-mer)
+//                   where the end k-mer is the one BEYOND the path when the walk stopped on a left branch
+//                   (processSequence :83-107) -- this is what makes a path come out 0, 1 or 2 times
+//   U5 k_ut_emit    every node writes its last base at offset + distance; weights by atomics
+//
+// Isolated cycles have no start node and are never emitted (same as the reference).
+#include "mf_common.h"
+#include <algorithm>
+#include <numeric>
+
+#define UT_NONE 0xFFFFFFFFu
+// info byte: bits 0-2 rcode, bits 3-5 lcode (0..3 = unique nucleotide, 4 = none, 5 = several), bit 6 ror, bit 7 lor
+#define UT_CODE_NONE 4u
+#define UT_CODE_MANY 5u
+// node flags
+#define UT_START 1u
+#define UT_HASOUT 2u
+#define UT_DONE 4u
+
+struct ut_arrays {
+    const uint64_t *gk; const uint16_t *gv; uint64_t n; int k;
+    uint8_t *info; uint32_t *ridx; uint32_t *lidx;
+    unsigned long long *pk;   // per node: low 32 = pointer (node id), high 32 = distance
+    uint8_t *nflags;          // per node
+};
+
+__global__ void k_ut_flags(const mf_slot *__restrict__ slots, uint64_t mask, ut_arrays A) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= A.n) return;
+    const int k = A.k;
+    const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
+    const uint64_t x = A.gk[i];
+    uint32_t rcode = UT_CODE_NONE, lcode = UT_CODE_NONE, ridx = UT_NONE, lidx = UT_NONE, ror = 0, lor = 0;
+#pragma unroll
+    for (uint32_t nuc = 0; nuc < 4; nuc++) {
+        uint64_t y = ((x << 2) | nuc) & kmask;                 // ShortKmer.shiftRight
+        uint64_t ry = mf_revcomp(y, k);
+        uint64_t c = y < ry ? y : ry;
+        uint32_t idx, val;
+        if (mf_index_find(slots, mask, c, &idx, &val)) {
+            if (rcode == UT_CODE_NONE) { rcode = nuc; ridx = idx; ror = (c != y); }
+            else rcode = UT_CODE_MANY;
+        }
+    }
+#pragma unroll
+    for (uint32_t nuc = 0; nuc < 4; nuc++) {
+        uint64_t y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2));   // ShortKmer.shiftLeft
+        uint64_t ry = mf_revcomp(y, k);
+        uint64_t c = y < ry ? y : ry;
+        uint32_t idx, val;
+        if (mf_index_find(slots, mask, c, &idx, &val)) {
+            if (lcode == UT_CODE_NONE) { lcode = nuc; lidx = idx; lor = (c != y); }
+            else lcode = UT_CODE_MANY;
+        }
+    }
+    A.info[i] = (uint8_t)(rcode | (lcode << 3) | (ror << 6) | (lor << 7));
+    A.ridx[i] = ridx;
+    A.lidx[i] = lidx;
+}
+
+// helpers on oriented nodes: node = 2*i + o, o = 1 means reverse complement of the canonical k-mer
+__device__ __forceinline__ bool ut_r_unique(uint8_t info, uint32_t o) { return ((o ? (info >> 3) : info) & 7u) < 4u; }
+__device__ __forceinline__ bool ut_l_unique(uint8_t info, uint32_t o) { return ((o ? info : (info >> 3)) & 7u) < 4u; }
+__device__ __forceinline__ uint32_t ut_right_node(const ut_arrays &A, uint32_t i, uint32_t o, uint8_t info) {
+    // right neighbour of x is (ridx, ror); right neighbour of rc(x) is rc(left neighbour of x) = (lidx, !lor)
+    return o ? (A.lidx[i] * 2u + (((info >> 7) & 1u) ^ 1u)) : (A.ridx[i] * 2u + ((info >> 6) & 1u));
+}
+__device__ __forceinline__ uint32_t ut_left_node(const ut_arrays &A, uint32_t i, uint32_t o, uint8_t info) {
+    return o ? (A.ridx[i] * 2u + (((info >> 6) & 1u) ^ 1u)) : (A.lidx[i] * 2u + ((info >> 7) & 1u));
+}
+
+__global__ void k_ut_links(ut_arrays A) {
+    uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= 2 * A.n) return;
+    uint32_t i = (uint32_t)(f >> 1), o = (uint32_t)(f & 1);
+    uint8_t info = A.info[i];
+    bool has_out = false, has_in = false;
+    uint32_t pred = (uint32_t)f;
+    if (ut_r_unique(info, o)) {
+        uint32_t g = ut_right_node(A, i, o, info);
+        has_out = ut_l_unique(A.info[g >> 1], g & 1u);
+    }
+    if (ut_l_unique(info, o)) {
+        uint32_t h = ut_left_node(A, i, o, info);
+        if (ut_r_unique(A.info[h >> 1], h & 1u)) { has_in = true; pred = h; }
+    }
+    A.pk[f] = (unsigned long long)pred | ((unsigned long long)(has_in ? 1u : 0u) << 32);
+    A.nflags[f] = (uint8_t)((has_in ? 0u : (UT_START | UT_DONE)) | (has_out ? UT_HASOUT : 0u));
+}
+
+// one round of pointer jumping; counts the nodes that reached their start in this round
+__global__ void k_ut_jump(ut_arrays A, unsigned int *__restrict__ newly_done) {
+    uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t fin = 0;
+    if (f < 2 * A.n && !(A.nflags[f] & UT_DONE)) {
+        unsigned long long me = __hip_atomic_load(&A.pk[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t p = (uint32_t)me, d = (uint32_t)(me >> 32);
+        if (A.nflags[p] & UT_START) { A.nflags[f] |= UT_DONE; fin = 1; }
+        else {
+            unsigned long long up = __hip_atomic_load(&A.pk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t pp = (uint32_t)up, dd = (uint32_t)(up >> 32);
+            __hip_atomic_store(&A.pk[f], (unsigned long long)pp | ((unsigned long long)(d + dd) << 32), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            if (A.nflags[pp] & UT_START) { A.nflags[f] |= UT_DONE; fin = 1; }
+        }
+    }
+    unsigned long long b = __ballot(fin);
+    if (mf_lane() == 0 && b) atomicAdd(newly_done, (unsigned int)__popcll(b));
+}
+
+// PASS 0: equal-case arbitration (atomicMin of the start node id per start k-mer), count candidates
+// PASS 1: emit: path id from a cursor, pidmap[start] = pid, plen/pstart/pkey
+struct ut_paths {
+    uint32_t *eqmin;      // [n]
+    uint32_t *pidmap;     // [2n]
+    uint32_t *plen;       // [n_paths] length in nt
+    uint64_t *pkey;       // [n_paths] canonical start k-mer * 2 + strand
+    unsigned int *cursor;
+};
+template <int PASS>
+__global__ void k_ut_ends(ut_arrays A, ut_paths P, int min_len) {
+    uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= 2 * A.n) return;
+    uint8_t nf = A.nflags[f];
+    if (!(nf & UT_DONE) || (nf & UT_HASOUT)) return;       // only path ends whose start is known
+    uint32_t i = (uint32_t)(f >> 1), o = (uint32_t)(f & 1);
+    unsigned long long me = A.pk[f];
+    uint32_t s = (uint32_t)me, dist = (uint32_t)(me >> 32);
+    uint64_t len_nt = (uint64_t)dist + (uint64_t)A.k;
+    if ((int64_t)len_nt < (int64_t)min_len) return;
+    uint8_t info = A.info[i];
+    // end k-mer: the walk stops either because R(f) < 0 (cur = f) or because the k-mer beyond f has
+    // several left neighbours (cur = that k-mer): processSequence :83-92
+    uint64_t endc = A.gk[i];
+    if (ut_r_unique(info, o)) endc = A.gk[ut_right_node(A, i, o, info) >> 1];
+    uint64_t stc = A.gk[s >> 1];
+    if (stc > endc) return;
+    bool eq = stc == endc;
+    if (PASS == 0) {
+        if (eq) atomicMin(&P.eqmin[s >> 1], s);
+        atomicAdd(P.cursor, 1u);
+    } else {
+        if (eq && P.eqmin[s >> 1] != s) return;            // "print any sequence, but only one of them" :109-118
+        uint32_t pid = atomicAdd(P.cursor, 1u);
+        P.pidmap[s] = pid;
+        P.plen[pid] = (uint32_t)len_nt;
+        P.pkey[pid] = stc * 2ull + (uint64_t)(s & 1u);
+    }
+}
+
+struct ut_out {
+    const uint64_t *off;     // [n_paths+1]
+    uint8_t *bases;
+    unsigned long long *wsum; int32_t *wmin; int32_t *wmax;
+};
+__global__ void k_ut_emit(ut_arrays A, const uint32_t *__restrict__ pidmap, ut_out O) {
+    uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= 2 * A.n) return;
+    if (!(A.nflags[f] & UT_DONE)) return;
+    unsigned long long me = A.pk[f];
+    uint32_t s = (uint32_t)me, dist = (uint32_t)(me >> 32);
+    uint32_t pid = pidmap[s];
+    if (pid == UT_NONE) return;
+    const int k = A.k;
+    uint32_t i = (uint32_t)(f >> 1), o = (uint32_t)(f & 1);
+    uint64_t x = A.gk[i];
+    uint64_t y = o ? mf_revcomp(x, k) : x;
+    const uint64_t base = O.off[pid];
+    const char *NUC = "AGCT";
+    O.bases[base + dist + (uint64_t)(k - 1)] = (uint8_t)NUC[y & 3u];
+    if (dist == 0)
+        for (int j = 0; j < k - 1; j++) O.bases[base + j] = (uint8_t)NUC[(y >> (2 * (k - 1 - j))) & 3u];
+    int32_t v = (int32_t)A.gv[i];
+    atomicAdd(&O.wsum[pid], (unsigned long long)v);
+    atomicMin(&O.wmin[pid], v);
+    atomicMax(&O.wmax[pid], v);
+}
+__global__ void k_ut_weights(const unsigned long long *__restrict__ wsum, const uint64_t *__restrict__ off, uint64_t np, int k,
+                             int32_t *__restrict__ avg) {
+    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= np) return;
+    uint64_t len = off[p + 1] - off[p];
+    avg[p] = (int32_t)(wsum[p] / (len - (uint64_t)k + 1));      // (int)(seqWeight / (len - k + 1)) :120-121
+}
+__global__ void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+
+static inline unsigned grid_for(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_threshold, int min_len, mf_seqs **out) {
+    if (!ctx || !t || !out) return mf_set_error("mf_build_unitigs_device: NULL argument");
+    *out = nullptr;
+    MF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int k = t->k;
+
+    // nodes = k-mers with value > freqThreshold (task.run :46-48)
+    mf_table *g = nullptr;
+    MF_TRY(mf_table_filter(t, freq_threshold, &g));
+    struct guard { mf_table *p; ~guard() { mf_table_destroy(p); } } gg{g};
+    const uint64_t n = g->n;
+    mf_seqs *S = new mf_seqs();
+    S->ctx = ctx; S->k = k;
+    if (n == 0) {
+        void *p = nullptr;
+        if (mf_alloc(ctx, 8, &p) < 0) { delete S; return MF_ERR; }
+        S->d_offsets = (uint64_t *)p; S->offsets_bytes = 8;
+        hipMemsetAsync(S->d_offsets, 0, 8, st);
+        *out = S;
+        return MF_OK;
+    }
+    if (n >= 0x7FFFFFFFull) { delete S; return mf_set_error("unitigs: more than 2^31 good k-mers per table is not supported"); }
+    int rc = MF_OK;
+    do {
+        if ((rc = mf_table_ensure_index(g)) < 0) break;
+        mf_buf<uint8_t> info, nflags; mf_buf<uint32_t> ridx, lidx, eqmin, pidmap; mf_buf<unsigned long long> pk;
+        mf_buf<unsigned int> ctr;
+        if ((rc = info.alloc(ctx, n)) < 0 || (rc = ridx.alloc(ctx, n)) < 0 || (rc = lidx.alloc(ctx, n)) < 0 ||
+            (rc = pk.alloc(ctx, 2 * n)) < 0 || (rc = nflags.alloc(ctx, 2 * n)) < 0 || (rc = ctr.alloc(ctx, 4)) < 0) break;
+        ut_arrays A;
+        A.gk = g->d_keys; A.gv = g->d_counts; A.n = n; A.k = k;
+        A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.pk = pk.p; A.nflags = nflags.p;
+        {
+            mf_ktimer tm(ctx, "k_ut_flags");
+            k_ut_flags<<<grid_for(n), 256, 0, st>>>((const mf_slot *)g->index.slots, g->index.cap - 1, A);
+        }
+        {
+            mf_ktimer tm(ctx, "k_ut_links");
+            k_ut_links<<<grid_for(2 * n), 256, 0, st>>>(A);
+        }
+        // U3: rounds until a round finishes no node (then only cycle nodes are left)
+        int rounds = 0;
+        for (;;) {
+            hipMemsetAsync(ctr.p, 0, 4, st);
+            {
+                mf_ktimer tm(ctx, "k_ut_jump");
+                k_ut_jump<<<grid_for(2 * n), 256, 0, st>>>(A, ctr.p);
+            }
+            unsigned int nd = 0;
+            if (hipMemcpyAsync(&nd, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                rc = mf_set_error("unitigs: jump round failed"); break;
+            }
+            rounds++;
+            if (nd == 0) break;
+            if (rounds > 64) { rc = mf_set_error("unitigs: pointer jumping did not converge"); break; }
+        }
+        if (rc < 0) break;
+        // U4
+        if ((rc = eqmin.alloc(ctx, n)) < 0 || (rc = pidmap.alloc(ctx, 2 * n)) < 0) break;
+        k_fill_u32<<<std::min(grid_for(n), 65536u), 256, 0, st>>>(eqmin.p, n, UT_NONE);
+        k_fill_u32<<<std::min(grid_for(2 * n), 65536u), 256, 0, st>>>(pidmap.p, 2 * n, UT_NONE);
+        hipMemsetAsync(ctr.p, 0, 4, st);
+        ut_paths P; P.eqmin = eqmin.p; P.pidmap = pidmap.p; P.plen = nullptr; P.pkey = nullptr; P.cursor = ctr.p;
+        {
+            mf_ktimer tm(ctx, "k_ut_ends");
+            k_ut_ends<0><<<grid_for(2 * n), 256, 0, st>>>(A, P, min_len);
+        }
+        unsigned int ncand = 0;
+        if (hipMemcpyAsync(&ncand, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rc = mf_set_error("unitigs: ends pass failed"); break;
+        }
+        mf_buf<uint32_t> plen; mf_buf<uint64_t> pkey;
+        if ((rc = plen.alloc(ctx, ncand)) < 0 || (rc = pkey.alloc(ctx, ncand)) < 0) break;
+        hipMemsetAsync(ctr.p, 0, 4, st);
+        P.plen = plen.p; P.pkey = pkey.p;
+        {
+            mf_ktimer tm(ctx, "k_ut_ends");
+            k_ut_ends<1><<<grid_for(2 * n), 256, 0, st>>>(A, P, min_len);
+        }
+        unsigned int np = 0;
+        if (hipMemcpyAsync(&np, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rc = mf_set_error("unitigs: ends pass failed"); break;
+        }
+        // U5
+        mf_buf<uint64_t> off, tot; mf_buf<unsigned long long> wsum; mf_buf<int32_t> wmin, wmax, wavg;
+        if ((rc = off.alloc(ctx, (size_t)np + 1)) < 0 || (rc = tot.alloc(ctx, 1)) < 0 || (rc = wsum.alloc(ctx, np)) < 0 ||
+            (rc = wmin.alloc(ctx, np)) < 0 || (rc = wmax.alloc(ctx, np)) < 0 || (rc = wavg.alloc(ctx, np)) < 0) break;
+        k_scan<false><<<1, 1024, 0, st>>>(plen.p, off.p, (uint64_t)np, tot.p);
+        uint64_t total = 0;
+        if (hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rc = mf_set_error("unitigs: scan failed"); break;
+        }
+        mf_buf<uint8_t> bases;
+        if ((rc = bases.alloc(ctx, total + 64)) < 0) break;     // slack for the counting kernels' 16-byte loads
+        if (np) {
+            hipMemsetAsync(wsum.p, 0, (size_t)np * 8, st);
+            k_fill_u32<<<std::min(grid_for(np), 65536u), 256, 0, st>>>((uint32_t *)wmin.p, np, 0x7FFFFFFFu);
+            hipMemsetAsync(wmax.p, 0, (size_t)np * 4, st);
+            ut_out O; O.off = off.p; O.bases = bases.p; O.wsum = wsum.p; O.wmin = wmin.p; O.wmax = wmax.p;
+            {
+                mf_ktimer tm(ctx, "k_ut_emit");
+                k_ut_emit<<<grid_for(2 * n), 256, 0, st>>>(A, pidmap.p, O);
+            }
+            k_ut_weights<<<grid_for(np), 256, 0, st>>>(wsum.p, off.p, np, k, wavg.p);
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = mf_set_error("unitigs: emit failed: %s", hipGetErrorString(hipGetLastError())); break; }
+        if (ctx->opt_verbose)
+            fprintf(stderr, "[mf] unitigs: good=%llu rounds=%d candidates=%u paths=%u bases=%llu\n", (unsigned long long)n, rounds,
+                    ncand, np, (unsigned long long)total);
+        S->n = np; S->n_bases = total;
+        S->bases_bytes = bases.bytes(); S->d_bases = bases.take();
+        S->offsets_bytes = off.bytes(); S->d_offsets = off.take();
+        S->w_bytes = wavg.bytes();
+        S->d_avg = wavg.take(); S->d_min = wmin.take(); S->d_max = wmax.take();
+        S->sk_bytes = pkey.bytes(); S->d_startkey = pkey.take();
+    } while (0);
+    if (rc < 0) { delete S; return rc; }
+    *out = S;
+    return MF_OK;
+}
+
+extern "C" void mf_seqs_destroy(mf_seqs *s) {
+    if (!s) return;
+    if (s->d_bases) mf_release(s->ctx, s->d_bases, s->bases_bytes);
+    if (s->d_offsets) mf_release(s->ctx, s->d_offsets, s->offsets_bytes);
+    if (s->d_avg) mf_release(s->ctx, s->d_avg, s->w_bytes);
+    if (s->d_min) mf_release(s->ctx, s->d_min, s->w_bytes);
+    if (s->d_max) mf_release(s->ctx, s->d_max, s->w_bytes);
+    if (s->d_startkey) mf_release(s->ctx, s->d_startkey, s->sk_bytes);
+    delete s;
+}
+extern "C" int mf_seqs_stats(const mf_seqs *s, uint64_t *n_seqs, uint64_t *total_len) {
+    if (!s) return mf_set_error("seqs is NULL");
+    if (n_seqs) *n_seqs = s->n;
+    if (total_len) *total_len = s->n_bases;
+    return MF_OK;
+}
+extern "C" int mf_seqs_device_view(const mf_seqs *s, const void **d_bases, const void **d_offsets, const void **d_avg,
+                                   const void **d_min, const void **d_max, uint64_t *n_seqs, uint64_t *n_bases) {
+    if (!s) return mf_set_error("seqs is NULL");
+    if (d_bases) *d_bases = s->d_bases;
+    if (d_offsets) *d_offsets = s->d_offsets;
+    if (d_avg) *d_avg = s->d_avg;
+    if (d_min) *d_min = s->d_min;
+    if (d_max) *d_max = s->d_max;
+    if (n_seqs) *n_seqs = s->n;
+    if (n_bases) *n_bases = s->n_bases;
+    return MF_OK;
+}
+
+// host copy in deterministic order (canonical start k-mer, strand)
+int mf_seqs_to_host(const mf_seqs *s, std::vector<uint8_t> &bases, std::vector<uint64_t> &off, std::vector<int32_t> &avg,
+                    std::vector<int32_t> &mn, std::vector<int32_t> &mx) {
+    mf_ctx *ctx = s->ctx;
+    MF_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = s->n;
+    std::vector<uint8_t> hb(s->n_bases); std::vector<uint64_t> ho(n + 1, 0), hkey(n);
+    std::vector<int32_t> ha(n), hmn(n), hmx(n);
+    if (n) {
+        MF_HIP(hipMemcpyAsync(hb.data(), s->d_bases, s->n_bases, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipMemcpyAsync(ho.data(), s->d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipMemcpyAsync(hkey.data(), s->d_startkey, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipMemcpyAsync(ha.data(), s->d_avg, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipMemcpyAsync(hmn.data(), s->d_min, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipMemcpyAsync(hmx.data(), s->d_max, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    std::vector<uint64_t> order(n);
+    std::iota(order.begin(), order.end(), 0);
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return hkey[a] < hkey[b]; });
+    bases.resize(s->n_bases); off.assign(n + 1, 0); avg.resize(n); mn.resize(n); mx.resize(n);
+    uint64_t pos = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t j = order[i], len = ho[j + 1] - ho[j];
+        off[i] = pos;
+        memcpy(bases.data() + pos, hb.data() + ho[j], len);
+        pos += len;
+        avg[i] = ha[j]; mn[i] = hmn[j]; mx[i] = hmx[j];
+    }
+    off[n] = pos;
+    return MF_OK;
+}
+extern "C" int mf_seqs_export(const mf_seqs *s, uint8_t *bases, uint64_t *offsets, int32_t *avg, int32_t *mn, int32_t *mx) {
+    if (!s || !offsets) return mf_set_error("mf_seqs_export: NULL argument");
+    std::vector<uint8_t> b; std::vector<uint64_t> o; std::vector<int32_t> a, lo, hi;
+    MF_TRY(mf_seqs_to_host(s, b, o, a, lo, hi));
+    if (bases && !b.empty()) memcpy(bases, b.data(), b.size());
+    memcpy(offsets, o.data(), o.size() * 8);
+    if (avg && s->n) memcpy(avg, a.data(), s->n * 4);
+    if (mn && s->n) memcpy(mn, lo.data(), s->n * 4);
+    if (mx && s->n) memcpy(mx, hi.data(), s->n * 4);
+    return MF_OK;
+}

@@ -114,12 +114,15 @@ class Context:
             self.set_stream(stream)
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().mf_ctx_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mf_ctx_destroy(self.h)
+        self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def set_stream(self, stream):
         """stream: a raw hipStream_t (int), or a torch.cuda.Stream"""
@@ -223,12 +226,15 @@ class Table:
         self.ctx, self.h = ctx, h
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().mf_table_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None and getattr(self.ctx, "h", None):
+            _lib.mf_table_destroy(self.h)
+        self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def stats(self):
         a, b = C.c_uint64(), C.c_uint64()
@@ -283,12 +289,15 @@ class Seqs:
         self.ctx, self.h = ctx, h
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().mf_seqs_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None and getattr(self.ctx, "h", None):
+            _lib.mf_seqs_destroy(self.h)
+        self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def stats(self):
         a, b = C.c_uint64(), C.c_uint64()
@@ -327,12 +336,15 @@ class Comps:
         self.ctx, self.h = ctx, h
 
     def close(self):
-        if getattr(self, "h", None):
-            lib().mf_comps_destroy(self.h)
-            self.h = None
+        if getattr(self, "h", None) and _lib is not None and getattr(self.ctx, "h", None):
+            _lib.mf_comps_destroy(self.h)
+        self.h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def stats(self):
         a, b = C.c_uint64(), C.c_uint64()

@@ -1,0 +1,197 @@
+"""GPU parity for unitigs, component cutter, features and the distance matrix (through the C-ABI) vs the CPU oracle,
+including the reference's golden matrix on its own test_data."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import REF_DATA
+from util import canon_seq, genome_reads, gpu_count, pack_reads
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_good(oracle, bases, off, k, b):
+    t = oracle.Table().count_buffer(bases, off, k)
+    keys, vals = t.export(b)
+    g = oracle.Table()
+    for kk, vv in zip(keys.tolist(), vals.tolist()):
+        g.add(kk, vv)
+    return g
+
+
+def _norm_seqs(seqs):
+    return sorted((canon_seq(s), a, mn, mx) for s, a, mn, mx in seqs)
+
+
+def _check_unitigs(ctx, oracle, bases, off, k, b, l):
+    t = gpu_count(ctx, bases, off, k)
+    gs = ctx.build_unitigs(t, b, l)
+    got = gs.export()
+    want = oracle.build_unitigs(_oracle_good(oracle, bases, off, k, b), k, b, l).all()
+    assert len(got) == len(want), (len(got), len(want))
+    assert _norm_seqs(got) == _norm_seqs(want)
+    n, total = gs.stats()
+    assert n == len(want) and total == sum(len(s[0]) for s in want)
+    return gs, got
+
+
+def test_unitigs_reference_data(gpu_ctx, oracle, ref_files):
+    for f, (ns, nt) in zip(ref_files, [(15, 17322), (29, 7910), (25, 11123)]):
+        b, o = oracle.read_file(f)
+        gs, got = _check_unitigs(gpu_ctx, oracle, b, o, 31, 1, 100)
+        assert (len(got), sum(len(s[0]) for s in got)) == (ns, nt)
+
+
+def _branchy_reads(seed):
+    """genome with two extra copies of a 400-bp repeat + substitution errors: gives branches, tips and bubbles,
+    i.e. paths that the reference's emission rule prints 0, 1 or 2 times"""
+    rng = np.random.default_rng(seed)
+    al = np.frombuffer(b"ACGT", dtype=np.uint8)
+    g = al[rng.integers(0, 4, size=60000)]
+    rep = g[1000:1400].copy()
+    g = np.concatenate([g[:30000], rep, g[30000:45000], rep, g[45000:]])
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    n, rl = 12000, 150
+    starts = rng.integers(0, len(g) - rl + 1, size=n)
+    out = np.empty((n, rl), dtype=np.uint8)
+    for i, s in enumerate(starts):
+        r = g[s:s + rl]
+        out[i] = comp[r[::-1]] if rng.integers(0, 2) else r
+    m = rng.random(out.shape) < 0.004
+    out[m] = al[rng.integers(0, 4, size=int(m.sum()))]
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(rl)
+    return out.reshape(-1).copy(), off
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_unitigs_branchy_emission_rule(gpu_ctx, oracle, seed):
+    b, o = _branchy_reads(seed)
+    gs, got = _check_unitigs(gpu_ctx, oracle, b, o, 31, 1, 100)
+    # the quirk must actually be exercised: some unitig comes out in both orientations
+    cs = [canon_seq(s[0]) for s in got]
+    assert len(cs) > len(set(cs)) or seed != 7
+
+
+@pytest.mark.parametrize("k,b,l", [(5, 0, 5), (11, 0, 20), (16, 1, 40), (21, 2, 30), (31, 0, 31)])
+def test_unitigs_small_k_and_thresholds(gpu_ctx, oracle, k, b, l):
+    rng = np.random.default_rng(50 + k)
+    bs, o = genome_reads(rng, 3000 if k > 8 else 300, 1500, 80, err=0.01)
+    _check_unitigs(gpu_ctx, oracle, bs, o, k, b, l)
+
+
+def test_unitigs_cycles_and_homopolymers(gpu_ctx, oracle):
+    # an isolated cycle (never emitted), poly-A (self loop) and a palindrome-rich even-k case
+    cyc = "ACGTTGCATGCCGATAGGCTTAACCGGATATCCGGTTAAGC"
+    reads = [cyc * 3, "A" * 80, "ACGT" * 30, "AATT" * 30]
+    b, o = pack_reads(reads)
+    for k in (7, 8, 12):
+        _check_unitigs(gpu_ctx, oracle, b, o, k, 0, k)
+
+
+def _check_components(ctx, oracle, cutter_gpu, cutter_or, k, b1, b2):
+    gc = ctx.cut_components(cutter_gpu, b1, b2)
+    oc = oracle.cut_components(cutter_or, k, b1, b2)
+    got, want = gc.export(), oc.all()
+    assert [(a, b, c) for a, b, c, _ in got] == [(a, b, c) for a, b, c, _ in want]
+    for (_, _, _, gk), (_, _, _, ok) in zip(got, want):
+        assert np.array_equal(gk, ok)
+    return gc, oc
+
+
+def _pipeline(ctx, oracle, inputs, k, b, l, b1, b2):
+    """inputs: list of (bases, offsets); mirrors DistanceMatrixBuilderMain's step wiring on the device"""
+    import torch
+    tables, goods, seqs, o_goods, o_seqs = [], [], [], [], []
+    for bases, off in inputs:
+        t = gpu_count(ctx, bases, off, k)
+        tables.append(t)
+        goods.append(t.filter(b))
+        seqs.append(ctx.build_unitigs(t, b, l))
+        og = _oracle_good(oracle, bases, off, k, b)
+        o_goods.append(og)
+        o_seqs.append(oracle.build_unitigs(og, k, b, l))
+    # cutter table: k-mers of all samples' unitigs (ComponentCutterMain.java:81)
+    views = [s.device_view() for s in seqs]
+    nb = sum(v["n_bases"] for v in views)
+    ns = sum(v["n"] for v in views)
+    allb = torch.zeros(nb + 64, dtype=torch.uint8, device="cuda")
+    allo = torch.zeros(ns + 1, dtype=torch.int64, device="cuda")
+    pb = po = 0
+    for v in views:
+        if v["n"] == 0:
+            continue
+        tb = torch.empty(0)  # noqa: F841
+        import ctypes
+        # copy through torch by wrapping the device pointers
+        src_b = _wrap(v["bases"], v["n_bases"], torch.uint8)
+        src_o = _wrap(v["offsets"], (v["n"] + 1) * 8, torch.uint8).view(torch.int64)
+        allb[pb:pb + v["n_bases"]] = src_b
+        allo[po:po + v["n"]] = src_o[:-1] + pb
+        pb += v["n_bases"]
+        po += v["n"]
+    allo[ns] = nb
+    ctx.synchronize()
+    cutter = ctx.count_device(allb.data_ptr(), allo.data_ptr(), ns, nb, k, l)
+    o_cutter = oracle.Table()
+    for s in o_seqs:
+        o_cutter.count_seqs(s, k, l)
+    ck, cc = cutter.export()
+    ok, ov = o_cutter.export()
+    assert np.array_equal(ck, ok) and np.array_equal(cc.astype(np.int32), ov)
+    gc, oc = _check_components(ctx, oracle, cutter, o_cutter, k, b1, b2)
+    vecs, ovecs = [], []
+    for g, og in zip(goods, o_goods):
+        v, br = ctx.features(gc, g, 0)
+        wv, wbr = oc.features(og, 0)
+        assert np.array_equal(v, wv)
+        assert np.array_equal(br, wbr)
+        vecs.append(v)
+        ovecs.append(wv)
+    return np.array(vecs).reshape(len(inputs), -1), gc
+
+
+def _wrap(ptr, nbytes, dtype):
+    """torch view of a device buffer owned by the library (for tests only)"""
+    import torch
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 3}
+    return torch.as_tensor(h, device="cuda")
+
+
+def test_golden_matrix_on_gpu(gpu_ctx, oracle, ref_files):
+    """the reference's golden vector: test_data/meta_test_matrix.txt (k=31 b=1 l=100 b1=1000 b2=10000)"""
+    from metafast_amd import lib as L
+    inputs = [oracle.read_file(f) for f in ref_files]
+    vecs, gc = _pipeline(gpu_ctx, oracle, inputs, 31, 1, 100, 1000, 10000)
+    assert vecs.tolist() == [[41935, 38354, 20375, 14211], [20208, 0, 0, 11337], [6517, 34484, 20359, 749]]
+    m = L.bray_curtis(vecs)
+    assert m[0, 1] == 0.5691162409506898 and m[0, 2] == 0.2981399448537721 and m[1, 2] == 0.8448331091037222
+    assert abs(m - oracle.bray_curtis(vecs)).max() <= 1e-6     # north_star tolerance (expected exact)
+
+
+def test_threshold_split_on_gpu(gpu_ctx, oracle, ref_files):
+    """b1=50 b2=500 forces oversize components to be re-split at threshold 2 (ComponentsBuilder.java:157-180)"""
+    from metafast_amd import lib as L
+    inputs = [oracle.read_file(f) for f in ref_files]
+    vecs, gc = _pipeline(gpu_ctx, oracle, inputs, 31, 1, 100, 50, 500)
+    comps = gc.export()
+    assert len(comps) == 37 and [(a, b, c) for a, b, c, _ in comps[:3]] == [(448, 1076, 2), (456, 1066, 2), (426, 939, 2)]
+    m = L.bray_curtis(vecs)
+    assert m[0, 1] == 0.40246783273019704
+
+
+def test_pipeline_synthetic_samples(gpu_ctx, oracle):
+    """three synthetic samples from the bench generator (shared genomes -> cross-sample components)"""
+    from metafast_amd import lib as L
+    inputs = [L.synth_reads_host(0x4D45544146415354, s, 0, 30000, 150, 3000) for s in range(3)]
+    vecs, gc = _pipeline(gpu_ctx, oracle, inputs, 31, 1, 100, 100, 5000)
+    assert len(gc) > 0
+    m = L.bray_curtis(vecs)
+    assert abs(m - oracle.bray_curtis(vecs)).max() <= 1e-6
