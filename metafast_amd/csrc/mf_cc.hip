@@ -77,12 +77,16 @@ __global__ void k_cc_hook(const uint32_t *__restrict__ nbr, const uint8_t *__res
         }
     }
 }
-__global__ void k_cc_flatten_stats(const uint8_t *__restrict__ alive, uint32_t *parent, const uint16_t *__restrict__ vals,
+// The forest is final after k_cc_hook.  root[] is a SEPARATE array and the find below does not write: storing the
+// root into parent[] here would race with other threads' path-halving stores (which may put back a non-root ancestor).
+__global__ void k_cc_flatten_stats(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ parent,
+                                   uint32_t *__restrict__ root, const uint16_t *__restrict__ vals,
                                    uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight, uint64_t n) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n || !alive[v]) return;
-    uint32_t r = cc_find(parent, (uint32_t)v);
-    parent[v] = r;
+    uint32_t r = (uint32_t)v;
+    for (;;) { uint32_t p = parent[r]; if (p == r) break; r = p; }
+    root[v] = r;
     atomicAdd(&csize[r], 1u);
     atomicAdd(&cweight[r], (unsigned long long)vals[v]);
 }
@@ -197,9 +201,9 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
     std::vector<host_comp> hc;
     if (n) {
         MF_TRY(mf_table_ensure_index(t));
-        mf_buf<uint32_t> nbr, parent, csize, keptslot, slot_fill; mf_buf<unsigned long long> cweight; mf_buf<uint8_t> alive;
+        mf_buf<uint32_t> nbr, parent, root, csize, keptslot, slot_fill; mf_buf<unsigned long long> cweight; mf_buf<uint8_t> alive;
         mf_buf<unsigned int> counters; mf_buf<cc_kept> kept;
-        MF_TRY(nbr.alloc(ctx, n * 8)); MF_TRY(parent.alloc(ctx, n)); MF_TRY(csize.alloc(ctx, n)); MF_TRY(keptslot.alloc(ctx, n));
+        MF_TRY(nbr.alloc(ctx, n * 8)); MF_TRY(parent.alloc(ctx, n)); MF_TRY(root.alloc(ctx, n)); MF_TRY(csize.alloc(ctx, n)); MF_TRY(keptslot.alloc(ctx, n));
         MF_TRY(cweight.alloc(ctx, n)); MF_TRY(alive.alloc(ctx, n)); MF_TRY(counters.alloc(ctx, 4));
         {
             mf_ktimer tm(ctx, "k_cc_adjacency");
@@ -215,12 +219,12 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             }
             {
                 mf_ktimer tm(ctx, "k_cc_stats");
-                k_cc_flatten_stats<<<cgrid(n), 256, 0, st>>>(alive.p, parent.p, t->d_counts, csize.p, cweight.p, n);
+                k_cc_flatten_stats<<<cgrid(n), 256, 0, st>>>(alive.p, parent.p, root.p, t->d_counts, csize.p, cweight.p, n);
             }
             // number of kept components is bounded by n / max(b1,1); size the list by a first counting pass
             unsigned int cnt[4];
             MF_TRY(kept.alloc(ctx, n / (uint64_t)std::max(b1, 1) + 1));
-            k_cc_classify<<<cgrid(n), 256, 0, st>>>(alive.p, parent.p, csize.p, cweight.p, n, (uint32_t)b1, (uint32_t)b2, keptslot.p,
+            k_cc_classify<<<cgrid(n), 256, 0, st>>>(alive.p, root.p, csize.p, cweight.p, n, (uint32_t)b1, (uint32_t)b2, keptslot.p,
                                                     kept.p, counters.p);
             MF_HIP(hipMemcpyAsync(cnt, counters.p, 16, hipMemcpyDeviceToHost, st));
             MF_HIP(hipStreamSynchronize(st));
@@ -238,7 +242,7 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             MF_HIP(hipMemsetAsync(slot_fill.p, 0, slot_fill.bytes(), st));
             {
                 mf_ktimer tm(ctx, "k_cc_members");
-                k_cc_members<<<cgrid(n), 256, 0, st>>>(alive.p, parent.p, csize.p, t->d_counts, t->d_keys, n, (uint32_t)b1, (uint32_t)b2,
+                k_cc_members<<<cgrid(n), 256, 0, st>>>(alive.p, root.p, csize.p, t->d_counts, t->d_keys, n, (uint32_t)b1, (uint32_t)b2,
                                                        (uint32_t)(thr + 1), keptslot.p, d_soff.p, slot_fill.p, members.p);
             }
             std::vector<uint64_t> hm(nkm);

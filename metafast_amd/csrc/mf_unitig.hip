@@ -31,6 +31,7 @@
 struct ut_arrays {
     const uint64_t *gk; const uint16_t *gv; uint64_t n; int k;
     uint8_t *info; uint32_t *ridx; uint32_t *lidx;
+    uint8_t *pal;             // even k only: 1 if the k-mer equals its reverse complement (else nullptr)
     unsigned long long *pk;   // per node: low 32 = pointer (node id), high 32 = distance
     uint8_t *nflags;          // per node
 };
@@ -65,6 +66,7 @@ __global__ void k_ut_flags(const mf_slot *__restrict__ slots, uint64_t mask, ut_
         }
     }
     A.info[i] = (uint8_t)(rcode | (lcode << 3) | (ror << 6) | (lor << 7));
+    if (A.pal) A.pal[i] = (uint8_t)(mf_revcomp(x, k) == x);
     A.ridx[i] = ridx;
     A.lidx[i] = lidx;
 }
@@ -72,12 +74,17 @@ __global__ void k_ut_flags(const mf_slot *__restrict__ slots, uint64_t mask, ut_
 // helpers on oriented nodes: node = 2*i + o, o = 1 means reverse complement of the canonical k-mer
 __device__ __forceinline__ bool ut_r_unique(uint8_t info, uint32_t o) { return ((o ? (info >> 3) : info) & 7u) < 4u; }
 __device__ __forceinline__ bool ut_l_unique(uint8_t info, uint32_t o) { return ((o ? info : (info >> 3)) & 7u) < 4u; }
+// A palindromic k-mer (even k) is ONE oriented k-mer: only its strand-0 node exists, every reference to it uses strand 0.
+__device__ __forceinline__ uint32_t ut_node(const ut_arrays &A, uint32_t idx, uint32_t strand) {
+    if (A.pal && A.pal[idx]) strand = 0;
+    return idx * 2u + strand;
+}
 __device__ __forceinline__ uint32_t ut_right_node(const ut_arrays &A, uint32_t i, uint32_t o, uint8_t info) {
     // right neighbour of x is (ridx, ror); right neighbour of rc(x) is rc(left neighbour of x) = (lidx, !lor)
-    return o ? (A.lidx[i] * 2u + (((info >> 7) & 1u) ^ 1u)) : (A.ridx[i] * 2u + ((info >> 6) & 1u));
+    return o ? ut_node(A, A.lidx[i], ((info >> 7) & 1u) ^ 1u) : ut_node(A, A.ridx[i], (info >> 6) & 1u);
 }
 __device__ __forceinline__ uint32_t ut_left_node(const ut_arrays &A, uint32_t i, uint32_t o, uint8_t info) {
-    return o ? (A.ridx[i] * 2u + (((info >> 6) & 1u) ^ 1u)) : (A.lidx[i] * 2u + ((info >> 7) & 1u));
+    return o ? ut_node(A, A.ridx[i], ((info >> 6) & 1u) ^ 1u) : ut_node(A, A.lidx[i], (info >> 7) & 1u);
 }
 
 __global__ void k_ut_links(ut_arrays A) {
@@ -85,6 +92,11 @@ __global__ void k_ut_links(ut_arrays A) {
     if (f >= 2 * A.n) return;
     uint32_t i = (uint32_t)(f >> 1), o = (uint32_t)(f & 1);
     uint8_t info = A.info[i];
+    if (o == 1 && A.pal && A.pal[i]) {            // not a node of its own (see ut_node): never start, never done
+        A.pk[f] = (unsigned long long)f | (1ull << 32);
+        A.nflags[f] = 0;
+        return;
+    }
     bool has_out = false, has_in = false;
     uint32_t pred = (uint32_t)f;
     if (ut_r_unique(info, o)) {
@@ -126,6 +138,7 @@ struct ut_paths {
     uint32_t *pidmap;     // [2n]
     uint32_t *plen;       // [n_paths] length in nt
     uint64_t *pkey;       // [n_paths] canonical start k-mer * 2 + strand
+    uint32_t *dup;        // [n_paths] second copy of the path (palindromic start k-mer) or UT_NONE
     unsigned int *cursor;
 };
 template <int PASS>
@@ -147,15 +160,20 @@ __global__ void k_ut_ends(ut_arrays A, ut_paths P, int min_len) {
     uint64_t stc = A.gk[s >> 1];
     if (stc > endc) return;
     bool eq = stc == endc;
+    // task.run :50-51 processes {kmerF, kmerF.rc()}: for a palindromic start k-mer these are the same oriented k-mer, so
+    // the reference walks the identical path twice and prints it twice unless the equal-case `used` set stops the second
+    bool twice = A.pal && A.pal[s >> 1] && !eq;
     if (PASS == 0) {
         if (eq) atomicMin(&P.eqmin[s >> 1], s);
-        atomicAdd(P.cursor, 1u);
+        atomicAdd(P.cursor, twice ? 2u : 1u);
     } else {
         if (eq && P.eqmin[s >> 1] != s) return;            // "print any sequence, but only one of them" :109-118
-        uint32_t pid = atomicAdd(P.cursor, 1u);
+        uint32_t pid = atomicAdd(P.cursor, twice ? 2u : 1u);
         P.pidmap[s] = pid;
         P.plen[pid] = (uint32_t)len_nt;
         P.pkey[pid] = stc * 2ull + (uint64_t)(s & 1u);
+        P.dup[pid] = twice ? pid + 1 : UT_NONE;
+        if (twice) { P.plen[pid + 1] = (uint32_t)len_nt; P.pkey[pid + 1] = stc * 2ull + 1ull; P.dup[pid + 1] = UT_NONE; }
     }
 }
 
@@ -164,7 +182,7 @@ struct ut_out {
     uint8_t *bases;
     unsigned long long *wsum; int32_t *wmin; int32_t *wmax;
 };
-__global__ void k_ut_emit(ut_arrays A, const uint32_t *__restrict__ pidmap, ut_out O) {
+__global__ void k_ut_emit(ut_arrays A, const uint32_t *__restrict__ pidmap, const uint32_t *__restrict__ dup, ut_out O) {
     uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= 2 * A.n) return;
     if (!(A.nflags[f] & UT_DONE)) return;
@@ -176,15 +194,18 @@ __global__ void k_ut_emit(ut_arrays A, const uint32_t *__restrict__ pidmap, ut_o
     uint32_t i = (uint32_t)(f >> 1), o = (uint32_t)(f & 1);
     uint64_t x = A.gk[i];
     uint64_t y = o ? mf_revcomp(x, k) : x;
-    const uint64_t base = O.off[pid];
     const char *NUC = "AGCT";
-    O.bases[base + dist + (uint64_t)(k - 1)] = (uint8_t)NUC[y & 3u];
-    if (dist == 0)
-        for (int j = 0; j < k - 1; j++) O.bases[base + j] = (uint8_t)NUC[(y >> (2 * (k - 1 - j))) & 3u];
     int32_t v = (int32_t)A.gv[i];
-    atomicAdd(&O.wsum[pid], (unsigned long long)v);
-    atomicMin(&O.wmin[pid], v);
-    atomicMax(&O.wmax[pid], v);
+    for (int copy = 0; copy < 2 && pid != UT_NONE; copy++) {
+        const uint64_t base = O.off[pid];
+        O.bases[base + dist + (uint64_t)(k - 1)] = (uint8_t)NUC[y & 3u];
+        if (dist == 0)
+            for (int j = 0; j < k - 1; j++) O.bases[base + j] = (uint8_t)NUC[(y >> (2 * (k - 1 - j))) & 3u];
+        atomicAdd(&O.wsum[pid], (unsigned long long)v);
+        atomicMin(&O.wmin[pid], v);
+        atomicMax(&O.wmax[pid], v);
+        pid = dup[pid];
+    }
 }
 __global__ void k_ut_weights(const unsigned long long *__restrict__ wsum, const uint64_t *__restrict__ off, uint64_t np, int k,
                              int32_t *__restrict__ avg) {
@@ -227,13 +248,15 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
     int rc = MF_OK;
     do {
         if ((rc = mf_table_ensure_index(g)) < 0) break;
-        mf_buf<uint8_t> info, nflags; mf_buf<uint32_t> ridx, lidx, eqmin, pidmap; mf_buf<unsigned long long> pk;
+        mf_buf<uint8_t> info, nflags, pal; mf_buf<uint32_t> ridx, lidx, eqmin, pidmap; mf_buf<unsigned long long> pk;
         mf_buf<unsigned int> ctr;
         if ((rc = info.alloc(ctx, n)) < 0 || (rc = ridx.alloc(ctx, n)) < 0 || (rc = lidx.alloc(ctx, n)) < 0 ||
             (rc = pk.alloc(ctx, 2 * n)) < 0 || (rc = nflags.alloc(ctx, 2 * n)) < 0 || (rc = ctr.alloc(ctx, 4)) < 0) break;
         ut_arrays A;
         A.gk = g->d_keys; A.gv = g->d_counts; A.n = n; A.k = k;
         A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.pk = pk.p; A.nflags = nflags.p;
+        A.pal = nullptr;
+        if ((k & 1) == 0) { if ((rc = pal.alloc(ctx, n)) < 0) break; A.pal = pal.p; }   // palindromes need an even k
         {
             mf_ktimer tm(ctx, "k_ut_flags");
             k_ut_flags<<<grid_for(n), 256, 0, st>>>((const mf_slot *)g->index.slots, g->index.cap - 1, A);
@@ -264,7 +287,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         k_fill_u32<<<std::min(grid_for(n), 65536u), 256, 0, st>>>(eqmin.p, n, UT_NONE);
         k_fill_u32<<<std::min(grid_for(2 * n), 65536u), 256, 0, st>>>(pidmap.p, 2 * n, UT_NONE);
         hipMemsetAsync(ctr.p, 0, 4, st);
-        ut_paths P; P.eqmin = eqmin.p; P.pidmap = pidmap.p; P.plen = nullptr; P.pkey = nullptr; P.cursor = ctr.p;
+        ut_paths P; P.eqmin = eqmin.p; P.pidmap = pidmap.p; P.plen = nullptr; P.pkey = nullptr; P.dup = nullptr; P.cursor = ctr.p;
         {
             mf_ktimer tm(ctx, "k_ut_ends");
             k_ut_ends<0><<<grid_for(2 * n), 256, 0, st>>>(A, P, min_len);
@@ -273,10 +296,10 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if (hipMemcpyAsync(&ncand, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = mf_set_error("unitigs: ends pass failed"); break;
         }
-        mf_buf<uint32_t> plen; mf_buf<uint64_t> pkey;
-        if ((rc = plen.alloc(ctx, ncand)) < 0 || (rc = pkey.alloc(ctx, ncand)) < 0) break;
+        mf_buf<uint32_t> plen, dup; mf_buf<uint64_t> pkey;
+        if ((rc = plen.alloc(ctx, ncand)) < 0 || (rc = pkey.alloc(ctx, ncand)) < 0 || (rc = dup.alloc(ctx, ncand)) < 0) break;
         hipMemsetAsync(ctr.p, 0, 4, st);
-        P.plen = plen.p; P.pkey = pkey.p;
+        P.plen = plen.p; P.pkey = pkey.p; P.dup = dup.p;
         {
             mf_ktimer tm(ctx, "k_ut_ends");
             k_ut_ends<1><<<grid_for(2 * n), 256, 0, st>>>(A, P, min_len);
@@ -303,7 +326,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
             ut_out O; O.off = off.p; O.bases = bases.p; O.wsum = wsum.p; O.wmin = wmin.p; O.wmax = wmax.p;
             {
                 mf_ktimer tm(ctx, "k_ut_emit");
-                k_ut_emit<<<grid_for(2 * n), 256, 0, st>>>(A, pidmap.p, O);
+                k_ut_emit<<<grid_for(2 * n), 256, 0, st>>>(A, pidmap.p, dup.p, O);
             }
             k_ut_weights<<<grid_for(np), 256, 0, st>>>(wsum.p, off.p, np, k, wavg.p);
         }

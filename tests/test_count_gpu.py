@@ -71,7 +71,7 @@ def test_empty_inputs(gpu_ctx, oracle):
     assert len(t) == 0
 
 
-@pytest.mark.parametrize("l1,l2,staged,blocks", [(0, 0, 1, 0), (3, 0, 1, 0), (3, 4, 1, 2), (5, 5, 0, 3), (11, 0, 1, 0),
+@pytest.mark.parametrize("l1,l2,staged,blocks", [(0, -1, 1, 0), (3, -1, 1, 0), (3, 4, 1, 2), (5, 5, 0, 3), (11, -1, 1, 0),
                                                  (6, 6, 1, 0), (2, 11, 1, 5)])
 def test_partition_plans(gpu_ctx, oracle, l1, l2, staged, blocks):
     """every partition plan / scatter flavour must give the same table"""
