@@ -78,6 +78,7 @@ def main():
     n_bases = n_reads * rl
     bases = torch.zeros(n_bases + 64, dtype=torch.uint8, device=device)
     offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
+    torch.cuda.synchronize()
     ctx.synth_reads_device(SEED, rank, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr())
     torch.cuda.synchronize()
 

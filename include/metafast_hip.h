@@ -51,7 +51,8 @@ const char *mf_version(void);
  * side parsers; GPU parallelism is fixed by the device. */
 int  mf_ctx_create(int device, int host_threads, mf_ctx **out);
 void mf_ctx_destroy(mf_ctx *ctx);
-/* Use an existing HIP stream (hipStream_t as void*) for all launches; NULL = ctx-owned stream. */
+/* Use an existing HIP stream (hipStream_t as void*) for all launches instead of the ctx-owned one;
+ * NULL = the device's default (null) stream. The caller keeps ownership. */
 int  mf_ctx_set_stream(mf_ctx *ctx, void *hip_stream);
 /* Tuning / test knobs, e.g. "l1_bits", "l2_bits", "part_target", "scatter_staged", "profile". */
 int  mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t value);

@@ -431,6 +431,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         k_mask_reads<<<(unsigned)((n_reads + 255) / 256), 256, 0, st>>>(d_offsets, n_reads, k, min_len, vmask.p, &scal.p[0]);
     }
     MF_DBG(ctx, "k_mask");
+    MF_HIP(hipGetLastError());
     unsigned long long n_occ = 0;
     MF_HIP(hipMemcpyAsync(&n_occ, &scal.p[0], 8, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
@@ -541,6 +542,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         k_scan<false><<<1, 1024, 0, st>>>(dcount.p, doff.p, np, (uint64_t *)&scal.p[3]);
     }
     MF_DBG(ctx, "k_scan");
+    MF_HIP(hipGetLastError());
     unsigned long long res[4];
     MF_HIP(hipMemcpyAsync(res, scal.p, 32, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
@@ -558,6 +560,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     if (ctx->opt_verbose)
         fprintf(stderr, "[mf] count: n_occ=%llu levels=%zu bits=%d np=%u distinct=%llu\n", (unsigned long long)n_occ,
                 lv.size(), total_bits, np, (unsigned long long)n_dist);
+    MF_HIP(hipGetLastError());
     size_t kb = dk.bytes(), cb = dc.bytes();
     return mf_table_adopt(ctx, k, n_dist, n_occ, dk.take(), kb, dc.take(), cb, out);
 }

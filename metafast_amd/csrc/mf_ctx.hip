@@ -59,11 +59,10 @@ extern "C" void mf_ctx_destroy(mf_ctx *ctx) {
 extern "C" int mf_ctx_set_stream(mf_ctx *ctx, void *hip_stream) {
     if (!ctx) return mf_set_error("ctx is NULL");
     if (ctx->own_stream && ctx->stream) { hipStreamSynchronize(ctx->stream); hipStreamDestroy(ctx->stream); }
-    if (hip_stream) { ctx->stream = (hipStream_t)hip_stream; ctx->own_stream = false; }
-    else {
-        MF_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-        ctx->own_stream = true;
-    }
+    // NULL = the device's default (null) stream, which is what torch uses unless told otherwise: work submitted by the
+    // caller on that stream (allocations' fill kernels, copies) is then ordered before the library's kernels
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
     return MF_OK;
 }
 

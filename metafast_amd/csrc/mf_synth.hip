@@ -131,6 +131,7 @@ extern "C" int mf_synth_reads_device(mf_ctx *ctx, uint64_t seed, int sample, uin
         uint64_t z = 0;
         MF_HIP(hipMemcpyAsync(d_offsets, &z, 8, hipMemcpyHostToDevice, ctx->stream));
     }
+    MF_HIP(hipGetLastError());
     MF_HIP(hipStreamSynchronize(ctx->stream));
     return MF_OK;
 }
