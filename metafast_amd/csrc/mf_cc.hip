@@ -18,6 +18,7 @@
 #include "mf_common.h"
 #include <algorithm>
 #include <numeric>
+#include <memory>
 
 #define CC_NONE 0xFFFFFFFFu
 
@@ -90,11 +91,11 @@ __global__ void k_cc_flatten_stats(const uint8_t *__restrict__ alive, const uint
     atomicAdd(&csize[r], 1u);
     atomicAdd(&cweight[r], (unsigned long long)vals[v]);
 }
-// per root: classify; kept roots get a slot in the kept list
-struct cc_kept { uint32_t root; uint32_t size; unsigned long long weight; };
+// per root: classify; kept roots get a slot in the kept list (SoA: root / size / weight / smallest k-mer)
+struct cc_kept_arrays { uint32_t *root; uint32_t *size; unsigned long long *weight; unsigned long long *minkey; };
 __global__ void k_cc_classify(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ parent,
                               const uint32_t *__restrict__ csize, const unsigned long long *__restrict__ cweight, uint64_t n,
-                              uint32_t b1, uint32_t b2, uint32_t *__restrict__ keptslot, cc_kept *__restrict__ kept,
+                              uint32_t b1, uint32_t b2, uint32_t *__restrict__ keptslot, cc_kept_arrays K,
                               unsigned int *__restrict__ counters /* [0]=kept comps [1]=kept kmers [2]=big comps */) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n || !alive[v] || parent[v] != (uint32_t)v) return;
@@ -104,16 +105,17 @@ __global__ void k_cc_classify(const uint8_t *__restrict__ alive, const uint32_t 
         uint32_t slot = atomicAdd(&counters[0], 1u);
         atomicAdd(&counters[1], s);
         keptslot[v] = slot;
-        kept[slot].root = (uint32_t)v; kept[slot].size = s; kept[slot].weight = cweight[v];
+        K.root[slot] = (uint32_t)v; K.size[slot] = s; K.weight[slot] = cweight[v]; K.minkey[slot] = ~0ull;
     } else atomicAdd(&counters[2], 1u);
 }
-// per vertex: members of kept components are appended to the member list; vertices of oversize components with
-// value >= thr+1 stay alive, everything else dies
+// per vertex: members of kept components are appended to the member list (k-mer + temporary component id);
+// vertices of oversize components with value >= thr+1 stay alive, everything else dies
 __global__ void k_cc_members(uint8_t *__restrict__ alive, const uint32_t *__restrict__ parent, const uint32_t *__restrict__ csize,
                              const uint16_t *__restrict__ vals, const uint64_t *__restrict__ keys, uint64_t n, uint32_t b1,
                              uint32_t b2, uint32_t next_thr, const uint32_t *__restrict__ keptslot,
-                             const uint64_t *__restrict__ slot_off, uint32_t *__restrict__ slot_fill,
-                             uint64_t *__restrict__ members) {
+                             const uint64_t *__restrict__ slot_off, uint32_t *__restrict__ slot_fill, uint32_t comp_base,
+                             unsigned long long *__restrict__ minkey, uint64_t *__restrict__ members,
+                             uint32_t *__restrict__ member_comp) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n || !alive[v]) return;
     uint32_t r = parent[v];
@@ -123,7 +125,14 @@ __global__ void k_cc_members(uint8_t *__restrict__ alive, const uint32_t *__rest
     if (s < b1) return;
     uint32_t slot = keptslot[r];
     uint32_t pos = atomicAdd(&slot_fill[slot], 1u);
-    members[slot_off[slot] + pos] = keys[v];
+    uint64_t key = keys[v];
+    members[slot_off[slot] + pos] = key;
+    member_comp[slot_off[slot] + pos] = comp_base + slot;
+    atomicMin(&minkey[slot], (unsigned long long)key);
+}
+__global__ void k_cc_remap(uint32_t *__restrict__ comp, uint64_t n, const uint32_t *__restrict__ rank) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) comp[i] = rank[comp[i]];
 }
 
 // ---- features: one thread per sample record ----
@@ -145,7 +154,7 @@ __global__ void k_features(const mf_slot *__restrict__ slots, uint64_t mask, con
 
 static inline unsigned cgrid(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
-// builds d_kmers / d_comp / index from the host vectors of a finished mf_comps
+// builds d_kmers / d_comp / index from the host vectors of a finished mf_comps (mf_comps_load path)
 static int comps_upload(mf_comps *C) {
     mf_ctx *ctx = C->ctx;
     const uint64_t nk = C->kmers.size();
@@ -164,29 +173,30 @@ static int comps_upload(mf_comps *C) {
     }
     MF_TRY(mf_index_build(ctx, C->d_kmers, nullptr, nk, &C->index, &C->index_bytes));
     MF_HIP(hipStreamSynchronize(ctx->stream));
+    C->host_ready = true;
     return MF_OK;
 }
 
-struct host_comp { uint64_t size; int64_t weight; int32_t thr; std::vector<uint64_t> kmers; };
-
-// final order: ConnectedComponent.compareTo (src/structures/ConnectedComponent.java:125-136): thr asc, weight desc,
-// size desc; ties (discovery order in the reference = hash / race dependent) broken by the smallest k-mer
-static void comps_finalize(mf_comps *C, std::vector<host_comp> &hc) {
-    for (auto &c : hc) std::sort(c.kmers.begin(), c.kmers.end());
-    std::sort(hc.begin(), hc.end(), [](const host_comp &a, const host_comp &b) {
-        if (a.thr != b.thr) return a.thr < b.thr;
-        if (a.weight != b.weight) return a.weight > b.weight;
-        if (a.size != b.size) return a.size > b.size;
-        uint64_t ka = a.kmers.empty() ? 0 : a.kmers[0], kb = b.kmers.empty() ? 0 : b.kmers[0];
-        return ka < kb;
-    });
-    C->n = hc.size();
-    C->sizes.clear(); C->weights.clear(); C->thr.clear(); C->offsets.assign(1, 0); C->kmers.clear();
-    for (auto &c : hc) {
-        C->sizes.push_back(c.size); C->weights.push_back(c.weight); C->thr.push_back(c.thr);
-        C->kmers.insert(C->kmers.end(), c.kmers.begin(), c.kmers.end());
-        C->offsets.push_back(C->kmers.size());
+// member lists on the host (ascending k-mers inside each component), built on first use
+int mf_comps_materialize(mf_comps *C) {
+    if (C->host_ready) return MF_OK;
+    mf_ctx *ctx = C->ctx;
+    MF_HIP(hipSetDevice(ctx->device));
+    const uint64_t nk = C->n_kmers;
+    std::vector<uint64_t> hk(nk); std::vector<uint32_t> hc(nk);
+    if (nk) {
+        MF_HIP(hipMemcpyAsync(hk.data(), C->d_kmers, nk * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipMemcpyAsync(hc.data(), C->d_comp, nk * 4, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipStreamSynchronize(ctx->stream));
     }
+    C->offsets.assign(C->n + 1, 0);
+    for (uint64_t c = 0; c < C->n; c++) C->offsets[c + 1] = C->offsets[c] + C->sizes[c];
+    C->kmers.assign(nk, 0);
+    std::vector<uint64_t> fill(C->offsets.begin(), C->offsets.end() - 1);
+    for (uint64_t j = 0; j < nk; j++) C->kmers[fill[hc[j]]++] = hk[j];
+    for (uint64_t c = 0; c < C->n; c++) std::sort(C->kmers.begin() + C->offsets[c], C->kmers.begin() + C->offsets[c + 1]);
+    C->host_ready = true;
+    return MF_OK;
 }
 
 extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2, mf_comps **out) {
@@ -198,13 +208,22 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
     const int k = t->k;
     if (n >= 0xFFFFFFFFull) return mf_set_error("components: more than 2^32 vertices is not supported");
     if (b1 < 0) b1 = 0;
-    std::vector<host_comp> hc;
+    struct rec { uint64_t size; int64_t weight; int32_t thr; uint64_t minkey; uint32_t temp; };
+    std::vector<rec> recs;
+    struct level_buf { mf_buf<uint64_t> members; mf_buf<uint32_t> comp; uint64_t n = 0; };
+    std::vector<std::unique_ptr<level_buf>> levels;
+    uint64_t total_k = 0;
     if (n) {
         MF_TRY(mf_table_ensure_index(t));
-        mf_buf<uint32_t> nbr, parent, root, csize, keptslot, slot_fill; mf_buf<unsigned long long> cweight; mf_buf<uint8_t> alive;
-        mf_buf<unsigned int> counters; mf_buf<cc_kept> kept;
-        MF_TRY(nbr.alloc(ctx, n * 8)); MF_TRY(parent.alloc(ctx, n)); MF_TRY(root.alloc(ctx, n)); MF_TRY(csize.alloc(ctx, n)); MF_TRY(keptslot.alloc(ctx, n));
-        MF_TRY(cweight.alloc(ctx, n)); MF_TRY(alive.alloc(ctx, n)); MF_TRY(counters.alloc(ctx, 4));
+        mf_buf<uint32_t> nbr, parent, root, csize, keptslot, slot_fill, k_root, k_size; mf_buf<unsigned long long> cweight, k_weight, k_minkey;
+        mf_buf<uint8_t> alive; mf_buf<unsigned int> counters; mf_buf<uint64_t> slot_off, tot;
+        const uint64_t max_kept = n / (uint64_t)std::max(b1, 1) + 1;
+        MF_TRY(nbr.alloc(ctx, n * 8)); MF_TRY(parent.alloc(ctx, n)); MF_TRY(root.alloc(ctx, n)); MF_TRY(csize.alloc(ctx, n));
+        MF_TRY(keptslot.alloc(ctx, n)); MF_TRY(cweight.alloc(ctx, n)); MF_TRY(alive.alloc(ctx, n)); MF_TRY(counters.alloc(ctx, 4));
+        MF_TRY(k_root.alloc(ctx, max_kept)); MF_TRY(k_size.alloc(ctx, max_kept)); MF_TRY(k_weight.alloc(ctx, max_kept));
+        MF_TRY(k_minkey.alloc(ctx, max_kept)); MF_TRY(slot_off.alloc(ctx, max_kept + 1)); MF_TRY(slot_fill.alloc(ctx, max_kept));
+        MF_TRY(tot.alloc(ctx, 1));
+        cc_kept_arrays K; K.root = k_root.p; K.size = k_size.p; K.weight = k_weight.p; K.minkey = k_minkey.p;
         {
             mf_ktimer tm(ctx, "k_cc_adjacency");
             k_cc_adjacency<<<cgrid(n), 256, 0, st>>>((const mf_slot *)t->index.slots, t->index.cap - 1, t->d_keys, n, k, nbr.p);
@@ -220,49 +239,79 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             {
                 mf_ktimer tm(ctx, "k_cc_stats");
                 k_cc_flatten_stats<<<cgrid(n), 256, 0, st>>>(alive.p, parent.p, root.p, t->d_counts, csize.p, cweight.p, n);
+                k_cc_classify<<<cgrid(n), 256, 0, st>>>(alive.p, root.p, csize.p, cweight.p, n, (uint32_t)b1, (uint32_t)b2, keptslot.p, K,
+                                                        counters.p);
             }
-            // number of kept components is bounded by n / max(b1,1); size the list by a first counting pass
             unsigned int cnt[4];
-            MF_TRY(kept.alloc(ctx, n / (uint64_t)std::max(b1, 1) + 1));
-            k_cc_classify<<<cgrid(n), 256, 0, st>>>(alive.p, root.p, csize.p, cweight.p, n, (uint32_t)b1, (uint32_t)b2, keptslot.p,
-                                                    kept.p, counters.p);
             MF_HIP(hipMemcpyAsync(cnt, counters.p, 16, hipMemcpyDeviceToHost, st));
             MF_HIP(hipStreamSynchronize(st));
             const uint32_t nkept = cnt[0], nkm = cnt[1], nbig = cnt[2];
-            std::vector<cc_kept> hk(nkept);
-            std::vector<uint64_t> soff(nkept + 1, 0);
-            if (nkept) {
-                MF_HIP(hipMemcpyAsync(hk.data(), kept.p, nkept * sizeof(cc_kept), hipMemcpyDeviceToHost, st));
-                MF_HIP(hipStreamSynchronize(st));
-                for (uint32_t i = 0; i < nkept; i++) soff[i + 1] = soff[i] + hk[i].size;
-            }
-            mf_buf<uint64_t> d_soff, members;
-            MF_TRY(d_soff.alloc(ctx, nkept + 1)); MF_TRY(members.alloc(ctx, nkm)); MF_TRY(slot_fill.alloc(ctx, nkept));
-            MF_HIP(hipMemcpyAsync(d_soff.p, soff.data(), (nkept + 1) * 8, hipMemcpyHostToDevice, st));
-            MF_HIP(hipMemsetAsync(slot_fill.p, 0, slot_fill.bytes(), st));
+            auto lv = std::make_unique<level_buf>();
+            MF_TRY(lv->members.alloc(ctx, nkm)); MF_TRY(lv->comp.alloc(ctx, nkm));
+            lv->n = nkm;
+            k_scan<false><<<1, 1024, 0, st>>>(k_size.p, slot_off.p, (uint64_t)nkept, tot.p);
+            MF_HIP(hipMemsetAsync(slot_fill.p, 0, (size_t)(nkept ? nkept : 1) * 4, st));
             {
                 mf_ktimer tm(ctx, "k_cc_members");
                 k_cc_members<<<cgrid(n), 256, 0, st>>>(alive.p, root.p, csize.p, t->d_counts, t->d_keys, n, (uint32_t)b1, (uint32_t)b2,
-                                                       (uint32_t)(thr + 1), keptslot.p, d_soff.p, slot_fill.p, members.p);
+                                                       (uint32_t)(thr + 1), keptslot.p, slot_off.p, slot_fill.p, (uint32_t)recs.size(),
+                                                       k_minkey.p, lv->members.p, lv->comp.p);
             }
-            std::vector<uint64_t> hm(nkm);
-            if (nkm) MF_HIP(hipMemcpyAsync(hm.data(), members.p, (size_t)nkm * 8, hipMemcpyDeviceToHost, st));
-            MF_HIP(hipStreamSynchronize(st));
-            for (uint32_t i = 0; i < nkept; i++) {
-                host_comp c; c.size = hk[i].size; c.weight = (int64_t)hk[i].weight; c.thr = thr;
-                c.kmers.assign(hm.begin() + soff[i], hm.begin() + soff[i + 1]);
-                hc.push_back(std::move(c));
+            if (nkept) {
+                std::vector<uint32_t> hs(nkept); std::vector<unsigned long long> hw(nkept), hm(nkept);
+                MF_HIP(hipMemcpyAsync(hs.data(), k_size.p, (size_t)nkept * 4, hipMemcpyDeviceToHost, st));
+                MF_HIP(hipMemcpyAsync(hw.data(), k_weight.p, (size_t)nkept * 8, hipMemcpyDeviceToHost, st));
+                MF_HIP(hipMemcpyAsync(hm.data(), k_minkey.p, (size_t)nkept * 8, hipMemcpyDeviceToHost, st));
+                MF_HIP(hipStreamSynchronize(st));
+                for (uint32_t i = 0; i < nkept; i++)
+                    recs.push_back({hs[i], (int64_t)hw[i], thr, hm[i], (uint32_t)recs.size()});
             }
+            total_k += nkm;
+            levels.push_back(std::move(lv));
             if (ctx->opt_verbose)
                 fprintf(stderr, "[mf] components: thr=%d kept=%u (%u k-mers) big=%u\n", thr, nkept, nkm, nbig);
             if (!nbig) break;
             if (thr > MF_MAX_COUNT) return mf_set_error("components: threshold loop did not terminate");
         }
     }
+    // final order: ConnectedComponent.compareTo (src/structures/ConnectedComponent.java:125-136): thr asc, weight desc,
+    // size desc; ties (discovery order in the reference = hash / race dependent) broken by the smallest k-mer
+    std::sort(recs.begin(), recs.end(), [](const rec &a, const rec &b) {
+        if (a.thr != b.thr) return a.thr < b.thr;
+        if (a.weight != b.weight) return a.weight > b.weight;
+        if (a.size != b.size) return a.size > b.size;
+        return a.minkey < b.minkey;
+    });
     mf_comps *C = new mf_comps();
-    C->ctx = ctx; C->k = k;
-    comps_finalize(C, hc);
-    int rc = comps_upload(C);
+    C->ctx = ctx; C->k = k; C->n = recs.size(); C->n_kmers = total_k;
+    std::vector<uint32_t> rank(recs.size() ? recs.size() : 1);
+    for (size_t i = 0; i < recs.size(); i++) {
+        C->sizes.push_back(recs[i].size); C->weights.push_back(recs[i].weight); C->thr.push_back(recs[i].thr);
+        rank[recs[i].temp] = (uint32_t)i;
+    }
+    int rc = MF_OK;
+    do {
+        void *p = nullptr;
+        if ((rc = mf_alloc(ctx, (total_k ? total_k : 1) * 8, &p)) < 0) break;
+        C->d_kmers = (uint64_t *)p; C->kmers_bytes = (total_k ? total_k : 1) * 8;
+        if ((rc = mf_alloc(ctx, (total_k ? total_k : 1) * 4, &p)) < 0) break;
+        C->d_comp = (uint32_t *)p; C->comp_bytes = (total_k ? total_k : 1) * 4;
+        uint64_t pos = 0;
+        for (auto &lv : levels) {
+            if (!lv->n) continue;
+            hipMemcpyAsync(C->d_kmers + pos, lv->members.p, lv->n * 8, hipMemcpyDeviceToDevice, st);
+            hipMemcpyAsync(C->d_comp + pos, lv->comp.p, lv->n * 4, hipMemcpyDeviceToDevice, st);
+            pos += lv->n;
+        }
+        if (total_k) {
+            mf_buf<uint32_t> d_rank;
+            if ((rc = d_rank.alloc(ctx, rank.size())) < 0) break;
+            hipMemcpyAsync(d_rank.p, rank.data(), rank.size() * 4, hipMemcpyHostToDevice, st);
+            k_cc_remap<<<cgrid(total_k), 256, 0, st>>>(C->d_comp, total_k, d_rank.p);
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = mf_set_error("components: remap failed"); break; }
+        }
+        if ((rc = mf_index_build(ctx, C->d_kmers, nullptr, total_k, &C->index, &C->index_bytes)) < 0) break;
+    } while (0);
     if (rc < 0) { mf_comps_destroy(C); return rc; }
     *out = C;
     return MF_OK;
@@ -278,12 +327,14 @@ extern "C" void mf_comps_destroy(mf_comps *c) {
 extern "C" int mf_comps_stats(const mf_comps *c, uint64_t *n_comp, uint64_t *n_kmers) {
     if (!c) return mf_set_error("comps is NULL");
     if (n_comp) *n_comp = c->n;
-    if (n_kmers) *n_kmers = c->kmers.size();
+    if (n_kmers) *n_kmers = c->n_kmers;
     return MF_OK;
 }
-extern "C" int mf_comps_export(const mf_comps *c, uint64_t *sizes, int64_t *weights, int32_t *thr, uint64_t *kmer_offsets,
+extern "C" int mf_comps_export(const mf_comps *cc, uint64_t *sizes, int64_t *weights, int32_t *thr, uint64_t *kmer_offsets,
                                uint64_t *kmers) {
-    if (!c) return mf_set_error("comps is NULL");
+    if (!cc) return mf_set_error("comps is NULL");
+    mf_comps *c = const_cast<mf_comps *>(cc);
+    MF_TRY(mf_comps_materialize(c));
     if (sizes && c->n) memcpy(sizes, c->sizes.data(), c->n * 8);
     if (weights && c->n) memcpy(weights, c->weights.data(), c->n * 8);
     if (thr && c->n) memcpy(thr, c->thr.data(), c->n * 4);
@@ -327,7 +378,7 @@ extern "C" int mf_features_device(mf_ctx *ctx, mf_comps *c, const mf_table *samp
     MF_HIP(hipStreamSynchronize(st));
     if (breadth)
         for (uint64_t i = 0; i < nc; i++) {
-            uint64_t cnt = c->offsets[i + 1] - c->offsets[i];
+            uint64_t cnt = c->sizes[i];
             // a negative threshold makes absent k-mers (value 0) count as found (value > threshold)
             double f = threshold < 0 ? (double)cnt : (double)hf[i];
             breadth[i] = f / (double)cnt;                    // ((double) kmersFound) / kmersCount :203

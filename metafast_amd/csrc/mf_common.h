@@ -36,7 +36,7 @@ int mf_set_error(const char *fmt, ...);   // returns MF_ERR
 static constexpr uint64_t MF_EMPTY = 0xFFFFFFFFFFFFFFFFull;  // unreachable key: k<=31 keys are < 2^62
 static constexpr int MF_MAX_DIGIT_BITS = 11;                 // 2048 staging lines of 64 B = 128 KiB LDS
 static constexpr int MF_LINE = 8;                            // k-mers per 64-byte staging line
-static constexpr int MF_COUNT_SLOTS = 8192;                  // LDS count table slots (64 KiB keys + 32 KiB counts)
+static constexpr int MF_COUNT_SLOTS = 4096;                  // LDS count table slots (32 KiB keys + 16 KiB counts): 3 workgroups per CU
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -59,10 +59,12 @@ struct mf_ctx {
     int64_t opt_profile = 0;
     int64_t opt_l1_blocks = 0;     // 0 = auto
     int64_t opt_verbose = 0;
-    // workspace cache
-    struct blk { void *p; size_t sz; };
-    std::vector<blk> free_list;
-    size_t cached_bytes = 0;
+    // workspace arena: a few large hipMalloc'd regions, sub-allocated with first-fit + coalescing free lists.
+    // Everything runs on one stream, so a block can be handed out again as soon as it is released.
+    struct span { size_t off, sz; };
+    struct region { char *base; size_t size; std::vector<span> free_spans; };   // free_spans sorted by offset
+    std::vector<region> regions;
+    size_t arena_bytes = 0;
     // timers
     std::vector<mf_timer_rec> pending;
     std::vector<hipEvent_t> event_pool;
@@ -133,9 +135,11 @@ struct mf_comps {
     mf_ctx *ctx = nullptr;
     int k = 0;
     uint64_t n = 0, n_kmers = 0;
-    // host copies (component lists are small relative to the tables; ordering is done on the host)
+    // per-component records on the host in final order; the member lists (offsets / kmers) are
+    // materialised from the device arrays on first use (export / write)
     std::vector<uint64_t> sizes; std::vector<int64_t> weights; std::vector<int32_t> thr;
     std::vector<uint64_t> offsets; std::vector<uint64_t> kmers;
+    bool host_ready = false;
     // device: component k-mers + component id per k-mer, and an index over them (for features)
     uint64_t *d_kmers = nullptr; uint32_t *d_comp = nullptr;
     size_t kmers_bytes = 0, comp_bytes = 0;
@@ -145,6 +149,7 @@ struct mf_comps {
 int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, mf_index *out,
                    size_t *bytes);
 int mf_table_ensure_index(mf_table *t);
+int mf_comps_materialize(mf_comps *c);
 int mf_table_adopt(mf_ctx *ctx, int k, uint64_t n, uint64_t n_occ, uint64_t *d_keys, size_t kb, uint16_t *d_counts,
                    size_t cb, mf_table **out);
 

@@ -142,6 +142,7 @@ struct mf_stage {
     uint32_t *ctr;    // [nd] low 16 = slots reserved, high 16 = slots committed
 };
 #define MF_WG __HIP_MEMORY_SCOPE_WORKGROUP
+#define MF_MLP 4          // 16-byte loads in flight per thread in the streaming loops
 
 // Lock-free within the workgroup: reserve a slot, write it, commit; the 8th committer flushes the
 // line to HBM with four 16-byte stores and reopens it.  Lanes that find the line full retry.
@@ -270,9 +271,21 @@ __global__ __launch_bounds__(1024) void k_split(const uint64_t *__restrict__ in,
         const uint64_t obase = start + (uint64_t)p * (uint64_t)(MF_LINE * nd);   // room for per-bin padding
         for (int i = threadIdx.x; i < nd; i += blockDim.x) L.ctr[i] = 0;
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-            uint64_t key = in[start + i];
-            if (key != MF_EMPTY) atomicAdd(&L.ctr[mf_digit(mf_hash64(key), bits_used, bits)], 1u);
+        // 16-byte loads, MF_MLP of them in flight per thread (start is 64-byte aligned, len a multiple of 8)
+        const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(in + start);
+        const uint32_t npairs = len >> 1;
+        for (uint32_t jb = 0; jb < npairs; jb += MF_MLP * blockDim.x) {
+            ulonglong2 v[MF_MLP];
+#pragma unroll
+            for (int u = 0; u < MF_MLP; u++) {
+                uint32_t j = jb + u * blockDim.x + threadIdx.x;
+                v[u] = j < npairs ? in2[j] : make_ulonglong2(MF_EMPTY, MF_EMPTY);
+            }
+#pragma unroll
+            for (int u = 0; u < MF_MLP; u++) {
+                if (v[u].x != MF_EMPTY) atomicAdd(&L.ctr[mf_digit(mf_hash64(v[u].x), bits_used, bits)], 1u);
+                if (v[u].y != MF_EMPTY) atomicAdd(&L.ctr[mf_digit(mf_hash64(v[u].y), bits_used, bits)], 1u);
+            }
         }
         __syncthreads();
         // exclusive scan of padded bin sizes
@@ -295,16 +308,27 @@ __global__ __launch_bounds__(1024) void k_split(const uint64_t *__restrict__ in,
         __syncthreads();
         for (int i = threadIdx.x; i < nd; i += blockDim.x) L.ctr[i] = 0;
         __syncthreads();
-        // uniform trip count per wave (see k_l1_scatter)
-        const uint32_t len_up = (len + blockDim.x - 1) / blockDim.x * blockDim.x;
-        for (uint32_t i = threadIdx.x; i < len_up; i += blockDim.x) {
-            uint64_t key = i < len ? in[start + i] : MF_EMPTY;
-            bool valid = key != MF_EMPTY;
-            uint32_t d = mf_digit(mf_hash64(key), bits_used, bits);
-            if (STAGED) mf_stage_insert(L, out, d, key, valid);
-            else if (valid) {
-                uint64_t pos = atomicAdd(reinterpret_cast<unsigned long long *>(&L.cur[d]), 1ull);
-                out[pos] = key;
+        // uniform trip count for every wave (the insert's retry loop is wave-uniform)
+        for (uint32_t jb = 0; jb < npairs; jb += MF_MLP * blockDim.x) {
+            ulonglong2 v[MF_MLP];
+#pragma unroll
+            for (int u = 0; u < MF_MLP; u++) {
+                uint32_t j = jb + u * blockDim.x + threadIdx.x;
+                v[u] = j < npairs ? in2[j] : make_ulonglong2(MF_EMPTY, MF_EMPTY);
+            }
+#pragma unroll
+            for (int u = 0; u < MF_MLP; u++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    uint64_t key = h ? v[u].y : v[u].x;
+                    bool valid = key != MF_EMPTY;
+                    uint32_t d = mf_digit(mf_hash64(key), bits_used, bits);
+                    if (STAGED) mf_stage_insert(L, out, d, key, valid);
+                    else if (valid) {
+                        uint64_t pos = atomicAdd(reinterpret_cast<unsigned long long *>(&L.cur[d]), 1ull);
+                        out[pos] = key;
+                    }
+                }
             }
         }
         __syncthreads();
@@ -322,11 +346,13 @@ __global__ __launch_bounds__(1024) void k_split(const uint64_t *__restrict__ in,
 // =============================================================================================
 // K3: hash-count one partition at a time in LDS, compact in place
 // =============================================================================================
-// keys[start .. start+len) (with sentinels) -> keys[start .. start+d) distinct, cnt[start .. start+d) counts
-__global__ __launch_bounds__(1024) void k_count(uint64_t *__restrict__ keys, uint16_t *__restrict__ cnt,
-                                                const uint64_t *__restrict__ pstart, const uint32_t *__restrict__ plen,
-                                                uint32_t np, uint32_t *__restrict__ dcount,
-                                                unsigned int *__restrict__ overflow) {
+// keys[start .. start+len) (with sentinels) -> keys[start .. start+d) distinct, cnt[start .. start+d) counts.
+// 256-thread workgroups with a 48 KiB table so that three of them share a CU: while one waits for its
+// partition to arrive from HBM the others probe.
+__global__ __launch_bounds__(256) void k_count(uint64_t *__restrict__ keys, uint16_t *__restrict__ cnt,
+                                               const uint64_t *__restrict__ pstart, const uint32_t *__restrict__ plen,
+                                               uint32_t np, uint32_t *__restrict__ dcount,
+                                               unsigned int *__restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t scratch[17];
     uint64_t *tk = reinterpret_cast<uint64_t *>(smem);                    // [MF_COUNT_SLOTS]
@@ -334,28 +360,42 @@ __global__ __launch_bounds__(1024) void k_count(uint64_t *__restrict__ keys, uin
     for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
         const uint64_t start = pstart[p];
         const uint32_t len = plen[p];
-        // table size: power of two >= 4/3 * len, in [blockDim, MF_COUNT_SLOTS]
-        uint32_t want = len + len / 3 + 1;
+        // table size: power of two >= 9/8 * len, in [blockDim, MF_COUNT_SLOTS]
+        uint32_t want = len + len / 8 + 1;
         uint32_t slots = blockDim.x;
         while (slots < want && slots < (uint32_t)MF_COUNT_SLOTS) slots <<= 1;
         const uint32_t mask = slots - 1;
         for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
         __syncthreads();
-        for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
-            uint64_t key = keys[start + i];
-            if (key == MF_EMPTY) continue;
-            uint32_t s = (uint32_t)mf_hash64(key) & mask;
-            uint32_t probes = 0;
-            for (;;) {
-                uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tk[s]);
-                if (cur == MF_EMPTY) {
-                    cur = atomicCAS(reinterpret_cast<unsigned long long *>(&tk[s]), (unsigned long long)MF_EMPTY,
-                                    (unsigned long long)key);
-                    if (cur == MF_EMPTY) cur = key;
+        const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(keys + start);
+        const uint32_t npairs = len >> 1;
+        for (uint32_t jb = 0; jb < npairs; jb += MF_MLP * blockDim.x) {
+            ulonglong2 v[MF_MLP];
+#pragma unroll
+            for (int u = 0; u < MF_MLP; u++) {
+                uint32_t j = jb + u * blockDim.x + threadIdx.x;
+                v[u] = j < npairs ? in2[j] : make_ulonglong2(MF_EMPTY, MF_EMPTY);
+            }
+#pragma unroll
+            for (int u = 0; u < MF_MLP; u++) {
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    uint64_t key = h ? v[u].y : v[u].x;
+                    if (key == MF_EMPTY) continue;
+                    uint32_t s = (uint32_t)mf_hash64(key) & mask;
+                    uint32_t probes = 0;
+                    for (;;) {
+                        uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tk[s]);
+                        if (cur == MF_EMPTY) {
+                            cur = atomicCAS(reinterpret_cast<unsigned long long *>(&tk[s]), (unsigned long long)MF_EMPTY,
+                                            (unsigned long long)key);
+                            if (cur == MF_EMPTY) cur = key;
+                        }
+                        if (cur == key) { atomicAdd(&tc[s], 1u); break; }
+                        s = (s + 1) & mask;
+                        if (++probes > slots) { atomicExch(overflow, 1u); break; }
+                    }
                 }
-                if (cur == key) { atomicAdd(&tc[s], 1u); break; }
-                s = (s + 1) & mask;
-                if (++probes > slots) { atomicExch(overflow, 1u); break; }
             }
         }
         __syncthreads();
@@ -531,9 +571,9 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     {
         size_t lds = (size_t)MF_COUNT_SLOTS * 12;
         MF_TRY(set_lds(k_count, lds));
-        unsigned grid = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu);
+        unsigned grid = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 3);
         mf_ktimer t(ctx, "k_count");
-        k_count<<<grid, 1024, lds, st>>>(bufA.p, cnt.p, pstart.p, plen.p, np, dcount.p, (unsigned int *)&scal.p[2]);
+        k_count<<<grid, 256, lds, st>>>(bufA.p, cnt.p, pstart.p, plen.p, np, dcount.p, (unsigned int *)&scal.p[2]);
     }
     MF_DBG(ctx, "k_count");
     mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));
@@ -546,7 +586,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     unsigned long long res[4];
     MF_HIP(hipMemcpyAsync(res, scal.p, 32, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
-    if (res[2]) return mf_set_error("k_count: LDS table overflow (more than %d distinct k-mers in one partition); "
+    if (res[2]) return mf_set_error("k_count: LDS table overflow (about %d or more distinct k-mers in one partition); "
                                     "lower option part_target", MF_COUNT_SLOTS);
     const uint64_t n_dist = res[3];
     mf_buf<uint64_t> dk; MF_TRY(dk.alloc(ctx, n_dist));

@@ -37,19 +37,28 @@ extern "C" int mf_ctx_create(int device, int host_threads, mf_ctx **out) {
     return MF_OK;
 }
 
+// give every completely free region back to the driver
 extern "C" int mf_ctx_trim(mf_ctx *ctx) {
     if (!ctx) return MF_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    for (auto &b : ctx->free_list) hipFree(b.p);
-    ctx->free_list.clear();
-    ctx->cached_bytes = 0;
+    for (size_t i = 0; i < ctx->regions.size();) {
+        auto &r = ctx->regions[i];
+        if (r.free_spans.size() == 1 && r.free_spans[0].off == 0 && r.free_spans[0].sz == r.size) {
+            hipFree(r.base);
+            ctx->arena_bytes -= r.size;
+            ctx->regions.erase(ctx->regions.begin() + i);
+        } else i++;
+    }
     return MF_OK;
 }
 
 extern "C" void mf_ctx_destroy(mf_ctx *ctx) {
     if (!ctx) return;
-    mf_ctx_trim(ctx);
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &r : ctx->regions) hipFree(r.base);
+    ctx->regions.clear();
     for (auto &r : ctx->pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : ctx->event_pool) hipEventDestroy(ev);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
@@ -86,35 +95,59 @@ extern "C" int mf_ctx_synchronize(mf_ctx *ctx) {
     return MF_OK;
 }
 
-// ---- workspace cache: best-fit reuse of freed blocks (hipMalloc/hipFree stay out of timed loops) ----
+// ---- workspace arena ----
+static const size_t MF_ALIGN = 256;
+static bool arena_take(mf_ctx *ctx, size_t bytes, void **out) {
+    // best fit over all regions
+    int br = -1, bs = -1; size_t best = ~(size_t)0;
+    for (size_t r = 0; r < ctx->regions.size(); r++)
+        for (size_t s = 0; s < ctx->regions[r].free_spans.size(); s++) {
+            size_t sz = ctx->regions[r].free_spans[s].sz;
+            if (sz >= bytes && sz < best) { best = sz; br = (int)r; bs = (int)s; }
+        }
+    if (br < 0) return false;
+    auto &R = ctx->regions[br];
+    mf_ctx::span sp = R.free_spans[bs];
+    *out = R.base + sp.off;
+    if (sp.sz == bytes) R.free_spans.erase(R.free_spans.begin() + bs);
+    else { R.free_spans[bs].off += bytes; R.free_spans[bs].sz -= bytes; }
+    return true;
+}
 int mf_alloc(mf_ctx *ctx, size_t bytes, void **out) {
-    bytes = (bytes + 255) & ~(size_t)255;
-    int best = -1;
-    for (size_t i = 0; i < ctx->free_list.size(); i++) {
-        size_t sz = ctx->free_list[i].sz;
-        if (sz >= bytes && sz <= bytes + bytes / 4 + 4096 && (best < 0 || sz < ctx->free_list[best].sz)) best = (int)i;
-    }
-    if (best >= 0) {
-        *out = ctx->free_list[best].p;
-        ctx->cached_bytes -= ctx->free_list[best].sz;
-        ctx->free_list.erase(ctx->free_list.begin() + best);
-        return MF_OK;
-    }
-    hipError_t e = hipMalloc(out, bytes);
+    bytes = (bytes + MF_ALIGN - 1) & ~(MF_ALIGN - 1);
+    if (arena_take(ctx, bytes, out)) return MF_OK;
+    // new region: small requests share 256 MiB regions, large ones get their own
+    size_t rsz = bytes < ((size_t)256 << 20) ? ((size_t)256 << 20) : bytes;
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, rsz);
+    if (e != hipSuccess && rsz != bytes) { (void)hipGetLastError(); rsz = bytes; e = hipMalloc(&p, rsz); }
     if (e != hipSuccess) {
-        // give cached blocks back and retry once
         (void)hipGetLastError();
-        mf_ctx_trim(ctx);
-        e = hipMalloc(out, bytes);
-        if (e != hipSuccess) { (void)hipGetLastError(); return mf_set_error("hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e)); }
+        mf_ctx_trim(ctx);                       // return idle regions and retry once
+        e = hipMalloc(&p, rsz);
+        if (e != hipSuccess) { (void)hipGetLastError(); return mf_set_error("hipMalloc(%zu bytes) failed: %s", rsz, hipGetErrorString(e)); }
     }
+    mf_ctx::region R; R.base = (char *)p; R.size = rsz; R.free_spans.push_back({0, rsz});
+    ctx->regions.push_back(R);
+    ctx->arena_bytes += rsz;
+    if (!arena_take(ctx, bytes, out)) return mf_set_error("arena: internal error");
     return MF_OK;
 }
 void mf_release(mf_ctx *ctx, void *p, size_t bytes) {
     if (!p) return;
-    bytes = (bytes + 255) & ~(size_t)255;
-    ctx->free_list.push_back({p, bytes});
-    ctx->cached_bytes += bytes;
+    bytes = (bytes + MF_ALIGN - 1) & ~(MF_ALIGN - 1);
+    for (auto &R : ctx->regions) {
+        if ((char *)p < R.base || (char *)p >= R.base + R.size) continue;
+        size_t off = (size_t)((char *)p - R.base);
+        auto &fs = R.free_spans;
+        size_t i = 0;
+        while (i < fs.size() && fs[i].off < off) i++;
+        fs.insert(fs.begin() + i, {off, bytes});
+        if (i + 1 < fs.size() && fs[i].off + fs[i].sz == fs[i + 1].off) { fs[i].sz += fs[i + 1].sz; fs.erase(fs.begin() + i + 1); }
+        if (i > 0 && fs[i - 1].off + fs[i - 1].sz == fs[i].off) { fs[i - 1].sz += fs[i].sz; fs.erase(fs.begin() + i); }
+        return;
+    }
+    fprintf(stderr, "[mf] warning: mf_release of a pointer that is not in the arena\n");
 }
 
 // ---- timers ----

@@ -280,8 +280,10 @@ extern "C" int mf_build_unitigs(mf_ctx *ctx, mf_table *t, int k, int freq_thresh
 // A11 components files
 // ---------------------------------------------------------------------------------------------
 // ConnectedComponent.saveComponents (src/structures/ConnectedComponent.java:80-93); stat file ComponentsBuilder.java:146-152
-extern "C" int mf_comps_write(const mf_comps *c, const char *components_bin, const char *stat_txt) {
-    if (!c || !components_bin) return mf_set_error("mf_comps_write: NULL argument");
+extern "C" int mf_comps_write(const mf_comps *cc, const char *components_bin, const char *stat_txt) {
+    if (!cc || !components_bin) return mf_set_error("mf_comps_write: NULL argument");
+    mf_comps *c = const_cast<mf_comps *>(cc);
+    MF_TRY(mf_comps_materialize(c));
     FILE *f = fopen(components_bin, "wb");
     if (!f) return mf_set_error("can't write '%s'", components_bin);
     uint8_t b[12];

@@ -8,7 +8,10 @@
 //                   canonical orientation (the other orientation follows by symmetry) + the unique neighbours' indices
 //   U2 k_ut_links   per ORIENTED k-mer (node = 2*index + strand): link f->g exists iff R(f) is unique and L(g) is
 //                   unique; a node without an incoming link is a start (task.run :52-69)
-//   U3 k_ut_jump    pointer jumping (Wyllie list ranking) to the path start: start id + distance, O(log len) rounds
+//   U3 k_ut_walk    one thread per START node follows the successor links and stamps (start, distance) on every node
+//                   of its path: one hop per node in total (pointer jumping costs O(log len) passes over ALL nodes);
+//                   walks are cut every UT_WALK_CHUNK hops and continued from a work list, so the launch count grows
+//                   with the longest path only
 //   U4 k_ut_ends    per path end: length filter and the reference's emission rule canon(start) <= canon(end k-mer)
 //                   where the end k-mer is the one BEYOND the path when the walk stopped on a left branch
 //                   (processSequence :83-107) -- this is what makes a path come out 0, 1 or 2 times
@@ -23,17 +26,17 @@
 // info byte: bits 0-2 rcode, bits 3-5 lcode (0..3 = unique nucleotide, 4 = none, 5 = several), bit 6 ror, bit 7 lor
 #define UT_CODE_NONE 4u
 #define UT_CODE_MANY 5u
-// node flags
-#define UT_START 1u
-#define UT_HASOUT 2u
-#define UT_DONE 4u
+#define UT_WALK_CHUNK 4096
+#define UT_UNSEEN 0xFFFFFFFFFFFFFFFFull      // pk value of a node no walk has reached (nodes on cycles keep it)
 
 struct ut_arrays {
     const uint64_t *gk; const uint16_t *gv; uint64_t n; int k;
     uint8_t *info; uint32_t *ridx; uint32_t *lidx;
     uint8_t *pal;             // even k only: 1 if the k-mer equals its reverse complement (else nullptr)
-    unsigned long long *pk;   // per node: low 32 = pointer (node id), high 32 = distance
-    uint8_t *nflags;          // per node
+    unsigned long long *pk;   // per node: low 32 = start node of its path, high 32 = distance from it (UT_UNSEEN if none)
+    uint32_t *succ;           // per node: next node on the path or UT_NONE
+    uint32_t *starts;         // compacted list of start nodes
+    unsigned int *n_starts;
 };
 
 __global__ void k_ut_flags(const mf_slot *__restrict__ slots, uint64_t mask, ut_arrays A) {
@@ -87,48 +90,67 @@ __device__ __forceinline__ uint32_t ut_left_node(const ut_arrays &A, uint32_t i,
     return o ? ut_node(A, A.ridx[i], ((info >> 6) & 1u) ^ 1u) : ut_node(A, A.lidx[i], (info >> 7) & 1u);
 }
 
-__global__ void k_ut_links(ut_arrays A) {
+__global__ __launch_bounds__(1024) void k_ut_links(ut_arrays A) {
     uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= 2 * A.n) return;
-    uint32_t i = (uint32_t)(f >> 1), o = (uint32_t)(f & 1);
-    uint8_t info = A.info[i];
-    if (o == 1 && A.pal && A.pal[i]) {            // not a node of its own (see ut_node): never start, never done
-        A.pk[f] = (unsigned long long)f | (1ull << 32);
-        A.nflags[f] = 0;
-        return;
+    bool is_start = false;
+    if (f < 2 * A.n) {
+        uint32_t i = (uint32_t)(f >> 1), o = (uint32_t)(f & 1);
+        uint8_t info = A.info[i];
+        uint32_t succ = UT_NONE;
+        if (!(o == 1 && A.pal && A.pal[i])) {         // strand 1 of a palindrome is not a node of its own (see ut_node)
+            bool has_in = false;
+            if (ut_r_unique(info, o)) {
+                uint32_t g = ut_right_node(A, i, o, info);
+                if (ut_l_unique(A.info[g >> 1], g & 1u)) succ = g;
+            }
+            if (ut_l_unique(info, o)) {
+                uint32_t h = ut_left_node(A, i, o, info);
+                has_in = ut_r_unique(A.info[h >> 1], h & 1u);
+            }
+            is_start = !has_in;
+        }
+        A.succ[f] = succ;
     }
-    bool has_out = false, has_in = false;
-    uint32_t pred = (uint32_t)f;
-    if (ut_r_unique(info, o)) {
-        uint32_t g = ut_right_node(A, i, o, info);
-        has_out = ut_l_unique(A.info[g >> 1], g & 1u);
+    // block-aggregated append of the start nodes: ONE global atomic per 1024-thread workgroup (a per-wave atomic on the
+    // single cursor serialises at ~12 ns each and cost 126 ms on 7.2e8 nodes)
+    __shared__ uint32_t wave_base[16];
+    __shared__ uint32_t block_base;
+    unsigned long long b = __ballot(is_start);
+    const int wave = threadIdx.x >> 6;
+    if (mf_lane() == 0) wave_base[wave] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) { uint32_t c = wave_base[w]; wave_base[w] = acc; acc += c; }
+        block_base = acc ? atomicAdd(A.n_starts, acc) : 0u;
     }
-    if (ut_l_unique(info, o)) {
-        uint32_t h = ut_left_node(A, i, o, info);
-        if (ut_r_unique(A.info[h >> 1], h & 1u)) { has_in = true; pred = h; }
-    }
-    A.pk[f] = (unsigned long long)pred | ((unsigned long long)(has_in ? 1u : 0u) << 32);
-    A.nflags[f] = (uint8_t)((has_in ? 0u : (UT_START | UT_DONE)) | (has_out ? UT_HASOUT : 0u));
+    __syncthreads();
+    if (is_start) A.starts[block_base + wave_base[wave] + (uint32_t)__popcll(b & ((1ull << mf_lane()) - 1ull))] = (uint32_t)f;
 }
 
-// one round of pointer jumping; counts the nodes that reached their start in this round
-__global__ void k_ut_jump(ut_arrays A, unsigned int *__restrict__ newly_done) {
-    uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t fin = 0;
-    if (f < 2 * A.n && !(A.nflags[f] & UT_DONE)) {
-        unsigned long long me = __hip_atomic_load(&A.pk[f], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t p = (uint32_t)me, d = (uint32_t)(me >> 32);
-        if (A.nflags[p] & UT_START) { A.nflags[f] |= UT_DONE; fin = 1; }
-        else {
-            unsigned long long up = __hip_atomic_load(&A.pk[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            uint32_t pp = (uint32_t)up, dd = (uint32_t)(up >> 32);
-            __hip_atomic_store(&A.pk[f], (unsigned long long)pp | ((unsigned long long)(d + dd) << 32), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            if (A.nflags[pp] & UT_START) { A.nflags[f] |= UT_DONE; fin = 1; }
-        }
+// walk item: a path being followed from `start` (slot = its index in starts[]), currently at `node`, `dist` hops in
+struct ut_item { uint32_t node, slot, dist; };
+struct ut_walk_out {
+    uint32_t *end_node;       // [n_starts] last node of the path
+    uint32_t *end_dist;       // [n_starts] its distance from the start
+    ut_item *cont; unsigned int *n_cont;
+};
+template <bool FIRST>
+__global__ void k_ut_walk(ut_arrays A, const ut_item *__restrict__ items, uint32_t n_items, ut_walk_out W) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_items) return;
+    uint32_t f, slot, d;
+    if (FIRST) { f = A.starts[t]; slot = t; d = 0; }
+    else { ut_item it = items[t]; f = it.node; slot = it.slot; d = it.dist; }
+    const uint32_t s = A.starts[slot];
+    for (int step = 0; step < UT_WALK_CHUNK; step++) {
+        A.pk[f] = (unsigned long long)s | ((unsigned long long)d << 32);
+        uint32_t g = A.succ[f];
+        if (g == UT_NONE) { W.end_node[slot] = f; W.end_dist[slot] = d; return; }
+        f = g; d++;
     }
-    unsigned long long b = __ballot(fin);
-    if (mf_lane() == 0 && b) atomicAdd(newly_done, (unsigned int)__popcll(b));
+    uint32_t c = atomicAdd(W.n_cont, 1u);
+    W.cont[c].node = f; W.cont[c].slot = slot; W.cont[c].dist = d;
 }
 
 // PASS 0: equal-case arbitration (atomicMin of the start node id per start k-mer), count candidates
@@ -142,14 +164,12 @@ struct ut_paths {
     unsigned int *cursor;
 };
 template <int PASS>
-__global__ void k_ut_ends(ut_arrays A, ut_paths P, int min_len) {
-    uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= 2 * A.n) return;
-    uint8_t nf = A.nflags[f];
-    if (!(nf & UT_DONE) || (nf & UT_HASOUT)) return;       // only path ends whose start is known
-    uint32_t i = (uint32_t)(f >> 1), o = (uint32_t)(f & 1);
-    unsigned long long me = A.pk[f];
-    uint32_t s = (uint32_t)me, dist = (uint32_t)(me >> 32);
+__global__ void k_ut_ends(ut_arrays A, ut_paths P, const uint32_t *__restrict__ end_node, const uint32_t *__restrict__ end_dist,
+                          uint32_t n_starts, int min_len) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_starts) return;
+    const uint32_t s = A.starts[t], f = end_node[t], dist = end_dist[t];
+    uint32_t i = f >> 1, o = f & 1u;
     uint64_t len_nt = (uint64_t)dist + (uint64_t)A.k;
     if ((int64_t)len_nt < (int64_t)min_len) return;
     uint8_t info = A.info[i];
@@ -185,8 +205,8 @@ struct ut_out {
 __global__ void k_ut_emit(ut_arrays A, const uint32_t *__restrict__ pidmap, const uint32_t *__restrict__ dup, ut_out O) {
     uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= 2 * A.n) return;
-    if (!(A.nflags[f] & UT_DONE)) return;
     unsigned long long me = A.pk[f];
+    if (me == UT_UNSEEN) return;
     uint32_t s = (uint32_t)me, dist = (uint32_t)(me >> 32);
     uint32_t pid = pidmap[s];
     if (pid == UT_NONE) return;
@@ -248,13 +268,16 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
     int rc = MF_OK;
     do {
         if ((rc = mf_table_ensure_index(g)) < 0) break;
-        mf_buf<uint8_t> info, nflags, pal; mf_buf<uint32_t> ridx, lidx, eqmin, pidmap; mf_buf<unsigned long long> pk;
+        mf_buf<uint8_t> info, pal; mf_buf<uint32_t> ridx, lidx, eqmin, pidmap, succ, starts; mf_buf<unsigned long long> pk;
         mf_buf<unsigned int> ctr;
         if ((rc = info.alloc(ctx, n)) < 0 || (rc = ridx.alloc(ctx, n)) < 0 || (rc = lidx.alloc(ctx, n)) < 0 ||
-            (rc = pk.alloc(ctx, 2 * n)) < 0 || (rc = nflags.alloc(ctx, 2 * n)) < 0 || (rc = ctr.alloc(ctx, 4)) < 0) break;
+            (rc = pk.alloc(ctx, 2 * n)) < 0 || (rc = succ.alloc(ctx, 2 * n)) < 0 || (rc = starts.alloc(ctx, 2 * n)) < 0 ||
+            (rc = ctr.alloc(ctx, 4)) < 0) break;
+        hipMemsetAsync(ctr.p, 0, 16, st);
+        hipMemsetAsync(pk.p, 0xFF, 2 * n * 8, st);
         ut_arrays A;
         A.gk = g->d_keys; A.gv = g->d_counts; A.n = n; A.k = k;
-        A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.pk = pk.p; A.nflags = nflags.p;
+        A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.pk = pk.p; A.succ = succ.p; A.starts = starts.p; A.n_starts = &ctr.p[1];
         A.pal = nullptr;
         if ((k & 1) == 0) { if ((rc = pal.alloc(ctx, n)) < 0) break; A.pal = pal.p; }   // palindromes need an even k
         {
@@ -263,34 +286,52 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         }
         {
             mf_ktimer tm(ctx, "k_ut_links");
-            k_ut_links<<<grid_for(2 * n), 256, 0, st>>>(A);
+            k_ut_links<<<grid_for(2 * n, 1024), 1024, 0, st>>>(A);
         }
-        // U3: rounds until a round finishes no node (then only cycle nodes are left)
+        unsigned int n_starts = 0;
+        if (hipMemcpyAsync(&n_starts, &ctr.p[1], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+            rc = mf_set_error("unitigs: links pass failed: %s", hipGetErrorString(hipGetLastError())); break;
+        }
+        // U3: chunked walks from the start nodes
+        mf_buf<uint32_t> end_node, end_dist; mf_buf<ut_item> contA, contB;
+        if ((rc = end_node.alloc(ctx, n_starts)) < 0 || (rc = end_dist.alloc(ctx, n_starts)) < 0) break;
         int rounds = 0;
-        for (;;) {
-            hipMemsetAsync(ctr.p, 0, 4, st);
+        if (n_starts) {
+            if ((rc = contA.alloc(ctx, n_starts)) < 0) break;
+            ut_walk_out W; W.end_node = end_node.p; W.end_dist = end_dist.p; W.cont = contA.p; W.n_cont = &ctr.p[2];
             {
-                mf_ktimer tm(ctx, "k_ut_jump");
-                k_ut_jump<<<grid_for(2 * n), 256, 0, st>>>(A, ctr.p);
+                mf_ktimer tm(ctx, "k_ut_walk");
+                k_ut_walk<true><<<grid_for(n_starts), 256, 0, st>>>(A, nullptr, n_starts, W);
             }
-            unsigned int nd = 0;
-            if (hipMemcpyAsync(&nd, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-                rc = mf_set_error("unitigs: jump round failed"); break;
+            rounds = 1;
+            for (;;) {
+                unsigned int n_cont = 0;
+                if (hipMemcpyAsync(&n_cont, &ctr.p[2], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                    rc = mf_set_error("unitigs: walk failed: %s", hipGetErrorString(hipGetLastError())); break;
+                }
+                if (!n_cont) break;
+                if (!contB.p && (rc = contB.alloc(ctx, n_cont)) < 0) break;
+                hipMemsetAsync(&ctr.p[2], 0, 4, st);
+                ut_item *in = (rounds & 1) ? contA.p : contB.p;
+                W.cont = (rounds & 1) ? contB.p : contA.p;
+                {
+                    mf_ktimer tm(ctx, "k_ut_walk");
+                    k_ut_walk<false><<<grid_for(n_cont), 256, 0, st>>>(A, in, n_cont, W);
+                }
+                rounds++;
             }
-            rounds++;
-            if (nd == 0) break;
-            if (rounds > 64) { rc = mf_set_error("unitigs: pointer jumping did not converge"); break; }
+            if (rc < 0) break;
         }
-        if (rc < 0) break;
+        contA.reset(); contB.reset(); succ.reset();
         // U4
         if ((rc = eqmin.alloc(ctx, n)) < 0 || (rc = pidmap.alloc(ctx, 2 * n)) < 0) break;
         k_fill_u32<<<std::min(grid_for(n), 65536u), 256, 0, st>>>(eqmin.p, n, UT_NONE);
         k_fill_u32<<<std::min(grid_for(2 * n), 65536u), 256, 0, st>>>(pidmap.p, 2 * n, UT_NONE);
         hipMemsetAsync(ctr.p, 0, 4, st);
         ut_paths P; P.eqmin = eqmin.p; P.pidmap = pidmap.p; P.plen = nullptr; P.pkey = nullptr; P.dup = nullptr; P.cursor = ctr.p;
-        {
+        if (n_starts) {
             mf_ktimer tm(ctx, "k_ut_ends");
-            k_ut_ends<0><<<grid_for(2 * n), 256, 0, st>>>(A, P, min_len);
+            k_ut_ends<0><<<grid_for(n_starts), 256, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
         }
         unsigned int ncand = 0;
         if (hipMemcpyAsync(&ncand, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
@@ -300,14 +341,15 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if ((rc = plen.alloc(ctx, ncand)) < 0 || (rc = pkey.alloc(ctx, ncand)) < 0 || (rc = dup.alloc(ctx, ncand)) < 0) break;
         hipMemsetAsync(ctr.p, 0, 4, st);
         P.plen = plen.p; P.pkey = pkey.p; P.dup = dup.p;
-        {
+        if (n_starts) {
             mf_ktimer tm(ctx, "k_ut_ends");
-            k_ut_ends<1><<<grid_for(2 * n), 256, 0, st>>>(A, P, min_len);
+            k_ut_ends<1><<<grid_for(n_starts), 256, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
         }
         unsigned int np = 0;
         if (hipMemcpyAsync(&np, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = mf_set_error("unitigs: ends pass failed"); break;
         }
+        ridx.reset(); lidx.reset(); end_node.reset(); end_dist.reset(); eqmin.reset();
         // U5
         mf_buf<uint64_t> off, tot; mf_buf<unsigned long long> wsum; mf_buf<int32_t> wmin, wmax, wavg;
         if ((rc = off.alloc(ctx, (size_t)np + 1)) < 0 || (rc = tot.alloc(ctx, 1)) < 0 || (rc = wsum.alloc(ctx, np)) < 0 ||
@@ -332,8 +374,8 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         }
         if (hipStreamSynchronize(st) != hipSuccess) { rc = mf_set_error("unitigs: emit failed: %s", hipGetErrorString(hipGetLastError())); break; }
         if (ctx->opt_verbose)
-            fprintf(stderr, "[mf] unitigs: good=%llu rounds=%d candidates=%u paths=%u bases=%llu\n", (unsigned long long)n, rounds,
-                    ncand, np, (unsigned long long)total);
+            fprintf(stderr, "[mf] unitigs: good=%llu starts=%u walk_rounds=%d candidates=%u paths=%u bases=%llu\n", (unsigned long long)n,
+                    n_starts, rounds, ncand, np, (unsigned long long)total);
         S->n = np; S->n_bases = total;
         S->bases_bytes = bases.bytes(); S->d_bases = bases.take();
         S->offsets_bytes = off.bytes(); S->d_offsets = off.take();
