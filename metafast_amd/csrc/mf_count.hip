@@ -104,6 +104,39 @@ __device__ __forceinline__ void mf_word_kmers(const uint8_t *__restrict__ bases,
     }
 }
 
+// Same walk, handing the k-mers to f in groups of 4: f(keys[4], valid[4]) is called 8 times.
+template <typename F>
+__device__ __forceinline__ void mf_word_kmers4(const uint8_t *__restrict__ bases, uint64_t n_bases, uint64_t w,
+                                               uint32_t m, int k, F &&f) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(bases + w * 32);
+    uint64_t b0 = w * 32;
+    uint4 z = make_uint4(0, 0, 0, 0);
+    uint4 c0 = (b0 < n_bases) ? p[0] : z;
+    uint4 c1 = (b0 + 16 < n_bases) ? p[1] : z;
+    uint4 c2 = (b0 + 32 < n_bases) ? p[2] : z;
+    uint4 c3 = (b0 + 48 < n_bases) ? p[3] : z;
+    uint64_t W0 = ((uint64_t)mf_dec16(c0) << 32) | mf_dec16(c1);
+    uint64_t W1 = ((uint64_t)mf_dec16(c2) << 32) | mf_dec16(c3);
+    const int sh = 64 - 2 * k;
+    const int top = 2 * k - 2;
+    uint64_t fw = W0 >> sh;
+    uint64_t rc = mf_revcomp(fw, k);
+#pragma unroll 2
+    for (int j = 0; j < 32; j += 4) {
+        uint64_t keys[4]; bool valid[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            keys[u] = fw < rc ? fw : rc;
+            valid[u] = (bool)((m >> (j + u)) & 1u);
+            W0 = (W0 << 2) | (W1 >> 62);
+            W1 <<= 2;
+            fw = W0 >> sh;
+            rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fw & 3u)) << top);
+        }
+        f(keys, valid);
+    }
+}
+
 __device__ __forceinline__ uint32_t mf_digit(uint64_t h, int shift_hi, int bits) {
     // digit = bits [64-shift_hi-bits, 64-shift_hi) of h, i.e. skip the shift_hi top bits already used
     return bits ? (uint32_t)((h << shift_hi) >> (64 - bits)) : 0u;
@@ -182,6 +215,53 @@ __device__ __forceinline__ void mf_stage_insert(const mf_stage &L, uint64_t *__r
         __builtin_amdgcn_wave_barrier();
     }
 }
+// Same protocol for MF_B elements per lane at once: the peek / reserve / write / commit steps of the MF_B
+// independent elements are issued back to back, so their LDS round trips overlap instead of adding up
+// (with one element per call the kernel is bound by three dependent LDS latencies per k-mer).
+#define MF_B 4
+__device__ __forceinline__ void mf_stage_insert_batch(const mf_stage &L, uint64_t *__restrict__ out, const uint32_t (&d)[MF_B],
+                                                      const uint64_t (&key)[MF_B], bool (&pending)[MF_B]) {
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < MF_B; b++) any |= pending[b];
+        if (__ballot(any) == 0ull) break;
+        uint32_t w[MF_B], r[MF_B];
+        bool got[MF_B];
+#pragma unroll
+        for (int b = 0; b < MF_B; b++) w[b] = pending[b] ? __hip_atomic_load(&L.ctr[d[b]], __ATOMIC_RELAXED, MF_WG) : 0xFFFFu;
+#pragma unroll
+        for (int b = 0; b < MF_B; b++) {
+            got[b] = false; r[b] = 0;
+            if (pending[b] && (w[b] & 0xFFFFu) < (uint32_t)MF_LINE) {
+                uint32_t old = __hip_atomic_fetch_add(&L.ctr[d[b]], 1u, __ATOMIC_RELAXED, MF_WG);
+                r[b] = old & 0xFFFFu;
+                got[b] = r[b] < (uint32_t)MF_LINE;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < MF_B; b++)
+            if (got[b]) L.line[d[b] * MF_LINE + r[b]] = key[b];
+#pragma unroll
+        for (int b = 0; b < MF_B; b++) {
+            if (got[b]) {
+                uint32_t old2 = __hip_atomic_fetch_add(&L.ctr[d[b]], 0x10000u, __ATOMIC_ACQ_REL, MF_WG);
+                if ((old2 >> 16) == (uint32_t)(MF_LINE - 1)) {
+                    uint64_t pos = L.cur[d[b]];
+                    L.cur[d[b]] = pos + MF_LINE;
+                    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(&L.line[d[b] * MF_LINE]);
+                    ulonglong2 a = s[0], bb = s[1], c = s[2], e = s[3];
+                    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + pos);
+                    o[0] = a; o[1] = bb; o[2] = c; o[3] = e;
+                    __hip_atomic_store(&L.ctr[d[b]], 0u, __ATOMIC_RELEASE, MF_WG);
+                }
+                pending[b] = false;
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
 // after a barrier: write every partly filled line, padding with the sentinel
 __device__ __forceinline__ void mf_stage_flush_all(const mf_stage &L, uint64_t *__restrict__ out, int nd) {
     for (int d = threadIdx.x; d < nd; d += blockDim.x) {
@@ -223,12 +303,18 @@ __global__ __launch_bounds__(1024) void k_l1_scatter(const uint8_t *__restrict__
     for (uint64_t w = wlo + threadIdx.x; w < whi; w += blockDim.x) {
         uint32_t m = vmask[w];
         if (!m) continue;
-        mf_word_kmers(bases, n_bases, w, m, k, [&](int, uint64_t key, bool valid) {
-            uint32_t d = mf_digit(mf_hash64(key), 0, bits);
-            if (STAGED) mf_stage_insert(L, out, d, key, valid);
-            else if (valid) {
-                uint64_t pos = atomicAdd(reinterpret_cast<unsigned long long *>(&L.cur[d]), 1ull);
-                out[pos] = key;
+        mf_word_kmers4(bases, n_bases, w, m, k, [&](const uint64_t (&keys)[4], bool (&valid)[4]) {
+            uint32_t d[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) d[u] = mf_digit(mf_hash64(keys[u]), 0, bits);
+            if (STAGED) mf_stage_insert_batch(L, out, d, keys, valid);
+            else {
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (valid[u]) {
+                        uint64_t pos = atomicAdd(reinterpret_cast<unsigned long long *>(&L.cur[d[u]]), 1ull);
+                        out[pos] = keys[u];
+                    }
             }
         });
     }
@@ -317,17 +403,19 @@ __global__ __launch_bounds__(1024) void k_split(const uint64_t *__restrict__ in,
                 v[u] = j < npairs ? in2[j] : make_ulonglong2(MF_EMPTY, MF_EMPTY);
             }
 #pragma unroll
-            for (int u = 0; u < MF_MLP; u++) {
+            for (int u = 0; u < MF_MLP; u += 2) {
+                uint64_t keys[4] = {v[u].x, v[u].y, v[u + 1].x, v[u + 1].y};
+                uint32_t d[4]; bool valid[4];
 #pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    uint64_t key = h ? v[u].y : v[u].x;
-                    bool valid = key != MF_EMPTY;
-                    uint32_t d = mf_digit(mf_hash64(key), bits_used, bits);
-                    if (STAGED) mf_stage_insert(L, out, d, key, valid);
-                    else if (valid) {
-                        uint64_t pos = atomicAdd(reinterpret_cast<unsigned long long *>(&L.cur[d]), 1ull);
-                        out[pos] = key;
-                    }
+                for (int q = 0; q < 4; q++) { valid[q] = keys[q] != MF_EMPTY; d[q] = mf_digit(mf_hash64(keys[q]), bits_used, bits); }
+                if (STAGED) mf_stage_insert_batch(L, out, d, keys, valid);
+                else {
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (valid[q]) {
+                            uint64_t pos = atomicAdd(reinterpret_cast<unsigned long long *>(&L.cur[d[q]]), 1ull);
+                            out[pos] = keys[q];
+                        }
                 }
             }
         }
@@ -347,75 +435,121 @@ __global__ __launch_bounds__(1024) void k_split(const uint64_t *__restrict__ in,
 // K3: hash-count one partition at a time in LDS, compact in place
 // =============================================================================================
 // keys[start .. start+len) (with sentinels) -> keys[start .. start+d) distinct, cnt[start .. start+d) counts.
-// 256-thread workgroups with a 48 KiB table so that three of them share a CU: while one waits for its
-// partition to arrive from HBM the others probe.
+// 256-thread workgroups with a 48 KiB table so that three of them share a CU.  The first MF_PF*2*256 keys of the
+// NEXT partition are loaded into registers while the current one is being counted, so the HBM latency of a
+// partition (one per ~3 k k-mers) is hidden behind the LDS work of the previous one.
+#define MF_PF 6            // 16-byte prefetch loads per thread: 12 keys x 256 threads = 3072 keys
+__device__ __forceinline__ void mf_count_insert(uint64_t *tk, uint32_t *tc, uint32_t mask, uint32_t slots, uint64_t key, uint32_t s,
+                                                unsigned int *overflow) {
+    uint32_t probes = 0;
+    for (;;) {
+        uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tk[s]);
+        if (cur == MF_EMPTY) {
+            cur = atomicCAS(reinterpret_cast<unsigned long long *>(&tk[s]), (unsigned long long)MF_EMPTY, (unsigned long long)key);
+            if (cur == MF_EMPTY) cur = key;
+        }
+        if (cur == key) { atomicAdd(&tc[s], 1u); return; }
+        s = (s + 1) & mask;
+        if (++probes > slots) { atomicExch(overflow, 1u); return; }
+    }
+}
+// four keys at a time: the four first-probe reads are in flight together; a hit is one fire-and-forget LDS add
+__device__ __forceinline__ void mf_count_insert4(uint64_t *tk, uint32_t *tc, uint32_t mask, uint32_t slots, const uint64_t (&key)[4],
+                                                 unsigned int *overflow) {
+    uint32_t s[4]; uint64_t cur[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) s[b] = (uint32_t)mf_hash64(key[b]) & mask;
+#pragma unroll
+    for (int b = 0; b < 4; b++) cur[b] = *reinterpret_cast<volatile uint64_t *>(&tk[s[b]]);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        if (key[b] == MF_EMPTY) continue;
+        if (cur[b] == key[b]) atomicAdd(&tc[s[b]], 1u);
+        else mf_count_insert(tk, tc, mask, slots, key[b], s[b], overflow);
+    }
+}
 __global__ __launch_bounds__(256) void k_count(uint64_t *__restrict__ keys, uint16_t *__restrict__ cnt,
                                                const uint64_t *__restrict__ pstart, const uint32_t *__restrict__ plen,
                                                uint32_t np, uint32_t *__restrict__ dcount,
                                                unsigned int *__restrict__ overflow) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t scratch[17];
+    __shared__ uint32_t out_cursor;
     uint64_t *tk = reinterpret_cast<uint64_t *>(smem);                    // [MF_COUNT_SLOTS]
     uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS);     // [MF_COUNT_SLOTS]
-    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
-        const uint64_t start = pstart[p];
-        const uint32_t len = plen[p];
+    const ulonglong2 EE = make_ulonglong2(MF_EMPTY, MF_EMPTY);
+    uint32_t p = blockIdx.x;
+    if (p >= np) return;
+    uint64_t start = pstart[p];
+    uint32_t len = plen[p];
+    ulonglong2 R[MF_PF];
+    {
+        const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(keys + start);
+        const uint32_t npairs = len >> 1;
+#pragma unroll
+        for (int u = 0; u < MF_PF; u++) { uint32_t j = u * blockDim.x + threadIdx.x; R[u] = j < npairs ? in2[j] : EE; }
+    }
+    for (;;) {
+        const uint32_t pn = p + gridDim.x;
+        uint64_t start_n = 0; uint32_t len_n = 0;
+        if (pn < np) { start_n = pstart[pn]; len_n = plen[pn]; }
         // table size: power of two >= 9/8 * len, in [blockDim, MF_COUNT_SLOTS]
         uint32_t want = len + len / 8 + 1;
         uint32_t slots = blockDim.x;
         while (slots < want && slots < (uint32_t)MF_COUNT_SLOTS) slots <<= 1;
         const uint32_t mask = slots - 1;
         for (uint32_t i = threadIdx.x; i < slots; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
+        if (threadIdx.x == 0) out_cursor = 0;
         __syncthreads();
-        const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(keys + start);
-        const uint32_t npairs = len >> 1;
-        for (uint32_t jb = 0; jb < npairs; jb += MF_MLP * blockDim.x) {
-            ulonglong2 v[MF_MLP];
+        // take over the prefetched keys, then start fetching the next partition
+        ulonglong2 K[MF_PF];
 #pragma unroll
-            for (int u = 0; u < MF_MLP; u++) {
-                uint32_t j = jb + u * blockDim.x + threadIdx.x;
-                v[u] = j < npairs ? in2[j] : make_ulonglong2(MF_EMPTY, MF_EMPTY);
+        for (int u = 0; u < MF_PF; u++) K[u] = R[u];
+        if (pn < np) {
+            const ulonglong2 *nx2 = reinterpret_cast<const ulonglong2 *>(keys + start_n);
+            const uint32_t npairs_n = len_n >> 1;
+#pragma unroll
+            for (int u = 0; u < MF_PF; u++) { uint32_t j = u * blockDim.x + threadIdx.x; R[u] = j < npairs_n ? nx2[j] : EE; }
+        }
+#pragma unroll
+        for (int u = 0; u < MF_PF; u += 2) {
+            uint64_t k4[4] = {K[u].x, K[u].y, K[u + 1].x, K[u + 1].y};
+            mf_count_insert4(tk, tc, mask, slots, k4, overflow);
+        }
+        {   // partitions longer than the prefetch window (heavy hitters): the rest straight from HBM
+            const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(keys + start);
+            const uint32_t npairs = len >> 1;
+            for (uint32_t jb = MF_PF * blockDim.x; jb < npairs; jb += 2 * blockDim.x) {
+                uint32_t j0 = jb + threadIdx.x, j1 = j0 + blockDim.x;
+                ulonglong2 a = j0 < npairs ? in2[j0] : EE, b = j1 < npairs ? in2[j1] : EE;
+                uint64_t k4[4] = {a.x, a.y, b.x, b.y};
+                mf_count_insert4(tk, tc, mask, slots, k4, overflow);
             }
-#pragma unroll
-            for (int u = 0; u < MF_MLP; u++) {
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    uint64_t key = h ? v[u].y : v[u].x;
-                    if (key == MF_EMPTY) continue;
-                    uint32_t s = (uint32_t)mf_hash64(key) & mask;
-                    uint32_t probes = 0;
-                    for (;;) {
-                        uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tk[s]);
-                        if (cur == MF_EMPTY) {
-                            cur = atomicCAS(reinterpret_cast<unsigned long long *>(&tk[s]), (unsigned long long)MF_EMPTY,
-                                            (unsigned long long)key);
-                            if (cur == MF_EMPTY) cur = key;
-                        }
-                        if (cur == key) { atomicAdd(&tc[s], 1u); break; }
-                        s = (s + 1) & mask;
-                        if (++probes > slots) { atomicExch(overflow, 1u); break; }
-                    }
+        }
+        __syncthreads();
+        // compaction: each wave walks 64-slot chunks (lane = slot: conflict-free LDS reads; a per-thread run of 16
+        // consecutive slots is a 128-byte lane stride = 32-way bank conflict and made this phase dominate the kernel)
+        // and appends the occupied ones behind a cursor in LDS; the order inside a partition does not matter
+        for (uint32_t base = (threadIdx.x >> 6) << 6; base < slots; base += blockDim.x) {
+            const uint32_t sl = base + (uint32_t)mf_lane();
+            const uint64_t key = tk[sl];
+            const bool has = key != MF_EMPTY;
+            const unsigned long long b = __ballot(has);
+            if (b) {
+                uint32_t wb = 0;
+                if (mf_lane() == 0) wb = atomicAdd(&out_cursor, (uint32_t)__popcll(b));
+                wb = __shfl(wb, 0, 64);
+                if (has) {
+                    const uint32_t pos = wb + (uint32_t)__popcll(b & ((1ull << mf_lane()) - 1ull));
+                    const uint32_t v = tc[sl];
+                    keys[start + pos] = key;
+                    cnt[start + pos] = (uint16_t)(v > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : v);
                 }
             }
         }
         __syncthreads();
-        // compaction: thread t owns slots [t*spt, (t+1)*spt)
-        const uint32_t spt = slots / blockDim.x;   // >= 1
-        uint32_t s0 = threadIdx.x * spt, c = 0;
-        for (uint32_t j = 0; j < spt; j++) c += tk[s0 + j] != MF_EMPTY;
-        uint32_t tot;
-        uint32_t ex = mf_block_excl_scan(c, scratch, &tot);
-        for (uint32_t j = 0; j < spt; j++) {
-            uint64_t key = tk[s0 + j];
-            if (key != MF_EMPTY) {
-                uint32_t v = tc[s0 + j];
-                keys[start + ex] = key;
-                cnt[start + ex] = (uint16_t)(v > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : v);
-                ex++;
-            }
-        }
-        if (threadIdx.x == 0) dcount[p] = tot;
-        __syncthreads();
+        if (threadIdx.x == 0) dcount[p] = out_cursor;
+        if (pn >= np) break;
+        p = pn; start = start_n; len = len_n;
     }
 }
 
