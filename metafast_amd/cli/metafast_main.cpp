@@ -1,0 +1,449 @@
+// metafast_main.cpp -- metafast.sh-compatible command line driver for the MI355X hot path.
+//
+// Host-side mirror (C++; the image has no JDK) of the reference's tool shells for this path, on top of the C-ABI only
+// (include/metafast_hip.h):
+//   src/Runner.java:27-30 + itmo!/Runner.java:108-182          tool registry, -t/--tool, -ts/--tools, --version, default matrix-builder
+//   itmo!/utils/tool/Tool.java:61-143, 212-214, 318-392        launch options (-w -p -c --force -s -f -v -h), <workDir>/<tool>/, SUCCESS
+//   src/tools/KmersCounterMain.java, KmersCounterForManyFilesMain.java, SeqBuilderMain.java, SeqBuilderForManyFilesMain.java,
+//   ComponentCutterMain.java, FeaturesCalculatorMain.java, DistanceMatrixCalculatorMain.java, DistanceMatrixBuilderMain.java
+// Parameter names, defaults, output file names and the workDir layout are the reference's; the Tool
+// framework itself (in/out.properties, interactive prompts, log4j) is not reproduced.  Errors: message on stderr, exit 1.
+#include <algorithm>
+#include <cerrno>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <map>
+#include <set>
+#include <string>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <vector>
+#include "../../include/metafast_hip.h"
+
+using std::string;
+using std::vector;
+
+// ------------------------------------------------------------------------------------------------ utilities
+static bool g_verbose = false;
+static FILE *g_logfile = nullptr;
+static void logmsg(const char *level, const char *fmt, ...) {
+    char buf[4096];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    bool debug = !strcmp(level, "DEBUG");
+    if (!debug || g_verbose) fprintf(stderr, "%s: %s\n", level, buf);
+    if (g_logfile) { fprintf(g_logfile, "%s: %s\n", level, buf); fflush(g_logfile); }
+}
+[[noreturn]] static void die(const char *fmt, ...) {
+    char buf[4096];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    logmsg("ERROR", "%s", buf);
+    exit(1);                                            // Tool.java:450-463: ExecutionFailedException -> exit code 1
+}
+static void check(int rc) { if (rc < 0) die("%s", mf_last_error()); }
+static bool exists(const string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
+static bool is_dir(const string &p) { struct stat st; return stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode); }
+static void mkdirs(const string &p) {
+    string cur;
+    for (size_t i = 0; i <= p.size(); i++) {
+        if (i == p.size() || p[i] == '/') { if (!cur.empty() && !is_dir(cur) && mkdir(cur.c_str(), 0777) != 0 && errno != EEXIST) die("can't create directory %s", cur.c_str()); }
+        if (i < p.size()) cur.push_back(p[i]);
+    }
+}
+static string basename_of(const string &p) { size_t s = p.find_last_of('/'); return s == string::npos ? p : p.substr(s + 1); }
+static bool ends_with_ci(const string &s, const string &suf) {
+    if (suf.size() > s.size()) return false;
+    for (size_t i = 0; i < suf.size(); i++) if (tolower((unsigned char)s[s.size() - suf.size() + i]) != tolower((unsigned char)suf[i])) return false;
+    return true;
+}
+// FileUtils.removeExtension (itmo!/utils/FileUtils.java:199-210): first matching extension only
+static string remove_ext(const string &s, std::initializer_list<const char *> exts) {
+    for (const char *e : exts) { string x = e[0] == '.' ? e : string(".") + e; if (ends_with_ci(s, x)) return s.substr(0, s.size() - x.size()); }
+    return s;
+}
+// NamedSource.name(): FastaReader.java:22 / FastqReader.java:25
+static string library_name(const string &path) {
+    string b = basename_of(path);
+    if (ends_with_ci(b, ".fastq") || ends_with_ci(b, ".fq")) return remove_ext(b, {".fastq", ".fq"});
+    return remove_ext(b, {".fasta", ".fa", ".fn", ".fna"});
+}
+static string timestamp() {                                 // Tool.java:664 "yyyy.MM.dd_HH.mm.ss"
+    time_t t = time(nullptr); struct tm tmv; localtime_r(&t, &tmv);
+    char b[64]; strftime(b, sizeof b, "%Y.%m.%d_%H.%M.%S", &tmv);
+    return b;
+}
+static void touch(const string &p) { FILE *f = fopen(p.c_str(), "w"); if (f) fclose(f); }
+static string group_digits(uint64_t v) {                    // NumUtils.groupDigits: 1'234'567
+    string s = std::to_string(v), o;
+    for (size_t i = 0; i < s.size(); i++) { o.push_back(s[i]); size_t r = s.size() - 1 - i; if (r && r % 3 == 0) o.push_back('\''); }
+    return o;
+}
+
+// ------------------------------------------------------------------------------------------------ argument parsing
+struct Args {
+    std::map<string, vector<string>> opt;      // canonical long name -> values
+    bool has(const string &k) const { return opt.count(k) > 0; }
+    string get(const string &k, const string &def = "") const { auto it = opt.find(k); return it == opt.end() || it->second.empty() ? def : it->second[0]; }
+    int geti(const string &k, int def) const {
+        auto it = opt.find(k); if (it == opt.end() || it->second.empty()) return def;
+        char *e; long v = strtol(it->second[0].c_str(), &e, 10); if (*e) die("Can't parse integer value '%s' of option --%s", it->second[0].c_str(), k.c_str());
+        return (int)v;
+    }
+    vector<string> list(const string &k) const { auto it = opt.find(k); return it == opt.end() ? vector<string>() : it->second; }
+};
+struct OptDef { const char *lng; const char *sht; bool multi; bool flag; };
+// every option of the tools on the path (short names as in the reference; note --maximal-bad-frequence in the counters,
+// KmersCounterMain.java:40, vs --maximal-bad-frequency elsewhere)
+static const OptDef OPTS[] = {
+    {"tool", "t", false, false}, {"tools", "ts", false, true}, {"version", "", false, true}, {"work-dir", "w", false, false},
+    {"available-processors", "p", false, false}, {"continue", "c", false, true}, {"force", "", false, true},
+    {"start", "s", false, false}, {"finish", "f", false, false}, {"verbose", "v", false, true}, {"help", "h", false, true},
+    {"help-all", "ha", false, true}, {"memory", "m", false, false},
+    {"k", "k", false, false}, {"reads", "i", true, false}, {"k-mers", "i", true, false}, {"sequences", "i", true, false},
+    {"maximal-bad-frequence", "b", false, false}, {"maximal-bad-frequency", "b", false, false},
+    {"bottom-cut-percent", "bp", false, false}, {"sequence-len", "l", false, false}, {"min-seq-len", "l", false, false},
+    {"output-dir", "o", false, false}, {"stats-dir", "", false, false},
+    {"min-component-size", "b1", false, false}, {"max-component-size", "b2", false, false}, {"components-file", "cm", false, false},
+    {"kmers", "ka", true, false}, {"selected", "", true, false}, {"threshold", "", false, false},
+    {"features", "", true, false}, {"without-names", "wn", false, true}, {"matrix-file", "", false, false},
+    {"output-format", "", false, false}, {"heatmap-file", "", false, false},
+    {"use-reads-for-calculating-features", "", false, true}, {"device", "", false, false},
+};
+// `ctx_i` says what -i means for the selected tool
+static Args parse_args(int argc, char **argv, string *tool_out) {
+    // first pass: find the tool (needed to resolve the overloaded short options)
+    string tool = "matrix-builder";                                         // src/Runner.java:29
+    for (int i = 1; i + 1 < argc; i++) if (!strcmp(argv[i], "-t") || !strcmp(argv[i], "--tool")) tool = argv[i + 1];
+    *tool_out = tool;
+    auto long_of_short = [&](const string &s) -> string {
+        if (s == "i") {
+            if (tool == "seq-builder" || tool == "seq-builder-many") return "k-mers";
+            if (tool == "component-cutter") return "sequences";
+            return "reads";
+        }
+        if (s == "b") return (tool == "kmer-counter" || tool == "kmer-counter-many") ? "maximal-bad-frequence" : "maximal-bad-frequency";
+        if (s == "l") return (tool == "seq-builder" || tool == "seq-builder-many") ? "sequence-len" : "min-seq-len";
+        for (auto &o : OPTS) if (o.sht[0] && s == o.sht) return o.lng;
+        return "";
+    };
+    Args a;
+    for (int i = 1; i < argc;) {
+        string tok = argv[i];
+        // launcher-level options handled by stub.sh in the reference (src/stub.sh:6-19): accepted and ignored
+        if (tok == "-ea" || tok.rfind("-X", 0) == 0 || tok.rfind("-agentlib:", 0) == 0) { i++; continue; }
+        string name;
+        if (tok.rfind("--", 0) == 0) name = tok.substr(2);
+        else if (tok.size() > 1 && tok[0] == '-') name = long_of_short(tok.substr(1));
+        else die("Unknown argument '%s'", tok.c_str());
+        const OptDef *def = nullptr;
+        for (auto &o : OPTS) if (name == o.lng) def = &o;
+        if (!def) die("Unrecognized option: %s", tok.c_str());
+        i++;
+        auto &vals = a.opt[name];
+        if (def->flag) {                                                    // booleans take an optional true/false (Parameter.java:51-58)
+            if (i < argc && (!strcmp(argv[i], "true") || !strcmp(argv[i], "false"))) { vals.push_back(argv[i]); i++; }
+            else vals.push_back("true");
+            continue;
+        }
+        if (i >= argc) die("Missing argument for option: %s", tok.c_str());
+        if (def->multi) { while (i < argc && !(argv[i][0] == '-' && strlen(argv[i]) > 1 && !isdigit((unsigned char)argv[i][1]))) vals.push_back(argv[i++]); }
+        else vals.push_back(argv[i++]);
+    }
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------------ tools
+struct Env {
+    mf_ctx *ctx = nullptr;
+    string work_dir;
+    bool cont = false;
+    string start_ts;
+};
+static mf_ctx *ctx_of(Env &e, const Args &a) {
+    if (!e.ctx) check(mf_ctx_create(a.geti("device", 0), a.geti("available-processors", (int)sysconf(_SC_NPROCESSORS_ONLN)), &e.ctx));
+    return e.ctx;
+}
+static vector<const char *> cptrs(const vector<string> &v) { vector<const char *> p; for (auto &s : v) p.push_back(s.c_str()); return p; }
+static void check_k(int k) {                                                 // KmersCounterMain.java:66-73
+    if (k <= 0) die("The size of k-mer must be at least 1.");
+    if (k > 31) die("The size of k-mer must be no more than 31.");
+}
+
+// kmer-counter (src/tools/KmersCounterMain.java:65-137)
+static string run_kmer_counter(Env &e, const Args &a, const vector<string> &files, int k, int b, const string &out_dir, const string &stats_dir) {
+    check_k(k);
+    if (files.empty()) die("Mandatory option --reads is not set");
+    mf_ctx *ctx = ctx_of(e, a);
+    for (auto &f : files) logmsg("INFO", "Loading file %s...", basename_of(f).c_str());
+    mf_table *t = nullptr;
+    auto fp = cptrs(files);
+    check(mf_count_reads(ctx, fp.data(), (int)fp.size(), k, 0, &t));
+    mkdirs(out_dir); mkdirs(stats_dir);
+    string name;                                                             // getName :122-137
+    if (files.size() == 2) {
+        string n1 = library_name(files[0]), n2 = library_name(files[1]);
+        auto ends = [](const string &s, const char *x) { return s.size() >= 3 && s.compare(s.size() - 3, 3, x) == 0; };
+        if ((ends(n1, "_r1") && ends(n2, "_r2")) || (ends(n1, "_R1") && ends(n2, "_R2"))) name = n1.substr(0, n1.size() - 3);
+        else name = n1 + "+";
+    } else name = library_name(files[0]) + (files.size() > 1 ? "+" : "");
+    string out = out_dir + "/" + name + ".kmers.bin", st = stats_dir + "/" + name + ".stat.txt";
+    uint64_t good = 0, size = 0;
+    check(mf_table_write_kmers(t, b, out.c_str(), st.c_str(), &good));
+    check(mf_table_stats(t, &size, nullptr));
+    logmsg("INFO", "%s k-mers found, %s (%.1f%%) of them is good (not erroneous)", group_digits(size).c_str(), group_digits(good).c_str(),
+           size ? good * 100.0 / size : 0.0);
+    if (size == 0) logmsg("WARN", "No k-mers found in reads! Perhaps you reads file is empty or k-mer size is too big");
+    else if (good == 0 || good < (uint64_t)(size * 0.03)) logmsg("WARN", "Too few good k-mers were found! Perhaps you should decrease k-mer size or --maximal-bad-frequency value");
+    logmsg("INFO", "Good k-mers printed to %s", out.c_str());
+    mf_table_destroy(t);
+    return out;
+}
+// kmer-counter-many (src/tools/KmersCounterForManyFilesMain.java:66-108): sort, pair _r1/_r2, one counter per sample
+static vector<string> run_kmer_counter_many(Env &e, const Args &a, vector<string> files, int k, int b, const string &wd) {
+    if (files.empty()) die("Mandatory option --reads is not set");
+    std::sort(files.begin(), files.end());
+    string out_dir = a.get("output-dir", wd + "/kmers"), stats_dir = a.get("stats-dir", wd + "/stats");
+    mkdirs(wd + "/sub-counter");
+    vector<string> outs;
+    auto ends = [](const string &s, const char *x) { return s.size() >= 3 && s.compare(s.size() - 3, 3, x) == 0; };
+    for (size_t i = 0; i < files.size();) {
+        string n = library_name(files[i]);
+        bool pair = i + 1 < files.size() && ((ends(n, "_r1") && ends(library_name(files[i + 1]), "_r2")) || (ends(n, "_R1") && ends(library_name(files[i + 1]), "_R2")));
+        vector<string> fs(files.begin() + i, files.begin() + i + (pair ? 2 : 1));
+        outs.push_back(run_kmer_counter(e, a, fs, k, b, out_dir, stats_dir));
+        i += pair ? 2 : 1;
+    }
+    return outs;
+}
+// seq-builder (src/tools/SeqBuilderMain.java:78-160)
+static string run_seq_builder(Env &e, const Args &a, const vector<string> &files, int k, int b, int bp, int l, const string &wd, const string &out_dir) {
+    if (files.empty()) die("Mandatory option --k-mers is not set");
+    mf_ctx *ctx = ctx_of(e, a);
+    mf_table *t = nullptr;
+    auto fp = cptrs(files);
+    check(mf_table_load_kmers(ctx, fp.data(), (int)fp.size(), b, k, &t));
+    if (bp >= 0) {                                                           // bottom-cut-percent :103-115
+        uint64_t n = 0; check(mf_table_export(t, -1, nullptr, nullptr, 0, &n));
+        vector<uint64_t> keys(n); vector<uint16_t> cnts(n);
+        if (n) check(mf_table_export(t, -1, keys.data(), cnts.data(), n, &n));
+        vector<uint64_t> stat(1024, 0); uint64_t total = 0;
+        for (uint16_t c : cnts) { total += c; stat[c >= 1024 ? 1023 : c]++; }
+        uint64_t to_cut = total * (uint64_t)bp / 100, cur = 0;
+        logmsg("INFO", "Using bottom cut percent = %d", bp);
+        for (int i = 0; i < 1023; i++) { if (cur >= to_cut) { b = i; break; } cur += (uint64_t)i * stat[i]; }
+    }
+    logmsg("INFO", "Using maximal bad frequency = %d", b);
+    mkdirs(wd); mkdirs(out_dir);
+    string base = remove_ext(basename_of(files[0]), {".kmers.bin"});
+    string fasta = out_dir + "/" + base + (files.size() > 1 ? "+" : "") + ".seq.fasta";
+    string distr = wd + "/distribution";
+    uint64_t nseq = 0;
+    check(mf_build_unitigs(ctx, t, k, b, l, fasta.c_str(), distr.c_str(), &nseq));
+    logmsg("INFO", "%s sequences found", group_digits(nseq).c_str());
+    if (nseq == 0) logmsg("WARN", "No sequences were found! Perhaps you should decrease --min-seq-len or --maximal-bad-frequency values");
+    logmsg("INFO", "Sequences printed to %s", fasta.c_str());
+    mf_table_destroy(t);
+    return fasta;
+}
+// component-cutter (src/tools/ComponentCutterMain.java:78-114)
+static string run_component_cutter(Env &e, const Args &a, const vector<string> &files, int k, int l, int b1, int b2, const string &wd, const string &comp_file) {
+    if (files.empty()) die("Mandatory option --sequences is not set");
+    mf_ctx *ctx = ctx_of(e, a);
+    mf_table *t = nullptr;
+    auto fp = cptrs(files);
+    logmsg("DEBUG", "Loading sequences from files...");
+    check(mf_count_reads(ctx, fp.data(), (int)fp.size(), k, l, &t));
+    uint64_t size = 0; check(mf_table_stats(t, &size, nullptr));
+    if (size == 0) die("No sequences were found in input files! The following steps will be useless");
+    logmsg("INFO", "Searching for components...");
+    mkdirs(wd);
+    string stat = wd + "/components-stat-" + std::to_string(b1) + "-" + std::to_string(b2) + ".txt";
+    uint64_t nc = 0;
+    check(mf_cut_components(ctx, t, k, b1, b2, comp_file.c_str(), stat.c_str(), &nc));
+    logmsg("INFO", "Total %s components were found", group_digits(nc).c_str());
+    if (nc == 0) logmsg("WARN", "No components were extracted! Perhaps you should decrease --min-component-size value");
+    logmsg("INFO", "Components saved to %s", comp_file.c_str());
+    mf_table_destroy(t);
+    return comp_file;
+}
+// features-calculator (src/tools/FeaturesCalculatorMain.java:77-167), k-mers files branch
+static vector<string> run_features(Env &e, const Args &a, const string &comp_file, const vector<string> &kmers, int k, int thr, const string &wd) {
+    if (comp_file.empty()) die("Mandatory option --components-file is not set");
+    if (a.has("selected")) die("--selected is not supported by the HIP path");
+    if (kmers.empty()) die("no k-mers files given (the --reads variant of features-calculator is not supported by the HIP path yet; pass -ka <name>.kmers.bin)");
+    mf_ctx *ctx = ctx_of(e, a);
+    string out_dir = wd + "/vectors";
+    mkdirs(out_dir);
+    vector<string> vecs;
+    for (auto &kf : kmers) {
+        string base = remove_ext(basename_of(kf), {".kmers.bin"});
+        string vec = out_dir + "/" + base + ".vec", br = out_dir + "/" + base + ".breadth";
+        check(mf_features(ctx, comp_file.c_str(), kf.c_str(), k, thr, vec.c_str(), br.c_str()));
+        logmsg("INFO", "Features for file %s printed to %s", basename_of(kf).c_str(), vec.c_str());
+        vecs.push_back(vec);
+    }
+    return vecs;
+}
+// dist-matrix-calculator (src/tools/DistanceMatrixCalculatorMain.java:51-123)
+static string run_dist_matrix(Env &e, const Args &a, const vector<string> &features, const string &matrix_path_tpl) {
+    if (features.empty()) die("Mandatory option --features is not set");
+    vector<vector<int64_t>> vs;
+    for (auto &f : features) {
+        FILE *fp = fopen(f.c_str(), "r");
+        if (!fp) die("Failed to read features from %s", f.c_str());
+        vector<int64_t> v; char line[256];
+        while (fgets(line, sizeof line, fp)) { if (line[0] != '\n' && line[0] != 0) v.push_back((int64_t)strtod(line, nullptr)); }
+        fclose(fp);
+        vs.push_back(v);
+    }
+    size_t nc = vs[0].size();
+    for (auto &v : vs) if (v.size() != nc) die("feature files have different numbers of components");
+    vector<int64_t> flat; for (auto &v : vs) flat.insert(flat.end(), v.begin(), v.end());
+    int ns = (int)vs.size();
+    vector<double> m((size_t)ns * ns, 0.0);
+    check(mf_bray_curtis(flat.data(), ns, (int)nc, m.data()));
+    string path = matrix_path_tpl;
+    size_t p = path.find("$DT"); if (p != string::npos) path.replace(p, 3, e.start_ts);
+    size_t slash = path.find_last_of('/'); if (slash != string::npos) mkdirs(path.substr(0, slash));
+    FILE *out = fopen(path.c_str(), "w");
+    if (!out) die("Failed to print matrix to %s", path.c_str());
+    bool names = a.get("without-names", "false") != "true";
+    string fmt = a.get("output-format", "%.4f");
+    if (names) { fprintf(out, "#"); for (auto &f : features) fprintf(out, "\t%s", remove_ext(basename_of(f), {"vec"}).c_str()); fprintf(out, "\n"); }
+    for (int i = 0; i < ns; i++) {
+        if (names) fprintf(out, "%s\t", remove_ext(basename_of(features[i]), {"vec"}).c_str());
+        for (int j = 0; j < ns; j++) { if (j) fprintf(out, "\t"); fprintf(out, fmt.c_str(), m[(size_t)i * ns + j]); }
+        fprintf(out, "\n");
+    }
+    fclose(out);
+    logmsg("INFO", "Distance matrix printed to %s", path.c_str());
+    return path;
+}
+
+// one step of a composite tool: <workDir>/<name>/ + SUCCESS marker (Tool.java:212-214, 318-392); -c skips finished steps
+struct Step { string name; string dir; };
+static void step_finish(const Step &s) { touch(s.dir + "/SUCCESS"); }
+static vector<string> list_files(const string &dir, const string &suffix) {
+    vector<string> out; string cmd = "ls -1 '" + dir + "' 2>/dev/null"; FILE *p = popen(cmd.c_str(), "r");
+    if (!p) return out;
+    char line[4096];
+    while (fgets(line, sizeof line, p)) { string s(line); while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back(); if (ends_with_ci(s, suffix)) out.push_back(dir + "/" + s); }
+    pclose(p); std::sort(out.begin(), out.end());
+    return out;
+}
+
+static const char *TOOLS_TEXT =
+    "kmer-counter\t\tCount k-mers in given reads\n"
+    "kmer-counter-many\tCount k-mers in many files (one library = one output)\n"
+    "seq-builder\t\tMetagenome De Bruijn graph analysis and sequences building\n"
+    "seq-builder-many\tseq-builder for many k-mers files\n"
+    "component-cutter\tBuild graph components from sequences\n"
+    "features-calculator\tCalculate features values for input reads/k-mers files\n"
+    "dist-matrix-calculator\tCalculate the distance matrix using features values\n"
+    "matrix-builder\t\tBuild the distance matrix for input sequences (default tool)\n";
+
+int main(int argc, char **argv) {
+    string tool;
+    Args a = parse_args(argc, argv, &tool);
+    if (a.has("version")) { printf("MetaFast (MI355X HIP hot path) %s\n", mf_version()); return 0; }
+    if (a.has("tools")) { printf("Available tools:\n%s", TOOLS_TEXT); return 0; }
+    if (a.has("help") || a.has("help-all")) {
+        printf("Usage: metafast.sh [-t <tool>] [options]\n\nTools:\n%s\nLaunch options: -w/--work-dir <dir>  -p/--available-processors <n>  -c/--continue  --force  "
+               "-s/--start <step>  -f/--finish <step>  -v/--verbose  --device <n>\nTool options follow the reference (see SURVEY.md 8(b1)).\n", TOOLS_TEXT);
+        return 0;
+    }
+    g_verbose = a.get("verbose", "false") == "true";
+    Env e;
+    e.work_dir = a.get("work-dir", "workDir");
+    e.cont = a.has("continue");
+    e.start_ts = timestamp();
+    mkdirs(e.work_dir);
+    g_logfile = fopen((e.work_dir + "/log").c_str(), "a");
+    const string wd = e.work_dir;
+    const int k_dflt = tool == "matrix-builder" ? 31 : -1;
+    int k = a.geti("k", k_dflt);
+
+    if (tool == "kmer-counter") {
+        if (!a.has("k")) die("Mandatory option -k is not set");
+        run_kmer_counter(e, a, a.list("reads"), k, a.geti("maximal-bad-frequence", 1), a.get("output-dir", wd + "/kmers"), a.get("stats-dir", wd + "/stats"));
+    } else if (tool == "kmer-counter-many") {
+        if (!a.has("k")) die("Mandatory option -k is not set");
+        check_k(k);
+        run_kmer_counter_many(e, a, a.list("reads"), k, a.geti("maximal-bad-frequence", 1), wd);
+    } else if (tool == "seq-builder" || tool == "seq-builder-many") {
+        if (!a.has("k")) die("Mandatory option -k is not set");
+        if (!a.has("sequence-len")) die("Mandatory option --sequence-len is not set");
+        if (a.has("maximal-bad-frequency") && a.has("bottom-cut-percent") && tool == "seq-builder-many") die("-b and -bp can not be set both");
+        int b = a.geti("maximal-bad-frequency", 1), bp = a.has("bottom-cut-percent") ? a.geti("bottom-cut-percent", 0) : -1, l = a.geti("sequence-len", 100);
+        string out_dir = a.get("output-dir", wd + "/sequences");
+        if (tool == "seq-builder") run_seq_builder(e, a, a.list("k-mers"), k, b, bp, l, wd, out_dir);
+        else for (auto &f : a.list("k-mers")) run_seq_builder(e, a, {f}, k, b, bp, l, wd + "/sub-builder", out_dir);
+    } else if (tool == "component-cutter") {
+        if (!a.has("k")) die("Mandatory option -k is not set");
+        run_component_cutter(e, a, a.list("sequences"), k, a.geti("min-seq-len", 100), a.geti("min-component-size", 1000), a.geti("max-component-size", 10000), wd,
+                             a.get("components-file", wd + "/components.bin"));
+    } else if (tool == "features-calculator") {
+        if (!a.has("k")) die("Mandatory option -k is not set");
+        run_features(e, a, a.get("components-file"), a.list("kmers"), k, a.geti("threshold", 0), wd);
+    } else if (tool == "dist-matrix-calculator") {
+        run_dist_matrix(e, a, a.list("features"), a.get("matrix-file", wd + "/dist_matrix_$DT_original_order.txt"));
+    } else if (tool == "matrix-builder") {
+        // DistanceMatrixBuilderMain.java:88-175: steps kmer-counter-many, seq-builder-many, component-cutter, features-calculator,
+        // dist-matrix-calculator (+ heatmap-maker: rendering, out of scope)
+        vector<string> reads = a.list("reads");
+        if (reads.empty()) die("No libraries to process!!! Can't continue the calculations.");
+        if (a.get("use-reads-for-calculating-features", "false") == "true") die("--use-reads-for-calculating-features is not supported by the HIP path yet");
+        logmsg("INFO", "Found %zu libraries to process", reads.size());
+        check_k(k);
+        int b = a.geti("maximal-bad-frequency", a.geti("maximal-bad-frequence", 1)), l = a.geti("min-seq-len", 100);
+        int b1 = a.geti("min-component-size", 1000), b2 = a.geti("max-component-size", 10000);
+        string start = a.get("start"), finish = a.get("finish");
+        Step s1{"kmer-counter-many", wd + "/kmer-counter-many"}, s2{"seq-builder-many", wd + "/seq-builder-many"}, s3{"component-cutter", wd + "/component-cutter"},
+             s4{"features-calculator", wd + "/features-calculator"}, s5{"dist-matrix-calculator", wd + "/matrices"};
+        // -s/--start <step>: reuse everything before it; -c/--continue: reuse leading steps that have a SUCCESS marker;
+        // once one step runs, all later ones run (Tool.java:485-529)
+        bool running = false;
+        auto should_run = [&](const Step &s) {
+            if (running) return true;
+            if (!start.empty()) { if (s.name == start) running = true; return running; }
+            if (e.cont && exists(s.dir + "/SUCCESS")) return false;
+            running = true;
+            return true;
+        };
+        auto stop_after = [&](const Step &s) { return !finish.empty() && s.name == finish; };
+        vector<string> kmers, seqs, vecs;
+        // 1
+        if (should_run(s1)) {
+            Args sub = a; sub.opt.erase("output-dir");
+            kmers = run_kmer_counter_many(e, sub, reads, k, b, s1.dir); step_finish(s1);
+        } else { logmsg("INFO", "Step %s: reusing results", s1.name.c_str()); kmers = list_files(s1.dir + "/kmers", ".kmers.bin"); }
+        if (stop_after(s1)) return 0;
+        // 2
+        if (should_run(s2)) {
+            for (auto &f : kmers) seqs.push_back(run_seq_builder(e, a, {f}, k, b, -1, l, s2.dir + "/sub-builder", s2.dir + "/sequences"));
+            step_finish(s2);
+        } else { logmsg("INFO", "Step %s: reusing results", s2.name.c_str()); seqs = list_files(s2.dir + "/sequences", ".seq.fasta"); }
+        if (stop_after(s2)) return 0;
+        // 3
+        string comp = s3.dir + "/components.bin";
+        if (should_run(s3)) { run_component_cutter(e, a, seqs, k, l, b1, b2, s3.dir, comp); step_finish(s3); }
+        else logmsg("INFO", "Step %s: reusing results", s3.name.c_str());
+        if (stop_after(s3)) return 0;
+        // 4
+        if (should_run(s4)) { vecs = run_features(e, a, comp, kmers, k, 0, s4.dir); step_finish(s4); }
+        else { logmsg("INFO", "Step %s: reusing results", s4.name.c_str()); vecs = list_files(s4.dir + "/vectors", ".vec"); }
+        if (stop_after(s4)) return 0;
+        // 5
+        string mpath = run_dist_matrix(e, a, vecs, wd + "/matrices/dist_matrix_$DT_original_order.txt");
+        (void)mpath;
+        logmsg("INFO", "heatmap-maker (dendrogram ordering + image) is outside the HIP hot path: the matrix above keeps the original sample order");
+    } else {
+        die("Unknown tool '%s' (use -ts to list the tools of the HIP hot path)", tool.c_str());
+    }
+    touch(wd + "/SUCCESS");
+    if (e.ctx) mf_ctx_destroy(e.ctx);
+    if (g_logfile) fclose(g_logfile);
+    return 0;
+}

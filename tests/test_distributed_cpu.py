@@ -1,0 +1,65 @@
+"""N>1 path on CPU: the two exchanges of the multi-GPU pipeline (ragged all-gather of unitigs, all-gather of feature
+vectors) under world_size-2 gloo."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metafast_amd import pipeline as P
+    # rank r owns r+2 "unitigs" of different lengths (rank 1 has more bases than rank 0)
+    seqs = [("ACGT" * (3 + rank + i))[: 10 + 7 * rank + i] for i in range(rank + 2)]
+    bases = torch.from_numpy(np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy())
+    offs = torch.tensor(np.concatenate([[0], np.cumsum([len(s) for s in seqs])]), dtype=torch.int64)
+    allb, allo, ns, nb = P.gather_sequences(bases, offs)
+    vec = torch.tensor([10 * rank + 1, 7, 100 * (rank + 1)], dtype=torch.int64)
+    vecs = P.gather_vectors(vec)
+    rag = P.all_gather_ragged(torch.arange(rank * 3, dtype=torch.int64))     # rank 0 contributes an EMPTY tensor
+    np.save(os.path.join(out_dir, f"b{rank}.npy"), allb.numpy())
+    np.save(os.path.join(out_dir, f"o{rank}.npy"), allo.numpy())
+    np.save(os.path.join(out_dir, f"v{rank}.npy"), vecs.numpy())
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([len(x) for x in rag]))
+    dist.destroy_process_group()
+
+
+def test_exchanges_world2(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    exp_seqs = []
+    for rank in range(world):
+        exp_seqs += [("ACGT" * (3 + rank + i))[: 10 + 7 * rank + i] for i in range(rank + 2)]
+    exp_b = "".join(exp_seqs).encode()
+    exp_o = np.concatenate([[0], np.cumsum([len(s) for s in exp_seqs])])
+    for rank in range(world):
+        b = np.load(tmp_path / f"b{rank}.npy")
+        o = np.load(tmp_path / f"o{rank}.npy")
+        v = np.load(tmp_path / f"v{rank}.npy")
+        r = np.load(tmp_path / f"r{rank}.npy")
+        assert bytes(b[: len(exp_b)]) == exp_b and len(b) == len(exp_b) + 64     # 64 bytes of slack for the kernels
+        assert o.tolist() == exp_o.tolist()                                      # every rank sees the same, rebased offsets
+        assert v.tolist() == [[1, 7, 100], [11, 7, 200]]
+        assert r.tolist() == [0, 3]
+
+
+def test_single_process_paths():
+    from metafast_amd import pipeline as P
+    t = torch.arange(5)
+    assert P.all_gather_ragged(t)[0] is t
+    assert P.gather_vectors(torch.tensor([1, 2])).tolist() == [[1, 2]]
+    b, o, ns, nb = P.gather_sequences(torch.zeros(6, dtype=torch.uint8), torch.tensor([0, 2, 6]))
+    assert (ns, nb, o.tolist()) == (2, 6, [0, 2, 6])

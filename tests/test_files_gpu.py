@@ -1,0 +1,190 @@
+"""GPU parity of the file-level seams and the metafast.sh-compatible driver: readers, .kmers.bin / .stat.txt,
+.seq.fasta / distribution, components.bin / stat, .vec / .breadth, the matrix file and the workDir layout."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REF_DATA, ROOT
+from util import canon_seq
+
+pytestmark = pytest.mark.gpu
+
+
+def _fasta_records(path):
+    recs, cur = [], None
+    for line in open(path):
+        line = line.rstrip("\n")
+        if line.startswith(">"):
+            cur = [line[1:], ""]
+            recs.append(cur)
+        else:
+            assert len(line) <= 70
+            cur[1] += line
+    return recs
+
+
+def test_count_reads_fasta_and_fastq(gpu_ctx, oracle, ref_files, tmp_path):
+    for f in ref_files[:2]:
+        gk, gc = gpu_ctx.count_reads([f], 31).export()
+        ok, ov = oracle.Table().count_files([f], 31).export()
+        assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+    fq = [os.path.join(REF_DATA, "tinytest_A.fastq"), os.path.join(REF_DATA, "tinytest_B.fastq")]
+    gk, gc = gpu_ctx.count_reads(fq, 5).export()            # two files -> one table (paired files are summed)
+    ok, ov = oracle.Table().count_files(fq, 5).export()
+    assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov) and gc.max() == 2
+    fa = tmp_path / "x.fasta"
+    fa.write_text(">r1\nACGTACGTAC\nGTACGTTTGA\n;c\n>r2\nACGNNACGTACGT\n>r3\nacgtacgtacgtaaa\r\n>r4\n\n")
+    q = tmp_path / "y.fq"
+    q.write_text("@a\nACGTACGTAA\n+\nIIIIIIIIII\n@b\nACNTACGTAA\n+\nIIIIIIIIII\n@c\nGGGGACGTAA\n+\nI!IIIIIIII\n@d\nTTTTACGTAA\n+\nIIIIIIIIII\n")
+    gk, gc = gpu_ctx.count_reads([str(fa), str(q)], 7).export()
+    ok, ov = oracle.Table().count_files([str(fa), str(q)], 7).export()
+    assert len(gk) > 0 and np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+
+
+def test_reader_errors(gpu_ctx, tmp_path):
+    from metafast_amd.lib import MetafastError
+    bad = tmp_path / "reads.txt"
+    bad.write_text(">a\nACGT\n")
+    with pytest.raises(MetafastError, match="Can't detect file format"):
+        gpu_ctx.count_reads([str(bad)], 3)
+    gz = tmp_path / "reads.fa.gz"
+    gz.write_bytes(b"\x1f\x8b")
+    with pytest.raises(MetafastError, match="not supported"):
+        gpu_ctx.count_reads([str(gz)], 3)
+    x = tmp_path / "x.fa"
+    x.write_text(">a\nACGTXACGT\n")
+    with pytest.raises(MetafastError, match="Incorrect nucleotide"):
+        gpu_ctx.count_reads([str(x)], 3)
+    with pytest.raises(MetafastError, match="no more than 31"):
+        gpu_ctx.count_reads([str(x)], 32)
+    with pytest.raises(MetafastError, match="can't open"):
+        gpu_ctx.count_reads([str(tmp_path / "missing.fa")], 3)
+
+
+def test_kmers_bin_and_stat_identical_to_oracle(gpu_ctx, oracle, ref_files, tmp_path):
+    f = ref_files[2]
+    t = gpu_ctx.count_reads([f], 31)
+    good = t.write_kmers(1, str(tmp_path / "g.kmers.bin"), str(tmp_path / "g.stat.txt"))
+    ot = oracle.Table().count_files([f], 31)
+    ogood = ot.write_kmers(1, str(tmp_path / "o.kmers.bin"), str(tmp_path / "o.stat.txt"))
+    assert good == ogood == 11351
+    assert (tmp_path / "g.kmers.bin").read_bytes() == (tmp_path / "o.kmers.bin").read_bytes()      # both ascending key order
+    assert (tmp_path / "g.stat.txt").read_text() == (tmp_path / "o.stat.txt").read_text()
+    # loadKmers: threshold on load, duplicates across files are summed with saturation
+    l1 = gpu_ctx.load_kmers([str(tmp_path / "g.kmers.bin")], 2, 31)
+    k1, c1 = l1.export()
+    ok, ov = ot.export(2)
+    assert np.array_equal(k1, ok) and np.array_equal(c1.astype(np.int32), ov)
+    l2 = gpu_ctx.load_kmers([str(tmp_path / "g.kmers.bin")] * 2, 0, 31)
+    k2, c2 = l2.export()
+    ok1, ov1 = ot.export(1)
+    assert np.array_equal(k2, ok1) and np.array_equal(c2.astype(np.int32), np.minimum(2 * ov1, 32767))
+
+
+def test_seq_fasta_and_distribution(gpu_ctx, oracle, ref_files, tmp_path):
+    from metafast_amd import lib as L
+    import ctypes as C
+    f = ref_files[1]
+    t = gpu_ctx.count_reads([f], 31)
+    t.write_kmers(1, str(tmp_path / "s.kmers.bin"))
+    g = gpu_ctx.load_kmers([str(tmp_path / "s.kmers.bin")], 1, 31)
+    n = C.c_uint64()
+    L._check(L.lib().mf_build_unitigs(gpu_ctx.h, g.h, 31, 1, 100, os.fsencode(tmp_path / "s.seq.fasta"),
+                                      os.fsencode(tmp_path / "distribution"), C.byref(n)))
+    og = oracle.Table().load_kmers([str(tmp_path / "s.kmers.bin")], 1)
+    oseqs = oracle.build_unitigs(og, 31, 1, 100)
+    og.write_distribution(str(tmp_path / "o.distribution"))
+    assert n.value == len(oseqs) == 29
+    assert (tmp_path / "distribution").read_text() == (tmp_path / "o.distribution").read_text()
+    recs = _fasta_records(tmp_path / "s.seq.fasta")
+    want = sorted((canon_seq(s), f"length={len(s)} av_weight={a} min_weight={mn} max_weight={mx}") for s, a, mn, mx in oseqs.all())
+    got = sorted((canon_seq(s), h.split(" ", 1)[1]) for h, s in recs)
+    assert got == want
+    assert [h.split(" ")[0] for h, _ in recs] == [str(i + 1) for i in range(len(recs))]
+
+
+def test_components_and_features_files(gpu_ctx, oracle, ref_files, tmp_path):
+    from metafast_amd import lib as L
+    import ctypes as C
+    k, b, l = 31, 1, 100
+    seq_files, kmers_files, o_goods = [], [], []
+    for i, f in enumerate(ref_files):
+        t = gpu_ctx.count_reads([f], k)
+        kb = tmp_path / f"s{i}.kmers.bin"
+        t.write_kmers(b, str(kb))
+        kmers_files.append(str(kb))
+        sf = tmp_path / f"s{i}.seq.fasta"
+        gpu_ctx.build_unitigs(t, b, l).write_fasta(str(sf))
+        seq_files.append(str(sf))
+        o_goods.append(oracle.Table().load_kmers([str(kb)], 0))
+    cutter = gpu_ctx.count_reads(seq_files, k, l)                      # ComponentCutterMain.java:81
+    o_cutter = oracle.Table().count_files(seq_files, k, l)
+    n = C.c_uint64()
+    L._check(L.lib().mf_cut_components(gpu_ctx.h, cutter.h, k, 1000, 10000, os.fsencode(tmp_path / "components.bin"),
+                                       os.fsencode(tmp_path / "components-stat-1000-10000.txt"), C.byref(n)))
+    oc = oracle.cut_components(o_cutter, k, 1000, 10000)
+    oc.write(str(tmp_path / "o.components.bin"), str(tmp_path / "o.stat.txt"))
+    assert n.value == 4
+    assert (tmp_path / "components.bin").read_bytes() == (tmp_path / "o.components.bin").read_bytes()
+    assert (tmp_path / "components-stat-1000-10000.txt").read_text() == (tmp_path / "o.stat.txt").read_text()
+    # load back (ConnectedComponent.loadComponents) and compute the feature files
+    loaded = gpu_ctx.load_components(str(tmp_path / "components.bin"))
+    assert [(a, w) for a, w, _, _ in loaded.export()] == [(6240, 12783), (5713, 11265), (3020, 5977), (2088, 4260)]
+    expect = [[41935, 38354, 20375, 14211], [20208, 0, 0, 11337], [6517, 34484, 20359, 749]]
+    for i, kf in enumerate(kmers_files):
+        gpu_ctx.features_files(str(tmp_path / "components.bin"), kf, k, 0, str(tmp_path / f"s{i}.vec"), str(tmp_path / f"s{i}.breadth"))
+        vec = [int(x) for x in (tmp_path / f"s{i}.vec").read_text().split()]
+        assert vec == expect[i]
+        wv, wbr = oc.features(o_goods[i], 0)
+        br_lines = (tmp_path / f"s{i}.breadth").read_text().split()
+        assert [float(x) for x in br_lines] == wbr.tolist()
+        for s, v in zip(br_lines, wbr.tolist()):                        # Java Double.toString: shortest round-trip, "x.y" form
+            assert s == repr(float(v)) or (v == 0 and s == "0.0")
+
+
+def test_cli_matrix_builder_workdir(oracle, ref_files, tmp_path):
+    """metafast.sh -i a b c  (default tool matrix-builder): workDir layout + the reference's README matrix"""
+    wd = tmp_path / "workDir"
+    cmd = [os.path.join(ROOT, "metafast.sh"), "-m", "4G", "-ea", "-k", "31", "-i", *ref_files, "-w", str(wd), "-p", "4"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for rel in ["kmer-counter-many/kmers/meta_test_1.kmers.bin", "kmer-counter-many/stats/meta_test_2.stat.txt",
+                "seq-builder-many/sequences/meta_test_3.seq.fasta", "seq-builder-many/sub-builder/distribution",
+                "component-cutter/components.bin", "component-cutter/components-stat-1000-10000.txt",
+                "features-calculator/vectors/meta_test_1.vec", "features-calculator/vectors/meta_test_1.breadth",
+                "kmer-counter-many/SUCCESS", "component-cutter/SUCCESS", "SUCCESS", "log"]:
+        assert (wd / rel).exists(), rel
+    assert os.path.getsize(wd / "kmer-counter-many/kmers/meta_test_1.kmers.bin") == 169180
+    mats = sorted((wd / "matrices").glob("dist_matrix_*_original_order.txt"))
+    assert len(mats) == 1
+    lines = mats[0].read_text().splitlines()
+    assert lines[0] == "#\tmeta_test_1\tmeta_test_2\tmeta_test_3"
+    assert lines[1] == "meta_test_1\t0.0000\t0.5691\t0.2981"          # README.md:96-99 values in the original order
+    assert lines[2] == "meta_test_2\t0.5691\t0.0000\t0.8448"
+    assert lines[3] == "meta_test_3\t0.2981\t0.8448\t0.0000"
+    # --continue reuses finished steps; --start re-runs from a step
+    r = subprocess.run(cmd + ["-c"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "reusing results" in r.stderr
+    r = subprocess.run(cmd + ["-s", "features-calculator"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Step component-cutter: reusing results" in r.stderr
+
+
+def test_cli_errors_and_single_tools(ref_files, tmp_path):
+    exe = os.path.join(ROOT, "metafast.sh")
+    r = subprocess.run([exe, "-t", "kmer-counter", "-k", "32", "-i", ref_files[0], "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    assert r.returncode == 1 and "no more than 31" in r.stderr
+    r = subprocess.run([exe, "-t", "nope"], capture_output=True, text=True)
+    assert r.returncode == 1
+    r = subprocess.run([exe, "-t", "component-cutter", "-k", "31", "-i", str(tmp_path / "none.fa"), "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    assert r.returncode == 1
+    # paired files x_r1 / x_r2 -> one library "x" (KmersCounterForManyFilesMain.java:80-108, KmersCounterMain.java:122-137)
+    a, b = tmp_path / "lib_r1.fa", tmp_path / "lib_r2.fa"
+    a.write_text(open(ref_files[1]).read())
+    b.write_text(open(ref_files[2]).read())
+    wd = tmp_path / "w2"
+    r = subprocess.run([exe, "-t", "kmer-counter-many", "-k", "31", "-i", str(b), str(a), ref_files[0], "-w", str(wd)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert sorted(os.listdir(wd / "kmers")) == ["lib.kmers.bin", "meta_test_1.kmers.bin"]
+    assert sorted(os.listdir(wd / "stats")) == ["lib.stat.txt", "meta_test_1.stat.txt"]
