@@ -59,6 +59,7 @@ struct mf_ctx {
     int64_t opt_profile = 0;
     int64_t opt_l1_blocks = 0;     // 0 = auto
     int64_t opt_verbose = 0;
+    int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero
     // workspace arena: a few large hipMalloc'd regions, sub-allocated with first-fit + coalescing free lists.
     // Everything runs on one stream, so a block can be handed out again as soon as it is released.
     struct span { size_t off, sz; };
@@ -166,6 +167,16 @@ __host__ __device__ __forceinline__ uint64_t mf_hash64(uint64_t x) {
     x ^= x >> 33;
     return x;
 }
+
+// Cheap hash of the counting path (5 evaluations per k-mer occurrence across the passes, and those kernels are
+// instruction-issue bound): one xor-shift + one 64-bit multiply.  Partition digits = TOP bits of the product (they
+// depend on every key bit), LDS slot = fold of the high and low halves.  Measured on 2e7 real canonical 31-mers the
+// partition sizes are Poisson-like, same as with fmix64.
+__host__ __device__ __forceinline__ uint64_t mf_phash(uint64_t x) {
+    x ^= x >> 31;
+    return x * 0x9E3779B97F4A7C15ULL;
+}
+__host__ __device__ __forceinline__ uint32_t mf_pslot(uint64_t h) { return (uint32_t)(h ^ (h >> 32)); }
 
 // reverse complement of a 2-bit packed k-mer (A0 G1 C2 T3 -> complement = 3-n), k in [1,31]
 __host__ __device__ __forceinline__ uint64_t mf_revcomp(uint64_t x, int k) {

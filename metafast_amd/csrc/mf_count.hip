@@ -159,7 +159,7 @@ __global__ __launch_bounds__(1024) void k_l1_hist(const uint8_t *__restrict__ ba
         uint32_t m = vmask[w];
         if (!m) continue;
         mf_word_kmers(bases, n_bases, w, m, k, [&](int, uint64_t key, bool valid) {
-            if (valid) atomicAdd(&hist[mf_digit(mf_hash64(key), 0, bits)], 1u);
+            if (valid) atomicAdd(&hist[mf_digit(mf_phash(key), 0, bits)], 1u);
         });
     }
     __syncthreads();
@@ -170,92 +170,124 @@ __global__ __launch_bounds__(1024) void k_l1_hist(const uint8_t *__restrict__ ba
 // LDS-staged scatter: one 64-byte line (8 k-mers) per digit
 // =============================================================================================
 struct mf_stage {
-    uint64_t *line;   // [nd][8]
+    uint64_t *line;   // [nd][8] staging lines + 64 dummy slots (one per lane)
     uint64_t *cur;    // [nd] next global element index (multiple of 8) for this workgroup's range of digit d
-    uint32_t *ctr;    // [nd] low 16 = slots reserved, high 16 = slots committed
+    uint32_t *ctr;    // [nd] low 16 = slots reserved, high 16 = slots committed; + 64 dummy counters (always 0)
+    uint64_t *q_pos;  // [16 waves][MF_QCAP] flush queue: output position
+    uint32_t *q_d;    // [16 waves][MF_QCAP] flush queue: digit
+    int nd;
 };
+#define MF_QCAP 16
 #define MF_WG __HIP_MEMORY_SCOPE_WORKGROUP
 #define MF_MLP 4          // 16-byte loads in flight per thread in the streaming loops
 
-// Lock-free within the workgroup: reserve a slot, write it, commit; the 8th committer flushes the
-// line to HBM with four 16-byte stores and reopens it.  Lanes that find the line full retry.
+// Lock-free within the workgroup: reserve a slot, write it, commit; the 8th committer flushes the line to HBM with
+// four 16-byte stores and reopens it.  Lanes that find the line full retry.
 //
-// The retry loop is WAVE-UNIFORM (ballot): every lane of the wave stays in the loop until the whole
-// wave has placed its element, and the write + commit + flush of a successful lane happen INSIDE the
-// iteration.  A per-lane `while (!done)` loop is wrong here: hipcc sinks the success path below the
-// loop, so the lane holding slot 7 would wait at the loop exit for a same-wave lane that spins on the
-// full line forever (SIMT deadlock, observed on gfx950).
-__device__ __forceinline__ void mf_stage_insert(const mf_stage &L, uint64_t *__restrict__ out, uint32_t d, uint64_t key,
-                                                bool active) {
-    bool pending = active;
-    while (__ballot(pending) != 0ull) {
-        if (pending) {
-            uint32_t w = __hip_atomic_load(&L.ctr[d], __ATOMIC_RELAXED, MF_WG);
-            if ((w & 0xFFFFu) < (uint32_t)MF_LINE) {
-                uint32_t old = __hip_atomic_fetch_add(&L.ctr[d], 1u, __ATOMIC_RELAXED, MF_WG);
-                uint32_t r = old & 0xFFFFu;
-                if (r < (uint32_t)MF_LINE) {
-                    L.line[d * MF_LINE + r] = key;
-                    uint32_t old2 = __hip_atomic_fetch_add(&L.ctr[d], 0x10000u, __ATOMIC_ACQ_REL, MF_WG);
-                    if ((old2 >> 16) == (uint32_t)(MF_LINE - 1)) {
-                        uint64_t pos = L.cur[d];
-                        L.cur[d] = pos + MF_LINE;
-                        const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(&L.line[d * MF_LINE]);
-                        ulonglong2 a = s[0], b = s[1], c = s[2], e = s[3];
-                        ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + pos);
-                        o[0] = a; o[1] = b; o[2] = c; o[3] = e;
-                        __hip_atomic_store(&L.ctr[d], 0u, __ATOMIC_RELEASE, MF_WG);
-                    }
-                    pending = false;
-                }
-            }
-        }
-        // keep every memory operation of this iteration inside it
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-// Same protocol for MF_B elements per lane at once: the peek / reserve / write / commit steps of the MF_B
-// independent elements are issued back to back, so their LDS round trips overlap instead of adding up
-// (with one element per call the kernel is bound by three dependent LDS latencies per k-mer).
+// Two things in this function were learnt the hard way on gfx950:
+//  * The retry loop is WAVE-UNIFORM (ballot): every lane stays in the loop until the whole wave has placed its
+//    elements, and the write + commit + flush of a successful lane happen INSIDE the iteration.  With a per-lane
+//    `while (!done)` loop hipcc sinks the success path below the loop, and the lane holding slot 7 then waits at the
+//    loop exit for a same-wave lane that spins on the full line forever (SIMT deadlock).
+//  * MF_B elements per lane go through the protocol together and every step is BRANCH-FREE: lanes with nothing to do
+//    in a step still execute the LDS instruction, on a private dummy counter / dummy slot, and "add" 0.  Written
+//    with `if (pending[b])` around each step, hipcc emits one exec-mask branch + s_waitcnt per element and the 4 x 3
+//    LDS round trips are fully serialised (the kernel was LDS-latency bound at 12 round trips per 4 k-mers).
 #define MF_B 4
+// LDS byte address of a pointer into __shared__ memory (operand of the ds_* instructions below)
+__device__ __forceinline__ uint32_t mf_lds_addr(const void *p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
+}
+// Four LDS operations issued back to back, ONE s_waitcnt for all of them.  These are inline asm because hipcc turns the
+// equivalent C++ (atomics that add 0 on dummy slots) back into per-element exec branches with a wait after each atomic.
+// LDS instructions of one wave execute in order, so a write issued before the commit atomic is visible to whoever
+// observes that commit; the "memory" clobbers keep the compiler from moving other accesses across.
+__device__ __forceinline__ void mf_lds_read4(const uint32_t (&a)[4], uint32_t (&v)[4]) {
+    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+                 : "memory");
+}
+__device__ __forceinline__ void mf_lds_add_rtn4(const uint32_t (&a)[4], const uint32_t (&inc)[4], uint32_t (&old)[4]) {
+    asm volatile("ds_add_rtn_u32 %0, %4, %8\n\tds_add_rtn_u32 %1, %5, %9\n\tds_add_rtn_u32 %2, %6, %10\n\t"
+                 "ds_add_rtn_u32 %3, %7, %11\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(inc[0]), "v"(inc[1]), "v"(inc[2]), "v"(inc[3])
+                 : "memory");
+}
+// four 8-byte stores, then four returning adds (the commits); the stores need no wait of their own (in-order LDS)
+__device__ __forceinline__ void mf_lds_write4_add_rtn4(const uint32_t (&wa)[4], const uint64_t (&wv)[4], const uint32_t (&a)[4],
+                                                       const uint32_t (&inc)[4], uint32_t (&old)[4]) {
+    asm volatile("ds_write_b64 %4, %8\n\tds_write_b64 %5, %9\n\tds_write_b64 %6, %10\n\tds_write_b64 %7, %11\n\t"
+                 "ds_add_rtn_u32 %0, %12, %16\n\tds_add_rtn_u32 %1, %13, %17\n\tds_add_rtn_u32 %2, %14, %18\n\t"
+                 "ds_add_rtn_u32 %3, %15, %19\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
+                 : "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3]),
+                   "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(inc[0]), "v"(inc[1]), "v"(inc[2]), "v"(inc[3])
+                 : "memory");
+}
 __device__ __forceinline__ void mf_stage_insert_batch(const mf_stage &L, uint64_t *__restrict__ out, const uint32_t (&d)[MF_B],
-                                                      const uint64_t (&key)[MF_B], bool (&pending)[MF_B]) {
+                                                      const uint64_t (&key)[MF_B], bool (&pending)[MF_B], int ablate = 0) {
+    if (ablate == 1) {            // diagnostic: k-mer generation + hashing only (keeps the values alive)
+        uint64_t acc = 0;
+#pragma unroll
+        for (int b = 0; b < MF_B; b++) acc += pending[b] ? key[b] + d[b] : 0;
+        if (acc == 0x123456789ull) out[0] = acc;
+        return;
+    }
+    const uint32_t ctr0 = mf_lds_addr(L.ctr), line0 = mf_lds_addr(L.line);
+    const uint32_t dummy_ctr = ctr0 + 4u * ((uint32_t)L.nd + (uint32_t)mf_lane());               // ctr[nd .. nd+64): one per lane
+    const uint32_t dummy_slot = line0 + 8u * ((uint32_t)L.nd * MF_LINE + (uint32_t)mf_lane());   // line[nd*8 .. nd*8+64)
     for (;;) {
         bool any = false;
 #pragma unroll
         for (int b = 0; b < MF_B; b++) any |= pending[b];
         if (__ballot(any) == 0ull) break;
-        uint32_t w[MF_B], r[MF_B];
+        uint32_t ca[MF_B], w[MF_B], inc[MF_B], old[MF_B], old2[MF_B], wa[MF_B];
         bool got[MF_B];
 #pragma unroll
-        for (int b = 0; b < MF_B; b++) w[b] = pending[b] ? __hip_atomic_load(&L.ctr[d[b]], __ATOMIC_RELAXED, MF_WG) : 0xFFFFu;
+        for (int b = 0; b < MF_B; b++) ca[b] = pending[b] ? ctr0 + 4u * d[b] : dummy_ctr;
+        mf_lds_read4(ca, w);                                                     // peek: is the line open?
+#pragma unroll
+        for (int b = 0; b < MF_B; b++) inc[b] = (pending[b] && (w[b] & 0xFFFFu) < (uint32_t)MF_LINE) ? 1u : 0u;
+        mf_lds_add_rtn4(ca, inc, old);                                           // reserve a slot
 #pragma unroll
         for (int b = 0; b < MF_B; b++) {
-            got[b] = false; r[b] = 0;
-            if (pending[b] && (w[b] & 0xFFFFu) < (uint32_t)MF_LINE) {
-                uint32_t old = __hip_atomic_fetch_add(&L.ctr[d[b]], 1u, __ATOMIC_RELAXED, MF_WG);
-                r[b] = old & 0xFFFFu;
-                got[b] = r[b] < (uint32_t)MF_LINE;
-            }
+            got[b] = inc[b] && (old[b] & 0xFFFFu) < (uint32_t)MF_LINE;
+            wa[b] = got[b] ? line0 + 8u * (d[b] * MF_LINE + (old[b] & 0xFFFFu)) : dummy_slot;
+            ca[b] = got[b] ? ctr0 + 4u * d[b] : dummy_ctr;
+            inc[b] = got[b] ? 0x10000u : 0u;
         }
-#pragma unroll
-        for (int b = 0; b < MF_B; b++)
-            if (got[b]) L.line[d[b] * MF_LINE + r[b]] = key[b];
+        mf_lds_write4_add_rtn4(wa, key, ca, inc, old2);                          // write the slot, commit
+        // Flush of the completed lines, wave-cooperative: the completing lanes queue (digit, position) in a small per-wave
+        // LDS queue and then FOUR lanes write one 64-byte line with ONE store instruction (16 lines per instruction).
+        // One lane writing its line with four 16-byte stores costs 4x the L2 write requests and made the HBM flush half
+        // of the kernel time (ablation: 18.4 ms -> 8.8 ms without the stores at 2.4e9 k-mers).
+        uint64_t *qpos = L.q_pos + (threadIdx.x >> 6) * MF_QCAP;
+        uint32_t *qd = L.q_d + (threadIdx.x >> 6) * MF_QCAP;
+        const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
 #pragma unroll
         for (int b = 0; b < MF_B; b++) {
-            if (got[b]) {
-                uint32_t old2 = __hip_atomic_fetch_add(&L.ctr[d[b]], 0x10000u, __ATOMIC_ACQ_REL, MF_WG);
-                if ((old2 >> 16) == (uint32_t)(MF_LINE - 1)) {
-                    uint64_t pos = L.cur[d[b]];
-                    L.cur[d[b]] = pos + MF_LINE;
-                    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(&L.line[d[b] * MF_LINE]);
-                    ulonglong2 a = s[0], bb = s[1], c = s[2], e = s[3];
-                    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(out + pos);
-                    o[0] = a; o[1] = bb; o[2] = c; o[3] = e;
-                    __hip_atomic_store(&L.ctr[d[b]], 0u, __ATOMIC_RELEASE, MF_WG);
+            const bool fl = got[b] && (old2[b] >> 16) == (uint32_t)(MF_LINE - 1);     // 8th committer of its line
+            const unsigned long long F = __ballot(fl);
+            if (got[b]) pending[b] = false;
+            if (F == 0ull) continue;
+            const uint32_t n = (uint32_t)__popcll(F), qi = (uint32_t)__popcll(F & lt_mask);
+            uint64_t mypos = 0;
+            if (fl) { mypos = L.cur[d[b]]; L.cur[d[b]] = mypos + MF_LINE; }
+            for (uint32_t e0 = 0; e0 < n; e0 += MF_QCAP) {
+                if (fl && qi >= e0 && qi < e0 + MF_QCAP) { qpos[qi - e0] = mypos; qd[qi - e0] = d[b]; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // queue visible to the wave (in-order LDS)
+                const uint32_t e = e0 + ((uint32_t)mf_lane() >> 2), c = (uint32_t)mf_lane() & 3u;
+                if (e < n) {
+                    const uint32_t dd = qd[e - e0];
+                    const uint64_t pp = qpos[e - e0];
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(&L.line[dd * MF_LINE + 2 * c]);
+                    if (ablate != 2) *reinterpret_cast<ulonglong2 *>(out + pp + 2 * c) = v;
+                    asm volatile("" ::: "memory");
+                    if (c == 0) __hip_atomic_store(&L.ctr[dd], 0u, __ATOMIC_RELEASE, MF_WG);   // reopen (after the reads above)
                 }
-                pending[b] = false;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // before the queue is reused
             }
         }
         asm volatile("" ::: "memory");
@@ -276,12 +308,15 @@ __device__ __forceinline__ void mf_stage_flush_all(const mf_stage &L, uint64_t *
 }
 __device__ __forceinline__ mf_stage mf_stage_carve(unsigned char *smem, int nd) {
     mf_stage L;
+    L.nd = nd;
     L.line = reinterpret_cast<uint64_t *>(smem);
-    L.cur = L.line + (size_t)nd * MF_LINE;
-    L.ctr = reinterpret_cast<uint32_t *>(L.cur + nd);
+    L.cur = L.line + (size_t)nd * MF_LINE + 64;
+    L.q_pos = L.cur + nd;
+    L.ctr = reinterpret_cast<uint32_t *>(L.q_pos + 16 * MF_QCAP);
+    L.q_d = L.ctr + nd + 64;
     return L;
 }
-static inline size_t mf_stage_bytes(int nd) { return (size_t)nd * (MF_LINE * 8 + 8 + 4); }
+static inline size_t mf_stage_bytes(int nd) { return (size_t)nd * (MF_LINE * 8 + 8 + 4) + 64 * 8 + 64 * 4 + 16 * MF_QCAP * 12; }
 
 // =============================================================================================
 // K1b: scatter reads' k-mers into 2^bits partitions (ranges from k_l1_hist + k_scan)
@@ -291,23 +326,26 @@ __global__ __launch_bounds__(1024) void k_l1_scatter(const uint8_t *__restrict__
                                                      const uint32_t *__restrict__ vmask, uint64_t n_words,
                                                      uint64_t words_per_block, int k, int bits,
                                                      const uint64_t *__restrict__ blockstart, int G,
-                                                     uint64_t *__restrict__ out) {
+                                                     uint64_t *__restrict__ out, int ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nd = 1 << bits;
     mf_stage L = mf_stage_carve(smem, nd);
     for (int i = threadIdx.x; i < nd; i += blockDim.x) { L.cur[i] = blockstart[(size_t)i * G + blockIdx.x]; L.ctr[i] = 0; }
+    if (threadIdx.x < 64) L.ctr[nd + threadIdx.x] = 0;
     __syncthreads();
     uint64_t wlo = (uint64_t)blockIdx.x * words_per_block;
     uint64_t whi = wlo + words_per_block < n_words ? wlo + words_per_block : n_words;
-    // every wave runs the same number of iterations so that no wave exits while others still spin
-    for (uint64_t w = wlo + threadIdx.x; w < whi; w += blockDim.x) {
-        uint32_t m = vmask[w];
-        if (!m) continue;
+    // ALL 64 lanes of a wave must reach mf_stage_insert_batch together (its flush is wave-cooperative: four lanes per
+    // line, lane 4e reopens line e), so the loop bounds and the skip of empty words are wave-uniform
+    for (uint64_t wb = wlo; wb < whi; wb += blockDim.x) {
+        const uint64_t w = wb + threadIdx.x;
+        const uint32_t m = w < whi ? vmask[w] : 0u;
+        if (__ballot(m != 0u) == 0ull) continue;
         mf_word_kmers4(bases, n_bases, w, m, k, [&](const uint64_t (&keys)[4], bool (&valid)[4]) {
             uint32_t d[4];
 #pragma unroll
-            for (int u = 0; u < 4; u++) d[u] = mf_digit(mf_hash64(keys[u]), 0, bits);
-            if (STAGED) mf_stage_insert_batch(L, out, d, keys, valid);
+            for (int u = 0; u < 4; u++) d[u] = mf_digit(mf_phash(keys[u]), 0, bits);
+            if (STAGED) mf_stage_insert_batch(L, out, d, keys, valid, ablate);
             else {
 #pragma unroll
                 for (int u = 0; u < 4; u++)
@@ -369,8 +407,8 @@ __global__ __launch_bounds__(1024) void k_split(const uint64_t *__restrict__ in,
             }
 #pragma unroll
             for (int u = 0; u < MF_MLP; u++) {
-                if (v[u].x != MF_EMPTY) atomicAdd(&L.ctr[mf_digit(mf_hash64(v[u].x), bits_used, bits)], 1u);
-                if (v[u].y != MF_EMPTY) atomicAdd(&L.ctr[mf_digit(mf_hash64(v[u].y), bits_used, bits)], 1u);
+                if (v[u].x != MF_EMPTY) atomicAdd(&L.ctr[mf_digit(mf_phash(v[u].x), bits_used, bits)], 1u);
+                if (v[u].y != MF_EMPTY) atomicAdd(&L.ctr[mf_digit(mf_phash(v[u].y), bits_used, bits)], 1u);
             }
         }
         __syncthreads();
@@ -392,7 +430,7 @@ __global__ __launch_bounds__(1024) void k_split(const uint64_t *__restrict__ in,
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < nd; i += blockDim.x) L.ctr[i] = 0;
+        for (int i = threadIdx.x; i < nd + 64; i += blockDim.x) L.ctr[i] = 0;
         __syncthreads();
         // uniform trip count for every wave (the insert's retry loop is wave-uniform)
         for (uint32_t jb = 0; jb < npairs; jb += MF_MLP * blockDim.x) {
@@ -407,7 +445,7 @@ __global__ __launch_bounds__(1024) void k_split(const uint64_t *__restrict__ in,
                 uint64_t keys[4] = {v[u].x, v[u].y, v[u + 1].x, v[u + 1].y};
                 uint32_t d[4]; bool valid[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) { valid[q] = keys[q] != MF_EMPTY; d[q] = mf_digit(mf_hash64(keys[q]), bits_used, bits); }
+                for (int q = 0; q < 4; q++) { valid[q] = keys[q] != MF_EMPTY; d[q] = mf_digit(mf_phash(keys[q]), bits_used, bits); }
                 if (STAGED) mf_stage_insert_batch(L, out, d, keys, valid);
                 else {
 #pragma unroll
@@ -458,7 +496,7 @@ __device__ __forceinline__ void mf_count_insert4(uint64_t *tk, uint32_t *tc, uin
                                                  unsigned int *overflow) {
     uint32_t s[4]; uint64_t cur[4];
 #pragma unroll
-    for (int b = 0; b < 4; b++) s[b] = (uint32_t)mf_hash64(key[b]) & mask;
+    for (int b = 0; b < 4; b++) s[b] = mf_pslot(mf_phash(key[b])) & mask;
 #pragma unroll
     for (int b = 0; b < 4; b++) cur[b] = *reinterpret_cast<volatile uint64_t *>(&tk[s[b]]);
 #pragma unroll
@@ -656,10 +694,10 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         mf_ktimer t(ctx, "k_l1_scatter");
         if (staged) {
             MF_TRY(set_lds(k_l1_scatter<true>, lds));
-            k_l1_scatter<true><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask.p, n_words, wpb, k, bits1, blockstart.p, G, bufA.p);
+            k_l1_scatter<true><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask.p, n_words, wpb, k, bits1, blockstart.p, G, bufA.p, (int)ctx->opt_ablate);
         } else {
             MF_TRY(set_lds(k_l1_scatter<false>, lds));
-            k_l1_scatter<false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask.p, n_words, wpb, k, bits1, blockstart.p, G, bufA.p);
+            k_l1_scatter<false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask.p, n_words, wpb, k, bits1, blockstart.p, G, bufA.p, 0);
         }
     }
     MF_DBG(ctx, "k_l1_scatter");
