@@ -62,7 +62,7 @@ int  mf_ctx_trim(mf_ctx *ctx);
 /* Per-kernel HIP-event timings accumulated while option "profile"=1.
  * Returns number of launches of `kernel` since the last reset; *total_ms = summed duration. */
 int64_t mf_ctx_kernel_time(mf_ctx *ctx, const char *kernel, double *total_ms);
-/* Writes "name\tlaunches\ttotal_ms\n" lines for every timed kernel into buf (NUL-terminated). */
+/* Writes "name\tlaunches\ttotal_ms\tmax_launch_ms\n" lines for every timed kernel into buf (NUL-terminated). */
 int  mf_ctx_kernel_report(mf_ctx *ctx, char *buf, uint64_t cap);
 int  mf_ctx_reset_timers(mf_ctx *ctx);
 

@@ -69,7 +69,8 @@ struct mf_ctx {
     // timers
     std::vector<mf_timer_rec> pending;
     std::vector<hipEvent_t> event_pool;
-    std::map<std::string, std::pair<int64_t, double>> timings;
+    struct ktime { int64_t n = 0; double total_ms = 0, max_ms = 0; };
+    std::map<std::string, ktime> timings;
 };
 
 int  mf_alloc(mf_ctx *ctx, size_t bytes, void **out);   // cached hipMalloc

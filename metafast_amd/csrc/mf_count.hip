@@ -31,6 +31,7 @@ __global__ void k_mask_init(uint32_t *__restrict__ vmask, uint64_t n_words, uint
     vmask[w] = m;
 }
 
+template <bool ATOMIC>
 __device__ __forceinline__ void mf_clear_bits(uint32_t *vmask, uint64_t lo, uint64_t hi) {  // clear [lo,hi)
     while (lo < hi) {
         uint64_t w = lo >> 5;
@@ -38,12 +39,16 @@ __device__ __forceinline__ void mf_clear_bits(uint32_t *vmask, uint64_t lo, uint
         uint64_t wend = (w + 1) << 5;
         uint32_t b1 = (uint32_t)((hi < wend ? hi : wend) - (w << 5));  // 1..32
         uint32_t m = (b1 == 32 ? 0xFFFFFFFFu : ((1u << b1) - 1u)) & ~((1u << b0) - 1u);
-        atomicAnd(&vmask[w], ~m);
+        if (ATOMIC) atomicAnd(&vmask[w], ~m);
+        else vmask[w] &= ~m;
         lo = wend;
     }
 }
 
-// one thread per read: clear the last k-1 start positions (or the whole read if too short)
+// one thread per read: clear the last k-1 start positions (or the whole read if too short).
+// The words of a long read's window [e-k+1, e) can only be shared with the NEXT read's cleared range, and only if that
+// read is short; so when this read and the next are both >= 64 bases the update is a plain read-modify-write
+// (1e8 reads x 2 atomics on the bitmap were 20 ms).
 __global__ void k_mask_reads(const uint64_t *__restrict__ off, uint64_t n_reads, int k, int min_len,
                              uint32_t *__restrict__ vmask, unsigned long long *__restrict__ n_occ) {
     uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,12 +56,25 @@ __global__ void k_mask_reads(const uint64_t *__restrict__ off, uint64_t n_reads,
     if (r < n_reads) {
         uint64_t s = off[r], e = off[r + 1];
         uint64_t len = e - s;
-        if (len < (uint64_t)k || (int64_t)len < (int64_t)min_len) mf_clear_bits(vmask, s, e);
-        else { mf_clear_bits(vmask, e - (uint64_t)k + 1, e); occ = len - (uint64_t)k + 1; }
+        uint64_t len_next = r + 1 < n_reads ? off[r + 2] - e : 64;
+        if (len < (uint64_t)k || (int64_t)len < (int64_t)min_len) mf_clear_bits<true>(vmask, s, e);
+        else {
+            if (len >= 64 && len_next >= 64 && (int64_t)len_next >= (int64_t)min_len) mf_clear_bits<false>(vmask, e - (uint64_t)k + 1, e);   // (a next read below min_len is cleared whole, with atomics, starting in our last word)
+            else mf_clear_bits<true>(vmask, e - (uint64_t)k + 1, e);
+            occ = len - (uint64_t)k + 1;
+        }
     }
-    // wave reduce, one atomic per wave
+    // block reduce, ONE atomic per 1024-thread workgroup (an atomic per wave on this single counter is 1.6e6 serialised
+    // atomics at 100 M reads = the whole 19 ms of this kernel)
+    __shared__ unsigned long long part[16];
     for (int d = 32; d >= 1; d >>= 1) occ += __shfl_down(occ, d, 64);
-    if (mf_lane() == 0 && occ) atomicAdd(n_occ, (unsigned long long)occ);
+    if (mf_lane() == 0) part[threadIdx.x >> 6] = occ;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += part[w];
+        if (t) atomicAdd(n_occ, t);
+    }
 }
 
 // =============================================================================================
@@ -477,43 +495,75 @@ __global__ __launch_bounds__(1024) void k_split(const uint64_t *__restrict__ in,
 // NEXT partition are loaded into registers while the current one is being counted, so the HBM latency of a
 // partition (one per ~3 k k-mers) is hidden behind the LDS work of the previous one.
 #define MF_PF 6            // 16-byte prefetch loads per thread: 12 keys x 256 threads = 3072 keys
-__device__ __forceinline__ void mf_count_insert(uint64_t *tk, uint32_t *tc, uint32_t mask, uint32_t slots, uint64_t key, uint32_t s,
-                                                unsigned int *overflow) {
-    uint32_t probes = 0;
-    for (;;) {
-        uint64_t cur = *reinterpret_cast<volatile uint64_t *>(&tk[s]);
-        if (cur == MF_EMPTY) {
-            cur = atomicCAS(reinterpret_cast<unsigned long long *>(&tk[s]), (unsigned long long)MF_EMPTY, (unsigned long long)key);
-            if (cur == MF_EMPTY) cur = key;
-        }
-        if (cur == key) { atomicAdd(&tc[s], 1u); return; }
-        s = (s + 1) & mask;
-        if (++probes > slots) { atomicExch(overflow, 1u); return; }
-    }
+// ---- four-wide LDS steps of the counting table (inline asm for the same reason as in the staging protocol) ----
+__device__ __forceinline__ void mf_lds_read4_b64(const uint32_t (&a)[4], uint64_t (&v)[4]) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
+                 : "memory");
 }
-// four keys at a time: the four first-probe reads are in flight together; a hit is one fire-and-forget LDS add
-__device__ __forceinline__ void mf_count_insert4(uint64_t *tk, uint32_t *tc, uint32_t mask, uint32_t slots, const uint64_t (&key)[4],
-                                                 unsigned int *overflow) {
-    uint32_t s[4]; uint64_t cur[4];
+// ds_cmpst_rtn_b64 vdst, vaddr, vcmp, vnew : MEM = (MEM == cmp) ? new : MEM, returns the old value
+__device__ __forceinline__ void mf_lds_cmpst4_b64(const uint32_t (&a)[4], uint64_t cmp, const uint64_t (&nv)[4], uint64_t (&old)[4]) {
+    asm volatile("ds_cmpst_rtn_b64 %0, %4, %8, %9\n\tds_cmpst_rtn_b64 %1, %5, %8, %10\n\tds_cmpst_rtn_b64 %2, %6, %8, %11\n\t"
+                 "ds_cmpst_rtn_b64 %3, %7, %8, %12\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
+                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(cmp), "v"(nv[0]), "v"(nv[1]), "v"(nv[2]), "v"(nv[3])
+                 : "memory");
+}
+__device__ __forceinline__ void mf_lds_add4(const uint32_t (&a)[4], const uint32_t (&inc)[4]) {
+    asm volatile("ds_add_u32 %0, %4\n\tds_add_u32 %1, %5\n\tds_add_u32 %2, %6\n\tds_add_u32 %3, %7"
+                 :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(inc[0]), "v"(inc[1]), "v"(inc[2]), "v"(inc[3])
+                 : "memory");
+}
+// Insert four keys per lane: probe (4 reads in flight) -> claim empty slots (4 CAS in flight) -> count hits (4 adds, not
+// waited for).  Lanes with nothing to do in a step use a private dummy slot / counter.  The loop is wave-uniform; a
+// miss moves that key to the next slot (linear probing).  A `volatile` C++ probe here compiled to flat_load sc0 sc1 +
+// a full vmcnt/lgkmcnt wait, and the CAS path ran serially with a few active lanes: 45 % of the kernel.
+__device__ __forceinline__ void mf_count_insert4(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
+                                                 uint32_t slots, const uint64_t (&key)[4], unsigned int *overflow) {
+    uint32_t s[4]; bool pend[4];
 #pragma unroll
-    for (int b = 0; b < 4; b++) s[b] = mf_pslot(mf_phash(key[b])) & mask;
+    for (int b = 0; b < 4; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = mf_pslot(mf_phash(key[b])) & mask; }
+    for (uint32_t probes = 0;; probes++) {
+        bool any = false;
 #pragma unroll
-    for (int b = 0; b < 4; b++) cur[b] = *reinterpret_cast<volatile uint64_t *>(&tk[s[b]]);
+        for (int b = 0; b < 4; b++) any |= pend[b];
+        if (__ballot(any) == 0ull) break;
+        if (probes > slots) { if (mf_lane() == 0) atomicExch(overflow, 1u); break; }
+        uint32_t ka[4], ca[4], aa[4], inc[4]; uint64_t cur[4], ret[4]; bool need[4]; bool anyneed = false;
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        if (key[b] == MF_EMPTY) continue;
-        if (cur[b] == key[b]) atomicAdd(&tc[s[b]], 1u);
-        else mf_count_insert(tk, tc, mask, slots, key[b], s[b], overflow);
+        for (int b = 0; b < 4; b++) ka[b] = pend[b] ? tk0 + 8u * s[b] : dummy_k;
+        mf_lds_read4_b64(ka, cur);
+#pragma unroll
+        for (int b = 0; b < 4; b++) { need[b] = pend[b] && cur[b] == MF_EMPTY; ca[b] = need[b] ? ka[b] : dummy_k; anyneed |= need[b]; }
+        if (__ballot(anyneed) != 0ull) {
+            mf_lds_cmpst4_b64(ca, MF_EMPTY, key, ret);
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (need[b]) cur[b] = ret[b] == MF_EMPTY ? key[b] : ret[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const bool hit = pend[b] && cur[b] == key[b];
+            aa[b] = hit ? tc0 + 4u * s[b] : dummy_c;
+            inc[b] = hit ? 1u : 0u;
+            if (hit) pend[b] = false;
+            else s[b] = (s[b] + 1) & mask;
+        }
+        mf_lds_add4(aa, inc);
     }
 }
 __global__ __launch_bounds__(256) void k_count(uint64_t *__restrict__ keys, uint16_t *__restrict__ cnt,
                                                const uint64_t *__restrict__ pstart, const uint32_t *__restrict__ plen,
                                                uint32_t np, uint32_t *__restrict__ dcount,
-                                               unsigned int *__restrict__ overflow) {
+                                               unsigned int *__restrict__ overflow, int ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t out_cursor;
-    uint64_t *tk = reinterpret_cast<uint64_t *>(smem);                    // [MF_COUNT_SLOTS]
-    uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS);     // [MF_COUNT_SLOTS]
+    uint64_t *tk = reinterpret_cast<uint64_t *>(smem);                    // [MF_COUNT_SLOTS] + 64 dummy slots
+    uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS + 64);   // [MF_COUNT_SLOTS] + 64 dummy counters
+    const uint32_t tk0 = mf_lds_addr(tk), tc0 = mf_lds_addr(tc);
+    const uint32_t dummy_k = tk0 + 8u * ((uint32_t)MF_COUNT_SLOTS + (uint32_t)mf_lane());
+    const uint32_t dummy_c = tc0 + 4u * ((uint32_t)MF_COUNT_SLOTS + (uint32_t)mf_lane());
+    if (threadIdx.x < 64) { tk[MF_COUNT_SLOTS + threadIdx.x] = 0; tc[MF_COUNT_SLOTS + threadIdx.x] = 0; }   // dummies: never EMPTY
     const ulonglong2 EE = make_ulonglong2(MF_EMPTY, MF_EMPTY);
     uint32_t p = blockIdx.x;
     if (p >= np) return;
@@ -548,11 +598,16 @@ __global__ __launch_bounds__(256) void k_count(uint64_t *__restrict__ keys, uint
 #pragma unroll
             for (int u = 0; u < MF_PF; u++) { uint32_t j = u * blockDim.x + threadIdx.x; R[u] = j < npairs_n ? nx2[j] : EE; }
         }
+        if (ablate != 3) {
 #pragma unroll
         for (int u = 0; u < MF_PF; u += 2) {
             uint64_t k4[4] = {K[u].x, K[u].y, K[u + 1].x, K[u + 1].y};
-            mf_count_insert4(tk, tc, mask, slots, k4, overflow);
+            mf_count_insert4(tk0, tc0, dummy_k, dummy_c, mask, slots, k4, overflow);
         }
+        } else { uint64_t acc = 0;
+#pragma unroll
+            for (int u = 0; u < MF_PF; u++) acc += K[u].x ^ K[u].y;
+            if (acc == 0x1234567ull) tk[0] = acc; }
         {   // partitions longer than the prefetch window (heavy hitters): the rest straight from HBM
             const ulonglong2 *in2 = reinterpret_cast<const ulonglong2 *>(keys + start);
             const uint32_t npairs = len >> 1;
@@ -560,27 +615,40 @@ __global__ __launch_bounds__(256) void k_count(uint64_t *__restrict__ keys, uint
                 uint32_t j0 = jb + threadIdx.x, j1 = j0 + blockDim.x;
                 ulonglong2 a = j0 < npairs ? in2[j0] : EE, b = j1 < npairs ? in2[j1] : EE;
                 uint64_t k4[4] = {a.x, a.y, b.x, b.y};
-                mf_count_insert4(tk, tc, mask, slots, k4, overflow);
+                mf_count_insert4(tk0, tc0, dummy_k, dummy_c, mask, slots, k4, overflow);
             }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ds_add_u32 of the asm blocks are invisible to hipcc's waitcnt pass
         __syncthreads();
         // compaction: each wave walks 64-slot chunks (lane = slot: conflict-free LDS reads; a per-thread run of 16
-        // consecutive slots is a 128-byte lane stride = 32-way bank conflict and made this phase dominate the kernel)
-        // and appends the occupied ones behind a cursor in LDS; the order inside a partition does not matter
-        for (uint32_t base = (threadIdx.x >> 6) << 6; base < slots; base += blockDim.x) {
-            const uint32_t sl = base + (uint32_t)mf_lane();
-            const uint64_t key = tk[sl];
-            const bool has = key != MF_EMPTY;
-            const unsigned long long b = __ballot(has);
-            if (b) {
-                uint32_t wb = 0;
-                if (mf_lane() == 0) wb = atomicAdd(&out_cursor, (uint32_t)__popcll(b));
-                wb = __shfl(wb, 0, 64);
-                if (has) {
-                    const uint32_t pos = wb + (uint32_t)__popcll(b & ((1ull << mf_lane()) - 1ull));
-                    const uint32_t v = tc[sl];
-                    keys[start + pos] = key;
-                    cnt[start + pos] = (uint16_t)(v > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : v);
+        // consecutive slots is a 128-byte lane stride = 32-way bank conflict and made this phase dominate the kernel),
+        // keeps them in registers, reserves its output range with ONE LDS atomic and writes; the order inside a
+        // partition does not matter
+        {
+            constexpr int NCH = MF_COUNT_SLOTS / 256;
+            const int nch = (int)(slots >> 8);
+            uint64_t ck[NCH]; uint32_t cv[NCH], pre[NCH]; uint32_t total = 0;
+            const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                ck[i] = MF_EMPTY; cv[i] = 0; pre[i] = 0;
+                if (i < nch) {
+                    const uint32_t sl = ((threadIdx.x >> 6) << 6) + (uint32_t)i * blockDim.x + (uint32_t)mf_lane();
+                    ck[i] = tk[sl]; cv[i] = tc[sl];
+                    const unsigned long long bal = __ballot(ck[i] != MF_EMPTY);
+                    pre[i] = total + (uint32_t)__popcll(bal & lt_mask);
+                    total += (uint32_t)__popcll(bal);
+                }
+            }
+            uint32_t wb = 0;
+            if (mf_lane() == 0 && total) wb = atomicAdd(&out_cursor, total);
+            wb = __shfl(wb, 0, 64);
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                if (i < nch && ck[i] != MF_EMPTY) {
+                    const uint32_t pos = wb + pre[i];
+                    keys[start + pos] = ck[i];
+                    cnt[start + pos] = (uint16_t)(cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]);
                 }
             }
         }
@@ -640,7 +708,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     {
         mf_ktimer t(ctx, "k_mask");
         k_mask_init<<<(unsigned)((n_words + 255) / 256), 256, 0, st>>>(vmask.p, n_words, n_bases);
-        k_mask_reads<<<(unsigned)((n_reads + 255) / 256), 256, 0, st>>>(d_offsets, n_reads, k, min_len, vmask.p, &scal.p[0]);
+        k_mask_reads<<<(unsigned)((n_reads + 1023) / 1024), 1024, 0, st>>>(d_offsets, n_reads, k, min_len, vmask.p, &scal.p[0]);
     }
     MF_DBG(ctx, "k_mask");
     MF_HIP(hipGetLastError());
@@ -741,11 +809,11 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     mf_buf<uint16_t> cnt; MF_TRY(cnt.alloc(ctx, cap));
     mf_buf<uint32_t> dcount; MF_TRY(dcount.alloc(ctx, np));
     {
-        size_t lds = (size_t)MF_COUNT_SLOTS * 12;
+        size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12;
         MF_TRY(set_lds(k_count, lds));
         unsigned grid = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 3);
         mf_ktimer t(ctx, "k_count");
-        k_count<<<grid, 256, lds, st>>>(bufA.p, cnt.p, pstart.p, plen.p, np, dcount.p, (unsigned int *)&scal.p[2]);
+        k_count<<<grid, 256, lds, st>>>(bufA.p, cnt.p, pstart.p, plen.p, np, dcount.p, (unsigned int *)&scal.p[2], (int)ctx->opt_ablate);
     }
     MF_DBG(ctx, "k_count");
     mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));

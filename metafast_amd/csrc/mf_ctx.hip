@@ -175,7 +175,7 @@ int mf_collect_timers(mf_ctx *ctx) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             auto &t = ctx->timings[r.name];
-            t.first += 1; t.second += ms;
+            t.n += 1; t.total_ms += ms; if (ms > t.max_ms) t.max_ms = ms;
         }
         ctx->event_pool.push_back(r.a);
         ctx->event_pool.push_back(r.b);
@@ -188,8 +188,8 @@ extern "C" int64_t mf_ctx_kernel_time(mf_ctx *ctx, const char *kernel, double *t
     if (mf_collect_timers(ctx) < 0) return MF_ERR;
     auto it = ctx->timings.find(kernel);
     if (it == ctx->timings.end()) { if (total_ms) *total_ms = 0; return 0; }
-    if (total_ms) *total_ms = it->second.second;
-    return it->second.first;
+    if (total_ms) *total_ms = it->second.total_ms;
+    return it->second.n;
 }
 extern "C" int mf_ctx_kernel_report(mf_ctx *ctx, char *buf, uint64_t cap) {
     if (!ctx || !buf || !cap) return mf_set_error("NULL argument");
@@ -197,7 +197,7 @@ extern "C" int mf_ctx_kernel_report(mf_ctx *ctx, char *buf, uint64_t cap) {
     std::string s;
     char line[256];
     for (auto &kv : ctx->timings) {
-        snprintf(line, sizeof line, "%s\t%lld\t%.6f\n", kv.first.c_str(), (long long)kv.second.first, kv.second.second);
+        snprintf(line, sizeof line, "%s\t%lld\t%.6f\t%.6f\n", kv.first.c_str(), (long long)kv.second.n, kv.second.total_ms, kv.second.max_ms);
         s += line;
     }
     if (s.size() + 1 > cap) return mf_set_error("report buffer too small (%zu needed)", s.size() + 1);

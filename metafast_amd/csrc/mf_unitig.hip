@@ -10,8 +10,8 @@
 //                   unique; a node without an incoming link is a start (task.run :52-69)
 //   U3 k_ut_walk    one thread per START node follows the successor links and stamps (start, distance) on every node
 //                   of its path: one hop per node in total (pointer jumping costs O(log len) passes over ALL nodes);
-//                   walks are cut every UT_WALK_CHUNK hops and continued from a work list, so the launch count grows
-//                   with the longest path only
+//                   walks are cut after 32 / 128 / 512 / 4096 / 4096 ... hops and the unfinished ones continue from a
+//                   compacted work list: lanes of a wave stay busy although path lengths differ by orders of magnitude
 //   U4 k_ut_ends    per path end: length filter and the reference's emission rule canon(start) <= canon(end k-mer)
 //                   where the end k-mer is the one BEYOND the path when the walk stopped on a left branch
 //                   (processSequence :83-107) -- this is what makes a path come out 0, 1 or 2 times
@@ -136,14 +136,14 @@ struct ut_walk_out {
     ut_item *cont; unsigned int *n_cont;
 };
 template <bool FIRST>
-__global__ void k_ut_walk(ut_arrays A, const ut_item *__restrict__ items, uint32_t n_items, ut_walk_out W) {
+__global__ void k_ut_walk(ut_arrays A, const ut_item *__restrict__ items, uint32_t n_items, ut_walk_out W, int chunk) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_items) return;
     uint32_t f, slot, d;
     if (FIRST) { f = A.starts[t]; slot = t; d = 0; }
     else { ut_item it = items[t]; f = it.node; slot = it.slot; d = it.dist; }
     const uint32_t s = A.starts[slot];
-    for (int step = 0; step < UT_WALK_CHUNK; step++) {
+    for (int step = 0; step < chunk; step++) {
         A.pk[f] = (unsigned long long)s | ((unsigned long long)d << 32);
         uint32_t g = A.succ[f];
         if (g == UT_NONE) { W.end_node[slot] = f; W.end_dist[slot] = d; return; }
@@ -301,7 +301,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
             ut_walk_out W; W.end_node = end_node.p; W.end_dist = end_dist.p; W.cont = contA.p; W.n_cont = &ctr.p[2];
             {
                 mf_ktimer tm(ctx, "k_ut_walk");
-                k_ut_walk<true><<<grid_for(n_starts), 256, 0, st>>>(A, nullptr, n_starts, W);
+                k_ut_walk<true><<<grid_for(n_starts), 256, 0, st>>>(A, nullptr, n_starts, W, 32);
             }
             rounds = 1;
             for (;;) {
@@ -316,7 +316,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
                 W.cont = (rounds & 1) ? contB.p : contA.p;
                 {
                     mf_ktimer tm(ctx, "k_ut_walk");
-                    k_ut_walk<false><<<grid_for(n_cont), 256, 0, st>>>(A, in, n_cont, W);
+                    k_ut_walk<false><<<grid_for(n_cont), 256, 0, st>>>(A, in, n_cont, W, rounds == 1 ? 128 : rounds == 2 ? 512 : UT_WALK_CHUNK);
                 }
                 rounds++;
             }

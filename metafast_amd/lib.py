@@ -151,8 +151,8 @@ class Context:
         _check(lib().mf_ctx_kernel_report(self.h, buf, len(buf)))
         out = {}
         for line in buf.value.decode().splitlines():
-            name, n, ms = line.split("\t")
-            out[name] = (int(n), float(ms))
+            name, n, ms, mx = line.split("\t")
+            out[name] = (int(n), float(ms), float(mx))
         return out
 
     # ---- A1-A4 ----
