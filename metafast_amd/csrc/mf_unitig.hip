@@ -8,14 +8,16 @@
 //                   canonical orientation (the other orientation follows by symmetry) + the unique neighbours' indices
 //   U2 k_ut_links   per ORIENTED k-mer (node = 2*index + strand): link f->g exists iff R(f) is unique and L(g) is
 //                   unique; a node without an incoming link is a start (task.run :52-69)
-//   U3 k_ut_walk    one thread per START node follows the successor links and stamps (start, distance) on every node
-//                   of its path: one hop per node in total (pointer jumping costs O(log len) passes over ALL nodes);
-//                   walks are cut after 32 / 128 / 512 / 4096 / 4096 ... hops and the unfinished ones continue from a
-//                   compacted work list: lanes of a wave stay busy although path lengths differ by orders of magnitude
-//   U4 k_ut_ends    per path end: length filter and the reference's emission rule canon(start) <= canon(end k-mer)
-//                   where the end k-mer is the one BEYOND the path when the walk stopped on a left branch
+//   U3 k_ut_walk1   one thread per START node follows the successor links to the end of its path (one random 4-byte read
+//                   per node, nothing written per node): path length + end node.  Walks are cut after 32 / 128 / 512 /
+//                   4096 ... hops and the unfinished ones continue from a compacted work list, so lanes stay busy
+//                   although path lengths differ by orders of magnitude (pointer jumping would cost O(log len) passes
+//                   over ALL nodes: it was 1.06 s of a 3.4 s step)
+//   U4 k_ut_ends    per path: length filter and the reference's emission rule canon(start) <= canon(end k-mer), where
+//                   the end k-mer is the one BEYOND the path when the walk stopped on a left branch
 //                   (processSequence :83-107) -- this is what makes a path come out 0, 1 or 2 times
-//   U5 k_ut_emit    every node writes its last base at offset + distance; weights by atomics
+//   U5 k_ut_walk2   only the EMITTED paths (a small fraction of the nodes) are walked again: bases are written at
+//                   offset + distance, weights are summed in registers (no atomics), same chunking
 //
 // Isolated cycles have no start node and are never emitted (same as the reference).
 #include "mf_common.h"
@@ -27,13 +29,11 @@
 #define UT_CODE_NONE 4u
 #define UT_CODE_MANY 5u
 #define UT_WALK_CHUNK 4096
-#define UT_UNSEEN 0xFFFFFFFFFFFFFFFFull      // pk value of a node no walk has reached (nodes on cycles keep it)
 
 struct ut_arrays {
     const uint64_t *gk; const uint16_t *gv; uint64_t n; int k;
     uint8_t *info; uint32_t *ridx; uint32_t *lidx;
     uint8_t *pal;             // even k only: 1 if the k-mer equals its reverse complement (else nullptr)
-    unsigned long long *pk;   // per node: low 32 = start node of its path, high 32 = distance from it (UT_UNSEEN if none)
     uint32_t *succ;           // per node: next node on the path or UT_NONE
     uint32_t *starts;         // compacted list of start nodes
     unsigned int *n_starts;
@@ -136,15 +136,13 @@ struct ut_walk_out {
     ut_item *cont; unsigned int *n_cont;
 };
 template <bool FIRST>
-__global__ void k_ut_walk(ut_arrays A, const ut_item *__restrict__ items, uint32_t n_items, ut_walk_out W, int chunk) {
+__global__ void k_ut_walk1(ut_arrays A, const ut_item *__restrict__ items, uint32_t n_items, ut_walk_out W, int chunk) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_items) return;
     uint32_t f, slot, d;
     if (FIRST) { f = A.starts[t]; slot = t; d = 0; }
     else { ut_item it = items[t]; f = it.node; slot = it.slot; d = it.dist; }
-    const uint32_t s = A.starts[slot];
     for (int step = 0; step < chunk; step++) {
-        A.pk[f] = (unsigned long long)s | ((unsigned long long)d << 32);
         uint32_t g = A.succ[f];
         if (g == UT_NONE) { W.end_node[slot] = f; W.end_dist[slot] = d; return; }
         f = g; d++;
@@ -154,13 +152,12 @@ __global__ void k_ut_walk(ut_arrays A, const ut_item *__restrict__ items, uint32
 }
 
 // PASS 0: equal-case arbitration (atomicMin of the start node id per start k-mer), count candidates
-// PASS 1: emit: path id from a cursor, pidmap[start] = pid, plen/pstart/pkey
+// PASS 1: emit: path id from a cursor, pstart / plen / pkey per path (a palindromic start gives two paths)
 struct ut_paths {
     uint32_t *eqmin;      // [n]
-    uint32_t *pidmap;     // [2n]
+    uint32_t *pstart;     // [n_paths] start node
     uint32_t *plen;       // [n_paths] length in nt
     uint64_t *pkey;       // [n_paths] canonical start k-mer * 2 + strand
-    uint32_t *dup;        // [n_paths] second copy of the path (palindromic start k-mer) or UT_NONE
     unsigned int *cursor;
 };
 template <int PASS>
@@ -189,50 +186,54 @@ __global__ void k_ut_ends(ut_arrays A, ut_paths P, const uint32_t *__restrict__ 
     } else {
         if (eq && P.eqmin[s >> 1] != s) return;            // "print any sequence, but only one of them" :109-118
         uint32_t pid = atomicAdd(P.cursor, twice ? 2u : 1u);
-        P.pidmap[s] = pid;
+        P.pstart[pid] = s;
         P.plen[pid] = (uint32_t)len_nt;
         P.pkey[pid] = stc * 2ull + (uint64_t)(s & 1u);
-        P.dup[pid] = twice ? pid + 1 : UT_NONE;
-        if (twice) { P.plen[pid + 1] = (uint32_t)len_nt; P.pkey[pid + 1] = stc * 2ull + 1ull; P.dup[pid + 1] = UT_NONE; }
+        if (twice) { P.pstart[pid + 1] = s; P.plen[pid + 1] = (uint32_t)len_nt; P.pkey[pid + 1] = stc * 2ull + 1ull; }
     }
 }
 
 struct ut_out {
     const uint64_t *off;     // [n_paths+1]
     uint8_t *bases;
-    unsigned long long *wsum; int32_t *wmin; int32_t *wmax;
+    int32_t *wavg, *wmin, *wmax;
 };
-__global__ void k_ut_emit(ut_arrays A, const uint32_t *__restrict__ pidmap, const uint32_t *__restrict__ dup, ut_out O) {
-    uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= 2 * A.n) return;
-    unsigned long long me = A.pk[f];
-    if (me == UT_UNSEEN) return;
-    uint32_t s = (uint32_t)me, dist = (uint32_t)(me >> 32);
-    uint32_t pid = pidmap[s];
-    if (pid == UT_NONE) return;
+// second walk, emitted paths only
+struct ut_item2 { uint32_t node, pid, dist; int32_t mn, mx; uint32_t pad; unsigned long long sum; };
+template <bool FIRST>
+__global__ void k_ut_walk2(ut_arrays A, const uint32_t *__restrict__ pstart, const ut_item2 *__restrict__ items, uint32_t n_items,
+                           ut_out O, ut_item2 *__restrict__ cont, unsigned int *__restrict__ n_cont, int chunk) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_items) return;
+    ut_item2 it;
+    if (FIRST) { it.node = pstart[t]; it.pid = t; it.dist = 0; it.mn = 0x7FFFFFFF; it.mx = 0; it.sum = 0; it.pad = 0; }
+    else it = items[t];
     const int k = A.k;
-    uint32_t i = (uint32_t)(f >> 1), o = (uint32_t)(f & 1);
-    uint64_t x = A.gk[i];
-    uint64_t y = o ? mf_revcomp(x, k) : x;
+    const uint64_t base = O.off[it.pid];
     const char *NUC = "AGCT";
-    int32_t v = (int32_t)A.gv[i];
-    for (int copy = 0; copy < 2 && pid != UT_NONE; copy++) {
-        const uint64_t base = O.off[pid];
-        O.bases[base + dist + (uint64_t)(k - 1)] = (uint8_t)NUC[y & 3u];
-        if (dist == 0)
+    uint32_t f = it.node, d = it.dist;
+    for (int step = 0; step < chunk; step++) {
+        const uint32_t i = f >> 1, o = f & 1u;
+        const uint64_t x = A.gk[i];
+        const uint64_t y = o ? mf_revcomp(x, k) : x;
+        O.bases[base + d + (uint64_t)(k - 1)] = (uint8_t)NUC[y & 3u];
+        if (d == 0)
             for (int j = 0; j < k - 1; j++) O.bases[base + j] = (uint8_t)NUC[(y >> (2 * (k - 1 - j))) & 3u];
-        atomicAdd(&O.wsum[pid], (unsigned long long)v);
-        atomicMin(&O.wmin[pid], v);
-        atomicMax(&O.wmax[pid], v);
-        pid = dup[pid];
+        const int32_t v = (int32_t)A.gv[i];
+        it.sum += (unsigned long long)v;
+        it.mn = v < it.mn ? v : it.mn;
+        it.mx = v > it.mx ? v : it.mx;
+        const uint32_t g = A.succ[f];
+        if (g == UT_NONE) {
+            const uint64_t len = O.off[it.pid + 1] - base;
+            O.wavg[it.pid] = (int32_t)(it.sum / (len - (uint64_t)k + 1));      // (int)(seqWeight / (len - k + 1)) :120-121
+            O.wmin[it.pid] = it.mn; O.wmax[it.pid] = it.mx;
+            return;
+        }
+        f = g; d++;
     }
-}
-__global__ void k_ut_weights(const unsigned long long *__restrict__ wsum, const uint64_t *__restrict__ off, uint64_t np, int k,
-                             int32_t *__restrict__ avg) {
-    uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= np) return;
-    uint64_t len = off[p + 1] - off[p];
-    avg[p] = (int32_t)(wsum[p] / (len - (uint64_t)k + 1));      // (int)(seqWeight / (len - k + 1)) :120-121
+    it.node = f; it.dist = d;
+    cont[atomicAdd(n_cont, 1u)] = it;
 }
 __global__ void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -268,16 +269,14 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
     int rc = MF_OK;
     do {
         if ((rc = mf_table_ensure_index(g)) < 0) break;
-        mf_buf<uint8_t> info, pal; mf_buf<uint32_t> ridx, lidx, eqmin, pidmap, succ, starts; mf_buf<unsigned long long> pk;
+        mf_buf<uint8_t> info, pal; mf_buf<uint32_t> ridx, lidx, eqmin, succ, starts;
         mf_buf<unsigned int> ctr;
         if ((rc = info.alloc(ctx, n)) < 0 || (rc = ridx.alloc(ctx, n)) < 0 || (rc = lidx.alloc(ctx, n)) < 0 ||
-            (rc = pk.alloc(ctx, 2 * n)) < 0 || (rc = succ.alloc(ctx, 2 * n)) < 0 || (rc = starts.alloc(ctx, 2 * n)) < 0 ||
-            (rc = ctr.alloc(ctx, 4)) < 0) break;
+            (rc = succ.alloc(ctx, 2 * n)) < 0 || (rc = starts.alloc(ctx, 2 * n)) < 0 || (rc = ctr.alloc(ctx, 4)) < 0) break;
         hipMemsetAsync(ctr.p, 0, 16, st);
-        hipMemsetAsync(pk.p, 0xFF, 2 * n * 8, st);
         ut_arrays A;
         A.gk = g->d_keys; A.gv = g->d_counts; A.n = n; A.k = k;
-        A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.pk = pk.p; A.succ = succ.p; A.starts = starts.p; A.n_starts = &ctr.p[1];
+        A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.succ = succ.p; A.starts = starts.p; A.n_starts = &ctr.p[1];
         A.pal = nullptr;
         if ((k & 1) == 0) { if ((rc = pal.alloc(ctx, n)) < 0) break; A.pal = pal.p; }   // palindromes need an even k
         {
@@ -292,16 +291,18 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if (hipMemcpyAsync(&n_starts, &ctr.p[1], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = mf_set_error("unitigs: links pass failed: %s", hipGetErrorString(hipGetLastError())); break;
         }
-        // U3: chunked walks from the start nodes
-        mf_buf<uint32_t> end_node, end_dist; mf_buf<ut_item> contA, contB;
+        auto chunk_of = [](int round) { return round == 0 ? 32 : round == 1 ? 128 : round == 2 ? 512 : UT_WALK_CHUNK; };
+        // U3: length-only walks from the start nodes
+        mf_buf<uint32_t> end_node, end_dist;
         if ((rc = end_node.alloc(ctx, n_starts)) < 0 || (rc = end_dist.alloc(ctx, n_starts)) < 0) break;
         int rounds = 0;
         if (n_starts) {
+            mf_buf<ut_item> contA, contB;
             if ((rc = contA.alloc(ctx, n_starts)) < 0) break;
             ut_walk_out W; W.end_node = end_node.p; W.end_dist = end_dist.p; W.cont = contA.p; W.n_cont = &ctr.p[2];
             {
-                mf_ktimer tm(ctx, "k_ut_walk");
-                k_ut_walk<true><<<grid_for(n_starts), 256, 0, st>>>(A, nullptr, n_starts, W, 32);
+                mf_ktimer tm(ctx, "k_ut_walk1");
+                k_ut_walk1<true><<<grid_for(n_starts), 256, 0, st>>>(A, nullptr, n_starts, W, chunk_of(0));
             }
             rounds = 1;
             for (;;) {
@@ -315,20 +316,18 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
                 ut_item *in = (rounds & 1) ? contA.p : contB.p;
                 W.cont = (rounds & 1) ? contB.p : contA.p;
                 {
-                    mf_ktimer tm(ctx, "k_ut_walk");
-                    k_ut_walk<false><<<grid_for(n_cont), 256, 0, st>>>(A, in, n_cont, W, rounds == 1 ? 128 : rounds == 2 ? 512 : UT_WALK_CHUNK);
+                    mf_ktimer tm(ctx, "k_ut_walk1");
+                    k_ut_walk1<false><<<grid_for(n_cont), 256, 0, st>>>(A, in, n_cont, W, chunk_of(rounds));
                 }
                 rounds++;
             }
             if (rc < 0) break;
         }
-        contA.reset(); contB.reset(); succ.reset();
         // U4
-        if ((rc = eqmin.alloc(ctx, n)) < 0 || (rc = pidmap.alloc(ctx, 2 * n)) < 0) break;
+        if ((rc = eqmin.alloc(ctx, n)) < 0) break;
         k_fill_u32<<<std::min(grid_for(n), 65536u), 256, 0, st>>>(eqmin.p, n, UT_NONE);
-        k_fill_u32<<<std::min(grid_for(2 * n), 65536u), 256, 0, st>>>(pidmap.p, 2 * n, UT_NONE);
         hipMemsetAsync(ctr.p, 0, 4, st);
-        ut_paths P; P.eqmin = eqmin.p; P.pidmap = pidmap.p; P.plen = nullptr; P.pkey = nullptr; P.dup = nullptr; P.cursor = ctr.p;
+        ut_paths P; P.eqmin = eqmin.p; P.pstart = nullptr; P.plen = nullptr; P.pkey = nullptr; P.cursor = ctr.p;
         if (n_starts) {
             mf_ktimer tm(ctx, "k_ut_ends");
             k_ut_ends<0><<<grid_for(n_starts), 256, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
@@ -337,10 +336,10 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if (hipMemcpyAsync(&ncand, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = mf_set_error("unitigs: ends pass failed"); break;
         }
-        mf_buf<uint32_t> plen, dup; mf_buf<uint64_t> pkey;
-        if ((rc = plen.alloc(ctx, ncand)) < 0 || (rc = pkey.alloc(ctx, ncand)) < 0 || (rc = dup.alloc(ctx, ncand)) < 0) break;
+        mf_buf<uint32_t> plen, pstart; mf_buf<uint64_t> pkey;
+        if ((rc = plen.alloc(ctx, ncand)) < 0 || (rc = pkey.alloc(ctx, ncand)) < 0 || (rc = pstart.alloc(ctx, ncand)) < 0) break;
         hipMemsetAsync(ctr.p, 0, 4, st);
-        P.plen = plen.p; P.pkey = pkey.p; P.dup = dup.p;
+        P.plen = plen.p; P.pkey = pkey.p; P.pstart = pstart.p;
         if (n_starts) {
             mf_ktimer tm(ctx, "k_ut_ends");
             k_ut_ends<1><<<grid_for(n_starts), 256, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
@@ -349,11 +348,11 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if (hipMemcpyAsync(&np, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = mf_set_error("unitigs: ends pass failed"); break;
         }
-        ridx.reset(); lidx.reset(); end_node.reset(); end_dist.reset(); eqmin.reset();
-        // U5
-        mf_buf<uint64_t> off, tot; mf_buf<unsigned long long> wsum; mf_buf<int32_t> wmin, wmax, wavg;
-        if ((rc = off.alloc(ctx, (size_t)np + 1)) < 0 || (rc = tot.alloc(ctx, 1)) < 0 || (rc = wsum.alloc(ctx, np)) < 0 ||
-            (rc = wmin.alloc(ctx, np)) < 0 || (rc = wmax.alloc(ctx, np)) < 0 || (rc = wavg.alloc(ctx, np)) < 0) break;
+        ridx.reset(); lidx.reset(); end_node.reset(); end_dist.reset(); eqmin.reset(); starts.reset();
+        // U5: walk the emitted paths again and write them out
+        mf_buf<uint64_t> off, tot; mf_buf<int32_t> wmin, wmax, wavg;
+        if ((rc = off.alloc(ctx, (size_t)np + 1)) < 0 || (rc = tot.alloc(ctx, 1)) < 0 || (rc = wmin.alloc(ctx, np)) < 0 ||
+            (rc = wmax.alloc(ctx, np)) < 0 || (rc = wavg.alloc(ctx, np)) < 0) break;
         k_scan<false><<<1, 1024, 0, st>>>(plen.p, off.p, (uint64_t)np, tot.p);
         uint64_t total = 0;
         if (hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
@@ -361,21 +360,39 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         }
         mf_buf<uint8_t> bases;
         if ((rc = bases.alloc(ctx, total + 64)) < 0) break;     // slack for the counting kernels' 16-byte loads
+        int rounds2 = 0;
         if (np) {
-            hipMemsetAsync(wsum.p, 0, (size_t)np * 8, st);
-            k_fill_u32<<<std::min(grid_for(np), 65536u), 256, 0, st>>>((uint32_t *)wmin.p, np, 0x7FFFFFFFu);
-            hipMemsetAsync(wmax.p, 0, (size_t)np * 4, st);
-            ut_out O; O.off = off.p; O.bases = bases.p; O.wsum = wsum.p; O.wmin = wmin.p; O.wmax = wmax.p;
+            mf_buf<ut_item2> c2A, c2B;
+            if ((rc = c2A.alloc(ctx, np)) < 0) break;
+            ut_out O; O.off = off.p; O.bases = bases.p; O.wavg = wavg.p; O.wmin = wmin.p; O.wmax = wmax.p;
+            hipMemsetAsync(&ctr.p[2], 0, 4, st);
             {
-                mf_ktimer tm(ctx, "k_ut_emit");
-                k_ut_emit<<<grid_for(2 * n), 256, 0, st>>>(A, pidmap.p, dup.p, O);
+                mf_ktimer tm(ctx, "k_ut_walk2");
+                k_ut_walk2<true><<<grid_for(np), 256, 0, st>>>(A, pstart.p, nullptr, np, O, c2A.p, &ctr.p[2], chunk_of(0));
             }
-            k_ut_weights<<<grid_for(np), 256, 0, st>>>(wsum.p, off.p, np, k, wavg.p);
+            rounds2 = 1;
+            for (;;) {
+                unsigned int n_cont = 0;
+                if (hipMemcpyAsync(&n_cont, &ctr.p[2], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                    rc = mf_set_error("unitigs: emit walk failed: %s", hipGetErrorString(hipGetLastError())); break;
+                }
+                if (!n_cont) break;
+                if (!c2B.p && (rc = c2B.alloc(ctx, n_cont)) < 0) break;
+                hipMemsetAsync(&ctr.p[2], 0, 4, st);
+                ut_item2 *in = (rounds2 & 1) ? c2A.p : c2B.p;
+                ut_item2 *outq = (rounds2 & 1) ? c2B.p : c2A.p;
+                {
+                    mf_ktimer tm(ctx, "k_ut_walk2");
+                    k_ut_walk2<false><<<grid_for(n_cont), 256, 0, st>>>(A, pstart.p, in, n_cont, O, outq, &ctr.p[2], chunk_of(rounds2));
+                }
+                rounds2++;
+            }
+            if (rc < 0) break;
         }
         if (hipStreamSynchronize(st) != hipSuccess) { rc = mf_set_error("unitigs: emit failed: %s", hipGetErrorString(hipGetLastError())); break; }
         if (ctx->opt_verbose)
-            fprintf(stderr, "[mf] unitigs: good=%llu starts=%u walk_rounds=%d candidates=%u paths=%u bases=%llu\n", (unsigned long long)n,
-                    n_starts, rounds, ncand, np, (unsigned long long)total);
+            fprintf(stderr, "[mf] unitigs: good=%llu starts=%u walk_rounds=%d+%d candidates=%u paths=%u bases=%llu\n", (unsigned long long)n,
+                    n_starts, rounds, rounds2, ncand, np, (unsigned long long)total);
         S->n = np; S->n_bases = total;
         S->bases_bytes = bases.bytes(); S->d_bases = bases.take();
         S->offsets_bytes = off.bytes(); S->d_offsets = off.take();
