@@ -156,7 +156,7 @@ def main():
                         traffic=tr)
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:       # reported at N=1 only
             from oracle import oracle as O          # checker only: CPU baseline leg
             m = min(args.cpu_sample_reads, n_reads)
             hb = bases[: m * rl].cpu().numpy()
