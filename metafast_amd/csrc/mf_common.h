@@ -122,6 +122,7 @@ struct mf_table {
     size_t keys_bytes = 0, counts_bytes = 0;
     mf_index index;               // built lazily
     size_t index_bytes = 0;
+    bool owns_arrays = true;      // false: d_keys / d_counts belong to another table (internal alias)
 };
 struct mf_seqs {
     mf_ctx *ctx = nullptr;
@@ -151,6 +152,8 @@ struct mf_comps {
 int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, mf_index *out,
                    size_t *bytes);
 int mf_table_ensure_index(mf_table *t);
+// entries with count > threshold; when every entry passes, a non-owning alias of `t` (no copy) -- internal use only
+int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out);
 int mf_comps_materialize(mf_comps *c);
 int mf_table_adopt(mf_ctx *ctx, int k, uint64_t n, uint64_t n_occ, uint64_t *d_keys, size_t kb, uint16_t *d_counts,
                    size_t cb, mf_table **out);
@@ -269,4 +272,41 @@ static __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict
     for (uint64_t i = lo; i < hi; i++) { uint64_t v = in[i]; if (PAD8) v = (v + 7) & ~7ull; out[i] = base; base += v; }
 }
 
+
+// ---- multi-block exclusive scan (u32 in -> u64 out) for long arrays: tile sums, scan of the tile sums, add-back ----
+#define MF_SCAN_TILE 4096
+template <bool PAD8>
+static __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n,
+                                                            uint32_t *__restrict__ tile_sum) {
+    __shared__ uint32_t scratch[17];
+    const uint64_t base = (uint64_t)blockIdx.x * MF_SCAN_TILE + (uint64_t)threadIdx.x * 4;
+    uint32_t v[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { uint32_t x = base + j < n ? in[base + j] : 0u; if (PAD8) x = (x + 7u) & ~7u; v[j] = x; s += x; }
+    uint32_t tot;
+    uint32_t ex = mf_block_excl_scan(s, scratch, &tot);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { if (base + j < n) out[base + j] = ex; ex += v[j]; }
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = tot;
+}
+static __global__ __launch_bounds__(1024) void k_scan_addback(uint64_t *__restrict__ out, uint64_t n, const uint64_t *__restrict__ tile_off) {
+    const uint64_t base = (uint64_t)blockIdx.x * MF_SCAN_TILE + (uint64_t)threadIdx.x * 4;
+    const uint64_t o = tile_off[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < 4; j++) if (base + j < n) out[base + j] += o;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = tile_off[gridDim.x];
+}
+// out[0..n] = exclusive prefix of in (out[n] = total, also written to *total); tiles must hold < 2^32 each
+template <bool PAD8>
+static int mf_scan(mf_ctx *ctx, const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *total) {
+    hipStream_t st = ctx->stream;
+    if (n <= 65536) { k_scan<PAD8><<<1, 1024, 0, st>>>(in, out, n, total); return MF_OK; }
+    const uint64_t nt = (n + MF_SCAN_TILE - 1) / MF_SCAN_TILE;
+    mf_buf<uint32_t> ts; MF_TRY(ts.alloc(ctx, nt));
+    mf_buf<uint64_t> to; MF_TRY(to.alloc(ctx, nt + 1));
+    k_scan_tiles<PAD8><<<(unsigned)nt, 1024, 0, st>>>(in, out, n, ts.p);
+    k_scan<false><<<1, 1024, 0, st>>>(ts.p, to.p, nt, total);
+    k_scan_addback<<<(unsigned)nt, 1024, 0, st>>>(out, n, to.p);
+    return MF_OK;
+}
 #endif  // __HIPCC__

@@ -751,7 +751,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     MF_DBG(ctx, "k_l1_hist");
     {
         mf_ktimer t(ctx, "k_scan");
-        k_scan<true><<<1, 1024, 0, st>>>(blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal.p[1]);
+        MF_TRY(mf_scan<true>(ctx, blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal.p[1]));
     }
     MF_DBG(ctx, "k_scan");
     uint64_t cap = n_occ + (uint64_t)MF_LINE * nd1 * G;    // upper bound of the padded total
@@ -819,7 +819,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));
     {
         mf_ktimer t(ctx, "k_scan");
-        k_scan<false><<<1, 1024, 0, st>>>(dcount.p, doff.p, np, (uint64_t *)&scal.p[3]);
+        MF_TRY(mf_scan<false>(ctx, dcount.p, doff.p, np, (uint64_t *)&scal.p[3]));
     }
     MF_DBG(ctx, "k_scan");
     MF_HIP(hipGetLastError());

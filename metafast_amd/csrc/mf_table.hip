@@ -147,8 +147,8 @@ int mf_table_adopt(mf_ctx *ctx, int k, uint64_t n, uint64_t n_occ, uint64_t *d_k
 
 extern "C" void mf_table_destroy(mf_table *t) {
     if (!t) return;
-    if (t->d_keys) mf_release(t->ctx, t->d_keys, t->keys_bytes);
-    if (t->d_counts) mf_release(t->ctx, t->d_counts, t->counts_bytes);
+    if (t->owns_arrays && t->d_keys) mf_release(t->ctx, t->d_keys, t->keys_bytes);
+    if (t->owns_arrays && t->d_counts) mf_release(t->ctx, t->d_counts, t->counts_bytes);
     if (t->index.slots) mf_release(t->ctx, t->index.slots, t->index_bytes);
     delete t;
 }
@@ -235,6 +235,31 @@ extern "C" int mf_table_filter(const mf_table *t, int threshold, mf_table **out)
     MF_TRY(select_entries<0>(ctx, t->d_keys, t->d_counts, nullptr, t->n, threshold, ok, oc, &m));
     size_t kb = ok.bytes(), cb = oc.bytes();
     return mf_table_adopt(ctx, t->k, m, 0, ok.take(), kb, oc.take(), cb, out);
+}
+
+int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out) {
+    mf_ctx *ctx = t->ctx;
+    if (t->n) {
+        // count first; copy only if something is filtered out
+        uint64_t n = t->n;
+        uint64_t nb = std::min<uint64_t>((n + 1023) / 1024, 2048);
+        uint64_t per = ((n + nb - 1) / nb + 1023) / 1024 * 1024;
+        nb = (n + per - 1) / per;
+        mf_buf<uint32_t> bcount; MF_TRY(bcount.alloc(ctx, nb));
+        mf_buf<uint64_t> boff; MF_TRY(boff.alloc(ctx, nb + 1));
+        mf_buf<uint64_t> tot; MF_TRY(tot.alloc(ctx, 1));
+        k_select_count<0><<<(unsigned)nb, 1024, 0, ctx->stream>>>(t->d_keys, t->d_counts, nullptr, n, per, threshold, bcount.p);
+        k_scan<false><<<1, 1024, 0, ctx->stream>>>(bcount.p, boff.p, nb, tot.p);
+        uint64_t m = 0;
+        MF_HIP(hipMemcpyAsync(&m, tot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipStreamSynchronize(ctx->stream));
+        if (m == n) {
+            MF_TRY(mf_table_adopt(ctx, t->k, t->n, 0, t->d_keys, t->keys_bytes, t->d_counts, t->counts_bytes, out));
+            (*out)->owns_arrays = false;
+            return MF_OK;
+        }
+    }
+    return mf_table_filter(t, threshold, out);
 }
 
 // host arrays -> table (insert-or-add with saturation through the HBM index)

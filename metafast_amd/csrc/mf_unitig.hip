@@ -252,7 +252,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
 
     // nodes = k-mers with value > freqThreshold (task.run :46-48)
     mf_table *g = nullptr;
-    MF_TRY(mf_table_filter(t, freq_threshold, &g));
+    MF_TRY(mf_table_filter_or_alias(t, freq_threshold, &g));
     struct guard { mf_table *p; ~guard() { mf_table_destroy(p); } } gg{g};
     const uint64_t n = g->n;
     mf_seqs *S = new mf_seqs();

@@ -8,6 +8,7 @@ step 3 joins all samples (ComponentCutterMain.java:81), so the ranks exchange th
 RCCL / xGMI) and every rank builds the same cutter table and components; the per-sample feature vectors are
 all-gathered for the Bray-Curtis matrix.  torch is used for device memory and torch.distributed only.
 """
+import os
 import time
 
 import numpy as np
@@ -15,6 +16,10 @@ import torch
 import torch.distributed as dist
 
 from . import lib as L
+
+
+# MF_FORCE_DIST=1: run the collectives even at world size 1 (lets a 1-GPU box exercise the RCCL code path)
+_FORCE = bool(os.environ.get("MF_FORCE_DIST")) and dist.is_available()
 
 
 def _world():
@@ -27,7 +32,7 @@ def all_gather_ragged(t):
     """all-gather of 1-D tensors of different lengths -> list of per-rank tensors (same device/dtype as t).
     Sizes are exchanged first; payloads are padded to the largest one (one collective each)."""
     rank, world = _world()
-    if world == 1:
+    if world == 1 and not _FORCE:
         return [t]
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
@@ -64,7 +69,7 @@ def gather_sequences(bases, offsets):
 def gather_vectors(vec):
     """vec: int64[C] -> int64[world, C] (every rank has the same C)"""
     rank, world = _world()
-    if world == 1:
+    if world == 1 and not _FORCE:
         return vec.reshape(1, -1)
     outs = [torch.empty_like(vec) for _ in range(world)]
     dist.all_gather(outs, vec)
