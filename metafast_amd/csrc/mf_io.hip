@@ -4,7 +4,12 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <chrono>
+#include <fcntl.h>
 #include <string>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
 int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k,
@@ -42,13 +47,42 @@ static uint64_t be_get(const uint8_t *p, int nb) { uint64_t v = 0; for (int i = 
 // ---------------------------------------------------------------------------------------------
 // A1 readers
 // ---------------------------------------------------------------------------------------------
+// growable byte buffer WITHOUT value-initialisation (a std::vector would zero gigabytes before every parse)
+struct byte_buf {
+    uint8_t *p = nullptr; size_t n = 0, cap = 0;
+    byte_buf() {}
+    byte_buf(const byte_buf &) = delete;
+    byte_buf &operator=(const byte_buf &) = delete;
+    byte_buf(byte_buf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
+    byte_buf &operator=(byte_buf &&o) noexcept { free(p); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; return *this; }
+    ~byte_buf() { free(p); }
+    void reserve(size_t c) { if (c > cap) { p = (uint8_t *)realloc(p, c); cap = c; } }
+    uint8_t *grow(size_t add) { if (n + add > cap) reserve(std::max(cap * 2, n + add + 4096)); return p + n; }   // room for `add` more bytes
+    void push_back(uint8_t c) { *grow(1) = c; n++; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    void resize(size_t m) { n = m; }                 // shrink only
+    const uint8_t *data() const { return p; }
+};
 struct read_batch {
-    std::vector<uint8_t> bases;      // upper-case ACGT
+    byte_buf bases;                  // upper-case ACGT
     std::vector<uint64_t> offsets;   // [n+1]
     read_batch() { offsets.push_back(0); }
     void end_read() { offsets.push_back(bases.size()); }
     void drop_read() { bases.resize(offsets.back()); }
 };
+// byte -> base (DnaTools.fromChar, itmo!/dna/DnaTools.java:46-64; IUPAC codes: first listed choice, see nucleotide_of),
+// 0xFE = N/n (the whole read is skipped), 0xFF = not a nucleotide
+struct base_lut {
+    uint8_t t[256];
+    base_lut() {
+        for (int c = 0; c < 256; c++) t[c] = 0xFF;
+        const char *from = "ACGTacgtRrYyMmKkSsWwHhBbVvDd", *to = "ACGTACGTGGTTAAGGGGAAAAGGAAAA";
+        for (int i = 0; from[i]; i++) t[(unsigned char)from[i]] = (uint8_t)to[i];
+        t['N'] = t['n'] = 0xFE;
+    }
+};
+static const base_lut BASE_LUT;
 // one text line at a time; BufferedReader.readLine semantics (\n, \r or \r\n)
 struct line_reader {
     const char *b; size_t n, pos;
@@ -75,13 +109,27 @@ static int nucleotide_of(int c) {
 }
 // FastaReader (itmo!/io/readers/FastaReader.java:53-104): records = concatenation of the non-comment lines between
 // '>'/';' lines; a record containing N/n is skipped
-static int parse_fasta(const std::vector<char> &buf, const char *path, read_batch &rb) {
-    line_reader lr{buf.data(), buf.size(), 0};
-    const char *ln; size_t len;
+static int parse_fasta(const char *data, size_t size, const char *path, read_batch &rb) {
+    size_t pos = 0;
     bool have = false, has_n = false;
     int bad = -1;
     for (;;) {
-        bool got = lr.next(&ln, &len);
+        // one line: [ln, ln+len), BufferedReader.readLine line ends (\n, \r\n; a lone \r also ends a line)
+        bool got = pos < size;
+        const char *ln = data + pos; size_t len = 0;
+        if (got) {
+            const char *nl = (const char *)memchr(ln, '\n', size - pos);
+            size_t e = nl ? (size_t)(nl - data) : size;
+            len = e - pos;
+            pos = nl ? e + 1 : size;
+            if (len && ln[len - 1] == '\r') len--;
+            if (len && memchr(ln, '\r', len)) {            // rare: lone CR inside -> let the generic reader split it
+                line_reader lr{data, size, (size_t)(ln - data)};
+                const char *l2; size_t n2;
+                lr.next(&l2, &n2);
+                len = n2; pos = lr.pos;
+            }
+        }
         bool comment = got && len > 0 && (ln[0] == '>' || ln[0] == ';');
         if (!got || comment) {
             if (have) {
@@ -93,13 +141,14 @@ static int parse_fasta(const std::vector<char> &buf, const char *path, read_batc
             if (!got) break;
             continue;
         }
+        uint8_t *w = rb.bases.grow(len);
+        size_t k = 0;
         for (size_t i = 0; i < len; i++) {
-            int c = (unsigned char)ln[i];
-            if (c == 'N' || c == 'n') { has_n = true; continue; }
-            int b = nucleotide_of(c);
-            if (b < 0) { if (bad < 0) bad = c; continue; }
-            rb.bases.push_back((uint8_t)b);
+            uint8_t b = BASE_LUT.t[(unsigned char)ln[i]];
+            if (b >= 0xFE) { if (b == 0xFE) has_n = true; else if (bad < 0) bad = (unsigned char)ln[i]; continue; }
+            w[k++] = b;
         }
+        rb.bases.n += k;
         if (len) have = true;
     }
     return MF_OK;
@@ -112,43 +161,123 @@ static int fastq_line(line_reader &lr, const char *path, const char **ln, size_t
     if (!lr.next(ln, len)) return mf_set_error("Unexpected end of file. File is corrupted/Format mismatch. (%s)", path);
     return 1;
 }
-static int parse_fastq(const std::vector<char> &buf, const char *path, read_batch &rb) {
-    int offset = 64;
-    for (int pass = 0; pass < 2; pass++) {
-        line_reader lr{buf.data(), buf.size(), 0};
-        const char *d, *q; size_t dl, ql;
-        long rec = 0;
-        for (;;) {
-            int g = fastq_line(lr, path, &d, &dl);
-            if (g < 0) return g;
-            if (!g) break;
-            g = fastq_line(lr, path, &q, &ql);
-            if (g < 0) return g;
-            if (!g) return mf_set_error("Unexpected end of file. File is corrupted/Format mismatch. (%s)", path);
-            if (dl != ql) return mf_set_error("Bad DnaQ record: length of chars and quality is not the same. (%s)", path);
-            bool good = true;
-            for (size_t i = 0; i < dl; i++) {
-                int c = (unsigned char)d[i];
-                if (c == 'N' || c == 'n' || c == '.') { good = false; continue; }
-                int b = nucleotide_of(c);
-                if (b < 0) return mf_set_error("Incorrect nucleotide char: \"%c\" (%s)", c, path);
-                int qc = (unsigned char)q[i];
-                if (pass == 0) { if (qc < 64 || qc > 126) { offset = 33; goto sniffed; } }
-                else {
-                    if (qc < offset || qc > 126) return mf_set_error("Invalid quality code char: \"%c\" char code = %d (%s)", qc, qc, path);
-                    if (qc == offset) good = false;
-                    rb.bases.push_back((uint8_t)b);
-                }
+// pass 0: quality sniffing only (returns the offset, 64 or 33); pass 1: parse [data, data+size) with `offset`
+static int parse_fastq_pass(const char *data, size_t size, const char *path, int pass, int offset, read_batch &rb) {
+    line_reader lr{data, size, 0};
+    const char *d, *q; size_t dl, ql;
+    long rec = 0;
+    for (;;) {
+        int g = fastq_line(lr, path, &d, &dl);
+        if (g < 0) return g;
+        if (!g) break;
+        g = fastq_line(lr, path, &q, &ql);
+        if (g < 0) return g;
+        if (!g) return mf_set_error("Unexpected end of file. File is corrupted/Format mismatch. (%s)", path);
+        if (dl != ql) return mf_set_error("Bad DnaQ record: length of chars and quality is not the same. (%s)", path);
+        bool good = true;
+        for (size_t i = 0; i < dl; i++) {
+            int c = (unsigned char)d[i];
+            if (c == 'N' || c == 'n' || c == '.') { good = false; continue; }
+            int b = nucleotide_of(c);
+            if (b < 0) return mf_set_error("Incorrect nucleotide char: \"%c\" (%s)", c, path);
+            int qc = (unsigned char)q[i];
+            if (pass == 0) { if (qc < 64 || qc > 126) return 33; }
+            else {
+                if (qc < offset || qc > 126) return mf_set_error("Invalid quality code char: \"%c\" char code = %d (%s)", qc, qc, path);
+                if (qc == offset) good = false;
+                rb.bases.push_back((uint8_t)b);
             }
-            if (pass == 1) { if (good) rb.end_read(); else rb.drop_read(); }
-            if (pass == 0 && ++rec >= 1000) break;
         }
-    sniffed:;
+        if (pass == 1) { if (good) rb.end_read(); else rb.drop_read(); }
+        if (pass == 0 && ++rec >= 1000) break;
     }
+    return pass == 0 ? 64 : MF_OK;
+}
+// ---- parallel host parsing: the file is cut at record starts, each host thread parses its piece with the serial
+// parser above (so the semantics are the serial ones by construction), pieces are concatenated in order.
+// The reference parses serially under a monitor (src/io/ReadersDispatcher.java:34-53) -- its Amdahl limit; here the
+// parser has to keep a 40 GB/s PCIe link busy. ----
+struct raw_file {            // uninitialised heap buffer (std::vector would zero 15 GB serially first)
+    char *p = nullptr; size_t n = 0;
+    ~raw_file() { free(p); }
+    const char *data() const { return p; }
+    size_t size() const { return n; }
+};
+static int read_file_parallel(const char *path, raw_file &buf, int threads) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return mf_set_error("can't open '%s'", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return mf_set_error("can't stat '%s'", path); }
+    const size_t n = (size_t)st.st_size;
+    buf.p = (char *)malloc(n ? n : 1); buf.n = n;
+    if (!buf.p) { close(fd); return mf_set_error("out of host memory reading '%s'", path); }
+    int T = (int)std::min<size_t>((size_t)std::max(threads, 1), n / (16u << 20) + 1);
+    std::vector<std::thread> th;
+    std::vector<int> ok(T, 1);
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t]() {
+            size_t lo = n * t / T, hi = n * (t + 1) / T;
+            while (lo < hi) { ssize_t r = pread(fd, buf.p + lo, hi - lo, (off_t)lo); if (r <= 0) { ok[t] = 0; break; } lo += (size_t)r; }
+        });
+    for (auto &x : th) x.join();
+    close(fd);
+    for (int t = 0; t < T; t++) if (!ok[t]) return mf_set_error("short read on '%s'", path);
+    return MF_OK;
+}
+// start of the first record at or after `pos` (or n): FASTA = a line starting with '>' or ';';
+// FASTQ = a line starting with '@' whose second-next line starts with '+' (a quality line may start with '@' too,
+// but then the line two below it is a sequence line)
+static size_t next_record_start(const char *b, size_t n, size_t pos, int fmt) {
+    if (pos == 0) return 0;
+    while (pos < n) {
+        const void *nl = memchr(b + pos, '\n', n - pos);
+        if (!nl) return n;
+        pos = (size_t)((const char *)nl - b) + 1;
+        if (pos >= n) return n;
+        if (fmt == 1) { if (b[pos] == '>' || b[pos] == ';') return pos; }
+        else if (b[pos] == '@') {
+            const void *l1 = memchr(b + pos, '\n', n - pos);
+            if (!l1) return n;
+            size_t p2 = (size_t)((const char *)l1 - b) + 1;
+            const void *l2 = p2 < n ? memchr(b + p2, '\n', n - p2) : nullptr;
+            if (!l2) return n;
+            size_t p3 = (size_t)((const char *)l2 - b) + 1;
+            if (p3 < n && b[p3] == '+') return pos;
+        }
+    }
+    return n;
+}
+static int parse_buffer_parallel(const raw_file &buf, int fmt, const char *path, int threads, std::vector<read_batch> &out_parts) {
+    const char *b = buf.data();
+    const size_t n = buf.size();
+    int offset = 64;
+    if (fmt == 2) { read_batch tmp; offset = parse_fastq_pass(b, n, path, 0, 0, tmp); if (offset < 0) return offset; }
+    int T = (int)std::min<size_t>((size_t)std::max(threads, 1), n / (4u << 20) + 1);
+    // a FASTQ file with empty lines, or a file without '\n' line ends, is parsed serially (cut points would be unsafe)
+    if (T > 1 && !memchr(b, '\n', std::min<size_t>(n, 1u << 20))) T = 1;
+    if (T > 1 && fmt == 2 && (memmem(b, n, "\n\n", 2) || memmem(b, n, "\n\r\n", 3))) T = 1;
+    std::vector<size_t> cut(T + 1, n);
+    cut[0] = 0;
+    for (int t = 1; t < T; t++) cut[t] = next_record_start(b, n, n * t / T, fmt);
+    for (int t = 1; t <= T; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
+    std::vector<read_batch> parts(T);
+    std::vector<int> rc(T, MF_OK);
+    std::vector<std::string> err(T);
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t]() {
+            parts[t].bases.reserve(cut[t + 1] - cut[t]);
+            rc[t] = fmt == 1 ? parse_fasta(b + cut[t], cut[t + 1] - cut[t], path, parts[t])
+                             : parse_fastq_pass(b + cut[t], cut[t + 1] - cut[t], path, 1, offset, parts[t]);
+            if (rc[t] < 0) err[t] = mf_last_error();         // thread-local message -> carry it to the caller
+        });
+    for (auto &x : th) x.join();
+    for (int t = 0; t < T; t++) if (rc[t] < 0) return mf_set_error("%s", err[t].c_str());
+    for (auto &p : parts) out_parts.push_back(std::move(p));      // pieces stay separate: they go to the device one by one
     return MF_OK;
 }
 // ReadersUtils.detectFileFormat (itmo!/io/ReadersUtils.java:27-54); compressed / binq inputs are not supported yet
-static int parse_reads_file(const char *path, read_batch &rb) {
+static int parse_reads_file(const char *path, int threads, std::vector<read_batch> &parts) {
     std::string p(path);
     int fmt = 0;
     if (ends_with_nocase(p, ".gz") || ends_with_nocase(p, ".bz2") || ends_with_nocase(p, ".binq"))
@@ -156,9 +285,14 @@ static int parse_reads_file(const char *path, read_batch &rb) {
     if (ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq")) fmt = 2;
     else if (ends_with_nocase(p, ".fasta") || ends_with_nocase(p, ".fa") || ends_with_nocase(p, ".fn") || ends_with_nocase(p, ".fna")) fmt = 1;
     if (!fmt) return mf_set_error("Can't detect file format for file '%s'", path);
-    std::vector<char> buf;
-    MF_TRY(read_whole_file(path, buf));
-    return fmt == 1 ? parse_fasta(buf, path, rb) : parse_fastq(buf, path, rb);
+    raw_file buf;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    MF_TRY(read_file_parallel(path, buf, threads));
+    const double t1 = now();
+    int rc = parse_buffer_parallel(buf, fmt, path, threads, parts);
+    if (getenv("MF_IO_TIMING")) fprintf(stderr, "[mf] %s: read %.3f s, parse %.3f s\n", path, t1 - t0, now() - t1);
+    return rc;
 }
 
 // IOUtils.loadReads (src/io/IOUtils.java:772-803): all files into one table
@@ -167,16 +301,42 @@ extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles,
     *out = nullptr;
     if (k < 1) return mf_set_error("The size of k-mer must be at least 1.");
     if (k > 31) return mf_set_error("The size of k-mer must be no more than 31.");
-    read_batch rb;
-    for (int i = 0; i < nfiles; i++) MF_TRY(parse_reads_file(files[i], rb));
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    std::vector<read_batch> parts;
+    for (int i = 0; i < nfiles; i++) MF_TRY(parse_reads_file(files[i], ctx->host_threads, parts));
+    const double t1 = now();
     MF_HIP(hipSetDevice(ctx->device));
-    const uint64_t nb = rb.bases.size(), nr = rb.offsets.size() - 1;
+    // pieces -> one (bases, offsets) pair in HBM: bases piece by piece, offsets rebased on the host
+    uint64_t nb = 0, nr = 0;
+    std::vector<uint64_t> pb(parts.size()), pr(parts.size());
+    for (size_t t = 0; t < parts.size(); t++) { pb[t] = nb; pr[t] = nr; nb += parts[t].bases.size(); nr += parts[t].offsets.size() - 1; }
+    std::vector<uint64_t> offsets(nr + 1);
+    offsets[0] = 0;
+    {
+        std::vector<std::thread> th;
+        int T = (int)std::min<size_t>(parts.size(), (size_t)std::max(ctx->host_threads, 1));
+        for (int w = 0; w < T; w++)
+            th.emplace_back([&, w]() {
+                for (size_t t = (size_t)w; t < parts.size(); t += (size_t)T)
+                    for (size_t i = 1; i < parts[t].offsets.size(); i++) offsets[pr[t] + i] = parts[t].offsets[i] + pb[t];
+            });
+        for (auto &x : th) x.join();
+    }
     mf_buf<uint8_t> db; mf_buf<uint64_t> doff;
     MF_TRY(db.alloc(ctx, nb + 64)); MF_TRY(doff.alloc(ctx, nr + 1));
-    if (nb) MF_HIP(hipMemcpyAsync(db.p, rb.bases.data(), nb, hipMemcpyHostToDevice, ctx->stream));
-    MF_HIP(hipMemcpyAsync(doff.p, rb.offsets.data(), (nr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (size_t t = 0; t < parts.size(); t++)
+        if (!parts[t].bases.empty())
+            MF_HIP(hipMemcpyAsync(db.p + pb[t], parts[t].bases.data(), parts[t].bases.size(), hipMemcpyHostToDevice, ctx->stream));
+    MF_HIP(hipMemcpyAsync(doff.p, offsets.data(), (nr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     MF_HIP(hipStreamSynchronize(ctx->stream));
-    return mf_count_core(ctx, db.p, doff.p, nr, nb, k, min_read_len, out);
+    const double t2 = now();
+    parts.clear();
+    int rc = mf_count_core(ctx, db.p, doff.p, nr, nb, k, min_read_len, out);
+    if (ctx->opt_verbose)
+        fprintf(stderr, "[mf] count_reads: read+parse %.3f s, offsets+H2D %.3f s, count %.3f s (%llu reads, %llu bases, %d host threads)\n",
+                t1 - t0, t2 - t1, now() - t2, (unsigned long long)nr, (unsigned long long)nb, ctx->host_threads);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -195,3 +195,43 @@ def test_cli_errors_and_single_tools(ref_files, tmp_path):
     assert r.returncode == 0, r.stderr
     assert sorted(os.listdir(wd / "kmers")) == ["lib.kmers.bin", "meta_test_1.kmers.bin"]
     assert sorted(os.listdir(wd / "stats")) == ["lib.stat.txt", "meta_test_1.stat.txt"]
+
+
+def test_parallel_host_parser_large_files(gpu_ctx, oracle, tmp_path):
+    """files big enough to be cut into many pieces (one per host thread): multi-line FASTA with comment lines and N reads,
+    FASTQ with quality lines that start with '@' and '+'; counts must equal the oracle's serial reader"""
+    rng = np.random.default_rng(5)
+    al = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n = 150_000
+    fa = tmp_path / "big.fasta"
+    with open(fa, "wb") as f:
+        for i in range(n):
+            L = int(rng.integers(40, 260))
+            s = al[rng.integers(0, 4, size=L)].tobytes()
+            if i % 97 == 0:
+                s = s[:10] + b"N" + s[11:]
+            if i % 53 == 0:
+                f.write(b";comment line\n")
+            f.write(b">r%d some description\n" % i)
+            for j in range(0, L, 80):
+                f.write(s[j:j + 80] + (b"\r\n" if i % 11 == 0 else b"\n"))
+    assert os.path.getsize(fa) > 20_000_000
+    gk, gc = gpu_ctx.count_reads([str(fa)], 21).export()
+    ok, ov = oracle.Table().count_files([str(fa)], 21).export()
+    assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+    fq = tmp_path / "big.fq"
+    quals = np.frombuffer(b"@+IIIIFFFF5555!", dtype=np.uint8)
+    with open(fq, "wb") as f:
+        for i in range(n // 2):
+            L = int(rng.integers(60, 151))
+            s = al[rng.integers(0, 4, size=L)].tobytes()
+            q = quals[rng.integers(0, len(quals) - (0 if i % 41 == 0 else 1), size=L)].tobytes()   # '!' (phred 0) only sometimes
+            if i % 29 == 0:
+                q = b"@" + q[1:]
+            if i % 31 == 0:
+                q = b"+" + q[1:]
+            f.write(b"@read%d\n" % i + s + b"\n+\n" + q + b"\n")
+    assert os.path.getsize(fq) > 8_000_000
+    gk, gc = gpu_ctx.count_reads([str(fq)], 21).export()
+    ok, ov = oracle.Table().count_files([str(fq)], 21).export()
+    assert len(ok) > 0 and np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
