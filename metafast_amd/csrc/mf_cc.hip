@@ -22,7 +22,7 @@
 
 #define CC_NONE 0xFFFFFFFFu
 
-__global__ void k_cc_adjacency(const mf_slot *__restrict__ slots, uint64_t mask, const uint64_t *__restrict__ keys, uint64_t n,
+__global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ keys, uint64_t n,
                                int k, uint32_t *__restrict__ nbr) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
@@ -33,9 +33,9 @@ __global__ void k_cc_adjacency(const mf_slot *__restrict__ slots, uint64_t mask,
     for (uint32_t nuc = 0; nuc < 4; nuc++) {
         uint32_t idx, val;
         uint64_t y = ((x << 2) | nuc) & kmask;
-        out[2 * nuc] = mf_index_find(slots, mask, mf_canon(y, k), &idx, &val) ? idx : CC_NONE;
+        out[2 * nuc] = mf_index_find(ix, mf_canon(y, k), &idx, &val) ? idx : CC_NONE;
         y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2));
-        out[2 * nuc + 1] = mf_index_find(slots, mask, mf_canon(y, k), &idx, &val) ? idx : CC_NONE;
+        out[2 * nuc + 1] = mf_index_find(ix, mf_canon(y, k), &idx, &val) ? idx : CC_NONE;
     }
     uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
     o[0] = make_uint4(out[0], out[1], out[2], out[3]);
@@ -136,7 +136,7 @@ __global__ void k_cc_remap(uint32_t *__restrict__ comp, uint64_t n, const uint32
 }
 
 // ---- features: one thread per sample record ----
-__global__ void k_features(const mf_slot *__restrict__ slots, uint64_t mask, const uint32_t *__restrict__ comp_of,
+__global__ void k_features(mf_index_view ix, const uint32_t *__restrict__ comp_of,
                            const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnts, uint64_t n, int threshold,
                            unsigned long long *__restrict__ vec, unsigned int *__restrict__ found) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -145,7 +145,7 @@ __global__ void k_features(const mf_slot *__restrict__ slots, uint64_t mask, con
         int c = (int)cnts[i];
         if (c <= threshold) continue;                       // value > threshold (buildAndPrintVector :196-199)
         uint32_t idx, val;
-        if (!mf_index_find(slots, mask, keys[i], &idx, &val)) continue;   // hm.contains(kmer) (KmersPresenceWorker :583-587)
+        if (!mf_index_find(ix, keys[i], &idx, &val)) continue;   // hm.contains(kmer) (KmersPresenceWorker :583-587)
         uint32_t comp = comp_of[idx];
         atomicAdd(&vec[comp], (unsigned long long)c);
         atomicAdd(&found[comp], 1u);
@@ -226,7 +226,7 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
         cc_kept_arrays K; K.root = k_root.p; K.size = k_size.p; K.weight = k_weight.p; K.minkey = k_minkey.p;
         {
             mf_ktimer tm(ctx, "k_cc_adjacency");
-            k_cc_adjacency<<<cgrid(n), 256, 0, st>>>((const mf_slot *)t->index.slots, t->index.cap - 1, t->d_keys, n, k, nbr.p);
+            k_cc_adjacency<<<cgrid(n), 256, 0, st>>>(mf_view(t->index), t->d_keys, n, k, nbr.p);
         }
         MF_HIP(hipMemsetAsync(alive.p, 1, n, st));
         for (int thr = 1;; thr++) {
@@ -369,7 +369,7 @@ extern "C" int mf_features_device(mf_ctx *ctx, mf_comps *c, const mf_table *samp
     if (sample->n) {
         unsigned grid = (unsigned)std::min<uint64_t>((sample->n + 255) / 256, 65536);
         mf_ktimer tm(ctx, "k_features");
-        k_features<<<grid, 256, 0, st>>>((const mf_slot *)c->index.slots, c->index.cap - 1, c->d_comp, sample->d_keys,
+        k_features<<<grid, 256, 0, st>>>(mf_view(c->index), c->d_comp, sample->d_keys,
                                          sample->d_counts, sample->n, threshold, dvec.p, dfound.p);
     }
     std::vector<unsigned int> hf(nc);

@@ -111,7 +111,12 @@ template <typename T> struct mf_buf {   // RAII workspace buffer
 struct mf_index {                 // open-addressed table in HBM: 16-byte slots {key, idx, val}
     void *slots = nullptr;        // ulonglong2-like: .x = key, .y = (uint64)idx | (uint64)val << 32
     uint64_t cap = 0;             // power of two
+    // partitioned form (part_bits > 0): slot region of a key = top part_bits of mf_phash(key), linear probing wraps
+    // inside the 2^region_bits slots of that region; generic form (part_bits == 0): fmix64(key) & (cap-1)
+    uint32_t part_bits = 0, region_bits = 0;
 };
+struct mf_index_view { const void *slots; uint64_t mask; uint32_t part_bits, region_bits; };
+static inline mf_index_view mf_view(const mf_index &ix) { return mf_index_view{ix.slots, ix.cap - 1, ix.part_bits, ix.region_bits}; }
 struct mf_table {
     mf_ctx *ctx = nullptr;
     int k = 0;
@@ -123,6 +128,10 @@ struct mf_table {
     mf_index index;               // built lazily
     size_t index_bytes = 0;
     bool owns_arrays = true;      // false: d_keys / d_counts belong to another table (internal alias)
+    // partition structure left by the counting path: entries of hash partition p (top part_bits of mf_phash) are
+    // d_keys[d_part_off[p] .. d_part_off[p+1]); lets the index be built partition by partition without HBM atomics
+    int part_bits = 0;
+    uint64_t *d_part_off = nullptr; size_t part_off_bytes = 0;
 };
 struct mf_seqs {
     mf_ctx *ctx = nullptr;
@@ -237,14 +246,20 @@ __device__ __forceinline__ uint32_t mf_block_excl_scan(uint32_t v, uint32_t *scr
 
 // ---- HBM open-addressed index lookup (16-byte slots) ----
 struct mf_slot { uint64_t key; uint32_t idx; uint32_t val; };
-__device__ __forceinline__ bool mf_index_find(const mf_slot *__restrict__ slots, uint64_t mask, uint64_t key,
-                                              uint32_t *idx, uint32_t *val) {
-    uint64_t s = mf_hash64(key) & mask;
+__device__ __forceinline__ bool mf_index_find(const mf_index_view &ix, uint64_t key, uint32_t *idx, uint32_t *val) {
+    const mf_slot *__restrict__ slots = reinterpret_cast<const mf_slot *>(ix.slots);
+    uint64_t base = 0, rmask = ix.mask, s;
+    if (ix.part_bits) {
+        const uint64_t h = mf_phash(key);
+        base = (h >> (64 - ix.part_bits)) << ix.region_bits;
+        rmask = (1ull << ix.region_bits) - 1;
+        s = mf_pslot(h) & rmask;
+    } else s = mf_hash64(key) & rmask;
     for (;;) {
-        const ulonglong2 raw = *reinterpret_cast<const ulonglong2 *>(&slots[s]);
+        const ulonglong2 raw = *reinterpret_cast<const ulonglong2 *>(&slots[base | s]);
         if (raw.x == key) { *idx = (uint32_t)raw.y; *val = (uint32_t)(raw.y >> 32); return true; }
         if (raw.x == MF_EMPTY) return false;
-        s = (s + 1) & mask;
+        s = (s + 1) & rmask;
     }
 }
 // =============================================================================================

@@ -842,7 +842,13 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
                 lv.size(), total_bits, np, (unsigned long long)n_dist);
     MF_HIP(hipGetLastError());
     size_t kb = dk.bytes(), cb = dc.bytes();
-    return mf_table_adopt(ctx, k, n_dist, n_occ, dk.take(), kb, dc.take(), cb, out);
+    MF_TRY(mf_table_adopt(ctx, k, n_dist, n_occ, dk.take(), kb, dc.take(), cb, out));
+    if (total_bits > 0 && total_bits <= 30) {          // keep the partition structure (see mf_table_ensure_index)
+        (*out)->part_bits = total_bits;
+        (*out)->part_off_bytes = doff.bytes();
+        (*out)->d_part_off = doff.take();
+    }
+    return MF_OK;
 }
 
 int mf_sum_counts(mf_ctx *ctx, const uint16_t *d_counts, uint64_t n, uint64_t *total) {

@@ -59,12 +59,70 @@ __global__ void k_index_insert_add(mf_slot *__restrict__ slots, uint64_t mask, c
     }
 }
 
-__global__ void k_index_lookup(const mf_slot *__restrict__ slots, uint64_t mask, const uint64_t *__restrict__ keys,
-                               uint64_t n, int32_t *__restrict__ out) {
+__global__ void k_index_lookup(mf_index_view ix, const uint64_t *__restrict__ keys, uint64_t n, int32_t *__restrict__ out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t idx, val;
-    out[i] = mf_index_find(slots, mask, keys[i], &idx, &val) ? (int32_t)val : -1;
+    out[i] = mf_index_find(ix, keys[i], &idx, &val) ? (int32_t)val : -1;
+}
+
+// ---- partitioned index build: one wave per hash partition builds that partition's 2^region_bits slots in LDS
+// (LDS CAS) and writes them out as one contiguous block.  The dense table comes out of k_count grouped by the same
+// partition bits, so this is a streaming pass: no HBM atomics, no random HBM accesses (the generic build below
+// costs one random CAS + one random store per key: 40 ms for 3.6e8 keys). ----
+// TEAM = 64: a wave per partition (regions up to 1024 slots, 4 regions per block); TEAM = 256: the block per partition
+template <int TEAM>
+__global__ __launch_bounds__(256) void k_index_build_part(mf_slot *__restrict__ slots, uint32_t region_bits, const uint64_t *__restrict__ keys,
+                                                          const uint16_t *__restrict__ vals, const uint64_t *__restrict__ part_off,
+                                                          uint32_t np) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t S = 1u << region_bits, rmask = S - 1;
+    constexpr int TEAMS = 256 / TEAM;
+    const int team = threadIdx.x / TEAM, tl = threadIdx.x % TEAM;
+    mf_slot *reg = reinterpret_cast<mf_slot *>(smem) + (size_t)team * S;
+    auto sync = [&]() {
+        if (TEAM == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+        else __syncthreads();
+    };
+    const uint32_t nteams = gridDim.x * TEAMS;
+    for (uint32_t p = blockIdx.x * TEAMS + team; p < np; p += nteams) {   // p is team-uniform
+        for (uint32_t j = tl; j < S; j += TEAM) { ulonglong2 e; e.x = MF_EMPTY; e.y = 0; *reinterpret_cast<ulonglong2 *>(&reg[j]) = e; }
+        sync();
+        const uint64_t lo = part_off[p], hi = part_off[p + 1];
+        for (uint64_t i = lo + tl; i < hi; i += TEAM) {
+            const uint64_t key = keys[i];
+            const uint64_t aux = (uint64_t)(uint32_t)i | ((uint64_t)(vals ? vals[i] : 0) << 32);
+            uint32_t s = mf_pslot(mf_phash(key)) & rmask;
+            for (;;) {
+                unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&reg[s].key), (unsigned long long)MF_EMPTY,
+                                                   (unsigned long long)key);
+                if (old == MF_EMPTY) { *reinterpret_cast<uint64_t *>(&reg[s].idx) = aux; break; }
+                s = (s + 1) & rmask;
+            }
+        }
+        sync();
+        mf_slot *dst = slots + ((size_t)p << region_bits);
+        for (uint32_t j = tl; j < S; j += TEAM) *reinterpret_cast<ulonglong2 *>(&dst[j]) = *reinterpret_cast<const ulonglong2 *>(&reg[j]);
+        sync();
+    }
+}
+// largest partition
+__global__ void k_part_max(const uint64_t *__restrict__ part_off, uint32_t np, unsigned int *__restrict__ mx) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t c = p < np ? (uint32_t)(part_off[p + 1] - part_off[p]) : 0u;
+    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_down(c, d, 64); c = o > c ? o : c; }
+    if (mf_lane() == 0 && c) atomicMax(mx, c);
+}
+// entries with count > thr per partition (one wave per partition)
+__global__ __launch_bounds__(256) void k_part_selcount(const uint16_t *__restrict__ cnts, const uint64_t *__restrict__ part_off, uint32_t np,
+                                                       int thr, uint32_t *__restrict__ pcount) {
+    const uint32_t nwaves = gridDim.x * (blockDim.x >> 6);
+    for (uint32_t p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); p < np; p += nwaves) {
+        uint32_t c = 0;
+        for (uint64_t i = part_off[p] + mf_lane(); i < part_off[p + 1]; i += 64) c += (int)cnts[i] > thr;
+        for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+        if (mf_lane() == 0) pcount[p] = c;
+    }
 }
 
 // ---- stable stream compaction in two passes: select entries with pred(i) ----
@@ -150,6 +208,7 @@ extern "C" void mf_table_destroy(mf_table *t) {
     if (t->owns_arrays && t->d_keys) mf_release(t->ctx, t->d_keys, t->keys_bytes);
     if (t->owns_arrays && t->d_counts) mf_release(t->ctx, t->d_counts, t->counts_bytes);
     if (t->index.slots) mf_release(t->ctx, t->index.slots, t->index_bytes);
+    if (t->owns_arrays && t->d_part_off) mf_release(t->ctx, t->d_part_off, t->part_off_bytes);
     delete t;
 }
 
@@ -175,7 +234,40 @@ int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, 
 int mf_table_ensure_index(mf_table *t) {
     if (t->index.slots) return MF_OK;
     if (t->n >= 0xFFFFFFFFull) return mf_set_error("index supports < 2^32 entries");
-    return mf_index_build(t->ctx, t->d_keys, t->d_counts, t->n, &t->index, &t->index_bytes);
+    mf_ctx *ctx = t->ctx;
+    if (t->part_bits > 0 && t->d_part_off && t->n) {
+        // partitioned build: region = power of two >= 1.5 x the largest partition
+        const uint32_t np = 1u << t->part_bits;
+        mf_buf<unsigned int> mx; MF_TRY(mx.alloc(ctx, 1));
+        MF_HIP(hipMemsetAsync(mx.p, 0, 4, ctx->stream));
+        k_part_max<<<(np + 255) / 256, 256, 0, ctx->stream>>>(t->d_part_off, np, mx.p);
+        unsigned int m = 0;
+        MF_HIP(hipMemcpyAsync(&m, mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipStreamSynchronize(ctx->stream));
+        uint32_t rb = 4;
+        while ((1ull << rb) < (uint64_t)m + m / 2 + 1) rb++;
+        const uint64_t cap = (uint64_t)np << rb;
+        if (rb <= 13 && cap * sizeof(mf_slot) <= ((size_t)64 << 30) && cap <= 16 * std::max<uint64_t>(t->n, 1024)) {
+            void *p = nullptr;
+            MF_TRY(mf_alloc(ctx, cap * sizeof(mf_slot), &p));
+            const bool wave = rb <= 10;
+            size_t lds = (size_t)(wave ? 4 : 1) * ((size_t)1 << rb) * sizeof(mf_slot);
+            auto fn = wave ? k_index_build_part<64> : k_index_build_part<256>;
+            MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));
+            unsigned grid = (unsigned)std::min<uint64_t>(wave ? (np + 3) / 4 : np, (uint64_t)ctx->n_cu * wg_per_cu);
+            {
+                mf_ktimer tm(ctx, "k_index_build_part");
+                fn<<<grid, 256, lds, ctx->stream>>>((mf_slot *)p, rb, t->d_keys, t->d_counts, t->d_part_off, np);
+            }
+            MF_HIP(hipGetLastError());
+            t->index.slots = p; t->index.cap = cap; t->index.part_bits = (uint32_t)t->part_bits; t->index.region_bits = rb;
+            t->index_bytes = cap * sizeof(mf_slot);
+            if (ctx->opt_verbose) fprintf(stderr, "[mf] index: %u partitions x %u slots (max %u keys), %.2f GB\n", np, 1u << rb, m, cap * 16 / 1e9);
+            return MF_OK;
+        }
+    }
+    return mf_index_build(ctx, t->d_keys, t->d_counts, t->n, &t->index, &t->index_bytes);
 }
 
 extern "C" int mf_table_stats(const mf_table *t, uint64_t *n_distinct, uint64_t *n_total) {
@@ -234,7 +326,21 @@ extern "C" int mf_table_filter(const mf_table *t, int threshold, mf_table **out)
     mf_buf<uint64_t> ok; mf_buf<uint16_t> oc; uint64_t m = 0;
     MF_TRY(select_entries<0>(ctx, t->d_keys, t->d_counts, nullptr, t->n, threshold, ok, oc, &m));
     size_t kb = ok.bytes(), cb = oc.bytes();
-    return mf_table_adopt(ctx, t->k, m, 0, ok.take(), kb, oc.take(), cb, out);
+    MF_TRY(mf_table_adopt(ctx, t->k, m, 0, ok.take(), kb, oc.take(), cb, out));
+    if (t->part_bits > 0 && t->d_part_off && m) {
+        // the compaction is stable, so the selected entries of partition p are still contiguous: new offsets by a scan
+        const uint32_t np = 1u << t->part_bits;
+        mf_buf<uint32_t> pc; MF_TRY(pc.alloc(ctx, np));
+        mf_buf<uint64_t> po; MF_TRY(po.alloc(ctx, (size_t)np + 1));
+        mf_buf<uint64_t> tot; MF_TRY(tot.alloc(ctx, 1));
+        unsigned grid = (unsigned)std::min<uint64_t>((np + 3) / 4, (uint64_t)ctx->n_cu * 32);
+        k_part_selcount<<<grid, 256, 0, ctx->stream>>>(t->d_counts, t->d_part_off, np, threshold, pc.p);
+        MF_TRY(mf_scan<false>(ctx, pc.p, po.p, np, tot.p));
+        (*out)->part_bits = t->part_bits;
+        (*out)->part_off_bytes = po.bytes();
+        (*out)->d_part_off = po.take();
+    }
+    return MF_OK;
 }
 
 int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out) {
@@ -256,6 +362,7 @@ int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out) {
         if (m == n) {
             MF_TRY(mf_table_adopt(ctx, t->k, t->n, 0, t->d_keys, t->keys_bytes, t->d_counts, t->counts_bytes, out));
             (*out)->owns_arrays = false;
+            (*out)->part_bits = t->part_bits; (*out)->d_part_off = t->d_part_off; (*out)->part_off_bytes = t->part_off_bytes;
             return MF_OK;
         }
     }
@@ -326,7 +433,7 @@ extern "C" int mf_table_lookup(mf_table *t, const uint64_t *keys, uint64_t n, in
     mf_buf<uint64_t> dk; MF_TRY(dk.alloc(ctx, n));
     mf_buf<int32_t> dv; MF_TRY(dv.alloc(ctx, n));
     MF_HIP(hipMemcpyAsync(dk.p, keys, n * 8, hipMemcpyHostToDevice, ctx->stream));
-    k_index_lookup<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>((const mf_slot *)t->index.slots, t->index.cap - 1, dk.p, n, dv.p);
+    k_index_lookup<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(mf_view(t->index), dk.p, n, dv.p);
     MF_HIP(hipMemcpyAsync(values, dv.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     MF_HIP(hipStreamSynchronize(ctx->stream));
     return MF_OK;

@@ -39,7 +39,7 @@ struct ut_arrays {
     unsigned int *n_starts;
 };
 
-__global__ void k_ut_flags(const mf_slot *__restrict__ slots, uint64_t mask, ut_arrays A) {
+__global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= A.n) return;
     const int k = A.k;
@@ -52,7 +52,7 @@ __global__ void k_ut_flags(const mf_slot *__restrict__ slots, uint64_t mask, ut_
         uint64_t ry = mf_revcomp(y, k);
         uint64_t c = y < ry ? y : ry;
         uint32_t idx, val;
-        if (mf_index_find(slots, mask, c, &idx, &val)) {
+        if (mf_index_find(ix, c, &idx, &val)) {
             if (rcode == UT_CODE_NONE) { rcode = nuc; ridx = idx; ror = (c != y); }
             else rcode = UT_CODE_MANY;
         }
@@ -63,7 +63,7 @@ __global__ void k_ut_flags(const mf_slot *__restrict__ slots, uint64_t mask, ut_
         uint64_t ry = mf_revcomp(y, k);
         uint64_t c = y < ry ? y : ry;
         uint32_t idx, val;
-        if (mf_index_find(slots, mask, c, &idx, &val)) {
+        if (mf_index_find(ix, c, &idx, &val)) {
             if (lcode == UT_CODE_NONE) { lcode = nuc; lidx = idx; lor = (c != y); }
             else lcode = UT_CODE_MANY;
         }
@@ -281,7 +281,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if ((k & 1) == 0) { if ((rc = pal.alloc(ctx, n)) < 0) break; A.pal = pal.p; }   // palindromes need an even k
         {
             mf_ktimer tm(ctx, "k_ut_flags");
-            k_ut_flags<<<grid_for(n), 256, 0, st>>>((const mf_slot *)g->index.slots, g->index.cap - 1, A);
+            k_ut_flags<<<grid_for(n), 256, 0, st>>>(mf_view(g->index), A);
         }
         {
             mf_ktimer tm(ctx, "k_ut_links");
