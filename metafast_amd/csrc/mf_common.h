@@ -59,6 +59,7 @@ struct mf_ctx {
     int64_t opt_profile = 0;
     int64_t opt_l1_blocks = 0;     // 0 = auto
     int64_t opt_verbose = 0;
+    int64_t opt_skm = 1;           // super-k-mer counting path (mf_skm.hip) for k >= MF_SKM_MIN_K; 0 = always one record per k-mer
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero
     // workspace arena: a few large hipMalloc'd regions, sub-allocated with first-fit + coalescing free lists.
     // Everything runs on one stream, so a block can be handed out again as soon as it is released.
@@ -114,9 +115,10 @@ struct mf_index {                 // open-addressed table in HBM: 16-byte slots 
     // partitioned form (part_bits > 0): slot region of a key = top part_bits of mf_phash(key), linear probing wraps
     // inside the 2^region_bits slots of that region; generic form (part_bits == 0): fmix64(key) & (cap-1)
     uint32_t part_bits = 0, region_bits = 0;
+    uint32_t skm_k = 0;           // != 0: partitions are MINIMIZER partitions of k-mers of this length (mf_skm_ph), else mf_phash
 };
-struct mf_index_view { const void *slots; uint64_t mask; uint32_t part_bits, region_bits; };
-static inline mf_index_view mf_view(const mf_index &ix) { return mf_index_view{ix.slots, ix.cap - 1, ix.part_bits, ix.region_bits}; }
+struct mf_index_view { const void *slots; uint64_t mask; uint32_t part_bits, region_bits, skm_k; };
+static inline mf_index_view mf_view(const mf_index &ix) { return mf_index_view{ix.slots, ix.cap - 1, ix.part_bits, ix.region_bits, ix.skm_k}; }
 struct mf_table {
     mf_ctx *ctx = nullptr;
     int k = 0;
@@ -131,6 +133,7 @@ struct mf_table {
     // partition structure left by the counting path: entries of hash partition p (top part_bits of mf_phash) are
     // d_keys[d_part_off[p] .. d_part_off[p+1]); lets the index be built partition by partition without HBM atomics
     int part_bits = 0;
+    int part_skm = 0;             // 1: the partitions are minimizer partitions (super-k-mer counting path), 0: mf_phash partitions
     uint64_t *d_part_off = nullptr; size_t part_off_bytes = 0;
 };
 struct mf_seqs {
@@ -163,6 +166,7 @@ int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, 
 int mf_table_ensure_index(mf_table *t);
 // entries with count > threshold; when every entry passes, a non-owning alias of `t` (no copy) -- internal use only
 int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out);
+#define MF_SKM_FALLBACK 1          /* mf_count_skm: input does not suit the super-k-mer path, nothing was produced */
 int mf_comps_materialize(mf_comps *c);
 int mf_table_adopt(mf_ctx *ctx, int k, uint64_t n, uint64_t n_occ, uint64_t *d_keys, size_t kb, uint16_t *d_counts,
                    size_t cb, mf_table **out);
@@ -245,13 +249,43 @@ __device__ __forceinline__ uint32_t mf_block_excl_scan(uint32_t v, uint32_t *scr
 }
 
 // ---- HBM open-addressed index lookup (16-byte slots) ----
+// ---- minimizer partitions (super-k-mer counting path, mf_skm.hip) ----
+// A k-mer's partition is decided by its MINIMIZER: the smallest mf_mmer_hash over the canonical forms of its k-M+1 M-mers.
+// Consecutive k-mers of a read mostly share it, so a read is cut into a few super-k-mers (runs of k-mers with one
+// minimizer) that travel through the radix passes as ONE 16-byte record instead of 8 bytes per k-mer, and graph
+// neighbours mostly live in the same partition.  Orientation-independent: rc(x) has the reverse-complemented M-mers.
+#define MF_SKM_M 15
+#define MF_SKM_MIN_K 20           // shorter k: too few M-mers per k-mer for runs worth packing -> one-record-per-k-mer path
+#define MF_SKM_BASES 50           // bases a record can hold: x = bases 0..31, y = bases 32..49 | 22 digit bits | 6-bit k-mer count
+__device__ __forceinline__ uint32_t mf_mmer_rc(uint32_t f) {      // reverse complement of a 2*MF_SKM_M-bit M-mer
+    uint32_t r = __brev(~f);
+    r = ((r & 0xAAAAAAAAu) >> 1) | ((r & 0x55555555u) << 1);
+    return r >> (32 - 2 * MF_SKM_M);
+}
+__device__ __forceinline__ uint32_t mf_mmer_hash(uint32_t canon) { uint32_t h = canon * 0x9E3779B1u; return h ^ (h >> 15); }
+// minimizer hash -> partition hash (the minimum of several uniform values is not uniform: mix again)
+__device__ __forceinline__ uint32_t mf_remix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; return h ^ (h >> 16); }
+__device__ __forceinline__ uint32_t mf_skm_ph(uint64_t key, int k) {
+    const uint32_t mm = (1u << (2 * MF_SKM_M)) - 1u;
+    uint32_t f = (uint32_t)(key >> (2 * (k - MF_SKM_M))) & mm, r = mf_mmer_rc(f);
+    uint32_t best = mf_mmer_hash(f < r ? f : r);
+    for (int j = k - MF_SKM_M - 1; j >= 0; j--) {
+        const uint32_t b = (uint32_t)(key >> (2 * j)) & 3u;
+        f = ((f << 2) | b) & mm;
+        r = (r >> 2) | ((3u - b) << (2 * MF_SKM_M - 2));
+        const uint32_t h = mf_mmer_hash(f < r ? f : r);
+        best = h < best ? h : best;
+    }
+    return mf_remix32(best);
+}
 struct mf_slot { uint64_t key; uint32_t idx; uint32_t val; };
 __device__ __forceinline__ bool mf_index_find(const mf_index_view &ix, uint64_t key, uint32_t *idx, uint32_t *val) {
     const mf_slot *__restrict__ slots = reinterpret_cast<const mf_slot *>(ix.slots);
     uint64_t base = 0, rmask = ix.mask, s;
     if (ix.part_bits) {
         const uint64_t h = mf_phash(key);
-        base = (h >> (64 - ix.part_bits)) << ix.region_bits;
+        const uint64_t part = ix.skm_k ? (uint64_t)(mf_skm_ph(key, (int)ix.skm_k) >> (32 - ix.part_bits)) : (h >> (64 - ix.part_bits));
+        base = part << ix.region_bits;
         rmask = (1ull << ix.region_bits) - 1;
         s = mf_pslot(h) & rmask;
     } else s = mf_hash64(key) & rmask;
@@ -263,9 +297,9 @@ __device__ __forceinline__ bool mf_index_find(const mf_index_view &ix, uint64_t 
     }
 }
 // =============================================================================================
-// single-block exclusive scan (u32 in -> u64 out); PAD8 rounds every item up to a multiple of 8
+// single-block exclusive scan (u32 in -> u64 out); PAD (a power of two) rounds every item up to a multiple of PAD
 // =============================================================================================
-template <bool PAD8>
+template <int PAD>
 static __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
                                                uint64_t n, uint64_t *__restrict__ total) {
     __shared__ uint64_t sums[1024];
@@ -273,7 +307,7 @@ static __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict
     uint64_t lo = (uint64_t)threadIdx.x * per;
     uint64_t hi = lo + per < n ? lo + per : n;
     uint64_t s = 0;
-    for (uint64_t i = lo; i < hi; i++) { uint64_t v = in[i]; if (PAD8) v = (v + 7) & ~7ull; s += v; }
+    for (uint64_t i = lo; i < hi; i++) { uint64_t v = in[i]; v = (v + (PAD - 1)) & ~(uint64_t)(PAD - 1); s += v; }
     sums[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -284,20 +318,20 @@ static __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict
     }
     __syncthreads();
     uint64_t base = sums[threadIdx.x];
-    for (uint64_t i = lo; i < hi; i++) { uint64_t v = in[i]; if (PAD8) v = (v + 7) & ~7ull; out[i] = base; base += v; }
+    for (uint64_t i = lo; i < hi; i++) { uint64_t v = in[i]; v = (v + (PAD - 1)) & ~(uint64_t)(PAD - 1); out[i] = base; base += v; }
 }
 
 
 // ---- multi-block exclusive scan (u32 in -> u64 out) for long arrays: tile sums, scan of the tile sums, add-back ----
 #define MF_SCAN_TILE 4096
-template <bool PAD8>
+template <int PAD>
 static __global__ __launch_bounds__(1024) void k_scan_tiles(const uint32_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n,
                                                             uint32_t *__restrict__ tile_sum) {
     __shared__ uint32_t scratch[17];
     const uint64_t base = (uint64_t)blockIdx.x * MF_SCAN_TILE + (uint64_t)threadIdx.x * 4;
     uint32_t v[4], s = 0;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { uint32_t x = base + j < n ? in[base + j] : 0u; if (PAD8) x = (x + 7u) & ~7u; v[j] = x; s += x; }
+    for (int j = 0; j < 4; j++) { uint32_t x = base + j < n ? in[base + j] : 0u; x = (x + (uint32_t)(PAD - 1)) & ~(uint32_t)(PAD - 1); v[j] = x; s += x; }
     uint32_t tot;
     uint32_t ex = mf_block_excl_scan(s, scratch, &tot);
 #pragma unroll
@@ -312,15 +346,15 @@ static __global__ __launch_bounds__(1024) void k_scan_addback(uint64_t *__restri
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) out[n] = tile_off[gridDim.x];
 }
 // out[0..n] = exclusive prefix of in (out[n] = total, also written to *total); tiles must hold < 2^32 each
-template <bool PAD8>
+template <int PAD>
 static int mf_scan(mf_ctx *ctx, const uint32_t *in, uint64_t *out, uint64_t n, uint64_t *total) {
     hipStream_t st = ctx->stream;
-    if (n <= 65536) { k_scan<PAD8><<<1, 1024, 0, st>>>(in, out, n, total); return MF_OK; }
+    if (n <= 65536) { k_scan<PAD><<<1, 1024, 0, st>>>(in, out, n, total); return MF_OK; }
     const uint64_t nt = (n + MF_SCAN_TILE - 1) / MF_SCAN_TILE;
     mf_buf<uint32_t> ts; MF_TRY(ts.alloc(ctx, nt));
     mf_buf<uint64_t> to; MF_TRY(to.alloc(ctx, nt + 1));
-    k_scan_tiles<PAD8><<<(unsigned)nt, 1024, 0, st>>>(in, out, n, ts.p);
-    k_scan<false><<<1, 1024, 0, st>>>(ts.p, to.p, nt, total);
+    k_scan_tiles<PAD><<<(unsigned)nt, 1024, 0, st>>>(in, out, n, ts.p);
+    k_scan<1><<<1, 1024, 0, st>>>(ts.p, to.p, nt, total);
     k_scan_addback<<<(unsigned)nt, 1024, 0, st>>>(out, n, to.p);
     return MF_OK;
 }

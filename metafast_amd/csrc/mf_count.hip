@@ -17,7 +17,12 @@
 //
 // Random accesses never leave LDS; HBM only sees streaming reads and full 64-byte line writes.
 #include "mf_common.h"
+#include "mf_count_dev.h"
 #include <algorithm>
+#include <vector>
+
+int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
+                 int k, const std::vector<int> &lv, unsigned long long *scal, mf_table **out);
 
 // =============================================================================================
 // K0: valid-start bitmap
@@ -80,19 +85,6 @@ __global__ void k_mask_reads(const uint64_t *__restrict__ off, uint64_t n_reads,
 // =============================================================================================
 // k-mer producer: one lane = one 32-position word of the base stream
 // =============================================================================================
-// 4 ASCII bases (byte 0 = first base) -> 8 bits, first base most significant, code A0 G1 C2 T3.
-// (c>>1)&3 maps A,C,T,G (either case) to 0,1,2,3; the reference order needs f(x)=((x0^x1)<<1)|x1.
-__device__ __forceinline__ uint32_t mf_dec4(uint32_t w) {
-    uint32_t t = (w >> 1) & 0x03030303u;
-    uint32_t x1 = (t >> 1) & 0x01010101u;
-    uint32_t x0 = t & 0x01010101u;
-    uint32_t c = ((x0 ^ x1) << 1) | x1;
-    return (c * 0x40100401u) >> 24;   // gathers the four 2-bit fields into one byte
-}
-__device__ __forceinline__ uint32_t mf_dec16(uint4 v) {
-    return (mf_dec4(v.x) << 24) | (mf_dec4(v.y) << 16) | (mf_dec4(v.z) << 8) | mf_dec4(v.w);
-}
-
 // Calls f(j, canonical_kmer, valid) for j = 0..31 (every lane makes all 32 calls so that wave-level
 // protocols inside f stay convergent).  Word w covers base positions [32w, 32w+32).
 template <typename F>
@@ -196,7 +188,6 @@ struct mf_stage {
     int nd;
 };
 #define MF_QCAP 16
-#define MF_WG __HIP_MEMORY_SCOPE_WORKGROUP
 #define MF_MLP 4          // 16-byte loads in flight per thread in the streaming loops
 
 // Lock-free within the workgroup: reserve a slot, write it, commit; the 8th committer flushes the line to HBM with
@@ -212,27 +203,6 @@ struct mf_stage {
 //    with `if (pending[b])` around each step, hipcc emits one exec-mask branch + s_waitcnt per element and the 4 x 3
 //    LDS round trips are fully serialised (the kernel was LDS-latency bound at 12 round trips per 4 k-mers).
 #define MF_B 4
-// LDS byte address of a pointer into __shared__ memory (operand of the ds_* instructions below)
-__device__ __forceinline__ uint32_t mf_lds_addr(const void *p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void *)p;
-}
-// Four LDS operations issued back to back, ONE s_waitcnt for all of them.  These are inline asm because hipcc turns the
-// equivalent C++ (atomics that add 0 on dummy slots) back into per-element exec branches with a wait after each atomic.
-// LDS instructions of one wave execute in order, so a write issued before the commit atomic is visible to whoever
-// observes that commit; the "memory" clobbers keep the compiler from moving other accesses across.
-__device__ __forceinline__ void mf_lds_read4(const uint32_t (&a)[4], uint32_t (&v)[4]) {
-    asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %5\n\tds_read_b32 %2, %6\n\tds_read_b32 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
-                 : "memory");
-}
-__device__ __forceinline__ void mf_lds_add_rtn4(const uint32_t (&a)[4], const uint32_t (&inc)[4], uint32_t (&old)[4]) {
-    asm volatile("ds_add_rtn_u32 %0, %4, %8\n\tds_add_rtn_u32 %1, %5, %9\n\tds_add_rtn_u32 %2, %6, %10\n\t"
-                 "ds_add_rtn_u32 %3, %7, %11\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(inc[0]), "v"(inc[1]), "v"(inc[2]), "v"(inc[3])
-                 : "memory");
-}
 // four 8-byte stores, then four returning adds (the commits); the stores need no wait of their own (in-order LDS)
 __device__ __forceinline__ void mf_lds_write4_add_rtn4(const uint32_t (&wa)[4], const uint64_t (&wv)[4], const uint32_t (&a)[4],
                                                        const uint32_t (&inc)[4], uint32_t (&old)[4]) {
@@ -495,63 +465,6 @@ __global__ __launch_bounds__(1024) void k_split(const uint64_t *__restrict__ in,
 // NEXT partition are loaded into registers while the current one is being counted, so the HBM latency of a
 // partition (one per ~3 k k-mers) is hidden behind the LDS work of the previous one.
 #define MF_PF 6            // 16-byte prefetch loads per thread: 12 keys x 256 threads = 3072 keys
-// ---- four-wide LDS steps of the counting table (inline asm for the same reason as in the staging protocol) ----
-__device__ __forceinline__ void mf_lds_read4_b64(const uint32_t (&a)[4], uint64_t (&v)[4]) {
-    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3])
-                 : "memory");
-}
-// ds_cmpst_rtn_b64 vdst, vaddr, vcmp, vnew : MEM = (MEM == cmp) ? new : MEM, returns the old value
-__device__ __forceinline__ void mf_lds_cmpst4_b64(const uint32_t (&a)[4], uint64_t cmp, const uint64_t (&nv)[4], uint64_t (&old)[4]) {
-    asm volatile("ds_cmpst_rtn_b64 %0, %4, %8, %9\n\tds_cmpst_rtn_b64 %1, %5, %8, %10\n\tds_cmpst_rtn_b64 %2, %6, %8, %11\n\t"
-                 "ds_cmpst_rtn_b64 %3, %7, %8, %12\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
-                 : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(cmp), "v"(nv[0]), "v"(nv[1]), "v"(nv[2]), "v"(nv[3])
-                 : "memory");
-}
-__device__ __forceinline__ void mf_lds_add4(const uint32_t (&a)[4], const uint32_t (&inc)[4]) {
-    asm volatile("ds_add_u32 %0, %4\n\tds_add_u32 %1, %5\n\tds_add_u32 %2, %6\n\tds_add_u32 %3, %7"
-                 :: "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(inc[0]), "v"(inc[1]), "v"(inc[2]), "v"(inc[3])
-                 : "memory");
-}
-// Insert four keys per lane: probe (4 reads in flight) -> claim empty slots (4 CAS in flight) -> count hits (4 adds, not
-// waited for).  Lanes with nothing to do in a step use a private dummy slot / counter.  The loop is wave-uniform; a
-// miss moves that key to the next slot (linear probing).  A `volatile` C++ probe here compiled to flat_load sc0 sc1 +
-// a full vmcnt/lgkmcnt wait, and the CAS path ran serially with a few active lanes: 45 % of the kernel.
-__device__ __forceinline__ void mf_count_insert4(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
-                                                 uint32_t slots, const uint64_t (&key)[4], unsigned int *overflow) {
-    uint32_t s[4]; bool pend[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = mf_pslot(mf_phash(key[b])) & mask; }
-    for (uint32_t probes = 0;; probes++) {
-        bool any = false;
-#pragma unroll
-        for (int b = 0; b < 4; b++) any |= pend[b];
-        if (__ballot(any) == 0ull) break;
-        if (probes > slots) { if (mf_lane() == 0) atomicExch(overflow, 1u); break; }
-        uint32_t ka[4], ca[4], aa[4], inc[4]; uint64_t cur[4], ret[4]; bool need[4]; bool anyneed = false;
-#pragma unroll
-        for (int b = 0; b < 4; b++) ka[b] = pend[b] ? tk0 + 8u * s[b] : dummy_k;
-        mf_lds_read4_b64(ka, cur);
-#pragma unroll
-        for (int b = 0; b < 4; b++) { need[b] = pend[b] && cur[b] == MF_EMPTY; ca[b] = need[b] ? ka[b] : dummy_k; anyneed |= need[b]; }
-        if (__ballot(anyneed) != 0ull) {
-            mf_lds_cmpst4_b64(ca, MF_EMPTY, key, ret);
-#pragma unroll
-            for (int b = 0; b < 4; b++) if (need[b]) cur[b] = ret[b] == MF_EMPTY ? key[b] : ret[b];
-        }
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const bool hit = pend[b] && cur[b] == key[b];
-            aa[b] = hit ? tc0 + 4u * s[b] : dummy_c;
-            inc[b] = hit ? 1u : 0u;
-            if (hit) pend[b] = false;
-            else s[b] = (s[b] + 1) & mask;
-        }
-        mf_lds_add4(aa, inc);
-    }
-}
 __global__ __launch_bounds__(256) void k_count(uint64_t *__restrict__ keys, uint16_t *__restrict__ cnt,
                                                const uint64_t *__restrict__ pstart, const uint32_t *__restrict__ plen,
                                                uint32_t np, uint32_t *__restrict__ dcount,
@@ -645,7 +558,7 @@ __global__ __launch_bounds__(256) void k_count(uint64_t *__restrict__ keys, uint
             wb = __shfl(wb, 0, 64);
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
-                if (i < nch && ck[i] != MF_EMPTY) {
+                if (i < nch && ck[i] != MF_EMPTY && ablate != 5) {
                     const uint32_t pos = wb + pre[i];
                     keys[start + pos] = ck[i];
                     cnt[start + pos] = (uint16_t)(cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]);
@@ -656,18 +569,6 @@ __global__ __launch_bounds__(256) void k_count(uint64_t *__restrict__ keys, uint
         if (threadIdx.x == 0) dcount[p] = out_cursor;
         if (pn >= np) break;
         p = pn; start = start_n; len = len_n;
-    }
-}
-
-// dense output: partition p's d distinct entries go to [doff[p], doff[p]+d)
-__global__ __launch_bounds__(256) void k_gather(const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnt,
-                                                const uint64_t *__restrict__ pstart, const uint32_t *__restrict__ dcount,
-                                                const uint64_t *__restrict__ doff, uint32_t np,
-                                                uint64_t *__restrict__ dk, uint16_t *__restrict__ dc) {
-    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
-        uint64_t s = pstart[p], o = doff[p];
-        uint32_t d = dcount[p];
-        for (uint32_t j = threadIdx.x; j < d; j += blockDim.x) { dk[o + j] = keys[s + j]; dc[o + j] = cnt[s + j]; }
     }
 }
 
@@ -733,6 +634,12 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     int total_bits = 0; for (int b : lv) total_bits += b;
     if (total_bits > 40) return mf_set_error("partition plan needs %d bits", total_bits);
 
+    // ---- super-k-mer path (mf_skm.hip); falls through to the k-mer path below if the input does not suit it ----
+    if (ctx->opt_skm && k >= MF_SKM_MIN_K) {
+        int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, lv, scal.p, out);
+        if (rc != MF_SKM_FALLBACK) return rc;
+    }
+
     // ---- K1 ----
     const int bits1 = lv[0], nd1 = 1 << bits1;
     int G = ctx->opt_l1_blocks > 0 ? (int)ctx->opt_l1_blocks : ctx->n_cu;
@@ -751,7 +658,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     MF_DBG(ctx, "k_l1_hist");
     {
         mf_ktimer t(ctx, "k_scan");
-        MF_TRY(mf_scan<true>(ctx, blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal.p[1]));
+        MF_TRY(mf_scan<8>(ctx, blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal.p[1]));
     }
     MF_DBG(ctx, "k_scan");
     uint64_t cap = n_occ + (uint64_t)MF_LINE * nd1 * G;    // upper bound of the padded total
@@ -819,7 +726,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));
     {
         mf_ktimer t(ctx, "k_scan");
-        MF_TRY(mf_scan<false>(ctx, dcount.p, doff.p, np, (uint64_t *)&scal.p[3]));
+        MF_TRY(mf_scan<1>(ctx, dcount.p, doff.p, np, (uint64_t *)&scal.p[3]));
     }
     MF_DBG(ctx, "k_scan");
     MF_HIP(hipGetLastError());

@@ -86,6 +86,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "l1_blocks") ctx->opt_l1_blocks = v;
     else if (s == "verbose") ctx->opt_verbose = v;
     else if (s == "ablate") ctx->opt_ablate = v;
+    else if (s == "skm") ctx->opt_skm = v;
     else return mf_set_error("unknown option '%s'", name);
     return MF_OK;
 }

@@ -1,0 +1,766 @@
+// mf_skm.hip -- k-mer counting through SUPER-K-MERS (minimizer partitions), the default path for k >= MF_SKM_MIN_K.
+//
+// Same job as mf_count.hip (IOUtils.loadReads, src/io/IOUtils.java:756-768: every k-mer of every read ->
+// BigLong2ShortHashMap.addAndBound(canonical, 1)), same result (dense (key,count) arrays), different traffic: the
+// one-record-per-k-mer path moves 8 bytes per k-mer OCCURRENCE through two radix passes and the count pass (3 x 96 GB
+// at 1.2e10 occurrences).  Here a read is cut into runs of consecutive k-mers that share their minimizer (mf_common.h),
+// and a run of r k-mers travels as ONE 16-byte record holding its r+k-1 bases (about 9 k-mers per record at k=31):
+//
+//   S1 k_skm_hist     ASCII -> 2-bit -> M-mer hashes -> sliding-window minimum -> runs; per-block histogram of the
+//                     records' level-1 digit (top bits of the partition hash of the run's minimizer)
+//      k_scan         exact output ranges (padded to whole 64-byte lines)
+//   S2 k_skm_scatter  same scan again, records built and radix-partitioned through 64-byte LDS staging lines
+//   S3 k_skm_split    further levels: the digit is read from the record (22 digit bits travel with it)
+//   S4 k_skm_count    one partition per 512-thread workgroup: records -> canonical k-mers (LDS buffer, lane-balanced)
+//                     -> open-addressed count table in LDS -> compacted (key,count) lists
+//      k_gather       dense arrays, grouped by partition (the HBM index is built partition by partition, mf_table.hip)
+//
+// A partition holds ALL occurrences of its k-mers, so the counts are exact; only the grouping of the dense table
+// differs from mf_count.hip (by minimizer partition instead of by hash partition).  If a partition has more distinct
+// k-mers than the LDS table holds, the caller falls back to mf_count.hip's path.
+#include "mf_common.h"
+#include "mf_count_dev.h"
+#include <algorithm>
+#include <vector>
+
+typedef ulonglong2 skm_rec;
+typedef uint32_t skm_v4 __attribute__((ext_vector_type(4)));
+#define SKM_LINE 4                 // records per 64-byte staging line
+#define SKM_QCAP 16
+#define SKM_DIGIT_BITS 22          // digit bits stored in a record (levels after the first)
+#define SKM_KBUF 3584              // k-mers expanded at a time in k_skm_count (LDS)
+#define SKM_CT 512                 // threads of k_skm_count
+
+__device__ __forceinline__ bool skm_rec_valid(const skm_rec &r) { return ((uint32_t)r.y & 63u) != 63u; }
+__device__ __forceinline__ uint32_t skm_rec_n(const skm_rec &r) { return (uint32_t)r.y & 63u; }
+__device__ __forceinline__ uint32_t skm_rec_digits(const skm_rec &r) { return (uint32_t)(r.y >> 6) & ((1u << SKM_DIGIT_BITS) - 1u); }
+
+// =============================================================================================
+// one lane = one 32-position word of the base stream: minimizer hash of each of its 32 k-mers, run starts
+// =============================================================================================
+template <int K> struct skm_word {
+    static constexpr int W = K - MF_SKM_M + 1;          // M-mers per k-mer
+    static constexpr int NM = 31 + W;                   // M-mers of the word's 32 k-mers
+    static constexpr int RMAX = (MF_SKM_BASES - (K - 1)) < 32 ? (MF_SKM_BASES - (K - 1)) : 32;   // k-mers per record
+    uint32_t D[4];        // 64 bases from the word's first position, 2 bits each, first base in the top bits of D[0]
+    uint32_t mh[32];      // minimizer hash of the k-mer at each position
+    uint32_t valid;       // positions that start a k-mer (from the bitmap)
+    uint32_t cut;         // positions where a run starts
+};
+
+template <int K>
+__device__ __forceinline__ void skm_scan_word(skm_word<K> &S, const uint8_t *__restrict__ bases, uint64_t n_bases, uint64_t w, uint32_t m) {
+    constexpr int W = skm_word<K>::W, NM = skm_word<K>::NM, M = MF_SKM_M;
+    // four unconditional 16-byte loads (a guarded `cond ? p[i] : zero` compiles to sixteen predicated dword loads); chunks
+    // that start beyond the buffer are re-pointed at the first one and zeroed afterwards
+    const uint64_t b0 = w * 32;
+    const uint4 *p = reinterpret_cast<const uint4 *>(bases + (b0 < n_bases ? b0 : 0));
+    const bool in1 = b0 + 16 < n_bases, in2 = b0 + 32 < n_bases, in3 = b0 + 48 < n_bases;
+    const uint4 c0 = p[0], c1 = p[in1 ? 1 : 0], c2 = p[in2 ? 2 : 0], c3 = p[in3 ? 3 : 0];
+    S.D[0] = b0 < n_bases ? mf_dec16(c0) : 0u; S.D[1] = in1 ? mf_dec16(c1) : 0u; S.D[2] = in2 ? mf_dec16(c2) : 0u; S.D[3] = in3 ? mf_dec16(c3) : 0u;
+    S.valid = m;
+    uint32_t hs[NM];
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < NM; i++) {
+        const int q = i >> 4, o = i & 15;       // bases i .. i+M-1 start in dword q at base offset o
+        const uint32_t top = o ? __builtin_amdgcn_alignbit(S.D[q], S.D[q + 1 < 4 ? q + 1 : 3], 32 - 2 * o) : S.D[q];
+        const uint32_t f = top >> (32 - 2 * M);
+        r = (i == 0) ? mf_mmer_rc(f) : ((r >> 2) | ((3u - (f & 3u)) << (2 * M - 2)));
+        hs[i] = mf_mmer_hash(f < r ? f : r);
+    }
+    // sliding-window minimum over W M-mers: in-place doubling to spans of P (largest power of two <= W), then two
+    // overlapping spans
+    constexpr int P = W >= 16 ? 16 : W >= 8 ? 8 : W >= 4 ? 4 : W >= 2 ? 2 : 1;
+#pragma unroll
+    for (int step = 1; step < P; step <<= 1) {
+#pragma unroll
+        for (int i = 0; i + step < NM; i++) hs[i] = hs[i] < hs[i + step] ? hs[i] : hs[i + step];
+    }
+#pragma unroll
+    for (int j = 0; j < 32; j++) S.mh[j] = hs[j] < hs[j + W - P] ? hs[j] : hs[j + W - P];
+    uint32_t same = 0;
+#pragma unroll
+    for (int j = 1; j < 32; j++) same |= (S.mh[j] == S.mh[j - 1]) ? (1u << j) : 0u;
+    S.cut = m & ~(same & (m << 1));
+}
+
+// lane-wise m ? b : a as ONE v_cndmask.  Written in C++ (`c ? x[2i+1] : x[2i]`) hipcc turns the select between two
+// neighbouring array elements into a load with a run-time index, i.e. the whole register array goes to scratch memory and
+// every select becomes a scratch round trip (k_skm_hist spent 40 % of its wave time in s_waitcnt on those).
+__device__ __forceinline__ uint32_t skm_sel(uint32_t a, uint32_t b, unsigned long long m) {
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(m));
+    return r;
+}
+// S.mh[s] for a per-lane s: binary select tree over the register array
+template <int K>
+__device__ __forceinline__ uint32_t skm_mh_at(const skm_word<K> &S, uint32_t s) {
+    uint32_t a[16], b[8], c[4], d[2];
+    const unsigned long long s0 = __ballot((s & 1u) != 0), s1 = __ballot((s & 2u) != 0), s2 = __ballot((s & 4u) != 0),
+                             s3 = __ballot((s & 8u) != 0), s4 = __ballot((s & 16u) != 0);
+#pragma unroll
+    for (int i = 0; i < 16; i++) a[i] = skm_sel(S.mh[2 * i], S.mh[2 * i + 1], s0);
+#pragma unroll
+    for (int i = 0; i < 8; i++) b[i] = skm_sel(a[2 * i], a[2 * i + 1], s1);
+#pragma unroll
+    for (int i = 0; i < 4; i++) c[i] = skm_sel(b[2 * i], b[2 * i + 1], s2);
+#pragma unroll
+    for (int i = 0; i < 2; i++) d[i] = skm_sel(c[2 * i], c[2 * i + 1], s3);
+    return skm_sel(d[0], d[1], s4);
+}
+
+// takes the next run off `cut`: start s, number of k-mers len (<= RMAX; a longer run leaves its rest in `cut`)
+template <int K>
+__device__ __forceinline__ void skm_next_run(const skm_word<K> &S, uint32_t &cut, uint32_t &s, uint32_t &len) {
+    s = (uint32_t)__builtin_ctz(cut);
+    cut &= cut - 1u;
+    const uint32_t stop = (cut | ~S.valid) & ~((2u << s) - 1u);
+    const uint32_t e = stop ? (uint32_t)__builtin_ctz(stop) : 32u;
+    len = e - s;
+    if (len > (uint32_t)skm_word<K>::RMAX) { len = (uint32_t)skm_word<K>::RMAX; cut |= 1u << (s + len); }
+}
+
+// the record of the run [s, s+len): its len+K-1 bases left-aligned, the remaining bits zero, digit bits, k-mer count
+template <int K>
+__device__ __forceinline__ skm_rec skm_make_rec(const skm_word<K> &S, uint32_t s, uint32_t len, uint32_t digits) {
+    const uint32_t o = (2u * s) & 31u;
+    const unsigned long long q = __ballot(s >= 16u);
+    const uint32_t E0 = skm_sel(S.D[0], S.D[1], q), E1 = skm_sel(S.D[1], S.D[2], q), E2 = skm_sel(S.D[2], S.D[3], q), E3 = skm_sel(S.D[3], 0u, q);
+    uint32_t T0 = E0, T1 = E1, T2 = E2, T3 = E3;
+    if (o) {
+        T0 = __builtin_amdgcn_alignbit(E0, E1, 32u - o);
+        T1 = __builtin_amdgcn_alignbit(E1, E2, 32u - o);
+        T2 = __builtin_amdgcn_alignbit(E2, E3, 32u - o);
+        T3 = E3 << o;
+    }
+    const int kb = 2 * (int)(len + K - 1);                 // bits to keep (<= 100)
+    auto keep = [](uint32_t v, int bits) { return bits >= 32 ? v : (bits <= 0 ? 0u : (v & ~(0xFFFFFFFFu >> bits))); };
+    T0 = keep(T0, kb); T1 = keep(T1, kb - 32); T2 = keep(T2, kb - 64); T3 = keep(T3, kb - 96);
+    skm_rec r;
+    r.x = ((uint64_t)T0 << 32) | T1;
+    r.y = ((uint64_t)T2 << 32) | (uint64_t)(T3 & 0xF0000000u) | ((uint64_t)digits << 6) | (uint64_t)len;
+    return r;
+}
+// level-1 digit and the digit bits that travel in the record, from the run's minimizer hash
+__device__ __forceinline__ void skm_route(uint32_t mh, int bits1, uint32_t &d1, uint32_t &digits) {
+    const uint32_t ph = mf_remix32(mh);
+    d1 = bits1 ? ph >> (32 - bits1) : 0u;
+    digits = (bits1 ? (ph << bits1) : ph) >> (32 - SKM_DIGIT_BITS);
+}
+
+// =============================================================================================
+// S1: per-block histogram of the records' level-1 digit (and of their k-mers, for plans without a split level)
+// =============================================================================================
+template <int K>
+__global__ __launch_bounds__(1024) void k_skm_hist(const uint8_t *__restrict__ bases, uint64_t n_bases, const uint32_t *__restrict__ vmask,
+                                                   uint64_t n_words, uint64_t words_per_block, int bits1,
+                                                   uint32_t *__restrict__ blockhist, uint32_t *__restrict__ blockocc, int G) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nd = 1 << bits1;
+    uint32_t *hist = reinterpret_cast<uint32_t *>(smem), *occ = hist + nd;
+    for (int i = threadIdx.x; i < 2 * nd; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    const uint64_t wlo = (uint64_t)blockIdx.x * words_per_block;
+    const uint64_t whi = wlo + words_per_block < n_words ? wlo + words_per_block : n_words;
+    for (uint64_t wb = wlo; wb < whi; wb += blockDim.x) {
+        const uint64_t w = wb + threadIdx.x;
+        const uint32_t m = w < whi ? vmask[w] : 0u;
+        if (__ballot(m != 0u) == 0ull) continue;
+        skm_word<K> S;
+        skm_scan_word<K>(S, bases, n_bases, w < n_words ? w : 0, m);
+        uint32_t cut = S.cut;
+        while (__ballot(cut != 0u) != 0ull) {
+            if (cut) {
+                uint32_t s, len, d1, digits;
+                skm_next_run<K>(S, cut, s, len);
+                skm_route(skm_mh_at<K>(S, s), bits1, d1, digits);
+                atomicAdd(&hist[d1], 1u);
+                if (blockocc) atomicAdd(&occ[d1], len);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) {
+        blockhist[(size_t)i * G + blockIdx.x] = hist[i];
+        if (blockocc) blockocc[(size_t)i * G + blockIdx.x] = occ[i];
+    }
+}
+
+// =============================================================================================
+// LDS staging of 16-byte records: one 64-byte line (4 records) per digit; same protocol as mf_stage (mf_count.hip):
+// reserve a slot, write it, commit; the 4th committer's line is written to HBM by four lanes with one store instruction
+// =============================================================================================
+struct skm_stage {
+    skm_rec *line;     // [nd][4] + 64 dummy slots (one per lane)
+    uint64_t *cur;     // [nd] next record index of this workgroup's range of digit d
+    uint64_t *q_pos;   // [16 waves][SKM_QCAP]
+    uint32_t *ctr;     // [nd] low 16 = reserved, high 16 = committed; + 64 dummy counters
+    uint32_t *q_d;     // [16 waves][SKM_QCAP]
+    int nd;
+};
+__device__ __forceinline__ skm_stage skm_stage_carve(unsigned char *smem, int nd) {
+    skm_stage L;
+    L.nd = nd;
+    L.line = reinterpret_cast<skm_rec *>(smem);
+    L.cur = reinterpret_cast<uint64_t *>(L.line + (size_t)nd * SKM_LINE + 64);
+    L.q_pos = L.cur + nd;
+    L.ctr = reinterpret_cast<uint32_t *>(L.q_pos + 16 * SKM_QCAP);
+    L.q_d = L.ctr + nd + 64;
+    return L;
+}
+static inline size_t skm_stage_bytes(int nd) {
+    return ((size_t)nd * SKM_LINE + 64) * 16 + (size_t)nd * 8 + 16 * SKM_QCAP * 8 + ((size_t)nd + 64) * 4 + 16 * SKM_QCAP * 4;
+}
+// four 16-byte stores, then four returning adds (the commits); LDS operations of one wave execute in order
+__device__ __forceinline__ void skm_lds_write4_add_rtn4(const uint32_t (&wa)[4], const skm_v4 (&wv)[4], const uint32_t (&a)[4],
+                                                        const uint32_t (&inc)[4], uint32_t (&old)[4]) {
+    asm volatile("ds_write_b128 %4, %8\n\tds_write_b128 %5, %9\n\tds_write_b128 %6, %10\n\tds_write_b128 %7, %11\n\t"
+                 "ds_add_rtn_u32 %0, %12, %16\n\tds_add_rtn_u32 %1, %13, %17\n\tds_add_rtn_u32 %2, %14, %18\n\t"
+                 "ds_add_rtn_u32 %3, %15, %19\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(old[0]), "=&v"(old[1]), "=&v"(old[2]), "=&v"(old[3])
+                 : "v"(wa[0]), "v"(wa[1]), "v"(wa[2]), "v"(wa[3]), "v"(wv[0]), "v"(wv[1]), "v"(wv[2]), "v"(wv[3]),
+                   "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(inc[0]), "v"(inc[1]), "v"(inc[2]), "v"(inc[3])
+                 : "memory");
+}
+// ALL 64 lanes of the wave must call this together (wave-uniform loop, wave-cooperative flush)
+__device__ __forceinline__ void skm_stage_insert(const skm_stage &L, skm_rec *__restrict__ out, const uint32_t (&d)[4],
+                                                 const skm_rec (&rec)[4], bool (&pending)[4]) {
+    const uint32_t ctr0 = mf_lds_addr(L.ctr), line0 = mf_lds_addr(L.line);
+    const uint32_t dummy_ctr = ctr0 + 4u * ((uint32_t)L.nd + (uint32_t)mf_lane());
+    const uint32_t dummy_slot = line0 + 16u * ((uint32_t)L.nd * SKM_LINE + (uint32_t)mf_lane());
+    skm_v4 wv[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) { wv[b].x = (uint32_t)rec[b].x; wv[b].y = (uint32_t)(rec[b].x >> 32); wv[b].z = (uint32_t)rec[b].y; wv[b].w = (uint32_t)(rec[b].y >> 32); }
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < 4; b++) any |= pending[b];
+        if (__ballot(any) == 0ull) break;
+        uint32_t ca[4], w[4], inc[4], old[4], old2[4], wa[4];
+        bool got[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) ca[b] = pending[b] ? ctr0 + 4u * d[b] : dummy_ctr;
+        mf_lds_read4(ca, w);                                                     // peek: is the line open?
+#pragma unroll
+        for (int b = 0; b < 4; b++) inc[b] = (pending[b] && (w[b] & 0xFFFFu) < (uint32_t)SKM_LINE) ? 1u : 0u;
+        mf_lds_add_rtn4(ca, inc, old);                                           // reserve a slot
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            got[b] = inc[b] && (old[b] & 0xFFFFu) < (uint32_t)SKM_LINE;
+            wa[b] = got[b] ? line0 + 16u * (d[b] * SKM_LINE + (old[b] & 0xFFFFu)) : dummy_slot;
+            ca[b] = got[b] ? ctr0 + 4u * d[b] : dummy_ctr;
+            inc[b] = got[b] ? 0x10000u : 0u;
+        }
+        skm_lds_write4_add_rtn4(wa, wv, ca, inc, old2);                          // write the slot, commit
+        uint64_t *qpos = L.q_pos + (threadIdx.x >> 6) * SKM_QCAP;
+        uint32_t *qd = L.q_d + (threadIdx.x >> 6) * SKM_QCAP;
+        const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const bool fl = got[b] && (old2[b] >> 16) == (uint32_t)(SKM_LINE - 1);   // last committer of its line
+            const unsigned long long F = __ballot(fl);
+            if (got[b]) pending[b] = false;
+            if (F == 0ull) continue;
+            const uint32_t n = (uint32_t)__popcll(F), qi = (uint32_t)__popcll(F & lt_mask);
+            uint64_t mypos = 0;
+            if (fl) { mypos = L.cur[d[b]]; L.cur[d[b]] = mypos + SKM_LINE; }
+            for (uint32_t e0 = 0; e0 < n; e0 += SKM_QCAP) {
+                if (fl && qi >= e0 && qi < e0 + SKM_QCAP) { qpos[qi - e0] = mypos; qd[qi - e0] = d[b]; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // queue visible to the wave (in-order LDS)
+                const uint32_t e = e0 + ((uint32_t)mf_lane() >> 2), c = (uint32_t)mf_lane() & 3u;
+                if (e < n) {
+                    const uint32_t dd = qd[e - e0];
+                    const uint64_t pp = qpos[e - e0];
+                    const skm_rec v = L.line[dd * SKM_LINE + c];
+                    out[pp + c] = v;
+                    asm volatile("" ::: "memory");
+                    if (c == 0) __hip_atomic_store(&L.ctr[dd], 0u, __ATOMIC_RELEASE, MF_WG);   // reopen (after the reads above)
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // before the queue is reused
+            }
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// after a barrier: write every partly filled line, padded with sentinel records
+__device__ __forceinline__ void skm_stage_flush_all(const skm_stage &L, skm_rec *__restrict__ out, int nd) {
+    for (int d = threadIdx.x; d < nd; d += blockDim.x) {
+        const uint32_t c = L.ctr[d] >> 16;
+        if (c) {
+            const uint64_t pos = L.cur[d];
+            for (uint32_t s = 0; s < (uint32_t)SKM_LINE; s++) out[pos + s] = s < c ? L.line[d * SKM_LINE + s] : make_ulonglong2(~0ull, ~0ull);
+            L.cur[d] = pos + SKM_LINE;
+            L.ctr[d] = 0;
+        }
+    }
+}
+
+// =============================================================================================
+// S2: records of every run, radix-partitioned by the level-1 digit
+// =============================================================================================
+template <int K>
+__global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict__ bases, uint64_t n_bases, const uint32_t *__restrict__ vmask,
+                                                      uint64_t n_words, uint64_t words_per_block, int bits1,
+                                                      const uint64_t *__restrict__ blockstart, int G, skm_rec *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nd = 1 << bits1;
+    skm_stage L = skm_stage_carve(smem, nd);
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) { L.cur[i] = blockstart[(size_t)i * G + blockIdx.x]; L.ctr[i] = 0; }
+    if (threadIdx.x < 64) L.ctr[nd + threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t wlo = (uint64_t)blockIdx.x * words_per_block;
+    const uint64_t whi = wlo + words_per_block < n_words ? wlo + words_per_block : n_words;
+    for (uint64_t wb = wlo; wb < whi; wb += blockDim.x) {          // wave-uniform: all lanes reach skm_stage_insert together
+        const uint64_t w = wb + threadIdx.x;
+        const uint32_t m = w < whi ? vmask[w] : 0u;
+        if (__ballot(m != 0u) == 0ull) continue;
+        skm_word<K> S;
+        skm_scan_word<K>(S, bases, n_bases, w < n_words ? w : 0, m);
+        uint32_t cut = S.cut;
+        while (__ballot(cut != 0u) != 0ull) {
+            uint32_t d[4]; skm_rec rec[4]; bool pend[4];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                pend[b] = cut != 0u;
+                d[b] = 0; rec[b] = make_ulonglong2(~0ull, ~0ull);
+                if (pend[b]) {
+                    uint32_t s, len, digits;
+                    skm_next_run<K>(S, cut, s, len);
+                    skm_route(skm_mh_at<K>(S, s), bits1, d[b], digits);
+                    rec[b] = skm_make_rec<K>(S, s, len, digits);
+                }
+            }
+            skm_stage_insert(L, out, d, rec, pend);
+        }
+    }
+    __syncthreads();
+    skm_stage_flush_all(L, out, nd);
+}
+
+// partition directory after level 1: start / padded length per digit; k-mers per digit (plans without a split level)
+__global__ void k_skm_dir(const uint64_t *__restrict__ blockstart, const uint32_t *__restrict__ blockocc, int G, int nd,
+                          uint64_t *__restrict__ pstart, uint32_t *__restrict__ plen, uint32_t *__restrict__ pocc) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd) return;
+    const uint64_t s = blockstart[(size_t)d * G], e = blockstart[(size_t)(d + 1) * G];
+    pstart[d] = s;
+    plen[d] = (uint32_t)(e - s);
+    if (blockocc) {
+        uint64_t t = 0;
+        for (int b = 0; b < G; b++) t += blockocc[(size_t)d * G + b];
+        pocc[d] = t > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)t;
+    }
+}
+
+// =============================================================================================
+// S3: split every partition into 2^bits sub-partitions by the next digit bits stored in the records
+// =============================================================================================
+__global__ __launch_bounds__(1024) void k_skm_split(const skm_rec *__restrict__ in, const uint64_t *__restrict__ pstart,
+                                                    const uint32_t *__restrict__ plen, uint32_t np, int shift, int bits,
+                                                    skm_rec *__restrict__ out, uint64_t *__restrict__ ostart, uint32_t *__restrict__ olen,
+                                                    uint32_t *__restrict__ oocc) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t scratch[17];
+    const int nd = 1 << bits;
+    const uint32_t dmask = (uint32_t)nd - 1u;
+    skm_stage L = skm_stage_carve(smem, nd);
+    uint32_t *occ = reinterpret_cast<uint32_t *>(L.line);       // k-mers per digit: lives in the (idle) staging lines during the histogram
+    const int ipt = (nd + (int)blockDim.x - 1) / (int)blockDim.x;
+    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
+        const uint64_t start = pstart[p];
+        const uint32_t len = plen[p];
+        const uint64_t obase = start + (uint64_t)p * (uint64_t)(SKM_LINE * nd);   // room for per-digit padding
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) { L.ctr[i] = 0; occ[i] = 0; }
+        __syncthreads();
+        const skm_rec *src = in + start;
+        for (uint32_t jb = 0; jb < len; jb += 4 * blockDim.x) {
+            skm_rec v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const uint32_t j = jb + u * blockDim.x + threadIdx.x; v[u] = j < len ? src[j] : make_ulonglong2(~0ull, ~0ull); }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                if (skm_rec_valid(v[u])) {
+                    const uint32_t dg = (skm_rec_digits(v[u]) >> shift) & dmask;
+                    atomicAdd(&L.ctr[dg], 1u);
+                    if (oocc) atomicAdd(&occ[dg], skm_rec_n(v[u]));
+                }
+        }
+        __syncthreads();
+        uint32_t mine = 0;
+        const int b0 = threadIdx.x * ipt;
+        for (int j = 0; j < ipt; j++) { const int b = b0 + j; if (b < nd) mine += (L.ctr[b] + 3u) & ~3u; }
+        uint32_t tot;
+        uint32_t ex = mf_block_excl_scan(mine, scratch, &tot);
+        for (int j = 0; j < ipt; j++) {
+            const int b = b0 + j;
+            if (b < nd) {
+                const uint32_t c = (L.ctr[b] + 3u) & ~3u;
+                L.cur[b] = obase + ex;
+                ostart[(size_t)p * nd + b] = obase + ex;
+                olen[(size_t)p * nd + b] = c;
+                if (oocc) oocc[(size_t)p * nd + b] = occ[b];
+                ex += c;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nd; i += blockDim.x) L.ctr[i] = 0;
+        if (threadIdx.x < 64) L.ctr[nd + threadIdx.x] = 0;
+        __syncthreads();
+        // wave-uniform loop bounds: every lane reaches skm_stage_insert
+        for (uint32_t jb = 0; jb < len; jb += 4 * blockDim.x) {
+            skm_rec v[4]; uint32_t d[4]; bool pend[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = jb + u * blockDim.x + threadIdx.x;
+                v[u] = j < len ? src[j] : make_ulonglong2(~0ull, ~0ull);
+                pend[u] = skm_rec_valid(v[u]);
+                d[u] = pend[u] ? ((skm_rec_digits(v[u]) >> shift) & dmask) : 0u;
+            }
+            skm_stage_insert(L, out, d, v, pend);
+        }
+        __syncthreads();
+        skm_stage_flush_all(L, out, nd);
+        __syncthreads();
+    }
+}
+
+// =============================================================================================
+// S4: count one partition per workgroup
+// =============================================================================================
+// LDS steps of 1, 2 or 4 keys per lane (one asm block each: the waits belong to the block, see mf_count_dev.h)
+template <int B> __device__ __forceinline__ void skm_lds_read_b64(const uint32_t (&a)[B], uint64_t (&v)[B]);
+template <> __device__ __forceinline__ void skm_lds_read_b64<1>(const uint32_t (&a)[1], uint64_t (&v)[1]) {
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]) : "v"(a[0]) : "memory");
+}
+template <> __device__ __forceinline__ void skm_lds_read_b64<2>(const uint32_t (&a)[2], uint64_t (&v)[2]) {
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]), "=&v"(v[1]) : "v"(a[0]), "v"(a[1]) : "memory");
+}
+template <> __device__ __forceinline__ void skm_lds_read_b64<4>(const uint32_t (&a)[4], uint64_t (&v)[4]) { mf_lds_read4_b64(a, v); }
+template <int B> __device__ __forceinline__ void skm_lds_cmpst_b64(const uint32_t (&a)[B], uint64_t cmp, const uint64_t (&nv)[B], uint64_t (&old)[B]);
+template <> __device__ __forceinline__ void skm_lds_cmpst_b64<1>(const uint32_t (&a)[1], uint64_t cmp, const uint64_t (&nv)[1], uint64_t (&old)[1]) {
+    asm volatile("ds_cmpst_rtn_b64 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old[0]) : "v"(a[0]), "v"(cmp), "v"(nv[0]) : "memory");
+}
+template <> __device__ __forceinline__ void skm_lds_cmpst_b64<2>(const uint32_t (&a)[2], uint64_t cmp, const uint64_t (&nv)[2], uint64_t (&old)[2]) {
+    asm volatile("ds_cmpst_rtn_b64 %0, %2, %4, %5\n\tds_cmpst_rtn_b64 %1, %3, %4, %6\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(old[0]), "=&v"(old[1]) : "v"(a[0]), "v"(a[1]), "v"(cmp), "v"(nv[0]), "v"(nv[1]) : "memory");
+}
+template <> __device__ __forceinline__ void skm_lds_cmpst_b64<4>(const uint32_t (&a)[4], uint64_t cmp, const uint64_t (&nv)[4], uint64_t (&old)[4]) {
+    mf_lds_cmpst4_b64(a, cmp, nv, old);
+}
+template <int B> __device__ __forceinline__ void skm_lds_add(const uint32_t (&a)[B], const uint32_t (&inc)[B]);
+template <> __device__ __forceinline__ void skm_lds_add<1>(const uint32_t (&a)[1], const uint32_t (&inc)[1]) {
+    asm volatile("ds_add_u32 %0, %1" ::"v"(a[0]), "v"(inc[0]) : "memory");
+}
+template <> __device__ __forceinline__ void skm_lds_add<2>(const uint32_t (&a)[2], const uint32_t (&inc)[2]) {
+    asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %3" ::"v"(a[0]), "v"(a[1]), "v"(inc[0]), "v"(inc[1]) : "memory");
+}
+template <> __device__ __forceinline__ void skm_lds_add<4>(const uint32_t (&a)[4], const uint32_t (&inc)[4]) { mf_lds_add4(a, inc); }
+
+// insert B keys per lane into the LDS table (same protocol as mf_count_insert4); key MF_EMPTY = nothing to insert
+template <int B>
+__device__ __forceinline__ void skm_count_insert(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
+                                                 const uint64_t (&key)[B], unsigned int *overflow) {
+    uint32_t s[B]; bool pend[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = mf_pslot(mf_phash(key[b])) & mask; }
+    for (uint32_t probes = 0;; probes++) {
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < B; b++) any |= pend[b];
+        if (__ballot(any) == 0ull) break;
+        if (probes > mask) { if (mf_lane() == 0) atomicExch(overflow, 1u); break; }
+        uint32_t ka[B], ca[B], aa[B], inc[B]; uint64_t cur[B], ret[B]; bool need[B]; bool anyneed = false;
+#pragma unroll
+        for (int b = 0; b < B; b++) ka[b] = pend[b] ? tk0 + 8u * s[b] : dummy_k;
+        skm_lds_read_b64<B>(ka, cur);
+#pragma unroll
+        for (int b = 0; b < B; b++) { need[b] = pend[b] && cur[b] == MF_EMPTY; ca[b] = need[b] ? ka[b] : dummy_k; anyneed |= need[b]; }
+        if (__ballot(anyneed) != 0ull) {
+            skm_lds_cmpst_b64<B>(ca, MF_EMPTY, key, ret);
+#pragma unroll
+            for (int b = 0; b < B; b++) if (need[b]) cur[b] = ret[b] == MF_EMPTY ? key[b] : ret[b];
+        }
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+            const bool hit = pend[b] && cur[b] == key[b];
+            aa[b] = hit ? tc0 + 4u * s[b] : dummy_c;
+            inc[b] = hit ? 1u : 0u;
+            if (hit) pend[b] = false;
+            else s[b] = (s[b] + 1) & mask;
+        }
+        skm_lds_add<B>(aa, inc);
+    }
+}
+
+// records[pstart[p] .. +plen[p]) -> tkeys/tcnt[toff[p] .. +dcount[p])
+template <int K>
+__global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart,
+                                                      const uint32_t *__restrict__ plen, uint32_t np,
+                                                      const uint64_t *__restrict__ toff, uint64_t *__restrict__ tkeys,
+                                                      uint16_t *__restrict__ tcnt, uint32_t *__restrict__ dcount,
+                                                      unsigned int *__restrict__ overflow) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ uint32_t scratch[17];
+    __shared__ uint32_t out_cursor;
+    uint64_t *tk = reinterpret_cast<uint64_t *>(smem);                          // [MF_COUNT_SLOTS] + 64 dummy slots
+    uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS + 64);      // [MF_COUNT_SLOTS] + 64 dummy counters
+    uint64_t *kbuf = reinterpret_cast<uint64_t *>(tc + MF_COUNT_SLOTS + 64);    // [SKM_KBUF] expanded canonical k-mers
+    const uint32_t tk0 = mf_lds_addr(tk), tc0 = mf_lds_addr(tc);
+    const uint32_t dummy_k = tk0 + 8u * ((uint32_t)MF_COUNT_SLOTS + (uint32_t)mf_lane());
+    const uint32_t dummy_c = tc0 + 4u * ((uint32_t)MF_COUNT_SLOTS + (uint32_t)mf_lane());
+    if (threadIdx.x < 64) { tk[MF_COUNT_SLOTS + threadIdx.x] = 0; tc[MF_COUNT_SLOTS + threadIdx.x] = 0; }   // dummies: never EMPTY
+    constexpr uint32_t mask = MF_COUNT_SLOTS - 1;
+    constexpr int sh = 64 - 2 * K, top = 2 * K - 2;
+    const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
+    uint32_t p = blockIdx.x;
+    if (p >= np) return;
+    uint64_t start = pstart[p];
+    uint32_t len = plen[p];
+    skm_rec R = threadIdx.x < len ? recs[start + threadIdx.x] : SENT;             // first round, prefetched
+    for (;;) {
+        const uint32_t pn = p + gridDim.x;
+        uint64_t start_n = 0; uint32_t len_n = 0;
+        if (pn < np) { start_n = pstart[pn]; len_n = plen[pn]; }
+        for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
+        if (threadIdx.x == 0) out_cursor = 0;
+        skm_rec cur = R;
+        if (pn < np) R = threadIdx.x < len_n ? recs[start_n + threadIdx.x] : SENT;   // next partition's first round
+        for (uint32_t rb = 0; rb < len; rb += blockDim.x) {
+            if (rb) cur = rb + threadIdx.x < len ? recs[start + rb + threadIdx.x] : SENT;
+            const uint32_t r = skm_rec_valid(cur) ? skm_rec_n(cur) : 0u;
+            uint32_t T;
+            const uint32_t off = mf_block_excl_scan(r, scratch, &T);           // (contains barriers: the table init is done)
+            for (uint32_t lo = 0; lo < T; lo += SKM_KBUF) {
+                // expand: k-mer j of the record = bases j .. j+K-1
+                if (r && off < lo + SKM_KBUF && off + r > lo) {
+                    uint64_t X = cur.x, Y = cur.y & ~((1ull << 28) - 1ull);
+                    uint64_t fw = X >> sh, rc = mf_revcomp(fw, K);
+                    for (uint32_t j = 0; j < r; j++) {
+                        const uint32_t idx = off + j;
+                        if (idx >= lo && idx < lo + SKM_KBUF) kbuf[idx - lo] = fw < rc ? fw : rc;
+                        X = (X << 2) | (Y >> 62); Y <<= 2;
+                        fw = X >> sh;
+                        rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fw & 3u)) << top);
+                    }
+                }
+                __syncthreads();
+                const uint32_t n = T - lo < (uint32_t)SKM_KBUF ? T - lo : (uint32_t)SKM_KBUF;
+                uint32_t i0 = 0;
+                while (i0 < n) {                                               // block-uniform
+                    const uint32_t rem = n - i0;
+                    if (rem > 2 * blockDim.x) {
+                        uint64_t k4[4];
+#pragma unroll
+                        for (int b = 0; b < 4; b++) { const uint32_t i = i0 + b * blockDim.x + threadIdx.x; k4[b] = i < n ? kbuf[i] : MF_EMPTY; }
+                        skm_count_insert<4>(tk0, tc0, dummy_k, dummy_c, mask, k4, overflow);
+                        i0 += 4 * blockDim.x;
+                    } else if (rem > blockDim.x) {
+                        uint64_t k2[2];
+#pragma unroll
+                        for (int b = 0; b < 2; b++) { const uint32_t i = i0 + b * blockDim.x + threadIdx.x; k2[b] = i < n ? kbuf[i] : MF_EMPTY; }
+                        skm_count_insert<2>(tk0, tc0, dummy_k, dummy_c, mask, k2, overflow);
+                        i0 += 2 * blockDim.x;
+                    } else {
+                        uint64_t k1[1];
+                        const uint32_t i = i0 + threadIdx.x; k1[0] = i < n ? kbuf[i] : MF_EMPTY;
+                        skm_count_insert<1>(tk0, tc0, dummy_k, dummy_c, mask, k1, overflow);
+                        i0 += blockDim.x;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ds_add_u32 of the asm blocks are invisible to hipcc's waitcnt pass
+                __syncthreads();
+            }
+        }
+        if (len == 0) __syncthreads();                                  // table init visible before the compaction reads it
+        // compaction: each wave walks 64-slot chunks (lane = slot: conflict-free), keeps them in registers, reserves its
+        // output range with ONE LDS atomic
+        {
+            constexpr int NCH = MF_COUNT_SLOTS / SKM_CT;
+            uint64_t ck[NCH]; uint32_t cv[NCH], pre[NCH]; uint32_t total = 0;
+            const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                const uint32_t sl = ((threadIdx.x >> 6) << 6) + (uint32_t)i * SKM_CT + (uint32_t)mf_lane();
+                ck[i] = tk[sl]; cv[i] = tc[sl];
+                const unsigned long long bal = __ballot(ck[i] != MF_EMPTY);
+                pre[i] = total + (uint32_t)__popcll(bal & lt_mask);
+                total += (uint32_t)__popcll(bal);
+            }
+            uint32_t wb = 0;
+            if (mf_lane() == 0 && total) wb = atomicAdd(&out_cursor, total);
+            wb = __shfl(wb, 0, 64);
+            const uint64_t o = toff[p];
+            const uint32_t room = (uint32_t)(toff[p + 1] - o);
+            if (mf_lane() == 0 && wb + total > room) atomicExch(overflow, 1u);      // (only if a partition's k-mer count wrapped)
+#pragma unroll
+            for (int i = 0; i < NCH; i++) {
+                if (ck[i] != MF_EMPTY && wb + pre[i] < room) {
+                    const uint64_t pos = o + wb + pre[i];
+                    tkeys[pos] = ck[i];
+                    tcnt[pos] = (uint16_t)(cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) dcount[p] = out_cursor;
+        if (pn >= np) break;
+        p = pn; start = start_n; len = len_n;
+    }
+}
+
+// capacity of a partition's slice of the temporary (key,count) lists: it cannot hold more distinct k-mers than it has
+// k-mers, nor more than the LDS table
+__global__ void k_skm_cap(const uint32_t *__restrict__ pocc, uint32_t np, uint32_t *__restrict__ cap) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < np) cap[p] = pocc[p] < (uint32_t)MF_COUNT_SLOTS ? pocc[p] : (uint32_t)MF_COUNT_SLOTS;
+}
+
+// =============================================================================================
+// host orchestration
+// =============================================================================================
+template <typename KF> static int skm_set_lds(KF kern, size_t bytes) {
+    MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MF_OK;
+}
+
+// lv: digit bits per level (lv[0] = level 1).  Returns MF_OK and *out, or MF_SKM_FALLBACK (nothing allocated) when the
+// input does not suit this path (a partition too rich for the LDS table, too many levels, not enough memory).
+template <int K>
+static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words,
+                   uint64_t n_occ, const std::vector<int> &lv, unsigned long long *scal, mf_table **out) {
+    hipStream_t st = ctx->stream;
+    const int bits1 = lv[0], nd1 = 1 << bits1;
+    int total_bits = 0; for (int b : lv) total_bits += b;
+    if (total_bits > 32 || total_bits - bits1 > SKM_DIGIT_BITS) return MF_SKM_FALLBACK;
+    int G = ctx->opt_l1_blocks > 0 ? (int)ctx->opt_l1_blocks : ctx->n_cu;
+    {
+        uint64_t maxG = (n_words + 1023) / 1024;
+        if ((uint64_t)G > maxG) G = (int)maxG;
+        if (G < 1) G = 1;
+    }
+    const uint64_t wpb = (n_words + G - 1) / G;
+    const bool l1_only = lv.size() == 1;
+    mf_buf<uint32_t> blockhist; MF_TRY(blockhist.alloc(ctx, (size_t)nd1 * G));
+    mf_buf<uint32_t> blockocc; if (l1_only) MF_TRY(blockocc.alloc(ctx, (size_t)nd1 * G));
+    mf_buf<uint64_t> blockstart; MF_TRY(blockstart.alloc(ctx, (size_t)nd1 * G + 1));
+    {
+        mf_ktimer t(ctx, "k_skm_hist");
+        k_skm_hist<K><<<G, 1024, (size_t)nd1 * 8, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockhist.p, blockocc.p, G);
+    }
+    MF_DBG(ctx, "k_skm_hist");
+    MF_TRY(mf_scan<SKM_LINE>(ctx, blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal[1]));
+    unsigned long long cap = 0;
+    MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));                       // padded number of records
+    mf_buf<skm_rec> bufA; MF_TRY(bufA.alloc(ctx, cap));
+    {
+        const size_t lds = skm_stage_bytes(nd1);
+        MF_TRY(skm_set_lds(k_skm_scatter<K>, lds));
+        mf_ktimer t(ctx, "k_skm_scatter");
+        k_skm_scatter<K><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p);
+    }
+    MF_DBG(ctx, "k_skm_scatter");
+    uint32_t np = (uint32_t)nd1;
+    mf_buf<uint64_t> pstart; MF_TRY(pstart.alloc(ctx, np));
+    mf_buf<uint32_t> plen; MF_TRY(plen.alloc(ctx, np));
+    mf_buf<uint32_t> pocc; MF_TRY(pocc.alloc(ctx, np));
+    k_skm_dir<<<(nd1 + 255) / 256, 256, 0, st>>>(blockstart.p, blockocc.p, G, nd1, pstart.p, plen.p, pocc.p);
+    blockhist.reset(); blockocc.reset(); blockstart.reset();
+
+    int used = 0;
+    for (size_t li = 1; li < lv.size(); li++) {
+        const int bits = lv[li], nd = 1 << bits;
+        const uint64_t cap2 = cap + (uint64_t)np * SKM_LINE * nd;
+        const uint64_t np2 = (uint64_t)np * nd;
+        if (np2 > 0xFFFFFFF0ull) return mf_set_error("too many partitions");
+        const bool last = li + 1 == lv.size();
+        mf_buf<skm_rec> bufB; MF_TRY(bufB.alloc(ctx, cap2));
+        mf_buf<uint64_t> ostart; MF_TRY(ostart.alloc(ctx, np2));
+        mf_buf<uint32_t> olen; MF_TRY(olen.alloc(ctx, np2));
+        mf_buf<uint32_t> oocc; if (last) MF_TRY(oocc.alloc(ctx, np2));
+        const size_t lds = skm_stage_bytes(nd);
+        const unsigned grid = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * (lds > 72 * 1024 ? 1 : 2));
+        {
+            MF_TRY(skm_set_lds(k_skm_split, lds));
+            mf_ktimer t(ctx, "k_skm_split");
+            k_skm_split<<<grid, 1024, lds, st>>>(bufA.p, pstart.p, plen.p, np, SKM_DIGIT_BITS - used - bits, bits, bufB.p, ostart.p, olen.p, oocc.p);
+        }
+        MF_DBG(ctx, "k_skm_split");
+        std::swap(bufA.p, bufB.p); std::swap(bufA.n, bufB.n);
+        std::swap(pstart.p, ostart.p); std::swap(pstart.n, ostart.n);
+        std::swap(plen.p, olen.p); std::swap(plen.n, olen.n);
+        if (last) { std::swap(pocc.p, oocc.p); std::swap(pocc.n, oocc.n); }
+        cap = cap2; np = (uint32_t)np2; used += bits;
+    }
+
+    // ---- temporary (key,count) lists, one slice per partition ----
+    mf_buf<uint32_t> pcap; MF_TRY(pcap.alloc(ctx, np));
+    mf_buf<uint64_t> toff; MF_TRY(toff.alloc(ctx, (size_t)np + 1));
+    k_skm_cap<<<(np + 255) / 256, 256, 0, st>>>(pocc.p, np, pcap.p);
+    MF_TRY(mf_scan<1>(ctx, pcap.p, toff.p, np, (uint64_t *)&scal[4]));
+    unsigned long long tcap = 0;
+    MF_HIP(hipMemcpyAsync(&tcap, &scal[4], 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    pcap.reset(); pocc.reset();
+    mf_buf<uint64_t> tkeys; mf_buf<uint16_t> tcnt;
+    if (tkeys.alloc(ctx, tcap) != MF_OK || tcnt.alloc(ctx, tcap) != MF_OK) {
+        if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: no room for %.1f GB of temporary lists, using the k-mer path\n", tcap * 10 / 1e9);
+        return MF_SKM_FALLBACK;
+    }
+    mf_buf<uint32_t> dcount; MF_TRY(dcount.alloc(ctx, np));
+    {
+        const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_KBUF * 8;
+        MF_TRY(skm_set_lds(k_skm_count<K>, lds));
+        const unsigned grid = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 2);
+        mf_ktimer t(ctx, "k_skm_count");
+        k_skm_count<K><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, np, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2]);
+    }
+    MF_DBG(ctx, "k_skm_count");
+    mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));
+    MF_TRY(mf_scan<1>(ctx, dcount.p, doff.p, np, (uint64_t *)&scal[3]));
+    MF_HIP(hipGetLastError());
+    unsigned long long res[4];
+    MF_HIP(hipMemcpyAsync(res, scal, 32, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    if (res[2]) {
+        if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: a minimizer partition overflows the LDS table, using the k-mer path\n");
+        MF_HIP(hipMemsetAsync(&scal[2], 0, 8, st));
+        return MF_SKM_FALLBACK;
+    }
+    bufA.reset();
+    const uint64_t n_dist = res[3];
+    mf_buf<uint64_t> dk; MF_TRY(dk.alloc(ctx, n_dist));
+    mf_buf<uint16_t> dc; MF_TRY(dc.alloc(ctx, n_dist));
+    {
+        const unsigned grid = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 32);
+        mf_ktimer t(ctx, "k_gather");
+        k_gather<<<grid, 256, 0, st>>>(tkeys.p, tcnt.p, toff.p, dcount.p, doff.p, np, dk.p, dc.p);
+    }
+    MF_DBG(ctx, "k_gather");
+    if (ctx->opt_verbose)
+        fprintf(stderr, "[mf] count(skm): n_occ=%llu records=%llu levels=%zu bits=%d np=%u distinct=%llu\n", (unsigned long long)n_occ,
+                (unsigned long long)cap, lv.size(), total_bits, np, (unsigned long long)n_dist);
+    MF_HIP(hipGetLastError());
+    const size_t kb = dk.bytes(), cb = dc.bytes();
+    MF_TRY(mf_table_adopt(ctx, K, n_dist, n_occ, dk.take(), kb, dc.take(), cb, out));
+    if (total_bits > 0 && total_bits <= 30) {
+        (*out)->part_bits = total_bits;
+        (*out)->part_skm = 1;
+        (*out)->part_off_bytes = doff.bytes();
+        (*out)->d_part_off = doff.take();
+    }
+    return MF_OK;
+}
+
+int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
+                 int k, const std::vector<int> &lv, unsigned long long *scal, mf_table **out) {
+    switch (k) {
+#define SKM_CASE(KK) case KK: return skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, out);
+        SKM_CASE(20) SKM_CASE(21) SKM_CASE(22) SKM_CASE(23) SKM_CASE(24) SKM_CASE(25)
+        SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29) SKM_CASE(30) SKM_CASE(31)
+#undef SKM_CASE
+        default: return MF_SKM_FALLBACK;
+    }
+}

@@ -262,6 +262,7 @@ int mf_table_ensure_index(mf_table *t) {
             }
             MF_HIP(hipGetLastError());
             t->index.slots = p; t->index.cap = cap; t->index.part_bits = (uint32_t)t->part_bits; t->index.region_bits = rb;
+            t->index.skm_k = t->part_skm ? (uint32_t)t->k : 0u;
             t->index_bytes = cap * sizeof(mf_slot);
             if (ctx->opt_verbose) fprintf(stderr, "[mf] index: %u partitions x %u slots (max %u keys), %.2f GB\n", np, 1u << rb, m, cap * 16 / 1e9);
             return MF_OK;
@@ -304,7 +305,7 @@ static int select_entries(mf_ctx *ctx, const uint64_t *keys, const uint16_t *cnt
     {
         mf_ktimer t(ctx, "k_select");
         k_select_count<MODE><<<(unsigned)nb, 1024, 0, ctx->stream>>>(keys, cnts, slots, n, per, thr, bcount.p);
-        k_scan<false><<<1, 1024, 0, ctx->stream>>>(bcount.p, boff.p, nb, tot.p);
+        k_scan<1><<<1, 1024, 0, ctx->stream>>>(bcount.p, boff.p, nb, tot.p);
     }
     uint64_t m = 0;
     MF_HIP(hipMemcpyAsync(&m, tot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -335,8 +336,8 @@ extern "C" int mf_table_filter(const mf_table *t, int threshold, mf_table **out)
         mf_buf<uint64_t> tot; MF_TRY(tot.alloc(ctx, 1));
         unsigned grid = (unsigned)std::min<uint64_t>((np + 3) / 4, (uint64_t)ctx->n_cu * 32);
         k_part_selcount<<<grid, 256, 0, ctx->stream>>>(t->d_counts, t->d_part_off, np, threshold, pc.p);
-        MF_TRY(mf_scan<false>(ctx, pc.p, po.p, np, tot.p));
-        (*out)->part_bits = t->part_bits;
+        MF_TRY(mf_scan<1>(ctx, pc.p, po.p, np, tot.p));
+        (*out)->part_bits = t->part_bits; (*out)->part_skm = t->part_skm;
         (*out)->part_off_bytes = po.bytes();
         (*out)->d_part_off = po.take();
     }
@@ -355,14 +356,14 @@ int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out) {
         mf_buf<uint64_t> boff; MF_TRY(boff.alloc(ctx, nb + 1));
         mf_buf<uint64_t> tot; MF_TRY(tot.alloc(ctx, 1));
         k_select_count<0><<<(unsigned)nb, 1024, 0, ctx->stream>>>(t->d_keys, t->d_counts, nullptr, n, per, threshold, bcount.p);
-        k_scan<false><<<1, 1024, 0, ctx->stream>>>(bcount.p, boff.p, nb, tot.p);
+        k_scan<1><<<1, 1024, 0, ctx->stream>>>(bcount.p, boff.p, nb, tot.p);
         uint64_t m = 0;
         MF_HIP(hipMemcpyAsync(&m, tot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         MF_HIP(hipStreamSynchronize(ctx->stream));
         if (m == n) {
             MF_TRY(mf_table_adopt(ctx, t->k, t->n, 0, t->d_keys, t->keys_bytes, t->d_counts, t->counts_bytes, out));
             (*out)->owns_arrays = false;
-            (*out)->part_bits = t->part_bits; (*out)->d_part_off = t->d_part_off; (*out)->part_off_bytes = t->part_off_bytes;
+            (*out)->part_bits = t->part_bits; (*out)->part_skm = t->part_skm; (*out)->d_part_off = t->d_part_off; (*out)->part_off_bytes = t->part_off_bytes;
             return MF_OK;
         }
     }
