@@ -112,13 +112,15 @@ template <typename T> struct mf_buf {   // RAII workspace buffer
 struct mf_index {                 // open-addressed table in HBM: 16-byte slots {key, idx, val}
     void *slots = nullptr;        // ulonglong2-like: .x = key, .y = (uint64)idx | (uint64)val << 32
     uint64_t cap = 0;             // power of two
-    // partitioned form (part_bits > 0): slot region of a key = top part_bits of mf_phash(key), linear probing wraps
-    // inside the 2^region_bits slots of that region; generic form (part_bits == 0): fmix64(key) & (cap-1)
-    uint32_t part_bits = 0, region_bits = 0;
+    // partitioned form (part_bits > 0): every partition of the dense table (top part_bits of mf_phash(key), or the
+    // minimizer partition) has its own power-of-two region, dir[p] = (first slot << 6) | log2(region slots); linear
+    // probing wraps inside the region.  Generic form (part_bits == 0): fmix64(key) & (cap-1).
+    uint32_t part_bits = 0;
+    uint64_t *dir = nullptr; size_t dir_bytes = 0;
     uint32_t skm_k = 0;           // != 0: partitions are MINIMIZER partitions of k-mers of this length (mf_skm_ph), else mf_phash
 };
-struct mf_index_view { const void *slots; uint64_t mask; uint32_t part_bits, region_bits, skm_k; };
-static inline mf_index_view mf_view(const mf_index &ix) { return mf_index_view{ix.slots, ix.cap - 1, ix.part_bits, ix.region_bits, ix.skm_k}; }
+struct mf_index_view { const void *slots; uint64_t mask; const uint64_t *dir; uint32_t part_bits, skm_k; };
+static inline mf_index_view mf_view(const mf_index &ix) { return mf_index_view{ix.slots, ix.cap - 1, ix.dir, ix.part_bits, ix.skm_k}; }
 struct mf_table {
     mf_ctx *ctx = nullptr;
     int k = 0;
@@ -285,12 +287,13 @@ __device__ __forceinline__ bool mf_index_find(const mf_index_view &ix, uint64_t 
     if (ix.part_bits) {
         const uint64_t h = mf_phash(key);
         const uint64_t part = ix.skm_k ? (uint64_t)(mf_skm_ph(key, (int)ix.skm_k) >> (32 - ix.part_bits)) : (h >> (64 - ix.part_bits));
-        base = part << ix.region_bits;
-        rmask = (1ull << ix.region_bits) - 1;
+        const uint64_t d = ix.dir[part];
+        base = d >> 6;
+        rmask = (1ull << (d & 63ull)) - 1;
         s = mf_pslot(h) & rmask;
     } else s = mf_hash64(key) & rmask;
     for (;;) {
-        const ulonglong2 raw = *reinterpret_cast<const ulonglong2 *>(&slots[base | s]);
+        const ulonglong2 raw = *reinterpret_cast<const ulonglong2 *>(&slots[base + s]);
         if (raw.x == key) { *idx = (uint32_t)raw.y; *val = (uint32_t)(raw.y >> 32); return true; }
         if (raw.x == MF_EMPTY) return false;
         s = (s + 1) & rmask;

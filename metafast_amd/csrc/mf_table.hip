@@ -66,26 +66,47 @@ __global__ void k_index_lookup(mf_index_view ix, const uint64_t *__restrict__ ke
     out[i] = mf_index_find(ix, keys[i], &idx, &val) ? (int32_t)val : -1;
 }
 
-// ---- partitioned index build: one wave per hash partition builds that partition's 2^region_bits slots in LDS
-// (LDS CAS) and writes them out as one contiguous block.  The dense table comes out of k_count grouped by the same
-// partition bits, so this is a streaming pass: no HBM atomics, no random HBM accesses (the generic build below
-// costs one random CAS + one random store per key: 40 ms for 3.6e8 keys). ----
-// TEAM = 64: a wave per partition (regions up to 1024 slots, 4 regions per block); TEAM = 256: the block per partition
+// ---- partitioned index build: the dense table comes out of the counting pass grouped by partition, so every partition's
+// region can be built in LDS (LDS CAS) and written out as one contiguous block: a streaming pass, no HBM atomics, no random
+// HBM accesses (the generic build below costs one random CAS + one random store per key: 40 ms for 3.6e8 keys).
+// Regions are sized per partition (minimizer partitions differ a lot in size): power of two >= 1.5 x its keys. ----
+#define MF_IDX_WAVE_SLOTS 1024      // regions up to this size are built by one wave, larger ones by a whole workgroup
+__global__ void k_index_region_sizes(const uint64_t *__restrict__ part_off, uint32_t np, uint32_t *__restrict__ sz,
+                                     uint32_t *__restrict__ biglist, unsigned int *__restrict__ n_big) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= np) return;
+    uint64_t c = part_off[p + 1] - part_off[p];
+    if (c > 5461) { atomicAdd(n_big + 2, 1u); c = 5461; }       // region would not fit in LDS: the caller builds the generic index
+    const uint64_t want = c + c / 2 + 1;
+    uint32_t S = 2;
+    while (S < want) S <<= 1;
+    sz[p] = S;
+    if (S > MF_IDX_WAVE_SLOTS) biglist[atomicAdd(n_big, 1u)] = p;
+}
+__global__ void k_index_dir_pack(const uint64_t *__restrict__ roff, const uint32_t *__restrict__ sz, uint32_t np, uint64_t *__restrict__ dir) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < np) dir[p] = (roff[p] << 6) | (uint64_t)(31 - __clz(sz[p]));
+}
+// TEAM = 64: a wave per partition (4 regions per block), skips the large ones; TEAM = 256: the block per LISTED partition
 template <int TEAM>
-__global__ __launch_bounds__(256) void k_index_build_part(mf_slot *__restrict__ slots, uint32_t region_bits, const uint64_t *__restrict__ keys,
+__global__ __launch_bounds__(256) void k_index_build_part(mf_slot *__restrict__ slots, const uint64_t *__restrict__ dir, const uint64_t *__restrict__ keys,
                                                           const uint16_t *__restrict__ vals, const uint64_t *__restrict__ part_off,
-                                                          uint32_t np) {
+                                                          uint32_t np, const uint32_t *__restrict__ biglist, const unsigned int *__restrict__ n_big) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const uint32_t S = 1u << region_bits, rmask = S - 1;
     constexpr int TEAMS = 256 / TEAM;
     const int team = threadIdx.x / TEAM, tl = threadIdx.x % TEAM;
-    mf_slot *reg = reinterpret_cast<mf_slot *>(smem) + (size_t)team * S;
+    mf_slot *reg = reinterpret_cast<mf_slot *>(smem) + (size_t)team * MF_IDX_WAVE_SLOTS;     // (TEAM 256: team == 0, the whole buffer)
     auto sync = [&]() {
         if (TEAM == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
     };
     const uint32_t nteams = gridDim.x * TEAMS;
-    for (uint32_t p = blockIdx.x * TEAMS + team; p < np; p += nteams) {   // p is team-uniform
+    const uint32_t count = TEAM == 64 ? np : *n_big;
+    for (uint32_t it = blockIdx.x * TEAMS + team; it < count; it += nteams) {   // team-uniform
+        const uint32_t p = TEAM == 64 ? it : biglist[it];
+        const uint64_t d = dir[p];
+        const uint32_t S = 1u << (uint32_t)(d & 63ull), rmask = S - 1;
+        if (TEAM == 64 && S > MF_IDX_WAVE_SLOTS) continue;
         for (uint32_t j = tl; j < S; j += TEAM) { ulonglong2 e; e.x = MF_EMPTY; e.y = 0; *reinterpret_cast<ulonglong2 *>(&reg[j]) = e; }
         sync();
         const uint64_t lo = part_off[p], hi = part_off[p + 1];
@@ -101,17 +122,10 @@ __global__ __launch_bounds__(256) void k_index_build_part(mf_slot *__restrict__ 
             }
         }
         sync();
-        mf_slot *dst = slots + ((size_t)p << region_bits);
+        mf_slot *dst = slots + (d >> 6);
         for (uint32_t j = tl; j < S; j += TEAM) *reinterpret_cast<ulonglong2 *>(&dst[j]) = *reinterpret_cast<const ulonglong2 *>(&reg[j]);
         sync();
     }
-}
-// largest partition
-__global__ void k_part_max(const uint64_t *__restrict__ part_off, uint32_t np, unsigned int *__restrict__ mx) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t c = p < np ? (uint32_t)(part_off[p + 1] - part_off[p]) : 0u;
-    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_down(c, d, 64); c = o > c ? o : c; }
-    if (mf_lane() == 0 && c) atomicMax(mx, c);
 }
 // entries with count > thr per partition (one wave per partition)
 __global__ __launch_bounds__(256) void k_part_selcount(const uint16_t *__restrict__ cnts, const uint64_t *__restrict__ part_off, uint32_t np,
@@ -208,6 +222,7 @@ extern "C" void mf_table_destroy(mf_table *t) {
     if (t->owns_arrays && t->d_keys) mf_release(t->ctx, t->d_keys, t->keys_bytes);
     if (t->owns_arrays && t->d_counts) mf_release(t->ctx, t->d_counts, t->counts_bytes);
     if (t->index.slots) mf_release(t->ctx, t->index.slots, t->index_bytes);
+    if (t->index.dir) mf_release(t->ctx, t->index.dir, t->index.dir_bytes);
     if (t->owns_arrays && t->d_part_off) mf_release(t->ctx, t->d_part_off, t->part_off_bytes);
     delete t;
 }
@@ -236,37 +251,45 @@ int mf_table_ensure_index(mf_table *t) {
     if (t->n >= 0xFFFFFFFFull) return mf_set_error("index supports < 2^32 entries");
     mf_ctx *ctx = t->ctx;
     if (t->part_bits > 0 && t->d_part_off && t->n) {
-        // partitioned build: region = power of two >= 1.5 x the largest partition
         const uint32_t np = 1u << t->part_bits;
-        mf_buf<unsigned int> mx; MF_TRY(mx.alloc(ctx, 1));
-        MF_HIP(hipMemsetAsync(mx.p, 0, 4, ctx->stream));
-        k_part_max<<<(np + 255) / 256, 256, 0, ctx->stream>>>(t->d_part_off, np, mx.p);
-        unsigned int m = 0;
-        MF_HIP(hipMemcpyAsync(&m, mx.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        mf_buf<uint32_t> sz; MF_TRY(sz.alloc(ctx, np));
+        mf_buf<uint32_t> biglist; MF_TRY(biglist.alloc(ctx, np));
+        mf_buf<uint64_t> roff; MF_TRY(roff.alloc(ctx, (size_t)np + 1));
+        mf_buf<uint64_t> scal; MF_TRY(scal.alloc(ctx, 3));            // [0] total slots, [1] number of large regions, [2] oversized partitions
+        mf_buf<uint64_t> dir; MF_TRY(dir.alloc(ctx, np));
+        MF_HIP(hipMemsetAsync(scal.p, 0, 24, ctx->stream));
+        k_index_region_sizes<<<(np + 255) / 256, 256, 0, ctx->stream>>>(t->d_part_off, np, sz.p, biglist.p, (unsigned int *)&scal.p[1]);
+        MF_TRY(mf_scan<1>(ctx, sz.p, roff.p, np, &scal.p[0]));
+        k_index_dir_pack<<<(np + 255) / 256, 256, 0, ctx->stream>>>(roff.p, sz.p, np, dir.p);
+        uint64_t hs[3];
+        MF_HIP(hipMemcpyAsync(hs, scal.p, 24, hipMemcpyDeviceToHost, ctx->stream));
         MF_HIP(hipStreamSynchronize(ctx->stream));
-        uint32_t rb = 4;
-        while ((1ull << rb) < (uint64_t)m + m / 2 + 1) rb++;
-        const uint64_t cap = (uint64_t)np << rb;
-        if (rb <= 13 && cap * sizeof(mf_slot) <= ((size_t)64 << 30) && cap <= 16 * std::max<uint64_t>(t->n, 1024)) {
-            void *p = nullptr;
-            MF_TRY(mf_alloc(ctx, cap * sizeof(mf_slot), &p));
-            const bool wave = rb <= 10;
-            size_t lds = (size_t)(wave ? 4 : 1) * ((size_t)1 << rb) * sizeof(mf_slot);
-            auto fn = wave ? k_index_build_part<64> : k_index_build_part<256>;
-            MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const int wg_per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / lds));
-            unsigned grid = (unsigned)std::min<uint64_t>(wave ? (np + 3) / 4 : np, (uint64_t)ctx->n_cu * wg_per_cu);
-            {
-                mf_ktimer tm(ctx, "k_index_build_part");
-                fn<<<grid, 256, lds, ctx->stream>>>((mf_slot *)p, rb, t->d_keys, t->d_counts, t->d_part_off, np);
+        if (hs[2]) return mf_index_build(ctx, t->d_keys, t->d_counts, t->n, &t->index, &t->index_bytes);
+        const uint64_t cap = hs[0];
+        const uint32_t n_big = (uint32_t)hs[1];
+        void *p = nullptr;
+        MF_TRY(mf_alloc(ctx, cap * sizeof(mf_slot), &p));
+        {
+            mf_ktimer tm(ctx, "k_index_build_part");
+            const size_t lds = (size_t)4 * MF_IDX_WAVE_SLOTS * sizeof(mf_slot);
+            MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_index_build_part<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            const unsigned grid = (unsigned)std::min<uint64_t>((np + 3) / 4, (uint64_t)ctx->n_cu * 2);
+            k_index_build_part<64><<<grid, 256, lds, ctx->stream>>>((mf_slot *)p, dir.p, t->d_keys, t->d_counts, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1]);
+            if (n_big) {      // regions of up to 8192 slots (the counting pass cannot produce partitions of more than 4096 keys)
+                const size_t lds2 = (size_t)8192 * sizeof(mf_slot);
+                MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_index_build_part<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+                k_index_build_part<256><<<(unsigned)std::min<uint32_t>(n_big, (uint32_t)ctx->n_cu), 256, lds2, ctx->stream>>>((mf_slot *)p, dir.p, t->d_keys, t->d_counts, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1]);
             }
-            MF_HIP(hipGetLastError());
-            t->index.slots = p; t->index.cap = cap; t->index.part_bits = (uint32_t)t->part_bits; t->index.region_bits = rb;
-            t->index.skm_k = t->part_skm ? (uint32_t)t->k : 0u;
-            t->index_bytes = cap * sizeof(mf_slot);
-            if (ctx->opt_verbose) fprintf(stderr, "[mf] index: %u partitions x %u slots (max %u keys), %.2f GB\n", np, 1u << rb, m, cap * 16 / 1e9);
-            return MF_OK;
         }
+        MF_HIP(hipGetLastError());
+        MF_HIP(hipStreamSynchronize(ctx->stream));          // (biglist / scal are released below)
+        t->index.slots = p; t->index.cap = cap; t->index.part_bits = (uint32_t)t->part_bits;
+        t->index.skm_k = t->part_skm ? (uint32_t)t->k : 0u;
+        t->index.dir_bytes = dir.bytes(); t->index.dir = dir.take();
+        t->index_bytes = cap * sizeof(mf_slot);
+        if (ctx->opt_verbose) fprintf(stderr, "[mf] index: %u partitions, %llu slots for %llu keys (%u large regions), %.2f GB\n", np,
+                                      (unsigned long long)cap, (unsigned long long)t->n, n_big, cap * 16 / 1e9);
+        return MF_OK;
     }
     return mf_index_build(ctx, t->d_keys, t->d_counts, t->n, &t->index, &t->index_bytes);
 }
