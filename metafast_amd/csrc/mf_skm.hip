@@ -28,7 +28,6 @@ typedef uint32_t skm_v4 __attribute__((ext_vector_type(4)));
 #define SKM_LINE 4                 // records per 64-byte staging line
 #define SKM_QCAP 16
 #define SKM_DIGIT_BITS 22          // digit bits stored in a record (levels after the first)
-#define SKM_KBUF 3584              // k-mers expanded at a time in k_skm_count (LDS)
 #define SKM_CT 512                 // threads of k_skm_count
 
 __device__ __forceinline__ bool skm_rec_valid(const skm_rec &r) { return ((uint32_t)r.y & 63u) != 63u; }
@@ -458,13 +457,19 @@ template <> __device__ __forceinline__ void skm_lds_add<2>(const uint32_t (&a)[2
 }
 template <> __device__ __forceinline__ void skm_lds_add<4>(const uint32_t (&a)[4], const uint32_t (&inc)[4]) { mf_lds_add4(a, inc); }
 
+// slot of a key in the LDS table: two 32-bit multiplies (the 64-bit multiply of mf_phash is six quarter-rate instructions)
+__device__ __forceinline__ uint32_t skm_slot(uint64_t key) {
+    uint32_t f = ((uint32_t)(key >> 32) * 0x85EBCA6Bu) ^ (uint32_t)key;
+    f *= 0x9E3779B1u;
+    return f >> 16;
+}
 // insert B keys per lane into the LDS table (same protocol as mf_count_insert4); key MF_EMPTY = nothing to insert
 template <int B>
 __device__ __forceinline__ void skm_count_insert(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
                                                  const uint64_t (&key)[B], unsigned int *overflow) {
     uint32_t s[B]; bool pend[B];
 #pragma unroll
-    for (int b = 0; b < B; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = mf_pslot(mf_phash(key[b])) & mask; }
+    for (int b = 0; b < B; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = skm_slot(key[b]) & mask; }
     for (uint32_t probes = 0;; probes++) {
         bool any = false;
 #pragma unroll
@@ -494,7 +499,72 @@ __device__ __forceinline__ void skm_count_insert(uint32_t tk0, uint32_t tc0, uin
     }
 }
 
+// Four keys per lane, narrowing: ONE four-wide probe settles about nine keys in ten (first-probe hits and fresh slots);
+// what is left (keys that met a collision) goes on one key per lane at a time with one-wide steps.  Keeping the loop
+// four-wide until the last of the wave's 256 keys is placed costs 3.3 four-wide iterations on average, most of them LDS
+// instructions on dummy slots.
+__device__ __forceinline__ void skm_count_insert4n(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
+                                                   const uint64_t (&key)[4], unsigned int *overflow) {
+    uint32_t s[4]; bool pend[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = skm_slot(key[b]) & mask; }
+    {
+        uint32_t ka[4], ca[4], aa[4], inc[4]; uint64_t cur[4], ret[4]; bool need[4]; bool anyneed = false;
+#pragma unroll
+        for (int b = 0; b < 4; b++) ka[b] = pend[b] ? tk0 + 8u * s[b] : dummy_k;
+        mf_lds_read4_b64(ka, cur);
+#pragma unroll
+        for (int b = 0; b < 4; b++) { need[b] = pend[b] && cur[b] == MF_EMPTY; ca[b] = need[b] ? ka[b] : dummy_k; anyneed |= need[b]; }
+        if (__ballot(anyneed) != 0ull) {
+            mf_lds_cmpst4_b64(ca, MF_EMPTY, key, ret);
+#pragma unroll
+            for (int b = 0; b < 4; b++) if (need[b]) cur[b] = ret[b] == MF_EMPTY ? key[b] : ret[b];
+        }
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            const bool hit = pend[b] && cur[b] == key[b];
+            aa[b] = hit ? tc0 + 4u * s[b] : dummy_c;
+            inc[b] = hit ? 1u : 0u;
+            if (hit) pend[b] = false;
+            else s[b] = (s[b] + 1) & mask;
+        }
+        mf_lds_add4(aa, inc);
+    }
+    for (;;) {
+        const bool any = pend[0] | pend[1] | pend[2] | pend[3];
+        if (__ballot(any) == 0ull) break;
+        // this lane's first unsettled key
+        const uint64_t k1[1] = {pend[0] ? key[0] : pend[1] ? key[1] : pend[2] ? key[2] : key[3]};
+        uint32_t s1 = pend[0] ? s[0] : pend[1] ? s[1] : pend[2] ? s[2] : s[3];
+        bool p1 = any;
+        if (pend[0]) pend[0] = false; else if (pend[1]) pend[1] = false; else if (pend[2]) pend[2] = false; else pend[3] = false;
+        for (uint32_t probes = 0;; probes++) {
+            if (__ballot(p1) == 0ull) break;
+            if (probes > mask) { if (mf_lane() == 0) atomicExch(overflow, 1u); break; }
+            uint32_t ka[1], ca[1], aa[1], inc[1]; uint64_t cur[1], ret[1];
+            ka[0] = p1 ? tk0 + 8u * s1 : dummy_k;
+            skm_lds_read_b64<1>(ka, cur);
+            const bool need = p1 && cur[0] == MF_EMPTY;
+            ca[0] = need ? ka[0] : dummy_k;
+            if (__ballot(need) != 0ull) {
+                skm_lds_cmpst_b64<1>(ca, MF_EMPTY, k1, ret);
+                if (need) cur[0] = ret[0] == MF_EMPTY ? k1[0] : ret[0];
+            }
+            const bool hit = p1 && cur[0] == k1[0];
+            aa[0] = hit ? tc0 + 4u * s1 : dummy_c;
+            inc[0] = hit ? 1u : 0u;
+            if (hit) p1 = false;
+            else s1 = (s1 + 1) & mask;
+            skm_lds_add<1>(aa, inc);
+        }
+    }
+}
+
 // records[pstart[p] .. +plen[p]) -> tkeys/tcnt[toff[p] .. +dcount[p])
+// The records of a round (one per thread) are parked in LDS and cut into ITEMS of up to four consecutive k-mers; the
+// items are dealt out evenly, a thread extracts its item's first k-mer with one 128-bit shift, rolls to the next three
+// and inserts the four straight from registers.  (One thread expanding its whole record serially costs the wave the
+// LONGEST record of its 64: twice the work, and only the waves that hold records take part.)
 template <int K>
 __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart,
                                                       const uint32_t *__restrict__ plen, uint32_t np,
@@ -506,7 +576,8 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
     __shared__ uint32_t out_cursor;
     uint64_t *tk = reinterpret_cast<uint64_t *>(smem);                          // [MF_COUNT_SLOTS] + 64 dummy slots
     uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS + 64);      // [MF_COUNT_SLOTS] + 64 dummy counters
-    uint64_t *kbuf = reinterpret_cast<uint64_t *>(tc + MF_COUNT_SLOTS + 64);    // [SKM_KBUF] expanded canonical k-mers
+    skm_rec *rbuf = reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64);      // [SKM_CT] records of the round
+    uint16_t *items = reinterpret_cast<uint16_t *>(rbuf + SKM_CT);              // [SKM_CT * 8] (thread, chunk) of each item
     const uint32_t tk0 = mf_lds_addr(tk), tc0 = mf_lds_addr(tc);
     const uint32_t dummy_k = tk0 + 8u * ((uint32_t)MF_COUNT_SLOTS + (uint32_t)mf_lane());
     const uint32_t dummy_c = tc0 + 4u * ((uint32_t)MF_COUNT_SLOTS + (uint32_t)mf_lane());
@@ -530,50 +601,35 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
         for (uint32_t rb = 0; rb < len; rb += blockDim.x) {
             if (rb) cur = rb + threadIdx.x < len ? recs[start + rb + threadIdx.x] : SENT;
             const uint32_t r = skm_rec_valid(cur) ? skm_rec_n(cur) : 0u;
-            uint32_t T;
-            const uint32_t off = mf_block_excl_scan(r, scratch, &T);           // (contains barriers: the table init is done)
-            for (uint32_t lo = 0; lo < T; lo += SKM_KBUF) {
-                // expand: k-mer j of the record = bases j .. j+K-1
-                if (r && off < lo + SKM_KBUF && off + r > lo) {
-                    uint64_t X = cur.x, Y = cur.y & ~((1ull << 28) - 1ull);
+            const uint32_t nch = (r + 3u) >> 2;
+            uint32_t NI;
+            const uint32_t ioff = mf_block_excl_scan(nch, scratch, &NI);       // (contains barriers: table init / previous round done)
+            rbuf[threadIdx.x] = cur;
+            for (uint32_t c = 0; c < nch; c++) items[ioff + c] = (uint16_t)(threadIdx.x | (c << 9));
+            __syncthreads();
+            for (uint32_t i0 = 0; i0 < NI; i0 += blockDim.x) {                  // block-uniform
+                uint64_t k4[4] = {MF_EMPTY, MF_EMPTY, MF_EMPTY, MF_EMPTY};
+                if (i0 + threadIdx.x < NI) {
+                    const uint32_t it = items[i0 + threadIdx.x];
+                    const skm_rec rec = rbuf[it & 511u];
+                    const uint32_t c = it >> 9, sft = 8u * c;                   // the item's first k-mer starts 4c bases in
+                    const uint32_t nk = skm_rec_n(rec) - 4u * c;                // k-mers left in the record (>= 1)
+                    uint64_t X = rec.x, Y = rec.y & ~((1ull << 28) - 1ull);
+                    if (sft) { X = (X << sft) | (Y >> (64u - sft)); Y <<= sft; }
                     uint64_t fw = X >> sh, rc = mf_revcomp(fw, K);
-                    for (uint32_t j = 0; j < r; j++) {
-                        const uint32_t idx = off + j;
-                        if (idx >= lo && idx < lo + SKM_KBUF) kbuf[idx - lo] = fw < rc ? fw : rc;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if ((uint32_t)j < nk) k4[j] = fw < rc ? fw : rc;
                         X = (X << 2) | (Y >> 62); Y <<= 2;
                         fw = X >> sh;
                         rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fw & 3u)) << top);
                     }
                 }
-                __syncthreads();
-                const uint32_t n = T - lo < (uint32_t)SKM_KBUF ? T - lo : (uint32_t)SKM_KBUF;
-                uint32_t i0 = 0;
-                while (i0 < n) {                                               // block-uniform
-                    const uint32_t rem = n - i0;
-                    if (rem > 2 * blockDim.x) {
-                        uint64_t k4[4];
-#pragma unroll
-                        for (int b = 0; b < 4; b++) { const uint32_t i = i0 + b * blockDim.x + threadIdx.x; k4[b] = i < n ? kbuf[i] : MF_EMPTY; }
-                        skm_count_insert<4>(tk0, tc0, dummy_k, dummy_c, mask, k4, overflow);
-                        i0 += 4 * blockDim.x;
-                    } else if (rem > blockDim.x) {
-                        uint64_t k2[2];
-#pragma unroll
-                        for (int b = 0; b < 2; b++) { const uint32_t i = i0 + b * blockDim.x + threadIdx.x; k2[b] = i < n ? kbuf[i] : MF_EMPTY; }
-                        skm_count_insert<2>(tk0, tc0, dummy_k, dummy_c, mask, k2, overflow);
-                        i0 += 2 * blockDim.x;
-                    } else {
-                        uint64_t k1[1];
-                        const uint32_t i = i0 + threadIdx.x; k1[0] = i < n ? kbuf[i] : MF_EMPTY;
-                        skm_count_insert<1>(tk0, tc0, dummy_k, dummy_c, mask, k1, overflow);
-                        i0 += blockDim.x;
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ds_add_u32 of the asm blocks are invisible to hipcc's waitcnt pass
-                __syncthreads();
+                skm_count_insert4n(tk0, tc0, dummy_k, dummy_c, mask, k4, overflow);
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ds_add_u32 of the asm blocks are invisible to hipcc's waitcnt pass
         }
-        if (len == 0) __syncthreads();                                  // table init visible before the compaction reads it
+        __syncthreads();
         // compaction: each wave walks 64-slot chunks (lane = slot: conflict-free), keeps them in registers, reserves its
         // output range with ONE LDS atomic
         {
@@ -711,7 +767,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     }
     mf_buf<uint32_t> dcount; MF_TRY(dcount.alloc(ctx, np));
     {
-        const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_KBUF * 8;
+        const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 8 * 2;
         MF_TRY(skm_set_lds(k_skm_count<K>, lds));
         const unsigned grid = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 2);
         mf_ktimer t(ctx, "k_skm_count");

@@ -7,6 +7,7 @@ n_reads = int(sys.argv[1]) if len(sys.argv) > 1 else 20_000_000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rl = 150
 ctx = L.Context(0, stream=torch.cuda.current_stream())
+if os.environ.get("MF_VERBOSE"): ctx.set_option("verbose", int(os.environ["MF_VERBOSE"]))
 bases = torch.zeros(n_reads * rl + 64, dtype=torch.uint8, device="cuda")
 offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
