@@ -561,35 +561,38 @@ __device__ __forceinline__ void skm_count_insert4n(uint32_t tk0, uint32_t tc0, u
 }
 
 // records[pstart[p] .. +plen[p]) -> tkeys/tcnt[toff[p] .. +dcount[p])
-// The records of a round (one per thread) are parked in LDS and cut into ITEMS of up to four consecutive k-mers; the
-// items are dealt out evenly, a thread extracts its item's first k-mer with one 128-bit shift, rolls to the next three
-// and inserts the four straight from registers.  (One thread expanding its whole record serially costs the wave the
-// LONGEST record of its 64: twice the work, and only the waves that hold records take part.)
+// Every WAVE works on its own: it takes records in groups of eight (round-robin over the eight waves, so a partition of a
+// few hundred records keeps all of them busy), parks its 64 records in its private LDS corner and cuts them into ITEMS
+// of up to four consecutive k-mers; the items are dealt out evenly over the lanes, a lane extracts its item's first
+// k-mer with one 128-bit shift, rolls to the next three and inserts the four straight from registers.  No workgroup
+// barrier between the table initialisation and the compaction.  (One lane expanding its whole record serially costs the
+// wave the LONGEST record of its 64; a block-wide item list costs four barriers per round.)
 template <int K>
 __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart,
                                                       const uint32_t *__restrict__ plen, uint32_t np,
                                                       const uint64_t *__restrict__ toff, uint64_t *__restrict__ tkeys,
                                                       uint16_t *__restrict__ tcnt, uint32_t *__restrict__ dcount,
-                                                      unsigned int *__restrict__ overflow) {
+                                                      unsigned int *__restrict__ overflow, int ablate) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t scratch[17];
     __shared__ uint32_t out_cursor;
     uint64_t *tk = reinterpret_cast<uint64_t *>(smem);                          // [MF_COUNT_SLOTS] + 64 dummy slots
     uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS + 64);      // [MF_COUNT_SLOTS] + 64 dummy counters
-    skm_rec *rbuf = reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64);      // [SKM_CT] records of the round
-    uint16_t *items = reinterpret_cast<uint16_t *>(rbuf + SKM_CT);              // [SKM_CT * 8] (thread, chunk) of each item
+    const uint32_t wave = threadIdx.x >> 6, lane = (uint32_t)mf_lane();
+    skm_rec *rbuf = reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64) + wave * 64;              // [64] this wave's records
+    uint16_t *items = reinterpret_cast<uint16_t *>(reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64) + SKM_CT) + wave * 512;   // [64 * 8]
     const uint32_t tk0 = mf_lds_addr(tk), tc0 = mf_lds_addr(tc);
-    const uint32_t dummy_k = tk0 + 8u * ((uint32_t)MF_COUNT_SLOTS + (uint32_t)mf_lane());
-    const uint32_t dummy_c = tc0 + 4u * ((uint32_t)MF_COUNT_SLOTS + (uint32_t)mf_lane());
+    const uint32_t dummy_k = tk0 + 8u * ((uint32_t)MF_COUNT_SLOTS + lane);
+    const uint32_t dummy_c = tc0 + 4u * ((uint32_t)MF_COUNT_SLOTS + lane);
     if (threadIdx.x < 64) { tk[MF_COUNT_SLOTS + threadIdx.x] = 0; tc[MF_COUNT_SLOTS + threadIdx.x] = 0; }   // dummies: never EMPTY
     constexpr uint32_t mask = MF_COUNT_SLOTS - 1;
     constexpr int sh = 64 - 2 * K, top = 2 * K - 2;
     const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
+    const uint32_t mine = (lane >> 3) * 64u + wave * 8u + (lane & 7u);          // this lane's record within a round of 512
     uint32_t p = blockIdx.x;
     if (p >= np) return;
     uint64_t start = pstart[p];
     uint32_t len = plen[p];
-    skm_rec R = threadIdx.x < len ? recs[start + threadIdx.x] : SENT;             // first round, prefetched
+    skm_rec R = mine < len ? recs[start + mine] : SENT;                        // first round, prefetched
     for (;;) {
         const uint32_t pn = p + gridDim.x;
         uint64_t start_n = 0; uint32_t len_n = 0;
@@ -597,22 +600,25 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
         for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
         if (threadIdx.x == 0) out_cursor = 0;
         skm_rec cur = R;
-        if (pn < np) R = threadIdx.x < len_n ? recs[start_n + threadIdx.x] : SENT;   // next partition's first round
+        if (pn < np) R = mine < len_n ? recs[start_n + mine] : SENT;           // next partition's first round
+        __syncthreads();
         for (uint32_t rb = 0; rb < len; rb += blockDim.x) {
-            if (rb) cur = rb + threadIdx.x < len ? recs[start + rb + threadIdx.x] : SENT;
+            if (rb) cur = rb + mine < len ? recs[start + rb + mine] : SENT;
             const uint32_t r = skm_rec_valid(cur) ? skm_rec_n(cur) : 0u;
             const uint32_t nch = (r + 3u) >> 2;
             uint32_t NI;
-            const uint32_t ioff = mf_block_excl_scan(nch, scratch, &NI);       // (contains barriers: table init / previous round done)
-            rbuf[threadIdx.x] = cur;
-            for (uint32_t c = 0; c < nch; c++) items[ioff + c] = (uint16_t)(threadIdx.x | (c << 9));
-            __syncthreads();
-            for (uint32_t i0 = 0; i0 < NI; i0 += blockDim.x) {                  // block-uniform
+            const uint32_t ioff = mf_wave_excl_scan(nch, &NI);
+            if (NI == 0) continue;                                              // wave-uniform
+            rbuf[lane] = cur;
+            for (uint32_t c = 0; c < nch; c++) items[ioff + c] = (uint16_t)(lane | (c << 6));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // LDS of one wave is in order: visible to its lanes
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t i0 = 0; i0 < (ablate == 4 ? 0u : NI); i0 += 64) {    // wave-uniform
                 uint64_t k4[4] = {MF_EMPTY, MF_EMPTY, MF_EMPTY, MF_EMPTY};
-                if (i0 + threadIdx.x < NI) {
-                    const uint32_t it = items[i0 + threadIdx.x];
-                    const skm_rec rec = rbuf[it & 511u];
-                    const uint32_t c = it >> 9, sft = 8u * c;                   // the item's first k-mer starts 4c bases in
+                if (i0 + lane < NI) {
+                    const uint32_t it = items[i0 + lane];
+                    const skm_rec rec = rbuf[it & 63u];
+                    const uint32_t c = it >> 6, sft = 8u * c;                   // the item's first k-mer starts 4c bases in
                     const uint32_t nk = skm_rec_n(rec) - 4u * c;                // k-mers left in the record (>= 1)
                     uint64_t X = rec.x, Y = rec.y & ~((1ull << 28) - 1ull);
                     if (sft) { X = (X << sft) | (Y >> (64u - sft)); Y <<= sft; }
@@ -625,10 +631,13 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                         rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fw & 3u)) << top);
                     }
                 }
-                skm_count_insert4n(tk0, tc0, dummy_k, dummy_c, mask, k4, overflow);
+                if (ablate != 3) skm_count_insert4n(tk0, tc0, dummy_k, dummy_c, mask, k4, overflow);
+                else if ((k4[0] ^ k4[1] ^ k4[2] ^ k4[3]) == 0x1234567ull) tk[0] = k4[0];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ds_add_u32 of the asm blocks are invisible to hipcc's waitcnt pass
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
+            __builtin_amdgcn_wave_barrier();
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ds_add_u32 of the asm blocks are invisible to hipcc's waitcnt pass
         __syncthreads();
         // compaction: each wave walks 64-slot chunks (lane = slot: conflict-free), keeps them in registers, reserves its
         // output range with ONE LDS atomic
@@ -771,7 +780,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         MF_TRY(skm_set_lds(k_skm_count<K>, lds));
         const unsigned grid = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 2);
         mf_ktimer t(ctx, "k_skm_count");
-        k_skm_count<K><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, np, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2]);
+        k_skm_count<K><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, np, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2], (int)ctx->opt_ablate);
     }
     MF_DBG(ctx, "k_skm_count");
     mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));

@@ -11,7 +11,7 @@ bases = torch.zeros(n_reads * rl + 64, dtype=torch.uint8, device="cuda")
 offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 ctx.synth_reads_device(0x4D45544146415354, 0, 0, n_reads, rl, 1_000_000, bases.data_ptr(), offsets.data_ptr())
-for ab in (0, 3, 5, 0):
+for ab in (0, 3, 4, 0):
     ctx.set_option("ablate", ab)
     ctx.reset_timers()
     try:
@@ -20,4 +20,4 @@ for ab in (0, 3, 5, 0):
     except Exception as e:
         print("ablate", ab, "error (expected for 1/2):", str(e)[:80])
     rep = ctx.kernel_report()
-    print("ablate", ab, {k: round(v[2], 2) for k, v in rep.items() if k in ("k_l1_hist", "k_l1_scatter", "k_split", "k_count")}, flush=True)
+    print("ablate", ab, {k: round(v[2], 2) for k, v in rep.items() if k.startswith("k_skm") or k in ("k_l1_hist", "k_l1_scatter", "k_split", "k_count")}, flush=True)
