@@ -29,13 +29,15 @@ __global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ ke
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint64_t x = keys[v];
     uint32_t out[8];
+    uint32_t m_nf = 0, m_nl = 0;
+    if (ix.skm_k) mf_skm_nbr_mins(x, k, &m_nf, &m_nl);
 #pragma unroll
     for (uint32_t nuc = 0; nuc < 4; nuc++) {
         uint32_t idx, val;
         uint64_t y = ((x << 2) | nuc) & kmask;
-        out[2 * nuc] = mf_index_find(ix, mf_canon(y, k), &idx, &val) ? idx : CC_NONE;
+        out[2 * nuc] = mf_index_find_ph(ix, mf_canon(y, k), ix.skm_k ? mf_skm_ph_right(y, m_nf) : 0u, &idx, &val) ? idx : CC_NONE;
         y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2));
-        out[2 * nuc + 1] = mf_index_find(ix, mf_canon(y, k), &idx, &val) ? idx : CC_NONE;
+        out[2 * nuc + 1] = mf_index_find_ph(ix, mf_canon(y, k), ix.skm_k ? mf_skm_ph_left(y, k, m_nl) : 0u, &idx, &val) ? idx : CC_NONE;
     }
     uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
     o[0] = make_uint4(out[0], out[1], out[2], out[3]);

@@ -280,13 +280,42 @@ __device__ __forceinline__ uint32_t mf_skm_ph(uint64_t key, int k) {
     }
     return mf_remix32(best);
 }
+// The 8 graph neighbours of x share all but one of its M-mers, so their minimizers need ONE pass over x, not eight:
+// smallest M-mer hash of x without its first M-mer (right neighbours drop it) and without its last (left neighbours).
+__device__ __forceinline__ void mf_skm_nbr_mins(uint64_t x, int k, uint32_t *no_first, uint32_t *no_last) {
+    const uint32_t mm = (1u << (2 * MF_SKM_M)) - 1u;
+    uint32_t f = (uint32_t)(x >> (2 * (k - MF_SKM_M))) & mm, r = mf_mmer_rc(f);
+    uint32_t h = mf_mmer_hash(f < r ? f : r);
+    uint32_t a = 0xFFFFFFFFu, b = h;
+    for (int j = k - MF_SKM_M - 1; j >= 0; j--) {
+        const uint32_t c = (uint32_t)(x >> (2 * j)) & 3u;
+        f = ((f << 2) | c) & mm;
+        r = (r >> 2) | ((3u - c) << (2 * MF_SKM_M - 2));
+        h = mf_mmer_hash(f < r ? f : r);
+        a = h < a ? h : a;
+        if (j > 0) b = h < b ? h : b;
+    }
+    *no_first = a; *no_last = b;
+}
+// partition hash of the neighbour y = x[1..]+c (right) / c+x[..k-2] (left) from the matching minimum of x
+__device__ __forceinline__ uint32_t mf_skm_ph_right(uint64_t y, uint32_t no_first_of_x) {
+    const uint32_t f = (uint32_t)y & ((1u << (2 * MF_SKM_M)) - 1u), r = mf_mmer_rc(f);
+    const uint32_t h = mf_mmer_hash(f < r ? f : r);
+    return mf_remix32(h < no_first_of_x ? h : no_first_of_x);
+}
+__device__ __forceinline__ uint32_t mf_skm_ph_left(uint64_t y, int k, uint32_t no_last_of_x) {
+    const uint32_t f = (uint32_t)(y >> (2 * (k - MF_SKM_M))) & ((1u << (2 * MF_SKM_M)) - 1u), r = mf_mmer_rc(f);
+    const uint32_t h = mf_mmer_hash(f < r ? f : r);
+    return mf_remix32(h < no_last_of_x ? h : no_last_of_x);
+}
 struct mf_slot { uint64_t key; uint32_t idx; uint32_t val; };
-__device__ __forceinline__ bool mf_index_find(const mf_index_view &ix, uint64_t key, uint32_t *idx, uint32_t *val) {
+// ph: the key's partition hash if the caller has it already (minimizer partitions only), see mf_index_find
+__device__ __forceinline__ bool mf_index_find_ph(const mf_index_view &ix, uint64_t key, uint32_t ph, uint32_t *idx, uint32_t *val) {
     const mf_slot *__restrict__ slots = reinterpret_cast<const mf_slot *>(ix.slots);
     uint64_t base = 0, rmask = ix.mask, s;
     if (ix.part_bits) {
         const uint64_t h = mf_phash(key);
-        const uint64_t part = ix.skm_k ? (uint64_t)(mf_skm_ph(key, (int)ix.skm_k) >> (32 - ix.part_bits)) : (h >> (64 - ix.part_bits));
+        const uint64_t part = ix.skm_k ? (uint64_t)(ph >> (32 - ix.part_bits)) : (h >> (64 - ix.part_bits));
         const uint64_t d = ix.dir[part];
         base = d >> 6;
         rmask = (1ull << (d & 63ull)) - 1;
@@ -298,6 +327,9 @@ __device__ __forceinline__ bool mf_index_find(const mf_index_view &ix, uint64_t 
         if (raw.x == MF_EMPTY) return false;
         s = (s + 1) & rmask;
     }
+}
+__device__ __forceinline__ bool mf_index_find(const mf_index_view &ix, uint64_t key, uint32_t *idx, uint32_t *val) {
+    return mf_index_find_ph(ix, key, ix.skm_k ? mf_skm_ph(key, (int)ix.skm_k) : 0u, idx, val);
 }
 // =============================================================================================
 // single-block exclusive scan (u32 in -> u64 out); PAD (a power of two) rounds every item up to a multiple of PAD

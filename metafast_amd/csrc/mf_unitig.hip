@@ -46,13 +46,15 @@ __global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
     const uint64_t kmask = (k == 32) ? ~0ull : ((1ull << (2 * k)) - 1);
     const uint64_t x = A.gk[i];
     uint32_t rcode = UT_CODE_NONE, lcode = UT_CODE_NONE, ridx = UT_NONE, lidx = UT_NONE, ror = 0, lor = 0;
+    uint32_t m_nf = 0, m_nl = 0;
+    if (ix.skm_k) mf_skm_nbr_mins(x, k, &m_nf, &m_nl);
 #pragma unroll
     for (uint32_t nuc = 0; nuc < 4; nuc++) {
         uint64_t y = ((x << 2) | nuc) & kmask;                 // ShortKmer.shiftRight
         uint64_t ry = mf_revcomp(y, k);
         uint64_t c = y < ry ? y : ry;
         uint32_t idx, val;
-        if (mf_index_find(ix, c, &idx, &val)) {
+        if (mf_index_find_ph(ix, c, ix.skm_k ? mf_skm_ph_right(y, m_nf) : 0u, &idx, &val)) {
             if (rcode == UT_CODE_NONE) { rcode = nuc; ridx = idx; ror = (c != y); }
             else rcode = UT_CODE_MANY;
         }
@@ -63,7 +65,7 @@ __global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
         uint64_t ry = mf_revcomp(y, k);
         uint64_t c = y < ry ? y : ry;
         uint32_t idx, val;
-        if (mf_index_find(ix, c, &idx, &val)) {
+        if (mf_index_find_ph(ix, c, ix.skm_k ? mf_skm_ph_left(y, k, m_nl) : 0u, &idx, &val)) {
             if (lcode == UT_CODE_NONE) { lcode = nuc; lidx = idx; lor = (c != y); }
             else lcode = UT_CODE_MANY;
         }
