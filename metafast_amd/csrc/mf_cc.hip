@@ -154,6 +154,28 @@ __global__ void k_features(mf_index_view ix, const uint32_t *__restrict__ comp_o
     }
 }
 
+// ---- features, the other way round: one thread per COMPONENT k-mer, looked up in the sample's index (the component
+// lists are a few percent of a sample's table: 3e7 probes instead of 3.6e8, and no index over the components).  The
+// k-mers of a component are contiguous, so a wave mostly adds to ONE component: wave-level sum, one atomic. ----
+__global__ void k_features_rev(mf_index_view ix, const uint64_t *__restrict__ ckeys, const uint32_t *__restrict__ comp_of, uint64_t nk,
+                               int threshold, unsigned long long *__restrict__ vec, unsigned int *__restrict__ found) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t comp = 0xFFFFFFFFu, val = 0, hit = 0;
+    if (j < nk) {
+        uint32_t idx, v;
+        comp = comp_of[j];
+        if (mf_index_find(ix, ckeys[j], &idx, &v) && (int)v > threshold) { val = v; hit = 1; }
+    }
+    const uint32_t first = __shfl(comp, 0, 64);
+    if (__ballot(comp != first) == 0ull) {
+        for (int d = 32; d >= 1; d >>= 1) { val += __shfl_down(val, d, 64); hit += __shfl_down(hit, d, 64); }
+        if (mf_lane() == 0 && hit) { atomicAdd(&vec[first], (unsigned long long)val); atomicAdd(&found[first], hit); }
+    } else if (hit) {
+        atomicAdd(&vec[comp], (unsigned long long)val);
+        atomicAdd(&found[comp], 1u);
+    }
+}
+
 static inline unsigned cgrid(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 // builds d_kmers / d_comp / index from the host vectors of a finished mf_comps (mf_comps_load path)
@@ -173,8 +195,6 @@ static int comps_upload(mf_comps *C) {
         MF_HIP(hipMemcpyAsync(C->d_comp, comp.data(), nk * 4, hipMemcpyHostToDevice, ctx->stream));
         MF_HIP(hipStreamSynchronize(ctx->stream));
     }
-    MF_TRY(mf_index_build(ctx, C->d_kmers, nullptr, nk, &C->index, &C->index_bytes));
-    MF_HIP(hipStreamSynchronize(ctx->stream));
     C->host_ready = true;
     return MF_OK;
 }
@@ -312,7 +332,6 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             k_cc_remap<<<cgrid(total_k), 256, 0, st>>>(C->d_comp, total_k, d_rank.p);
             if (hipStreamSynchronize(st) != hipSuccess) { rc = mf_set_error("components: remap failed"); break; }
         }
-        if ((rc = mf_index_build(ctx, C->d_kmers, nullptr, total_k, &C->index, &C->index_bytes)) < 0) break;
     } while (0);
     if (rc < 0) { mf_comps_destroy(C); return rc; }
     *out = C;
@@ -368,11 +387,19 @@ extern "C" int mf_features_device(mf_ctx *ctx, mf_comps *c, const mf_table *samp
     MF_TRY(dvec.alloc(ctx, nc)); MF_TRY(dfound.alloc(ctx, nc));
     MF_HIP(hipMemsetAsync(dvec.p, 0, nc * 8, st));
     MF_HIP(hipMemsetAsync(dfound.p, 0, nc * 4, st));
-    if (sample->n) {
-        unsigned grid = (unsigned)std::min<uint64_t>((sample->n + 255) / 256, 65536);
-        mf_ktimer tm(ctx, "k_features");
-        k_features<<<grid, 256, 0, st>>>(mf_view(c->index), c->d_comp, sample->d_keys,
-                                         sample->d_counts, sample->n, threshold, dvec.p, dfound.p);
+    if (sample->n && c->n_kmers) {
+        // probe whichever side has an index already or is cheaper to index: the sample's table (built for the unitigs) ...
+        if (sample->index.slots || c->n_kmers < sample->n) {
+            MF_TRY(mf_table_ensure_index(const_cast<mf_table *>(sample)));
+            mf_ktimer tm(ctx, "k_features");
+            k_features_rev<<<cgrid(c->n_kmers), 256, 0, st>>>(mf_view(sample->index), c->d_kmers, c->d_comp, c->n_kmers, threshold, dvec.p, dfound.p);
+        } else {          // ... or the components
+            if (!c->index.slots) MF_TRY(mf_index_build(ctx, c->d_kmers, nullptr, c->n_kmers, &c->index, &c->index_bytes));
+            unsigned grid = (unsigned)std::min<uint64_t>((sample->n + 255) / 256, 65536);
+            mf_ktimer tm(ctx, "k_features");
+            k_features<<<grid, 256, 0, st>>>(mf_view(c->index), c->d_comp, sample->d_keys,
+                                             sample->d_counts, sample->n, threshold, dvec.p, dfound.p);
+        }
     }
     std::vector<unsigned int> hf(nc);
     MF_HIP(hipMemcpyAsync(vec, dvec.p, nc * 8, hipMemcpyDeviceToHost, st));

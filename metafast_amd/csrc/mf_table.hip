@@ -69,15 +69,15 @@ __global__ void k_index_lookup(mf_index_view ix, const uint64_t *__restrict__ ke
 // ---- partitioned index build: the dense table comes out of the counting pass grouped by partition, so every partition's
 // region can be built in LDS (LDS CAS) and written out as one contiguous block: a streaming pass, no HBM atomics, no random
 // HBM accesses (the generic build below costs one random CAS + one random store per key: 40 ms for 3.6e8 keys).
-// Regions are sized per partition (minimizer partitions differ a lot in size): power of two >= 1.5 x its keys. ----
+// Regions are sized per partition (minimizer partitions differ a lot in size): power of two > 2 x its keys. ----
 #define MF_IDX_WAVE_SLOTS 1024      // regions up to this size are built by one wave, larger ones by a whole workgroup
 __global__ void k_index_region_sizes(const uint64_t *__restrict__ part_off, uint32_t np, uint32_t *__restrict__ sz,
                                      uint32_t *__restrict__ biglist, unsigned int *__restrict__ n_big) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= np) return;
     uint64_t c = part_off[p + 1] - part_off[p];
-    if (c > 5461) { atomicAdd(n_big + 2, 1u); c = 5461; }       // region would not fit in LDS: the caller builds the generic index
-    const uint64_t want = c + c / 2 + 1;
+    if (c > 4095) { atomicAdd(n_big + 2, 1u); c = 4095; }       // region would not fit in LDS: the caller builds the generic index
+    const uint64_t want = 2 * c + 1;        // load <= 0.5: most probes are for absent neighbours, and a miss walks to the end of its cluster
     uint32_t S = 2;
     while (S < want) S <<= 1;
     sz[p] = S;
@@ -221,8 +221,8 @@ extern "C" void mf_table_destroy(mf_table *t) {
     if (!t) return;
     if (t->owns_arrays && t->d_keys) mf_release(t->ctx, t->d_keys, t->keys_bytes);
     if (t->owns_arrays && t->d_counts) mf_release(t->ctx, t->d_counts, t->counts_bytes);
-    if (t->index.slots) mf_release(t->ctx, t->index.slots, t->index_bytes);
-    if (t->index.dir) mf_release(t->ctx, t->index.dir, t->index.dir_bytes);
+    if (t->owns_arrays && t->index.slots) mf_release(t->ctx, t->index.slots, t->index_bytes);       // (an alias borrows the index too)
+    if (t->owns_arrays && t->index.dir) mf_release(t->ctx, t->index.dir, t->index.dir_bytes);
     if (t->owns_arrays && t->d_part_off) mf_release(t->ctx, t->d_part_off, t->part_off_bytes);
     delete t;
 }
@@ -384,8 +384,12 @@ int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out) {
         MF_HIP(hipMemcpyAsync(&m, tot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         MF_HIP(hipStreamSynchronize(ctx->stream));
         if (m == n) {
+            // nothing to filter: an alias that borrows the arrays AND the index of t (built here on t, so that later users
+            // of t -- the features step -- find it instead of building their own)
+            MF_TRY(mf_table_ensure_index(const_cast<mf_table *>(t)));
             MF_TRY(mf_table_adopt(ctx, t->k, t->n, 0, t->d_keys, t->keys_bytes, t->d_counts, t->counts_bytes, out));
             (*out)->owns_arrays = false;
+            (*out)->index = t->index; (*out)->index_bytes = t->index_bytes;
             (*out)->part_bits = t->part_bits; (*out)->part_skm = t->part_skm; (*out)->d_part_off = t->d_part_off; (*out)->part_off_bytes = t->part_off_bytes;
             return MF_OK;
         }
