@@ -2,7 +2,7 @@
 """bench.py -- k-mers/s counted + graphed at k=31 on synthetic 150 bp reads (BASELINE.json metric).
 
 A step = one pass of the hot path over one synthetic sample that is already resident in HBM:
-  count (mask -> LDS-staged radix partition -> LDS hash-count) -> unitigs -> [all-gather unitigs] ->
+  count (mask -> super-k-mer records -> LDS-staged radix partition -> LDS hash-count) -> unitigs -> [all-gather unitigs] ->
   cutter table -> connected components -> features -> [all-gather vectors] -> Bray-Curtis.
 One process per GPU, one sample (100 M reads) per GPU (weak scaling).  Rank 0 prints ONE JSON line.
 
@@ -43,7 +43,14 @@ TRAFFIC = {}
 def algorithmic_bytes(kernel, s):
     """Algorithmic HBM bytes of ONE full pass of `kernel` over the sample."""
     occ, dist_, good, nb = s["n_occ"], s["n_distinct"], s["n_good"], s["n_bases"]
+    rec = s.get("n_records", 0) * s.get("record_bytes", 0)      # bytes of the records the counting pass partitioned
     return {
+        # super-k-mer path (k >= 20): 16-byte records of about 7 k-mers each
+        "k_skm_hist": nb + nb / 8,                      # ASCII bases + valid-start bitmap
+        "k_skm_scatter": nb + nb / 8 + rec,             # + every record written once
+        "k_skm_split": 3 * rec,                         # histogram read + scatter read + write
+        "k_skm_count": rec + 10 * dist_,                # records read + (8 B key + 2 B count) per distinct k-mer
+        # one-record-per-k-mer path (k < 20, option skm=0)
         "k_mask": nb / 8 * 2 + s["n_reads"] * 8,
         "k_l1_hist": nb + nb / 8,                       # ASCII bases + valid-start bitmap
         "k_l1_scatter": nb + nb / 8 + 8 * occ,          # + one 8-byte k-mer written per occurrence
@@ -105,8 +112,10 @@ def main():
     def step(timings=None):
         r = P.run_sample(ctx, bases, offsets, n_reads, n_bases, k=k, b=1, l=100, b1=args.b1, b2=args.b2, device=device,
                          timings=timings)
+        nrec, rbytes = r["table"].records()
         stats = dict(n_occ=r["n_occ"], n_distinct=len(r["table"]), n_good=len(r["good"]), n_unitigs=len(r["seqs"]),
-                     n_cutter=len(r["cutter"]), n_components=len(r["comps"]), n_reads=n_reads, n_bases=n_bases)
+                     n_cutter=len(r["cutter"]), n_components=len(r["comps"]), n_reads=n_reads, n_bases=n_bases,
+                     n_records=nrec, record_bytes=rbytes)
         for key in ("table", "good", "seqs", "cutter", "comps"):
             r[key].close()
         return stats, r["matrix"]
@@ -181,7 +190,7 @@ def main():
                                    f"count+unitigs+components+features (b=1 l=100 b1={args.b1} b2={args.b2})",
                        "reads_per_gpu": n_reads, "read_len": rl, "k": k, "genome_scale_bp": args.genome_scale},
             "roofline": roof(dom),
-            "roofline_hash_count": roof("k_count"),
+            "roofline_hash_count": roof("k_skm_count" if "k_skm_count" in kern else "k_count"),
             "cpu_baseline": cpu,
             "stats": stats,
             "stage_ms_per_step": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in stage_t.items()},

@@ -86,6 +86,10 @@ void mf_table_destroy(mf_table *t);
 int mf_table_stats(const mf_table *t, uint64_t *n_distinct, uint64_t *n_total);
 /* k-mer occurrences fed into the table by the call that built it (N_occ) */
 int mf_table_occurrences(const mf_table *t, uint64_t *n_occ);
+/* Records the counting pass moved through its radix partitions to build this table: super-k-mer records of 16 bytes
+ * (padding included) on the default path for k >= 20, else one 8-byte record per k-mer occurrence; 0 for tables that
+ * were loaded or filtered.  Measurement only (bench.py prices the kernels' algorithmic bytes with it). */
+int mf_table_records(const mf_table *t, uint64_t *n_records, int *record_bytes);
 /* Copies entries with count > threshold to host arrays in ASCENDING KEY order (the reference's
  * iteration order is thread-count dependent, BigLong2ShortHashMap.java:216-253, so callers must
  * not rely on it).  Call with cap=0 to get *n only. */

@@ -755,6 +755,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     MF_HIP(hipGetLastError());
     size_t kb = dk.bytes(), cb = dc.bytes();
     MF_TRY(mf_table_adopt(ctx, k, n_dist, n_occ, dk.take(), kb, dc.take(), cb, out));
+    (*out)->n_records = cap; (*out)->record_bytes = 8;
     if (total_bits > 0 && total_bits <= 30) {          // keep the partition structure (see mf_table_ensure_index)
         (*out)->part_bits = total_bits;
         (*out)->part_off_bytes = doff.bytes();

@@ -810,6 +810,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     MF_HIP(hipGetLastError());
     const size_t kb = dk.bytes(), cb = dc.bytes();
     MF_TRY(mf_table_adopt(ctx, K, n_dist, n_occ, dk.take(), kb, dc.take(), cb, out));
+    (*out)->n_records = cap; (*out)->record_bytes = 16;
     if (total_bits > 0 && total_bits <= 30) {
         (*out)->part_bits = total_bits;
         (*out)->part_skm = 1;

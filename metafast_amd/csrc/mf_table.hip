@@ -300,6 +300,12 @@ extern "C" int mf_table_stats(const mf_table *t, uint64_t *n_distinct, uint64_t 
     if (n_total) MF_TRY(mf_sum_counts(t->ctx, t->d_counts, t->n, n_total));
     return MF_OK;
 }
+extern "C" int mf_table_records(const mf_table *t, uint64_t *n_records, int *record_bytes) {
+    if (!t) return mf_set_error("table is NULL");
+    if (n_records) *n_records = t->n_records;
+    if (record_bytes) *record_bytes = t->record_bytes;
+    return MF_OK;
+}
 extern "C" int mf_table_occurrences(const mf_table *t, uint64_t *n_occ) {
     if (!t || !n_occ) return mf_set_error("NULL argument");
     *n_occ = t->n_occ;

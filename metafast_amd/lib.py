@@ -36,6 +36,7 @@ _SIGS = {
     "mf_table_destroy": (None, [vp]),
     "mf_table_stats": (i32, [vp, pu64, pu64]),
     "mf_table_occurrences": (i32, [vp, pu64]),
+    "mf_table_records": (i32, [vp, pu64, C.POINTER(i32)]),
     "mf_table_export": (i32, [vp, i32, vp, vp, u64, pu64]),
     "mf_table_device_view": (i32, [vp, pvp, pvp, pu64]),
     "mf_table_lookup": (i32, [vp, vp, u64, vp]),
@@ -250,6 +251,12 @@ class Table:
         a = C.c_uint64()
         _check(lib().mf_table_occurrences(self.h, C.byref(a)))
         return a.value
+
+    def records(self):
+        """-> (records the counting pass partitioned, bytes per record); measurement only"""
+        a, b = C.c_uint64(), C.c_int32()
+        _check(lib().mf_table_records(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def export(self, threshold=-1):
         """-> (keys uint64[n] ascending, counts uint16[n]) with count > threshold"""

@@ -23,7 +23,7 @@ def _check(ctx, oracle, bases, off, k, min_len=0, thr=-1):
 
 
 def _reset(ctx):
-    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0)):
+    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1)):
         ctx.set_option(name, v)
 
 
@@ -136,3 +136,60 @@ def test_synth_generator_matches_host(gpu_ctx):
     hb, ho = L.synth_reads_host(0x4D45544146415354, 3, 1000, n, rl, 20000)
     assert np.array_equal(tb[: n * rl].cpu().numpy(), hb)
     assert np.array_equal(to.cpu().numpy().astype(np.uint64), ho)
+
+
+# ---- super-k-mer path (default for k >= 20) against the one-record-per-k-mer path and the oracle ----
+@pytest.mark.parametrize("k", list(range(20, 32)))
+def test_skm_every_k(gpu_ctx, oracle, k):
+    """every k the super-k-mer path is compiled for: same table from both paths, equal to the oracle"""
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(500 + k)
+    b1, o1 = genome_reads(rng, 30000, 3000, 150, err=0.01)
+    b2, o2 = random_reads(rng, 1500, 0, 120)                 # ragged: empty reads, reads shorter than k
+    b = np.concatenate([b1, b2]); o = np.concatenate([o1, o2[1:] + o1[-1]])
+    try:
+        for target in (3072, 64):                            # one and two partition levels
+            gpu_ctx.set_option("part_target", target)
+            gpu_ctx.set_option("skm", 1)
+            t = _check(gpu_ctx, oracle, b, o, k)
+            assert t.records()[1] == 16
+            gpu_ctx.set_option("skm", 0)
+            t = _check(gpu_ctx, oracle, b, o, k)
+            assert t.records()[1] == 8
+    finally:
+        _reset(gpu_ctx)
+
+
+@pytest.mark.parametrize("k", [20, 27, 31])
+def test_skm_low_complexity(gpu_ctx, oracle, k):
+    """runs longer than a record holds (homopolymers, short tandem repeats: ONE minimizer for the whole read) are cut"""
+    _reset(gpu_ctx)
+    reads = ["A" * 500, "AC" * 200, "ACG" * 150, "T" * 33, "ACGTTGCA" * 40, "G" * 64 + "ACGTACGTTTGACCA" * 9, "C" * (k - 1), "C" * k]
+    b, o = pack_reads(reads)
+    t = _check(gpu_ctx, oracle, b, o, k)
+    _check(gpu_ctx, oracle, b, o, k, min_len=100)
+    assert t.records()[1] == 16
+
+
+def test_skm_lookup_filter_two_levels(gpu_ctx, oracle):
+    """index over minimizer partitions (per-partition regions): present / absent keys, before and after a filter"""
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(77)
+    b, o = genome_reads(rng, 200_000, 40_000, 150, err=0.004)
+    gpu_ctx.set_option("part_target", 128)
+    try:
+        t = gpu_count(gpu_ctx, b, o, 31)
+        keys, cnts = t.export()
+        absent = rng.integers(0, 2 ** 62, size=2000, dtype=np.uint64)
+        probe = np.concatenate([keys[::7], absent])
+        ot = oracle.Table().count_buffer(b, o, 31)
+        want = np.array([ot.get(int(x)) for x in probe], dtype=np.int32)
+        assert np.array_equal(t.lookup(probe), want)
+        f = t.filter(1)
+        fk, fc = f.export()
+        m = cnts > 1
+        assert np.array_equal(fk, keys[m]) and np.array_equal(fc, cnts[m])
+        want_f = np.where(want > 1, want, -1)
+        assert np.array_equal(f.lookup(probe), want_f)
+    finally:
+        _reset(gpu_ctx)
