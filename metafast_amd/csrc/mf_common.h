@@ -221,14 +221,17 @@ __device__ __forceinline__ int mf_lane() { return (int)(threadIdx.x & 63); }
 
 // exclusive prefix sum of v over the wave; *total = wave sum
 __device__ __forceinline__ uint32_t mf_wave_excl_scan(uint32_t v, uint32_t *total) {
-    uint32_t x = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t y = __shfl_up(x, d, 64);
-        if (mf_lane() >= d) x += y;
-    }
-    *total = __shfl(x, 63, 64);
-    return x - v;
+    // inclusive scan with DPP (row shifts inside the 16-lane rows, then the row totals broadcast to the following rows):
+    // six VALU instructions, no LDS round trips (the __shfl_up version is seven dependent ds_bpermute, ~100 cycles each)
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2 and 3
+    *total = (uint32_t)__builtin_amdgcn_readlane(x, 63);
+    return (uint32_t)x - v;
 }
 
 // Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024).

@@ -504,7 +504,7 @@ __device__ __forceinline__ void skm_count_insert(uint32_t tk0, uint32_t tc0, uin
 // four-wide until the last of the wave's 256 keys is placed costs 3.3 four-wide iterations on average, most of them LDS
 // instructions on dummy slots.
 __device__ __forceinline__ void skm_count_insert4n(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
-                                                   const uint64_t (&key)[4], unsigned int *overflow) {
+                                                   const uint64_t (&key)[4], unsigned int *overflow, int ablate = 0) {
     uint32_t s[4]; bool pend[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = skm_slot(key[b]) & mask; }
@@ -532,7 +532,7 @@ __device__ __forceinline__ void skm_count_insert4n(uint32_t tk0, uint32_t tc0, u
     }
     for (;;) {
         const bool any = pend[0] | pend[1] | pend[2] | pend[3];
-        if (__ballot(any) == 0ull) break;
+        if (__ballot(any) == 0ull || ablate == 5) break;
         // this lane's first unsettled key
         const uint64_t k1[1] = {pend[0] ? key[0] : pend[1] ? key[1] : pend[2] ? key[2] : key[3]};
         uint32_t s1 = pend[0] ? s[0] : pend[1] ? s[1] : pend[2] ? s[2] : s[3];
@@ -592,11 +592,12 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
     if (p >= np) return;
     uint64_t start = pstart[p];
     uint32_t len = plen[p];
+    uint64_t o = toff[p]; uint32_t room = (uint32_t)(toff[p + 1] - o);         // this partition's slice of the output lists
     skm_rec R = mine < len ? recs[start + mine] : SENT;                        // first round, prefetched
     for (;;) {
         const uint32_t pn = p + gridDim.x;
-        uint64_t start_n = 0; uint32_t len_n = 0;
-        if (pn < np) { start_n = pstart[pn]; len_n = plen[pn]; }
+        uint64_t start_n = 0, o_n = 0; uint32_t len_n = 0, room_n = 0;
+        if (pn < np) { start_n = pstart[pn]; len_n = plen[pn]; o_n = toff[pn]; room_n = (uint32_t)(toff[pn + 1] - o_n); }   // (no load latency inside the compaction)
         for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
         if (threadIdx.x == 0) out_cursor = 0;
         skm_rec cur = R;
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                         rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fw & 3u)) << top);
                     }
                 }
-                if (ablate != 3) skm_count_insert4n(tk0, tc0, dummy_k, dummy_c, mask, k4, overflow);
+                if (ablate != 3) skm_count_insert4n(tk0, tc0, dummy_k, dummy_c, mask, k4, overflow, ablate);
                 else if ((k4[0] ^ k4[1] ^ k4[2] ^ k4[3]) == 0x1234567ull) tk[0] = k4[0];
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
@@ -649,6 +650,7 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
             for (int i = 0; i < NCH; i++) {
                 const uint32_t sl = ((threadIdx.x >> 6) << 6) + (uint32_t)i * SKM_CT + (uint32_t)mf_lane();
                 ck[i] = tk[sl]; cv[i] = tc[sl];
+                if (ablate == 6 && i > 0) ck[i] = MF_EMPTY;
                 const unsigned long long bal = __ballot(ck[i] != MF_EMPTY);
                 pre[i] = total + (uint32_t)__popcll(bal & lt_mask);
                 total += (uint32_t)__popcll(bal);
@@ -656,8 +658,6 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
             uint32_t wb = 0;
             if (mf_lane() == 0 && total) wb = atomicAdd(&out_cursor, total);
             wb = __shfl(wb, 0, 64);
-            const uint64_t o = toff[p];
-            const uint32_t room = (uint32_t)(toff[p + 1] - o);
             if (mf_lane() == 0 && wb + total > room) atomicExch(overflow, 1u);      // (only if a partition's k-mer count wrapped)
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
         __syncthreads();
         if (threadIdx.x == 0) dcount[p] = out_cursor;
         if (pn >= np) break;
-        p = pn; start = start_n; len = len_n;
+        p = pn; start = start_n; len = len_n; o = o_n; room = room_n;
     }
 }
 
