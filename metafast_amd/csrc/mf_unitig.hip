@@ -34,7 +34,8 @@ struct ut_arrays {
     const uint64_t *gk; const uint16_t *gv; uint64_t n; int k;
     uint8_t *info; uint32_t *ridx; uint32_t *lidx;
     uint8_t *pal;             // even k only: 1 if the k-mer equals its reverse complement (else nullptr)
-    uint32_t *succ;           // per node: next node on the path or UT_NONE
+    uint64_t *node;           // per oriented node: successor on its path (low 32 bits, UT_NONE = none) | count << 32 |
+                              // last base of the oriented k-mer << 48: everything a walk needs per hop in ONE 8-byte load
     uint32_t *starts;         // compacted list of start nodes
     unsigned int *n_starts;
 };
@@ -111,7 +112,11 @@ __global__ __launch_bounds__(1024) void k_ut_links(ut_arrays A) {
             }
             is_start = !has_in;
         }
-        A.succ[f] = succ;
+        {   // (the walks used to read succ[], keys[] and counts[]: three random lines per hop)
+            const uint64_t x = A.gk[i];
+            const uint32_t last = o ? 3u - (uint32_t)((x >> (2 * A.k - 2)) & 3ull) : (uint32_t)(x & 3ull);
+            A.node[f] = (uint64_t)succ | ((uint64_t)A.gv[i] << 32) | ((uint64_t)last << 48);
+        }
     }
     // block-aggregated append of the start nodes: ONE global atomic per 1024-thread workgroup (a per-wave atomic on the
     // single cursor serialises at ~12 ns each and cost 126 ms on 7.2e8 nodes)
@@ -145,7 +150,7 @@ __global__ void k_ut_walk1(ut_arrays A, const ut_item *__restrict__ items, uint3
     if (FIRST) { f = A.starts[t]; slot = t; d = 0; }
     else { ut_item it = items[t]; f = it.node; slot = it.slot; d = it.dist; }
     for (int step = 0; step < chunk; step++) {
-        uint32_t g = A.succ[f];
+        uint32_t g = (uint32_t)A.node[f];
         if (g == UT_NONE) { W.end_node[slot] = f; W.end_dist[slot] = d; return; }
         f = g; d++;
     }
@@ -214,19 +219,34 @@ __global__ void k_ut_walk2(ut_arrays A, const uint32_t *__restrict__ pstart, con
     const uint64_t base = O.off[it.pid];
     const char *NUC = "AGCT";
     uint32_t f = it.node, d = it.dist;
+    if (d == 0) {                                              // the first k-mer in full
+        const uint64_t x = A.gk[f >> 1];
+        const uint64_t y = (f & 1u) ? mf_revcomp(x, k) : x;
+        for (int j = 0; j < k - 1; j++) O.bases[base + j] = (uint8_t)NUC[(y >> (2 * (k - 1 - j))) & 3u];
+    }
+    // one base per hop: collected in a register and written as aligned 8-byte words (a byte store per hop is one
+    // partial-line write per hop)
+    uint64_t acc = 0; uint32_t nacc = 0;
+    auto flush_bytes = [&](uint64_t end_pos) {                  // the nacc bytes ending just before end_pos
+        for (uint32_t j = 0; j < nacc; j++) O.bases[end_pos - nacc + j] = (uint8_t)(acc >> (8 * (8 - nacc + j)));
+        nacc = 0;
+    };
     for (int step = 0; step < chunk; step++) {
-        const uint32_t i = f >> 1, o = f & 1u;
-        const uint64_t x = A.gk[i];
-        const uint64_t y = o ? mf_revcomp(x, k) : x;
-        O.bases[base + d + (uint64_t)(k - 1)] = (uint8_t)NUC[y & 3u];
-        if (d == 0)
-            for (int j = 0; j < k - 1; j++) O.bases[base + j] = (uint8_t)NUC[(y >> (2 * (k - 1 - j))) & 3u];
-        const int32_t v = (int32_t)A.gv[i];
+        const uint64_t e = A.node[f];
+        const uint64_t pos = base + d + (uint64_t)(k - 1);
+        acc = (acc >> 8) | ((uint64_t)(uint8_t)NUC[(e >> 48) & 3u] << 56);
+        nacc++;
+        if ((pos & 7ull) == 7ull) {
+            if (nacc == 8) { *reinterpret_cast<uint64_t *>(O.bases + pos - 7) = acc; nacc = 0; }
+            else flush_bytes(pos + 1);
+        }
+        const int32_t v = (int32_t)((e >> 32) & 0xFFFFull);
         it.sum += (unsigned long long)v;
         it.mn = v < it.mn ? v : it.mn;
         it.mx = v > it.mx ? v : it.mx;
-        const uint32_t g = A.succ[f];
+        const uint32_t g = (uint32_t)e;
         if (g == UT_NONE) {
+            flush_bytes(pos + 1);
             const uint64_t len = O.off[it.pid + 1] - base;
             O.wavg[it.pid] = (int32_t)(it.sum / (len - (uint64_t)k + 1));      // (int)(seqWeight / (len - k + 1)) :120-121
             O.wmin[it.pid] = it.mn; O.wmax[it.pid] = it.mx;
@@ -234,6 +254,7 @@ __global__ void k_ut_walk2(ut_arrays A, const uint32_t *__restrict__ pstart, con
         }
         f = g; d++;
     }
+    flush_bytes(base + d + (uint64_t)(k - 1));
     it.node = f; it.dist = d;
     cont[atomicAdd(n_cont, 1u)] = it;
 }
@@ -271,14 +292,14 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
     int rc = MF_OK;
     do {
         if ((rc = mf_table_ensure_index(g)) < 0) break;
-        mf_buf<uint8_t> info, pal; mf_buf<uint32_t> ridx, lidx, eqmin, succ, starts;
+        mf_buf<uint8_t> info, pal; mf_buf<uint32_t> ridx, lidx, eqmin, starts; mf_buf<uint64_t> succ;
         mf_buf<unsigned int> ctr;
         if ((rc = info.alloc(ctx, n)) < 0 || (rc = ridx.alloc(ctx, n)) < 0 || (rc = lidx.alloc(ctx, n)) < 0 ||
             (rc = succ.alloc(ctx, 2 * n)) < 0 || (rc = starts.alloc(ctx, 2 * n)) < 0 || (rc = ctr.alloc(ctx, 4)) < 0) break;
         hipMemsetAsync(ctr.p, 0, 16, st);
         ut_arrays A;
         A.gk = g->d_keys; A.gv = g->d_counts; A.n = n; A.k = k;
-        A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.succ = succ.p; A.starts = starts.p; A.n_starts = &ctr.p[1];
+        A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.node = succ.p; A.starts = starts.p; A.n_starts = &ctr.p[1];
         A.pal = nullptr;
         if ((k & 1) == 0) { if ((rc = pal.alloc(ctx, n)) < 0) break; A.pal = pal.p; }   // palindromes need an even k
         {
