@@ -234,6 +234,16 @@ __device__ __forceinline__ uint32_t mf_wave_excl_scan(uint32_t v, uint32_t *tota
     return (uint32_t)x - v;
 }
 
+// Reserve `mine` consecutive indices from a global cursor with ONE atomic per wave (an atomic per lane on a single address
+// serialises at ~12 ns each).  EVERY lane of the wave must call it (no early return before it); returns this lane's first index.
+__device__ __forceinline__ uint32_t mf_wave_reserve(unsigned int *counter, uint32_t mine) {
+    uint32_t tot;
+    const uint32_t ex = mf_wave_excl_scan(mine, &tot);
+    uint32_t base = 0;
+    if (mf_lane() == 0 && tot) base = atomicAdd(counter, tot);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)base) + ex;
+}
+
 // Block-wide exclusive scan of one value per thread (blockDim.x multiple of 64, <= 1024).
 // `scratch` must hold 17 uint32 in LDS.  Returns exclusive prefix; *block_total = sum.
 __device__ __forceinline__ uint32_t mf_block_excl_scan(uint32_t v, uint32_t *scratch, uint32_t *block_total) {

@@ -145,17 +145,19 @@ struct ut_walk_out {
 template <bool FIRST>
 __global__ void k_ut_walk1(ut_arrays A, const ut_item *__restrict__ items, uint32_t n_items, ut_walk_out W, int chunk) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_items) return;
-    uint32_t f, slot, d;
-    if (FIRST) { f = A.starts[t]; slot = t; d = 0; }
-    else { ut_item it = items[t]; f = it.node; slot = it.slot; d = it.dist; }
-    for (int step = 0; step < chunk; step++) {
-        uint32_t g = (uint32_t)A.node[f];
-        if (g == UT_NONE) { W.end_node[slot] = f; W.end_dist[slot] = d; return; }
-        f = g; d++;
+    bool going = t < n_items;
+    uint32_t f = 0, slot = 0, d = 0;
+    if (going) {
+        if (FIRST) { f = A.starts[t]; slot = t; d = 0; }
+        else { ut_item it = items[t]; f = it.node; slot = it.slot; d = it.dist; }
+        for (int step = 0; step < chunk; step++) {
+            uint32_t g = (uint32_t)A.node[f];
+            if (g == UT_NONE) { W.end_node[slot] = f; W.end_dist[slot] = d; going = false; break; }
+            f = g; d++;
+        }
     }
-    uint32_t c = atomicAdd(W.n_cont, 1u);
-    W.cont[c].node = f; W.cont[c].slot = slot; W.cont[c].dist = d;
+    const uint32_t c = mf_wave_reserve(W.n_cont, going ? 1u : 0u);       // unfinished walks go on in the next round
+    if (going) { W.cont[c].node = f; W.cont[c].slot = slot; W.cont[c].dist = d; }
 }
 
 // PASS 0: equal-case arbitration (atomicMin of the start node id per start k-mer), count candidates
@@ -171,28 +173,31 @@ template <int PASS>
 __global__ void k_ut_ends(ut_arrays A, ut_paths P, const uint32_t *__restrict__ end_node, const uint32_t *__restrict__ end_dist,
                           uint32_t n_starts, int min_len) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_starts) return;
-    const uint32_t s = A.starts[t], f = end_node[t], dist = end_dist[t];
+    uint32_t take = 0;                 // paths this start emits (0, 1 or 2); the cursor is advanced once per wave
+    uint32_t s = 0; uint64_t len_nt = 0, stc = 0; bool eq = false, twice = false;
+    if (t < n_starts) do {
+    s = A.starts[t];
+    const uint32_t f = end_node[t], dist = end_dist[t];
     uint32_t i = f >> 1, o = f & 1u;
-    uint64_t len_nt = (uint64_t)dist + (uint64_t)A.k;
-    if ((int64_t)len_nt < (int64_t)min_len) return;
+    len_nt = (uint64_t)dist + (uint64_t)A.k;
+    if ((int64_t)len_nt < (int64_t)min_len) break;
     uint8_t info = A.info[i];
     // end k-mer: the walk stops either because R(f) < 0 (cur = f) or because the k-mer beyond f has
     // several left neighbours (cur = that k-mer): processSequence :83-92
     uint64_t endc = A.gk[i];
     if (ut_r_unique(info, o)) endc = A.gk[ut_right_node(A, i, o, info) >> 1];
-    uint64_t stc = A.gk[s >> 1];
-    if (stc > endc) return;
-    bool eq = stc == endc;
+    stc = A.gk[s >> 1];
+    if (stc > endc) break;
+    eq = stc == endc;
     // task.run :50-51 processes {kmerF, kmerF.rc()}: for a palindromic start k-mer these are the same oriented k-mer, so
     // the reference walks the identical path twice and prints it twice unless the equal-case `used` set stops the second
-    bool twice = A.pal && A.pal[s >> 1] && !eq;
-    if (PASS == 0) {
-        if (eq) atomicMin(&P.eqmin[s >> 1], s);
-        atomicAdd(P.cursor, twice ? 2u : 1u);
-    } else {
-        if (eq && P.eqmin[s >> 1] != s) return;            // "print any sequence, but only one of them" :109-118
-        uint32_t pid = atomicAdd(P.cursor, twice ? 2u : 1u);
+    twice = A.pal && A.pal[s >> 1] && !eq;
+    if (PASS == 0) { if (eq) atomicMin(&P.eqmin[s >> 1], s); }
+    else if (eq && P.eqmin[s >> 1] != s) break;            // "print any sequence, but only one of them" :109-118
+    take = twice ? 2u : 1u;
+    } while (0);
+    const uint32_t pid = mf_wave_reserve(P.cursor, take);
+    if (PASS == 1 && take) {
         P.pstart[pid] = s;
         P.plen[pid] = (uint32_t)len_nt;
         P.pkey[pid] = stc * 2ull + (uint64_t)(s & 1u);
@@ -211,9 +216,11 @@ template <bool FIRST>
 __global__ void k_ut_walk2(ut_arrays A, const uint32_t *__restrict__ pstart, const ut_item2 *__restrict__ items, uint32_t n_items,
                            ut_out O, ut_item2 *__restrict__ cont, unsigned int *__restrict__ n_cont, int chunk) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_items) return;
+    bool going = t < n_items;
     ut_item2 it;
-    if (FIRST) { it.node = pstart[t]; it.pid = t; it.dist = 0; it.mn = 0x7FFFFFFF; it.mx = 0; it.sum = 0; it.pad = 0; }
+    it.node = 0; it.pid = 0; it.dist = 0; it.mn = 0x7FFFFFFF; it.mx = 0; it.sum = 0; it.pad = 0;
+    if (going) {
+    if (FIRST) { it.node = pstart[t]; it.pid = t; }
     else it = items[t];
     const int k = A.k;
     const uint64_t base = O.off[it.pid];
@@ -250,13 +257,16 @@ __global__ void k_ut_walk2(ut_arrays A, const uint32_t *__restrict__ pstart, con
             const uint64_t len = O.off[it.pid + 1] - base;
             O.wavg[it.pid] = (int32_t)(it.sum / (len - (uint64_t)k + 1));      // (int)(seqWeight / (len - k + 1)) :120-121
             O.wmin[it.pid] = it.mn; O.wmax[it.pid] = it.mx;
-            return;
+            going = false;
+            break;
         }
         f = g; d++;
     }
-    flush_bytes(base + d + (uint64_t)(k - 1));
+    if (going) flush_bytes(base + d + (uint64_t)(k - 1));
     it.node = f; it.dist = d;
-    cont[atomicAdd(n_cont, 1u)] = it;
+    }
+    const uint32_t c = mf_wave_reserve(n_cont, going ? 1u : 0u);
+    if (going) cont[c] = it;
 }
 __global__ void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
