@@ -1,6 +1,7 @@
 // mf_io.hip -- host side of the C-ABI: readers, writers and the file-level entry points.
 // Plain C++ (no kernels); formats follow SURVEY.md Appendix A, each function cites the reference it replaces.
 #include "mf_common.h"
+#include <zlib.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -276,19 +277,65 @@ static int parse_buffer_parallel(const raw_file &buf, int fmt, const char *path,
     for (auto &p : parts) out_parts.push_back(std::move(p));      // pieces stay separate: they go to the device one by one
     return MF_OK;
 }
-// ReadersUtils.detectFileFormat (itmo!/io/ReadersUtils.java:27-54); compressed / binq inputs are not supported yet
+// .gz inputs (FastaGZReader.java:22-30, FastqGZReader.java:24-32: a GZIPInputStream over the file, which also reads
+// CONCATENATED gzip members): the compressed file is read whole, inflated into one host buffer (zlib; one stream cannot be
+// inflated in parallel) and then parsed by the same parallel parser as a plain file.
+static int inflate_gz(const raw_file &in, raw_file &out, const char *path) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, 15 + 32) != Z_OK) return mf_set_error("zlib: inflateInit2 failed");
+    size_t cap = std::max<size_t>(in.n * 5, (size_t)1 << 20), have = 0, fed = 0;
+    out.p = (char *)malloc(cap);
+    if (!out.p) { inflateEnd(&zs); return mf_set_error("out of host memory inflating '%s'", path); }
+    int ret = Z_OK;
+    for (;;) {
+        if (zs.avail_in == 0 && fed < in.n) {
+            const size_t chunk = std::min<size_t>(in.n - fed, (size_t)1 << 30);
+            zs.next_in = (Bytef *)(in.p + fed); zs.avail_in = (uInt)chunk; fed += chunk;
+        }
+        if (have == cap) {
+            cap *= 2;
+            char *np = (char *)realloc(out.p, cap);
+            if (!np) { inflateEnd(&zs); return mf_set_error("out of host memory inflating '%s'", path); }
+            out.p = np;
+        }
+        const size_t room = std::min<size_t>(cap - have, (size_t)1 << 30);
+        zs.next_out = (Bytef *)(out.p + have); zs.avail_out = (uInt)room;
+        ret = inflate(&zs, Z_NO_FLUSH);
+        have += room - zs.avail_out;
+        if (ret == Z_STREAM_END) {
+            if (zs.avail_in == 0 && fed == in.n) break;          // end of the last member
+            if (inflateReset(&zs) != Z_OK) { ret = Z_DATA_ERROR; break; }      // next member of a concatenated file
+            continue;
+        }
+        if (ret == Z_BUF_ERROR && zs.avail_in == 0 && fed == in.n) { ret = Z_DATA_ERROR; break; }   // truncated stream
+        if (ret != Z_OK && ret != Z_BUF_ERROR) break;
+    }
+    inflateEnd(&zs);
+    if (ret != Z_STREAM_END) return mf_set_error("Not in GZIP format or corrupt stream: '%s'", path);
+    out.n = have;
+    return MF_OK;
+}
+// ReadersUtils.detectFileFormat (itmo!/io/ReadersUtils.java:27-54): ".gz" is stripped first, then the format extension.
+// .bz2 and .binq inputs are not supported by the HIP path yet.
 static int parse_reads_file(const char *path, int threads, std::vector<read_batch> &parts) {
     std::string p(path);
     int fmt = 0;
-    if (ends_with_nocase(p, ".gz") || ends_with_nocase(p, ".bz2") || ends_with_nocase(p, ".binq"))
-        return mf_set_error("compressed / binq input is not supported by the HIP path yet: '%s'", path);
+    bool gz = false;
+    if (ends_with_nocase(p, ".gz")) { gz = true; p.resize(p.size() - 3); }
+    if (ends_with_nocase(p, ".bz2") || ends_with_nocase(p, ".binq"))
+        return mf_set_error("bzip2 / binq input is not supported by the HIP path yet: '%s'", path);
     if (ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq")) fmt = 2;
     else if (ends_with_nocase(p, ".fasta") || ends_with_nocase(p, ".fa") || ends_with_nocase(p, ".fn") || ends_with_nocase(p, ".fna")) fmt = 1;
     if (!fmt) return mf_set_error("Can't detect file format for file '%s'", path);
     raw_file buf;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    MF_TRY(read_file_parallel(path, buf, threads));
+    if (gz) {
+        raw_file packed;
+        MF_TRY(read_file_parallel(path, packed, threads));
+        MF_TRY(inflate_gz(packed, buf, path));
+    } else MF_TRY(read_file_parallel(path, buf, threads));
     const double t1 = now();
     int rc = parse_buffer_parallel(buf, fmt, path, threads, parts);
     if (getenv("MF_IO_TIMING")) fprintf(stderr, "[mf] %s: read %.3f s, parse %.3f s\n", path, t1 - t0, now() - t1);

@@ -50,6 +50,33 @@ def test_count_reads_fasta_and_fastq(gpu_ctx, oracle, ref_files, tmp_path):
     assert len(gk) > 0 and np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
 
 
+def test_gzip_inputs(gpu_ctx, oracle, ref_files, tmp_path):
+    """.fa.gz / .fq.gz (FastaGZReader / FastqGZReader): same table as the plain file; concatenated members are read
+    through like java.util.zip.GZIPInputStream does; the CLI names the library without the .gz"""
+    import gzip
+    plain = open(ref_files[0], "rb").read()
+    one = tmp_path / "a.fa.gz"
+    one.write_bytes(gzip.compress(plain, 6))
+    cut = plain.index(b"\n>", len(plain) // 2) + 1
+    two = tmp_path / "b.fasta.gz"
+    two.write_bytes(gzip.compress(plain[:cut], 1) + gzip.compress(plain[cut:], 9))      # two members
+    ok, ov = oracle.Table().count_files([ref_files[0]], 31).export()
+    for f in (one, two):
+        gk, gc = gpu_ctx.count_reads([str(f)], 31).export()
+        assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+    fq = os.path.join(REF_DATA, "tinytest_A.fastq")
+    fqz = tmp_path / "t.fq.gz"
+    fqz.write_bytes(gzip.compress(open(fq, "rb").read()))
+    gk, gc = gpu_ctx.count_reads([str(fqz)], 5).export()
+    ok5, ov5 = oracle.Table().count_files([fq], 5).export()
+    assert np.array_equal(gk, ok5) and np.array_equal(gc.astype(np.int32), ov5)
+    wd = tmp_path / "w"
+    r = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-t", "kmer-counter-many", "-k", "31", "-i", str(one), "-w", str(wd)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert os.listdir(wd / "kmers") == ["a.kmers.bin"] and os.path.getsize(wd / "kmers" / "a.kmers.bin") == 169180
+
+
 def test_reader_errors(gpu_ctx, tmp_path):
     from metafast_amd.lib import MetafastError
     bad = tmp_path / "reads.txt"
@@ -58,8 +85,12 @@ def test_reader_errors(gpu_ctx, tmp_path):
         gpu_ctx.count_reads([str(bad)], 3)
     gz = tmp_path / "reads.fa.gz"
     gz.write_bytes(b"\x1f\x8b")
-    with pytest.raises(MetafastError, match="not supported"):
+    with pytest.raises(MetafastError, match="GZIP"):              # truncated / corrupt gzip stream
         gpu_ctx.count_reads([str(gz)], 3)
+    bz = tmp_path / "reads.fa.bz2"
+    bz.write_bytes(b"BZh9")
+    with pytest.raises(MetafastError, match="not supported"):
+        gpu_ctx.count_reads([str(bz)], 3)
     x = tmp_path / "x.fa"
     x.write_text(">a\nACGTXACGT\n")
     with pytest.raises(MetafastError, match="Incorrect nucleotide"):
