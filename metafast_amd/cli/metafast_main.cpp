@@ -10,6 +10,7 @@
 // framework itself (in/out.properties, interactive prompts, log4j) is not reproduced.  Errors: message on stderr, exit 1.
 #include <algorithm>
 #include <cerrno>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -109,7 +110,8 @@ static const OptDef OPTS[] = {
     {"min-component-size", "b1", false, false}, {"max-component-size", "b2", false, false}, {"components-file", "cm", false, false},
     {"kmers", "ka", true, false}, {"selected", "", true, false}, {"threshold", "", false, false},
     {"features", "", true, false}, {"without-names", "wn", false, true}, {"matrix-file", "", false, false},
-    {"output-format", "", false, false}, {"heatmap-file", "", false, false},
+    {"output-format", "", false, false}, {"heatmap-file", "", false, false}, {"new-matrix-file", "", false, false},
+    {"without-renumbering", "", false, true},
     {"use-reads-for-calculating-features", "", false, true}, {"device", "", false, false},
 };
 // `ctx_i` says what -i means for the selected tool
@@ -287,6 +289,136 @@ static vector<string> run_features(Env &e, const Args &a, const string &comp_fil
     }
     return vecs;
 }
+// Double.toString (what Java's "%s" prints for a double): shortest digits that round-trip, decimal notation in [1e-3, 1e7)
+static string java_double(double d) {
+    if (std::isnan(d)) return "NaN";
+    if (std::isinf(d)) return d > 0 ? "Infinity" : "-Infinity";
+    if (d == 0) return std::signbit(d) ? "-0.0" : "0.0";
+    char buf[64];
+    for (int prec = 1; prec <= 17; prec++) { snprintf(buf, sizeof buf, "%.*e", prec - 1, d); if (strtod(buf, nullptr) == d) break; }
+    string s(buf);
+    bool neg = s[0] == '-';
+    if (neg) s = s.substr(1);
+    size_t epos = s.find('e');
+    int ex = atoi(s.c_str() + epos + 1);
+    string digits;
+    for (char ch : s.substr(0, epos)) if (ch != '.') digits.push_back(ch);
+    string out;
+    double ad = std::fabs(d);
+    if (ad >= 1e-3 && ad < 1e7) {
+        if (ex >= 0) {
+            string ip = digits.substr(0, std::min<size_t>(digits.size(), (size_t)ex + 1));
+            while ((int)ip.size() < ex + 1) ip.push_back('0');
+            out = ip + "." + (digits.size() > (size_t)ex + 1 ? digits.substr(ex + 1) : string("0"));
+        } else out = "0." + string((size_t)(-ex - 1), '0') + digits;
+    } else out = digits.substr(0, 1) + "." + (digits.size() > 1 ? digits.substr(1) : string("0")) + "E" + std::to_string(ex);
+    return neg ? "-" + out : out;
+}
+// one matrix cell in a Java format string (PrintWriter.printf(format, double), DistanceMatrixCalculatorMain.java:112-116):
+// "%s" -> Double.toString, "%[flags][width][.prec]{f,e,g}" -> printf; anything else is refused
+static string format_cell(const string &fmt, double v) {
+    if (fmt == "%s") return java_double(v);
+    size_t i = 0;
+    bool ok = fmt.size() >= 2 && fmt[0] == '%';
+    for (i = 1; ok && i + 1 < fmt.size(); i++) if (!strchr("0123456789.+- ", fmt[i])) ok = false;
+    if (!ok || !strchr("feg", fmt[fmt.size() - 1])) die("Unsupported --output-format '%s' (use %%s or %%[.N]f / e / g)", fmt.c_str());
+    char buf[128]; snprintf(buf, sizeof buf, fmt.c_str(), v);
+    return buf;
+}
+// DistanceMatrixCalculatorMain.printMatrix (:91-123): perm == nullptr prints the original order
+static void print_matrix(const vector<double> &m, int n, const string &path, const vector<string> *names, const int *perm, const string &fmt) {
+    size_t slash = path.find_last_of('/'); if (slash != string::npos) mkdirs(path.substr(0, slash));
+    FILE *out = fopen(path.c_str(), "w");
+    if (!out) die("Failed to print matrix to %s", path.c_str());
+    if (names) { fprintf(out, "#"); for (int i = 0; i < n; i++) fprintf(out, "\t%s", (*names)[perm ? perm[i] : i].c_str()); fprintf(out, "\n"); }
+    for (int i = 0; i < n; i++) {
+        if (names) fprintf(out, "%s\t", (*names)[perm ? perm[i] : i].c_str());
+        for (int j = 0; j < n; j++) {
+            if (j) fprintf(out, "\t");
+            fprintf(out, "%s", format_cell(fmt, perm ? m[(size_t)perm[i] * n + perm[j]] : m[(size_t)i * n + j]).c_str());
+        }
+        fprintf(out, "\n");
+    }
+    fclose(out);
+}
+// heatmap-maker, the numeric half (src/tools/HeatMapMakerMain.java:93-145): average-linkage clustering of the samples
+// (FullHeatMap.clusterObjects :221-296: O(n^3), the FIRST closest pair in row-major order is merged, the merged node stays
+// at the smaller index with the old node on the left) and the matrix renumbered in the dendrogram's leaf order
+// (renumber :327-337).  The image itself is not rendered.
+struct HNode { int no = -1, left = -1, right = -1; };
+static void hm_group(const vector<HNode> &t, int node, vector<int> &out) {
+    if (node < 0) return;
+    if (t[node].no >= 0) { out.push_back(t[node].no); return; }
+    hm_group(t, t[node].left, out); hm_group(t, t[node].right, out);
+}
+static vector<int> heatmap_order(const vector<double> &m, int n) {
+    vector<HNode> t(n);
+    vector<int> nodes(n);
+    for (int i = 0; i < n; i++) { t[i].no = i; nodes[i] = i; }
+    vector<double> dist((size_t)n * n, 0.0);
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) dist[(size_t)i * n + j] = m[(size_t)i * n + j] / 1 / 1;
+    auto between = [&](const vector<int> &g1, const vector<int> &g2) {
+        if (g1.empty() || g2.empty()) return -1.0;
+        double sum = 0;
+        for (int a : g1) for (int b : g2) sum += m[(size_t)a * n + b];
+        return sum / (double)g1.size() / (double)g2.size();
+    };
+    int count = n, root = n > 0 ? 0 : -1;
+    while (count > 1) {
+        double best = 1.7976931348623157e308; int bi = -1, bj = -1;
+        for (int i = 0; i < n; i++) for (int j = i + 1; j < n; j++)
+            if (nodes[i] >= 0 && nodes[j] >= 0 && dist[(size_t)i * n + j] < best) { best = dist[(size_t)i * n + j]; bi = i; bj = j; }
+        if (bi < 0 || best < 0) die("Internal error. Wrong minDist index.");
+        HNode r; r.left = nodes[bi]; r.right = nodes[bj];
+        t.push_back(r); root = (int)t.size() - 1;
+        nodes[bi] = root; nodes[bj] = -1;
+        vector<int> g1; hm_group(t, root, g1);
+        for (int i = 0; i < n; i++) {
+            dist[(size_t)i * n + bj] = dist[(size_t)bj * n + i] = -1;
+            if (i != bi) { vector<int> g2; hm_group(t, nodes[i], g2); dist[(size_t)i * n + bi] = dist[(size_t)bi * n + i] = between(g1, g2); }
+        }
+        count--;
+    }
+    vector<int> perm;
+    hm_group(t, root, perm);
+    return perm;
+}
+static string run_heatmap_maker(Env &e, const Args &a, const string &matrix_path, const string &new_matrix_tpl) {
+    FILE *fp = fopen(matrix_path.c_str(), "r");
+    if (!fp) die("Can't read matrix file %s", matrix_path.c_str());
+    vector<vector<string>> rows; char *line = nullptr; size_t cap = 0;
+    while (getline(&line, &cap, fp) > 0) {
+        vector<string> cells; string cur;
+        for (char *q = line; *q && *q != '\n' && *q != '\r'; q++) { if (*q == '\t') { if (!cur.empty()) cells.push_back(cur); cur.clear(); } else cur.push_back(*q); }
+        if (!cur.empty()) cells.push_back(cur);
+        rows.push_back(cells);
+    }
+    free(line); fclose(fp);
+    if (rows.empty()) die("No data to read in matrix file %s", matrix_path.c_str());
+    const size_t fn = rows[0].size();
+    if (fn > rows.size()) die("Can't parse matrix, columns' number > rows' number");
+    for (size_t i = 0; i < fn; i++) if (rows[i].size() != fn) die("Can't parse matrix, columns' number is different for different rows");
+    const bool with_names = rows[0][0] == "#";
+    const int n = (int)fn - (with_names ? 1 : 0);
+    vector<string> names;
+    vector<double> m((size_t)n * n);
+    for (int i = 0; i < n; i++) {
+        if (with_names) names.push_back(rows[0][i + 1]);
+        for (int j = 0; j < n; j++) {
+            const string &cell = rows[i + (with_names ? 1 : 0)][j + (with_names ? 1 : 0)];
+            char *end; m[(size_t)i * n + j] = strtod(cell.c_str(), &end);
+            if (*end) die("Can't parse matrix, '%s' is not a number", cell.c_str());
+        }
+    }
+    if (a.get("without-renumbering", "false") == "true") return matrix_path;
+    vector<int> perm = heatmap_order(m, n);
+    string path = new_matrix_tpl.empty() ? remove_ext(matrix_path, {".txt"}) + "_renumbered.txt" : new_matrix_tpl;
+    size_t p = path.find("$DT"); if (p != string::npos) path.replace(p, 3, e.start_ts);
+    print_matrix(m, n, path, with_names ? &names : nullptr, perm.data(), a.get("output-format", "%.4f"));
+    logmsg("INFO", "Renumbered matrix saved to %s", path.c_str());
+    return path;
+}
+
 // dist-matrix-calculator (src/tools/DistanceMatrixCalculatorMain.java:51-123)
 static string run_dist_matrix(Env &e, const Args &a, const vector<string> &features, const string &matrix_path_tpl) {
     if (features.empty()) die("Mandatory option --features is not set");
@@ -307,18 +439,9 @@ static string run_dist_matrix(Env &e, const Args &a, const vector<string> &featu
     check(mf_bray_curtis(flat.data(), ns, (int)nc, m.data()));
     string path = matrix_path_tpl;
     size_t p = path.find("$DT"); if (p != string::npos) path.replace(p, 3, e.start_ts);
-    size_t slash = path.find_last_of('/'); if (slash != string::npos) mkdirs(path.substr(0, slash));
-    FILE *out = fopen(path.c_str(), "w");
-    if (!out) die("Failed to print matrix to %s", path.c_str());
-    bool names = a.get("without-names", "false") != "true";
-    string fmt = a.get("output-format", "%.4f");
-    if (names) { fprintf(out, "#"); for (auto &f : features) fprintf(out, "\t%s", remove_ext(basename_of(f), {"vec"}).c_str()); fprintf(out, "\n"); }
-    for (int i = 0; i < ns; i++) {
-        if (names) fprintf(out, "%s\t", remove_ext(basename_of(features[i]), {"vec"}).c_str());
-        for (int j = 0; j < ns; j++) { if (j) fprintf(out, "\t"); fprintf(out, fmt.c_str(), m[(size_t)i * ns + j]); }
-        fprintf(out, "\n");
-    }
-    fclose(out);
+    vector<string> names;
+    for (auto &f : features) names.push_back(remove_ext(basename_of(f), {"vec"}));
+    print_matrix(m, ns, path, a.get("without-names", "false") != "true" ? &names : nullptr, nullptr, a.get("output-format", "%.4f"));
     logmsg("INFO", "Distance matrix printed to %s", path.c_str());
     return path;
 }
@@ -343,6 +466,7 @@ static const char *TOOLS_TEXT =
     "component-cutter\tBuild graph components from sequences\n"
     "features-calculator\tCalculate features values for input reads/k-mers files\n"
     "dist-matrix-calculator\tCalculate the distance matrix using features values\n"
+    "heatmap-maker\t\tCluster the samples of a distance matrix and renumber it (no image)\n"
     "matrix-builder\t\tBuild the distance matrix for input sequences (default tool)\n";
 
 int main(int argc, char **argv) {
@@ -390,6 +514,9 @@ int main(int argc, char **argv) {
         run_features(e, a, a.get("components-file"), a.list("kmers"), k, a.geti("threshold", 0), wd);
     } else if (tool == "dist-matrix-calculator") {
         run_dist_matrix(e, a, a.list("features"), a.get("matrix-file", wd + "/dist_matrix_$DT_original_order.txt"));
+    } else if (tool == "heatmap-maker") {
+        if (!a.has("matrix-file")) die("Mandatory option --matrix-file is not set");
+        run_heatmap_maker(e, a, a.get("matrix-file"), a.get("new-matrix-file"));
     } else if (tool == "matrix-builder") {
         // DistanceMatrixBuilderMain.java:88-175: steps kmer-counter-many, seq-builder-many, component-cutter, features-calculator,
         // dist-matrix-calculator (+ heatmap-maker: rendering, out of scope)
@@ -438,8 +565,9 @@ int main(int argc, char **argv) {
         if (stop_after(s4)) return 0;
         // 5
         string mpath = run_dist_matrix(e, a, vecs, wd + "/matrices/dist_matrix_$DT_original_order.txt");
-        (void)mpath;
-        logmsg("INFO", "heatmap-maker (dendrogram ordering + image) is outside the HIP hot path: the matrix above keeps the original sample order");
+        // 6: heatmap-maker, numeric half: dendrogram order + renumbered matrix (DistanceMatrixBuilderMain.java:137-145)
+        run_heatmap_maker(e, a, mpath, a.get("matrix-file", wd + "/matrices/dist_matrix_$DT.txt"));
+        logmsg("INFO", "heatmap image (dist_matrix_<date>_heatmap.png) is not rendered by the HIP path");
     } else {
         die("Unknown tool '%s' (use -ts to list the tools of the HIP hot path)", tool.c_str());
     }

@@ -245,6 +245,54 @@ def bray_curtis(vecs):
     return out
 
 
+def heatmap_order(matrix):
+    """Leaf order of the heat map's dendrogram = the permutation the reference renumbers the matrix with.
+    Restates FullHeatMap.clusterObjects (src/algo/FullHeatMap.java:221-296: average linkage over the ORIGINAL distances,
+    O(n^3); the first closest pair in row-major order is merged with a strict '<'; the new node takes the smaller index,
+    old node on the left) and renumber (:327-337: left subtree first).  Pure Python: n is the number of samples."""
+    m = [[float(x) for x in row] for row in matrix]
+    n = len(m)
+    nodes = [("leaf", i) for i in range(n)]
+
+    def group(node):
+        if node is None:
+            return []
+        if node[0] == "leaf":
+            return [node[1]]
+        return group(node[1]) + group(node[2])
+
+    def between(g1, g2):
+        if not g1 or not g2:
+            return -1.0
+        s = 0.0
+        for a in g1:
+            for b in g2:
+                s += m[a][b]
+        return s / len(g1) / len(g2)
+
+    dist = [[0.0] * n for _ in range(n)]
+    for i in range(n):
+        for j in range(i + 1, n):
+            dist[i][j] = dist[j][i] = between([i], [j])
+    count, root = n, (nodes[0] if n else None)
+    while count > 1:
+        best, bi, bj = float("inf"), -1, -1          # (Double.MAX_VALUE in the reference)
+        for i in range(n):
+            for j in range(i + 1, n):
+                if nodes[i] is not None and nodes[j] is not None and dist[i][j] < best:
+                    best, bi, bj = dist[i][j], i, j
+        assert bi >= 0 and best >= 0
+        root = ("node", nodes[bi], nodes[bj])
+        nodes[bi], nodes[bj] = root, None
+        g1 = group(root)
+        for i in range(n):
+            dist[i][bj] = dist[bj][i] = -1.0
+            if i != bi:
+                dist[i][bi] = dist[bi][i] = between(g1, group(nodes[i]))
+        count -= 1
+    return group(root)
+
+
 def revcomp(kmer, k):
     return lib().or_revcomp(int(kmer), k)
 

@@ -202,6 +202,14 @@ def test_cli_matrix_builder_workdir(oracle, ref_files, tmp_path):
     assert lines[1] == "meta_test_1\t0.0000\t0.5691\t0.2981"          # README.md:96-99 values in the original order
     assert lines[2] == "meta_test_2\t0.5691\t0.0000\t0.8448"
     assert lines[3] == "meta_test_3\t0.2981\t0.8448\t0.0000"
+    # heatmap-maker's numeric half: the same matrix in dendrogram order = the order of the reference's golden file
+    ren = [p for p in (wd / "matrices").glob("dist_matrix_*.txt") if not p.name.endswith("_original_order.txt")]
+    assert len(ren) == 1
+    lines = ren[0].read_text().splitlines()
+    assert lines[0] == "#\tmeta_test_1\tmeta_test_3\tmeta_test_2"
+    assert lines[1] == "meta_test_1\t0.0000\t0.2981\t0.5691"
+    assert lines[2] == "meta_test_3\t0.2981\t0.0000\t0.8448"
+    assert lines[3] == "meta_test_2\t0.5691\t0.8448\t0.0000"
     # --continue reuses finished steps; --start re-runs from a step
     r = subprocess.run(cmd + ["-c"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "reusing results" in r.stderr

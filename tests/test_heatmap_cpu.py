@@ -1,0 +1,91 @@
+"""CPU-only pieces of the driver: heatmap-maker's numeric half (clustering order + renumbered matrix) against the
+reference's golden file and against the oracle's restatement of FullHeatMap.clusterObjects."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import REF_DATA, ROOT
+
+EXE = os.path.join(ROOT, "metafast.sh")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _cli_built():
+    if not os.path.exists(os.path.join(ROOT, "metafast_amd", "cli", "metafast")):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "metafast_amd", "cli")])
+
+
+def _write(path, m, names=None, fmt="%r"):
+    with open(path, "w") as f:
+        if names:
+            f.write("#\t" + "\t".join(names) + "\n")
+        for i, row in enumerate(m):
+            f.write((names[i] + "\t" if names else "") + "\t".join(fmt % float(x) for x in row) + "\n")
+
+
+def _read(path):
+    rows = [l.rstrip("\n").split("\t") for l in open(path)]
+    names = rows[0][1:] if rows[0][0] == "#" else None
+    body = rows[1:] if names else rows
+    return names, [[float(x) for x in (r[1:] if names else r)] for r in body]
+
+
+def test_golden_renumbered_matrix(tmp_path):
+    """the reference's only golden file for the path IS the heat-map maker's renumbered matrix (order 1,3,2):
+    original-order matrix -> heatmap-maker --output-format %s -> byte-identical to test_data/meta_test_matrix.txt"""
+    golden = open(os.path.join(REF_DATA, "meta_test_matrix.txt")).read()
+    names, g = _read(os.path.join(REF_DATA, "meta_test_matrix.txt"))
+    assert names == ["meta_test_1", "meta_test_3", "meta_test_2"]
+    order = ["meta_test_1", "meta_test_2", "meta_test_3"]
+    idx = [names.index(x) for x in order]
+    orig = [[g[i][j] for j in idx] for i in idx]
+    src = tmp_path / "dist_matrix_original_order.txt"
+    _write(src, orig, order)
+    out = tmp_path / "renumbered.txt"
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(src), "--new-matrix-file", str(out), "--output-format", "%s",
+                        "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out).read() == golden
+
+
+@pytest.mark.parametrize("n,seed", [(2, 1), (3, 2), (5, 3), (8, 4), (12, 5), (9, 6)])
+def test_heatmap_order_matches_oracle(oracle, tmp_path, n, seed):
+    rng = np.random.default_rng(seed)
+    a = rng.random((n, n))
+    if seed == 6:
+        a = np.round(a, 1)                      # many equal distances: the tie rule (first pair, strict <) decides
+    m = (a + a.T) / 2
+    np.fill_diagonal(m, 0.0)
+    names = ["s%d" % i for i in range(n)]
+    src = tmp_path / "m.txt"
+    _write(src, m, names)
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(src), "--output-format", "%s", "-w", str(tmp_path / "w")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got_names, got = _read(tmp_path / "m_renumbered.txt")
+    perm = oracle.heatmap_order(m)
+    assert sorted(perm) == list(range(n))
+    assert got_names == [names[i] for i in perm]
+    assert np.array_equal(np.array(got), m[np.ix_(perm, perm)])
+    # default format and a matrix without names
+    src2 = tmp_path / "plain.txt"
+    _write(src2, m)
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(src2), "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    n2, got2 = _read(tmp_path / "plain_renumbered.txt")
+    assert n2 is None and np.allclose(np.array(got2), m[np.ix_(perm, perm)], atol=5e-5)
+
+
+def test_heatmap_maker_errors(tmp_path):
+    bad = tmp_path / "bad.txt"
+    bad.write_text("0.0\t0.1\n0.1\n")
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(bad), "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    assert r.returncode == 1
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(tmp_path / "none.txt"), "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Can't read matrix file" in r.stderr
+    m = tmp_path / "m.txt"
+    m.write_text("0.0\t0.1\n0.1\t0.0\n")
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(m), "--output-format", "%d", "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    assert r.returncode == 1 and "Unsupported --output-format" in r.stderr
