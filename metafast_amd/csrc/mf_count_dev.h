@@ -104,9 +104,11 @@ __device__ __forceinline__ void mf_count_insert4(uint32_t tk0, uint32_t tc0, uin
 static __global__ __launch_bounds__(256) void k_gather(const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnt,
                                                 const uint64_t *__restrict__ pstart, const uint32_t *__restrict__ dcount,
                                                 const uint64_t *__restrict__ doff, uint32_t np,
-                                                uint64_t *__restrict__ dk, uint16_t *__restrict__ dc) {
-    for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
-        uint64_t s = pstart[p], o = doff[p];
+                                                uint64_t *__restrict__ dk, uint16_t *__restrict__ dc,
+                                                uint32_t p0 = 0, uint64_t sbase = 0) {
+    // partitions [p0, np); sbase: index of keys[0] / cnt[0] in pstart's numbering (a buffer that holds one batch of slices)
+    for (uint32_t p = p0 + blockIdx.x; p < np; p += gridDim.x) {
+        uint64_t s = pstart[p] - sbase, o = doff[p];
         uint32_t d = dcount[p];
         for (uint32_t j = threadIdx.x; j < d; j += blockDim.x) { dk[o + j] = keys[s + j]; dc[o + j] = cnt[s + j]; }
     }

@@ -572,7 +572,8 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                                                       const uint32_t *__restrict__ plen, uint32_t np,
                                                       const uint64_t *__restrict__ toff, uint64_t *__restrict__ tkeys,
                                                       uint16_t *__restrict__ tcnt, uint32_t *__restrict__ dcount,
-                                                      unsigned int *__restrict__ overflow, int ablate) {
+                                                      unsigned int *__restrict__ overflow, int ablate, uint32_t p0, uint64_t tbase) {
+    // partitions [p0, np); tkeys / tcnt hold the slices of this batch only: slice of p starts at toff[p] - tbase
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t out_cursor;
     uint64_t *tk = reinterpret_cast<uint64_t *>(smem);                          // [MF_COUNT_SLOTS] + 64 dummy slots
@@ -588,16 +589,16 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
     constexpr int sh = 64 - 2 * K, top = 2 * K - 2;
     const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
     const uint32_t mine = (lane >> 3) * 64u + wave * 8u + (lane & 7u);          // this lane's record within a round of 512
-    uint32_t p = blockIdx.x;
+    uint32_t p = p0 + blockIdx.x;
     if (p >= np) return;
     uint64_t start = pstart[p];
     uint32_t len = plen[p];
-    uint64_t o = toff[p]; uint32_t room = (uint32_t)(toff[p + 1] - o);         // this partition's slice of the output lists
+    uint64_t o = toff[p] - tbase; uint32_t room = (uint32_t)(toff[p + 1] - toff[p]);   // this partition's slice of the output lists
     skm_rec R = mine < len ? recs[start + mine] : SENT;                        // first round, prefetched
     for (;;) {
         const uint32_t pn = p + gridDim.x;
         uint64_t start_n = 0, o_n = 0; uint32_t len_n = 0, room_n = 0;
-        if (pn < np) { start_n = pstart[pn]; len_n = plen[pn]; o_n = toff[pn]; room_n = (uint32_t)(toff[pn + 1] - o_n); }   // (no load latency inside the compaction)
+        if (pn < np) { start_n = pstart[pn]; len_n = plen[pn]; o_n = toff[pn] - tbase; room_n = (uint32_t)(toff[pn + 1] - toff[pn]); }   // (no load latency inside the compaction)
         for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
         if (threadIdx.x == 0) out_cursor = 0;
         skm_rec cur = R;
@@ -675,6 +676,10 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
     }
 }
 
+__global__ void k_skm_add_base(uint64_t *__restrict__ v, uint64_t n, uint64_t base) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] += base;
+}
 // capacity of a partition's slice of the temporary (key,count) lists: it cannot hold more distinct k-mers than it has
 // k-mers, nor more than the LDS table
 __global__ void k_skm_cap(const uint32_t *__restrict__ pocc, uint32_t np, uint32_t *__restrict__ cap) {
@@ -760,55 +765,92 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         cap = cap2; np = (uint32_t)np2; used += bits;
     }
 
-    // ---- temporary (key,count) lists, one slice per partition ----
+    // ---- count + gather, a batch of partitions at a time.  A partition's (key,count) slice is sized by its k-mer count
+    // (it cannot hold more distinct k-mers than it has k-mers, nor more than the LDS table), i.e. all slices together
+    // are as large as the k-mer stream itself: the buffer holds ONE batch of slices and is redused, the dense table grows
+    // batch by batch (sized from the first batch's distinct / k-mer ratio; re-allocated if that was too optimistic).
     mf_buf<uint32_t> pcap; MF_TRY(pcap.alloc(ctx, np));
     mf_buf<uint64_t> toff; MF_TRY(toff.alloc(ctx, (size_t)np + 1));
     k_skm_cap<<<(np + 255) / 256, 256, 0, st>>>(pocc.p, np, pcap.p);
     MF_TRY(mf_scan<1>(ctx, pcap.p, toff.p, np, (uint64_t *)&scal[4]));
-    unsigned long long tcap = 0;
-    MF_HIP(hipMemcpyAsync(&tcap, &scal[4], 8, hipMemcpyDeviceToHost, st));
+    const uint32_t nbatch = ctx->opt_skm_batches > 0 ? (uint32_t)std::min<int64_t>(ctx->opt_skm_batches, np) : (np >= (1u << 18) ? 8u : (np >= 4096 ? 2u : 1u));
+    const uint32_t PB = (np + nbatch - 1) / nbatch;
+    std::vector<unsigned long long> tb(nbatch + 1);
+    for (uint32_t b = 0; b <= nbatch; b++)
+        MF_HIP(hipMemcpyAsync(&tb[b], &toff.p[std::min<uint64_t>((uint64_t)b * PB, np)], 8, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
     pcap.reset(); pocc.reset();
+    const unsigned long long tcap = tb[nbatch];
+    unsigned long long tmax = 0;
+    for (uint32_t b = 0; b < nbatch; b++) tmax = std::max(tmax, tb[b + 1] - tb[b]);
     mf_buf<uint64_t> tkeys; mf_buf<uint16_t> tcnt;
-    if (tkeys.alloc(ctx, tcap) != MF_OK || tcnt.alloc(ctx, tcap) != MF_OK) {
-        if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: no room for %.1f GB of temporary lists, using the k-mer path\n", tcap * 10 / 1e9);
+    if (tkeys.alloc(ctx, tmax) != MF_OK || tcnt.alloc(ctx, tmax) != MF_OK) {
+        if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: no room for %.1f GB of temporary lists, using the k-mer path\n", tmax * 10 / 1e9);
         return MF_SKM_FALLBACK;
     }
     mf_buf<uint32_t> dcount; MF_TRY(dcount.alloc(ctx, np));
+    mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));
+    mf_buf<uint64_t> dk; mf_buf<uint16_t> dc;
+    uint64_t dused = 0, dcap = 0;
     {
         const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 8 * 2;
         MF_TRY(skm_set_lds(k_skm_count<K>, lds));
-        const unsigned grid = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 2);
-        mf_ktimer t(ctx, "k_skm_count");
-        k_skm_count<K><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, np, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2], (int)ctx->opt_ablate);
     }
-    MF_DBG(ctx, "k_skm_count");
-    mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));
-    MF_TRY(mf_scan<1>(ctx, dcount.p, doff.p, np, (uint64_t *)&scal[3]));
+    for (uint32_t b = 0; b < nbatch; b++) {
+        const uint32_t p0 = (uint32_t)std::min<uint64_t>((uint64_t)b * PB, np), p1 = (uint32_t)std::min<uint64_t>((uint64_t)(b + 1) * PB, np);
+        if (p0 == p1) continue;
+        {
+            const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 8 * 2;
+            const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);
+            mf_ktimer t(ctx, "k_skm_count");
+            k_skm_count<K><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
+                                                      (int)ctx->opt_ablate, p0, (uint64_t)tb[b]);
+        }
+        MF_DBG(ctx, "k_skm_count");
+        MF_TRY(mf_scan<1>(ctx, dcount.p + p0, doff.p + p0, p1 - p0, (uint64_t *)&scal[3]));      // offsets inside the batch
+        unsigned long long res[2];
+        MF_HIP(hipMemcpyAsync(res, &scal[2], 16, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+        if (res[0]) {
+            if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: a minimizer partition overflows the LDS table, using the k-mer path\n");
+            MF_HIP(hipMemsetAsync(&scal[2], 0, 8, st));
+            return MF_SKM_FALLBACK;
+        }
+        const uint64_t d_b = res[1];
+        if (dused + d_b > dcap) {
+            // everything still to come is bounded by the slices of the remaining batches; expect the ratio seen so far
+            const uint64_t done_cap = tb[b + 1], rest_cap = tcap - tb[b + 1];
+            const double ratio = done_cap ? (double)(dused + d_b) / (double)done_cap : 1.0;
+            uint64_t want = dused + d_b + (uint64_t)std::min<double>((double)rest_cap, (double)rest_cap * ratio * 1.12 + 4096.0);
+            if (want < dused + d_b) want = dused + d_b;
+            mf_buf<uint64_t> nk; mf_buf<uint16_t> nc;
+            MF_TRY(nk.alloc(ctx, want)); MF_TRY(nc.alloc(ctx, want));
+            if (dused) {
+                MF_HIP(hipMemcpyAsync(nk.p, dk.p, dused * 8, hipMemcpyDeviceToDevice, st));
+                MF_HIP(hipMemcpyAsync(nc.p, dc.p, dused * 2, hipMemcpyDeviceToDevice, st));
+                MF_HIP(hipStreamSynchronize(st));
+            }
+            std::swap(dk.p, nk.p); std::swap(dk.n, nk.n); std::swap(dk.ctx, nk.ctx);
+            std::swap(dc.p, nc.p); std::swap(dc.n, nc.n); std::swap(dc.ctx, nc.ctx);
+            dcap = want;
+        }
+        {
+            const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 32);
+            mf_ktimer t(ctx, "k_gather");
+            k_gather<<<grid, 256, 0, st>>>(tkeys.p, tcnt.p, toff.p, dcount.p, doff.p, p1, dk.p + dused, dc.p + dused, p0, (uint64_t)tb[b]);
+            k_skm_add_base<<<(p1 - p0 + 1 + 255) / 256, 256, 0, st>>>(doff.p + p0, (uint64_t)(p1 - p0) + 1, dused);
+        }
+        MF_DBG(ctx, "k_gather");
+        dused += d_b;
+    }
     MF_HIP(hipGetLastError());
-    unsigned long long res[4];
-    MF_HIP(hipMemcpyAsync(res, scal, 32, hipMemcpyDeviceToHost, st));
-    MF_HIP(hipStreamSynchronize(st));
-    if (res[2]) {
-        if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: a minimizer partition overflows the LDS table, using the k-mer path\n");
-        MF_HIP(hipMemsetAsync(&scal[2], 0, 8, st));
-        return MF_SKM_FALLBACK;
-    }
     bufA.reset();
-    const uint64_t n_dist = res[3];
-    mf_buf<uint64_t> dk; MF_TRY(dk.alloc(ctx, n_dist));
-    mf_buf<uint16_t> dc; MF_TRY(dc.alloc(ctx, n_dist));
-    {
-        const unsigned grid = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 32);
-        mf_ktimer t(ctx, "k_gather");
-        k_gather<<<grid, 256, 0, st>>>(tkeys.p, tcnt.p, toff.p, dcount.p, doff.p, np, dk.p, dc.p);
-    }
-    MF_DBG(ctx, "k_gather");
+    const uint64_t n_dist = dused;
     if (ctx->opt_verbose)
         fprintf(stderr, "[mf] count(skm): n_occ=%llu records=%llu levels=%zu bits=%d np=%u distinct=%llu\n", (unsigned long long)n_occ,
                 (unsigned long long)cap, lv.size(), total_bits, np, (unsigned long long)n_dist);
     MF_HIP(hipGetLastError());
-    const size_t kb = dk.bytes(), cb = dc.bytes();
+    const size_t kb = dk.bytes(), cb = dc.bytes();       // (capacity: may be a little larger than n_dist)
     MF_TRY(mf_table_adopt(ctx, K, n_dist, n_occ, dk.take(), kb, dc.take(), cb, out));
     (*out)->n_records = cap; (*out)->record_bytes = 16;
     if (total_bits > 0 && total_bits <= 30) {

@@ -23,7 +23,7 @@ def _check(ctx, oracle, bases, off, k, min_len=0, thr=-1):
 
 
 def _reset(ctx):
-    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1)):
+    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0)):
         ctx.set_option(name, v)
 
 
@@ -151,6 +151,7 @@ def test_skm_every_k(gpu_ctx, oracle, k):
         for target in (3072, 64):                            # one and two partition levels
             gpu_ctx.set_option("part_target", target)
             gpu_ctx.set_option("skm", 1)
+            gpu_ctx.set_option("skm_batches", 0 if target == 3072 else 5)     # count + gather in one / in five batches
             t = _check(gpu_ctx, oracle, b, o, k)
             assert t.records()[1] == 16
             gpu_ctx.set_option("skm", 0)
