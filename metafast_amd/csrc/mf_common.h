@@ -60,6 +60,7 @@ struct mf_ctx {
     int64_t opt_l1_blocks = 0;     // 0 = auto
     int64_t opt_verbose = 0;
     int64_t opt_skm = 1;           // super-k-mer counting path (mf_skm.hip) for k >= MF_SKM_MIN_K; 0 = always one record per k-mer
+    int64_t opt_skm_dyn = 1;       // one-pass level-1 scatter with sampled region sizes: 0 never, 1 auto (large inputs), 2 always
     int64_t opt_skm_batches = 0;   // partitions are counted + gathered in this many batches (0 = auto); tests force small values
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero
     // workspace arena: a few large hipMalloc'd regions, sub-allocated with first-fit + coalescing free lists.

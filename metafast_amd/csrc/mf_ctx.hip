@@ -88,6 +88,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "ablate") ctx->opt_ablate = v;
     else if (s == "skm") ctx->opt_skm = v;
     else if (s == "skm_batches") ctx->opt_skm_batches = v;
+    else if (s == "skm_dyn") ctx->opt_skm_dyn = v;
     else return mf_set_error("unknown option '%s'", name);
     return MF_OK;
 }

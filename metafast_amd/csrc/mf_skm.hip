@@ -154,7 +154,8 @@ __device__ __forceinline__ void skm_route(uint32_t mh, int bits1, uint32_t &d1, 
 template <int K>
 __global__ __launch_bounds__(1024) void k_skm_hist(const uint8_t *__restrict__ bases, uint64_t n_bases, const uint32_t *__restrict__ vmask,
                                                    uint64_t n_words, uint64_t words_per_block, int bits1,
-                                                   uint32_t *__restrict__ blockhist, uint32_t *__restrict__ blockocc, int G) {
+                                                   uint32_t *__restrict__ blockhist, uint32_t *__restrict__ blockocc, int G, int stride) {
+    // stride > 1: a SAMPLE (every stride-th tile of 1024 words), used to size the digit regions of the one-pass scatter
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nd = 1 << bits1;
     uint32_t *hist = reinterpret_cast<uint32_t *>(smem), *occ = hist + nd;
@@ -162,7 +163,7 @@ __global__ __launch_bounds__(1024) void k_skm_hist(const uint8_t *__restrict__ b
     __syncthreads();
     const uint64_t wlo = (uint64_t)blockIdx.x * words_per_block;
     const uint64_t whi = wlo + words_per_block < n_words ? wlo + words_per_block : n_words;
-    for (uint64_t wb = wlo; wb < whi; wb += blockDim.x) {
+    for (uint64_t wb = wlo; wb < whi; wb += (uint64_t)blockDim.x * (uint64_t)stride) {
         const uint64_t w = wb + threadIdx.x;
         const uint32_t m = w < whi ? vmask[w] : 0u;
         if (__ballot(m != 0u) == 0ull) continue;
@@ -222,9 +223,31 @@ __device__ __forceinline__ void skm_lds_write4_add_rtn4(const uint32_t (&wa)[4],
                    "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(inc[0]), "v"(inc[1]), "v"(inc[2]), "v"(inc[3])
                  : "memory");
 }
+// DYN (one-pass level-1 scatter): a workgroup does not know its share of a digit in advance; it reserves the digit's region
+// chunk by chunk (SKM_CH records) with a global atomic when its current chunk is used up.  Chunk starts are multiples of
+// SKM_CH and a position is advanced right after it is taken, so "position % SKM_CH == 0" means "no room left".
+#define SKM_CH 256
+#define SKM_NONE (~0ull)
+struct skm_dyn {
+    unsigned long long *gcur;     // [nd] next free record of every digit's region
+    const uint64_t *rend;         // [nd] end of the region
+    unsigned int *overflow;       // set when a region was too small (the caller repeats the level with exact ranges)
+    uint64_t dump;                // a scratch chunk of this workgroup: where lines go after an overflow
+};
+template <bool DYN>
+__device__ __forceinline__ uint64_t skm_take_line(const skm_stage &L, uint32_t dg, const skm_dyn &Dy) {
+    uint64_t pos = L.cur[dg];
+    if (DYN && (pos == SKM_NONE || (pos & (uint64_t)(SKM_CH - 1)) == 0ull)) {
+        pos = atomicAdd(&Dy.gcur[dg], (unsigned long long)SKM_CH);
+        if (pos + SKM_CH > Dy.rend[dg]) { atomicExch(Dy.overflow, 1u); pos = Dy.dump; }
+    }
+    L.cur[dg] = pos + SKM_LINE;
+    return pos;
+}
 // ALL 64 lanes of the wave must call this together (wave-uniform loop, wave-cooperative flush)
+template <bool DYN = false>
 __device__ __forceinline__ void skm_stage_insert(const skm_stage &L, skm_rec *__restrict__ out, const uint32_t (&d)[4],
-                                                 const skm_rec (&rec)[4], bool (&pending)[4]) {
+                                                 const skm_rec (&rec)[4], bool (&pending)[4], const skm_dyn &Dy = skm_dyn()) {
     const uint32_t ctr0 = mf_lds_addr(L.ctr), line0 = mf_lds_addr(L.line);
     const uint32_t dummy_ctr = ctr0 + 4u * ((uint32_t)L.nd + (uint32_t)mf_lane());
     const uint32_t dummy_slot = line0 + 16u * ((uint32_t)L.nd * SKM_LINE + (uint32_t)mf_lane());
@@ -263,7 +286,7 @@ __device__ __forceinline__ void skm_stage_insert(const skm_stage &L, skm_rec *__
             if (F == 0ull) continue;
             const uint32_t n = (uint32_t)__popcll(F), qi = (uint32_t)__popcll(F & lt_mask);
             uint64_t mypos = 0;
-            if (fl) { mypos = L.cur[d[b]]; L.cur[d[b]] = mypos + SKM_LINE; }
+            if (fl) mypos = skm_take_line<DYN>(L, d[b], Dy);
             for (uint32_t e0 = 0; e0 < n; e0 += SKM_QCAP) {
                 if (fl && qi >= e0 && qi < e0 + SKM_QCAP) { qpos[qi - e0] = mypos; qd[qi - e0] = d[b]; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // queue visible to the wave (in-order LDS)
@@ -283,15 +306,21 @@ __device__ __forceinline__ void skm_stage_insert(const skm_stage &L, skm_rec *__
         __builtin_amdgcn_wave_barrier();
     }
 }
-// after a barrier: write every partly filled line, padded with sentinel records
-__device__ __forceinline__ void skm_stage_flush_all(const skm_stage &L, skm_rec *__restrict__ out, int nd) {
+// after a barrier: write every partly filled line, padded with sentinel records (DYN: and the unused rest of the
+// workgroup's last chunk of every digit, the reader of the region skips sentinels)
+template <bool DYN = false>
+__device__ __forceinline__ void skm_stage_flush_all(const skm_stage &L, skm_rec *__restrict__ out, int nd, const skm_dyn &Dy = skm_dyn()) {
+    const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
     for (int d = threadIdx.x; d < nd; d += blockDim.x) {
         const uint32_t c = L.ctr[d] >> 16;
         if (c) {
-            const uint64_t pos = L.cur[d];
-            for (uint32_t s = 0; s < (uint32_t)SKM_LINE; s++) out[pos + s] = s < c ? L.line[d * SKM_LINE + s] : make_ulonglong2(~0ull, ~0ull);
-            L.cur[d] = pos + SKM_LINE;
+            const uint64_t pos = skm_take_line<DYN>(L, (uint32_t)d, Dy);
+            for (uint32_t s = 0; s < (uint32_t)SKM_LINE; s++) out[pos + s] = s < c ? L.line[d * SKM_LINE + s] : SENT;
             L.ctr[d] = 0;
+        }
+        if (DYN) {
+            uint64_t pos = L.cur[d];
+            if (pos != SKM_NONE) for (; (pos & (uint64_t)(SKM_CH - 1)) != 0ull; pos++) out[pos] = SENT;
         }
     }
 }
@@ -299,14 +328,15 @@ __device__ __forceinline__ void skm_stage_flush_all(const skm_stage &L, skm_rec 
 // =============================================================================================
 // S2: records of every run, radix-partitioned by the level-1 digit
 // =============================================================================================
-template <int K>
+template <int K, bool DYN>
 __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict__ bases, uint64_t n_bases, const uint32_t *__restrict__ vmask,
                                                       uint64_t n_words, uint64_t words_per_block, int bits1,
-                                                      const uint64_t *__restrict__ blockstart, int G, skm_rec *__restrict__ out) {
+                                                      const uint64_t *__restrict__ blockstart, int G, skm_rec *__restrict__ out, skm_dyn Dy) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nd = 1 << bits1;
     skm_stage L = skm_stage_carve(smem, nd);
-    for (int i = threadIdx.x; i < nd; i += blockDim.x) { L.cur[i] = blockstart[(size_t)i * G + blockIdx.x]; L.ctr[i] = 0; }
+    if (DYN) Dy.dump += (uint64_t)blockIdx.x * SKM_CH;
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) { L.cur[i] = DYN ? SKM_NONE : blockstart[(size_t)i * G + blockIdx.x]; L.ctr[i] = 0; }
     if (threadIdx.x < 64) L.ctr[nd + threadIdx.x] = 0;
     __syncthreads();
     const uint64_t wlo = (uint64_t)blockIdx.x * words_per_block;
@@ -331,11 +361,30 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
                     rec[b] = skm_make_rec<K>(S, s, len, digits);
                 }
             }
-            skm_stage_insert(L, out, d, rec, pend);
+            skm_stage_insert<DYN>(L, out, d, rec, pend, Dy);
         }
     }
     __syncthreads();
-    skm_stage_flush_all(L, out, nd);
+    skm_stage_flush_all<DYN>(L, out, nd, Dy);
+}
+
+// one-pass level 1: region size of every digit from a sampled histogram, and the directory afterwards
+__global__ void k_skm_region_sizes(const uint32_t *__restrict__ blockhist, int G, int nd, uint32_t scale, uint32_t *__restrict__ rsize) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd) return;
+    uint64_t t = 0;
+    for (int b = 0; b < G; b++) t += blockhist[(size_t)d * G + b];
+    t *= scale;
+    t += t / 16 + (uint64_t)G * SKM_CH + 8192;          // sampling error + a partly used chunk per workgroup
+    t = (t + SKM_CH - 1) & ~(uint64_t)(SKM_CH - 1);
+    rsize[d] = t > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)t;
+}
+__global__ void k_skm_dir_dyn(const uint64_t *__restrict__ rstart, const unsigned long long *__restrict__ gcur, int nd,
+                              uint64_t *__restrict__ pstart, uint32_t *__restrict__ plen) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd) return;
+    pstart[d] = rstart[d];
+    plen[d] = (uint32_t)(gcur[d] - rstart[d]);          // whole chunks; unused records are sentinels
 }
 
 // partition directory after level 1: start / padded length per digit; k-mers per digit (plans without a split level)
@@ -359,7 +408,7 @@ __global__ void k_skm_dir(const uint64_t *__restrict__ blockstart, const uint32_
 __global__ __launch_bounds__(1024) void k_skm_split(const skm_rec *__restrict__ in, const uint64_t *__restrict__ pstart,
                                                     const uint32_t *__restrict__ plen, uint32_t np, int shift, int bits,
                                                     skm_rec *__restrict__ out, uint64_t *__restrict__ ostart, uint32_t *__restrict__ olen,
-                                                    uint32_t *__restrict__ oocc) {
+                                                    uint32_t *__restrict__ oocc, unsigned long long *__restrict__ n_valid) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t scratch[17];
     const int nd = 1 << bits;
@@ -387,9 +436,13 @@ __global__ __launch_bounds__(1024) void k_skm_split(const skm_rec *__restrict__ 
                 }
         }
         __syncthreads();
-        uint32_t mine = 0;
+        uint32_t mine = 0, raw = 0;
         const int b0 = threadIdx.x * ipt;
-        for (int j = 0; j < ipt; j++) { const int b = b0 + j; if (b < nd) mine += (L.ctr[b] + 3u) & ~3u; }
+        for (int j = 0; j < ipt; j++) { const int b = b0 + j; if (b < nd) { mine += (L.ctr[b] + 3u) & ~3u; raw += L.ctr[b]; } }
+        if (n_valid) {                                            // records without the padding (measurement: mf_table_records)
+            for (int dd = 32; dd >= 1; dd >>= 1) raw += __shfl_down(raw, dd, 64);
+            if (mf_lane() == 0 && raw) atomicAdd(n_valid, (unsigned long long)raw);
+        }
         uint32_t tot;
         uint32_t ex = mf_block_excl_scan(mine, scratch, &tot);
         for (int j = 0; j < ipt; j++) {
@@ -428,22 +481,15 @@ __global__ __launch_bounds__(1024) void k_skm_split(const skm_rec *__restrict__ 
 // =============================================================================================
 // S4: count one partition per workgroup
 // =============================================================================================
-// LDS steps of 1, 2 or 4 keys per lane (one asm block each: the waits belong to the block, see mf_count_dev.h)
+// LDS steps of 1 or 4 keys per lane (one asm block each: the waits belong to the block, see mf_count_dev.h)
 template <int B> __device__ __forceinline__ void skm_lds_read_b64(const uint32_t (&a)[B], uint64_t (&v)[B]);
 template <> __device__ __forceinline__ void skm_lds_read_b64<1>(const uint32_t (&a)[1], uint64_t (&v)[1]) {
     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]) : "v"(a[0]) : "memory");
-}
-template <> __device__ __forceinline__ void skm_lds_read_b64<2>(const uint32_t (&a)[2], uint64_t (&v)[2]) {
-    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]), "=&v"(v[1]) : "v"(a[0]), "v"(a[1]) : "memory");
 }
 template <> __device__ __forceinline__ void skm_lds_read_b64<4>(const uint32_t (&a)[4], uint64_t (&v)[4]) { mf_lds_read4_b64(a, v); }
 template <int B> __device__ __forceinline__ void skm_lds_cmpst_b64(const uint32_t (&a)[B], uint64_t cmp, const uint64_t (&nv)[B], uint64_t (&old)[B]);
 template <> __device__ __forceinline__ void skm_lds_cmpst_b64<1>(const uint32_t (&a)[1], uint64_t cmp, const uint64_t (&nv)[1], uint64_t (&old)[1]) {
     asm volatile("ds_cmpst_rtn_b64 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old[0]) : "v"(a[0]), "v"(cmp), "v"(nv[0]) : "memory");
-}
-template <> __device__ __forceinline__ void skm_lds_cmpst_b64<2>(const uint32_t (&a)[2], uint64_t cmp, const uint64_t (&nv)[2], uint64_t (&old)[2]) {
-    asm volatile("ds_cmpst_rtn_b64 %0, %2, %4, %5\n\tds_cmpst_rtn_b64 %1, %3, %4, %6\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(old[0]), "=&v"(old[1]) : "v"(a[0]), "v"(a[1]), "v"(cmp), "v"(nv[0]), "v"(nv[1]) : "memory");
 }
 template <> __device__ __forceinline__ void skm_lds_cmpst_b64<4>(const uint32_t (&a)[4], uint64_t cmp, const uint64_t (&nv)[4], uint64_t (&old)[4]) {
     mf_lds_cmpst4_b64(a, cmp, nv, old);
@@ -451,9 +497,6 @@ template <> __device__ __forceinline__ void skm_lds_cmpst_b64<4>(const uint32_t 
 template <int B> __device__ __forceinline__ void skm_lds_add(const uint32_t (&a)[B], const uint32_t (&inc)[B]);
 template <> __device__ __forceinline__ void skm_lds_add<1>(const uint32_t (&a)[1], const uint32_t (&inc)[1]) {
     asm volatile("ds_add_u32 %0, %1" ::"v"(a[0]), "v"(inc[0]) : "memory");
-}
-template <> __device__ __forceinline__ void skm_lds_add<2>(const uint32_t (&a)[2], const uint32_t (&inc)[2]) {
-    asm volatile("ds_add_u32 %0, %2\n\tds_add_u32 %1, %3" ::"v"(a[0]), "v"(a[1]), "v"(inc[0]), "v"(inc[1]) : "memory");
 }
 template <> __device__ __forceinline__ void skm_lds_add<4>(const uint32_t (&a)[4], const uint32_t (&inc)[4]) { mf_lds_add4(a, inc); }
 
@@ -463,42 +506,6 @@ __device__ __forceinline__ uint32_t skm_slot(uint64_t key) {
     f *= 0x9E3779B1u;
     return f >> 16;
 }
-// insert B keys per lane into the LDS table (same protocol as mf_count_insert4); key MF_EMPTY = nothing to insert
-template <int B>
-__device__ __forceinline__ void skm_count_insert(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
-                                                 const uint64_t (&key)[B], unsigned int *overflow) {
-    uint32_t s[B]; bool pend[B];
-#pragma unroll
-    for (int b = 0; b < B; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = skm_slot(key[b]) & mask; }
-    for (uint32_t probes = 0;; probes++) {
-        bool any = false;
-#pragma unroll
-        for (int b = 0; b < B; b++) any |= pend[b];
-        if (__ballot(any) == 0ull) break;
-        if (probes > mask) { if (mf_lane() == 0) atomicExch(overflow, 1u); break; }
-        uint32_t ka[B], ca[B], aa[B], inc[B]; uint64_t cur[B], ret[B]; bool need[B]; bool anyneed = false;
-#pragma unroll
-        for (int b = 0; b < B; b++) ka[b] = pend[b] ? tk0 + 8u * s[b] : dummy_k;
-        skm_lds_read_b64<B>(ka, cur);
-#pragma unroll
-        for (int b = 0; b < B; b++) { need[b] = pend[b] && cur[b] == MF_EMPTY; ca[b] = need[b] ? ka[b] : dummy_k; anyneed |= need[b]; }
-        if (__ballot(anyneed) != 0ull) {
-            skm_lds_cmpst_b64<B>(ca, MF_EMPTY, key, ret);
-#pragma unroll
-            for (int b = 0; b < B; b++) if (need[b]) cur[b] = ret[b] == MF_EMPTY ? key[b] : ret[b];
-        }
-#pragma unroll
-        for (int b = 0; b < B; b++) {
-            const bool hit = pend[b] && cur[b] == key[b];
-            aa[b] = hit ? tc0 + 4u * s[b] : dummy_c;
-            inc[b] = hit ? 1u : 0u;
-            if (hit) pend[b] = false;
-            else s[b] = (s[b] + 1) & mask;
-        }
-        skm_lds_add<B>(aa, inc);
-    }
-}
-
 // Four keys per lane, narrowing: ONE four-wide probe settles about nine keys in ten (first-probe hits and fresh slots);
 // what is left (keys that met a collision) goes on one key per lane at a time with one-wide steps.  Keeping the loop
 // four-wide until the last of the wave's 256 keys is placed costs 3.3 four-wide iterations on average, most of them LDS
@@ -712,33 +719,72 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     }
     const uint64_t wpb = (n_words + G - 1) / G;
     const bool l1_only = lv.size() == 1;
-    mf_buf<uint32_t> blockhist; MF_TRY(blockhist.alloc(ctx, (size_t)nd1 * G));
-    mf_buf<uint32_t> blockocc; if (l1_only) MF_TRY(blockocc.alloc(ctx, (size_t)nd1 * G));
-    mf_buf<uint64_t> blockstart; MF_TRY(blockstart.alloc(ctx, (size_t)nd1 * G + 1));
-    {
-        mf_ktimer t(ctx, "k_skm_hist");
-        k_skm_hist<K><<<G, 1024, (size_t)nd1 * 8, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockhist.p, blockocc.p, G);
-    }
-    MF_DBG(ctx, "k_skm_hist");
-    MF_TRY(mf_scan<SKM_LINE>(ctx, blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal[1]));
-    unsigned long long cap = 0;
-    MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
-    MF_HIP(hipStreamSynchronize(st));                       // padded number of records
-    mf_buf<skm_rec> bufA; MF_TRY(bufA.alloc(ctx, cap));
-    {
-        const size_t lds = skm_stage_bytes(nd1);
-        MF_TRY(skm_set_lds(k_skm_scatter<K>, lds));
-        mf_ktimer t(ctx, "k_skm_scatter");
-        k_skm_scatter<K><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p);
-    }
-    MF_DBG(ctx, "k_skm_scatter");
     uint32_t np = (uint32_t)nd1;
     mf_buf<uint64_t> pstart; MF_TRY(pstart.alloc(ctx, np));
     mf_buf<uint32_t> plen; MF_TRY(plen.alloc(ctx, np));
     mf_buf<uint32_t> pocc; MF_TRY(pocc.alloc(ctx, np));
-    k_skm_dir<<<(nd1 + 255) / 256, 256, 0, st>>>(blockstart.p, blockocc.p, G, nd1, pstart.p, plen.p, pocc.p);
-    blockhist.reset(); blockocc.reset(); blockstart.reset();
+    mf_buf<skm_rec> bufA;
+    unsigned long long cap = 0;
+    // Level 1 in ONE pass over the reads where it pays (large inputs, a split level follows): the digit regions are sized
+    // from a histogram of a sixteenth of the input and handed out chunk-wise during the scatter, instead of a full
+    // minimizer pass just to count (k_skm_hist over everything costs 17 ms of 300 at 100 M reads).  If a region turns out
+    // too small the level is repeated with exact ranges.  skm_dyn: 0 never, 1 auto, 2 always (tests).
+    bool dyn = !l1_only && (ctx->opt_skm_dyn == 2 || (ctx->opt_skm_dyn == 1 && n_words >= (1ull << 22)));
+    for (int attempt = dyn ? 0 : 1; attempt < 2; attempt++) {
+        const bool D = attempt == 0;
+        const int stride = D ? (ctx->opt_skm_dyn == 2 ? 3 : 16) : 1;
+        mf_buf<uint32_t> blockhist; MF_TRY(blockhist.alloc(ctx, (size_t)nd1 * G));
+        mf_buf<uint32_t> blockocc; if (l1_only) MF_TRY(blockocc.alloc(ctx, (size_t)nd1 * G));
+        {
+            mf_ktimer t(ctx, D ? "k_skm_hist_sample" : "k_skm_hist");
+            k_skm_hist<K><<<G, 1024, (size_t)nd1 * 8, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockhist.p, blockocc.p, G, stride);
+        }
+        MF_DBG(ctx, "k_skm_hist");
+        if (D) {
+            mf_buf<uint32_t> rsize; MF_TRY(rsize.alloc(ctx, np));
+            mf_buf<uint64_t> rstart; MF_TRY(rstart.alloc(ctx, (size_t)np + 1));
+            mf_buf<unsigned long long> gcur; MF_TRY(gcur.alloc(ctx, np));
+            k_skm_region_sizes<<<(nd1 + 255) / 256, 256, 0, st>>>(blockhist.p, G, nd1, (uint32_t)stride, rsize.p);
+            MF_TRY(mf_scan<1>(ctx, rsize.p, rstart.p, np, (uint64_t *)&scal[1]));
+            MF_HIP(hipMemcpyAsync(gcur.p, rstart.p, (size_t)np * 8, hipMemcpyDeviceToDevice, st));
+            MF_HIP(hipMemsetAsync(&scal[5], 0, 8, st));
+            MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            if (bufA.alloc(ctx, cap + (uint64_t)G * SKM_CH) != MF_OK) return MF_SKM_FALLBACK;
+            skm_dyn Dy; Dy.gcur = gcur.p; Dy.rend = rstart.p + 1; Dy.overflow = (unsigned int *)&scal[5]; Dy.dump = cap;
+            {
+                const size_t lds = skm_stage_bytes(nd1);
+                MF_TRY(skm_set_lds(k_skm_scatter<K, true>, lds));
+                mf_ktimer t(ctx, "k_skm_scatter");
+                k_skm_scatter<K, true><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, bufA.p, Dy);
+            }
+            MF_DBG(ctx, "k_skm_scatter");
+            k_skm_dir_dyn<<<(nd1 + 255) / 256, 256, 0, st>>>(rstart.p, gcur.p, nd1, pstart.p, plen.p);
+            unsigned long long ovf = 0;
+            MF_HIP(hipMemcpyAsync(&ovf, &scal[5], 8, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            if (!ovf) break;
+            if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: a sampled digit region was too small, level 1 again with exact ranges\n");
+            bufA.reset();
+            continue;
+        }
+        mf_buf<uint64_t> blockstart; MF_TRY(blockstart.alloc(ctx, (size_t)nd1 * G + 1));
+        MF_TRY(mf_scan<SKM_LINE>(ctx, blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal[1]));
+        MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));                       // padded number of records
+        if (bufA.alloc(ctx, cap) != MF_OK) return MF_SKM_FALLBACK;            // (the k-mer path will report the shortage if it cannot run either)
+        {
+            const size_t lds = skm_stage_bytes(nd1);
+            MF_TRY(skm_set_lds(k_skm_scatter<K, false>, lds));
+            mf_ktimer t(ctx, "k_skm_scatter");
+            k_skm_scatter<K, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p, skm_dyn());
+        }
+        MF_DBG(ctx, "k_skm_scatter");
+        k_skm_dir<<<(nd1 + 255) / 256, 256, 0, st>>>(blockstart.p, blockocc.p, G, nd1, pstart.p, plen.p, pocc.p);
+    }
 
+    MF_HIP(hipMemsetAsync(&scal[6], 0, 8, st));
+    const unsigned long long cap_l1 = cap;
     int used = 0;
     for (size_t li = 1; li < lv.size(); li++) {
         const int bits = lv[li], nd = 1 << bits;
@@ -746,7 +792,8 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         const uint64_t np2 = (uint64_t)np * nd;
         if (np2 > 0xFFFFFFF0ull) return mf_set_error("too many partitions");
         const bool last = li + 1 == lv.size();
-        mf_buf<skm_rec> bufB; MF_TRY(bufB.alloc(ctx, cap2));
+        mf_buf<skm_rec> bufB;
+        if (bufB.alloc(ctx, cap2) != MF_OK) return MF_SKM_FALLBACK;
         mf_buf<uint64_t> ostart; MF_TRY(ostart.alloc(ctx, np2));
         mf_buf<uint32_t> olen; MF_TRY(olen.alloc(ctx, np2));
         mf_buf<uint32_t> oocc; if (last) MF_TRY(oocc.alloc(ctx, np2));
@@ -755,7 +802,8 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         {
             MF_TRY(skm_set_lds(k_skm_split, lds));
             mf_ktimer t(ctx, "k_skm_split");
-            k_skm_split<<<grid, 1024, lds, st>>>(bufA.p, pstart.p, plen.p, np, SKM_DIGIT_BITS - used - bits, bits, bufB.p, ostart.p, olen.p, oocc.p);
+            k_skm_split<<<grid, 1024, lds, st>>>(bufA.p, pstart.p, plen.p, np, SKM_DIGIT_BITS - used - bits, bits, bufB.p, ostart.p, olen.p, oocc.p,
+                                                 li == 1 ? &scal[6] : nullptr);
         }
         MF_DBG(ctx, "k_skm_split");
         std::swap(bufA.p, bufB.p); std::swap(bufA.n, bufB.n);
@@ -852,7 +900,13 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     MF_HIP(hipGetLastError());
     const size_t kb = dk.bytes(), cb = dc.bytes();       // (capacity: may be a little larger than n_dist)
     MF_TRY(mf_table_adopt(ctx, K, n_dist, n_occ, dk.take(), kb, dc.take(), cb, out));
-    (*out)->n_records = cap; (*out)->record_bytes = 16;
+    {
+        unsigned long long nv = 0;
+        MF_HIP(hipMemcpyAsync(&nv, &scal[6], 8, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+        (*out)->n_records = nv ? nv : cap_l1;             // (plans without a split level: the padded level-1 count)
+        (*out)->record_bytes = 16;
+    }
     if (total_bits > 0 && total_bits <= 30) {
         (*out)->part_bits = total_bits;
         (*out)->part_skm = 1;

@@ -23,7 +23,7 @@ def _check(ctx, oracle, bases, off, k, min_len=0, thr=-1):
 
 
 def _reset(ctx):
-    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0)):
+    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0), ("skm_dyn", 1)):
         ctx.set_option(name, v)
 
 
@@ -152,6 +152,7 @@ def test_skm_every_k(gpu_ctx, oracle, k):
             gpu_ctx.set_option("part_target", target)
             gpu_ctx.set_option("skm", 1)
             gpu_ctx.set_option("skm_batches", 0 if target == 3072 else 5)     # count + gather in one / in five batches
+            gpu_ctx.set_option("skm_dyn", 2 if k % 2 else 1)                  # odd k: one-pass level 1 (sampled regions)
             t = _check(gpu_ctx, oracle, b, o, k)
             assert t.records()[1] == 16
             gpu_ctx.set_option("skm", 0)
@@ -192,5 +193,26 @@ def test_skm_lookup_filter_two_levels(gpu_ctx, oracle):
         assert np.array_equal(fk, keys[m]) and np.array_equal(fc, cnts[m])
         want_f = np.where(want > 1, want, -1)
         assert np.array_equal(f.lookup(probe), want_f)
+    finally:
+        _reset(gpu_ctx)
+
+
+def test_skm_one_pass_level1(gpu_ctx, oracle):
+    """level 1 in one pass (regions from a sampled histogram, chunk-wise allocation), also when the sample misleads:
+    reads sorted by genome make every third tile unrepresentative, the overflow must be detected and repaired"""
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(2024)
+    b, o = genome_reads(rng, 400_000, 120_000, 150, err=0.003)
+    srt, so = [], [0]
+    rl = 150
+    reads = b.reshape(-1, rl)
+    order = np.lexsort(reads.T[::-1][:8])                     # sorted reads: neighbouring tiles look alike, distant ones do not
+    bs = reads[order].reshape(-1).copy()
+    try:
+        gpu_ctx.set_option("part_target", 96)                 # two levels
+        for data in (b, bs):
+            for mode in (2, 0):
+                gpu_ctx.set_option("skm_dyn", mode)
+                _check(gpu_ctx, oracle, data, o, 31)
     finally:
         _reset(gpu_ctx)
