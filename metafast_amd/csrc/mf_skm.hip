@@ -506,12 +506,42 @@ __device__ __forceinline__ uint32_t skm_slot(uint64_t key) {
     f *= 0x9E3779B1u;
     return f >> 16;
 }
-// Four keys per lane, narrowing: ONE four-wide probe settles about nine keys in ten (first-probe hits and fresh slots);
-// what is left (keys that met a collision) goes on one key per lane at a time with one-wide steps.  Keeping the loop
-// four-wide until the last of the wave's 256 keys is placed costs 3.3 four-wide iterations on average, most of them LDS
-// instructions on dummy slots.
-__device__ __forceinline__ void skm_count_insert4n(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
-                                                   const uint64_t (&key)[4], unsigned int *overflow, int ablate = 0) {
+// Four keys per lane: ONE four-wide probe settles about nine keys in ten (first-probe hits and fresh slots).  The keys
+// that met a collision are not chased on the spot (that loop is wave-uniform: every unsettled key, anywhere in the wave,
+// costs all 64 lanes a round of LDS latencies, and keeping it four-wide costs 3.3 iterations on dummy slots): they go to
+// a small wave-private queue in LDS and are finished 64 at a time, one key per lane, when the queue has filled up.
+#define SKM_QN 128               // queue entries per wave
+struct skm_tailq { uint64_t *qk; uint16_t *qs; };
+// finish up to 64 queued keys (the last `c` entries), one per lane, by plain linear probing from their next slot
+__device__ __forceinline__ void skm_tail_drain(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
+                                               const skm_tailq &Q, uint32_t &qn, unsigned int *overflow) {
+    const uint32_t c = qn < 64u ? qn : 64u;
+    qn -= c;
+    bool p1 = (uint32_t)mf_lane() < c;
+    uint64_t k1[1] = {MF_EMPTY}; uint32_t s1 = 0;
+    if (p1) { k1[0] = Q.qk[qn + (uint32_t)mf_lane()]; s1 = Q.qs[qn + (uint32_t)mf_lane()]; }
+    for (uint32_t probes = 0;; probes++) {
+        if (__ballot(p1) == 0ull) break;
+        if (probes > mask) { if (mf_lane() == 0) atomicExch(overflow, 1u); break; }
+        uint32_t ka[1], ca[1], aa[1], inc[1]; uint64_t cur[1], ret[1];
+        ka[0] = p1 ? tk0 + 8u * s1 : dummy_k;
+        skm_lds_read_b64<1>(ka, cur);
+        const bool need = p1 && cur[0] == MF_EMPTY;
+        ca[0] = need ? ka[0] : dummy_k;
+        if (__ballot(need) != 0ull) {
+            skm_lds_cmpst_b64<1>(ca, MF_EMPTY, k1, ret);
+            if (need) cur[0] = ret[0] == MF_EMPTY ? k1[0] : ret[0];
+        }
+        const bool hit = p1 && cur[0] == k1[0];
+        aa[0] = hit ? tc0 + 4u * s1 : dummy_c;
+        inc[0] = hit ? 1u : 0u;
+        if (hit) p1 = false;
+        else s1 = (s1 + 1) & mask;
+        skm_lds_add<1>(aa, inc);
+    }
+}
+__device__ __forceinline__ void skm_count_insert4q(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
+                                                   const uint64_t (&key)[4], const skm_tailq &Q, uint32_t &qn, unsigned int *overflow, int ablate = 0) {
     uint32_t s[4]; bool pend[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = skm_slot(key[b]) & mask; }
@@ -537,33 +567,15 @@ __device__ __forceinline__ void skm_count_insert4n(uint32_t tk0, uint32_t tc0, u
         }
         mf_lds_add4(aa, inc);
     }
-    for (;;) {
-        const bool any = pend[0] | pend[1] | pend[2] | pend[3];
-        if (__ballot(any) == 0ull || ablate == 5) break;
-        // this lane's first unsettled key
-        const uint64_t k1[1] = {pend[0] ? key[0] : pend[1] ? key[1] : pend[2] ? key[2] : key[3]};
-        uint32_t s1 = pend[0] ? s[0] : pend[1] ? s[1] : pend[2] ? s[2] : s[3];
-        bool p1 = any;
-        if (pend[0]) pend[0] = false; else if (pend[1]) pend[1] = false; else if (pend[2]) pend[2] = false; else pend[3] = false;
-        for (uint32_t probes = 0;; probes++) {
-            if (__ballot(p1) == 0ull) break;
-            if (probes > mask) { if (mf_lane() == 0) atomicExch(overflow, 1u); break; }
-            uint32_t ka[1], ca[1], aa[1], inc[1]; uint64_t cur[1], ret[1];
-            ka[0] = p1 ? tk0 + 8u * s1 : dummy_k;
-            skm_lds_read_b64<1>(ka, cur);
-            const bool need = p1 && cur[0] == MF_EMPTY;
-            ca[0] = need ? ka[0] : dummy_k;
-            if (__ballot(need) != 0ull) {
-                skm_lds_cmpst_b64<1>(ca, MF_EMPTY, k1, ret);
-                if (need) cur[0] = ret[0] == MF_EMPTY ? k1[0] : ret[0];
-            }
-            const bool hit = p1 && cur[0] == k1[0];
-            aa[0] = hit ? tc0 + 4u * s1 : dummy_c;
-            inc[0] = hit ? 1u : 0u;
-            if (hit) p1 = false;
-            else s1 = (s1 + 1) & mask;
-            skm_lds_add<1>(aa, inc);
-        }
+    if (ablate == 5) return;
+    const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        const unsigned long long bal = __ballot(pend[b]);
+        if (bal == 0ull) continue;
+        if (pend[b]) { const uint32_t at = qn + (uint32_t)__popcll(bal & lt_mask); Q.qk[at] = key[b]; Q.qs[at] = (uint16_t)s[b]; }
+        qn += (uint32_t)__popcll(bal);
+        if (qn >= 64u) skm_tail_drain(tk0, tc0, dummy_k, dummy_c, mask, Q, qn, overflow);      // (qn < 64 + 64 <= SKM_QN)
     }
 }
 
@@ -587,7 +599,11 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
     uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS + 64);      // [MF_COUNT_SLOTS] + 64 dummy counters
     const uint32_t wave = threadIdx.x >> 6, lane = (uint32_t)mf_lane();
     skm_rec *rbuf = reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64) + wave * 64;              // [64] this wave's records
-    uint16_t *items = reinterpret_cast<uint16_t *>(reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64) + SKM_CT) + wave * 512;   // [64 * 8]
+    uint64_t *qk_all = reinterpret_cast<uint64_t *>(reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64) + SKM_CT);   // [waves][SKM_QN]
+    uint16_t *qs_all = reinterpret_cast<uint16_t *>(qk_all + (SKM_CT / 64) * SKM_QN);                                   // [waves][SKM_QN]
+    uint16_t *items = qs_all + (SKM_CT / 64) * SKM_QN + wave * 512;                                                     // [64 * 8]
+    skm_tailq Q; Q.qk = qk_all + wave * SKM_QN; Q.qs = qs_all + wave * SKM_QN;
+    uint32_t qn = 0;                                                                                                    // wave-uniform
     const uint32_t tk0 = mf_lds_addr(tk), tc0 = mf_lds_addr(tc);
     const uint32_t dummy_k = tk0 + 8u * ((uint32_t)MF_COUNT_SLOTS + lane);
     const uint32_t dummy_c = tc0 + 4u * ((uint32_t)MF_COUNT_SLOTS + lane);
@@ -602,10 +618,14 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
     uint32_t len = plen[p];
     uint64_t o = toff[p] - tbase; uint32_t room = (uint32_t)(toff[p + 1] - toff[p]);   // this partition's slice of the output lists
     skm_rec R = mine < len ? recs[start + mine] : SENT;                        // first round, prefetched
+    // directory entries are fetched TWO partitions ahead: the prefetch of the next partition's records needs its start,
+    // and waiting for that load at the top of every partition costs a global round trip per partition
+    uint64_t start_n = 0, o_n = 0; uint32_t len_n = 0, room_n = 0;
+    if (p + gridDim.x < np) { const uint32_t q = p + gridDim.x; start_n = pstart[q]; len_n = plen[q]; o_n = toff[q] - tbase; room_n = (uint32_t)(toff[q + 1] - toff[q]); }
     for (;;) {
-        const uint32_t pn = p + gridDim.x;
-        uint64_t start_n = 0, o_n = 0; uint32_t len_n = 0, room_n = 0;
-        if (pn < np) { start_n = pstart[pn]; len_n = plen[pn]; o_n = toff[pn] - tbase; room_n = (uint32_t)(toff[pn + 1] - toff[pn]); }   // (no load latency inside the compaction)
+        const uint32_t pn = p + gridDim.x, pnn = pn + gridDim.x;
+        uint64_t start_nn = 0, o_nn = 0; uint32_t len_nn = 0, room_nn = 0;
+        if (pnn < np) { start_nn = pstart[pnn]; len_nn = plen[pnn]; o_nn = toff[pnn] - tbase; room_nn = (uint32_t)(toff[pnn + 1] - toff[pnn]); }
         for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
         if (threadIdx.x == 0) out_cursor = 0;
         skm_rec cur = R;
@@ -640,9 +660,10 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                         rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fw & 3u)) << top);
                     }
                 }
-                if (ablate != 3) skm_count_insert4n(tk0, tc0, dummy_k, dummy_c, mask, k4, overflow, ablate);
+                if (ablate != 3) skm_count_insert4q(tk0, tc0, dummy_k, dummy_c, mask, k4, Q, qn, overflow, ablate);
                 else if ((k4[0] ^ k4[1] ^ k4[2] ^ k4[3]) == 0x1234567ull) tk[0] = k4[0];
             }
+            while (qn) skm_tail_drain(tk0, tc0, dummy_k, dummy_c, mask, Q, qn, overflow);       // wave-uniform
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
             __builtin_amdgcn_wave_barrier();
         }
@@ -680,6 +701,7 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
         if (threadIdx.x == 0) dcount[p] = out_cursor;
         if (pn >= np) break;
         p = pn; start = start_n; len = len_n; o = o_n; room = room_n;
+        start_n = start_nn; len_n = len_nn; o_n = o_nn; room_n = room_nn;
     }
 }
 
@@ -841,14 +863,14 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     mf_buf<uint64_t> dk; mf_buf<uint16_t> dc;
     uint64_t dused = 0, dcap = 0;
     {
-        const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 8 * 2;
+        const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 8 * 2 + (size_t)(SKM_CT / 64) * SKM_QN * 10;
         MF_TRY(skm_set_lds(k_skm_count<K>, lds));
     }
     for (uint32_t b = 0; b < nbatch; b++) {
         const uint32_t p0 = (uint32_t)std::min<uint64_t>((uint64_t)b * PB, np), p1 = (uint32_t)std::min<uint64_t>((uint64_t)(b + 1) * PB, np);
         if (p0 == p1) continue;
         {
-            const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 8 * 2;
+            const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 8 * 2 + (size_t)(SKM_CT / 64) * SKM_QN * 10;
             const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);
             mf_ktimer t(ctx, "k_skm_count");
             k_skm_count<K><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],

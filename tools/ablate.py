@@ -20,4 +20,4 @@ for ab in (0, 3, 4, 5, 6, 0):
     except Exception as e:
         print("ablate", ab, "error (expected for 1/2):", str(e)[:80])
     rep = ctx.kernel_report()
-    print("ablate", ab, {k: round(v[2], 2) for k, v in rep.items() if k.startswith("k_skm") or k in ("k_l1_hist", "k_l1_scatter", "k_split", "k_count")}, flush=True)
+    print("ablate", ab, {k: round(v[1], 2) for k, v in rep.items() if k.startswith("k_skm") or k in ("k_l1_hist", "k_l1_scatter", "k_split", "k_count")}, flush=True)
