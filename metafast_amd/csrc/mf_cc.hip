@@ -86,12 +86,30 @@ __global__ void k_cc_flatten_stats(const uint8_t *__restrict__ alive, const uint
                                    uint32_t *__restrict__ root, const uint16_t *__restrict__ vals,
                                    uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight, uint64_t n) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n || !alive[v]) return;
-    uint32_t r = (uint32_t)v;
-    for (;;) { uint32_t p = parent[r]; if (p == r) break; r = p; }
-    root[v] = r;
-    atomicAdd(&csize[r], 1u);
-    atomicAdd(&cweight[r], (unsigned long long)vals[v]);
+    bool act = v < n && alive[v];
+    uint32_t r = 0, w = 0;
+    if (act) {
+        r = (uint32_t)v;
+        for (;;) { uint32_t p = parent[r]; if (p == r) break; r = p; }
+        root[v] = r;
+        w = vals[v];
+    }
+    // size / weight of the components: the lanes of a wave mostly belong to ONE component (the giant one holds most of the
+    // graph), and an atomic per vertex on its root's two counters serialises (9 of the 38 ms of the components step,
+    // 69 of 205 ms on the union of 8 samples): one atomic pair per distinct root and wave, a few rounds, then singly
+    unsigned long long todo = __ballot(act);
+    for (int round = 0; round < 4 && todo; round++) {               // wave-uniform
+        const int lead = __ffsll((long long)todo) - 1;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, lead);
+        const bool in = act && r == r0;
+        const unsigned long long grp = __ballot(in);
+        uint32_t tot;
+        mf_wave_excl_scan(in ? w : 0u, &tot);
+        if (mf_lane() == lead) { atomicAdd(&csize[r0], (uint32_t)__popcll(grp)); atomicAdd(&cweight[r0], (unsigned long long)tot); }
+        if (in) act = false;
+        todo &= ~grp;
+    }
+    if (act) { atomicAdd(&csize[r], 1u); atomicAdd(&cweight[r], (unsigned long long)w); }
 }
 // per root: classify; kept roots get a slot in the kept list (SoA: root / size / weight / smallest k-mer)
 struct cc_kept_arrays { uint32_t *root; uint32_t *size; unsigned long long *weight; unsigned long long *minkey; };
@@ -119,18 +137,44 @@ __global__ void k_cc_members(uint8_t *__restrict__ alive, const uint32_t *__rest
                              unsigned long long *__restrict__ minkey, uint64_t *__restrict__ members,
                              uint32_t *__restrict__ member_comp) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n || !alive[v]) return;
-    uint32_t r = parent[v];
-    uint32_t s = csize[r];
-    if (s > b2) { if ((uint32_t)vals[v] < next_thr) alive[v] = 0; return; }
-    alive[v] = 0;
-    if (s < b1) return;
-    uint32_t slot = keptslot[r];
-    uint32_t pos = atomicAdd(&slot_fill[slot], 1u);
-    uint64_t key = keys[v];
-    members[slot_off[slot] + pos] = key;
-    member_comp[slot_off[slot] + pos] = comp_base + slot;
-    atomicMin(&minkey[slot], (unsigned long long)key);
+    bool put = false;
+    uint32_t slot = 0; uint64_t key = 0;
+    if (v < n && alive[v]) {
+        const uint32_t r = parent[v];
+        const uint32_t s = csize[r];
+        if (s > b2) { if ((uint32_t)vals[v] < next_thr) alive[v] = 0; }
+        else {
+            alive[v] = 0;
+            if (s >= b1) { put = true; slot = keptslot[r]; key = keys[v]; }
+        }
+    }
+    // positions in the member lists: one cursor atomic per distinct component and wave (see k_cc_flatten_stats)
+    unsigned long long todo = __ballot(put);
+    const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
+    for (int round = 0; round < 4 && todo; round++) {               // wave-uniform
+        const int lead = __ffsll((long long)todo) - 1;
+        const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)slot, lead);
+        const bool in = put && slot == s0;
+        const unsigned long long grp = __ballot(in);
+        uint64_t mk = in ? key : ~0ull;
+        for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = __shfl_xor(mk, d, 64); mk = o < mk ? o : mk; }
+        uint32_t base = 0;
+        if (mf_lane() == lead) { base = atomicAdd(&slot_fill[s0], (uint32_t)__popcll(grp)); atomicMin(&minkey[s0], (unsigned long long)mk); }
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, lead);
+        if (in) {
+            const uint64_t at = slot_off[s0] + base + (uint32_t)__popcll(grp & lt_mask);
+            members[at] = key;
+            member_comp[at] = comp_base + s0;
+            put = false;
+        }
+        todo &= ~grp;
+    }
+    if (put) {
+        const uint32_t pos = atomicAdd(&slot_fill[slot], 1u);
+        members[slot_off[slot] + pos] = key;
+        member_comp[slot_off[slot] + pos] = comp_base + slot;
+        atomicMin(&minkey[slot], (unsigned long long)key);
+    }
 }
 __global__ void k_cc_remap(uint32_t *__restrict__ comp, uint64_t n, const uint32_t *__restrict__ rank) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
