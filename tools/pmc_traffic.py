@@ -1,26 +1,30 @@
 """HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) -> profiles/traffic_<tag>.json
 usage: python tools/pmc_traffic.py gpurun_out/pmc_<tag> profiles/traffic_100M.json
 FETCH_SIZE / WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads
-(MI355X_MICROARCH.md, HBM section), so it is doubled.  The largest dispatch of each kernel is the sample launch."""
+(MI355X_MICROARCH.md, HBM section), so it is doubled.  The largest dispatch of each kernel is the sample launch; kernels that
+work through the sample in several launches (k_skm_count / k_gather: 8 batches, the walks: rounds) are summed over the
+step (the passes run bench.py with --steps 1 --warmup 0, so that is one step; the small cutter-table launches are in)."""
 import csv, json, os, sys
 tag, out = sys.argv[1], sys.argv[2]
 res = {}
 for d, cname in ((tag + "_c", "FETCH_SIZE"), (tag + "_d", "WRITE_SIZE")):
     rows = list(csv.DictReader(open(os.path.join(d, "p_counter_collection.csv"))))
-    best = {}
+    best, tot, cnt = {}, {}, {}
     for r in rows:
         if r["Counter_Name"] != cname:
             continue
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         v = float(r["Counter_Value"])
-        if v > best.get(name, 0):
-            best[name] = v
-    for n, v in best.items():
-        res.setdefault(n, {})[cname] = v
+        best[name] = max(best.get(name, 0.0), v)
+        tot[name] = tot.get(name, 0.0) + v
+        cnt[name] = cnt.get(name, 0) + 1
+    for n in best:
+        res.setdefault(n, {})[cname] = tot[n] if cnt[n] > 3 else best[n]
+        res[n]["dispatches"] = cnt[n]
 final = {}
 for n, v in res.items():
     f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
     final[n] = {"hbm_GB": round((2 * f + w) * 1024 / 1e9, 3), "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB": w,
-                "note": "2*FETCH_SIZE+WRITE_SIZE, per sample launch"}
+                "note": "2*FETCH_SIZE+WRITE_SIZE, " + ("summed over the %d launches of one step" % v["dispatches"] if v.get("dispatches", 1) > 3 else "per sample launch")}
 json.dump(final, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v["hbm_GB"] for k, v in final.items()}, indent=0))
