@@ -4,16 +4,19 @@
 // BigLong2ShortHashMap.addAndBound(canonical, 1)), same result (dense (key,count) arrays), different traffic: the
 // one-record-per-k-mer path moves 8 bytes per k-mer OCCURRENCE through two radix passes and the count pass (3 x 96 GB
 // at 1.2e10 occurrences).  Here a read is cut into runs of consecutive k-mers that share their minimizer (mf_common.h),
-// and a run of r k-mers travels as ONE 16-byte record holding its r+k-1 bases (about 9 k-mers per record at k=31):
+// and a run of r k-mers travels as ONE 16-byte record holding its r+k-1 bases (about 7 k-mers per record at k=31):
 //
 //   S1 k_skm_hist     ASCII -> 2-bit -> M-mer hashes -> sliding-window minimum -> runs; per-block histogram of the
-//                     records' level-1 digit (top bits of the partition hash of the run's minimizer)
-//      k_scan         exact output ranges (padded to whole 64-byte lines)
-//   S2 k_skm_scatter  same scan again, records built and radix-partitioned through 64-byte LDS staging lines
+//                     records' level-1 digit (top bits of the partition hash of the run's minimizer).  On large inputs it
+//                     runs over every 16th tile only and just SIZES the digit regions
+//      k_scan         region starts / exact output ranges (padded to whole 64-byte lines)
+//   S2 k_skm_scatter  the minimizer scan (again, where S1 ran over everything), records built and radix-partitioned through
+//                     64-byte LDS staging lines; one-pass form: regions reserved chunk by chunk during the scatter
 //   S3 k_skm_split    further levels: the digit is read from the record (22 digit bits travel with it)
-//   S4 k_skm_count    one partition per 512-thread workgroup: records -> canonical k-mers (LDS buffer, lane-balanced)
-//                     -> open-addressed count table in LDS -> compacted (key,count) lists
-//      k_gather       dense arrays, grouped by partition (the HBM index is built partition by partition, mf_table.hip)
+//   S4 k_skm_count    one partition per 512-thread workgroup: every wave deals its records out as items of <= 4 k-mers
+//                     -> open-addressed count table in LDS -> compacted (key,count) slices; a batch of partitions at a time
+//      k_gather       slices of the batch -> dense arrays, grouped by partition (the HBM index is built partition by
+//                     partition, mf_table.hip)
 //
 // A partition holds ALL occurrences of its k-mers, so the counts are exact; only the grouping of the dense table
 // differs from mf_count.hip (by minimizer partition instead of by hash partition).  If a partition has more distinct
