@@ -49,14 +49,14 @@ def algorithmic_bytes(kernel, s):
         "k_skm_hist": nb + nb / 8,                      # ASCII bases + valid-start bitmap
         "k_skm_scatter": nb + nb / 8 + rec,             # + every record written once
         "k_skm_split": 3 * rec,                         # histogram read + scatter read + write
-        "k_skm_count": rec + 10 * dist_,                # records read + (8 B key + 2 B count) per distinct k-mer
+        "k_skm_count": rec + 10 * good,                 # records read + (8 B key + 2 B count) per KEPT k-mer (count > b)
         # one-record-per-k-mer path (k < 20, option skm=0)
         "k_mask": nb / 8 * 2 + s["n_reads"] * 8,
         "k_l1_hist": nb + nb / 8,                       # ASCII bases + valid-start bitmap
         "k_l1_scatter": nb + nb / 8 + 8 * occ,          # + one 8-byte k-mer written per occurrence
         "k_split": 16 * occ + 8 * occ,                  # histogram read + scatter read + write
         "k_count": 8 * occ + 10 * dist_,                # stream read + (8 B key + 2 B count) per distinct k-mer
-        "k_gather": 20 * dist_,
+        "k_gather": 20 * (good if rec and s.get("record_bytes") == 16 else dist_),
         "k_ut_flags": 105 * good,
     }.get(kernel)
 
@@ -112,11 +112,11 @@ def main():
     def step(timings=None):
         r = P.run_sample(ctx, bases, offsets, n_reads, n_bases, k=k, b=1, l=100, b1=args.b1, b2=args.b2, device=device,
                          timings=timings)
-        nrec, rbytes = r["table"].records()
-        stats = dict(n_occ=r["n_occ"], n_distinct=len(r["table"]), n_good=len(r["good"]), n_unitigs=len(r["seqs"]),
+        nrec, rbytes = r["good"].records()
+        stats = dict(n_occ=r["n_occ"], n_distinct=r["n_distinct"], n_good=len(r["good"]), n_unitigs=len(r["seqs"]),
                      n_cutter=len(r["cutter"]), n_components=len(r["comps"]), n_reads=n_reads, n_bases=n_bases,
                      n_records=nrec, record_bytes=rbytes)
-        for key in ("table", "good", "seqs", "cutter", "comps"):
+        for key in ("good", "seqs", "cutter", "comps"):
             r[key].close()
         return stats, r["matrix"]
 

@@ -82,6 +82,13 @@ int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles, int k, int
  * ReadsLoadWorker.process (src/io/IOUtils.java:756-768). */
 int mf_count_device(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads,
                     uint64_t n_bases, int k, int min_read_len, mf_table **out);
+/* Same counting pass, but only the k-mers with count > threshold are kept (what KmersCounterMain hands on: IOUtils.printKmers
+ * writes the entries with value > maximalBadFrequency, src/io/IOUtils.java:52-60; src/tools/KmersCounterMain.java:99) -- the
+ * rejected entries are dropped inside the counting kernels instead of being written out and filtered afterwards.
+ * *n_distinct_all (may be NULL) = number of distinct k-mers before the cut (BigLong2ShortHashMap.size()). */
+int mf_count_device_above(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads,
+                          uint64_t n_bases, int k, int min_read_len, int threshold, mf_table **out,
+                          uint64_t *n_distinct_all);
 void mf_table_destroy(mf_table *t);
 /* BigLong2ShortHashMap.size() and the sum of all (saturated) values */
 int mf_table_stats(const mf_table *t, uint64_t *n_distinct, uint64_t *n_total);

@@ -22,7 +22,7 @@
 #include <vector>
 
 int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
-                 int k, const std::vector<int> &lv, unsigned long long *scal, mf_table **out);
+                 int k, const std::vector<int> &lv, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out);
 
 // =============================================================================================
 // K0: valid-start bitmap
@@ -591,8 +591,10 @@ template <typename K> static int set_lds(K kern, size_t bytes) {
     return MF_OK;
 }
 
+// thr >= 0: keep only the k-mers with count > thr (*n_all = distinct k-mers before the cut); thr < 0: keep everything
 int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases,
-                  int k, int min_len, mf_table **out) {
+                  int k, int min_len, mf_table **out, int thr, uint64_t *n_all) {
+    if (n_all) *n_all = 0;
     if (k < 1) return mf_set_error("The size of k-mer must be at least 1.");           // KmersCounterMain.java:66-69
     if (k > 31) return mf_set_error("The size of k-mer must be no more than 31.");     // KmersCounterMain.java:70-73
     if (((uintptr_t)d_bases & 15) != 0) return mf_set_error("mf_count_device: d_bases must be 16-byte aligned");
@@ -641,7 +643,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
 
     // ---- super-k-mer path (mf_skm.hip); falls through to the k-mer path below if the input does not suit it ----
     if (ctx->opt_skm && k >= MF_SKM_MIN_K) {
-        int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, lv, scal.p, out);
+        int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, lv, scal.p, thr, n_all, out);
         if (rc != MF_SKM_FALLBACK) return rc;
     }
 
@@ -761,6 +763,15 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         (*out)->part_off_bytes = doff.bytes();
         (*out)->d_part_off = doff.take();
     }
+    if (n_all) *n_all = n_dist;
+    if (thr >= 0) {                                     // (this path keeps the cut as a separate pass)
+        mf_table *all = *out, *good = nullptr;
+        int rc = mf_table_filter(all, thr, &good);
+        if (rc == MF_OK) { good->n_occ = all->n_occ; good->n_records = all->n_records; good->record_bytes = all->record_bytes; }
+        mf_table_destroy(all);
+        *out = good;
+        return rc;
+    }
     return MF_OK;
 }
 
@@ -782,5 +793,13 @@ extern "C" int mf_count_device(mf_ctx *ctx, const void *d_bases, const void *d_o
                                uint64_t n_bases, int k, int min_read_len, mf_table **out) {
     if (!ctx || !out) return mf_set_error("mf_count_device: NULL argument");
     *out = nullptr;
-    return mf_count_core(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, min_read_len, out);
+    return mf_count_core(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, min_read_len, out, -1, nullptr);
+}
+extern "C" int mf_count_device_above(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads,
+                                     uint64_t n_bases, int k, int min_read_len, int threshold, mf_table **out,
+                                     uint64_t *n_distinct_all) {
+    if (!ctx || !out) return mf_set_error("mf_count_device_above: NULL argument");
+    *out = nullptr;
+    return mf_count_core(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, min_read_len, out,
+                         threshold < 0 ? -1 : threshold, n_distinct_all);
 }

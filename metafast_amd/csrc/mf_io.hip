@@ -14,7 +14,7 @@
 #include <vector>
 
 int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k,
-                  int min_len, mf_table **out);
+                  int min_len, mf_table **out, int thr, uint64_t *n_all);
 int mf_table_count_hist(const mf_table *t, std::vector<uint64_t> &hist);
 int mf_seqs_to_host(const mf_seqs *s, std::vector<uint8_t> &bases, std::vector<uint64_t> &off, std::vector<int32_t> &avg,
                     std::vector<int32_t> &mn, std::vector<int32_t> &mx);
@@ -379,7 +379,7 @@ extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles,
     MF_HIP(hipStreamSynchronize(ctx->stream));
     const double t2 = now();
     parts.clear();
-    int rc = mf_count_core(ctx, db.p, doff.p, nr, nb, k, min_read_len, out);
+    int rc = mf_count_core(ctx, db.p, doff.p, nr, nb, k, min_read_len, out, -1, nullptr);
     if (ctx->opt_verbose)
         fprintf(stderr, "[mf] count_reads: read+parse %.3f s, offsets+H2D %.3f s, count %.3f s (%llu reads, %llu bases, %d host threads)\n",
                 t1 - t0, t2 - t1, now() - t2, (unsigned long long)nr, (unsigned long long)nb, ctx->host_threads);

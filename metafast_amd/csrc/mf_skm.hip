@@ -594,10 +594,13 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                                                       const uint32_t *__restrict__ plen, uint32_t np,
                                                       const uint64_t *__restrict__ toff, uint64_t *__restrict__ tkeys,
                                                       uint16_t *__restrict__ tcnt, uint32_t *__restrict__ dcount,
-                                                      unsigned int *__restrict__ overflow, int ablate, uint32_t p0, uint64_t tbase) {
+                                                      unsigned int *__restrict__ overflow, int ablate, uint32_t p0, uint64_t tbase,
+                                                      int thr, unsigned long long *__restrict__ n_all) {
+    // thr >= 0: only the k-mers with count > thr are written; *n_all += distinct k-mers of the partitions (all of them)
     // partitions [p0, np); tkeys / tcnt hold the slices of this batch only: slice of p starts at toff[p] - tbase
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t out_cursor;
+    __shared__ uint32_t out_cursor, all_cursor;
+    unsigned long long all_acc = 0;                                             // thread 0: distinct k-mers of this workgroup's partitions
     uint64_t *tk = reinterpret_cast<uint64_t *>(smem);                          // [MF_COUNT_SLOTS] + 64 dummy slots
     uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS + 64);      // [MF_COUNT_SLOTS] + 64 dummy counters
     const uint32_t wave = threadIdx.x >> 6, lane = (uint32_t)mf_lane();
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
         uint64_t start_nn = 0, o_nn = 0; uint32_t len_nn = 0, room_nn = 0;
         if (pnn < np) { start_nn = pstart[pnn]; len_nn = plen[pnn]; o_nn = toff[pnn] - tbase; room_nn = (uint32_t)(toff[pnn + 1] - toff[pnn]); }
         for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
-        if (threadIdx.x == 0) out_cursor = 0;
+        if (threadIdx.x == 0) { out_cursor = 0; all_cursor = 0; }
         skm_rec cur = R;
         if (pn < np) R = mine < len_n ? recs[start_n + mine] : SENT;           // next partition's first round
         __syncthreads();
@@ -676,18 +679,21 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
         // output range with ONE LDS atomic
         {
             constexpr int NCH = MF_COUNT_SLOTS / SKM_CT;
-            uint64_t ck[NCH]; uint32_t cv[NCH], pre[NCH]; uint32_t total = 0;
+            uint64_t ck[NCH]; uint32_t cv[NCH], pre[NCH]; uint32_t total = 0, total_all = 0;
             const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 const uint32_t sl = ((threadIdx.x >> 6) << 6) + (uint32_t)i * SKM_CT + (uint32_t)mf_lane();
                 ck[i] = tk[sl]; cv[i] = tc[sl];
                 if (ablate == 6 && i > 0) ck[i] = MF_EMPTY;
+                total_all += (uint32_t)__popcll(__ballot(ck[i] != MF_EMPTY));
+                if ((int)(cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]) <= thr) ck[i] = MF_EMPTY;     // (thr < 0 keeps everything)
                 const unsigned long long bal = __ballot(ck[i] != MF_EMPTY);
                 pre[i] = total + (uint32_t)__popcll(bal & lt_mask);
                 total += (uint32_t)__popcll(bal);
             }
             uint32_t wb = 0;
+            if (mf_lane() == 0 && total_all) atomicAdd(&all_cursor, total_all);
             if (mf_lane() == 0 && total) wb = atomicAdd(&out_cursor, total);
             wb = __shfl(wb, 0, 64);
             if (mf_lane() == 0 && wb + total > room) atomicExch(overflow, 1u);      // (only if a partition's k-mer count wrapped)
@@ -701,11 +707,12 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
             }
         }
         __syncthreads();
-        if (threadIdx.x == 0) dcount[p] = out_cursor;
+        if (threadIdx.x == 0) { dcount[p] = out_cursor; all_acc += all_cursor; }
         if (pn >= np) break;
         p = pn; start = start_n; len = len_n; o = o_n; room = room_n;
         start_n = start_nn; len_n = len_nn; o_n = o_nn; room_n = room_nn;
     }
+    if (threadIdx.x == 0 && n_all && all_acc) atomicAdd(n_all, all_acc);
 }
 
 __global__ void k_skm_add_base(uint64_t *__restrict__ v, uint64_t n, uint64_t base) {
@@ -731,7 +738,7 @@ template <typename KF> static int skm_set_lds(KF kern, size_t bytes) {
 // input does not suit this path (a partition too rich for the LDS table, too many levels, not enough memory).
 template <int K>
 static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words,
-                   uint64_t n_occ, const std::vector<int> &lv, unsigned long long *scal, mf_table **out) {
+                   uint64_t n_occ, const std::vector<int> &lv, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
     hipStream_t st = ctx->stream;
     const int bits1 = lv[0], nd1 = 1 << bits1;
     int total_bits = 0; for (int b : lv) total_bits += b;
@@ -808,7 +815,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         k_skm_dir<<<(nd1 + 255) / 256, 256, 0, st>>>(blockstart.p, blockocc.p, G, nd1, pstart.p, plen.p, pocc.p);
     }
 
-    MF_HIP(hipMemsetAsync(&scal[6], 0, 8, st));
+    MF_HIP(hipMemsetAsync(&scal[6], 0, 16, st));          // [6] records without padding, [7] distinct k-mers before the cut
     const unsigned long long cap_l1 = cap;
     int used = 0;
     for (size_t li = 1; li < lv.size(); li++) {
@@ -877,7 +884,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);
             mf_ktimer t(ctx, "k_skm_count");
             k_skm_count<K><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
-                                                      (int)ctx->opt_ablate, p0, (uint64_t)tb[b]);
+                                                      (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr, &scal[7]);
         }
         MF_DBG(ctx, "k_skm_count");
         MF_TRY(mf_scan<1>(ctx, dcount.p + p0, doff.p + p0, p1 - p0, (uint64_t *)&scal[3]));      // offsets inside the batch
@@ -926,9 +933,11 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     const size_t kb = dk.bytes(), cb = dc.bytes();       // (capacity: may be a little larger than n_dist)
     MF_TRY(mf_table_adopt(ctx, K, n_dist, n_occ, dk.take(), kb, dc.take(), cb, out));
     {
-        unsigned long long nv = 0;
-        MF_HIP(hipMemcpyAsync(&nv, &scal[6], 8, hipMemcpyDeviceToHost, st));
+        unsigned long long nv2[2] = {0, 0};
+        MF_HIP(hipMemcpyAsync(nv2, &scal[6], 16, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
+        const unsigned long long nv = nv2[0];
+        if (n_all) *n_all = nv2[1];
         (*out)->n_records = nv ? nv : cap_l1;             // (plans without a split level: the padded level-1 count)
         (*out)->record_bytes = 16;
     }
@@ -942,9 +951,9 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
 }
 
 int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
-                 int k, const std::vector<int> &lv, unsigned long long *scal, mf_table **out) {
+                 int k, const std::vector<int> &lv, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
     switch (k) {
-#define SKM_CASE(KK) case KK: return skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, out);
+#define SKM_CASE(KK) case KK: return skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, thr, n_all, out);
         SKM_CASE(20) SKM_CASE(21) SKM_CASE(22) SKM_CASE(23) SKM_CASE(24) SKM_CASE(25)
         SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29) SKM_CASE(30) SKM_CASE(31)
 #undef SKM_CASE

@@ -33,6 +33,7 @@ _SIGS = {
     "mf_ctx_reset_timers": (i32, [vp]),
     "mf_count_reads": (i32, [vp, C.POINTER(cp), i32, i32, i32, pvp]),
     "mf_count_device": (i32, [vp, vp, vp, u64, u64, i32, i32, pvp]),
+    "mf_count_device_above": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, pvp, pu64]),
     "mf_table_destroy": (None, [vp]),
     "mf_table_stats": (i32, [vp, pu64, pu64]),
     "mf_table_occurrences": (i32, [vp, pu64]),
@@ -169,6 +170,15 @@ class Context:
         _check(lib().mf_count_device(self.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k,
                                      min_read_len, C.byref(t)))
         return Table(self, t)
+
+    def count_device_above(self, d_bases, d_offsets, n_reads, n_bases, k, threshold, min_read_len=0):
+        """count, keeping only the k-mers with count > threshold (what the k-mer counter hands on, IOUtils.printKmers);
+        -> (Table of the kept k-mers, number of distinct k-mers before the cut)"""
+        t = C.c_void_p()
+        n_all = C.c_uint64()
+        _check(lib().mf_count_device_above(self.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k,
+                                           min_read_len, threshold, C.byref(t), C.byref(n_all)))
+        return Table(self, t), n_all.value
 
     def load_kmers(self, files, freq_threshold, k):
         """IOUtils.loadKmers (src/io/IOUtils.java:369-401)"""

@@ -103,9 +103,9 @@ def run_sample(ctx, d_bases, d_offsets, n_reads, n_bases, k=31, b=1, l=100, b1=1
             timings[name] = timings.get(name, 0.0) + (t1 - t0)
             t0 = t1
 
-    table = ctx.count_device(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, k, 0)
+    # kmer-counter: k-mers with count > b go on (IOUtils.printKmers); the others are dropped inside the counting kernels
+    good, n_distinct = ctx.count_device_above(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, k, b)
     mark("count")
-    good = table.filter(b)
     seqs = ctx.build_unitigs(good, b, l)
     mark("unitigs")
     v = seqs.device_view()
@@ -125,5 +125,5 @@ def run_sample(ctx, d_bases, d_offsets, n_reads, n_bases, k=31, b=1, l=100, b1=1
     vecs = gather_vectors(vt).cpu().numpy()
     matrix = L.bray_curtis(vecs) if vecs.shape[1] else np.zeros((vecs.shape[0], vecs.shape[0]))
     mark("features_matrix")
-    return dict(table=table, good=good, seqs=seqs, cutter=cutter, comps=comps, vec=vec, breadth=breadth, vecs=vecs,
-                matrix=matrix, n_occ=table.occurrences())
+    return dict(good=good, seqs=seqs, cutter=cutter, comps=comps, vec=vec, breadth=breadth, vecs=vecs,
+                matrix=matrix, n_occ=good.occurrences(), n_distinct=n_distinct)

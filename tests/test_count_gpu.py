@@ -216,3 +216,32 @@ def test_skm_one_pass_level1(gpu_ctx, oracle):
                 _check(gpu_ctx, oracle, data, o, 31)
     finally:
         _reset(gpu_ctx)
+
+
+@pytest.mark.parametrize("skm", [1, 0])
+def test_count_above_threshold(gpu_ctx, oracle, skm):
+    """mf_count_device_above = count + IOUtils.printKmers' cut (count > threshold), done inside the counting kernels on the
+    super-k-mer path: same entries as count_device().filter(), plus the number of distinct k-mers before the cut"""
+    from util import to_device
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(91)
+    b, o = genome_reads(rng, 60_000, 20_000, 150, err=0.01)
+    tb, to = to_device(b, o)
+    ok, ov = oracle.Table().count_buffer(b, o, 31).export()
+    try:
+        gpu_ctx.set_option("skm", skm)
+        for target, batches in ((3072, 0), (96, 3)):
+            gpu_ctx.set_option("part_target", target)
+            gpu_ctx.set_option("skm_batches", batches)
+            for thr in (0, 1, 3, 40):
+                t, n_all = gpu_ctx.count_device_above(tb.data_ptr(), to.data_ptr(), len(o) - 1, int(o[-1]), 31, thr)
+                gk, gc = t.export()
+                m = ov > thr
+                assert n_all == len(ok)
+                assert np.array_equal(gk, ok[m]) and np.array_equal(gc.astype(np.int32), ov[m])
+                assert t.occurrences() == int(np.maximum(np.diff(o.astype(np.int64)) - 30, 0).sum())
+                probe = np.concatenate([ok[:50], ok[-50:]])
+                want = np.array([int(v) if v > thr else -1 for v in np.concatenate([ov[:50], ov[-50:]])], dtype=np.int32)
+                assert np.array_equal(t.lookup(probe), want)
+    finally:
+        _reset(gpu_ctx)

@@ -195,3 +195,22 @@ def test_pipeline_synthetic_samples(gpu_ctx, oracle):
     assert len(gc) > 0
     m = L.bray_curtis(vecs)
     assert abs(m - oracle.bray_curtis(vecs)).max() <= 1e-6
+
+
+def test_run_sample_single_gpu(gpu_ctx, oracle, ref_files):
+    """the device-resident driver bench.py times (metafast_amd.pipeline.run_sample) on one sample = the oracle's pipeline"""
+    import torch
+    from metafast_amd import pipeline as P
+    from util import to_device
+    f = ref_files[0]
+    b, o = oracle.read_file(f)
+    tb, to = to_device(b, o)
+    r = P.run_sample(gpu_ctx, tb, to, len(o) - 1, int(o[-1]), k=31, b=1, l=100, b1=1000, b2=10000, device="cuda")
+    want = oracle.run_pipeline([f])
+    s = want["samples"][0]
+    assert r["n_distinct"] == s["n_distinct"] and len(r["good"]) == s["n_good"]
+    assert len(r["seqs"]) == len(s["seqs"]) and len(r["comps"]) == len(want["comps"])
+    assert r["vec"].tolist() == want["vecs"][0].tolist()
+    assert r["matrix"].shape == (1, 1) and r["matrix"][0, 0] == 0.0
+    for key in ("good", "seqs", "cutter", "comps"):
+        r[key].close()
