@@ -761,7 +761,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     // from a histogram of a sixteenth of the input and handed out chunk-wise during the scatter, instead of a full
     // minimizer pass just to count (k_skm_hist over everything costs 17 ms of 300 at 100 M reads).  If a region turns out
     // too small the level is repeated with exact ranges.  skm_dyn: 0 never, 1 auto, 2 always (tests).
-    bool dyn = !l1_only && (ctx->opt_skm_dyn == 2 || (ctx->opt_skm_dyn == 1 && n_words >= (1ull << 22)));
+    bool dyn = !l1_only && (ctx->opt_skm_dyn == 2 || (ctx->opt_skm_dyn == 1 && n_words >= (1ull << 24)));
     for (int attempt = dyn ? 0 : 1; attempt < 2; attempt++) {
         const bool D = attempt == 0;
         const int stride = D ? (ctx->opt_skm_dyn == 2 ? 3 : 16) : 1;
