@@ -643,7 +643,14 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
 
     // ---- super-k-mer path (mf_skm.hip); falls through to the k-mer path below if the input does not suit it ----
     if (ctx->opt_skm && k >= MF_SKM_MIN_K) {
-        int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, lv, scal.p, thr, n_all, out);
+        // A third radix level costs a whole extra pass over the records (k = 21, 100 M reads: 23 bits, +96 ms).  The LDS table
+        // limits a partition's DISTINCT k-mers, the plan sizes it by occurrences: up to twice the target is tried with two
+        // full levels first (if a partition turns out too rich the call ends up on the k-mer path, with its own plan).
+        std::vector<int> slv = lv;
+        if (ctx->opt_l1_bits < 0 && slv.size() == 3 && total_bits <= 2 * MF_MAX_DIGIT_BITS + 1 &&
+            (n_occ >> (2 * MF_MAX_DIGIT_BITS)) <= 2 * target)
+            slv = {MF_MAX_DIGIT_BITS, MF_MAX_DIGIT_BITS};
+        int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, slv, scal.p, thr, n_all, out);
         if (rc != MF_SKM_FALLBACK) return rc;
     }
 
