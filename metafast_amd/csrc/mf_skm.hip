@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t skm_rec_digits(const skm_rec &r) { return (u
 template <int K> struct skm_word {
     static constexpr int W = K - MF_SKM_M + 1;          // M-mers per k-mer
     static constexpr int NM = 31 + W;                   // M-mers of the word's 32 k-mers
-    static constexpr int RMAX = (MF_SKM_BASES - (K - 1)) < 32 ? (MF_SKM_BASES - (K - 1)) : 32;   // k-mers per record
+    static constexpr int RMAX = (MF_SKM_BASES - (K - 1)) < 24 ? (MF_SKM_BASES - (K - 1)) : 24;   // k-mers per record (<= 6 items of 4 in k_skm_count)
     uint32_t D[4];        // 64 bases from the word's first position, 2 bits each, first base in the top bits of D[0]
     uint32_t mh[32];      // minimizer hash of the k-mer at each position
     uint32_t valid;       // positions that start a k-mer (from the bitmap)
@@ -514,10 +514,27 @@ __device__ __forceinline__ uint32_t skm_slot(uint64_t key) {
 // costs all 64 lanes a round of LDS latencies, and keeping it four-wide costs 3.3 iterations on dummy slots): they go to
 // a small wave-private queue in LDS and are finished 64 at a time, one key per lane, when the queue has filled up.
 #define SKM_QN 128               // queue entries per wave
-struct skm_tailq { uint64_t *qk; uint16_t *qs; };
+#define SKM_CLN 384              // claimed-slot list entries per wave (more claims in one partition: the table is swept in full)
+struct skm_tailq { uint64_t *qk; uint16_t *qs; uint16_t *cl; };
+// Every slot a wave claims (CAS won) goes to the wave's list: the compaction visits and clears the claimed slots only
+// instead of sweeping and re-initialising all 4096 (a partition claims about a tenth of them).  cnt = this lane's claims
+// among slot[0..B): one wave scan places them all.  ncl may run past SKM_CLN: the caller checks.
+template <int B>
+__device__ __forceinline__ void skm_note_claims(const skm_tailq &Q, uint32_t &ncl, const bool (&claimed)[B], const uint32_t (&slot)[B]) {
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int b = 0; b < B; b++) cnt += claimed[b] ? 1u : 0u;
+    if (__ballot(cnt != 0u) == 0ull) return;
+    uint32_t tot;
+    uint32_t at = ncl + mf_wave_excl_scan(cnt, &tot);
+#pragma unroll
+    for (int b = 0; b < B; b++)
+        if (claimed[b]) { if (at < (uint32_t)SKM_CLN) Q.cl[at] = (uint16_t)slot[b]; at++; }
+    ncl += tot;
+}
 // finish up to 64 queued keys (the last `c` entries), one per lane, by plain linear probing from their next slot
 __device__ __forceinline__ void skm_tail_drain(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
-                                               const skm_tailq &Q, uint32_t &qn, unsigned int *overflow) {
+                                               const skm_tailq &Q, uint32_t &qn, uint32_t &ncl, unsigned int *overflow) {
     const uint32_t c = qn < 64u ? qn : 64u;
     qn -= c;
     bool p1 = (uint32_t)mf_lane() < c;
@@ -533,6 +550,7 @@ __device__ __forceinline__ void skm_tail_drain(uint32_t tk0, uint32_t tc0, uint3
         ca[0] = need ? ka[0] : dummy_k;
         if (__ballot(need) != 0ull) {
             skm_lds_cmpst_b64<1>(ca, MF_EMPTY, k1, ret);
+            { const bool cl1[1] = {need && ret[0] == MF_EMPTY}; const uint32_t sl1[1] = {s1}; skm_note_claims<1>(Q, ncl, cl1, sl1); }
             if (need) cur[0] = ret[0] == MF_EMPTY ? k1[0] : ret[0];
         }
         const bool hit = p1 && cur[0] == k1[0];
@@ -544,7 +562,7 @@ __device__ __forceinline__ void skm_tail_drain(uint32_t tk0, uint32_t tc0, uint3
     }
 }
 __device__ __forceinline__ void skm_count_insert4q(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
-                                                   const uint64_t (&key)[4], const skm_tailq &Q, uint32_t &qn, unsigned int *overflow, int ablate = 0) {
+                                                   const uint64_t (&key)[4], const skm_tailq &Q, uint32_t &qn, uint32_t &ncl, unsigned int *overflow, int ablate = 0) {
     uint32_t s[4]; bool pend[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = skm_slot(key[b]) & mask; }
@@ -557,8 +575,13 @@ __device__ __forceinline__ void skm_count_insert4q(uint32_t tk0, uint32_t tc0, u
         for (int b = 0; b < 4; b++) { need[b] = pend[b] && cur[b] == MF_EMPTY; ca[b] = need[b] ? ka[b] : dummy_k; anyneed |= need[b]; }
         if (__ballot(anyneed) != 0ull) {
             mf_lds_cmpst4_b64(ca, MF_EMPTY, key, ret);
+            bool won[4];
 #pragma unroll
-            for (int b = 0; b < 4; b++) if (need[b]) cur[b] = ret[b] == MF_EMPTY ? key[b] : ret[b];
+            for (int b = 0; b < 4; b++) {
+                won[b] = need[b] && ret[b] == MF_EMPTY;
+                if (need[b]) cur[b] = ret[b] == MF_EMPTY ? key[b] : ret[b];
+            }
+            skm_note_claims<4>(Q, ncl, won, s);
         }
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -578,7 +601,7 @@ __device__ __forceinline__ void skm_count_insert4q(uint32_t tk0, uint32_t tc0, u
         if (bal == 0ull) continue;
         if (pend[b]) { const uint32_t at = qn + (uint32_t)__popcll(bal & lt_mask); Q.qk[at] = key[b]; Q.qs[at] = (uint16_t)s[b]; }
         qn += (uint32_t)__popcll(bal);
-        if (qn >= 64u) skm_tail_drain(tk0, tc0, dummy_k, dummy_c, mask, Q, qn, overflow);      // (qn < 64 + 64 <= SKM_QN)
+        if (qn >= 64u) skm_tail_drain(tk0, tc0, dummy_k, dummy_c, mask, Q, qn, ncl, overflow);      // (qn < 64 + 64 <= SKM_QN)
     }
 }
 
@@ -607,13 +630,17 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
     skm_rec *rbuf = reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64) + wave * 64;              // [64] this wave's records
     uint64_t *qk_all = reinterpret_cast<uint64_t *>(reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64) + SKM_CT);   // [waves][SKM_QN]
     uint16_t *qs_all = reinterpret_cast<uint16_t *>(qk_all + (SKM_CT / 64) * SKM_QN);                                   // [waves][SKM_QN]
-    uint16_t *items = qs_all + (SKM_CT / 64) * SKM_QN + wave * 512;                                                     // [64 * 8]
-    skm_tailq Q; Q.qk = qk_all + wave * SKM_QN; Q.qs = qs_all + wave * SKM_QN;
-    uint32_t qn = 0;                                                                                                    // wave-uniform
+    uint16_t *cl_all = qs_all + (SKM_CT / 64) * SKM_QN;                                                                 // [waves][SKM_CLN]
+    uint16_t *items = cl_all + (SKM_CT / 64) * SKM_CLN + wave * (64 * 6);                                               // [64 * 6] (RMAX <= 24)
+    skm_tailq Q; Q.qk = qk_all + wave * SKM_QN; Q.qs = qs_all + wave * SKM_QN; Q.cl = cl_all + wave * SKM_CLN;
+    uint32_t qn = 0, ncl = 0;                                                                                           // wave-uniform
+    __shared__ uint32_t sweep_all;
     const uint32_t tk0 = mf_lds_addr(tk), tc0 = mf_lds_addr(tc);
     const uint32_t dummy_k = tk0 + 8u * ((uint32_t)MF_COUNT_SLOTS + lane);
     const uint32_t dummy_c = tc0 + 4u * ((uint32_t)MF_COUNT_SLOTS + lane);
     if (threadIdx.x < 64) { tk[MF_COUNT_SLOTS + threadIdx.x] = 0; tc[MF_COUNT_SLOTS + threadIdx.x] = 0; }   // dummies: never EMPTY
+    // the table is cleared ONCE; after that every partition leaves it clean (its compaction clears the slots it claimed)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
     constexpr uint32_t mask = MF_COUNT_SLOTS - 1;
     constexpr int sh = 64 - 2 * K, top = 2 * K - 2;
     const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
@@ -632,8 +659,7 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
         const uint32_t pn = p + gridDim.x, pnn = pn + gridDim.x;
         uint64_t start_nn = 0, o_nn = 0; uint32_t len_nn = 0, room_nn = 0;
         if (pnn < np) { start_nn = pstart[pnn]; len_nn = plen[pnn]; o_nn = toff[pnn] - tbase; room_nn = (uint32_t)(toff[pnn + 1] - toff[pnn]); }
-        for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
-        if (threadIdx.x == 0) { out_cursor = 0; all_cursor = 0; }
+        if (threadIdx.x == 0) { out_cursor = 0; all_cursor = 0; sweep_all = 0; }
         skm_rec cur = R;
         if (pn < np) R = mine < len_n ? recs[start_n + mine] : SENT;           // next partition's first round
         __syncthreads();
@@ -648,7 +674,7 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
             for (uint32_t c = 0; c < nch; c++) items[ioff + c] = (uint16_t)(lane | (c << 6));
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // LDS of one wave is in order: visible to its lanes
             __builtin_amdgcn_wave_barrier();
-            for (uint32_t i0 = 0; i0 < (ablate == 4 ? 0u : NI); i0 += 64) {    // wave-uniform
+            for (uint32_t i0 = 0; i0 < ((ablate & 4) ? 0u : NI); i0 += 64) {    // wave-uniform
                 uint64_t k4[4] = {MF_EMPTY, MF_EMPTY, MF_EMPTY, MF_EMPTY};
                 if (i0 + lane < NI) {
                     const uint32_t it = items[i0 + lane];
@@ -666,26 +692,44 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                         rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fw & 3u)) << top);
                     }
                 }
-                if (ablate != 3) skm_count_insert4q(tk0, tc0, dummy_k, dummy_c, mask, k4, Q, qn, overflow, ablate);
+                if (ablate != 3) skm_count_insert4q(tk0, tc0, dummy_k, dummy_c, mask, k4, Q, qn, ncl, overflow, ablate);
                 else if ((k4[0] ^ k4[1] ^ k4[2] ^ k4[3]) == 0x1234567ull) tk[0] = k4[0];
             }
-            while (qn) skm_tail_drain(tk0, tc0, dummy_k, dummy_c, mask, Q, qn, overflow);       // wave-uniform
+            while (qn) skm_tail_drain(tk0, tc0, dummy_k, dummy_c, mask, Q, qn, ncl, overflow);       // wave-uniform
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
             __builtin_amdgcn_wave_barrier();
         }
+        if (ncl > (uint32_t)SKM_CLN && lane == 0) sweep_all = 1;        // this wave's list is incomplete: sweep the whole table
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ds_add_u32 of the asm blocks are invisible to hipcc's waitcnt pass
         __syncthreads();
-        // compaction: each wave walks 64-slot chunks (lane = slot: conflict-free), keeps them in registers, reserves its
-        // output range with ONE LDS atomic
-        {
+        const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
+        if (!sweep_all) {
+            // compaction over the claimed slots: every wave walks ITS list (the slots it won), writes the entries that pass
+            // the cut and leaves the slots empty for the next partition
+            if (lane == 0 && ncl) atomicAdd(&all_cursor, ncl);
+            for (uint32_t i0 = 0; i0 < ncl; i0 += 64) {             // wave-uniform
+                const bool have = i0 + lane < ncl;
+                uint32_t sl = 0; uint64_t key = MF_EMPTY; uint32_t cnt = 0;
+                if (have) { sl = Q.cl[i0 + lane]; key = tk[sl]; cnt = tc[sl]; tk[sl] = MF_EMPTY; tc[sl] = 0; }
+                if (cnt > (uint32_t)MF_MAX_COUNT) cnt = (uint32_t)MF_MAX_COUNT;
+                const bool keep = have && (int)cnt > thr;           // (thr < 0 keeps everything)
+                const unsigned long long bal = __ballot(keep);
+                uint32_t wb = 0;
+                if (lane == 0 && bal) wb = atomicAdd(&out_cursor, (uint32_t)__popcll(bal));
+                wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb) + (uint32_t)__popcll(bal & lt_mask);
+                if (keep && wb < room) { tkeys[o + wb] = key; tcnt[o + wb] = (uint16_t)cnt; }
+                if (keep && wb >= room) atomicExch(overflow, 1u);   // (only if a partition's k-mer count wrapped)
+            }
+        } else {
+            // full sweep: each wave walks 64-slot chunks (lane = slot: conflict-free), keeps them in registers, reserves its
+            // output range with ONE LDS atomic, clears the table
             constexpr int NCH = MF_COUNT_SLOTS / SKM_CT;
             uint64_t ck[NCH]; uint32_t cv[NCH], pre[NCH]; uint32_t total = 0, total_all = 0;
-            const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
 #pragma unroll
             for (int i = 0; i < NCH; i++) {
                 const uint32_t sl = ((threadIdx.x >> 6) << 6) + (uint32_t)i * SKM_CT + (uint32_t)mf_lane();
                 ck[i] = tk[sl]; cv[i] = tc[sl];
-                if (ablate == 6 && i > 0) ck[i] = MF_EMPTY;
+                tk[sl] = MF_EMPTY; tc[sl] = 0;
                 total_all += (uint32_t)__popcll(__ballot(ck[i] != MF_EMPTY));
                 if ((int)(cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]) <= thr) ck[i] = MF_EMPTY;     // (thr < 0 keeps everything)
                 const unsigned long long bal = __ballot(ck[i] != MF_EMPTY);
@@ -706,6 +750,7 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                 }
             }
         }
+        ncl = 0;
         __syncthreads();
         if (threadIdx.x == 0) { dcount[p] = out_cursor; all_acc += all_cursor; }
         if (pn >= np) break;
@@ -873,14 +918,14 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     mf_buf<uint64_t> dk; mf_buf<uint16_t> dc;
     uint64_t dused = 0, dcap = 0;
     {
-        const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 8 * 2 + (size_t)(SKM_CT / 64) * SKM_QN * 10;
+        const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 6 * 2 + (size_t)(SKM_CT / 64) * (SKM_QN * 10 + SKM_CLN * 2);
         MF_TRY(skm_set_lds(k_skm_count<K>, lds));
     }
     for (uint32_t b = 0; b < nbatch; b++) {
         const uint32_t p0 = (uint32_t)std::min<uint64_t>((uint64_t)b * PB, np), p1 = (uint32_t)std::min<uint64_t>((uint64_t)(b + 1) * PB, np);
         if (p0 == p1) continue;
         {
-            const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 8 * 2 + (size_t)(SKM_CT / 64) * SKM_QN * 10;
+            const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 6 * 2 + (size_t)(SKM_CT / 64) * (SKM_QN * 10 + SKM_CLN * 2);
             const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);
             mf_ktimer t(ctx, "k_skm_count");
             k_skm_count<K><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],

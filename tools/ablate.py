@@ -11,7 +11,7 @@ bases = torch.zeros(n_reads * rl + 64, dtype=torch.uint8, device="cuda")
 offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
 torch.cuda.synchronize()
 ctx.synth_reads_device(0x4D45544146415354, 0, 0, n_reads, rl, 1_000_000, bases.data_ptr(), offsets.data_ptr())
-for ab in (0, 3, 4, 5, 6, 0):
+for ab in (0, 3, 4, 5, 0):
     ctx.set_option("ablate", ab)
     ctx.reset_timers()
     try:
