@@ -76,6 +76,11 @@ def main():
     ap.add_argument("--b2", type=int, default=10000)
     args = ap.parse_args()
 
+    # stdout carries ONE line, the JSON; anything libraries print there on the way (RCCL's version banner ...) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -202,7 +207,10 @@ def main():
             "stage_ms_per_step": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in stage_t.items()},
             "kernels": kern,
         }
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
     if use_dist:
         dist.destroy_process_group()
 
