@@ -181,6 +181,16 @@ int  mf_features_device(mf_ctx *ctx, mf_comps *c, const mf_table *sample, int th
 int  mf_features(mf_ctx *ctx, const char *components_bin, const char *kmers_bin, int k, int threshold,
                  const char *vec_path, const char *breadth_path);
 
+/* --use-reads-for-calculating-features (FeaturesCalculatorMain.java:117-131 + IOUtils.calculatePresenceForReads /
+ * ReadsPresenceWorker, src/io/IOUtils.java:806-834): the features of a sample straight from its READS -- every k-mer of
+ * every read that is a component k-mer adds 1 (64-bit counts, no saturation; reads shorter than k give nothing), then
+ * vec[c] = sum of the counts > threshold, breadth[c] = found / size.  Device form: reads resident in HBM (layout of
+ * mf_count_device); file form: FASTA / FASTQ (.gz) files of ONE library, output as mf_features. */
+int mf_features_reads_device(mf_ctx *ctx, mf_comps *c, const void *d_bases, const void *d_offsets, uint64_t n_reads,
+                             uint64_t n_bases, int k, int threshold, int64_t *vec, double *breadth);
+int mf_features_reads(mf_ctx *ctx, const char *components_bin, const char *const *files, int nfiles, int k, int threshold,
+                      const char *vec_path, const char *breadth_path);
+
 /* ---- A13  Bray-Curtis ---------------------------------------------------------------- */
 /* replaces DistanceMatrixCalculatorMain.brayCurtisDistance (src/tools/DistanceMatrixCalculatorMain.java:
  * 140-152): d = sum|a-b| / sum(|a|+|b|) on raw vectors; vecs is row-major [n_samples][n_comp]. */

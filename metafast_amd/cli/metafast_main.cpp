@@ -272,14 +272,24 @@ static string run_component_cutter(Env &e, const Args &a, const vector<string> &
     return comp_file;
 }
 // features-calculator (src/tools/FeaturesCalculatorMain.java:77-167), k-mers files branch
-static vector<string> run_features(Env &e, const Args &a, const string &comp_file, const vector<string> &kmers, int k, int thr, const string &wd) {
+static vector<string> run_features(Env &e, const Args &a, const string &comp_file, const vector<string> &reads, const vector<string> &kmers,
+                                   int k, int thr, const string &wd) {
     if (comp_file.empty()) die("Mandatory option --components-file is not set");
     if (a.has("selected")) die("--selected is not supported by the HIP path");
-    if (kmers.empty()) die("no k-mers files given (the --reads variant of features-calculator is not supported by the HIP path yet; pass -ka <name>.kmers.bin)");
+    if (kmers.empty() && reads.empty()) die("No input files: pass reads (-i) or k-mers files (-ka)");
     mf_ctx *ctx = ctx_of(e, a);
     string out_dir = wd + "/vectors";
     mkdirs(out_dir);
     vector<string> vecs;
+    // reads files first, one vector per FILE, then k-mers files (FeaturesCalculatorMain.java:117-162)
+    for (auto &rf : reads) {
+        string base = library_name(rf);
+        string vec = out_dir + "/" + base + ".vec", br = out_dir + "/" + base + ".breadth";
+        const char *fs[1] = {rf.c_str()};
+        check(mf_features_reads(ctx, comp_file.c_str(), fs, 1, k, thr, vec.c_str(), br.c_str()));
+        logmsg("INFO", "Features for file %s printed to %s", basename_of(rf).c_str(), vec.c_str());
+        vecs.push_back(vec);
+    }
     for (auto &kf : kmers) {
         string base = remove_ext(basename_of(kf), {".kmers.bin"});
         string vec = out_dir + "/" + base + ".vec", br = out_dir + "/" + base + ".breadth";
@@ -511,7 +521,7 @@ int main(int argc, char **argv) {
                              a.get("components-file", wd + "/components.bin"));
     } else if (tool == "features-calculator") {
         if (!a.has("k")) die("Mandatory option -k is not set");
-        run_features(e, a, a.get("components-file"), a.list("kmers"), k, a.geti("threshold", 0), wd);
+        run_features(e, a, a.get("components-file"), a.list("reads"), a.list("kmers"), k, a.geti("threshold", 0), wd);
     } else if (tool == "dist-matrix-calculator") {
         run_dist_matrix(e, a, a.list("features"), a.get("matrix-file", wd + "/dist_matrix_$DT_original_order.txt"));
     } else if (tool == "heatmap-maker") {
@@ -522,7 +532,7 @@ int main(int argc, char **argv) {
         // dist-matrix-calculator (+ heatmap-maker: rendering, out of scope)
         vector<string> reads = a.list("reads");
         if (reads.empty()) die("No libraries to process!!! Can't continue the calculations.");
-        if (a.get("use-reads-for-calculating-features", "false") == "true") die("--use-reads-for-calculating-features is not supported by the HIP path yet");
+        const bool use_reads = a.get("use-reads-for-calculating-features", "false") == "true";     // DistanceMatrixBuilderMain.java:162-165
         logmsg("INFO", "Found %zu libraries to process", reads.size());
         check_k(k);
         int b = a.geti("maximal-bad-frequency", a.geti("maximal-bad-frequence", 1)), l = a.geti("min-seq-len", 100);
@@ -560,7 +570,7 @@ int main(int argc, char **argv) {
         else logmsg("INFO", "Step %s: reusing results", s3.name.c_str());
         if (stop_after(s3)) return 0;
         // 4
-        if (should_run(s4)) { vecs = run_features(e, a, comp, kmers, k, 0, s4.dir); step_finish(s4); }
+        if (should_run(s4)) { vecs = use_reads ? run_features(e, a, comp, reads, {}, k, 0, s4.dir) : run_features(e, a, comp, {}, kmers, k, 0, s4.dir); step_finish(s4); }
         else { logmsg("INFO", "Step %s: reusing results", s4.name.c_str()); vecs = list_files(s4.dir + "/vectors", ".vec"); }
         if (stop_after(s4)) return 0;
         // 5

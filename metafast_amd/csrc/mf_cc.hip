@@ -220,6 +220,26 @@ __global__ void k_features_rev(mf_index_view ix, const uint64_t *__restrict__ ck
     }
 }
 
+// features from per-k-mer occurrence counters (reads mode): same reduction as k_features_rev
+__global__ void k_features_occ(const unsigned long long *__restrict__ occ, const uint32_t *__restrict__ comp_of, uint64_t nk,
+                               int threshold, unsigned long long *__restrict__ vec, unsigned int *__restrict__ found) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t comp = 0xFFFFFFFFu, hit = 0; unsigned long long val = 0;
+    if (j < nk) {
+        comp = comp_of[j];
+        const unsigned long long v = occ[j];
+        if ((long long)v > (long long)threshold) { val = v; hit = 1; }
+    }
+    const uint32_t first = __shfl(comp, 0, 64);
+    if (__ballot(comp != first) == 0ull) {
+        for (int d = 32; d >= 1; d >>= 1) { val += __shfl_down(val, d, 64); hit += __shfl_down(hit, d, 64); }
+        if (mf_lane() == 0 && hit) { atomicAdd(&vec[first], val); atomicAdd(&found[first], hit); }
+    } else if (hit) {
+        atomicAdd(&vec[comp], val);
+        atomicAdd(&found[comp], 1u);
+    }
+}
+
 static inline unsigned cgrid(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 // builds d_kmers / d_comp / index from the host vectors of a finished mf_comps (mf_comps_load path)
@@ -455,6 +475,39 @@ extern "C" int mf_features_device(mf_ctx *ctx, mf_comps *c, const mf_table *samp
             // a negative threshold makes absent k-mers (value 0) count as found (value > threshold)
             double f = threshold < 0 ? (double)cnt : (double)hf[i];
             breadth[i] = f / (double)cnt;                    // ((double) kmersFound) / kmersCount :203
+        }
+    return MF_OK;
+}
+
+int mf_presence_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k,
+                     const mf_index &index, unsigned long long *d_occ);
+extern "C" int mf_features_reads_device(mf_ctx *ctx, mf_comps *c, const void *d_bases, const void *d_offsets, uint64_t n_reads,
+                                        uint64_t n_bases, int k, int threshold, int64_t *vec, double *breadth) {
+    if (!ctx || !c || !vec) return mf_set_error("mf_features_reads_device: NULL argument");
+    MF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t nc = c->n;
+    if (!nc) return MF_OK;
+    mf_buf<unsigned long long> dvec, occ; mf_buf<unsigned int> dfound;
+    MF_TRY(dvec.alloc(ctx, nc)); MF_TRY(dfound.alloc(ctx, nc)); MF_TRY(occ.alloc(ctx, c->n_kmers));
+    MF_HIP(hipMemsetAsync(dvec.p, 0, nc * 8, st));
+    MF_HIP(hipMemsetAsync(dfound.p, 0, nc * 4, st));
+    MF_HIP(hipMemsetAsync(occ.p, 0, (c->n_kmers ? c->n_kmers : 1) * 8, st));
+    if (c->n_kmers) {
+        if (!c->index.slots) MF_TRY(mf_index_build(ctx, c->d_kmers, nullptr, c->n_kmers, &c->index, &c->index_bytes));   // hm.put(kmer, 0) :99-103
+        MF_TRY(mf_presence_core(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, c->index, occ.p));
+        mf_ktimer tm(ctx, "k_features");
+        k_features_occ<<<cgrid(c->n_kmers), 256, 0, st>>>(occ.p, c->d_comp, c->n_kmers, threshold, dvec.p, dfound.p);
+    }
+    std::vector<unsigned int> hf(nc);
+    MF_HIP(hipMemcpyAsync(vec, dvec.p, nc * 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemcpyAsync(hf.data(), dfound.p, nc * 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    if (breadth)
+        for (uint64_t i = 0; i < nc; i++) {
+            const uint64_t cnt = c->sizes[i];
+            const double f = threshold < 0 ? (double)cnt : (double)hf[i];
+            breadth[i] = f / (double)cnt;
         }
     return MF_OK;
 }

@@ -796,6 +796,41 @@ int mf_sum_counts(mf_ctx *ctx, const uint16_t *d_counts, uint64_t n, uint64_t *t
     return MF_OK;
 }
 
+// ---- occurrences of the k-mers of an index in the reads (ReadsPresenceWorker.process, src/io/IOUtils.java:816-825):
+// one lane = one 32-position word, every valid k-mer is looked up and, if present, its entry's counter goes up by one ----
+__global__ __launch_bounds__(256) void k_presence(const uint8_t *__restrict__ bases, uint64_t n_bases, const uint32_t *__restrict__ vmask,
+                                                  uint64_t n_words, int k, mf_index_view ix, unsigned long long *__restrict__ occ) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const uint32_t m = vmask[w];
+    if (!m) return;
+    mf_word_kmers(bases, n_bases, w, m, k, [&](int, uint64_t key, bool valid) {
+        uint32_t idx, val;
+        if (valid && mf_index_find(ix, key, &idx, &val)) atomicAdd(&occ[idx], 1ull);
+    });
+}
+// occ[i] += occurrences in the reads of the key at entry i of the index (reads shorter than k contribute nothing)
+int mf_presence_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k,
+                     const mf_index &index, unsigned long long *d_occ) {
+    if (k < 1 || k > 31) return mf_set_error("k must be in [1,31]");
+    if (((uintptr_t)d_bases & 15) != 0) return mf_set_error("reads: d_bases must be 16-byte aligned");
+    if (n_reads == 0 || n_bases == 0) return MF_OK;
+    hipStream_t st = ctx->stream;
+    const uint64_t n_words = (n_bases + 31) / 32;
+    mf_buf<uint32_t> vmask; MF_TRY(vmask.alloc(ctx, n_words));
+    mf_buf<unsigned long long> scal; MF_TRY(scal.alloc(ctx, 1));
+    MF_HIP(hipMemsetAsync(scal.p, 0, 8, st));
+    k_mask_init<<<(unsigned)((n_words + 255) / 256), 256, 0, st>>>(vmask.p, n_words, n_bases);
+    k_mask_reads<<<(unsigned)((n_reads + 1023) / 1024), 1024, 0, st>>>(d_offsets, n_reads, k, 0, vmask.p, scal.p);
+    {
+        mf_ktimer t(ctx, "k_presence");
+        k_presence<<<(unsigned)((n_words + 255) / 256), 256, 0, st>>>(d_bases, n_bases, vmask.p, n_words, k, mf_view(index), d_occ);
+    }
+    MF_HIP(hipGetLastError());
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
+
 extern "C" int mf_count_device(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads,
                                uint64_t n_bases, int k, int min_read_len, mf_table **out) {
     if (!ctx || !out) return mf_set_error("mf_count_device: NULL argument");

@@ -342,12 +342,9 @@ static int parse_reads_file(const char *path, int threads, std::vector<read_batc
     return rc;
 }
 
-// IOUtils.loadReads (src/io/IOUtils.java:772-803): all files into one table
-extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, mf_table **out) {
-    if (!ctx || !out || (nfiles && !files)) return mf_set_error("mf_count_reads: NULL argument");
-    *out = nullptr;
-    if (k < 1) return mf_set_error("The size of k-mer must be at least 1.");
-    if (k > 31) return mf_set_error("The size of k-mer must be no more than 31.");
+// files -> (bases, offsets) in HBM (the layout mf_count_device takes); all files of the call form ONE read set
+static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfiles, mf_buf<uint8_t> &db, mf_buf<uint64_t> &doff,
+                                uint64_t *n_reads, uint64_t *n_bases, double *t_parse, double *t_h2d) {
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     std::vector<read_batch> parts;
@@ -370,19 +367,33 @@ extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles,
             });
         for (auto &x : th) x.join();
     }
-    mf_buf<uint8_t> db; mf_buf<uint64_t> doff;
     MF_TRY(db.alloc(ctx, nb + 64)); MF_TRY(doff.alloc(ctx, nr + 1));
     for (size_t t = 0; t < parts.size(); t++)
         if (!parts[t].bases.empty())
             MF_HIP(hipMemcpyAsync(db.p + pb[t], parts[t].bases.data(), parts[t].bases.size(), hipMemcpyHostToDevice, ctx->stream));
     MF_HIP(hipMemcpyAsync(doff.p, offsets.data(), (nr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     MF_HIP(hipStreamSynchronize(ctx->stream));
+    *n_reads = nr; *n_bases = nb;
+    if (t_parse) *t_parse = t1 - t0;
+    if (t_h2d) *t_h2d = now() - t1;
+    return MF_OK;
+}
+
+// IOUtils.loadReads (src/io/IOUtils.java:772-803): all files into one table
+extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, mf_table **out) {
+    if (!ctx || !out || (nfiles && !files)) return mf_set_error("mf_count_reads: NULL argument");
+    *out = nullptr;
+    if (k < 1) return mf_set_error("The size of k-mer must be at least 1.");
+    if (k > 31) return mf_set_error("The size of k-mer must be no more than 31.");
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    mf_buf<uint8_t> db; mf_buf<uint64_t> doff;
+    uint64_t nr = 0, nb = 0; double tp = 0, th = 0;
+    MF_TRY(load_reads_to_device(ctx, files, nfiles, db, doff, &nr, &nb, &tp, &th));
     const double t2 = now();
-    parts.clear();
     int rc = mf_count_core(ctx, db.p, doff.p, nr, nb, k, min_read_len, out, -1, nullptr);
     if (ctx->opt_verbose)
         fprintf(stderr, "[mf] count_reads: read+parse %.3f s, offsets+H2D %.3f s, count %.3f s (%llu reads, %llu bases, %d host threads)\n",
-                t1 - t0, t2 - t1, now() - t2, (unsigned long long)nr, (unsigned long long)nb, ctx->host_threads);
+                tp, th, now() - t2, (unsigned long long)nr, (unsigned long long)nb, ctx->host_threads);
     return rc;
 }
 
@@ -586,6 +597,23 @@ static std::string java_double(double d) {
     }
     return neg ? "-" + out : out;
 }
+static int write_features_files(const std::vector<int64_t> &vec, const std::vector<double> &br, const char *vec_path, const char *breadth_path);
+// FeaturesCalculatorMain.runImpl reads branch (:117-131): the files of ONE library
+extern "C" int mf_features_reads(mf_ctx *ctx, const char *components_bin, const char *const *files, int nfiles, int k, int threshold,
+                                 const char *vec_path, const char *breadth_path) {
+    if (!ctx || !components_bin || (nfiles && !files)) return mf_set_error("mf_features_reads: NULL argument");
+    mf_comps *c = nullptr;
+    MF_TRY(mf_comps_load(ctx, components_bin, &c));
+    if (c->n == 0) { mf_comps_destroy(c); return mf_set_error("No components were found in input files! Can't continue the calculations."); }
+    mf_buf<uint8_t> db; mf_buf<uint64_t> doff;
+    uint64_t nr = 0, nb = 0;
+    int rc = load_reads_to_device(ctx, files, nfiles, db, doff, &nr, &nb, nullptr, nullptr);
+    std::vector<int64_t> vec(c->n); std::vector<double> br(c->n);
+    if (rc == MF_OK) rc = mf_features_reads_device(ctx, c, db.p, doff.p, nr, nb, k, threshold, vec.data(), br.data());
+    if (rc == MF_OK) rc = write_features_files(vec, br, vec_path, breadth_path);
+    mf_comps_destroy(c);
+    return rc;
+}
 // FeaturesCalculatorMain.runImpl kmers-file branch (:137-162) + buildAndPrintVector output (:217-230)
 extern "C" int mf_features(mf_ctx *ctx, const char *components_bin, const char *kmers_bin, int k, int threshold,
                            const char *vec_path, const char *breadth_path) {
@@ -600,17 +628,24 @@ extern "C" int mf_features(mf_ctx *ctx, const char *components_bin, const char *
     if (rc < 0) { mf_comps_destroy(c); return rc; }
     std::vector<int64_t> vec(c->n); std::vector<double> br(c->n);
     rc = mf_features_device(ctx, c, t, threshold, vec.data(), br.data());
-    if (rc == MF_OK && vec_path) {
-        FILE *f = fopen(vec_path, "w");
-        if (!f) rc = mf_set_error("Can't write vector to file %s", vec_path);
-        else { for (int64_t v : vec) fprintf(f, "%lld\n", (long long)v); fclose(f); }
-    }
-    if (rc == MF_OK && breadth_path) {
-        FILE *f = fopen(breadth_path, "w");
-        if (!f) rc = mf_set_error("Can't write vector to file %s", breadth_path);
-        else { for (double v : br) fprintf(f, "%s\n", java_double(v).c_str()); fclose(f); }
-    }
+    if (rc == MF_OK) rc = write_features_files(vec, br, vec_path, breadth_path);
     mf_table_destroy(t);
     mf_comps_destroy(c);
     return rc;
+}
+// buildAndPrintVector output (:217-230): one long per line / one Double.toString per line
+static int write_features_files(const std::vector<int64_t> &vec, const std::vector<double> &br, const char *vec_path, const char *breadth_path) {
+    if (vec_path) {
+        FILE *f = fopen(vec_path, "w");
+        if (!f) return mf_set_error("Can't write vector to file %s", vec_path);
+        for (int64_t v : vec) fprintf(f, "%lld\n", (long long)v);
+        fclose(f);
+    }
+    if (breadth_path) {
+        FILE *f = fopen(breadth_path, "w");
+        if (!f) return mf_set_error("Can't write vector to file %s", breadth_path);
+        for (double v : br) fprintf(f, "%s\n", java_double(v).c_str());
+        fclose(f);
+    }
+    return MF_OK;
 }

@@ -60,6 +60,8 @@ _SIGS = {
     "mf_comps_load": (i32, [vp, cp, pvp]),
     "mf_cut_components": (i32, [vp, vp, i32, i32, i32, cp, cp, pu64]),
     "mf_features_device": (i32, [vp, vp, vp, i32, vp, vp]),
+    "mf_features_reads_device": (i32, [vp, vp, vp, vp, u64, u64, i32, i32, vp, vp]),
+    "mf_features_reads": (i32, [vp, cp, C.POINTER(cp), i32, i32, i32, cp, cp]),
     "mf_features": (i32, [vp, cp, cp, i32, i32, cp, cp]),
     "mf_bray_curtis": (i32, [vp, i32, i32, vp]),
     "mf_synth_reads_device": (i32, [vp, u64, i32, u64, u64, i32, u64, vp, vp]),
@@ -219,6 +221,19 @@ class Context:
         br = np.zeros(n, dtype=np.float64)
         _check(lib().mf_features_device(self.h, comps.h, sample_table.h, threshold, vec.ctypes.data, br.ctypes.data))
         return vec, br
+
+    def features_reads(self, comps, d_bases, d_offsets, n_reads, n_bases, k, threshold=0):
+        """features of a sample straight from its reads in HBM (--use-reads-for-calculating-features): 64-bit counts"""
+        n = comps.stats()[0]
+        vec = np.zeros(n, dtype=np.int64)
+        br = np.zeros(n, dtype=np.float64)
+        _check(lib().mf_features_reads_device(self.h, comps.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k,
+                                              threshold, vec.ctypes.data, br.ctypes.data))
+        return vec, br
+
+    def features_reads_files(self, components_bin, files, k, threshold, vec_path, breadth_path):
+        _check(lib().mf_features_reads(self.h, os.fsencode(components_bin), _cfiles(files), len(files), k, threshold,
+                                       _opt(vec_path), _opt(breadth_path)))
 
     def features_files(self, components_bin, kmers_bin, k, threshold, vec_path, breadth_path):
         _check(lib().mf_features(self.h, os.fsencode(components_bin), os.fsencode(kmers_bin), k, threshold,

@@ -758,6 +758,48 @@ int or_features(const or_comps *c, const or_table *sample, int threshold, int64_
     return 0;
 }
 
+/* FeaturesCalculatorMain.runImpl reads branch (:117-131): hm (k-mer -> long, BigLong2LongHashMap: no saturation at 32767)
+ * holds the component k-mers; IOUtils.calculatePresenceForReads / ReadsPresenceWorker.process (src/io/IOUtils.java:806-834)
+ * adds 1 for every k-mer of every read that is a component k-mer; then buildAndPrintVector as above */
+int or_features_reads(const or_comps *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k, int threshold,
+                      int64_t *vec, double *breadth) {
+    if (k < 1 || k > 31) return fail("k must be in [1,31]");
+    or_table *hm = or_table_new();
+    for (uint64_t i = 0; i < c->n; i++)
+        for (uint64_t j = 0; j < c->a[i].nk; j++) table_put(hm, c->a[i].kmers[j], 0);
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const uint8_t *s = bases + offsets[r];
+        uint64_t len = offsets[r + 1] - offsets[r];
+        if (len < (uint64_t)k) continue;
+        uint64_t fw = 0;
+        for (int i = 0; i < k; i++) {
+            int cc = nuc_code(s[i]);
+            if (cc < 0) { or_table_free(hm); return fail("bad base in buffer"); }
+            fw = (fw << 2) | (uint64_t)cc;
+        }
+        skmer km = sk_make(fw, k);
+        if (or_table_get(hm, sk_canon(km)) != -1) table_add_bound(hm, sk_canon(km), 1, INT64_MAX);
+        for (uint64_t i = (uint64_t)k; i < len; i++) {
+            int cc = nuc_code(s[i]);
+            if (cc < 0) { or_table_free(hm); return fail("bad base in buffer"); }
+            sk_shift_right(&km, cc, k);
+            if (or_table_get(hm, sk_canon(km)) != -1) table_add_bound(hm, sk_canon(km), 1, INT64_MAX);
+        }
+    }
+    for (uint64_t i = 0; i < c->n; i++) {
+        int64_t kmers = 0, cnt = 0, found = 0;
+        for (uint64_t j = 0; j < c->a[i].nk; j++) {
+            int64_t value = get_with_zero(hm, c->a[i].kmers[j]);
+            if (value > threshold) { kmers += value; found++; }
+            cnt++;
+        }
+        vec[i] = kmers;
+        if (breadth) breadth[i] = (double)found / (double)cnt;
+    }
+    or_table_free(hm);
+    return 0;
+}
+
 /* ------------------------------------------------------------------ */
 /* A13 Bray-Curtis                                                     */
 /* ------------------------------------------------------------------ */

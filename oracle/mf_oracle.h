@@ -94,6 +94,11 @@ or_comps *or_comps_load(const char *components_bin);
 int       or_features(const or_comps *c, const or_table *sample, int threshold,
                       int64_t *vec, double *breadth);
 
+/* --use-reads-for-calculating-features (FeaturesCalculatorMain.java:117-131; src/io/IOUtils.java:806-834): the
+ * features straight from the reads, with long (unsaturated) per-k-mer counts */
+int       or_features_reads(const or_comps *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                            int k, int threshold, int64_t *vec, double *breadth);
+
 /* ---- A13 Bray-Curtis (src/tools/DistanceMatrixCalculatorMain.java:140-152) ---- */
 int       or_bray_curtis(const int64_t *vecs, int n_samples, int n_comp, double *out);
 

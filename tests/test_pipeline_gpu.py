@@ -214,3 +214,52 @@ def test_run_sample_single_gpu(gpu_ctx, oracle, ref_files):
     assert r["matrix"].shape == (1, 1) and r["matrix"][0, 0] == 0.0
     for key in ("good", "seqs", "cutter", "comps"):
         r[key].close()
+
+
+def test_features_from_reads(gpu_ctx, oracle, ref_files, tmp_path):
+    """--use-reads-for-calculating-features: occurrences of the component k-mers in the READS (64-bit, not the saturated
+    table counts), device form, file form and the driver's matrix-builder switch, against the oracle's restatement"""
+    import os, subprocess
+    from conftest import ROOT
+    from util import to_device, pack_reads
+    want = oracle.run_pipeline(ref_files)
+    comps_file = tmp_path / "components.bin"
+    want["comps"].write(str(comps_file), None)
+    comps = gpu_ctx.load_components(str(comps_file))
+    for f in ref_files:
+        b, o = oracle.read_file(f)
+        tb, to = to_device(b, o)
+        for thr in (0, 2):
+            ev, eb = oracle.features_from_reads(want["comps"], b, o, 31, thr)
+            gv, gb = gpu_ctx.features_reads(comps, tb.data_ptr(), to.data_ptr(), len(o) - 1, int(o[-1]), 31, thr)
+            assert gv.tolist() == ev.tolist() and np.array_equal(gb, eb)
+    # file form
+    vec, br = tmp_path / "x.vec", tmp_path / "x.breadth"
+    gpu_ctx.features_reads_files(str(comps_file), [ref_files[1]], 31, 0, str(vec), str(br))
+    b, o = oracle.read_file(ref_files[1])
+    ev, eb = oracle.features_from_reads(want["comps"], b, o, 31, 0)
+    assert [int(x) for x in vec.read_text().split()] == ev.tolist()
+    assert [float(x) for x in br.read_text().split()] == eb.tolist()
+    # a k-mer that occurs more often than a short count holds: poly-A component k-mers are counted in full
+    reads = ["A" * 40] * 4000 + ["ACGTTGCAAGGCTTAACGGATTACAGGCATCGATCGGCTAAGCT"] * 3
+    pb, po = pack_reads(reads)
+    t = oracle.Table().count_buffer(pb, po, 31)
+    oc = oracle.cut_components(t, 31, 1, 1000)
+    cf = tmp_path / "c2.bin"
+    oc.write(str(cf), None)
+    gc = gpu_ctx.load_components(str(cf))
+    tb, to = to_device(pb, po)
+    ev, eb = oracle.features_from_reads(oc, pb, po, 31, 0)
+    gv, gb = gpu_ctx.features_reads(gc, tb.data_ptr(), to.data_ptr(), len(po) - 1, int(po[-1]), 31, 0)
+    assert gv.tolist() == ev.tolist() and max(ev.tolist()) == 40000          # 4000 reads x 10 k-mers, beyond 32767
+    # driver: matrix-builder --use-reads-for-calculating-features (one vector per reads FILE)
+    wd = tmp_path / "w"
+    r = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", "31", "-i", *ref_files, "-w", str(wd), "--use-reads-for-calculating-features"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for f in ref_files:
+        name = os.path.basename(f)[:-3]
+        b, o = oracle.read_file(f)
+        ev, _ = oracle.features_from_reads(want["comps"], b, o, 31, 0)
+        got = [int(x) for x in (wd / "features-calculator" / "vectors" / (name + ".vec")).read_text().split()]
+        assert got == ev.tolist()
