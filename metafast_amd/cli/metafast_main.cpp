@@ -112,6 +112,7 @@ static const OptDef OPTS[] = {
     {"features", "", true, false}, {"without-names", "wn", false, true}, {"matrix-file", "", false, false},
     {"output-format", "", false, false}, {"heatmap-file", "", false, false}, {"new-matrix-file", "", false, false},
     {"without-renumbering", "", false, true},
+    {"kmers-file", "kf", false, false}, {"output-file", "o", false, false}, {"split", "", false, true}, {"long", "", false, true},
     {"use-reads-for-calculating-features", "", false, true}, {"device", "", false, false},
 };
 // `ctx_i` says what -i means for the selected tool
@@ -128,6 +129,8 @@ static Args parse_args(int argc, char **argv, string *tool_out) {
         }
         if (s == "b") return (tool == "kmer-counter" || tool == "kmer-counter-many") ? "maximal-bad-frequence" : "maximal-bad-frequency";
         if (s == "l") return (tool == "seq-builder" || tool == "seq-builder-many") ? "sequence-len" : "min-seq-len";
+        if (s == "o") return (tool == "view" || tool == "bin2fasta") ? "output-file" : "output-dir";
+        if (s == "cf") return "components-file";                           // ViewMain.java:45, BinaryToFasta.java:47
         for (auto &o : OPTS) if (o.sht[0] && s == o.sht) return o.lng;
         return "";
     };
@@ -429,6 +432,91 @@ static string run_heatmap_maker(Env &e, const Args &a, const string &matrix_path
     return path;
 }
 
+// ---- view / bin2fasta: text dumps of the binary files (src/tools/ViewMain.java:64-131, src/tools/BinaryToFasta.java:74-170).
+// Host-only.  The reference prints the k-mers of a .kmers.bin in its hash map's iteration order; here: file order.
+static string kmer_string(uint64_t km, int k) {             // ShortKmer.toString (itmo!/dna/kmers/ShortKmer.java:153-160)
+    string s((size_t)k, 'A');
+    for (int i = 0; i < k; i++) s[(size_t)i] = "AGCT"[(km >> (2 * (k - 1 - i))) & 3u];
+    return s;
+}
+static uint64_t be_read(const unsigned char *p, int n) { uint64_t v = 0; for (int i = 0; i < n; i++) v = (v << 8) | p[i]; return v; }
+static vector<unsigned char> slurp(const string &path) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) die("Can't read file %s", path.c_str());
+    vector<unsigned char> b; unsigned char buf[1 << 16]; size_t n;
+    while ((n = fread(buf, 1, sizeof buf, f)) > 0) b.insert(b.end(), buf, buf + n);
+    fclose(f);
+    return b;
+}
+struct HostComp { int64_t weight; vector<uint64_t> kmers; };
+static vector<HostComp> read_components(const string &path) {       // ConnectedComponent.loadComponents :95-122
+    vector<unsigned char> b = slurp(path);
+    if (b.size() < 4) die("Can't load components from %s", path.c_str());
+    size_t pos = 0; uint64_t n = be_read(&b[0], 4); pos = 4;
+    vector<HostComp> cs((size_t)n);
+    for (auto &cp : cs) {
+        if (pos + 12 > b.size()) die("Can't load components from %s", path.c_str());
+        uint64_t sz = be_read(&b[pos], 4); cp.weight = (int64_t)be_read(&b[pos + 4], 8); pos += 12;
+        if (pos + 8 * sz > b.size()) die("Can't load components from %s", path.c_str());
+        cp.kmers.resize((size_t)sz);
+        for (auto &km : cp.kmers) { km = be_read(&b[pos], 8); pos += 8; }
+    }
+    return cs;
+}
+static FILE *open_out(const string &path) { if (path.empty()) return stdout; FILE *f = fopen(path.c_str(), "w"); if (!f) die("Couldn't open output file"); return f; }
+static void close_out(FILE *f) { if (f != stdout) fclose(f); else fflush(f); }
+static void run_view(const Args &a, int k) {
+    const string kf = a.get("kmers-file"), cf = a.get("components-file");
+    if (kf.empty() && cf.empty()) { logmsg("WARN", "No input file is selected  --->  no data to display!"); return; }
+    FILE *out = open_out(a.get("output-file"));
+    if (!kf.empty()) {
+        const int rec = a.get("long", "false") == "true" ? 16 : 10;          // IOUtils.loadLongKmers / loadKmers
+        vector<unsigned char> b = slurp(kf);
+        fprintf(out, "Kmer\tCount\n");
+        for (size_t p = 0; p + rec <= b.size(); p += rec)
+            fprintf(out, "%s\t%lld\n", kmer_string(be_read(&b[p], 8), k).c_str(), rec == 10 ? (long long)(int16_t)be_read(&b[p + 8], 2) : (long long)be_read(&b[p + 8], 8));
+    }
+    if (!cf.empty()) {
+        vector<HostComp> cs = read_components(cf);
+        logmsg("INFO", "%zu components loaded from %s", cs.size(), cf.c_str());
+        fprintf(out, "%zu components:\n", cs.size());
+        for (size_t i = 0; i < cs.size(); i++) {
+            fprintf(out, "Component %zu, size = %zu kmers, weight = %lld. Kmers:\n", i + 1, cs[i].kmers.size(), (long long)cs[i].weight);
+            for (uint64_t km : cs[i].kmers) fprintf(out, "%s\n", kmer_string(km, k).c_str());
+            fprintf(out, "\n");
+        }
+    }
+    close_out(out);
+}
+static void run_bin2fasta(const Args &a, int k) {
+    const string kf = a.get("kmers-file"), cf = a.get("components-file"), prefix = a.get("output-file");
+    if (kf.empty() && cf.empty()) { logmsg("WARN", "No input file is selected  --->  no data to display!"); return; }
+    if (!prefix.empty()) { size_t s = prefix.find_last_of('/'); if (s != string::npos) mkdirs(prefix.substr(0, s)); }
+    if (!kf.empty()) {
+        FILE *out = open_out(prefix.empty() ? "" : prefix + ".fasta");
+        vector<unsigned char> b = slurp(kf);
+        size_t i = 1;
+        for (size_t p = 0; p + 10 <= b.size(); p += 10, i++) fprintf(out, ">%zu\n%s\n", i, kmer_string(be_read(&b[p], 8), k).c_str());
+        close_out(out);
+    }
+    if (!cf.empty()) {
+        vector<HostComp> cs = read_components(cf);
+        logmsg("INFO", "%zu components loaded from %s", cs.size(), cf.c_str());
+        if (a.get("split", "false") == "true") {
+            for (size_t i = 0; i < cs.size(); i++) {
+                FILE *out = open_out(prefix.empty() ? "" : prefix + "_" + std::to_string(i + 1) + ".fasta");
+                size_t j = 1;
+                for (uint64_t km : cs[i].kmers) fprintf(out, ">%zu\n%s\n", j++, kmer_string(km, k).c_str());
+                close_out(out);
+            }
+        } else {
+            FILE *out = open_out(prefix.empty() ? "" : prefix + ".fasta");
+            for (size_t i = 0; i < cs.size(); i++) { size_t j = 1; for (uint64_t km : cs[i].kmers) fprintf(out, ">%zu_%zu\n%s\n", i + 1, j++, kmer_string(km, k).c_str()); }
+            close_out(out);
+        }
+    }
+}
+
 // dist-matrix-calculator (src/tools/DistanceMatrixCalculatorMain.java:51-123)
 static string run_dist_matrix(Env &e, const Args &a, const vector<string> &features, const string &matrix_path_tpl) {
     if (features.empty()) die("Mandatory option --features is not set");
@@ -477,6 +565,8 @@ static const char *TOOLS_TEXT =
     "features-calculator\tCalculate features values for input reads/k-mers files\n"
     "dist-matrix-calculator\tCalculate the distance matrix using features values\n"
     "heatmap-maker\t\tCluster the samples of a distance matrix and renumber it (no image)\n"
+    "view\t\t\tView different binary objects (k-mers files, components)\n"
+    "bin2fasta\t\tConverts different binary objects to FASTA format\n"
     "matrix-builder\t\tBuild the distance matrix for input sequences (default tool)\n";
 
 int main(int argc, char **argv) {
@@ -524,6 +614,10 @@ int main(int argc, char **argv) {
         run_features(e, a, a.get("components-file"), a.list("reads"), a.list("kmers"), k, a.geti("threshold", 0), wd);
     } else if (tool == "dist-matrix-calculator") {
         run_dist_matrix(e, a, a.list("features"), a.get("matrix-file", wd + "/dist_matrix_$DT_original_order.txt"));
+    } else if (tool == "view") {
+        run_view(a, k);
+    } else if (tool == "bin2fasta") {
+        run_bin2fasta(a, k);
     } else if (tool == "heatmap-maker") {
         if (!a.has("matrix-file")) die("Mandatory option --matrix-file is not set");
         run_heatmap_maker(e, a, a.get("matrix-file"), a.get("new-matrix-file"));

@@ -89,3 +89,43 @@ def test_heatmap_maker_errors(tmp_path):
     m.write_text("0.0\t0.1\n0.1\t0.0\n")
     r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(m), "--output-format", "%d", "-w", str(tmp_path / "w")], capture_output=True, text=True)
     assert r.returncode == 1 and "Unsupported --output-format" in r.stderr
+
+
+def _kmer_str(km, k):
+    return "".join("AGCT"[(km >> (2 * (k - 1 - i))) & 3] for i in range(k))
+
+
+def test_view_and_bin2fasta(oracle, ref_files, tmp_path):
+    """view / bin2fasta (ViewMain.java:64-131, BinaryToFasta.java:74-170): text dumps of .kmers.bin and components.bin
+    written by the oracle; k-mers of a .kmers.bin are printed in file order (the reference: hash-map order)"""
+    k = 31
+    r = oracle.run_pipeline(ref_files[:1], b1=50, b2=500)
+    kb, cb = tmp_path / "s.kmers.bin", tmp_path / "components.bin"
+    r["samples"][0]["table"].write_kmers(1, str(kb))
+    r["comps"].write(str(cb), None)
+    raw = open(kb, "rb").read()
+    recs = [(int.from_bytes(raw[i:i + 8], "big"), int.from_bytes(raw[i + 8:i + 10], "big")) for i in range(0, len(raw), 10)]
+    comps = r["comps"].all()
+    out = tmp_path / "view.txt"
+    p = subprocess.run([EXE, "-t", "view", "-k", str(k), "-kf", str(kb), "-cf", str(cb), "-o", str(out), "-w", str(tmp_path / "w")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    want = ["Kmer\tCount"] + ["%s\t%d" % (_kmer_str(km, k), c) for km, c in recs] + ["%d components:" % len(comps)]
+    for i, (size, weight, thr, kmers) in enumerate(comps):
+        want.append("Component %d, size = %d kmers, weight = %d. Kmers:" % (i + 1, size, weight))
+        want += [_kmer_str(int(km), k) for km in kmers] + [""]
+    assert open(out).read().split("\n") == want + [""]
+    pre = tmp_path / "fa" / "comp"
+    p = subprocess.run([EXE, "-t", "bin2fasta", "-k", str(k), "-cf", str(cb), "-o", str(pre), "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    want = []
+    for i, (size, weight, thr, kmers) in enumerate(comps):
+        for j, km in enumerate(kmers):
+            want += [">%d_%d" % (i + 1, j + 1), _kmer_str(int(km), k)]
+    assert open(str(pre) + ".fasta").read().split("\n") == want + [""]
+    p = subprocess.run([EXE, "-t", "bin2fasta", "-k", str(k), "-kf", str(kb), "-cf", str(cb), "--split", "-o", str(pre), "-w", str(tmp_path / "w")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    assert open(str(pre) + ".fasta").read().split("\n")[:4] == [">1", _kmer_str(recs[0][0], k), ">2", _kmer_str(recs[1][0], k)]
+    last = len(comps)
+    assert open("%s_%d.fasta" % (pre, last)).read().split("\n")[:2] == [">1", _kmer_str(int(comps[-1][3][0]), k)]
