@@ -2,6 +2,7 @@
 // Plain C++ (no kernels); formats follow SURVEY.md Appendix A, each function cites the reference it replaces.
 #include "mf_common.h"
 #include <zlib.h>
+#include <dlfcn.h>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -316,25 +317,85 @@ static int inflate_gz(const raw_file &in, raw_file &out, const char *path) {
     out.n = have;
     return MF_OK;
 }
-// ReadersUtils.detectFileFormat (itmo!/io/ReadersUtils.java:27-54): ".gz" is stripped first, then the format extension.
-// .bz2 and .binq inputs are not supported by the HIP path yet.
+// .bz2 inputs (FastaBZ2Reader.java:26-30, FastqBZ2Reader: Hadoop's BZip2Codec, which reads concatenated streams): libbz2 is
+// loaded at run time (the build image carries libbz2.so.1.0 but not its header; the four entry points and bz_stream below are
+// the library's stable public ABI since 1.0).
+struct mf_bz_stream {
+    char *next_in; unsigned int avail_in, total_in_lo32, total_in_hi32;
+    char *next_out; unsigned int avail_out, total_out_lo32, total_out_hi32;
+    void *state; void *(*bzalloc)(void *, int, int); void (*bzfree)(void *, void *); void *opaque;
+};
+static int inflate_bz2(const raw_file &in, raw_file &out, const char *path) {
+    static void *lib = nullptr;
+    typedef int (*init_fn)(mf_bz_stream *, int, int); typedef int (*step_fn)(mf_bz_stream *);
+    static init_fn bz_init = nullptr; static step_fn bz_step = nullptr, bz_end = nullptr;
+    if (!lib) {
+        for (const char *n : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) if ((lib = dlopen(n, RTLD_NOW))) break;
+        if (lib) {
+            bz_init = (init_fn)dlsym(lib, "BZ2_bzDecompressInit"); bz_step = (step_fn)dlsym(lib, "BZ2_bzDecompress"); bz_end = (step_fn)dlsym(lib, "BZ2_bzDecompressEnd");
+        }
+    }
+    if (!lib || !bz_init || !bz_step || !bz_end) return mf_set_error("bzip2 input needs libbz2 at run time (not found): '%s'", path);
+    size_t cap = std::max<size_t>(in.n * 6, (size_t)1 << 20), have = 0, fed = 0;
+    out.p = (char *)malloc(cap);
+    if (!out.p) return mf_set_error("out of host memory inflating '%s'", path);
+    mf_bz_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (bz_init(&zs, 0, 0) != 0) return mf_set_error("bzip2: init failed");
+    int ret = 0;                              // BZ_OK 0, BZ_STREAM_END 4
+    for (;;) {
+        if (zs.avail_in == 0 && fed < in.n) {
+            const size_t chunk = std::min<size_t>(in.n - fed, (size_t)1 << 30);
+            zs.next_in = in.p + fed; zs.avail_in = (unsigned int)chunk; fed += chunk;
+        }
+        if (have == cap) {
+            cap *= 2;
+            char *np = (char *)realloc(out.p, cap);
+            if (!np) { bz_end(&zs); return mf_set_error("out of host memory inflating '%s'", path); }
+            out.p = np;
+        }
+        const size_t room = std::min<size_t>(cap - have, (size_t)1 << 30);
+        zs.next_out = out.p + have; zs.avail_out = (unsigned int)room;
+        const unsigned int in_before = zs.avail_in;
+        ret = bz_step(&zs);
+        have += room - zs.avail_out;
+        if (ret == 4) {
+            if (zs.avail_in == 0 && fed == in.n) break;                    // end of the last stream
+            bz_end(&zs);
+            char *ni = zs.next_in; unsigned int ai = zs.avail_in;
+            memset(&zs, 0, sizeof zs);
+            if (bz_init(&zs, 0, 0) != 0) return mf_set_error("bzip2: init failed");
+            zs.next_in = ni; zs.avail_in = ai;                             // next stream of a concatenated file
+            continue;
+        }
+        if (ret != 0) break;
+        if (zs.avail_in == 0 && fed == in.n && room == zs.avail_out && in_before == 0) { ret = -7; break; }   // truncated
+    }
+    bz_end(&zs);
+    if (ret != 4) return mf_set_error("Not in BZIP2 format or corrupt stream: '%s'", path);
+    out.n = have;
+    return MF_OK;
+}
+// ReadersUtils.detectFileFormat (itmo!/io/ReadersUtils.java:27-54): ".gz" / ".bz2" is stripped first, then the format extension.
+// .binq inputs are not supported by the HIP path.
 static int parse_reads_file(const char *path, int threads, std::vector<read_batch> &parts) {
     std::string p(path);
     int fmt = 0;
-    bool gz = false;
+    bool gz = false, bz = false;
     if (ends_with_nocase(p, ".gz")) { gz = true; p.resize(p.size() - 3); }
-    if (ends_with_nocase(p, ".bz2") || ends_with_nocase(p, ".binq"))
-        return mf_set_error("bzip2 / binq input is not supported by the HIP path yet: '%s'", path);
+    if (ends_with_nocase(p, ".bz2")) { bz = true; p.resize(p.size() - 4); }
+    if (ends_with_nocase(p, ".binq"))
+        return mf_set_error("binq input is not supported by the HIP path yet: '%s'", path);
     if (ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq")) fmt = 2;
     else if (ends_with_nocase(p, ".fasta") || ends_with_nocase(p, ".fa") || ends_with_nocase(p, ".fn") || ends_with_nocase(p, ".fna")) fmt = 1;
     if (!fmt) return mf_set_error("Can't detect file format for file '%s'", path);
     raw_file buf;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    if (gz) {
+    if (gz || bz) {
         raw_file packed;
         MF_TRY(read_file_parallel(path, packed, threads));
-        MF_TRY(inflate_gz(packed, buf, path));
+        MF_TRY(gz ? inflate_gz(packed, buf, path) : inflate_bz2(packed, buf, path));
     } else MF_TRY(read_file_parallel(path, buf, threads));
     const double t1 = now();
     int rc = parse_buffer_parallel(buf, fmt, path, threads, parts);

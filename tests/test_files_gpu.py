@@ -64,6 +64,11 @@ def test_gzip_inputs(gpu_ctx, oracle, ref_files, tmp_path):
     for f in (one, two):
         gk, gc = gpu_ctx.count_reads([str(f)], 31).export()
         assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+    import bz2
+    bz1 = tmp_path / "c.fa.bz2"
+    bz1.write_bytes(bz2.compress(plain[:cut], 9) + bz2.compress(plain[cut:], 1))       # two streams
+    gk, gc = gpu_ctx.count_reads([str(bz1)], 31).export()
+    assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
     fq = os.path.join(REF_DATA, "tinytest_A.fastq")
     fqz = tmp_path / "t.fq.gz"
     fqz.write_bytes(gzip.compress(open(fq, "rb").read()))
@@ -89,8 +94,12 @@ def test_reader_errors(gpu_ctx, tmp_path):
         gpu_ctx.count_reads([str(gz)], 3)
     bz = tmp_path / "reads.fa.bz2"
     bz.write_bytes(b"BZh9")
-    with pytest.raises(MetafastError, match="not supported"):
+    with pytest.raises(MetafastError, match="BZIP2"):             # truncated / corrupt bzip2 stream
         gpu_ctx.count_reads([str(bz)], 3)
+    bq = tmp_path / "reads.binq"
+    bq.write_bytes(b"\x00")
+    with pytest.raises(MetafastError, match="not supported"):
+        gpu_ctx.count_reads([str(bq)], 3)
     x = tmp_path / "x.fa"
     x.write_text(">a\nACGTXACGT\n")
     with pytest.raises(MetafastError, match="Incorrect nucleotide"):
