@@ -71,7 +71,7 @@ int  mf_ctx_reset_timers(mf_ctx *ctx);
  * KmersCounterMain.runImpl (src/tools/KmersCounterMain.java:77) with min_read_len=0 and from
  * ComponentCutterMain.runImpl (src/tools/ComponentCutterMain.java:81) with min_read_len=l.
  * Files are FASTA/FASTQ by extension, optionally compressed (.gz, .bz2; itmo!/io/ReadersUtils.java:27-54,
- * FastaGZReader.java, FastqGZReader.java, FastaBZ2Reader.java; .binq is rejected); reads with N (FASTA)
+ * FastaGZReader.java, FastqGZReader.java, FastaBZ2Reader.java) or .binq (BinqReader.java); reads with N (FASTA)
  * or any phred-0 base (FASTQ) are dropped (FastaReader.java:53-76, FastaReaderFromXQSource.java:66-70).
  * All files go into ONE table (paired files are summed). */
 int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len,

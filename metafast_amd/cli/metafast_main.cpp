@@ -69,6 +69,7 @@ static string library_name(const string &path) {
     string b = basename_of(path);
     if (ends_with_ci(b, ".gz")) b = b.substr(0, b.size() - 3);          // FastaGZReader.java:17, FastqGZReader.java:21
     else if (ends_with_ci(b, ".bz2")) b = b.substr(0, b.size() - 4);    // FastaBZ2Reader.java:20
+    if (ends_with_ci(b, ".binq")) return remove_ext(b, {".binq"});         // BinqReader.java:19
     if (ends_with_ci(b, ".fastq") || ends_with_ci(b, ".fq")) return remove_ext(b, {".fastq", ".fq"});
     return remove_ext(b, {".fasta", ".fa", ".fn", ".fna"});
 }

@@ -195,6 +195,26 @@ static int parse_fastq_pass(const char *data, size_t size, const char *path, int
     }
     return pass == 0 ? 64 : MF_OK;
 }
+// .binq (BinqReader.java:52-88 + FastaReaderFromXQSource.java:62-76): records of a 4-byte big-endian length followed by one byte
+// per base, nucleotide in bits 0-1 (A0 G1 C2 T3), phred in bits 2-7; bytes of 255 before a record are padding; a read with a
+// phred-0 base is dropped (that is how N is stored)
+static int parse_binq(const char *b, size_t n, const char *path, read_batch &rb) {
+    const unsigned char *u = (const unsigned char *)b;
+    size_t pos = 0;
+    for (;;) {
+        while (pos < n && u[pos] == 255) pos++;
+        if (pos >= n) return MF_OK;
+        if (pos + 4 > n) return mf_set_error("Unexpected end of file %s", path);
+        const size_t len = ((size_t)u[pos] << 24) | ((size_t)u[pos + 1] << 16) | ((size_t)u[pos + 2] << 8) | (size_t)u[pos + 3];
+        pos += 4;
+        if (pos + len > n) return mf_set_error("Unexpected end of file %s", path);
+        bool good = true;
+        uint8_t *dst = rb.bases.grow(len);
+        for (size_t i = 0; i < len; i++) { const unsigned v = u[pos + i]; dst[i] = (uint8_t)"AGCT"[v & 3u]; good &= (v >> 2) != 0; }
+        pos += len;
+        if (good) { rb.bases.n += len; rb.end_read(); }
+    }
+}
 // ---- parallel host parsing: the file is cut at record starts, each host thread parses its piece with the serial
 // parser above (so the semantics are the serial ones by construction), pieces are concatenated in order.
 // The reference parses serially under a monitor (src/io/ReadersDispatcher.java:34-53) -- its Amdahl limit; here the
@@ -377,16 +397,15 @@ static int inflate_bz2(const raw_file &in, raw_file &out, const char *path) {
     return MF_OK;
 }
 // ReadersUtils.detectFileFormat (itmo!/io/ReadersUtils.java:27-54): ".gz" / ".bz2" is stripped first, then the format extension.
-// .binq inputs are not supported by the HIP path.
+// .binq: the reference's own binary read format, parsed serially.
 static int parse_reads_file(const char *path, int threads, std::vector<read_batch> &parts) {
     std::string p(path);
     int fmt = 0;
     bool gz = false, bz = false;
     if (ends_with_nocase(p, ".gz")) { gz = true; p.resize(p.size() - 3); }
     if (ends_with_nocase(p, ".bz2")) { bz = true; p.resize(p.size() - 4); }
-    if (ends_with_nocase(p, ".binq"))
-        return mf_set_error("binq input is not supported by the HIP path yet: '%s'", path);
-    if (ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq")) fmt = 2;
+    if (ends_with_nocase(p, ".binq")) fmt = 3;
+    else if (ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq")) fmt = 2;
     else if (ends_with_nocase(p, ".fasta") || ends_with_nocase(p, ".fa") || ends_with_nocase(p, ".fn") || ends_with_nocase(p, ".fna")) fmt = 1;
     if (!fmt) return mf_set_error("Can't detect file format for file '%s'", path);
     raw_file buf;
@@ -398,7 +417,9 @@ static int parse_reads_file(const char *path, int threads, std::vector<read_batc
         MF_TRY(gz ? inflate_gz(packed, buf, path) : inflate_bz2(packed, buf, path));
     } else MF_TRY(read_file_parallel(path, buf, threads));
     const double t1 = now();
-    int rc = parse_buffer_parallel(buf, fmt, path, threads, parts);
+    int rc;
+    if (fmt == 3) { read_batch rb; rc = parse_binq(buf.data(), buf.size(), path, rb); if (rc == MF_OK) parts.push_back(std::move(rb)); }
+    else rc = parse_buffer_parallel(buf, fmt, path, threads, parts);
     if (getenv("MF_IO_TIMING")) fprintf(stderr, "[mf] %s: read %.3f s, parse %.3f s\n", path, t1 - t0, now() - t1);
     return rc;
 }

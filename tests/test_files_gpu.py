@@ -82,6 +82,32 @@ def test_gzip_inputs(gpu_ctx, oracle, ref_files, tmp_path):
     assert os.listdir(wd / "kmers") == ["a.kmers.bin"] and os.path.getsize(wd / "kmers" / "a.kmers.bin") == 169180
 
 
+def test_binq_input(gpu_ctx, oracle, tmp_path):
+    """.binq (BinqReader): length-prefixed records, nucleotide in bits 0-1 and phred in bits 2-7 of each byte; a phred-0
+    base drops the read, 255 bytes between records are padding"""
+    from util import pack_reads
+    rng = np.random.default_rng(5)
+    reads = ["".join("AGCT"[c] for c in rng.integers(0, 4, size=int(n))) for n in rng.integers(0, 90, size=300)]
+    code = {"A": 0, "G": 1, "C": 2, "T": 3}
+    blob, kept = b"", []
+    for i, r in enumerate(reads):
+        ph = rng.integers(1, 41, size=len(r))
+        if i % 7 == 3 and len(r):
+            ph[rng.integers(0, len(r))] = 0                       # an N: the read is skipped
+        else:
+            kept.append(r)
+        if i % 11 == 0:
+            blob += b"\xff" * 3
+        blob += len(r).to_bytes(4, "big") + bytes((int(q) << 2) | code[c] for c, q in zip(r, ph))
+    f = tmp_path / "lib.binq"
+    f.write_bytes(blob + b"\xff")
+    b, o = pack_reads(kept)
+    for k in (5, 21):
+        gk, gc = gpu_ctx.count_reads([str(f)], k).export()
+        ok, ov = oracle.Table().count_buffer(b, o, k).export()
+        assert len(gk) > 0 and np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+
+
 def test_reader_errors(gpu_ctx, tmp_path):
     from metafast_amd.lib import MetafastError
     bad = tmp_path / "reads.txt"
@@ -97,8 +123,8 @@ def test_reader_errors(gpu_ctx, tmp_path):
     with pytest.raises(MetafastError, match="BZIP2"):             # truncated / corrupt bzip2 stream
         gpu_ctx.count_reads([str(bz)], 3)
     bq = tmp_path / "reads.binq"
-    bq.write_bytes(b"\x00")
-    with pytest.raises(MetafastError, match="not supported"):
+    bq.write_bytes(b"\x00\x00\x00\x09AC")
+    with pytest.raises(MetafastError, match="Unexpected end of file"):
         gpu_ctx.count_reads([str(bq)], 3)
     x = tmp_path / "x.fa"
     x.write_text(">a\nACGTXACGT\n")
