@@ -245,3 +245,22 @@ def test_count_above_threshold(gpu_ctx, oracle, skm):
                 assert np.array_equal(t.lookup(probe), want)
     finally:
         _reset(gpu_ctx)
+
+
+def test_long_sequences(gpu_ctx, oracle):
+    """assembled sequences (the cutter's input: mean length >= 8k selects the small-partition plan): one long sequence
+    among short ones, with and without the length filter, on both paths"""
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(13)
+    al = np.frombuffer(b"ACGT", dtype=np.uint8)
+    parts = [al[rng.integers(0, 4, size=n)] for n in (70, 1_500_000, 31, 30, 400, 99, 100)]
+    b = np.concatenate(parts).astype(np.uint8)
+    o = np.concatenate([[0], np.cumsum([len(x) for x in parts])]).astype(np.uint64)
+    try:
+        for skm in (1, 0):
+            gpu_ctx.set_option("skm", skm)
+            _check(gpu_ctx, oracle, b, o, 31)
+            _check(gpu_ctx, oracle, b, o, 31, min_len=100)
+            _check(gpu_ctx, oracle, b, o, 21, min_len=100)
+    finally:
+        _reset(gpu_ctx)
