@@ -129,6 +129,7 @@ struct mf_table {
     uint64_t n = 0;               // distinct k-mers
     uint64_t n_occ = 0;           // occurrences fed in
     uint64_t n_records = 0; int record_bytes = 0;   // records the counting pass partitioned (mf_table_records)
+    int cut_thr = -1;             // every entry has count > cut_thr (tables that went through a cut: no need to test again)
     uint64_t *d_keys = nullptr;   // [n]
     uint16_t *d_counts = nullptr; // [n]
     size_t keys_bytes = 0, counts_bytes = 0;

@@ -774,7 +774,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     if (thr >= 0) {                                     // (this path keeps the cut as a separate pass)
         mf_table *all = *out, *good = nullptr;
         int rc = mf_table_filter(all, thr, &good);
-        if (rc == MF_OK) { good->n_occ = all->n_occ; good->n_records = all->n_records; good->record_bytes = all->record_bytes; }
+        if (rc == MF_OK) { good->n_occ = all->n_occ; good->n_records = all->n_records; good->record_bytes = all->record_bytes; good->cut_thr = thr; }
         mf_table_destroy(all);
         *out = good;
         return rc;

@@ -984,6 +984,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         const unsigned long long nv = nv2[0];
         if (n_all) *n_all = nv2[1];
         (*out)->n_records = nv ? nv : cap_l1;             // (plans without a split level: the padded level-1 count)
+        (*out)->cut_thr = thr;
         (*out)->record_bytes = 16;
     }
     if (total_bits > 0 && total_bits <= 30) {

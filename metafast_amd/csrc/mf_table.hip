@@ -357,6 +357,7 @@ extern "C" int mf_table_filter(const mf_table *t, int threshold, mf_table **out)
     MF_TRY(select_entries<0>(ctx, t->d_keys, t->d_counts, nullptr, t->n, threshold, ok, oc, &m));
     size_t kb = ok.bytes(), cb = oc.bytes();
     MF_TRY(mf_table_adopt(ctx, t->k, m, 0, ok.take(), kb, oc.take(), cb, out));
+    (*out)->cut_thr = std::max(t->cut_thr, threshold);
     if (t->part_bits > 0 && t->d_part_off && m) {
         // the compaction is stable, so the selected entries of partition p are still contiguous: new offsets by a scan
         const uint32_t np = 1u << t->part_bits;
@@ -375,7 +376,8 @@ extern "C" int mf_table_filter(const mf_table *t, int threshold, mf_table **out)
 
 int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out) {
     mf_ctx *ctx = t->ctx;
-    if (t->n) {
+    bool all_pass = t->n && t->cut_thr >= threshold;          // the table went through this cut (or a stricter one) already
+    if (t->n && !all_pass) {
         // count first; copy only if something is filtered out
         uint64_t n = t->n;
         uint64_t nb = std::min<uint64_t>((n + 1023) / 1024, 2048);
@@ -389,16 +391,18 @@ int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out) {
         uint64_t m = 0;
         MF_HIP(hipMemcpyAsync(&m, tot.p, 8, hipMemcpyDeviceToHost, ctx->stream));
         MF_HIP(hipStreamSynchronize(ctx->stream));
-        if (m == n) {
-            // nothing to filter: an alias that borrows the arrays AND the index of t (built here on t, so that later users
-            // of t -- the features step -- find it instead of building their own)
-            MF_TRY(mf_table_ensure_index(const_cast<mf_table *>(t)));
-            MF_TRY(mf_table_adopt(ctx, t->k, t->n, 0, t->d_keys, t->keys_bytes, t->d_counts, t->counts_bytes, out));
-            (*out)->owns_arrays = false;
-            (*out)->index = t->index; (*out)->index_bytes = t->index_bytes;
-            (*out)->part_bits = t->part_bits; (*out)->part_skm = t->part_skm; (*out)->d_part_off = t->d_part_off; (*out)->part_off_bytes = t->part_off_bytes;
-            return MF_OK;
-        }
+        all_pass = m == n;
+    }
+    if (all_pass) {
+        // nothing to filter: an alias that borrows the arrays AND the index of t (built here on t, so that later users
+        // of t -- the features step -- find it instead of building their own)
+        MF_TRY(mf_table_ensure_index(const_cast<mf_table *>(t)));
+        MF_TRY(mf_table_adopt(ctx, t->k, t->n, 0, t->d_keys, t->keys_bytes, t->d_counts, t->counts_bytes, out));
+        (*out)->owns_arrays = false;
+        (*out)->cut_thr = std::max(t->cut_thr, threshold);
+        (*out)->index = t->index; (*out)->index_bytes = t->index_bytes;
+        (*out)->part_bits = t->part_bits; (*out)->part_skm = t->part_skm; (*out)->d_part_off = t->d_part_off; (*out)->part_off_bytes = t->part_off_bytes;
+        return MF_OK;
     }
     return mf_table_filter(t, threshold, out);
 }
