@@ -484,24 +484,20 @@ __global__ __launch_bounds__(1024) void k_skm_split(const skm_rec *__restrict__ 
 // =============================================================================================
 // S4: count one partition per workgroup
 // =============================================================================================
-// LDS steps of 1 or 4 keys per lane (one asm block each: the waits belong to the block, see mf_count_dev.h)
+// one-key-per-lane LDS steps of the collision queue (one asm block each: the waits belong to the block, see
+// mf_count_dev.h; the four-wide steps of the first probe are mf_lds_read4_b64 / mf_lds_cmpst4_b64 / mf_lds_add4)
 template <int B> __device__ __forceinline__ void skm_lds_read_b64(const uint32_t (&a)[B], uint64_t (&v)[B]);
 template <> __device__ __forceinline__ void skm_lds_read_b64<1>(const uint32_t (&a)[1], uint64_t (&v)[1]) {
     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]) : "v"(a[0]) : "memory");
 }
-template <> __device__ __forceinline__ void skm_lds_read_b64<4>(const uint32_t (&a)[4], uint64_t (&v)[4]) { mf_lds_read4_b64(a, v); }
 template <int B> __device__ __forceinline__ void skm_lds_cmpst_b64(const uint32_t (&a)[B], uint64_t cmp, const uint64_t (&nv)[B], uint64_t (&old)[B]);
 template <> __device__ __forceinline__ void skm_lds_cmpst_b64<1>(const uint32_t (&a)[1], uint64_t cmp, const uint64_t (&nv)[1], uint64_t (&old)[1]) {
     asm volatile("ds_cmpst_rtn_b64 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old[0]) : "v"(a[0]), "v"(cmp), "v"(nv[0]) : "memory");
-}
-template <> __device__ __forceinline__ void skm_lds_cmpst_b64<4>(const uint32_t (&a)[4], uint64_t cmp, const uint64_t (&nv)[4], uint64_t (&old)[4]) {
-    mf_lds_cmpst4_b64(a, cmp, nv, old);
 }
 template <int B> __device__ __forceinline__ void skm_lds_add(const uint32_t (&a)[B], const uint32_t (&inc)[B]);
 template <> __device__ __forceinline__ void skm_lds_add<1>(const uint32_t (&a)[1], const uint32_t (&inc)[1]) {
     asm volatile("ds_add_u32 %0, %1" ::"v"(a[0]), "v"(inc[0]) : "memory");
 }
-template <> __device__ __forceinline__ void skm_lds_add<4>(const uint32_t (&a)[4], const uint32_t (&inc)[4]) { mf_lds_add4(a, inc); }
 
 // slot of a key in the LDS table: two 32-bit multiplies (the 64-bit multiply of mf_phash is six quarter-rate instructions)
 __device__ __forceinline__ uint32_t skm_slot(uint64_t key) {
