@@ -6,8 +6,10 @@
 //   itmo!/utils/tool/Tool.java:61-143, 212-214, 318-392        launch options (-w -p -c --force -s -f -v -h), <workDir>/<tool>/, SUCCESS
 //   src/tools/KmersCounterMain.java, KmersCounterForManyFilesMain.java, SeqBuilderMain.java, SeqBuilderForManyFilesMain.java,
 //   ComponentCutterMain.java, FeaturesCalculatorMain.java, DistanceMatrixCalculatorMain.java, DistanceMatrixBuilderMain.java
-// Parameter names, defaults, output file names and the workDir layout are the reference's; the Tool
-// framework itself (in/out.properties, interactive prompts, log4j) is not reproduced.  Errors: message on stderr, exit 1.
+// Parameter names, defaults, output file names and the workDir layout are the reference's, and so is the
+// step bookkeeping of the Tool framework (in.properties / out.properties / SUCCESS per step, -c/--force/-s/-f, the
+// "rewrite them?" prompt, log + logs/log_<ts>, output_description.txt), so that a Java run can continue a workDir this
+// program wrote and the other way round.  Errors: message on stderr, exit 1.
 #include <algorithm>
 #include <cerrno>
 #include <cmath>
@@ -29,13 +31,18 @@ using std::vector;
 
 // ------------------------------------------------------------------------------------------------ utilities
 static bool g_verbose = false;
-static FILE *g_logfile = nullptr;
+static FILE *g_logfile = nullptr, *g_logfile2 = nullptr;      // <workDir>/log and <workDir>/logs/log_<ts> (identical)
 static void logmsg(const char *level, const char *fmt, ...) {
     char buf[4096];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     bool debug = !strcmp(level, "DEBUG");
     if (!debug || g_verbose) fprintf(stderr, "%s: %s\n", level, buf);
-    if (g_logfile) { fprintf(g_logfile, "%s: %s\n", level, buf); fflush(g_logfile); }
+    if (g_logfile || g_logfile2) {                          // "%d{dd-MMM-yy  HH:mm:ss,SSS}  %-5p  %m%n" (Tool.java:700)
+        struct timespec ts; clock_gettime(CLOCK_REALTIME, &ts);
+        struct tm tmv; localtime_r(&ts.tv_sec, &tmv);
+        char d[64]; strftime(d, sizeof d, "%d-%b-%y  %H:%M:%S", &tmv);
+        for (FILE *f : {g_logfile, g_logfile2}) if (f) { fprintf(f, "%s,%03ld  %-5s  %s\n", d, ts.tv_nsec / 1000000, level, buf); fflush(f); }
+    }
 }
 [[noreturn]] static void die(const char *fmt, ...) {
     char buf[4096];
@@ -79,6 +86,11 @@ static string timestamp() {                                 // Tool.java:664 "yy
     return b;
 }
 static void touch(const string &p) { FILE *f = fopen(p.c_str(), "w"); if (f) fclose(f); }
+static string abspath(const string &p) {                    // File.getAbsolutePath: no normalisation
+    if (!p.empty() && p[0] == '/') return p;
+    char cwd[4096]; if (!getcwd(cwd, sizeof cwd)) return p;
+    return string(cwd) + "/" + p;
+}
 static string group_digits(uint64_t v) {                    // NumUtils.groupDigits: 1'234'567
     string s = std::to_string(v), o;
     for (size_t i = 0; i < s.size(); i++) { o.push_back(s[i]); size_t r = s.size() - 1 - i; if (r && r % 3 == 0) o.push_back('\''); }
@@ -112,8 +124,8 @@ static const OptDef OPTS[] = {
     {"min-component-size", "b1", false, false}, {"max-component-size", "b2", false, false}, {"components-file", "cm", false, false},
     {"kmers", "ka", true, false}, {"selected", "", true, false}, {"threshold", "", false, false},
     {"features", "", true, false}, {"without-names", "wn", false, true}, {"matrix-file", "", false, false},
-    {"output-format", "", false, false}, {"heatmap-file", "", false, false}, {"new-matrix-file", "", false, false},
-    {"without-renumbering", "", false, true},
+    {"output-format", "", false, false}, {"heatmap-file", "", false, false}, {"newMatrix-file", "", false, false},
+    {"without-renumbering", "wr", false, true}, {"colors-file", "col", false, false}, {"invert-colors", "", false, true},
     {"kmers-file", "kf", false, false}, {"output-file", "o", false, false}, {"split", "", false, true}, {"long", "", false, true},
     {"use-reads-for-calculating-features", "", false, true}, {"device", "", false, false},
 };
@@ -125,6 +137,7 @@ static Args parse_args(int argc, char **argv, string *tool_out) {
     *tool_out = tool;
     auto long_of_short = [&](const string &s) -> string {
         if (s == "i") {
+            if (tool == "heatmap-maker") return "matrix-file";                 // HeatMapMakerMain.java:34-36
             if (tool == "seq-builder" || tool == "seq-builder-many") return "k-mers";
             if (tool == "component-cutter") return "sequences";
             return "reads";
@@ -142,7 +155,7 @@ static Args parse_args(int argc, char **argv, string *tool_out) {
         // launcher-level options handled by stub.sh in the reference (src/stub.sh:6-19): accepted and ignored
         if (tok == "-ea" || tok.rfind("-X", 0) == 0 || tok.rfind("-agentlib:", 0) == 0) { i++; continue; }
         string name;
-        if (tok.rfind("--", 0) == 0) name = tok.substr(2);
+        if (tok.rfind("--", 0) == 0) { name = tok.substr(2); if (name == "new-matrix-file") name = "newMatrix-file"; }
         else if (tok.size() > 1 && tok[0] == '-') name = long_of_short(tok.substr(1));
         else die("Unknown argument '%s'", tok.c_str());
         const OptDef *def = nullptr;
@@ -546,18 +559,89 @@ static string run_dist_matrix(Env &e, const Args &a, const vector<string> &featu
     return path;
 }
 
-// one step of a composite tool: <workDir>/<name>/ + SUCCESS marker (Tool.java:212-214, 318-392); -c skips finished steps
-struct Step { string name; string dir; };
-static void step_finish(const Step &s) { touch(s.dir + "/SUCCESS"); }
-static vector<string> list_files(const string &dir, const string &suffix) {
-    vector<string> out; string cmd = "ls -1 '" + dir + "' 2>/dev/null"; FILE *p = popen(cmd.c_str(), "r");
-    if (!p) return out;
-    char line[4096];
-    while (fgets(line, sizeof line, p)) { string s(line); while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back(); if (ends_with_ci(s, suffix)) out.push_back(dir + "/" + s); }
-    pclose(p); std::sort(out.begin(), out.end());
-    return out;
+// ------------------------------------------------------------------------------------------------ step bookkeeping
+// Tool.runAsStep (itmo!/utils/tool/Tool.java:318-392) and its property files (:740-960): every tool run, top level or sub-step,
+// owns a directory with in.properties (its input parameters, written before it runs), out.properties (its output
+// parameters) and SUCCESS.  A finished step is re-used by --continue iff in.properties and SUCCESS exist and every stored
+// input equals the current one.  PropertiesConfiguration.save with delimiter parsing disabled: "key = value", one line
+// per value of a multi-valued key, null parameters left out, files as absolute paths (Tool.objectToString :950-966).
+struct PV {
+    string name; vector<string> vals; bool set = true;                       // set == false: null, not written
+    PV(string n, vector<string> v) : name(std::move(n)), vals(std::move(v)) {}
+    PV(string n, const string &v) : name(std::move(n)), vals{v} {}
+    PV(string n, int v) : name(std::move(n)), vals{std::to_string(v)} {}
+    static PV null(string n) { PV p(std::move(n), vector<string>()); p.set = false; return p; }
+    static PV file(string n, const string &v) { return v.empty() ? null(std::move(n)) : PV(std::move(n), abspath(v)); }
+    static PV files(string n, const vector<string> &v) { vector<string> o; for (auto &x : v) o.push_back(abspath(x)); return PV(std::move(n), o); }
+    static PV flag(string n, bool v) { return PV(std::move(n), string(v ? "true" : "false")); }
+};
+typedef std::map<string, vector<string>> Props;
+static void props_write(const string &path, const vector<PV> &ps) {
+    FILE *f = fopen(path.c_str(), "w");
+    if (!f) die("Can't dump configuration to %s", path.c_str());
+    for (auto &p : ps) if (p.set) for (auto &v : p.vals) {
+        string esc; for (char c : v) { if (c == '\\') esc += "\\\\"; else esc.push_back(c); }
+        fprintf(f, "%s = %s\n", p.name.c_str(), esc.c_str());
+    }
+    fclose(f);
 }
-
+static bool props_read(const string &path, Props &out) {
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char *line = nullptr; size_t cap = 0;
+    while (getline(&line, &cap, f) > 0) {
+        string l(line); while (!l.empty() && (l.back() == '\n' || l.back() == '\r')) l.pop_back();
+        size_t i = 0; while (i < l.size() && isspace((unsigned char)l[i])) i++;
+        if (i == l.size() || l[i] == '#' || l[i] == '!') continue;
+        size_t ke = i; while (ke < l.size() && l[ke] != '=' && l[ke] != ':' && !isspace((unsigned char)l[ke])) ke++;
+        string key = l.substr(i, ke - i);
+        size_t v = ke; while (v < l.size() && isspace((unsigned char)l[v])) v++;
+        if (v < l.size() && (l[v] == '=' || l[v] == ':')) { v++; while (v < l.size() && isspace((unsigned char)l[v])) v++; }
+        string val; for (size_t j = v; j < l.size(); j++) { if (l[j] == '\\' && j + 1 < l.size()) j++; val.push_back(l[j]); }
+        out[key].push_back(val);
+    }
+    free(line); fclose(f);
+    return true;
+}
+static bool props_equal(const vector<PV> &cur, const Props &stored) {      // (null and an empty list both leave no line)
+    for (auto &p : cur) {
+        auto it = stored.find(p.name);
+        const vector<string> none, &now = p.set ? p.vals : none, &then = it == stored.end() ? none : it->second;
+        if (now != then) { logmsg("DEBUG", "Parameter %s changed from last run", p.name.c_str()); return false; }
+    }
+    return true;
+}
+static vector<string> props_list(const Props &p, const string &k) { auto it = p.find(k); return it == p.end() ? vector<string>() : it->second; }
+// one sub-step of a composite tool (Tool.runAllSteps :485-529): `force` turns true once a step has run, so everything
+// after it runs too.  run() does the work and returns the output parameters; load() takes them from out.properties.
+template <class RUN, class LOAD>
+static void run_as_step(const string &name, const string &dir, const vector<PV> &in, const string &start, bool &force, RUN run, LOAD load) {
+    if (name == start) force = true;
+    mkdirs(dir);
+    const string inp = dir + "/in.properties", outp = dir + "/out.properties", succ = dir + "/SUCCESS";
+    const bool f = force || !exists(inp);
+    bool can = exists(inp) && exists(succ);
+    if (!f && can) { Props stored; can = props_read(inp, stored) && props_equal(in, stored); }
+    if (!f && can) {
+        logmsg("INFO", "SUCCESS file found for tool %s - loading results...", name.c_str());
+        Props out; props_read(outp, out);
+        load(out);
+        return;
+    }
+    logmsg("DEBUG", "Running tool %s", name.c_str());
+    unlink(succ.c_str()); unlink(outp.c_str());
+    props_write(inp, in);
+    const vector<PV> out = run();
+    props_write(outp, out);
+    touch(succ);
+    force = true;
+}
+// output_description.txt in the current directory and in the workDir (DistanceMatrixBuilderMain.java:81-83, 178-200;
+// IOUtils.tryToAppendDescription src/io/IOUtils.java:217-231)
+static vector<string> g_desc_files;
+static void describe(const string &path, const char *msg) {
+    for (auto &d : g_desc_files) { FILE *f = fopen(d.c_str(), "a"); if (!f) continue; fprintf(f, "\n%s\n   %s\n", path.c_str(), msg); fclose(f); }
+}
 static const char *TOOLS_TEXT =
     "kmer-counter\t\tCount k-mers in given reads\n"
     "kmer-counter-many\tCount k-mers in many files (one library = one output)\n"
@@ -571,6 +655,50 @@ static const char *TOOLS_TEXT =
     "bin2fasta\t\tConverts different binary objects to FASTA format\n"
     "matrix-builder\t\tBuild the distance matrix for input sequences (default tool)\n";
 
+// input parameters of a tool as in.properties lists them: declaration order of the reference's Parameter fields, values
+// = what the run will use (defaults filled in).  matrix-builder: its own, then the sub-tools' parameters it does not fix
+// (Tool.addSubTool :168-207).
+static vector<PV> tool_inputs(const string &tool, const Args &a, const string &wd, const string &ts) {
+    auto dt = [&](string p) { size_t q = p.find("$DT"); if (q != string::npos) p.replace(q, 3, ts); return p; };
+    auto opt_i = [&](const char *n) { return a.has(n) ? PV(n, a.get(n)) : PV::null(n); };
+    auto opt_f = [&](const char *n) { return a.has(n) ? PV::file(n, a.get(n)) : PV::null(n); };
+    auto flag = [&](const char *n) { return PV::flag(n, a.get(n, "false") == "true"); };
+    vector<PV> v;
+    if (tool == "kmer-counter" || tool == "kmer-counter-many") {
+        v = {opt_i("k"), PV::files("reads", a.list("reads")), PV("maximal-bad-frequence", a.get("maximal-bad-frequence", "1")),
+             PV::file("output-dir", a.get("output-dir", wd + "/kmers")), PV::file("stats-dir", a.get("stats-dir", wd + "/stats"))};
+    } else if (tool == "seq-builder" || tool == "seq-builder-many") {
+        v = {opt_i("k"), PV::files("k-mers", a.list("k-mers")),
+             tool == "seq-builder" ? PV("maximal-bad-frequency", a.get("maximal-bad-frequency", "1")) : opt_i("maximal-bad-frequency"),
+             opt_i("bottom-cut-percent"), opt_i("sequence-len"), PV::file("output-dir", a.get("output-dir", wd + "/sequences"))};
+    } else if (tool == "component-cutter") {
+        v = {opt_i("k"), PV("min-seq-len", a.get("min-seq-len", "100")), PV("min-component-size", a.get("min-component-size", "1000")),
+             PV("max-component-size", a.get("max-component-size", "10000")), PV::files("sequences", a.list("sequences")),
+             PV::file("components-file", a.get("components-file", wd + "/components.bin"))};
+    } else if (tool == "features-calculator") {
+        v = {opt_i("k"), opt_f("components-file"), PV::files("reads", a.list("reads")), PV::files("kmers", a.list("kmers")),
+             a.has("selected") ? PV::files("selected", a.list("selected")) : PV::null("selected"), PV("threshold", a.get("threshold", "0"))};
+    } else if (tool == "dist-matrix-calculator") {
+        v = {PV::files("features", a.list("features")), flag("without-names"),
+             PV::file("matrix-file", dt(a.get("matrix-file", wd + "/dist_matrix_$DT_original_order.txt"))), PV("output-format", a.get("output-format", "%.4f"))};
+    } else if (tool == "heatmap-maker") {
+        v = {opt_f("matrix-file"), opt_f("colors-file"), flag("without-renumbering"), opt_f("newMatrix-file"), opt_f("heatmap-file"),
+             flag("invert-colors"), PV("output-format", a.get("output-format", "%.4f"))};
+    } else if (tool == "matrix-builder") {
+        v = {PV("k", a.get("k", "31")), PV::files("reads", a.list("reads")), PV("maximal-bad-frequency", a.get("maximal-bad-frequency", "1")),
+             PV("min-seq-len", a.get("min-seq-len", "100")), flag("use-reads-for-calculating-features"),
+             PV::file("matrix-file", dt(a.get("matrix-file", wd + "/matrices/dist_matrix_$DT.txt"))),
+             PV::file("heatmap-file", dt(a.get("heatmap-file", wd + "/matrices/dist_matrix_$DT_heatmap.png"))),
+             PV::file("stats-dir", a.get("stats-dir", wd + "/kmer-counter-many/stats")), opt_i("bottom-cut-percent"),
+             PV("min-component-size", a.get("min-component-size", "1000")), PV("max-component-size", a.get("max-component-size", "10000")),
+             a.has("selected") ? PV::files("selected", a.list("selected")) : PV::null("selected"), flag("without-names"),
+             PV("output-format", a.get("output-format", "%.4f")), opt_f("colors-file"), flag("without-renumbering"), flag("invert-colors")};
+    } else if (tool == "view" || tool == "bin2fasta") {
+        v = {opt_i("k"), opt_f("kmers-file"), opt_f("components-file"), opt_f("output-file")};
+    }
+    return v;
+}
+
 int main(int argc, char **argv) {
     string tool;
     Args a = parse_args(argc, argv, &tool);
@@ -581,39 +709,100 @@ int main(int argc, char **argv) {
                "-s/--start <step>  -f/--finish <step>  -v/--verbose  --device <n>\nTool options follow the reference (see SURVEY.md 8(b1)).\n", TOOLS_TEXT);
         return 0;
     }
+    static const char *KNOWN[] = {"kmer-counter", "kmer-counter-many", "seq-builder", "seq-builder-many", "component-cutter", "features-calculator",
+                                  "dist-matrix-calculator", "heatmap-maker", "view", "bin2fasta", "matrix-builder"};
+    if (std::find_if(std::begin(KNOWN), std::end(KNOWN), [&](const char *n) { return tool == n; }) == std::end(KNOWN)) {
+        fprintf(stderr, "ERROR: Tool '%s' not found !\n", tool.c_str());          // itmo!/Runner.java:136-139
+        return 1;
+    }
     g_verbose = a.get("verbose", "false") == "true";
     Env e;
     e.work_dir = a.get("work-dir", "workDir");
-    e.cont = a.has("continue");
     e.start_ts = timestamp();
-    mkdirs(e.work_dir);
-    g_logfile = fopen((e.work_dir + "/log").c_str(), "a");
     const string wd = e.work_dir;
+    mkdirs(wd); mkdirs(wd + "/logs");
+    {   // Tool.updateFileLoggers :666-690: <workDir>/log (this run only) and <workDir>/logs/log_<ts>, same content
+        time_t t = time(nullptr); struct tm tmv; localtime_r(&t, &tmv);
+        char hdr[128]; strftime(hdr, sizeof hdr, "Log created at %d-%b-%Y (%a) %H:%M:%S", &tmv);
+        g_logfile = fopen((wd + "/log").c_str(), "w");
+        g_logfile2 = fopen((wd + "/logs/log_" + e.start_ts).c_str(), "w");
+        for (FILE *f : {g_logfile, g_logfile2}) if (f) { fprintf(f, "%s\n", hdr); fflush(f); }
+    }
+    // ---- --continue / --force (Tool.run :400-462).  matrix-builder forces by default, unless -c or -s is given
+    // (DistanceMatrixBuilderMain.java:23-26, 211-216).
+    bool cont = a.get("continue", "false") == "true", force = a.get("force", "false") == "true";
+    if (tool == "matrix-builder") {
+        if (a.has("force")) die("Cannot parse command line: Unrecognized option: --force");       // (removed from its launch options, :25)
+        force = !(a.has("continue") || a.has("start"));
+    }
+    const string start = a.get("start"), finish = a.get("finish");
+    const string inprop = wd + "/in.properties";
+    if (cont && force) die("Continue and force options can't be set simultaneously");
+    if (exists(inprop)) {
+        if (cont) {}
+        else if (force) { if (tool != "matrix-builder") logmsg("WARN", "Force run, all data in working directory will be rewritten!"); }
+        else {
+            fprintf(stderr, "Working directory (%s/) contains files from previous run, rewrite them? [Yes(y)/No(n), default:No] ", wd.c_str());
+            char ans[64] = ""; if (!fgets(ans, sizeof ans, stdin)) ans[0] = 0;
+            string s(ans); while (!s.empty() && isspace((unsigned char)s.back())) s.pop_back();
+            for (auto &c : s) c = (char)tolower((unsigned char)c);
+            if (s == "y" || s == "yes") force = true; else return 1;
+        }
+    } else force = true;
+    e.cont = cont;
+    // ---- runAsStep for the tool itself (:318-392)
+    bool can = exists(inprop) && exists(wd + "/SUCCESS");
+    if (!force) {
+        Props stored;
+        if (props_read(inprop, stored)) {
+            // parameters not given on the command line take last run's values (loadUnsetParametersFromProperties :757-793)
+            for (auto &kv : stored) if (!a.has(kv.first)) a.opt[kv.first] = kv.second;
+            can = can && props_equal(tool_inputs(tool, a, wd, e.start_ts), stored);
+        } else can = false;
+    }
+    if (!force && start.empty() && can) {
+        logmsg("INFO", "SUCCESS file found for tool %s - loading results...", tool.c_str());
+        return 0;
+    }
+    unlink((wd + "/SUCCESS").c_str()); unlink((wd + "/out.properties").c_str());
     const int k_dflt = tool == "matrix-builder" ? 31 : -1;
     int k = a.geti("k", k_dflt);
+    vector<PV> outs;
+
+    // mandatory parameters are checked before anything is written (Tool.checkArguments :712-724)
+    auto need = [&](const char *n, const char *shrt) { if (!a.has(n)) die("Mandatory argument --%s (-%s) not set", n, shrt); };
+    if (tool == "kmer-counter" || tool == "kmer-counter-many") { need("k", "k"); need("reads", "i"); }
+    else if (tool == "seq-builder" || tool == "seq-builder-many") { need("k", "k"); need("k-mers", "i"); need("sequence-len", "l"); }
+    else if (tool == "component-cutter") { need("k", "k"); need("sequences", "i"); }
+    else if (tool == "features-calculator") { need("k", "k"); need("components-file", "cm"); }
+    else if (tool == "dist-matrix-calculator") { if (!a.has("features")) die("Mandatory argument --features not set"); }
+    else if (tool == "heatmap-maker") need("matrix-file", "i");
+    else if (tool == "matrix-builder") need("reads", "i");
+    props_write(inprop, tool_inputs(tool, a, wd, e.start_ts));
 
     if (tool == "kmer-counter") {
-        if (!a.has("k")) die("Mandatory option -k is not set");
-        run_kmer_counter(e, a, a.list("reads"), k, a.geti("maximal-bad-frequence", 1), a.get("output-dir", wd + "/kmers"), a.get("stats-dir", wd + "/stats"));
+        outs = {PV::file("resulting-kmers-file", run_kmer_counter(e, a, a.list("reads"), k, a.geti("maximal-bad-frequence", 1), a.get("output-dir", wd + "/kmers"),
+                                                                  a.get("stats-dir", wd + "/stats")))};
     } else if (tool == "kmer-counter-many") {
-        if (!a.has("k")) die("Mandatory option -k is not set");
         check_k(k);
-        run_kmer_counter_many(e, a, a.list("reads"), k, a.geti("maximal-bad-frequence", 1), wd);
+        outs = {PV::files("resulting-kmers-files", run_kmer_counter_many(e, a, a.list("reads"), k, a.geti("maximal-bad-frequence", 1), wd))};
     } else if (tool == "seq-builder" || tool == "seq-builder-many") {
-        if (!a.has("k")) die("Mandatory option -k is not set");
-        if (!a.has("sequence-len")) die("Mandatory option --sequence-len is not set");
         if (a.has("maximal-bad-frequency") && a.has("bottom-cut-percent") && tool == "seq-builder-many") die("-b and -bp can not be set both");
         int b = a.geti("maximal-bad-frequency", 1), bp = a.has("bottom-cut-percent") ? a.geti("bottom-cut-percent", 0) : -1, l = a.geti("sequence-len", 100);
         string out_dir = a.get("output-dir", wd + "/sequences");
-        if (tool == "seq-builder") run_seq_builder(e, a, a.list("k-mers"), k, b, bp, l, wd, out_dir);
-        else for (auto &f : a.list("k-mers")) run_seq_builder(e, a, {f}, k, b, bp, l, wd + "/sub-builder", out_dir);
+        if (tool == "seq-builder") outs = {PV::file("output-file", run_seq_builder(e, a, a.list("k-mers"), k, b, bp, l, wd, out_dir))};
+        else {
+            vector<string> fs;
+            for (auto &f : a.list("k-mers")) fs.push_back(run_seq_builder(e, a, {f}, k, b, bp, l, wd + "/sub-builder", out_dir));
+            outs = {PV::files("output-files", fs)};
+        }
     } else if (tool == "component-cutter") {
-        if (!a.has("k")) die("Mandatory option -k is not set");
-        run_component_cutter(e, a, a.list("sequences"), k, a.geti("min-seq-len", 100), a.geti("min-component-size", 1000), a.geti("max-component-size", 10000), wd,
-                             a.get("components-file", wd + "/components.bin"));
+        const int b1 = a.geti("min-component-size", 1000), b2 = a.geti("max-component-size", 10000);
+        string cf = run_component_cutter(e, a, a.list("sequences"), k, a.geti("min-seq-len", 100), b1, b2, wd, a.get("components-file", wd + "/components.bin"));
+        outs = {PV::file("components-file", cf), PV::file("components-stat", wd + "/components-stat-" + std::to_string(b1) + "-" + std::to_string(b2) + ".txt")};
     } else if (tool == "features-calculator") {
-        if (!a.has("k")) die("Mandatory option -k is not set");
-        run_features(e, a, a.get("components-file"), a.list("reads"), a.list("kmers"), k, a.geti("threshold", 0), wd);
+        outs = {PV::files("features-files", run_features(e, a, a.get("components-file"), a.list("reads"), a.list("kmers"), k, a.geti("threshold", 0), wd)),
+                PV::file("features-dir", wd + "/vectors")};
     } else if (tool == "dist-matrix-calculator") {
         run_dist_matrix(e, a, a.list("features"), a.get("matrix-file", wd + "/dist_matrix_$DT_original_order.txt"));
     } else if (tool == "view") {
@@ -621,64 +810,113 @@ int main(int argc, char **argv) {
     } else if (tool == "bin2fasta") {
         run_bin2fasta(a, k);
     } else if (tool == "heatmap-maker") {
-        if (!a.has("matrix-file")) die("Mandatory option --matrix-file is not set");
-        run_heatmap_maker(e, a, a.get("matrix-file"), a.get("new-matrix-file"));
+        string nm = run_heatmap_maker(e, a, a.get("matrix-file"), a.get("newMatrix-file"));
+        outs = {PV::null("heatmap-file"), a.get("without-renumbering", "false") == "true" ? PV::null("newMatrix-file-out") : PV::file("newMatrix-file-out", nm)};
     } else if (tool == "matrix-builder") {
         // DistanceMatrixBuilderMain.java:88-175: steps kmer-counter-many, seq-builder-many, component-cutter, features-calculator,
-        // dist-matrix-calculator (+ heatmap-maker: rendering, out of scope)
+        // dist-matrix-calculator, heatmap-maker (its image is not rendered here)
         vector<string> reads = a.list("reads");
+        logmsg("INFO", "Found %zu libraries to process", reads.size());
         if (reads.empty()) die("No libraries to process!!! Can't continue the calculations.");
         const bool use_reads = a.get("use-reads-for-calculating-features", "false") == "true";     // DistanceMatrixBuilderMain.java:162-165
-        logmsg("INFO", "Found %zu libraries to process", reads.size());
         check_k(k);
         int b = a.geti("maximal-bad-frequency", a.geti("maximal-bad-frequence", 1)), l = a.geti("min-seq-len", 100);
         int b1 = a.geti("min-component-size", 1000), b2 = a.geti("max-component-size", 10000);
-        string start = a.get("start"), finish = a.get("finish");
-        Step s1{"kmer-counter-many", wd + "/kmer-counter-many"}, s2{"seq-builder-many", wd + "/seq-builder-many"}, s3{"component-cutter", wd + "/component-cutter"},
-             s4{"features-calculator", wd + "/features-calculator"}, s5{"dist-matrix-calculator", wd + "/matrices"};
-        // -s/--start <step>: reuse everything before it; -c/--continue: reuse leading steps that have a SUCCESS marker;
-        // once one step runs, all later ones run (Tool.java:485-529)
-        bool running = false;
-        auto should_run = [&](const Step &s) {
-            if (running) return true;
-            if (!start.empty()) { if (s.name == start) running = true; return running; }
-            if (e.cont && exists(s.dir + "/SUCCESS")) return false;
-            running = true;
+        static const char *STEPS[] = {"kmer-counter-many", "seq-builder-many", "component-cutter", "features-calculator", "dist-matrix-calculator", "heatmap-maker"};
+        for (const string *bound : {&start, &finish})                           // Tool.checkBoundExistence :726-741
+            if (!bound->empty() && std::find_if(std::begin(STEPS), std::end(STEPS), [&](const char *n) { return *bound == n; }) == std::end(STEPS))
+                die("There is no substep with name '%s' in step matrix-builder!", bound->c_str());
+        {   // createOutputDescFiles :178-200
+            g_desc_files = {"output_description.txt", wd + "/output_description.txt"};
+            time_t t = time(nullptr); struct tm tmv; localtime_r(&t, &tmv);
+            char hdr[128]; strftime(hdr, sizeof hdr, "%d-%b-%Y (%a) %H:%M:%S", &tmv);
+            for (auto &d : g_desc_files) {
+                FILE *f = fopen(d.c_str(), "w");
+                if (!f) { logmsg("WARN", "Can't create file %s, skipping", d.c_str()); continue; }
+                fprintf(f, "# Output files' description for run started at %s\n\n%s\n%s\n   Identical files with run log\n\n%s\n%s\n   Identical files with output files' description\n",
+                        hdr, (wd + "/log").c_str(), (wd + "/logs/log_" + e.start_ts).c_str(), g_desc_files[0].c_str(), g_desc_files[1].c_str());
+                fclose(f);
+            }
+        }
+        const string d1 = wd + "/kmer-counter-many", d2 = wd + "/seq-builder-many", d3 = wd + "/component-cutter", d4 = wd + "/features-calculator",
+                     d5 = wd + "/dist-matrix-calculator", d6 = wd + "/heatmap-maker";
+        const string dirs[] = {d1, d2, d3, d4, d5, d6};
+        // --finish <step>: stop after it; the next step's results are outdated then (:512-527)
+        auto finished = [&](int i) {
+            if (finish.empty() || finish != STEPS[i]) return false;
+            if (i + 1 < 6) { unlink((dirs[i + 1] + "/SUCCESS").c_str()); unlink((dirs[i + 1] + "/in.properties").c_str()); }
             return true;
         };
-        auto stop_after = [&](const Step &s) { return !finish.empty() && s.name == finish; };
+        auto done = [&]() { if (e.ctx) mf_ctx_destroy(e.ctx); return 0; };
         vector<string> kmers, seqs, vecs;
-        // 1
-        if (should_run(s1)) {
-            Args sub = a; sub.opt.erase("output-dir");
-            kmers = run_kmer_counter_many(e, sub, reads, k, b, s1.dir); step_finish(s1);
-        } else { logmsg("INFO", "Step %s: reusing results", s1.name.c_str()); kmers = list_files(s1.dir + "/kmers", ".kmers.bin"); }
-        if (stop_after(s1)) return 0;
-        // 2
-        if (should_run(s2)) {
-            for (auto &f : kmers) seqs.push_back(run_seq_builder(e, a, {f}, k, b, -1, l, s2.dir + "/sub-builder", s2.dir + "/sequences"));
-            step_finish(s2);
-        } else { logmsg("INFO", "Step %s: reusing results", s2.name.c_str()); seqs = list_files(s2.dir + "/sequences", ".seq.fasta"); }
-        if (stop_after(s2)) return 0;
-        // 3
-        string comp = s3.dir + "/components.bin";
-        if (should_run(s3)) { run_component_cutter(e, a, seqs, k, l, b1, b2, s3.dir, comp); step_finish(s3); }
-        else logmsg("INFO", "Step %s: reusing results", s3.name.c_str());
-        if (stop_after(s3)) return 0;
-        // 4
-        if (should_run(s4)) { vecs = use_reads ? run_features(e, a, comp, reads, {}, k, 0, s4.dir) : run_features(e, a, comp, {}, kmers, k, 0, s4.dir); step_finish(s4); }
-        else { logmsg("INFO", "Step %s: reusing results", s4.name.c_str()); vecs = list_files(s4.dir + "/vectors", ".vec"); }
-        if (stop_after(s4)) return 0;
-        // 5
-        string mpath = run_dist_matrix(e, a, vecs, wd + "/matrices/dist_matrix_$DT_original_order.txt");
-        // 6: heatmap-maker, numeric half: dendrogram order + renumbered matrix (DistanceMatrixBuilderMain.java:137-145)
-        run_heatmap_maker(e, a, mpath, a.get("matrix-file", wd + "/matrices/dist_matrix_$DT.txt"));
+        // 1 kmer-counter-many
+        const string stats_dir = a.get("stats-dir", d1 + "/stats");
+        run_as_step(STEPS[0], d1, {PV("k", k), PV::files("reads", reads), PV("maximal-bad-frequence", b), PV::file("output-dir", d1 + "/kmers"), PV::file("stats-dir", stats_dir)},
+                    start, force,
+                    [&]() { Args sub = a; sub.opt.erase("output-dir"); sub.opt["stats-dir"] = {stats_dir};
+                            kmers = run_kmer_counter_many(e, sub, reads, k, b, d1); return vector<PV>{PV::files("resulting-kmers-files", kmers)}; },
+                    [&](const Props &o) { kmers = props_list(o, "resulting-kmers-files"); });
+        describe(stats_dir, "Directory with kmer frequency statistics (statistics files is in text format for every input reads file)");
+        if (finished(0)) return done();
+        // 2 seq-builder-many
+        const int bp = a.has("bottom-cut-percent") ? a.geti("bottom-cut-percent", 0) : -1;
+        run_as_step(STEPS[1], d2, {PV("k", k), PV::files("k-mers", kmers), PV("maximal-bad-frequency", b), bp >= 0 ? PV("bottom-cut-percent", bp) : PV::null("bottom-cut-percent"),
+                                   PV("sequence-len", l), PV::file("output-dir", d2 + "/sequences")},
+                    start, force,
+                    [&]() { for (auto &f : kmers) seqs.push_back(run_seq_builder(e, a, {f}, k, b, bp, l, d2 + "/sub-builder", d2 + "/sequences"));
+                            return vector<PV>{PV::files("output-files", seqs)}; },
+                    [&](const Props &o) { seqs = props_list(o, "output-files"); });
+        describe(d2 + "/sequences", "Directory with FASTA files - paths from reads for every library");
+        if (finished(1)) return done();
+        // 3 component-cutter
+        const string comp = d3 + "/components.bin", cstat = d3 + "/components-stat-" + std::to_string(b1) + "-" + std::to_string(b2) + ".txt";
+        run_as_step(STEPS[2], d3, {PV("k", k), PV("min-seq-len", l), PV("min-component-size", b1), PV("max-component-size", b2), PV::files("sequences", seqs), PV::file("components-file", comp)},
+                    start, force,
+                    [&]() { run_component_cutter(e, a, seqs, k, l, b1, b2, d3, comp); return vector<PV>{PV::file("components-file", comp), PV::file("components-stat", cstat)}; },
+                    [&](const Props &) {});
+        describe(cstat, "File with components' statistics (in text format)");
+        describe(comp, "File with extracted components (in binary format)");
+        if (finished(2)) return done();
+        // 4 features-calculator
+        const vector<string> none;
+        run_as_step(STEPS[3], d4, {PV("k", k), PV::file("components-file", comp), PV::files("reads", use_reads ? reads : none), PV::files("kmers", use_reads ? none : kmers),
+                                   PV::null("selected"), PV("threshold", 0)},
+                    start, force,
+                    [&]() { vecs = use_reads ? run_features(e, a, comp, reads, {}, k, 0, d4) : run_features(e, a, comp, {}, kmers, k, 0, d4);
+                            return vector<PV>{PV::files("features-files", vecs), PV::file("features-dir", d4 + "/vectors")}; },
+                    [&](const Props &o) { vecs = props_list(o, "features-files"); });
+        describe(d4 + "/vectors", "Directory with features values files for every library (in text format)");
+        if (finished(3)) return done();
+        // 5 dist-matrix-calculator: the matrix in the original order goes to <workDir>/matrices (:132-134)
+        string mpath = wd + "/matrices/dist_matrix_" + e.start_ts + "_original_order.txt";
+        const bool wn = a.get("without-names", "false") == "true";
+        const string fmt = a.get("output-format", "%.4f");
+        run_as_step(STEPS[4], d5, {PV::files("features", vecs), PV::flag("without-names", wn), PV::file("matrix-file", mpath), PV("output-format", fmt)},
+                    start, force,
+                    [&]() { mkdirs(wd + "/matrices"); mpath = run_dist_matrix(e, a, vecs, mpath); return vector<PV>(); },
+                    [&](const Props &) {});
+        describe(mpath, "File with resulted distance matrix between samples keeping original order");
+        if (finished(4)) return done();
+        // 6 heatmap-maker, numeric half: dendrogram order + renumbered matrix (:137-145)
+        string npath = a.get("matrix-file", wd + "/matrices/dist_matrix_$DT.txt");
+        { size_t q = npath.find("$DT"); if (q != string::npos) npath.replace(q, 3, e.start_ts); }
+        const bool wr = a.get("without-renumbering", "false") == "true";
+        run_as_step(STEPS[5], d6, {PV::file("matrix-file", mpath), a.has("colors-file") ? PV::file("colors-file", a.get("colors-file")) : PV::null("colors-file"),
+                                   PV::flag("without-renumbering", wr), PV::file("newMatrix-file", npath),
+                                   PV::file("heatmap-file", tool_inputs(tool, a, wd, e.start_ts)[6].vals[0]), PV::flag("invert-colors", a.get("invert-colors", "false") == "true"),
+                                   PV("output-format", fmt)},
+                    start, force,
+                    [&]() { run_heatmap_maker(e, a, mpath, npath); return vector<PV>{PV::null("heatmap-file"), wr ? PV::null("newMatrix-file-out") : PV::file("newMatrix-file-out", npath)}; },
+                    [&](const Props &) {});
+        if (!wr) describe(npath, "File with resulted distance matrix between samples with new order based on adjacency of the samples");
         logmsg("INFO", "heatmap image (dist_matrix_<date>_heatmap.png) is not rendered by the HIP path");
-    } else {
-        die("Unknown tool '%s' (use -ts to list the tools of the HIP hot path)", tool.c_str());
+        if (finished(5)) return done();
     }
-    touch(wd + "/SUCCESS");
     if (e.ctx) mf_ctx_destroy(e.ctx);
+    if (!finish.empty()) return 0;                      // (a run cut short by --finish leaves no SUCCESS, :377-379)
+    props_write(wd + "/out.properties", outs);
+    touch(wd + "/SUCCESS");
     if (g_logfile) fclose(g_logfile);
+    if (g_logfile2) fclose(g_logfile2);
     return 0;
 }

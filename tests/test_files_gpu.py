@@ -221,14 +221,29 @@ def test_cli_matrix_builder_workdir(oracle, ref_files, tmp_path):
     """metafast.sh -i a b c  (default tool matrix-builder): workDir layout + the reference's README matrix"""
     wd = tmp_path / "workDir"
     cmd = [os.path.join(ROOT, "metafast.sh"), "-m", "4G", "-ea", "-k", "31", "-i", *ref_files, "-w", str(wd), "-p", "4"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert r.returncode == 0, r.stderr
     for rel in ["kmer-counter-many/kmers/meta_test_1.kmers.bin", "kmer-counter-many/stats/meta_test_2.stat.txt",
                 "seq-builder-many/sequences/meta_test_3.seq.fasta", "seq-builder-many/sub-builder/distribution",
                 "component-cutter/components.bin", "component-cutter/components-stat-1000-10000.txt",
                 "features-calculator/vectors/meta_test_1.vec", "features-calculator/vectors/meta_test_1.breadth",
-                "kmer-counter-many/SUCCESS", "component-cutter/SUCCESS", "SUCCESS", "log"]:
+                "kmer-counter-many/SUCCESS", "component-cutter/SUCCESS", "SUCCESS", "log", "in.properties", "out.properties",
+                "output_description.txt", "dist-matrix-calculator/SUCCESS", "heatmap-maker/out.properties"]:
         assert (wd / rel).exists(), rel
+    assert (tmp_path / "output_description.txt").exists() and len(list((wd / "logs").glob("log_*"))) == 1
+    # step bookkeeping as Tool.java:318-392, 795-966 writes it: "key = value", one line per value, absolute paths
+    props = (wd / "kmer-counter-many" / "in.properties").read_text().splitlines()
+    assert props == ["k = 31"] + ["reads = %s" % f for f in sorted(ref_files)] + [
+        "maximal-bad-frequence = 1", "output-dir = %s" % (wd / "kmer-counter-many" / "kmers"), "stats-dir = %s" % (wd / "kmer-counter-many" / "stats")]
+    outp = (wd / "kmer-counter-many" / "out.properties").read_text().splitlines()
+    assert outp == ["resulting-kmers-files = %s" % (wd / "kmer-counter-many" / "kmers" / ("meta_test_%d.kmers.bin" % i)) for i in (1, 2, 3)]
+    top = (wd / "in.properties").read_text().splitlines()
+    assert top[0] == "k = 31" and "maximal-bad-frequency = 1" in top and "min-component-size = 1000" in top and "without-names = false" in top
+    cc = (wd / "component-cutter" / "out.properties").read_text().splitlines()
+    assert cc == ["components-file = %s" % (wd / "component-cutter" / "components.bin"),
+                  "components-stat = %s" % (wd / "component-cutter" / "components-stat-1000-10000.txt")]
+    desc = (wd / "output_description.txt").read_text()
+    assert desc.startswith("# Output files' description for run started at ") and "File with extracted components (in binary format)" in desc
     assert os.path.getsize(wd / "kmer-counter-many/kmers/meta_test_1.kmers.bin") == 169180
     mats = sorted((wd / "matrices").glob("dist_matrix_*_original_order.txt"))
     assert len(mats) == 1
@@ -245,11 +260,32 @@ def test_cli_matrix_builder_workdir(oracle, ref_files, tmp_path):
     assert lines[1] == "meta_test_1\t0.0000\t0.2981\t0.5691"
     assert lines[2] == "meta_test_3\t0.2981\t0.0000\t0.8448"
     assert lines[3] == "meta_test_2\t0.5691\t0.8448\t0.0000"
-    # --continue reuses finished steps; --start re-runs from a step
-    r = subprocess.run(cmd + ["-c"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "reusing results" in r.stderr
-    r = subprocess.run(cmd + ["-s", "features-calculator"], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "Step component-cutter: reusing results" in r.stderr
+    # --continue with nothing changed: the whole tool is already done (Tool.java:339-351)
+    r = subprocess.run(cmd + ["-c"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0 and "SUCCESS file found for tool matrix-builder - loading results..." in r.stderr
+    # -c -s <step>: everything before the step is re-used, the step and all later ones run again (:485-509)
+    mt = os.path.getmtime(wd / "component-cutter" / "components.bin")
+    r = subprocess.run(cmd + ["-c", "-s", "features-calculator"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "SUCCESS file found for tool component-cutter - loading results..." in r.stderr
+    assert "SUCCESS file found for tool features-calculator" not in r.stderr and "Features for file" in r.stderr
+    assert os.path.getmtime(wd / "component-cutter" / "components.bin") == mt
+    # -c with a changed parameter: the first step that sees a different input runs again, and so does everything after it
+    r = subprocess.run(cmd + ["-c", "-b1", "2000"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert "SUCCESS file found for tool seq-builder-many - loading results..." in r.stderr
+    assert "SUCCESS file found for tool component-cutter" not in r.stderr and "Total 4 components were found" in r.stderr
+    assert (wd / "component-cutter" / "components-stat-2000-10000.txt").exists()
+    assert "min-component-size = 2000" in (wd / "component-cutter" / "in.properties").read_text()
+    # -s without -c on a used workDir: the reference asks before rewriting; no answer = No = exit 1 (:408-428)
+    r = subprocess.run(cmd + ["-s", "features-calculator"], capture_output=True, text=True, timeout=300, cwd=tmp_path, stdin=subprocess.DEVNULL)
+    assert r.returncode == 1 and "rewrite them?" in r.stderr
+    # -f <step>: stop after it, the next step's results are outdated, no SUCCESS for the whole tool (:377-379, 512-527)
+    r = subprocess.run(cmd + ["-f", "seq-builder-many"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert (wd / "seq-builder-many" / "SUCCESS").exists() and not (wd / "component-cutter" / "SUCCESS").exists() and not (wd / "SUCCESS").exists()
+    r = subprocess.run(cmd + ["--force"], capture_output=True, text=True, cwd=tmp_path)      # matrix-builder always forces; it has no such option
+    assert r.returncode == 1 and "Unrecognized option: --force" in r.stderr
 
 
 def test_cli_errors_and_single_tools(ref_files, tmp_path):
@@ -258,7 +294,7 @@ def test_cli_errors_and_single_tools(ref_files, tmp_path):
     assert r.returncode == 1 and "no more than 31" in r.stderr
     r = subprocess.run([exe, "-t", "nope"], capture_output=True, text=True)
     assert r.returncode == 1
-    r = subprocess.run([exe, "-t", "component-cutter", "-k", "31", "-i", str(tmp_path / "none.fa"), "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    r = subprocess.run([exe, "-t", "component-cutter", "-k", "31", "-i", str(tmp_path / "none.fa"), "-w", str(tmp_path / "w1")], capture_output=True, text=True)
     assert r.returncode == 1
     # paired files x_r1 / x_r2 -> one library "x" (KmersCounterForManyFilesMain.java:80-108, KmersCounterMain.java:122-137)
     a, b = tmp_path / "lib_r1.fa", tmp_path / "lib_r2.fa"

@@ -72,10 +72,27 @@ def test_heatmap_order_matches_oracle(oracle, tmp_path, n, seed):
     # default format and a matrix without names
     src2 = tmp_path / "plain.txt"
     _write(src2, m)
-    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(src2), "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(src2), "-w", str(tmp_path / "w")], capture_output=True, text=True,
+                       stdin=subprocess.DEVNULL)
+    assert r.returncode == 1 and "rewrite them?" in r.stderr          # a used workDir: the reference asks (Tool.java:408-428), default No
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "-i", str(src2), "-w", str(tmp_path / "w"), "--force", "-c"], capture_output=True, text=True)
+    assert r.returncode == 1 and "Continue and force options can't be set simultaneously" in r.stderr
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "-i", str(src2), "-w", str(tmp_path / "w"), "--force"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     n2, got2 = _read(tmp_path / "plain_renumbered.txt")
     assert n2 is None and np.allclose(np.array(got2), m[np.ix_(perm, perm)], atol=5e-5)
+    # step bookkeeping (Tool.java:318-392): in.properties before the run, out.properties + SUCCESS after it; -c with the
+    # same parameters finds the step done, with a different one runs it again
+    w = tmp_path / "w"
+    assert (w / "in.properties").read_text().splitlines() == ["matrix-file = %s" % src2, "without-renumbering = false", "invert-colors = false", "output-format = %.4f"]
+    assert (w / "out.properties").read_text().splitlines() == ["newMatrix-file-out = %s" % (tmp_path / "plain_renumbered.txt")]
+    assert (w / "SUCCESS").exists() and (w / "log").read_text().startswith("Log created at ")
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "-w", str(w), "-c"], capture_output=True, text=True)     # (matrix-file comes from in.properties)
+    assert r.returncode == 0 and "SUCCESS file found for tool heatmap-maker - loading results..." in r.stderr
+    os.remove(tmp_path / "plain_renumbered.txt")
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "-w", str(w), "-c", "--output-format", "%.3f"], capture_output=True, text=True)
+    assert r.returncode == 0 and (tmp_path / "plain_renumbered.txt").exists()
+    assert "output-format = %.3f" in (w / "in.properties").read_text()
 
 
 def test_heatmap_maker_errors(tmp_path):
@@ -83,11 +100,11 @@ def test_heatmap_maker_errors(tmp_path):
     bad.write_text("0.0\t0.1\n0.1\n")
     r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(bad), "-w", str(tmp_path / "w")], capture_output=True, text=True)
     assert r.returncode == 1
-    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(tmp_path / "none.txt"), "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(tmp_path / "none.txt"), "-w", str(tmp_path / "w"), "--force"], capture_output=True, text=True)
     assert r.returncode == 1 and "Can't read matrix file" in r.stderr
     m = tmp_path / "m.txt"
     m.write_text("0.0\t0.1\n0.1\t0.0\n")
-    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(m), "--output-format", "%d", "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    r = subprocess.run([EXE, "-t", "heatmap-maker", "--matrix-file", str(m), "--output-format", "%d", "-w", str(tmp_path / "w"), "--force"], capture_output=True, text=True)
     assert r.returncode == 1 and "Unsupported --output-format" in r.stderr
 
 
@@ -116,14 +133,14 @@ def test_view_and_bin2fasta(oracle, ref_files, tmp_path):
         want += [_kmer_str(int(km), k) for km in kmers] + [""]
     assert open(out).read().split("\n") == want + [""]
     pre = tmp_path / "fa" / "comp"
-    p = subprocess.run([EXE, "-t", "bin2fasta", "-k", str(k), "-cf", str(cb), "-o", str(pre), "-w", str(tmp_path / "w")], capture_output=True, text=True)
+    p = subprocess.run([EXE, "-t", "bin2fasta", "-k", str(k), "-cf", str(cb), "-o", str(pre), "-w", str(tmp_path / "w"), "--force"], capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     want = []
     for i, (size, weight, thr, kmers) in enumerate(comps):
         for j, km in enumerate(kmers):
             want += [">%d_%d" % (i + 1, j + 1), _kmer_str(int(km), k)]
     assert open(str(pre) + ".fasta").read().split("\n") == want + [""]
-    p = subprocess.run([EXE, "-t", "bin2fasta", "-k", str(k), "-kf", str(kb), "-cf", str(cb), "--split", "-o", str(pre), "-w", str(tmp_path / "w")],
+    p = subprocess.run([EXE, "-t", "bin2fasta", "-k", str(k), "-kf", str(kb), "-cf", str(cb), "--split", "-o", str(pre), "-w", str(tmp_path / "w"), "--force"],
                        capture_output=True, text=True)
     assert p.returncode == 0, p.stderr
     assert open(str(pre) + ".fasta").read().split("\n")[:4] == [">1", _kmer_str(recs[0][0], k), ">2", _kmer_str(recs[1][0], k)]

@@ -255,7 +255,7 @@ def test_features_from_reads(gpu_ctx, oracle, ref_files, tmp_path):
     # driver: matrix-builder --use-reads-for-calculating-features (one vector per reads FILE)
     wd = tmp_path / "w"
     r = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", "31", "-i", *ref_files, "-w", str(wd), "--use-reads-for-calculating-features"],
-                       capture_output=True, text=True, timeout=300)
+                       capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert r.returncode == 0, r.stderr
     for f in ref_files:
         name = os.path.basename(f)[:-3]
