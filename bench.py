@@ -61,6 +61,38 @@ def algorithmic_bytes(kernel, s):
     }.get(kernel)
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _reference_java(hb, ho, k, cores):
+    """the real reference, only if this box has a JVM and $METAFAST_JAR points at an upstream metafast.jar
+    (neither ships with this repository); timed on the same sample written out as FASTA, file reading included."""
+    import shutil, subprocess, tempfile
+    jar = os.environ.get("METAFAST_JAR", "")
+    if not shutil.which("java") or not jar or not os.path.exists(jar):
+        return "reference Java not runnable on this box (no java on PATH and/or $METAFAST_JAR not set)"
+    with tempfile.TemporaryDirectory() as td:
+        fa = os.path.join(td, "sample.fa")
+        with open(fa, "wb") as f:
+            for i in range(len(ho) - 1):
+                f.write(b">%d\n" % i + hb[int(ho[i]):int(ho[i + 1])].tobytes() + b"\n")
+        n_occ = int(sum(max(0, int(ho[i + 1] - ho[i]) - k + 1) for i in range(len(ho) - 1)))
+        t0 = time.perf_counter()
+        r = subprocess.run(["java", "-jar", jar, "-t", "kmer-counter-many", "-k", str(k), "-i", fa, "-p", str(cores), "-w", os.path.join(td, "w")],
+                           capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            return "reference Java failed: " + r.stderr[-200:]
+        return dict(value=round(n_occ / dt, 1), unit="k-mers/s", cores=cores, seconds=round(dt, 2), note="kmer-counter-many incl. JVM start and FASTA parsing")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -188,7 +220,8 @@ def main():
             cdt = time.perf_counter() - c0
             cpu = dict(value=round(o / cdt, 1), unit="k-mers/s", cores=cores, kind="port",
                        sample=f"counting stage only (multi-threaded restatement of IOUtils.loadReads) on the first {m} reads "
-                              f"of the same sample, reads already parsed in memory; {o} k-mer occurrences, {d} distinct, {cdt:.2f} s")
+                              f"of the same sample, reads already parsed in memory; {o} k-mer occurrences, {d} distinct, {cdt:.2f} s",
+                       cpu_model=_cpu_model(), reference_java=_reference_java(hb, ho, k, cores))
         out = {
             "metric": "k-mers/s counted+graphed at k=31, 150 bp reads",
             "value": round(total_occ * args.steps / elapsed, 1),
