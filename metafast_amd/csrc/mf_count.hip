@@ -606,7 +606,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     // ---- K0 ----
     const uint64_t n_words = (n_bases + 31) / 32;
     mf_buf<uint32_t> vmask; MF_TRY(vmask.alloc(ctx, n_words));
-    mf_buf<unsigned long long> scal; MF_TRY(scal.alloc(ctx, 8));   // [0]=n_occ [1]=scan total [2]=overflow [3]=scan total 2
+    mf_buf<unsigned long long> scal; MF_TRY(scal.alloc(ctx, 12));  // [0]=n_occ [1]=scan total [2]=overflow [3]=scan total 2
     MF_HIP(hipMemsetAsync(scal.p, 0, scal.bytes(), st));
     {
         mf_ktimer t(ctx, "k_mask");

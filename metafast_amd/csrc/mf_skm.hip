@@ -499,6 +499,14 @@ template <> __device__ __forceinline__ void skm_lds_add<1>(const uint32_t (&a)[1
     asm volatile("ds_add_u32 %0, %1" ::"v"(a[0]), "v"(inc[0]) : "memory");
 }
 
+#define SKM_FILL 3400             // MULTI: claimed slots of the 4096 beyond which a pass is abandoned for more passes
+#define SKM_MAX_PASSES 64
+// pass of a key when its partition is counted in several passes (bits independent of skm_slot's)
+__device__ __forceinline__ uint32_t skm_pass_of(uint64_t key) {
+    uint32_t g = ((uint32_t)(key >> 32) * 0xC2B2AE35u) ^ ((uint32_t)key * 0x27D4EB2Fu);
+    g ^= g >> 15; g *= 0x165667B1u;
+    return g >> 24;
+}
 // slot of a key in the LDS table: two 32-bit multiplies (the 64-bit multiply of mf_phash is six quarter-rate instructions)
 __device__ __forceinline__ uint32_t skm_slot(uint64_t key) {
     uint32_t f = ((uint32_t)(key >> 32) * 0x85EBCA6Bu) ^ (uint32_t)key;
@@ -529,8 +537,9 @@ __device__ __forceinline__ void skm_note_claims(const skm_tailq &Q, uint32_t &nc
     ncl += tot;
 }
 // finish up to 64 queued keys (the last `c` entries), one per lane, by plain linear probing from their next slot
+// overflow: an LDS flag of the workgroup, raised when a key finds no slot (the partition is counted again in passes)
 __device__ __forceinline__ void skm_tail_drain(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
-                                               const skm_tailq &Q, uint32_t &qn, uint32_t &ncl, unsigned int *overflow) {
+                                               const skm_tailq &Q, uint32_t &qn, uint32_t &ncl, uint32_t *overflow) {
     const uint32_t c = qn < 64u ? qn : 64u;
     qn -= c;
     bool p1 = (uint32_t)mf_lane() < c;
@@ -538,7 +547,10 @@ __device__ __forceinline__ void skm_tail_drain(uint32_t tk0, uint32_t tc0, uint3
     if (p1) { k1[0] = Q.qk[qn + (uint32_t)mf_lane()]; s1 = Q.qs[qn + (uint32_t)mf_lane()]; }
     for (uint32_t probes = 0;; probes++) {
         if (__ballot(p1) == 0ull) break;
-        if (probes > mask) { if (mf_lane() == 0) atomicExch(overflow, 1u); break; }
+        if (probes >= 256u && ((probes & 255u) == 0u)) {                // a crowded table: give up as soon as anybody has
+            if (probes > mask) { if (mf_lane() == 0) *overflow = 1u; break; }
+            if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)overflow)) break;
+        }
         uint32_t ka[1], ca[1], aa[1], inc[1]; uint64_t cur[1], ret[1];
         ka[0] = p1 ? tk0 + 8u * s1 : dummy_k;
         skm_lds_read_b64<1>(ka, cur);
@@ -558,7 +570,7 @@ __device__ __forceinline__ void skm_tail_drain(uint32_t tk0, uint32_t tc0, uint3
     }
 }
 __device__ __forceinline__ void skm_count_insert4q(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
-                                                   const uint64_t (&key)[4], const skm_tailq &Q, uint32_t &qn, uint32_t &ncl, unsigned int *overflow, int ablate = 0) {
+                                                   const uint64_t (&key)[4], const skm_tailq &Q, uint32_t &qn, uint32_t &ncl, uint32_t *overflow, int ablate = 0) {
     uint32_t s[4]; bool pend[4];
 #pragma unroll
     for (int b = 0; b < 4; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = skm_slot(key[b]) & mask; }
@@ -608,13 +620,20 @@ __device__ __forceinline__ void skm_count_insert4q(uint32_t tk0, uint32_t tc0, u
 // k-mer with one 128-bit shift, rolls to the next three and inserts the four straight from registers.  No workgroup
 // barrier between the table initialisation and the compaction.  (One lane expanding its whole record serially costs the
 // wave the LONGEST record of its 64; a block-wide item list costs four barriers per round.)
-template <int K>
+//
+// A partition with more distinct k-mers than the table takes (a heavy minimizer: low-complexity sequence between many
+// different flanks) is put on the REDO list and its slice left empty; the MULTI instantiation of the kernel, launched
+// after every batch over that list (normally empty: its workgroups leave at once), counts such a partition in P = 4, 16
+// or 64 passes over its records, pass i inserting the k-mers with skm_pass_of(key) mod P = i.  More than 64 passes: the
+// global overflow flag, and the caller falls back to the k-mer path.
+template <int K, bool MULTI>
 __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart,
                                                       const uint32_t *__restrict__ plen, uint32_t np,
                                                       const uint64_t *__restrict__ toff, uint64_t *__restrict__ tkeys,
                                                       uint16_t *__restrict__ tcnt, uint32_t *__restrict__ dcount,
                                                       unsigned int *__restrict__ overflow, int ablate, uint32_t p0, uint64_t tbase,
-                                                      int thr, unsigned long long *__restrict__ n_all) {
+                                                      int thr, unsigned long long *__restrict__ n_all,
+                                                      uint32_t *__restrict__ redo, unsigned int *__restrict__ n_redo) {
     // thr >= 0: only the k-mers with count > thr are written; *n_all += distinct k-mers of the partitions (all of them)
     // partitions [p0, np); tkeys / tcnt hold the slices of this batch only: slice of p starts at toff[p] - tbase
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -630,7 +649,10 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
     uint16_t *items = cl_all + (SKM_CT / 64) * SKM_CLN + wave * (64 * 6);                                               // [64 * 6] (RMAX <= 24)
     skm_tailq Q; Q.qk = qk_all + wave * SKM_QN; Q.qs = qs_all + wave * SKM_QN; Q.cl = cl_all + wave * SKM_CLN;
     uint32_t qn = 0, ncl = 0;                                                                                           // wave-uniform
-    __shared__ uint32_t sweep_all;
+    __shared__ __attribute__((aligned(8))) uint32_t pflags[2];      // [0] sweep_all, [1] part_over: read together after the rounds
+    __shared__ uint32_t blk_claims;
+    uint32_t &sweep_all = pflags[0], &part_over = pflags[1];
+    uint32_t P = MULTI ? 4u : 1u, ncl_rep = 0;
     const uint32_t tk0 = mf_lds_addr(tk), tc0 = mf_lds_addr(tc);
     const uint32_t dummy_k = tk0 + 8u * ((uint32_t)MF_COUNT_SLOTS + lane);
     const uint32_t dummy_c = tc0 + 4u * ((uint32_t)MF_COUNT_SLOTS + lane);
@@ -641,26 +663,36 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
     constexpr int sh = 64 - 2 * K, top = 2 * K - 2;
     const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
     const uint32_t mine = (lane >> 3) * 64u + wave * 8u + (lane & 7u);          // this lane's record within a round of 512
-    uint32_t p = p0 + blockIdx.x;
-    if (p >= np) return;
+    // partitions [p0, np) in turn, or (MULTI) the partitions of the redo list
+    const uint32_t iend = MULTI ? *n_redo : np;
+    uint32_t pi = (MULTI ? 0u : p0) + blockIdx.x;
+    if (pi >= iend) return;
+    auto part_at = [&](uint32_t i) -> uint32_t { return MULTI ? redo[i] : i; };
+    uint32_t p = part_at(pi);
     uint64_t start = pstart[p];
     uint32_t len = plen[p];
     uint64_t o = toff[p] - tbase; uint32_t room = (uint32_t)(toff[p + 1] - toff[p]);   // this partition's slice of the output lists
     skm_rec R = mine < len ? recs[start + mine] : SENT;                        // first round, prefetched
     // directory entries are fetched TWO partitions ahead: the prefetch of the next partition's records needs its start,
     // and waiting for that load at the top of every partition costs a global round trip per partition
-    uint64_t start_n = 0, o_n = 0; uint32_t len_n = 0, room_n = 0;
-    if (p + gridDim.x < np) { const uint32_t q = p + gridDim.x; start_n = pstart[q]; len_n = plen[q]; o_n = toff[q] - tbase; room_n = (uint32_t)(toff[q + 1] - toff[q]); }
+    uint64_t start_n = 0, o_n = 0; uint32_t len_n = 0, room_n = 0, p_n = 0;
+    if (pi + gridDim.x < iend) { const uint32_t q = part_at(pi + gridDim.x); p_n = q; start_n = pstart[q]; len_n = plen[q]; o_n = toff[q] - tbase; room_n = (uint32_t)(toff[q + 1] - toff[q]); }
     for (;;) {
-        const uint32_t pn = p + gridDim.x, pnn = pn + gridDim.x;
-        uint64_t start_nn = 0, o_nn = 0; uint32_t len_nn = 0, room_nn = 0;
-        if (pnn < np) { start_nn = pstart[pnn]; len_nn = plen[pnn]; o_nn = toff[pnn] - tbase; room_nn = (uint32_t)(toff[pnn + 1] - toff[pnn]); }
-        if (threadIdx.x == 0) { out_cursor = 0; all_cursor = 0; sweep_all = 0; }
+        const uint32_t pn = pi + gridDim.x, pnn = pn + gridDim.x;
+        uint64_t start_nn = 0, o_nn = 0; uint32_t len_nn = 0, room_nn = 0, p_nn = 0;
+        if (pnn < iend) { const uint32_t q = part_at(pnn); p_nn = q; start_nn = pstart[q]; len_nn = plen[q]; o_nn = toff[q] - tbase; room_nn = (uint32_t)(toff[q + 1] - toff[q]); }
         skm_rec cur = R;
-        if (pn < np) R = mine < len_n ? recs[start_n + mine] : SENT;           // next partition's first round
+        if (pn < iend) R = mine < len_n ? recs[start_n + mine] : SENT;         // next partition's first round
+        if (threadIdx.x == 0) { out_cursor = 0; all_cursor = 0; }
+      for (uint32_t pass = 0; pass < P; pass++) {                              // (one pass unless MULTI)
+        if (threadIdx.x == 0) { *reinterpret_cast<uint64_t *>(pflags) = 0ull; if (MULTI) blk_claims = 0; }
+        if (MULTI) cur = mine < len ? recs[start + mine] : SENT;
         __syncthreads();
         for (uint32_t rb = 0; rb < len; rb += blockDim.x) {
-            if (rb) cur = rb + mine < len ? recs[start + rb + mine] : SENT;
+            if (rb) {
+                if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&part_over)) break;      // (abandoned)
+                cur = rb + mine < len ? recs[start + rb + mine] : SENT;
+            }
             const uint32_t r = skm_rec_valid(cur) ? skm_rec_n(cur) : 0u;
             const uint32_t nch = (r + 3u) >> 2;
             uint32_t NI;
@@ -688,18 +720,39 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                         rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fw & 3u)) << top);
                     }
                 }
-                if (ablate != 3) skm_count_insert4q(tk0, tc0, dummy_k, dummy_c, mask, k4, Q, qn, ncl, overflow, ablate);
+                if (MULTI) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++) if ((skm_pass_of(k4[j]) & (P - 1u)) != pass) k4[j] = MF_EMPTY;
+                }
+                if (ablate != 3) skm_count_insert4q(tk0, tc0, dummy_k, dummy_c, mask, k4, Q, qn, ncl, &part_over, ablate);
                 else if ((k4[0] ^ k4[1] ^ k4[2] ^ k4[3]) == 0x1234567ull) tk[0] = k4[0];
+                if (MULTI && ncl - ncl_rep >= 64u) {                           // wave-uniform: give up early, a crowded table is slow
+                    if (lane == 0 && atomicAdd(&blk_claims, ncl - ncl_rep) + (ncl - ncl_rep) > (uint32_t)SKM_FILL) part_over = 1;
+                    ncl_rep = ncl;
+                }
             }
-            while (qn) skm_tail_drain(tk0, tc0, dummy_k, dummy_c, mask, Q, qn, ncl, overflow);       // wave-uniform
+            while (qn) skm_tail_drain(tk0, tc0, dummy_k, dummy_c, mask, Q, qn, ncl, &part_over);     // wave-uniform
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
             __builtin_amdgcn_wave_barrier();
         }
         if (ncl > (uint32_t)SKM_CLN && lane == 0) sweep_all = 1;        // this wave's list is incomplete: sweep the whole table
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ds_add_u32 of the asm blocks are invisible to hipcc's waitcnt pass
         __syncthreads();
+        const uint64_t pf = *reinterpret_cast<volatile uint64_t *>(pflags);
+        if ((uint32_t)(pf >> 32)) {
+            // more distinct k-mers than the table takes: wipe it; the partition goes to the redo list, or (MULTI) starts again
+            // with four times the passes
+            for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
+            ncl = 0; ncl_rep = 0; qn = 0;
+            if (threadIdx.x == 0) { out_cursor = 0; all_cursor = 0; }
+            if (!MULTI) { if (threadIdx.x == 0) redo[atomicAdd(n_redo, 1u)] = p; __syncthreads(); break; }
+            if (P >= (uint32_t)SKM_MAX_PASSES) { if (threadIdx.x == 0) atomicExch(overflow, 1u); __syncthreads(); break; }
+            P *= 4; pass = ~0u;
+            __syncthreads();
+            continue;
+        }
         const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
-        if (!sweep_all) {
+        if (!(uint32_t)pf) {
             // compaction over the claimed slots: every wave walks ITS list (the slots it won), writes the entries that pass
             // the cut and leaves the slots empty for the next partition
             if (lane == 0 && ncl) atomicAdd(&all_cursor, ncl);
@@ -746,12 +799,14 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                 }
             }
         }
-        ncl = 0;
+        ncl = 0; ncl_rep = 0;
         __syncthreads();
+      }
+        if (MULTI) P = 4;
         if (threadIdx.x == 0) { dcount[p] = out_cursor; all_acc += all_cursor; }
-        if (pn >= np) break;
-        p = pn; start = start_n; len = len_n; o = o_n; room = room_n;
-        start_n = start_nn; len_n = len_nn; o_n = o_nn; room_n = room_nn;
+        if (pn >= iend) break;
+        pi = pn; p = p_n; start = start_n; len = len_n; o = o_n; room = room_n;
+        p_n = p_nn; start_n = start_nn; len_n = len_nn; o_n = o_nn; room_n = room_nn;
     }
     if (threadIdx.x == 0 && n_all && all_acc) atomicAdd(n_all, all_acc);
 }
@@ -761,10 +816,10 @@ __global__ void k_skm_add_base(uint64_t *__restrict__ v, uint64_t n, uint64_t ba
     if (i < n) v[i] += base;
 }
 // capacity of a partition's slice of the temporary (key,count) lists: it cannot hold more distinct k-mers than it has
-// k-mers, nor more than the LDS table
+// k-mers (a partition counted in several passes may hold more than the LDS table)
 __global__ void k_skm_cap(const uint32_t *__restrict__ pocc, uint32_t np, uint32_t *__restrict__ cap) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < np) cap[p] = pocc[p] < (uint32_t)MF_COUNT_SLOTS ? pocc[p] : (uint32_t)MF_COUNT_SLOTS;
+    if (p < np) cap[p] = pocc[p];
 }
 
 // =============================================================================================
@@ -915,17 +970,24 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     uint64_t dused = 0, dcap = 0;
     {
         const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 6 * 2 + (size_t)(SKM_CT / 64) * (SKM_QN * 10 + SKM_CLN * 2);
-        MF_TRY(skm_set_lds(k_skm_count<K>, lds));
+        MF_TRY(skm_set_lds(k_skm_count<K, false>, lds));
+        MF_TRY(skm_set_lds(k_skm_count<K, true>, lds));
     }
+    mf_buf<uint32_t> redo; MF_TRY(redo.alloc(ctx, PB));        // partitions of the running batch that need several passes
     for (uint32_t b = 0; b < nbatch; b++) {
         const uint32_t p0 = (uint32_t)std::min<uint64_t>((uint64_t)b * PB, np), p1 = (uint32_t)std::min<uint64_t>((uint64_t)(b + 1) * PB, np);
         if (p0 == p1) continue;
         {
             const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 6 * 2 + (size_t)(SKM_CT / 64) * (SKM_QN * 10 + SKM_CLN * 2);
             const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);
+            MF_HIP(hipMemsetAsync(&scal[8], 0, 8, st));
             mf_ktimer t(ctx, "k_skm_count");
-            k_skm_count<K><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
-                                                      (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr, &scal[7]);
+            k_skm_count<K, false><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
+                                                             (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8]);
+            // the partitions that did not fit (normally none: the workgroups find an empty list and leave)
+            k_skm_count<K, true><<<std::min<unsigned>(grid, 64u), SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p,
+                                                                                       (unsigned int *)&scal[2], (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr,
+                                                                                       &scal[7], redo.p, (unsigned int *)&scal[8]);
         }
         MF_DBG(ctx, "k_skm_count");
         MF_TRY(mf_scan<1>(ctx, dcount.p + p0, doff.p + p0, p1 - p0, (uint64_t *)&scal[3]));      // offsets inside the batch

@@ -76,12 +76,15 @@ __global__ void k_index_region_sizes(const uint64_t *__restrict__ part_off, uint
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= np) return;
     uint64_t c = part_off[p + 1] - part_off[p];
-    if (c > 4095) { atomicAdd(n_big + 2, 1u); c = 4095; }       // region would not fit in LDS: the caller builds the generic index
+    if (c >= (1ull << 30)) { atomicAdd(n_big + 2, 1u); c = 1; }  // (a region of 2^31 slots: the caller builds the generic index)
     const uint64_t want = 2 * c + 1;        // load <= 0.5: most probes are for absent neighbours, and a miss walks to the end of its cluster
     uint32_t S = 2;
     while (S < want) S <<= 1;
     sz[p] = S;
-    if (S > MF_IDX_WAVE_SLOTS) biglist[atomicAdd(n_big, 1u)] = p;
+    // up to MF_IDX_WAVE_SLOTS: built in LDS by one wave; up to 8192: in LDS by a workgroup; larger (a partition that was
+    // counted in several passes): in place in HBM.  biglist: the workgroup ones from the front, the HBM ones from the back.
+    if (S > 8192u) biglist[np - 1u - atomicAdd(n_big + 4, 1u)] = p;
+    else if (S > MF_IDX_WAVE_SLOTS) biglist[atomicAdd(n_big, 1u)] = p;
 }
 __global__ void k_index_dir_pack(const uint64_t *__restrict__ roff, const uint32_t *__restrict__ sz, uint32_t np, uint64_t *__restrict__ dir) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,6 +128,34 @@ __global__ __launch_bounds__(256) void k_index_build_part(mf_slot *__restrict__ 
         mf_slot *dst = slots + (d >> 6);
         for (uint32_t j = tl; j < S; j += TEAM) *reinterpret_cast<ulonglong2 *>(&dst[j]) = *reinterpret_cast<const ulonglong2 *>(&reg[j]);
         sync();
+    }
+}
+// regions too large for LDS: one workgroup per listed partition (biglist from the back) clears its region in HBM and
+// inserts with global atomics
+__global__ __launch_bounds__(256) void k_index_build_huge(mf_slot *__restrict__ slots, const uint64_t *__restrict__ dir, const uint64_t *__restrict__ keys,
+                                                          const uint16_t *__restrict__ vals, const uint64_t *__restrict__ part_off,
+                                                          uint32_t np, const uint32_t *__restrict__ biglist, uint32_t n_huge) {
+    for (uint32_t it = blockIdx.x; it < n_huge; it += gridDim.x) {
+        const uint32_t p = biglist[np - 1u - it];
+        const uint64_t d = dir[p];
+        const uint64_t S = 1ull << (d & 63ull), rmask = S - 1;
+        mf_slot *reg = slots + (d >> 6);
+        for (uint64_t j = threadIdx.x; j < S; j += blockDim.x) { ulonglong2 e; e.x = MF_EMPTY; e.y = 0; *reinterpret_cast<ulonglong2 *>(&reg[j]) = e; }
+        __threadfence();
+        __syncthreads();
+        const uint64_t lo = part_off[p], hi = part_off[p + 1];
+        for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
+            const uint64_t key = keys[i];
+            const uint64_t aux = (uint64_t)(uint32_t)i | ((uint64_t)(vals ? vals[i] : 0) << 32);
+            uint64_t s = mf_pslot(mf_phash(key)) & rmask;
+            for (;;) {
+                unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&reg[s].key), (unsigned long long)MF_EMPTY,
+                                                   (unsigned long long)key);
+                if (old == MF_EMPTY) { *reinterpret_cast<uint64_t *>(&reg[s].idx) = aux; break; }
+                s = (s + 1) & rmask;
+            }
+        }
+        __syncthreads();
     }
 }
 // entries with count > thr per partition (one wave per partition)
@@ -255,18 +286,18 @@ int mf_table_ensure_index(mf_table *t) {
         mf_buf<uint32_t> sz; MF_TRY(sz.alloc(ctx, np));
         mf_buf<uint32_t> biglist; MF_TRY(biglist.alloc(ctx, np));
         mf_buf<uint64_t> roff; MF_TRY(roff.alloc(ctx, (size_t)np + 1));
-        mf_buf<uint64_t> scal; MF_TRY(scal.alloc(ctx, 3));            // [0] total slots, [1] number of large regions, [2] oversized partitions
+        mf_buf<uint64_t> scal; MF_TRY(scal.alloc(ctx, 4));            // [0] total slots, [1] number of large regions, [2] oversized partitions, [3] HBM-built regions
         mf_buf<uint64_t> dir; MF_TRY(dir.alloc(ctx, np));
-        MF_HIP(hipMemsetAsync(scal.p, 0, 24, ctx->stream));
+        MF_HIP(hipMemsetAsync(scal.p, 0, 32, ctx->stream));
         k_index_region_sizes<<<(np + 255) / 256, 256, 0, ctx->stream>>>(t->d_part_off, np, sz.p, biglist.p, (unsigned int *)&scal.p[1]);
         MF_TRY(mf_scan<1>(ctx, sz.p, roff.p, np, &scal.p[0]));
         k_index_dir_pack<<<(np + 255) / 256, 256, 0, ctx->stream>>>(roff.p, sz.p, np, dir.p);
-        uint64_t hs[3];
-        MF_HIP(hipMemcpyAsync(hs, scal.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+        uint64_t hs[4];
+        MF_HIP(hipMemcpyAsync(hs, scal.p, 32, hipMemcpyDeviceToHost, ctx->stream));
         MF_HIP(hipStreamSynchronize(ctx->stream));
         if (hs[2]) return mf_index_build(ctx, t->d_keys, t->d_counts, t->n, &t->index, &t->index_bytes);
         const uint64_t cap = hs[0];
-        const uint32_t n_big = (uint32_t)hs[1];
+        const uint32_t n_big = (uint32_t)hs[1], n_huge = (uint32_t)hs[3];
         void *p = nullptr;
         MF_TRY(mf_alloc(ctx, cap * sizeof(mf_slot), &p));
         {
@@ -280,6 +311,8 @@ int mf_table_ensure_index(mf_table *t) {
                 MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_index_build_part<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
                 k_index_build_part<256><<<(unsigned)std::min<uint32_t>(n_big, (uint32_t)ctx->n_cu), 256, lds2, ctx->stream>>>((mf_slot *)p, dir.p, t->d_keys, t->d_counts, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1]);
             }
+            if (n_huge)
+                k_index_build_huge<<<(unsigned)std::min<uint32_t>(n_huge, (uint32_t)ctx->n_cu * 4), 256, 0, ctx->stream>>>((mf_slot *)p, dir.p, t->d_keys, t->d_counts, t->d_part_off, np, biglist.p, n_huge);
         }
         MF_HIP(hipGetLastError());
         MF_HIP(hipStreamSynchronize(ctx->stream));          // (biglist / scal are released below)

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmetafast_hip.so")
+LIB_PATH = os.environ.get("METAFAST_HIP_LIB") or os.path.join(_HERE, "lib", "libmetafast_hip.so")     # (override: A/B runs of two builds)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "metafast_hip.h")
 _lib = None
 

@@ -173,6 +173,29 @@ def test_skm_low_complexity(gpu_ctx, oracle, k):
     assert t.records()[1] == 16
 
 
+@pytest.mark.parametrize("n_reads,skm_path", [(20000, True), (400000, False)])
+def test_skm_homopolymer_flanks(gpu_ctx, oracle, n_reads, skm_path):
+    """many reads with a poly-A / poly-T stretch between random flanks: tens of thousands of distinct k-mers share the few
+    M-mers made of the stretch and a base or two of flank, i.e. ONE minimizer partition holds far more distinct k-mers than
+    the LDS table.  Such a partition is counted in several passes (4, 16, 64) instead of sending the whole call down the
+    slower k-mer path; beyond 64 passes the k-mer path takes over.  The index gets an HBM-built region for it."""
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(21)
+    fl = rng.integers(0, 4, size=(n_reads, 90))
+    lut = np.frombuffer(b"AGCT", dtype=np.uint8)
+    mid = np.where((np.arange(n_reads) & 1)[:, None] == 1, ord("A"), ord("T")).astype(np.uint8).repeat(22, axis=1)
+    arr = np.concatenate([lut[fl[:, :45]], mid, lut[fl[:, 45:]]], axis=1)
+    b = np.concatenate([arr.reshape(-1), np.zeros(64, dtype=np.uint8)])
+    o = (np.arange(n_reads + 1, dtype=np.uint64) * 112)
+    t = _check(gpu_ctx, oracle, b, o, 31)
+    assert (t.records()[1] == 16) == skm_path          # 16-byte records: counted by the super-k-mer path
+    ok, ov = oracle.Table().count_buffer(b, o, 31).export()
+    pick = rng.choice(len(ok), size=5000, replace=False)
+    absent = rng.integers(0, 1 << 62, size=500, dtype=np.uint64)
+    got = t.lookup(np.concatenate([ok[pick], absent]))
+    assert np.array_equal(got[:5000], ov[pick]) and np.all(got[5000:] == -1)
+
+
 def test_skm_lookup_filter_two_levels(gpu_ctx, oracle):
     """index over minimizer partitions (per-partition regions): present / absent keys, before and after a filter"""
     _reset(gpu_ctx)
