@@ -44,13 +44,6 @@ __global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ ke
     o[1] = make_uint4(out[4], out[5], out[6], out[7]);
 }
 
-__global__ void k_cc_init(uint32_t *__restrict__ parent, uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight,
-                          uint64_t n) {
-    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
-    parent[v] = (uint32_t)v; csize[v] = 0; cweight[v] = 0;
-}
-
 __device__ __forceinline__ uint32_t cc_find(uint32_t *parent, uint32_t x) {
     // path halving; plain (relaxed) loads/stores: any stale value is still an ancestor
     for (;;) {
@@ -61,16 +54,69 @@ __device__ __forceinline__ uint32_t cc_find(uint32_t *parent, uint32_t x) {
         x = gp;
     }
 }
+// The table is ordered by minimizer partition, so most edges join vertices a few hundred places apart: a workgroup first
+// solves its TILE of consecutive vertices in LDS (the edges with both ends inside: about five in six), writes every
+// vertex's tile root to parent[], and only the edges that leave the tile go through the union-find in HBM (k_cc_hook).
+#define CC_TILE 1024
+__global__ __launch_bounds__(256) void k_cc_hook_tile(const uint32_t *__restrict__ nbr, const uint8_t *__restrict__ alive, uint32_t *__restrict__ parent,
+                                                      uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight, uint64_t n) {
+    __shared__ uint32_t lp[CC_TILE];
+    __shared__ uint8_t la[CC_TILE];
+    const uint64_t base = (uint64_t)blockIdx.x * CC_TILE;
+    for (uint32_t i = threadIdx.x; i < CC_TILE; i += blockDim.x) {
+        lp[i] = i;
+        la[i] = base + i < n ? alive[base + i] : 0;
+        if (base + i < n) { csize[base + i] = 0; cweight[base + i] = 0; }
+    }
+    __syncthreads();
+    auto find_l = [&](uint32_t x) -> uint32_t {
+        for (;;) {
+            const uint32_t p = *(volatile uint32_t *)&lp[x];
+            if (p == x) return x;
+            const uint32_t gp = *(volatile uint32_t *)&lp[p];
+            if (gp != p) *(volatile uint32_t *)&lp[x] = gp;
+            x = gp;
+        }
+    };
+    for (uint32_t i = threadIdx.x; i < CC_TILE; i += blockDim.x) {
+        if (!la[i]) continue;
+        const uint64_t v = base + i;
+        const uint4 *q = reinterpret_cast<const uint4 *>(nbr + v * 8);
+        const uint4 a = q[0], b = q[1];
+        const uint32_t nb[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t u = nb[j];
+            if (u == CC_NONE || u >= (uint32_t)v || u < (uint32_t)base || !la[u - (uint32_t)base]) continue;
+            uint32_t ra = i, rb = u - (uint32_t)base;
+            for (;;) {
+                ra = find_l(ra); rb = find_l(rb);
+                if (ra == rb) break;
+                if (ra < rb) { const uint32_t t = ra; ra = rb; rb = t; }
+                if (atomicCAS(&lp[ra], ra, rb) == ra) break;
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < CC_TILE; i += blockDim.x) {
+        if (base + i >= n) break;
+        uint32_t r = i;
+        for (;;) { const uint32_t p = lp[r]; if (p == r) break; r = p; }
+        parent[base + i] = (uint32_t)base + r;
+    }
+}
+// the edges that leave the tile of their larger end
 __global__ void k_cc_hook(const uint32_t *__restrict__ nbr, const uint8_t *__restrict__ alive, uint32_t *parent, uint64_t n) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n || !alive[v]) return;
     const uint4 *q = reinterpret_cast<const uint4 *>(nbr + v * 8);
     uint4 a = q[0], b = q[1];
     uint32_t nb[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const uint32_t tile0 = (uint32_t)v & ~(uint32_t)(CC_TILE - 1);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         uint32_t u = nb[j];
-        if (u == CC_NONE || u >= (uint32_t)v || !alive[u]) continue;    // each undirected edge once (adjacency is symmetric)
+        if (u == CC_NONE || u >= tile0 || !alive[u]) continue;          // each undirected edge once (adjacency is symmetric)
         uint32_t ra = (uint32_t)v, rb = u;
         for (;;) {
             ra = cc_find(parent, ra); rb = cc_find(parent, rb);
@@ -319,7 +365,7 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             MF_HIP(hipMemsetAsync(counters.p, 0, 16, st));
             {
                 mf_ktimer tm(ctx, "k_cc_hook");
-                k_cc_init<<<cgrid(n), 256, 0, st>>>(parent.p, csize.p, cweight.p, n);
+                k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(nbr.p, alive.p, parent.p, csize.p, cweight.p, n);
                 k_cc_hook<<<cgrid(n), 256, 0, st>>>(nbr.p, alive.p, parent.p, n);
             }
             {
