@@ -128,34 +128,51 @@ __global__ void k_cc_hook(const uint32_t *__restrict__ nbr, const uint8_t *__res
 }
 // The forest is final after k_cc_hook.  root[] is a SEPARATE array and the find below does not write: storing the
 // root into parent[] here would race with other threads' path-halving stores (which may put back a non-root ancestor).
-__global__ void k_cc_flatten_stats(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ parent,
-                                   uint32_t *__restrict__ root, const uint16_t *__restrict__ vals,
-                                   uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight, uint64_t n) {
-    uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool act = v < n && alive[v];
-    uint32_t r = 0, w = 0;
-    if (act) {
-        r = (uint32_t)v;
-        for (;;) { uint32_t p = parent[r]; if (p == r) break; r = p; }
-        root[v] = r;
-        w = vals[v];
+// A workgroup takes a tile of CC_TILE consecutive vertices.  After k_cc_hook_tile most of them still point at one of a
+// few tile roots, so the tile is first grouped by parent value in an LDS hash table (size and weight summed with LDS
+// atomics); the walk to the root and the atomics on the root's two global counters then happen once per distinct parent
+// value instead of once per vertex (the giant component's counters are the hottest addresses of the whole step).
+__global__ __launch_bounds__(256) void k_cc_flatten_stats(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ parent,
+                                                          uint32_t *__restrict__ root, const uint16_t *__restrict__ vals,
+                                                          uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight, uint64_t n) {
+    constexpr uint32_t HS = 2 * CC_TILE;
+    __shared__ uint32_t hk[HS], hr[HS], hs[HS];
+    __shared__ unsigned long long hw[HS];
+    const uint64_t base = (uint64_t)blockIdx.x * CC_TILE;
+    for (uint32_t i = threadIdx.x; i < HS; i += blockDim.x) { hk[i] = CC_NONE; hs[i] = 0; hw[i] = 0; }
+    __syncthreads();
+    uint32_t slot[CC_TILE / 256];
+#pragma unroll
+    for (int j = 0; j < CC_TILE / 256; j++) {
+        const uint64_t v = base + (uint32_t)j * 256u + threadIdx.x;
+        slot[j] = CC_NONE;
+        if (v >= n || !alive[v]) continue;
+        const uint32_t key = parent[v];
+        uint32_t s = (key * 0x9E3779B1u) >> (32 - 11);
+        for (;;) {
+            const uint32_t old = atomicCAS(&hk[s], CC_NONE, key);
+            if (old == CC_NONE || old == key) break;
+            s = (s + 1) & (HS - 1);
+        }
+        slot[j] = s;
+        atomicAdd(&hs[s], 1u);
+        atomicAdd(&hw[s], (unsigned long long)vals[v]);
     }
-    // size / weight of the components: the lanes of a wave mostly belong to ONE component (the giant one holds most of the
-    // graph), and an atomic per vertex on its root's two counters serialises (9 of the 38 ms of the components step,
-    // 69 of 205 ms on the union of 8 samples): one atomic pair per distinct root and wave, a few rounds, then singly
-    unsigned long long todo = __ballot(act);
-    for (int round = 0; round < 4 && todo; round++) {               // wave-uniform
-        const int lead = __ffsll((long long)todo) - 1;
-        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, lead);
-        const bool in = act && r == r0;
-        const unsigned long long grp = __ballot(in);
-        uint32_t tot;
-        mf_wave_excl_scan(in ? w : 0u, &tot);
-        if (mf_lane() == lead) { atomicAdd(&csize[r0], (uint32_t)__popcll(grp)); atomicAdd(&cweight[r0], (unsigned long long)tot); }
-        if (in) act = false;
-        todo &= ~grp;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < HS; i += blockDim.x) {
+        uint32_t r = hk[i];
+        if (r == CC_NONE) continue;
+        for (;;) { const uint32_t p = parent[r]; if (p == r) break; r = p; }
+        hr[i] = r;
+        atomicAdd(&csize[r], hs[i]);
+        atomicAdd(&cweight[r], hw[i]);
     }
-    if (act) { atomicAdd(&csize[r], 1u); atomicAdd(&cweight[r], (unsigned long long)w); }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CC_TILE / 256; j++) {
+        const uint64_t v = base + (uint32_t)j * 256u + threadIdx.x;
+        if (slot[j] != CC_NONE) root[v] = hr[slot[j]];
+    }
 }
 // per root: classify; kept roots get a slot in the kept list (SoA: root / size / weight / smallest k-mer)
 struct cc_kept_arrays { uint32_t *root; uint32_t *size; unsigned long long *weight; unsigned long long *minkey; };
@@ -370,7 +387,7 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             }
             {
                 mf_ktimer tm(ctx, "k_cc_stats");
-                k_cc_flatten_stats<<<cgrid(n), 256, 0, st>>>(alive.p, parent.p, root.p, t->d_counts, csize.p, cweight.p, n);
+                k_cc_flatten_stats<<<cgrid(n, CC_TILE), 256, 0, st>>>(alive.p, parent.p, root.p, t->d_counts, csize.p, cweight.p, n);
                 k_cc_classify<<<cgrid(n), 256, 0, st>>>(alive.p, root.p, csize.p, cweight.p, n, (uint32_t)b1, (uint32_t)b2, keptslot.p, K,
                                                         counters.p);
             }
