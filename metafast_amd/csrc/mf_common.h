@@ -285,7 +285,8 @@ __device__ __forceinline__ uint32_t mf_mmer_rc(uint32_t f) {      // reverse com
 // global minimum, so EVERY k-mer that touches a poly-A / poly-T stretch would meet in one partition (hundreds of thousands
 // of distinct k-mers in real reads: the LDS table overflows).  0x051E6720 puts all 38 canonical repeats of period 1-3
 // (homopolymers, di- and trinucleotide microsatellites) above the 77th percentile, so they are almost never the minimum.
-__device__ __forceinline__ uint32_t mf_mmer_hash(uint32_t canon) { uint32_t h = (canon ^ 0x051E6720u) * 0x9E3779B1u; return h ^ (h >> 15); }
+// (No xor-shift after the multiply: the hash only ORDERS the M-mers, and the order is decided by the well-mixed top bits.)
+__device__ __forceinline__ uint32_t mf_mmer_hash(uint32_t canon) { return (canon ^ 0x051E6720u) * 0x9E3779B1u; }
 // minimizer hash -> partition hash (the minimum of several uniform values is not uniform: mix again)
 __device__ __forceinline__ uint32_t mf_remix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; return h ^ (h >> 16); }
 __device__ __forceinline__ uint32_t mf_skm_ph(uint64_t key, int k) {

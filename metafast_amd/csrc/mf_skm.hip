@@ -71,16 +71,22 @@ __device__ __forceinline__ void skm_scan_word(skm_word<K> &S, const uint8_t *__r
         r = (i == 0) ? mf_mmer_rc(f) : ((r >> 2) | ((3u - (f & 3u)) << (2 * M - 2)));
         hs[i] = mf_mmer_hash(f < r ? f : r);
     }
-    // sliding-window minimum over W M-mers: in-place doubling to spans of P (largest power of two <= W), then two
-    // overlapping spans
-    constexpr int P = W >= 16 ? 16 : W >= 8 ? 8 : W >= 4 ? 4 : W >= 2 ? 2 : 1;
+    // sliding-window minimum over W M-mers with three-input minima (v_min3_u32): spans of 3, then of 9, then two (or
+    // three) overlapping spans: 118 instructions for W = 17 instead of 214 with doubling
+    static_assert(W >= 3 && W <= 18, "window");
+    auto min3 = [](uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; };
 #pragma unroll
-    for (int step = 1; step < P; step <<= 1) {
+    for (int i = 0; i + 2 < NM; i++) hs[i] = min3(hs[i], hs[i + 1], hs[i + 2]);                 // hs[i] = min of M-mers i .. i+2
+    if (W >= 9) {
 #pragma unroll
-        for (int i = 0; i + step < NM; i++) hs[i] = hs[i] < hs[i + step] ? hs[i] : hs[i + step];
+        for (int i = 0; i + 8 < NM; i++) hs[i] = min3(hs[i], hs[i + 3], hs[i + 6]);             // i .. i+8
+#pragma unroll
+        for (int j = 0; j < 32; j++) S.mh[j] = hs[j] < hs[j + W - 9] ? hs[j] : hs[j + W - 9];
+    } else {
+        constexpr int D = W - 3 < 3 ? W - 3 : 3;
+#pragma unroll
+        for (int j = 0; j < 32; j++) S.mh[j] = min3(hs[j], hs[j + D], hs[j + W - 3]);
     }
-#pragma unroll
-    for (int j = 0; j < 32; j++) S.mh[j] = hs[j] < hs[j + W - P] ? hs[j] : hs[j + W - P];
     uint32_t same = 0;
 #pragma unroll
     for (int j = 1; j < 32; j++) same |= (S.mh[j] == S.mh[j - 1]) ? (1u << j) : 0u;
