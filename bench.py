@@ -46,7 +46,8 @@ def algorithmic_bytes(kernel, s):
     rec = s.get("n_records", 0) * s.get("record_bytes", 0)      # bytes of the records the counting pass partitioned
     return {
         # super-k-mer path (k >= 20): 16-byte records of about 7 k-mers each
-        "k_skm_hist": nb + nb / 8,                      # ASCII bases + valid-start bitmap
+        # (k_skm_hist: on the sample it only sizes regions from a sixteenth of the reads; the full pass runs on the cutter's
+        #  small input only -- not priced)
         "k_skm_scatter": nb + nb / 8 + rec,             # + every record written once
         "k_skm_split": 3 * rec,                         # histogram read + scatter read + write
         "k_skm_count": rec + 10 * good,                 # records read + (8 B key + 2 B count) per KEPT k-mer (count > b)
