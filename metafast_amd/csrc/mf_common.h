@@ -61,6 +61,9 @@ struct mf_ctx {
     int64_t opt_verbose = 0;
     int64_t opt_skm = 1;           // super-k-mer counting path (mf_skm.hip) for k >= MF_SKM_MIN_K; 0 = always one record per k-mer
     int64_t opt_skm_dyn = 1;       // one-pass level-1 scatter with sampled region sizes: 0 never, 1 auto (large inputs), 2 always
+    int64_t opt_stream_reader = 1; // plain FASTA/FASTQ files go through the pinned, double-buffered streaming reader (mf_io.hip)
+    int64_t opt_sr_piece = 8 << 20, opt_sr_slack = 1 << 20;
+    void *pin_pool = nullptr; size_t pin_pool_bytes = 0;           // pinned staging chunks of the streaming reader (lazy, kept)
     int64_t opt_skm_batches = 0;   // partitions are counted + gathered in this many batches (0 = auto); tests force small values
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero
     // workspace arena: a few large hipMalloc'd regions, sub-allocated with first-fit + coalescing free lists.

@@ -61,6 +61,7 @@ extern "C" void mf_ctx_destroy(mf_ctx *ctx) {
     ctx->regions.clear();
     for (auto &r : ctx->pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : ctx->event_pool) hipEventDestroy(ev);
+    if (ctx->pin_pool) hipHostFree(ctx->pin_pool);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -88,6 +89,9 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "ablate") ctx->opt_ablate = v;
     else if (s == "skm") ctx->opt_skm = v;
     else if (s == "skm_batches") ctx->opt_skm_batches = v;
+    else if (s == "stream_reader") ctx->opt_stream_reader = v;
+    else if (s == "stream_piece_bytes") ctx->opt_sr_piece = v;
+    else if (s == "stream_slack_bytes") ctx->opt_sr_slack = v;
     else if (s == "skm_dyn") ctx->opt_skm_dyn = v;
     else return mf_set_error("unknown option '%s'", name);
     return MF_OK;

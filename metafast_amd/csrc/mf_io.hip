@@ -11,6 +11,8 @@
 #include <string>
 #include <sys/stat.h>
 #include <thread>
+#include <atomic>
+#include <mutex>
 #include <unistd.h>
 #include <vector>
 
@@ -52,13 +54,15 @@ static uint64_t be_get(const uint8_t *p, int nb) { uint64_t v = 0; for (int i = 
 // growable byte buffer WITHOUT value-initialisation (a std::vector would zero gigabytes before every parse)
 struct byte_buf {
     uint8_t *p = nullptr; size_t n = 0, cap = 0;
+    bool ext = false;                // p is somebody else's fixed region (a pinned staging chunk): never reallocated or freed
     byte_buf() {}
+    void use_external(uint8_t *q, size_t c) { if (!ext) free(p); p = q; n = 0; cap = c; ext = true; }
     byte_buf(const byte_buf &) = delete;
     byte_buf &operator=(const byte_buf &) = delete;
-    byte_buf(byte_buf &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
-    byte_buf &operator=(byte_buf &&o) noexcept { free(p); p = o.p; n = o.n; cap = o.cap; o.p = nullptr; o.n = o.cap = 0; return *this; }
-    ~byte_buf() { free(p); }
-    void reserve(size_t c) { if (c > cap) { p = (uint8_t *)realloc(p, c); cap = c; } }
+    byte_buf(byte_buf &&o) noexcept : p(o.p), n(o.n), cap(o.cap), ext(o.ext) { o.p = nullptr; o.n = o.cap = 0; o.ext = false; }
+    byte_buf &operator=(byte_buf &&o) noexcept { if (!ext) free(p); p = o.p; n = o.n; cap = o.cap; ext = o.ext; o.p = nullptr; o.n = o.cap = 0; o.ext = false; return *this; }
+    ~byte_buf() { if (!ext) free(p); }
+    void reserve(size_t c) { if (c > cap && !ext) { p = (uint8_t *)realloc(p, c); cap = c; } }     // (an external region is as large as its input)
     uint8_t *grow(size_t add) { if (n + add > cap) reserve(std::max(cap * 2, n + add + 4096)); return p + n; }   // room for `add` more bytes
     void push_back(uint8_t c) { *grow(1) = c; n++; }
     size_t size() const { return n; }
@@ -424,35 +428,180 @@ static int parse_reads_file(const char *path, int threads, std::vector<read_batc
     return rc;
 }
 
+// ---- streaming reader for plain FASTA / FASTQ files: constant host memory, PCIe busy while the host parses --------------
+// The file is cut into pieces of SR_PIECE bytes (ends moved to the next record start, at most SR_SLACK further).  Up to 64
+// workers take pieces in turn: pread the piece into a private buffer, parse it with the SERIAL parser above into one of
+// the worker's two PINNED chunks, hipMemcpyAsync it to the piece's slot of a device buffer and go on with the other chunk
+// (a chunk is re-used when the event behind its copy has fired).  The compacting D2D copies into the final (bases,
+// offsets) layout are the caller's.  Returns 1 if the file needs the whole-file reader instead (a record longer than the
+// slack, a FASTQ file with empty lines, no '\n' line ends), < 0 on errors, 0 when done.
+// (piece / slack sizes: options stream_piece_bytes, stream_slack_bytes -- the tests use small ones to get many cuts)
+struct sr_piece { uint64_t dev_off = 0, n_bases = 0; std::vector<uint64_t> offsets; };
+struct sr_file { mf_buf<uint8_t> dev; std::vector<sr_piece> pieces; };
+// first record start at a buffer position >= from (the byte before it is a '\n', or it is the file's first byte), or n
+static size_t sr_record_start(const char *b, size_t n, size_t from, bool file_start, int fmt) {
+    if (from == 0 && file_start) return 0;
+    size_t pos = from ? from - 1 : 0;
+    while (pos < n) {
+        const void *nl = memchr(b + pos, '\n', n - pos);
+        if (!nl) return n;
+        pos = (size_t)((const char *)nl - b) + 1;
+        if (pos >= n) return n;
+        if (fmt == 1) { if (b[pos] == '>' || b[pos] == ';') return pos; }
+        else if (b[pos] == '@') {
+            const void *l1 = memchr(b + pos, '\n', n - pos);
+            if (!l1) return n;
+            const size_t p2 = (size_t)((const char *)l1 - b) + 1;
+            const void *l2 = p2 < n ? memchr(b + p2, '\n', n - p2) : nullptr;
+            if (!l2) return n;
+            const size_t p3 = (size_t)((const char *)l2 - b) + 1;
+            if (p3 < n && b[p3] == '+') return pos;
+        }
+    }
+    return n;
+}
+static int stream_file_to_device(mf_ctx *ctx, const char *path, int fmt, sr_file &out) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return mf_set_error("can't open '%s'", path);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return mf_set_error("can't stat '%s'", path); }
+    const size_t fsize = (size_t)st.st_size;
+    const size_t SR_PIECE = (size_t)std::max<int64_t>(ctx->opt_sr_piece, 4096), SR_SLACK = (size_t)std::max<int64_t>(ctx->opt_sr_slack, 1024);
+    const size_t np = (fsize + SR_PIECE - 1) / SR_PIECE;
+    const int W = (int)std::min<size_t>(std::min<size_t>((size_t)std::max(ctx->host_threads, 1), 64), np);
+    const size_t chunk = (size_t)SR_PIECE + SR_SLACK + 64;
+    // quality offset: the first 1000 records (ReadersUtils.java:63-77)
+    int qoff = 64;
+    if (fmt == 2) {
+        std::vector<char> head(std::min<size_t>(fsize, 4u << 20));
+        if (pread(fd, head.data(), head.size(), 0) != (ssize_t)head.size()) { close(fd); return mf_set_error("short read on '%s'", path); }
+        read_batch tmp;
+        qoff = parse_fastq_pass(head.data(), head.size(), path, 0, 0, tmp);
+        if (qoff < 0) { close(fd); return head.size() < fsize ? 1 : qoff; }      // (cut mid-record: let the whole-file reader decide)
+    }
+    if (ctx->pin_pool_bytes < (size_t)2 * W * chunk) {
+        if (ctx->pin_pool) { hipHostFree(ctx->pin_pool); ctx->pin_pool = nullptr; ctx->pin_pool_bytes = 0; }
+        const size_t want = (size_t)2 * std::min<size_t>((size_t)std::max(ctx->host_threads, 1), 64) * chunk;
+        if (hipHostMalloc(&ctx->pin_pool, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->pin_pool = nullptr; close(fd); return 1; }
+        ctx->pin_pool_bytes = want;
+    }
+    if (out.dev.alloc(ctx, np * chunk) != MF_OK) { close(fd); return 1; }
+    out.pieces.assign(np, sr_piece());
+    std::atomic<size_t> next{0};
+    std::atomic<int> state{0};                       // 0 ok, 1 = use the whole-file reader, < 0 = error
+    std::string err; std::mutex err_mu;
+    std::vector<std::thread> th;
+    for (int w = 0; w < W; w++)
+        th.emplace_back([&, w]() {
+            (void)hipSetDevice(ctx->device);
+            std::vector<char> raw(chunk + 1);
+            uint8_t *pin[2] = {(uint8_t *)ctx->pin_pool + (size_t)(2 * w) * chunk, (uint8_t *)ctx->pin_pool + (size_t)(2 * w + 1) * chunk};
+            hipEvent_t ev[2]; bool busy[2] = {false, false};
+            (void)hipEventCreateWithFlags(&ev[0], hipEventDisableTiming); (void)hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
+            int cur = 0;
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= np || state.load() != 0) break;
+                // bytes [i*PIECE - 1, (i+1)*PIECE + SLACK) of the file; the record starts at or after i*PIECE and
+                // (i+1)*PIECE bound the piece
+                const size_t lo = i ? i * SR_PIECE - 1 : 0, hi = std::min<size_t>(fsize, (i + 1) * (size_t)SR_PIECE + SR_SLACK);
+                size_t got = 0;
+                while (got < hi - lo) { const ssize_t r = pread(fd, raw.data() + got, hi - lo - got, (off_t)(lo + got)); if (r <= 0) break; got += (size_t)r; }
+                if (got != hi - lo) { std::lock_guard<std::mutex> g(err_mu); err = std::string("short read on '") + path + "'"; state = -1; break; }
+                const size_t n = hi - lo;
+                const size_t s0 = sr_record_start(raw.data(), n, i ? 1 : 0, i == 0, fmt);
+                size_t e0 = n;
+                if (hi < fsize || (i + 1) * (size_t)SR_PIECE < fsize) {
+                    const size_t from = (i + 1) * (size_t)SR_PIECE - lo;
+                    e0 = from < n ? sr_record_start(raw.data(), n, from, false, fmt) : n;
+                    if (e0 >= n && hi < fsize) { state = 1; break; }              // no record start within the slack
+                }
+                if (i && s0 > (size_t)SR_SLACK + 1) { state = 1; break; }
+                const char *pb = raw.data() + std::min(s0, e0); const size_t pn = e0 > s0 ? e0 - s0 : 0;
+                if (fmt == 2 && pn && (memmem(pb, pn, "\n\n", 2) || memmem(pb, pn, "\n\r\n", 3))) { state = 1; break; }
+                if (i == 0 && pn && !memchr(pb, '\n', std::min<size_t>(pn, 1u << 20))) { state = 1; break; }
+                if (busy[cur]) { (void)hipEventSynchronize(ev[cur]); busy[cur] = false; }
+                read_batch rb;
+                rb.bases.use_external(pin[cur], chunk);
+                const int rc = fmt == 1 ? parse_fasta(pb, pn, path, rb) : parse_fastq_pass(pb, pn, path, 1, qoff, rb);
+                if (rc < 0) { std::lock_guard<std::mutex> g(err_mu); if (state.load() >= 0) { err = mf_last_error(); state = rc; } break; }
+                sr_piece &P = out.pieces[i];
+                P.dev_off = i * chunk; P.n_bases = rb.bases.size(); P.offsets = std::move(rb.offsets);
+                if (P.n_bases) {
+                    if (hipMemcpyAsync(out.dev.p + P.dev_off, pin[cur], P.n_bases, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+                        hipEventRecord(ev[cur], ctx->stream) != hipSuccess) {
+                        std::lock_guard<std::mutex> g(err_mu); err = "H2D copy failed"; state = -1; break;
+                    }
+                    busy[cur] = true;
+                    cur ^= 1;
+                }
+            }
+            for (int j = 0; j < 2; j++) { if (busy[j]) (void)hipEventSynchronize(ev[j]); (void)hipEventDestroy(ev[j]); }
+        });
+    for (auto &x : th) x.join();
+    close(fd);
+    const int stt = state.load();
+    if (stt < 0) return mf_set_error("%s", err.c_str());
+    if (stt == 1) { out.dev.reset(); out.pieces.clear(); return 1; }
+    return 0;
+}
+
 // files -> (bases, offsets) in HBM (the layout mf_count_device takes); all files of the call form ONE read set
 static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfiles, mf_buf<uint8_t> &db, mf_buf<uint64_t> &doff,
                                 uint64_t *n_reads, uint64_t *n_bases, double *t_parse, double *t_h2d) {
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    std::vector<read_batch> parts;
-    for (int i = 0; i < nfiles; i++) MF_TRY(parse_reads_file(files[i], ctx->host_threads, parts));
-    const double t1 = now();
     MF_HIP(hipSetDevice(ctx->device));
+    // every file becomes a list of pieces: bases either already in HBM (streaming reader) or still on the host
+    struct piece { const uint8_t *dev = nullptr; const uint8_t *host = nullptr; uint64_t n_bases = 0; const std::vector<uint64_t> *offsets = nullptr; };
+    std::vector<piece> pieces;
+    std::vector<std::unique_ptr<sr_file>> streamed;
+    std::vector<std::unique_ptr<std::vector<read_batch>>> parsed;
+    for (int i = 0; i < nfiles; i++) {
+        std::string p(files[i]);
+        int fmt = 0;
+        if (ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq")) fmt = 2;
+        else if (ends_with_nocase(p, ".fasta") || ends_with_nocase(p, ".fa") || ends_with_nocase(p, ".fn") || ends_with_nocase(p, ".fna")) fmt = 1;
+        struct stat st;
+        if (fmt && ctx->opt_stream_reader && stat(files[i], &st) == 0 && (size_t)st.st_size >= (size_t)std::max<int64_t>(ctx->opt_sr_piece, 4096) / 2) {
+            auto sf = std::make_unique<sr_file>();
+            const int rc = stream_file_to_device(ctx, files[i], fmt, *sf);
+            if (rc < 0) return rc;
+            if (rc == 0) {
+                for (auto &P : sf->pieces) pieces.push_back(piece{sf->dev.p + P.dev_off, nullptr, P.n_bases, &P.offsets});
+                streamed.push_back(std::move(sf));
+                continue;
+            }
+        }
+        auto parts = std::make_unique<std::vector<read_batch>>();
+        MF_TRY(parse_reads_file(files[i], ctx->host_threads, *parts));
+        for (auto &rb : *parts) pieces.push_back(piece{nullptr, rb.bases.data(), rb.bases.size(), &rb.offsets});
+        parsed.push_back(std::move(parts));
+    }
+    const double t1 = now();
     // pieces -> one (bases, offsets) pair in HBM: bases piece by piece, offsets rebased on the host
     uint64_t nb = 0, nr = 0;
-    std::vector<uint64_t> pb(parts.size()), pr(parts.size());
-    for (size_t t = 0; t < parts.size(); t++) { pb[t] = nb; pr[t] = nr; nb += parts[t].bases.size(); nr += parts[t].offsets.size() - 1; }
+    std::vector<uint64_t> pb(pieces.size()), pr(pieces.size());
+    for (size_t t = 0; t < pieces.size(); t++) { pb[t] = nb; pr[t] = nr; nb += pieces[t].n_bases; nr += pieces[t].offsets->size() - 1; }
     std::vector<uint64_t> offsets(nr + 1);
     offsets[0] = 0;
     {
         std::vector<std::thread> th;
-        int T = (int)std::min<size_t>(parts.size(), (size_t)std::max(ctx->host_threads, 1));
+        int T = (int)std::min<size_t>(pieces.size(), (size_t)std::max(ctx->host_threads, 1));
         for (int w = 0; w < T; w++)
             th.emplace_back([&, w]() {
-                for (size_t t = (size_t)w; t < parts.size(); t += (size_t)T)
-                    for (size_t i = 1; i < parts[t].offsets.size(); i++) offsets[pr[t] + i] = parts[t].offsets[i] + pb[t];
+                for (size_t t = (size_t)w; t < pieces.size(); t += (size_t)T) {
+                    const std::vector<uint64_t> &o = *pieces[t].offsets;
+                    for (size_t i = 1; i < o.size(); i++) offsets[pr[t] + i] = o[i] + pb[t];
+                }
             });
         for (auto &x : th) x.join();
     }
     MF_TRY(db.alloc(ctx, nb + 64)); MF_TRY(doff.alloc(ctx, nr + 1));
-    for (size_t t = 0; t < parts.size(); t++)
-        if (!parts[t].bases.empty())
-            MF_HIP(hipMemcpyAsync(db.p + pb[t], parts[t].bases.data(), parts[t].bases.size(), hipMemcpyHostToDevice, ctx->stream));
+    for (size_t t = 0; t < pieces.size(); t++)
+        if (pieces[t].n_bases)
+            MF_HIP(hipMemcpyAsync(db.p + pb[t], pieces[t].dev ? (const void *)pieces[t].dev : (const void *)pieces[t].host, pieces[t].n_bases,
+                                  pieces[t].dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     MF_HIP(hipMemcpyAsync(doff.p, offsets.data(), (nr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
     MF_HIP(hipStreamSynchronize(ctx->stream));
     *n_reads = nr; *n_bases = nb;

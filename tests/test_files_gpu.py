@@ -343,5 +343,56 @@ def test_parallel_host_parser_large_files(gpu_ctx, oracle, tmp_path):
             f.write(b"@read%d\n" % i + s + b"\n+\n" + q + b"\n")
     assert os.path.getsize(fq) > 8_000_000
     gk, gc = gpu_ctx.count_reads([str(fq)], 21).export()
-    ok, ov = oracle.Table().count_files([str(fq)], 21).export()
-    assert len(ok) > 0 and np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+    okq, ovq = oracle.Table().count_files([str(fq)], 21).export()
+    assert len(okq) > 0 and np.array_equal(gk, okq) and np.array_equal(gc.astype(np.int32), ovq)
+    # the streaming reader (pinned, double-buffered pieces) with small pieces: hundreds of cuts, every one at a record start;
+    # then the whole-file reader; both files as ONE read set
+    try:
+        for piece, slack in ((64 << 10, 8 << 10), (1 << 20, 4096)):
+            gpu_ctx.set_option("stream_piece_bytes", piece)
+            gpu_ctx.set_option("stream_slack_bytes", slack)
+            gk, gc = gpu_ctx.count_reads([str(fa)], 21).export()
+            assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+            gk, gc = gpu_ctx.count_reads([str(fq)], 21).export()
+            assert np.array_equal(gk, okq) and np.array_equal(gc.astype(np.int32), ovq)
+        both_k, both_v = oracle.Table().count_files([str(fa), str(fq)], 21).export()
+        gk, gc = gpu_ctx.count_reads([str(fa), str(fq)], 21).export()
+        assert np.array_equal(gk, both_k) and np.array_equal(gc.astype(np.int32), both_v)
+        gpu_ctx.set_option("stream_reader", 0)
+        gk, gc = gpu_ctx.count_reads([str(fa), str(fq)], 21).export()
+        assert np.array_equal(gk, both_k) and np.array_equal(gc.astype(np.int32), both_v)
+        gpu_ctx.set_option("stream_reader", 1)
+        # a record longer than the slack (a genome-sized FASTA entry), a FASTQ file with an empty line, a bad character:
+        # the whole-file reader takes over / the error arrives with the reference's text
+        gpu_ctx.set_option("stream_piece_bytes", 64 << 10)
+        gpu_ctx.set_option("stream_slack_bytes", 4096)
+        lg = tmp_path / "long.fa"
+        with open(lg, "wb") as f:
+            f.write(b">short\nACGTACGTACGTACGTACGTACGTACGT\n>long\n")
+            s = al[rng.integers(0, 4, size=300_000)].tobytes()
+            for j in range(0, len(s), 70):
+                f.write(s[j:j + 70] + b"\n")
+            f.write(b">tail\nTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTTACG\n")
+        gk, gc = gpu_ctx.count_reads([str(lg)], 21).export()
+        lk, lv = oracle.Table().count_files([str(lg)], 21).export()
+        assert len(lk) > 250_000 and np.array_equal(gk, lk) and np.array_equal(gc.astype(np.int32), lv)
+        eq = tmp_path / "empty_lines.fq"
+        raw = open(fq, "rb").read()
+        cut = raw.index(b"\n@read40000\n")
+        eq.write_bytes(raw[:cut] + b"\n" + raw[cut:])
+        gk, gc = gpu_ctx.count_reads([str(eq)], 21).export()
+        assert np.array_equal(gk, okq) and np.array_equal(gc.astype(np.int32), ovq)
+        bad = tmp_path / "bad.fa"
+        raw = bytearray(open(fa, "rb").read())
+        pos = raw.index(b"\n", 15_000_000) + 1
+        while raw[pos] in b">;":
+            pos = raw.index(b"\n", pos) + 1
+        raw[pos] = ord("!")
+        bad.write_bytes(bytes(raw))
+        from metafast_amd.lib import MetafastError
+        with pytest.raises(MetafastError, match="Incorrect nucleotide char"):
+            gpu_ctx.count_reads([str(bad)], 21)
+    finally:
+        gpu_ctx.set_option("stream_reader", 1)
+        gpu_ctx.set_option("stream_piece_bytes", 8 << 20)
+        gpu_ctx.set_option("stream_slack_bytes", 1 << 20)
