@@ -332,18 +332,16 @@ int mf_comps_materialize(mf_comps *C) {
     mf_ctx *ctx = C->ctx;
     MF_HIP(hipSetDevice(ctx->device));
     const uint64_t nk = C->n_kmers;
-    std::vector<uint64_t> hk(nk); std::vector<uint32_t> hc(nk);
-    if (nk) {
-        MF_HIP(hipMemcpyAsync(hk.data(), C->d_kmers, nk * 8, hipMemcpyDeviceToHost, ctx->stream));
-        MF_HIP(hipMemcpyAsync(hc.data(), C->d_comp, nk * 4, hipMemcpyDeviceToHost, ctx->stream));
-        MF_HIP(hipStreamSynchronize(ctx->stream));
-    }
     C->offsets.assign(C->n + 1, 0);
     for (uint64_t c = 0; c < C->n; c++) C->offsets[c + 1] = C->offsets[c] + C->sizes[c];
-    C->kmers.assign(nk, 0);
-    std::vector<uint64_t> fill(C->offsets.begin(), C->offsets.end() - 1);
-    for (uint64_t j = 0; j < nk; j++) C->kmers[fill[hc[j]]++] = hk[j];
-    for (uint64_t c = 0; c < C->n; c++) std::sort(C->kmers.begin() + C->offsets[c], C->kmers.begin() + C->offsets[c + 1]);
+    C->kmers.resize(nk);
+    if (nk) {
+        // grouped by component, ascending inside: sorted in HBM (the host version of this took seconds per 1e7 k-mers)
+        mf_buf<uint64_t> sorted; MF_TRY(sorted.alloc(ctx, nk));
+        MF_TRY(mf_sort_kmers_by_comp(ctx, C->d_comp, C->d_kmers, nk, 2 * (C->k > 0 ? C->k : 32), (uint32_t)std::max<uint64_t>(C->n, 1), sorted.p));
+        MF_HIP(hipMemcpyAsync(C->kmers.data(), sorted.p, nk * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipStreamSynchronize(ctx->stream));
+    }
     C->host_ready = true;
     return MF_OK;
 }

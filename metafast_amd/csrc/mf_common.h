@@ -334,6 +334,11 @@ __device__ __forceinline__ uint32_t mf_skm_ph_left(uint64_t y, int k, uint32_t n
     return mf_remix32(h < no_last_of_x ? h : no_last_of_x);
 }
 struct mf_slot { uint64_t key; uint32_t idx; uint32_t val; };
+// ascending (key, value) order (mf_sort.hip); select + sort of a table's entries with count > threshold (mf_table.hip)
+int mf_sort_pairs(mf_ctx *ctx, const uint64_t *d_keys_in, const uint16_t *d_vals_in, uint64_t n, int key_bits, uint64_t *d_keys_out,
+                  uint16_t *d_vals_out);
+int mf_sort_kmers_by_comp(mf_ctx *ctx, const uint32_t *d_comp, const uint64_t *d_kmers, uint64_t n, int key_bits, uint32_t n_comps,
+                          uint64_t *d_out);
 // ph: the key's partition hash if the caller has it already (minimizer partitions only), see mf_index_find
 __device__ __forceinline__ bool mf_index_find_ph(const mf_index_view &ix, uint64_t key, uint32_t ph, uint32_t *idx, uint32_t *val) {
     const mf_slot *__restrict__ slots = reinterpret_cast<const mf_slot *>(ix.slots);

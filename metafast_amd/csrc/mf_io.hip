@@ -13,6 +13,7 @@
 #include <thread>
 #include <atomic>
 #include <mutex>
+#include <memory>
 #include <unistd.h>
 #include <vector>
 
@@ -632,20 +633,70 @@ extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles,
 // A5 / A6
 // ---------------------------------------------------------------------------------------------
 // IOUtils.printKmers (src/io/IOUtils.java:45-71) + QuickQuantitativeStatistics.printToFile (:65-72)
+// 10-byte big-endian records <-> (key, count) arrays, on the device: 256 records per workgroup staged through LDS so that
+// HBM sees whole dwords
+#define REC_PER_BLOCK 256
+__global__ __launch_bounds__(REC_PER_BLOCK) void k_records_encode(const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnts, uint64_t n,
+                                                                   uint32_t *__restrict__ out) {
+    __shared__ __attribute__((aligned(4))) uint8_t st[REC_PER_BLOCK * 10];
+    const uint64_t base = (uint64_t)blockIdx.x * REC_PER_BLOCK, i = base + threadIdx.x;
+    if (i < n) {
+        const uint64_t k = keys[i]; const uint32_t c = cnts[i];
+        uint8_t *p = st + threadIdx.x * 10;
+#pragma unroll
+        for (int b = 0; b < 8; b++) p[b] = (uint8_t)(k >> (8 * (7 - b)));
+        p[8] = (uint8_t)(c >> 8); p[9] = (uint8_t)c;
+    }
+    __syncthreads();
+    const uint64_t nrec = n - base < REC_PER_BLOCK ? n - base : REC_PER_BLOCK;
+    const uint32_t nbytes = (uint32_t)nrec * 10u, nw = (nbytes + 3u) / 4u;        // (the output buffer is padded to a dword)
+    for (uint32_t w = threadIdx.x; w < nw; w += REC_PER_BLOCK) out[base * 10 / 4 + w] = reinterpret_cast<const uint32_t *>(st)[w];
+}
+// counts come out as freq + 1 for the records with freq > thr and 0 for the others (a selection on "> 0" follows)
+__global__ __launch_bounds__(REC_PER_BLOCK) void k_records_decode(const uint32_t *__restrict__ raw, uint64_t n, int thr, uint64_t *__restrict__ keys,
+                                                                   uint16_t *__restrict__ cnts) {
+    __shared__ __attribute__((aligned(4))) uint8_t st[REC_PER_BLOCK * 10];
+    const uint64_t base = (uint64_t)blockIdx.x * REC_PER_BLOCK, i = base + threadIdx.x;
+    const uint64_t nrec = n - base < REC_PER_BLOCK ? n - base : REC_PER_BLOCK;
+    const uint32_t nw = ((uint32_t)nrec * 10u + 3u) / 4u;
+    for (uint32_t w = threadIdx.x; w < nw; w += REC_PER_BLOCK) reinterpret_cast<uint32_t *>(st)[w] = raw[base * 10 / 4 + w];
+    __syncthreads();
+    if (i < n) {
+        const uint8_t *p = st + threadIdx.x * 10;
+        uint64_t k = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) k = (k << 8) | p[b];
+        const int f = (int)(int16_t)(((uint32_t)p[8] << 8) | p[9]);
+        keys[i] = k;
+        cnts[i] = f > thr ? (uint16_t)(f + 1) : (uint16_t)0;
+    }
+}
+__global__ void k_counts_minus_one(uint16_t *__restrict__ c, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) c[i] = (uint16_t)(c[i] - 1);
+}
+int mf_table_select_sorted(const mf_table *t, int threshold, mf_buf<uint64_t> &sk, mf_buf<uint16_t> &sc, uint64_t *n);
 extern "C" int mf_table_write_kmers(const mf_table *t, int threshold, const char *kmers_bin, const char *stat_txt, uint64_t *n_good) {
     if (!t || !kmers_bin) return mf_set_error("mf_table_write_kmers: NULL argument");
+    mf_ctx *ctx = t->ctx;
     uint64_t n = 0;
-    MF_TRY(mf_table_export(t, threshold, nullptr, nullptr, 0, &n));
-    std::vector<uint64_t> keys(n); std::vector<uint16_t> cnts(n);
-    if (n) MF_TRY(mf_table_export(t, threshold, keys.data(), cnts.data(), n, &n));
+    mf_buf<uint64_t> sk; mf_buf<uint16_t> sc;
+    MF_TRY(mf_table_select_sorted(t, threshold, sk, sc, &n));
     FILE *f = fopen(kmers_bin, "wb");
     if (!f) return mf_set_error("can't write '%s'", kmers_bin);
-    std::vector<uint8_t> rec(10 * (size_t)std::min<uint64_t>(n ? n : 1, 1 << 20));
-    for (uint64_t i = 0; i < n;) {
-        uint64_t m = std::min<uint64_t>(n - i, 1 << 20);
-        for (uint64_t j = 0; j < m; j++) { be_put(&rec[10 * j], keys[i + j], 8); be_put(&rec[10 * j + 8], cnts[i + j], 2); }
-        fwrite(rec.data(), 10, m, f);
-        i += m;
+    if (n) {
+        // records are encoded in HBM and come down in slabs of 2^22 records (40 MB)
+        const uint64_t SLAB = 1ull << 22;
+        mf_buf<uint32_t> enc;
+        if (enc.alloc(ctx, (std::min(n, SLAB) * 10 + 3) / 4 + 1) != MF_OK) { fclose(f); return -1; }
+        std::vector<uint8_t> host(std::min(n, SLAB) * 10 + 4);
+        for (uint64_t i = 0; i < n; i += SLAB) {
+            const uint64_t m = std::min(SLAB, n - i);
+            k_records_encode<<<(unsigned)((m + REC_PER_BLOCK - 1) / REC_PER_BLOCK), REC_PER_BLOCK, 0, ctx->stream>>>(sk.p + i, sc.p + i, m, enc.p);
+            if (hipMemcpyAsync(host.data(), enc.p, m * 10, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess) { fclose(f); return mf_set_error("write_kmers: device copy failed"); }
+            if (fwrite(host.data(), 10, m, f) != m) { fclose(f); return mf_set_error("can't write '%s'", kmers_bin); }
+        }
     }
     fclose(f);
     if (stat_txt) {
@@ -661,22 +712,44 @@ extern "C" int mf_table_write_kmers(const mf_table *t, int threshold, const char
     if (n_good) *n_good = n;
     return MF_OK;
 }
-// IOUtils.loadKmers (src/io/IOUtils.java:369-401), Kmers2HMWorker.processKmer (:249-257), KmersLoadWorker (src/io/KmersLoadWorker.java:16-34)
+// IOUtils.loadKmers (src/io/IOUtils.java:369-401), Kmers2HMWorker.processKmer (:249-257), KmersLoadWorker (src/io/KmersLoadWorker.java:16-34):
+// the files go to HBM as they are and are decoded there; records with freq <= freq_threshold are dropped; a k-mer that
+// occurs in several files gets the (saturating) sum
+int mf_table_from_device_pairs(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, int k, mf_table **out);
 extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nfiles, int freq_threshold, int k, mf_table **out) {
     if (!ctx || !out || (nfiles && !files)) return mf_set_error("mf_table_load_kmers: NULL argument");
     *out = nullptr;
-    std::vector<uint64_t> keys; std::vector<uint16_t> cnts;
+    MF_HIP(hipSetDevice(ctx->device));
+    std::vector<raw_file> raws((size_t)nfiles);
+    uint64_t total = 0;
     for (int i = 0; i < nfiles; i++) {
-        std::vector<char> buf;
-        MF_TRY(read_whole_file(files[i], buf));
-        if (buf.size() % 10) return mf_set_error("Can't load k-mers file '%s': size is not a multiple of the 10-byte record", files[i]);
-        const uint8_t *p = (const uint8_t *)buf.data();
-        for (size_t o = 0; o < buf.size(); o += 10) {
-            int freq = (int16_t)be_get(p + o + 8, 2);
-            if (freq > freq_threshold) { keys.push_back(be_get(p + o, 8)); cnts.push_back((uint16_t)freq); }
-        }
+        MF_TRY(read_file_parallel(files[i], raws[(size_t)i], ctx->host_threads));
+        if (raws[(size_t)i].size() % 10) return mf_set_error("Can't load k-mers file '%s': size is not a multiple of the 10-byte record", files[i]);
+        total += raws[(size_t)i].size() / 10;
     }
-    return mf_table_from_host(ctx, keys.data(), cnts.data(), keys.size(), k, out);
+    mf_buf<uint64_t> dk; mf_buf<uint16_t> dc;
+    MF_TRY(dk.alloc(ctx, total)); MF_TRY(dc.alloc(ctx, total));
+    uint64_t at = 0;
+    for (int i = 0; i < nfiles; i++) {
+        const uint64_t m = raws[(size_t)i].size() / 10;
+        if (!m) continue;
+        mf_buf<uint32_t> raw; MF_TRY(raw.alloc(ctx, (m * 10 + 3) / 4 + 1));
+        MF_HIP(hipMemcpyAsync(raw.p, raws[(size_t)i].data(), m * 10, hipMemcpyHostToDevice, ctx->stream));
+        k_records_decode<<<(unsigned)((m + REC_PER_BLOCK - 1) / REC_PER_BLOCK), REC_PER_BLOCK, 0, ctx->stream>>>(raw.p, m, freq_threshold, dk.p + at, dc.p + at);
+        MF_HIP(hipStreamSynchronize(ctx->stream));
+        at += m;
+    }
+    // keep the records with freq > freq_threshold (encoded as freq + 1 > 0)
+    mf_table *all = nullptr;
+    {
+        mf_table tmp; tmp.ctx = ctx; tmp.k = k; tmp.n = total; tmp.d_keys = dk.p; tmp.d_counts = dc.p; tmp.owns_arrays = false;
+        MF_TRY(mf_table_filter(&tmp, 0, &all));
+    }
+    k_counts_minus_one<<<(unsigned)((all->n + 255) / 256 + 1), 256, 0, ctx->stream>>>(all->d_counts, all->n);
+    int rc = mf_table_from_device_pairs(ctx, all->d_keys, all->d_counts, all->n, k, out);
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    mf_table_destroy(all);
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -737,13 +810,13 @@ extern "C" int mf_comps_write(const mf_comps *cc, const char *components_bin, co
     if (!f) return mf_set_error("can't write '%s'", components_bin);
     uint8_t b[12];
     be_put(b, c->n, 4); fwrite(b, 1, 4, f);
-    std::vector<uint8_t> buf;
+    std::vector<uint64_t> buf;
     for (uint64_t i = 0; i < c->n; i++) {
         be_put(b, c->sizes[i], 4); be_put(b + 4, (uint64_t)c->weights[i], 8); fwrite(b, 1, 12, f);
         uint64_t lo = c->offsets[i], hi = c->offsets[i + 1];
-        buf.resize((hi - lo) * 8);
-        for (uint64_t j = lo; j < hi; j++) be_put(&buf[(j - lo) * 8], c->kmers[j], 8);
-        if (hi > lo) fwrite(buf.data(), 1, buf.size(), f);
+        buf.resize(hi - lo);
+        for (uint64_t j = lo; j < hi; j++) buf[j - lo] = __builtin_bswap64(c->kmers[j]);
+        if (hi > lo) fwrite(buf.data(), 8, buf.size(), f);
     }
     fclose(f);
     if (stat_txt) {
@@ -756,29 +829,61 @@ extern "C" int mf_comps_write(const mf_comps *cc, const char *components_bin, co
     }
     return MF_OK;
 }
-// ConnectedComponent.loadComponents (:95-122)
+// ConnectedComponent.loadComponents (:95-122).  The host only walks the component headers (size, weight); the file goes to
+// HBM as it is and the k-mers are byte-swapped there, one workgroup per component.
+__global__ __launch_bounds__(256) void k_comps_decode(const uint32_t *__restrict__ raw, const uint64_t *__restrict__ foff, const uint64_t *__restrict__ koff,
+                                                      uint32_t n_comp, uint64_t *__restrict__ kmers, uint32_t *__restrict__ comp) {
+    for (uint32_t c = blockIdx.x; c < n_comp; c += gridDim.x) {
+        const uint64_t w0 = foff[c] / 4, k0 = koff[c], sz = koff[c + 1] - k0;
+        for (uint64_t j = threadIdx.x; j < sz; j += blockDim.x) {
+            const uint32_t hi = __builtin_bswap32(raw[w0 + 2 * j]), lo = __builtin_bswap32(raw[w0 + 2 * j + 1]);
+            kmers[k0 + j] = ((uint64_t)hi << 32) | lo;
+            comp[k0 + j] = c;
+        }
+    }
+}
 extern "C" int mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps **out) {
     if (!ctx || !components_bin || !out) return mf_set_error("mf_comps_load: NULL argument");
     *out = nullptr;
-    std::vector<char> buf;
-    if (read_whole_file(components_bin, buf) < 0) return mf_set_error("Can't load components: file not found (%s)", components_bin);
+    raw_file buf;
+    if (read_file_parallel(components_bin, buf, ctx->host_threads) < 0) return mf_set_error("Can't load components: file not found (%s)", components_bin);
     const uint8_t *p = (const uint8_t *)buf.data();
-    size_t n = buf.size(), pos = 4;
+    const size_t n = buf.size();
+    size_t pos = 4;
     if (n < 4) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
-    uint64_t cnt = be_get(p, 4);
-    std::vector<uint64_t> sizes, offsets(1, 0), kmers; std::vector<int64_t> weights; std::vector<int32_t> thr;
+    const uint64_t cnt = be_get(p, 4);
+    std::unique_ptr<mf_comps, void (*)(mf_comps *)> C(new mf_comps(), [](mf_comps *c) { mf_comps_destroy(c); });
+    C->ctx = ctx; C->k = 0; C->n = cnt;
+    std::vector<uint64_t> foff(cnt + 1, 0), koff(cnt + 1, 0);
     for (uint64_t i = 0; i < cnt; i++) {
         if (pos + 12 > n) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
-        uint64_t sz = be_get(p + pos, 4);
-        weights.push_back((int64_t)be_get(p + pos + 4, 8));
+        const uint64_t sz = be_get(p + pos, 4);
+        C->weights.push_back((int64_t)be_get(p + pos + 4, 8));
         pos += 12;
         if (pos + 8 * sz > n) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
-        for (uint64_t j = 0; j < sz; j++) kmers.push_back(be_get(p + pos + 8 * j, 8));
+        foff[i] = pos; koff[i + 1] = koff[i] + sz;
         pos += 8 * sz;
-        sizes.push_back(sz); thr.push_back(0); offsets.push_back(kmers.size());
+        C->sizes.push_back(sz); C->thr.push_back(0);
     }
+    const uint64_t nk = koff[cnt];
+    if (nk >= 0xFFFFFFFFull) return mf_set_error("components: too many k-mers");
+    C->n_kmers = nk;
     MF_HIP(hipSetDevice(ctx->device));
-    return mf_comps_from_host(ctx, 0, sizes, weights, thr, offsets, kmers, out);
+    void *q = nullptr;
+    MF_TRY(mf_alloc(ctx, (nk ? nk : 1) * 8, &q)); C->d_kmers = (uint64_t *)q; C->kmers_bytes = (nk ? nk : 1) * 8;
+    MF_TRY(mf_alloc(ctx, (nk ? nk : 1) * 4, &q)); C->d_comp = (uint32_t *)q; C->comp_bytes = (nk ? nk : 1) * 4;
+    if (nk) {
+        mf_buf<uint32_t> raw; MF_TRY(raw.alloc(ctx, n / 4 + 2));
+        mf_buf<uint64_t> dfo, dko; MF_TRY(dfo.alloc(ctx, cnt + 1)); MF_TRY(dko.alloc(ctx, cnt + 1));
+        MF_HIP(hipMemcpyAsync(raw.p, p, n, hipMemcpyHostToDevice, ctx->stream));
+        MF_HIP(hipMemcpyAsync(dfo.p, foff.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        MF_HIP(hipMemcpyAsync(dko.p, koff.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        k_comps_decode<<<(unsigned)std::min<uint64_t>(cnt, 65535), 256, 0, ctx->stream>>>(raw.p, dfo.p, dko.p, (uint32_t)cnt, C->d_kmers, C->d_comp);
+        MF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    C->host_ready = false;             // (member lists on the host: built from the device arrays when somebody asks)
+    *out = C.release();
+    return MF_OK;
 }
 // ComponentCutterMain.runImpl :92-108
 extern "C" int mf_cut_components(mf_ctx *ctx, mf_table *cutter, int k, int b1, int b2, const char *components_bin,
@@ -849,17 +954,23 @@ extern "C" int mf_features_reads(mf_ctx *ctx, const char *components_bin, const 
 extern "C" int mf_features(mf_ctx *ctx, const char *components_bin, const char *kmers_bin, int k, int threshold,
                            const char *vec_path, const char *breadth_path) {
     if (!ctx || !components_bin || !kmers_bin) return mf_set_error("mf_features: NULL argument");
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
     mf_comps *c = nullptr;
     MF_TRY(mf_comps_load(ctx, components_bin, &c));
     if (c->n == 0) { mf_comps_destroy(c); return mf_set_error("No components were found in input files! Can't continue the calculations."); }
+    const double t1 = now();
     mf_table *t = nullptr;
     const char *files[1] = {kmers_bin};
     // calculatePresenceForKmers streams EVERY record of the file (no threshold on load): freq_threshold = -1 keeps all
     int rc = mf_table_load_kmers(ctx, files, 1, -1, k, &t);
     if (rc < 0) { mf_comps_destroy(c); return rc; }
+    const double t2 = now();
     std::vector<int64_t> vec(c->n); std::vector<double> br(c->n);
     rc = mf_features_device(ctx, c, t, threshold, vec.data(), br.data());
+    const double t3 = now();
     if (rc == MF_OK) rc = write_features_files(vec, br, vec_path, breadth_path);
+    if (getenv("MF_IO_TIMING")) fprintf(stderr, "[mf] features: components %.3f s, k-mers file %.3f s, features %.3f s, output %.3f s\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
     mf_table_destroy(t);
     mf_comps_destroy(c);
     return rc;

@@ -473,25 +473,34 @@ extern "C" int mf_table_from_host(mf_ctx *ctx, const uint64_t *keys, const uint1
     return r;
 }
 
-extern "C" int mf_table_export(const mf_table *t, int threshold, uint64_t *keys, uint16_t *counts, uint64_t cap, uint64_t *n) {
-    if (!t || !n) return mf_set_error("NULL argument");
+// the entries with count > threshold in ascending k-mer order, in HBM (sorted there: a host sort of 3.6e8 entries takes
+// a minute, the device-wide radix sort 30 ms)
+int mf_table_select_sorted(const mf_table *t, int threshold, mf_buf<uint64_t> &sk, mf_buf<uint16_t> &sc, uint64_t *n) {
     mf_ctx *ctx = t->ctx;
     MF_HIP(hipSetDevice(ctx->device));
     mf_buf<uint64_t> ok; mf_buf<uint16_t> oc; uint64_t m = 0;
     MF_TRY(select_entries<0>(ctx, t->d_keys, t->d_counts, nullptr, t->n, threshold, ok, oc, &m));
     *n = m;
-    if (cap == 0 || !keys || !counts) return MF_OK;
+    MF_TRY(sk.alloc(ctx, m)); MF_TRY(sc.alloc(ctx, m));
+    return mf_sort_pairs(ctx, ok.p, oc.p, m, 2 * t->k, sk.p, sc.p);
+}
+extern "C" int mf_table_export(const mf_table *t, int threshold, uint64_t *keys, uint16_t *counts, uint64_t cap, uint64_t *n) {
+    if (!t || !n) return mf_set_error("NULL argument");
+    mf_ctx *ctx = t->ctx;
+    MF_HIP(hipSetDevice(ctx->device));
+    if (cap == 0 || !keys || !counts) {               // size query
+        mf_buf<uint64_t> ok; mf_buf<uint16_t> oc;
+        return select_entries<0>(ctx, t->d_keys, t->d_counts, nullptr, t->n, threshold, ok, oc, n);
+    }
+    mf_buf<uint64_t> sk; mf_buf<uint16_t> sc; uint64_t m = 0;
+    MF_TRY(mf_table_select_sorted(t, threshold, sk, sc, &m));
+    *n = m;
     if (cap < m) return mf_set_error("mf_table_export: capacity %llu < %llu", (unsigned long long)cap, (unsigned long long)m);
-    std::vector<uint64_t> hk(m); std::vector<uint16_t> hc(m);
     if (m) {
-        MF_HIP(hipMemcpyAsync(hk.data(), ok.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
-        MF_HIP(hipMemcpyAsync(hc.data(), oc.p, m * 2, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipMemcpyAsync(keys, sk.p, m * 8, hipMemcpyDeviceToHost, ctx->stream));
+        MF_HIP(hipMemcpyAsync(counts, sc.p, m * 2, hipMemcpyDeviceToHost, ctx->stream));
         MF_HIP(hipStreamSynchronize(ctx->stream));
     }
-    std::vector<uint64_t> order(m);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return hk[a] < hk[b]; });
-    for (uint64_t i = 0; i < m; i++) { keys[i] = hk[order[i]]; counts[i] = hc[order[i]]; }
     return MF_OK;
 }
 
