@@ -441,7 +441,60 @@ int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out) {
 }
 
 // host arrays -> table (insert-or-add with saturation through the HBM index)
+// ---- a table with MINIMIZER partitions from pairs whose keys are all different (a .kmers.bin file): partition hash per
+// key, stable radix sort of (partition, position), gather, partition offsets by binary search.  The table then gets the
+// per-partition index and its cache-local neighbour probes, like a table that comes out of the counting pass.
+__global__ void k_pairs_part(const uint64_t *__restrict__ keys, uint64_t n, int k, int bits, uint32_t *__restrict__ part, uint32_t *__restrict__ pos,
+                             unsigned int *__restrict__ unsorted) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    part[i] = mf_skm_ph(key, k) >> (32 - bits);
+    pos[i] = (uint32_t)i;
+    if (i + 1 < n && keys[i + 1] <= key) atomicExch(unsorted, 1u);        // (not strictly ascending: duplicates are possible)
+}
+__global__ void k_pairs_gather(const uint64_t *__restrict__ keys, const uint16_t *__restrict__ vals, const uint32_t *__restrict__ pos, uint64_t n,
+                               uint64_t *__restrict__ ok, uint16_t *__restrict__ ov) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t s = pos[i]; ok[i] = keys[s]; ov[i] = vals[s]; }
+}
+__global__ void k_pairs_offsets(const uint32_t *__restrict__ part_sorted, uint64_t n, uint32_t np, uint64_t *__restrict__ off) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > np) return;
+    uint64_t lo = 0, hi = n;                      // first position with part >= p
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (part_sorted[mid] < p) lo = mid + 1; else hi = mid; }
+    off[p] = lo;
+}
+// returns 1 if the pairs do not qualify (k too small for minimizers, keys not strictly ascending, too many)
+static int table_from_unique_pairs(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, int k, mf_table **out) {
+    if (k < MF_SKM_MIN_K || n < 4096 || n >= 0xFFFFFFFFull) return 1;
+    int bits = 1; while (bits < 26 && (n >> bits) > 96) bits++;
+    const uint32_t np = 1u << bits;
+    mf_buf<uint32_t> part, pos, part2, pos2; mf_buf<unsigned int> flag;
+    MF_TRY(part.alloc(ctx, n)); MF_TRY(pos.alloc(ctx, n)); MF_TRY(part2.alloc(ctx, n)); MF_TRY(pos2.alloc(ctx, n)); MF_TRY(flag.alloc(ctx, 1));
+    MF_HIP(hipMemsetAsync(flag.p, 0, 4, ctx->stream));
+    k_pairs_part<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(d_keys, n, k, bits, part.p, pos.p, flag.p);
+    unsigned int uns = 0;
+    MF_HIP(hipMemcpyAsync(&uns, flag.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    if (uns) return 1;
+    MF_TRY(mf_sort_u32_pairs(ctx, part.p, pos.p, n, bits, part2.p, pos2.p));
+    mf_buf<uint64_t> ok; mf_buf<uint16_t> oc; mf_buf<uint64_t> off;
+    MF_TRY(ok.alloc(ctx, n)); MF_TRY(oc.alloc(ctx, n)); MF_TRY(off.alloc(ctx, (size_t)np + 1));
+    k_pairs_gather<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(d_keys, d_vals, pos2.p, n, ok.p, oc.p);
+    k_pairs_offsets<<<(np + 1 + 255) / 256, 256, 0, ctx->stream>>>(part2.p, n, np, off.p);
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    size_t kb = ok.bytes(), cb = oc.bytes();
+    MF_TRY(mf_table_adopt(ctx, k, n, 0, ok.take(), kb, oc.take(), cb, out));
+    (*out)->part_bits = bits; (*out)->part_skm = 1;
+    (*out)->part_off_bytes = off.bytes(); (*out)->d_part_off = off.take();
+    return MF_OK;
+}
 int mf_table_from_device_pairs(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, int k, mf_table **out) {
+    {
+        const int rc = table_from_unique_pairs(ctx, d_keys, d_vals, n, k, out);
+        if (rc <= 0) return rc;
+    }
     uint64_t cap = pow2_at_least(std::max<uint64_t>(2 * n, 1024));
     mf_buf<mf_slot> slots; MF_TRY(slots.alloc(ctx, cap));
     unsigned grid = (unsigned)std::min<uint64_t>((cap + 255) / 256, 65536);
