@@ -16,6 +16,31 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(L.exported_symbols())
 
 
+def test_jni_shim_matches_the_abi():
+    """jni/metafast_jni.cpp (compiled only where a JDK exists) calls nothing but declared entry points, with the declared
+    number of arguments; every native of jni/HipBackend.java has its Java_io_HipBackend_* definition"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = re.sub(r"/\*.*?\*/", "", open(L.HEADER_PATH).read(), flags=re.S)
+    decl = {}
+    for m in re.finditer(r"\b(mf_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr, flags=re.S):
+        args = m.group(2).strip()
+        decl[m.group(1)] = 0 if args in ("", "void") else args.count(",") + 1
+    shim = open(os.path.join(root, "jni", "metafast_jni.cpp")).read()
+    calls = re.findall(r"\b(mf_[a-z0-9_]+)\s*\(", shim)
+    assert len(set(calls)) >= 10
+    for name in set(calls):
+        assert name in decl, name
+    for m in re.finditer(r"\b(mf_[a-z0-9_]+)\s*\(((?:[^()]|\([^()]*\))*)\)", shim):
+        inner = re.sub(r"\([^()]*\)", "", m.group(2))
+        n = 0 if not inner.strip() else inner.count(",") + 1
+        assert n == decl[m.group(1)], (m.group(1), n, decl[m.group(1)])
+    java = open(os.path.join(root, "jni", "HipBackend.java")).read()
+    natives = re.findall(r"public static native [\w\[\]]+\s+(\w+)\(", java)
+    assert len(natives) >= 12
+    for n in natives:
+        assert "Java_io_HipBackend_%s(" % n in shim, n
+
+
 def test_no_cpu_fallback_without_gpu():
     import torch
     if torch.cuda.is_available():
