@@ -12,10 +12,9 @@ torch.cuda.synchronize()
 ctx.synth_reads_device(0x4D45544146415354, 0, 0, n_reads, rl, 1_000_000, bases.data_ptr(), offsets.data_ptr())
 good, nd = ctx.count_device_above(bases.data_ptr(), offsets.data_ptr(), n_reads, n_reads * rl, 31, 1)
 ctx.set_option("profile", 1)
-for tile in (1, 0, 1, 0):
-    ctx.set_option("index_tile", tile)
+for rep_no in range(2):
     ctx.reset_timers()
     s = ctx.build_unitigs(good, 1, 100)
     n = len(s); s.close()
     rep = ctx.kernel_report()
-    print("index_tile", tile, "unitigs", n, {k: round(v[1], 2) for k, v in rep.items() if k.startswith("k_ut")}, flush=True)
+    print("unitigs", n, {k: round(v[1], 2) for k, v in rep.items() if k.startswith("k_ut")}, flush=True)
