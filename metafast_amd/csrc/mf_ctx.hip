@@ -81,7 +81,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     std::string s(name);
     if (s == "l1_bits") { if (v > MF_MAX_DIGIT_BITS) return mf_set_error("l1_bits > %d", MF_MAX_DIGIT_BITS); ctx->opt_l1_bits = v; }
     else if (s == "l2_bits") { if (v > MF_MAX_DIGIT_BITS) return mf_set_error("l2_bits > %d", MF_MAX_DIGIT_BITS); ctx->opt_l2_bits = v; }
-    else if (s == "part_target") { if (v < 16 || v > 4096) return mf_set_error("part_target out of [16,4096]"); ctx->opt_part_target = v; }
+    else if (s == "part_target") { if (v < 1 || v > 4096) return mf_set_error("part_target out of [1,4096]"); ctx->opt_part_target = v; }
     else if (s == "scatter_staged") ctx->opt_scatter_staged = v;
     else if (s == "profile") ctx->opt_profile = v;
     else if (s == "l1_blocks") ctx->opt_l1_blocks = v;

@@ -859,6 +859,16 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     mf_buf<uint32_t> pocc; MF_TRY(pocc.alloc(ctx, np));
     mf_buf<skm_rec> bufA;
     unsigned long long cap = 0;
+    // Three or more levels ping-pong between record buffers: all of them get the size of the LAST level's (every level
+    // adds padding), so the third level re-uses the first level's buffer instead of asking for a third one that is a few
+    // megabytes too large for it (at 200 M reads, k = 21 a buffer is 125 GB: there is no room for three, and a second
+    // sample would find the arena's idle regions just too small again).
+    auto final_cap = [&](unsigned long long c1) {
+        if (lv.size() < 3) return c1;
+        unsigned long long c = c1, p = (unsigned long long)nd1;
+        for (size_t li = 1; li < lv.size(); li++) { c += p * SKM_LINE * (1ull << lv[li]); p <<= lv[li]; }
+        return c;
+    };
     // Level 1 in ONE pass over the reads where it pays (large inputs, a split level follows): the digit regions are sized
     // from a histogram of a sixteenth of the input and handed out chunk-wise during the scatter, instead of a full
     // minimizer pass just to count (k_skm_hist over everything costs 17 ms of 300 at 100 M reads).  If a region turns out
@@ -884,7 +894,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             MF_HIP(hipMemsetAsync(&scal[5], 0, 8, st));
             MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
             MF_HIP(hipStreamSynchronize(st));
-            if (bufA.alloc(ctx, cap + (uint64_t)G * SKM_CH) != MF_OK) return MF_SKM_FALLBACK;
+            if (bufA.alloc(ctx, std::max<unsigned long long>(cap + (uint64_t)G * SKM_CH, final_cap(cap))) != MF_OK) return MF_SKM_FALLBACK;
             skm_dyn Dy; Dy.gcur = gcur.p; Dy.rend = rstart.p + 1; Dy.overflow = (unsigned int *)&scal[5]; Dy.dump = cap;
             {
                 const size_t lds = skm_stage_bytes(nd1);
@@ -906,7 +916,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         MF_TRY(mf_scan<SKM_LINE>(ctx, blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal[1]));
         MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));                       // padded number of records
-        if (bufA.alloc(ctx, cap) != MF_OK) return MF_SKM_FALLBACK;            // (the k-mer path will report the shortage if it cannot run either)
+        if (bufA.alloc(ctx, final_cap(cap)) != MF_OK) return MF_SKM_FALLBACK;   // (the k-mer path will report the shortage if it cannot run either)
         {
             const size_t lds = skm_stage_bytes(nd1);
             MF_TRY(skm_set_lds(k_skm_scatter<K, false>, lds));
@@ -918,8 +928,9 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     }
 
     MF_HIP(hipMemsetAsync(&scal[6], 0, 16, st));          // [6] records without padding, [7] distinct k-mers before the cut
-    const unsigned long long cap_l1 = cap;
+    const unsigned long long cap_l1 = cap, cap_last = final_cap(cap);
     int used = 0;
+    mf_buf<skm_rec> spare;                                // the buffer a level has read from: the next level writes into it
     for (size_t li = 1; li < lv.size(); li++) {
         const int bits = lv[li], nd = 1 << bits;
         const uint64_t cap2 = cap + (uint64_t)np * SKM_LINE * nd;
@@ -927,7 +938,11 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         if (np2 > 0xFFFFFFF0ull) return mf_set_error("too many partitions");
         const bool last = li + 1 == lv.size();
         mf_buf<skm_rec> bufB;
-        if (bufB.alloc(ctx, cap2) != MF_OK) return MF_SKM_FALLBACK;
+        if (spare.p && spare.n >= cap2) { std::swap(bufB.p, spare.p); std::swap(bufB.n, spare.n); std::swap(bufB.ctx, spare.ctx); }
+        else if (bufB.alloc(ctx, std::max<unsigned long long>(cap2, cap_last)) != MF_OK) {
+            if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: no room for %.1f GB of level-%zu records (arena %.1f GB): %s\n", cap2 * 16 / 1e9, li + 1, ctx->arena_bytes / 1e9, mf_last_error());
+            return MF_SKM_FALLBACK;
+        }
         mf_buf<uint64_t> ostart; MF_TRY(ostart.alloc(ctx, np2));
         mf_buf<uint32_t> olen; MF_TRY(olen.alloc(ctx, np2));
         mf_buf<uint32_t> oocc; if (last) MF_TRY(oocc.alloc(ctx, np2));
@@ -940,13 +955,15 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
                                                  li == 1 ? &scal[6] : nullptr);
         }
         MF_DBG(ctx, "k_skm_split");
-        std::swap(bufA.p, bufB.p); std::swap(bufA.n, bufB.n);
+        std::swap(bufA.p, bufB.p); std::swap(bufA.n, bufB.n); std::swap(bufA.ctx, bufB.ctx);
+        if (!last) { spare.reset(); std::swap(spare.p, bufB.p); std::swap(spare.n, bufB.n); std::swap(spare.ctx, bufB.ctx); }
         std::swap(pstart.p, ostart.p); std::swap(pstart.n, ostart.n);
         std::swap(plen.p, olen.p); std::swap(plen.n, olen.n);
         if (last) { std::swap(pocc.p, oocc.p); std::swap(pocc.n, oocc.n); }
         cap = cap2; np = (uint32_t)np2; used += bits;
     }
 
+    spare.reset();
     // ---- count + gather, a batch of partitions at a time.  A partition's (key,count) slice is sized by its k-mer count
     // (it cannot hold more distinct k-mers than it has k-mers, nor more than the LDS table), i.e. all slices together
     // are as large as the k-mer stream itself: the buffer holds ONE batch of slices and is redused, the dense table grows

@@ -220,6 +220,24 @@ def test_skm_lookup_filter_two_levels(gpu_ctx, oracle):
         _reset(gpu_ctx)
 
 
+def test_skm_three_levels(gpu_ctx, oracle):
+    """a plan with three radix levels (what 200 M reads at k = 21 need): the third level writes into the buffer the first
+    level's records came from; one-pass and exact level 1"""
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(78)
+    b, o = genome_reads(rng, 500_000, 160_000, 150, err=0.004)
+    try:
+        gpu_ctx.set_option("part_target", 1)               # 1.9e7 occurrences -> 25 bits = 11 + 11 + 3
+        for dyn in (2, 0):
+            gpu_ctx.set_option("skm_dyn", dyn)
+            t = _check(gpu_ctx, oracle, b, o, 31)
+            assert t.records()[1] == 16
+            t2 = _check(gpu_ctx, oracle, b, o, 21)             # again on the same context: the arena's idle buffers are re-used
+            assert t2.records()[1] == 16
+    finally:
+        _reset(gpu_ctx)
+
+
 def test_skm_one_pass_level1(gpu_ctx, oracle):
     """level 1 in one pass (regions from a sampled histogram, chunk-wise allocation), also when the sample misleads:
     reads sorted by genome make every third tile unrepresentative, the overflow must be detected and repaired"""
