@@ -115,6 +115,11 @@ int mf_table_lookup(mf_table *t, const uint64_t *keys, uint64_t n, int32_t *valu
  * histogram of ALL counts to stat_txt (may be NULL). */
 int mf_table_write_kmers(const mf_table *t, int threshold, const char *kmers_bin,
                          const char *stat_txt, uint64_t *n_good);
+/* replaces IOUtils.filterAndPrintKmers (src/io/IOUtils.java:101-123; KmersFilter.java:107): the
+ * records of `t` with count > threshold whose k-mer has a value > filter_threshold in `filter`
+ * (absent = 0), same record format and order as mf_table_write_kmers. */
+int mf_table_write_kmers_filtered(const mf_table *t, int threshold, mf_table *filter, int filter_threshold,
+                                  const char *kmers_bin, uint64_t *n_good);
 /* replaces IOUtils.loadKmers (src/io/IOUtils.java:369-401; SeqBuilderMain.java:80): keeps records
  * with freq > freq_threshold; duplicate k-mers across files are summed with saturation. */
 int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nfiles, int freq_threshold, int k,

@@ -128,6 +128,7 @@ static const OptDef OPTS[] = {
     {"without-renumbering", "wr", false, true}, {"colors-file", "col", false, false}, {"invert-colors", "", false, true},
     {"kmers-file", "kf", false, false}, {"output-file", "o", false, false}, {"split", "", false, true}, {"long", "", false, true},
     {"use-reads-for-calculating-features", "", false, true}, {"device", "", false, false},
+    {"positiveReads", "pos", true, false}, {"negativeReads", "neg", true, false}, {"filter-kmers", "", true, false}, {"max-thresh", "", false, false},
 };
 // `ctx_i` says what -i means for the selected tool
 static Args parse_args(int argc, char **argv, string *tool_out) {
@@ -138,11 +139,11 @@ static Args parse_args(int argc, char **argv, string *tool_out) {
     auto long_of_short = [&](const string &s) -> string {
         if (s == "i") {
             if (tool == "heatmap-maker") return "matrix-file";                 // HeatMapMakerMain.java:34-36
-            if (tool == "seq-builder" || tool == "seq-builder-many") return "k-mers";
+            if (tool == "seq-builder" || tool == "seq-builder-many" || tool == "kmers-filter") return "k-mers";
             if (tool == "component-cutter") return "sequences";
             return "reads";
         }
-        if (s == "b") return (tool == "kmer-counter" || tool == "kmer-counter-many") ? "maximal-bad-frequence" : "maximal-bad-frequency";
+        if (s == "b") return (tool == "kmer-counter" || tool == "kmer-counter-many" || tool == "kmers-filter") ? "maximal-bad-frequence" : "maximal-bad-frequency";
         if (s == "l") return (tool == "seq-builder" || tool == "seq-builder-many") ? "sequence-len" : "min-seq-len";
         if (s == "o") return (tool == "view" || tool == "bin2fasta") ? "output-file" : "output-dir";
         if (s == "cf") return "components-file";                           // ViewMain.java:45, BinaryToFasta.java:47
@@ -651,6 +652,8 @@ static const char *TOOLS_TEXT =
     "features-calculator\tCalculate features values for input reads/k-mers files\n"
     "dist-matrix-calculator\tCalculate the distance matrix using features values\n"
     "heatmap-maker\t\tCluster the samples of a distance matrix and renumber it (no image)\n"
+    "kmer-counter-posneg\tCount k-mers for files from two groups independently\n"
+    "kmers-filter\t\tFilter k-mers from test set according to known samples\n"
     "view\t\t\tView different binary objects (k-mers files, components)\n"
     "bin2fasta\t\tConverts different binary objects to FASTA format\n"
     "matrix-builder\t\tBuild the distance matrix for input sequences (default tool)\n";
@@ -693,6 +696,13 @@ static vector<PV> tool_inputs(const string &tool, const Args &a, const string &w
              PV("min-component-size", a.get("min-component-size", "1000")), PV("max-component-size", a.get("max-component-size", "10000")),
              a.has("selected") ? PV::files("selected", a.list("selected")) : PV::null("selected"), flag("without-names"),
              PV("output-format", a.get("output-format", "%.4f")), opt_f("colors-file"), flag("without-renumbering"), flag("invert-colors")};
+    } else if (tool == "kmer-counter-posneg") {
+        v = {opt_i("k"), PV::files("positiveReads", a.list("positiveReads")), PV::files("negativeReads", a.list("negativeReads")),
+             PV("maximal-bad-frequency", a.get("maximal-bad-frequency", "1")), PV::file("output-dir", a.get("output-dir", wd + "/kmers_posneg"))};
+    } else if (tool == "kmers-filter") {
+        v = {opt_i("k"), PV::files("k-mers", a.list("k-mers")), PV::files("filter-kmers", a.list("filter-kmers")),
+             PV("maximal-bad-frequence", a.get("maximal-bad-frequence", "1")), PV("max-thresh", a.get("max-thresh", "0")),
+             PV::file("output-dir", a.get("output-dir", wd + "/kmers")), PV::file("stats-dir", a.get("stats-dir", wd + "/stats"))};
     } else if (tool == "view" || tool == "bin2fasta") {
         v = {opt_i("k"), opt_f("kmers-file"), opt_f("components-file"), opt_f("output-file")};
     }
@@ -710,7 +720,7 @@ int main(int argc, char **argv) {
         return 0;
     }
     static const char *KNOWN[] = {"kmer-counter", "kmer-counter-many", "seq-builder", "seq-builder-many", "component-cutter", "features-calculator",
-                                  "dist-matrix-calculator", "heatmap-maker", "view", "bin2fasta", "matrix-builder"};
+                                  "dist-matrix-calculator", "heatmap-maker", "view", "bin2fasta", "matrix-builder", "kmer-counter-posneg", "kmers-filter"};
     if (std::find_if(std::begin(KNOWN), std::end(KNOWN), [&](const char *n) { return tool == n; }) == std::end(KNOWN)) {
         fprintf(stderr, "ERROR: Tool '%s' not found !\n", tool.c_str());          // itmo!/Runner.java:136-139
         return 1;
@@ -778,6 +788,8 @@ int main(int argc, char **argv) {
     else if (tool == "dist-matrix-calculator") { if (!a.has("features")) die("Mandatory argument --features not set"); }
     else if (tool == "heatmap-maker") need("matrix-file", "i");
     else if (tool == "matrix-builder") need("reads", "i");
+    else if (tool == "kmer-counter-posneg") { need("k", "k"); need("positiveReads", "pos"); need("negativeReads", "neg"); }
+    else if (tool == "kmers-filter") { need("k", "k"); need("k-mers", "i"); if (!a.has("filter-kmers")) die("Mandatory argument --filter-kmers not set"); }
     props_write(inprop, tool_inputs(tool, a, wd, e.start_ts));
 
     if (tool == "kmer-counter") {
@@ -805,6 +817,57 @@ int main(int argc, char **argv) {
                 PV::file("features-dir", wd + "/vectors")};
     } else if (tool == "dist-matrix-calculator") {
         run_dist_matrix(e, a, a.list("features"), a.get("matrix-file", wd + "/dist_matrix_$DT_original_order.txt"));
+    } else if (tool == "kmer-counter-posneg") {
+        // KmersCounterPositiveNegative.java:66-108: two kmer-counter-many steps with the work directories <workDir>/pos and /neg
+        vector<string> pos = a.list("positiveReads"), neg = a.list("negativeReads");
+        logmsg("INFO", "Found %zu samples in positive class and %zu samples in negative class to process", pos.size(), neg.size());
+        if (pos.empty() || neg.empty()) die("No libraries to process!!! Can't continue the calculations.");
+        check_k(k);
+        const int b = a.geti("maximal-bad-frequency", 1);
+        vector<string> kp, kn;
+        for (int side = 0; side < 2; side++) {
+            const string d = wd + (side ? "/neg" : "/pos");
+            const vector<string> &files = side ? neg : pos;
+            vector<string> &res = side ? kn : kp;
+            run_as_step("kmer-counter-many", d, {PV("k", k), PV::files("reads", files), PV("maximal-bad-frequence", b), PV::file("output-dir", d + "/kmers"),
+                                                 PV::file("stats-dir", d + "/stats")},
+                        start, force,
+                        [&]() { Args sub = a; sub.opt["output-dir"] = {d + "/kmers"}; sub.opt["stats-dir"] = {d + "/stats"};
+                                res = run_kmer_counter_many(e, sub, files, k, b, d); return vector<PV>{PV::files("resulting-kmers-files", res)}; },
+                        [&](const Props &o) { res = props_list(o, "resulting-kmers-files"); });
+        }
+        outs = {PV::files("resulting-pos-kmers-files", kp), PV::files("resulting-neg-kmers-files", kn)};
+    } else if (tool == "kmers-filter") {
+        // KmersFilter.java:80-121: every input k-mers file is written again with the records whose k-mer is frequent enough
+        // in the filter files (IOUtils.filterAndPrintKmers, src/io/IOUtils.java:101-123)
+        check_k(k);
+        const int b = a.geti("maximal-bad-frequence", 1), mt = a.geti("max-thresh", 0);
+        const string out_dir = a.get("output-dir", wd + "/kmers");
+        mkdirs(out_dir);
+        mf_ctx *ctx = ctx_of(e, a);
+        const vector<string> ff = a.list("filter-kmers");
+        auto fp = cptrs(ff);
+        mf_table *filter = nullptr;
+        check(mf_table_load_kmers(ctx, fp.data(), (int)fp.size(), b, k, &filter));
+        vector<string> written;
+        for (auto &f : a.list("k-mers")) {
+            mf_table *t = nullptr;
+            const char *one[1] = {f.c_str()};
+            check(mf_table_load_kmers(ctx, one, 1, b, k, &t));
+            string name = basename_of(f);
+            for (size_t q; (q = name.find(".kmers.bin")) != string::npos;) name.erase(q, 10);        // replaceAll(".kmers.bin", "")
+            const string out = out_dir + "/" + name + ".kmers.bin";
+            uint64_t c = 0, size = 0;
+            check(mf_table_write_kmers_filtered(t, b, filter, mt * (int)ff.size(), out.c_str(), &c));
+            check(mf_table_stats(t, &size, nullptr));
+            logmsg("INFO", "%s k-mers found, %s (%.1f%%) of them survived after filtering", group_digits(size).c_str(), group_digits(c).c_str(),
+                   size ? c * 100.0 / size : 0.0);
+            logmsg("INFO", "Filtered k-mers printed to %s", out.c_str());
+            mf_table_destroy(t);
+            written.push_back(out);
+        }
+        mf_table_destroy(filter);
+        outs = {written.empty() ? PV::null("resulting-kmers-file") : PV::file("resulting-kmers-file", written.back())};
     } else if (tool == "view") {
         run_view(a, k);
     } else if (tool == "bin2fasta") {

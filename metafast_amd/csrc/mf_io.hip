@@ -676,14 +676,10 @@ __global__ void k_counts_minus_one(uint16_t *__restrict__ c, uint64_t n) {
     if (i < n) c[i] = (uint16_t)(c[i] - 1);
 }
 int mf_table_select_sorted(const mf_table *t, int threshold, mf_buf<uint64_t> &sk, mf_buf<uint16_t> &sc, uint64_t *n);
-extern "C" int mf_table_write_kmers(const mf_table *t, int threshold, const char *kmers_bin, const char *stat_txt, uint64_t *n_good) {
-    if (!t || !kmers_bin) return mf_set_error("mf_table_write_kmers: NULL argument");
-    mf_ctx *ctx = t->ctx;
-    uint64_t n = 0;
-    mf_buf<uint64_t> sk; mf_buf<uint16_t> sc;
-    MF_TRY(mf_table_select_sorted(t, threshold, sk, sc, &n));
-    FILE *f = fopen(kmers_bin, "wb");
-    if (!f) return mf_set_error("can't write '%s'", kmers_bin);
+// n sorted (k-mer, count) pairs in HBM -> 10-byte big-endian records in `path`
+static int write_records_file(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_cnts, uint64_t n, const char *path) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return mf_set_error("can't write '%s'", path);
     if (n) {
         // records are encoded in HBM and come down in slabs of 2^22 records (40 MB)
         const uint64_t SLAB = 1ull << 22;
@@ -692,13 +688,36 @@ extern "C" int mf_table_write_kmers(const mf_table *t, int threshold, const char
         std::vector<uint8_t> host(std::min(n, SLAB) * 10 + 4);
         for (uint64_t i = 0; i < n; i += SLAB) {
             const uint64_t m = std::min(SLAB, n - i);
-            k_records_encode<<<(unsigned)((m + REC_PER_BLOCK - 1) / REC_PER_BLOCK), REC_PER_BLOCK, 0, ctx->stream>>>(sk.p + i, sc.p + i, m, enc.p);
+            k_records_encode<<<(unsigned)((m + REC_PER_BLOCK - 1) / REC_PER_BLOCK), REC_PER_BLOCK, 0, ctx->stream>>>(d_keys + i, d_cnts + i, m, enc.p);
             if (hipMemcpyAsync(host.data(), enc.p, m * 10, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
                 hipStreamSynchronize(ctx->stream) != hipSuccess) { fclose(f); return mf_set_error("write_kmers: device copy failed"); }
-            if (fwrite(host.data(), 10, m, f) != m) { fclose(f); return mf_set_error("can't write '%s'", kmers_bin); }
+            if (fwrite(host.data(), 10, m, f) != m) { fclose(f); return mf_set_error("can't write '%s'", path); }
         }
     }
     fclose(f);
+    return MF_OK;
+}
+int mf_table_select_filtered_sorted(const mf_table *t, int threshold, mf_table *filter, int filter_threshold, mf_buf<uint64_t> &sk, mf_buf<uint16_t> &sc,
+                                    uint64_t *n);
+extern "C" int mf_table_write_kmers_filtered(const mf_table *t, int threshold, mf_table *filter, int filter_threshold, const char *kmers_bin,
+                                             uint64_t *n_good) {
+    if (!t || !filter || !kmers_bin) return mf_set_error("mf_table_write_kmers_filtered: NULL argument");
+    if (t->k != filter->k) return mf_set_error("mf_table_write_kmers_filtered: tables with different k (%d, %d)", t->k, filter->k);
+    uint64_t n = 0;
+    mf_buf<uint64_t> sk; mf_buf<uint16_t> sc;
+    MF_TRY(mf_table_select_filtered_sorted(t, threshold, filter, filter_threshold, sk, sc, &n));
+    MF_TRY(write_records_file(t->ctx, sk.p, sc.p, n, kmers_bin));
+    if (n_good) *n_good = n;
+    return MF_OK;
+}
+extern "C" int mf_table_write_kmers(const mf_table *t, int threshold, const char *kmers_bin, const char *stat_txt, uint64_t *n_good) {
+    if (!t || !kmers_bin) return mf_set_error("mf_table_write_kmers: NULL argument");
+    mf_ctx *ctx = t->ctx;
+    uint64_t n = 0;
+    mf_buf<uint64_t> sk; mf_buf<uint16_t> sc;
+    MF_TRY(mf_table_select_sorted(t, threshold, sk, sc, &n));
+    MF_TRY(write_records_file(ctx, sk.p, sc.p, n, kmers_bin));
+    FILE *f = nullptr;
     if (stat_txt) {
         std::vector<uint64_t> hist;
         MF_TRY(mf_table_count_hist(t, hist));

@@ -537,6 +537,36 @@ int mf_table_select_sorted(const mf_table *t, int threshold, mf_buf<uint64_t> &s
     MF_TRY(sk.alloc(ctx, m)); MF_TRY(sc.alloc(ctx, m));
     return mf_sort_pairs(ctx, ok.p, oc.p, m, 2 * t->k, sk.p, sc.p);
 }
+// counts of the entries that pass (count > thr and value in the filter's index > fthr, absent = 0), 0 for the others
+__global__ void k_mask_by_filter(mf_index_view fx, const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnts, uint64_t n, int thr, int fthr,
+                                 uint16_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t idx, val = 0;
+    const int c = cnts[i];
+    int fv = 0;
+    if (c > thr && fx.slots && mf_index_find(fx, keys[i], &idx, &val)) fv = (int)val;
+    out[i] = (c > thr && fv > fthr) ? (uint16_t)c : (uint16_t)0;
+}
+// IOUtils.filterAndPrintKmers (src/io/IOUtils.java:101-123): selection + ascending order, in HBM
+int mf_table_select_filtered_sorted(const mf_table *t, int threshold, mf_table *filter, int filter_threshold, mf_buf<uint64_t> &sk, mf_buf<uint16_t> &sc,
+                                    uint64_t *n) {
+    mf_ctx *ctx = t->ctx;
+    MF_HIP(hipSetDevice(ctx->device));
+    *n = 0;
+    MF_TRY(sk.alloc(ctx, 0)); MF_TRY(sc.alloc(ctx, 0));
+    if (!t->n) return MF_OK;
+    if (filter->n) MF_TRY(mf_table_ensure_index(filter));
+    mf_buf<uint16_t> masked; MF_TRY(masked.alloc(ctx, t->n));
+    mf_index_view fx = mf_view(filter->index);
+    if (!filter->n) fx.slots = nullptr;
+    k_mask_by_filter<<<(unsigned)((t->n + 255) / 256), 256, 0, ctx->stream>>>(fx, t->d_keys, t->d_counts, t->n, threshold, filter_threshold, masked.p);
+    mf_buf<uint64_t> ok; mf_buf<uint16_t> oc; uint64_t m = 0;
+    MF_TRY(select_entries<0>(ctx, t->d_keys, masked.p, nullptr, t->n, 0, ok, oc, &m));
+    *n = m;
+    MF_TRY(sk.alloc(ctx, m)); MF_TRY(sc.alloc(ctx, m));
+    return mf_sort_pairs(ctx, ok.p, oc.p, m, 2 * t->k, sk.p, sc.p);
+}
 extern "C" int mf_table_export(const mf_table *t, int threshold, uint64_t *keys, uint16_t *counts, uint64_t cap, uint64_t *n) {
     if (!t || !n) return mf_set_error("NULL argument");
     mf_ctx *ctx = t->ctx;

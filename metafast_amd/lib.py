@@ -42,6 +42,7 @@ _SIGS = {
     "mf_table_device_view": (i32, [vp, pvp, pvp, pu64]),
     "mf_table_lookup": (i32, [vp, vp, u64, vp]),
     "mf_table_write_kmers": (i32, [vp, i32, cp, cp, pu64]),
+    "mf_table_write_kmers_filtered": (i32, [vp, i32, vp, i32, cp, pu64]),
     "mf_table_load_kmers": (i32, [vp, C.POINTER(cp), i32, i32, i32, pvp]),
     "mf_table_filter": (i32, [vp, i32, pvp]),
     "mf_table_from_host": (i32, [vp, vp, vp, u64, i32, pvp]),
@@ -308,6 +309,12 @@ class Table:
         """IOUtils.printKmers (src/io/IOUtils.java:45-71)"""
         g = C.c_uint64()
         _check(lib().mf_table_write_kmers(self.h, threshold, os.fsencode(kmers_bin), _opt(stat_txt), C.byref(g)))
+        return g.value
+
+    def write_kmers_filtered(self, threshold, filter_table, filter_threshold, kmers_bin):
+        """IOUtils.filterAndPrintKmers (src/io/IOUtils.java:101-123)"""
+        g = C.c_uint64()
+        _check(lib().mf_table_write_kmers_filtered(self.h, threshold, filter_table.h, filter_threshold, os.fsencode(kmers_bin), C.byref(g)))
         return g.value
 
     def filter(self, threshold):

@@ -307,6 +307,42 @@ def test_cli_errors_and_single_tools(ref_files, tmp_path):
     assert sorted(os.listdir(wd / "stats")) == ["lib.stat.txt", "meta_test_1.stat.txt"]
 
 
+def test_cli_posneg_and_kmers_filter(gpu_ctx, oracle, ref_files, tmp_path):
+    """kmer-counter-posneg (KmersCounterPositiveNegative.java:66-108): two kmer-counter-many steps under pos/ and neg/;
+    kmers-filter (KmersFilter.java:80-121, IOUtils.filterAndPrintKmers src/io/IOUtils.java:101-123): the records of a
+    k-mers file whose k-mer is frequent enough in the filter files (their counts summed with saturation)"""
+    exe = os.path.join(ROOT, "metafast.sh")
+    wd = tmp_path / "pn"
+    r = subprocess.run([exe, "-t", "kmer-counter-posneg", "-k", "31", "-pos", ref_files[0], "-neg", ref_files[1], ref_files[2], "-w", str(wd)],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert sorted(os.listdir(wd / "pos" / "kmers")) == ["meta_test_1.kmers.bin"]
+    assert sorted(os.listdir(wd / "neg" / "kmers")) == ["meta_test_2.kmers.bin", "meta_test_3.kmers.bin"]
+    assert (wd / "pos" / "SUCCESS").exists() and (wd / "neg" / "in.properties").exists()
+    outp = (wd / "out.properties").read_text().splitlines()
+    assert outp[0] == "resulting-pos-kmers-files = %s" % (wd / "pos" / "kmers" / "meta_test_1.kmers.bin") and len(outp) == 3
+    tabs = [oracle.Table().count_files([f], 31).export(1) for f in ref_files]       # (keys ascending, counts) with count > 1
+    for i, sub in enumerate(("pos/kmers/meta_test_1", "neg/kmers/meta_test_2", "neg/kmers/meta_test_3")):
+        raw = (wd / (sub + ".kmers.bin")).read_bytes()
+        assert len(raw) == 10 * len(tabs[i][0])
+    for mt in (0, 1):
+        w2 = tmp_path / ("kf%d" % mt)
+        r = subprocess.run([exe, "-t", "kmers-filter", "-k", "31", "-i", str(wd / "pos/kmers/meta_test_1.kmers.bin"), "--filter-kmers",
+                            str(wd / "neg/kmers/meta_test_2.kmers.bin"), str(wd / "neg/kmers/meta_test_3.kmers.bin"), "--max-thresh", str(mt),
+                            "-w", str(w2)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        k1, c1 = tabs[0]
+        filt = {}
+        for kk, cc in (tabs[1], tabs[2]):
+            for a, b in zip(kk.tolist(), cc.tolist()):
+                filt[a] = min(32767, filt.get(a, 0) + b)
+        keep = [(a, b) for a, b in zip(k1.tolist(), c1.tolist()) if filt.get(a, 0) > mt * 2]
+        want = b"".join(int(a).to_bytes(8, "big") + int(b).to_bytes(2, "big") for a, b in keep)
+        got = (w2 / "kmers" / "meta_test_1.kmers.bin").read_bytes()
+        assert len(keep) > 0 and got == want
+        assert "of them survived after filtering" in r.stderr
+
+
 def test_parallel_host_parser_large_files(gpu_ctx, oracle, tmp_path):
     """files big enough to be cut into many pieces (one per host thread): multi-line FASTA with comment lines and N reads,
     FASTQ with quality lines that start with '@' and '+'; counts must equal the oracle's serial reader"""
