@@ -15,6 +15,8 @@ public final class HipBackend {
     public static native long tableSize(long table);
     /** IOUtils.printKmers (src/io/IOUtils.java:45): returns the number of good k-mers written */
     public static native long writeKmers(long table, int threshold, String kmersBin, String statTxt);
+    /** IOUtils.filterAndPrintKmers (src/io/IOUtils.java:101): returns the number of records written */
+    public static native long writeKmersFiltered(long table, int threshold, long filterTable, int filterThreshold, String kmersBin);
     /** IOUtils.loadKmers (src/io/IOUtils.java:369) */
     public static native long loadKmers(long ctx, String[] files, int freqThreshold, int k);
     /** SequencesFinders.thresholdStrategy + Sequence.printSequences (SeqBuilderMain.java:147,160): returns the number of sequences */

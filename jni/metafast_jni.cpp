@@ -60,6 +60,13 @@ JNIEXPORT jlong JNICALL Java_io_HipBackend_writeKmers(JNIEnv *e, jclass, jlong t
     if (mf_table_write_kmers((mf_table *)(intptr_t)table, threshold, b.p, s.p, &good) < 0) { raise(e); return 0; }
     return (jlong)good;
 }
+JNIEXPORT jlong JNICALL Java_io_HipBackend_writeKmersFiltered(JNIEnv *e, jclass, jlong table, jint threshold, jlong filterTable, jint filterThreshold,
+                                                              jstring kmersBin) {
+    utf b(e, kmersBin);
+    uint64_t good = 0;
+    if (mf_table_write_kmers_filtered((mf_table *)(intptr_t)table, threshold, (mf_table *)(intptr_t)filterTable, filterThreshold, b.p, &good) < 0) { raise(e); return 0; }
+    return (jlong)good;
+}
 JNIEXPORT jlong JNICALL Java_io_HipBackend_loadKmers(JNIEnv *e, jclass, jlong ctx, jobjectArray files, jint freqThreshold, jint k) {
     utf_array f(e, files);
     mf_table *t = nullptr;
