@@ -65,8 +65,9 @@ __global__ __launch_bounds__(256) void k_cc_hook_tile(const uint32_t *__restrict
     const uint64_t base = (uint64_t)blockIdx.x * CC_TILE;
     for (uint32_t i = threadIdx.x; i < CC_TILE; i += blockDim.x) {
         lp[i] = i;
-        la[i] = base + i < n ? alive[base + i] : 0;
-        if (base + i < n) { csize[base + i] = 0; cweight[base + i] = 0; }
+        const uint8_t al = base + i < n ? alive[base + i] : 0;
+        la[i] = al;
+        if (al) { csize[base + i] = 0; cweight[base + i] = 0; }          // (dead vertices are never read again: later levels skip 16 B each)
     }
     __syncthreads();
     auto find_l = [&](uint32_t x) -> uint32_t {
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void k_cc_hook_tile(const uint32_t *__restrict
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < CC_TILE; i += blockDim.x) {
         if (base + i >= n) break;
+        if (!la[i]) continue;
         uint32_t r = i;
         for (;;) { const uint32_t p = lp[r]; if (p == r) break; r = p; }
         parent[base + i] = (uint32_t)base + r;
