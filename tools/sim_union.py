@@ -10,6 +10,7 @@ n_reads = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
 rl, k = 150, 31
 ctx = L.Context(0, stream=torch.cuda.current_stream())
 ctx.set_option("profile", 1)
+if os.environ.get("MF_VERBOSE"): ctx.set_option("verbose", int(os.environ["MF_VERBOSE"]))
 bases = torch.zeros(n_reads * rl + 64, dtype=torch.uint8, device="cuda")
 offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
 parts_b, parts_o = [], []
