@@ -22,7 +22,7 @@ for a, b in zip(b"ACGT", b"TGCA"):
 
 
 def make_reads():
-    glen = int(rng.integers(200, 60000))
+    glen = int(rng.integers(200, 60000 * int(os.environ.get("MF_FUZZ_SCALE", "1"))))
     g = AL[rng.integers(0, 4, size=glen)]
     for _ in range(int(rng.integers(0, 4))):                      # repeats: copies of a stretch elsewhere (branches)
         L0 = int(rng.integers(20, min(400, glen // 2)))
@@ -30,7 +30,7 @@ def make_reads():
         g[d:d + L0] = g[s:s + L0]
     if rng.random() < 0.3:                                        # low-complexity stretch
         L0 = int(rng.integers(10, 80)); d = int(rng.integers(0, glen - L0)); g[d:d + L0] = AL[rng.integers(0, 4)]
-    n = int(rng.integers(1, 4000))
+    n = int(rng.integers(1, 4000 * int(os.environ.get("MF_FUZZ_SCALE", "1"))))
     lo = int(rng.integers(1, 120)); hi = lo + int(rng.integers(0, 200))
     lens = np.minimum(rng.integers(lo, hi + 1, size=n), glen)
     err = float(rng.choice([0.0, 0.002, 0.01, 0.05]))
