@@ -98,6 +98,12 @@ int mf_table_occurrences(const mf_table *t, uint64_t *n_occ);
  * (padding included) on the default path for k >= 20, else one 8-byte record per k-mer occurrence; 0 for tables that
  * were loaded or filtered.  Measurement only (bench.py prices the kernels' algorithmic bytes with it). */
 int mf_table_records(const mf_table *t, uint64_t *n_records, int *record_bytes);
+/* QuickQuantitativeStatistics of IOUtils.printKmers (src/io/IOUtils.java:45-71; itmo!/statistics/
+ * QuickQuantitativeStatistics.java:38-72): hist[c] = number of distinct k-mers with count c over ALL k-mers that were
+ * counted, c = 0 .. MF_MAX_COUNT (hist must hold MF_MAX_COUNT + 1 entries).  A table that comes out of
+ * mf_count_device_above / mf_table_filter has remembered the k-mers the cut dropped, so this is what the .stat.txt of
+ * the uncut table would hold. */
+int mf_table_hist(const mf_table *t, uint64_t *hist);
 /* Copies entries with count > threshold to host arrays in ASCENDING KEY order (the reference's
  * iteration order is thread-count dependent, BigLong2ShortHashMap.java:216-253, so callers must
  * not rely on it).  Call with cap=0 to get *n only. */

@@ -65,6 +65,7 @@ struct mf_ctx {
     int64_t opt_sr_piece = 8 << 20, opt_sr_slack = 1 << 20;
     void *pin_pool = nullptr; size_t pin_pool_bytes = 0;           // pinned staging chunks of the streaming reader (lazy, kept)
     int64_t opt_skm_batches = 0;   // partitions are counted + gathered in this many batches (0 = auto); tests force small values
+    int64_t opt_count2 = 1;        // second-generation super-k-mer count kernel (k_skm_count2); 0 = the first one
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero
     // workspace arena: a few large hipMalloc'd regions, sub-allocated with first-fit + coalescing free lists.
     // Everything runs on one stream, so a block can be handed out again as soon as it is released.
@@ -133,6 +134,7 @@ struct mf_table {
     uint64_t n_occ = 0;           // occurrences fed in
     uint64_t n_records = 0; int record_bytes = 0;   // records the counting pass partitioned (mf_table_records)
     int cut_thr = -1;             // every entry has count > cut_thr (tables that went through a cut: no need to test again)
+    std::vector<uint64_t> dropped_hist;   // cut inside the counting pass: [c] = distinct k-mers with count c <= cut_thr (not in the table)
     uint64_t *d_keys = nullptr;   // [n]
     uint16_t *d_counts = nullptr; // [n]
     size_t keys_bytes = 0, counts_bytes = 0;
@@ -173,6 +175,7 @@ struct mf_comps {
 int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, mf_index *out,
                    size_t *bytes);
 int mf_table_ensure_index(mf_table *t);
+int mf_table_count_hist(const mf_table *t, std::vector<uint64_t> &hist);   // all counts, dropped k-mers included
 // entries with count > threshold; when every entry passes, a non-owning alias of `t` (no copy) -- internal use only
 int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out);
 #define MF_SKM_FALLBACK 1          /* mf_count_skm: input does not suit the super-k-mer path, nothing was produced */

@@ -81,7 +81,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     std::string s(name);
     if (s == "l1_bits") { if (v > MF_MAX_DIGIT_BITS) return mf_set_error("l1_bits > %d", MF_MAX_DIGIT_BITS); ctx->opt_l1_bits = v; }
     else if (s == "l2_bits") { if (v > MF_MAX_DIGIT_BITS) return mf_set_error("l2_bits > %d", MF_MAX_DIGIT_BITS); ctx->opt_l2_bits = v; }
-    else if (s == "part_target") { if (v < 1 || v > 4096) return mf_set_error("part_target out of [1,4096]"); ctx->opt_part_target = v; }
+    else if (s == "part_target") { if (v < 1 || v > 16384) return mf_set_error("part_target out of [1,16384]"); ctx->opt_part_target = v; }
     else if (s == "scatter_staged") ctx->opt_scatter_staged = v;
     else if (s == "profile") ctx->opt_profile = v;
     else if (s == "l1_blocks") ctx->opt_l1_blocks = v;
@@ -93,6 +93,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "stream_piece_bytes") ctx->opt_sr_piece = v;
     else if (s == "stream_slack_bytes") ctx->opt_sr_slack = v;
     else if (s == "skm_dyn") ctx->opt_skm_dyn = v;
+    else if (s == "count2") ctx->opt_count2 = v;
     else return mf_set_error("unknown option '%s'", name);
     return MF_OK;
 }

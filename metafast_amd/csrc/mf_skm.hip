@@ -639,8 +639,10 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                                                       uint16_t *__restrict__ tcnt, uint32_t *__restrict__ dcount,
                                                       unsigned int *__restrict__ overflow, int ablate, uint32_t p0, uint64_t tbase,
                                                       int thr, unsigned long long *__restrict__ n_all,
-                                                      uint32_t *__restrict__ redo, unsigned int *__restrict__ n_redo) {
-    // thr >= 0: only the k-mers with count > thr are written; *n_all += distinct k-mers of the partitions (all of them)
+                                                      uint32_t *__restrict__ redo, unsigned int *__restrict__ n_redo,
+                                                      unsigned long long *__restrict__ drop_hist) {
+    // thr >= 0: only the k-mers with count > thr are written (the others are tallied in drop_hist[count], if given);
+    // *n_all += distinct k-mers of the partitions (all of them)
     // partitions [p0, np); tkeys / tcnt hold the slices of this batch only: slice of p starts at toff[p] - tbase
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t out_cursor, all_cursor;
@@ -659,6 +661,7 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
     __shared__ uint32_t blk_claims;
     uint32_t &sweep_all = pflags[0], &part_over = pflags[1];
     uint32_t P = MULTI ? 4u : 1u, ncl_rep = 0;
+    uint32_t ones_acc = 0;                                                      // per wave: dropped entries with count 1
     const uint32_t tk0 = mf_lds_addr(tk), tc0 = mf_lds_addr(tc);
     const uint32_t dummy_k = tk0 + 8u * ((uint32_t)MF_COUNT_SLOTS + lane);
     const uint32_t dummy_c = tc0 + 4u * ((uint32_t)MF_COUNT_SLOTS + lane);
@@ -768,6 +771,10 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                 if (have) { sl = Q.cl[i0 + lane]; key = tk[sl]; cnt = tc[sl]; tk[sl] = MF_EMPTY; tc[sl] = 0; }
                 if (cnt > (uint32_t)MF_MAX_COUNT) cnt = (uint32_t)MF_MAX_COUNT;
                 const bool keep = have && (int)cnt > thr;           // (thr < 0 keeps everything)
+                if (drop_hist) {                                    // (count 1 is nearly all of them: one atomic per wave at the end)
+                    ones_acc += (uint32_t)__popcll(__ballot(have && !keep && cnt == 1u));
+                    if (have && !keep && cnt != 1u) atomicAdd(&drop_hist[cnt], 1ull);
+                }
                 const unsigned long long bal = __ballot(keep);
                 uint32_t wb = 0;
                 if (lane == 0 && bal) wb = atomicAdd(&out_cursor, (uint32_t)__popcll(bal));
@@ -786,7 +793,13 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                 ck[i] = tk[sl]; cv[i] = tc[sl];
                 tk[sl] = MF_EMPTY; tc[sl] = 0;
                 total_all += (uint32_t)__popcll(__ballot(ck[i] != MF_EMPTY));
-                if ((int)(cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]) <= thr) ck[i] = MF_EMPTY;     // (thr < 0 keeps everything)
+                if ((int)(cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]) <= thr) {     // (thr < 0 keeps everything)
+                    if (drop_hist) {
+                        ones_acc += (uint32_t)__popcll(__ballot(ck[i] != MF_EMPTY && cv[i] == 1u));
+                        if (ck[i] != MF_EMPTY && cv[i] != 1u) atomicAdd(&drop_hist[cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]], 1ull);
+                    }
+                    ck[i] = MF_EMPTY;
+                }
                 const unsigned long long bal = __ballot(ck[i] != MF_EMPTY);
                 pre[i] = total + (uint32_t)__popcll(bal & lt_mask);
                 total += (uint32_t)__popcll(bal);
@@ -815,6 +828,416 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
         p_n = p_nn; start_n = start_nn; len_n = len_nn; o_n = o_nn; room_n = room_nn;
     }
     if (threadIdx.x == 0 && n_all && all_acc) atomicAdd(n_all, all_acc);
+    if (drop_hist && lane == 0 && ones_acc) atomicAdd(&drop_hist[1], (unsigned long long)ones_acc);
+}
+
+// =============================================================================================
+// S4 (second generation): the same job as k_skm_count<K,false>, rebuilt from its counters (profiles/r01j_pmc_100M: 160 VALU
+// lane-operations per k-mer) and from ablations of the rebuild itself (profiles/r02_count_ablation.txt):
+//   * all arithmetic on 32-bit halves (v_alignbit funnel shifts, v_bfrev): the 64-bit variable shifts of the record
+//     expansion and of mf_revcomp are multi-instruction sequences on CDNA;
+//   * the probe IS the claim: one ds_cmpst_rtn_b64(slot, EMPTY, key) per key, four keys per lane.  It returns EMPTY (the
+//     slot is ours now), the key (a hit) or another key (a collision, 5 %: those go to the wave's queue and are finished 64
+//     at a time, one key per lane).  A separate read first (hits only, first sightings queued) looked cheaper on paper
+//     -- a CAS costs its LDS cycles whether 8 lanes or 64 need it -- but all eight waves meet a partition's k-mers at the
+//     same time: with the claims deferred, every copy of a new k-mer missed and went through the slow path (27 of 59 ms);
+//   * lanes without work are switched off with EXEC inside the asm blocks, not parked on dummy slots (no address selects);
+//   * the records are parked in LDS shifted right by ONE bit: the k-mer at base offset t then starts at the odd bit
+//     2t+1, so the funnel-shift amount 32 - ((2t+1) & 31) is never 32 and the extraction needs no special case;
+//   * the step is software-pipelined over LDS: the next step's item is fetched beside the probes and its record beside the
+//     count updates, so one LDS round trip per step is exposed instead of three.
+// Items carry everything the consumer lane needs (record slot, funnel-shift amount, word select, k-mers in the item) in
+// 16 bits.  Two workgroup barriers per partition (flags are double-buffered by partition parity).
+// The all-counts histogram of IOUtils.printKmers (src/io/IOUtils.java:45-71, the .stat.txt file) needs the entries the
+// cut drops: their counts (<= thr) are tallied here (count 1 by ballot, the others in a small LDS histogram).
+// =============================================================================================
+#define C2_QN 192                // queue entries per wave (keys): drained at 64, two pushes (<= 128 keys) between checks
+#define C2_CLN 160               // claimed-slot list entries per wave
+#define C2_LH 256                // bins of the workgroup's dropped-count histogram (cuts with thr >= C2_LH do not run in the kernel)
+#define C2_ITEMS 512             // item entries per wave: 64 records x 6 chunks + two steps of padding (one is read ahead)
+static constexpr size_t C2_LDS = (size_t)MF_COUNT_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8 + C2_CLN * 2) + C2_LH * 4 + 32;
+static_assert(C2_LDS <= 80 * 1024, "two workgroups per CU");
+
+__device__ __forceinline__ uint32_t c2_swap_pairs(uint32_t x) {                 // exchanges the two bits of every base
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+}
+__device__ __forceinline__ uint32_t c2_slot(uint32_t hi, uint32_t lo) {          // = skm_slot on halves
+    uint32_t f = (hi * 0x85EBCA6Bu) ^ lo;
+    f *= 0x9E3779B1u;
+    return (f >> 16) & (uint32_t)(MF_COUNT_SLOTS - 1);
+}
+struct c2_wave {                 // LDS byte addresses of this wave's private areas + the table
+    uint32_t tk0, tc0, rb0, items0, qk0, cl0;
+};
+// ---- lane masks straight from the compare (a C++ bool that meets __ballot costs a v_cndmask + v_cmp round trip per use)
+__device__ __forceinline__ unsigned long long c2_eq_u64(uint64_t a, uint64_t b) {
+    unsigned long long m;
+    asm("v_cmp_eq_u64_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ unsigned long long c2_lt_u32(uint32_t a, uint32_t b) {      // lanes with a < b
+    unsigned long long m;
+    asm("v_cmp_lt_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+template <int U> __device__ __forceinline__ unsigned long long c2_gt(uint32_t a) {       // lanes with a > U (U: inline constant)
+    unsigned long long m;
+    asm("v_cmp_lt_u32_e64 %0, %2, %1" : "=s"(m) : "v"(a), "n"(U));
+    return m;
+}
+// ---- LDS operations of the lanes of a mask (EXEC is switched inside the block and restored)
+__device__ __forceinline__ void c2_push64(unsigned long long m, uint32_t addr, uint64_t v) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(m), "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ void c2_push16(unsigned long long m, uint32_t addr, uint32_t v) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b16 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(m), "v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint64_t c2_cas_m(unsigned long long m, uint32_t addr, uint64_t key) {      // waited for
+    unsigned long long save; uint64_t ret;
+    asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %2\n\tds_cmpst_rtn_b64 %0, %3, %4, %5\n\ts_mov_b64 exec, %1\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(ret), "=&s"(save) : "s"(m), "v"(addr), "v"(MF_EMPTY), "v"(key) : "memory");
+    return ret;
+}
+__device__ __forceinline__ void c2_add_m(unsigned long long m, uint32_t addr, uint32_t one) {
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_add_u32 %2, %3\n\ts_mov_b64 exec, %0"
+                 : "=&s"(save) : "s"(m), "v"(addr), "v"(one) : "memory");
+}
+__device__ __forceinline__ uint32_t c2_lds_u32(const uint32_t *p) {                    // a volatile C++ read of LDS becomes a flat load
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(mf_lds_addr(p)) : "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+// the claim list: every slot a wave wins goes to ITS list; the compaction visits and clears the claimed slots only
+__device__ __forceinline__ void c2_note(const c2_wave &L, unsigned long long won, uint32_t s, uint32_t &ncl) {
+    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(won >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)won, ncl));
+    c2_push16(won & c2_lt_u32(at, (uint32_t)C2_CLN), L.cl0 + 2u * at, s);
+    ncl += (uint32_t)__popcll(won);
+}
+// finish up to 64 queued keys (collisions), one per lane: linear probing from the slot AFTER the home slot
+__device__ __forceinline__ void c2_drain(const c2_wave &L, uint32_t &qn, uint32_t &ncl, uint32_t *part_over, uint32_t *blk_claims) {
+    const uint32_t lane = (uint32_t)mf_lane();
+    const uint32_t c = qn < 64u ? qn : 64u;
+    qn -= c;
+    unsigned long long pend = c2_lt_u32(lane, c);
+    uint64_t key;
+    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(key) : "v"(L.qk0 + 8u * (qn + lane)) : "memory");   // (idle lanes: an in-range entry)
+    uint32_t s = (c2_slot((uint32_t)(key >> 32), (uint32_t)key) + 1u) & (uint32_t)(MF_COUNT_SLOTS - 1);
+    const uint32_t one = 1u;
+    uint32_t won_total = 0;
+    for (uint32_t probes = 0; pend != 0ull; probes++) {
+        if (probes >= 256u && ((probes & 255u) == 0u)) {
+            if (probes > (uint32_t)MF_COUNT_SLOTS) { if (lane == 0) *part_over = 1u; break; }
+            if (c2_lds_u32(part_over)) break;
+        }
+        const uint64_t ret = c2_cas_m(pend, L.tk0 + 8u * s, key);
+        const unsigned long long won = pend & c2_eq_u64(ret, MF_EMPTY);
+        const unsigned long long ok = won | (pend & c2_eq_u64(ret, key));
+        c2_add_m(ok, L.tc0 + 4u * s, one);
+        if (won != 0ull) { c2_note(L, won, s, ncl); won_total += (uint32_t)__popcll(won); }
+        pend &= ~ok;
+        s = (s + 1u) & (uint32_t)(MF_COUNT_SLOTS - 1);
+    }
+    if (won_total && lane == 0) atomicAdd(blk_claims, won_total);
+}
+
+// ---- the pipelined step.  State carried from step to step: the item and the parked record of THIS step (fetched during
+// the previous one).  Item entry (16 bits): [0,3) k-mers in the item (0 = the padding after the list), [4,10) record slot,
+// [10,15) funnel-shift amount, [15] the item starts in the record's second word.
+template <int K>
+__device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t &it, skm_v4 &W, uint32_t &qn, uint32_t &ncl,
+                                        uint32_t &won_acc, uint32_t *part_over, uint32_t *blk_claims, int ablate) {
+    constexpr int sh = 64 - 2 * K;              // 2 .. 24
+    constexpr int nb = 2 * K - 34;              // bit of the high word where a new base enters the reverse complement
+    const uint32_t lane = (uint32_t)mf_lane();
+    const uint32_t nk = it & 7u;
+    const uint32_t sa = it >> 10;                                          // funnel-shift amount in the low five bits
+    unsigned long long q;                                                  // (VOP3 takes no 32-bit literal on gfx950: the bound sits in an SGPR)
+    asm("v_cmp_lt_u32_e64 %0, %2, %1" : "=s"(q) : "v"(it), "s"(0x7FFFu));
+    const uint32_t A = skm_sel(W.x, W.y, q), B = skm_sel(W.y, W.z, q), C = skm_sel(W.z, W.w, q), D = skm_sel(W.w, 0u, q);
+    const uint32_t hr = __builtin_amdgcn_alignbit(A, B, sa), lr = __builtin_amdgcn_alignbit(B, C, sa), xr = __builtin_amdgcn_alignbit(C, D, sa);
+    uint32_t fh[4], fl[4], ch[4], cl[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const uint32_t Vh = u ? __builtin_amdgcn_alignbit(hr, lr, 32 - 2 * u) : hr;
+        const uint32_t Vl = u ? __builtin_amdgcn_alignbit(lr, xr, 32 - 2 * u) : lr;
+        fh[u] = Vh >> sh;
+        fl[u] = __builtin_amdgcn_alignbit(Vh, Vl, sh);
+    }
+    uint32_t rh, rl;
+    {
+        const uint32_t H = c2_swap_pairs(__builtin_bitreverse32(~fl[0])), Lo = c2_swap_pairs(__builtin_bitreverse32(~fh[0]));
+        rh = H >> sh;
+        rl = __builtin_amdgcn_alignbit(H, Lo, sh);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (u) {
+            rl = __builtin_amdgcn_alignbit(rh, rl, 2);
+            rh = (rh >> 2) | (((~fl[u]) & 3u) << nb);
+        }
+        const bool lt = (((uint64_t)fh[u] << 32) | fl[u]) < (((uint64_t)rh << 32) | rl);      // one v_cmp_lt_u64
+        ch[u] = lt ? fh[u] : rh;
+        cl[u] = lt ? fl[u] : rl;
+    }
+    uint32_t s[4], ka[4]; uint64_t key[4], ret[4]; unsigned long long live[4];
+    live[0] = c2_gt<0>(nk); live[1] = c2_gt<1>(nk); live[2] = c2_gt<2>(nk); live[3] = c2_gt<3>(nk);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        key[u] = ((uint64_t)ch[u] << 32) | cl[u];
+        s[u] = c2_slot(ch[u], cl[u]);
+        ka[u] = L.tk0 + 8u * s[u];
+    }
+    // ---- probes (= claims) of this step + the NEXT step's item, one wait
+    uint32_t it_n; unsigned long long save;
+    const uint32_t ia_n = L.items0 + 2u * (i0 + 64u + lane);
+    if (ablate & 16) { if ((ka[0] ^ ka[1] ^ ka[2] ^ ka[3]) == 0x12345u) *part_over = 1u; ret[0] = ret[1] = ret[2] = ret[3] = 0; live[0] = live[1] = live[2] = live[3] = 0;
+        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(it_n) : "v"(ia_n) : "memory"); }
+    else
+    asm volatile("s_mov_b64 %5, exec\n\tds_read_u16 %4, %6\n\t"
+                 "s_mov_b64 exec, %7\n\tds_cmpst_rtn_b64 %0, %11, %15, %16\n\t"
+                 "s_mov_b64 exec, %8\n\tds_cmpst_rtn_b64 %1, %12, %15, %17\n\t"
+                 "s_mov_b64 exec, %9\n\tds_cmpst_rtn_b64 %2, %13, %15, %18\n\t"
+                 "s_mov_b64 exec, %10\n\tds_cmpst_rtn_b64 %3, %14, %15, %19\n\t"
+                 "s_mov_b64 exec, %5\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(ret[0]), "=&v"(ret[1]), "=&v"(ret[2]), "=&v"(ret[3]), "=&v"(it_n), "=&s"(save)
+                 : "v"(ia_n), "s"(live[0]), "s"(live[1]), "s"(live[2]), "s"(live[3]), "v"(ka[0]), "v"(ka[1]), "v"(ka[2]), "v"(ka[3]),
+                   "v"(MF_EMPTY), "v"(key[0]), "v"(key[1]), "v"(key[2]), "v"(key[3])
+                 : "memory");
+    unsigned long long won[4], ok[4], coll[4]; uint32_t aa[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        won[u] = live[u] & c2_eq_u64(ret[u], MF_EMPTY);
+        ok[u] = won[u] | (live[u] & c2_eq_u64(ret[u], key[u]));
+        coll[u] = live[u] & ~ok[u];
+        aa[u] = L.tc0 + 4u * s[u];
+    }
+    // ---- count updates of this step + the NEXT step's record (waited for at the end of the step)
+    skm_v4 W_n;
+    const uint32_t ra_n = L.rb0 | (it_n & 0x3F0u);                         // (rb0 is 1024-byte aligned)
+    const uint32_t one = 1u;
+    asm volatile("s_mov_b64 %1, exec\n\tds_read_b128 %0, %2\n\t"
+                 "s_mov_b64 exec, %3\n\tds_add_u32 %7, %11\n\t"
+                 "s_mov_b64 exec, %4\n\tds_add_u32 %8, %11\n\t"
+                 "s_mov_b64 exec, %5\n\tds_add_u32 %9, %11\n\t"
+                 "s_mov_b64 exec, %6\n\tds_add_u32 %10, %11\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=&v"(W_n), "=&s"(save)
+                 : "v"(ra_n), "s"(ok[0]), "s"(ok[1]), "s"(ok[2]), "s"(ok[3]), "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(one)
+                 : "memory");
+    if (!(ablate & 8)) {
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (won[u] != 0ull) { c2_note(L, won[u], s[u], ncl); won_acc += (uint32_t)__popcll(won[u]); }
+        if (coll[u] != 0ull) {
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(coll[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)coll[u], qn));
+            c2_push64(coll[u], L.qk0 + 8u * at, key[u]);
+            qn += (uint32_t)__popcll(coll[u]);
+        }
+        if ((u & 1) && qn >= 64u) { if (ablate & 4) qn = 0; else c2_drain(L, qn, ncl, part_over, blk_claims); }       // (qn < 64 + 128 <= C2_QN)
+    }
+    }
+    // the next step's record must have landed before anything touches its registers
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W_n), "+v"(it_n) :: "memory");
+    it = it_n; W = W_n;
+}
+
+// PROF: cycle counters per phase (diagnostics, option ablate & 32; s_memtime perturbs the kernel by about a tenth)
+#define C2_TICK(i) do { if (PROF) { const long long t__ = clock64(); prof[i] += (unsigned long long)(t__ - tlast); tlast = t__; } } while (0)
+template <int K, bool PROF>
+__global__ __launch_bounds__(SKM_CT, 4) void k_skm_count2(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart,
+                                                           const uint32_t *__restrict__ plen, uint32_t np,
+                                                           const uint64_t *__restrict__ toff, uint64_t *__restrict__ tkeys,
+                                                           uint16_t *__restrict__ tcnt, uint32_t *__restrict__ dcount,
+                                                           unsigned int *__restrict__ overflow, uint32_t p0, uint64_t tbase, int thr,
+                                                           unsigned long long *__restrict__ n_all, uint32_t *__restrict__ redo,
+                                                           unsigned int *__restrict__ n_redo, unsigned long long *__restrict__ drop_hist, int ablate,
+                                                           unsigned long long *__restrict__ prof_out) {
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = PROF ? clock64() : 0;
+    // partitions [p0, np); slice of p in tkeys / tcnt starts at toff[p] - tbase; thr >= 0: entries with count <= thr are
+    // dropped and tallied in drop_hist[count] (thr < C2_LH); *n_all += distinct k-mers before the cut
+    // NO static __shared__ in this kernel: the dynamic array must start at LDS address 0 (the parked records are
+    // addressed with `rb0 | offset`; an alignment attribute on the extern array is not honoured behind static variables)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const uint32_t wave = threadIdx.x >> 6, lane = (uint32_t)mf_lane();
+    skm_v4 *rbuf_all = reinterpret_cast<skm_v4 *>(smem);                        // [SKM_CT] parked records (1 KiB per wave, aligned)
+    uint64_t *tk = reinterpret_cast<uint64_t *>(rbuf_all + SKM_CT);             // [MF_COUNT_SLOTS]
+    uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS);           // [MF_COUNT_SLOTS]
+    uint16_t *items_all = reinterpret_cast<uint16_t *>(tc + MF_COUNT_SLOTS);    // [waves][C2_ITEMS]
+    uint64_t *qk_all = reinterpret_cast<uint64_t *>(items_all + (SKM_CT / 64) * C2_ITEMS);   // [waves][C2_QN]
+    uint16_t *cl_all = reinterpret_cast<uint16_t *>(qk_all + (SKM_CT / 64) * C2_QN);         // [waves][C2_CLN]
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(cl_all + (SKM_CT / 64) * C2_CLN);         // [C2_LH]
+    uint32_t (*pflags)[2] = reinterpret_cast<uint32_t (*)[2]>(lhist + C2_LH);                // [parity][0] sweep_all, [parity][1] part_over
+    uint32_t &out_cursor = lhist[C2_LH + 4], &all_cursor = lhist[C2_LH + 5], &blk_claims = lhist[C2_LH + 6];
+    c2_wave L;
+    L.tk0 = mf_lds_addr(tk); L.tc0 = mf_lds_addr(tc);
+    L.rb0 = mf_lds_addr(rbuf_all + wave * 64);
+    L.items0 = mf_lds_addr(items_all + wave * C2_ITEMS);
+    L.qk0 = mf_lds_addr(qk_all + wave * C2_QN);
+    L.cl0 = mf_lds_addr(cl_all + wave * C2_CLN);
+    uint16_t *cl = cl_all + wave * C2_CLN;
+    uint32_t qn = 0, ncl = 0, won_acc = 0;                                      // wave-uniform
+    unsigned long long all_acc = 0;                                             // thread 0
+    uint32_t ones_acc = 0;                                                      // per wave: dropped entries with count 1
+    // the table is cleared ONCE; after that every partition leaves it clean (its compaction clears the slots it claimed)
+    for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += (uint32_t)SKM_CT) { tk[i] = MF_EMPTY; tc[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) lhist[i] = 0;
+    if (threadIdx.x == 0) { out_cursor = 0; all_cursor = 0; blk_claims = 0; pflags[0][0] = pflags[0][1] = pflags[1][0] = pflags[1][1] = 0; }
+    const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
+    const uint32_t mine = (lane >> 3) * 64u + wave * 8u + (lane & 7u);          // this lane's record within a round of 512
+    uint32_t pi = p0 + blockIdx.x;
+    if (pi >= np) return;
+    uint32_t p = pi;
+    uint64_t start = pstart[p];
+    uint32_t len = plen[p];
+    uint64_t o = toff[p] - tbase; uint32_t room = (uint32_t)(toff[p + 1] - toff[p]);
+    // (an address select between the record and a sentinel object would turn the load into a flat load from scratch)
+    auto load_rec = [&](uint64_t first, uint32_t j, uint32_t n) -> skm_rec {
+        const bool ok = j < n;
+        const uint4 w = reinterpret_cast<const uint4 *>(recs)[ok ? first + j : 0];
+        skm_rec v = make_ulonglong2(((uint64_t)w.y << 32) | w.x, ((uint64_t)w.w << 32) | w.z);
+        if (!ok) v = SENT;
+        return v;
+    };
+    // the first TWO rounds of a partition are in registers before it starts (the second one used to cost an exposed HBM
+    // round trip per partition once partitions grew past 512 records)
+    skm_rec R0 = load_rec(start, mine, len), R1 = load_rec(start, (uint32_t)SKM_CT + mine, len);
+    uint64_t start_n = 0, o_n = 0; uint32_t len_n = 0, room_n = 0;
+    if (pi + gridDim.x < np) { const uint32_t qq = pi + gridDim.x; start_n = pstart[qq]; len_n = plen[qq]; o_n = toff[qq] - tbase; room_n = (uint32_t)(toff[qq + 1] - toff[qq]); }
+    __syncthreads();
+    for (uint32_t parity = 0;; parity ^= 1u) {
+        const uint32_t pn = pi + gridDim.x, pnn = pn + gridDim.x;
+        uint64_t start_nn = 0, o_nn = 0; uint32_t len_nn = 0, room_nn = 0;
+        if (pnn < np) { start_nn = pstart[pnn]; len_nn = plen[pnn]; o_nn = toff[pnn] - tbase; room_nn = (uint32_t)(toff[pnn + 1] - toff[pnn]); }
+        skm_rec cur = R0, cur1 = R1;
+        if (pn < np) { R0 = load_rec(start_n, mine, len_n); R1 = load_rec(start_n, (uint32_t)SKM_CT + mine, len_n); }      // next partition
+        uint32_t *part_over = &pflags[parity][1];
+        C2_TICK(0);                                                             // partition top: directory, record prefetch
+        for (uint32_t rb = 0; rb < len; rb += (uint32_t)SKM_CT) {
+            if (rb == (uint32_t)SKM_CT) cur = cur1;
+            else if (rb) {
+                if (c2_lds_u32(part_over)) break;                               // (abandoned)
+                cur = load_rec(start, rb + mine, len);
+            }
+            const uint32_t r = skm_rec_valid(cur) ? skm_rec_n(cur) : 0u;
+            const uint32_t nch = (r + 3u) >> 2;
+            uint32_t NI;
+            const uint32_t ioff = mf_wave_excl_scan(nch, &NI);
+            if (NI == 0) continue;                                              // wave-uniform
+            {   // park the record shifted right by one bit (bases only)
+                const uint32_t x1 = (uint32_t)(cur.x >> 32), x0 = (uint32_t)cur.x, y1 = (uint32_t)(cur.y >> 32), y0 = (uint32_t)cur.y & 0xF0000000u;
+                skm_v4 P;
+                P.x = x1 >> 1; P.y = __builtin_amdgcn_alignbit(x1, x0, 1); P.z = __builtin_amdgcn_alignbit(x0, y1, 1); P.w = __builtin_amdgcn_alignbit(y1, y0, 1);
+                *reinterpret_cast<__attribute__((address_space(3))) skm_v4 *>((uintptr_t)(L.rb0 + 16u * lane)) = P;
+            }
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                // chunk c starts at bit 8c+1 of the parked record: funnel shift (32 - (8c+1)) & 31, second word from c = 4
+                if ((uint32_t)c < nch) {
+                    const uint32_t left = r - 4u * (uint32_t)c;
+                    const uint32_t e = (left < 4u ? left : 4u) | (lane << 4) | ((uint32_t)((31 - 8 * c) & 31) << 10) | ((uint32_t)(c >> 2) << 15);
+                    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (ioff + (uint32_t)c))) = (uint16_t)e;
+                }
+            }
+            // one step of padding after the list: items without k-mers for the idle lanes of the last step (the step after
+            // that is only read ahead, never used)
+            *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (NI + lane))) = (uint16_t)0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // LDS of one wave is in order: visible to its lanes
+            __builtin_amdgcn_wave_barrier();
+            C2_TICK(1);                                                         // round set-up (incl. the wait for the records)
+            if (!(ablate & 1)) {
+                uint32_t it; skm_v4 W;
+                asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(it) : "v"(L.items0 + 2u * lane) : "memory");
+                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(W) : "v"(L.rb0 | (it & 0x3F0u)) : "memory");
+                for (uint32_t i0 = 0; i0 < NI; i0 += 64) c2_step<K>(L, i0, it, W, qn, ncl, won_acc, part_over, &blk_claims, ablate);      // wave-uniform
+            }
+            // a crowded table probes slowly: past SKM_FILL claims the partition is handed to the multi-pass kernel
+            if (won_acc) { if (lane == 0 && atomicAdd(&blk_claims, won_acc) + won_acc > (uint32_t)SKM_FILL) *part_over = 1u; won_acc = 0; }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
+            __builtin_amdgcn_wave_barrier();
+            C2_TICK(2);                                                         // steps (with the drains inside them)
+        }
+        if (ablate & 6) qn = 0;
+        while (qn) c2_drain(L, qn, ncl, part_over, &blk_claims);               // wave-uniform
+        if (ncl > (uint32_t)C2_CLN && lane == 0) pflags[parity][0] = 1;        // this wave's list is incomplete: sweep the whole table
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS operations of the asm blocks are invisible to hipcc's waitcnt pass
+        C2_TICK(3);                                                             // last drains
+        __syncthreads();                                                        // ---- B1: every insert of the partition is done
+        C2_TICK(4);                                                             // waiting for the other waves
+        const uint64_t pf = (uint64_t)c2_lds_u32(&pflags[parity][0]) | ((uint64_t)c2_lds_u32(&pflags[parity][1]) << 32);
+        const bool crowded = c2_lds_u32(&blk_claims) > (uint32_t)SKM_FILL;     // (claims reported by the drains after the last round)
+        if (threadIdx.x == 0) *reinterpret_cast<uint64_t *>(pflags[parity ^ 1u]) = 0ull;      // for the next partition
+        const uint64_t lt_mask = (1ull << lane) - 1ull;
+        if ((uint32_t)(pf >> 32) || crowded) {
+            // more distinct k-mers than the table takes: wipe it, the partition goes to the redo list (multi-pass kernel)
+            for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += (uint32_t)SKM_CT) { tk[i] = MF_EMPTY; tc[i] = 0; }
+            if (threadIdx.x == 0) redo[atomicAdd(n_redo, 1u)] = p;
+        } else if (!(uint32_t)pf) {
+            // compaction over the claimed slots: every wave walks ITS list, writes the entries that pass the cut, tallies
+            // the ones that do not, and leaves the slots empty for the next partition
+            if (lane == 0 && ncl) atomicAdd(&all_cursor, ncl);
+            for (uint32_t i0 = 0; i0 < ncl; i0 += 64) {             // wave-uniform
+                const bool have = i0 + lane < ncl;
+                uint32_t sl = 0; uint64_t key = MF_EMPTY; uint32_t cnt = 0;
+                if (have) { sl = cl[i0 + lane]; key = tk[sl]; cnt = tc[sl]; tk[sl] = MF_EMPTY; tc[sl] = 0; }
+                if (cnt > (uint32_t)MF_MAX_COUNT) cnt = (uint32_t)MF_MAX_COUNT;
+                const bool keep = have && (int)cnt > thr;           // (thr < 0 keeps everything)
+                if (thr >= 0) {
+                    ones_acc += (uint32_t)__popcll(__ballot(have && !keep && cnt == 1u));
+                    if (have && !keep && cnt != 1u) atomicAdd(&lhist[cnt], 1u);
+                }
+                const unsigned long long bal = __ballot(keep);
+                uint32_t wb = 0;
+                if (lane == 0 && bal) wb = atomicAdd(&out_cursor, (uint32_t)__popcll(bal));
+                wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb) + (uint32_t)__popcll(bal & lt_mask);
+                if (keep && wb < room) { tkeys[o + wb] = key; tcnt[o + wb] = (uint16_t)cnt; }
+                if (keep && wb >= room) atomicExch(overflow, 1u);   // (only if a partition's k-mer count wrapped)
+            }
+        } else {
+            // full sweep (a wave's claim list ran over): 64-slot chunks per wave (lane = slot: conflict-free)
+            constexpr int NCH = MF_COUNT_SLOTS / SKM_CT;
+#pragma unroll 1
+            for (int i = 0; i < NCH; i++) {
+                const uint32_t sl = (wave << 6) + (uint32_t)i * SKM_CT + lane;
+                const uint64_t key = tk[sl]; uint32_t cnt = tc[sl];
+                tk[sl] = MF_EMPTY; tc[sl] = 0;
+                const bool have = key != MF_EMPTY;
+                if (cnt > (uint32_t)MF_MAX_COUNT) cnt = (uint32_t)MF_MAX_COUNT;
+                const bool keep = have && (int)cnt > thr;
+                const unsigned long long hb = __ballot(have);
+                if (lane == 0 && hb) atomicAdd(&all_cursor, (uint32_t)__popcll(hb));
+                if (thr >= 0) {
+                    ones_acc += (uint32_t)__popcll(__ballot(have && !keep && cnt == 1u));
+                    if (have && !keep && cnt != 1u) atomicAdd(&lhist[cnt], 1u);
+                }
+                const unsigned long long bal = __ballot(keep);
+                uint32_t wb = 0;
+                if (lane == 0 && bal) wb = atomicAdd(&out_cursor, (uint32_t)__popcll(bal));
+                wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb) + (uint32_t)__popcll(bal & lt_mask);
+                if (keep && wb < room) { tkeys[o + wb] = key; tcnt[o + wb] = (uint16_t)cnt; }
+                if (keep && wb >= room) atomicExch(overflow, 1u);
+            }
+        }
+        ncl = 0; qn = 0;
+        C2_TICK(5);                                                             // compaction
+        __syncthreads();                                                        // ---- B2: the table is clean, the cursors final
+        C2_TICK(6);
+        if (threadIdx.x == 0) { dcount[p] = out_cursor; all_acc += all_cursor; out_cursor = 0; all_cursor = 0; blk_claims = 0; }
+        if (pn >= np) break;
+        pi = pn; p = pn; start = start_n; len = len_n; o = o_n; room = room_n;
+        start_n = start_nn; len_n = len_nn; o_n = o_nn; room_n = room_nn;
+    }
+    if (threadIdx.x == 0 && n_all && all_acc) atomicAdd(n_all, all_acc);
+    if (PROF && lane == 0 && prof_out) for (int i = 0; i < 8; i++) atomicAdd(&prof_out[i], prof[i]);
+    if (thr >= 0 && drop_hist) {
+        if (lane == 0 && ones_acc) atomicAdd(&lhist[1], ones_acc);
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) { const uint32_t v = lhist[i]; if (v) atomicAdd(&drop_hist[i], (unsigned long long)v); }
+    }
 }
 
 __global__ void k_skm_add_base(uint64_t *__restrict__ v, uint64_t n, uint64_t base) {
@@ -997,6 +1420,22 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         MF_TRY(skm_set_lds(k_skm_count<K, true>, lds));
     }
     mf_buf<uint32_t> redo; MF_TRY(redo.alloc(ctx, PB));        // partitions of the running batch that need several passes
+    // counts of the entries the cut drops (the .stat.txt histogram needs them): drop_hist[c], c <= thr
+    mf_buf<unsigned long long> dhist;
+    if (thr >= 0) { MF_TRY(dhist.alloc(ctx, (size_t)MF_MAX_COUNT + 1)); MF_HIP(hipMemsetAsync(dhist.p, 0, dhist.bytes(), st)); }
+    const bool count2 = ctx->opt_count2 != 0 && thr < C2_LH;
+    const bool c2prof = count2 && K == 31 && (ctx->opt_ablate & 32);
+    mf_buf<unsigned long long> c2p;
+    if (c2prof) { MF_TRY(c2p.alloc(ctx, 8)); MF_HIP(hipMemsetAsync(c2p.p, 0, 64, st)); }
+    if (count2) {
+        MF_TRY(skm_set_lds(k_skm_count2<K, false>, C2_LDS));
+        if (K == 31) MF_TRY(skm_set_lds(k_skm_count2<(K == 31 ? 31 : 20), true>, C2_LDS));
+        if (ctx->opt_verbose) {
+            int nb = 0;
+            MF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_skm_count2<K, false>, SKM_CT, C2_LDS));
+            fprintf(stderr, "[mf] k_skm_count2: %zu bytes of LDS, %d workgroups per CU\n", (size_t)C2_LDS, nb);
+        }
+    }
     for (uint32_t b = 0; b < nbatch; b++) {
         const uint32_t p0 = (uint32_t)std::min<uint64_t>((uint64_t)b * PB, np), p1 = (uint32_t)std::min<uint64_t>((uint64_t)(b + 1) * PB, np);
         if (p0 == p1) continue;
@@ -1005,12 +1444,19 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);
             MF_HIP(hipMemsetAsync(&scal[8], 0, 8, st));
             mf_ktimer t(ctx, "k_skm_count");
-            k_skm_count<K, false><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
-                                                             (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8]);
+            if (c2prof)
+                k_skm_count2<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
+                                                             p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p);
+            else if (count2)
+                k_skm_count2<K, false><<<grid, SKM_CT, C2_LDS, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
+                                                             p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, nullptr);
+            else
+                k_skm_count<K, false><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
+                                                                 (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p);
             // the partitions that did not fit (normally none: the workgroups find an empty list and leave)
             k_skm_count<K, true><<<std::min<unsigned>(grid, 64u), SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p,
                                                                                        (unsigned int *)&scal[2], (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr,
-                                                                                       &scal[7], redo.p, (unsigned int *)&scal[8]);
+                                                                                       &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p);
         }
         MF_DBG(ctx, "k_skm_count");
         MF_TRY(mf_scan<1>(ctx, dcount.p + p0, doff.p + p0, p1 - p0, (uint64_t *)&scal[3]));      // offsets inside the batch
@@ -1050,6 +1496,14 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         dused += d_b;
     }
     MF_HIP(hipGetLastError());
+    if (c2prof) {
+        unsigned long long h[8];
+        MF_HIP(hipMemcpyAsync(h, c2p.p, 64, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+        unsigned long long tot = 0; for (int i = 0; i < 7; i++) tot += h[i];
+        static const char *nm[7] = {"partition top", "round set-up", "steps", "last drains", "barrier 1", "compaction", "barrier 2"};
+        for (int i = 0; i < 7; i++) fprintf(stderr, "[mf] k_skm_count2 wave cycles: %-14s %5.1f %%\n", nm[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+    }
     bufA.reset();
     const uint64_t n_dist = dused;
     if (ctx->opt_verbose)
@@ -1066,6 +1520,11 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         if (n_all) *n_all = nv2[1];
         (*out)->n_records = nv ? nv : cap_l1;             // (plans without a split level: the padded level-1 count)
         (*out)->cut_thr = thr;
+        if (thr >= 0) {
+            (*out)->dropped_hist.assign((size_t)thr + 1, 0);
+            MF_HIP(hipMemcpyAsync((*out)->dropped_hist.data(), dhist.p, ((size_t)thr + 1) * 8, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+        }
         (*out)->record_bytes = 16;
     }
     if (total_bits > 0 && total_bits <= 30) {

@@ -391,6 +391,12 @@ extern "C" int mf_table_filter(const mf_table *t, int threshold, mf_table **out)
     size_t kb = ok.bytes(), cb = oc.bytes();
     MF_TRY(mf_table_adopt(ctx, t->k, m, 0, ok.take(), kb, oc.take(), cb, out));
     (*out)->cut_thr = std::max(t->cut_thr, threshold);
+    if (threshold >= 0 && threshold > t->cut_thr) {
+        // what this cut drops joins what earlier cuts dropped: the count histogram (.stat.txt) stays that of ALL k-mers
+        std::vector<uint64_t> h;
+        MF_TRY(mf_table_count_hist(t, h));
+        (*out)->dropped_hist.assign(h.begin(), h.begin() + std::min<size_t>((size_t)threshold + 1, h.size()));
+    } else (*out)->dropped_hist = t->dropped_hist;
     if (t->part_bits > 0 && t->d_part_off && m) {
         // the compaction is stable, so the selected entries of partition p are still contiguous: new offsets by a scan
         const uint32_t np = 1u << t->part_bits;
@@ -433,6 +439,7 @@ int mf_table_filter_or_alias(const mf_table *t, int threshold, mf_table **out) {
         MF_TRY(mf_table_adopt(ctx, t->k, t->n, 0, t->d_keys, t->keys_bytes, t->d_counts, t->counts_bytes, out));
         (*out)->owns_arrays = false;
         (*out)->cut_thr = std::max(t->cut_thr, threshold);
+        (*out)->dropped_hist = t->dropped_hist;
         (*out)->index = t->index; (*out)->index_bytes = t->index_bytes;
         (*out)->part_bits = t->part_bits; (*out)->part_skm = t->part_skm; (*out)->d_part_off = t->d_part_off; (*out)->part_off_bytes = t->part_off_bytes;
         return MF_OK;
@@ -606,7 +613,7 @@ extern "C" int mf_table_lookup(mf_table *t, const uint64_t *keys, uint64_t n, in
 int mf_table_count_hist(const mf_table *t, std::vector<uint64_t> &hist) {
     mf_ctx *ctx = t->ctx;
     hist.assign(MF_MAX_COUNT + 1, 0);
-    if (!t->n) return MF_OK;
+    if (!t->n) { for (size_t c = 0; c < t->dropped_hist.size() && c < hist.size(); c++) hist[c] += t->dropped_hist[c]; return MF_OK; }
     mf_buf<unsigned long long> dh; MF_TRY(dh.alloc(ctx, MF_MAX_COUNT + 1));
     MF_HIP(hipMemsetAsync(dh.p, 0, dh.bytes(), ctx->stream));
     unsigned grid = (unsigned)std::min<uint64_t>((t->n + 255) / 256, 2048);
@@ -616,5 +623,17 @@ int mf_table_count_hist(const mf_table *t, std::vector<uint64_t> &hist) {
     }
     MF_HIP(hipMemcpyAsync(hist.data(), dh.p, (MF_MAX_COUNT + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
     MF_HIP(hipStreamSynchronize(ctx->stream));
+    // the k-mers a cut inside the counting pass kept out of the table (count <= cut_thr) were tallied there
+    for (size_t c = 0; c < t->dropped_hist.size() && c < hist.size(); c++) hist[c] += t->dropped_hist[c];
+    return MF_OK;
+}
+// QuickQuantitativeStatistics of IOUtils.printKmers (src/io/IOUtils.java:45-71): number of distinct k-mers per count,
+// over ALL k-mers that were counted -- also those a cut has dropped from the table
+extern "C" int mf_table_hist(const mf_table *t, uint64_t *hist) {
+    if (!t || !hist) return mf_set_error("mf_table_hist: NULL argument");
+    MF_HIP(hipSetDevice(t->ctx->device));
+    std::vector<uint64_t> h;
+    MF_TRY(mf_table_count_hist(t, h));
+    memcpy(hist, h.data(), (size_t)(MF_MAX_COUNT + 1) * 8);
     return MF_OK;
 }

@@ -38,6 +38,7 @@ _SIGS = {
     "mf_table_stats": (i32, [vp, pu64, pu64]),
     "mf_table_occurrences": (i32, [vp, pu64]),
     "mf_table_records": (i32, [vp, pu64, C.POINTER(i32)]),
+    "mf_table_hist": (i32, [vp, vp]),
     "mf_table_export": (i32, [vp, i32, vp, vp, u64, pu64]),
     "mf_table_device_view": (i32, [vp, pvp, pvp, pu64]),
     "mf_table_lookup": (i32, [vp, vp, u64, vp]),
@@ -283,6 +284,12 @@ class Table:
         a, b = C.c_uint64(), C.c_int32()
         _check(lib().mf_table_records(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def hist(self):
+        """number of distinct k-mers per count over ALL counted k-mers (those a cut dropped included): the .stat.txt rows"""
+        h = np.zeros(32768, dtype=np.uint64)
+        _check(lib().mf_table_hist(self.h, h.ctypes.data))
+        return h
 
     def export(self, threshold=-1):
         """-> (keys uint64[n] ascending, counts uint16[n]) with count > threshold"""
