@@ -54,7 +54,7 @@ struct mf_ctx {
     // options
     int64_t opt_l1_bits = -1;      // -1 = auto
     int64_t opt_l2_bits = -1;
-    int64_t opt_part_target = 3072;  // mean k-mer occurrences per final partition
+    int64_t opt_part_target = 6144;  // mean k-mer occurrences per final partition (k_skm_count2: ~800 distinct k-mers in 4096 slots)
     int64_t opt_scatter_staged = 1;
     int64_t opt_profile = 0;
     int64_t opt_l1_blocks = 0;     // 0 = auto

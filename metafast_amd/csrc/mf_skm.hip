@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t skm_rec_digits(const skm_rec &r) { return (u
 template <int K> struct skm_word {
     static constexpr int W = K - MF_SKM_M + 1;          // M-mers per k-mer
     static constexpr int NM = 31 + W;                   // M-mers of the word's 32 k-mers
-    static constexpr int RMAX = (MF_SKM_BASES - (K - 1)) < 24 ? (MF_SKM_BASES - (K - 1)) : 24;   // k-mers per record (<= 6 items of 4 in k_skm_count)
+    static constexpr int RMAX = (MF_SKM_BASES - (K - 1)) < 20 ? (MF_SKM_BASES - (K - 1)) : 20;   // k-mers per record (<= 10 items of 2 in k_skm_count2)
     uint32_t D[4];        // 64 bases from the word's first position, 2 bits each, first base in the top bits of D[0]
     uint32_t mh[32];      // minimizer hash of the k-mer at each position
     uint32_t valid;       // positions that start a k-mer (from the bitmap)
@@ -851,23 +851,30 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
 // The all-counts histogram of IOUtils.printKmers (src/io/IOUtils.java:45-71, the .stat.txt file) needs the entries the
 // cut drops: their counts (<= thr) are tallied here (count 1 by ballot, the others in a small LDS histogram).
 // =============================================================================================
-#define C2_QN 192                // queue entries per wave (keys): drained at 64, two pushes (<= 128 keys) between checks
-#define C2_CLN 160               // claimed-slot list entries per wave
-#define C2_LH 256                // bins of the workgroup's dropped-count histogram (cuts with thr >= C2_LH do not run in the kernel)
-#define C2_ITEMS 512             // item entries per wave: 64 records x 6 chunks + two steps of padding (one is read ahead)
-static constexpr size_t C2_LDS = (size_t)MF_COUNT_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8 + C2_CLN * 2) + C2_LH * 4 + 32;
+#define C2_SLOTS 4096            // table slots: at the planned ~800 distinct k-mers per partition the table is 1/5 full.  (2048 slots
+                                 // = three workgroups per CU instead of two, but an 80-VGPR budget: 54 ms against 45.)
+#define C2_FILL 3400             // claims beyond which a partition is counted again in several passes
+#define C2_QN 128                // queue entries per wave (keys): drained at 64, one push (<= 64 keys) between checks
+#define C2_LH 128                // bins of the workgroup's dropped-count histogram (cuts with thr >= C2_LH do not run in the kernel)
+#define C2_ITEMS 768             // item entries per wave: 64 records x 10 items + two steps of padding (the read-ahead of the last step runs past them, unused)
+#define C2_W 2                   // k-mers per item
+static constexpr size_t C2_LDS = (size_t)C2_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8) + 2 * C2_LH * 4 + 32;
 static_assert(C2_LDS <= 80 * 1024, "two workgroups per CU");
 
 __device__ __forceinline__ uint32_t c2_swap_pairs(uint32_t x) {                 // exchanges the two bits of every base
     return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
 }
-__device__ __forceinline__ uint32_t c2_slot(uint32_t hi, uint32_t lo) {          // = skm_slot on halves
-    uint32_t f = (hi * 0x85EBCA6Bu) ^ lo;
-    f *= 0x9E3779B1u;
-    return (f >> 16) & (uint32_t)(MF_COUNT_SLOTS - 1);
+// slot of a key: full-rate instructions only (v_mul_lo_u32 is a quarter-rate instruction, and this is evaluated per k-mer
+// occurrence): fold the halves, fold the top bits down, one 24-bit multiply, bits 11..22 of the product
+__device__ __forceinline__ uint32_t c2_slot(uint32_t hi, uint32_t lo) {
+    uint32_t x = lo ^ __builtin_amdgcn_alignbit(hi, hi, 19);
+    x ^= x >> 15;
+    uint32_t t;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(t) : "v"(x), "s"(0x9E3779u));      // (low 24 bits of x) * constant, low 32 bits of the product
+    return (t >> 11) & (uint32_t)(C2_SLOTS - 1);
 }
 struct c2_wave {                 // LDS byte addresses of this wave's private areas + the table
-    uint32_t tk0, tc0, rb0, items0, qk0, cl0;
+    uint32_t tk0, tc0, rb0, items0, qk0;
 };
 // ---- lane masks straight from the compare (a C++ bool that meets __ballot costs a v_cndmask + v_cmp round trip per use)
 __device__ __forceinline__ unsigned long long c2_eq_u64(uint64_t a, uint64_t b) {
@@ -884,6 +891,15 @@ template <int U> __device__ __forceinline__ unsigned long long c2_gt(uint32_t a)
     unsigned long long m;
     asm("v_cmp_lt_u32_e64 %0, %2, %1" : "=s"(m) : "v"(a), "n"(U));
     return m;
+}
+// Workgroup barrier for LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and the fence makes hipcc
+// wait for vmcnt(0) first: every wave would sit out the HBM latency of the NEXT partition's record prefetch at each barrier
+// (the prefetch is issued a whole partition ahead precisely so that nobody waits for it).  The data the barriers order
+// lives in LDS; the global stores of the compaction are read by later kernels only.
+__device__ __forceinline__ void c2_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// a wave-uniform 64-bit value that lives in VGPRs -> SGPRs (readfirstlane returns int: no sign extension on the way back)
+__device__ __forceinline__ uint64_t c2_uniform64(uint64_t v) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
 }
 // ---- LDS operations of the lanes of a mask (EXEC is switched inside the block and restored)
 __device__ __forceinline__ void c2_push64(unsigned long long m, uint32_t addr, uint64_t v) {
@@ -912,62 +928,77 @@ __device__ __forceinline__ uint32_t c2_lds_u32(const uint32_t *p) {             
     asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(mf_lds_addr(p)) : "memory");
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
-// the claim list: every slot a wave wins goes to ITS list; the compaction visits and clears the claimed slots only
-__device__ __forceinline__ void c2_note(const c2_wave &L, unsigned long long won, uint32_t s, uint32_t &ncl) {
-    const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(won >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)won, ncl));
-    c2_push16(won & c2_lt_u32(at, (uint32_t)C2_CLN), L.cl0 + 2u * at, s);
-    ncl += (uint32_t)__popcll(won);
-}
-// finish up to 64 queued keys (collisions), one per lane: linear probing from the slot AFTER the home slot
-__device__ __forceinline__ void c2_drain(const c2_wave &L, uint32_t &qn, uint32_t &ncl, uint32_t *part_over, uint32_t *blk_claims) {
+// finish up to 64 queued keys (collisions), one per lane, by linear probing from the slot AFTER the home slot.  Four slots
+// are read ahead per round (reads are cheap and go out together): the key is found (-> count), or an empty slot comes first
+// (-> CAS there; if another key got in first, on from the next slot), or neither (-> four slots further).  Most keys need
+// one round; one slot per round cost four to six dependent LDS round trips per drain.
+__device__ __forceinline__ void c2_drain(const c2_wave &L, uint32_t &qn, uint32_t &won_acc, uint32_t *part_over) {
     const uint32_t lane = (uint32_t)mf_lane();
+    constexpr uint32_t mask = (uint32_t)(C2_SLOTS - 1);
     const uint32_t c = qn < 64u ? qn : 64u;
     qn -= c;
     unsigned long long pend = c2_lt_u32(lane, c);
     uint64_t key;
     asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(key) : "v"(L.qk0 + 8u * (qn + lane)) : "memory");   // (idle lanes: an in-range entry)
-    uint32_t s = (c2_slot((uint32_t)(key >> 32), (uint32_t)key) + 1u) & (uint32_t)(MF_COUNT_SLOTS - 1);
+    uint32_t s = (c2_slot((uint32_t)(key >> 32), (uint32_t)key) + 1u) & mask;
     const uint32_t one = 1u;
-    uint32_t won_total = 0;
-    for (uint32_t probes = 0; pend != 0ull; probes++) {
+    for (uint32_t probes = 0; pend != 0ull; probes += 4) {
         if (probes >= 256u && ((probes & 255u) == 0u)) {
-            if (probes > (uint32_t)MF_COUNT_SLOTS) { if (lane == 0) *part_over = 1u; break; }
+            if (probes > (uint32_t)C2_SLOTS) { if (lane == 0) *part_over = 1u; break; }
             if (c2_lds_u32(part_over)) break;
         }
-        const uint64_t ret = c2_cas_m(pend, L.tk0 + 8u * s, key);
-        const unsigned long long won = pend & c2_eq_u64(ret, MF_EMPTY);
-        const unsigned long long ok = won | (pend & c2_eq_u64(ret, key));
-        c2_add_m(ok, L.tc0 + 4u * s, one);
-        if (won != 0ull) { c2_note(L, won, s, ncl); won_total += (uint32_t)__popcll(won); }
+        uint32_t a[4]; uint64_t v[4]; unsigned long long save;
+#pragma unroll
+        for (int j = 0; j < 4; j++) a[j] = L.tk0 + 8u * ((s + (uint32_t)j) & mask);
+        asm volatile("s_mov_b64 %4, exec\n\ts_mov_b64 exec, %5\n\tds_read_b64 %0, %6\n\tds_read_b64 %1, %7\n\tds_read_b64 %2, %8\n\tds_read_b64 %3, %9\n\t"
+                     "s_mov_b64 exec, %4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&s"(save)
+                     : "s"(pend), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]) : "memory");
+        // first slot among the four that holds the key or is empty
+        unsigned long long eK[4], ev[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { eK[j] = c2_eq_u64(v[j], key); ev[j] = eK[j] | c2_eq_u64(v[j], MF_EMPTY); }
+        const unsigned long long any = pend & (ev[0] | ev[1] | ev[2] | ev[3]);
+        uint32_t j = skm_sel(3u, 2u, ev[2]); j = skm_sel(j, 1u, ev[1]); j = skm_sel(j, 0u, ev[0]);
+        const unsigned long long f0 = ev[0], f1 = ev[1] & ~ev[0], f2 = ev[2] & ~(ev[0] | ev[1]), f3 = ev[3] & ~(ev[0] | ev[1] | ev[2]);
+        unsigned long long ok = pend & ((f0 & eK[0]) | (f1 & eK[1]) | (f2 & eK[2]) | (f3 & eK[3]));      // found: count
+        const unsigned long long need = any & ~ok;                                                          // an empty slot first: claim it
+        const uint32_t sj = (s + j) & mask;
+        unsigned long long lost = 0ull;
+        if (need != 0ull) {
+            const uint64_t ret = c2_cas_m(need, L.tk0 + 8u * sj, key);
+            const unsigned long long won = need & c2_eq_u64(ret, MF_EMPTY);
+            ok |= won | (need & c2_eq_u64(ret, key));
+            lost = need & ~ok;                                              // another key got the slot: on from the next one
+            won_acc += (uint32_t)__popcll(won);
+        }
+        c2_add_m(ok, L.tc0 + 4u * sj, one);
         pend &= ~ok;
-        s = (s + 1u) & (uint32_t)(MF_COUNT_SLOTS - 1);
+        s = skm_sel((s + 4u) & mask, (sj + 1u) & mask, lost);
     }
-    if (won_total && lane == 0) atomicAdd(blk_claims, won_total);
 }
 
 // ---- the pipelined step.  State carried from step to step: the item and the parked record of THIS step (fetched during
-// the previous one).  Item entry (16 bits): [0,3) k-mers in the item (0 = the padding after the list), [4,10) record slot,
-// [10,15) funnel-shift amount, [15] the item starts in the record's second word.
+// the previous one).  An item is up to TWO consecutive k-mers of one record: with four, the last item of a record is half
+// empty on average and a step's instructions (VALU and LDS alike cost the same for 8 live lanes as for 64) ran at 71 %
+// occupancy; with two at 93 %.  Item entry (16 bits): [0,2) k-mers in the item (0 = the padding after the list), [4,10)
+// record slot, [10,15) funnel-shift amount, [15] the item starts in the record's second word.
 template <int K>
-__device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t &it, skm_v4 &W, uint32_t &qn, uint32_t &ncl,
-                                        uint32_t &won_acc, uint32_t *part_over, uint32_t *blk_claims, int ablate) {
+__device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t &it, skm_v4 &W, uint32_t &it1, uint32_t &qn,
+                                        uint32_t &won_acc, uint32_t *part_over, int ablate, uint32_t P, uint32_t pass) {
     constexpr int sh = 64 - 2 * K;              // 2 .. 24
     constexpr int nb = 2 * K - 34;              // bit of the high word where a new base enters the reverse complement
     const uint32_t lane = (uint32_t)mf_lane();
-    const uint32_t nk = it & 7u;
+    const uint32_t nk = it & 3u;
     const uint32_t sa = it >> 10;                                          // funnel-shift amount in the low five bits
     unsigned long long q;                                                  // (VOP3 takes no 32-bit literal on gfx950: the bound sits in an SGPR)
     asm("v_cmp_lt_u32_e64 %0, %2, %1" : "=s"(q) : "v"(it), "s"(0x7FFFu));
-    const uint32_t A = skm_sel(W.x, W.y, q), B = skm_sel(W.y, W.z, q), C = skm_sel(W.z, W.w, q), D = skm_sel(W.w, 0u, q);
-    const uint32_t hr = __builtin_amdgcn_alignbit(A, B, sa), lr = __builtin_amdgcn_alignbit(B, C, sa), xr = __builtin_amdgcn_alignbit(C, D, sa);
-    uint32_t fh[4], fl[4], ch[4], cl[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        const uint32_t Vh = u ? __builtin_amdgcn_alignbit(hr, lr, 32 - 2 * u) : hr;
-        const uint32_t Vl = u ? __builtin_amdgcn_alignbit(lr, xr, 32 - 2 * u) : lr;
-        fh[u] = Vh >> sh;
-        fl[u] = __builtin_amdgcn_alignbit(Vh, Vl, sh);
-    }
+    // two k-mers span 2K + 2 <= 64 bits from the item's first base: two funnel shifts over three words
+    const uint32_t A = skm_sel(W.x, W.y, q), B = skm_sel(W.y, W.z, q), C = skm_sel(W.z, W.w, q);
+    const uint32_t hr = __builtin_amdgcn_alignbit(A, B, sa), lr = __builtin_amdgcn_alignbit(B, C, sa);
+    uint32_t fh[2], fl[2], ch[2], cl[2];
+    fh[0] = hr >> sh; fl[0] = __builtin_amdgcn_alignbit(hr, lr, sh);
+    { const uint32_t Vh = __builtin_amdgcn_alignbit(hr, lr, 30), Vl = lr << 2; fh[1] = Vh >> sh; fl[1] = __builtin_amdgcn_alignbit(Vh, Vl, sh); }
     uint32_t rh, rl;
     {
         const uint32_t H = c2_swap_pairs(__builtin_bitreverse32(~fl[0])), Lo = c2_swap_pairs(__builtin_bitreverse32(~fh[0]));
@@ -975,7 +1006,7 @@ __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t 
         rl = __builtin_amdgcn_alignbit(H, Lo, sh);
     }
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < 2; u++) {
         if (u) {
             rl = __builtin_amdgcn_alignbit(rh, rl, 2);
             rh = (rh >> 2) | (((~fl[u]) & 3u) << nb);
@@ -984,66 +1015,64 @@ __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t 
         ch[u] = lt ? fh[u] : rh;
         cl[u] = lt ? fl[u] : rl;
     }
-    uint32_t s[4], ka[4]; uint64_t key[4], ret[4]; unsigned long long live[4];
-    live[0] = c2_gt<0>(nk); live[1] = c2_gt<1>(nk); live[2] = c2_gt<2>(nk); live[3] = c2_gt<3>(nk);
+    uint32_t s[2], ka[2]; uint64_t key[2], ret[2]; unsigned long long live[2];
+    live[0] = c2_gt<0>(nk); live[1] = c2_gt<1>(nk);
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < 2; u++) {
         key[u] = ((uint64_t)ch[u] << 32) | cl[u];
         s[u] = c2_slot(ch[u], cl[u]);
         ka[u] = L.tk0 + 8u * s[u];
     }
-    // ---- probes (= claims) of this step + the NEXT step's item, one wait
-    uint32_t it_n; unsigned long long save;
-    const uint32_t ia_n = L.items0 + 2u * (i0 + 64u + lane);
-    if (ablate & 16) { if ((ka[0] ^ ka[1] ^ ka[2] ^ ka[3]) == 0x12345u) *part_over = 1u; ret[0] = ret[1] = ret[2] = ret[3] = 0; live[0] = live[1] = live[2] = live[3] = 0;
-        asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(it_n) : "v"(ia_n) : "memory"); }
-    else
-    asm volatile("s_mov_b64 %5, exec\n\tds_read_u16 %4, %6\n\t"
-                 "s_mov_b64 exec, %7\n\tds_cmpst_rtn_b64 %0, %11, %15, %16\n\t"
-                 "s_mov_b64 exec, %8\n\tds_cmpst_rtn_b64 %1, %12, %15, %17\n\t"
-                 "s_mov_b64 exec, %9\n\tds_cmpst_rtn_b64 %2, %13, %15, %18\n\t"
-                 "s_mov_b64 exec, %10\n\tds_cmpst_rtn_b64 %3, %14, %15, %19\n\t"
-                 "s_mov_b64 exec, %5\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(ret[0]), "=&v"(ret[1]), "=&v"(ret[2]), "=&v"(ret[3]), "=&v"(it_n), "=&s"(save)
-                 : "v"(ia_n), "s"(live[0]), "s"(live[1]), "s"(live[2]), "s"(live[3]), "v"(ka[0]), "v"(ka[1]), "v"(ka[2]), "v"(ka[3]),
-                   "v"(MF_EMPTY), "v"(key[0]), "v"(key[1]), "v"(key[2]), "v"(key[3])
-                 : "memory");
-    unsigned long long won[4], ok[4], coll[4]; uint32_t aa[4];
+    if (P > 1u) {                                   // a partition counted in P passes: this pass takes the keys of its residue class
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 2; u++) live[u] &= c2_lt_u32((skm_pass_of(key[u]) & (P - 1u)) ^ pass, 1u);
+    }
+    // ---- probes (= claims) of this step, the NEXT step's record and the item of the step after that: one block, one wait.
+    // (Everything an asm block reads ahead is waited for inside the same block: a register that is still in flight when the
+    // block ends may be copied or spilled by the compiler before the data has landed.)
+    uint32_t it2; skm_v4 W_n; unsigned long long save;
+    const uint32_t ia2 = L.items0 + 2u * (i0 + 128u + lane);
+    const uint32_t ra1 = L.rb0 | (it1 & 0x3F0u);                           // (rb0 is 1024-byte aligned)
+    if (ablate & 16) { if ((ka[0] ^ ka[1]) == 0x12345u) *part_over = 1u; ret[0] = ret[1] = 0; live[0] = live[1] = 0;
+        asm volatile("ds_read_u16 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(it2), "=&v"(W_n) : "v"(ia2), "v"(ra1) : "memory"); }
+    else
+    asm volatile("s_mov_b64 %4, exec\n\tds_read_u16 %2, %5\n\tds_read_b128 %3, %6\n\t"
+                 "s_mov_b64 exec, %7\n\tds_cmpst_rtn_b64 %0, %9, %11, %12\n\t"
+                 "s_mov_b64 exec, %8\n\tds_cmpst_rtn_b64 %1, %10, %11, %13\n\t"
+                 "s_mov_b64 exec, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(ret[0]), "=&v"(ret[1]), "=&v"(it2), "=&v"(W_n), "=&s"(save)
+                 : "v"(ia2), "v"(ra1), "s"(live[0]), "s"(live[1]), "v"(ka[0]), "v"(ka[1]), "v"(MF_EMPTY), "v"(key[0]), "v"(key[1])
+                 : "memory");
+    unsigned long long won[2], ok[2], coll[2]; uint32_t aa[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
         won[u] = live[u] & c2_eq_u64(ret[u], MF_EMPTY);
         ok[u] = won[u] | (live[u] & c2_eq_u64(ret[u], key[u]));
         coll[u] = live[u] & ~ok[u];
         aa[u] = L.tc0 + 4u * s[u];
     }
-    // ---- count updates of this step + the NEXT step's record (waited for at the end of the step)
-    skm_v4 W_n;
-    const uint32_t ra_n = L.rb0 | (it_n & 0x3F0u);                         // (rb0 is 1024-byte aligned)
+    // ---- count updates of this step (nothing to wait for)
     const uint32_t one = 1u;
-    asm volatile("s_mov_b64 %1, exec\n\tds_read_b128 %0, %2\n\t"
-                 "s_mov_b64 exec, %3\n\tds_add_u32 %7, %11\n\t"
-                 "s_mov_b64 exec, %4\n\tds_add_u32 %8, %11\n\t"
-                 "s_mov_b64 exec, %5\n\tds_add_u32 %9, %11\n\t"
-                 "s_mov_b64 exec, %6\n\tds_add_u32 %10, %11\n\t"
-                 "s_mov_b64 exec, %1"
-                 : "=&v"(W_n), "=&s"(save)
-                 : "v"(ra_n), "s"(ok[0]), "s"(ok[1]), "s"(ok[2]), "s"(ok[3]), "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(one)
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\tds_add_u32 %3, %5\n\t"
+                 "s_mov_b64 exec, %2\n\tds_add_u32 %4, %5\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save)
+                 : "s"(ok[0]), "s"(ok[1]), "v"(aa[0]), "v"(aa[1]), "v"(one)
                  : "memory");
     if (!(ablate & 8)) {
+        won_acc += (uint32_t)__popcll(won[0]) + (uint32_t)__popcll(won[1]);
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
-        if (won[u] != 0ull) { c2_note(L, won[u], s[u], ncl); won_acc += (uint32_t)__popcll(won[u]); }
-        if (coll[u] != 0ull) {
-            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(coll[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)coll[u], qn));
-            c2_push64(coll[u], L.qk0 + 8u * at, key[u]);
-            qn += (uint32_t)__popcll(coll[u]);
+        for (int u = 0; u < 2; u++) {
+            if (coll[u] != 0ull) {
+                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(coll[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)coll[u], qn));
+                c2_push64(coll[u], L.qk0 + 8u * at, key[u]);
+                qn += (uint32_t)__popcll(coll[u]);
+                while (qn >= 64u) { if (ablate & 4) qn = 0; else c2_drain(L, qn, won_acc, part_over); }       // (then qn < 64: + one push <= C2_QN)
+            }
         }
-        if ((u & 1) && qn >= 64u) { if (ablate & 4) qn = 0; else c2_drain(L, qn, ncl, part_over, blk_claims); }       // (qn < 64 + 128 <= C2_QN)
     }
-    }
-    // the next step's record must have landed before anything touches its registers
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W_n), "+v"(it_n) :: "memory");
-    it = it_n; W = W_n;
+    it = it1; W = W_n; it1 = it2;
 }
 
 // PROF: cycle counters per phase (diagnostics, option ablate & 32; s_memtime perturbs the kernel by about a tenth)
@@ -1056,7 +1085,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count2(const skm_rec *__restr
                                                            unsigned int *__restrict__ overflow, uint32_t p0, uint64_t tbase, int thr,
                                                            unsigned long long *__restrict__ n_all, uint32_t *__restrict__ redo,
                                                            unsigned int *__restrict__ n_redo, unsigned long long *__restrict__ drop_hist, int ablate,
-                                                           unsigned long long *__restrict__ prof_out) {
+                                                           unsigned long long *__restrict__ prof_out, uint64_t tcap) {
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = PROF ? clock64() : 0;
     // partitions [p0, np); slice of p in tkeys / tcnt starts at toff[p] - tbase; thr >= 0: entries with count <= thr are
     // dropped and tallied in drop_hist[count] (thr < C2_LH); *n_all += distinct k-mers before the cut
@@ -1065,28 +1094,26 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count2(const skm_rec *__restr
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const uint32_t wave = threadIdx.x >> 6, lane = (uint32_t)mf_lane();
     skm_v4 *rbuf_all = reinterpret_cast<skm_v4 *>(smem);                        // [SKM_CT] parked records (1 KiB per wave, aligned)
-    uint64_t *tk = reinterpret_cast<uint64_t *>(rbuf_all + SKM_CT);             // [MF_COUNT_SLOTS]
-    uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS);           // [MF_COUNT_SLOTS]
-    uint16_t *items_all = reinterpret_cast<uint16_t *>(tc + MF_COUNT_SLOTS);    // [waves][C2_ITEMS]
+    uint64_t *tk = reinterpret_cast<uint64_t *>(rbuf_all + SKM_CT);             // [C2_SLOTS]
+    uint32_t *tc = reinterpret_cast<uint32_t *>(tk + C2_SLOTS);           // [C2_SLOTS]
+    uint16_t *items_all = reinterpret_cast<uint16_t *>(tc + C2_SLOTS);    // [waves][C2_ITEMS]
     uint64_t *qk_all = reinterpret_cast<uint64_t *>(items_all + (SKM_CT / 64) * C2_ITEMS);   // [waves][C2_QN]
-    uint16_t *cl_all = reinterpret_cast<uint16_t *>(qk_all + (SKM_CT / 64) * C2_QN);         // [waves][C2_CLN]
-    uint32_t *lhist = reinterpret_cast<uint32_t *>(cl_all + (SKM_CT / 64) * C2_CLN);         // [C2_LH]
-    uint32_t (*pflags)[2] = reinterpret_cast<uint32_t (*)[2]>(lhist + C2_LH);                // [parity][0] sweep_all, [parity][1] part_over
-    uint32_t &out_cursor = lhist[C2_LH + 4], &all_cursor = lhist[C2_LH + 5], &blk_claims = lhist[C2_LH + 6];
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(qk_all + (SKM_CT / 64) * C2_QN);          // [C2_LH] dropped counts, committed
+    uint32_t *lhist_try = lhist + C2_LH;                                                     // [C2_LH] ... of the running attempt at a partition
+    uint32_t (*pflags)[2] = reinterpret_cast<uint32_t (*)[2]>(lhist_try + C2_LH);            // [parity][1] part_over
+    uint32_t &out_cursor = lhist_try[C2_LH + 4], &blk_claims = lhist_try[C2_LH + 6];
     c2_wave L;
     L.tk0 = mf_lds_addr(tk); L.tc0 = mf_lds_addr(tc);
     L.rb0 = mf_lds_addr(rbuf_all + wave * 64);
     L.items0 = mf_lds_addr(items_all + wave * C2_ITEMS);
     L.qk0 = mf_lds_addr(qk_all + wave * C2_QN);
-    L.cl0 = mf_lds_addr(cl_all + wave * C2_CLN);
-    uint16_t *cl = cl_all + wave * C2_CLN;
-    uint32_t qn = 0, ncl = 0, won_acc = 0;                                      // wave-uniform
-    unsigned long long all_acc = 0;                                             // thread 0
+    uint32_t qn = 0, won_acc = 0;                                               // wave-uniform
+    unsigned long long all_acc = 0;                                             // per wave: distinct k-mers of its share of the tables
     uint32_t ones_acc = 0;                                                      // per wave: dropped entries with count 1
     // the table is cleared ONCE; after that every partition leaves it clean (its compaction clears the slots it claimed)
-    for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += (uint32_t)SKM_CT) { tk[i] = MF_EMPTY; tc[i] = 0; }
-    for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) lhist[i] = 0;
-    if (threadIdx.x == 0) { out_cursor = 0; all_cursor = 0; blk_claims = 0; pflags[0][0] = pflags[0][1] = pflags[1][0] = pflags[1][1] = 0; }
+    for (uint32_t i = threadIdx.x; i < (uint32_t)C2_SLOTS; i += (uint32_t)SKM_CT) { tk[i] = MF_EMPTY; tc[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < 2u * (uint32_t)C2_LH; i += (uint32_t)SKM_CT) lhist[i] = 0;
+    if (threadIdx.x == 0) { out_cursor = 0; blk_claims = 0; pflags[0][0] = pflags[0][1] = pflags[1][0] = pflags[1][1] = 0; }
     const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
     const uint32_t mine = (lane >> 3) * 64u + wave * 8u + (lane & 7u);          // this lane's record within a round of 512
     uint32_t pi = p0 + blockIdx.x;
@@ -1103,135 +1130,198 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count2(const skm_rec *__restr
         if (!ok) v = SENT;
         return v;
     };
-    // the first TWO rounds of a partition are in registers before it starts (the second one used to cost an exposed HBM
-    // round trip per partition once partitions grew past 512 records)
-    skm_rec R0 = load_rec(start, mine, len), R1 = load_rec(start, (uint32_t)SKM_CT + mine, len);
-    uint64_t start_n = 0, o_n = 0; uint32_t len_n = 0, room_n = 0;
-    if (pi + gridDim.x < np) { const uint32_t qq = pi + gridDim.x; start_n = pstart[qq]; len_n = plen[qq]; o_n = toff[qq] - tbase; room_n = (uint32_t)(toff[qq + 1] - toff[qq]); }
+    // the first round of a partition is in registers before the partition starts; every further round is fetched while
+    // the round before it is worked on
+    skm_rec R0 = load_rec(start, mine, len);
+    // Directory entries are fetched TWO partitions ahead by scalar loads (they live in SGPRs: as vector loads they cost 14
+    // VGPRs of a budget of 80).  A scalar load is counted in lgkmcnt, so the next LDS wait sits out its memory latency: they
+    // are issued right in front of the first barrier of a partition, where the wave waits anyway.
+    struct dirent { uint64_t start, toff0, toff1; uint32_t len; };
+    auto load_dir = [&](uint32_t i) -> dirent {
+        dirent d;
+        d.start = pstart[i]; d.len = plen[i]; d.toff0 = toff[i]; d.toff1 = toff[i + 1];
+        return d;
+    };
+    dirent dn = {0, 0, 0, 0};
+    if (pi + gridDim.x < np) dn = load_dir(pi + gridDim.x);
     __syncthreads();
-    for (uint32_t parity = 0;; parity ^= 1u) {
+    uint32_t parity = 0;
+    for (;;) {
         const uint32_t pn = pi + gridDim.x, pnn = pn + gridDim.x;
-        uint64_t start_nn = 0, o_nn = 0; uint32_t len_nn = 0, room_nn = 0;
-        if (pnn < np) { start_nn = pstart[pnn]; len_nn = plen[pnn]; o_nn = toff[pnn] - tbase; room_nn = (uint32_t)(toff[pnn + 1] - toff[pnn]); }
-        skm_rec cur = R0, cur1 = R1;
-        if (pn < np) { R0 = load_rec(start_n, mine, len_n); R1 = load_rec(start_n, (uint32_t)SKM_CT + mine, len_n); }      // next partition
-        uint32_t *part_over = &pflags[parity][1];
+        dirent dnn = {0, 0, 0, 0};
+        bool dir_loaded = false;
+        skm_rec cur = R0;
+        const uint64_t start_n = dn.start;
+        const uint32_t len_n = dn.len;
+        if (pn < np) R0 = load_rec(start_n, mine, len_n);                      // next partition
         C2_TICK(0);                                                             // partition top: directory, record prefetch
+        // A partition with more distinct k-mers than the table takes (a heavy minimizer: low-complexity sequence between many
+        // different flanks) is counted again in P = 4, 16, 64 passes over its records, pass i inserting the k-mers with
+        // skm_pass_of(key) mod P = i; the passes append to the same slice.  More than 64 passes: the global overflow flag,
+        // and the caller falls back to the k-mer path.  What a failed attempt tallied is not committed.
+        uint32_t P = 1, pass = 0, ones_try = 0, all_try = 0;
+        for (;;) {
+        P = (uint32_t)__builtin_amdgcn_readfirstlane((int)P); pass = (uint32_t)__builtin_amdgcn_readfirstlane((int)pass);      // (uniform: say so)
+        uint32_t *part_over = &pflags[parity][1];
+        if (P > 1u) cur = load_rec(start, mine, len);
         for (uint32_t rb = 0; rb < len; rb += (uint32_t)SKM_CT) {
-            if (rb == (uint32_t)SKM_CT) cur = cur1;
-            else if (rb) {
-                if (c2_lds_u32(part_over)) break;                               // (abandoned)
-                cur = load_rec(start, rb + mine, len);
-            }
+            if (rb && c2_lds_u32(part_over)) break;                             // (abandoned)
+            skm_rec nxt = SENT;
+            if (rb + (uint32_t)SKM_CT < len) nxt = load_rec(start, rb + (uint32_t)SKM_CT + mine, len);      // the round after this one
             const uint32_t r = skm_rec_valid(cur) ? skm_rec_n(cur) : 0u;
-            const uint32_t nch = (r + 3u) >> 2;
+            const uint32_t nch = (r + (uint32_t)(C2_W - 1)) / (uint32_t)C2_W;
             uint32_t NI;
             const uint32_t ioff = mf_wave_excl_scan(nch, &NI);
-            if (NI == 0) continue;                                              // wave-uniform
+            if (NI == 0) { cur = nxt; continue; }                               // wave-uniform
             {   // park the record shifted right by one bit (bases only)
                 const uint32_t x1 = (uint32_t)(cur.x >> 32), x0 = (uint32_t)cur.x, y1 = (uint32_t)(cur.y >> 32), y0 = (uint32_t)cur.y & 0xF0000000u;
-                skm_v4 P;
-                P.x = x1 >> 1; P.y = __builtin_amdgcn_alignbit(x1, x0, 1); P.z = __builtin_amdgcn_alignbit(x0, y1, 1); P.w = __builtin_amdgcn_alignbit(y1, y0, 1);
-                *reinterpret_cast<__attribute__((address_space(3))) skm_v4 *>((uintptr_t)(L.rb0 + 16u * lane)) = P;
+                skm_v4 Pk;
+                Pk.x = x1 >> 1; Pk.y = __builtin_amdgcn_alignbit(x1, x0, 1); Pk.z = __builtin_amdgcn_alignbit(x0, y1, 1); Pk.w = __builtin_amdgcn_alignbit(y1, y0, 1);
+                *reinterpret_cast<__attribute__((address_space(3))) skm_v4 *>((uintptr_t)(L.rb0 + 16u * lane)) = Pk;
             }
 #pragma unroll
-            for (int c = 0; c < 6; c++) {
-                // chunk c starts at bit 8c+1 of the parked record: funnel shift (32 - (8c+1)) & 31, second word from c = 4
+            for (int c = 0; c < 20 / C2_W; c++) {
+                // item c starts at bit 4c+1 of the parked record: funnel shift (32 - (4c+1)) & 31, second word from c = 8
                 if ((uint32_t)c < nch) {
-                    const uint32_t left = r - 4u * (uint32_t)c;
-                    const uint32_t e = (left < 4u ? left : 4u) | (lane << 4) | ((uint32_t)((31 - 8 * c) & 31) << 10) | ((uint32_t)(c >> 2) << 15);
+                    const uint32_t left = r - (uint32_t)(C2_W * c);
+                    const uint32_t e = (left < (uint32_t)C2_W ? left : (uint32_t)C2_W) | (lane << 4) | ((uint32_t)((31 - 2 * C2_W * c) & 31) << 10) | ((uint32_t)((2 * C2_W * c + 1) >> 5) << 15);
                     *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (ioff + (uint32_t)c))) = (uint16_t)e;
                 }
             }
             // one step of padding after the list: items without k-mers for the idle lanes of the last step (the step after
             // that is only read ahead, never used)
             *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (NI + lane))) = (uint16_t)0;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // LDS of one wave is in order: visible to its lanes
+            *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (NI + 64u + lane))) = (uint16_t)0;
             __builtin_amdgcn_wave_barrier();
+            uint32_t it, it1; skm_v4 W;
+            // (LDS operations of one wave execute in order: the reads see the stores above without a wait in between)
+            asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(it), "=&v"(it1) : "v"(L.items0 + 2u * lane) : "memory");
+            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(W) : "v"(L.rb0 | (it & 0x3F0u)) : "memory");
             C2_TICK(1);                                                         // round set-up (incl. the wait for the records)
-            if (!(ablate & 1)) {
-                uint32_t it; skm_v4 W;
-                asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(it) : "v"(L.items0 + 2u * lane) : "memory");
-                asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(W) : "v"(L.rb0 | (it & 0x3F0u)) : "memory");
-                for (uint32_t i0 = 0; i0 < NI; i0 += 64) c2_step<K>(L, i0, it, W, qn, ncl, won_acc, part_over, &blk_claims, ablate);      // wave-uniform
-            }
-            // a crowded table probes slowly: past SKM_FILL claims the partition is handed to the multi-pass kernel
-            if (won_acc) { if (lane == 0 && atomicAdd(&blk_claims, won_acc) + won_acc > (uint32_t)SKM_FILL) *part_over = 1u; won_acc = 0; }
+            if (!(ablate & 1))
+                for (uint32_t i0 = 0; i0 < NI; i0 += 64) c2_step<K>(L, i0, it, W, it1, qn, won_acc, part_over, ablate, P, pass);      // wave-uniform
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
             __builtin_amdgcn_wave_barrier();
             C2_TICK(2);                                                         // steps (with the drains inside them)
+            cur = nxt;
         }
         if (ablate & 6) qn = 0;
-        while (qn) c2_drain(L, qn, ncl, part_over, &blk_claims);               // wave-uniform
-        if (ncl > (uint32_t)C2_CLN && lane == 0) pflags[parity][0] = 1;        // this wave's list is incomplete: sweep the whole table
+        while (qn) c2_drain(L, qn, won_acc, part_over);                        // wave-uniform
+        // a crowded table probes slowly: past C2_FILL claims the partition is counted in (more) passes
+        if (won_acc) { if (lane == 0) atomicAdd(&blk_claims, won_acc); won_acc = 0; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS operations of the asm blocks are invisible to hipcc's waitcnt pass
         C2_TICK(3);                                                             // last drains
-        __syncthreads();                                                        // ---- B1: every insert of the partition is done
+        if (!dir_loaded) { dir_loaded = true; if (pnn < np) dnn = load_dir(pnn); }
+        c2_barrier();                                                           // ---- B1: every insert of the pass is done
         C2_TICK(4);                                                             // waiting for the other waves
-        const uint64_t pf = (uint64_t)c2_lds_u32(&pflags[parity][0]) | ((uint64_t)c2_lds_u32(&pflags[parity][1]) << 32);
-        const bool crowded = c2_lds_u32(&blk_claims) > (uint32_t)SKM_FILL;     // (claims reported by the drains after the last round)
-        if (threadIdx.x == 0) *reinterpret_cast<uint64_t *>(pflags[parity ^ 1u]) = 0ull;      // for the next partition
-        const uint64_t lt_mask = (1ull << lane) - 1ull;
-        if ((uint32_t)(pf >> 32) || crowded) {
-            // more distinct k-mers than the table takes: wipe it, the partition goes to the redo list (multi-pass kernel)
-            for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += (uint32_t)SKM_CT) { tk[i] = MF_EMPTY; tc[i] = 0; }
-            if (threadIdx.x == 0) redo[atomicAdd(n_redo, 1u)] = p;
-        } else if (!(uint32_t)pf) {
-            // compaction over the claimed slots: every wave walks ITS list, writes the entries that pass the cut, tallies
-            // the ones that do not, and leaves the slots empty for the next partition
-            if (lane == 0 && ncl) atomicAdd(&all_cursor, ncl);
-            for (uint32_t i0 = 0; i0 < ncl; i0 += 64) {             // wave-uniform
-                const bool have = i0 + lane < ncl;
-                uint32_t sl = 0; uint64_t key = MF_EMPTY; uint32_t cnt = 0;
-                if (have) { sl = cl[i0 + lane]; key = tk[sl]; cnt = tc[sl]; tk[sl] = MF_EMPTY; tc[sl] = 0; }
-                if (cnt > (uint32_t)MF_MAX_COUNT) cnt = (uint32_t)MF_MAX_COUNT;
-                const bool keep = have && (int)cnt > thr;           // (thr < 0 keeps everything)
-                if (thr >= 0) {
-                    ones_acc += (uint32_t)__popcll(__ballot(have && !keep && cnt == 1u));
-                    if (have && !keep && cnt != 1u) atomicAdd(&lhist[cnt], 1u);
-                }
-                const unsigned long long bal = __ballot(keep);
-                uint32_t wb = 0;
-                if (lane == 0 && bal) wb = atomicAdd(&out_cursor, (uint32_t)__popcll(bal));
-                wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb) + (uint32_t)__popcll(bal & lt_mask);
-                if (keep && wb < room) { tkeys[o + wb] = key; tcnt[o + wb] = (uint16_t)cnt; }
-                if (keep && wb >= room) atomicExch(overflow, 1u);   // (only if a partition's k-mer count wrapped)
-            }
-        } else {
-            // full sweep (a wave's claim list ran over): 64-slot chunks per wave (lane = slot: conflict-free)
-            constexpr int NCH = MF_COUNT_SLOTS / SKM_CT;
+        const bool over = c2_lds_u32(part_over) != 0u || c2_lds_u32(&blk_claims) > (uint32_t)C2_FILL;
+        if (threadIdx.x == 0) pflags[parity ^ 1u][1] = 0;                      // for the next pass / partition
+        // ---- compaction: every wave sweeps ITS eighth of the table (consecutive slots, lane = slot: conflict-free),
+        // 4 chunks of 64 in flight: keys are read and reset with one exchange, the counts of the occupied slots likewise.
+        // (Claim lists -- visit only the slots that were won -- cost a list append per key slot in the hot loop and four
+        // dependent LDS round trips per 64 entries here; with the table 2/5 full the sweep is cheaper on both counts.)
+        {
+            constexpr int NCH = 4;                                      // chunks in flight
+            static_assert(C2_SLOTS % (8 * 64 * NCH) == 0, "sweep: whole groups of four chunks per wave");
 #pragma unroll 1
-            for (int i = 0; i < NCH; i++) {
-                const uint32_t sl = (wave << 6) + (uint32_t)i * SKM_CT + lane;
-                const uint64_t key = tk[sl]; uint32_t cnt = tc[sl];
-                tk[sl] = MF_EMPTY; tc[sl] = 0;
-                const bool have = key != MF_EMPTY;
-                if (cnt > (uint32_t)MF_MAX_COUNT) cnt = (uint32_t)MF_MAX_COUNT;
-                const bool keep = have && (int)cnt > thr;
-                const unsigned long long hb = __ballot(have);
-                if (lane == 0 && hb) atomicAdd(&all_cursor, (uint32_t)__popcll(hb));
-                if (thr >= 0) {
-                    ones_acc += (uint32_t)__popcll(__ballot(have && !keep && cnt == 1u));
-                    if (have && !keep && cnt != 1u) atomicAdd(&lhist[cnt], 1u);
+            for (uint32_t g = 0; g < (uint32_t)(C2_SLOTS / (8 * 64 * NCH)); g++) {
+            uint64_t ck[NCH]; uint32_t cc[NCH]; unsigned long long have[NCH], keep[NCH];
+            const uint32_t sl0 = wave * (uint32_t)(C2_SLOTS / 8) + g * (uint32_t)(64 * NCH) + lane;
+            const uint32_t ka0 = L.tk0 + 8u * sl0, ca0 = L.tc0 + 4u * sl0;
+            const uint64_t E = MF_EMPTY; const uint32_t zero = 0u;
+            asm volatile("ds_wrxchg_rtn_b64 %0, %4, %5\n\tds_wrxchg_rtn_b64 %1, %4, %5 offset:512\n\tds_wrxchg_rtn_b64 %2, %4, %5 offset:1024\n\t"
+                         "ds_wrxchg_rtn_b64 %3, %4, %5 offset:1536\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(ck[0]), "=&v"(ck[1]), "=&v"(ck[2]), "=&v"(ck[3])
+                         : "v"(ka0), "v"(E) : "memory");
+            unsigned long long anyhave = 0ull;
+#pragma unroll
+            for (int i = 0; i < NCH; i++) { have[i] = ~c2_eq_u64(ck[i], MF_EMPTY) & __builtin_amdgcn_ballot_w64(true); anyhave |= have[i]; cc[i] = 0u; }
+            {   // (all lanes: an exchange costs the same for 8 lanes as for 64)
+                asm volatile("ds_wrxchg_rtn_b32 %0, %4, %5\n\tds_wrxchg_rtn_b32 %1, %4, %5 offset:256\n\tds_wrxchg_rtn_b32 %2, %4, %5 offset:512\n\t"
+                             "ds_wrxchg_rtn_b32 %3, %4, %5 offset:768\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(cc[0]), "=&v"(cc[1]), "=&v"(cc[2]), "=&v"(cc[3])
+                             : "v"(ca0), "v"(zero) : "memory");
+                if (prof_out) {                                 // diagnostics: counters that were not zero under an empty key
+                    uint32_t bad = 0;
+#pragma unroll
+                    for (int i = 0; i < NCH; i++) bad += (uint32_t)__popcll(~have[i] & c2_lt_u32(0u, cc[i]) & __builtin_amdgcn_ballot_w64(true));
+                    if (bad && lane == 0) atomicAdd(&prof_out[7], (unsigned long long)bad);
                 }
-                const unsigned long long bal = __ballot(keep);
+            }
+            if (!over) {
+                uint32_t nkeep = 0, nhave = 0;
+#pragma unroll
+                for (int i = 0; i < NCH; i++) {
+                    if (cc[i] > (uint32_t)MF_MAX_COUNT) cc[i] = (uint32_t)MF_MAX_COUNT;
+                    keep[i] = thr >= 0 ? (have[i] & c2_lt_u32((uint32_t)thr, cc[i])) : have[i];
+                    nkeep += (uint32_t)__popcll(keep[i]); nhave += (uint32_t)__popcll(have[i]);
+                    if (thr >= 0) {
+                        const unsigned long long drop = have[i] & ~keep[i];
+                        if (drop != 0ull) {
+                            const unsigned long long d1 = drop & c2_lt_u32(cc[i], 2u);       // (count 1: nearly all of them)
+                            ones_try += (uint32_t)__popcll(d1);
+                            if ((drop & ~d1) != 0ull && ((drop & ~d1) >> lane) & 1ull) atomicAdd(&lhist_try[cc[i]], 1u);
+                        }
+                    }
+                }
+                all_try += nhave;
                 uint32_t wb = 0;
-                if (lane == 0 && bal) wb = atomicAdd(&out_cursor, (uint32_t)__popcll(bal));
-                wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb) + (uint32_t)__popcll(bal & lt_mask);
-                if (keep && wb < room) { tkeys[o + wb] = key; tcnt[o + wb] = (uint16_t)cnt; }
-                if (keep && wb >= room) atomicExch(overflow, 1u);
+                if (lane == 0 && nkeep) wb = atomicAdd(&out_cursor, nkeep);
+                wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb);
+                if (nkeep && (wb + nkeep > room || o + wb + nkeep > tcap)) {                   // (only if a partition's k-mer count wrapped)
+                    if (lane == 0) {
+                        if (atomicExch(overflow, 2u) == 0u && prof_out) {
+                            prof_out[8] = p; prof_out[9] = o; prof_out[10] = room; prof_out[11] = wb; prof_out[12] = nkeep; prof_out[13] = tcap;
+                            prof_out[14] = p0; prof_out[15] = np;
+                        }
+                    }
+                }
+                else {
+#pragma unroll
+                    for (int i = 0; i < NCH; i++) {
+                        if (keep[i] != 0ull) {
+                            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(keep[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)keep[i], wb));
+                            if ((keep[i] >> lane) & 1ull) { tkeys[o + at] = ck[i]; tcnt[o + at] = (uint16_t)cc[i]; }
+                            wb += (uint32_t)__popcll(keep[i]);
+                        }
+                    }
+                }
             }
         }
-        ncl = 0; qn = 0;
+        }
+        qn = 0;
         C2_TICK(5);                                                             // compaction
-        __syncthreads();                                                        // ---- B2: the table is clean, the cursors final
+        c2_barrier();                                                           // ---- B2: the table is clean, the cursor final
         C2_TICK(6);
-        if (threadIdx.x == 0) { dcount[p] = out_cursor; all_acc += all_cursor; out_cursor = 0; all_cursor = 0; blk_claims = 0; }
+        parity ^= 1u;
+        if (threadIdx.x == 0) blk_claims = 0;
+        bool done = false;
+        if (over) {
+            // start again with four times the passes; nothing of this attempt counts
+            ones_try = 0; all_try = 0; pass = 0;
+            if (threadIdx.x == 0) out_cursor = 0;
+            if (thr >= 0) for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) lhist_try[i] = 0;
+            if (P >= (uint32_t)SKM_MAX_PASSES) { if (threadIdx.x == 0) atomicExch(overflow, 1u); done = true; }
+            P *= 4u;
+            if (threadIdx.x == 0 && n_redo && P == 4u) atomicAdd(n_redo, 1u);    // (statistics: partitions counted in several passes)
+        } else if (++pass == P) {
+            done = true;
+            ones_acc += ones_try; all_acc += all_try;
+            if (thr >= 2) for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) { const uint32_t v = lhist_try[i]; if (v) { atomicAdd(&lhist[i], v); lhist_try[i] = 0; } }
+        }
+        if (done) break;
+        c2_barrier();                                                           // (the cursor / the tallies are reset before the next pass appends)
+        }
+        if (threadIdx.x == 0) { dcount[p] = out_cursor; out_cursor = 0; }
         if (pn >= np) break;
-        pi = pn; p = pn; start = start_n; len = len_n; o = o_n; room = room_n;
-        start_n = start_nn; len_n = len_nn; o_n = o_nn; room_n = room_nn;
+        pi = pn; p = pn; start = start_n; len = len_n;
+        o = dn.toff0 - tbase;
+        room = (uint32_t)(dn.toff1 - dn.toff0);
+        dn = dnn;
     }
-    if (threadIdx.x == 0 && n_all && all_acc) atomicAdd(n_all, all_acc);
+    {   // distinct k-mers before the cut: one atomic per wave
+        if (lane == 0 && n_all && all_acc) atomicAdd(n_all, all_acc);
+    }
     if (PROF && lane == 0 && prof_out) for (int i = 0; i < 8; i++) atomicAdd(&prof_out[i], prof[i]);
     if (thr >= 0 && drop_hist) {
         if (lane == 0 && ones_acc) atomicAdd(&lhist[1], ones_acc);
@@ -1426,7 +1516,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     const bool count2 = ctx->opt_count2 != 0 && thr < C2_LH;
     const bool c2prof = count2 && K == 31 && (ctx->opt_ablate & 32);
     mf_buf<unsigned long long> c2p;
-    if (c2prof) { MF_TRY(c2p.alloc(ctx, 8)); MF_HIP(hipMemsetAsync(c2p.p, 0, 64, st)); }
+    if (count2) { MF_TRY(c2p.alloc(ctx, 16)); MF_HIP(hipMemsetAsync(c2p.p, 0, 128, st)); }
     if (count2) {
         MF_TRY(skm_set_lds(k_skm_count2<K, false>, C2_LDS));
         if (K == 31) MF_TRY(skm_set_lds(k_skm_count2<(K == 31 ? 31 : 20), true>, C2_LDS));
@@ -1441,19 +1531,21 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         if (p0 == p1) continue;
         {
             const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 6 * 2 + (size_t)(SKM_CT / 64) * (SKM_QN * 10 + SKM_CLN * 2);
-            const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);
+            const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);      // resident workgroups
             MF_HIP(hipMemsetAsync(&scal[8], 0, 8, st));
             mf_ktimer t(ctx, "k_skm_count");
             if (c2prof)
                 k_skm_count2<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
-                                                             p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p);
+                                                             p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p, (uint64_t)tmax);
             else if (count2)
                 k_skm_count2<K, false><<<grid, SKM_CT, C2_LDS, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
-                                                             p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, nullptr);
+                                                             p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p, (uint64_t)tmax);
             else
                 k_skm_count<K, false><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
                                                                  (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p);
-            // the partitions that did not fit (normally none: the workgroups find an empty list and leave)
+            // the partitions that did not fit (normally none: the workgroups find an empty list and leave); the second-generation
+            // kernel counts those in several passes itself
+            if (!count2)
             k_skm_count<K, true><<<std::min<unsigned>(grid, 64u), SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p,
                                                                                        (unsigned int *)&scal[2], (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr,
                                                                                        &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p);
@@ -1463,8 +1555,23 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         unsigned long long res[2];
         MF_HIP(hipMemcpyAsync(res, &scal[2], 16, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
+        if (ctx->opt_verbose) {
+            unsigned long long nr = 0;
+            MF_HIP(hipMemcpy(&nr, &scal[8], 8, hipMemcpyDeviceToHost));
+            if (nr & 0xFFFFFFFFull) fprintf(stderr, "[mf] skm: batch %u: %llu partition(s) counted in several passes\n", b, nr & 0xFFFFFFFFull);
+        }
+        if (ctx->opt_verbose && count2) {
+            unsigned long long bad = 0;
+            MF_HIP(hipMemcpy(&bad, &c2p.p[7], 8, hipMemcpyDeviceToHost));
+            if (bad && !c2prof) fprintf(stderr, "[mf] skm: batch %u: %llu counter(s) found non-zero under an empty key so far\n", b, bad);
+        }
         if (res[0]) {
-            if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: a minimizer partition overflows the LDS table, using the k-mer path\n");
+            if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: a minimizer partition overflows the LDS table (code %llu), using the k-mer path\n", res[0]);
+            if (ctx->opt_verbose && count2 && res[0] == 2) {
+                unsigned long long h[16];
+                MF_HIP(hipMemcpy(h, c2p.p, 128, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[mf]   p=%llu o=%llu room=%llu wb=%llu nkeep=%llu tcap=%llu p0=%llu np=%llu (batch %u: tb=%llu..%llu)\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], b, tb[b], tb[b + 1]);
+            }
             MF_HIP(hipMemsetAsync(&scal[2], 0, 8, st));
             return MF_SKM_FALLBACK;
         }

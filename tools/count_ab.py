@@ -36,7 +36,7 @@ ref = None
 for c2, pt, ab in variants:
     ctx.set_option("count2", c2)
     ctx.set_option("ablate", ab)
-    ctx.set_option("verbose", 1 if ab in (0, 32) else 0)
+    ctx.set_option("verbose", int(os.environ.get("MF_VERBOSE", "1")) if ab in (0, 32) else 0)
     ctx.set_option("part_target", pt)
     for rep in range(2):
         ctx.reset_timers()
