@@ -38,6 +38,8 @@ def _load_traffic():
 
 
 TRAFFIC = {}
+# what limits a kernel according to its counters (profiles/*_pmc_*): k_skm_count is not an HBM kernel
+BOUND = {"k_skm_count": "lds+valu", "k_skm_scatter": "valu", "k_skm_hist": "valu"}
 
 
 def algorithmic_bytes(kernel, s):
@@ -94,16 +96,57 @@ def _reference_java(hb, ho, k, cores):
         return dict(value=round(n_occ / dt, 1), unit="k-mers/s", cores=cores, seconds=round(dt, 2), note="kmer-counter-many incl. JVM start and FASTA parsing")
 
 
+def cpu_baseline(bases, offsets, n_reads, rl, k, args):
+    """the multi-threaded C restatement of the reference's k-mer counter on this box's host cores.
+    with_reader: the reference's structure end to end on a FASTA file of the first `--cpu-sample-reads` reads of the same
+    sample (file written untimed): serial reader inside the dispatcher's monitor feeding P workers in 32768-read batches
+    (src/io/ReadsDispatcher.java:34-53, src/io/IOUtils.java:838-865), lock-sharded linear-probing maps, single-threaded
+    dump of the entries with count > 1 (IOUtils.printKmers :45-71).  count_only: the counting loop alone on reads that
+    are already parsed in memory.  `value` is the with_reader figure."""
+    import tempfile
+    from oracle import oracle as O          # checker only: CPU baseline leg
+    cores = os.cpu_count() or 1
+    m = min(args.cpu_sample_reads, n_reads)
+    hb = bases[: m * rl].cpu().numpy()
+    td = tempfile.mkdtemp(prefix="mf_cpu_")
+    fa = os.path.join(td, "sample.fa")
+    rec = np.empty((m, rl + 4), dtype=np.uint8)           # ">r\n" + bases + "\n"
+    rec[:, 0], rec[:, 1], rec[:, 2], rec[:, rl + 3] = ord(">"), ord("r"), 10, 10
+    rec[:, 3:rl + 3] = hb.reshape(m, rl)
+    rec.tofile(fa)
+    del rec
+    r = O.cpu_baseline_file(fa, k, cores, 1, os.path.join(td, "sample.kmers.bin"))
+    wr_s = r["load_s"] + r["dump_s"]
+    for f in os.listdir(td):
+        os.remove(os.path.join(td, f))
+    os.rmdir(td)
+    m2 = min(args.cpu_count_only_reads, n_reads)
+    ho = offsets[: m2 + 1].cpu().numpy().astype(np.uint64)
+    c0 = time.perf_counter()
+    d2, o2 = O.cpu_baseline_count(hb[: m2 * rl], ho, k, cores)
+    cdt = time.perf_counter() - c0
+    return dict(value=round(r["n_occ"] / wr_s, 1), unit="k-mers/s", cores=cores, kind="port", cpu_model=_cpu_model(),
+                sample=f"with_reader: k-mer counter end to end on a FASTA file of the first {m} reads of the same sample "
+                       f"({r['n_occ']} k-mer occurrences, {r['distinct']} distinct, {r['written']} written): serial reader + "
+                       f"{cores} counting threads {r['load_s']:.2f} s, single-threaded dump {r['dump_s']:.2f} s",
+                with_reader=dict(value=round(r["n_occ"] / wr_s, 1), reads=m, load_s=round(r["load_s"], 2), dump_s=round(r["dump_s"], 2)),
+                count_only=dict(value=round(o2 / cdt, 1), reads=m2, seconds=round(cdt, 2),
+                                note="counting loop only, reads already parsed in memory (no reader, no dump)"),
+                reference_java=_reference_java(hb[: m2 * rl], ho, k, cores))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100_000_000, help="reads per GPU (BASELINE config: 100 M)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: BASELINE.json config 2 at one GPU = 100 M, "
+                                                         "config 3 = 50 M per GPU at more than one)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("-k", type=int, default=31)
     ap.add_argument("--genome-scale", type=int, default=1_000_000, help="pool genome length scale in bp")
-    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=20_000_000, help="reads of the with-reader CPU baseline (FASTA file)")
+    ap.add_argument("--cpu-count-only-reads", type=int, default=4_000_000, help="reads of the parser-free CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--b1", type=int, default=1000)
     ap.add_argument("--b2", type=int, default=10000)
@@ -117,11 +160,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.reads <= 0:
+        args.reads = 100_000_000 if world == 1 else 50_000_000
     if world != args.gpus and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    use_dist = world > 1 or (os.environ.get("MF_FORCE_DIST") and "RANK" in os.environ)
+    use_dist = world > 1 or bool(os.environ.get("MF_FORCE_DIST") and "RANK" in os.environ)
     if use_dist:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", device_id=device)      # "nccl" is RCCL on ROCm
@@ -206,7 +251,7 @@ def main():
             tr = TRAFFIC.get(name)
             # traffic: HBM gigabytes per launch (set) from the committed rocprofv3 --pmc passes of this same workload
             # (profiles/traffic_100M.json; null for other workloads), raw counters beside it
-            r = dict(kernel=name, bound="hbm", achieved=kern[name]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+            r = dict(kernel=name, bound=BOUND.get(name, "hbm"), achieved=kern[name]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=round(kern[name]["GBps"] / HBM_PEAK_GBS, 4),
                      launch_ms=kern[name]["sample_ms"], algorithmic_GB=kern[name]["algorithmic_GB"],
                      traffic=(tr or {}).get("hbm_GB") if isinstance(tr, dict) else None, traffic_unit="GB", traffic_counters=tr)
@@ -221,22 +266,19 @@ def main():
                          algorithmic_GB=round(surv / 1e9, 4), priced_as="SURVEY 8(d) K3, LDS-resident: 8 B/occurrence + 12 B/distinct k-mer",
                          bytes_moved_GB=moved, achieved_on_bytes_moved=kern[name]["GBps"],
                          frac_on_bytes_moved=round(kern[name]["GBps"] / HBM_PEAK_GBS, 4))
+                # What binds it: LDS atomics and instruction issue, not HBM.  LDS-operation roofline beside the HBM-priced one:
+                # an insert is one ds_cmpst_rtn_b64 (probe = claim) + one ds_add_u32 (count) per occurrence; tools/lds_ops.hip
+                # measured 9.1 + 4.4 ns per 64-lane instruction per CU on random slots (gpurun_out/lds_ops.txt), i.e. at full lane
+                # occupancy 256 CUs x 64 / 13.5 ns occurrences per second.
+                lds_peak = 256 * 64 / 13.5e-9
+                r["lds_roofline"] = dict(bound="lds-atomics", achieved=round(stats["n_occ"] / t_s / 1e9, 2), peak=round(lds_peak / 1e9, 1),
+                                         unit="G inserts/s", frac=round(stats["n_occ"] / t_s / lds_peak, 4),
+                                         model="1 ds_cmpst_rtn_b64 (9.1 ns) + 1 ds_add_u32 (4.4 ns) per 64 occurrences per CU")
             return r
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only
-            from oracle import oracle as O          # checker only: CPU baseline leg
-            m = min(args.cpu_sample_reads, n_reads)
-            hb = bases[: m * rl].cpu().numpy()
-            ho = offsets[: m + 1].cpu().numpy().astype(np.uint64)
-            cores = os.cpu_count() or 1
-            c0 = time.perf_counter()
-            d, o = O.cpu_baseline_count(hb, ho, k, cores)
-            cdt = time.perf_counter() - c0
-            cpu = dict(value=round(o / cdt, 1), unit="k-mers/s", cores=cores, kind="port",
-                       sample=f"counting stage only (multi-threaded restatement of IOUtils.loadReads) on the first {m} reads "
-                              f"of the same sample, reads already parsed in memory; {o} k-mer occurrences, {d} distinct, {cdt:.2f} s",
-                       cpu_model=_cpu_model(), reference_java=_reference_java(hb, ho, k, cores))
+            cpu = cpu_baseline(bases, offsets, n_reads, rl, k, args)
         out = {
             "metric": "k-mers/s counted+graphed at k=31, 150 bp reads",
             "value": round(total_occ * args.steps / elapsed, 1),

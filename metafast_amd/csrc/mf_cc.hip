@@ -398,7 +398,7 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             auto lv = std::make_unique<level_buf>();
             MF_TRY(lv->members.alloc(ctx, nkm)); MF_TRY(lv->comp.alloc(ctx, nkm));
             lv->n = nkm;
-            k_scan<1><<<1, 1024, 0, st>>>(k_size.p, slot_off.p, (uint64_t)nkept, tot.p);
+            MF_TRY(mf_scan<1>(ctx, k_size.p, slot_off.p, (uint64_t)nkept, tot.p));      // (multi-block: nkept reaches millions)
             MF_HIP(hipMemsetAsync(slot_fill.p, 0, (size_t)(nkept ? nkept : 1) * 4, st));
             {
                 mf_ktimer tm(ctx, "k_cc_members");

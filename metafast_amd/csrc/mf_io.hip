@@ -766,8 +766,9 @@ extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nf
     }
     k_counts_minus_one<<<(unsigned)((all->n + 255) / 256 + 1), 256, 0, ctx->stream>>>(all->d_counts, all->n);
     int rc = mf_table_from_device_pairs(ctx, all->d_keys, all->d_counts, all->n, k, out);
-    MF_HIP(hipStreamSynchronize(ctx->stream));
-    mf_table_destroy(all);
+    const hipError_t se = hipStreamSynchronize(ctx->stream);
+    mf_table_destroy(all);                                  // (on every path: the synchronise used to return past it)
+    if (se != hipSuccess) return mf_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(se));
     return rc;
 }
 
@@ -871,6 +872,9 @@ extern "C" int mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps *
     size_t pos = 4;
     if (n < 4) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
     const uint64_t cnt = be_get(p, 4);
+    // every component has at least its 12-byte header: a count the file cannot hold is a wrong file, not a reason to
+    // allocate 2 x 8 x cnt bytes (std::bad_alloc must not cross the C boundary)
+    if (4 + 12 * cnt > n) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
     std::unique_ptr<mf_comps, void (*)(mf_comps *)> C(new mf_comps(), [](mf_comps *c) { mf_comps_destroy(c); });
     C->ctx = ctx; C->k = 0; C->n = cnt;
     std::vector<uint64_t> foff(cnt + 1, 0), koff(cnt + 1, 0);

@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t skm_rec_digits(const skm_rec &r) { return (u
 template <int K> struct skm_word {
     static constexpr int W = K - MF_SKM_M + 1;          // M-mers per k-mer
     static constexpr int NM = 31 + W;                   // M-mers of the word's 32 k-mers
-    static constexpr int RMAX = (MF_SKM_BASES - (K - 1)) < 20 ? (MF_SKM_BASES - (K - 1)) : 20;   // k-mers per record (<= 10 items of 2 in k_skm_count2)
+    static constexpr int RMAX = (MF_SKM_BASES - (K - 1)) < 20 ? (MF_SKM_BASES - (K - 1)) : 20;   // k-mers per record (<= 10 items of 2 in k_skm_count)
     uint32_t D[4];        // 64 bases from the word's first position, 2 bits each, first base in the top bits of D[0]
     uint32_t mh[32];      // minimizer hash of the k-mer at each position
     uint32_t valid;       // positions that start a k-mer (from the bitmap)
@@ -487,353 +487,18 @@ __global__ __launch_bounds__(1024) void k_skm_split(const skm_rec *__restrict__ 
     }
 }
 
-// =============================================================================================
-// S4: count one partition per workgroup
-// =============================================================================================
-// one-key-per-lane LDS steps of the collision queue (one asm block each: the waits belong to the block, see
-// mf_count_dev.h; the four-wide steps of the first probe are mf_lds_read4_b64 / mf_lds_cmpst4_b64 / mf_lds_add4)
-template <int B> __device__ __forceinline__ void skm_lds_read_b64(const uint32_t (&a)[B], uint64_t (&v)[B]);
-template <> __device__ __forceinline__ void skm_lds_read_b64<1>(const uint32_t (&a)[1], uint64_t (&v)[1]) {
-    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v[0]) : "v"(a[0]) : "memory");
-}
-template <int B> __device__ __forceinline__ void skm_lds_cmpst_b64(const uint32_t (&a)[B], uint64_t cmp, const uint64_t (&nv)[B], uint64_t (&old)[B]);
-template <> __device__ __forceinline__ void skm_lds_cmpst_b64<1>(const uint32_t (&a)[1], uint64_t cmp, const uint64_t (&nv)[1], uint64_t (&old)[1]) {
-    asm volatile("ds_cmpst_rtn_b64 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(old[0]) : "v"(a[0]), "v"(cmp), "v"(nv[0]) : "memory");
-}
-template <int B> __device__ __forceinline__ void skm_lds_add(const uint32_t (&a)[B], const uint32_t (&inc)[B]);
-template <> __device__ __forceinline__ void skm_lds_add<1>(const uint32_t (&a)[1], const uint32_t (&inc)[1]) {
-    asm volatile("ds_add_u32 %0, %1" ::"v"(a[0]), "v"(inc[0]) : "memory");
-}
-
-#define SKM_FILL 3400             // MULTI: claimed slots of the 4096 beyond which a pass is abandoned for more passes
 #define SKM_MAX_PASSES 64
-// pass of a key when its partition is counted in several passes (bits independent of skm_slot's)
+// pass of a key when its partition is counted in several passes (bits independent of the slot hash's)
 __device__ __forceinline__ uint32_t skm_pass_of(uint64_t key) {
     uint32_t g = ((uint32_t)(key >> 32) * 0xC2B2AE35u) ^ ((uint32_t)key * 0x27D4EB2Fu);
     g ^= g >> 15; g *= 0x165667B1u;
     return g >> 24;
 }
-// slot of a key in the LDS table: two 32-bit multiplies (the 64-bit multiply of mf_phash is six quarter-rate instructions)
-__device__ __forceinline__ uint32_t skm_slot(uint64_t key) {
-    uint32_t f = ((uint32_t)(key >> 32) * 0x85EBCA6Bu) ^ (uint32_t)key;
-    f *= 0x9E3779B1u;
-    return f >> 16;
-}
-// Four keys per lane: ONE four-wide probe settles about nine keys in ten (first-probe hits and fresh slots).  The keys
-// that met a collision are not chased on the spot (that loop is wave-uniform: every unsettled key, anywhere in the wave,
-// costs all 64 lanes a round of LDS latencies, and keeping it four-wide costs 3.3 iterations on dummy slots): they go to
-// a small wave-private queue in LDS and are finished 64 at a time, one key per lane, when the queue has filled up.
-#define SKM_QN 128               // queue entries per wave
-#define SKM_CLN 384              // claimed-slot list entries per wave (more claims in one partition: the table is swept in full)
-struct skm_tailq { uint64_t *qk; uint16_t *qs; uint16_t *cl; };
-// Every slot a wave claims (CAS won) goes to the wave's list: the compaction visits and clears the claimed slots only
-// instead of sweeping and re-initialising all 4096 (a partition claims about a tenth of them).  cnt = this lane's claims
-// among slot[0..B): one wave scan places them all.  ncl may run past SKM_CLN: the caller checks.
-template <int B>
-__device__ __forceinline__ void skm_note_claims(const skm_tailq &Q, uint32_t &ncl, const bool (&claimed)[B], const uint32_t (&slot)[B]) {
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int b = 0; b < B; b++) cnt += claimed[b] ? 1u : 0u;
-    if (__ballot(cnt != 0u) == 0ull) return;
-    uint32_t tot;
-    uint32_t at = ncl + mf_wave_excl_scan(cnt, &tot);
-#pragma unroll
-    for (int b = 0; b < B; b++)
-        if (claimed[b]) { if (at < (uint32_t)SKM_CLN) Q.cl[at] = (uint16_t)slot[b]; at++; }
-    ncl += tot;
-}
-// finish up to 64 queued keys (the last `c` entries), one per lane, by plain linear probing from their next slot
-// overflow: an LDS flag of the workgroup, raised when a key finds no slot (the partition is counted again in passes)
-__device__ __forceinline__ void skm_tail_drain(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
-                                               const skm_tailq &Q, uint32_t &qn, uint32_t &ncl, uint32_t *overflow) {
-    const uint32_t c = qn < 64u ? qn : 64u;
-    qn -= c;
-    bool p1 = (uint32_t)mf_lane() < c;
-    uint64_t k1[1] = {MF_EMPTY}; uint32_t s1 = 0;
-    if (p1) { k1[0] = Q.qk[qn + (uint32_t)mf_lane()]; s1 = Q.qs[qn + (uint32_t)mf_lane()]; }
-    for (uint32_t probes = 0;; probes++) {
-        if (__ballot(p1) == 0ull) break;
-        if (probes >= 256u && ((probes & 255u) == 0u)) {                // a crowded table: give up as soon as anybody has
-            if (probes > mask) { if (mf_lane() == 0) *overflow = 1u; break; }
-            if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)overflow)) break;
-        }
-        uint32_t ka[1], ca[1], aa[1], inc[1]; uint64_t cur[1], ret[1];
-        ka[0] = p1 ? tk0 + 8u * s1 : dummy_k;
-        skm_lds_read_b64<1>(ka, cur);
-        const bool need = p1 && cur[0] == MF_EMPTY;
-        ca[0] = need ? ka[0] : dummy_k;
-        if (__ballot(need) != 0ull) {
-            skm_lds_cmpst_b64<1>(ca, MF_EMPTY, k1, ret);
-            { const bool cl1[1] = {need && ret[0] == MF_EMPTY}; const uint32_t sl1[1] = {s1}; skm_note_claims<1>(Q, ncl, cl1, sl1); }
-            if (need) cur[0] = ret[0] == MF_EMPTY ? k1[0] : ret[0];
-        }
-        const bool hit = p1 && cur[0] == k1[0];
-        aa[0] = hit ? tc0 + 4u * s1 : dummy_c;
-        inc[0] = hit ? 1u : 0u;
-        if (hit) p1 = false;
-        else s1 = (s1 + 1) & mask;
-        skm_lds_add<1>(aa, inc);
-    }
-}
-__device__ __forceinline__ void skm_count_insert4q(uint32_t tk0, uint32_t tc0, uint32_t dummy_k, uint32_t dummy_c, uint32_t mask,
-                                                   const uint64_t (&key)[4], const skm_tailq &Q, uint32_t &qn, uint32_t &ncl, uint32_t *overflow, int ablate = 0) {
-    uint32_t s[4]; bool pend[4];
-#pragma unroll
-    for (int b = 0; b < 4; b++) { pend[b] = key[b] != MF_EMPTY; s[b] = skm_slot(key[b]) & mask; }
-    {
-        uint32_t ka[4], ca[4], aa[4], inc[4]; uint64_t cur[4], ret[4]; bool need[4]; bool anyneed = false;
-#pragma unroll
-        for (int b = 0; b < 4; b++) ka[b] = pend[b] ? tk0 + 8u * s[b] : dummy_k;
-        mf_lds_read4_b64(ka, cur);
-#pragma unroll
-        for (int b = 0; b < 4; b++) { need[b] = pend[b] && cur[b] == MF_EMPTY; ca[b] = need[b] ? ka[b] : dummy_k; anyneed |= need[b]; }
-        if (__ballot(anyneed) != 0ull) {
-            mf_lds_cmpst4_b64(ca, MF_EMPTY, key, ret);
-            bool won[4];
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                won[b] = need[b] && ret[b] == MF_EMPTY;
-                if (need[b]) cur[b] = ret[b] == MF_EMPTY ? key[b] : ret[b];
-            }
-            skm_note_claims<4>(Q, ncl, won, s);
-        }
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            const bool hit = pend[b] && cur[b] == key[b];
-            aa[b] = hit ? tc0 + 4u * s[b] : dummy_c;
-            inc[b] = hit ? 1u : 0u;
-            if (hit) pend[b] = false;
-            else s[b] = (s[b] + 1) & mask;
-        }
-        mf_lds_add4(aa, inc);
-    }
-    if (ablate == 5) return;
-    const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-        const unsigned long long bal = __ballot(pend[b]);
-        if (bal == 0ull) continue;
-        if (pend[b]) { const uint32_t at = qn + (uint32_t)__popcll(bal & lt_mask); Q.qk[at] = key[b]; Q.qs[at] = (uint16_t)s[b]; }
-        qn += (uint32_t)__popcll(bal);
-        if (qn >= 64u) skm_tail_drain(tk0, tc0, dummy_k, dummy_c, mask, Q, qn, ncl, overflow);      // (qn < 64 + 64 <= SKM_QN)
-    }
-}
-
-// records[pstart[p] .. +plen[p]) -> tkeys/tcnt[toff[p] .. +dcount[p])
-// Every WAVE works on its own: it takes records in groups of eight (round-robin over the eight waves, so a partition of a
-// few hundred records keeps all of them busy), parks its 64 records in its private LDS corner and cuts them into ITEMS
-// of up to four consecutive k-mers; the items are dealt out evenly over the lanes, a lane extracts its item's first
-// k-mer with one 128-bit shift, rolls to the next three and inserts the four straight from registers.  No workgroup
-// barrier between the table initialisation and the compaction.  (One lane expanding its whole record serially costs the
-// wave the LONGEST record of its 64; a block-wide item list costs four barriers per round.)
-//
-// A partition with more distinct k-mers than the table takes (a heavy minimizer: low-complexity sequence between many
-// different flanks) is put on the REDO list and its slice left empty; the MULTI instantiation of the kernel, launched
-// after every batch over that list (normally empty: its workgroups leave at once), counts such a partition in P = 4, 16
-// or 64 passes over its records, pass i inserting the k-mers with skm_pass_of(key) mod P = i.  More than 64 passes: the
-// global overflow flag, and the caller falls back to the k-mer path.
-template <int K, bool MULTI>
-__global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart,
-                                                      const uint32_t *__restrict__ plen, uint32_t np,
-                                                      const uint64_t *__restrict__ toff, uint64_t *__restrict__ tkeys,
-                                                      uint16_t *__restrict__ tcnt, uint32_t *__restrict__ dcount,
-                                                      unsigned int *__restrict__ overflow, int ablate, uint32_t p0, uint64_t tbase,
-                                                      int thr, unsigned long long *__restrict__ n_all,
-                                                      uint32_t *__restrict__ redo, unsigned int *__restrict__ n_redo,
-                                                      unsigned long long *__restrict__ drop_hist) {
-    // thr >= 0: only the k-mers with count > thr are written (the others are tallied in drop_hist[count], if given);
-    // *n_all += distinct k-mers of the partitions (all of them)
-    // partitions [p0, np); tkeys / tcnt hold the slices of this batch only: slice of p starts at toff[p] - tbase
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ uint32_t out_cursor, all_cursor;
-    unsigned long long all_acc = 0;                                             // thread 0: distinct k-mers of this workgroup's partitions
-    uint64_t *tk = reinterpret_cast<uint64_t *>(smem);                          // [MF_COUNT_SLOTS] + 64 dummy slots
-    uint32_t *tc = reinterpret_cast<uint32_t *>(tk + MF_COUNT_SLOTS + 64);      // [MF_COUNT_SLOTS] + 64 dummy counters
-    const uint32_t wave = threadIdx.x >> 6, lane = (uint32_t)mf_lane();
-    skm_rec *rbuf = reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64) + wave * 64;              // [64] this wave's records
-    uint64_t *qk_all = reinterpret_cast<uint64_t *>(reinterpret_cast<skm_rec *>(tc + MF_COUNT_SLOTS + 64) + SKM_CT);   // [waves][SKM_QN]
-    uint16_t *qs_all = reinterpret_cast<uint16_t *>(qk_all + (SKM_CT / 64) * SKM_QN);                                   // [waves][SKM_QN]
-    uint16_t *cl_all = qs_all + (SKM_CT / 64) * SKM_QN;                                                                 // [waves][SKM_CLN]
-    uint16_t *items = cl_all + (SKM_CT / 64) * SKM_CLN + wave * (64 * 6);                                               // [64 * 6] (RMAX <= 24)
-    skm_tailq Q; Q.qk = qk_all + wave * SKM_QN; Q.qs = qs_all + wave * SKM_QN; Q.cl = cl_all + wave * SKM_CLN;
-    uint32_t qn = 0, ncl = 0;                                                                                           // wave-uniform
-    __shared__ __attribute__((aligned(8))) uint32_t pflags[2];      // [0] sweep_all, [1] part_over: read together after the rounds
-    __shared__ uint32_t blk_claims;
-    uint32_t &sweep_all = pflags[0], &part_over = pflags[1];
-    uint32_t P = MULTI ? 4u : 1u, ncl_rep = 0;
-    uint32_t ones_acc = 0;                                                      // per wave: dropped entries with count 1
-    const uint32_t tk0 = mf_lds_addr(tk), tc0 = mf_lds_addr(tc);
-    const uint32_t dummy_k = tk0 + 8u * ((uint32_t)MF_COUNT_SLOTS + lane);
-    const uint32_t dummy_c = tc0 + 4u * ((uint32_t)MF_COUNT_SLOTS + lane);
-    if (threadIdx.x < 64) { tk[MF_COUNT_SLOTS + threadIdx.x] = 0; tc[MF_COUNT_SLOTS + threadIdx.x] = 0; }   // dummies: never EMPTY
-    // the table is cleared ONCE; after that every partition leaves it clean (its compaction clears the slots it claimed)
-    for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
-    constexpr uint32_t mask = MF_COUNT_SLOTS - 1;
-    constexpr int sh = 64 - 2 * K, top = 2 * K - 2;
-    const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
-    const uint32_t mine = (lane >> 3) * 64u + wave * 8u + (lane & 7u);          // this lane's record within a round of 512
-    // partitions [p0, np) in turn, or (MULTI) the partitions of the redo list
-    const uint32_t iend = MULTI ? *n_redo : np;
-    uint32_t pi = (MULTI ? 0u : p0) + blockIdx.x;
-    if (pi >= iend) return;
-    auto part_at = [&](uint32_t i) -> uint32_t { return MULTI ? redo[i] : i; };
-    uint32_t p = part_at(pi);
-    uint64_t start = pstart[p];
-    uint32_t len = plen[p];
-    uint64_t o = toff[p] - tbase; uint32_t room = (uint32_t)(toff[p + 1] - toff[p]);   // this partition's slice of the output lists
-    skm_rec R = mine < len ? recs[start + mine] : SENT;                        // first round, prefetched
-    // directory entries are fetched TWO partitions ahead: the prefetch of the next partition's records needs its start,
-    // and waiting for that load at the top of every partition costs a global round trip per partition
-    uint64_t start_n = 0, o_n = 0; uint32_t len_n = 0, room_n = 0, p_n = 0;
-    if (pi + gridDim.x < iend) { const uint32_t q = part_at(pi + gridDim.x); p_n = q; start_n = pstart[q]; len_n = plen[q]; o_n = toff[q] - tbase; room_n = (uint32_t)(toff[q + 1] - toff[q]); }
-    for (;;) {
-        const uint32_t pn = pi + gridDim.x, pnn = pn + gridDim.x;
-        uint64_t start_nn = 0, o_nn = 0; uint32_t len_nn = 0, room_nn = 0, p_nn = 0;
-        if (pnn < iend) { const uint32_t q = part_at(pnn); p_nn = q; start_nn = pstart[q]; len_nn = plen[q]; o_nn = toff[q] - tbase; room_nn = (uint32_t)(toff[q + 1] - toff[q]); }
-        skm_rec cur = R;
-        if (pn < iend) R = mine < len_n ? recs[start_n + mine] : SENT;         // next partition's first round
-        if (threadIdx.x == 0) { out_cursor = 0; all_cursor = 0; }
-      for (uint32_t pass = 0; pass < P; pass++) {                              // (one pass unless MULTI)
-        if (threadIdx.x == 0) { *reinterpret_cast<uint64_t *>(pflags) = 0ull; if (MULTI) blk_claims = 0; }
-        if (MULTI) cur = mine < len ? recs[start + mine] : SENT;
-        __syncthreads();
-        for (uint32_t rb = 0; rb < len; rb += blockDim.x) {
-            if (rb) {
-                if (__builtin_amdgcn_readfirstlane((int)*(volatile uint32_t *)&part_over)) break;      // (abandoned)
-                cur = rb + mine < len ? recs[start + rb + mine] : SENT;
-            }
-            const uint32_t r = skm_rec_valid(cur) ? skm_rec_n(cur) : 0u;
-            const uint32_t nch = (r + 3u) >> 2;
-            uint32_t NI;
-            const uint32_t ioff = mf_wave_excl_scan(nch, &NI);
-            if (NI == 0) continue;                                              // wave-uniform
-            rbuf[lane] = cur;
-            for (uint32_t c = 0; c < nch; c++) items[ioff + c] = (uint16_t)(lane | (c << 6));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // LDS of one wave is in order: visible to its lanes
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t i0 = 0; i0 < ((ablate & 4) ? 0u : NI); i0 += 64) {    // wave-uniform
-                uint64_t k4[4] = {MF_EMPTY, MF_EMPTY, MF_EMPTY, MF_EMPTY};
-                if (i0 + lane < NI) {
-                    const uint32_t it = items[i0 + lane];
-                    const skm_rec rec = rbuf[it & 63u];
-                    const uint32_t c = it >> 6, sft = 8u * c;                   // the item's first k-mer starts 4c bases in
-                    const uint32_t nk = skm_rec_n(rec) - 4u * c;                // k-mers left in the record (>= 1)
-                    uint64_t X = rec.x, Y = rec.y & ~((1ull << 28) - 1ull);
-                    if (sft) { X = (X << sft) | (Y >> (64u - sft)); Y <<= sft; }
-                    uint64_t fw = X >> sh, rc = mf_revcomp(fw, K);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if ((uint32_t)j < nk) k4[j] = fw < rc ? fw : rc;
-                        X = (X << 2) | (Y >> 62); Y <<= 2;
-                        fw = X >> sh;
-                        rc = (rc >> 2) | ((uint64_t)(3u - (uint32_t)(fw & 3u)) << top);
-                    }
-                }
-                if (MULTI) {
-#pragma unroll
-                    for (int j = 0; j < 4; j++) if ((skm_pass_of(k4[j]) & (P - 1u)) != pass) k4[j] = MF_EMPTY;
-                }
-                if (ablate != 3) skm_count_insert4q(tk0, tc0, dummy_k, dummy_c, mask, k4, Q, qn, ncl, &part_over, ablate);
-                else if ((k4[0] ^ k4[1] ^ k4[2] ^ k4[3]) == 0x1234567ull) tk[0] = k4[0];
-                if (MULTI && ncl - ncl_rep >= 64u) {                           // wave-uniform: give up early, a crowded table is slow
-                    if (lane == 0 && atomicAdd(&blk_claims, ncl - ncl_rep) + (ncl - ncl_rep) > (uint32_t)SKM_FILL) part_over = 1;
-                    ncl_rep = ncl;
-                }
-            }
-            while (qn) skm_tail_drain(tk0, tc0, dummy_k, dummy_c, mask, Q, qn, ncl, &part_over);     // wave-uniform
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (ncl > (uint32_t)SKM_CLN && lane == 0) sweep_all = 1;        // this wave's list is incomplete: sweep the whole table
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ds_add_u32 of the asm blocks are invisible to hipcc's waitcnt pass
-        __syncthreads();
-        const uint64_t pf = *reinterpret_cast<volatile uint64_t *>(pflags);
-        if ((uint32_t)(pf >> 32)) {
-            // more distinct k-mers than the table takes: wipe it; the partition goes to the redo list, or (MULTI) starts again
-            // with four times the passes
-            for (uint32_t i = threadIdx.x; i < (uint32_t)MF_COUNT_SLOTS; i += blockDim.x) { tk[i] = MF_EMPTY; tc[i] = 0; }
-            ncl = 0; ncl_rep = 0; qn = 0;
-            if (threadIdx.x == 0) { out_cursor = 0; all_cursor = 0; }
-            if (!MULTI) { if (threadIdx.x == 0) redo[atomicAdd(n_redo, 1u)] = p; __syncthreads(); break; }
-            if (P >= (uint32_t)SKM_MAX_PASSES) { if (threadIdx.x == 0) atomicExch(overflow, 1u); __syncthreads(); break; }
-            P *= 4; pass = ~0u;
-            __syncthreads();
-            continue;
-        }
-        const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
-        if (!(uint32_t)pf) {
-            // compaction over the claimed slots: every wave walks ITS list (the slots it won), writes the entries that pass
-            // the cut and leaves the slots empty for the next partition
-            if (lane == 0 && ncl) atomicAdd(&all_cursor, ncl);
-            for (uint32_t i0 = 0; i0 < ncl; i0 += 64) {             // wave-uniform
-                const bool have = i0 + lane < ncl;
-                uint32_t sl = 0; uint64_t key = MF_EMPTY; uint32_t cnt = 0;
-                if (have) { sl = Q.cl[i0 + lane]; key = tk[sl]; cnt = tc[sl]; tk[sl] = MF_EMPTY; tc[sl] = 0; }
-                if (cnt > (uint32_t)MF_MAX_COUNT) cnt = (uint32_t)MF_MAX_COUNT;
-                const bool keep = have && (int)cnt > thr;           // (thr < 0 keeps everything)
-                if (drop_hist) {                                    // (count 1 is nearly all of them: one atomic per wave at the end)
-                    ones_acc += (uint32_t)__popcll(__ballot(have && !keep && cnt == 1u));
-                    if (have && !keep && cnt != 1u) atomicAdd(&drop_hist[cnt], 1ull);
-                }
-                const unsigned long long bal = __ballot(keep);
-                uint32_t wb = 0;
-                if (lane == 0 && bal) wb = atomicAdd(&out_cursor, (uint32_t)__popcll(bal));
-                wb = (uint32_t)__builtin_amdgcn_readfirstlane((int)wb) + (uint32_t)__popcll(bal & lt_mask);
-                if (keep && wb < room) { tkeys[o + wb] = key; tcnt[o + wb] = (uint16_t)cnt; }
-                if (keep && wb >= room) atomicExch(overflow, 1u);   // (only if a partition's k-mer count wrapped)
-            }
-        } else {
-            // full sweep: each wave walks 64-slot chunks (lane = slot: conflict-free), keeps them in registers, reserves its
-            // output range with ONE LDS atomic, clears the table
-            constexpr int NCH = MF_COUNT_SLOTS / SKM_CT;
-            uint64_t ck[NCH]; uint32_t cv[NCH], pre[NCH]; uint32_t total = 0, total_all = 0;
-#pragma unroll
-            for (int i = 0; i < NCH; i++) {
-                const uint32_t sl = ((threadIdx.x >> 6) << 6) + (uint32_t)i * SKM_CT + (uint32_t)mf_lane();
-                ck[i] = tk[sl]; cv[i] = tc[sl];
-                tk[sl] = MF_EMPTY; tc[sl] = 0;
-                total_all += (uint32_t)__popcll(__ballot(ck[i] != MF_EMPTY));
-                if ((int)(cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]) <= thr) {     // (thr < 0 keeps everything)
-                    if (drop_hist) {
-                        ones_acc += (uint32_t)__popcll(__ballot(ck[i] != MF_EMPTY && cv[i] == 1u));
-                        if (ck[i] != MF_EMPTY && cv[i] != 1u) atomicAdd(&drop_hist[cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]], 1ull);
-                    }
-                    ck[i] = MF_EMPTY;
-                }
-                const unsigned long long bal = __ballot(ck[i] != MF_EMPTY);
-                pre[i] = total + (uint32_t)__popcll(bal & lt_mask);
-                total += (uint32_t)__popcll(bal);
-            }
-            uint32_t wb = 0;
-            if (mf_lane() == 0 && total_all) atomicAdd(&all_cursor, total_all);
-            if (mf_lane() == 0 && total) wb = atomicAdd(&out_cursor, total);
-            wb = __shfl(wb, 0, 64);
-            if (mf_lane() == 0 && wb + total > room) atomicExch(overflow, 1u);      // (only if a partition's k-mer count wrapped)
-#pragma unroll
-            for (int i = 0; i < NCH; i++) {
-                if (ck[i] != MF_EMPTY && wb + pre[i] < room) {
-                    const uint64_t pos = o + wb + pre[i];
-                    tkeys[pos] = ck[i];
-                    tcnt[pos] = (uint16_t)(cv[i] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : cv[i]);
-                }
-            }
-        }
-        ncl = 0; ncl_rep = 0;
-        __syncthreads();
-      }
-        if (MULTI) P = 4;
-        if (threadIdx.x == 0) { dcount[p] = out_cursor; all_acc += all_cursor; }
-        if (pn >= iend) break;
-        pi = pn; p = p_n; start = start_n; len = len_n; o = o_n; room = room_n;
-        p_n = p_nn; start_n = start_nn; len_n = len_nn; o_n = o_nn; room_n = room_nn;
-    }
-    if (threadIdx.x == 0 && n_all && all_acc) atomicAdd(n_all, all_acc);
-    if (drop_hist && lane == 0 && ones_acc) atomicAdd(&drop_hist[1], (unsigned long long)ones_acc);
-}
 
 // =============================================================================================
-// S4 (second generation): the same job as k_skm_count<K,false>, rebuilt from its counters (profiles/r01j_pmc_100M: 160 VALU
-// lane-operations per k-mer) and from ablations of the rebuild itself (profiles/r02_count_ablation.txt):
+// S4: count one partition per workgroup.  Second generation: the first one (round 1, profiles/r01j_pmc_100M: 160 VALU lane-
+// operations per k-mer occurrence, 76 ms at 100 M reads) probed four-wide with a separate read, CAS and claim-list scan per
+// step and expanded records with 64-bit shifts.  What this one is built on (ablations: profiles/r02_count_ablation_*.txt):
 //   * all arithmetic on 32-bit halves (v_alignbit funnel shifts, v_bfrev): the 64-bit variable shifts of the record
 //     expansion and of mf_revcomp are multi-instruction sequences on CDNA;
 //   * the probe IS the claim: one ds_cmpst_rtn_b64(slot, EMPTY, key) per key, four keys per lane.  It returns EMPTY (the
@@ -855,7 +520,7 @@ __global__ __launch_bounds__(SKM_CT) void k_skm_count(const skm_rec *__restrict_
                                  // = three workgroups per CU instead of two, but an 80-VGPR budget: 54 ms against 45.)
 #define C2_FILL 3400             // claims beyond which a partition is counted again in several passes
 #define C2_QN 128                // queue entries per wave (keys): drained at 64, one push (<= 64 keys) between checks
-#define C2_LH 128                // bins of the workgroup's dropped-count histogram (cuts with thr >= C2_LH do not run in the kernel)
+#define C2_LH 128                // bins of the workgroup's dropped-count histogram (a cut with thr >= C2_LH is made after the kernel)
 #define C2_ITEMS 768             // item entries per wave: 64 records x 10 items + two steps of padding (the read-ahead of the last step runs past them, unused)
 #define C2_W 2                   // k-mers per item
 static constexpr size_t C2_LDS = (size_t)C2_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8) + 2 * C2_LH * 4 + 32;
@@ -1078,12 +743,12 @@ __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t 
 // PROF: cycle counters per phase (diagnostics, option ablate & 32; s_memtime perturbs the kernel by about a tenth)
 #define C2_TICK(i) do { if (PROF) { const long long t__ = clock64(); prof[i] += (unsigned long long)(t__ - tlast); tlast = t__; } } while (0)
 template <int K, bool PROF>
-__global__ __launch_bounds__(SKM_CT, 4) void k_skm_count2(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart,
+__global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart,
                                                            const uint32_t *__restrict__ plen, uint32_t np,
                                                            const uint64_t *__restrict__ toff, uint64_t *__restrict__ tkeys,
                                                            uint16_t *__restrict__ tcnt, uint32_t *__restrict__ dcount,
                                                            unsigned int *__restrict__ overflow, uint32_t p0, uint64_t tbase, int thr,
-                                                           unsigned long long *__restrict__ n_all, uint32_t *__restrict__ redo,
+                                                           unsigned long long *__restrict__ n_all,
                                                            unsigned int *__restrict__ n_redo, unsigned long long *__restrict__ drop_hist, int ablate,
                                                            unsigned long long *__restrict__ prof_out, uint64_t tcap) {
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = PROF ? clock64() : 0;
@@ -1133,12 +798,13 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count2(const skm_rec *__restr
     // the first round of a partition is in registers before the partition starts; every further round is fetched while
     // the round before it is worked on
     skm_rec R0 = load_rec(start, mine, len);
-    // Directory entries are fetched TWO partitions ahead by scalar loads (they live in SGPRs: as vector loads they cost 14
-    // VGPRs of a budget of 80).  A scalar load is counted in lgkmcnt, so the next LDS wait sits out its memory latency: they
-    // are issued right in front of the first barrier of a partition, where the wave waits anyway.
+    // Directory entries are fetched TWO partitions ahead, with VECTOR loads: a scalar load (what hipcc makes of a uniform
+    // address) is counted in lgkmcnt, and the next LDS wait would sit out its whole memory latency (and hipcc spilt the
+    // scalars to VGPR lanes at once, with a wait after every load).  `vz` is a zero the compiler cannot see through.
+    uint32_t vz; asm("v_mov_b32 %0, 0" : "=v"(vz));
     struct dirent { uint64_t start, toff0, toff1; uint32_t len; };
-    auto load_dir = [&](uint32_t i) -> dirent {
-        dirent d;
+    auto load_dir = [&](uint32_t q) -> dirent {
+        dirent d; const uint32_t i = q + vz;
         d.start = pstart[i]; d.len = plen[i]; d.toff0 = toff[i]; d.toff1 = toff[i + 1];
         return d;
     };
@@ -1149,10 +815,10 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count2(const skm_rec *__restr
     for (;;) {
         const uint32_t pn = pi + gridDim.x, pnn = pn + gridDim.x;
         dirent dnn = {0, 0, 0, 0};
-        bool dir_loaded = false;
+        if (pnn < np) dnn = load_dir(pnn);
         skm_rec cur = R0;
-        const uint64_t start_n = dn.start;
-        const uint32_t len_n = dn.len;
+        const uint64_t start_n = c2_uniform64(dn.start);
+        const uint32_t len_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)dn.len);
         if (pn < np) R0 = load_rec(start_n, mine, len_n);                      // next partition
         C2_TICK(0);                                                             // partition top: directory, record prefetch
         // A partition with more distinct k-mers than the table takes (a heavy minimizer: low-complexity sequence between many
@@ -1211,7 +877,6 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count2(const skm_rec *__restr
         if (won_acc) { if (lane == 0) atomicAdd(&blk_claims, won_acc); won_acc = 0; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS operations of the asm blocks are invisible to hipcc's waitcnt pass
         C2_TICK(3);                                                             // last drains
-        if (!dir_loaded) { dir_loaded = true; if (pnn < np) dnn = load_dir(pnn); }
         c2_barrier();                                                           // ---- B1: every insert of the pass is done
         C2_TICK(4);                                                             // waiting for the other waves
         const bool over = c2_lds_u32(part_over) != 0u || c2_lds_u32(&blk_claims) > (uint32_t)C2_FILL;
@@ -1221,33 +886,26 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count2(const skm_rec *__restr
         // (Claim lists -- visit only the slots that were won -- cost a list append per key slot in the hot loop and four
         // dependent LDS round trips per 64 entries here; with the table 2/5 full the sweep is cheaper on both counts.)
         {
-            constexpr int NCH = 4;                                      // chunks in flight
-            static_assert(C2_SLOTS % (8 * 64 * NCH) == 0, "sweep: whole groups of four chunks per wave");
+            constexpr int NCH = 8;                                      // chunks in flight
+            static_assert(C2_SLOTS % (8 * 64 * NCH) == 0, "sweep: whole groups of eight chunks per wave");
 #pragma unroll 1
             for (uint32_t g = 0; g < (uint32_t)(C2_SLOTS / (8 * 64 * NCH)); g++) {
             uint64_t ck[NCH]; uint32_t cc[NCH]; unsigned long long have[NCH], keep[NCH];
             const uint32_t sl0 = wave * (uint32_t)(C2_SLOTS / 8) + g * (uint32_t)(64 * NCH) + lane;
             const uint32_t ka0 = L.tk0 + 8u * sl0, ca0 = L.tc0 + 4u * sl0;
             const uint64_t E = MF_EMPTY; const uint32_t zero = 0u;
-            asm volatile("ds_wrxchg_rtn_b64 %0, %4, %5\n\tds_wrxchg_rtn_b64 %1, %4, %5 offset:512\n\tds_wrxchg_rtn_b64 %2, %4, %5 offset:1024\n\t"
-                         "ds_wrxchg_rtn_b64 %3, %4, %5 offset:1536\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(ck[0]), "=&v"(ck[1]), "=&v"(ck[2]), "=&v"(ck[3])
-                         : "v"(ka0), "v"(E) : "memory");
-            unsigned long long anyhave = 0ull;
+            // (the counters of ALL lanes: an exchange costs the same for 8 lanes as for 64)
+            asm volatile("ds_wrxchg_rtn_b64 %0, %16, %17\n\tds_wrxchg_rtn_b64 %1, %16, %17 offset:512\n\tds_wrxchg_rtn_b64 %2, %16, %17 offset:1024\n\t"
+                         "ds_wrxchg_rtn_b64 %3, %16, %17 offset:1536\n\tds_wrxchg_rtn_b64 %4, %16, %17 offset:2048\n\tds_wrxchg_rtn_b64 %5, %16, %17 offset:2560\n\t"
+                         "ds_wrxchg_rtn_b64 %6, %16, %17 offset:3072\n\tds_wrxchg_rtn_b64 %7, %16, %17 offset:3584\n\t"
+                         "ds_wrxchg_rtn_b32 %8, %18, %19\n\tds_wrxchg_rtn_b32 %9, %18, %19 offset:256\n\tds_wrxchg_rtn_b32 %10, %18, %19 offset:512\n\t"
+                         "ds_wrxchg_rtn_b32 %11, %18, %19 offset:768\n\tds_wrxchg_rtn_b32 %12, %18, %19 offset:1024\n\tds_wrxchg_rtn_b32 %13, %18, %19 offset:1280\n\t"
+                         "ds_wrxchg_rtn_b32 %14, %18, %19 offset:1536\n\tds_wrxchg_rtn_b32 %15, %18, %19 offset:1792\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(ck[0]), "=&v"(ck[1]), "=&v"(ck[2]), "=&v"(ck[3]), "=&v"(ck[4]), "=&v"(ck[5]), "=&v"(ck[6]), "=&v"(ck[7]),
+                           "=&v"(cc[0]), "=&v"(cc[1]), "=&v"(cc[2]), "=&v"(cc[3]), "=&v"(cc[4]), "=&v"(cc[5]), "=&v"(cc[6]), "=&v"(cc[7])
+                         : "v"(ka0), "v"(E), "v"(ca0), "v"(zero) : "memory");
 #pragma unroll
-            for (int i = 0; i < NCH; i++) { have[i] = ~c2_eq_u64(ck[i], MF_EMPTY) & __builtin_amdgcn_ballot_w64(true); anyhave |= have[i]; cc[i] = 0u; }
-            {   // (all lanes: an exchange costs the same for 8 lanes as for 64)
-                asm volatile("ds_wrxchg_rtn_b32 %0, %4, %5\n\tds_wrxchg_rtn_b32 %1, %4, %5 offset:256\n\tds_wrxchg_rtn_b32 %2, %4, %5 offset:512\n\t"
-                             "ds_wrxchg_rtn_b32 %3, %4, %5 offset:768\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(cc[0]), "=&v"(cc[1]), "=&v"(cc[2]), "=&v"(cc[3])
-                             : "v"(ca0), "v"(zero) : "memory");
-                if (prof_out) {                                 // diagnostics: counters that were not zero under an empty key
-                    uint32_t bad = 0;
-#pragma unroll
-                    for (int i = 0; i < NCH; i++) bad += (uint32_t)__popcll(~have[i] & c2_lt_u32(0u, cc[i]) & __builtin_amdgcn_ballot_w64(true));
-                    if (bad && lane == 0) atomicAdd(&prof_out[7], (unsigned long long)bad);
-                }
-            }
+            for (int i = 0; i < NCH; i++) have[i] = ~c2_eq_u64(ck[i], MF_EMPTY) & __builtin_amdgcn_ballot_w64(true);
             if (!over) {
                 uint32_t nkeep = 0, nhave = 0;
 #pragma unroll
@@ -1315,8 +973,8 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count2(const skm_rec *__restr
         if (threadIdx.x == 0) { dcount[p] = out_cursor; out_cursor = 0; }
         if (pn >= np) break;
         pi = pn; p = pn; start = start_n; len = len_n;
-        o = dn.toff0 - tbase;
-        room = (uint32_t)(dn.toff1 - dn.toff0);
+        o = c2_uniform64(dn.toff0) - tbase;
+        room = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dn.toff1 - dn.toff0));
         dn = dnn;
     }
     {   // distinct k-mers before the cut: one atomic per wave
@@ -1504,51 +1162,34 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));
     mf_buf<uint64_t> dk; mf_buf<uint16_t> dc;
     uint64_t dused = 0, dcap = 0;
-    {
-        const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 6 * 2 + (size_t)(SKM_CT / 64) * (SKM_QN * 10 + SKM_CLN * 2);
-        MF_TRY(skm_set_lds(k_skm_count<K, false>, lds));
-        MF_TRY(skm_set_lds(k_skm_count<K, true>, lds));
-    }
-    mf_buf<uint32_t> redo; MF_TRY(redo.alloc(ctx, PB));        // partitions of the running batch that need several passes
-    // counts of the entries the cut drops (the .stat.txt histogram needs them): drop_hist[c], c <= thr
+    // counts of the entries the cut drops (the .stat.txt histogram needs them): drop_hist[c], c <= thr.  The kernel tallies
+    // them in a small LDS histogram: a cut above C2_LH - 1 is made afterwards (mf_count_skm)
+    const int kthr = thr < C2_LH ? thr : -1;
     mf_buf<unsigned long long> dhist;
-    if (thr >= 0) { MF_TRY(dhist.alloc(ctx, (size_t)MF_MAX_COUNT + 1)); MF_HIP(hipMemsetAsync(dhist.p, 0, dhist.bytes(), st)); }
-    const bool count2 = ctx->opt_count2 != 0 && thr < C2_LH;
-    const bool c2prof = count2 && K == 31 && (ctx->opt_ablate & 32);
-    mf_buf<unsigned long long> c2p;
-    if (count2) { MF_TRY(c2p.alloc(ctx, 16)); MF_HIP(hipMemsetAsync(c2p.p, 0, 128, st)); }
-    if (count2) {
-        MF_TRY(skm_set_lds(k_skm_count2<K, false>, C2_LDS));
-        if (K == 31) MF_TRY(skm_set_lds(k_skm_count2<(K == 31 ? 31 : 20), true>, C2_LDS));
-        if (ctx->opt_verbose) {
-            int nb = 0;
-            MF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_skm_count2<K, false>, SKM_CT, C2_LDS));
-            fprintf(stderr, "[mf] k_skm_count2: %zu bytes of LDS, %d workgroups per CU\n", (size_t)C2_LDS, nb);
-        }
+    if (kthr >= 0) { MF_TRY(dhist.alloc(ctx, (size_t)MF_MAX_COUNT + 1)); MF_HIP(hipMemsetAsync(dhist.p, 0, dhist.bytes(), st)); }
+    const bool c2prof = K == 31 && (ctx->opt_ablate & 32);
+    mf_buf<unsigned long long> c2p;                             // [0,8) phase cycles (profiling build), [8,16) overflow diagnostics
+    MF_TRY(c2p.alloc(ctx, 16)); MF_HIP(hipMemsetAsync(c2p.p, 0, 128, st));
+    MF_TRY(skm_set_lds(k_skm_count<K, false>, C2_LDS));
+    if (K == 31) MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), true>, C2_LDS));
+    if (ctx->opt_verbose) {
+        int nb = 0;
+        MF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_skm_count<K, false>, SKM_CT, C2_LDS));
+        fprintf(stderr, "[mf] k_skm_count: %zu bytes of LDS, %d workgroups per CU\n", (size_t)C2_LDS, nb);
     }
     for (uint32_t b = 0; b < nbatch; b++) {
         const uint32_t p0 = (uint32_t)std::min<uint64_t>((uint64_t)b * PB, np), p1 = (uint32_t)std::min<uint64_t>((uint64_t)(b + 1) * PB, np);
         if (p0 == p1) continue;
         {
-            const size_t lds = (size_t)(MF_COUNT_SLOTS + 64) * 12 + (size_t)SKM_CT * 16 + (size_t)SKM_CT * 6 * 2 + (size_t)(SKM_CT / 64) * (SKM_QN * 10 + SKM_CLN * 2);
             const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);      // resident workgroups
             MF_HIP(hipMemsetAsync(&scal[8], 0, 8, st));
             mf_ktimer t(ctx, "k_skm_count");
             if (c2prof)
-                k_skm_count2<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
-                                                             p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p, (uint64_t)tmax);
-            else if (count2)
-                k_skm_count2<K, false><<<grid, SKM_CT, C2_LDS, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
-                                                             p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p, (uint64_t)tmax);
+                k_skm_count<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
+                                                             p0, (uint64_t)tb[b], kthr, &scal[7], (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p, (uint64_t)tmax);
             else
-                k_skm_count<K, false><<<grid, SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
-                                                                 (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr, &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p);
-            // the partitions that did not fit (normally none: the workgroups find an empty list and leave); the second-generation
-            // kernel counts those in several passes itself
-            if (!count2)
-            k_skm_count<K, true><<<std::min<unsigned>(grid, 64u), SKM_CT, lds, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p,
-                                                                                       (unsigned int *)&scal[2], (int)ctx->opt_ablate, p0, (uint64_t)tb[b], thr,
-                                                                                       &scal[7], redo.p, (unsigned int *)&scal[8], dhist.p);
+                k_skm_count<K, false><<<grid, SKM_CT, C2_LDS, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
+                                                             p0, (uint64_t)tb[b], kthr, &scal[7], (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p, (uint64_t)tmax);
         }
         MF_DBG(ctx, "k_skm_count");
         MF_TRY(mf_scan<1>(ctx, dcount.p + p0, doff.p + p0, p1 - p0, (uint64_t *)&scal[3]));      // offsets inside the batch
@@ -1560,14 +1201,14 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             MF_HIP(hipMemcpy(&nr, &scal[8], 8, hipMemcpyDeviceToHost));
             if (nr & 0xFFFFFFFFull) fprintf(stderr, "[mf] skm: batch %u: %llu partition(s) counted in several passes\n", b, nr & 0xFFFFFFFFull);
         }
-        if (ctx->opt_verbose && count2) {
+        if (ctx->opt_verbose) {
             unsigned long long bad = 0;
             MF_HIP(hipMemcpy(&bad, &c2p.p[7], 8, hipMemcpyDeviceToHost));
             if (bad && !c2prof) fprintf(stderr, "[mf] skm: batch %u: %llu counter(s) found non-zero under an empty key so far\n", b, bad);
         }
         if (res[0]) {
             if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: a minimizer partition overflows the LDS table (code %llu), using the k-mer path\n", res[0]);
-            if (ctx->opt_verbose && count2 && res[0] == 2) {
+            if (ctx->opt_verbose && res[0] == 2) {
                 unsigned long long h[16];
                 MF_HIP(hipMemcpy(h, c2p.p, 128, hipMemcpyDeviceToHost));
                 fprintf(stderr, "[mf]   p=%llu o=%llu room=%llu wb=%llu nkeep=%llu tcap=%llu p0=%llu np=%llu (batch %u: tb=%llu..%llu)\n", h[8], h[9], h[10], h[11], h[12], h[13], h[14], h[15], b, tb[b], tb[b + 1]);
@@ -1609,7 +1250,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         MF_HIP(hipStreamSynchronize(st));
         unsigned long long tot = 0; for (int i = 0; i < 7; i++) tot += h[i];
         static const char *nm[7] = {"partition top", "round set-up", "steps", "last drains", "barrier 1", "compaction", "barrier 2"};
-        for (int i = 0; i < 7; i++) fprintf(stderr, "[mf] k_skm_count2 wave cycles: %-14s %5.1f %%\n", nm[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+        for (int i = 0; i < 7; i++) fprintf(stderr, "[mf] k_skm_count wave cycles: %-14s %5.1f %%\n", nm[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
     }
     bufA.reset();
     const uint64_t n_dist = dused;
@@ -1626,10 +1267,10 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         const unsigned long long nv = nv2[0];
         if (n_all) *n_all = nv2[1];
         (*out)->n_records = nv ? nv : cap_l1;             // (plans without a split level: the padded level-1 count)
-        (*out)->cut_thr = thr;
-        if (thr >= 0) {
-            (*out)->dropped_hist.assign((size_t)thr + 1, 0);
-            MF_HIP(hipMemcpyAsync((*out)->dropped_hist.data(), dhist.p, ((size_t)thr + 1) * 8, hipMemcpyDeviceToHost, st));
+        (*out)->cut_thr = kthr;
+        if (kthr >= 0) {
+            (*out)->dropped_hist.assign((size_t)kthr + 1, 0);
+            MF_HIP(hipMemcpyAsync((*out)->dropped_hist.data(), dhist.p, ((size_t)kthr + 1) * 8, hipMemcpyDeviceToHost, st));
             MF_HIP(hipStreamSynchronize(st));
         }
         (*out)->record_bytes = 16;
@@ -1645,11 +1286,21 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
 
 int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
                  int k, const std::vector<int> &lv, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
+    int rc = MF_SKM_FALLBACK;
     switch (k) {
-#define SKM_CASE(KK) case KK: return skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, thr, n_all, out);
+#define SKM_CASE(KK) case KK: rc = skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, thr, n_all, out); break;
         SKM_CASE(20) SKM_CASE(21) SKM_CASE(22) SKM_CASE(23) SKM_CASE(24) SKM_CASE(25)
         SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29) SKM_CASE(30) SKM_CASE(31)
 #undef SKM_CASE
         default: return MF_SKM_FALLBACK;
     }
+    if (rc == MF_OK && thr >= 0 && (*out)->cut_thr < thr) {
+        // a cut the counting kernel does not make itself (thr >= C2_LH): as a pass over the finished table
+        mf_table *all = *out, *good = nullptr;
+        rc = mf_table_filter(all, thr, &good);
+        if (rc == MF_OK) { good->n_occ = all->n_occ; good->n_records = all->n_records; good->record_bytes = all->record_bytes; }
+        mf_table_destroy(all);
+        *out = good;
+    }
+    return rc;
 }

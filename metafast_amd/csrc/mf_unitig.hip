@@ -386,7 +386,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         mf_buf<uint64_t> off, tot; mf_buf<int32_t> wmin, wmax, wavg;
         if ((rc = off.alloc(ctx, (size_t)np + 1)) < 0 || (rc = tot.alloc(ctx, 1)) < 0 || (rc = wmin.alloc(ctx, np)) < 0 ||
             (rc = wmax.alloc(ctx, np)) < 0 || (rc = wavg.alloc(ctx, np)) < 0) break;
-        k_scan<1><<<1, 1024, 0, st>>>(plen.p, off.p, (uint64_t)np, tot.p);
+        if ((rc = mf_scan<1>(ctx, plen.p, off.p, (uint64_t)np, tot.p)) < 0) break;      // (multi-block: np reaches millions)
         uint64_t total = 0;
         if (hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = mf_set_error("unitigs: scan failed"); break;

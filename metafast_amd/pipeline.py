@@ -19,7 +19,10 @@ from . import lib as L
 
 
 # MF_FORCE_DIST=1: run the collectives even at world size 1 (lets a 1-GPU box exercise the RCCL code path)
-_FORCE = bool(os.environ.get("MF_FORCE_DIST")) and dist.is_available()
+def _force():
+    """MF_FORCE_DIST=1 and an initialised process group (checked at call time: the variable alone must not send a
+    single-process run into collectives without a group)"""
+    return bool(os.environ.get("MF_FORCE_DIST")) and dist.is_available() and dist.is_initialized()
 
 
 def _world():
@@ -32,7 +35,7 @@ def all_gather_ragged(t):
     """all-gather of 1-D tensors of different lengths -> list of per-rank tensors (same device/dtype as t).
     Sizes are exchanged first; payloads are padded to the largest one (one collective each)."""
     rank, world = _world()
-    if world == 1 and not _FORCE:
+    if world == 1 and not _force():
         return [t]
     n = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
     sizes = [torch.zeros_like(n) for _ in range(world)]
@@ -69,7 +72,7 @@ def gather_sequences(bases, offsets):
 def gather_vectors(vec):
     """vec: int64[C] -> int64[world, C] (every rank has the same C)"""
     rank, world = _world()
-    if world == 1 and not _FORCE:
+    if world == 1 and not _force():
         return vec.reshape(1, -1)
     outs = [torch.empty_like(vec) for _ in range(world)]
     dist.all_gather(outs, vec)
@@ -105,6 +108,8 @@ def run_sample(ctx, d_bases, d_offsets, n_reads, n_bases, k=31, b=1, l=100, b1=1
 
     # kmer-counter: k-mers with count > b go on (IOUtils.printKmers); the others are dropped inside the counting kernels
     good, n_distinct = ctx.count_device_above(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, k, b)
+    # ... and the histogram of ALL counts, dropped k-mers included (the .stat.txt of IOUtils.printKmers, src/io/IOUtils.java:45-71)
+    hist = good.hist()
     mark("count")
     seqs = ctx.build_unitigs(good, b, l)
     mark("unitigs")
@@ -126,4 +131,4 @@ def run_sample(ctx, d_bases, d_offsets, n_reads, n_bases, k=31, b=1, l=100, b1=1
     matrix = L.bray_curtis(vecs) if vecs.shape[1] else np.zeros((vecs.shape[0], vecs.shape[0]))
     mark("features_matrix")
     return dict(good=good, seqs=seqs, cutter=cutter, comps=comps, vec=vec, breadth=breadth, vecs=vecs,
-                matrix=matrix, n_occ=good.occurrences(), n_distinct=n_distinct)
+                matrix=matrix, n_occ=good.occurrences(), n_distinct=n_distinct, hist=hist)

@@ -464,7 +464,12 @@ static inline int64_t get_with_zero(const or_table *t, uint64_t key) {   /* Long
 }
 
 /* AddSequencesShiftingRightTask.processSequence :74-123 */
+/* census of the last or_build_unitigs call (tests: the 0 / 1 / 2-emission rule must be exercised):
+ * [0] walks started, [1] walks of at least min_len nucleotides, [2] walks emitted */
+static uint64_t g_census[3];
+void or_unitig_census(uint64_t out[3]) { out[0] = g_census[0]; out[1] = g_census[1]; out[2] = g_census[2]; }
 static void process_sequence(const or_table *t, skmer start, int k, int thr, int min_len, or_table *used, or_seqs *out) {
+    g_census[0]++;
     int64_t value = get_with_zero(t, sk_canon(start));
     uint64_t cap = 256, len = 0;
     char *sb = (char *)malloc(cap);
@@ -485,6 +490,7 @@ static void process_sequence(const or_table *t, skmer start, int k, int thr, int
         if (value > mx) mx = (int)value;
     }
     if ((int64_t)len >= (int64_t)min_len) {
+        g_census[1]++;
         uint64_t st = sk_canon(start), en = sk_canon(km);
         if (st > en) { free(sb); return; }
         if (st == en) {                                   /* print only one of them */
@@ -492,6 +498,7 @@ static void process_sequence(const or_table *t, skmer start, int k, int thr, int
             table_put(used, st, 1);
         }
         if (out->n == out->cap) { out->cap = out->cap ? out->cap * 2 : 64; out->a = (seq_t *)realloc(out->a, out->cap * sizeof(seq_t)); }
+        g_census[2]++;
         seq_t *q = &out->a[out->n++];
         q->s = sb; q->len = len; q->avg = (int)(w / (int64_t)(len - (uint64_t)k + 1)); q->mn = mn; q->mx = mx;
         return;
@@ -501,6 +508,7 @@ static void process_sequence(const or_table *t, skmer start, int k, int thr, int
 
 /* SequencesFinders.thresholdStrategy :13-31 + AddSequencesShiftingRightTask.run :40-71 */
 or_seqs *or_build_unitigs(const or_table *t, int k, int thr, int min_len) {
+    g_census[0] = g_census[1] = g_census[2] = 0;
     or_seqs *out = (or_seqs *)calloc(1, sizeof *out);
     or_table *used = or_table_new();
     uint64_t n; kv_t *a = table_sorted(t, thr, &n);       /* value <= freqThreshold -> continue */
@@ -912,4 +920,130 @@ uint64_t or_cpu_baseline_count(const uint8_t *bases, const uint64_t *offsets, ui
     free(c.sh); free(th);
     if (n_occ) *n_occ = c.n_occ;
     return distinct;
+}
+
+/* ------------------------------------------------------------------ */
+/* The same baseline WITH the reference's reader and dump (bench.py)   */
+/* ------------------------------------------------------------------ */
+/* kmer-counter on one FASTA file as the reference runs it:
+ *  - IOUtils.run (src/io/IOUtils.java:838-865) starts P ReadsWorkers; a worker's loop (src/io/ReadsWorker.java:28-41) asks
+ *    the ReadsDispatcher for the next <= 32768 reads; getWorkRange is `synchronized` (src/io/ReadsDispatcher.java:34-53) and
+ *    PARSES them from the file inside the monitor (FastaReader, itmo!/io/readers/FastaReader.java:53-104: multi-line
+ *    records, reads with N dropped) -- the reference's serial section -- then the worker counts its batch in parallel;
+ *  - IOUtils.printKmers (src/io/IOUtils.java:45-71): ONE thread walks every slot of every shard, writes the entries with
+ *    count > b as 10-byte big-endian records and tallies the histogram of all counts.
+ * Times are returned separately: sec[0] = loadReads (reader + counting), sec[1] = printKmers. */
+typedef struct {
+    bctx b;                        /* shards, k, n_occ (bases / off / next unused) */
+    FILE *f; pthread_mutex_t rd;   /* the dispatcher's monitor */
+    char *line; size_t line_cap;   /* getline buffer (used under the monitor) */
+    char *pending; size_t pend_len, pend_cap; int have_pending_header, eof;
+    uint64_t n_reads;
+} fctx;
+/* next record under the monitor -> appended to (buf, off); returns 0 at end of file */
+static int fa_next(fctx *c, uint8_t **buf, size_t *len, size_t *cap) {
+    /* header line already consumed (have_pending_header) or to be found */
+    ssize_t n;
+    if (!c->have_pending_header) {
+        for (;;) {
+            n = getline(&c->line, &c->line_cap, c->f);
+            if (n < 0) return 0;
+            if (c->line[0] == '>' || c->line[0] == ';') break;
+        }
+    }
+    c->have_pending_header = 0;
+    size_t start = *len; int bad = 0;
+    for (;;) {
+        n = getline(&c->line, &c->line_cap, c->f);
+        if (n < 0) { c->eof = 1; break; }
+        if (c->line[0] == '>' || c->line[0] == ';') { c->have_pending_header = 1; break; }
+        while (n > 0 && (c->line[n - 1] == '\n' || c->line[n - 1] == '\r')) n--;
+        if (*len + (size_t)n > *cap) { *cap = (*len + (size_t)n) * 2 + 4096; *buf = (uint8_t *)realloc(*buf, *cap); }
+        for (ssize_t i = 0; i < n; i++) { char ch = c->line[i]; if (ch == 'N' || ch == 'n') bad = 1; (*buf)[(*len)++] = (uint8_t)ch; }
+    }
+    if (bad) *len = start;          /* FastaReaderFromXQSource: a read with N is skipped */
+    return 1;
+}
+static void *fworker(void *arg) {
+    fctx *c = (fctx *)arg;
+    const int k = c->b.k; uint64_t occ = 0, nr = 0;
+    uint8_t *buf = NULL; size_t len = 0, cap = 0;
+    uint64_t *off = (uint64_t *)malloc(32769 * sizeof(uint64_t));
+    for (;;) {
+        int m = 0; len = 0; off[0] = 0;
+        pthread_mutex_lock(&c->rd);                 /* ReadsDispatcher.getWorkRange: parse up to 32768 reads */
+        while (m < 32768 && !(c->eof && !c->have_pending_header)) {
+            size_t before = len;
+            if (!fa_next(c, &buf, &len, &cap)) break;
+            if (len > before) { m++; off[m] = len; }
+        }
+        pthread_mutex_unlock(&c->rd);
+        if (m == 0) break;
+        nr += (uint64_t)m;
+        for (int r = 0; r < m; r++) {
+            const uint8_t *s = buf + off[r]; uint64_t L = off[r + 1] - off[r];
+            if (L < (uint64_t)k) continue;
+            uint64_t fw = 0;
+            for (int i = 0; i < k; i++) fw = (fw << 2) | (uint64_t)nuc_code(s[i]);
+            skmer km = sk_make(fw, k);
+            for (uint64_t i = (uint64_t)k;; i++) {
+                int64_t key = (int64_t)sk_canon(km);
+                bshard_add(&c->b.sh[murmur32((uint32_t)key) & c->b.mask], key);
+                occ++;
+                if (i >= L) break;
+                sk_shift_right(&km, nuc_code(s[i]), k);
+            }
+        }
+    }
+    free(buf); free(off);
+    __sync_fetch_and_add(&c->b.n_occ, occ);
+    __sync_fetch_and_add(&c->n_reads, nr);
+    return NULL;
+}
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
+int or_cpu_baseline_file(const char *fasta, int k, int threads, int bcut, const char *kmers_bin, uint64_t *res, double *sec) {
+    /* res[0] = occurrences, [1] = distinct, [2] = written (count > bcut), [3] = reads */
+    fctx c; memset(&c, 0, sizeof c);
+    c.f = fopen(fasta, "rb");
+    if (!c.f) return -1;
+    setvbuf(c.f, NULL, _IOFBF, 1 << 22);
+    int lg = 0; while ((1 << (lg + 1)) <= threads) lg++;
+    uint32_t ns = 1u << (lg + 4);
+    c.b.sh = (bshard *)calloc(ns, sizeof(bshard)); c.b.mask = ns - 1; c.b.k = k;
+    for (uint32_t i = 0; i < ns; i++) {
+        pthread_mutex_init(&c.b.sh[i].lock, NULL);
+        c.b.sh[i].cap = 4096; c.b.sh[i].max_fill = 3072;
+        c.b.sh[i].keys = (int64_t *)calloc(4096, sizeof(int64_t)); c.b.sh[i].vals = (int16_t *)calloc(4096, sizeof(int16_t));
+    }
+    pthread_mutex_init(&c.rd, NULL);
+    const double t0 = now_s();
+    pthread_t *th = (pthread_t *)malloc((size_t)threads * sizeof(pthread_t));
+    for (int i = 0; i < threads; i++) pthread_create(&th[i], NULL, fworker, &c);
+    for (int i = 0; i < threads; i++) pthread_join(th[i], NULL);
+    const double t1 = now_s();
+    /* printKmers: one thread, every slot */
+    FILE *o = kmers_bin ? fopen(kmers_bin, "wb") : NULL;
+    if (o) setvbuf(o, NULL, _IOFBF, 1 << 24);       /* (16 MiB buffer: IOUtils.java:52) */
+    uint64_t distinct = 0, written = 0, *hist = (uint64_t *)calloc(SHORT_MAX + 1, sizeof(uint64_t));
+    for (uint32_t i = 0; i < ns; i++) {
+        bshard *s = &c.b.sh[i];
+        for (uint32_t j = 0; j < s->cap; j++) if (s->keys[j]) {
+            const int16_t v = s->vals[j]; hist[v]++; distinct++;
+            if (v > bcut) {
+                uint8_t rec[10]; uint64_t kk = (uint64_t)s->keys[j];
+                for (int q = 0; q < 8; q++) rec[q] = (uint8_t)(kk >> (8 * (7 - q)));
+                rec[8] = (uint8_t)((uint16_t)v >> 8); rec[9] = (uint8_t)v;
+                if (o) fwrite(rec, 1, 10, o);
+                written++;
+            }
+        }
+        if (s->has_free) { hist[s->free_val]++; distinct++; if (s->free_val > bcut) { uint8_t rec[10] = {0}; rec[8] = (uint8_t)((uint16_t)s->free_val >> 8); rec[9] = (uint8_t)s->free_val; if (o) fwrite(rec, 1, 10, o); written++; } }
+        free(s->keys); free(s->vals);
+    }
+    if (o) fclose(o);
+    const double t2 = now_s();
+    res[0] = c.b.n_occ; res[1] = distinct; res[2] = written; res[3] = c.n_reads;
+    sec[0] = t1 - t0; sec[1] = t2 - t1;
+    free(hist); free(c.b.sh); free(th); free(c.line); fclose(c.f);
+    return 0;
 }

@@ -66,6 +66,7 @@ int       or_load_kmers(or_table *t, const char *const *files, int nfiles, int f
  *      src/algo/HashMapOperations.java:13-47; src/algo/SequencesFinders.java:13-31;
  *      src/structures/Sequence.java:26-37; FastaDedicatedWriter.java:15,33-49) ---- */
 or_seqs  *or_build_unitigs(const or_table *t, int k, int freq_threshold, int min_len);
+void      or_unitig_census(uint64_t out[3]);   /* of the last or_build_unitigs: walks started / long enough / emitted */
 void      or_seqs_free(or_seqs *s);
 uint64_t  or_seqs_count(const or_seqs *s);
 uint64_t  or_seqs_total_len(const or_seqs *s);
@@ -113,6 +114,8 @@ uint64_t  or_canonical(uint64_t kmer, int k);
  * number of distinct k-mers, fills *n_occ.                                    */
 uint64_t  or_cpu_baseline_count(const uint8_t *bases, const uint64_t *offsets,
                                 uint64_t n_reads, int k, int threads, uint64_t *n_occ);
+/* the same with the reference's serial reader (FASTA file) and single-threaded dump; res[4], sec[2]: see mf_oracle.c */
+int       or_cpu_baseline_file(const char *fasta, int k, int threads, int bcut, const char *kmers_bin, uint64_t *res, double *sec);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,7 @@ def lib():
     sig("or_load_kmers", i32, vp, C.POINTER(cp), i32, i32)
     sig("or_build_unitigs", vp, vp, i32, i32, i32)
     sig("or_seqs_free", None, vp)
+    sig("or_unitig_census", None, pu64)
     sig("or_seqs_count", u64, vp)
     sig("or_seqs_total_len", u64, vp)
     sig("or_seqs_get", i32, vp, u64, C.POINTER(vp), pu64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
@@ -72,6 +73,7 @@ def lib():
     sig("or_revcomp", u64, u64, i32)
     sig("or_canonical", u64, u64, i32)
     sig("or_cpu_baseline_count", u64, vp, vp, u64, i32, i32, pu64)
+    sig("or_cpu_baseline_file", i32, cp, i32, i32, i32, cp, pu64, C.POINTER(C.c_double))
     _lib = L
     return L
 
@@ -187,6 +189,13 @@ class Seqs:
 
     def write_fasta(self, path):
         _check(lib().or_seqs_write_fasta(self.h, os.fsencode(path)))
+
+
+def unitig_census():
+    """of the last build_unitigs call: (walks started, walks of at least min_len nucleotides, walks emitted)"""
+    c = (C.c_uint64 * 3)()
+    lib().or_unitig_census(c)
+    return int(c[0]), int(c[1]), int(c[2])
 
 
 def build_unitigs(table, k, freq_threshold, min_len):
@@ -321,6 +330,17 @@ def cpu_baseline_count(bases, offsets, k, threads):
     occ = C.c_uint64()
     d = lib().or_cpu_baseline_count(bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, k, threads, C.byref(occ))
     return d, occ.value
+
+
+def cpu_baseline_file(fasta, k, threads, bcut=1, kmers_bin=None):
+    """kmer-counter on a FASTA file the way the reference runs it: serial reader inside the dispatcher's monitor, P counting
+    workers, single-threaded dump.  -> dict(n_occ, distinct, written, reads, load_s, dump_s)"""
+    res = (C.c_uint64 * 4)()
+    sec = (C.c_double * 2)()
+    rc = lib().or_cpu_baseline_file(fasta.encode(), k, threads, bcut, kmers_bin.encode() if kmers_bin else None, res, sec)
+    if rc != 0:
+        raise RuntimeError(f"cannot read {fasta}")
+    return dict(n_occ=res[0], distinct=res[1], written=res[2], reads=res[3], load_s=sec[0], dump_s=sec[1])
 
 
 def run_pipeline(files, k=31, b=1, l=100, b1=1000, b2=10000):

@@ -51,6 +51,39 @@ def main():
             components=[[int(a), int(w), int(t)] for a, w, t, _ in comps],
             members_sha256=hashlib.sha256(b"".join(np.asarray(km, dtype="<u8").tobytes() for _, _, _, km in comps)).hexdigest(),
             vectors=r["vecs"].tolist(), matrix=[[float(x) for x in row] for row in r["matrix"]])
+    # ---- branchy synthetic samples (tests/util.py: branchy_reads): the 0 / 1 / 2-emission rule and threshold levels >= 3
+    sys.path.insert(0, os.path.dirname(HERE))
+    from util import branchy_reads, emission_census
+    import tempfile
+    out["branchy"] = {}
+    for seed in (7, 8, 9):
+        b, o = branchy_reads(seed)
+        keys, vals = O.Table().count_buffer(b, o, 31).export()
+        g = O.Table()
+        for kk, vv in zip(keys[vals > 1].tolist(), vals[vals > 1].tolist()):
+            g.add(kk, vv)
+        seqs = O.build_unitigs(g, 31, 1, 100).all()
+        started, long_enough, emitted = O.unitig_census()
+        once, twice = emission_census(seqs)
+        out["branchy"][str(seed)] = dict(n_distinct=int(len(keys)), counts_sha256=digest_table(keys, vals), n_unitigs=len(seqs),
+                                         unitigs_sha256=digest_seqs(seqs), census=[once, twice, long_enough // 2 - once - twice])
+    td = tempfile.mkdtemp()
+    lf = []
+    for i, rs in enumerate((107, 117, 127, 137)):
+        b, o = branchy_reads(rs, genome_seed=7, n=6000)
+        f = os.path.join(td, f"s{i}.fa")
+        with open(f, "wb") as fh:
+            for j in range(len(o) - 1):
+                fh.write(b">r\n" + b[int(o[j]):int(o[j + 1])].tobytes() + b"\n")
+        lf.append(f)
+    r = O.run_pipeline(lf, b1=100, b2=1000)
+    comps = r["comps"].all()
+    ck, cv = r["cutter"].export()
+    out["pipelines"]["levels"] = dict(
+        b1=100, b2=1000, read_seeds=[107, 117, 127, 137], genome_seed=7, n_reads=6000, cutter_size=len(r["cutter"]), cutter_sha256=digest_table(ck, cv),
+        components=[[int(a), int(w), int(t)] for a, w, t, _ in comps],
+        members_sha256=hashlib.sha256(b"".join(np.asarray(km, dtype="<u8").tobytes() for _, _, _, km in comps)).hexdigest(),
+        vectors=r["vecs"].tolist(), matrix=[[float(x) for x in row] for row in r["matrix"]])
     with open(os.path.join(HERE, "known_answers.json"), "w") as fh:
         json.dump(out, fh, indent=1)
     print("wrote known_answers.json")

@@ -307,6 +307,37 @@ def test_cli_errors_and_single_tools(ref_files, tmp_path):
     assert sorted(os.listdir(wd / "stats")) == ["lib.stat.txt", "meta_test_1.stat.txt"]
 
 
+def test_cli_bottom_cut_percent(oracle, ref_files, tmp_path):
+    """seq-builder -bp (SeqBuilderMain.runImpl, src/tools/SeqBuilderMain.java:80-115): the k-mers are loaded with the default
+    -b 1, and maximal-bad-frequency becomes the first count i whose lower counts hold >= bp % of all k-mer occurrences"""
+    exe = os.path.join(ROOT, "metafast.sh")
+    wd = tmp_path / "w"
+    r = subprocess.run([exe, "-t", "kmer-counter", "-k", "31", "-b", "0", "-i", ref_files[0], "-w", str(wd)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    kb = str(wd / "kmers" / "meta_test_1.kmers.bin")
+    t = oracle.Table().load_kmers([kb], 1)                       # loadKmers(files, maximalBadFrequency = 1)
+    keys, vals = t.export()
+    stat = np.bincount(np.minimum(vals, 1023), minlength=1024)
+    for bp in (5, 40):
+        to_cut, cur, b = int(vals.astype(np.int64).sum()) * bp // 100, 0, 1
+        for i in range(1023):
+            if cur >= to_cut:
+                b = i
+                break
+            cur += i * int(stat[i])
+        w2 = tmp_path / f"w_bp{bp}"
+        r = subprocess.run([exe, "-t", "seq-builder", "-k", "31", "-i", kb, "-bp", str(bp), "-l", "100", "-w", str(w2)], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert f"Using bottom cut percent = {bp}" in r.stdout + r.stderr + open(w2 / "log").read()
+        assert f"Using maximal bad frequency = {b}" in r.stdout + r.stderr + open(w2 / "log").read()
+        want = oracle.build_unitigs(t, 31, b, 100)
+        want.write_fasta(str(tmp_path / f"want_bp{bp}.fa"))
+        got = sorted(open(w2 / "sequences" / "meta_test_1.seq.fasta").read().split(">")[1:], key=lambda x: x.split("\n", 1)[1])
+        exp = sorted(open(tmp_path / f"want_bp{bp}.fa").read().split(">")[1:], key=lambda x: x.split("\n", 1)[1])
+        norm = lambda recs: sorted((min(q := "".join(x.split("\n")[1:]), q[::-1].translate(str.maketrans("ACGT", "TGCA"))), x.split("\n")[0].split(" ", 1)[1]) for x in recs)
+        assert norm(got) == norm(exp) and (bp == 5 or b > 1)     # (the larger percentage must really move the threshold)
+
+
 def test_cli_posneg_and_kmers_filter(gpu_ctx, oracle, ref_files, tmp_path):
     """kmer-counter-posneg (KmersCounterPositiveNegative.java:66-108): two kmer-counter-many steps under pos/ and neg/;
     kmers-filter (KmersFilter.java:80-121, IOUtils.filterAndPrintKmers src/io/IOUtils.java:101-123): the records of a

@@ -37,22 +37,13 @@ def test_oracle_matches_fixture(oracle, ref_files):
     assert p["matrix"][0][1] == 0.5691162409506898         # the reference's own golden value
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name", ["default", "split"])
-def test_gpu_matches_fixture(gpu_ctx, ref_files, name):
+def _gpu_pipeline_matches(gpu_ctx, p, tables):
+    """cutter -> components -> features -> matrix on the GPU against the fixture entry p (no oracle in the loop)"""
     import torch
     from metafast_amd import lib as L
     from metafast_amd import pipeline as P
-    p = KA["pipelines"][name]
-    tables, goods, seqs = [], [], []
-    for f, s in zip(ref_files, KA["samples"]):
-        t = gpu_ctx.count_reads([f], KA["k"])
-        keys, cnts = t.export()
-        assert (len(keys), _digest_table(keys, cnts)) == (s["n_distinct"], s["counts_sha256"])
-        sq = gpu_ctx.build_unitigs(t, KA["b"], KA["l"])
-        got = sq.export()
-        assert (len(got), sum(len(x[0]) for x in got), _digest_seqs(got)) == (s["n_unitigs"], s["unitig_nt"], s["unitigs_sha256"])
-        tables.append(t); goods.append(t.filter(KA["b"])); seqs.append(sq)
+    goods = [t.filter(KA["b"]) for t in tables]
+    seqs = [gpu_ctx.build_unitigs(t, KA["b"], KA["l"]) for t in tables]
     parts_b, parts_o, nb, ns = [], [], 0, 0
     for sq in seqs:
         v = sq.device_view()
@@ -74,3 +65,58 @@ def test_gpu_matches_fixture(gpu_ctx, ref_files, name):
     assert vecs.tolist() == p["vectors"]
     m = L.bray_curtis(vecs)
     assert np.abs(m - np.array(p["matrix"])).max() <= 1e-6 and m.tolist() == p["matrix"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["default", "split"])
+def test_gpu_matches_fixture(gpu_ctx, ref_files, name):
+    tables = []
+    for f, s in zip(ref_files, KA["samples"]):
+        t = gpu_ctx.count_reads([f], KA["k"])
+        keys, cnts = t.export()
+        assert (len(keys), _digest_table(keys, cnts)) == (s["n_distinct"], s["counts_sha256"])
+        sq = gpu_ctx.build_unitigs(t, KA["b"], KA["l"])
+        got = sq.export()
+        assert (len(got), sum(len(x[0]) for x in got), _digest_seqs(got)) == (s["n_unitigs"], s["unitig_nt"], s["unitigs_sha256"])
+        tables.append(t)
+    _gpu_pipeline_matches(gpu_ctx, KA["pipelines"][name], tables)
+
+
+def test_oracle_matches_branchy_fixture(oracle):
+    from util import branchy_reads, emission_census
+    for seed, e in KA["branchy"].items():
+        b, o = branchy_reads(int(seed))
+        keys, vals = oracle.Table().count_buffer(b, o, 31).export()
+        assert (len(keys), _digest_table(keys, vals)) == (e["n_distinct"], e["counts_sha256"])
+        g = oracle.Table()
+        for kk, vv in zip(keys[vals > 1].tolist(), vals[vals > 1].tolist()):
+            g.add(kk, vv)
+        seqs = oracle.build_unitigs(g, 31, 1, 100).all()
+        long_enough = oracle.unitig_census()[1]
+        once, twice = emission_census(seqs)
+        assert [once, twice, long_enough // 2 - once - twice] == e["census"] and _digest_seqs(seqs) == e["unitigs_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", ["7", "8", "9"])
+def test_gpu_matches_branchy_fixture(gpu_ctx, seed):
+    """counts and unitigs (with the 0 / 1 / 2-emission rule at work) against committed digests: no oracle in the loop"""
+    from util import branchy_reads, emission_census, gpu_count
+    e = KA["branchy"][seed]
+    b, o = branchy_reads(int(seed))
+    t = gpu_count(gpu_ctx, b, o, 31)
+    keys, cnts = t.export()
+    assert (len(keys), _digest_table(keys, cnts)) == (e["n_distinct"], e["counts_sha256"])
+    got = gpu_ctx.build_unitigs(t, 1, 100).export()
+    assert (len(got), _digest_seqs(got)) == (e["n_unitigs"], e["unitigs_sha256"])
+    assert list(emission_census(got)) == e["census"][:2]
+
+
+@pytest.mark.gpu
+def test_gpu_matches_levels_fixture(gpu_ctx):
+    """threshold levels up to 6 (components larger than b2 split again and again) against the committed answers"""
+    from util import branchy_reads, gpu_count
+    p = KA["pipelines"]["levels"]
+    tables = [gpu_count(gpu_ctx, *branchy_reads(rs, genome_seed=p["genome_seed"], n=p["n_reads"]), 31) for rs in p["read_seeds"]]
+    assert max(t for _, _, t in p["components"]) >= 3
+    _gpu_pipeline_matches(gpu_ctx, p, tables)

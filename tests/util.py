@@ -62,3 +62,36 @@ def canon_seq(s):
     """strand-normalised form of a sequence (min of itself and its reverse complement)"""
     rc = s[::-1].translate(str.maketrans("ACGT", "TGCA"))
     return min(s, rc)
+
+
+def branchy_reads(seed, genome_seed=None, n=12000):
+    """genome with two extra copies of a 400-bp repeat + substitution errors: gives branches, tips and bubbles,
+    i.e. paths that the reference's emission rule prints 0, 1 or 2 times.  genome_seed: several
+    samples (different `seed`s) of ONE genome, for cutter tables with values > 2."""
+    grng = np.random.default_rng(seed if genome_seed is None else genome_seed)
+    al = np.frombuffer(b"ACGT", dtype=np.uint8)
+    g = al[grng.integers(0, 4, size=60000)]
+    rep = g[1000:1400].copy()
+    g = np.concatenate([g[:30000], rep, g[30000:45000], rep, g[45000:]])
+    rng = grng if genome_seed is None else np.random.default_rng(seed)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    rl = 150
+    starts = rng.integers(0, len(g) - rl + 1, size=n)
+    out = np.empty((n, rl), dtype=np.uint8)
+    for i, s in enumerate(starts):
+        r = g[s:s + rl]
+        out[i] = comp[r[::-1]] if rng.integers(0, 2) else r
+    m = rng.random(out.shape) < 0.004
+    out[m] = al[rng.integers(0, 4, size=int(m.sum()))]
+    off = np.arange(n + 1, dtype=np.uint64) * np.uint64(rl)
+    return out.reshape(-1).copy(), off
+
+
+def emission_census(seqs):
+    """(printed once, printed twice) over the strand-normalised unitigs"""
+    from collections import Counter
+    c = Counter(canon_seq(s[0]) for s in seqs)
+    assert max(c.values(), default=1) <= 2
+    return sum(1 for v in c.values() if v == 1), sum(1 for v in c.values() if v == 2)
