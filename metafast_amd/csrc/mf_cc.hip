@@ -16,6 +16,7 @@
 // A round at threshold t is ONE global pass over all still-alive vertices: different oversize components
 // are disconnected, so splitting them together is the same as the reference's per-component Tasks.
 #include "mf_common.h"
+#include "mf_nbr.h"
 #include <algorithm>
 #include <numeric>
 #include <memory>
@@ -42,6 +43,17 @@ __global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ ke
     uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
     o[0] = make_uint4(out[0], out[1], out[2], out[3]);
     o[1] = make_uint4(out[4], out[5], out[6], out[7]);
+}
+
+// the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
+__global__ __launch_bounds__(64 * NB_WAVES) void k_cc_adjacency_part(mf_index_view ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
+                                                                   uint32_t np, int k, uint32_t *__restrict__ nbr, int abl) {
+    __shared__ nb_lds S;
+    nb_for_each(ix, keys, part_off, np, k, S, abl, [&](uint64_t v, uint64_t, const uint32_t (&idx)[8], uint32_t) {
+        uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
+        o[0] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
+        o[1] = make_uint4(idx[4], idx[5], idx[6], idx[7]);
+    });
 }
 
 __device__ __forceinline__ uint32_t cc_find(uint32_t *parent, uint32_t x) {
@@ -375,6 +387,11 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
         cc_kept_arrays K; K.root = k_root.p; K.size = k_size.p; K.weight = k_weight.p; K.minkey = k_minkey.p;
         {
             mf_ktimer tm(ctx, "k_cc_adjacency");
+            if (t->index.skm_k && t->index.part_bits && t->d_part_off && !ctx->opt_nbr_global && (n >> t->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
+                const uint32_t np = 1u << t->part_bits;
+                const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
+                k_cc_adjacency_part<<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p, (int)ctx->opt_ablate);
+            } else
             k_cc_adjacency<<<cgrid(n), 256, 0, st>>>(mf_view(t->index), t->d_keys, n, k, nbr.p);
         }
         MF_HIP(hipMemsetAsync(alive.p, 1, n, st));

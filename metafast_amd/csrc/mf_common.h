@@ -65,6 +65,7 @@ struct mf_ctx {
     int64_t opt_sr_piece = 8 << 20, opt_sr_slack = 1 << 20;
     void *pin_pool = nullptr; size_t pin_pool_bytes = 0;           // pinned staging chunks of the streaming reader (lazy, kept)
     int64_t opt_skm_batches = 0;   // partitions are counted + gathered in this many batches (0 = auto); tests force small values
+    int64_t opt_nbr_global = 0;    // 1: neighbour lookups of the graph kernels through the HBM index only (A/B of mf_nbr.h)
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero
     // workspace arena: a few large hipMalloc'd regions, sub-allocated with first-fit + coalescing free lists.
     // Everything runs on one stream, so a block can be handed out again as soon as it is released.

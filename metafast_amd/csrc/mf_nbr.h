@@ -1,0 +1,137 @@
+// mf_nbr.h -- the eight de Bruijn neighbours of every k-mer of a table, looked up PARTITION-LOCALLY.
+//
+// getLeftNucleotide / getRightNucleotide (src/algo/HashMapOperations.java:13-47) and possibleNeighbours
+// (src/algo/KmerOperations.java:9-26) probe the map eight times per k-mer.  Against the HBM index that is eight random
+// 16-byte reads per k-mer, each pulling in a whole line: round 1 measured 169 GB fetched for 38 GB asked (k_ut_flags) and
+// 60 GB for 10 GB (k_cc_adjacency).  But a table that comes out of the counting pass is ordered by MINIMIZER partition,
+// and nine neighbours in ten share their k-mer's minimizer, i.e. its partition -- a few hundred k-mers that sit next to
+// each other in the table.  So: one wave per partition.  It reads the partition's keys (coalesced), builds a small
+// open-addressed table of them in LDS (512 slots: 8-byte key + 2-byte position), and looks the neighbours up there; only a
+// neighbour whose own minimizer differs (its partition hash says so before any memory is touched) goes to the HBM index.
+// Partitions larger than NB_CAP keys use the HBM index for everything.
+#pragma once
+#include "mf_common.h"
+#ifdef __HIPCC__
+#define NB_SLOTS 512
+#define NB_CAP 352                 // keys of a partition that go into the LDS table (load <= 0.69)
+#define NB_WAVES 4                 // waves (= partitions in flight) per workgroup
+#define NB_NONE 0xFFFFFFFFu
+
+#define NB_RQ 128                  // remote requests a wave collects per 64 k-mers (more: looked up on the spot)
+struct nb_lds {
+    uint64_t key[NB_WAVES][NB_SLOTS]; uint64_t rq_key[NB_WAVES][NB_RQ];
+    uint32_t rq_ph[NB_WAVES][NB_RQ]; uint32_t rq_idx[NB_WAVES][NB_RQ];
+    uint16_t pos[NB_WAVES][NB_SLOTS];
+};
+
+__device__ __forceinline__ uint32_t nb_slot(uint64_t key) {
+    return (((uint32_t)key ^ (uint32_t)(key >> 29)) * 0x9E3779B1u) >> 23;          // 9 bits
+}
+// neighbour i of x: i = 2*nuc (append nuc on the right) or 2*nuc+1 (prepend nuc on the left); *ph = its partition hash
+__device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, int k, uint64_t kmask, uint32_t i, uint32_t m_nf, uint32_t m_nl, uint64_t *oriented, uint32_t *ph) {
+    const uint32_t nuc = i >> 1;
+    uint64_t y;
+    if (i & 1u) { y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2)); *ph = mf_skm_ph_left(y, k, m_nl); }
+    else { y = ((x << 2) | nuc) & kmask; *ph = mf_skm_ph_right(y, m_nf); }
+    *oriented = y;
+    const uint64_t r = mf_revcomp(y, k);
+    return y < r ? y : r;
+}
+// Calls emit(j, x, idx[8], canonical != oriented [8 bits]) for every k-mer j of the table; idx[i] = table index of
+// neighbour i or NB_NONE.  One wave per partition, partitions dealt round-robin to the waves of the grid.
+template <typename F>
+__device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
+                                            uint32_t np, int k, nb_lds &S, int abl, F &&emit) {
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x * NB_WAVES + wave, nw = gridDim.x * NB_WAVES;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    uint64_t *hk = S.key[wave]; uint16_t *hp = S.pos[wave];
+    uint64_t *rk = S.rq_key[wave]; uint32_t *rp = S.rq_ph[wave], *ri = S.rq_idx[wave];
+    const int shift = 32 - (int)ix.part_bits;
+    for (uint32_t p = gw; p < np; p += nw) {
+        const uint64_t lo = part_off[p], hi = part_off[p + 1];
+        const uint32_t n = (uint32_t)(hi - lo);
+        if (n == 0) continue;                                               // wave-uniform
+        const bool local = n <= (uint32_t)NB_CAP;
+        if (local && !(abl & 4)) {
+            for (uint32_t s = lane; s < (uint32_t)NB_SLOTS; s += 64) hk[s] = MF_EMPTY;
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = lane; j < n; j += 64) {
+                const uint64_t x = keys[lo + j];
+                uint32_t s = nb_slot(x);
+                for (;;) {                                                  // (keys of a table are distinct)
+                    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&hk[s]), (unsigned long long)MF_EMPTY, (unsigned long long)x);
+                    if (old == (unsigned long long)MF_EMPTY) { hp[s] = (uint16_t)j; break; }
+                    s = (s + 1u) & (uint32_t)(NB_SLOTS - 1);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        for (uint32_t j0 = 0; j0 < n; j0 += 64) {                           // wave-uniform
+            const uint32_t j = j0 + lane;
+            const bool have = j < n;
+            const uint64_t x = have ? keys[lo + j] : 0ull;
+            uint32_t m_nf = 0, m_nl = 0;
+            mf_skm_nbr_mins(x, k, &m_nf, &m_nl);
+            // Pass 1: which neighbours live in another partition (about one in ten)?  Those are REQUESTS for the HBM index --
+            // a directory entry, then a slot: two dependent cache misses.  Looked up where they arise they cost the wave
+            // eight such round trips per 64 k-mers with six lanes in 64 busy (ablation, 100 M reads: 25 of the kernel's 39
+            // ms).  So the wave collects them in LDS, looks them up 64 at a time, one request per lane, and hands the
+            // answers back through LDS.
+            uint32_t remote = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) {
+                uint64_t y; uint32_t ph;
+                nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &ph);
+                if (have && !(local && (ph >> shift) == p)) remote |= 1u << i;
+            }
+            uint32_t R;
+            const uint32_t rbase = mf_wave_excl_scan((uint32_t)__popc(remote), &R);
+            uint32_t idx[8]; uint32_t flip = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) {
+                uint64_t y; uint32_t ph;
+                const uint64_t c = nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &ph);
+                flip |= (c != y) ? (1u << i) : 0u;
+                idx[i] = NB_NONE;
+                if (have) {
+                    if (!((remote >> i) & 1u)) {
+                        if (!(abl & 2)) {
+                        uint32_t s = nb_slot(c);
+                        for (;;) {
+                            const uint64_t v = hk[s];
+                            if (v == c) { idx[i] = (uint32_t)lo + (uint32_t)hp[s]; break; }
+                            if (v == MF_EMPTY) break;
+                            s = (s + 1u) & (uint32_t)(NB_SLOTS - 1);
+                        }
+                        }
+                    } else if (!(abl & 1)) {
+                        const uint32_t at = rbase + (uint32_t)__popc(remote & ((1u << i) - 1u));
+                        if (at < (uint32_t)NB_RQ) { rk[at] = c; rp[at] = ph; }
+                        else { uint32_t ii, val; if (mf_index_find_ph(ix, c, ph, &ii, &val)) idx[i] = ii; }
+                    }
+                }
+            }
+            if (R && !(abl & 1)) {
+                __builtin_amdgcn_wave_barrier();
+                const uint32_t Rl = R < (uint32_t)NB_RQ ? R : (uint32_t)NB_RQ;
+                for (uint32_t r = lane; r < Rl; r += 64) {
+                    uint32_t ii, val;
+                    ri[r] = mf_index_find_ph(ix, rk[r], rp[r], &ii, &val) ? ii : NB_NONE;
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (uint32_t i = 0; i < 8; i++) {
+                    if ((remote >> i) & 1u) {
+                        const uint32_t at = rbase + (uint32_t)__popc(remote & ((1u << i) - 1u));
+                        if (at < (uint32_t)NB_RQ) idx[i] = ri[at];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (have) emit(lo + j, x, idx, flip);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+#endif

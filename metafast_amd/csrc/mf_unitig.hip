@@ -21,6 +21,7 @@
 //
 // Isolated cycles have no start node and are never emitted (same as the reference).
 #include "mf_common.h"
+#include "mf_nbr.h"
 #include <algorithm>
 #include <numeric>
 
@@ -75,6 +76,30 @@ __global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
     if (A.pal) A.pal[i] = (uint8_t)(mf_revcomp(x, k) == x);
     A.ridx[i] = ridx;
     A.lidx[i] = lidx;
+}
+
+// the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
+__global__ __launch_bounds__(64 * NB_WAVES) void k_ut_flags_part(mf_index_view ix, ut_arrays A, const uint64_t *__restrict__ part_off, uint32_t np, int abl) {
+    __shared__ nb_lds S;
+    const int k = A.k;
+    nb_for_each(ix, A.gk, part_off, np, k, S, abl, [&](uint64_t i, uint64_t x, const uint32_t (&idx)[8], uint32_t flip) {
+        uint32_t rcode = UT_CODE_NONE, lcode = UT_CODE_NONE, ridx = UT_NONE, lidx = UT_NONE, ror = 0, lor = 0;
+#pragma unroll
+        for (uint32_t nuc = 0; nuc < 4; nuc++) {
+            if (idx[2 * nuc] != NB_NONE) {
+                if (rcode == UT_CODE_NONE) { rcode = nuc; ridx = idx[2 * nuc]; ror = (flip >> (2 * nuc)) & 1u; }
+                else rcode = UT_CODE_MANY;
+            }
+            if (idx[2 * nuc + 1] != NB_NONE) {
+                if (lcode == UT_CODE_NONE) { lcode = nuc; lidx = idx[2 * nuc + 1]; lor = (flip >> (2 * nuc + 1)) & 1u; }
+                else lcode = UT_CODE_MANY;
+            }
+        }
+        A.info[i] = (uint8_t)(rcode | (lcode << 3) | (ror << 6) | (lor << 7));
+        if (A.pal) A.pal[i] = (uint8_t)(mf_revcomp(x, k) == x);
+        A.ridx[i] = ridx;
+        A.lidx[i] = lidx;
+    });
 }
 
 // helpers on oriented nodes: node = 2*i + o, o = 1 means reverse complement of the canonical k-mer
@@ -314,6 +339,11 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if ((k & 1) == 0) { if ((rc = pal.alloc(ctx, n)) < 0) break; A.pal = pal.p; }   // palindromes need an even k
         {
             mf_ktimer tm(ctx, "k_ut_flags");
+            if (g->index.skm_k && g->index.part_bits && g->d_part_off && !ctx->opt_nbr_global && (n >> g->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
+                const uint32_t np = 1u << g->part_bits;
+                const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
+                k_ut_flags_part<<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np, (int)ctx->opt_ablate);
+            } else
             k_ut_flags<<<grid_for(n), 256, 0, st>>>(mf_view(g->index), A);
         }
         {
