@@ -55,6 +55,7 @@ struct mf_ctx {
     int64_t opt_l1_bits = -1;      // -1 = auto
     int64_t opt_l2_bits = -1;
     int64_t opt_part_target = 6144;  // mean k-mer occurrences per final partition (k_skm_count2: ~800 distinct k-mers in 4096 slots)
+    int64_t opt_part_target_long = 512;   // ... for assembled sequences (mean length >= 8k: nearly duplicate-free)
     int64_t opt_scatter_staged = 1;
     int64_t opt_profile = 0;
     int64_t opt_l1_blocks = 0;     // 0 = auto
@@ -64,6 +65,8 @@ struct mf_ctx {
     int64_t opt_stream_reader = 1; // plain FASTA/FASTQ files go through the pinned, double-buffered streaming reader (mf_io.hip)
     int64_t opt_sr_piece = 8 << 20, opt_sr_slack = 1 << 20;
     void *pin_pool = nullptr; size_t pin_pool_bytes = 0;           // pinned staging chunks of the streaming reader (lazy, kept)
+    int64_t opt_skm_slices = 0;    // digit-range slices of a counting run (0 = as many as the HBM budget asks for)
+    int64_t opt_arena_cap_gb = 0;  // pretend the device has this much memory when the slices are chosen (0 = what it has)
     int64_t opt_skm_batches = 0;   // partitions are counted + gathered in this many batches (0 = auto); tests force small values
     int64_t opt_nbr_global = 0;    // 1: neighbour lookups of the graph kernels through the HBM index only (A/B of mf_nbr.h)
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero

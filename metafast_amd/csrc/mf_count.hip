@@ -626,7 +626,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     // cutter's input, ComponentCutterMain.java:81 -- whose k-mers are nearly all distinct: size those by a sixth, so that
     // a partition's index region stays a few KB and the 8 neighbour probes of a k-mer stay cache-local.
     uint64_t target = (uint64_t)ctx->opt_part_target;
-    if (n_bases / n_reads >= (uint64_t)(8 * k) && target > 512) target = 512;
+    if (n_bases / n_reads >= (uint64_t)(8 * k) && target > (uint64_t)ctx->opt_part_target_long) target = (uint64_t)ctx->opt_part_target_long;
     int B = ceil_log2_u64((n_occ + target - 1) / target);
     std::vector<int> lv;
     if (ctx->opt_l1_bits >= 0) {

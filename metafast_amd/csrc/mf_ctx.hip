@@ -82,6 +82,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     if (s == "l1_bits") { if (v > MF_MAX_DIGIT_BITS) return mf_set_error("l1_bits > %d", MF_MAX_DIGIT_BITS); ctx->opt_l1_bits = v; }
     else if (s == "l2_bits") { if (v > MF_MAX_DIGIT_BITS) return mf_set_error("l2_bits > %d", MF_MAX_DIGIT_BITS); ctx->opt_l2_bits = v; }
     else if (s == "part_target") { if (v < 1 || v > 16384) return mf_set_error("part_target out of [1,16384]"); ctx->opt_part_target = v; }
+    else if (s == "part_target_long") { if (v < 1 || v > 16384) return mf_set_error("part_target_long out of [1,16384]"); ctx->opt_part_target_long = v; }
     else if (s == "scatter_staged") ctx->opt_scatter_staged = v;
     else if (s == "profile") ctx->opt_profile = v;
     else if (s == "l1_blocks") ctx->opt_l1_blocks = v;
@@ -89,6 +90,8 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "ablate") ctx->opt_ablate = v;
     else if (s == "skm") ctx->opt_skm = v;
     else if (s == "skm_batches") ctx->opt_skm_batches = v;
+    else if (s == "skm_slices") { if (v < 0 || v > 64 || (v & (v - 1))) return mf_set_error("skm_slices must be 0 or a power of two <= 64"); ctx->opt_skm_slices = v; }
+    else if (s == "arena_cap_gb") ctx->opt_arena_cap_gb = v;
     else if (s == "stream_reader") ctx->opt_stream_reader = v;
     else if (s == "stream_piece_bytes") ctx->opt_sr_piece = v;
     else if (s == "stream_slack_bytes") ctx->opt_sr_slack = v;

@@ -163,7 +163,9 @@ __device__ __forceinline__ void skm_route(uint32_t mh, int bits1, uint32_t &d1, 
 template <int K>
 __global__ __launch_bounds__(1024) void k_skm_hist(const uint8_t *__restrict__ bases, uint64_t n_bases, const uint32_t *__restrict__ vmask,
                                                    uint64_t n_words, uint64_t words_per_block, int bits1,
-                                                   uint32_t *__restrict__ blockhist, uint32_t *__restrict__ blockocc, int G, int stride) {
+                                                   uint32_t *__restrict__ blockhist, uint32_t *__restrict__ blockocc, int G, int stride,
+                                                   uint32_t dlo, uint32_t dhi) {
+    // [dlo, dhi): the level-1 digits of this SLICE of the run (skm_run); records of other digits belong to other slices
     // stride > 1: a SAMPLE (every stride-th tile of 1024 words), used to size the digit regions of the one-pass scatter
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nd = 1 << bits1;
@@ -184,8 +186,10 @@ __global__ __launch_bounds__(1024) void k_skm_hist(const uint8_t *__restrict__ b
                 uint32_t s, len, d1, digits;
                 skm_next_run<K>(S, cut, s, len);
                 skm_route(skm_mh_at<K>(S, s), bits1, d1, digits);
-                atomicAdd(&hist[d1], 1u);
-                if (blockocc) atomicAdd(&occ[d1], len);
+                if (d1 >= dlo && d1 < dhi) {
+                    atomicAdd(&hist[d1], 1u);
+                    if (blockocc) atomicAdd(&occ[d1], len);
+                }
             }
         }
     }
@@ -340,7 +344,8 @@ __device__ __forceinline__ void skm_stage_flush_all(const skm_stage &L, skm_rec 
 template <int K, bool DYN>
 __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict__ bases, uint64_t n_bases, const uint32_t *__restrict__ vmask,
                                                       uint64_t n_words, uint64_t words_per_block, int bits1,
-                                                      const uint64_t *__restrict__ blockstart, int G, skm_rec *__restrict__ out, skm_dyn Dy) {
+                                                      const uint64_t *__restrict__ blockstart, int G, skm_rec *__restrict__ out, skm_dyn Dy,
+                                                      uint32_t dlo, uint32_t dhi) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nd = 1 << bits1;
     skm_stage L = skm_stage_carve(smem, nd);
@@ -368,6 +373,7 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
                     skm_next_run<K>(S, cut, s, len);
                     skm_route(skm_mh_at<K>(S, s), bits1, d[b], digits);
                     rec[b] = skm_make_rec<K>(S, s, len, digits);
+                    if (d[b] < dlo || d[b] >= dhi) { pend[b] = false; d[b] = 0; }      // (another slice's record)
                 }
             }
             skm_stage_insert<DYN>(L, out, d, rec, pend, Dy);
@@ -378,9 +384,11 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
 }
 
 // one-pass level 1: region size of every digit from a sampled histogram, and the directory afterwards
-__global__ void k_skm_region_sizes(const uint32_t *__restrict__ blockhist, int G, int nd, uint32_t scale, uint32_t *__restrict__ rsize) {
+__global__ void k_skm_region_sizes(const uint32_t *__restrict__ blockhist, int G, int nd, uint32_t scale, uint32_t *__restrict__ rsize,
+                                   uint32_t dlo, uint32_t dhi) {
     const int d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= nd) return;
+    if ((uint32_t)d < dlo || (uint32_t)d >= dhi) { rsize[d] = 0; return; }
     uint64_t t = 0;
     for (int b = 0; b < G; b++) t += blockhist[(size_t)d * G + b];
     t *= scale;
@@ -1009,13 +1017,27 @@ template <typename KF> static int skm_set_lds(KF kern, size_t bytes) {
 
 // lv: digit bits per level (lv[0] = level 1).  Returns MF_OK and *out, or MF_SKM_FALLBACK (nothing allocated) when the
 // input does not suit this path (a partition too rich for the LDS table, too many levels, not enough memory).
+// what the slices of one run add up to: the dense table (grouped by partition, slice after slice = partition order), the
+// partition offsets, the tallies
+struct skm_acc {
+    mf_buf<uint64_t> dk; mf_buf<uint16_t> dc; uint64_t dused = 0, dcap = 0;
+    mf_buf<uint64_t> doff;                 // [np_total + 1]
+    mf_buf<unsigned long long> dhist, c2p;
+    unsigned long long n_records = 0, cap_l1 = 0;
+    uint32_t np_total = 0;
+};
+#define MF_SKM_NOMEM 2             /* skm_slice: a record buffer did not fit -- the caller tries again with more slices */
+// One SLICE of the run: the records whose level-1 digit lies in [dlo, dhi) go through scatter, split and count.  A run is one
+// slice unless the records do not fit next to the reads (300 M reads and more): then the reads are scanned once per slice
+// and only a 1 / S share of the records exists at any time.  Partitions are numbered by digit, so slice after slice fills
+// the dense table in the same order as a single pass would.
 template <int K>
-static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words,
-                   uint64_t n_occ, const std::vector<int> &lv, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
+static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words,
+                     uint64_t n_occ, const std::vector<int> &lv, unsigned long long *scal, int kthr, uint32_t dlo, uint32_t dhi,
+                     uint32_t slice, uint32_t n_slices, skm_acc &A) {
     hipStream_t st = ctx->stream;
     const int bits1 = lv[0], nd1 = 1 << bits1;
     int total_bits = 0; for (int b : lv) total_bits += b;
-    if (total_bits > 32 || total_bits - bits1 > SKM_DIGIT_BITS) return MF_SKM_FALLBACK;
     int G = ctx->opt_l1_blocks > 0 ? (int)ctx->opt_l1_blocks : ctx->n_cu;
     {
         uint64_t maxG = (n_words + 1023) / 1024;
@@ -1052,26 +1074,26 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         mf_buf<uint32_t> blockocc; if (l1_only) MF_TRY(blockocc.alloc(ctx, (size_t)nd1 * G));
         {
             mf_ktimer t(ctx, D ? "k_skm_hist_sample" : "k_skm_hist");
-            k_skm_hist<K><<<G, 1024, (size_t)nd1 * 8, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockhist.p, blockocc.p, G, stride);
+            k_skm_hist<K><<<G, 1024, (size_t)nd1 * 8, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockhist.p, blockocc.p, G, stride, dlo, dhi);
         }
         MF_DBG(ctx, "k_skm_hist");
         if (D) {
             mf_buf<uint32_t> rsize; MF_TRY(rsize.alloc(ctx, np));
             mf_buf<uint64_t> rstart; MF_TRY(rstart.alloc(ctx, (size_t)np + 1));
             mf_buf<unsigned long long> gcur; MF_TRY(gcur.alloc(ctx, np));
-            k_skm_region_sizes<<<(nd1 + 255) / 256, 256, 0, st>>>(blockhist.p, G, nd1, (uint32_t)stride, rsize.p);
+            k_skm_region_sizes<<<(nd1 + 255) / 256, 256, 0, st>>>(blockhist.p, G, nd1, (uint32_t)stride, rsize.p, dlo, dhi);
             MF_TRY(mf_scan<1>(ctx, rsize.p, rstart.p, np, (uint64_t *)&scal[1]));
             MF_HIP(hipMemcpyAsync(gcur.p, rstart.p, (size_t)np * 8, hipMemcpyDeviceToDevice, st));
             MF_HIP(hipMemsetAsync(&scal[5], 0, 8, st));
             MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
             MF_HIP(hipStreamSynchronize(st));
-            if (bufA.alloc(ctx, std::max<unsigned long long>(cap + (uint64_t)G * SKM_CH, final_cap(cap))) != MF_OK) return MF_SKM_FALLBACK;
+            if (bufA.alloc(ctx, std::max<unsigned long long>(cap + (uint64_t)G * SKM_CH, final_cap(cap))) != MF_OK) return MF_SKM_NOMEM;
             skm_dyn Dy; Dy.gcur = gcur.p; Dy.rend = rstart.p + 1; Dy.overflow = (unsigned int *)&scal[5]; Dy.dump = cap;
             {
                 const size_t lds = skm_stage_bytes(nd1);
                 MF_TRY(skm_set_lds(k_skm_scatter<K, true>, lds));
                 mf_ktimer t(ctx, "k_skm_scatter");
-                k_skm_scatter<K, true><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, bufA.p, Dy);
+                k_skm_scatter<K, true><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, bufA.p, Dy, dlo, dhi);
             }
             MF_DBG(ctx, "k_skm_scatter");
             k_skm_dir_dyn<<<(nd1 + 255) / 256, 256, 0, st>>>(rstart.p, gcur.p, nd1, pstart.p, plen.p);
@@ -1087,19 +1109,28 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         MF_TRY(mf_scan<SKM_LINE>(ctx, blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal[1]));
         MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));                       // padded number of records
-        if (bufA.alloc(ctx, final_cap(cap)) != MF_OK) return MF_SKM_FALLBACK;   // (the k-mer path will report the shortage if it cannot run either)
+        if (bufA.alloc(ctx, final_cap(cap)) != MF_OK) return MF_SKM_NOMEM;
         {
             const size_t lds = skm_stage_bytes(nd1);
             MF_TRY(skm_set_lds(k_skm_scatter<K, false>, lds));
             mf_ktimer t(ctx, "k_skm_scatter");
-            k_skm_scatter<K, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p, skm_dyn());
+            k_skm_scatter<K, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p, skm_dyn(), dlo, dhi);
         }
         MF_DBG(ctx, "k_skm_scatter");
         k_skm_dir<<<(nd1 + 255) / 256, 256, 0, st>>>(blockstart.p, blockocc.p, G, nd1, pstart.p, plen.p, pocc.p);
     }
 
-    MF_HIP(hipMemsetAsync(&scal[6], 0, 16, st));          // [6] records without padding, [7] distinct k-mers before the cut
+    MF_HIP(hipMemsetAsync(&scal[6], 0, 8, st));           // [6] records without padding ([7] distinct k-mers before the cut: whole run)
     const unsigned long long cap_l1 = cap, cap_last = final_cap(cap);
+    if (dlo != 0 || dhi != (uint32_t)nd1) {
+        // the slice's digits only: the directory of the following levels starts at digit dlo
+        np = dhi - dlo;
+        mf_buf<uint64_t> ps; MF_TRY(ps.alloc(ctx, np)); mf_buf<uint32_t> pl, po; MF_TRY(pl.alloc(ctx, np)); MF_TRY(po.alloc(ctx, np));
+        MF_HIP(hipMemcpyAsync(ps.p, pstart.p + dlo, (size_t)np * 8, hipMemcpyDeviceToDevice, st));
+        MF_HIP(hipMemcpyAsync(pl.p, plen.p + dlo, (size_t)np * 4, hipMemcpyDeviceToDevice, st));
+        MF_HIP(hipMemcpyAsync(po.p, pocc.p + dlo, (size_t)np * 4, hipMemcpyDeviceToDevice, st));
+        std::swap(pstart.p, ps.p); std::swap(pstart.n, ps.n); std::swap(plen.p, pl.p); std::swap(plen.n, pl.n); std::swap(pocc.p, po.p); std::swap(pocc.n, po.n);
+    }
     int used = 0;
     mf_buf<skm_rec> spare;                                // the buffer a level has read from: the next level writes into it
     for (size_t li = 1; li < lv.size(); li++) {
@@ -1112,7 +1143,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         if (spare.p && spare.n >= cap2) { std::swap(bufB.p, spare.p); std::swap(bufB.n, spare.n); std::swap(bufB.ctx, spare.ctx); }
         else if (bufB.alloc(ctx, std::max<unsigned long long>(cap2, cap_last)) != MF_OK) {
             if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: no room for %.1f GB of level-%zu records (arena %.1f GB): %s\n", cap2 * 16 / 1e9, li + 1, ctx->arena_bytes / 1e9, mf_last_error());
-            return MF_SKM_FALLBACK;
+            return MF_SKM_NOMEM;
         }
         mf_buf<uint64_t> ostart; MF_TRY(ostart.alloc(ctx, np2));
         mf_buf<uint32_t> olen; MF_TRY(olen.alloc(ctx, np2));
@@ -1155,28 +1186,17 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     for (uint32_t b = 0; b < nbatch; b++) tmax = std::max(tmax, tb[b + 1] - tb[b]);
     mf_buf<uint64_t> tkeys; mf_buf<uint16_t> tcnt;
     if (tkeys.alloc(ctx, tmax) != MF_OK || tcnt.alloc(ctx, tmax) != MF_OK) {
-        if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: no room for %.1f GB of temporary lists, using the k-mer path\n", tmax * 10 / 1e9);
-        return MF_SKM_FALLBACK;
+        if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: no room for %.1f GB of temporary lists\n", tmax * 10 / 1e9);
+        return MF_SKM_NOMEM;
     }
     mf_buf<uint32_t> dcount; MF_TRY(dcount.alloc(ctx, np));
-    mf_buf<uint64_t> doff; MF_TRY(doff.alloc(ctx, (size_t)np + 1));
-    mf_buf<uint64_t> dk; mf_buf<uint16_t> dc;
-    uint64_t dused = 0, dcap = 0;
-    // counts of the entries the cut drops (the .stat.txt histogram needs them): drop_hist[c], c <= thr.  The kernel tallies
-    // them in a small LDS histogram: a cut above C2_LH - 1 is made afterwards (mf_count_skm)
-    const int kthr = thr < C2_LH ? thr : -1;
-    mf_buf<unsigned long long> dhist;
-    if (kthr >= 0) { MF_TRY(dhist.alloc(ctx, (size_t)MF_MAX_COUNT + 1)); MF_HIP(hipMemsetAsync(dhist.p, 0, dhist.bytes(), st)); }
+    // this slice's partitions in the numbering of the whole run
+    const uint32_t pbase = (uint32_t)(((uint64_t)dlo * A.np_total) >> bits1);
+    uint64_t *const doffp = A.doff.p + pbase;
+    mf_buf<uint64_t> &dk = A.dk; mf_buf<uint16_t> &dc = A.dc;
+    uint64_t &dused = A.dused, &dcap = A.dcap;
+    mf_buf<unsigned long long> &dhist = A.dhist, &c2p = A.c2p;
     const bool c2prof = K == 31 && (ctx->opt_ablate & 32);
-    mf_buf<unsigned long long> c2p;                             // [0,8) phase cycles (profiling build), [8,16) overflow diagnostics
-    MF_TRY(c2p.alloc(ctx, 16)); MF_HIP(hipMemsetAsync(c2p.p, 0, 128, st));
-    MF_TRY(skm_set_lds(k_skm_count<K, false>, C2_LDS));
-    if (K == 31) MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), true>, C2_LDS));
-    if (ctx->opt_verbose) {
-        int nb = 0;
-        MF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_skm_count<K, false>, SKM_CT, C2_LDS));
-        fprintf(stderr, "[mf] k_skm_count: %zu bytes of LDS, %d workgroups per CU\n", (size_t)C2_LDS, nb);
-    }
     for (uint32_t b = 0; b < nbatch; b++) {
         const uint32_t p0 = (uint32_t)std::min<uint64_t>((uint64_t)b * PB, np), p1 = (uint32_t)std::min<uint64_t>((uint64_t)(b + 1) * PB, np);
         if (p0 == p1) continue;
@@ -1192,7 +1212,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
                                                              p0, (uint64_t)tb[b], kthr, &scal[7], (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p, (uint64_t)tmax);
         }
         MF_DBG(ctx, "k_skm_count");
-        MF_TRY(mf_scan<1>(ctx, dcount.p + p0, doff.p + p0, p1 - p0, (uint64_t *)&scal[3]));      // offsets inside the batch
+        MF_TRY(mf_scan<1>(ctx, dcount.p + p0, doffp + p0, p1 - p0, (uint64_t *)&scal[3]));      // offsets inside the batch
         unsigned long long res[2];
         MF_HIP(hipMemcpyAsync(res, &scal[2], 16, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
@@ -1219,7 +1239,8 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         const uint64_t d_b = res[1];
         if (dused + d_b > dcap) {
             // everything still to come is bounded by the slices of the remaining batches; expect the ratio seen so far
-            const uint64_t done_cap = tb[b + 1], rest_cap = tcap - tb[b + 1];
+            // (+ the slices still to come, taken to be like this one)
+            const uint64_t done_cap = tb[b + 1], rest_cap = tcap - tb[b + 1] + (uint64_t)(n_slices - 1 - slice) * tcap;
             const double ratio = done_cap ? (double)(dused + d_b) / (double)done_cap : 1.0;
             uint64_t want = dused + d_b + (uint64_t)std::min<double>((double)rest_cap, (double)rest_cap * ratio * 1.12 + 4096.0);
             if (want < dused + d_b) want = dused + d_b;
@@ -1237,51 +1258,111 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         {
             const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 32);
             mf_ktimer t(ctx, "k_gather");
-            k_gather<<<grid, 256, 0, st>>>(tkeys.p, tcnt.p, toff.p, dcount.p, doff.p, p1, dk.p + dused, dc.p + dused, p0, (uint64_t)tb[b]);
-            k_skm_add_base<<<(p1 - p0 + 1 + 255) / 256, 256, 0, st>>>(doff.p + p0, (uint64_t)(p1 - p0) + 1, dused);
+            k_gather<<<grid, 256, 0, st>>>(tkeys.p, tcnt.p, toff.p, dcount.p, doffp, p1, dk.p + dused, dc.p + dused, p0, (uint64_t)tb[b]);
+            k_skm_add_base<<<(p1 - p0 + 1 + 255) / 256, 256, 0, st>>>(doffp + p0, (uint64_t)(p1 - p0) + 1, dused);
         }
         MF_DBG(ctx, "k_gather");
         dused += d_b;
     }
     MF_HIP(hipGetLastError());
-    if (c2prof) {
-        unsigned long long h[8];
-        MF_HIP(hipMemcpyAsync(h, c2p.p, 64, hipMemcpyDeviceToHost, st));
-        MF_HIP(hipStreamSynchronize(st));
-        unsigned long long tot = 0; for (int i = 0; i < 7; i++) tot += h[i];
-        static const char *nm[7] = {"partition top", "round set-up", "steps", "last drains", "barrier 1", "compaction", "barrier 2"};
-        for (int i = 0; i < 7; i++) fprintf(stderr, "[mf] k_skm_count wave cycles: %-14s %5.1f %%\n", nm[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
-    }
     bufA.reset();
-    const uint64_t n_dist = dused;
-    if (ctx->opt_verbose)
-        fprintf(stderr, "[mf] count(skm): n_occ=%llu records=%llu levels=%zu bits=%d np=%u distinct=%llu\n", (unsigned long long)n_occ,
-                (unsigned long long)cap, lv.size(), total_bits, np, (unsigned long long)n_dist);
-    MF_HIP(hipGetLastError());
-    const size_t kb = dk.bytes(), cb = dc.bytes();       // (capacity: may be a little larger than n_dist)
-    MF_TRY(mf_table_adopt(ctx, K, n_dist, n_occ, dk.take(), kb, dc.take(), cb, out));
     {
-        unsigned long long nv2[2] = {0, 0};
-        MF_HIP(hipMemcpyAsync(nv2, &scal[6], 16, hipMemcpyDeviceToHost, st));
+        unsigned long long nv = 0;
+        MF_HIP(hipMemcpyAsync(&nv, &scal[6], 8, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
-        const unsigned long long nv = nv2[0];
-        if (n_all) *n_all = nv2[1];
-        (*out)->n_records = nv ? nv : cap_l1;             // (plans without a split level: the padded level-1 count)
-        (*out)->cut_thr = kthr;
-        if (kthr >= 0) {
-            (*out)->dropped_hist.assign((size_t)kthr + 1, 0);
-            MF_HIP(hipMemcpyAsync((*out)->dropped_hist.data(), dhist.p, ((size_t)kthr + 1) * 8, hipMemcpyDeviceToHost, st));
-            MF_HIP(hipStreamSynchronize(st));
-        }
-        (*out)->record_bytes = 16;
+        A.n_records += nv ? nv : cap_l1;                  // (plans without a split level: the padded level-1 count)
     }
-    if (total_bits > 0 && total_bits <= 30) {
-        (*out)->part_bits = total_bits;
-        (*out)->part_skm = 1;
-        (*out)->part_off_bytes = doff.bytes();
-        (*out)->d_part_off = doff.take();
-    }
+    if (ctx->opt_verbose)
+        fprintf(stderr, "[mf] count(skm): slice %u/%u digits [%u,%u): records=%llu levels=%zu bits=%d np=%u distinct so far=%llu\n", slice + 1, n_slices, dlo, dhi,
+                (unsigned long long)cap, lv.size(), total_bits, np, (unsigned long long)dused);
     return MF_OK;
+}
+
+// lv: digit bits per level (lv[0] = level 1).  Returns MF_OK and *out, or MF_SKM_FALLBACK (nothing allocated) when the
+// input does not suit this path (a partition too rich for the LDS table, too many levels, not enough memory).
+template <int K>
+static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words,
+                   uint64_t n_occ, const std::vector<int> &lv, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
+    hipStream_t st = ctx->stream;
+    const int bits1 = lv[0], nd1 = 1 << bits1;
+    int total_bits = 0; for (int b : lv) total_bits += b;
+    if (total_bits > 32 || total_bits - bits1 > SKM_DIGIT_BITS) return MF_SKM_FALLBACK;
+    // counts of the entries the cut drops (the .stat.txt histogram needs them): drop_hist[c], c <= thr.  The kernel tallies
+    // them in a small LDS histogram: a cut above C2_LH - 1 is made afterwards (mf_count_skm)
+    const int kthr = thr < C2_LH ? thr : -1;
+    MF_TRY(skm_set_lds(k_skm_count<K, false>, C2_LDS));
+    if (K == 31) MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), true>, C2_LDS));
+    // Slices (HBM budget): the records of a run are about a third of the reads' bytes per radix level, two levels ping-pong.
+    // Reads, table and index have to fit beside them.  Option skm_slices forces a number (tests); arena_cap_gb stands in for
+    // a smaller device.
+    uint32_t S = 1;
+    if (lv.size() >= 2) {
+        if (ctx->opt_skm_slices > 0) S = (uint32_t)ctx->opt_skm_slices;
+        else {
+            size_t fr = 0, tot = 0;
+            MF_HIP(hipMemGetInfo(&fr, &tot));
+            double budget = (ctx->opt_arena_cap_gb > 0 ? (double)ctx->opt_arena_cap_gb * 1e9 : (double)tot * 0.92) - (double)n_bases * 1.15 - 8e9;
+            const double table = (double)n_occ * 0.14 * 26.0;       // (distinct k-mers that survive ~ a seventh of the occurrences) x (entry + index)
+            budget -= std::min(table, budget * 0.5);
+            const double recs = (double)n_occ / 5.5 * 16.0 * 2.3;    // two buffers + slices' padding
+            while (S < 64 && recs / S > budget) S *= 2;
+        }
+        while (S > 1 && (uint32_t)nd1 / S < 4) S /= 2;
+    }
+    for (;; S *= 2) {
+        skm_acc A;
+        A.np_total = (uint32_t)(1ull << total_bits);
+        MF_TRY(A.doff.alloc(ctx, (size_t)A.np_total + 1));
+        if (kthr >= 0) { MF_TRY(A.dhist.alloc(ctx, (size_t)MF_MAX_COUNT + 1)); MF_HIP(hipMemsetAsync(A.dhist.p, 0, A.dhist.bytes(), st)); }
+        MF_TRY(A.c2p.alloc(ctx, 16)); MF_HIP(hipMemsetAsync(A.c2p.p, 0, 128, st));     // [0,8) phase cycles (profiling build), [8,16) overflow diagnostics
+        MF_HIP(hipMemsetAsync(&scal[7], 0, 8, st));
+        int rc = MF_OK;
+        for (uint32_t sl = 0; sl < S && rc == MF_OK; sl++)
+            rc = skm_slice<K>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, kthr, (uint32_t)((uint64_t)nd1 * sl / S), (uint32_t)((uint64_t)nd1 * (sl + 1) / S), sl, S, A);
+        if (rc == MF_SKM_NOMEM) {
+            if (lv.size() >= 2 && S < 64 && (uint32_t)nd1 / (2 * S) >= 4) {
+                if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: %u slice(s) do not fit, trying %u\n", S, 2 * S);
+                continue;
+            }
+            return MF_SKM_FALLBACK;
+        }
+        if (rc != MF_OK) return rc;
+        if (K == 31 && (ctx->opt_ablate & 32)) {
+            unsigned long long h[8];
+            MF_HIP(hipMemcpyAsync(h, A.c2p.p, 64, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            unsigned long long tot = 0; for (int i = 0; i < 7; i++) tot += h[i];
+            static const char *nm[7] = {"partition top", "round set-up", "steps", "last drains", "barrier 1", "compaction", "barrier 2"};
+            for (int i = 0; i < 7; i++) fprintf(stderr, "[mf] k_skm_count wave cycles: %-14s %5.1f %%\n", nm[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+        }
+        const uint64_t n_dist = A.dused;
+        if (ctx->opt_verbose)
+            fprintf(stderr, "[mf] count(skm): n_occ=%llu records=%llu slices=%u levels=%zu bits=%d distinct=%llu\n", (unsigned long long)n_occ,
+                    A.n_records, S, lv.size(), total_bits, (unsigned long long)n_dist);
+        const size_t kb = A.dk.bytes(), cb = A.dc.bytes();       // (capacity: may be a little larger than n_dist)
+        MF_TRY(mf_table_adopt(ctx, K, n_dist, n_occ, A.dk.take(), kb, A.dc.take(), cb, out));
+        {
+            unsigned long long na = 0;
+            MF_HIP(hipMemcpyAsync(&na, &scal[7], 8, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            if (n_all) *n_all = na;
+            (*out)->n_records = A.n_records;
+            (*out)->cut_thr = kthr;
+            if (kthr >= 0) {
+                (*out)->dropped_hist.assign((size_t)kthr + 1, 0);
+                MF_HIP(hipMemcpyAsync((*out)->dropped_hist.data(), A.dhist.p, ((size_t)kthr + 1) * 8, hipMemcpyDeviceToHost, st));
+                MF_HIP(hipStreamSynchronize(st));
+            }
+            (*out)->record_bytes = 16;
+        }
+        if (total_bits > 0 && total_bits <= 30) {
+            (*out)->part_bits = total_bits;
+            (*out)->part_skm = 1;
+            (*out)->part_off_bytes = A.doff.bytes();
+            (*out)->d_part_off = A.doff.take();
+        }
+        return MF_OK;
+    }
 }
 
 int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,

@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from util import gpu_count, genome_reads, pack_reads, random_reads
+from util import gpu_count, genome_reads, pack_reads, random_reads, to_device
 
 pytestmark = pytest.mark.gpu
 
@@ -23,7 +23,7 @@ def _check(ctx, oracle, bases, off, k, min_len=0, thr=-1):
 
 
 def _reset(ctx):
-    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0), ("skm_dyn", 1)):
+    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0), ("skm_dyn", 1), ("skm_slices", 0), ("arena_cap_gb", 0)):
         ctx.set_option(name, v)
 
 
@@ -216,6 +216,32 @@ def test_skm_lookup_filter_two_levels(gpu_ctx, oracle):
         assert np.array_equal(fk, keys[m]) and np.array_equal(fc, cnts[m])
         want_f = np.where(want > 1, want, -1)
         assert np.array_equal(f.lookup(probe), want_f)
+    finally:
+        _reset(gpu_ctx)
+
+
+@pytest.mark.parametrize("slices,dyn", [(2, 1), (4, 2), (8, 0)])
+def test_skm_digit_range_slices(gpu_ctx, oracle, slices, dyn):
+    """a run cut into digit-range slices (what a sample with more records than HBM takes: BASELINE config 5): the reads are
+    scanned once per slice, every slice counts its share of the level-1 digits; same table, same order, same tallies"""
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(79)
+    b, o = genome_reads(rng, 300_000, 60_000, 150, err=0.004)
+    try:
+        gpu_ctx.set_option("part_target", 256)
+        gpu_ctx.set_option("skm_dyn", dyn)
+        ref = gpu_count(gpu_ctx, b, o, 31)
+        rk, rc, rn = ref.device_view()
+        gpu_ctx.set_option("skm_slices", slices)
+        t = _check(gpu_ctx, oracle, b, o, 31)
+        db, do = to_device(b, o)
+        cut, n_all = gpu_ctx.count_device_above(db.data_ptr(), do.data_ptr(), len(o) - 1, len(b), 31, 1)
+        keys, cnts = t.export()
+        ck, cc = cut.export()
+        assert n_all == len(keys) and np.array_equal(ck, keys[cnts > 1]) and np.array_equal(cc, cnts[cnts > 1])
+        h = cut.hist()
+        assert np.array_equal(h[:64], np.bincount(cnts, minlength=64)[:64])
+        assert t.records()[0] == ref.records()[0]
     finally:
         _reset(gpu_ctx)
 

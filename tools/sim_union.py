@@ -11,6 +11,7 @@ rl, k = 150, 31
 ctx = L.Context(0, stream=torch.cuda.current_stream())
 ctx.set_option("profile", 1)
 if os.environ.get("MF_VERBOSE"): ctx.set_option("verbose", int(os.environ["MF_VERBOSE"]))
+if os.environ.get("MF_PTL"): ctx.set_option("part_target_long", int(os.environ["MF_PTL"]))
 bases = torch.zeros(n_reads * rl + 64, dtype=torch.uint8, device="cuda")
 offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device="cuda")
 parts_b, parts_o = [], []
