@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--reads", type=int, default=0, help="reads per GPU (default: BASELINE.json config 2 at one GPU = 100 M, "
                                                          "config 3 = 50 M per GPU at more than one)")
+    ap.add_argument("--samples-per-gpu", type=int, default=1, help="samples a rank processes one after the other (BASELINE config 5: 4)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("-k", type=int, default=31)
     ap.add_argument("--genome-scale", type=int, default=1_000_000, help="pool genome length scale in bp")
@@ -183,8 +184,22 @@ def main():
     bases = torch.zeros(n_bases + 64, dtype=torch.uint8, device=device)
     offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
     torch.cuda.synchronize()
-    ctx.synth_reads_device(SEED, rank, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr())
+    spg = max(1, args.samples_per_gpu)
+    gen_s = [0.0]
+    ctx.synth_reads_device(SEED, rank * spg, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr())
     torch.cuda.synchronize()
+
+    def samples():
+        """this rank's samples, the reads of ONE sample in HBM at a time (the generator refills the buffer; with one
+        sample per GPU nothing is generated inside the timed region)"""
+        for j in range(spg):
+            if spg > 1:
+                torch.cuda.synchronize()
+                g0 = time.perf_counter()
+                ctx.synth_reads_device(SEED, rank * spg + j, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr())
+                torch.cuda.synchronize()
+                gen_s[0] += time.perf_counter() - g0        # (taken out of the timed region again: data generation is not the path)
+            yield bases, offsets, n_reads, n_bases
 
     def barrier():
         torch.cuda.synchronize()
@@ -193,14 +208,13 @@ def main():
         torch.cuda.synchronize()
 
     def step(timings=None):
-        r = P.run_sample(ctx, bases, offsets, n_reads, n_bases, k=k, b=1, l=100, b1=args.b1, b2=args.b2, device=device,
-                         timings=timings)
-        nrec, rbytes = r["good"].records()
-        stats = dict(n_occ=r["n_occ"], n_distinct=r["n_distinct"], n_good=len(r["good"]), n_unitigs=len(r["seqs"]),
-                     n_cutter=len(r["cutter"]), n_components=len(r["comps"]), n_reads=n_reads, n_bases=n_bases,
-                     n_records=nrec, record_bytes=rbytes)
-        for key in ("good", "seqs", "cutter", "comps"):
-            r[key].close()
+        r = P.run_samples(ctx, samples(), k=k, b=1, l=100, b1=args.b1, b2=args.b2, device=device, timings=timings)
+        nrec, rbytes = r["goods"][0].records()
+        stats = dict(n_occ=r["n_occ"], n_distinct=r["n_distinct"], n_good=sum(len(g) for g in r["goods"]), n_unitigs=sum(len(q) for q in r["seqss"]),
+                     n_cutter=len(r["cutter"]), n_components=len(r["comps"]), n_reads=n_reads * spg, n_bases=n_bases * spg,
+                     n_records=nrec * spg, record_bytes=rbytes, n_singletons=int(sum(int(h[1]) for h in r["hists"])))
+        for x in r["goods"] + r["seqss"] + [r["cutter"], r["comps"]]:
+            x.close()
         return stats, r["matrix"]
 
     for _ in range(args.warmup):
@@ -208,11 +222,12 @@ def main():
     ctx.reset_timers()
     stage_t = {}
     barrier()
+    gen_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats, matrix = step(stage_t)
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0 - gen_s[0]
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     occ = torch.tensor([float(stats["n_occ"])], dtype=torch.float64, device=device)
     if use_dist:
@@ -287,7 +302,7 @@ def main():
             "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"{world} sample(s) x {n_reads} synthetic {rl} bp reads, k={k}, one sample per GPU, "
+            "config": {"workload": f"{world * spg} sample(s) x {n_reads} synthetic {rl} bp reads, k={k}, {spg} sample(s) per GPU, "
                                    f"count+unitigs+components+features (b=1 l=100 b1={args.b1} b2={args.b2})",
                        "reads_per_gpu": n_reads, "read_len": rl, "k": k, "genome_scale_bp": args.genome_scale},
             "roofline": roof(dom),

@@ -30,6 +30,10 @@ def _worker(rank, world, port, out_dir):
     vec = torch.tensor([10 * rank + 1, 7, 100 * (rank + 1)], dtype=torch.int64)
     vecs = P.gather_vectors(vec)
     rag = P.all_gather_ragged(torch.arange(rank * 3, dtype=torch.int64))     # rank 0 contributes an EMPTY tensor
+    rows = P.gather_vector_rows(torch.full((rank + 1, 3), rank + 1, dtype=torch.int64))       # rank r holds r + 1 samples
+    np.save(os.path.join(out_dir, f"w{rank}.npy"), rows.numpy())
+    same = P.all_gather_ragged(torch.arange(4, dtype=torch.int64) + 10 * rank)                # equal sizes: one collective
+    np.save(os.path.join(out_dir, f"s{rank}.npy"), torch.cat(same).numpy())
     np.save(os.path.join(out_dir, f"b{rank}.npy"), allb.numpy())
     np.save(os.path.join(out_dir, f"o{rank}.npy"), allo.numpy())
     np.save(os.path.join(out_dir, f"v{rank}.npy"), vecs.numpy())
@@ -54,6 +58,8 @@ def test_exchanges_world2(tmp_path):
         assert o.tolist() == exp_o.tolist()                                      # every rank sees the same, rebased offsets
         assert v.tolist() == [[1, 7, 100], [11, 7, 200]]
         assert r.tolist() == [0, 3]
+        assert np.load(tmp_path / f"w{rank}.npy").tolist() == [[1, 1, 1], [2, 2, 2], [2, 2, 2]]
+        assert np.load(tmp_path / f"s{rank}.npy").tolist() == [0, 1, 2, 3, 10, 11, 12, 13]
 
 
 def test_single_process_paths():
