@@ -42,6 +42,7 @@ typedef struct mf_ctx   mf_ctx;    /* device + stream + workspace               
 typedef struct mf_table mf_table;  /* canonical k-mer -> saturating count (BigLong2ShortHashMap) */
 typedef struct mf_seqs  mf_seqs;   /* unitigs with weights (Deque<Sequence>)                */
 typedef struct mf_comps mf_comps;  /* connected components (List<ConnectedComponent>)       */
+typedef struct mf_dcc   mf_dcc;    /* one rank's part of the distributed component cutter   */
 
 const char *mf_last_error(void);
 const char *mf_version(void);
@@ -181,6 +182,62 @@ int  mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps **out);
 /* One call = ComponentCutterMain.runImpl :92-108 */
 int  mf_cut_components(mf_ctx *ctx, mf_table *cutter, int k, int b1, int b2,
                        const char *components_bin, const char *stat_txt, uint64_t *n_comp);
+
+/* ---- A9-A11 on several GPUs: every rank owns a shard of the cutter table ---------------------
+ * The cutter table and the components step join ALL samples (ComponentCutterMain.runImpl,
+ * src/tools/ComponentCutterMain.java:78-114; ComponentsBuilder.run, src/algo/ComponentsBuilder.java:58-153).
+ * With one process per GPU, rank r owns the k-mers whose minimizer-partition hash starts with r
+ * (world = power of two <= 64).  The library does the per-rank work on device buffers; the caller moves
+ * the buffers between the ranks (torch.distributed over RCCL in metafast_amd/pipeline.py; any
+ * all-to-all / all-gather will do).  All d_* pointers are device memory of the ctx's GPU.
+ *
+ *   tables:   mf_table_split_by_owner -> all-to-all -> mf_table_from_pairs_device  (the shard)
+ *   once:     mf_dcc_create; mf_dcc_queries + _fill -> all-to-all -> mf_dcc_answer -> all-to-all back
+ *             -> mf_dcc_set_answers
+ *   level t:  mf_dcc_level_local + mf_dcc_pairs_fill -> all-to-all -> mf_dcc_pairs_complete
+ *             -> all-gather -> mf_dcc_merge + mf_dcc_stats_fill -> all-gather -> mf_dcc_classify
+ *             + mf_dcc_kept_fill -> all-gather (kept components; stop when no rank has an oversize one)
+ *   end:      mf_dcc_members + _fill -> all-gather -> mf_dcc_finish: the same mf_comps on every rank,
+ *             identical to mf_cut_components_device on the merged table.                              */
+/* keys u64[n] / counts u16[n] of `t` regrouped by owner; off[world + 1] (host) */
+int  mf_table_split_by_owner(const mf_table *t, int world, void *d_keys, void *d_counts, uint64_t *off);
+/* (k-mer, count) pairs -> table; repeated k-mers: saturating sum (NumUtils.addAndBound, src/utils/NumUtils.java) */
+int  mf_table_from_pairs_device(mf_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, int k,
+                                mf_table **out);
+/* base[world + 1]: global id of each rank's first vertex (prefix sums of the shard sizes; total < 2^32).
+ * The shard must outlive the handle. */
+int  mf_dcc_create(mf_ctx *ctx, mf_table *shard, int rank, int world, const uint32_t *base, mf_dcc **out);
+void mf_dcc_destroy(mf_dcc *d);
+/* neighbours in other shards: counts[world] (host), then the 16-byte queries grouped by owner */
+int  mf_dcc_queries(mf_dcc *d, uint64_t *counts);
+int  mf_dcc_queries_fill(mf_dcc *d, void *d_queries);
+/* owner side: n queries -> n 16-byte answers, same order */
+int  mf_dcc_answer(mf_dcc *d, const void *d_queries, uint64_t n, void *d_answers);
+/* the answers to this rank's queries, in the order the queries were written */
+int  mf_dcc_set_answers(mf_dcc *d, const void *d_answers, uint64_t n);
+/* one threshold level (ComponentsBuilder.java:86-150): union-find inside the shard; counts[world] = 8-byte half
+ * pairs (edges to fragments of HIGHER ranks) for each owner, then the half pairs themselves */
+int  mf_dcc_level_local(mf_dcc *d, uint64_t *counts);
+int  mf_dcc_pairs_fill(mf_dcc *d, void *d_pairs);
+/* owner side, in place: half pairs -> (own fragment root, other fragment root), global ids */
+int  mf_dcc_pairs_complete(mf_dcc *d, void *d_pairs, uint64_t n);
+/* ALL ranks' completed pairs -> global root of each own fragment; *n_stats own fragments, then their 16-byte
+ * records (global root u32, size u32, weight u64) */
+int  mf_dcc_merge(mf_dcc *d, const void *d_pairs, uint64_t n, uint64_t *n_stats);
+int  mf_dcc_stats_fill(mf_dcc *d, void *d_stats);
+/* ALL ranks' fragment records -> classification of every own vertex at threshold thr (size window [b1, b2]);
+ * n_kept / n_big: kept / oversize components whose global root is in this rank's id range; then the kept ones'
+ * 16-byte records (root u32, size u32, weight u64) */
+int  mf_dcc_classify(mf_dcc *d, const void *d_stats, uint64_t n, int b1, int b2, int thr, uint64_t *n_kept,
+                     uint64_t *n_big);
+int  mf_dcc_kept_fill(mf_dcc *d, void *d_kept);
+/* members of kept components among this rank's k-mers, all levels: k-mers u64[n], global roots u32[n] */
+int  mf_dcc_members(mf_dcc *d, uint64_t *n);
+int  mf_dcc_members_fill(mf_dcc *d, void *d_kmers, void *d_roots);
+/* ALL ranks' members + all levels' kept components (host arrays) -> components, ordered as above */
+int  mf_dcc_finish(mf_dcc *d, const void *d_kmers, const void *d_roots, uint64_t n_members, const uint32_t *kept_root,
+                   const uint32_t *kept_size, const int64_t *kept_weight, const int32_t *kept_thr, uint64_t n_kept,
+                   mf_comps **out);
 
 /* ---- A12  features ------------------------------------------------------------------ */
 /* replaces FeaturesCalculatorMain: hm.put(kmer,0) for component k-mers (:97-103), presence pass

@@ -611,3 +611,527 @@ extern "C" int mf_bray_curtis(const int64_t *vecs, int n_samples, int n_comp, do
     }
     return MF_OK;
 }
+
+// =============================================================================================
+// Distributed component cutter: the cutter table and the components step over ALL samples' unitigs are
+// the one global join of the pipeline (ComponentCutterMain.runImpl, src/tools/ComponentCutterMain.java:78-114;
+// ComponentsBuilder.run, src/algo/ComponentsBuilder.java:58-153).  Repeating them on every rank costs each rank the work of
+// the whole node.  Here every rank OWNS the k-mers whose minimizer-partition hash starts with its rank (top log2(world)
+// bits of mf_skm_ph): it holds that shard of the cutter table, finds its vertices' neighbours (its own ones in its index,
+// the others' by asking their owners), and solves its part of every threshold level; the ranks exchange
+//   * the shard entries of the per-sample cutter tables                               (once, all-to-all)
+//   * neighbour queries and answers                                                   (once, all-to-all both ways)
+//   * per level: the edges between fragments of different ranks (all-to-all + all-gather of root pairs), the fragments'
+//     sizes / weights (all-gather), the kept components of each owner (all-gather)
+//   * the members of the kept components                                              (once, all-gather)
+// The collectives themselves are torch.distributed's (metafast_amd/pipeline.py); the entry points below take and fill
+// device buffers.  Global vertex id = base[rank] + position in the rank's shard table (< 2^32 over all ranks).
+//
+// Per level, on every rank: union-find over its own vertices and the edges inside its shard (the kernels above) -> local
+// roots ("fragments"); an edge to another rank's vertex becomes a pair (root of this end, root of that end) -- the lower
+// rank sends (remote vertex, global id of its own root) to the owner, who answers with the pair; all pairs are gathered on
+// every rank, which runs the same union-find over fragment roots (an array over all global ids) and so knows the global root
+// of each of its fragments; sizes and weights of the fragments are gathered and summed per global root everywhere, so every
+// rank classifies alike.  Whether a remote neighbour is still alive at level t needs no message: the edge was active at level
+// t-1, so both ends were in the same component and share its fate; what remains is the neighbour's own value, which the
+// answer to the query brought along.
+// =============================================================================================
+struct mf_dcc {
+    mf_ctx *ctx = nullptr; mf_table *t = nullptr; int k = 0, rank = 0, world = 1, lw = 0;
+    uint32_t n = 0, n_total = 0; std::vector<uint32_t> base;
+    mf_buf<uint32_t> nbr, parent, root, csize, groot;        // [8n] local neighbour ids; [n]; [n]; [n]; [n] global root of a LOCAL ROOT
+    mf_buf<unsigned long long> cweight; mf_buf<uint8_t> alive;
+    mf_buf<unsigned int> ctr;                                // [64] counters
+    // queries (16 bytes: key, source = vertex*8 + neighbour number) grouped by owner
+    std::vector<uint64_t> qoff;                              // [world + 1]
+    mf_buf<unsigned long long> qcur;                         // [world] cursors
+    // cross edges
+    mf_buf<uint32_t> xv, xu; mf_buf<uint8_t> xr, xalive; mf_buf<uint16_t> xval; uint64_t nx = 0;
+    std::vector<uint64_t> xoff;                              // [world + 1] (pairs this rank sends per level)
+    // contracted graph, replicated
+    mf_buf<uint32_t> pg, gsize; mf_buf<unsigned long long> gweight;     // [n_total]
+    // results
+    struct level_buf { mf_buf<uint64_t> mk; mf_buf<uint32_t> mg; uint64_t n = 0; };     // members of kept components: k-mer, global root
+    std::vector<std::unique_ptr<level_buf>> levels; uint64_t nm = 0;
+    uint64_t nstat = 0, nkept_owned = 0; int b1 = 0, b2 = 0;
+};
+
+__device__ __forceinline__ uint32_t dcc_owner(uint32_t ph, int lw) { return lw ? ph >> (32 - lw) : 0u; }
+
+// ---- shard entries of a table, grouped by owner
+__global__ void k_dcc_owner_hist(const uint64_t *__restrict__ keys, uint64_t n, int k, int lw, unsigned long long *__restrict__ cnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[dcc_owner(mf_skm_ph(keys[i], k), lw)], 1ull);
+}
+__global__ void k_dcc_owner_scatter(const uint64_t *__restrict__ keys, const uint16_t *__restrict__ vals, uint64_t n, int k, int lw,
+                                    unsigned long long *__restrict__ cur, uint64_t *__restrict__ ok, uint16_t *__restrict__ ov) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t key = keys[i];
+    const unsigned long long at = atomicAdd(&cur[dcc_owner(mf_skm_ph(key, k), lw)], 1ull);
+    ok[at] = key; ov[at] = vals[i];
+}
+static int dcc_log2(int w) { int l = 0; while ((1 << l) < w) l++; return l; }
+// keys / counts of `t` regrouped by owner rank into d_keys / d_counts (room for t->n entries each); off[0..world]
+extern "C" int mf_table_split_by_owner(const mf_table *t, int world, void *d_keys, void *d_counts, uint64_t *off) {
+    if (!t || !off || (t->n && (!d_keys || !d_counts))) return mf_set_error("mf_table_split_by_owner: NULL argument");
+    if (world < 1 || world > 64 || (world & (world - 1))) return mf_set_error("mf_table_split_by_owner: the world size must be a power of two <= 64");
+    if (t->k < MF_SKM_M) return mf_set_error("mf_table_split_by_owner: k >= %d needed (minimizer ownership)", MF_SKM_M);
+    mf_ctx *ctx = t->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    const int lw = dcc_log2(world);
+    mf_buf<unsigned long long> cnt; MF_TRY(cnt.alloc(ctx, 2 * (size_t)world));
+    MF_HIP(hipMemsetAsync(cnt.p, 0, cnt.bytes(), st));
+    std::vector<unsigned long long> h(world, 0);
+    if (t->n) {
+        k_dcc_owner_hist<<<cgrid(t->n), 256, 0, st>>>(t->d_keys, t->n, t->k, lw, cnt.p);
+        MF_HIP(hipMemcpyAsync(h.data(), cnt.p, (size_t)world * 8, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+    }
+    off[0] = 0;
+    for (int o = 0; o < world; o++) off[o + 1] = off[o] + h[o];
+    if (t->n) {
+        std::vector<unsigned long long> c0(off, off + world);
+        MF_HIP(hipMemcpyAsync(cnt.p + world, c0.data(), (size_t)world * 8, hipMemcpyHostToDevice, st));
+        k_dcc_owner_scatter<<<cgrid(t->n), 256, 0, st>>>(t->d_keys, t->d_counts, t->n, t->k, lw, cnt.p + world, (uint64_t *)d_keys, (uint16_t *)d_counts);
+        MF_HIP(hipStreamSynchronize(st));
+    }
+    return MF_OK;
+}
+int mf_table_from_device_pairs(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, int k, mf_table **out);
+// (k-mer, count) pairs in HBM -> table; a k-mer that occurs several times gets the saturating sum (NumUtils.addAndBound)
+extern "C" int mf_table_from_pairs_device(mf_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, int k, mf_table **out) {
+    if (!ctx || !out || (n && (!d_keys || !d_counts))) return mf_set_error("mf_table_from_pairs_device: NULL argument");
+    *out = nullptr;
+    if (k < 1 || k > 31) return mf_set_error("k must be in [1,31]");
+    MF_HIP(hipSetDevice(ctx->device));
+    int r = mf_table_from_device_pairs(ctx, (const uint64_t *)d_keys, (const uint16_t *)d_counts, n, k, out);
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    return r;
+}
+
+// ---- neighbours: own ones looked up, the others' counted / written as queries
+struct dcc_query { uint64_t key; uint64_t src; };
+template <bool FILL>
+__global__ void k_dcc_adjacency(mf_index_view ix, const uint64_t *__restrict__ keys, uint32_t n, int k, int lw, uint32_t me,
+                                uint32_t *__restrict__ nbr, unsigned long long *__restrict__ qcur, dcc_query *__restrict__ q) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n) return;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    const uint64_t x = keys[v];
+    uint32_t m_nf = 0, m_nl = 0;
+    mf_skm_nbr_mins(x, k, &m_nf, &m_nl);
+    uint32_t out[8];
+#pragma unroll
+    for (uint32_t i = 0; i < 8; i++) {
+        uint64_t y; uint32_t ph;
+        const uint64_t c = nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &ph);
+        const uint32_t o = dcc_owner(ph, lw);
+        out[i] = CC_NONE;
+        if (o == me) {
+            if (!FILL) { uint32_t idx, val; if (mf_index_find(ix, c, &idx, &val)) out[i] = idx; }
+        } else {
+            const unsigned long long at = atomicAdd(&qcur[o], 1ull);
+            if (FILL) { q[at].key = c; q[at].src = (uint64_t)v * 8 + i; }
+        }
+    }
+    if (!FILL) {
+        uint4 *op = reinterpret_cast<uint4 *>(nbr + (size_t)v * 8);
+        op[0] = make_uint4(out[0], out[1], out[2], out[3]);
+        op[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    }
+}
+struct dcc_answer { uint64_t src; uint32_t lid; uint32_t val; };
+__global__ void k_dcc_answer(mf_index_view ix, const dcc_query *__restrict__ q, uint64_t n, dcc_answer *__restrict__ a) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t idx, val;
+    const bool f = ix.slots && mf_index_find(ix, q[i].key, &idx, &val);
+    a[i].src = q[i].src; a[i].lid = f ? idx : CC_NONE; a[i].val = f ? val : 0u;
+}
+// answers -> cross edges (appended; *nx counts them).  owner_of_answer: answers arrive grouped by answering rank
+__global__ void k_dcc_cross(const dcc_answer *__restrict__ a, uint64_t n, const uint64_t *__restrict__ aoff, int world, uint32_t *__restrict__ xv,
+                            uint32_t *__restrict__ xu, uint8_t *__restrict__ xr, uint16_t *__restrict__ xval, unsigned int *__restrict__ nx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || a[i].lid == CC_NONE) return;
+    int r = 0;
+    while (r + 1 < world && i >= aoff[r + 1]) r++;
+    const uint32_t at = atomicAdd(nx, 1u);
+    if (xv) { xv[at] = (uint32_t)(a[i].src >> 3); xu[at] = a[i].lid; xr[at] = (uint8_t)r; xval[at] = (uint16_t)a[i].val; }
+}
+
+extern "C" void mf_dcc_destroy(mf_dcc *d) { delete d; }
+// shard: this rank's part of the cutter table; base[0..world]: global id of every rank's first vertex
+extern "C" int mf_dcc_create(mf_ctx *ctx, mf_table *shard, int rank, int world, const uint32_t *base, mf_dcc **out) {
+    if (!ctx || !shard || !base || !out) return mf_set_error("mf_dcc_create: NULL argument");
+    *out = nullptr;
+    if (world < 1 || world > 64 || (world & (world - 1))) return mf_set_error("mf_dcc_create: the world size must be a power of two <= 64");
+    if (base[world] != 0 && (uint64_t)base[rank] + shard->n != base[rank + 1]) return mf_set_error("mf_dcc_create: base[] does not match the shard");
+    MF_HIP(hipSetDevice(ctx->device));
+    std::unique_ptr<mf_dcc> D(new mf_dcc());
+    D->ctx = ctx; D->t = shard; D->k = shard->k; D->rank = rank; D->world = world; D->lw = dcc_log2(world);
+    D->n = (uint32_t)shard->n; D->n_total = base[world]; D->base.assign(base, base + world + 1);
+    const size_t n1 = D->n ? D->n : 1;
+    MF_TRY(D->nbr.alloc(ctx, n1 * 8)); MF_TRY(D->parent.alloc(ctx, n1)); MF_TRY(D->root.alloc(ctx, n1)); MF_TRY(D->csize.alloc(ctx, n1));
+    MF_TRY(D->groot.alloc(ctx, n1)); MF_TRY(D->cweight.alloc(ctx, n1)); MF_TRY(D->alive.alloc(ctx, n1)); MF_TRY(D->ctr.alloc(ctx, 64));
+    MF_TRY(D->qcur.alloc(ctx, (size_t)world));
+    const size_t nt = D->n_total ? D->n_total : 1;
+    MF_TRY(D->pg.alloc(ctx, nt)); MF_TRY(D->gsize.alloc(ctx, nt)); MF_TRY(D->gweight.alloc(ctx, nt));
+    if (D->n) MF_TRY(mf_table_ensure_index(shard));
+    MF_HIP(hipMemsetAsync(D->alive.p, 1, n1, ctx->stream));
+    *out = D.release();
+    return MF_OK;
+}
+// step 1: own neighbours looked up; counts[o] = queries for rank o
+extern "C" int mf_dcc_queries(mf_dcc *D, uint64_t *counts) {
+    if (!D || !counts) return mf_set_error("mf_dcc_queries: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    MF_HIP(hipMemsetAsync(D->qcur.p, 0, D->qcur.bytes(), st));
+    if (D->n) {
+        mf_ktimer tm(ctx, "k_dcc_adjacency");
+        k_dcc_adjacency<false><<<cgrid(D->n), 256, 0, st>>>(mf_view(D->t->index), D->t->d_keys, D->n, D->k, D->lw, (uint32_t)D->rank, D->nbr.p, D->qcur.p, nullptr);
+    }
+    std::vector<unsigned long long> h(D->world);
+    MF_HIP(hipMemcpyAsync(h.data(), D->qcur.p, (size_t)D->world * 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    D->qoff.assign(D->world + 1, 0);
+    for (int o = 0; o < D->world; o++) { counts[o] = h[o]; D->qoff[o + 1] = D->qoff[o] + h[o]; }
+    return MF_OK;
+}
+// step 2: the queries themselves, grouped by owner, 16 bytes each, into d_q (room for sum(counts))
+extern "C" int mf_dcc_queries_fill(mf_dcc *D, void *d_q) {
+    if (!D || (D->qoff.back() && !d_q)) return mf_set_error("mf_dcc_queries_fill: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    std::vector<unsigned long long> c0(D->qoff.begin(), D->qoff.begin() + D->world);
+    MF_HIP(hipMemcpyAsync(D->qcur.p, c0.data(), (size_t)D->world * 8, hipMemcpyHostToDevice, st));
+    if (D->n) k_dcc_adjacency<true><<<cgrid(D->n), 256, 0, st>>>(mf_view(D->t->index), D->t->d_keys, D->n, D->k, D->lw, (uint32_t)D->rank, nullptr, D->qcur.p, (dcc_query *)d_q);
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
+// step 3 (owner side): n queries -> n answers (16 bytes each)
+extern "C" int mf_dcc_answer(mf_dcc *D, const void *d_q, uint64_t n, void *d_a) {
+    if (!D || (n && (!d_q || !d_a))) return mf_set_error("mf_dcc_answer: NULL argument");
+    mf_ctx *ctx = D->ctx;
+    MF_HIP(hipSetDevice(ctx->device));
+    mf_index_view ix = mf_view(D->t->index);
+    if (!D->n) ix.slots = nullptr;
+    if (n) k_dcc_answer<<<cgrid(n), 256, 0, ctx->stream>>>(ix, (const dcc_query *)d_q, n, (dcc_answer *)d_a);
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    return MF_OK;
+}
+// step 4: the answers to this rank's queries (grouped by answering rank like the queries were) -> cross edges
+extern "C" int mf_dcc_set_answers(mf_dcc *D, const void *d_a, uint64_t n) {
+    if (!D || (n && !d_a)) return mf_set_error("mf_dcc_set_answers: NULL argument");
+    if (n != D->qoff.back()) return mf_set_error("mf_dcc_set_answers: %llu answers for %llu queries", (unsigned long long)n, (unsigned long long)D->qoff.back());
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    mf_buf<uint64_t> aoff; MF_TRY(aoff.alloc(ctx, (size_t)D->world + 1));
+    MF_HIP(hipMemcpyAsync(aoff.p, D->qoff.data(), ((size_t)D->world + 1) * 8, hipMemcpyHostToDevice, st));
+    MF_HIP(hipMemsetAsync(D->ctr.p, 0, 256, st));
+    unsigned int nx = 0;
+    if (n) {
+        k_dcc_cross<<<cgrid(n), 256, 0, st>>>((const dcc_answer *)d_a, n, aoff.p, D->world, nullptr, nullptr, nullptr, nullptr, &D->ctr.p[0]);
+        MF_HIP(hipMemcpyAsync(&nx, &D->ctr.p[0], 4, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+    }
+    D->nx = nx;
+    const size_t n1 = nx ? nx : 1;
+    MF_TRY(D->xv.alloc(ctx, n1)); MF_TRY(D->xu.alloc(ctx, n1)); MF_TRY(D->xr.alloc(ctx, n1)); MF_TRY(D->xval.alloc(ctx, n1)); MF_TRY(D->xalive.alloc(ctx, n1));
+    if (nx) {
+        MF_HIP(hipMemsetAsync(&D->ctr.p[0], 0, 4, st));
+        k_dcc_cross<<<cgrid(n), 256, 0, st>>>((const dcc_answer *)d_a, n, aoff.p, D->world, D->xv.p, D->xu.p, D->xr.p, D->xval.p, &D->ctr.p[0]);
+        MF_HIP(hipMemsetAsync(D->xalive.p, 1, nx, st));
+    }
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
+
+// ---- one threshold level
+// (a) union-find inside the shard; counts[o] = root pairs this rank asks rank o to complete (edges to higher ranks only)
+__global__ void k_dcc_pairs_out(const uint32_t *__restrict__ xv, const uint32_t *__restrict__ xu, const uint8_t *__restrict__ xr, const uint8_t *__restrict__ xalive,
+                                uint64_t nx, const uint8_t *__restrict__ alive, const uint32_t *__restrict__ root, uint32_t me, uint32_t mybase,
+                                unsigned long long *__restrict__ cur, uint2 *__restrict__ out) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nx || !xalive[e] || xr[e] <= me || !alive[xv[e]]) return;
+    const unsigned long long at = atomicAdd(&cur[xr[e]], 1ull);
+    if (out) out[at] = make_uint2(xu[e], mybase + root[xv[e]]);
+}
+extern "C" int mf_dcc_level_local(mf_dcc *D, uint64_t *counts) {
+    if (!D || !counts) return mf_set_error("mf_dcc_level_local: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = D->n;
+    if (n) {
+        mf_ktimer tm(ctx, "k_cc_hook");
+        k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, D->csize.p, D->cweight.p, n);
+        k_cc_hook<<<cgrid(n), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, n);
+    }
+    if (n) {
+        mf_ktimer tm(ctx, "k_cc_stats");
+        k_cc_flatten_stats<<<cgrid(n, CC_TILE), 256, 0, st>>>(D->alive.p, D->parent.p, D->root.p, D->t->d_counts, D->csize.p, D->cweight.p, n);
+    }
+    MF_HIP(hipMemsetAsync(D->qcur.p, 0, D->qcur.bytes(), st));
+    if (D->nx) k_dcc_pairs_out<<<cgrid(D->nx), 256, 0, st>>>(D->xv.p, D->xu.p, D->xr.p, D->xalive.p, D->nx, D->alive.p, D->root.p, (uint32_t)D->rank, D->base[D->rank], D->qcur.p, nullptr);
+    std::vector<unsigned long long> h(D->world);
+    MF_HIP(hipMemcpyAsync(h.data(), D->qcur.p, (size_t)D->world * 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    D->xoff.assign(D->world + 1, 0);
+    for (int o = 0; o < D->world; o++) { counts[o] = h[o]; D->xoff[o + 1] = D->xoff[o] + h[o]; }
+    return MF_OK;
+}
+// (b) the half pairs (remote vertex, global id of this end's root), 8 bytes each, grouped by rank
+extern "C" int mf_dcc_pairs_fill(mf_dcc *D, void *d_out) {
+    if (!D || (D->xoff.back() && !d_out)) return mf_set_error("mf_dcc_pairs_fill: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    std::vector<unsigned long long> c0(D->xoff.begin(), D->xoff.begin() + D->world);
+    MF_HIP(hipMemcpyAsync(D->qcur.p, c0.data(), (size_t)D->world * 8, hipMemcpyHostToDevice, st));
+    if (D->nx) k_dcc_pairs_out<<<cgrid(D->nx), 256, 0, st>>>(D->xv.p, D->xu.p, D->xr.p, D->xalive.p, D->nx, D->alive.p, D->root.p, (uint32_t)D->rank, D->base[D->rank], D->qcur.p, (uint2 *)d_out);
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
+// (c) owner side: (own vertex u, other root) -> (own root of u, other root), in place
+__global__ void k_dcc_pairs_complete(uint2 *__restrict__ p, uint64_t n, const uint32_t *__restrict__ root, uint32_t mybase) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i].x = mybase + root[p[i].x];
+}
+extern "C" int mf_dcc_pairs_complete(mf_dcc *D, void *d_pairs, uint64_t n) {
+    if (!D || (n && !d_pairs)) return mf_set_error("mf_dcc_pairs_complete: NULL argument");
+    MF_HIP(hipSetDevice(D->ctx->device));
+    if (n) k_dcc_pairs_complete<<<cgrid(n), 256, 0, D->ctx->stream>>>((uint2 *)d_pairs, n, D->root.p, D->base[D->rank]);
+    MF_HIP(hipStreamSynchronize(D->ctx->stream));
+    return MF_OK;
+}
+// (d) all ranks' pairs -> union-find over fragment roots (the same on every rank) -> the global root of every own fragment;
+//     *n_stats = this rank's fragments (records of mf_dcc_stats_fill)
+__global__ void k_dcc_iota(uint32_t *__restrict__ p, uint32_t *__restrict__ gs, unsigned long long *__restrict__ gw, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { p[i] = (uint32_t)i; gs[i] = 0; gw[i] = 0; }
+}
+__global__ void k_dcc_hook_pairs(const uint2 *__restrict__ pr, uint64_t n, uint32_t *parent) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t ra = pr[i].x, rb = pr[i].y;
+    for (;;) {
+        ra = cc_find(parent, ra); rb = cc_find(parent, rb);
+        if (ra == rb) break;
+        if (ra < rb) { const uint32_t t = ra; ra = rb; rb = t; }
+        if (atomicCAS(&parent[ra], ra, rb) == ra) break;
+    }
+}
+struct dcc_stat { uint32_t g, size; unsigned long long weight; };
+__global__ void k_dcc_groots(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ root, uint32_t n, const uint32_t *__restrict__ pg, uint32_t mybase,
+                             uint32_t *__restrict__ groot, const uint32_t *__restrict__ csize, const unsigned long long *__restrict__ cweight,
+                             unsigned int *__restrict__ cnt, dcc_stat *__restrict__ out) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || !alive[v] || root[v] != v) return;
+    uint32_t g = mybase + v;
+    for (;;) { const uint32_t p = pg[g]; if (p == g) break; g = p; }
+    groot[v] = g;
+    const uint32_t at = atomicAdd(cnt, 1u);
+    if (out) { out[at].g = g; out[at].size = csize[v]; out[at].weight = cweight[v]; }
+}
+extern "C" int mf_dcc_merge(mf_dcc *D, const void *d_pairs, uint64_t n, uint64_t *n_stats) {
+    if (!D || !n_stats || (n && !d_pairs)) return mf_set_error("mf_dcc_merge: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    if (D->n_total) k_dcc_iota<<<cgrid(D->n_total), 256, 0, st>>>(D->pg.p, D->gsize.p, D->gweight.p, D->n_total);
+    if (n) { mf_ktimer tm(ctx, "k_dcc_hook_pairs"); k_dcc_hook_pairs<<<cgrid(n), 256, 0, st>>>((const uint2 *)d_pairs, n, D->pg.p); }
+    MF_HIP(hipMemsetAsync(&D->ctr.p[1], 0, 4, st));
+    if (D->n) k_dcc_groots<<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->n, D->pg.p, D->base[D->rank], D->groot.p, D->csize.p, D->cweight.p, &D->ctr.p[1], nullptr);
+    unsigned int c = 0;
+    MF_HIP(hipMemcpyAsync(&c, &D->ctr.p[1], 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    D->nstat = c; *n_stats = c;
+    return MF_OK;
+}
+// (e) this rank's fragments: (global root, size, weight), 16 bytes each
+extern "C" int mf_dcc_stats_fill(mf_dcc *D, void *d_out) {
+    if (!D || (D->nstat && !d_out)) return mf_set_error("mf_dcc_stats_fill: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    MF_HIP(hipMemsetAsync(&D->ctr.p[1], 0, 4, st));
+    if (D->n) k_dcc_groots<<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->n, D->pg.p, D->base[D->rank], D->groot.p, D->csize.p, D->cweight.p, &D->ctr.p[1], (dcc_stat *)d_out);
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
+// (f) all ranks' fragments -> per global root; classify; members of kept components and the next level's alive set.
+//     kept components whose root this rank owns are appended to d_kept (12 bytes: g, size, ... see dcc_kept_rec): *n_kept, *n_big
+__global__ void k_dcc_accumulate(const dcc_stat *__restrict__ s, uint64_t n, uint32_t *__restrict__ gsize, unsigned long long *__restrict__ gweight) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    atomicAdd(&gsize[s[i].g], s[i].size);
+    atomicAdd(&gweight[s[i].g], s[i].weight);
+}
+struct dcc_kept_rec { uint32_t g, size; unsigned long long weight; };
+__global__ void k_dcc_owned_classes(const uint32_t *__restrict__ gsize, const unsigned long long *__restrict__ gweight, uint32_t lo, uint32_t hi, uint32_t b1, uint32_t b2,
+                                    unsigned int *__restrict__ cnt /* [0] kept [1] big */, dcc_kept_rec *__restrict__ out) {
+    const uint32_t g = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= hi) return;
+    const uint32_t s = gsize[g];
+    if (s == 0 || s < b1) return;
+    if (s <= b2) { const uint32_t at = atomicAdd(&cnt[0], 1u); if (out) { out[at].g = g; out[at].size = s; out[at].weight = gweight[g]; } }
+    else atomicAdd(&cnt[1], 1u);
+}
+template <bool DRY>
+__global__ void k_dcc_apply(uint8_t *__restrict__ alive, const uint32_t *__restrict__ root, const uint32_t *__restrict__ groot, const uint32_t *__restrict__ gsize,
+                            const uint16_t *__restrict__ vals, const uint64_t *__restrict__ keys, uint32_t n, uint32_t b1, uint32_t b2, uint32_t next_thr,
+                            unsigned int *__restrict__ cnt, uint64_t *__restrict__ mk, uint32_t *__restrict__ mg) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    bool put = false; uint32_t g = 0;
+    if (v < n && alive[v]) {
+        g = groot[root[v]];
+        const uint32_t s = gsize[g];
+        if (s > b2) { if (!DRY && (uint32_t)vals[v] < next_thr) alive[v] = 0; }
+        else { if (!DRY) alive[v] = 0; put = s >= b1; }
+    }
+    const unsigned long long b = __ballot(put);
+    if (!b) return;
+    uint32_t base = 0;
+    if (mf_lane() == (uint32_t)(__ffsll((long long)b) - 1)) base = atomicAdd(cnt, (uint32_t)__popcll(b));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((long long)b) - 1);
+    if (!DRY && put) { const uint32_t at = base + (uint32_t)__popcll(b & ((1ull << mf_lane()) - 1ull)); mk[at] = keys[v]; mg[at] = g; }
+}
+__global__ void k_dcc_cross_next(uint8_t *__restrict__ xalive, const uint32_t *__restrict__ xv, const uint16_t *__restrict__ xval, uint64_t nx,
+                                 const uint8_t *__restrict__ alive_after, uint32_t next_thr) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= nx || !xalive[e]) return;
+    // this end survived (its component is too large and its value reaches the next threshold), and so does the other end
+    // if its value does: it is in the same component
+    if (!alive_after[xv[e]] || (uint32_t)xval[e] < next_thr) xalive[e] = 0;
+}
+// all ranks' fragments (n records of mf_dcc_stats_fill) -> size / weight per global root; every vertex of this rank is
+// classified: members of kept components are remembered (k-mer, global root), vertices of oversize components whose value
+// reaches thr + 1 stay alive.  *n_kept / *n_big: the kept / oversize components whose global root this rank owns
+// (mf_dcc_kept_fill writes the kept ones).
+extern "C" int mf_dcc_classify(mf_dcc *D, const void *d_stats, uint64_t n, int b1, int b2, int thr, uint64_t *n_kept, uint64_t *n_big) {
+    if (!D || !n_kept || !n_big || (n && !d_stats)) return mf_set_error("mf_dcc_classify: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    if (b1 < 0) b1 = 0;
+    D->b1 = b1; D->b2 = b2;
+    if (n) k_dcc_accumulate<<<cgrid(n), 256, 0, st>>>((const dcc_stat *)d_stats, n, D->gsize.p, D->gweight.p);
+    MF_HIP(hipMemsetAsync(&D->ctr.p[2], 0, 16, st));
+    const uint32_t lo = D->base[D->rank], hi = D->base[D->rank + 1];
+    if (hi > lo) k_dcc_owned_classes<<<cgrid(hi - lo), 256, 0, st>>>(D->gsize.p, D->gweight.p, lo, hi, (uint32_t)b1, (uint32_t)b2, &D->ctr.p[2], nullptr);
+    if (D->n) k_dcc_apply<true><<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->groot.p, D->gsize.p, D->t->d_counts, D->t->d_keys, D->n, (uint32_t)b1, (uint32_t)b2,
+                                                             0u, &D->ctr.p[4], nullptr, nullptr);
+    unsigned int c[4];
+    MF_HIP(hipMemcpyAsync(c, &D->ctr.p[2], 16, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    *n_kept = D->nkept_owned = c[0]; *n_big = c[1];
+    const uint32_t nm = c[2];
+    auto lv = std::make_unique<mf_dcc::level_buf>();
+    MF_TRY(lv->mk.alloc(ctx, nm ? nm : 1)); MF_TRY(lv->mg.alloc(ctx, nm ? nm : 1));
+    lv->n = nm;
+    MF_HIP(hipMemsetAsync(&D->ctr.p[4], 0, 4, st));
+    if (D->n) {
+        mf_ktimer tm(ctx, "k_cc_members");
+        k_dcc_apply<false><<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->groot.p, D->gsize.p, D->t->d_counts, D->t->d_keys, D->n, (uint32_t)b1, (uint32_t)b2,
+                                                        (uint32_t)(thr + 1), &D->ctr.p[4], lv->mk.p, lv->mg.p);
+    }
+    if (D->nx) k_dcc_cross_next<<<cgrid(D->nx), 256, 0, st>>>(D->xalive.p, D->xv.p, D->xval.p, D->nx, D->alive.p, (uint32_t)(thr + 1));
+    D->nm += nm;
+    D->levels.push_back(std::move(lv));
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
+// the kept components of this level whose global root this rank owns: 16 bytes each (root u32, size u32, weight u64)
+extern "C" int mf_dcc_kept_fill(mf_dcc *D, void *d_out) {
+    if (!D || (D->nkept_owned && !d_out)) return mf_set_error("mf_dcc_kept_fill: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    MF_HIP(hipMemsetAsync(&D->ctr.p[2], 0, 16, st));
+    const uint32_t lo = D->base[D->rank], hi = D->base[D->rank + 1];
+    if (hi > lo && D->nkept_owned)
+        k_dcc_owned_classes<<<cgrid(hi - lo), 256, 0, st>>>(D->gsize.p, D->gweight.p, lo, hi, (uint32_t)D->b1, (uint32_t)D->b2, &D->ctr.p[2], (dcc_kept_rec *)d_out);
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
+// members of kept components among this rank's vertices, all levels: count, then (k-mer u64[], global root u32[])
+extern "C" int mf_dcc_members(mf_dcc *D, uint64_t *n) {
+    if (!D || !n) return mf_set_error("mf_dcc_members: NULL argument");
+    *n = D->nm;
+    return MF_OK;
+}
+extern "C" int mf_dcc_members_fill(mf_dcc *D, void *d_keys, void *d_roots) {
+    if (!D || (D->nm && (!d_keys || !d_roots))) return mf_set_error("mf_dcc_members_fill: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    uint64_t pos = 0;
+    for (auto &lv : D->levels) {
+        if (!lv->n) continue;
+        MF_HIP(hipMemcpyAsync((uint64_t *)d_keys + pos, lv->mk.p, lv->n * 8, hipMemcpyDeviceToDevice, st));
+        MF_HIP(hipMemcpyAsync((uint32_t *)d_roots + pos, lv->mg.p, lv->n * 4, hipMemcpyDeviceToDevice, st));
+        pos += lv->n;
+    }
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
+// all ranks' members + all levels' kept components (host arrays, the same on every rank) -> the components object every
+// rank holds (order: ConnectedComponent.compareTo, src/structures/ConnectedComponent.java:125-136, ties by the smallest k-mer)
+__global__ void k_dcc_slot_map(const uint32_t *__restrict__ g, uint32_t n, uint32_t *__restrict__ map, unsigned long long *__restrict__ minkey) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { map[g[i]] = i; minkey[i] = ~0ull; }
+}
+__global__ void k_dcc_member_slots(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ mg, uint64_t n, const uint32_t *__restrict__ map,
+                                   uint32_t *__restrict__ comp, unsigned long long *__restrict__ minkey) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = map[mg[i]];
+    comp[i] = s;
+    atomicMin(&minkey[s], (unsigned long long)keys[i]);
+}
+extern "C" int mf_dcc_finish(mf_dcc *D, const void *d_keys, const void *d_roots, uint64_t nm, const uint32_t *kept_root, const uint32_t *kept_size,
+                             const int64_t *kept_weight, const int32_t *kept_thr, uint64_t n_kept, mf_comps **out) {
+    if (!D || !out || (nm && (!d_keys || !d_roots)) || (n_kept && (!kept_root || !kept_size || !kept_weight || !kept_thr)))
+        return mf_set_error("mf_dcc_finish: NULL argument");
+    *out = nullptr;
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    if (nm >= 0xFFFFFFFFull || n_kept >= 0xFFFFFFFFull) return mf_set_error("components: too many k-mers");
+    uint64_t sum = 0;
+    for (uint64_t i = 0; i < n_kept; i++) { sum += kept_size[i]; if (kept_root[i] >= D->n_total) return mf_set_error("mf_dcc_finish: component root out of range"); }
+    if (sum != nm) return mf_set_error("mf_dcc_finish: %llu members for components of %llu k-mers", (unsigned long long)nm, (unsigned long long)sum);
+    std::vector<unsigned long long> minkey(n_kept);
+    std::unique_ptr<mf_comps, void (*)(mf_comps *)> C(new mf_comps(), mf_comps_destroy);
+    C->ctx = ctx; C->k = D->k; C->n = n_kept; C->n_kmers = nm;
+    void *p = nullptr;
+    MF_TRY(mf_alloc(ctx, (nm ? nm : 1) * 8, &p)); C->d_kmers = (uint64_t *)p; C->kmers_bytes = (nm ? nm : 1) * 8;
+    MF_TRY(mf_alloc(ctx, (nm ? nm : 1) * 4, &p)); C->d_comp = (uint32_t *)p; C->comp_bytes = (nm ? nm : 1) * 4;
+    mf_buf<uint32_t> d_g, d_rank; mf_buf<unsigned long long> d_min;
+    MF_TRY(d_g.alloc(ctx, n_kept ? n_kept : 1)); MF_TRY(d_rank.alloc(ctx, n_kept ? n_kept : 1)); MF_TRY(d_min.alloc(ctx, n_kept ? n_kept : 1));
+    if (n_kept) {
+        MF_HIP(hipMemcpyAsync(d_g.p, kept_root, n_kept * 4, hipMemcpyHostToDevice, st));
+        k_dcc_slot_map<<<cgrid(n_kept), 256, 0, st>>>(d_g.p, (uint32_t)n_kept, D->pg.p, d_min.p);
+        if (nm) {
+            MF_HIP(hipMemcpyAsync(C->d_kmers, d_keys, nm * 8, hipMemcpyDeviceToDevice, st));
+            k_dcc_member_slots<<<cgrid(nm), 256, 0, st>>>((const uint64_t *)d_keys, (const uint32_t *)d_roots, nm, D->pg.p, C->d_comp, d_min.p);
+        }
+        MF_HIP(hipMemcpyAsync(minkey.data(), d_min.p, n_kept * 8, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+    }
+    std::vector<uint32_t> order(n_kept);
+    for (uint64_t i = 0; i < n_kept; i++) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        if (kept_thr[a] != kept_thr[b]) return kept_thr[a] < kept_thr[b];
+        if (kept_weight[a] != kept_weight[b]) return kept_weight[a] > kept_weight[b];
+        if (kept_size[a] != kept_size[b]) return kept_size[a] > kept_size[b];
+        return minkey[a] < minkey[b];
+    });
+    std::vector<uint32_t> rank(n_kept ? n_kept : 1);
+    for (uint64_t i = 0; i < n_kept; i++) {
+        const uint32_t s = order[i];
+        C->sizes.push_back(kept_size[s]); C->weights.push_back(kept_weight[s]); C->thr.push_back(kept_thr[s]);
+        rank[s] = (uint32_t)i;
+    }
+    if (nm) {
+        MF_HIP(hipMemcpyAsync(d_rank.p, rank.data(), n_kept * 4, hipMemcpyHostToDevice, st));
+        k_cc_remap<<<cgrid(nm), 256, 0, st>>>(C->d_comp, nm, d_rank.p);
+        MF_HIP(hipStreamSynchronize(st));
+    }
+    *out = C.release();
+    return MF_OK;
+}

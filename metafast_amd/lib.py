@@ -47,6 +47,24 @@ _SIGS = {
     "mf_table_load_kmers": (i32, [vp, C.POINTER(cp), i32, i32, i32, pvp]),
     "mf_table_filter": (i32, [vp, i32, pvp]),
     "mf_table_from_host": (i32, [vp, vp, vp, u64, i32, pvp]),
+    "mf_table_split_by_owner": (i32, [vp, i32, vp, vp, pu64]),
+    "mf_table_from_pairs_device": (i32, [vp, vp, vp, u64, i32, pvp]),
+    "mf_dcc_create": (i32, [vp, vp, i32, i32, vp, pvp]),
+    "mf_dcc_destroy": (None, [vp]),
+    "mf_dcc_queries": (i32, [vp, vp]),
+    "mf_dcc_queries_fill": (i32, [vp, vp]),
+    "mf_dcc_answer": (i32, [vp, vp, u64, vp]),
+    "mf_dcc_set_answers": (i32, [vp, vp, u64]),
+    "mf_dcc_level_local": (i32, [vp, vp]),
+    "mf_dcc_pairs_fill": (i32, [vp, vp]),
+    "mf_dcc_pairs_complete": (i32, [vp, vp, u64]),
+    "mf_dcc_merge": (i32, [vp, vp, u64, pu64]),
+    "mf_dcc_stats_fill": (i32, [vp, vp]),
+    "mf_dcc_classify": (i32, [vp, vp, u64, i32, i32, i32, pu64, pu64]),
+    "mf_dcc_kept_fill": (i32, [vp, vp]),
+    "mf_dcc_members": (i32, [vp, pu64]),
+    "mf_dcc_members_fill": (i32, [vp, vp, vp]),
+    "mf_dcc_finish": (i32, [vp, vp, vp, u64, vp, vp, vp, vp, u64, pvp]),
     "mf_build_unitigs_device": (i32, [vp, vp, i32, i32, pvp]),
     "mf_seqs_destroy": (None, [vp]),
     "mf_seqs_stats": (i32, [vp, pu64, pu64]),
@@ -197,6 +215,12 @@ class Context:
         _check(lib().mf_table_from_host(self.h, keys.ctypes.data, counts.ctypes.data, len(keys), k, C.byref(t)))
         return Table(self, t)
 
+    def table_from_pairs_device(self, d_keys, d_counts, n, k):
+        """(k-mer, count) pairs in HBM -> table; repeated k-mers get the saturating sum of their counts"""
+        t = C.c_void_p()
+        _check(lib().mf_table_from_pairs_device(self.h, d_keys, d_counts, n, k, C.byref(t)))
+        return Table(self, t)
+
     # ---- A7 ----
     def build_unitigs(self, table, freq_threshold, min_len):
         """SequencesFinders.thresholdStrategy (src/algo/SequencesFinders.java:13-31)"""
@@ -306,6 +330,13 @@ class Table:
         _check(lib().mf_table_device_view(self.h, C.byref(k), C.byref(c), C.byref(n)))
         return k.value, c.value, n.value
 
+    def split_by_owner(self, world, d_keys, d_counts):
+        """entries regrouped by owner rank (top log2(world) bits of the minimizer-partition hash) into the two device
+        buffers (room for len(self) entries); -> offsets[world + 1]"""
+        off = np.zeros(world + 1, dtype=np.uint64)
+        _check(lib().mf_table_split_by_owner(self.h, world, d_keys, d_counts, off.ctypes.data_as(pu64)))
+        return off
+
     def lookup(self, keys):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
         out = np.empty(len(keys), dtype=np.int32)
@@ -414,6 +445,87 @@ class Comps:
 
     def write(self, components_bin, stat_txt=None):
         _check(lib().mf_comps_write(self.h, os.fsencode(components_bin), _opt(stat_txt)))
+
+
+class DistCutter:
+    """One rank's part of the distributed component cutter (mf_dcc_* in include/metafast_hip.h): it owns a shard of the
+    cutter table; the exchange steps in between are the caller's (metafast_amd/pipeline.py: distributed_components)."""
+
+    def __init__(self, ctx, shard, rank, world, base):
+        self.ctx, self.shard = ctx, shard
+        base = np.ascontiguousarray(base, dtype=np.uint32)
+        h = C.c_void_p()
+        _check(lib().mf_dcc_create(ctx.h, shard.h, rank, world, base.ctypes.data, C.byref(h)))
+        self.h, self.world = h, world
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None and getattr(self.ctx, "h", None):
+            _lib.mf_dcc_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _counts(self, fn):
+        c = np.zeros(self.world, dtype=np.uint64)
+        _check(fn(self.h, c.ctypes.data))
+        return c
+
+    def queries(self):
+        return self._counts(lib().mf_dcc_queries)
+
+    def queries_fill(self, d_q):
+        _check(lib().mf_dcc_queries_fill(self.h, d_q))
+
+    def answer(self, d_q, n, d_a):
+        _check(lib().mf_dcc_answer(self.h, d_q, n, d_a))
+
+    def set_answers(self, d_a, n):
+        _check(lib().mf_dcc_set_answers(self.h, d_a, n))
+
+    def level_local(self):
+        return self._counts(lib().mf_dcc_level_local)
+
+    def pairs_fill(self, d_out):
+        _check(lib().mf_dcc_pairs_fill(self.h, d_out))
+
+    def pairs_complete(self, d_pairs, n):
+        _check(lib().mf_dcc_pairs_complete(self.h, d_pairs, n))
+
+    def merge(self, d_pairs, n):
+        m = C.c_uint64()
+        _check(lib().mf_dcc_merge(self.h, d_pairs, n, C.byref(m)))
+        return m.value
+
+    def stats_fill(self, d_out):
+        _check(lib().mf_dcc_stats_fill(self.h, d_out))
+
+    def classify(self, d_stats, n, b1, b2, thr):
+        a, b = C.c_uint64(), C.c_uint64()
+        _check(lib().mf_dcc_classify(self.h, d_stats, n, b1, b2, thr, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def kept_fill(self, d_out):
+        _check(lib().mf_dcc_kept_fill(self.h, d_out))
+
+    def members(self):
+        n = C.c_uint64()
+        _check(lib().mf_dcc_members(self.h, C.byref(n)))
+        return n.value
+
+    def members_fill(self, d_keys, d_roots):
+        _check(lib().mf_dcc_members_fill(self.h, d_keys, d_roots))
+
+    def finish(self, d_keys, d_roots, nm, roots, sizes, weights, thrs):
+        roots = np.ascontiguousarray(roots, dtype=np.uint32); sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        weights = np.ascontiguousarray(weights, dtype=np.int64); thrs = np.ascontiguousarray(thrs, dtype=np.int32)
+        c = C.c_void_p()
+        _check(lib().mf_dcc_finish(self.h, d_keys, d_roots, nm, roots.ctypes.data, sizes.ctypes.data, weights.ctypes.data,
+                                   thrs.ctypes.data, len(roots), C.byref(c)))
+        return Comps(self.ctx, c)
 
 
 def bray_curtis(vecs):

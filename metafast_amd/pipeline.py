@@ -4,9 +4,10 @@ Host-side mirror of the step wiring in DistanceMatrixBuilderMain (src/tools/Dist
 kmer-counter -> seq-builder -> component-cutter -> features-calculator -> dist-matrix-calculator, with the
 files between the steps replaced by buffers that stay in HBM.  Steps 1, 2 and 4 are independent per sample
 (KmersCounterForManyFilesMain.java:80-108, SeqBuilderForManyFilesMain.java:82-94, FeaturesCalculatorMain.java:137-162);
-step 3 joins all samples (ComponentCutterMain.java:81), so the ranks exchange their unitigs once (all-gather over
-RCCL / xGMI) and every rank builds the same cutter table and components; the per-sample feature vectors are
-all-gathered for the Bray-Curtis matrix.  torch is used for device memory and torch.distributed only.
+step 3 joins all samples (ComponentCutterMain.java:81): every rank counts the k-mers of its own unitigs, the ranks exchange the entries by
+owner (all-to-all over RCCL / xGMI) so that each holds a shard of the cutter table, and the components are found with
+every rank working on its shard (distributed_components); the per-sample feature vectors are all-gathered for the
+Bray-Curtis matrix.  torch is used for device memory and torch.distributed only.
 """
 import os
 import time
@@ -115,6 +116,216 @@ def device_tensor(ptr, nbytes, device):
     return torch.as_tensor(h, device=device)
 
 
+class TorchComm:
+    """The exchange steps of the distributed cutter over torch.distributed (nccl = RCCL over xGMI; gloo in the CPU-side
+    tests, staged through the host)."""
+
+    def __init__(self):
+        self.rank, self.world = _world()
+
+    def all_gather_ints(self, vals):
+        """small host vectors (same length on every rank) -> int64 ndarray [world, len]"""
+        if self.world == 1 and not _force():
+            return np.asarray([vals], dtype=np.int64)
+        dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
+        t = torch.tensor(list(vals), dtype=torch.int64, device=dev)
+        out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy().reshape(self.world, -1)
+
+    def all_gather(self, t, sizes):
+        """1-D tensors, sizes[r] elements on rank r (known to all) -> their concatenation in rank order"""
+        sizes = [int(x) for x in sizes]
+        if self.world == 1 and not _force():
+            return t
+        if t.is_cuda and dist.get_backend() == "gloo":
+            return self.all_gather(t.cpu(), sizes).to(t.device)
+        buf = torch.empty(sum(sizes), dtype=t.dtype, device=t.device)
+        if not sum(sizes):
+            return buf
+        if len(set(sizes)) == 1:
+            dist.all_gather_into_tensor(buf, t.contiguous())
+            return buf
+        at, works = 0, []
+        for r, n in enumerate(sizes):
+            if n:
+                if r == self.rank:
+                    buf[at:at + n].copy_(t)
+                works.append(dist.broadcast(buf[at:at + n], src=r, async_op=True))
+            at += n
+        for w in works:
+            w.wait()
+        return buf
+
+    def all_to_all(self, t, matrix):
+        """t: this rank's payload grouped by destination, matrix[src][dst] = elements (known to all) -> what the others sent here,
+        grouped by source"""
+        send = [int(x) for x in matrix[self.rank]]
+        recv = [int(matrix[r][self.rank]) for r in range(self.world)]
+        if self.world == 1 and not _force():
+            return t
+        if dist.get_backend() == "gloo":         # (tests) every rank sees everything and takes its slices
+            sizes = [int(sum(matrix[r])) for r in range(self.world)]
+            allt = self.all_gather(t, sizes)
+            parts, at = [], 0
+            for r in range(self.world):
+                o = at + int(sum(matrix[r][:self.rank]))
+                parts.append(allt[o:o + recv[r]]); at += sizes[r]
+            return torch.cat(parts)
+        out = torch.empty(sum(recv), dtype=t.dtype, device=t.device)
+        dist.all_to_all_single(out, t.contiguous(), recv, send)
+        return out
+
+
+class ThreadGroup:
+    """W virtual ranks inside ONE process (one thread each, all on the same GPU): the distributed cutter end to end on a
+    1-GPU box -- tests and tools/sim_union.py.  serial=True lets only one rank compute at a time (clean per-rank timings)."""
+
+    def __init__(self, world, serial=True):
+        import threading
+        self.world, self.slots = world, [None] * world
+        self.barrier = threading.Barrier(world)
+        self.turn = threading.Lock() if serial else None
+
+
+class ThreadComm:
+    def __init__(self, group, rank):
+        self.g, self.rank, self.world = group, rank, group.world
+        if group.turn:
+            group.turn.acquire()
+
+    def done(self):
+        if self.g.turn:
+            self.g.turn.release()
+
+    def _exchange(self, x):
+        g = self.g
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        g.slots[self.rank] = x
+        if g.turn:
+            g.turn.release()
+        try:
+            g.barrier.wait()
+            out = list(g.slots)
+            g.barrier.wait()
+        finally:
+            if g.turn:
+                g.turn.acquire()
+        return out
+
+    def all_gather_ints(self, vals):
+        return np.asarray(self._exchange([int(v) for v in vals]), dtype=np.int64).reshape(self.world, -1)
+
+    def all_gather(self, t, sizes):
+        return torch.cat(self._exchange(t))
+
+    def all_to_all(self, t, matrix):
+        parts = self._exchange(t)
+        out = []
+        for r in range(self.world):
+            o = int(sum(matrix[r][:self.rank]))
+            out.append(parts[r][o:o + int(matrix[r][self.rank])])
+        return torch.cat(out)
+
+
+def _i64(n, device):
+    return torch.empty(max(int(n), 1), dtype=torch.int64, device=device)
+
+
+def distributed_components(ctx, comm, local_cutter, k, b1, b2, device="cuda", timings=None, info=None):
+    """Component cutter over the union of all ranks' cutter tables with every rank owning a shard (include/metafast_hip.h,
+    "A9-A11 on several GPUs").  local_cutter: the table of THIS rank's unitig k-mers.  Returns (shard table, components);
+    the components are the same object on every rank, identical to cut_components on the merged table
+    (ComponentsBuilder.splitStrategy, src/algo/ComponentsBuilder.java:24-32)."""
+    W, me = comm.world, comm.rank
+    t0 = time.perf_counter()
+
+    def mark(name):
+        nonlocal t0
+        if timings is not None:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (t1 - t0)
+            t0 = t1
+
+    def sync():
+        torch.cuda.current_stream().synchronize()
+
+    # ---- the shard of the cutter table
+    _, _, n = local_cutter.device_view()
+    sk = _i64(n, device); sc = torch.empty(max(2 * n, 2), dtype=torch.uint8, device=device)     # (counts: u16 as bytes, RCCL has no 16-bit integer type)
+    sync()
+    off = local_cutter.split_by_owner(W, sk.data_ptr(), sc.data_ptr())
+    m = comm.all_gather_ints(np.diff(off.astype(np.int64)))
+    rk = comm.all_to_all(sk[:n], m); rc = comm.all_to_all(sc[:2 * n], 2 * m)
+    sync()
+    shard = ctx.table_from_pairs_device(rk.data_ptr(), rc.data_ptr(), int(rk.numel()), k)
+    del sk, sc, rk, rc
+    ns = comm.all_gather_ints([len(shard)])[:, 0]
+    base = np.concatenate([[0], np.cumsum(ns)])
+    if int(base[-1]) >= 0xFFFFFFFF:
+        raise L.MetafastError("components: more than 2^32 vertices over all ranks is not supported")
+    D = L.DistCutter(ctx, shard, me, W, base)
+    mark("cutter_shard")
+    # ---- neighbours in other shards
+    qm = comm.all_gather_ints(D.queries())
+    nq = int(qm[me].sum())
+    q = _i64(2 * nq, device); sync()
+    D.queries_fill(q.data_ptr())
+    rq = comm.all_to_all(q[:2 * nq], 2 * qm); sync()
+    na = int(rq.numel()) // 2
+    a = _i64(2 * na, device); sync()
+    D.answer(rq.data_ptr(), na, a.data_ptr())
+    ra = comm.all_to_all(a[:2 * na], 2 * qm.T); sync()
+    D.set_answers(ra.data_ptr(), nq)
+    del q, rq, a, ra
+    mark("cutter_adjacency")
+    # ---- threshold levels
+    kept, levels = [], 0
+    for thr in range(1, 1 << 16):
+        pm = comm.all_gather_ints(D.level_local())
+        nsend = int(pm[me].sum())
+        hp = _i64(nsend, device); sync()
+        D.pairs_fill(hp.data_ptr())
+        rp = comm.all_to_all(hp[:nsend], pm); sync()
+        nr = int(rp.numel())
+        if nr:
+            rp = rp.contiguous()
+            D.pairs_complete(rp.data_ptr(), nr)
+        allp = comm.all_gather(rp, pm.sum(axis=0)); sync()
+        n_stats = D.merge(allp.data_ptr(), int(allp.numel()))
+        st = _i64(2 * n_stats, device); sync()
+        D.stats_fill(st.data_ptr())
+        sm = comm.all_gather_ints([n_stats])[:, 0]
+        alls = comm.all_gather(st[:2 * n_stats], 2 * sm); sync()
+        n_kept, n_big = D.classify(alls.data_ptr(), int(alls.numel()) // 2, b1, b2, thr)
+        kb = _i64(2 * n_kept, device); sync()
+        D.kept_fill(kb.data_ptr())
+        km = comm.all_gather_ints([n_kept, n_big])
+        allk = comm.all_gather(kb[:2 * n_kept], 2 * km[:, 0]).cpu().numpy()
+        if allk.size:
+            r = allk.reshape(-1, 2)
+            kept.append((r[:, 0] & 0xFFFFFFFF, (r[:, 0] >> 32) & 0xFFFFFFFF, r[:, 1], np.full(len(r), thr, dtype=np.int32)))
+        levels = thr
+        if int(km[:, 1].sum()) == 0:
+            break
+    mark("cutter_levels")
+    # ---- members of the kept components, everywhere
+    nm = D.members()
+    mk = _i64(nm, device); mg = torch.empty(max(nm, 1), dtype=torch.int32, device=device); sync()
+    D.members_fill(mk.data_ptr(), mg.data_ptr())
+    mm = comm.all_gather_ints([nm])[:, 0]
+    allmk = comm.all_gather(mk[:nm], mm); allmg = comm.all_gather(mg[:nm], mm); sync()
+    cat = (lambda i, dt: np.concatenate([x[i] for x in kept]).astype(dt)) if kept else (lambda i, dt: np.zeros(0, dtype=dt))
+    comps = D.finish(allmk.data_ptr(), allmg.data_ptr(), int(allmk.numel()), cat(0, np.uint32), cat(1, np.uint32), cat(2, np.int64), cat(3, np.int32))
+    if info is not None:
+        info.update(levels=levels, shard=int(ns[me]), vertices=int(base[-1]), queries=nq, members=int(allmk.numel()))
+    D.close()
+    mark("cutter_members")
+    return shard, comps
+
+
 def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda", timings=None):
     """This rank's samples (KmersCounterForManyFilesMain.java:80-108 loops over all libraries: with more samples than GPUs a
     rank takes several, one after the other), joined with the other ranks' for the cutter and the matrix.
@@ -154,14 +365,29 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
     else:
         sb = torch.cat(parts_b) if parts_b else torch.zeros(0, dtype=torch.uint8, device=device)
         so = torch.cat(parts_o + [torch.tensor([nb], dtype=torch.int64, device=device)])
-    allb, allo, ns, nbt = gather_sequences(sb, so)
-    if torch.cuda.is_available():
+    rank, world = _world()
+    sharded = (world > 1 or _force()) and k >= 15 and world & (world - 1) == 0 and world <= 64 and not os.environ.get("MF_REPLICATED_CUTTER")
+    if sharded:
+        # every rank owns a shard of the cutter table and of the components step (distributed_components)
+        pb = torch.zeros(int(nb) + 64, dtype=torch.uint8, device=device)         # (the counting kernels read up to 64 bytes past the last base)
+        pb[:int(nb)] = sb
+        so = so.contiguous()
         torch.cuda.current_stream().synchronize()
-    mark("exchange_unitigs")
-    cutter = ctx.count_device(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l)
-    mark("cutter_count")
-    comps = ctx.cut_components(cutter, b1, b2)
-    mark("components")
+        local = ctx.count_device(pb.data_ptr(), so.data_ptr(), int(so.numel()) - 1, int(nb), k, l)
+        mark("cutter_count")
+        cutter, comps = distributed_components(ctx, TorchComm(), local, k, b1, b2, device=device, timings=timings)
+        local.close()
+        t0 = time.perf_counter()
+    else:
+        # (world sizes that are not a power of two, k < 15: every rank builds the whole cutter table and all components)
+        allb, allo, ns, nbt = gather_sequences(sb, so)
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+        mark("exchange_unitigs")
+        cutter = ctx.count_device(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l)
+        mark("cutter_count")
+        comps = ctx.cut_components(cutter, b1, b2)
+        mark("components")
     vecs_local, breadths = [], []
     for good in goods:
         vec, breadth = ctx.features(comps, good, 0)
