@@ -191,19 +191,18 @@ int  mf_cut_components(mf_ctx *ctx, mf_table *cutter, int k, int b1, int b2,
  * the buffers between the ranks (torch.distributed over RCCL in metafast_amd/pipeline.py; any
  * all-to-all / all-gather will do).  All d_* pointers are device memory of the ctx's GPU.
  *
- *   tables:   mf_table_split_by_owner -> all-to-all -> mf_table_from_pairs_device  (the shard)
+ *   table:    all-gather of the unitigs -> mf_count_device_shard                   (the shard)
  *   once:     mf_dcc_create; mf_dcc_queries + _fill -> all-to-all -> mf_dcc_answer -> all-to-all back
  *             -> mf_dcc_set_answers
  *   level t:  mf_dcc_level_local + mf_dcc_pairs_fill -> all-to-all -> mf_dcc_pairs_complete
  *             -> all-gather -> mf_dcc_merge + mf_dcc_stats_fill -> all-gather -> mf_dcc_classify
  *             + mf_dcc_kept_fill -> all-gather (kept components; stop when no rank has an oversize one)
- *   end:      mf_dcc_members + _fill -> all-gather -> mf_dcc_finish: the same mf_comps on every rank,
+ *   end:      mf_dcc_minkeys -> all-reduce (min); mf_dcc_members + _fill -> all-gather -> mf_dcc_finish: the same mf_comps on every rank,
  *             identical to mf_cut_components_device on the merged table.                              */
-/* keys u64[n] / counts u16[n] of `t` regrouped by owner; off[world + 1] (host) */
-int  mf_table_split_by_owner(const mf_table *t, int world, void *d_keys, void *d_counts, uint64_t *off);
-/* (k-mer, count) pairs -> table; repeated k-mers: saturating sum (NumUtils.addAndBound, src/utils/NumUtils.java) */
-int  mf_table_from_pairs_device(mf_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, int k,
-                                mf_table **out);
+/* rank's shard of the table of ALL the given sequences (every rank passes the same input, the unitigs of all samples):
+ * the k-mers whose minimizer-partition hash starts with `rank`.  k >= 20. */
+int  mf_count_device_shard(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases,
+                           int k, int min_len, int rank, int world, mf_table **out);
 /* base[world + 1]: global id of each rank's first vertex (prefix sums of the shard sizes; total < 2^32).
  * The shard must outlive the handle. */
 int  mf_dcc_create(mf_ctx *ctx, mf_table *shard, int rank, int world, const uint32_t *base, mf_dcc **out);
@@ -221,23 +220,26 @@ int  mf_dcc_level_local(mf_dcc *d, uint64_t *counts);
 int  mf_dcc_pairs_fill(mf_dcc *d, void *d_pairs);
 /* owner side, in place: half pairs -> (own fragment root, other fragment root), global ids */
 int  mf_dcc_pairs_complete(mf_dcc *d, void *d_pairs, uint64_t n);
-/* ALL ranks' completed pairs -> global root of each own fragment; *n_stats own fragments, then their 16-byte
- * records (global root u32, size u32, weight u64) */
+/* ALL ranks' completed pairs -> global root of each own fragment; *n_stats = components this rank has vertices of, then
+ * its share of each: 16-byte records (global root u32, size u32, weight u64) */
 int  mf_dcc_merge(mf_dcc *d, const void *d_pairs, uint64_t n, uint64_t *n_stats);
 int  mf_dcc_stats_fill(mf_dcc *d, void *d_stats);
-/* ALL ranks' fragment records -> classification of every own vertex at threshold thr (size window [b1, b2]);
- * n_kept / n_big: kept / oversize components whose global root is in this rank's id range; then the kept ones'
- * 16-byte records (root u32, size u32, weight u64) */
-int  mf_dcc_classify(mf_dcc *d, const void *d_stats, uint64_t n, int b1, int b2, int thr, uint64_t *n_kept,
-                     uint64_t *n_big);
+/* ALL ranks' records in rank order ([own_first, own_first + own_n) are this rank's own) -> classification of every own
+ * vertex at threshold thr (size window [b1, b2]); n_kept / n_big: kept / oversize components whose global root this rank
+ * owns; then the kept ones' 16-byte records (root u32, size u32, weight u64) */
+int  mf_dcc_classify(mf_dcc *d, const void *d_stats, uint64_t n, uint64_t own_first, uint64_t own_n, int b1, int b2,
+                     int thr, uint64_t *n_kept, uint64_t *n_big);
 int  mf_dcc_kept_fill(mf_dcc *d, void *d_kept);
 /* members of kept components among this rank's k-mers, all levels: k-mers u64[n], global roots u32[n] */
 int  mf_dcc_members(mf_dcc *d, uint64_t *n);
 int  mf_dcc_members_fill(mf_dcc *d, void *d_kmers, void *d_roots);
+/* smallest member k-mer of each kept component among this rank's k-mers (0x7FFF...F: none) -> d_min u64[n_kept];
+ * the caller takes the minimum over the ranks (it breaks ties in the components' order) */
+int  mf_dcc_minkeys(mf_dcc *d, const uint32_t *kept_root, uint64_t n_kept, void *d_min);
 /* ALL ranks' members + all levels' kept components (host arrays) -> components, ordered as above */
 int  mf_dcc_finish(mf_dcc *d, const void *d_kmers, const void *d_roots, uint64_t n_members, const uint32_t *kept_root,
-                   const uint32_t *kept_size, const int64_t *kept_weight, const int32_t *kept_thr, uint64_t n_kept,
-                   mf_comps **out);
+                   const uint32_t *kept_size, const int64_t *kept_weight, const int32_t *kept_thr,
+                   const uint64_t *kept_minkey, uint64_t n_kept, mf_comps **out);
 
 /* ---- A12  features ------------------------------------------------------------------ */
 /* replaces FeaturesCalculatorMain: hm.put(kmer,0) for component k-mers (:97-103), presence pass

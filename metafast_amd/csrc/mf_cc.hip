@@ -49,7 +49,8 @@ __global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ ke
 __global__ __launch_bounds__(64 * NB_WAVES) void k_cc_adjacency_part(mf_index_view ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
                                                                    uint32_t np, int k, uint32_t *__restrict__ nbr, int abl) {
     __shared__ nb_lds S;
-    nb_for_each(ix, keys, part_off, np, k, S, abl, [&](uint64_t v, uint64_t, const uint32_t (&idx)[8], uint32_t) {
+    nb_for_each(ix, keys, part_off, 0u, np, k, S, abl, 0, 0u, [&](uint64_t v, uint64_t, const uint32_t (&idx)[8], uint32_t, uint32_t, bool have) {
+        if (!have) return;
         uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
         o[0] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
         o[1] = make_uint4(idx[4], idx[5], idx[6], idx[7]);
@@ -619,7 +620,7 @@ extern "C" int mf_bray_curtis(const int64_t *vecs, int n_samples, int n_comp, do
 // the whole node.  Here every rank OWNS the k-mers whose minimizer-partition hash starts with its rank (top log2(world)
 // bits of mf_skm_ph): it holds that shard of the cutter table, finds its vertices' neighbours (its own ones in its index,
 // the others' by asking their owners), and solves its part of every threshold level; the ranks exchange
-//   * the shard entries of the per-sample cutter tables                               (once, all-to-all)
+//   * their unitigs (all-gather); every rank then counts the k-mers IT owns (mf_count_device_shard)
 //   * neighbour queries and answers                                                   (once, all-to-all both ways)
 //   * per level: the edges between fragments of different ranks (all-to-all + all-gather of root pairs), the fragments'
 //     sizes / weights (all-gather), the kept components of each owner (all-gather)
@@ -636,6 +637,9 @@ extern "C" int mf_bray_curtis(const int64_t *vecs, int n_samples, int n_comp, do
 // t-1, so both ends were in the same component and share its fate; what remains is the neighbour's own value, which the
 // answer to the query brought along.
 // =============================================================================================
+struct dcc_query { uint64_t key; uint64_t src; };
+struct dcc_kept_rec { uint32_t g, size; unsigned long long weight; };
+#define DCC_NOKEY 0x7FFFFFFFFFFFFFFFull          /* "no member here" (k-mers are < 2^62; signed-safe for a MIN all-reduce on int64) */
 struct mf_dcc {
     mf_ctx *ctx = nullptr; mf_table *t = nullptr; int k = 0, rank = 0, world = 1, lw = 0;
     uint32_t n = 0, n_total = 0; std::vector<uint32_t> base;
@@ -644,101 +648,98 @@ struct mf_dcc {
     mf_buf<unsigned int> ctr;                                // [64] counters
     // queries (16 bytes: key, source = vertex*8 + neighbour number) grouped by owner
     std::vector<uint64_t> qoff;                              // [world + 1]
-    mf_buf<unsigned long long> qcur;                         // [world] cursors
+    mf_buf<unsigned long long> qcur;                         // [64] cursors
+    mf_buf<dcc_query> qflat; uint32_t nq = 0;                // this rank's queries in the order they arose
     // cross edges
     mf_buf<uint32_t> xv, xu; mf_buf<uint8_t> xr, xalive; mf_buf<uint16_t> xval; uint64_t nx = 0;
     std::vector<uint64_t> xoff;                              // [world + 1] (pairs this rank sends per level)
     // contracted graph, replicated
-    mf_buf<uint32_t> pg, gsize; mf_buf<unsigned long long> gweight;     // [n_total]
+    mf_buf<uint32_t> pg, gsize; mf_buf<unsigned long long> gweight, gmin;     // [n_total]
     // results
-    struct level_buf { mf_buf<uint64_t> mk; mf_buf<uint32_t> mg; uint64_t n = 0; };     // members of kept components: k-mer, global root
-    std::vector<std::unique_ptr<level_buf>> levels; uint64_t nm = 0;
-    uint64_t nstat = 0, nkept_owned = 0; int b1 = 0, b2 = 0;
+    mf_buf<uint64_t> mk; mf_buf<uint32_t> mg; uint64_t nm = 0;          // [n] members of kept components: k-mer, global root
+    uint64_t nstat = 0, nkept_owned = 0; int level = 0;
+    mf_buf<uint32_t> touched; mf_buf<uint2> hp; std::vector<uint64_t> xstart;     // [n] global roots this rank contributes to; [nx] half pairs; [world + 1] cross edges by rank
+    mf_buf<dcc_kept_rec> keptbuf;
 };
 
 __device__ __forceinline__ uint32_t dcc_owner(uint32_t ph, int lw) { return lw ? ph >> (32 - lw) : 0u; }
 
-// ---- shard entries of a table, grouped by owner
-__global__ void k_dcc_owner_hist(const uint64_t *__restrict__ keys, uint64_t n, int k, int lw, unsigned long long *__restrict__ cnt) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&cnt[dcc_owner(mf_skm_ph(keys[i], k), lw)], 1ull);
-}
-__global__ void k_dcc_owner_scatter(const uint64_t *__restrict__ keys, const uint16_t *__restrict__ vals, uint64_t n, int k, int lw,
-                                    unsigned long long *__restrict__ cur, uint64_t *__restrict__ ok, uint16_t *__restrict__ ov) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t key = keys[i];
-    const unsigned long long at = atomicAdd(&cur[dcc_owner(mf_skm_ph(key, k), lw)], 1ull);
-    ok[at] = key; ov[at] = vals[i];
-}
 static int dcc_log2(int w) { int l = 0; while ((1 << l) < w) l++; return l; }
-// keys / counts of `t` regrouped by owner rank into d_keys / d_counts (room for t->n entries each); off[0..world]
-extern "C" int mf_table_split_by_owner(const mf_table *t, int world, void *d_keys, void *d_counts, uint64_t *off) {
-    if (!t || !off || (t->n && (!d_keys || !d_counts))) return mf_set_error("mf_table_split_by_owner: NULL argument");
-    if (world < 1 || world > 64 || (world & (world - 1))) return mf_set_error("mf_table_split_by_owner: the world size must be a power of two <= 64");
-    if (t->k < MF_SKM_M) return mf_set_error("mf_table_split_by_owner: k >= %d needed (minimizer ownership)", MF_SKM_M);
-    mf_ctx *ctx = t->ctx; hipStream_t st = ctx->stream;
-    MF_HIP(hipSetDevice(ctx->device));
-    const int lw = dcc_log2(world);
-    mf_buf<unsigned long long> cnt; MF_TRY(cnt.alloc(ctx, 2 * (size_t)world));
-    MF_HIP(hipMemsetAsync(cnt.p, 0, cnt.bytes(), st));
-    std::vector<unsigned long long> h(world, 0);
-    if (t->n) {
-        k_dcc_owner_hist<<<cgrid(t->n), 256, 0, st>>>(t->d_keys, t->n, t->k, lw, cnt.p);
-        MF_HIP(hipMemcpyAsync(h.data(), cnt.p, (size_t)world * 8, hipMemcpyDeviceToHost, st));
-        MF_HIP(hipStreamSynchronize(st));
-    }
-    off[0] = 0;
-    for (int o = 0; o < world; o++) off[o + 1] = off[o] + h[o];
-    if (t->n) {
-        std::vector<unsigned long long> c0(off, off + world);
-        MF_HIP(hipMemcpyAsync(cnt.p + world, c0.data(), (size_t)world * 8, hipMemcpyHostToDevice, st));
-        k_dcc_owner_scatter<<<cgrid(t->n), 256, 0, st>>>(t->d_keys, t->d_counts, t->n, t->k, lw, cnt.p + world, (uint64_t *)d_keys, (uint16_t *)d_counts);
-        MF_HIP(hipStreamSynchronize(st));
-    }
-    return MF_OK;
-}
-int mf_table_from_device_pairs(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, int k, mf_table **out);
-// (k-mer, count) pairs in HBM -> table; a k-mer that occurs several times gets the saturating sum (NumUtils.addAndBound)
-extern "C" int mf_table_from_pairs_device(mf_ctx *ctx, const void *d_keys, const void *d_counts, uint64_t n, int k, mf_table **out) {
-    if (!ctx || !out || (n && (!d_keys || !d_counts))) return mf_set_error("mf_table_from_pairs_device: NULL argument");
-    *out = nullptr;
-    if (k < 1 || k > 31) return mf_set_error("k must be in [1,31]");
-    MF_HIP(hipSetDevice(ctx->device));
-    int r = mf_table_from_device_pairs(ctx, (const uint64_t *)d_keys, (const uint16_t *)d_counts, n, k, out);
-    MF_HIP(hipStreamSynchronize(ctx->stream));
-    return r;
-}
-
-// ---- neighbours: own ones looked up, the others' counted / written as queries
-struct dcc_query { uint64_t key; uint64_t src; };
-template <bool FILL>
-__global__ void k_dcc_adjacency(mf_index_view ix, const uint64_t *__restrict__ keys, uint32_t n, int k, int lw, uint32_t me,
-                                uint32_t *__restrict__ nbr, unsigned long long *__restrict__ qcur, dcc_query *__restrict__ q) {
-    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n) return;
+// ---- neighbours: own ones looked up partition-locally (mf_nbr.h), the others' become queries (flat list, owner in the top
+// byte of src; sorted by owner afterwards)
+#define DCC_SRC_MASK ((1ull << 56) - 1ull)
+// A wave takes room in the query list DCC_QCHUNK entries at a time (one atomic on the list's cursor per chunk, not per 64
+// k-mers: 600 k atomics on one address cost 7 ms); what it leaves unused of a chunk is marked void (src = ~0).
+#define DCC_QCHUNK 512u
+__global__ __launch_bounds__(64 * NB_WAVES) void k_dcc_adjacency_part(mf_index_view ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
+                                                                    uint32_t p_lo, uint32_t p_hi, int k, int lw, uint32_t me, uint32_t *__restrict__ nbr,
+                                                                    dcc_query *__restrict__ q, uint32_t qcap, unsigned int *__restrict__ qcount, int abl) {
+    __shared__ nb_lds S;
     const uint64_t kmask = (1ull << (2 * k)) - 1;
-    const uint64_t x = keys[v];
-    uint32_t m_nf = 0, m_nl = 0;
-    mf_skm_nbr_mins(x, k, &m_nf, &m_nl);
-    uint32_t out[8];
-#pragma unroll
-    for (uint32_t i = 0; i < 8; i++) {
-        uint64_t y; uint32_t ph;
-        const uint64_t c = nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &ph);
-        const uint32_t o = dcc_owner(ph, lw);
-        out[i] = CC_NONE;
-        if (o == me) {
-            if (!FILL) { uint32_t idx, val; if (mf_index_find(ix, c, &idx, &val)) out[i] = idx; }
-        } else {
-            const unsigned long long at = atomicAdd(&qcur[o], 1ull);
-            if (FILL) { q[at].key = c; q[at].src = (uint64_t)v * 8 + i; }
+    uint32_t qcur = 0, qend = 0;                                         // this wave's chunk (wave-uniform)
+    auto void_rest = [&]() {
+        for (uint32_t i = qcur + mf_lane(); i < qend; i += 64) if (i < qcap) q[i].src = ~0ull;
+    };
+    nb_for_each(ix, keys, part_off, p_lo, p_hi, k, S, abl, lw, me, [&](uint64_t v, uint64_t x, const uint32_t (&idx)[8], uint32_t, uint32_t foreign, bool have) {
+        if (have) {
+            uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
+            o[0] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
+            o[1] = make_uint4(idx[4], idx[5], idx[6], idx[7]);
         }
+        const uint32_t cnt = have ? (uint32_t)__popc(foreign) : 0u;
+        uint32_t tot;
+        const uint32_t ex = mf_wave_excl_scan(cnt, &tot);
+        if (!tot) return;                                                // wave-uniform
+        if (qcur + tot > qend) {
+            void_rest();
+            uint32_t base = 0;
+            const uint32_t ch = tot > DCC_QCHUNK ? tot : DCC_QCHUNK;
+            if (mf_lane() == 0) base = atomicAdd(qcount, ch);
+            qcur = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            qend = qcur + ch;
+        }
+        uint32_t at = qcur + ex;
+        qcur += tot;
+        if (cnt) {
+            uint32_t m_nf = 0, m_nl = 0;
+            mf_skm_nbr_mins(x, k, &m_nf, &m_nl);
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) {
+                if (!((foreign >> i) & 1u)) continue;
+                uint64_t y; uint32_t ph;
+                const uint64_t c = nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &ph);
+                if (at < qcap) { q[at].key = c; q[at].src = (v * 8 + i) | ((uint64_t)(ph >> (32 - lw)) << 56); }
+                at++;
+            }
+        }
+    });
+    void_rest();
+}
+// queries by owner: counts, then the grouped copy (a workgroup reserves its share of every owner's range with one atomic each)
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_dcc_q_group(const dcc_query *__restrict__ q, uint32_t n, unsigned long long *__restrict__ cur, dcc_query *__restrict__ out) {
+    __shared__ uint32_t cnt[64]; __shared__ unsigned long long base[64];
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t per = 256 * 8, i0 = blockIdx.x * per;
+    uint32_t o[8], pos[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t i = i0 + (uint32_t)j * 256u + threadIdx.x;
+        o[j] = 0xFFFFFFFFu;
+        if (i < n) { o[j] = (uint32_t)(q[i].src >> 56); if (o[j] < 64u) pos[j] = atomicAdd(&cnt[o[j]], 1u); else o[j] = 0xFFFFFFFFu; }      // (>= 64: void)
     }
-    if (!FILL) {
-        uint4 *op = reinterpret_cast<uint4 *>(nbr + (size_t)v * 8);
-        op[0] = make_uint4(out[0], out[1], out[2], out[3]);
-        op[1] = make_uint4(out[4], out[5], out[6], out[7]);
+    __syncthreads();
+    if (threadIdx.x < 64 && cnt[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cur[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+    if (!FILL) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const uint32_t i = i0 + (uint32_t)j * 256u + threadIdx.x;
+        if (o[j] == 0xFFFFFFFFu) continue;
+        dcc_query r = q[i];
+        r.src &= DCC_SRC_MASK;
+        out[base[o[j]] + pos[j]] = r;
     }
 }
 struct dcc_answer { uint64_t src; uint32_t lid; uint32_t val; };
@@ -749,17 +750,38 @@ __global__ void k_dcc_answer(mf_index_view ix, const dcc_query *__restrict__ q, 
     const bool f = ix.slots && mf_index_find(ix, q[i].key, &idx, &val);
     a[i].src = q[i].src; a[i].lid = f ? idx : CC_NONE; a[i].val = f ? val : 0u;
 }
-// answers -> cross edges (appended; *nx counts them).  owner_of_answer: answers arrive grouped by answering rank
-__global__ void k_dcc_cross(const dcc_answer *__restrict__ a, uint64_t n, const uint64_t *__restrict__ aoff, int world, uint32_t *__restrict__ xv,
-                            uint32_t *__restrict__ xu, uint8_t *__restrict__ xr, uint16_t *__restrict__ xval, unsigned int *__restrict__ nx) {
+// Every thread of the workgroup calls it; the threads with `act` get distinct positions from cur[r] (r < 64): the workgroup
+// counts per rank in LDS and takes its share of every rank's range with one atomic each, instead of one atomic per lane (or
+// wave) on a handful of addresses (~12 ns each, serialised).  L: 64 + 64 * 2 uint32 of LDS.
+__device__ __forceinline__ uint64_t dcc_reserve_by(unsigned long long *cur, uint32_t r, bool act, uint32_t *L) {
+    unsigned long long *base = reinterpret_cast<unsigned long long *>(L + 64);
+    __syncthreads();
+    if (threadIdx.x < 64) L[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t pos = 0;
+    if (act) pos = atomicAdd(&L[r], 1u);
+    __syncthreads();
+    if (threadIdx.x < 64 && L[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cur[threadIdx.x], (unsigned long long)L[threadIdx.x]);
+    __syncthreads();
+    return act ? base[r] + pos : 0ull;
+}
+// answers (grouped by answering rank, aoff[]) -> cross edges, grouped by rank too: cur[r] counts (xv == nullptr) or is the
+// cursor of rank r's range
+__global__ void k_dcc_cross(const dcc_answer *__restrict__ a, uint64_t n, const uint64_t *__restrict__ aoff, int world, unsigned long long *__restrict__ cur,
+                            uint32_t *__restrict__ xv, uint32_t *__restrict__ xu, uint8_t *__restrict__ xr, uint16_t *__restrict__ xval) {
+    __shared__ uint32_t L[192];
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n || a[i].lid == CC_NONE) return;
-    int r = 0;
-    while (r + 1 < world && i >= aoff[r + 1]) r++;
-    const uint32_t at = atomicAdd(nx, 1u);
-    if (xv) { xv[at] = (uint32_t)(a[i].src >> 3); xu[at] = a[i].lid; xr[at] = (uint8_t)r; xval[at] = (uint16_t)a[i].val; }
+    const bool act = i < n && a[i].lid != CC_NONE;
+    uint32_t r = 0;
+    if (act) while ((int)r + 1 < world && i >= aoff[r + 1]) r++;
+    const uint64_t at = dcc_reserve_by(cur, r, act, L);
+    if (act && xv) { xv[at] = (uint32_t)(a[i].src >> 3); xu[at] = a[i].lid; xr[at] = (uint8_t)r; xval[at] = (uint16_t)a[i].val; }
 }
 
+__global__ void k_dcc_fill64(unsigned long long *__restrict__ p, uint64_t n, unsigned long long v) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
 extern "C" void mf_dcc_destroy(mf_dcc *d) { delete d; }
 // shard: this rank's part of the cutter table; base[0..world]: global id of every rank's first vertex
 extern "C" int mf_dcc_create(mf_ctx *ctx, mf_table *shard, int rank, int world, const uint32_t *base, mf_dcc **out) {
@@ -774,11 +796,16 @@ extern "C" int mf_dcc_create(mf_ctx *ctx, mf_table *shard, int rank, int world, 
     const size_t n1 = D->n ? D->n : 1;
     MF_TRY(D->nbr.alloc(ctx, n1 * 8)); MF_TRY(D->parent.alloc(ctx, n1)); MF_TRY(D->root.alloc(ctx, n1)); MF_TRY(D->csize.alloc(ctx, n1));
     MF_TRY(D->groot.alloc(ctx, n1)); MF_TRY(D->cweight.alloc(ctx, n1)); MF_TRY(D->alive.alloc(ctx, n1)); MF_TRY(D->ctr.alloc(ctx, 64));
-    MF_TRY(D->qcur.alloc(ctx, (size_t)world));
+    MF_TRY(D->qcur.alloc(ctx, 64)); MF_TRY(D->mk.alloc(ctx, n1)); MF_TRY(D->mg.alloc(ctx, n1)); MF_TRY(D->touched.alloc(ctx, n1));
+    D->xstart.assign(world + 1, 0);
+    if (D->n && !(shard->part_skm && shard->part_bits >= D->lw && shard->d_part_off))
+        return mf_set_error("mf_dcc_create: the shard must come from mf_count_device_shard (minimizer partitions)");
     const size_t nt = D->n_total ? D->n_total : 1;
-    MF_TRY(D->pg.alloc(ctx, nt)); MF_TRY(D->gsize.alloc(ctx, nt)); MF_TRY(D->gweight.alloc(ctx, nt));
+    MF_TRY(D->pg.alloc(ctx, nt)); MF_TRY(D->gsize.alloc(ctx, nt)); MF_TRY(D->gweight.alloc(ctx, nt)); MF_TRY(D->gmin.alloc(ctx, nt));
+    { mf_ktimer tm_(ctx, "k_dcc_fill64"); k_dcc_fill64<<<cgrid(nt), 256, 0, ctx->stream>>>(D->gmin.p, nt, DCC_NOKEY); }
     if (D->n) MF_TRY(mf_table_ensure_index(shard));
     MF_HIP(hipMemsetAsync(D->alive.p, 1, n1, ctx->stream));
+    MF_HIP(hipMemsetAsync(D->ctr.p, 0, D->ctr.bytes(), ctx->stream));
     *out = D.release();
     return MF_OK;
 }
@@ -787,13 +814,33 @@ extern "C" int mf_dcc_queries(mf_dcc *D, uint64_t *counts) {
     if (!D || !counts) return mf_set_error("mf_dcc_queries: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
     MF_HIP(hipSetDevice(ctx->device));
-    MF_HIP(hipMemsetAsync(D->qcur.p, 0, D->qcur.bytes(), st));
+    D->nq = 0;
     if (D->n) {
-        mf_ktimer tm(ctx, "k_dcc_adjacency");
-        k_dcc_adjacency<false><<<cgrid(D->n), 256, 0, st>>>(mf_view(D->t->index), D->t->d_keys, D->n, D->k, D->lw, (uint32_t)D->rank, D->nbr.p, D->qcur.p, nullptr);
+        mf_table *t = D->t;
+        const uint32_t p_lo = (uint32_t)D->rank << (t->part_bits - D->lw), p_hi = ((uint32_t)D->rank + 1u) << (t->part_bits - D->lw);
+        const unsigned grid = (unsigned)std::min<uint64_t>((p_hi - p_lo + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 16);
+        uint64_t cap = std::min<uint64_t>((uint64_t)D->n + (D->n >> 1) + (uint64_t)grid * NB_WAVES * DCC_QCHUNK, 0xFFFFFFF0ull);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            MF_TRY(D->qflat.alloc(ctx, cap));
+            MF_HIP(hipMemsetAsync(&D->ctr.p[8], 0, 4, st));
+            {
+                mf_ktimer tm(ctx, "k_cc_adjacency");
+                k_dcc_adjacency_part<<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, p_lo, p_hi, D->k, D->lw, (uint32_t)D->rank, D->nbr.p,
+                                                                    D->qflat.p, (uint32_t)cap, &D->ctr.p[8], (int)ctx->opt_ablate);
+            }
+            unsigned int c = 0;
+            MF_HIP(hipMemcpyAsync(&c, &D->ctr.p[8], 4, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            D->nq = c;
+            if (c <= cap) break;
+            if (attempt) return mf_set_error("mf_dcc_queries: query list overflow");
+            cap = std::min<uint64_t>((uint64_t)c + (c >> 3) + (uint64_t)grid * NB_WAVES * DCC_QCHUNK, 0xFFFFFFF0ull);   // (more than 1.5 foreign neighbours per k-mer: once more with room for what was asked for)
+        }
     }
-    std::vector<unsigned long long> h(D->world);
-    MF_HIP(hipMemcpyAsync(h.data(), D->qcur.p, (size_t)D->world * 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemsetAsync(D->qcur.p, 0, D->qcur.bytes(), st));
+    if (D->nq) { mf_ktimer tm_(ctx, "k_dcc_q_group"); k_dcc_q_group<false><<<cgrid(D->nq, 2048), 256, 0, st>>>(D->qflat.p, D->nq, D->qcur.p, nullptr); }
+    std::vector<unsigned long long> h(64);
+    MF_HIP(hipMemcpyAsync(h.data(), D->qcur.p, 64 * 8, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
     D->qoff.assign(D->world + 1, 0);
     for (int o = 0; o < D->world; o++) { counts[o] = h[o]; D->qoff[o + 1] = D->qoff[o] + h[o]; }
@@ -804,10 +851,12 @@ extern "C" int mf_dcc_queries_fill(mf_dcc *D, void *d_q) {
     if (!D || (D->qoff.back() && !d_q)) return mf_set_error("mf_dcc_queries_fill: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
     MF_HIP(hipSetDevice(ctx->device));
-    std::vector<unsigned long long> c0(D->qoff.begin(), D->qoff.begin() + D->world);
-    MF_HIP(hipMemcpyAsync(D->qcur.p, c0.data(), (size_t)D->world * 8, hipMemcpyHostToDevice, st));
-    if (D->n) k_dcc_adjacency<true><<<cgrid(D->n), 256, 0, st>>>(mf_view(D->t->index), D->t->d_keys, D->n, D->k, D->lw, (uint32_t)D->rank, nullptr, D->qcur.p, (dcc_query *)d_q);
+    std::vector<unsigned long long> c0(64, 0);
+    for (int o = 0; o < D->world; o++) c0[o] = D->qoff[o];
+    MF_HIP(hipMemcpyAsync(D->qcur.p, c0.data(), 64 * 8, hipMemcpyHostToDevice, st));
+    if (D->nq) { mf_ktimer tm_(ctx, "k_dcc_q_group"); k_dcc_q_group<true><<<cgrid(D->nq, 2048), 256, 0, st>>>(D->qflat.p, D->nq, D->qcur.p, (dcc_query *)d_q); }
     MF_HIP(hipStreamSynchronize(st));
+    D->qflat.reset();
     return MF_OK;
 }
 // step 3 (owner side): n queries -> n answers (16 bytes each)
@@ -817,7 +866,7 @@ extern "C" int mf_dcc_answer(mf_dcc *D, const void *d_q, uint64_t n, void *d_a) 
     MF_HIP(hipSetDevice(ctx->device));
     mf_index_view ix = mf_view(D->t->index);
     if (!D->n) ix.slots = nullptr;
-    if (n) k_dcc_answer<<<cgrid(n), 256, 0, ctx->stream>>>(ix, (const dcc_query *)d_q, n, (dcc_answer *)d_a);
+    if (n) { mf_ktimer tm_(ctx, "k_dcc_answer"); k_dcc_answer<<<cgrid(n), 256, 0, ctx->stream>>>(ix, (const dcc_query *)d_q, n, (dcc_answer *)d_a); }
     MF_HIP(hipStreamSynchronize(ctx->stream));
     return MF_OK;
 }
@@ -829,19 +878,25 @@ extern "C" int mf_dcc_set_answers(mf_dcc *D, const void *d_a, uint64_t n) {
     MF_HIP(hipSetDevice(ctx->device));
     mf_buf<uint64_t> aoff; MF_TRY(aoff.alloc(ctx, (size_t)D->world + 1));
     MF_HIP(hipMemcpyAsync(aoff.p, D->qoff.data(), ((size_t)D->world + 1) * 8, hipMemcpyHostToDevice, st));
-    MF_HIP(hipMemsetAsync(D->ctr.p, 0, 256, st));
-    unsigned int nx = 0;
+    MF_HIP(hipMemsetAsync(D->qcur.p, 0, D->qcur.bytes(), st));
+    std::vector<unsigned long long> h(64, 0);
     if (n) {
-        k_dcc_cross<<<cgrid(n), 256, 0, st>>>((const dcc_answer *)d_a, n, aoff.p, D->world, nullptr, nullptr, nullptr, nullptr, &D->ctr.p[0]);
-        MF_HIP(hipMemcpyAsync(&nx, &D->ctr.p[0], 4, hipMemcpyDeviceToHost, st));
+        { mf_ktimer tm_(ctx, "k_dcc_cross"); k_dcc_cross<<<cgrid(n), 256, 0, st>>>((const dcc_answer *)d_a, n, aoff.p, D->world, D->qcur.p, nullptr, nullptr, nullptr, nullptr); }
+        MF_HIP(hipMemcpyAsync(h.data(), D->qcur.p, 64 * 8, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
     }
+    std::vector<unsigned long long> c0(64, 0);
+    uint64_t nx = 0;
+    for (int o = 0; o < D->world; o++) { c0[o] = nx; D->xstart[o] = nx; nx += h[o]; }
+    D->xstart[D->world] = nx;
+    if (nx >= 0xFFFFFFFFull) return mf_set_error("mf_dcc_set_answers: too many cross edges");
     D->nx = nx;
     const size_t n1 = nx ? nx : 1;
+    MF_TRY(D->hp.alloc(ctx, n1));
     MF_TRY(D->xv.alloc(ctx, n1)); MF_TRY(D->xu.alloc(ctx, n1)); MF_TRY(D->xr.alloc(ctx, n1)); MF_TRY(D->xval.alloc(ctx, n1)); MF_TRY(D->xalive.alloc(ctx, n1));
     if (nx) {
-        MF_HIP(hipMemsetAsync(&D->ctr.p[0], 0, 4, st));
-        k_dcc_cross<<<cgrid(n), 256, 0, st>>>((const dcc_answer *)d_a, n, aoff.p, D->world, D->xv.p, D->xu.p, D->xr.p, D->xval.p, &D->ctr.p[0]);
+        MF_HIP(hipMemcpyAsync(D->qcur.p, c0.data(), 64 * 8, hipMemcpyHostToDevice, st));
+        { mf_ktimer tm_(ctx, "k_dcc_cross"); k_dcc_cross<<<cgrid(n), 256, 0, st>>>((const dcc_answer *)d_a, n, aoff.p, D->world, D->qcur.p, D->xv.p, D->xu.p, D->xr.p, D->xval.p); }
         MF_HIP(hipMemsetAsync(D->xalive.p, 1, nx, st));
     }
     MF_HIP(hipStreamSynchronize(st));
@@ -849,14 +904,17 @@ extern "C" int mf_dcc_set_answers(mf_dcc *D, const void *d_a, uint64_t n) {
 }
 
 // ---- one threshold level
-// (a) union-find inside the shard; counts[o] = root pairs this rank asks rank o to complete (edges to higher ranks only)
-__global__ void k_dcc_pairs_out(const uint32_t *__restrict__ xv, const uint32_t *__restrict__ xu, const uint8_t *__restrict__ xr, const uint8_t *__restrict__ xalive,
-                                uint64_t nx, const uint8_t *__restrict__ alive, const uint32_t *__restrict__ root, uint32_t me, uint32_t mybase,
-                                unsigned long long *__restrict__ cur, uint2 *__restrict__ out) {
+// (a) union-find inside the shard; counts[o] = root pairs this rank asks rank o to complete (edges to higher ranks only).
+//     The cross edges are grouped by rank, so the half pairs of rank r are compacted inside r's range of the edge list.
+__global__ __launch_bounds__(256) void k_dcc_pairs_out(const uint32_t *__restrict__ xv, const uint32_t *__restrict__ xu, const uint8_t *__restrict__ xr,
+                                                       const uint8_t *__restrict__ xalive, uint64_t nx, const uint8_t *__restrict__ alive, const uint32_t *__restrict__ root,
+                                                       uint32_t me, uint32_t mybase, unsigned long long *__restrict__ cur, uint2 *__restrict__ out) {
+    __shared__ uint32_t L[192];
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= nx || !xalive[e] || xr[e] <= me || !alive[xv[e]]) return;
-    const unsigned long long at = atomicAdd(&cur[xr[e]], 1ull);
-    if (out) out[at] = make_uint2(xu[e], mybase + root[xv[e]]);
+    uint32_t r = 0; bool act = false;
+    if (e < nx && xalive[e]) { r = xr[e]; act = r > me && alive[xv[e]]; }
+    const uint64_t at = dcc_reserve_by(cur, r, act, L);
+    if (act) out[at] = make_uint2(xu[e], mybase + root[xv[e]]);
 }
 extern "C" int mf_dcc_level_local(mf_dcc *D, uint64_t *counts) {
     if (!D || !counts) return mf_set_error("mf_dcc_level_local: NULL argument");
@@ -872,13 +930,17 @@ extern "C" int mf_dcc_level_local(mf_dcc *D, uint64_t *counts) {
         mf_ktimer tm(ctx, "k_cc_stats");
         k_cc_flatten_stats<<<cgrid(n, CC_TILE), 256, 0, st>>>(D->alive.p, D->parent.p, D->root.p, D->t->d_counts, D->csize.p, D->cweight.p, n);
     }
-    MF_HIP(hipMemsetAsync(D->qcur.p, 0, D->qcur.bytes(), st));
-    if (D->nx) k_dcc_pairs_out<<<cgrid(D->nx), 256, 0, st>>>(D->xv.p, D->xu.p, D->xr.p, D->xalive.p, D->nx, D->alive.p, D->root.p, (uint32_t)D->rank, D->base[D->rank], D->qcur.p, nullptr);
-    std::vector<unsigned long long> h(D->world);
-    MF_HIP(hipMemcpyAsync(h.data(), D->qcur.p, (size_t)D->world * 8, hipMemcpyDeviceToHost, st));
+    std::vector<unsigned long long> h(64, 0);
+    for (int o = 0; o < D->world; o++) h[o] = D->xstart[o];
+    MF_HIP(hipMemcpyAsync(D->qcur.p, h.data(), 64 * 8, hipMemcpyHostToDevice, st));
+    if (D->nx) {
+        mf_ktimer tm_(ctx, "k_dcc_pairs_out");
+        k_dcc_pairs_out<<<cgrid(D->nx), 256, 0, st>>>(D->xv.p, D->xu.p, D->xr.p, D->xalive.p, D->nx, D->alive.p, D->root.p, (uint32_t)D->rank, D->base[D->rank], D->qcur.p, D->hp.p);
+    }
+    MF_HIP(hipMemcpyAsync(h.data(), D->qcur.p, 64 * 8, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
     D->xoff.assign(D->world + 1, 0);
-    for (int o = 0; o < D->world; o++) { counts[o] = h[o]; D->xoff[o + 1] = D->xoff[o] + h[o]; }
+    for (int o = 0; o < D->world; o++) { counts[o] = h[o] - D->xstart[o]; D->xoff[o + 1] = D->xoff[o] + counts[o]; }
     return MF_OK;
 }
 // (b) the half pairs (remote vertex, global id of this end's root), 8 bytes each, grouped by rank
@@ -886,9 +948,9 @@ extern "C" int mf_dcc_pairs_fill(mf_dcc *D, void *d_out) {
     if (!D || (D->xoff.back() && !d_out)) return mf_set_error("mf_dcc_pairs_fill: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
     MF_HIP(hipSetDevice(ctx->device));
-    std::vector<unsigned long long> c0(D->xoff.begin(), D->xoff.begin() + D->world);
-    MF_HIP(hipMemcpyAsync(D->qcur.p, c0.data(), (size_t)D->world * 8, hipMemcpyHostToDevice, st));
-    if (D->nx) k_dcc_pairs_out<<<cgrid(D->nx), 256, 0, st>>>(D->xv.p, D->xu.p, D->xr.p, D->xalive.p, D->nx, D->alive.p, D->root.p, (uint32_t)D->rank, D->base[D->rank], D->qcur.p, (uint2 *)d_out);
+    for (int o = 0; o < D->world; o++)
+        if (D->xoff[o + 1] > D->xoff[o])
+            MF_HIP(hipMemcpyAsync((uint2 *)d_out + D->xoff[o], D->hp.p + D->xstart[o], (D->xoff[o + 1] - D->xoff[o]) * 8, hipMemcpyDeviceToDevice, st));
     MF_HIP(hipStreamSynchronize(st));
     return MF_OK;
 }
@@ -900,15 +962,30 @@ __global__ void k_dcc_pairs_complete(uint2 *__restrict__ p, uint64_t n, const ui
 extern "C" int mf_dcc_pairs_complete(mf_dcc *D, void *d_pairs, uint64_t n) {
     if (!D || (n && !d_pairs)) return mf_set_error("mf_dcc_pairs_complete: NULL argument");
     MF_HIP(hipSetDevice(D->ctx->device));
-    if (n) k_dcc_pairs_complete<<<cgrid(n), 256, 0, D->ctx->stream>>>((uint2 *)d_pairs, n, D->root.p, D->base[D->rank]);
+    if (n) { mf_ktimer tm_(D->ctx, "k_dcc_pairs_complete"); k_dcc_pairs_complete<<<cgrid(n), 256, 0, D->ctx->stream>>>((uint2 *)d_pairs, n, D->root.p, D->base[D->rank]); }
     MF_HIP(hipStreamSynchronize(D->ctx->stream));
     return MF_OK;
 }
-// (d) all ranks' pairs -> union-find over fragment roots (the same on every rank) -> the global root of every own fragment;
-//     *n_stats = this rank's fragments (records of mf_dcc_stats_fill)
+// (d) all ranks' pairs -> union-find over fragment roots (the same on every rank) -> the global root of every own fragment.
+//     The arrays over all global ids (pg, gsize, gweight) are set up in full at the first level only; later levels, with a
+//     few per cent of the vertices left, touch the ids that occur: the ends of the pairs and this rank's own fragment roots.
 __global__ void k_dcc_iota(uint32_t *__restrict__ p, uint32_t *__restrict__ gs, unsigned long long *__restrict__ gw, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { p[i] = (uint32_t)i; gs[i] = 0; gw[i] = 0; }
+}
+__global__ void k_dcc_init_pairs(const uint2 *__restrict__ pr, uint64_t n, uint32_t *__restrict__ p, uint32_t *__restrict__ gs, unsigned long long *__restrict__ gw) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t a = pr[i].x, b = pr[i].y;
+    p[a] = a; gs[a] = 0; gw[a] = 0;
+    p[b] = b; gs[b] = 0; gw[b] = 0;
+}
+__global__ void k_dcc_init_roots(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ root, uint32_t n, uint32_t mybase, uint32_t *__restrict__ p,
+                                 uint32_t *__restrict__ gs, unsigned long long *__restrict__ gw) {
+    const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || !alive[v] || root[v] != v) return;
+    const uint32_t g = mybase + v;
+    p[g] = g; gs[g] = 0; gw[g] = 0;
 }
 __global__ void k_dcc_hook_pairs(const uint2 *__restrict__ pr, uint64_t n, uint32_t *parent) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -921,78 +998,116 @@ __global__ void k_dcc_hook_pairs(const uint2 *__restrict__ pr, uint64_t n, uint3
         if (atomicCAS(&parent[ra], ra, rb) == ra) break;
     }
 }
+// own fragments: global root; their sizes / weights are summed per global root HERE first (a large component has millions
+// of fragments on every rank: one record per rank and component travels instead of one per fragment).  touched[]: the
+// global roots this rank contributes to (the thread that finds the sum at zero lists the root).
 struct dcc_stat { uint32_t g, size; unsigned long long weight; };
-__global__ void k_dcc_groots(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ root, uint32_t n, const uint32_t *__restrict__ pg, uint32_t mybase,
-                             uint32_t *__restrict__ groot, const uint32_t *__restrict__ csize, const unsigned long long *__restrict__ cweight,
-                             unsigned int *__restrict__ cnt, dcc_stat *__restrict__ out) {
+__global__ __launch_bounds__(256) void k_dcc_groots(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ root, uint32_t n, const uint32_t *__restrict__ pg,
+                                                    uint32_t mybase, uint32_t *__restrict__ groot, const uint32_t *__restrict__ csize,
+                                                    const unsigned long long *__restrict__ cweight, uint32_t *__restrict__ gsize, unsigned long long *__restrict__ gweight,
+                                                    unsigned int *__restrict__ cnt, uint32_t *__restrict__ touched) {
+    __shared__ uint32_t scratch[18];
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n || !alive[v] || root[v] != v) return;
-    uint32_t g = mybase + v;
-    for (;;) { const uint32_t p = pg[g]; if (p == g) break; g = p; }
-    groot[v] = g;
-    const uint32_t at = atomicAdd(cnt, 1u);
-    if (out) { out[at].g = g; out[at].size = csize[v]; out[at].weight = cweight[v]; }
+    const bool is_root = v < n && alive[v] && root[v] == v;
+    uint32_t g = 0; bool first = false;
+    if (is_root) {
+        g = mybase + v;
+        for (;;) { const uint32_t p = pg[g]; if (p == g) break; g = p; }
+        groot[v] = g;
+        first = atomicAdd(&gsize[g], csize[v]) == 0u;                    // (a fragment has at least one vertex)
+        atomicAdd(&gweight[g], cweight[v]);
+    }
+    const uint32_t at = mf_block_reserve(cnt, first ? 1u : 0u, scratch);
+    if (first) touched[at] = g;
+}
+__global__ void k_dcc_stats_emit(const uint32_t *__restrict__ touched, uint32_t n, const uint32_t *__restrict__ gsize, const unsigned long long *__restrict__ gweight,
+                                 dcc_stat *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = touched[i];
+    out[i].g = g; out[i].size = gsize[g]; out[i].weight = gweight[g];
 }
 extern "C" int mf_dcc_merge(mf_dcc *D, const void *d_pairs, uint64_t n, uint64_t *n_stats) {
     if (!D || !n_stats || (n && !d_pairs)) return mf_set_error("mf_dcc_merge: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
     MF_HIP(hipSetDevice(ctx->device));
-    if (D->n_total) k_dcc_iota<<<cgrid(D->n_total), 256, 0, st>>>(D->pg.p, D->gsize.p, D->gweight.p, D->n_total);
+    if (D->level == 0 || n * 48 > D->n_total) {                           // (random writes: only worth it when few ids occur)
+        if (D->n_total) { mf_ktimer tm_(ctx, "k_dcc_iota"); k_dcc_iota<<<cgrid(D->n_total), 256, 0, st>>>(D->pg.p, D->gsize.p, D->gweight.p, D->n_total); }
+    } else {
+        mf_ktimer tm_(ctx, "k_dcc_iota");
+        if (n) k_dcc_init_pairs<<<cgrid(n), 256, 0, st>>>((const uint2 *)d_pairs, n, D->pg.p, D->gsize.p, D->gweight.p);
+        if (D->n) k_dcc_init_roots<<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->n, D->base[D->rank], D->pg.p, D->gsize.p, D->gweight.p);
+    }
+    D->level++;
     if (n) { mf_ktimer tm(ctx, "k_dcc_hook_pairs"); k_dcc_hook_pairs<<<cgrid(n), 256, 0, st>>>((const uint2 *)d_pairs, n, D->pg.p); }
     MF_HIP(hipMemsetAsync(&D->ctr.p[1], 0, 4, st));
-    if (D->n) k_dcc_groots<<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->n, D->pg.p, D->base[D->rank], D->groot.p, D->csize.p, D->cweight.p, &D->ctr.p[1], nullptr);
+    if (D->n) {
+        mf_ktimer tm_(ctx, "k_dcc_groots");
+        k_dcc_groots<<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->n, D->pg.p, D->base[D->rank], D->groot.p, D->csize.p, D->cweight.p, D->gsize.p, D->gweight.p,
+                                                  &D->ctr.p[1], D->touched.p);
+    }
     unsigned int c = 0;
     MF_HIP(hipMemcpyAsync(&c, &D->ctr.p[1], 4, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
     D->nstat = c; *n_stats = c;
     return MF_OK;
 }
-// (e) this rank's fragments: (global root, size, weight), 16 bytes each
+// (e) this rank's share of the components it touches: (global root, size, weight), 16 bytes each
 extern "C" int mf_dcc_stats_fill(mf_dcc *D, void *d_out) {
     if (!D || (D->nstat && !d_out)) return mf_set_error("mf_dcc_stats_fill: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
     MF_HIP(hipSetDevice(ctx->device));
-    MF_HIP(hipMemsetAsync(&D->ctr.p[1], 0, 4, st));
-    if (D->n) k_dcc_groots<<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->n, D->pg.p, D->base[D->rank], D->groot.p, D->csize.p, D->cweight.p, &D->ctr.p[1], (dcc_stat *)d_out);
+    if (D->nstat) k_dcc_stats_emit<<<cgrid(D->nstat), 256, 0, st>>>(D->touched.p, (uint32_t)D->nstat, D->gsize.p, D->gweight.p, (dcc_stat *)d_out);
     MF_HIP(hipStreamSynchronize(st));
     return MF_OK;
 }
-// (f) all ranks' fragments -> per global root; classify; members of kept components and the next level's alive set.
-//     kept components whose root this rank owns are appended to d_kept (12 bytes: g, size, ... see dcc_kept_rec): *n_kept, *n_big
-__global__ void k_dcc_accumulate(const dcc_stat *__restrict__ s, uint64_t n, uint32_t *__restrict__ gsize, unsigned long long *__restrict__ gweight) {
+// (f) the other ranks' shares -> size / weight per global root complete; classify; members of kept components and the next
+//     level's alive set
+__global__ void k_dcc_accumulate(const dcc_stat *__restrict__ s, uint64_t n, uint64_t skip_lo, uint64_t skip_hi, uint32_t *__restrict__ gsize,
+                                 unsigned long long *__restrict__ gweight) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || (i >= skip_lo && i < skip_hi)) return;
     atomicAdd(&gsize[s[i].g], s[i].size);
     atomicAdd(&gweight[s[i].g], s[i].weight);
 }
-struct dcc_kept_rec { uint32_t g, size; unsigned long long weight; };
-__global__ void k_dcc_owned_classes(const uint32_t *__restrict__ gsize, const unsigned long long *__restrict__ gweight, uint32_t lo, uint32_t hi, uint32_t b1, uint32_t b2,
-                                    unsigned int *__restrict__ cnt /* [0] kept [1] big */, dcc_kept_rec *__restrict__ out) {
-    const uint32_t g = lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= hi) return;
-    const uint32_t s = gsize[g];
-    if (s == 0 || s < b1) return;
-    if (s <= b2) { const uint32_t at = atomicAdd(&cnt[0], 1u); if (out) { out[at].g = g; out[at].size = s; out[at].weight = gweight[g]; } }
-    else atomicAdd(&cnt[1], 1u);
-}
-template <bool DRY>
-__global__ void k_dcc_apply(uint8_t *__restrict__ alive, const uint32_t *__restrict__ root, const uint32_t *__restrict__ groot, const uint32_t *__restrict__ gsize,
-                            const uint16_t *__restrict__ vals, const uint64_t *__restrict__ keys, uint32_t n, uint32_t b1, uint32_t b2, uint32_t next_thr,
-                            unsigned int *__restrict__ cnt, uint64_t *__restrict__ mk, uint32_t *__restrict__ mg) {
+// gmin[g]: smallest member k-mer of the kept component with global root g among THIS rank's vertices (the ranks' minima
+// are combined at the end, mf_dcc_minkeys).  A component is reported (kept list, oversize count) by the rank that owns
+// its global root: the vertex that is that root does it.
+__global__ __launch_bounds__(256) void k_dcc_apply(uint8_t *__restrict__ alive, const uint32_t *__restrict__ root, const uint32_t *__restrict__ groot,
+                                                   const uint32_t *__restrict__ gsize, const unsigned long long *__restrict__ gweight, const uint16_t *__restrict__ vals,
+                                                   const uint64_t *__restrict__ keys, uint32_t n, uint32_t mybase, uint32_t b1, uint32_t b2, uint32_t next_thr,
+                                                   unsigned int *__restrict__ cnt /* [0] kept [1] big [2] members */, uint64_t *__restrict__ mk,
+                                                   uint32_t *__restrict__ mg, unsigned long long *__restrict__ gmin, dcc_kept_rec *__restrict__ kept) {
+    __shared__ uint32_t scratch[18];
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
-    bool put = false; uint32_t g = 0;
+    bool put = false; uint32_t g = 0; uint64_t key = 0;
     if (v < n && alive[v]) {
-        g = groot[root[v]];
+        const uint32_t r = root[v];
+        g = groot[r];
         const uint32_t s = gsize[g];
-        if (s > b2) { if (!DRY && (uint32_t)vals[v] < next_thr) alive[v] = 0; }
-        else { if (!DRY) alive[v] = 0; put = s >= b1; }
+        if (r == v && g == mybase + v && s >= b1) {                      // (rare: straight atomics)
+            if (s <= b2) { const uint32_t at = atomicAdd(&cnt[0], 1u); kept[at].g = g; kept[at].size = s; kept[at].weight = gweight[g]; }
+            else atomicAdd(&cnt[1], 1u);
+        }
+        if (s > b2) { if ((uint32_t)vals[v] < next_thr) alive[v] = 0; }
+        else { alive[v] = 0; put = s >= b1; }
     }
-    const unsigned long long b = __ballot(put);
-    if (!b) return;
-    uint32_t base = 0;
-    if (mf_lane() == (uint32_t)(__ffsll((long long)b) - 1)) base = atomicAdd(cnt, (uint32_t)__popcll(b));
-    base = (uint32_t)__builtin_amdgcn_readlane((int)base, __ffsll((long long)b) - 1);
-    if (!DRY && put) { const uint32_t at = base + (uint32_t)__popcll(b & ((1ull << mf_lane()) - 1ull)); mk[at] = keys[v]; mg[at] = g; }
+    const uint32_t at = mf_block_reserve(&cnt[2], put ? 1u : 0u, scratch);
+    if (put) { key = keys[v]; mk[at] = key; mg[at] = g; }
+    // smallest k-mer per component: neighbours in the table mostly share their component -> one atomic per distinct root and wave
+    unsigned long long todo = __ballot(put);
+    for (int round = 0; round < 4 && todo; round++) {                   // wave-uniform
+        const int lead = __ffsll((long long)todo) - 1;
+        const uint32_t g0 = (uint32_t)__builtin_amdgcn_readlane((int)g, lead);
+        const bool in = put && g == g0;
+        const unsigned long long grp = __ballot(in);
+        uint64_t m = in ? key : ~0ull;
+        for (int d = 32; d >= 1; d >>= 1) { const uint64_t o = __shfl_xor(m, d, 64); m = o < m ? o : m; }
+        if ((int)mf_lane() == lead) atomicMin(&gmin[g0], (unsigned long long)m);
+        if (in) put = false;
+        todo &= ~grp;
+    }
+    if (put) atomicMin(&gmin[g], (unsigned long long)key);
 }
 __global__ void k_dcc_cross_next(uint8_t *__restrict__ xalive, const uint32_t *__restrict__ xv, const uint16_t *__restrict__ xval, uint64_t nx,
                                  const uint8_t *__restrict__ alive_after, uint32_t next_thr) {
@@ -1002,40 +1117,32 @@ __global__ void k_dcc_cross_next(uint8_t *__restrict__ xalive, const uint32_t *_
     // if its value does: it is in the same component
     if (!alive_after[xv[e]] || (uint32_t)xval[e] < next_thr) xalive[e] = 0;
 }
-// all ranks' fragments (n records of mf_dcc_stats_fill) -> size / weight per global root; every vertex of this rank is
-// classified: members of kept components are remembered (k-mer, global root), vertices of oversize components whose value
-// reaches thr + 1 stay alive.  *n_kept / *n_big: the kept / oversize components whose global root this rank owns
-// (mf_dcc_kept_fill writes the kept ones).
-extern "C" int mf_dcc_classify(mf_dcc *D, const void *d_stats, uint64_t n, int b1, int b2, int thr, uint64_t *n_kept, uint64_t *n_big) {
+// all ranks' records (n of them, in rank order; [own_first, own_first + own_n) are this rank's own, already counted) -> size /
+// weight per global root; every vertex of this rank is classified: members of kept components are remembered (k-mer, global
+// root), vertices of oversize components whose value reaches thr + 1 stay alive.  *n_kept / *n_big: the kept / oversize
+// components whose global root this rank owns (mf_dcc_kept_fill writes the kept ones).
+extern "C" int mf_dcc_classify(mf_dcc *D, const void *d_stats, uint64_t n, uint64_t own_first, uint64_t own_n, int b1, int b2, int thr, uint64_t *n_kept,
+                               uint64_t *n_big) {
     if (!D || !n_kept || !n_big || (n && !d_stats)) return mf_set_error("mf_dcc_classify: NULL argument");
+    if (own_n != D->nstat || own_first + own_n > n) return mf_set_error("mf_dcc_classify: this rank's own records are %llu, not %llu", (unsigned long long)D->nstat, (unsigned long long)own_n);
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
     MF_HIP(hipSetDevice(ctx->device));
     if (b1 < 0) b1 = 0;
-    D->b1 = b1; D->b2 = b2;
-    if (n) k_dcc_accumulate<<<cgrid(n), 256, 0, st>>>((const dcc_stat *)d_stats, n, D->gsize.p, D->gweight.p);
-    MF_HIP(hipMemsetAsync(&D->ctr.p[2], 0, 16, st));
-    const uint32_t lo = D->base[D->rank], hi = D->base[D->rank + 1];
-    if (hi > lo) k_dcc_owned_classes<<<cgrid(hi - lo), 256, 0, st>>>(D->gsize.p, D->gweight.p, lo, hi, (uint32_t)b1, (uint32_t)b2, &D->ctr.p[2], nullptr);
-    if (D->n) k_dcc_apply<true><<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->groot.p, D->gsize.p, D->t->d_counts, D->t->d_keys, D->n, (uint32_t)b1, (uint32_t)b2,
-                                                             0u, &D->ctr.p[4], nullptr, nullptr);
-    unsigned int c[4];
-    MF_HIP(hipMemcpyAsync(c, &D->ctr.p[2], 16, hipMemcpyDeviceToHost, st));
-    MF_HIP(hipStreamSynchronize(st));
-    *n_kept = D->nkept_owned = c[0]; *n_big = c[1];
-    const uint32_t nm = c[2];
-    auto lv = std::make_unique<mf_dcc::level_buf>();
-    MF_TRY(lv->mk.alloc(ctx, nm ? nm : 1)); MF_TRY(lv->mg.alloc(ctx, nm ? nm : 1));
-    lv->n = nm;
-    MF_HIP(hipMemsetAsync(&D->ctr.p[4], 0, 4, st));
+    if (n > own_n) { mf_ktimer tm_(ctx, "k_dcc_accumulate"); k_dcc_accumulate<<<cgrid(n), 256, 0, st>>>((const dcc_stat *)d_stats, n, own_first, own_first + own_n, D->gsize.p, D->gweight.p); }
+    MF_HIP(hipMemsetAsync(&D->ctr.p[2], 0, 8, st));
+    if (D->keptbuf.n < D->nstat + 1) MF_TRY(D->keptbuf.alloc(ctx, D->nstat + (D->nstat >> 2) + 1024));       // (a component this rank reports is one it touches)
+    // (every vertex becomes a member at most once: one list of n entries, the cursor ctr[4] runs on from level to level)
     if (D->n) {
         mf_ktimer tm(ctx, "k_cc_members");
-        k_dcc_apply<false><<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->groot.p, D->gsize.p, D->t->d_counts, D->t->d_keys, D->n, (uint32_t)b1, (uint32_t)b2,
-                                                        (uint32_t)(thr + 1), &D->ctr.p[4], lv->mk.p, lv->mg.p);
+        k_dcc_apply<<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->groot.p, D->gsize.p, D->gweight.p, D->t->d_counts, D->t->d_keys, D->n, D->base[D->rank],
+                                                 (uint32_t)b1, (uint32_t)b2, (uint32_t)(thr + 1), &D->ctr.p[2], D->mk.p, D->mg.p, D->gmin.p, D->keptbuf.p);
     }
-    if (D->nx) k_dcc_cross_next<<<cgrid(D->nx), 256, 0, st>>>(D->xalive.p, D->xv.p, D->xval.p, D->nx, D->alive.p, (uint32_t)(thr + 1));
-    D->nm += nm;
-    D->levels.push_back(std::move(lv));
+    if (D->nx) { mf_ktimer tm_(ctx, "k_dcc_cross_next"); k_dcc_cross_next<<<cgrid(D->nx), 256, 0, st>>>(D->xalive.p, D->xv.p, D->xval.p, D->nx, D->alive.p, (uint32_t)(thr + 1)); }
+    unsigned int c[4];
+    MF_HIP(hipMemcpyAsync(c, &D->ctr.p[2], 12, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
+    *n_kept = D->nkept_owned = c[0]; *n_big = c[1];
+    D->nm = c[2];
     return MF_OK;
 }
 // the kept components of this level whose global root this rank owns: 16 bytes each (root u32, size u32, weight u64)
@@ -1043,10 +1150,7 @@ extern "C" int mf_dcc_kept_fill(mf_dcc *D, void *d_out) {
     if (!D || (D->nkept_owned && !d_out)) return mf_set_error("mf_dcc_kept_fill: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
     MF_HIP(hipSetDevice(ctx->device));
-    MF_HIP(hipMemsetAsync(&D->ctr.p[2], 0, 16, st));
-    const uint32_t lo = D->base[D->rank], hi = D->base[D->rank + 1];
-    if (hi > lo && D->nkept_owned)
-        k_dcc_owned_classes<<<cgrid(hi - lo), 256, 0, st>>>(D->gsize.p, D->gweight.p, lo, hi, (uint32_t)D->b1, (uint32_t)D->b2, &D->ctr.p[2], (dcc_kept_rec *)d_out);
+    if (D->nkept_owned) MF_HIP(hipMemcpyAsync(d_out, D->keptbuf.p, D->nkept_owned * sizeof(dcc_kept_rec), hipMemcpyDeviceToDevice, st));
     MF_HIP(hipStreamSynchronize(st));
     return MF_OK;
 }
@@ -1060,33 +1164,45 @@ extern "C" int mf_dcc_members_fill(mf_dcc *D, void *d_keys, void *d_roots) {
     if (!D || (D->nm && (!d_keys || !d_roots))) return mf_set_error("mf_dcc_members_fill: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
     MF_HIP(hipSetDevice(ctx->device));
-    uint64_t pos = 0;
-    for (auto &lv : D->levels) {
-        if (!lv->n) continue;
-        MF_HIP(hipMemcpyAsync((uint64_t *)d_keys + pos, lv->mk.p, lv->n * 8, hipMemcpyDeviceToDevice, st));
-        MF_HIP(hipMemcpyAsync((uint32_t *)d_roots + pos, lv->mg.p, lv->n * 4, hipMemcpyDeviceToDevice, st));
-        pos += lv->n;
+    if (D->nm) {
+        MF_HIP(hipMemcpyAsync(d_keys, D->mk.p, D->nm * 8, hipMemcpyDeviceToDevice, st));
+        MF_HIP(hipMemcpyAsync(d_roots, D->mg.p, D->nm * 4, hipMemcpyDeviceToDevice, st));
     }
     MF_HIP(hipStreamSynchronize(st));
     return MF_OK;
 }
+// smallest member k-mer of each kept component among THIS rank's vertices (DCC_NOKEY: none here) -> d_out u64[n_kept];
+// the caller takes the minimum over the ranks
+__global__ void k_dcc_minkeys(const uint32_t *__restrict__ g, uint64_t n, const unsigned long long *__restrict__ gmin, unsigned long long *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = gmin[g[i]];
+}
+extern "C" int mf_dcc_minkeys(mf_dcc *D, const uint32_t *kept_root, uint64_t n_kept, void *d_out) {
+    if (!D || (n_kept && (!kept_root || !d_out))) return mf_set_error("mf_dcc_minkeys: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    for (uint64_t i = 0; i < n_kept; i++) if (kept_root[i] >= D->n_total) return mf_set_error("mf_dcc_minkeys: component root out of range");
+    if (n_kept) {
+        mf_buf<uint32_t> d_g; MF_TRY(d_g.alloc(ctx, n_kept));
+        MF_HIP(hipMemcpyAsync(d_g.p, kept_root, n_kept * 4, hipMemcpyHostToDevice, st));
+        { mf_ktimer tm_(ctx, "k_dcc_minkeys"); k_dcc_minkeys<<<cgrid(n_kept), 256, 0, st>>>(d_g.p, n_kept, D->gmin.p, (unsigned long long *)d_out); }
+        MF_HIP(hipStreamSynchronize(st));
+    }
+    return MF_OK;
+}
 // all ranks' members + all levels' kept components (host arrays, the same on every rank) -> the components object every
 // rank holds (order: ConnectedComponent.compareTo, src/structures/ConnectedComponent.java:125-136, ties by the smallest k-mer)
-__global__ void k_dcc_slot_map(const uint32_t *__restrict__ g, uint32_t n, uint32_t *__restrict__ map, unsigned long long *__restrict__ minkey) {
+__global__ void k_dcc_slot_map(const uint32_t *__restrict__ g, uint32_t n, uint32_t *__restrict__ map) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { map[g[i]] = i; minkey[i] = ~0ull; }
+    if (i < n) map[g[i]] = i;
 }
-__global__ void k_dcc_member_slots(const uint64_t *__restrict__ keys, const uint32_t *__restrict__ mg, uint64_t n, const uint32_t *__restrict__ map,
-                                   uint32_t *__restrict__ comp, unsigned long long *__restrict__ minkey) {
+__global__ void k_dcc_member_slots(const uint32_t *__restrict__ mg, uint64_t n, const uint32_t *__restrict__ map, uint32_t *__restrict__ comp) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t s = map[mg[i]];
-    comp[i] = s;
-    atomicMin(&minkey[s], (unsigned long long)keys[i]);
+    if (i < n) comp[i] = map[mg[i]];
 }
 extern "C" int mf_dcc_finish(mf_dcc *D, const void *d_keys, const void *d_roots, uint64_t nm, const uint32_t *kept_root, const uint32_t *kept_size,
-                             const int64_t *kept_weight, const int32_t *kept_thr, uint64_t n_kept, mf_comps **out) {
-    if (!D || !out || (nm && (!d_keys || !d_roots)) || (n_kept && (!kept_root || !kept_size || !kept_weight || !kept_thr)))
+                             const int64_t *kept_weight, const int32_t *kept_thr, const uint64_t *minkey, uint64_t n_kept, mf_comps **out) {
+    if (!D || !out || (nm && (!d_keys || !d_roots)) || (n_kept && (!kept_root || !kept_size || !kept_weight || !kept_thr || !minkey)))
         return mf_set_error("mf_dcc_finish: NULL argument");
     *out = nullptr;
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
@@ -1095,23 +1211,20 @@ extern "C" int mf_dcc_finish(mf_dcc *D, const void *d_keys, const void *d_roots,
     uint64_t sum = 0;
     for (uint64_t i = 0; i < n_kept; i++) { sum += kept_size[i]; if (kept_root[i] >= D->n_total) return mf_set_error("mf_dcc_finish: component root out of range"); }
     if (sum != nm) return mf_set_error("mf_dcc_finish: %llu members for components of %llu k-mers", (unsigned long long)nm, (unsigned long long)sum);
-    std::vector<unsigned long long> minkey(n_kept);
     std::unique_ptr<mf_comps, void (*)(mf_comps *)> C(new mf_comps(), mf_comps_destroy);
     C->ctx = ctx; C->k = D->k; C->n = n_kept; C->n_kmers = nm;
     void *p = nullptr;
     MF_TRY(mf_alloc(ctx, (nm ? nm : 1) * 8, &p)); C->d_kmers = (uint64_t *)p; C->kmers_bytes = (nm ? nm : 1) * 8;
     MF_TRY(mf_alloc(ctx, (nm ? nm : 1) * 4, &p)); C->d_comp = (uint32_t *)p; C->comp_bytes = (nm ? nm : 1) * 4;
-    mf_buf<uint32_t> d_g, d_rank; mf_buf<unsigned long long> d_min;
-    MF_TRY(d_g.alloc(ctx, n_kept ? n_kept : 1)); MF_TRY(d_rank.alloc(ctx, n_kept ? n_kept : 1)); MF_TRY(d_min.alloc(ctx, n_kept ? n_kept : 1));
+    mf_buf<uint32_t> d_g, d_rank;
+    MF_TRY(d_g.alloc(ctx, n_kept ? n_kept : 1)); MF_TRY(d_rank.alloc(ctx, n_kept ? n_kept : 1));
     if (n_kept) {
         MF_HIP(hipMemcpyAsync(d_g.p, kept_root, n_kept * 4, hipMemcpyHostToDevice, st));
-        k_dcc_slot_map<<<cgrid(n_kept), 256, 0, st>>>(d_g.p, (uint32_t)n_kept, D->pg.p, d_min.p);
+        { mf_ktimer tm_(ctx, "k_dcc_slot_map"); k_dcc_slot_map<<<cgrid(n_kept), 256, 0, st>>>(d_g.p, (uint32_t)n_kept, D->pg.p); }
         if (nm) {
             MF_HIP(hipMemcpyAsync(C->d_kmers, d_keys, nm * 8, hipMemcpyDeviceToDevice, st));
-            k_dcc_member_slots<<<cgrid(nm), 256, 0, st>>>((const uint64_t *)d_keys, (const uint32_t *)d_roots, nm, D->pg.p, C->d_comp, d_min.p);
+            { mf_ktimer tm_(ctx, "k_dcc_member_slots"); k_dcc_member_slots<<<cgrid(nm), 256, 0, st>>>((const uint32_t *)d_roots, nm, D->pg.p, C->d_comp); }
         }
-        MF_HIP(hipMemcpyAsync(minkey.data(), d_min.p, n_kept * 8, hipMemcpyDeviceToHost, st));
-        MF_HIP(hipStreamSynchronize(st));
     }
     std::vector<uint32_t> order(n_kept);
     for (uint64_t i = 0; i < n_kept; i++) order[i] = (uint32_t)i;

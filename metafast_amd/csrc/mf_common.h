@@ -68,6 +68,7 @@ struct mf_ctx {
     int64_t opt_skm_slices = 0;    // digit-range slices of a counting run (0 = as many as the HBM budget asks for)
     int64_t opt_arena_cap_gb = 0;  // pretend the device has this much memory when the slices are chosen (0 = what it has)
     int64_t opt_skm_batches = 0;   // partitions are counted + gathered in this many batches (0 = auto); tests force small values
+    int own_rank = 0, own_world = 1;   // mf_count_device_shard: only the k-mers this rank owns (level-1 digits [nd1 * rank / world, nd1 * (rank + 1) / world)) are counted
     int64_t opt_nbr_global = 0;    // 1: neighbour lookups of the graph kernels through the HBM index only (A/B of mf_nbr.h)
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero
     // workspace arena: a few large hipMalloc'd regions, sub-allocated with first-fit + coalescing free lists.
@@ -274,6 +275,16 @@ __device__ __forceinline__ uint32_t mf_block_excl_scan(uint32_t v, uint32_t *scr
     uint32_t r = ex + scratch[wave];
     *block_total = scratch[16];
     return r;
+}
+
+// Reserve `mine` consecutive indices from a global cursor with ONE atomic per WORKGROUP (every thread of the block calls it;
+// scratch: 18 uint32 in LDS).  A cursor that every wave of a large grid hits costs ~12 ns per atomic, serialised.
+__device__ __forceinline__ uint32_t mf_block_reserve(unsigned int *counter, uint32_t mine, uint32_t *scratch) {
+    uint32_t tot;
+    const uint32_t ex = mf_block_excl_scan(mine, scratch, &tot);
+    if (threadIdx.x == 0) scratch[17] = tot ? atomicAdd(counter, tot) : 0u;
+    __syncthreads();
+    return scratch[17] + ex;
 }
 
 // ---- HBM open-addressed index lookup (16-byte slots) ----

@@ -628,6 +628,11 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     uint64_t target = (uint64_t)ctx->opt_part_target;
     if (n_bases / n_reads >= (uint64_t)(8 * k) && target > (uint64_t)ctx->opt_part_target_long) target = (uint64_t)ctx->opt_part_target_long;
     int B = ceil_log2_u64((n_occ + target - 1) / target);
+    if (ctx->own_world > 1) {                       // (a shard: every rank must own at least one level-1 digit)
+        int lw = 0; while ((1 << lw) < ctx->own_world) lw++;
+        if (B < lw) B = lw;
+        if (!ctx->opt_skm || k < MF_SKM_MIN_K) return mf_set_error("mf_count_device_shard: k >= %d needed (minimizer partitions decide the owner)", MF_SKM_MIN_K);
+    }
     std::vector<int> lv;
     if (ctx->opt_l1_bits >= 0) {
         lv.push_back((int)ctx->opt_l1_bits);
@@ -653,6 +658,7 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, slv, scal.p, thr, n_all, out);
         if (rc != MF_SKM_FALLBACK) return rc;
     }
+    if (ctx->own_world > 1) return mf_set_error("mf_count_device_shard: the input does not suit the minimizer-partition path");
 
     // ---- K1 ----
     const int bits1 = lv[0], nd1 = 1 << bits1;
@@ -836,6 +842,19 @@ extern "C" int mf_count_device(mf_ctx *ctx, const void *d_bases, const void *d_o
     if (!ctx || !out) return mf_set_error("mf_count_device: NULL argument");
     *out = nullptr;
     return mf_count_core(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, min_read_len, out, -1, nullptr);
+}
+// rank's shard of the table of ALL the given sequences: the k-mers whose minimizer-partition hash starts with `rank` (its top
+// log2(world) bits).  The table has the partitions of the whole table; the other ranks' partitions are empty.
+extern "C" int mf_count_device_shard(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t n_bases, int k,
+                                     int min_read_len, int rank, int world, mf_table **out) {
+    if (!ctx || !out) return mf_set_error("mf_count_device_shard: NULL argument");
+    *out = nullptr;
+    if (world < 1 || world > 64 || (world & (world - 1)) || rank < 0 || rank >= world)
+        return mf_set_error("mf_count_device_shard: the world size must be a power of two <= 64 and 0 <= rank < world");
+    ctx->own_rank = rank; ctx->own_world = world;
+    const int rc = mf_count_core(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, min_read_len, out, -1, nullptr);
+    ctx->own_rank = 0; ctx->own_world = 1;
+    return rc;
 }
 extern "C" int mf_count_device_above(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads,
                                      uint64_t n_bases, int k, int min_read_len, int threshold, mf_table **out,

@@ -37,18 +37,21 @@ __device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, int k, uint64_t kma
     const uint64_t r = mf_revcomp(y, k);
     return y < r ? y : r;
 }
-// Calls emit(j, x, idx[8], canonical != oriented [8 bits]) for every k-mer j of the table; idx[i] = table index of
+// Calls emit(j, x, idx[8], canonical != oriented [8 bits], foreign [8 bits], have) for every k-mer j of the table (lanes past
+// the end of a partition call it with have = false); idx[i] = table index of
 // neighbour i or NB_NONE.  One wave per partition, partitions dealt round-robin to the waves of the grid.
+// With lw > 0 the table is rank `me`'s SHARD of a larger one (mf_count_device_shard; owner of a k-mer = top lw bits of its
+// partition hash): neighbours that other ranks own are not looked up, emit gets their numbers in `foreign` (8 bits).
 template <typename F>
 __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
-                                            uint32_t np, int k, nb_lds &S, int abl, F &&emit) {
+                                            uint32_t p_lo, uint32_t np, int k, nb_lds &S, int abl, int lw, uint32_t me, F &&emit) {
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t gw = blockIdx.x * NB_WAVES + wave, nw = gridDim.x * NB_WAVES;
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     uint64_t *hk = S.key[wave]; uint16_t *hp = S.pos[wave];
     uint64_t *rk = S.rq_key[wave]; uint32_t *rp = S.rq_ph[wave], *ri = S.rq_idx[wave];
     const int shift = 32 - (int)ix.part_bits;
-    for (uint32_t p = gw; p < np; p += nw) {
+    for (uint32_t p = p_lo + gw; p < np; p += nw) {
         const uint64_t lo = part_off[p], hi = part_off[p + 1];
         const uint32_t n = (uint32_t)(hi - lo);
         if (n == 0) continue;                                               // wave-uniform
@@ -78,12 +81,13 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             // eight such round trips per 64 k-mers with six lanes in 64 busy (ablation, 100 M reads: 25 of the kernel's 39
             // ms).  So the wave collects them in LDS, looks them up 64 at a time, one request per lane, and hands the
             // answers back through LDS.
-            uint32_t remote = 0;
+            uint32_t remote = 0, foreign = 0;
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) {
                 uint64_t y; uint32_t ph;
                 nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &ph);
-                if (have && !(local && (ph >> shift) == p)) remote |= 1u << i;
+                if (have && lw && (ph >> (32 - lw)) != me) foreign |= 1u << i;
+                else if (have && !(local && (ph >> shift) == p)) remote |= 1u << i;
             }
             uint32_t R;
             const uint32_t rbase = mf_wave_excl_scan((uint32_t)__popc(remote), &R);
@@ -94,7 +98,7 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                 const uint64_t c = nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &ph);
                 flip |= (c != y) ? (1u << i) : 0u;
                 idx[i] = NB_NONE;
-                if (have) {
+                if (have && !((foreign >> i) & 1u)) {
                     if (!((remote >> i) & 1u)) {
                         if (!(abl & 2)) {
                         uint32_t s = nb_slot(c);
@@ -129,7 +133,7 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            if (have) emit(lo + j, x, idx, flip);
+            emit(lo + j, x, idx, flip, foreign, have);                       // (every lane: the callee may use wave-wide operations)
         }
         __builtin_amdgcn_wave_barrier();
     }

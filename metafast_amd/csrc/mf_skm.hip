@@ -1309,6 +1309,11 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         }
         while (S > 1 && (uint32_t)nd1 / S < 4) S /= 2;
     }
+    // a shard of the table only (mf_count_device_shard): the owner's digits, sliced like a whole run
+    const uint32_t W = (uint32_t)std::max(ctx->own_world, 1);
+    if (W > 1 && (uint32_t)nd1 < W) return mf_set_error("count (shard): %d level-1 digits for %u ranks", nd1, W);
+    const uint32_t own_lo = (uint32_t)((uint64_t)nd1 * (uint32_t)ctx->own_rank / W), own_hi = (uint32_t)((uint64_t)nd1 * ((uint32_t)ctx->own_rank + 1) / W);
+    while (S > 1 && (own_hi - own_lo) / S < 1) S /= 2;
     for (;; S *= 2) {
         skm_acc A;
         A.np_total = (uint32_t)(1ull << total_bits);
@@ -1318,9 +1323,20 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         MF_HIP(hipMemsetAsync(&scal[7], 0, 8, st));
         int rc = MF_OK;
         for (uint32_t sl = 0; sl < S && rc == MF_OK; sl++)
-            rc = skm_slice<K>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, kthr, (uint32_t)((uint64_t)nd1 * sl / S), (uint32_t)((uint64_t)nd1 * (sl + 1) / S), sl, S, A);
+            rc = skm_slice<K>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, kthr, own_lo + (uint32_t)((uint64_t)(own_hi - own_lo) * sl / S),
+                              own_lo + (uint32_t)((uint64_t)(own_hi - own_lo) * (sl + 1) / S), sl, S, A);
+        if (rc == MF_OK && W > 1) {
+            // the other ranks' partitions are empty here: offsets 0 before the owner's range, the table's size after it
+            const uint32_t pb0 = (uint32_t)(((uint64_t)own_lo * A.np_total) >> bits1), pb1 = (uint32_t)(((uint64_t)own_hi * A.np_total) >> bits1);
+            if (pb0) MF_HIP(hipMemsetAsync(A.doff.p, 0, (size_t)pb0 * 8, st));
+            if (A.np_total > pb1) {
+                MF_HIP(hipMemsetAsync(A.doff.p + pb1 + 1, 0, (size_t)(A.np_total - pb1) * 8, st));
+                k_skm_add_base<<<(A.np_total - pb1 + 255) / 256, 256, 0, st>>>(A.doff.p + pb1 + 1, (uint64_t)(A.np_total - pb1), A.dused);
+            }
+            if (!A.dused) MF_HIP(hipMemsetAsync(A.doff.p, 0, ((size_t)A.np_total + 1) * 8, st));
+        }
         if (rc == MF_SKM_NOMEM) {
-            if (lv.size() >= 2 && S < 64 && (uint32_t)nd1 / (2 * S) >= 4) {
+            if (lv.size() >= 2 && S < 64 && (own_hi - own_lo) / (2 * S) >= 1 && (W > 1 || (uint32_t)nd1 / (2 * S) >= 4)) {
                 if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: %u slice(s) do not fit, trying %u\n", S, 2 * S);
                 continue;
             }

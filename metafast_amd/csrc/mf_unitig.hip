@@ -82,7 +82,8 @@ __global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
 __global__ __launch_bounds__(64 * NB_WAVES) void k_ut_flags_part(mf_index_view ix, ut_arrays A, const uint64_t *__restrict__ part_off, uint32_t np, int abl) {
     __shared__ nb_lds S;
     const int k = A.k;
-    nb_for_each(ix, A.gk, part_off, np, k, S, abl, [&](uint64_t i, uint64_t x, const uint32_t (&idx)[8], uint32_t flip) {
+    nb_for_each(ix, A.gk, part_off, 0u, np, k, S, abl, 0, 0u, [&](uint64_t i, uint64_t x, const uint32_t (&idx)[8], uint32_t flip, uint32_t, bool have) {
+        if (!have) return;
         uint32_t rcode = UT_CODE_NONE, lcode = UT_CODE_NONE, ridx = UT_NONE, lidx = UT_NONE, ror = 0, lor = 0;
 #pragma unroll
         for (uint32_t nuc = 0; nuc < 4; nuc++) {

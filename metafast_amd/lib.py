@@ -47,8 +47,7 @@ _SIGS = {
     "mf_table_load_kmers": (i32, [vp, C.POINTER(cp), i32, i32, i32, pvp]),
     "mf_table_filter": (i32, [vp, i32, pvp]),
     "mf_table_from_host": (i32, [vp, vp, vp, u64, i32, pvp]),
-    "mf_table_split_by_owner": (i32, [vp, i32, vp, vp, pu64]),
-    "mf_table_from_pairs_device": (i32, [vp, vp, vp, u64, i32, pvp]),
+    "mf_count_device_shard": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, i32, pvp]),
     "mf_dcc_create": (i32, [vp, vp, i32, i32, vp, pvp]),
     "mf_dcc_destroy": (None, [vp]),
     "mf_dcc_queries": (i32, [vp, vp]),
@@ -60,11 +59,12 @@ _SIGS = {
     "mf_dcc_pairs_complete": (i32, [vp, vp, u64]),
     "mf_dcc_merge": (i32, [vp, vp, u64, pu64]),
     "mf_dcc_stats_fill": (i32, [vp, vp]),
-    "mf_dcc_classify": (i32, [vp, vp, u64, i32, i32, i32, pu64, pu64]),
+    "mf_dcc_classify": (i32, [vp, vp, u64, u64, u64, i32, i32, i32, pu64, pu64]),
     "mf_dcc_kept_fill": (i32, [vp, vp]),
     "mf_dcc_members": (i32, [vp, pu64]),
     "mf_dcc_members_fill": (i32, [vp, vp, vp]),
-    "mf_dcc_finish": (i32, [vp, vp, vp, u64, vp, vp, vp, vp, u64, pvp]),
+    "mf_dcc_minkeys": (i32, [vp, vp, u64, vp]),
+    "mf_dcc_finish": (i32, [vp, vp, vp, u64, vp, vp, vp, vp, vp, u64, pvp]),
     "mf_build_unitigs_device": (i32, [vp, vp, i32, i32, pvp]),
     "mf_seqs_destroy": (None, [vp]),
     "mf_seqs_stats": (i32, [vp, pu64, pu64]),
@@ -215,10 +215,10 @@ class Context:
         _check(lib().mf_table_from_host(self.h, keys.ctypes.data, counts.ctypes.data, len(keys), k, C.byref(t)))
         return Table(self, t)
 
-    def table_from_pairs_device(self, d_keys, d_counts, n, k):
-        """(k-mer, count) pairs in HBM -> table; repeated k-mers get the saturating sum of their counts"""
+    def count_device_shard(self, d_bases, d_offsets, n_seqs, n_bases, k, min_len, rank, world):
+        """this rank's shard (k-mers whose minimizer-partition hash starts with `rank`) of the table of all the sequences"""
         t = C.c_void_p()
-        _check(lib().mf_table_from_pairs_device(self.h, d_keys, d_counts, n, k, C.byref(t)))
+        _check(lib().mf_count_device_shard(self.h, d_bases, d_offsets, n_seqs, n_bases, k, min_len, rank, world, C.byref(t)))
         return Table(self, t)
 
     # ---- A7 ----
@@ -329,13 +329,6 @@ class Table:
         k, c, n = C.c_void_p(), C.c_void_p(), C.c_uint64()
         _check(lib().mf_table_device_view(self.h, C.byref(k), C.byref(c), C.byref(n)))
         return k.value, c.value, n.value
-
-    def split_by_owner(self, world, d_keys, d_counts):
-        """entries regrouped by owner rank (top log2(world) bits of the minimizer-partition hash) into the two device
-        buffers (room for len(self) entries); -> offsets[world + 1]"""
-        off = np.zeros(world + 1, dtype=np.uint64)
-        _check(lib().mf_table_split_by_owner(self.h, world, d_keys, d_counts, off.ctypes.data_as(pu64)))
-        return off
 
     def lookup(self, keys):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
@@ -503,9 +496,9 @@ class DistCutter:
     def stats_fill(self, d_out):
         _check(lib().mf_dcc_stats_fill(self.h, d_out))
 
-    def classify(self, d_stats, n, b1, b2, thr):
+    def classify(self, d_stats, n, own_first, own_n, b1, b2, thr):
         a, b = C.c_uint64(), C.c_uint64()
-        _check(lib().mf_dcc_classify(self.h, d_stats, n, b1, b2, thr, C.byref(a), C.byref(b)))
+        _check(lib().mf_dcc_classify(self.h, d_stats, n, own_first, own_n, b1, b2, thr, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def kept_fill(self, d_out):
@@ -519,12 +512,17 @@ class DistCutter:
     def members_fill(self, d_keys, d_roots):
         _check(lib().mf_dcc_members_fill(self.h, d_keys, d_roots))
 
-    def finish(self, d_keys, d_roots, nm, roots, sizes, weights, thrs):
+    def minkeys(self, roots, d_out):
+        roots = np.ascontiguousarray(roots, dtype=np.uint32)
+        _check(lib().mf_dcc_minkeys(self.h, roots.ctypes.data, len(roots), d_out))
+
+    def finish(self, d_keys, d_roots, nm, roots, sizes, weights, thrs, minkeys):
         roots = np.ascontiguousarray(roots, dtype=np.uint32); sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
         weights = np.ascontiguousarray(weights, dtype=np.int64); thrs = np.ascontiguousarray(thrs, dtype=np.int32)
+        minkeys = np.ascontiguousarray(minkeys, dtype=np.uint64)
         c = C.c_void_p()
         _check(lib().mf_dcc_finish(self.h, d_keys, d_roots, nm, roots.ctypes.data, sizes.ctypes.data, weights.ctypes.data,
-                                   thrs.ctypes.data, len(roots), C.byref(c)))
+                                   thrs.ctypes.data, minkeys.ctypes.data, len(roots), C.byref(c)))
         return Comps(self.ctx, c)
 
 

@@ -4,9 +4,9 @@ Host-side mirror of the step wiring in DistanceMatrixBuilderMain (src/tools/Dist
 kmer-counter -> seq-builder -> component-cutter -> features-calculator -> dist-matrix-calculator, with the
 files between the steps replaced by buffers that stay in HBM.  Steps 1, 2 and 4 are independent per sample
 (KmersCounterForManyFilesMain.java:80-108, SeqBuilderForManyFilesMain.java:82-94, FeaturesCalculatorMain.java:137-162);
-step 3 joins all samples (ComponentCutterMain.java:81): every rank counts the k-mers of its own unitigs, the ranks exchange the entries by
-owner (all-to-all over RCCL / xGMI) so that each holds a shard of the cutter table, and the components are found with
-every rank working on its shard (distributed_components); the per-sample feature vectors are all-gathered for the
+step 3 joins all samples (ComponentCutterMain.java:81): the ranks exchange their unitigs once (all-gather over RCCL / xGMI), every rank counts
+the k-mers it OWNS (a shard of the cutter table, Context.count_device_shard), and the components are found with every
+rank working on its shard (distributed_components); the per-sample feature vectors are all-gathered for the
 Bray-Curtis matrix.  torch is used for device memory and torch.distributed only.
 """
 import os
@@ -157,6 +157,15 @@ class TorchComm:
             w.wait()
         return buf
 
+    def all_reduce_min(self, t):
+        if self.world == 1 and not _force():
+            return t
+        if t.is_cuda and dist.get_backend() == "gloo":
+            return self.all_reduce_min(t.cpu()).to(t.device)
+        if t.numel():
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t
+
     def all_to_all(self, t, matrix):
         """t: this rank's payload grouped by destination, matrix[src][dst] = elements (known to all) -> what the others sent here,
         grouped by source"""
@@ -191,6 +200,7 @@ class ThreadGroup:
 class ThreadComm:
     def __init__(self, group, rank):
         self.g, self.rank, self.world = group, rank, group.world
+        self.waited = 0.0            # seconds spent waiting for the other ranks (not this rank's work)
         if group.turn:
             group.turn.acquire()
 
@@ -203,6 +213,7 @@ class ThreadComm:
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         g.slots[self.rank] = x
+        tw = time.perf_counter()
         if g.turn:
             g.turn.release()
         try:
@@ -212,62 +223,66 @@ class ThreadComm:
         finally:
             if g.turn:
                 g.turn.acquire()
+        self.waited += time.perf_counter() - tw
+        return out
+
+    def _timed(self, fn):
+        """self.exchange: seconds this rank spent inside the exchanges (their copies; waiting for the others excluded)"""
+        t0, w0 = time.perf_counter(), self.waited
+        out = fn()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        self.exchange = getattr(self, "exchange", 0.0) + (time.perf_counter() - t0) - (self.waited - w0)
         return out
 
     def all_gather_ints(self, vals):
-        return np.asarray(self._exchange([int(v) for v in vals]), dtype=np.int64).reshape(self.world, -1)
+        return self._timed(lambda: np.asarray(self._exchange([int(v) for v in vals]), dtype=np.int64).reshape(self.world, -1))
 
     def all_gather(self, t, sizes):
-        return torch.cat(self._exchange(t))
+        return self._timed(lambda: torch.cat(self._exchange(t)))
+
+    def all_reduce_min(self, t):
+        return self._timed(lambda: torch.stack(self._exchange(t)).min(dim=0).values)
 
     def all_to_all(self, t, matrix):
-        parts = self._exchange(t)
-        out = []
-        for r in range(self.world):
-            o = int(sum(matrix[r][:self.rank]))
-            out.append(parts[r][o:o + int(matrix[r][self.rank])])
-        return torch.cat(out)
+        def f():
+            parts = self._exchange(t)
+            out = []
+            for r in range(self.world):
+                o = int(sum(matrix[r][:self.rank]))
+                out.append(parts[r][o:o + int(matrix[r][self.rank])])
+            return torch.cat(out)
+        return self._timed(f)
 
 
 def _i64(n, device):
     return torch.empty(max(int(n), 1), dtype=torch.int64, device=device)
 
 
-def distributed_components(ctx, comm, local_cutter, k, b1, b2, device="cuda", timings=None, info=None):
-    """Component cutter over the union of all ranks' cutter tables with every rank owning a shard (include/metafast_hip.h,
-    "A9-A11 on several GPUs").  local_cutter: the table of THIS rank's unitig k-mers.  Returns (shard table, components);
-    the components are the same object on every rank, identical to cut_components on the merged table
-    (ComponentsBuilder.splitStrategy, src/algo/ComponentsBuilder.java:24-32)."""
+def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=None, info=None):
+    """Component cutter with every rank owning a shard of the cutter table (include/metafast_hip.h, "A9-A11 on several
+    GPUs").  shard: this rank's Context.count_device_shard of all samples' unitigs.  Returns the components: the same
+    object on every rank, identical to cut_components on the whole table (ComponentsBuilder.splitStrategy,
+    src/algo/ComponentsBuilder.java:24-32)."""
     W, me = comm.world, comm.rank
-    t0 = time.perf_counter()
+    t0, w0 = time.perf_counter(), getattr(comm, "waited", 0.0)
 
     def mark(name):
-        nonlocal t0
+        nonlocal t0, w0
         if timings is not None:
             torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            timings[name] = timings.get(name, 0.0) + (t1 - t0)
-            t0 = t1
+            t1, w1 = time.perf_counter(), getattr(comm, "waited", 0.0)
+            timings[name] = timings.get(name, 0.0) + (t1 - t0) - (w1 - w0)      # (virtual ranks: the others' turns are not this rank's time)
+            t0, w0 = t1, w1
 
     def sync():
         torch.cuda.current_stream().synchronize()
 
-    # ---- the shard of the cutter table
-    _, _, n = local_cutter.device_view()
-    sk = _i64(n, device); sc = torch.empty(max(2 * n, 2), dtype=torch.uint8, device=device)     # (counts: u16 as bytes, RCCL has no 16-bit integer type)
-    sync()
-    off = local_cutter.split_by_owner(W, sk.data_ptr(), sc.data_ptr())
-    m = comm.all_gather_ints(np.diff(off.astype(np.int64)))
-    rk = comm.all_to_all(sk[:n], m); rc = comm.all_to_all(sc[:2 * n], 2 * m)
-    sync()
-    shard = ctx.table_from_pairs_device(rk.data_ptr(), rc.data_ptr(), int(rk.numel()), k)
-    del sk, sc, rk, rc
     ns = comm.all_gather_ints([len(shard)])[:, 0]
     base = np.concatenate([[0], np.cumsum(ns)])
     if int(base[-1]) >= 0xFFFFFFFF:
         raise L.MetafastError("components: more than 2^32 vertices over all ranks is not supported")
     D = L.DistCutter(ctx, shard, me, W, base)
-    mark("cutter_shard")
     # ---- neighbours in other shards
     qm = comm.all_gather_ints(D.queries())
     nq = int(qm[me].sum())
@@ -282,7 +297,7 @@ def distributed_components(ctx, comm, local_cutter, k, b1, b2, device="cuda", ti
     del q, rq, a, ra
     mark("cutter_adjacency")
     # ---- threshold levels
-    kept, levels = [], 0
+    kept, levels, per_level = [], 0, []
     for thr in range(1, 1 << 16):
         pm = comm.all_gather_ints(D.level_local())
         nsend = int(pm[me].sum())
@@ -299,7 +314,7 @@ def distributed_components(ctx, comm, local_cutter, k, b1, b2, device="cuda", ti
         D.stats_fill(st.data_ptr())
         sm = comm.all_gather_ints([n_stats])[:, 0]
         alls = comm.all_gather(st[:2 * n_stats], 2 * sm); sync()
-        n_kept, n_big = D.classify(alls.data_ptr(), int(alls.numel()) // 2, b1, b2, thr)
+        n_kept, n_big = D.classify(alls.data_ptr(), int(alls.numel()) // 2, int(sm[:me].sum()), n_stats, b1, b2, thr)
         kb = _i64(2 * n_kept, device); sync()
         D.kept_fill(kb.data_ptr())
         km = comm.all_gather_ints([n_kept, n_big])
@@ -308,6 +323,7 @@ def distributed_components(ctx, comm, local_cutter, k, b1, b2, device="cuda", ti
             r = allk.reshape(-1, 2)
             kept.append((r[:, 0] & 0xFFFFFFFF, (r[:, 0] >> 32) & 0xFFFFFFFF, r[:, 1], np.full(len(r), thr, dtype=np.int32)))
         levels = thr
+        per_level.append((int(allp.numel()), int(sm.sum()), int(km[:, 0].sum()), int(km[:, 1].sum())))
         if int(km[:, 1].sum()) == 0:
             break
     mark("cutter_levels")
@@ -318,12 +334,16 @@ def distributed_components(ctx, comm, local_cutter, k, b1, b2, device="cuda", ti
     mm = comm.all_gather_ints([nm])[:, 0]
     allmk = comm.all_gather(mk[:nm], mm); allmg = comm.all_gather(mg[:nm], mm); sync()
     cat = (lambda i, dt: np.concatenate([x[i] for x in kept]).astype(dt)) if kept else (lambda i, dt: np.zeros(0, dtype=dt))
-    comps = D.finish(allmk.data_ptr(), allmg.data_ptr(), int(allmk.numel()), cat(0, np.uint32), cat(1, np.uint32), cat(2, np.int64), cat(3, np.int32))
+    roots = cat(0, np.uint32)
+    mn = _i64(len(roots), device); sync()
+    D.minkeys(roots, mn.data_ptr())
+    mn = comm.all_reduce_min(mn[:len(roots)]).cpu().numpy().astype(np.uint64)
+    comps = D.finish(allmk.data_ptr(), allmg.data_ptr(), int(allmk.numel()), roots, cat(1, np.uint32), cat(2, np.int64), cat(3, np.int32), mn)
     if info is not None:
-        info.update(levels=levels, shard=int(ns[me]), vertices=int(base[-1]), queries=nq, members=int(allmk.numel()))
+        info.update(levels=levels, per_level=per_level, shard=int(ns[me]), vertices=int(base[-1]), queries=nq, members=int(allmk.numel()))
     D.close()
     mark("cutter_members")
-    return shard, comps
+    return comps
 
 
 def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda", timings=None):
@@ -366,20 +386,18 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
         sb = torch.cat(parts_b) if parts_b else torch.zeros(0, dtype=torch.uint8, device=device)
         so = torch.cat(parts_o + [torch.tensor([nb], dtype=torch.int64, device=device)])
     rank, world = _world()
-    sharded = (world > 1 or _force()) and k >= 15 and world & (world - 1) == 0 and world <= 64 and not os.environ.get("MF_REPLICATED_CUTTER")
+    sharded = (world > 1 or _force()) and k >= 20 and world & (world - 1) == 0 and world <= 64 and not os.environ.get("MF_REPLICATED_CUTTER")
     if sharded:
         # every rank owns a shard of the cutter table and of the components step (distributed_components)
-        pb = torch.zeros(int(nb) + 64, dtype=torch.uint8, device=device)         # (the counting kernels read up to 64 bytes past the last base)
-        pb[:int(nb)] = sb
-        so = so.contiguous()
+        allb, allo, ns, nbt = gather_sequences(sb, so)
         torch.cuda.current_stream().synchronize()
-        local = ctx.count_device(pb.data_ptr(), so.data_ptr(), int(so.numel()) - 1, int(nb), k, l)
+        mark("exchange_unitigs")
+        cutter = ctx.count_device_shard(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l, rank, world)
         mark("cutter_count")
-        cutter, comps = distributed_components(ctx, TorchComm(), local, k, b1, b2, device=device, timings=timings)
-        local.close()
+        comps = distributed_components(ctx, TorchComm(), cutter, k, b1, b2, device=device, timings=timings)
         t0 = time.perf_counter()
     else:
-        # (world sizes that are not a power of two, k < 15: every rank builds the whole cutter table and all components)
+        # (world sizes that are not a power of two, k < 20: every rank builds the whole cutter table and all components)
         allb, allo, ns, nbt = gather_sequences(sb, so)
         if torch.cuda.is_available():
             torch.cuda.current_stream().synchronize()

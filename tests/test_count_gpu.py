@@ -331,3 +331,23 @@ def test_long_sequences(gpu_ctx, oracle):
             _check(gpu_ctx, oracle, b, o, 21, min_len=100)
     finally:
         _reset(gpu_ctx)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_tables_partition_the_table(gpu_ctx, oracle, world):
+    """mf_count_device_shard: the ranks' shards are disjoint and together the oracle's table, counts included"""
+    rng = np.random.default_rng(77)
+    bases, offsets = genome_reads(rng, 30000, 4000, 150, err=0.01)
+    db, do = to_device(bases, offsets)
+    want_k, want_c = oracle.Table().count_buffer(bases, offsets, 31).export()
+    keys, cnts = [], []
+    for r in range(world):
+        t = gpu_ctx.count_device_shard(db.data_ptr(), do.data_ptr(), len(offsets) - 1, len(bases), 31, 0, r, world)
+        kk, cc = t.export()
+        assert len(kk) > 0
+        keys.append(kk); cnts.append(cc)
+    allk = np.concatenate(keys); order = np.argsort(allk, kind="stable")
+    assert len(np.unique(allk)) == len(allk)
+    assert np.array_equal(allk[order], want_k) and np.array_equal(np.concatenate(cnts)[order].astype(np.int32), want_c)
+    with pytest.raises(Exception):
+        gpu_ctx.count_device_shard(db.data_ptr(), do.data_ptr(), len(offsets) - 1, len(bases), 31, 0, 0, 3)

@@ -107,12 +107,29 @@ def test_rccl_path_world1(oracle, tmp_path):
 
 
 # ---- the sharded cutter with W virtual ranks in one process (threads; pipeline.ThreadComm stands in for RCCL) ----
-def _virtual_ranks(world, sample_sets, b1, b2, k=31, b=1, l=100):
-    """sample_sets[r] = list of (bases, offsets) host arrays of virtual rank r -> per rank (components export, info)"""
+def _virtual_ranks(world, inputs, b1, b2, k=31, b=1, l=100):
+    """inputs: (bases, offsets) host arrays of the samples; their unitigs are what every rank has after the all-gather of
+    pipeline.run_samples -> per rank (components export, info)"""
     import threading
     import torch
     from util import to_device
     from metafast_amd import lib as L, pipeline as P
+    ctx0 = L.Context(0)
+    bs, os_, nb = [], [], 0
+    for bases, offsets in inputs:
+        db, do = to_device(bases, offsets)
+        t = ctx0.count_device(db.data_ptr(), do.data_ptr(), len(offsets) - 1, len(bases), k, 0)
+        g = t.filter(b)
+        sq = ctx0.build_unitigs(g, b, l)
+        v = sq.device_view()
+        bs.append(P.device_tensor(v["bases"], v["n_bases"], "cuda").clone())
+        os_.append(P.device_tensor(v["offsets"], (v["n"] + 1) * 8, "cuda").view(torch.int64)[:-1] + nb)
+        nb += v["n_bases"]
+        sq.close(); g.close(); t.close()
+    allb = torch.zeros(nb + 64, dtype=torch.uint8, device="cuda")
+    allb[:nb] = torch.cat(bs)
+    allo = torch.cat(os_ + [torch.tensor([nb], dtype=torch.int64, device="cuda")])
+    torch.cuda.synchronize()
     group = P.ThreadGroup(world)
     out, errs = [None] * world, []
 
@@ -122,25 +139,9 @@ def _virtual_ranks(world, sample_sets, b1, b2, k=31, b=1, l=100):
             torch.cuda.set_device(0)
             comm = P.ThreadComm(group, rank)
             ctx = L.Context(0)
-            bs, os_, nb = [], [], 0
-            for bases, offsets in sample_sets[rank]:
-                db, do = to_device(bases, offsets)
-                t = ctx.count_device(db.data_ptr(), do.data_ptr(), len(offsets) - 1, len(bases), k, 0)
-                g = t.filter(b)
-                sq = ctx.build_unitigs(g, b, l)
-                v = sq.device_view()
-                bs.append(P.device_tensor(v["bases"], v["n_bases"], "cuda").clone())
-                os_.append(P.device_tensor(v["offsets"], (v["n"] + 1) * 8, "cuda").view(torch.int64)[:-1] + nb)
-                nb += v["n_bases"]
-                sq.close(); g.close(); t.close()
-            pb = torch.zeros(nb + 64, dtype=torch.uint8, device="cuda")
-            if bs:
-                pb[:nb] = torch.cat(bs)
-            so = torch.cat(os_ + [torch.tensor([nb], dtype=torch.int64, device="cuda")])
-            torch.cuda.synchronize()
-            local = ctx.count_device(pb.data_ptr(), so.data_ptr(), int(so.numel()) - 1, nb, k, l)
+            shard = ctx.count_device_shard(allb.data_ptr(), allo.data_ptr(), int(allo.numel()) - 1, nb, k, l, rank, world)
             info = {}
-            shard, comps = P.distributed_components(ctx, comm, local, k, b1, b2, info=info)
+            comps = P.distributed_components(ctx, comm, shard, k, b1, b2, info=info)
             info["shard_len"] = len(shard)
             out[rank] = (comps.export(), info)
         except BaseException as e:          # (a rank that dies must not leave the others waiting at the barrier)
@@ -172,16 +173,15 @@ def _oracle_components(oracle, inputs, b1, b2, k=31, b=1, l=100):
     return oracle.cut_components(o_cutter, k, b1, b2).all()
 
 
-@pytest.mark.parametrize("world,spr", [(2, 2), (4, 1), (8, 1)])
-def test_sharded_cutter_virtual_ranks(oracle, world, spr):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_cutter_virtual_ranks(oracle, world):
     """W ranks each own a shard of the cutter table (threshold levels 1..6 on the branchy genome): every rank ends with the
-    oracle's components, bit for bit; ranks beyond the samples hold no unitigs but still own a shard"""
+    oracle's components, bit for bit"""
     from util import branchy_reads
     seeds = [107, 117, 127, 137]
     inputs = [branchy_reads(rs, genome_seed=7, n=6000) for rs in seeds]
-    sets = [inputs[r * spr:(r + 1) * spr] for r in range(world)]
     want = _oracle_components(oracle, inputs, 100, 1000)
-    res = _virtual_ranks(world, sets, 100, 1000)
+    res = _virtual_ranks(world, inputs, 100, 1000)
     assert len(want) == 13
     for comps, info in res:
         assert [(a, w, t) for a, w, t, _ in comps] == [(a, w, t) for a, w, t, _ in want]

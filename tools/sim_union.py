@@ -1,6 +1,9 @@
-"""What the cutter + components cost on the union of N samples' unitigs (what EVERY rank repeats at N GPUs), measured
-on one GPU: samples are processed one after the other, only their unitigs are kept.  python3 tools/sim_union.py [N] [reads]"""
-import os, sys, time
+"""What the cutter + components cost at N GPUs, measured on one: the N samples are processed one after the other, only
+their unitigs are kept; then (a) the replicated variant -- every rank builds the cutter table of the union and all
+components -- and (b) the sharded one (pipeline.distributed_components) with N virtual ranks on this GPU, one computing at
+a time (per-rank wall time between the exchanges; the exchanges themselves are memory copies here).
+python3 tools/sim_union.py [N] [reads]"""
+import os, sys, time, threading
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from metafast_amd import lib as L
@@ -28,7 +31,7 @@ for s in range(N):
     print("sample", s, "unitigs", v["n"], "bases", v["n_bases"], flush=True)
     seqs.close(); g.close(); t.close()
 del bases, offsets
-for n in sorted({1, 2, 4, N}):
+for n in ([N] if os.environ.get('MF_SIM_SHARDED_ONLY') else sorted({1, 2, 4, N})):
     nb = sum(int(p.numel()) for p in parts_b[:n]); ns = sum(int(p.numel()) - 1 for p in parts_o[:n])
     allb = torch.zeros(nb + 64, dtype=torch.uint8, device="cuda"); allo = torch.zeros(ns + 1, dtype=torch.int64, device="cuda")
     pb = po = 0
@@ -36,7 +39,7 @@ for n in sorted({1, 2, 4, N}):
         m = int(o.numel()) - 1
         allb[pb:pb + b.numel()] = b; allo[po:po + m] = o[:-1] + pb; pb += int(b.numel()); po += m
     allo[ns] = nb
-    for rep in range(2):
+    for rep in range(0 if os.environ.get('MF_SIM_SHARDED_ONLY') else 2):
         ctx.reset_timers()
         torch.cuda.synchronize(); t0 = time.perf_counter()
         cutter = ctx.count_device(allb.data_ptr(), allo.data_ptr(), ns, nb, k, 100)
@@ -45,6 +48,46 @@ for n in sorted({1, 2, 4, N}):
         torch.cuda.synchronize(); t2 = time.perf_counter()
         nk = len(cutter); nc = len(comps)
         comps.close(); cutter.close()
+    if os.environ.get('MF_SIM_SHARDED_ONLY'): continue
     rep_k = ctx.kernel_report()
     print("   ", {kk: (v[0], round(v[1], 1)) for kk, v in sorted(rep_k.items(), key=lambda kv: -kv[1][1])[:12]})
     print(f"union of {n}: {ns} unitigs, {nb} bases, cutter k-mers {nk}, components {nc}: cutter count {1e3*(t1-t0):.1f} ms, components {1e3*(t2-t1):.1f} ms", flush=True)
+
+# ---- (b) sharded: N virtual ranks, every rank has all unitigs (the all-gather) and counts the k-mers it owns
+group = P.ThreadGroup(N)
+res = [None] * N
+def work(rank):
+    comm = None
+    try:
+        torch.cuda.set_device(0)
+        comm = P.ThreadComm(group, rank)
+        c2 = L.Context(0)
+        c2.set_option("profile", 1)
+        for rep in range(2):
+            c2.reset_timers()
+            tm = {}
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            shard = c2.count_device_shard(allb.data_ptr(), allo.data_ptr(), ns, nb, k, 100, rank, N)
+            torch.cuda.synchronize(); tm["cutter_count"] = time.perf_counter() - t0
+            info = {}
+            comps = P.distributed_components(c2, comm, shard, k, 1000, 10000, timings=tm, info=info)
+            info["components"] = len(comps); info["exchange_ms"] = round(1e3 * comm.exchange, 1); comm.exchange = 0.0
+            comps.close(); shard.close()
+        res[rank] = (tm, info, c2.kernel_report())
+    except BaseException as e:
+        res[rank] = e
+        group.barrier.abort()
+        raise
+    finally:
+        if comm: comm.done()
+th = [threading.Thread(target=work, args=(r,)) for r in range(N)]
+[t.start() for t in th]; [t.join() for t in th]
+for r, x in enumerate(res):
+    if isinstance(x, BaseException): raise x
+    tm, info, rep_k = x
+    print(f"rank {r}:", {kk: round(1e3 * v, 1) for kk, v in tm.items()}, "total", round(1e3 * sum(tm.values()), 1), "ms", info, flush=True)
+tm, info, rep_k = res[0]
+print("    rank 0 kernels:", {kk: (v[0], round(v[1], 1)) for kk, v in sorted(rep_k.items(), key=lambda kv: -kv[1][1])[:30]})
+stages = sorted({kk for x in res for kk in x[0]})
+print("sharded, max over ranks:", {kk: round(1e3 * max(x[0][kk] for x in res), 1) for kk in stages},
+      "sum of the maxima", round(1e3 * sum(max(x[0][kk] for x in res) for kk in stages), 1), "ms (exchanges: memory copies here)")
