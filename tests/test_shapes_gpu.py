@@ -1,0 +1,157 @@
+"""BASELINE.json's other shapes on one MI355X.
+
+* config 4's k = 21 leg at full size (200 M x 150 bp reads; MF_SHAPES_K21_READS overrides): the size-independent properties of
+  tests/test_fullsize_gpu.py -- occurrence conservation, an independent exact recount of a key sample in plain torch ops,
+  the cut inside the counting pass = filter afterwards, additivity of the two halves (saturating), the all-counts histogram.
+* config 3's semantics (8 samples -> 8 x 8 matrix) with the 8 samples one after the other on this GPU through
+  pipeline.run_samples, against the ORACLE's pipeline on the same reads (scaled down to MF_SHAPES_READS = 5 M reads per
+  sample; the oracle's kmer-counter and seq-builder run as 8 CPU child processes and leave the reference's own files,
+  .kmers.bin / .seq.fasta, from which the oracle's cutter, features and matrix are computed here): components, vectors and
+  matrix identical."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+RL = 150
+SEED = 0x4D45544146415354
+CHUNK = 1_000_000
+
+
+def _canon_chunk(torch, lut, chunk, k):
+    codes = lut[chunk.long()]
+    m = RL - k + 1
+    fw = torch.zeros((chunk.shape[0], m), dtype=torch.int64, device=chunk.device)
+    rc = torch.zeros_like(fw)
+    for i in range(k):
+        c = codes[:, i:i + m]
+        fw = (fw << 2) | c
+        rc = rc | ((3 - c) << (2 * i))
+    return torch.minimum(fw, rc)
+
+
+@pytest.fixture(autouse=True)
+def _give_back(gpu_ctx):
+    yield
+    import torch
+    gpu_ctx.trim()
+    torch.cuda.empty_cache()
+
+
+def test_200M_reads_k21_properties(gpu_ctx):
+    import torch
+    k = 21
+    n = int(os.environ.get("MF_SHAPES_K21_READS", "200000000"))
+    free, _ = torch.cuda.mem_get_info()
+    if free < n * 1250:
+        pytest.skip("needs %.0f GB of free HBM" % (n * 1250 / 1e9))
+    dev = "cuda"
+    bases = torch.zeros(n * RL + 64, dtype=torch.uint8, device=dev)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+    gpu_ctx.synth_reads_device(SEED, 0, 0, n, RL, 1_000_000, bases.data_ptr(), offsets.data_ptr())
+    gpu_ctx.synchronize()
+    table = gpu_ctx.count_device(bases.data_ptr(), offsets.data_ptr(), n, n * RL, k, 0)
+    n_distinct, n_occ = table.stats()
+    assert n_occ == n * (RL - k + 1)
+    lut = torch.zeros(256, dtype=torch.int64, device=dev)
+    for ch, c in (("A", 0), ("G", 1), ("C", 2), ("T", 3)):
+        lut[ord(ch)] = c
+    b2d = bases[: n * RL].view(n, RL)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    m = RL - k + 1
+    pres = torch.cat([_canon_chunk(torch, lut, b2d[:4096], k).reshape(-1)[torch.randperm(4096 * m, generator=g)[:5000].to(dev)],
+                      _canon_chunk(torch, lut, b2d[-4096:], k).reshape(-1)[torch.randperm(4096 * m, generator=g)[:5000].to(dev)]])
+    absent = torch.randint(0, 1 << 42, (3000,), generator=g, dtype=torch.int64).to(dev)       # (4^21 keys: some of these do occur)
+    sample = torch.unique(torch.cat([pres, absent]))
+    acc = torch.zeros(sample.numel(), dtype=torch.int64, device=dev)
+    acc1 = torch.zeros_like(acc)
+    h = n // 2
+    last = sample.numel() - 1
+    for lo in range(0, n, CHUNK):
+        canon = _canon_chunk(torch, lut, b2d[lo:lo + CHUNK], k).reshape(-1)
+        idx = torch.searchsorted(sample, canon).clamp_(max=last)
+        hit = sample[idx] == canon
+        bc = torch.bincount(idx[hit], minlength=sample.numel())
+        acc += bc
+        if lo + CHUNK <= h:
+            acc1 += bc
+        del canon, idx, hit, bc
+    exact, exact1 = acc.cpu().numpy(), acc1.cpu().numpy()
+    keys = sample.cpu().numpy().astype(np.uint64)
+    assert (exact > 0).sum() >= 9000
+    got = table.lookup(keys).astype(np.int64)
+    assert np.array_equal(got, np.where(exact > 0, np.minimum(exact, 32767), -1))
+    assert n_distinct < n_occ
+    hist = table.hist()
+    assert int(hist.sum()) == n_distinct and int(hist[0]) == 0
+    # the cut inside the counting pass + its histogram of everything
+    above, n_all = gpu_ctx.count_device_above(bases.data_ptr(), offsets.data_ptr(), n, n * RL, k, 1)
+    assert n_all == n_distinct and np.array_equal(above.hist(), hist)
+    assert len(above) == n_distinct - int(hist[1])
+    assert np.array_equal(above.lookup(keys).astype(np.int64), np.where(got > 1, got, -1))
+    above.close()
+    # additivity: first half (a whole number of chunks) (+) second half, saturating
+    h = (h // CHUNK) * CHUNK
+    if 0 < h < n:
+        off2 = (offsets[h:] - offsets[h]).contiguous()
+        t1 = gpu_ctx.count_device(bases.data_ptr(), offsets.data_ptr(), h, h * RL, k, 0)
+        a = t1.lookup(keys).astype(np.int64)
+        assert np.array_equal(a, np.where(exact1 > 0, np.minimum(exact1, 32767), -1))
+        t1.close()
+        t2 = gpu_ctx.count_device(bases.data_ptr() + h * RL, off2.data_ptr(), n - h, (n - h) * RL, k, 0)
+        b = t2.lookup(keys).astype(np.int64)
+        e2 = exact - exact1
+        assert np.array_equal(b, np.where(e2 > 0, np.minimum(e2, 32767), -1))
+        t2.close()
+    table.close()
+
+
+def test_eight_samples_one_gpu_against_the_oracle(gpu_ctx, oracle, tmp_path):
+    import torch
+    from metafast_amd import pipeline as P
+    S, k, b, l, b1, b2 = 8, 31, 1, 100, 1000, 10000
+    n = int(os.environ.get("MF_SHAPES_READS", "5000000"))
+    scale = max(n // 100, 1000)
+    worker = os.path.join(ROOT, "tests", "oracle_sample_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(s), str(n), str(scale), str(k), str(b), str(l), str(tmp_path)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for s in range(S)]
+
+    def samples():
+        for s in range(S):
+            bases = torch.zeros(n * RL + 64, dtype=torch.uint8, device="cuda")
+            offsets = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            gpu_ctx.synth_reads_device(SEED, s, 0, n, RL, scale, bases.data_ptr(), offsets.data_ptr())
+            gpu_ctx.synchronize()
+            yield bases, offsets, n, n * RL
+
+    r = P.run_samples(gpu_ctx, samples(), k=k, b=b, l=l, b1=b1, b2=b2)
+    n_distinct = 0
+    for p in procs:
+        out, err = p.communicate(timeout=1500)
+        assert p.returncode == 0, err[-2000:]
+        n_distinct += int(out.strip().splitlines()[-1])
+    assert r["n_distinct"] == n_distinct
+    goods = [oracle.Table().load_kmers([str(tmp_path / f"s{s:02d}.kmers.bin")]) for s in range(S)]
+    for g, og in zip(r["goods"], goods):
+        assert len(g) == len(og)
+    cutter = oracle.Table().count_files([str(tmp_path / f"s{s:02d}.seq.fasta") for s in range(S)], k, l)
+    assert len(r["cutter"]) == len(cutter)
+    oc = oracle.cut_components(cutter, k, b1, b2)
+    got, want = r["comps"].export(), oc.all()
+    assert len(want) > 50 and max(c[2] for c in want) >= 2
+    assert [(a, w, t) for a, w, t, _ in got] == [(a, w, t) for a, w, t, _ in want]
+    for (_, _, _, gk), (_, _, _, ok) in zip(got, want):
+        assert np.array_equal(gk, ok)
+    ovecs = np.array([oc.features(og, 0)[0] for og in goods], dtype=np.int64).reshape(S, len(want))
+    assert np.array_equal(r["vecs"], ovecs)
+    om = oracle.bray_curtis(ovecs)
+    assert r["matrix"].shape == (S, S) and np.abs(r["matrix"] - om).max() <= 1e-6      # north_star tolerance (expected exact)
+    assert np.array_equal(r["matrix"], om)
