@@ -30,7 +30,36 @@ public final class HipBackend {
     public static native void featuresReads(long ctx, String componentsBin, String[] files, int k, int threshold, String vec, String breadth);
     /** DistanceMatrixCalculatorMain.brayCurtisDistance (:140) for all pairs: row-major nSamples x nSamples */
     public static native double[] brayCurtis(long[] vecs, int nSamples, int nComp);
+    /** the .stat.txt rows of IOUtils.printKmers (src/io/IOUtils.java:45-71) of a table counted with the cut inside the counting pass: hist[count] */
+    public static native long[] tableHist(long table);
     public static native void tableDestroy(long table);
+
+    // ---- component-cutter on several GPUs (ComponentCutterMain.java:78-114 with one process per GPU): device pointers are plain longs;
+    //      the host moves the buffers between the ranks (all-to-all / all-gather) between these calls, see INTEGRATION.md section 5
+    /** this rank's shard of the cutter table of all samples' unitigs (IOUtils.loadReads of ComponentCutterMain.java:81, the k-mers this rank owns) */
+    public static native long countShard(long ctx, long dBases, long dOffsets, long nSeqs, long nBases, int k, int minLen, int rank, int world);
+    public static native long dccCreate(long ctx, long shard, int rank, int world, int[] base);
+    public static native void dccDestroy(long dcc);
+    /** queries for the owners of neighbours in other shards: counts per rank; dccQueriesFill writes the 16-byte queries */
+    public static native long[] dccQueries(long dcc, int world);
+    public static native void dccQueriesFill(long dcc, long dQueries);
+    public static native void dccAnswer(long dcc, long dQueries, long n, long dAnswers);
+    public static native void dccSetAnswers(long dcc, long dAnswers, long n);
+    /** one threshold level of ComponentsBuilder.run (src/algo/ComponentsBuilder.java:86-150) */
+    public static native long[] dccLevelLocal(long dcc, int world);
+    public static native void dccPairsFill(long dcc, long dPairs);
+    public static native void dccPairsComplete(long dcc, long dPairs, long n);
+    public static native long dccMerge(long dcc, long dPairs, long n);
+    public static native void dccStatsFill(long dcc, long dStats);
+    /** returns {kept, oversize} components whose root this rank owns */
+    public static native long[] dccClassify(long dcc, long dStats, long n, long ownFirst, long ownN, int b1, int b2, int thr);
+    public static native void dccKeptFill(long dcc, long dKept);
+    public static native long dccMembers(long dcc);
+    public static native void dccMembersFill(long dcc, long dKmers, long dRoots);
+    public static native void dccMinkeys(long dcc, int[] keptRoot, long dMin);
+    /** -> components handle (List&lt;ConnectedComponent&gt;), the same on every rank */
+    public static native long dccFinish(long dcc, long dKmers, long dRoots, long nMembers, int[] keptRoot, int[] keptSize, long[] keptWeight,
+                                        int[] keptThr, long[] keptMinkey);
 
     private HipBackend() {}
 }

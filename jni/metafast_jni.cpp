@@ -108,6 +108,93 @@ JNIEXPORT jdoubleArray JNICALL Java_io_HipBackend_brayCurtis(JNIEnv *e, jclass, 
     if (out) e->SetDoubleArrayRegion(out, 0, (jsize)m.size(), m.data());
     return out;
 }
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_tableHist(JNIEnv *e, jclass, jlong table) {
+    std::vector<uint64_t> h((size_t)MF_MAX_COUNT + 1);
+    if (mf_table_hist((const mf_table *)(intptr_t)table, h.data()) < 0) { raise(e); return nullptr; }
+    jlongArray out = e->NewLongArray((jsize)h.size());
+    if (out) e->SetLongArrayRegion(out, 0, (jsize)h.size(), (const jlong *)h.data());
+    return out;
+}
 JNIEXPORT void JNICALL Java_io_HipBackend_tableDestroy(JNIEnv *, jclass, jlong table) { mf_table_destroy((mf_table *)(intptr_t)table); }
+
+// ---- component-cutter on several GPUs: plain forwarding, device pointers travel as jlong
+#define CTX(x) ((mf_ctx *)(intptr_t)(x))
+#define DCC(x) ((mf_dcc *)(intptr_t)(x))
+#define DEV(x) ((void *)(intptr_t)(x))
+static jlongArray longs(JNIEnv *e, const uint64_t *v, int n) {
+    jlongArray out = e->NewLongArray(n);
+    if (out) e->SetLongArrayRegion(out, 0, n, (const jlong *)v);
+    return out;
+}
+JNIEXPORT jlong JNICALL Java_io_HipBackend_countShard(JNIEnv *e, jclass, jlong ctx, jlong dBases, jlong dOffsets, jlong nSeqs, jlong nBases, jint k,
+                                                      jint minLen, jint rank, jint world) {
+    mf_table *t = nullptr;
+    if (mf_count_device_shard(CTX(ctx), DEV(dBases), DEV(dOffsets), (uint64_t)nSeqs, (uint64_t)nBases, k, minLen, rank, world, &t) < 0) { raise(e); return 0; }
+    return (jlong)(intptr_t)t;
+}
+JNIEXPORT jlong JNICALL Java_io_HipBackend_dccCreate(JNIEnv *e, jclass, jlong ctx, jlong shard, jint rank, jint world, jintArray base) {
+    jint *b = e->GetIntArrayElements(base, nullptr);
+    mf_dcc *d = nullptr;
+    const int rc = mf_dcc_create(CTX(ctx), (mf_table *)(intptr_t)shard, rank, world, (const uint32_t *)b, &d);
+    e->ReleaseIntArrayElements(base, b, JNI_ABORT);
+    if (rc < 0) { raise(e); return 0; }
+    return (jlong)(intptr_t)d;
+}
+JNIEXPORT void JNICALL Java_io_HipBackend_dccDestroy(JNIEnv *, jclass, jlong dcc) { mf_dcc_destroy(DCC(dcc)); }
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_dccQueries(JNIEnv *e, jclass, jlong dcc, jint world) {
+    std::vector<uint64_t> c((size_t)world);
+    if (mf_dcc_queries(DCC(dcc), c.data()) < 0) { raise(e); return nullptr; }
+    return longs(e, c.data(), world);
+}
+JNIEXPORT void JNICALL Java_io_HipBackend_dccQueriesFill(JNIEnv *e, jclass, jlong dcc, jlong dQueries) { if (mf_dcc_queries_fill(DCC(dcc), DEV(dQueries)) < 0) raise(e); }
+JNIEXPORT void JNICALL Java_io_HipBackend_dccAnswer(JNIEnv *e, jclass, jlong dcc, jlong dQueries, jlong n, jlong dAnswers) {
+    if (mf_dcc_answer(DCC(dcc), DEV(dQueries), (uint64_t)n, DEV(dAnswers)) < 0) raise(e);
+}
+JNIEXPORT void JNICALL Java_io_HipBackend_dccSetAnswers(JNIEnv *e, jclass, jlong dcc, jlong dAnswers, jlong n) { if (mf_dcc_set_answers(DCC(dcc), DEV(dAnswers), (uint64_t)n) < 0) raise(e); }
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_dccLevelLocal(JNIEnv *e, jclass, jlong dcc, jint world) {
+    std::vector<uint64_t> c((size_t)world);
+    if (mf_dcc_level_local(DCC(dcc), c.data()) < 0) { raise(e); return nullptr; }
+    return longs(e, c.data(), world);
+}
+JNIEXPORT void JNICALL Java_io_HipBackend_dccPairsFill(JNIEnv *e, jclass, jlong dcc, jlong dPairs) { if (mf_dcc_pairs_fill(DCC(dcc), DEV(dPairs)) < 0) raise(e); }
+JNIEXPORT void JNICALL Java_io_HipBackend_dccPairsComplete(JNIEnv *e, jclass, jlong dcc, jlong dPairs, jlong n) { if (mf_dcc_pairs_complete(DCC(dcc), DEV(dPairs), (uint64_t)n) < 0) raise(e); }
+JNIEXPORT jlong JNICALL Java_io_HipBackend_dccMerge(JNIEnv *e, jclass, jlong dcc, jlong dPairs, jlong n) {
+    uint64_t ns = 0;
+    if (mf_dcc_merge(DCC(dcc), DEV(dPairs), (uint64_t)n, &ns) < 0) { raise(e); return 0; }
+    return (jlong)ns;
+}
+JNIEXPORT void JNICALL Java_io_HipBackend_dccStatsFill(JNIEnv *e, jclass, jlong dcc, jlong dStats) { if (mf_dcc_stats_fill(DCC(dcc), DEV(dStats)) < 0) raise(e); }
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_dccClassify(JNIEnv *e, jclass, jlong dcc, jlong dStats, jlong n, jlong ownFirst, jlong ownN, jint b1, jint b2, jint thr) {
+    uint64_t r[2] = {0, 0};
+    if (mf_dcc_classify(DCC(dcc), DEV(dStats), (uint64_t)n, (uint64_t)ownFirst, (uint64_t)ownN, b1, b2, thr, &r[0], &r[1]) < 0) { raise(e); return nullptr; }
+    return longs(e, r, 2);
+}
+JNIEXPORT void JNICALL Java_io_HipBackend_dccKeptFill(JNIEnv *e, jclass, jlong dcc, jlong dKept) { if (mf_dcc_kept_fill(DCC(dcc), DEV(dKept)) < 0) raise(e); }
+JNIEXPORT jlong JNICALL Java_io_HipBackend_dccMembers(JNIEnv *e, jclass, jlong dcc) {
+    uint64_t n = 0;
+    if (mf_dcc_members(DCC(dcc), &n) < 0) { raise(e); return 0; }
+    return (jlong)n;
+}
+JNIEXPORT void JNICALL Java_io_HipBackend_dccMembersFill(JNIEnv *e, jclass, jlong dcc, jlong dKmers, jlong dRoots) { if (mf_dcc_members_fill(DCC(dcc), DEV(dKmers), DEV(dRoots)) < 0) raise(e); }
+JNIEXPORT void JNICALL Java_io_HipBackend_dccMinkeys(JNIEnv *e, jclass, jlong dcc, jintArray keptRoot, jlong dMin) {
+    const jsize n = e->GetArrayLength(keptRoot);
+    jint *g = e->GetIntArrayElements(keptRoot, nullptr);
+    const int rc = mf_dcc_minkeys(DCC(dcc), (const uint32_t *)g, (uint64_t)n, DEV(dMin));
+    e->ReleaseIntArrayElements(keptRoot, g, JNI_ABORT);
+    if (rc < 0) raise(e);
+}
+JNIEXPORT jlong JNICALL Java_io_HipBackend_dccFinish(JNIEnv *e, jclass, jlong dcc, jlong dKmers, jlong dRoots, jlong nMembers, jintArray keptRoot, jintArray keptSize,
+                                                     jlongArray keptWeight, jintArray keptThr, jlongArray keptMinkey) {
+    const jsize n = e->GetArrayLength(keptRoot);
+    jint *g = e->GetIntArrayElements(keptRoot, nullptr), *sz = e->GetIntArrayElements(keptSize, nullptr), *th = e->GetIntArrayElements(keptThr, nullptr);
+    jlong *w = e->GetLongArrayElements(keptWeight, nullptr), *mk = e->GetLongArrayElements(keptMinkey, nullptr);
+    mf_comps *c = nullptr;
+    const int rc = mf_dcc_finish(DCC(dcc), DEV(dKmers), DEV(dRoots), (uint64_t)nMembers, (const uint32_t *)g, (const uint32_t *)sz, (const int64_t *)w, (const int32_t *)th,
+                                 (const uint64_t *)mk, (uint64_t)n, &c);
+    e->ReleaseIntArrayElements(keptRoot, g, JNI_ABORT); e->ReleaseIntArrayElements(keptSize, sz, JNI_ABORT); e->ReleaseIntArrayElements(keptThr, th, JNI_ABORT);
+    e->ReleaseLongArrayElements(keptWeight, w, JNI_ABORT); e->ReleaseLongArrayElements(keptMinkey, mk, JNI_ABORT);
+    if (rc < 0) { raise(e); return 0; }
+    return (jlong)(intptr_t)c;
+}
 }
 #endif

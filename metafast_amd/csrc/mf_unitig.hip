@@ -37,6 +37,7 @@ struct ut_arrays {
     uint8_t *pal;             // even k only: 1 if the k-mer equals its reverse complement (else nullptr)
     uint64_t *node;           // per oriented node: successor on its path (low 32 bits, UT_NONE = none) | count << 32 |
                               // last base of the oriented k-mer << 48: everything a walk needs per hop in ONE 8-byte load
+    const uint64_t *jump;     // per oriented node: where its chain leaves the node's partition + hops (k_ut_contract)
     uint32_t *starts;         // compacted list of start nodes
     unsigned int *n_starts;
 };
@@ -161,6 +162,73 @@ __global__ __launch_bounds__(1024) void k_ut_links(ut_arrays A) {
     if (is_start) A.starts[block_base + wave_base[wave] + (uint32_t)__popcll(b & ((1ull << mf_lane()) - 1ull))] = (uint32_t)f;
 }
 
+// U2b k_ut_contract: jump words.  A walk that reads one node word per hop misses the cache on nearly every hop (measured:
+// 82 GB fetched for 7.2e8 hops, 114 B per hop), although nine links in ten stay inside the node's minimizer partition -- a
+// few hundred nodes next to each other in memory.  So one wave per partition loads its nodes' successors (coalesced), follows
+// the links that stay inside by pointer jumping in LDS, and writes for every node ONE word: where the chain leaves the
+// partition (the successor of its last inside node) and how many hops that is; the length-only walk (U3) then makes one
+// load per partition crossed, not per node.
+//   jump[f] = target (low 32 bits) | hops << 32 | END << 47:  END: the chain ends in the partition, target = its last node,
+//   hops to it; else target = the first node outside, hops to it.
+#define UT_J_END (1ull << 47)
+#define UT_J_MAXN 1024              // oriented nodes of a partition the LDS arrays take (larger partitions: one hop per word)
+#define UT_J_WAVES 4
+__global__ __launch_bounds__(64 * UT_J_WAVES) void k_ut_contract(const uint64_t *__restrict__ node, const uint64_t *__restrict__ part_off, uint32_t np,
+                                                                 uint64_t *__restrict__ jump) {
+    __shared__ uint32_t sg[UT_J_WAVES][UT_J_MAXN];          // successor (global node id)
+    __shared__ uint32_t pj[UT_J_WAVES][UT_J_MAXN];          // local pointer (low 16 bits) | hops (high 16 bits)
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t gw = blockIdx.x * UT_J_WAVES + wave, nw = gridDim.x * UT_J_WAVES;
+    uint32_t *S = sg[wave], *P = pj[wave];
+    for (uint32_t p = gw; p < np; p += nw) {
+        const uint64_t lo = part_off[p], hi = part_off[p + 1];
+        const uint32_t m = (uint32_t)(hi - lo) * 2u;                       // oriented nodes [2 lo, 2 hi)
+        if (m == 0) continue;                                              // wave-uniform
+        const uint64_t f0 = lo * 2;
+        if (m > (uint32_t)UT_J_MAXN) {
+            for (uint32_t j = lane; j < m; j += 64) {
+                const uint32_t g = (uint32_t)node[f0 + j];
+                jump[f0 + j] = g == UT_NONE ? ((uint64_t)(uint32_t)(f0 + j) | UT_J_END) : ((uint64_t)g | (1ull << 32));
+            }
+            continue;
+        }
+        for (uint32_t j = lane; j < m; j += 64) {
+            const uint32_t g = (uint32_t)node[f0 + j];
+            S[j] = g;
+            const bool inside = g != UT_NONE && (uint64_t)g >= f0 && (uint64_t)g < f0 + m;
+            P[j] = inside ? ((g - (uint32_t)f0) | (1u << 16)) : j;          // the last inside node of a chain points at itself, 0 hops
+        }
+        __builtin_amdgcn_wave_barrier();
+        // pointer jumping; a (pointer, hops) pair is ONE word, so a read always sees a consistent pair: hops = distance to pointer
+        for (int round = 0; round < 11; round++) {                         // 2^11 > UT_J_MAXN (cycles inside a partition never settle: nobody walks them)
+            bool changed = false;
+            for (uint32_t j = lane; j < m; j += 64) {
+                const uint32_t a = P[j], t = a & 0xFFFFu;
+                if (t == j) continue;
+                const uint32_t b = P[t];
+                if ((b & 0xFFFFu) == t) continue;                           // already at the chain's last node
+                P[j] = (b & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16);
+                changed = true;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (!__any(changed)) break;
+        }
+        for (uint32_t j = lane; j < m; j += 64) {
+            const uint32_t a = P[j], e = a & 0xFFFFu, h = (a >> 16) & 0x7FFFu;
+            const uint32_t g = S[e];
+            jump[f0 + j] = g == UT_NONE ? ((uint64_t)((uint32_t)f0 + e) | ((uint64_t)h << 32) | UT_J_END) : ((uint64_t)g | ((uint64_t)(h + 1u) << 32));
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+// tables without minimizer partitions: one hop per word
+__global__ void k_ut_jump_plain(const uint64_t *__restrict__ node, uint64_t n_nodes, uint64_t *__restrict__ jump) {
+    const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_nodes) return;
+    const uint32_t g = (uint32_t)node[f];
+    jump[f] = g == UT_NONE ? ((uint64_t)(uint32_t)f | UT_J_END) : ((uint64_t)g | (1ull << 32));
+}
+
 // walk item: a path being followed from `start` (slot = its index in starts[]), currently at `node`, `dist` hops in
 struct ut_item { uint32_t node, slot, dist; };
 struct ut_walk_out {
@@ -177,9 +245,10 @@ __global__ void k_ut_walk1(ut_arrays A, const ut_item *__restrict__ items, uint3
         if (FIRST) { f = A.starts[t]; slot = t; d = 0; }
         else { ut_item it = items[t]; f = it.node; slot = it.slot; d = it.dist; }
         for (int step = 0; step < chunk; step++) {
-            uint32_t g = (uint32_t)A.node[f];
-            if (g == UT_NONE) { W.end_node[slot] = f; W.end_dist[slot] = d; going = false; break; }
-            f = g; d++;
+            const uint64_t w = A.jump[f];
+            d += (uint32_t)(w >> 32) & 0x7FFFu;
+            f = (uint32_t)w;
+            if (w & UT_J_END) { W.end_node[slot] = f; W.end_dist[slot] = d; going = false; break; }
         }
     }
     const uint32_t c = mf_wave_reserve(W.n_cont, going ? 1u : 0u);       // unfinished walks go on in the next round
@@ -336,7 +405,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         ut_arrays A;
         A.gk = g->d_keys; A.gv = g->d_counts; A.n = n; A.k = k;
         A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.node = succ.p; A.starts = starts.p; A.n_starts = &ctr.p[1];
-        A.pal = nullptr;
+        A.pal = nullptr; A.jump = nullptr;
         if ((k & 1) == 0) { if ((rc = pal.alloc(ctx, n)) < 0) break; A.pal = pal.p; }   // palindromes need an even k
         {
             mf_ktimer tm(ctx, "k_ut_flags");
@@ -350,6 +419,18 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         {
             mf_ktimer tm(ctx, "k_ut_links");
             k_ut_links<<<grid_for(2 * n, 1024), 1024, 0, st>>>(A);
+        }
+        mf_buf<uint64_t> jump;
+        if ((rc = jump.alloc(ctx, 2 * n)) < 0) break;
+        A.jump = jump.p;
+        {
+            mf_ktimer tm(ctx, "k_ut_contract");
+            if (g->part_bits > 0 && g->d_part_off) {
+                const uint32_t npart = 1u << g->part_bits;
+                const unsigned grid = (unsigned)std::min<uint64_t>((npart + UT_J_WAVES - 1) / UT_J_WAVES, (uint64_t)ctx->n_cu * 32);
+                k_ut_contract<<<grid, 64 * UT_J_WAVES, 0, st>>>(succ.p, g->d_part_off, npart, jump.p);
+            } else
+                k_ut_jump_plain<<<grid_for(2 * n), 256, 0, st>>>(succ.p, 2 * n, jump.p);
         }
         unsigned int n_starts = 0;
         if (hipMemcpyAsync(&n_starts, &ctr.p[1], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
@@ -412,7 +493,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if (hipMemcpyAsync(&np, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = mf_set_error("unitigs: ends pass failed"); break;
         }
-        ridx.reset(); lidx.reset(); end_node.reset(); end_dist.reset(); eqmin.reset(); starts.reset();
+        ridx.reset(); lidx.reset(); end_node.reset(); end_dist.reset(); eqmin.reset(); starts.reset(); jump.reset();
         // U5: walk the emitted paths again and write them out
         mf_buf<uint64_t> off, tot; mf_buf<int32_t> wmin, wmax, wavg;
         if ((rc = off.alloc(ctx, (size_t)np + 1)) < 0 || (rc = tot.alloc(ctx, 1)) < 0 || (rc = wmin.alloc(ctx, np)) < 0 ||
