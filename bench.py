@@ -177,6 +177,9 @@ def main():
 
     ctx = L.Context(local_rank, stream=torch.cuda.current_stream())
     ctx.set_option("profile", 1)
+    for kv in filter(None, os.environ.get("MF_OPTIONS", "").split(",")):     # A/B runs: MF_OPTIONS=part_target_long=256,...
+        name, val = kv.split("=")
+        ctx.set_option(name, int(val))
 
     # ---- synthetic sample of this rank, generated in HBM (untimed) ----
     n_reads, rl, k = args.reads, args.read_len, args.k

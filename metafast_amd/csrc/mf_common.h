@@ -55,7 +55,7 @@ struct mf_ctx {
     int64_t opt_l1_bits = -1;      // -1 = auto
     int64_t opt_l2_bits = -1;
     int64_t opt_part_target = 6144;  // mean k-mer occurrences per final partition (k_skm_count2: ~800 distinct k-mers in 4096 slots)
-    int64_t opt_part_target_long = 512;   // ... for assembled sequences (mean length >= 8k: nearly duplicate-free)
+    int64_t opt_part_target_long = 256;   // ... for assembled sequences (mean length >= 8k: nearly duplicate-free)
     int64_t opt_scatter_staged = 1;
     int64_t opt_profile = 0;
     int64_t opt_l1_blocks = 0;     // 0 = auto
@@ -68,6 +68,7 @@ struct mf_ctx {
     int64_t opt_skm_slices = 0;    // digit-range slices of a counting run (0 = as many as the HBM budget asks for)
     int64_t opt_arena_cap_gb = 0;  // pretend the device has this much memory when the slices are chosen (0 = what it has)
     int64_t opt_skm_batches = 0;   // partitions are counted + gathered in this many batches (0 = auto); tests force small values
+    int64_t opt_union_samples = 0;     // hint: the sequences of the next count are the unitigs of this many samples (they share k-mers: partitions are planned twice as large from 4 on)
     int own_rank = 0, own_world = 1;   // mf_count_device_shard: only the k-mers this rank owns (level-1 digits [nd1 * rank / world, nd1 * (rank + 1) / world)) are counted
     int64_t opt_nbr_global = 0;    // 1: neighbour lookups of the graph kernels through the HBM index only (A/B of mf_nbr.h)
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero

@@ -627,6 +627,9 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     // a partition's index region stays a few KB and the 8 neighbour probes of a k-mer stay cache-local.
     uint64_t target = (uint64_t)ctx->opt_part_target;
     if (n_bases / n_reads >= (uint64_t)(8 * k) && target > (uint64_t)ctx->opt_part_target_long) target = (uint64_t)ctx->opt_part_target_long;
+    // (a shard of the union of many samples' unitigs: the samples share most of their k-mers -- 0.36 distinct per occurrence at 8
+    // samples --, and it is the DISTINCT k-mers of a partition that must fit the LDS tables)
+    if ((ctx->own_world >= 4 || ctx->opt_union_samples >= 4) && target == (uint64_t)ctx->opt_part_target_long) target *= 2;
     int B = ceil_log2_u64((n_occ + target - 1) / target);
     if (ctx->own_world > 1) {                       // (a shard: every rank must own at least one level-1 digit)
         int lw = 0; while ((1 << lw) < ctx->own_world) lw++;

@@ -97,6 +97,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "stream_slack_bytes") ctx->opt_sr_slack = v;
     else if (s == "skm_dyn") ctx->opt_skm_dyn = v;
     else if (s == "nbr_global") ctx->opt_nbr_global = v;
+    else if (s == "union_samples") ctx->opt_union_samples = v;
     else return mf_set_error("unknown option '%s'", name);
     return MF_OK;
 }

@@ -402,7 +402,12 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
         if torch.cuda.is_available():
             torch.cuda.current_stream().synchronize()
         mark("exchange_unitigs")
-        cutter = ctx.count_device(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l)
+        n_all = int(TorchComm().all_gather_ints([len(goods)]).sum())
+        ctx.set_option("union_samples", n_all)          # (planning hint: many samples share most of their unitig k-mers)
+        try:
+            cutter = ctx.count_device(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l)
+        finally:
+            ctx.set_option("union_samples", 0)
         mark("cutter_count")
         comps = ctx.cut_components(cutter, b1, b2)
         mark("components")

@@ -42,7 +42,9 @@ for n in ([N] if os.environ.get('MF_SIM_SHARDED_ONLY') else sorted({1, 2, 4, N})
     for rep in range(0 if os.environ.get('MF_SIM_SHARDED_ONLY') else 2):
         ctx.reset_timers()
         torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctx.set_option("union_samples", n)
         cutter = ctx.count_device(allb.data_ptr(), allo.data_ptr(), ns, nb, k, 100)
+        ctx.set_option("union_samples", 0)
         torch.cuda.synchronize(); t1 = time.perf_counter()
         comps = ctx.cut_components(cutter, 1000, 10000)
         torch.cuda.synchronize(); t2 = time.perf_counter()
