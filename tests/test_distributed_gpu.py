@@ -189,3 +189,11 @@ def test_sharded_cutter_virtual_ranks(oracle, world):
         assert info["levels"] == 6
     assert sum(i["shard_len"] for _, i in res) == res[0][1]["vertices"]
     assert all(i["shard_len"] > 0 for _, i in res)
+
+
+@pytest.mark.skipif(not os.environ.get("MF_TRY_RCCL_2RANKS"), reason="two RCCL ranks on ONE device: RCCL refuses duplicate GPUs on most builds (opt-in: MF_TRY_RCCL_2RANKS=1)")
+def test_two_ranks_one_gpu_rccl(oracle, tmp_path):
+    res = _run(2, "nccl", tmp_path)
+    want = _oracle_pipeline(oracle, tmp_path, [107, 117])
+    for r in res:
+        _same(r, want)
