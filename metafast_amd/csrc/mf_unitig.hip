@@ -251,7 +251,8 @@ __global__ void k_ut_walk1(ut_arrays A, const ut_item *__restrict__ items, uint3
             if (w & UT_J_END) { W.end_node[slot] = f; W.end_dist[slot] = d; going = false; break; }
         }
     }
-    const uint32_t c = mf_wave_reserve(W.n_cont, going ? 1u : 0u);       // unfinished walks go on in the next round
+    __shared__ uint32_t rs_scratch[18];
+    const uint32_t c = mf_block_reserve(W.n_cont, going ? 1u : 0u, rs_scratch);       // unfinished walks go on in the next round (one atomic per workgroup)
     if (going) { W.cont[c].node = f; W.cont[c].slot = slot; W.cont[c].dist = d; }
 }
 
@@ -291,7 +292,8 @@ __global__ void k_ut_ends(ut_arrays A, ut_paths P, const uint32_t *__restrict__ 
     else if (eq && P.eqmin[s >> 1] != s) break;            // "print any sequence, but only one of them" :109-118
     take = twice ? 2u : 1u;
     } while (0);
-    const uint32_t pid = mf_wave_reserve(P.cursor, take);
+    __shared__ uint32_t rs_scratch[18];
+    const uint32_t pid = mf_block_reserve(P.cursor, take, rs_scratch);        // (one atomic per workgroup: 2e5 per-wave atomics on the cursor cost 2.4 ms a pass)
     if (PASS == 1 && take) {
         P.pstart[pid] = s;
         P.plen[pid] = (uint32_t)len_nt;
@@ -360,7 +362,8 @@ __global__ void k_ut_walk2(ut_arrays A, const uint32_t *__restrict__ pstart, con
     if (going) flush_bytes(base + d + (uint64_t)(k - 1));
     it.node = f; it.dist = d;
     }
-    const uint32_t c = mf_wave_reserve(n_cont, going ? 1u : 0u);
+    __shared__ uint32_t rs_scratch[18];
+    const uint32_t c = mf_block_reserve(n_cont, going ? 1u : 0u, rs_scratch);
     if (going) cont[c] = it;
 }
 __global__ void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
@@ -475,7 +478,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         ut_paths P; P.eqmin = eqmin.p; P.pstart = nullptr; P.plen = nullptr; P.pkey = nullptr; P.cursor = ctr.p;
         if (n_starts) {
             mf_ktimer tm(ctx, "k_ut_ends");
-            k_ut_ends<0><<<grid_for(n_starts), 256, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
+            k_ut_ends<0><<<grid_for(n_starts, 1024), 1024, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
         }
         unsigned int ncand = 0;
         if (hipMemcpyAsync(&ncand, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
@@ -487,7 +490,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         P.plen = plen.p; P.pkey = pkey.p; P.pstart = pstart.p;
         if (n_starts) {
             mf_ktimer tm(ctx, "k_ut_ends");
-            k_ut_ends<1><<<grid_for(n_starts), 256, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
+            k_ut_ends<1><<<grid_for(n_starts, 1024), 1024, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
         }
         unsigned int np = 0;
         if (hipMemcpyAsync(&np, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
