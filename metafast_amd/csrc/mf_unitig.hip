@@ -8,16 +8,19 @@
 //                   canonical orientation (the other orientation follows by symmetry) + the unique neighbours' indices
 //   U2 k_ut_links   per ORIENTED k-mer (node = 2*index + strand): link f->g exists iff R(f) is unique and L(g) is
 //                   unique; a node without an incoming link is a start (task.run :52-69)
-//   U3 k_ut_walk1   one thread per START node follows the successor links to the end of its path (one random 4-byte read
-//                   per node, nothing written per node): path length + end node.  Walks are cut after 32 / 128 / 512 /
-//                   4096 ... hops and the unfinished ones continue from a compacted work list, so lanes stay busy
-//                   although path lengths differ by orders of magnitude (pointer jumping would cost O(log len) passes
-//                   over ALL nodes: it was 1.06 s of a 3.4 s step)
+//   U2b k_ut_contract one wave per minimizer partition follows the links that stay inside it by pointer jumping in LDS: per
+//                   node ONE jump word (where its chain leaves the partition, hops)
+//   U3 k_ut_walk1   one thread per START node follows the jump words to the end of its path (a load per partition crossed,
+//                   nothing written per node): path length + end node.  Walks are cut after 32 / 128 / 512 / 4096 ... jumps
+//                   and the unfinished ones continue from a compacted work list, so lanes stay busy although path lengths
+//                   differ by orders of magnitude (pointer jumping over ALL nodes would cost O(log len) passes: it was
+//                   1.06 s of a 3.4 s step)
 //   U4 k_ut_ends    per path: length filter and the reference's emission rule canon(start) <= canon(end k-mer), where
 //                   the end k-mer is the one BEYOND the path when the walk stopped on a left branch
 //                   (processSequence :83-107) -- this is what makes a path come out 0, 1 or 2 times
-//   U5 k_ut_walk2   only the EMITTED paths (a small fraction of the nodes) are walked again: bases are written at
-//                   offset + distance, weights are summed in registers (no atomics), same chunking
+//   U5 k_ut_segments / k_ut_walk2   only the EMITTED paths (a small fraction of the nodes) are walked again, node by node:
+//                   a walk over the jump words cuts every path into segments of ~192 nodes, one thread per segment writes
+//                   its bases at offset + distance and adds its weights to the path's sum / min / max
 //
 // Isolated cycles have no start node and are never emitted (same as the reference).
 #include "mf_common.h"
@@ -308,34 +311,57 @@ struct ut_out {
     int32_t *wavg, *wmin, *wmax;
 };
 // second walk, emitted paths only
-struct ut_item2 { uint32_t node, pid, dist; int32_t mn, mx; uint32_t pad; unsigned long long sum; };
-template <bool FIRST>
-__global__ void k_ut_walk2(ut_arrays A, const uint32_t *__restrict__ pstart, const ut_item2 *__restrict__ items, uint32_t n_items,
-                           ut_out O, ut_item2 *__restrict__ cont, unsigned int *__restrict__ n_cont, int chunk) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    bool going = t < n_items;
-    ut_item2 it;
-    it.node = 0; it.pid = 0; it.dist = 0; it.mn = 0x7FFFFFFF; it.mx = 0; it.sum = 0; it.pad = 0;
-    if (going) {
-    if (FIRST) { it.node = pstart[t]; it.pid = t; }
-    else it = items[t];
+// A path is written by ONE thread per SEGMENT of about UT_SEG nodes: a thread per path is as slow as the longest path (1.5e4
+// hops of ~0.6 us each = 8 of this step's 11 ms at 100 M reads).  The cut points come from a walk over the jump words
+// (k_ut_segments: a hop per partition crossed), so a cut is always the first node of a chain inside a partition.
+#define UT_SEG 192u
+struct ut_seg { uint32_t node, pid, dist, stop; };        // nodes at distance [dist, stop) from the path's start; node = UT_NONE: unused entry
+__global__ void k_ut_seg_bound(const uint32_t *__restrict__ plen, uint32_t np, int k, uint32_t *__restrict__ nmax) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < np) nmax[t] = (plen[t] - (uint32_t)k + 1u) / UT_SEG + 1u;      // a cut uses up at least UT_SEG nodes
+}
+__global__ void k_ut_segments(ut_arrays A, const uint32_t *__restrict__ pstart, uint32_t np, const uint64_t *__restrict__ segoff, ut_seg *__restrict__ seg) {
+    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= np) return;
+    uint64_t idx = segoff[pid];
+    uint32_t f = pstart[pid], d = 0, last = 0;
+    ut_seg cur; cur.node = f; cur.pid = pid; cur.dist = 0; cur.stop = 0xFFFFFFFFu;
+    for (;;) {
+        const uint64_t w = A.jump[f];
+        if (w & UT_J_END) break;
+        d += (uint32_t)(w >> 32) & 0x7FFFu;
+        f = (uint32_t)w;
+        if (d - last >= UT_SEG) {
+            cur.stop = d; seg[idx++] = cur;
+            cur.node = f; cur.dist = d; cur.stop = 0xFFFFFFFFu; last = d;
+        }
+    }
+    seg[idx] = cur;
+}
+struct ut_wacc { unsigned long long *sum; };
+__global__ void k_ut_walk2(ut_arrays A, const ut_seg *__restrict__ seg, uint64_t n_seg, ut_out O, unsigned long long *__restrict__ wsum) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seg) return;
+    const ut_seg sg = seg[t];
+    if (sg.node == UT_NONE) return;
     const int k = A.k;
-    const uint64_t base = O.off[it.pid];
+    const uint64_t base = O.off[sg.pid];
     const char *NUC = "AGCT";
-    uint32_t f = it.node, d = it.dist;
+    uint32_t f = sg.node, d = sg.dist;
     if (d == 0) {                                              // the first k-mer in full
         const uint64_t x = A.gk[f >> 1];
         const uint64_t y = (f & 1u) ? mf_revcomp(x, k) : x;
         for (int j = 0; j < k - 1; j++) O.bases[base + j] = (uint8_t)NUC[(y >> (2 * (k - 1 - j))) & 3u];
     }
     // one base per hop: collected in a register and written as aligned 8-byte words (a byte store per hop is one
-    // partial-line write per hop)
+    // partial-line write per hop); a word is stored whole only when all its eight bytes are this segment's
     uint64_t acc = 0; uint32_t nacc = 0;
     auto flush_bytes = [&](uint64_t end_pos) {                  // the nacc bytes ending just before end_pos
         for (uint32_t j = 0; j < nacc; j++) O.bases[end_pos - nacc + j] = (uint8_t)(acc >> (8 * (8 - nacc + j)));
         nacc = 0;
     };
-    for (int step = 0; step < chunk; step++) {
+    unsigned long long sum = 0; int32_t mn = 0x7FFFFFFF, mx = 0;
+    while (d != sg.stop) {
         const uint64_t e = A.node[f];
         const uint64_t pos = base + d + (uint64_t)(k - 1);
         acc = (acc >> 8) | ((uint64_t)(uint8_t)NUC[(e >> 48) & 3u] << 56);
@@ -345,26 +371,24 @@ __global__ void k_ut_walk2(ut_arrays A, const uint32_t *__restrict__ pstart, con
             else flush_bytes(pos + 1);
         }
         const int32_t v = (int32_t)((e >> 32) & 0xFFFFull);
-        it.sum += (unsigned long long)v;
-        it.mn = v < it.mn ? v : it.mn;
-        it.mx = v > it.mx ? v : it.mx;
+        sum += (unsigned long long)v;
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+        d++;
         const uint32_t g = (uint32_t)e;
-        if (g == UT_NONE) {
-            flush_bytes(pos + 1);
-            const uint64_t len = O.off[it.pid + 1] - base;
-            O.wavg[it.pid] = (int32_t)(it.sum / (len - (uint64_t)k + 1));      // (int)(seqWeight / (len - k + 1)) :120-121
-            O.wmin[it.pid] = it.mn; O.wmax[it.pid] = it.mx;
-            going = false;
-            break;
-        }
-        f = g; d++;
+        if (g == UT_NONE) break;
+        f = g;
     }
-    if (going) flush_bytes(base + d + (uint64_t)(k - 1));
-    it.node = f; it.dist = d;
-    }
-    __shared__ uint32_t rs_scratch[18];
-    const uint32_t c = mf_block_reserve(n_cont, going ? 1u : 0u, rs_scratch);
-    if (going) cont[c] = it;
+    flush_bytes(base + d + (uint64_t)(k - 1));
+    atomicAdd(&wsum[sg.pid], sum);
+    atomicMin(&O.wmin[sg.pid], mn);
+    atomicMax(&O.wmax[sg.pid], mx);
+}
+__global__ void k_ut_wfinal(ut_out O, const unsigned long long *__restrict__ wsum, uint32_t np, int k) {
+    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= np) return;
+    const uint64_t len = O.off[pid + 1] - O.off[pid];
+    O.wavg[pid] = (int32_t)(wsum[pid] / (len - (uint64_t)k + 1));          // (int)(seqWeight / (len - k + 1)) :120-121
 }
 __global__ void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -496,7 +520,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if (hipMemcpyAsync(&np, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = mf_set_error("unitigs: ends pass failed"); break;
         }
-        ridx.reset(); lidx.reset(); end_node.reset(); end_dist.reset(); eqmin.reset(); starts.reset(); jump.reset();
+        ridx.reset(); lidx.reset(); end_node.reset(); end_dist.reset(); eqmin.reset(); starts.reset();
         // U5: walk the emitted paths again and write them out
         mf_buf<uint64_t> off, tot; mf_buf<int32_t> wmin, wmax, wavg;
         if ((rc = off.alloc(ctx, (size_t)np + 1)) < 0 || (rc = tot.alloc(ctx, 1)) < 0 || (rc = wmin.alloc(ctx, np)) < 0 ||
@@ -510,33 +534,34 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if ((rc = bases.alloc(ctx, total + 64)) < 0) break;     // slack for the counting kernels' 16-byte loads
         int rounds2 = 0;
         if (np) {
-            mf_buf<ut_item2> c2A, c2B;
-            if ((rc = c2A.alloc(ctx, np)) < 0) break;
             ut_out O; O.off = off.p; O.bases = bases.p; O.wavg = wavg.p; O.wmin = wmin.p; O.wmax = wmax.p;
-            hipMemsetAsync(&ctr.p[2], 0, 4, st);
+            mf_buf<uint32_t> nmax; mf_buf<uint64_t> segoff, stot; mf_buf<unsigned long long> wsum;
+            if ((rc = nmax.alloc(ctx, np)) < 0 || (rc = segoff.alloc(ctx, (size_t)np + 1)) < 0 || (rc = stot.alloc(ctx, 1)) < 0 || (rc = wsum.alloc(ctx, np)) < 0) break;
+            k_ut_seg_bound<<<grid_for(np), 256, 0, st>>>(plen.p, np, k, nmax.p);
+            if ((rc = mf_scan<1>(ctx, nmax.p, segoff.p, (uint64_t)np, stot.p)) < 0) break;
+            uint64_t n_seg = 0;
+            if (hipMemcpyAsync(&n_seg, stot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                rc = mf_set_error("unitigs: scan failed"); break;
+            }
+            mf_buf<ut_seg> seg;
+            if ((rc = seg.alloc(ctx, n_seg)) < 0) break;
+            hipMemsetAsync(seg.p, 0xFF, n_seg * sizeof(ut_seg), st);
+            hipMemsetAsync(wsum.p, 0, (size_t)np * 8, st);
+            k_fill_u32<<<std::min(grid_for(np), 65536u), 256, 0, st>>>(reinterpret_cast<uint32_t *>(wmin.p), np, 0x7FFFFFFFu);
+            hipMemsetAsync(wmax.p, 0, (size_t)np * 4, st);
+            {
+                mf_ktimer tm(ctx, "k_ut_segments");
+                k_ut_segments<<<grid_for(np, 64), 64, 0, st>>>(A, pstart.p, np, segoff.p, seg.p);
+            }
             {
                 mf_ktimer tm(ctx, "k_ut_walk2");
-                k_ut_walk2<true><<<grid_for(np), 256, 0, st>>>(A, pstart.p, nullptr, np, O, c2A.p, &ctr.p[2], chunk_of(0));
+                k_ut_walk2<<<grid_for(n_seg), 256, 0, st>>>(A, seg.p, n_seg, O, wsum.p);
+                k_ut_wfinal<<<grid_for(np), 256, 0, st>>>(O, wsum.p, np, k);
             }
             rounds2 = 1;
-            for (;;) {
-                unsigned int n_cont = 0;
-                if (hipMemcpyAsync(&n_cont, &ctr.p[2], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
-                    rc = mf_set_error("unitigs: emit walk failed: %s", hipGetErrorString(hipGetLastError())); break;
-                }
-                if (!n_cont) break;
-                if (!c2B.p && (rc = c2B.alloc(ctx, n_cont)) < 0) break;
-                hipMemsetAsync(&ctr.p[2], 0, 4, st);
-                ut_item2 *in = (rounds2 & 1) ? c2A.p : c2B.p;
-                ut_item2 *outq = (rounds2 & 1) ? c2B.p : c2A.p;
-                {
-                    mf_ktimer tm(ctx, "k_ut_walk2");
-                    k_ut_walk2<false><<<grid_for(n_cont), 256, 0, st>>>(A, pstart.p, in, n_cont, O, outq, &ctr.p[2], chunk_of(rounds2));
-                }
-                rounds2++;
-            }
-            if (rc < 0) break;
+            if (hipStreamSynchronize(st) != hipSuccess) { rc = mf_set_error("unitigs: emit failed: %s", hipGetErrorString(hipGetLastError())); break; }
         }
+        jump.reset();
         if (hipStreamSynchronize(st) != hipSuccess) { rc = mf_set_error("unitigs: emit failed: %s", hipGetErrorString(hipGetLastError())); break; }
         if (ctx->opt_verbose)
             fprintf(stderr, "[mf] unitigs: good=%llu starts=%u walk_rounds=%d+%d candidates=%u paths=%u bases=%llu\n", (unsigned long long)n,
