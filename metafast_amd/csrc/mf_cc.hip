@@ -46,10 +46,11 @@ __global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ ke
 }
 
 // the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
+template <int MODE>
 __global__ __launch_bounds__(64 * NB_WAVES) void k_cc_adjacency_part(mf_index_view ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
                                                                    uint32_t np, int k, uint32_t *__restrict__ nbr, int abl) {
     __shared__ nb_lds S;
-    nb_for_each(ix, keys, part_off, 0u, np, k, S, abl, 0, 0u, [&](uint64_t v, uint64_t, const uint32_t (&idx)[8], uint32_t, uint32_t, bool have) {
+    nb_for_each<MODE>(ix, keys, part_off, 0u, np, k, S, abl, 0, 0u, [&](uint64_t v, uint64_t, const uint32_t (&idx)[8], uint32_t, uint32_t, bool have) {
         if (!have) return;
         uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
         o[0] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
@@ -391,7 +392,8 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             if (t->index.skm_k && t->index.part_bits && t->d_part_off && !ctx->opt_nbr_global && (n >> t->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
                 const uint32_t np = 1u << t->part_bits;
                 const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
-                k_cc_adjacency_part<<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p, (int)ctx->opt_ablate);
+                k_cc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p, (int)ctx->opt_ablate);
+                k_cc_adjacency_part<2><<<(unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16), 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p, (int)ctx->opt_ablate);
             } else
             k_cc_adjacency<<<cgrid(n), 256, 0, st>>>(mf_view(t->index), t->d_keys, n, k, nbr.p);
         }
@@ -671,6 +673,7 @@ static int dcc_log2(int w) { int l = 0; while ((1 << l) < w) l++; return l; }
 // A wave takes room in the query list DCC_QCHUNK entries at a time (one atomic on the list's cursor per chunk, not per 64
 // k-mers: 600 k atomics on one address cost 7 ms); what it leaves unused of a chunk is marked void (src = ~0).
 #define DCC_QCHUNK 512u
+template <int MODE>
 __global__ __launch_bounds__(64 * NB_WAVES) void k_dcc_adjacency_part(mf_index_view ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
                                                                     uint32_t p_lo, uint32_t p_hi, int k, int lw, uint32_t me, uint32_t *__restrict__ nbr,
                                                                     dcc_query *__restrict__ q, uint32_t qcap, unsigned int *__restrict__ qcount, int abl) {
@@ -680,7 +683,7 @@ __global__ __launch_bounds__(64 * NB_WAVES) void k_dcc_adjacency_part(mf_index_v
     auto void_rest = [&]() {
         for (uint32_t i = qcur + mf_lane(); i < qend; i += 64) if (i < qcap) q[i].src = ~0ull;
     };
-    nb_for_each(ix, keys, part_off, p_lo, p_hi, k, S, abl, lw, me, [&](uint64_t v, uint64_t x, const uint32_t (&idx)[8], uint32_t, uint32_t foreign, bool have) {
+    nb_for_each<MODE>(ix, keys, part_off, p_lo, p_hi, k, S, abl, lw, me, [&](uint64_t v, uint64_t x, const uint32_t (&idx)[8], uint32_t, uint32_t foreign, bool have) {
         if (have) {
             uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
             o[0] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
@@ -819,14 +822,16 @@ extern "C" int mf_dcc_queries(mf_dcc *D, uint64_t *counts) {
         mf_table *t = D->t;
         const uint32_t p_lo = (uint32_t)D->rank << (t->part_bits - D->lw), p_hi = ((uint32_t)D->rank + 1u) << (t->part_bits - D->lw);
         const unsigned grid = (unsigned)std::min<uint64_t>((p_hi - p_lo + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 16);
-        uint64_t cap = std::min<uint64_t>((uint64_t)D->n + (D->n >> 1) + (uint64_t)grid * NB_WAVES * DCC_QCHUNK, 0xFFFFFFF0ull);
+        uint64_t cap = std::min<uint64_t>((uint64_t)D->n + (D->n >> 1) + 2ull * grid * NB_WAVES * DCC_QCHUNK, 0xFFFFFFF0ull);
         for (int attempt = 0; attempt < 2; attempt++) {
             MF_TRY(D->qflat.alloc(ctx, cap));
             MF_HIP(hipMemsetAsync(&D->ctr.p[8], 0, 4, st));
             {
                 mf_ktimer tm(ctx, "k_cc_adjacency");
-                k_dcc_adjacency_part<<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, p_lo, p_hi, D->k, D->lw, (uint32_t)D->rank, D->nbr.p,
-                                                                    D->qflat.p, (uint32_t)cap, &D->ctr.p[8], (int)ctx->opt_ablate);
+                k_dcc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, p_lo, p_hi, D->k, D->lw, (uint32_t)D->rank, D->nbr.p,
+                                                                       D->qflat.p, (uint32_t)cap, &D->ctr.p[8], (int)ctx->opt_ablate);
+                k_dcc_adjacency_part<2><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, p_lo, p_hi, D->k, D->lw, (uint32_t)D->rank, D->nbr.p,
+                                                                       D->qflat.p, (uint32_t)cap, &D->ctr.p[8], (int)ctx->opt_ablate);
             }
             unsigned int c = 0;
             MF_HIP(hipMemcpyAsync(&c, &D->ctr.p[8], 4, hipMemcpyDeviceToHost, st));
@@ -834,7 +839,7 @@ extern "C" int mf_dcc_queries(mf_dcc *D, uint64_t *counts) {
             D->nq = c;
             if (c <= cap) break;
             if (attempt) return mf_set_error("mf_dcc_queries: query list overflow");
-            cap = std::min<uint64_t>((uint64_t)c + (c >> 3) + (uint64_t)grid * NB_WAVES * DCC_QCHUNK, 0xFFFFFFF0ull);   // (more than 1.5 foreign neighbours per k-mer: once more with room for what was asked for)
+            cap = std::min<uint64_t>((uint64_t)c + (c >> 3) + 2ull * grid * NB_WAVES * DCC_QCHUNK, 0xFFFFFFF0ull);   // (more than 1.5 foreign neighbours per k-mer: once more with room for what was asked for)
         }
     }
     MF_HIP(hipMemsetAsync(D->qcur.p, 0, D->qcur.bytes(), st));

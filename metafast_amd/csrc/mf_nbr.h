@@ -24,9 +24,6 @@ struct nb_lds {
     uint16_t pos[NB_WAVES][NB_SLOTS];
 };
 
-__device__ __forceinline__ uint32_t nb_slot(uint64_t key) {
-    return (((uint32_t)key ^ (uint32_t)(key >> 29)) * 0x9E3779B1u) >> 23;          // 9 bits
-}
 // neighbour i of x: i = 2*nuc (append nuc on the right) or 2*nuc+1 (prepend nuc on the left); *ph = its partition hash
 __device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, int k, uint64_t kmask, uint32_t i, uint32_t m_nf, uint32_t m_nl, uint64_t *oriented, uint32_t *ph) {
     const uint32_t nuc = i >> 1;
@@ -38,39 +35,54 @@ __device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, int k, uint64_t kma
     return y < r ? y : r;
 }
 // Calls emit(j, x, idx[8], canonical != oriented [8 bits], foreign [8 bits], have) for every k-mer j of the table (lanes past
-// the end of a partition call it with have = false); idx[i] = table index of
-// neighbour i or NB_NONE.  One wave per partition, partitions dealt round-robin to the waves of the grid.
+// the end of a partition call it with have = false); idx[i] = table index of neighbour i or NB_NONE.
+// MODE 0: one wave per partition, partitions dealt round-robin to the waves of the grid; a partition of more than NB_CAP keys
+//         looks everything up in the HBM index.
+// MODE 1 + MODE 2 (two launches, together = MODE 0's result): 12 % of the benchmark's good k-mers sit in partitions of
+//         353 .. 1408 keys, and their 8 lookups each were HALF of all probes that went to HBM.  MODE 1 leaves those partitions
+//         out; MODE 2 takes only them, one WORKGROUP per partition: the four waves' LDS tables together (2048 slots) hold the
+//         partition, the waves share its k-mers.
 // With lw > 0 the table is rank `me`'s SHARD of a larger one (mf_count_device_shard; owner of a k-mer = top lw bits of its
 // partition hash): neighbours that other ranks own are not looked up, emit gets their numbers in `foreign` (8 bits).
-template <typename F>
+#define NB_BIGCAP (NB_CAP * NB_WAVES)
+__device__ __forceinline__ uint32_t nb_hash(uint64_t key) { return ((uint32_t)key ^ (uint32_t)(key >> 29)) * 0x9E3779B1u; }
+template <int MODE, typename F>
 __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
                                             uint32_t p_lo, uint32_t np, int k, nb_lds &S, int abl, int lw, uint32_t me, F &&emit) {
+    constexpr bool BIG = MODE == 2;
+    constexpr uint32_t SLOTS = BIG ? (uint32_t)(NB_SLOTS * NB_WAVES) : (uint32_t)NB_SLOTS;
+    constexpr int HSHIFT = BIG ? 21 : 23;                                   // 11 / 9 slot bits
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t gw = blockIdx.x * NB_WAVES + wave, nw = gridDim.x * NB_WAVES;
+    const uint32_t first = BIG ? blockIdx.x : blockIdx.x * NB_WAVES + wave, stride = BIG ? gridDim.x : gridDim.x * NB_WAVES;
     const uint64_t kmask = (1ull << (2 * k)) - 1;
-    uint64_t *hk = S.key[wave]; uint16_t *hp = S.pos[wave];
+    uint64_t *hk = BIG ? &S.key[0][0] : S.key[wave]; uint16_t *hp = BIG ? &S.pos[0][0] : S.pos[wave];
     uint64_t *rk = S.rq_key[wave]; uint32_t *rp = S.rq_ph[wave], *ri = S.rq_idx[wave];
     const int shift = 32 - (int)ix.part_bits;
-    for (uint32_t p = p_lo + gw; p < np; p += nw) {
+    const uint32_t tl = BIG ? threadIdx.x : lane, tn = BIG ? (uint32_t)(64 * NB_WAVES) : 64u;      // the team that builds the table
+    auto team_sync = [&]() { if (BIG) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    for (uint32_t p = p_lo + first; p < np; p += stride) {
         const uint64_t lo = part_off[p], hi = part_off[p + 1];
         const uint32_t n = (uint32_t)(hi - lo);
-        if (n == 0) continue;                                               // wave-uniform
-        const bool local = n <= (uint32_t)NB_CAP;
+        if (n == 0) continue;                                               // team-uniform
+        const bool mid = n > (uint32_t)NB_CAP && n <= (uint32_t)NB_BIGCAP;
+        if (MODE == 1 && mid) continue;
+        if (MODE == 2 && !mid) continue;
+        const bool local = BIG || n <= (uint32_t)NB_CAP;
         if (local && !(abl & 4)) {
-            for (uint32_t s = lane; s < (uint32_t)NB_SLOTS; s += 64) hk[s] = MF_EMPTY;
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t j = lane; j < n; j += 64) {
+            for (uint32_t s = tl; s < SLOTS; s += tn) hk[s] = MF_EMPTY;
+            team_sync();
+            for (uint32_t j = tl; j < n; j += tn) {
                 const uint64_t x = keys[lo + j];
-                uint32_t s = nb_slot(x);
+                uint32_t s = nb_hash(x) >> HSHIFT;
                 for (;;) {                                                  // (keys of a table are distinct)
                     const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&hk[s]), (unsigned long long)MF_EMPTY, (unsigned long long)x);
                     if (old == (unsigned long long)MF_EMPTY) { hp[s] = (uint16_t)j; break; }
-                    s = (s + 1u) & (uint32_t)(NB_SLOTS - 1);
+                    s = (s + 1u) & (SLOTS - 1u);
                 }
             }
-            __builtin_amdgcn_wave_barrier();
+            team_sync();
         }
-        for (uint32_t j0 = 0; j0 < n; j0 += 64) {                           // wave-uniform
+        for (uint32_t j0 = BIG ? wave * 64u : 0u; j0 < n; j0 += BIG ? (uint32_t)(64 * NB_WAVES) : 64u) {      // wave-uniform
             const uint32_t j = j0 + lane;
             const bool have = j < n;
             const uint64_t x = have ? keys[lo + j] : 0ull;
@@ -101,12 +113,12 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                 if (have && !((foreign >> i) & 1u)) {
                     if (!((remote >> i) & 1u)) {
                         if (!(abl & 2)) {
-                        uint32_t s = nb_slot(c);
+                        uint32_t s = nb_hash(c) >> HSHIFT;
                         for (;;) {
                             const uint64_t v = hk[s];
                             if (v == c) { idx[i] = (uint32_t)lo + (uint32_t)hp[s]; break; }
                             if (v == MF_EMPTY) break;
-                            s = (s + 1u) & (uint32_t)(NB_SLOTS - 1);
+                            s = (s + 1u) & (SLOTS - 1u);
                         }
                         }
                     } else if (!(abl & 1)) {
@@ -135,7 +147,7 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             }
             emit(lo + j, x, idx, flip, foreign, have);                       // (every lane: the callee may use wave-wide operations)
         }
-        __builtin_amdgcn_wave_barrier();
+        team_sync();                                                        // (the table is cleared for the next partition)
     }
 }
 #endif

@@ -83,10 +83,11 @@ __global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
 }
 
 // the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
+template <int MODE>
 __global__ __launch_bounds__(64 * NB_WAVES) void k_ut_flags_part(mf_index_view ix, ut_arrays A, const uint64_t *__restrict__ part_off, uint32_t np, int abl) {
     __shared__ nb_lds S;
     const int k = A.k;
-    nb_for_each(ix, A.gk, part_off, 0u, np, k, S, abl, 0, 0u, [&](uint64_t i, uint64_t x, const uint32_t (&idx)[8], uint32_t flip, uint32_t, bool have) {
+    nb_for_each<MODE>(ix, A.gk, part_off, 0u, np, k, S, abl, 0, 0u, [&](uint64_t i, uint64_t x, const uint32_t (&idx)[8], uint32_t flip, uint32_t, bool have) {
         if (!have) return;
         uint32_t rcode = UT_CODE_NONE, lcode = UT_CODE_NONE, ridx = UT_NONE, lidx = UT_NONE, ror = 0, lor = 0;
 #pragma unroll
@@ -434,12 +435,28 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.node = succ.p; A.starts = starts.p; A.n_starts = &ctr.p[1];
         A.pal = nullptr; A.jump = nullptr;
         if ((k & 1) == 0) { if ((rc = pal.alloc(ctx, n)) < 0) break; A.pal = pal.p; }   // palindromes need an even k
+        if (ctx->opt_verbose >= 2 && g->part_bits > 0 && g->d_part_off) {       // how the keys spread over the partitions (the neighbour lookup's LDS table takes NB_CAP)
+            const uint32_t npart = 1u << g->part_bits;
+            std::vector<uint64_t> po((size_t)npart + 1);
+            hipMemcpy(po.data(), g->d_part_off, po.size() * 8, hipMemcpyDeviceToHost);
+            uint64_t over = 0, nover = 0, mx = 0, b[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t p = 0; p < npart; p++) {
+                const uint64_t c = po[p + 1] - po[p];
+                if (c > (uint64_t)NB_CAP) { over += c; nover++; }
+                mx = std::max(mx, c);
+                b[c <= 64 ? 0 : c <= 128 ? 1 : c <= 256 ? 2 : c <= 352 ? 3 : c <= 704 ? 4 : 5] += c;
+            }
+            fprintf(stderr, "[mf] unitigs: %u partitions, %.1f keys each, largest %llu; keys in partitions > %d: %.1f %% (%llu partitions); keys by partition size <=64/128/256/352/704/more: %.1f %.1f %.1f %.1f %.1f %.1f %%\n",
+                    npart, (double)n / npart, (unsigned long long)mx, NB_CAP, 100.0 * over / n, (unsigned long long)nover, 100.0 * b[0] / n, 100.0 * b[1] / n, 100.0 * b[2] / n,
+                    100.0 * b[3] / n, 100.0 * b[4] / n, 100.0 * b[5] / n);
+        }
         {
             mf_ktimer tm(ctx, "k_ut_flags");
             if (g->index.skm_k && g->index.part_bits && g->d_part_off && !ctx->opt_nbr_global && (n >> g->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
                 const uint32_t np = 1u << g->part_bits;
                 const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
-                k_ut_flags_part<<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np, (int)ctx->opt_ablate);
+                k_ut_flags_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np, (int)ctx->opt_ablate);
+                k_ut_flags_part<2><<<(unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16), 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np, (int)ctx->opt_ablate);      // partitions of 353 .. 1408 keys: a workgroup each
             } else
             k_ut_flags<<<grid_for(n), 256, 0, st>>>(mf_view(g->index), A);
         }
