@@ -93,22 +93,22 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             // eight such round trips per 64 k-mers with six lanes in 64 busy (ablation, 100 M reads: 25 of the kernel's 39
             // ms).  So the wave collects them in LDS, looks them up 64 at a time, one request per lane, and hands the
             // answers back through LDS.
-            uint32_t remote = 0, foreign = 0;
+            uint32_t remote = 0, foreign = 0, flip = 0;
+            uint64_t cs[8]; uint32_t phs[8];                                // (kept: the eight neighbours cost ~60 instructions each)
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) {
-                uint64_t y; uint32_t ph;
-                nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &ph);
-                if (have && lw && (ph >> (32 - lw)) != me) foreign |= 1u << i;
-                else if (have && !(local && (ph >> shift) == p)) remote |= 1u << i;
+                uint64_t y;
+                cs[i] = nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &phs[i]);
+                flip |= (cs[i] != y) ? (1u << i) : 0u;
+                if (have && lw && (phs[i] >> (32 - lw)) != me) foreign |= 1u << i;
+                else if (have && !(local && (phs[i] >> shift) == p)) remote |= 1u << i;
             }
             uint32_t R;
             const uint32_t rbase = mf_wave_excl_scan((uint32_t)__popc(remote), &R);
-            uint32_t idx[8]; uint32_t flip = 0;
+            uint32_t idx[8];
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) {
-                uint64_t y; uint32_t ph;
-                const uint64_t c = nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &ph);
-                flip |= (c != y) ? (1u << i) : 0u;
+                const uint64_t c = cs[i]; const uint32_t ph = phs[i];
                 idx[i] = NB_NONE;
                 if (have && !((foreign >> i) & 1u)) {
                     if (!((remote >> i) & 1u)) {
