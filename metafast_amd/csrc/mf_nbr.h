@@ -25,14 +25,18 @@ struct nb_lds {
 };
 
 // neighbour i of x: i = 2*nuc (append nuc on the right) or 2*nuc+1 (prepend nuc on the left); *ph = its partition hash
-__device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, int k, uint64_t kmask, uint32_t i, uint32_t m_nf, uint32_t m_nl, uint64_t *oriented, uint32_t *ph) {
+// rcx = mf_revcomp(x, k), computed once per k-mer: the reverse complement of a neighbour is a shift of it (three
+// instructions instead of the ~25 of a full reverse complement, eight times per k-mer)
+__device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, uint64_t rcx, int k, uint64_t kmask, uint32_t i, uint32_t m_nf, uint32_t m_nl, uint64_t *oriented, uint32_t *ph) {
     const uint32_t nuc = i >> 1;
-    uint64_t y;
-    if (i & 1u) { y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2)); *ph = mf_skm_ph_left(y, k, m_nl); }
-    else { y = ((x << 2) | nuc) & kmask; *ph = mf_skm_ph_right(y, m_nf); }
+    uint64_t y, r;
+    if (i & 1u) { y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2)); r = ((rcx << 2) | (uint64_t)(3u - nuc)) & kmask; *ph = mf_skm_ph_left(y, k, m_nl); }
+    else { y = ((x << 2) | nuc) & kmask; r = (rcx >> 2) | ((uint64_t)(3u - nuc) << (2 * k - 2)); *ph = mf_skm_ph_right(y, m_nf); }
     *oriented = y;
-    const uint64_t r = mf_revcomp(y, k);
     return y < r ? y : r;
+}
+__device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, int k, uint64_t kmask, uint32_t i, uint32_t m_nf, uint32_t m_nl, uint64_t *oriented, uint32_t *ph) {
+    return nb_neighbour(x, mf_revcomp(x, k), k, kmask, i, m_nf, m_nl, oriented, ph);
 }
 // Calls emit(j, x, idx[8], canonical != oriented [8 bits], foreign [8 bits], have) for every k-mer j of the table (lanes past
 // the end of a partition call it with have = false); idx[i] = table index of neighbour i or NB_NONE.
@@ -95,10 +99,11 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             // answers back through LDS.
             uint32_t remote = 0, foreign = 0, flip = 0;
             uint64_t cs[8]; uint32_t phs[8];                                // (kept: the eight neighbours cost ~60 instructions each)
+            const uint64_t rcx = mf_revcomp(x, k);
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) {
                 uint64_t y;
-                cs[i] = nb_neighbour(x, k, kmask, i, m_nf, m_nl, &y, &phs[i]);
+                cs[i] = nb_neighbour(x, rcx, k, kmask, i, m_nf, m_nl, &y, &phs[i]);
                 flip |= (cs[i] != y) ? (1u << i) : 0u;
                 if (have && lw && (phs[i] >> (32 - lw)) != me) foreign |= 1u << i;
                 else if (have && !(local && (phs[i] >> shift) == p)) remote |= 1u << i;
