@@ -34,6 +34,10 @@ def _worker(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, f"w{rank}.npy"), rows.numpy())
     same = P.all_gather_ragged(torch.arange(4, dtype=torch.int64) + 10 * rank)                # equal sizes: one collective
     np.save(os.path.join(out_dir, f"s{rank}.npy"), torch.cat(same).numpy())
+    # the three ways a ragged gather travels: equal sizes (above), nearly equal (one padded collective), far apart (a broadcast per rank)
+    near = P.all_gather_ragged(torch.arange(100000 + 50 * rank, dtype=torch.int64) * (rank + 1))
+    far = P.all_gather_ragged(torch.arange(100 + 200000 * rank, dtype=torch.int64) + rank)
+    np.save(os.path.join(out_dir, f"n{rank}.npy"), np.array([int(x.sum()) for x in near] + [len(x) for x in near] + [int(x.sum()) for x in far] + [len(x) for x in far]))
     np.save(os.path.join(out_dir, f"b{rank}.npy"), allb.numpy())
     np.save(os.path.join(out_dir, f"o{rank}.npy"), allo.numpy())
     np.save(os.path.join(out_dir, f"v{rank}.npy"), vecs.numpy())
@@ -60,6 +64,8 @@ def test_exchanges_world2(tmp_path):
         assert r.tolist() == [0, 3]
         assert np.load(tmp_path / f"w{rank}.npy").tolist() == [[1, 1, 1], [2, 2, 2], [2, 2, 2]]
         assert np.load(tmp_path / f"s{rank}.npy").tolist() == [0, 1, 2, 3, 10, 11, 12, 13]
+        a0, a1, f0, f1 = np.arange(100000), np.arange(100050) * 2, np.arange(100), np.arange(200100) + 1
+        assert np.load(tmp_path / f"n{rank}.npy").tolist() == [a0.sum(), a1.sum(), 100000, 100050, f0.sum(), f1.sum(), 100, 200100]
 
 
 def test_single_process_paths():
