@@ -626,7 +626,10 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     // cutter's input, ComponentCutterMain.java:81 -- whose k-mers are nearly all distinct: size those by a sixth, so that
     // a partition's index region stays a few KB and the 8 neighbour probes of a k-mer stay cache-local.
     uint64_t target = (uint64_t)ctx->opt_part_target;
-    if (n_bases / n_reads >= (uint64_t)(8 * k) && target > (uint64_t)ctx->opt_part_target_long) target = (uint64_t)ctx->opt_part_target_long;
+    // (assembled: long sequences, or a caller that filters by length -- ComponentCutterMain.java:81 is the one that does --, or
+    // the pipeline's hint; at low coverage unitigs are short, and partitions planned for reads then hold 4000 distinct k-mers)
+    const bool assembled = n_bases / n_reads >= (uint64_t)(8 * k) || min_len > 0 || ctx->opt_union_samples > 0 || ctx->own_world > 1;
+    if (assembled && target > (uint64_t)ctx->opt_part_target_long) target = (uint64_t)ctx->opt_part_target_long;
     // (a shard of the union of many samples' unitigs: the samples share most of their k-mers -- 0.36 distinct per occurrence at 8
     // samples --, and it is the DISTINCT k-mers of a partition that must fit the LDS tables)
     if ((ctx->own_world >= 4 || ctx->opt_union_samples >= 4) && target == (uint64_t)ctx->opt_part_target_long) target *= 2;
