@@ -38,6 +38,14 @@ def _worker(rank, world, port, out_dir):
     near = P.all_gather_ragged(torch.arange(100000 + 50 * rank, dtype=torch.int64) * (rank + 1))
     far = P.all_gather_ragged(torch.arange(100 + 200000 * rank, dtype=torch.int64) + rank)
     np.save(os.path.join(out_dir, f"n{rank}.npy"), np.array([int(x.sum()) for x in near] + [len(x) for x in near] + [int(x.sum()) for x in far] + [len(x) for x in far]))
+    # the exchanges of the sharded cutter (pipeline.TorchComm), on host tensors
+    comm = P.TorchComm()
+    ints = comm.all_gather_ints([rank + 1, 10 * rank])
+    m = np.array([[1, 2], [3, 0]])                                                # matrix[src][dst] elements
+    a2a = comm.all_to_all(torch.arange(int(m[rank].sum()), dtype=torch.int64) + 100 * rank, m)
+    ag = comm.all_gather(torch.full((3 + 2 * rank,), rank + 7, dtype=torch.int32), [3, 5])
+    mn = comm.all_reduce_min(torch.tensor([5 - rank, 3 + rank, 0x7FFFFFFFFFFFFFFF], dtype=torch.int64))
+    np.save(os.path.join(out_dir, f"c{rank}.npy"), np.array(ints.reshape(-1).tolist() + a2a.tolist() + ag.tolist() + mn.tolist(), dtype=np.int64))
     np.save(os.path.join(out_dir, f"b{rank}.npy"), allb.numpy())
     np.save(os.path.join(out_dir, f"o{rank}.npy"), allo.numpy())
     np.save(os.path.join(out_dir, f"v{rank}.npy"), vecs.numpy())
@@ -64,6 +72,9 @@ def test_exchanges_world2(tmp_path):
         assert r.tolist() == [0, 3]
         assert np.load(tmp_path / f"w{rank}.npy").tolist() == [[1, 1, 1], [2, 2, 2], [2, 2, 2]]
         assert np.load(tmp_path / f"s{rank}.npy").tolist() == [0, 1, 2, 3, 10, 11, 12, 13]
+        # rank 0 receives [1 from rank 0 | 3 from rank 1], rank 1 receives [2 from rank 0 | nothing]
+        want_a2a = [0, 100, 101, 102] if rank == 0 else [1, 2]
+        assert np.load(tmp_path / f"c{rank}.npy").tolist() == [1, 0, 2, 10] + want_a2a + [7] * 3 + [8] * 5 + [4, 3, 0x7FFFFFFFFFFFFFFF]
         a0, a1, f0, f1 = np.arange(100000), np.arange(100050) * 2, np.arange(100), np.arange(200100) + 1
         assert np.load(tmp_path / f"n{rank}.npy").tolist() == [a0.sum(), a1.sum(), 100000, 100050, f0.sum(), f1.sum(), 100, 200100]
 
