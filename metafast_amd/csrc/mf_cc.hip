@@ -664,7 +664,6 @@ struct mf_dcc {
     mf_buf<dcc_kept_rec> keptbuf;
 };
 
-__device__ __forceinline__ uint32_t dcc_owner(uint32_t ph, int lw) { return lw ? ph >> (32 - lw) : 0u; }
 
 static int dcc_log2(int w) { int l = 0; while ((1 << l) < w) l++; return l; }
 // ---- neighbours: own ones looked up partition-locally (mf_nbr.h), the others' become queries (flat list, owner in the top
@@ -803,6 +802,13 @@ extern "C" int mf_dcc_create(mf_ctx *ctx, mf_table *shard, int rank, int world, 
     D->xstart.assign(world + 1, 0);
     if (D->n && !(shard->part_skm && shard->part_bits >= D->lw && shard->d_part_off))
         return mf_set_error("mf_dcc_create: the shard must come from mf_count_device_shard (minimizer partitions)");
+    if (D->n) {                                                           // ... and hold this rank's partitions only
+        const uint32_t p_lo = (uint32_t)rank << (shard->part_bits - D->lw), p_hi = ((uint32_t)rank + 1u) << (shard->part_bits - D->lw);
+        uint64_t lo = 0, hi = 0;
+        MF_HIP(hipMemcpy(&lo, shard->d_part_off + p_lo, 8, hipMemcpyDeviceToHost));
+        MF_HIP(hipMemcpy(&hi, shard->d_part_off + p_hi, 8, hipMemcpyDeviceToHost));
+        if (lo != 0 || hi != shard->n) return mf_set_error("mf_dcc_create: the table holds k-mers of other ranks' partitions (not rank %d's shard of %d)", rank, world);
+    }
     const size_t nt = D->n_total ? D->n_total : 1;
     MF_TRY(D->pg.alloc(ctx, nt)); MF_TRY(D->gsize.alloc(ctx, nt)); MF_TRY(D->gweight.alloc(ctx, nt)); MF_TRY(D->gmin.alloc(ctx, nt));
     { mf_ktimer tm_(ctx, "k_dcc_fill64"); k_dcc_fill64<<<cgrid(nt), 256, 0, ctx->stream>>>(D->gmin.p, nt, DCC_NOKEY); }

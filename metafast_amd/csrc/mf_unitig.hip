@@ -339,7 +339,6 @@ __global__ void k_ut_segments(ut_arrays A, const uint32_t *__restrict__ pstart, 
     }
     seg[idx] = cur;
 }
-struct ut_wacc { unsigned long long *sum; };
 __global__ void k_ut_walk2(ut_arrays A, const ut_seg *__restrict__ seg, uint64_t n_seg, ut_out O, unsigned long long *__restrict__ wsum) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_seg) return;

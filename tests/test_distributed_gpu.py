@@ -197,3 +197,32 @@ def test_two_ranks_one_gpu_rccl(oracle, tmp_path):
     want = _oracle_pipeline(oracle, tmp_path, [107, 117])
     for r in res:
         _same(r, want)
+
+
+def test_dist_cutter_rejects_bad_arguments(gpu_ctx):
+    """error behaviour of the sharded cutter's entry points: a clean MetafastError, nothing half-built"""
+    from util import branchy_reads, to_device
+    from metafast_amd import lib as L
+    b, o = branchy_reads(107, genome_seed=7, n=6000)
+    db, do = to_device(b, o)
+    args = (db.data_ptr(), do.data_ptr(), len(o) - 1, len(b), 31, 0)
+    with pytest.raises(L.MetafastError):
+        gpu_ctx.count_device_shard(*args, 0, 3)                       # world sizes are powers of two
+    with pytest.raises(L.MetafastError):
+        gpu_ctx.count_device_shard(*args, 2, 2)                       # rank < world
+    with pytest.raises(L.MetafastError):
+        gpu_ctx.count_device_shard(db.data_ptr(), do.data_ptr(), len(o) - 1, len(b), 15, 0, 0, 2)     # k >= 20: minimizer partitions decide the owner
+    shard = gpu_ctx.count_device_shard(*args, 1, 2)
+    n = len(shard)
+    assert n > 0
+    with pytest.raises(L.MetafastError):
+        L.DistCutter(gpu_ctx, shard, 1, 2, [0, 5, 5 + n + 1])         # base[] must match the shard
+    whole = gpu_ctx.count_device(*args)
+    with pytest.raises(L.MetafastError):
+        L.DistCutter(gpu_ctx, whole, 0, 2, [0, len(whole), len(whole)])               # a table that holds other ranks' k-mers too
+    D = L.DistCutter(gpu_ctx, shard, 1, 2, [0, 5, 5 + n])
+    q = D.queries()
+    assert q[1] == 0 and q[0] > 0                                     # every foreign neighbour belongs to rank 0
+    with pytest.raises(L.MetafastError):
+        D.set_answers(0, 0)                                           # as many answers as queries
+    D.close()
