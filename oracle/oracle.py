@@ -110,9 +110,12 @@ class Table:
         self.h = lib().or_table_new()
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().or_table_free(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().or_table_free(self.h)
+                self.h = None
+        except Exception:            # (interpreter shutdown: the module is already torn down)
+            pass
 
     def count_buffer(self, bases, offsets, k, min_len=0):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)
@@ -167,9 +170,12 @@ class Seqs:
         self.h = h
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().or_seqs_free(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().or_seqs_free(self.h)
+                self.h = None
+        except Exception:            # (interpreter shutdown: the module is already torn down)
+            pass
 
     def __len__(self):
         return lib().or_seqs_count(self.h)
@@ -209,9 +215,12 @@ class Comps:
         self.h = h
 
     def __del__(self):
-        if getattr(self, "h", None):
-            lib().or_comps_free(self.h)
-            self.h = None
+        try:
+            if getattr(self, "h", None):
+                lib().or_comps_free(self.h)
+                self.h = None
+        except Exception:            # (interpreter shutdown: the module is already torn down)
+            pass
 
     def __len__(self):
         return lib().or_comps_count(self.h)
