@@ -1174,7 +1174,19 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
     mf_buf<uint64_t> toff; MF_TRY(toff.alloc(ctx, (size_t)np + 1));
     k_skm_cap<<<(np + 255) / 256, 256, 0, st>>>(pocc.p, np, pcap.p);
     MF_TRY(mf_scan<1>(ctx, pcap.p, toff.p, np, (uint64_t *)&scal[4]));
-    const uint32_t nbatch = ctx->opt_skm_batches > 0 ? (uint32_t)std::min<int64_t>(ctx->opt_skm_batches, np) : (np >= (1u << 18) ? 8u : (np >= 4096 ? 2u : 1u));
+    // As few batches as the memory allows (every batch is a launch, a scan, a gather and a round trip to the host: 8 -> 2
+    // batches took 4 ms off a 200 ms step): the temporary lists of one batch may take a fifth of the device.
+    uint32_t nbatch = 1;
+    if (ctx->opt_skm_batches > 0) nbatch = (uint32_t)std::min<int64_t>(ctx->opt_skm_batches, np);
+    else {
+        unsigned long long tall = 0;
+        MF_HIP(hipMemcpyAsync(&tall, &scal[4], 8, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+        size_t fr = 0, tot = 0;
+        MF_HIP(hipMemGetInfo(&fr, &tot));
+        const double budget = (ctx->opt_arena_cap_gb > 0 ? (double)ctx->opt_arena_cap_gb * 1e9 : (double)tot) * 0.22;
+        while (nbatch < 64 && nbatch * 2 <= np && (double)tall * 10.0 / nbatch > budget) nbatch *= 2;
+    }
     const uint32_t PB = (np + nbatch - 1) / nbatch;
     std::vector<unsigned long long> tb(nbatch + 1);
     for (uint32_t b = 0; b <= nbatch; b++)
