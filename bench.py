@@ -253,7 +253,7 @@ def main():
             kern[name] = dict(launches=n, ms_per_step=round(per_step_ms, 4), max_launch_ms=round(mx, 4))
             if ab:
                 # a kernel that covers the sample in ONE launch is priced on that launch; one that works through the sample
-                # in batches (k_skm_count, k_gather: 8 launches) on all its launches of a step, the small cutter-table
+                # in batches (k_skm_count, k_gather) on all its launches of a step, the small cutter-table
                 # launches included (slightly pessimistic)
                 lps = n / max(args.steps, 1)
                 ms_sample = mx if lps <= 2.5 else per_step_ms
