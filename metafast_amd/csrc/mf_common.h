@@ -86,7 +86,8 @@ struct mf_ctx {
 };
 
 int  mf_alloc(mf_ctx *ctx, size_t bytes, void **out);   // cached hipMalloc
-void mf_release(mf_ctx *ctx, void *p, size_t bytes);     // back to the cache
+void mf_release(mf_ctx *ctx, void *p, size_t bytes);
+size_t mf_arena_idle(const mf_ctx *ctx);     // back to the cache
 int  mf_collect_timers(mf_ctx *ctx);
 // debugging aid (option verbose >= 2): synchronise after a launch and report which kernel failed / hung
 int  mf_debug_sync(mf_ctx *ctx, const char *what);

@@ -146,6 +146,12 @@ int mf_alloc(mf_ctx *ctx, size_t bytes, void **out) {
     if (!arena_take(ctx, bytes, out)) return mf_set_error("arena: internal error");
     return MF_OK;
 }
+// bytes the arena holds but nobody uses (they can serve the next request without a hipMalloc)
+size_t mf_arena_idle(const mf_ctx *ctx) {
+    size_t t = 0;
+    for (auto &R : ctx->regions) for (auto &f : R.free_spans) t += f.sz;
+    return t;
+}
 void mf_release(mf_ctx *ctx, void *p, size_t bytes) {
     if (!p) return;
     bytes = (bytes + MF_ALIGN - 1) & ~(MF_ALIGN - 1);

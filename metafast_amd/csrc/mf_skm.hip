@@ -1184,7 +1184,8 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         MF_HIP(hipStreamSynchronize(st));
         size_t fr = 0, tot = 0;
         MF_HIP(hipMemGetInfo(&fr, &tot));
-        const double budget = (ctx->opt_arena_cap_gb > 0 ? (double)ctx->opt_arena_cap_gb * 1e9 : (double)tot) * 0.22;
+        double budget = (ctx->opt_arena_cap_gb > 0 ? (double)ctx->opt_arena_cap_gb * 1e9 : (double)tot) * 0.22;
+        if (ctx->opt_arena_cap_gb <= 0) budget = std::min(budget, ((double)fr + (double)mf_arena_idle(ctx)) * 0.5);      // ... and half of what is free right now
         while (nbatch < 64 && nbatch * 2 <= np && (double)tall * 10.0 / nbatch > budget) nbatch *= 2;
     }
     const uint32_t PB = (np + nbatch - 1) / nbatch;
