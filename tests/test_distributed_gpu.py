@@ -226,3 +226,25 @@ def test_dist_cutter_rejects_bad_arguments(gpu_ctx):
     with pytest.raises(L.MetafastError):
         D.set_answers(0, 0)                                           # as many answers as queries
     D.close()
+
+
+def test_sharded_cutter_with_nothing_to_cut():
+    """samples without a single unitig (random reads, no k-mer seen twice): empty shards on every rank, no components, no hang"""
+    rng = np.random.default_rng(5)
+    from util import random_reads
+    inputs = [random_reads(rng, 300, 120, 160) for _ in range(2)]
+    res = _virtual_ranks(2, inputs, 100, 1000)
+    for comps, info in res:
+        assert comps == [] and info["vertices"] == 0 and info["members"] == 0 and info["levels"] == 1
+
+
+def test_sharded_cutter_small_graph_many_ranks(oracle):
+    """a graph of a few thousand k-mers over 8 ranks (some threshold levels leave ranks with nothing alive): the oracle's components"""
+    from util import branchy_reads
+    inputs = [branchy_reads(107, genome_seed=7, n=2500)]
+    want = _oracle_components(oracle, inputs, 20, 400)
+    res = _virtual_ranks(8, inputs, 20, 400)
+    assert len(want) > 0
+    for comps, info in res:
+        assert [(a, w, t) for a, w, t, _ in comps] == [(a, w, t) for a, w, t, _ in want]
+        assert all(np.array_equal(np.sort(g[3]), np.sort(x[3])) for g, x in zip(comps, want))
