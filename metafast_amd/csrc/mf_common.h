@@ -396,11 +396,17 @@ static __global__ __launch_bounds__(1024) void k_scan(const uint32_t *__restrict
     for (uint64_t i = lo; i < hi; i++) { uint64_t v = in[i]; v = (v + (PAD - 1)) & ~(uint64_t)(PAD - 1); s += v; }
     sums[threadIdx.x] = s;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t acc = 0;
-        for (int i = 0; i < 1024; i++) { uint64_t t = sums[i]; sums[i] = acc; acc += t; }
-        *total = acc;
-        out[n] = acc;
+    if (threadIdx.x < 64) {                               // the 1024 partial sums: 16 per lane of one wave, then a wave scan
+        const uint32_t lane = threadIdx.x;
+        uint64_t loc[16], s16 = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { loc[j] = sums[lane * 16 + j]; s16 += loc[j]; }
+        uint64_t inc = s16;
+        for (int d = 1; d < 64; d <<= 1) { const uint64_t o = __shfl_up(inc, d, 64); if ((int)lane >= d) inc += o; }
+        uint64_t acc = inc - s16;
+#pragma unroll
+        for (int j = 0; j < 16; j++) { const uint64_t t = loc[j]; sums[lane * 16 + j] = acc; acc += t; }
+        if (lane == 63) { *total = inc; out[n] = inc; }
     }
     __syncthreads();
     uint64_t base = sums[threadIdx.x];
