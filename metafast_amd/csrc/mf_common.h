@@ -326,7 +326,8 @@ __device__ __forceinline__ uint32_t mf_skm_ph(uint64_t key, int k) {
 }
 // The 8 graph neighbours of x share all but one of its M-mers, so their minimizers need ONE pass over x, not eight:
 // smallest M-mer hash of x without its first M-mer (right neighbours drop it) and without its last (left neighbours).
-__device__ __forceinline__ void mf_skm_nbr_mins(uint64_t x, int k, uint32_t *no_first, uint32_t *no_last) {
+// (*own: the k-mer's own minimizer hash, before the re-mix: equal minimizer hashes mean equal partitions)
+__device__ __forceinline__ void mf_skm_nbr_mins(uint64_t x, int k, uint32_t *no_first, uint32_t *no_last, uint32_t *own = nullptr) {
     const uint32_t mm = (1u << (2 * MF_SKM_M)) - 1u;
     uint32_t f = (uint32_t)(x >> (2 * (k - MF_SKM_M))) & mm, r = mf_mmer_rc(f);
     uint32_t h = mf_mmer_hash(f < r ? f : r);
@@ -340,18 +341,22 @@ __device__ __forceinline__ void mf_skm_nbr_mins(uint64_t x, int k, uint32_t *no_
         if (j > 0) b = h < b ? h : b;
     }
     *no_first = a; *no_last = b;
+    if (own) *own = h < b ? h : b;                    // (h: the last M-mer's)
 }
 // partition hash of the neighbour y = x[1..]+c (right) / c+x[..k-2] (left) from the matching minimum of x
-__device__ __forceinline__ uint32_t mf_skm_ph_right(uint64_t y, uint32_t no_first_of_x) {
+// (_mn: the neighbour's minimizer hash itself; the partition hash is its re-mix)
+__device__ __forceinline__ uint32_t mf_skm_mn_right(uint64_t y, uint32_t no_first_of_x) {
     const uint32_t f = (uint32_t)y & ((1u << (2 * MF_SKM_M)) - 1u), r = mf_mmer_rc(f);
     const uint32_t h = mf_mmer_hash(f < r ? f : r);
-    return mf_remix32(h < no_first_of_x ? h : no_first_of_x);
+    return h < no_first_of_x ? h : no_first_of_x;
 }
-__device__ __forceinline__ uint32_t mf_skm_ph_left(uint64_t y, int k, uint32_t no_last_of_x) {
+__device__ __forceinline__ uint32_t mf_skm_mn_left(uint64_t y, int k, uint32_t no_last_of_x) {
     const uint32_t f = (uint32_t)(y >> (2 * (k - MF_SKM_M))) & ((1u << (2 * MF_SKM_M)) - 1u), r = mf_mmer_rc(f);
     const uint32_t h = mf_mmer_hash(f < r ? f : r);
-    return mf_remix32(h < no_last_of_x ? h : no_last_of_x);
+    return h < no_last_of_x ? h : no_last_of_x;
 }
+__device__ __forceinline__ uint32_t mf_skm_ph_right(uint64_t y, uint32_t no_first_of_x) { return mf_remix32(mf_skm_mn_right(y, no_first_of_x)); }
+__device__ __forceinline__ uint32_t mf_skm_ph_left(uint64_t y, int k, uint32_t no_last_of_x) { return mf_remix32(mf_skm_mn_left(y, k, no_last_of_x)); }
 struct mf_slot { uint64_t key; uint32_t idx; uint32_t val; };
 // ascending (key, value) order (mf_sort.hip); select + sort of a table's entries with count > threshold (mf_table.hip)
 int mf_sort_pairs(mf_ctx *ctx, const uint64_t *d_keys_in, const uint16_t *d_vals_in, uint64_t n, int key_bits, uint64_t *d_keys_out,

@@ -38,6 +38,16 @@ __device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, uint64_t rcx, int k
 __device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, int k, uint64_t kmask, uint32_t i, uint32_t m_nf, uint32_t m_nl, uint64_t *oriented, uint32_t *ph) {
     return nb_neighbour(x, mf_revcomp(x, k), k, kmask, i, m_nf, m_nl, oriented, ph);
 }
+// the same with the neighbour's minimizer hash instead of its partition hash (= mf_remix32 of it: two quarter-rate multiplies
+// that only the tenth of the neighbours in other partitions needs)
+__device__ __forceinline__ uint64_t nb_neighbour_mn(uint64_t x, uint64_t rcx, int k, uint64_t kmask, uint32_t i, uint32_t m_nf, uint32_t m_nl, uint64_t *oriented, uint32_t *mn) {
+    const uint32_t nuc = i >> 1;
+    uint64_t y, r;
+    if (i & 1u) { y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2)); r = ((rcx << 2) | (uint64_t)(3u - nuc)) & kmask; *mn = mf_skm_mn_left(y, k, m_nl); }
+    else { y = ((x << 2) | nuc) & kmask; r = (rcx >> 2) | ((uint64_t)(3u - nuc) << (2 * k - 2)); *mn = mf_skm_mn_right(y, m_nf); }
+    *oriented = y;
+    return y < r ? y : r;
+}
 // Calls emit(j, x, idx[8], canonical != oriented [8 bits], foreign [8 bits], have) for every k-mer j of the table (lanes past
 // the end of a partition call it with have = false); idx[i] = table index of neighbour i or NB_NONE.
 // MODE 0: one wave per partition, partitions dealt round-robin to the waves of the grid; a partition of more than NB_CAP keys
@@ -61,7 +71,6 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     uint64_t *hk = BIG ? &S.key[0][0] : S.key[wave]; uint16_t *hp = BIG ? &S.pos[0][0] : S.pos[wave];
     uint64_t *rk = S.rq_key[wave]; uint32_t *rp = S.rq_ph[wave], *ri = S.rq_idx[wave];
-    const int shift = 32 - (int)ix.part_bits;
     const uint32_t tl = BIG ? threadIdx.x : lane, tn = BIG ? (uint32_t)(64 * NB_WAVES) : 64u;      // the team that builds the table
     auto team_sync = [&]() { if (BIG) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
     for (uint32_t p = p_lo + first; p < np; p += stride) {
@@ -90,8 +99,8 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             const uint32_t j = j0 + lane;
             const bool have = j < n;
             const uint64_t x = have ? keys[lo + j] : 0ull;
-            uint32_t m_nf = 0, m_nl = 0;
-            mf_skm_nbr_mins(x, k, &m_nf, &m_nl);
+            uint32_t m_nf = 0, m_nl = 0, m_own = 0;
+            mf_skm_nbr_mins(x, k, &m_nf, &m_nl, &m_own);
             // Pass 1: which neighbours live in another partition (about one in ten)?  Those are REQUESTS for the HBM index --
             // a directory entry, then a slot: two dependent cache misses.  Looked up where they arise they cost the wave
             // eight such round trips per 64 k-mers with six lanes in 64 busy (ablation, 100 M reads: 25 of the kernel's 39
@@ -103,10 +112,12 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) {
                 uint64_t y;
-                cs[i] = nb_neighbour(x, rcx, k, kmask, i, m_nf, m_nl, &y, &phs[i]);
+                cs[i] = nb_neighbour_mn(x, rcx, k, kmask, i, m_nf, m_nl, &y, &phs[i]);       // phs: minimizer hashes, re-mixed only where a partition hash is needed
                 flip |= (cs[i] != y) ? (1u << i) : 0u;
-                if (have && lw && (phs[i] >> (32 - lw)) != me) foreign |= 1u << i;
-                else if (have && !(local && (phs[i] >> shift) == p)) remote |= 1u << i;
+                // the same minimizer = the same partition; another minimizer that lands in this partition all the same (one in
+                // 2^part_bits) is simply looked up through the index
+                if (have && lw && (mf_remix32(phs[i]) >> (32 - lw)) != me) foreign |= 1u << i;
+                else if (have && !(local && phs[i] == m_own)) remote |= 1u << i;
             }
             uint32_t R;
             const uint32_t rbase = mf_wave_excl_scan((uint32_t)__popc(remote), &R);
@@ -129,7 +140,7 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                     } else if (!(abl & 1)) {
                         const uint32_t at = rbase + (uint32_t)__popc(remote & ((1u << i) - 1u));
                         if (at < (uint32_t)NB_RQ) { rk[at] = c; rp[at] = ph; }
-                        else { uint32_t ii, val; if (mf_index_find_ph(ix, c, ph, &ii, &val)) idx[i] = ii; }
+                        else { uint32_t ii, val; if (mf_index_find_ph(ix, c, mf_remix32(ph), &ii, &val)) idx[i] = ii; }
                     }
                 }
             }
@@ -138,7 +149,7 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                 const uint32_t Rl = R < (uint32_t)NB_RQ ? R : (uint32_t)NB_RQ;
                 for (uint32_t r = lane; r < Rl; r += 64) {
                     uint32_t ii, val;
-                    ri[r] = mf_index_find_ph(ix, rk[r], rp[r], &ii, &val) ? ii : NB_NONE;
+                    ri[r] = mf_index_find_ph(ix, rk[r], mf_remix32(rp[r]), &ii, &val) ? ii : NB_NONE;
                 }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
