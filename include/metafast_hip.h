@@ -77,6 +77,14 @@ int  mf_ctx_reset_timers(mf_ctx *ctx);
  * All files go into ONE table (paired files are summed). */
 int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len,
                    mf_table **out);
+/* The same load, keeping only the k-mers with count > threshold: KmersCounterMain.runImpl (src/tools/KmersCounterMain.java:77-99)
+ * is loadReads followed by printKmers(hm, maximalBadFrequency, ...), which writes the entries with value > threshold only
+ * (src/io/IOUtils.java:52-60).  The cut is made inside the counting kernels (mf_count_device_above), so a sample with more
+ * than 2^32 distinct k-mers never exists as an uncut table; mf_table_write_kmers / mf_table_hist on the result give the same
+ * .kmers.bin / .stat.txt as on the uncut table for every threshold >= this one.  *n_distinct_all (may be NULL) = distinct
+ * k-mers before the cut (the "k-mers found" log line, KmersCounterMain.java:101-103). */
+int mf_count_reads_above(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, int threshold,
+                         mf_table **out, uint64_t *n_distinct_all);
 /* Same, for reads already resident in HBM: d_bases = concatenated ASCII bases (ACGT, either case,
  * no N), d_offsets = uint64[n_reads+1] with offsets[0]=0, offsets[n_reads]=n_bases.  d_bases must
  * be 16-byte aligned and readable up to the next multiple of 16 bytes.  This is the device half of

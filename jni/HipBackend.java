@@ -11,6 +11,9 @@ public final class HipBackend {
     public static native void ctxDestroy(long ctx);
     /** IOUtils.loadReads (src/io/IOUtils.java:772) */
     public static native long countReads(long ctx, String[] files, int k, int minSeqLen);
+    /** loadReads + the cut of printKmers (value > threshold) inside the counting kernels (KmersCounterMain.java:77-99):
+     *  { table of the k-mers handed on, hm.size() before the cut } */
+    public static native long[] countReadsAbove(long ctx, String[] files, int k, int minSeqLen, int threshold);
     /** hm.size() */
     public static native long tableSize(long table);
     /** IOUtils.printKmers (src/io/IOUtils.java:45): returns the number of good k-mers written */

@@ -49,6 +49,17 @@ JNIEXPORT jlong JNICALL Java_io_HipBackend_countReads(JNIEnv *e, jclass, jlong c
     if (mf_count_reads((mf_ctx *)(intptr_t)ctx, f.p.data(), (int)f.p.size(), k, minLen, &t) < 0) { raise(e); return 0; }
     return (jlong)(intptr_t)t;
 }
+// long[2] = { table handle, distinct k-mers before the cut }
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_countReadsAbove(JNIEnv *e, jclass, jlong ctx, jobjectArray files, jint k, jint minLen, jint threshold) {
+    utf_array f(e, files);
+    mf_table *t = nullptr; uint64_t n_all = 0;
+    if (mf_count_reads_above((mf_ctx *)(intptr_t)ctx, f.p.data(), (int)f.p.size(), k, minLen, threshold, &t, &n_all) < 0) { raise(e); return nullptr; }
+    jlongArray r = e->NewLongArray(2);
+    if (!r) { mf_table_destroy(t); return nullptr; }
+    const jlong v[2] = {(jlong)(intptr_t)t, (jlong)n_all};
+    e->SetLongArrayRegion(r, 0, 2, v);
+    return r;
+}
 JNIEXPORT jlong JNICALL Java_io_HipBackend_tableSize(JNIEnv *e, jclass, jlong table) {
     uint64_t n = 0, total = 0;
     if (mf_table_stats((mf_table *)(intptr_t)table, &n, &total) < 0) { raise(e); return 0; }

@@ -201,7 +201,11 @@ static string run_kmer_counter(Env &e, const Args &a, const vector<string> &file
     for (auto &f : files) logmsg("INFO", "Loading file %s...", basename_of(f).c_str());
     mf_table *t = nullptr;
     auto fp = cptrs(files);
-    check(mf_count_reads(ctx, fp.data(), (int)fp.size(), k, 0, &t));
+    // loadReads + printKmers(hm, b, ...) (KmersCounterMain.java:77-99): only the entries with value > b are handed on, so the
+    // cut is made inside the counting kernels and the uncut table (> 2^32 entries for a large sample) never exists; the
+    // .stat.txt histogram still covers every counted k-mer (the table remembers what the cut dropped)
+    uint64_t size = 0;
+    check(mf_count_reads_above(ctx, fp.data(), (int)fp.size(), k, 0, b, &t, &size));
     mkdirs(out_dir); mkdirs(stats_dir);
     string name;                                                             // getName :122-137
     if (files.size() == 2) {
@@ -211,9 +215,8 @@ static string run_kmer_counter(Env &e, const Args &a, const vector<string> &file
         else name = n1 + "+";
     } else name = library_name(files[0]) + (files.size() > 1 ? "+" : "");
     string out = out_dir + "/" + name + ".kmers.bin", st = stats_dir + "/" + name + ".stat.txt";
-    uint64_t good = 0, size = 0;
+    uint64_t good = 0;
     check(mf_table_write_kmers(t, b, out.c_str(), st.c_str(), &good));
-    check(mf_table_stats(t, &size, nullptr));
     logmsg("INFO", "%s k-mers found, %s (%.1f%%) of them is good (not erroneous)", group_digits(size).c_str(), group_digits(good).c_str(),
            size ? good * 100.0 / size : 0.0);
     if (size == 0) logmsg("WARN", "No k-mers found in reads! Perhaps you reads file is empty or k-mer size is too big");

@@ -657,10 +657,21 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         // A third radix level costs a whole extra pass over the records (k = 21, 100 M reads: 23 bits, +96 ms).  The LDS table
         // limits a partition's DISTINCT k-mers, the plan sizes it by occurrences: up to twice the target is tried with two
         // full levels first (if a partition turns out too rich the call ends up on the k-mer path, with its own plan).
+        // The counting pass runs on partitions TWICE the planned size (one bit fewer): its per-partition costs (directory,
+        // barriers, the sweep of the LDS table) halve, and the gather cuts every counting partition in two by the next bit of
+        // the partition hash, so the table still has the B bits of partitions the graph kernels are planned for (k_gather_split).
+        // Forced plans (l1_bits / l2_bits: tests) are taken as the counting plan.
         std::vector<int> slv = lv;
-        if (ctx->opt_l1_bits < 0 && slv.size() == 3 && total_bits <= 2 * MF_MAX_DIGIT_BITS + 1 &&
-            (n_occ >> (2 * MF_MAX_DIGIT_BITS)) <= 2 * target)
-            slv = {MF_MAX_DIGIT_BITS, MF_MAX_DIGIT_BITS};
+        if (ctx->opt_l1_bits < 0) {
+            int Bc = B > 0 ? B - 1 : 0;
+            if (ctx->own_world > 1) { int lw = 0; while ((1 << lw) < ctx->own_world) lw++; if (Bc < lw) Bc = lw; }
+            slv.clear();
+            const int levels = std::max(1, (Bc + MF_MAX_DIGIT_BITS - 1) / MF_MAX_DIGIT_BITS);
+            int rest = Bc;
+            for (int i = 0; i < levels; i++) { int b = (rest + (levels - i) - 1) / (levels - i); slv.push_back(b); rest -= b; }
+            if (slv.size() == 3 && Bc <= 2 * MF_MAX_DIGIT_BITS + 1 && (n_occ >> (2 * MF_MAX_DIGIT_BITS)) <= 4 * target)
+                slv = {MF_MAX_DIGIT_BITS, MF_MAX_DIGIT_BITS};
+        }
         int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, slv, scal.p, thr, n_all, out);
         if (rc != MF_SKM_FALLBACK) return rc;
     }

@@ -612,8 +612,9 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
 }
 
 // IOUtils.loadReads (src/io/IOUtils.java:772-803): all files into one table
-extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, mf_table **out) {
-    if (!ctx || !out || (nfiles && !files)) return mf_set_error("mf_count_reads: NULL argument");
+static int count_reads_impl(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, int threshold, mf_table **out,
+                            uint64_t *n_distinct_all, const char *who) {
+    if (!ctx || !out || (nfiles && !files)) return mf_set_error("%s: NULL argument", who);
     *out = nullptr;
     if (k < 1) return mf_set_error("The size of k-mer must be at least 1.");
     if (k > 31) return mf_set_error("The size of k-mer must be no more than 31.");
@@ -622,11 +623,20 @@ extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles,
     uint64_t nr = 0, nb = 0; double tp = 0, th = 0;
     MF_TRY(load_reads_to_device(ctx, files, nfiles, db, doff, &nr, &nb, &tp, &th));
     const double t2 = now();
-    int rc = mf_count_core(ctx, db.p, doff.p, nr, nb, k, min_read_len, out, -1, nullptr);
+    int rc = mf_count_core(ctx, db.p, doff.p, nr, nb, k, min_read_len, out, threshold < 0 ? -1 : threshold, n_distinct_all);
     if (ctx->opt_verbose)
         fprintf(stderr, "[mf] count_reads: read+parse %.3f s, offsets+H2D %.3f s, count %.3f s (%llu reads, %llu bases, %d host threads)\n",
                 tp, th, now() - t2, (unsigned long long)nr, (unsigned long long)nb, ctx->host_threads);
     return rc;
+}
+extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, mf_table **out) {
+    return count_reads_impl(ctx, files, nfiles, k, min_read_len, -1, out, nullptr, "mf_count_reads");
+}
+// KmersCounterMain.runImpl (src/tools/KmersCounterMain.java:77-99): loadReads, then printKmers keeps value > threshold
+extern "C" int mf_count_reads_above(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, int threshold, mf_table **out,
+                                    uint64_t *n_distinct_all) {
+    if (n_distinct_all) *n_distinct_all = 0;
+    return count_reads_impl(ctx, files, nfiles, k, min_read_len, threshold, out, n_distinct_all, "mf_count_reads_above");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -529,7 +529,7 @@ __device__ __forceinline__ uint32_t skm_pass_of(uint64_t key) {
 #define C2_FILL 3400             // claims beyond which a partition is counted again in several passes
 #define C2_QN 128                // queue entries per wave (keys): drained at 64, one push (<= 64 keys) between checks
 #define C2_LH 128                // bins of the workgroup's dropped-count histogram (a cut with thr >= C2_LH is made after the kernel)
-#define C2_ITEMS 768             // item entries per wave: 64 records x 10 items + two steps of padding (the read-ahead of the last step runs past them, unused)
+#define C2_ITEMS 896             // item entries per wave: 64 records x 10 items + two (wide) steps of padding (the read-ahead of the last step runs past them, unused)
 #define C2_W 2                   // k-mers per item
 static constexpr size_t C2_LDS = (size_t)C2_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8) + 2 * C2_LH * 4 + 32;
 static_assert(C2_LDS <= 80 * 1024, "two workgroups per CU");
@@ -658,7 +658,7 @@ __device__ __forceinline__ void c2_drain(const c2_wave &L, uint32_t &qn, uint32_
 // record slot, [10,15) funnel-shift amount, [15] the item starts in the record's second word.
 template <int K>
 __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t &it, skm_v4 &W, uint32_t &it1, uint32_t &qn,
-                                        uint32_t &won_acc, uint32_t *part_over, int ablate, uint32_t P, uint32_t pass) {
+                                        uint32_t &won_acc, uint32_t *part_over, uint32_t P, uint32_t pass) {
     constexpr int sh = 64 - 2 * K;              // 2 .. 24
     constexpr int nb = 2 * K - 34;              // bit of the high word where a new base enters the reverse complement
     const uint32_t lane = (uint32_t)mf_lane();
@@ -706,9 +706,6 @@ __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t 
     uint32_t it2; skm_v4 W_n; unsigned long long save;
     const uint32_t ia2 = L.items0 + 2u * (i0 + 128u + lane);
     const uint32_t ra1 = L.rb0 | (it1 & 0x3F0u);                           // (rb0 is 1024-byte aligned)
-    if (ablate & 16) { if ((ka[0] ^ ka[1]) == 0x12345u) *part_over = 1u; ret[0] = ret[1] = 0; live[0] = live[1] = 0;
-        asm volatile("ds_read_u16 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(it2), "=&v"(W_n) : "v"(ia2), "v"(ra1) : "memory"); }
-    else
     asm volatile("s_mov_b64 %4, exec\n\tds_read_u16 %2, %5\n\tds_read_b128 %3, %6\n\t"
                  "s_mov_b64 exec, %7\n\tds_cmpst_rtn_b64 %0, %9, %11, %12\n\t"
                  "s_mov_b64 exec, %8\n\tds_cmpst_rtn_b64 %1, %10, %11, %13\n\t"
@@ -733,35 +730,137 @@ __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t 
                  : "=&s"(save)
                  : "s"(ok[0]), "s"(ok[1]), "v"(aa[0]), "v"(aa[1]), "v"(one)
                  : "memory");
-    if (!(ablate & 8)) {
-        won_acc += (uint32_t)__popcll(won[0]) + (uint32_t)__popcll(won[1]);
+    won_acc += (uint32_t)__popcll(won[0]) + (uint32_t)__popcll(won[1]);
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            if (coll[u] != 0ull) {
-                const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(coll[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)coll[u], qn));
-                c2_push64(coll[u], L.qk0 + 8u * at, key[u]);
-                qn += (uint32_t)__popcll(coll[u]);
-                while (qn >= 64u) { if (ablate & 4) qn = 0; else c2_drain(L, qn, won_acc, part_over); }       // (then qn < 64: + one push <= C2_QN)
-            }
+    for (int u = 0; u < 2; u++) {
+        if (coll[u] != 0ull) {
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(coll[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)coll[u], qn));
+            c2_push64(coll[u], L.qk0 + 8u * at, key[u]);
+            qn += (uint32_t)__popcll(coll[u]);
+            while (qn >= 64u) c2_drain(L, qn, won_acc, part_over);       // (then qn < 64: + one push <= C2_QN)
         }
     }
     it = it1; W = W_n; it1 = it2;
 }
 
+// ---- the same step, TWO items per lane (items i0 + lane and i0 + 64 + lane): four probes, two record reads and two item
+// reads in flight behind ONE wait, the loop / queue / EXEC bookkeeping once per 256 k-mers instead of once per 128.
+template <int K>
+__device__ __forceinline__ void c2_item_keys(uint32_t it, const skm_v4 &W, uint64_t (&key)[2], uint32_t (&s)[2], unsigned long long (&live)[2],
+                                             uint32_t P, uint32_t pass) {
+    constexpr int sh = 64 - 2 * K;
+    constexpr int nb = 2 * K - 34;
+    const uint32_t nk = it & 3u;
+    const uint32_t sa = it >> 10;
+    unsigned long long q;
+    asm("v_cmp_lt_u32_e64 %0, %2, %1" : "=s"(q) : "v"(it), "s"(0x7FFFu));
+    const uint32_t A = skm_sel(W.x, W.y, q), B = skm_sel(W.y, W.z, q), C = skm_sel(W.z, W.w, q);
+    const uint32_t hr = __builtin_amdgcn_alignbit(A, B, sa), lr = __builtin_amdgcn_alignbit(B, C, sa);
+    uint32_t fh[2], fl[2], ch[2], cl[2];
+    fh[0] = hr >> sh; fl[0] = __builtin_amdgcn_alignbit(hr, lr, sh);
+    { const uint32_t Vh = __builtin_amdgcn_alignbit(hr, lr, 30), Vl = lr << 2; fh[1] = Vh >> sh; fl[1] = __builtin_amdgcn_alignbit(Vh, Vl, sh); }
+    uint32_t rh, rl;
+    {
+        const uint32_t H = c2_swap_pairs(__builtin_bitreverse32(~fl[0])), Lo = c2_swap_pairs(__builtin_bitreverse32(~fh[0]));
+        rh = H >> sh;
+        rl = __builtin_amdgcn_alignbit(H, Lo, sh);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        if (u) {
+            rl = __builtin_amdgcn_alignbit(rh, rl, 2);
+            rh = (rh >> 2) | (((~fl[u]) & 3u) << nb);
+        }
+        const bool lt = (((uint64_t)fh[u] << 32) | fl[u]) < (((uint64_t)rh << 32) | rl);
+        ch[u] = lt ? fh[u] : rh;
+        cl[u] = lt ? fl[u] : rl;
+    }
+    live[0] = c2_gt<0>(nk); live[1] = c2_gt<1>(nk);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        key[u] = ((uint64_t)ch[u] << 32) | cl[u];
+        s[u] = c2_slot(ch[u], cl[u]);
+    }
+    if (P > 1u) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) live[u] &= c2_lt_u32((skm_pass_of(key[u]) & (P - 1u)) ^ pass, 1u);
+    }
+}
+template <int K>
+__device__ __forceinline__ void c2_step_wide(const c2_wave &L, uint32_t i0, uint32_t (&it)[2], skm_v4 (&W)[2], uint32_t (&it1)[2], uint32_t &qn,
+                                             uint32_t &won_acc, uint32_t *part_over, uint32_t P, uint32_t pass) {
+    const uint32_t lane = (uint32_t)mf_lane();
+    uint64_t key[4], ret[4]; uint32_t s[4], ka[4]; unsigned long long live[4];
+    {
+        uint64_t k2[2]; uint32_t s2[2]; unsigned long long l2[2];
+        c2_item_keys<K>(it[0], W[0], k2, s2, l2, P, pass);
+        key[0] = k2[0]; key[1] = k2[1]; s[0] = s2[0]; s[1] = s2[1]; live[0] = l2[0]; live[1] = l2[1];
+        c2_item_keys<K>(it[1], W[1], k2, s2, l2, P, pass);
+        key[2] = k2[0]; key[3] = k2[1]; s[2] = s2[0]; s[3] = s2[1]; live[2] = l2[0]; live[3] = l2[1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) ka[u] = L.tk0 + 8u * s[u];
+    uint32_t it2[2]; skm_v4 Wn[2]; unsigned long long save;
+    const uint32_t ia2 = L.items0 + 2u * (i0 + 256u + lane);
+    const uint32_t ra0 = L.rb0 | (it1[0] & 0x3F0u), ra1 = L.rb0 | (it1[1] & 0x3F0u);
+    asm volatile("s_mov_b64 %8, exec\n\tds_read_u16 %4, %9\n\tds_read_u16 %5, %9 offset:128\n\tds_read_b128 %6, %10\n\tds_read_b128 %7, %11\n\t"
+                 "s_mov_b64 exec, %12\n\tds_cmpst_rtn_b64 %0, %16, %20, %21\n\t"
+                 "s_mov_b64 exec, %13\n\tds_cmpst_rtn_b64 %1, %17, %20, %22\n\t"
+                 "s_mov_b64 exec, %14\n\tds_cmpst_rtn_b64 %2, %18, %20, %23\n\t"
+                 "s_mov_b64 exec, %15\n\tds_cmpst_rtn_b64 %3, %19, %20, %24\n\t"
+                 "s_mov_b64 exec, %8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(ret[0]), "=&v"(ret[1]), "=&v"(ret[2]), "=&v"(ret[3]), "=&v"(it2[0]), "=&v"(it2[1]), "=&v"(Wn[0]), "=&v"(Wn[1]), "=&s"(save)
+                 : "v"(ia2), "v"(ra0), "v"(ra1), "s"(live[0]), "s"(live[1]), "s"(live[2]), "s"(live[3]), "v"(ka[0]), "v"(ka[1]), "v"(ka[2]), "v"(ka[3]),
+                   "v"(MF_EMPTY), "v"(key[0]), "v"(key[1]), "v"(key[2]), "v"(key[3])
+                 : "memory");
+    unsigned long long won[4], ok[4], coll[4]; uint32_t aa[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        won[u] = live[u] & c2_eq_u64(ret[u], MF_EMPTY);
+        ok[u] = won[u] | (live[u] & c2_eq_u64(ret[u], key[u]));
+        coll[u] = live[u] & ~ok[u];
+        aa[u] = L.tc0 + 4u * s[u];
+    }
+    const uint32_t one = 1u;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\tds_add_u32 %5, %9\n\t"
+                 "s_mov_b64 exec, %2\n\tds_add_u32 %6, %9\n\t"
+                 "s_mov_b64 exec, %3\n\tds_add_u32 %7, %9\n\t"
+                 "s_mov_b64 exec, %4\n\tds_add_u32 %8, %9\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save)
+                 : "s"(ok[0]), "s"(ok[1]), "s"(ok[2]), "s"(ok[3]), "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(one)
+                 : "memory");
+    won_acc += (uint32_t)__popcll(won[0]) + (uint32_t)__popcll(won[1]) + (uint32_t)__popcll(won[2]) + (uint32_t)__popcll(won[3]);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (coll[u] != 0ull) {
+            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(coll[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)coll[u], qn));
+            c2_push64(coll[u], L.qk0 + 8u * at, key[u]);
+            qn += (uint32_t)__popcll(coll[u]);
+            while (qn >= 64u) c2_drain(L, qn, won_acc, part_over);       // (then qn < 64: + one push <= C2_QN)
+        }
+    }
+    it[0] = it1[0]; it[1] = it1[1]; W[0] = Wn[0]; W[1] = Wn[1]; it1[0] = it2[0]; it1[1] = it2[1];
+}
+
 // PROF: cycle counters per phase (diagnostics, option ablate & 32; s_memtime perturbs the kernel by about a tenth)
 #define C2_TICK(i) do { if (PROF) { const long long t__ = clock64(); prof[i] += (unsigned long long)(t__ - tlast); tlast = t__; } } while (0)
-template <int K, bool PROF>
+template <int K, bool PROF, bool WIDE = false>
 __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart,
                                                            const uint32_t *__restrict__ plen, uint32_t np,
                                                            const uint64_t *__restrict__ toff, uint64_t *__restrict__ tkeys,
                                                            uint16_t *__restrict__ tcnt, uint32_t *__restrict__ dcount,
                                                            unsigned int *__restrict__ overflow, uint32_t p0, uint64_t tbase, int thr,
                                                            unsigned long long *__restrict__ n_all,
-                                                           unsigned int *__restrict__ n_redo, unsigned long long *__restrict__ drop_hist, int ablate,
+                                                           unsigned int *__restrict__ n_redo, unsigned long long *__restrict__ drop_hist,
                                                            unsigned long long *__restrict__ prof_out, uint64_t tcap) {
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = PROF ? clock64() : 0;
     // partitions [p0, np); slice of p in tkeys / tcnt starts at toff[p] - tbase; thr >= 0: entries with count <= thr are
-    // dropped and tallied in drop_hist[count] (thr < C2_LH); *n_all += distinct k-mers before the cut
+    // dropped and tallied in drop_hist[count] (thr < C2_LH); *n_all += distinct k-mers before the cut.
+    // (Two neighbouring partitions per table pass, told apart by a tag bit in the key, were tried in round 3: 48.3 ms against
+    // 46.6 at 100 M reads -- a table twice as full costs more in collisions and extra passes than the halved per-partition
+    // work saves.)
     // NO static __shared__ in this kernel: the dynamic array must start at LDS address 0 (the parked records are
     // addressed with `rb0 | offset`; an alignment attribute on the extern array is not honoured behind static variables)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -789,12 +888,9 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     if (threadIdx.x == 0) { out_cursor = 0; blk_claims = 0; pflags[0][0] = pflags[0][1] = pflags[1][0] = pflags[1][1] = 0; }
     const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
     const uint32_t mine = (lane >> 3) * 64u + wave * 8u + (lane & 7u);          // this lane's record within a round of 512
-    uint32_t pi = p0 + blockIdx.x;
-    if (pi >= np) return;
-    uint32_t p = pi;
-    uint64_t start = pstart[p];
-    uint32_t len = plen[p];
-    uint64_t o = toff[p] - tbase; uint32_t room = (uint32_t)(toff[p + 1] - toff[p]);
+    const uint32_t nu = np - p0;                                                // unit u = partition p0 + u
+    uint32_t ui = blockIdx.x;
+    if (ui >= nu) return;
     // (an address select between the record and a sentinel object would turn the load into a flat load from scratch)
     auto load_rec = [&](uint64_t first, uint32_t j, uint32_t n) -> skm_rec {
         const bool ok = j < n;
@@ -803,35 +899,42 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         if (!ok) v = SENT;
         return v;
     };
-    // the first round of a partition is in registers before the partition starts; every further round is fetched while
-    // the round before it is worked on
-    skm_rec R0 = load_rec(start, mine, len);
-    // Directory entries are fetched TWO partitions ahead, with VECTOR loads: a scalar load (what hipcc makes of a uniform
+    // Directory entries are fetched TWO units ahead, with VECTOR loads: a scalar load (what hipcc makes of a uniform
     // address) is counted in lgkmcnt, and the next LDS wait would sit out its whole memory latency (and hipcc spilt the
     // scalars to VGPR lanes at once, with a wait after every load).  `vz` is a zero the compiler cannot see through.
     uint32_t vz; asm("v_mov_b32 %0, 0" : "=v"(vz));
     struct dirent { uint64_t start, toff0, toff1; uint32_t len; };
-    auto load_dir = [&](uint32_t q) -> dirent {
-        dirent d; const uint32_t i = q + vz;
+    auto load_dir = [&](uint32_t u) -> dirent {
+        dirent d; const uint32_t i = p0 + u + vz;
         d.start = pstart[i]; d.len = plen[i]; d.toff0 = toff[i]; d.toff1 = toff[i + 1];
         return d;
     };
+    dirent dc = load_dir(ui);
+    uint64_t start = c2_uniform64(dc.start);
+    uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)dc.len);
+    uint64_t o = c2_uniform64(dc.toff0) - tbase; uint32_t room = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dc.toff1 - dc.toff0));
+    // the first round of a unit is in registers before the unit starts; every further round is fetched while
+    // the round before it is worked on
+    skm_rec R0 = load_rec(start, mine, len);
     dirent dn = {0, 0, 0, 0};
-    if (pi + gridDim.x < np) dn = load_dir(pi + gridDim.x);
+    if (ui + gridDim.x < nu) dn = load_dir(ui + gridDim.x);
+    // (settled before the loop: a load still pending on entry would make the compiler wait at the loop's top -- behind the
+    // directory loads it has just issued there -- on every iteration)
+    asm volatile("" :: "v"(R0.x), "v"(R0.y), "v"(dn.start), "v"(dn.toff0), "v"(dn.toff1), "v"(dn.len));
     __syncthreads();
     uint32_t parity = 0;
     for (;;) {
-        const uint32_t pn = pi + gridDim.x, pnn = pn + gridDim.x;
+        const uint32_t un = ui + gridDim.x, unn = un + gridDim.x;
         dirent dnn = {0, 0, 0, 0};
-        if (pnn < np) dnn = load_dir(pnn);
+        if (unn < nu) dnn = load_dir(unn);
         skm_rec cur = R0;
         const uint64_t start_n = c2_uniform64(dn.start);
         const uint32_t len_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)dn.len);
-        if (pn < np) R0 = load_rec(start_n, mine, len_n);                      // next partition
-        C2_TICK(0);                                                             // partition top: directory, record prefetch
-        // A partition with more distinct k-mers than the table takes (a heavy minimizer: low-complexity sequence between many
+        if (un < nu) R0 = load_rec(start_n, mine, len_n);                      // next unit
+        C2_TICK(0);                                                             // unit top: directory, record prefetch
+        // A unit with more distinct k-mers than the table takes (a heavy minimizer: low-complexity sequence between many
         // different flanks) is counted again in P = 4, 16, 64 passes over its records, pass i inserting the k-mers with
-        // skm_pass_of(key) mod P = i; the passes append to the same slice.  More than 64 passes: the global overflow flag,
+        // skm_pass_of(key) mod P = i; the passes append to the same slices.  More than 64 passes: the global overflow flag,
         // and the caller falls back to the k-mer path.  What a failed attempt tallied is not committed.
         uint32_t P = 1, pass = 0, ones_try = 0, all_try = 0;
         for (;;) {
@@ -840,6 +943,11 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         if (P > 1u) cur = load_rec(start, mine, len);
         for (uint32_t rb = 0; rb < len; rb += (uint32_t)SKM_CT) {
             if (rb && c2_lds_u32(part_over)) break;                             // (abandoned)
+            // hipcc waits with vmcnt(0) at the first use of a loaded register, i.e. for EVERY load in flight.  This round's
+            // records (loaded a round ago) are "used" here, BEFORE the next round's load goes out: the wait the compiler puts
+            // in front of this statement finds them landed, and nothing further down waits for the prefetch (with the use
+            // after the prefetch every round sat out a full HBM round trip: profiles/r03_count_vmcnt.txt).
+            asm volatile("" :: "v"(cur.x), "v"(cur.y));
             skm_rec nxt = SENT;
             if (rb + (uint32_t)SKM_CT < len) nxt = load_rec(start, rb + (uint32_t)SKM_CT + mine, len);      // the round after this one
             const uint32_t r = skm_rec_valid(cur) ? skm_rec_n(cur) : 0u;
@@ -862,35 +970,50 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                     *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (ioff + (uint32_t)c))) = (uint16_t)e;
                 }
             }
-            // one step of padding after the list: items without k-mers for the idle lanes of the last step (the step after
+            // padding after the list: items without k-mers for the idle lanes of the last step (the step after
             // that is only read ahead, never used)
-            *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (NI + lane))) = (uint16_t)0;
-            *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (NI + 64u + lane))) = (uint16_t)0;
+            {
+                const uint32_t z = 0u;      // (u32 stores: NI may be odd -> two u16 stores per 64 entries; WIDE pads twice as far)
+#pragma unroll
+                for (int t = 0; t < (WIDE ? 4 : 2); t++)
+                    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (NI + 64u * (uint32_t)t + lane))) = (uint16_t)z;
+            }
             __builtin_amdgcn_wave_barrier();
+            if (WIDE) {
+                uint32_t it[2], it1[2]; skm_v4 W[2];
+                asm volatile("ds_read_u16 %0, %4\n\tds_read_u16 %1, %4 offset:128\n\tds_read_u16 %2, %4 offset:256\n\tds_read_u16 %3, %4 offset:384\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(it[0]), "=&v"(it[1]), "=&v"(it1[0]), "=&v"(it1[1]) : "v"(L.items0 + 2u * lane) : "memory");
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(W[0]), "=&v"(W[1]) : "v"(L.rb0 | (it[0] & 0x3F0u)), "v"(L.rb0 | (it[1] & 0x3F0u)) : "memory");
+                C2_TICK(1);
+                for (uint32_t i0 = 0; i0 < NI; i0 += 128) c2_step_wide<K>(L, i0, it, W, it1, qn, won_acc, part_over, P, pass);      // wave-uniform
+            } else {
             uint32_t it, it1; skm_v4 W;
             // (LDS operations of one wave execute in order: the reads see the stores above without a wait in between)
             asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(it), "=&v"(it1) : "v"(L.items0 + 2u * lane) : "memory");
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(W) : "v"(L.rb0 | (it & 0x3F0u)) : "memory");
             C2_TICK(1);                                                         // round set-up (incl. the wait for the records)
-            if (!(ablate & 1))
-                for (uint32_t i0 = 0; i0 < NI; i0 += 64) c2_step<K>(L, i0, it, W, it1, qn, won_acc, part_over, ablate, P, pass);      // wave-uniform
+            for (uint32_t i0 = 0; i0 < NI; i0 += 64) c2_step<K>(L, i0, it, W, it1, qn, won_acc, part_over, P, pass);      // wave-uniform
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
             __builtin_amdgcn_wave_barrier();
             C2_TICK(2);                                                         // steps (with the drains inside them)
             cur = nxt;
         }
-        if (ablate & 6) qn = 0;
         while (qn) c2_drain(L, qn, won_acc, part_over);                        // wave-uniform
-        // a crowded table probes slowly: past C2_FILL claims the partition is counted in (more) passes
+        // a crowded table probes slowly: past C2_FILL claims the unit is counted in (more) passes
         if (won_acc) { if (lane == 0) atomicAdd(&blk_claims, won_acc); won_acc = 0; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS operations of the asm blocks are invisible to hipcc's waitcnt pass
         C2_TICK(3);                                                             // last drains
         c2_barrier();                                                           // ---- B1: every insert of the pass is done
         C2_TICK(4);                                                             // waiting for the other waves
         const bool over = c2_lds_u32(part_over) != 0u || c2_lds_u32(&blk_claims) > (uint32_t)C2_FILL;
-        if (threadIdx.x == 0) pflags[parity ^ 1u][1] = 0;                      // for the next pass / partition
+        if (threadIdx.x == 0) pflags[parity ^ 1u][1] = 0;                      // for the next pass / unit
+        // the next unit's first round and the directory entries read ahead have been in flight for a whole unit: settle them
+        // here, while only loads are outstanding -- once the stores below are in flight as well, the counter no longer tells
+        // loads from stores and the first use of these registers would wait for the stores' acknowledgements too
+        asm volatile("" :: "v"(R0.x), "v"(R0.y), "v"(dn.start), "v"(dn.toff0), "v"(dn.toff1), "v"(dn.len), "v"(dnn.start), "v"(dnn.toff0), "v"(dnn.toff1), "v"(dnn.len));
         // ---- compaction: every wave sweeps ITS eighth of the table (consecutive slots, lane = slot: conflict-free),
-        // 4 chunks of 64 in flight: keys are read and reset with one exchange, the counts of the occupied slots likewise.
+        // 8 chunks of 64 in flight: keys are read and reset with one exchange, the counts of the occupied slots likewise.
         // (Claim lists -- visit only the slots that were won -- cost a list append per key slot in the hot loop and four
         // dependent LDS round trips per 64 entries here; with the table 2/5 full the sweep is cheaper on both counts.)
         {
@@ -937,7 +1060,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                 if (nkeep && (wb + nkeep > room || o + wb + nkeep > tcap)) {                   // (only if a partition's k-mer count wrapped)
                     if (lane == 0) {
                         if (atomicExch(overflow, 2u) == 0u && prof_out) {
-                            prof_out[8] = p; prof_out[9] = o; prof_out[10] = room; prof_out[11] = wb; prof_out[12] = nkeep; prof_out[13] = tcap;
+                            prof_out[8] = p0 + ui; prof_out[9] = o; prof_out[10] = room; prof_out[11] = wb; prof_out[12] = nkeep; prof_out[13] = tcap;
                             prof_out[14] = p0; prof_out[15] = np;
                         }
                     }
@@ -957,7 +1080,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         }
         qn = 0;
         C2_TICK(5);                                                             // compaction
-        c2_barrier();                                                           // ---- B2: the table is clean, the cursor final
+        c2_barrier();                                                           // ---- B2: the table is clean, the cursors final
         C2_TICK(6);
         parity ^= 1u;
         if (threadIdx.x == 0) blk_claims = 0;
@@ -969,18 +1092,18 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
             if (thr >= 0) for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) lhist_try[i] = 0;
             if (P >= (uint32_t)SKM_MAX_PASSES) { if (threadIdx.x == 0) atomicExch(overflow, 1u); done = true; }
             P *= 4u;
-            if (threadIdx.x == 0 && n_redo && P == 4u) atomicAdd(n_redo, 1u);    // (statistics: partitions counted in several passes)
+            if (threadIdx.x == 0 && n_redo && P == 4u) atomicAdd(n_redo, 1u);    // (statistics: units counted in several passes)
         } else if (++pass == P) {
             done = true;
             ones_acc += ones_try; all_acc += all_try;
             if (thr >= 2) for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) { const uint32_t v = lhist_try[i]; if (v) { atomicAdd(&lhist[i], v); lhist_try[i] = 0; } }
         }
         if (done) break;
-        c2_barrier();                                                           // (the cursor / the tallies are reset before the next pass appends)
+        c2_barrier();                                                           // (the cursors / the tallies are reset before the next pass appends)
         }
-        if (threadIdx.x == 0) { dcount[p] = out_cursor; out_cursor = 0; }
-        if (pn >= np) break;
-        pi = pn; p = pn; start = start_n; len = len_n;
+        if (threadIdx.x == 0) { dcount[p0 + ui] = out_cursor; out_cursor = 0; }
+        if (un >= nu) break;
+        ui = un; start = start_n; len = len_n;
         o = c2_uniform64(dn.toff0) - tbase;
         room = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dn.toff1 - dn.toff0));
         dn = dnn;
@@ -996,6 +1119,45 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     }
 }
 
+// Slices of a batch -> dense table, every COUNTING partition cut in two TABLE partitions on the way: the counting kernel likes
+// its partitions twice as large as the graph kernels like theirs (100 M reads: 38.8 ms at 12288 occurrences per partition against
+// 44.9 at 6144 -- fixed costs per partition --, while the neighbour lookup's LDS table (mf_nbr.h) wants the ~170 good k-mers of a
+// 6144-occurrence partition).  The next bit of the partition hash comes from the k-mer itself (its minimizer: 17 M-mer hashes per
+// kept k-mer, ~2 ms at 3.6e8 of them).  One wave per counting partition; the keys with bit 0 grow from the front of the
+// partition's range in the dense table, the others from its back (no order inside a partition).
+template <int K>
+__global__ __launch_bounds__(256) void k_gather_split(const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnt,
+                                                      const uint64_t *__restrict__ pstart, const uint32_t *__restrict__ dcount,
+                                                      const uint64_t *__restrict__ coff, uint32_t np, uint64_t *__restrict__ dk,
+                                                      uint16_t *__restrict__ dc, uint32_t p0, uint64_t sbase, uint64_t *__restrict__ dfine,
+                                                      uint64_t dbase, int bit) {
+    // partitions [p0, np) of the counting pass; coff[p]: offset of p's entries in dk / dc (this batch's part of the table, which
+    // starts at entry dbase of the whole); dfine[2p], dfine[2p+1] (and dfine[2 np] by the last one): offsets of the table's partitions
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t p = p0 + blockIdx.x * 4u + wave; p < np; p += gridDim.x * 4u) {
+        const uint64_t s = pstart[p] - sbase, o = coff[p];
+        const uint32_t d = dcount[p];
+        uint32_t front = 0, back = d;                                       // wave-uniform
+        for (uint32_t j0 = 0; j0 < d; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const bool have = j < d;
+            const uint64_t key = have ? keys[s + j] : 0ull;
+            const uint16_t c = have ? cnt[s + j] : (uint16_t)0;
+            const bool hi = ((mf_skm_ph(key, K) >> bit) & 1u) != 0u;
+            const unsigned long long m1 = __ballot(have && hi), m0 = __ballot(have && !hi);
+            const uint32_t n1 = (uint32_t)__popcll(m1), n0 = (uint32_t)__popcll(m0);
+            const uint32_t pos = hi ? back - n1 + __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, 0u))
+                                    : front + __builtin_amdgcn_mbcnt_hi((uint32_t)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m0, 0u));
+            if (have) { dk[o + pos] = key; dc[o + pos] = c; }
+            front += n0; back -= n1;
+        }
+        if (lane == 0) {
+            dfine[2 * (size_t)p] = dbase + o;
+            dfine[2 * (size_t)p + 1] = dbase + o + front;
+            if (p + 1 == np) dfine[2 * (size_t)np] = dbase + coff[np];
+        }
+    }
+}
 __global__ void k_skm_add_base(uint64_t *__restrict__ v, uint64_t n, uint64_t base) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] += base;
@@ -1021,7 +1183,7 @@ template <typename KF> static int skm_set_lds(KF kern, size_t bytes) {
 // partition offsets, the tallies
 struct skm_acc {
     mf_buf<uint64_t> dk; mf_buf<uint16_t> dc; uint64_t dused = 0, dcap = 0;
-    mf_buf<uint64_t> doff;                 // [np_total + 1]
+    mf_buf<uint64_t> doff;                 // [np_total + 1]: the TABLE's partitions (two per counting partition, k_gather_split)
     mf_buf<unsigned long long> dhist, c2p;
     unsigned long long n_records = 0, cap_l1 = 0;
     uint32_t np_total = 0;
@@ -1203,7 +1365,8 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         return MF_SKM_NOMEM;
     }
     mf_buf<uint32_t> dcount; MF_TRY(dcount.alloc(ctx, np));
-    // this slice's partitions in the numbering of the whole run
+    mf_buf<uint64_t> coff; MF_TRY(coff.alloc(ctx, (size_t)np + 1));      // offsets of the counting partitions inside their batch
+    // this slice's partitions in the numbering of the whole run (A.np_total, doffp: the table's partitions, two per counting partition)
     const uint32_t pbase = (uint32_t)(((uint64_t)dlo * A.np_total) >> bits1);
     uint64_t *const doffp = A.doff.p + pbase;
     mf_buf<uint64_t> &dk = A.dk; mf_buf<uint16_t> &dc = A.dc;
@@ -1217,15 +1380,17 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);      // resident workgroups
             MF_HIP(hipMemsetAsync(&scal[8], 0, 8, st));
             mf_ktimer t(ctx, "k_skm_count");
-            if (c2prof)
-                k_skm_count<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
-                                                             p0, (uint64_t)tb[b], kthr, &scal[7], (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p, (uint64_t)tmax);
-            else
-                k_skm_count<K, false><<<grid, SKM_CT, C2_LDS, st>>>(bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2],
-                                                             p0, (uint64_t)tb[b], kthr, &scal[7], (unsigned int *)&scal[8], dhist.p, (int)ctx->opt_ablate, c2p.p, (uint64_t)tmax);
+#define SKM_COUNT_ARGS bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2], p0, (uint64_t)tb[b], kthr, &scal[7], \
+                       (unsigned int *)&scal[8], dhist.p, c2p.p, (uint64_t)tmax
+            if (c2prof) {
+                if (ctx->opt_count_variant == 1) k_skm_count<(K == 31 ? 31 : 20), true, true><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
+                else k_skm_count<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
+            } else if (K == 31 && ctx->opt_count_variant == 1) k_skm_count<(K == 31 ? 31 : 20), false, true><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
+            else k_skm_count<K, false><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
+#undef SKM_COUNT_ARGS
         }
         MF_DBG(ctx, "k_skm_count");
-        MF_TRY(mf_scan<1>(ctx, dcount.p + p0, doffp + p0, p1 - p0, (uint64_t *)&scal[3]));      // offsets inside the batch
+        MF_TRY(mf_scan<1>(ctx, dcount.p + p0, coff.p + p0, p1 - p0, (uint64_t *)&scal[3]));      // offsets inside the batch
         unsigned long long res[2];
         MF_HIP(hipMemcpyAsync(res, &scal[2], 16, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));
@@ -1269,10 +1434,10 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             dcap = want;
         }
         {
-            const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 32);
+            const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)(p1 - p0) + 3) / 4, (uint64_t)ctx->n_cu * 32);
             mf_ktimer t(ctx, "k_gather");
-            k_gather<<<grid, 256, 0, st>>>(tkeys.p, tcnt.p, toff.p, dcount.p, doffp, p1, dk.p + dused, dc.p + dused, p0, (uint64_t)tb[b]);
-            k_skm_add_base<<<(p1 - p0 + 1 + 255) / 256, 256, 0, st>>>(doffp + p0, (uint64_t)(p1 - p0) + 1, dused);
+            k_gather_split<K><<<grid, 256, 0, st>>>(tkeys.p, tcnt.p, toff.p, dcount.p, coff.p, p1, dk.p + dused, dc.p + dused, p0, (uint64_t)tb[b],
+                                                    doffp, dused, 31 - total_bits);
         }
         MF_DBG(ctx, "k_gather");
         dused += d_b;
@@ -1299,12 +1464,16 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     hipStream_t st = ctx->stream;
     const int bits1 = lv[0], nd1 = 1 << bits1;
     int total_bits = 0; for (int b : lv) total_bits += b;
-    if (total_bits > 32 || total_bits - bits1 > SKM_DIGIT_BITS) return MF_SKM_FALLBACK;
+    if (total_bits > 30 || total_bits - bits1 > SKM_DIGIT_BITS) return MF_SKM_FALLBACK;      // (the table gets total_bits + 1 partition bits)
     // counts of the entries the cut drops (the .stat.txt histogram needs them): drop_hist[c], c <= thr.  The kernel tallies
     // them in a small LDS histogram: a cut above C2_LH - 1 is made afterwards (mf_count_skm)
     const int kthr = thr < C2_LH ? thr : -1;
     MF_TRY(skm_set_lds(k_skm_count<K, false>, C2_LDS));
-    if (K == 31) MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), true>, C2_LDS));
+    if (K == 31) {
+        MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), true>, C2_LDS));
+        MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), true, true>, C2_LDS));
+        MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), false, true>, C2_LDS));
+    }
     // Slices (HBM budget): the records of a run are about a third of the reads' bytes per radix level, two levels ping-pong.
     // Reads, table and index have to fit beside them.  Option skm_slices forces a number (tests); arena_cap_gb stands in for
     // a smaller device.
@@ -1329,7 +1498,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     while (S > 1 && (own_hi - own_lo) / S < 1) S /= 2;
     for (;; S *= 2) {
         skm_acc A;
-        A.np_total = (uint32_t)(1ull << total_bits);
+        A.np_total = (uint32_t)(1ull << (total_bits + 1));      // partitions of the table: two per counting partition
         MF_TRY(A.doff.alloc(ctx, (size_t)A.np_total + 1));
         if (kthr >= 0) { MF_TRY(A.dhist.alloc(ctx, (size_t)MF_MAX_COUNT + 1)); MF_HIP(hipMemsetAsync(A.dhist.p, 0, A.dhist.bytes(), st)); }
         MF_TRY(A.c2p.alloc(ctx, 16)); MF_HIP(hipMemsetAsync(A.c2p.p, 0, 128, st));     // [0,8) phase cycles (profiling build), [8,16) overflow diagnostics
@@ -1384,8 +1553,8 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             }
             (*out)->record_bytes = 16;
         }
-        if (total_bits > 0 && total_bits <= 30) {
-            (*out)->part_bits = total_bits;
+        if (total_bits + 1 <= 30) {
+            (*out)->part_bits = total_bits + 1;
             (*out)->part_skm = 1;
             (*out)->part_off_bytes = A.doff.bytes();
             (*out)->d_part_off = A.doff.take();

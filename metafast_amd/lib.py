@@ -32,6 +32,7 @@ _SIGS = {
     "mf_ctx_kernel_report": (i32, [vp, cp, u64]),
     "mf_ctx_reset_timers": (i32, [vp]),
     "mf_count_reads": (i32, [vp, C.POINTER(cp), i32, i32, i32, pvp]),
+    "mf_count_reads_above": (i32, [vp, C.POINTER(cp), i32, i32, i32, i32, pvp, pu64]),
     "mf_count_device": (i32, [vp, vp, vp, u64, u64, i32, i32, pvp]),
     "mf_count_device_above": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, pvp, pu64]),
     "mf_table_destroy": (None, [vp]),
@@ -185,6 +186,14 @@ class Context:
         t = C.c_void_p()
         _check(lib().mf_count_reads(self.h, _cfiles(files), len(files), k, min_read_len, C.byref(t)))
         return Table(self, t)
+
+    def count_reads_above(self, files, k, threshold, min_read_len=0):
+        """KmersCounterMain.runImpl (src/tools/KmersCounterMain.java:77-99): load + the cut value > threshold of printKmers,
+        made inside the counting kernels; -> (Table of the kept k-mers, distinct k-mers before the cut)"""
+        t = C.c_void_p()
+        n_all = C.c_uint64()
+        _check(lib().mf_count_reads_above(self.h, _cfiles(files), len(files), k, min_read_len, threshold, C.byref(t), C.byref(n_all)))
+        return Table(self, t), n_all.value
 
     def count_device(self, d_bases, d_offsets, n_reads, n_bases, k, min_read_len=0):
         """d_bases / d_offsets: raw device pointers (int) -- e.g. torch tensor.data_ptr()"""

@@ -156,6 +156,41 @@ def test_kmers_bin_and_stat_identical_to_oracle(gpu_ctx, oracle, ref_files, tmp_
     assert np.array_equal(k2, ok1) and np.array_equal(c2.astype(np.int32), np.minimum(2 * ov1, 32767))
 
 
+def test_count_reads_above_gives_the_same_files(gpu_ctx, oracle, ref_files, tmp_path):
+    """mf_count_reads_above (the cut of printKmers, src/io/IOUtils.java:52-60, inside the counting kernels: what
+    `metafast.sh -t kmer-counter` calls) must leave byte-identical .kmers.bin / .stat.txt to the uncut table's, on the
+    reference's data and on a 1 M-read file, for the threshold of the cut and for larger ones."""
+    from metafast_amd import lib as L
+    big = tmp_path / "big.fa"
+    bases, off = L.synth_reads_host(0x4D45544146415354, 2, 0, 1_000_000, 150, 40_000)
+    with open(big, "wb") as f:
+        arr = np.frombuffer(bases, dtype=np.uint8).reshape(-1, 150)
+        hdr = np.frombuffer(b">r\n", dtype=np.uint8)
+        rows = np.concatenate([np.tile(hdr, (len(arr), 1)), arr, np.full((len(arr), 1), 10, np.uint8)], axis=1)
+        f.write(rows.tobytes())
+    for name, files, k, cuts in (("ref", [ref_files[2]], 31, (0, 1, 3)), ("pair", ref_files[:2], 21, (1,)), ("big", [str(big)], 31, (1, 2))):
+        full = gpu_ctx.count_reads(files, k)
+        n_full = len(full)
+        for b in cuts:
+            cut, n_all = gpu_ctx.count_reads_above(files, k, b)
+            assert n_all == n_full and len(cut) <= n_full
+            for thr in (b, b + 2):
+                g1 = full.write_kmers(thr, str(tmp_path / "a.kmers.bin"), str(tmp_path / "a.stat.txt"))
+                g2 = cut.write_kmers(thr, str(tmp_path / "b.kmers.bin"), str(tmp_path / "b.stat.txt"))
+                assert g1 == g2 > 0, (name, b, thr)
+                assert (tmp_path / "a.kmers.bin").read_bytes() == (tmp_path / "b.kmers.bin").read_bytes(), (name, b, thr)
+                assert (tmp_path / "a.stat.txt").read_text() == (tmp_path / "b.stat.txt").read_text(), (name, b, thr)
+            cut.close()
+        if name == "ref":
+            ot = oracle.Table().count_files(files, k)
+            ot.write_kmers(1, str(tmp_path / "o.kmers.bin"), str(tmp_path / "o.stat.txt"))
+            cut, _ = gpu_ctx.count_reads_above(files, k, 1)
+            cut.write_kmers(1, str(tmp_path / "c.kmers.bin"), str(tmp_path / "c.stat.txt"))
+            assert (tmp_path / "c.kmers.bin").read_bytes() == (tmp_path / "o.kmers.bin").read_bytes()
+            assert (tmp_path / "c.stat.txt").read_text() == (tmp_path / "o.stat.txt").read_text()
+        full.close()
+
+
 def test_seq_fasta_and_distribution(gpu_ctx, oracle, ref_files, tmp_path):
     from metafast_amd import lib as L
     import ctypes as C
