@@ -123,6 +123,10 @@ int mf_table_device_view(const mf_table *t, const void **d_keys, const void **d_
 /* Long2ShortHashMap.get (itmo!/structures/map/Long2ShortHashMap.java:160-175) for a batch of host
  * keys: values[i] = count or -1.  Builds the HBM open-addressed index on first use. */
 int mf_table_lookup(mf_table *t, const uint64_t *keys, uint64_t n, int32_t *values);
+/* Releases the table's lookup index (built on first use by the unitig builder, the features step and mf_table_lookup; rebuilt
+ * when it is needed again).  The reference keeps one map per library alive at a time (KmersCounterForManyFilesMain.java:80-108);
+ * a rank that holds several samples' tables drops each index between the sample's seq-builder and features steps. */
+int mf_table_drop_index(mf_table *t);
 
 /* ---- A5/A6  .kmers.bin / .stat.txt --------------------------------------------------- */
 /* replaces IOUtils.printKmers (src/io/IOUtils.java:45-71; KmersCounterMain.java:99): 10-byte

@@ -14,6 +14,8 @@ public final class HipBackend {
     /** loadReads + the cut of printKmers (value > threshold) inside the counting kernels (KmersCounterMain.java:77-99):
      *  { table of the k-mers handed on, hm.size() before the cut } */
     public static native long[] countReadsAbove(long ctx, String[] files, int k, int minSeqLen, int threshold);
+    /** releases the table's lookup index until it is needed again (several libraries per GPU) */
+    public static native void tableDropIndex(long table);
     /** hm.size() */
     public static native long tableSize(long table);
     /** IOUtils.printKmers (src/io/IOUtils.java:45): returns the number of good k-mers written */

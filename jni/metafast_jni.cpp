@@ -60,6 +60,9 @@ JNIEXPORT jlongArray JNICALL Java_io_HipBackend_countReadsAbove(JNIEnv *e, jclas
     e->SetLongArrayRegion(r, 0, 2, v);
     return r;
 }
+JNIEXPORT void JNICALL Java_io_HipBackend_tableDropIndex(JNIEnv *e, jclass, jlong table) {
+    if (mf_table_drop_index((mf_table *)(intptr_t)table) < 0) raise(e);
+}
 JNIEXPORT jlong JNICALL Java_io_HipBackend_tableSize(JNIEnv *e, jclass, jlong table) {
     uint64_t n = 0, total = 0;
     if (mf_table_stats((mf_table *)(intptr_t)table, &n, &total) < 0) { raise(e); return 0; }

@@ -48,9 +48,9 @@ __global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ ke
 // the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
 template <int MODE>
 __global__ __launch_bounds__(64 * NB_WAVES) void k_cc_adjacency_part(mf_index_view ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
-                                                                   uint32_t np, int k, uint32_t *__restrict__ nbr, int abl) {
+                                                                   uint32_t np, int k, uint32_t *__restrict__ nbr) {
     __shared__ nb_lds S;
-    nb_for_each<MODE>(ix, keys, part_off, 0u, np, k, S, abl, 0, 0u, [&](uint64_t v, uint64_t, const uint32_t (&idx)[8], uint32_t, uint32_t, bool have) {
+    nb_for_each<MODE>(ix, keys, part_off, 0u, np, k, S, 0, 0u, [&](uint64_t v, uint64_t, const uint32_t (&idx)[8], uint32_t, uint32_t, bool have) {
         if (!have) return;
         uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
         o[0] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
@@ -392,8 +392,8 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             if (t->index.skm_k && t->index.part_bits && t->d_part_off && !ctx->opt_nbr_global && (n >> t->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
                 const uint32_t np = 1u << t->part_bits;
                 const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
-                k_cc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p, (int)ctx->opt_ablate);
-                k_cc_adjacency_part<2><<<(unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16), 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p, (int)ctx->opt_ablate);
+                k_cc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
+                k_cc_adjacency_part<2><<<(unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16), 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
             } else
             k_cc_adjacency<<<cgrid(n), 256, 0, st>>>(mf_view(t->index), t->d_keys, n, k, nbr.p);
         }
@@ -675,14 +675,14 @@ static int dcc_log2(int w) { int l = 0; while ((1 << l) < w) l++; return l; }
 template <int MODE>
 __global__ __launch_bounds__(64 * NB_WAVES) void k_dcc_adjacency_part(mf_index_view ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
                                                                     uint32_t p_lo, uint32_t p_hi, int k, int lw, uint32_t me, uint32_t *__restrict__ nbr,
-                                                                    dcc_query *__restrict__ q, uint32_t qcap, unsigned int *__restrict__ qcount, int abl) {
+                                                                    dcc_query *__restrict__ q, uint32_t qcap, unsigned int *__restrict__ qcount) {
     __shared__ nb_lds S;
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     uint32_t qcur = 0, qend = 0;                                         // this wave's chunk (wave-uniform)
     auto void_rest = [&]() {
         for (uint32_t i = qcur + mf_lane(); i < qend; i += 64) if (i < qcap) q[i].src = ~0ull;
     };
-    nb_for_each<MODE>(ix, keys, part_off, p_lo, p_hi, k, S, abl, lw, me, [&](uint64_t v, uint64_t x, const uint32_t (&idx)[8], uint32_t, uint32_t foreign, bool have) {
+    nb_for_each<MODE>(ix, keys, part_off, p_lo, p_hi, k, S, lw, me, [&](uint64_t v, uint64_t x, const uint32_t (&idx)[8], uint32_t, uint32_t foreign, bool have) {
         if (have) {
             uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
             o[0] = make_uint4(idx[0], idx[1], idx[2], idx[3]);
@@ -835,9 +835,9 @@ extern "C" int mf_dcc_queries(mf_dcc *D, uint64_t *counts) {
             {
                 mf_ktimer tm(ctx, "k_cc_adjacency");
                 k_dcc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, p_lo, p_hi, D->k, D->lw, (uint32_t)D->rank, D->nbr.p,
-                                                                       D->qflat.p, (uint32_t)cap, &D->ctr.p[8], (int)ctx->opt_ablate);
+                                                                       D->qflat.p, (uint32_t)cap, &D->ctr.p[8]);
                 k_dcc_adjacency_part<2><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, p_lo, p_hi, D->k, D->lw, (uint32_t)D->rank, D->nbr.p,
-                                                                       D->qflat.p, (uint32_t)cap, &D->ctr.p[8], (int)ctx->opt_ablate);
+                                                                       D->qflat.p, (uint32_t)cap, &D->ctr.p[8]);
             }
             unsigned int c = 0;
             MF_HIP(hipMemcpyAsync(&c, &D->ctr.p[8], 4, hipMemcpyDeviceToHost, st));

@@ -88,6 +88,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "l1_blocks") ctx->opt_l1_blocks = v;
     else if (s == "verbose") ctx->opt_verbose = v;
     else if (s == "ablate") ctx->opt_ablate = v;
+    else if (s == "scatter_fast") ctx->opt_scatter_fast = v;
     else if (s == "count_variant") ctx->opt_count_variant = v;
     else if (s == "skm") ctx->opt_skm = v;
     else if (s == "skm_batches") ctx->opt_skm_batches = v;

@@ -62,7 +62,7 @@ __device__ __forceinline__ uint64_t nb_neighbour_mn(uint64_t x, uint64_t rcx, in
 __device__ __forceinline__ uint32_t nb_hash(uint64_t key) { return ((uint32_t)key ^ (uint32_t)(key >> 29)) * 0x9E3779B1u; }
 template <int MODE, typename F>
 __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
-                                            uint32_t p_lo, uint32_t np, int k, nb_lds &S, int abl, int lw, uint32_t me, F &&emit) {
+                                            uint32_t p_lo, uint32_t np, int k, nb_lds &S, int lw, uint32_t me, F &&emit) {
     constexpr bool BIG = MODE == 2;
     constexpr uint32_t SLOTS = BIG ? (uint32_t)(NB_SLOTS * NB_WAVES) : (uint32_t)NB_SLOTS;
     constexpr int HSHIFT = BIG ? 21 : 23;                                   // 11 / 9 slot bits
@@ -72,7 +72,10 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
     uint64_t *hk = BIG ? &S.key[0][0] : S.key[wave]; uint16_t *hp = BIG ? &S.pos[0][0] : S.pos[wave];
     uint64_t *rk = S.rq_key[wave]; uint32_t *rp = S.rq_ph[wave], *ri = S.rq_idx[wave];
     const uint32_t tl = BIG ? threadIdx.x : lane, tn = BIG ? (uint32_t)(64 * NB_WAVES) : 64u;      // the team that builds the table
-    auto team_sync = [&]() { if (BIG) __syncthreads(); else __builtin_amdgcn_wave_barrier(); };
+    // (wave level: the barrier builtin orders nothing by itself -- pair it with a wavefront-scope fence so that the LDS hand-offs
+    // between lanes are ordered by contract, not by what the alias analysis happens to keep)
+    auto wave_sync = [&]() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    auto team_sync = [&]() { if (BIG) __syncthreads(); else wave_sync(); };
     for (uint32_t p = p_lo + first; p < np; p += stride) {
         const uint64_t lo = part_off[p], hi = part_off[p + 1];
         const uint32_t n = (uint32_t)(hi - lo);
@@ -81,7 +84,7 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
         if (MODE == 1 && mid) continue;
         if (MODE == 2 && !mid) continue;
         const bool local = BIG || n <= (uint32_t)NB_CAP;
-        if (local && !(abl & 4)) {
+        if (local) {
             for (uint32_t s = tl; s < SLOTS; s += tn) hk[s] = MF_EMPTY;
             team_sync();
             for (uint32_t j = tl; j < n; j += tn) {
@@ -122,13 +125,15 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             uint32_t R;
             const uint32_t rbase = mf_wave_excl_scan((uint32_t)__popc(remote), &R);
             uint32_t idx[8];
+            // (Tried in round 3: the first probes of all eight -- or four -- neighbours in flight behind one wait, the rest in a
+            // wave-uniform loop.  119 / 137 VGPRs instead of 81 take a wave per SIMD away, and every lane then reads for all
+            // eight neighbours whether it wants them or not: k_ut_flags 29.2 ms against 26.4 with the per-neighbour loops below.)
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) {
                 const uint64_t c = cs[i]; const uint32_t ph = phs[i];
                 idx[i] = NB_NONE;
                 if (have && !((foreign >> i) & 1u)) {
                     if (!((remote >> i) & 1u)) {
-                        if (!(abl & 2)) {
                         uint32_t s = nb_hash(c) >> HSHIFT;
                         for (;;) {
                             const uint64_t v = hk[s];
@@ -136,22 +141,21 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                             if (v == MF_EMPTY) break;
                             s = (s + 1u) & (SLOTS - 1u);
                         }
-                        }
-                    } else if (!(abl & 1)) {
+                    } else {
                         const uint32_t at = rbase + (uint32_t)__popc(remote & ((1u << i) - 1u));
                         if (at < (uint32_t)NB_RQ) { rk[at] = c; rp[at] = ph; }
                         else { uint32_t ii, val; if (mf_index_find_ph(ix, c, mf_remix32(ph), &ii, &val)) idx[i] = ii; }
                     }
                 }
             }
-            if (R && !(abl & 1)) {
-                __builtin_amdgcn_wave_barrier();
+            if (R) {
+                wave_sync();
                 const uint32_t Rl = R < (uint32_t)NB_RQ ? R : (uint32_t)NB_RQ;
                 for (uint32_t r = lane; r < Rl; r += 64) {
                     uint32_t ii, val;
                     ri[r] = mf_index_find_ph(ix, rk[r], mf_remix32(rp[r]), &ii, &val) ? ii : NB_NONE;
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_sync();
 #pragma unroll
                 for (uint32_t i = 0; i < 8; i++) {
                     if ((remote >> i) & 1u) {
@@ -159,7 +163,7 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                         if (at < (uint32_t)NB_RQ) idx[i] = ri[at];
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
+                wave_sync();
             }
             emit(lo + j, x, idx, flip, foreign, have);                       // (every lane: the callee may use wave-wide operations)
         }

@@ -131,10 +131,10 @@ __device__ __forceinline__ void skm_next_run(const skm_word<K> &S, uint32_t &cut
 
 // the record of the run [s, s+len): its len+K-1 bases left-aligned, the remaining bits zero, digit bits, k-mer count
 template <int K>
-__device__ __forceinline__ skm_rec skm_make_rec(const skm_word<K> &S, uint32_t s, uint32_t len, uint32_t digits) {
+__device__ __forceinline__ skm_rec skm_make_rec(const uint32_t (&D)[4], uint32_t s, uint32_t len, uint32_t digits) {
     const uint32_t o = (2u * s) & 31u;
     const unsigned long long q = __ballot(s >= 16u);
-    const uint32_t E0 = skm_sel(S.D[0], S.D[1], q), E1 = skm_sel(S.D[1], S.D[2], q), E2 = skm_sel(S.D[2], S.D[3], q), E3 = skm_sel(S.D[3], 0u, q);
+    const uint32_t E0 = skm_sel(D[0], D[1], q), E1 = skm_sel(D[1], D[2], q), E2 = skm_sel(D[2], D[3], q), E3 = skm_sel(D[3], 0u, q);
     uint32_t T0 = E0, T1 = E1, T2 = E2, T3 = E3;
     if (o) {
         T0 = __builtin_amdgcn_alignbit(E0, E1, 32u - o);
@@ -222,7 +222,7 @@ __device__ __forceinline__ skm_stage skm_stage_carve(unsigned char *smem, int nd
     L.q_d = L.ctr + nd + 64;
     return L;
 }
-static inline size_t skm_stage_bytes(int nd) {
+__host__ __device__ static inline size_t skm_stage_bytes(int nd) {
     return ((size_t)nd * SKM_LINE + 64) * 16 + (size_t)nd * 8 + 16 * SKM_QCAP * 8 + ((size_t)nd + 64) * 4 + 16 * SKM_QCAP * 4;
 }
 // four 16-byte stores, then four returning adds (the commits); LDS operations of one wave execute in order
@@ -341,7 +341,17 @@ __device__ __forceinline__ void skm_stage_flush_all(const skm_stage &L, skm_rec 
 // =============================================================================================
 // S2: records of every run, radix-partitioned by the level-1 digit
 // =============================================================================================
-template <int K, bool DYN>
+// FAST (level 1 of <= 10 bits: the staging lines leave LDS for it): the runs of a wave's 64 words are dealt EVENLY over its
+// lanes through LDS.  A word has 3.7 runs on average but the fullest of 64 has 8 or 9, so four runs per lane and iteration
+// meant a second, nearly empty iteration for the whole wave (r02: ~580 of the kernel's 2120 instructions per word), and every
+// run slot paid a 41-instruction select tree for the run's minimizer hash (a register array cannot be indexed per lane).  Now:
+// every lane parks its word (bases, run starts, valid starts: 24 bytes) and writes one 8-byte descriptor per run -- the loop
+// is over the 32 POSITIONS, so the hash is a fixed register, and lanes without a run at that position write to a dummy
+// slot --; then lane l takes the runs l, l + 64, l + 128, l + 192 of the list: one four-wide iteration per 256 runs (237 on
+// average per batch).  Rare batches (a run longer than RMAX that must be cut, more runs than the list holds) take the per-lane loop.
+#define SKM_LCAP 384               // run descriptors per wave and batch
+#define SKM_FAST_WAVE_BYTES (64 * 16 + 64 * 8 + (SKM_LCAP + 1) * 8)
+template <int K, bool DYN, bool FAST>
 __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict__ bases, uint64_t n_bases, const uint32_t *__restrict__ vmask,
                                                       uint64_t n_words, uint64_t words_per_block, int bits1,
                                                       const uint64_t *__restrict__ blockstart, int G, skm_rec *__restrict__ out, skm_dyn Dy,
@@ -353,6 +363,12 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
     for (int i = threadIdx.x; i < nd; i += blockDim.x) { L.cur[i] = DYN ? SKM_NONE : blockstart[(size_t)i * G + blockIdx.x]; L.ctr[i] = 0; }
     if (threadIdx.x < 64) L.ctr[nd + threadIdx.x] = 0;
     __syncthreads();
+    // FAST: this wave's parking area and run list, behind the staging area
+    const uint32_t lane = (uint32_t)mf_lane();
+    unsigned char *wbase = smem + ((skm_stage_bytes(nd) + 15) & ~(size_t)15) + (size_t)(threadIdx.x >> 6) * SKM_FAST_WAVE_BYTES;
+    uint4 *pd = reinterpret_cast<uint4 *>(wbase);                               // [64] the words' bases
+    uint2 *pc = reinterpret_cast<uint2 *>(wbase + 64 * 16);                     // [64] (run starts, valid starts)
+    uint2 *rl = reinterpret_cast<uint2 *>(wbase + 64 * 16 + 64 * 8);            // [SKM_LCAP + 1] (minimizer hash, lane << 5 | position); the last one: dummy
     const uint64_t wlo = (uint64_t)blockIdx.x * words_per_block;
     const uint64_t whi = wlo + words_per_block < n_words ? wlo + words_per_block : n_words;
     for (uint64_t wb = wlo; wb < whi; wb += blockDim.x) {          // wave-uniform: all lanes reach skm_stage_insert together
@@ -362,6 +378,59 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
         skm_word<K> S;
         skm_scan_word<K>(S, bases, n_bases, w < n_words ? w : 0, m);
         uint32_t cut = S.cut;
+        bool fast = FAST;
+        uint32_t NR = 0, roff = 0;
+        if (FAST) {
+            // a run of more than RMAX k-mers (RMAX continuation positions in a row) has to be cut: the per-lane loop does that
+            constexpr int R = skm_word<K>::RMAX;
+            static_assert(R >= 16 && R <= 20, "run-length check");
+            const uint32_t z = ~(cut | ~S.valid);
+            const uint32_t z2 = z & (z >> 1), z4 = z2 & (z2 >> 2), z8 = z4 & (z4 >> 4), z16 = z8 & (z8 >> 8);
+            const uint32_t zr = R == 16 ? z16 : (R == 17 ? (z16 & (z >> 16)) : (R == 18 ? (z16 & (z2 >> 16)) : (R == 19 ? (z16 & (z2 >> 16) & (z >> 18)) : (z16 & (z4 >> 16)))));
+            roff = mf_wave_excl_scan((uint32_t)__popc(cut), &NR);
+            fast = __ballot(zr != 0u) == 0ull && NR <= (uint32_t)SKM_LCAP;
+        }
+        if (FAST && fast) {
+            pd[lane] = make_uint4(S.D[0], S.D[1], S.D[2], S.D[3]);
+            pc[lane] = make_uint2(cut, S.valid);
+            {
+                const uint32_t l0 = mf_lds_addr(rl), dummy = l0 + 8u * (uint32_t)SKM_LCAP;
+                uint32_t at = l0 + 8u * roff;
+                const uint32_t tagl = lane << 5;
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const uint32_t bit = (cut >> j) & 1u;
+                    const uint32_t addr = bit ? at : dummy;
+                    const uint32_t v1 = tagl | (uint32_t)j;
+                    asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(addr), "v"(S.mh[j]), "v"(v1) : "memory");
+                    at += bit << 3;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t g0 = 0; g0 < NR; g0 += 256) {                     // wave-uniform
+                uint32_t d[4]; skm_rec rec[4]; bool pend[4];
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    const uint32_t g = g0 + 64u * (uint32_t)b + lane;
+                    pend[b] = g < NR;
+                    const uint2 de = rl[pend[b] ? g : 0u];
+                    const uint32_t src = (de.y >> 5) & 63u, s0 = de.y & 31u;
+                    const uint4 Dw = pd[src]; const uint2 cv = pc[src];
+                    const uint32_t stop = (cv.x | ~cv.y) & ~((2u << s0) - 1u);
+                    const uint32_t e = stop ? (uint32_t)__builtin_ctz(stop) : 32u;
+                    const uint32_t DD[4] = {Dw.x, Dw.y, Dw.z, Dw.w};
+                    uint32_t digits;
+                    skm_route(de.x, bits1, d[b], digits);
+                    rec[b] = skm_make_rec<K>(DD, s0, e - s0, digits);
+                    if (!pend[b] || d[b] < dlo || d[b] >= dhi) { pend[b] = false; d[b] = 0; rec[b] = make_ulonglong2(~0ull, ~0ull); }
+                }
+                skm_stage_insert<DYN>(L, out, d, rec, pend, Dy);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // (the parked words are rewritten by the next batch)
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         while (__ballot(cut != 0u) != 0ull) {
             uint32_t d[4]; skm_rec rec[4]; bool pend[4];
 #pragma unroll
@@ -372,7 +441,7 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
                     uint32_t s, len, digits;
                     skm_next_run<K>(S, cut, s, len);
                     skm_route(skm_mh_at<K>(S, s), bits1, d[b], digits);
-                    rec[b] = skm_make_rec<K>(S, s, len, digits);
+                    rec[b] = skm_make_rec<K>(S.D, s, len, digits);
                     if (d[b] < dlo || d[b] >= dhi) { pend[b] = false; d[b] = 0; }      // (another slice's record)
                 }
             }
@@ -1208,6 +1277,9 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
     }
     const uint64_t wpb = (n_words + G - 1) / G;
     const bool l1_only = lv.size() == 1;
+    // the scatter's run redistribution needs LDS behind the staging lines: levels of up to 10 bits (option scatter_fast = 0: never)
+    size_t fast_lds = ((skm_stage_bytes(nd1) + 15) & ~(size_t)15) + (size_t)16 * SKM_FAST_WAVE_BYTES;
+    if (fast_lds > (size_t)160 * 1024 || ctx->opt_scatter_fast == 0) fast_lds = 0;
     uint32_t np = (uint32_t)nd1;
     mf_buf<uint64_t> pstart; MF_TRY(pstart.alloc(ctx, np));
     mf_buf<uint32_t> plen; MF_TRY(plen.alloc(ctx, np));
@@ -1252,10 +1324,15 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             if (bufA.alloc(ctx, std::max<unsigned long long>(cap + (uint64_t)G * SKM_CH, final_cap(cap))) != MF_OK) return MF_SKM_NOMEM;
             skm_dyn Dy; Dy.gcur = gcur.p; Dy.rend = rstart.p + 1; Dy.overflow = (unsigned int *)&scal[5]; Dy.dump = cap;
             {
-                const size_t lds = skm_stage_bytes(nd1);
-                MF_TRY(skm_set_lds(k_skm_scatter<K, true>, lds));
                 mf_ktimer t(ctx, "k_skm_scatter");
-                k_skm_scatter<K, true><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, bufA.p, Dy, dlo, dhi);
+                if (fast_lds) {
+                    MF_TRY(skm_set_lds(k_skm_scatter<K, true, true>, fast_lds));
+                    k_skm_scatter<K, true, true><<<G, 1024, fast_lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, bufA.p, Dy, dlo, dhi);
+                } else {
+                    const size_t lds = skm_stage_bytes(nd1);
+                    MF_TRY(skm_set_lds(k_skm_scatter<K, true, false>, lds));
+                    k_skm_scatter<K, true, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, bufA.p, Dy, dlo, dhi);
+                }
             }
             MF_DBG(ctx, "k_skm_scatter");
             k_skm_dir_dyn<<<(nd1 + 255) / 256, 256, 0, st>>>(rstart.p, gcur.p, nd1, pstart.p, plen.p);
@@ -1273,10 +1350,15 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         MF_HIP(hipStreamSynchronize(st));                       // padded number of records
         if (bufA.alloc(ctx, final_cap(cap)) != MF_OK) return MF_SKM_NOMEM;
         {
-            const size_t lds = skm_stage_bytes(nd1);
-            MF_TRY(skm_set_lds(k_skm_scatter<K, false>, lds));
             mf_ktimer t(ctx, "k_skm_scatter");
-            k_skm_scatter<K, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p, skm_dyn(), dlo, dhi);
+            if (fast_lds) {
+                MF_TRY(skm_set_lds(k_skm_scatter<K, false, true>, fast_lds));
+                k_skm_scatter<K, false, true><<<G, 1024, fast_lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p, skm_dyn(), dlo, dhi);
+            } else {
+                const size_t lds = skm_stage_bytes(nd1);
+                MF_TRY(skm_set_lds(k_skm_scatter<K, false, false>, lds));
+                k_skm_scatter<K, false, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p, skm_dyn(), dlo, dhi);
+            }
         }
         MF_DBG(ctx, "k_skm_scatter");
         k_skm_dir<<<(nd1 + 255) / 256, 256, 0, st>>>(blockstart.p, blockocc.p, G, nd1, pstart.p, plen.p, pocc.p);

@@ -84,10 +84,10 @@ __global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
 
 // the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
 template <int MODE>
-__global__ __launch_bounds__(64 * NB_WAVES) void k_ut_flags_part(mf_index_view ix, ut_arrays A, const uint64_t *__restrict__ part_off, uint32_t np, int abl) {
+__global__ __launch_bounds__(64 * NB_WAVES) void k_ut_flags_part(mf_index_view ix, ut_arrays A, const uint64_t *__restrict__ part_off, uint32_t np) {
     __shared__ nb_lds S;
     const int k = A.k;
-    nb_for_each<MODE>(ix, A.gk, part_off, 0u, np, k, S, abl, 0, 0u, [&](uint64_t i, uint64_t x, const uint32_t (&idx)[8], uint32_t flip, uint32_t, bool have) {
+    nb_for_each<MODE>(ix, A.gk, part_off, 0u, np, k, S, 0, 0u, [&](uint64_t i, uint64_t x, const uint32_t (&idx)[8], uint32_t flip, uint32_t, bool have) {
         if (!have) return;
         uint32_t rcode = UT_CODE_NONE, lcode = UT_CODE_NONE, ridx = UT_NONE, lidx = UT_NONE, ror = 0, lor = 0;
 #pragma unroll
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(64 * UT_J_WAVES) void k_ut_contract(const uint64_t 
             const bool inside = g != UT_NONE && (uint64_t)g >= f0 && (uint64_t)g < f0 + m;
             P[j] = inside ? ((g - (uint32_t)f0) | (1u << 16)) : j;          // the last inside node of a chain points at itself, 0 hops
         }
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // pointer jumping; a (pointer, hops) pair is ONE word, so a read always sees a consistent pair: hops = distance to pointer
         for (int round = 0; round < 11; round++) {                         // 2^11 > UT_J_MAXN (cycles inside a partition never settle: nobody walks them)
             bool changed = false;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(64 * UT_J_WAVES) void k_ut_contract(const uint64_t 
                 P[j] = (b & 0xFFFFu) | (((a >> 16) + (b >> 16)) << 16);
                 changed = true;
             }
-            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             if (!__any(changed)) break;
         }
         for (uint32_t j = lane; j < m; j += 64) {
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(64 * UT_J_WAVES) void k_ut_contract(const uint64_t 
             const uint32_t g = S[e];
             jump[f0 + j] = g == UT_NONE ? ((uint64_t)((uint32_t)f0 + e) | ((uint64_t)h << 32) | UT_J_END) : ((uint64_t)g | ((uint64_t)(h + 1u) << 32));
         }
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 // tables without minimizer partitions: one hop per word
@@ -454,8 +454,8 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
             if (g->index.skm_k && g->index.part_bits && g->d_part_off && !ctx->opt_nbr_global && (n >> g->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
                 const uint32_t np = 1u << g->part_bits;
                 const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
-                k_ut_flags_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np, (int)ctx->opt_ablate);
-                k_ut_flags_part<2><<<(unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16), 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np, (int)ctx->opt_ablate);      // partitions of 353 .. 1408 keys: a workgroup each
+                k_ut_flags_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
+                k_ut_flags_part<2><<<(unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16), 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);      // partitions of 353 .. 1408 keys: a workgroup each
             } else
             k_ut_flags<<<grid_for(n), 256, 0, st>>>(mf_view(g->index), A);
         }

@@ -32,6 +32,7 @@ _SIGS = {
     "mf_ctx_kernel_report": (i32, [vp, cp, u64]),
     "mf_ctx_reset_timers": (i32, [vp]),
     "mf_count_reads": (i32, [vp, C.POINTER(cp), i32, i32, i32, pvp]),
+    "mf_table_drop_index": (i32, [vp]),
     "mf_count_reads_above": (i32, [vp, C.POINTER(cp), i32, i32, i32, i32, pvp, pu64]),
     "mf_count_device": (i32, [vp, vp, vp, u64, u64, i32, i32, pvp]),
     "mf_count_device_above": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, pvp, pu64]),
@@ -344,6 +345,10 @@ class Table:
         out = np.empty(len(keys), dtype=np.int32)
         _check(lib().mf_table_lookup(self.h, keys.ctypes.data, len(keys), out.ctypes.data))
         return out
+
+    def drop_index(self):
+        """give the lookup index back (rebuilt on the next lookup): several samples per GPU"""
+        _check(lib().mf_table_drop_index(self.h))
 
     def write_kmers(self, threshold, kmers_bin, stat_txt=None):
         """IOUtils.printKmers (src/io/IOUtils.java:45-71)"""

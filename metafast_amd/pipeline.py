@@ -365,13 +365,20 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
             t0 = t1
 
     goods, seqss, hists, n_occ, n_distinct = [], [], [], 0, 0
-    for d_bases, d_offsets, n_reads, n_bases in samples:
+    for si, (d_bases, d_offsets, n_reads, n_bases) in enumerate(samples):
+        if si:
+            # several samples on this rank: the previous sample's lookup index (3-6 times its table) is not needed again before
+            # its feature vector, where it is rebuilt (mf_table_drop_index) -- 4 samples of > 2^32 distinct k-mers each
+            # (BASELINE config 5) fit one GPU's HBM this way
+            goods[-1].drop_index()
         # kmer-counter: k-mers with count > b go on (IOUtils.printKmers); the others are dropped inside the counting kernels
         good, nd = ctx.count_device_above(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, k, b)
         # ... and the histogram of ALL counts, dropped k-mers included (the .stat.txt of IOUtils.printKmers, src/io/IOUtils.java:45-71)
         hists.append(good.hist())
         mark("count")
         seqss.append(ctx.build_unitigs(good, b, l))
+        if si:
+            good.drop_index()
         mark("unitigs")
         goods.append(good); n_occ += good.occurrences(); n_distinct += nd
     # this rank's unitigs, all samples one after the other
@@ -416,6 +423,8 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
     vecs_local, breadths = [], []
     for good in goods:
         vec, breadth = ctx.features(comps, good, 0)
+        if len(goods) > 1:
+            good.drop_index()
         vecs_local.append(vec); breadths.append(breadth)
     vt = torch.from_numpy(np.stack(vecs_local) if vecs_local else np.zeros((0, len(comps)), dtype=np.int64)).to(device)
     vecs = gather_vector_rows(vt).cpu().numpy()

@@ -323,6 +323,66 @@ def test_cli_matrix_builder_workdir(oracle, ref_files, tmp_path):
     assert r.returncode == 1 and "Unrecognized option: --force" in r.stderr
 
 
+def test_cli_fastq_pairs_against_the_oracle(oracle, tmp_path):
+    """metafast.sh on FASTQ inputs with an _r1/_r2 pair (KmersCounterForManyFilesMain.java:80-108: one library, both files
+    into one table), reads with a phred-0 base (dropped, FastaReaderFromXQSource.java:66-70) and a plain FASTA sample: the
+    matrix and the per-step files against the oracle's steps on the same files"""
+    from metafast_amd import lib as L
+    k, b, l, b1, b2 = 21, 1, 60, 40, 2000
+    rng = np.random.default_rng(5)
+
+    def fastq(path, sample, first, n):
+        bases, off = L.synth_reads_host(0x4D45544146415354, sample, first, n, 100, 3000)
+        arr = np.frombuffer(bases, dtype=np.uint8).reshape(n, 100)
+        with open(path, "w") as f:
+            for i in range(n):
+                q = rng.integers(34, 74, 100).astype(np.uint8)
+                if i % 17 == 3:
+                    q[int(rng.integers(0, 100))] = 33                       # phred 0: the whole read is dropped
+                f.write("@r%d\n%s\n+\n%s\n" % (i, arr[i].tobytes().decode(), q.tobytes().decode()))
+
+    fastq(tmp_path / "smpA_r1.fastq", 0, 0, 6000)
+    fastq(tmp_path / "smpA_r2.fastq", 0, 6000, 6000)
+    fastq(tmp_path / "smpB.fq", 1, 0, 9000)
+    bases, off = L.synth_reads_host(0x4D45544146415354, 2, 0, 9000, 100, 3000)
+    with open(tmp_path / "smpC.fa", "w") as f:
+        for i, row in enumerate(np.frombuffer(bases, dtype=np.uint8).reshape(9000, 100)):
+            f.write(">c%d\n%s\n" % (i, row.tobytes().decode()))
+    groups = [("smpA", ["smpA_r1.fastq", "smpA_r2.fastq"]), ("smpB", ["smpB.fq"]), ("smpC", ["smpC.fa"])]
+    files = [str(tmp_path / f) for _, fs in groups for f in fs]
+    wd = tmp_path / "wd"
+    r = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", str(k), "-b", str(b), "-l", str(l), "-b1", str(b1), "-b2", str(b2),
+                        "-i", *files, "-w", str(wd)], capture_output=True, text=True, timeout=600, cwd=tmp_path)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # the oracle, step by step on the same files
+    goods, seqfiles = [], []
+    for name, fs in groups:
+        t = oracle.Table().count_files([str(tmp_path / f) for f in fs], k)
+        t.write_kmers(b, str(tmp_path / (name + ".o.kmers.bin")))
+        assert (wd / "kmer-counter-many" / "kmers" / (name + ".kmers.bin")).read_bytes() == (tmp_path / (name + ".o.kmers.bin")).read_bytes(), name
+        good = oracle.Table().load_kmers([str(tmp_path / (name + ".o.kmers.bin"))], 0)
+        goods.append(good)
+        sf = tmp_path / (name + ".o.seq.fasta")
+        oracle.build_unitigs(good, k, b, l).write_fasta(str(sf))
+        seqfiles.append(str(sf))
+    cutter = oracle.Table().count_files(seqfiles, k, l)
+    comps = oracle.cut_components(cutter, k, b1, b2)
+    want = comps.all()
+    assert len(want) >= 3
+    vecs = np.array([comps.features(g, 0)[0] for g in goods], dtype=np.int64).reshape(3, len(want))
+    for (name, _), v in zip(groups, vecs):
+        got = np.array((wd / "features-calculator" / "vectors" / (name + ".vec")).read_text().split(), dtype=np.int64)
+        assert np.array_equal(got, v), name
+    om = oracle.bray_curtis(vecs)
+    mats = sorted((wd / "matrices").glob("dist_matrix_*_original_order.txt"))
+    assert len(mats) == 1
+    lines = mats[0].read_text().splitlines()
+    assert lines[0] == "#\tsmpA\tsmpB\tsmpC"
+    for i, (name, _) in enumerate(groups):
+        assert lines[1 + i] == name + "\t" + "\t".join("%.4f" % om[i, j] for j in range(3))
+    assert om[0, 1] > 0 and om[0, 2] > 0
+
+
 def test_cli_errors_and_single_tools(ref_files, tmp_path):
     exe = os.path.join(ROOT, "metafast.sh")
     r = subprocess.run([exe, "-t", "kmer-counter", "-k", "32", "-i", ref_files[0], "-w", str(tmp_path / "w")], capture_output=True, text=True)

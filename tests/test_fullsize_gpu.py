@@ -153,48 +153,50 @@ def test_cut_inside_the_counting_pass(full, gpu_ctx):
     flt.close(); above.close()
 
 
-def _kmers_of(seq):
+def _kmers_of(seq, k=K):
     code = np.zeros(256, dtype=np.uint64)
     for ch, c in (("A", 0), ("G", 1), ("C", 2), ("T", 3)):
         code[ord(ch)] = c
     c = code[np.frombuffer(seq.encode(), dtype=np.uint8)]
-    m = len(c) - K + 1
+    m = len(c) - k + 1
     fw = np.zeros(m, dtype=np.uint64)
     rc = np.zeros(m, dtype=np.uint64)
-    for i in range(K):
+    for i in range(k):
         fw = (fw << np.uint64(2)) | c[i:i + m]
         rc |= (np.uint64(3) - c[i:i + m]) << np.uint64(2 * i)
     return np.minimum(fw, rc)
 
 
-def _neighbours(x):
-    mask = np.uint64((1 << (2 * K)) - 1)
+def _neighbours(x, k=K):
+    mask = np.uint64((1 << (2 * k)) - 1)
     out = []
     for n in range(4):
-        for y in (((x << np.uint64(2)) | np.uint64(n)) & mask, (x >> np.uint64(2)) | (np.uint64(n) << np.uint64(2 * K - 2))):
+        for y in (((x << np.uint64(2)) | np.uint64(n)) & mask, (x >> np.uint64(2)) | (np.uint64(n) << np.uint64(2 * k - 2))):
             r = np.zeros_like(y)
             t = y.copy()
-            for _ in range(K):
+            for _ in range(k):
                 r = (r << np.uint64(2)) | (np.uint64(3) - (t & np.uint64(3)))
                 t >>= np.uint64(2)
             out.append(np.minimum(y, r))
     return np.stack(out, axis=1)
 
 
-def test_pipeline_properties(full, gpu_ctx):
+def check_pipeline_properties(gpu_ctx, bases, offsets, n_reads, k, n_distinct=None, b=1, l=100, b1=1000, b2=10000):
+    """the size-independent properties of unitigs, components and features of ONE sample (also used at 200 M reads, k = 21:
+    tests/test_shapes_gpu.py)"""
     from metafast_amd import lib as L
     from metafast_amd import pipeline as P
-    b, l, b1, b2 = 1, 100, 1000, 10000
-    r = P.run_sample(gpu_ctx, full["bases"], full["offsets"], N_READS, N_READS * RL, k=K, b=b, l=l, b1=b1, b2=b2)
+    r = P.run_sample(gpu_ctx, bases, offsets, n_reads, n_reads * RL, k=k, b=b, l=l, b1=b1, b2=b2)
     good, seqs, comps, cutter = r["good"], r["seqs"], r["comps"], r["cutter"]
-    assert r["n_distinct"] == full["table"].stats()[0]
+    if n_distinct is not None:
+        assert r["n_distinct"] == n_distinct
     # unitigs: a sample of them, k-mer by k-mer
     sq = seqs.export()
     assert len(sq) > 0 and all(len(s[0]) >= l for s in sq[:10000])
     rng = np.random.default_rng(3)
     for i in rng.choice(len(sq), size=min(300, len(sq)), replace=False):
         s, avg, mn, mx = sq[int(i)]
-        cnt = good.lookup(_kmers_of(s)).astype(np.int64)
+        cnt = good.lookup(_kmers_of(s, k)).astype(np.int64)
         assert cnt.min() > b and (mn, mx) == (cnt.min(), cnt.max()) and avg == int(cnt.sum() // len(cnt))
     # components
     cs = comps.export()
@@ -210,7 +212,7 @@ def test_pipeline_properties(full, gpu_ctx):
         size, weight, thr, km = cs[int(ci)]
         val = cutter.lookup(km).astype(np.int64)
         assert val.min() >= thr and weight == val.sum()
-        nb = _neighbours(km[:200])                                          # closed: a neighbour in the graph is in the same component
+        nb = _neighbours(km[:200], k)                                       # closed: a neighbour in the graph is in the same component
         present = cutter.lookup(nb.reshape(-1)).astype(np.int64).reshape(nb.shape) >= thr
         pos = np.searchsorted(allk, nb).clip(max=len(allk) - 1)
         same = (allk[pos] == nb) & (owner[pos] == ci)
@@ -220,3 +222,8 @@ def test_pipeline_properties(full, gpu_ctx):
         assert r["vec"][int(ci)] == sv[sv > 0].sum()
     m = L.bray_curtis(np.stack([r["vec"], r["vec"]]))
     assert m[0, 1] == 0.0 and m[1, 0] == 0.0
+    return dict(n_unitigs=len(sq), n_components=len(cs), max_thr=max(c[2] for c in cs))
+
+
+def test_pipeline_properties(full, gpu_ctx):
+    check_pipeline_properties(gpu_ctx, full["bases"], full["offsets"], N_READS, K, n_distinct=full["table"].stats()[0])

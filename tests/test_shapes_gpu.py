@@ -3,6 +3,10 @@
 * config 4's k = 21 leg at full size (200 M x 150 bp reads; MF_SHAPES_K21_READS overrides): the size-independent properties of
   tests/test_fullsize_gpu.py -- occurrence conservation, an independent exact recount of a key sample in plain torch ops,
   the cut inside the counting pass = filter afterwards, additivity of the two halves (saturating), the all-counts histogram.
+  The graph stages of the same shape (unitigs -> cutter -> components -> features) go through the property set of
+  test_fullsize_gpu.py::test_pipeline_properties at k = 21.
+* the whole pipeline at k = 21 and at k = 20 (the lower edge of the super-k-mer path) on 2 x 1 M synthetic reads against the
+  ORACLE's pipeline, with a component window that forces threshold >= 2 re-splits.
 * config 3's semantics (8 samples -> 8 x 8 matrix) with the 8 samples one after the other on this GPU through
   pipeline.run_samples, against the ORACLE's pipeline on the same reads (scaled down to MF_SHAPES_READS = 5 M reads per
   sample; the oracle's kmer-counter and seq-builder run as 8 CPU child processes and leave the reference's own files,
@@ -117,11 +121,41 @@ def test_200M_reads_k21_properties(gpu_ctx):
     table.close()
 
 
+def test_200M_reads_k21_graph_properties(gpu_ctx):
+    """config 4's k = 21 leg beyond counting: unitigs, cutter, components, features of one 200 M-read sample"""
+    import torch
+    from test_fullsize_gpu import check_pipeline_properties
+    k = 21
+    n = int(os.environ.get("MF_SHAPES_K21_READS", "200000000"))
+    import gc
+    gc.collect()
+    gpu_ctx.trim()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < n * 1100:
+        pytest.skip("needs %.0f GB of free HBM, %.0f GB are free" % (n * 1100 / 1e9, free / 1e9))
+    bases = torch.zeros(n * RL + 64, dtype=torch.uint8, device="cuda")
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    gpu_ctx.synth_reads_device(SEED, 0, 0, n, RL, 1_000_000, bases.data_ptr(), offsets.data_ptr())
+    gpu_ctx.synchronize()
+    info = check_pipeline_properties(gpu_ctx, bases, offsets, n, k)
+    assert info["n_unitigs"] > 1000 and info["n_components"] > 100
+
+
+@pytest.mark.parametrize("k", [21, 20])
+def test_pipeline_against_the_oracle_k21_k20(gpu_ctx, oracle, tmp_path, k):
+    _samples_against_the_oracle(gpu_ctx, oracle, tmp_path, S=2, k=k, b=1, l=100, b1=500, b2=5000, n=1_000_000, min_thr=3)
+
+
 def test_eight_samples_one_gpu_against_the_oracle(gpu_ctx, oracle, tmp_path):
+    _samples_against_the_oracle(gpu_ctx, oracle, tmp_path, S=8, k=31, b=1, l=100, b1=1000, b2=10000,
+                                n=int(os.environ.get("MF_SHAPES_READS", "5000000")), min_thr=2)
+
+
+def _samples_against_the_oracle(gpu_ctx, oracle, tmp_path, S, k, b, l, b1, b2, n, min_thr):
     import torch
     from metafast_amd import pipeline as P
-    S, k, b, l, b1, b2 = 8, 31, 1, 100, 1000, 10000
-    n = int(os.environ.get("MF_SHAPES_READS", "5000000"))
     scale = max(n // 100, 1000)
     worker = os.path.join(ROOT, "tests", "oracle_sample_worker.py")
     procs = [subprocess.Popen([sys.executable, worker, str(s), str(n), str(scale), str(k), str(b), str(l), str(tmp_path)],
@@ -150,7 +184,7 @@ def test_eight_samples_one_gpu_against_the_oracle(gpu_ctx, oracle, tmp_path):
     assert len(r["cutter"]) == len(cutter)
     oc = oracle.cut_components(cutter, k, b1, b2)
     got, want = r["comps"].export(), oc.all()
-    assert len(want) > 50 and max(c[2] for c in want) >= 2
+    assert len(want) > 50 and max(c[2] for c in want) >= min_thr
     assert [(a, w, t) for a, w, t, _ in got] == [(a, w, t) for a, w, t, _ in want]
     for (_, _, _, gk), (_, _, _, ok) in zip(got, want):
         assert np.array_equal(gk, ok)
