@@ -38,8 +38,25 @@ def _load_traffic():
 
 
 TRAFFIC = {}
-# what limits a kernel according to its counters (profiles/*_pmc_*): k_skm_count is not an HBM kernel
+# what limits a kernel when no counters of this workload are at hand (other shapes than the headline one)
 BOUND = {"k_skm_count": "lds+valu", "k_skm_scatter": "valu", "k_skm_hist": "valu"}
+
+
+def bound_from_counters(tr, launch_ms):
+    """roofline.bound from the PMC passes of the same workload (profiles/traffic_100M.json, tools/refresh_profiles.sh): "hbm" when
+    the measured traffic alone keeps HBM half busy, else whichever of the vector ALUs / the LDS pipe the SQ counters show busiest
+    (both named when they are within a third of each other); None without counters"""
+    if not isinstance(tr, dict) or "valu_busy" not in tr or launch_ms <= 0:
+        return None
+    hbm = tr.get("hbm_GB", 0.0) / (launch_ms / 1e3) / HBM_PEAK_GBS
+    v, l = tr.get("valu_busy", 0.0), tr.get("lds_busy", 0.0)
+    if hbm >= 0.5 and hbm >= max(v, l):
+        return "hbm"
+    if max(v, l) < 0.25 and hbm < 0.25:
+        return "latency"
+    if l > 0 and v > 0 and min(v, l) / max(v, l) >= 0.67:
+        return "lds+valu"
+    return "valu" if v >= l else "lds"
 
 
 def algorithmic_bytes(kernel, s):
@@ -218,10 +235,14 @@ def main():
                      n_records=nrec * spg, record_bytes=rbytes, n_singletons=int(sum(int(h[1]) for h in r["hists"])))
         for x in r["goods"] + r["seqss"] + [r["cutter"], r["comps"]]:
             x.close()
+        for kk, v in r["comm"].items():
+            comm_acc[kk] = comm_acc.get(kk, 0) + v
         return stats, r["matrix"]
 
+    comm_acc = {}
     for _ in range(args.warmup):
         stats, _m = step()
+    comm_acc.clear()
     ctx.reset_timers()
     stage_t = {}
     barrier()
@@ -271,7 +292,7 @@ def main():
             tr = TRAFFIC.get(name)
             # traffic: HBM gigabytes per launch (set) from the committed rocprofv3 --pmc passes of this same workload
             # (profiles/traffic_100M.json; null for other workloads), raw counters beside it
-            r = dict(kernel=name, bound=BOUND.get(name, "hbm"), achieved=kern[name]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
+            r = dict(kernel=name, bound=bound_from_counters(tr, kern[name]["sample_ms"]) or BOUND.get(name, "hbm"), achieved=kern[name]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
                      frac=round(kern[name]["GBps"] / HBM_PEAK_GBS, 4),
                      launch_ms=kern[name]["sample_ms"], algorithmic_GB=kern[name]["algorithmic_GB"],
                      traffic=(tr or {}).get("hbm_GB") if isinstance(tr, dict) else None, traffic_unit="GB", traffic_counters=tr)
@@ -314,6 +335,11 @@ def main():
             "roofline_hash_count": roof("k_skm_count" if "k_skm_count" in kern else "k_count"),
             "cpu_baseline": cpu,
             "stats": stats,
+            # the sharded cutter's exchanges on rank 0 (world > 1): collectives per step, bytes received per step, seconds inside
+            # them (each timed with a stream synchronisation on both sides; not measurable on this pool's 1-GPU boxes)
+            "comm": {"collectives_per_step": round(comm_acc.get("collectives", 0) / max(args.steps, 1), 1),
+                     "MB_received_per_step": round(comm_acc.get("bytes_in", 0) / max(args.steps, 1) / 1e6, 2),
+                     "comm_ms_per_step": round(comm_acc.get("seconds", 0.0) / max(args.steps, 1) * 1e3, 3)},
             "stage_ms_per_step": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in stage_t.items()},
             "kernels": kern,
         }

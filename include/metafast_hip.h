@@ -208,7 +208,8 @@ int  mf_cut_components(mf_ctx *ctx, mf_table *cutter, int k, int b1, int b2,
  *             -> mf_dcc_set_answers
  *   level t:  mf_dcc_level_local + mf_dcc_pairs_fill -> all-to-all -> mf_dcc_pairs_complete
  *             -> all-gather -> mf_dcc_merge + mf_dcc_stats_fill -> all-gather -> mf_dcc_classify
- *             + mf_dcc_kept_fill -> all-gather (kept components; stop when no rank has an oversize one)
+ *             (+ mf_dcc_kept_fill: every rank derives ALL kept components and the number of oversize ones from
+ *             the gathered records -- nothing more to exchange; stop when there is no oversize component)
  *   end:      mf_dcc_minkeys -> all-reduce (min); mf_dcc_members + _fill -> all-gather -> mf_dcc_finish: the same mf_comps on every rank,
  *             identical to mf_cut_components_device on the merged table.                              */
 /* rank's shard of the table of ALL the given sequences (every rank passes the same input, the unitigs of all samples):
@@ -219,6 +220,8 @@ int  mf_count_device_shard(mf_ctx *ctx, const void *d_bases, const void *d_offse
  * The shard must outlive the handle. */
 int  mf_dcc_create(mf_ctx *ctx, mf_table *shard, int rank, int world, const uint32_t *base, mf_dcc **out);
 void mf_dcc_destroy(mf_dcc *d);
+/* the world size the handle was created with (the length of the per-rank count arrays below) */
+int  mf_dcc_world(const mf_dcc *d);
 /* neighbours in other shards: counts[world] (host), then the 16-byte queries grouped by owner */
 int  mf_dcc_queries(mf_dcc *d, uint64_t *counts);
 int  mf_dcc_queries_fill(mf_dcc *d, void *d_queries);
@@ -236,11 +239,13 @@ int  mf_dcc_pairs_complete(mf_dcc *d, void *d_pairs, uint64_t n);
  * its share of each: 16-byte records (global root u32, size u32, weight u64) */
 int  mf_dcc_merge(mf_dcc *d, const void *d_pairs, uint64_t n, uint64_t *n_stats);
 int  mf_dcc_stats_fill(mf_dcc *d, void *d_stats);
-/* ALL ranks' records in rank order ([own_first, own_first + own_n) are this rank's own) -> classification of every own
- * vertex at threshold thr (size window [b1, b2]); n_kept / n_big: kept / oversize components whose global root this rank
- * owns; then the kept ones' 16-byte records (root u32, size u32, weight u64) */
-int  mf_dcc_classify(mf_dcc *d, const void *d_stats, uint64_t n, uint64_t own_first, uint64_t own_n, int b1, int b2,
-                     int thr, uint64_t *n_kept, uint64_t *n_big);
+/* ALL ranks' records in rank order (seg_first[world + 1], host: rank r's are [seg_first[r], seg_first[r + 1]); this rank's own
+ * are [own_first, own_first + own_n)) -> classification of every own vertex at threshold thr (size window [b1, b2]);
+ * n_kept / n_big: the kept / oversize components of the level over ALL ranks -- the same on every rank, which holds every
+ * component's records --; then the kept ones' 16-byte records (root u32, size u32, weight u64), all of them, in no
+ * particular order (sort by root for an order every rank agrees on) */
+int  mf_dcc_classify(mf_dcc *d, const void *d_stats, uint64_t n, const uint64_t *seg_first, uint64_t own_first, uint64_t own_n,
+                     int b1, int b2, int thr, uint64_t *n_kept, uint64_t *n_big);
 int  mf_dcc_kept_fill(mf_dcc *d, void *d_kept);
 /* members of kept components among this rank's k-mers, all levels: k-mers u64[n], global roots u32[n] */
 int  mf_dcc_members(mf_dcc *d, uint64_t *n);

@@ -46,18 +46,19 @@ public final class HipBackend {
     public static native long dccCreate(long ctx, long shard, int rank, int world, int[] base);
     public static native void dccDestroy(long dcc);
     /** queries for the owners of neighbours in other shards: counts per rank; dccQueriesFill writes the 16-byte queries */
-    public static native long[] dccQueries(long dcc, int world);
+    public static native long[] dccQueries(long dcc);
     public static native void dccQueriesFill(long dcc, long dQueries);
     public static native void dccAnswer(long dcc, long dQueries, long n, long dAnswers);
     public static native void dccSetAnswers(long dcc, long dAnswers, long n);
     /** one threshold level of ComponentsBuilder.run (src/algo/ComponentsBuilder.java:86-150) */
-    public static native long[] dccLevelLocal(long dcc, int world);
+    public static native long[] dccLevelLocal(long dcc);
     public static native void dccPairsFill(long dcc, long dPairs);
     public static native void dccPairsComplete(long dcc, long dPairs, long n);
     public static native long dccMerge(long dcc, long dPairs, long n);
     public static native void dccStatsFill(long dcc, long dStats);
-    /** returns {kept, oversize} components whose root this rank owns */
-    public static native long[] dccClassify(long dcc, long dStats, long n, long ownFirst, long ownN, int b1, int b2, int thr);
+    /** segFirst[world + 1]: first record of every rank in dStats; returns {kept, oversize} components of the level over ALL ranks
+     *  (every rank holds every component's records: nothing more is exchanged); dccKeptFill: their (root, size, weight) records */
+    public static native long[] dccClassify(long dcc, long dStats, long n, long[] segFirst, long ownFirst, long ownN, int b1, int b2, int thr);
     public static native void dccKeptFill(long dcc, long dKept);
     public static native long dccMembers(long dcc);
     public static native void dccMembersFill(long dcc, long dKmers, long dRoots);

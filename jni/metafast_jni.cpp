@@ -146,7 +146,12 @@ JNIEXPORT jlong JNICALL Java_io_HipBackend_countShard(JNIEnv *e, jclass, jlong c
     if (mf_count_device_shard(CTX(ctx), DEV(dBases), DEV(dOffsets), (uint64_t)nSeqs, (uint64_t)nBases, k, minLen, rank, world, &t) < 0) { raise(e); return 0; }
     return (jlong)(intptr_t)t;
 }
+static bool bad_length(JNIEnv *e, const char *what) {
+    e->ThrowNew(e->FindClass("java/lang/IllegalArgumentException"), what);
+    return true;
+}
 JNIEXPORT jlong JNICALL Java_io_HipBackend_dccCreate(JNIEnv *e, jclass, jlong ctx, jlong shard, jint rank, jint world, jintArray base) {
+    if (world < 1 || e->GetArrayLength(base) < world + 1) { bad_length(e, "dccCreate: base must hold world + 1 entries"); return 0; }
     jint *b = e->GetIntArrayElements(base, nullptr);
     mf_dcc *d = nullptr;
     const int rc = mf_dcc_create(CTX(ctx), (mf_table *)(intptr_t)shard, rank, world, (const uint32_t *)b, &d);
@@ -155,7 +160,10 @@ JNIEXPORT jlong JNICALL Java_io_HipBackend_dccCreate(JNIEnv *e, jclass, jlong ct
     return (jlong)(intptr_t)d;
 }
 JNIEXPORT void JNICALL Java_io_HipBackend_dccDestroy(JNIEnv *, jclass, jlong dcc) { mf_dcc_destroy(DCC(dcc)); }
-JNIEXPORT jlongArray JNICALL Java_io_HipBackend_dccQueries(JNIEnv *e, jclass, jlong dcc, jint world) {
+// (the per-rank count arrays are sized from the handle's own world size, not from a caller-supplied one)
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_dccQueries(JNIEnv *e, jclass, jlong dcc) {
+    const int world = mf_dcc_world(DCC(dcc));
+    if (world < 1) { raise(e); return nullptr; }
     std::vector<uint64_t> c((size_t)world);
     if (mf_dcc_queries(DCC(dcc), c.data()) < 0) { raise(e); return nullptr; }
     return longs(e, c.data(), world);
@@ -165,7 +173,9 @@ JNIEXPORT void JNICALL Java_io_HipBackend_dccAnswer(JNIEnv *e, jclass, jlong dcc
     if (mf_dcc_answer(DCC(dcc), DEV(dQueries), (uint64_t)n, DEV(dAnswers)) < 0) raise(e);
 }
 JNIEXPORT void JNICALL Java_io_HipBackend_dccSetAnswers(JNIEnv *e, jclass, jlong dcc, jlong dAnswers, jlong n) { if (mf_dcc_set_answers(DCC(dcc), DEV(dAnswers), (uint64_t)n) < 0) raise(e); }
-JNIEXPORT jlongArray JNICALL Java_io_HipBackend_dccLevelLocal(JNIEnv *e, jclass, jlong dcc, jint world) {
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_dccLevelLocal(JNIEnv *e, jclass, jlong dcc) {
+    const int world = mf_dcc_world(DCC(dcc));
+    if (world < 1) { raise(e); return nullptr; }
     std::vector<uint64_t> c((size_t)world);
     if (mf_dcc_level_local(DCC(dcc), c.data()) < 0) { raise(e); return nullptr; }
     return longs(e, c.data(), world);
@@ -178,9 +188,16 @@ JNIEXPORT jlong JNICALL Java_io_HipBackend_dccMerge(JNIEnv *e, jclass, jlong dcc
     return (jlong)ns;
 }
 JNIEXPORT void JNICALL Java_io_HipBackend_dccStatsFill(JNIEnv *e, jclass, jlong dcc, jlong dStats) { if (mf_dcc_stats_fill(DCC(dcc), DEV(dStats)) < 0) raise(e); }
-JNIEXPORT jlongArray JNICALL Java_io_HipBackend_dccClassify(JNIEnv *e, jclass, jlong dcc, jlong dStats, jlong n, jlong ownFirst, jlong ownN, jint b1, jint b2, jint thr) {
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_dccClassify(JNIEnv *e, jclass, jlong dcc, jlong dStats, jlong n, jlongArray segFirst, jlong ownFirst, jlong ownN, jint b1,
+                                                            jint b2, jint thr) {
+    const int world = mf_dcc_world(DCC(dcc));
+    if (world < 1) { raise(e); return nullptr; }
+    if (e->GetArrayLength(segFirst) < world + 1) { bad_length(e, "dccClassify: segFirst must hold world + 1 entries"); return nullptr; }
+    jlong *sf = e->GetLongArrayElements(segFirst, nullptr);
     uint64_t r[2] = {0, 0};
-    if (mf_dcc_classify(DCC(dcc), DEV(dStats), (uint64_t)n, (uint64_t)ownFirst, (uint64_t)ownN, b1, b2, thr, &r[0], &r[1]) < 0) { raise(e); return nullptr; }
+    const int rc = mf_dcc_classify(DCC(dcc), DEV(dStats), (uint64_t)n, (const uint64_t *)sf, (uint64_t)ownFirst, (uint64_t)ownN, b1, b2, thr, &r[0], &r[1]);
+    e->ReleaseLongArrayElements(segFirst, sf, JNI_ABORT);
+    if (rc < 0) { raise(e); return nullptr; }
     return longs(e, r, 2);
 }
 JNIEXPORT void JNICALL Java_io_HipBackend_dccKeptFill(JNIEnv *e, jclass, jlong dcc, jlong dKept) { if (mf_dcc_kept_fill(DCC(dcc), DEV(dKept)) < 0) raise(e); }
@@ -200,6 +217,10 @@ JNIEXPORT void JNICALL Java_io_HipBackend_dccMinkeys(JNIEnv *e, jclass, jlong dc
 JNIEXPORT jlong JNICALL Java_io_HipBackend_dccFinish(JNIEnv *e, jclass, jlong dcc, jlong dKmers, jlong dRoots, jlong nMembers, jintArray keptRoot, jintArray keptSize,
                                                      jlongArray keptWeight, jintArray keptThr, jlongArray keptMinkey) {
     const jsize n = e->GetArrayLength(keptRoot);
+    if (e->GetArrayLength(keptSize) != n || e->GetArrayLength(keptWeight) != n || e->GetArrayLength(keptThr) != n || e->GetArrayLength(keptMinkey) != n) {
+        bad_length(e, "dccFinish: the kept arrays must have one entry per component");
+        return 0;
+    }
     jint *g = e->GetIntArrayElements(keptRoot, nullptr), *sz = e->GetIntArrayElements(keptSize, nullptr), *th = e->GetIntArrayElements(keptThr, nullptr);
     jlong *w = e->GetLongArrayElements(keptWeight, nullptr), *mk = e->GetLongArrayElements(keptMinkey, nullptr);
     mf_comps *c = nullptr;

@@ -662,6 +662,7 @@ struct mf_dcc {
     uint64_t nstat = 0, nkept_owned = 0; int level = 0;
     mf_buf<uint32_t> touched; mf_buf<uint2> hp; std::vector<uint64_t> xstart;     // [n] global roots this rank contributes to; [nx] half pairs; [world + 1] cross edges by rank
     mf_buf<dcc_kept_rec> keptbuf;
+    mf_buf<uint64_t> dseg; mf_buf<uint32_t> dbase;         // [world + 1] on the device: first record of every rank (per level), first vertex of every rank
 };
 
 
@@ -784,6 +785,7 @@ __global__ void k_dcc_fill64(unsigned long long *__restrict__ p, uint64_t n, uns
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+extern "C" int mf_dcc_world(const mf_dcc *D) { return D ? D->world : mf_set_error("mf_dcc_world: NULL handle"); }
 extern "C" void mf_dcc_destroy(mf_dcc *d) { delete d; }
 // shard: this rank's part of the cutter table; base[0..world]: global id of every rank's first vertex
 extern "C" int mf_dcc_create(mf_ctx *ctx, mf_table *shard, int rank, int world, const uint32_t *base, mf_dcc **out) {
@@ -1082,13 +1084,12 @@ __global__ void k_dcc_accumulate(const dcc_stat *__restrict__ s, uint64_t n, uin
     atomicAdd(&gweight[s[i].g], s[i].weight);
 }
 // gmin[g]: smallest member k-mer of the kept component with global root g among THIS rank's vertices (the ranks' minima
-// are combined at the end, mf_dcc_minkeys).  A component is reported (kept list, oversize count) by the rank that owns
-// its global root: the vertex that is that root does it.
+// are combined at the end, mf_dcc_minkeys).
 __global__ __launch_bounds__(256) void k_dcc_apply(uint8_t *__restrict__ alive, const uint32_t *__restrict__ root, const uint32_t *__restrict__ groot,
                                                    const uint32_t *__restrict__ gsize, const unsigned long long *__restrict__ gweight, const uint16_t *__restrict__ vals,
                                                    const uint64_t *__restrict__ keys, uint32_t n, uint32_t mybase, uint32_t b1, uint32_t b2, uint32_t next_thr,
-                                                   unsigned int *__restrict__ cnt /* [0] kept [1] big [2] members */, uint64_t *__restrict__ mk,
-                                                   uint32_t *__restrict__ mg, unsigned long long *__restrict__ gmin, dcc_kept_rec *__restrict__ kept) {
+                                                   unsigned int *__restrict__ cnt /* [2] members */, uint64_t *__restrict__ mk,
+                                                   uint32_t *__restrict__ mg, unsigned long long *__restrict__ gmin) {
     __shared__ uint32_t scratch[18];
     const uint32_t v = blockIdx.x * blockDim.x + threadIdx.x;
     bool put = false; uint32_t g = 0; uint64_t key = 0;
@@ -1096,10 +1097,6 @@ __global__ __launch_bounds__(256) void k_dcc_apply(uint8_t *__restrict__ alive, 
         const uint32_t r = root[v];
         g = groot[r];
         const uint32_t s = gsize[g];
-        if (r == v && g == mybase + v && s >= b1) {                      // (rare: straight atomics)
-            if (s <= b2) { const uint32_t at = atomicAdd(&cnt[0], 1u); kept[at].g = g; kept[at].size = s; kept[at].weight = gweight[g]; }
-            else atomicAdd(&cnt[1], 1u);
-        }
         if (s > b2) { if ((uint32_t)vals[v] < next_thr) alive[v] = 0; }
         else { alive[v] = 0; put = s >= b1; }
     }
@@ -1120,6 +1117,24 @@ __global__ __launch_bounds__(256) void k_dcc_apply(uint8_t *__restrict__ alive, 
     }
     if (put) atomicMin(&gmin[g], (unsigned long long)key);
 }
+// EVERY rank lists ALL kept components of the level (and counts the oversize ones) from the gathered records: a component's
+// records arrive from every rank that touches it; the one from the rank that owns the global root -- it always has one, the
+// root vertex itself is in the component -- stands for the component.  (Round 2 had the owner report its components and
+// all-gathered those lists and their lengths: two collectives and a host round trip per level for data every rank already holds.)
+__global__ void k_dcc_report(const dcc_stat *__restrict__ s, uint64_t n, const uint64_t *__restrict__ seg, const uint32_t *__restrict__ base, int world,
+                             const uint32_t *__restrict__ gsize, const unsigned long long *__restrict__ gweight, uint32_t b1, uint32_t b2,
+                             unsigned int *__restrict__ cnt /* [0] kept [1] big */, dcc_kept_rec *__restrict__ kept) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int r = 0;
+    while (r + 1 < world && i >= seg[r + 1]) r++;                          // (world <= 64)
+    const uint32_t g = s[i].g;
+    if (g < base[r] || g >= base[r + 1]) return;
+    const uint32_t sz = gsize[g];
+    if (sz < b1) return;
+    if (sz <= b2) { const uint32_t at = atomicAdd(&cnt[0], 1u); kept[at].g = g; kept[at].size = sz; kept[at].weight = gweight[g]; }
+    else atomicAdd(&cnt[1], 1u);
+}
 __global__ void k_dcc_cross_next(uint8_t *__restrict__ xalive, const uint32_t *__restrict__ xv, const uint16_t *__restrict__ xval, uint64_t nx,
                                  const uint8_t *__restrict__ alive_after, uint32_t next_thr) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1128,25 +1143,35 @@ __global__ void k_dcc_cross_next(uint8_t *__restrict__ xalive, const uint32_t *_
     // if its value does: it is in the same component
     if (!alive_after[xv[e]] || (uint32_t)xval[e] < next_thr) xalive[e] = 0;
 }
-// all ranks' records (n of them, in rank order; [own_first, own_first + own_n) are this rank's own, already counted) -> size /
-// weight per global root; every vertex of this rank is classified: members of kept components are remembered (k-mer, global
-// root), vertices of oversize components whose value reaches thr + 1 stay alive.  *n_kept / *n_big: the kept / oversize
-// components whose global root this rank owns (mf_dcc_kept_fill writes the kept ones).
-extern "C" int mf_dcc_classify(mf_dcc *D, const void *d_stats, uint64_t n, uint64_t own_first, uint64_t own_n, int b1, int b2, int thr, uint64_t *n_kept,
-                               uint64_t *n_big) {
-    if (!D || !n_kept || !n_big || (n && !d_stats)) return mf_set_error("mf_dcc_classify: NULL argument");
+// all ranks' records (n of them, in rank order: rank r's are [seg_first[r], seg_first[r + 1]); [own_first, own_first + own_n) are
+// this rank's own, already counted) -> size / weight per global root; every vertex of this rank is classified: members of kept
+// components are remembered (k-mer, global root), vertices of oversize components whose value reaches thr + 1 stay alive.
+// *n_kept / *n_big: the kept / oversize components of the level over ALL ranks -- the same numbers and, up to order, the same list
+// (mf_dcc_kept_fill) on every rank.
+extern "C" int mf_dcc_classify(mf_dcc *D, const void *d_stats, uint64_t n, const uint64_t *seg_first, uint64_t own_first, uint64_t own_n, int b1, int b2,
+                               int thr, uint64_t *n_kept, uint64_t *n_big) {
+    if (!D || !n_kept || !n_big || !seg_first || (n && !d_stats)) return mf_set_error("mf_dcc_classify: NULL argument");
     if (own_n != D->nstat || own_first + own_n > n) return mf_set_error("mf_dcc_classify: this rank's own records are %llu, not %llu", (unsigned long long)D->nstat, (unsigned long long)own_n);
+    if (seg_first[0] != 0 || seg_first[D->world] != n || seg_first[D->rank] != own_first) return mf_set_error("mf_dcc_classify: seg_first does not describe %llu records", (unsigned long long)n);
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
     MF_HIP(hipSetDevice(ctx->device));
     if (b1 < 0) b1 = 0;
     if (n > own_n) { mf_ktimer tm_(ctx, "k_dcc_accumulate"); k_dcc_accumulate<<<cgrid(n), 256, 0, st>>>((const dcc_stat *)d_stats, n, own_first, own_first + own_n, D->gsize.p, D->gweight.p); }
     MF_HIP(hipMemsetAsync(&D->ctr.p[2], 0, 8, st));
-    if (D->keptbuf.n < D->nstat + 1) MF_TRY(D->keptbuf.alloc(ctx, D->nstat + (D->nstat >> 2) + 1024));       // (a component this rank reports is one it touches)
+    if (D->keptbuf.n < n + 1) MF_TRY(D->keptbuf.alloc(ctx, n + (n >> 2) + 1024));                 // (at most one component per record)
+    if (n) {
+        if (!D->dseg.p) { MF_TRY(D->dseg.alloc(ctx, (size_t)D->world + 1)); MF_TRY(D->dbase.alloc(ctx, (size_t)D->world + 1));
+                          MF_HIP(hipMemcpyAsync(D->dbase.p, D->base.data(), ((size_t)D->world + 1) * 4, hipMemcpyHostToDevice, st)); }
+        MF_HIP(hipMemcpyAsync(D->dseg.p, seg_first, ((size_t)D->world + 1) * 8, hipMemcpyHostToDevice, st));
+        mf_ktimer tm_(ctx, "k_dcc_report");
+        k_dcc_report<<<cgrid(n), 256, 0, st>>>((const dcc_stat *)d_stats, n, D->dseg.p, D->dbase.p, D->world, D->gsize.p, D->gweight.p, (uint32_t)b1, (uint32_t)b2,
+                                               &D->ctr.p[2], D->keptbuf.p);
+    }
     // (every vertex becomes a member at most once: one list of n entries, the cursor ctr[4] runs on from level to level)
     if (D->n) {
         mf_ktimer tm(ctx, "k_cc_members");
         k_dcc_apply<<<cgrid(D->n), 256, 0, st>>>(D->alive.p, D->root.p, D->groot.p, D->gsize.p, D->gweight.p, D->t->d_counts, D->t->d_keys, D->n, D->base[D->rank],
-                                                 (uint32_t)b1, (uint32_t)b2, (uint32_t)(thr + 1), &D->ctr.p[2], D->mk.p, D->mg.p, D->gmin.p, D->keptbuf.p);
+                                                 (uint32_t)b1, (uint32_t)b2, (uint32_t)(thr + 1), &D->ctr.p[2], D->mk.p, D->mg.p, D->gmin.p);
     }
     if (D->nx) { mf_ktimer tm_(ctx, "k_dcc_cross_next"); k_dcc_cross_next<<<cgrid(D->nx), 256, 0, st>>>(D->xalive.p, D->xv.p, D->xval.p, D->nx, D->alive.p, (uint32_t)(thr + 1)); }
     unsigned int c[4];
@@ -1156,7 +1181,8 @@ extern "C" int mf_dcc_classify(mf_dcc *D, const void *d_stats, uint64_t n, uint6
     D->nm = c[2];
     return MF_OK;
 }
-// the kept components of this level whose global root this rank owns: 16 bytes each (root u32, size u32, weight u64)
+// the kept components of this level, all ranks' (every rank holds the same set, in no particular order): 16 bytes each
+// (root u32, size u32, weight u64)
 extern "C" int mf_dcc_kept_fill(mf_dcc *D, void *d_out) {
     if (!D || (D->nkept_owned && !d_out)) return mf_set_error("mf_dcc_kept_fill: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;

@@ -71,7 +71,6 @@ struct mf_ctx {
     int64_t opt_union_samples = 0;     // hint: the sequences of the next count are the unitigs of this many samples (they share k-mers: partitions are planned twice as large from 4 on)
     int own_rank = 0, own_world = 1;   // mf_count_device_shard: only the k-mers this rank owns (level-1 digits [nd1 * rank / world, nd1 * (rank + 1) / world)) are counted
     int64_t opt_nbr_global = 0;    // 1: neighbour lookups of the graph kernels through the HBM index only (A/B of mf_nbr.h)
-    int64_t opt_count_variant = 0; // experiments on k_skm_count (k = 31 only): 1 = two items per lane and step
     int64_t opt_scatter_fast = 1;  // k_skm_scatter: runs dealt evenly over the lanes through LDS where the level leaves room (0 = never)
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero
     // workspace arena: a few large hipMalloc'd regions, sub-allocated with first-fit + coalescing free lists.

@@ -89,7 +89,6 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "verbose") ctx->opt_verbose = v;
     else if (s == "ablate") ctx->opt_ablate = v;
     else if (s == "scatter_fast") ctx->opt_scatter_fast = v;
-    else if (s == "count_variant") ctx->opt_count_variant = v;
     else if (s == "skm") ctx->opt_skm = v;
     else if (s == "skm_batches") ctx->opt_skm_batches = v;
     else if (s == "skm_slices") { if (v < 0 || v > 64 || (v & (v - 1))) return mf_set_error("skm_slices must be 0 or a power of two <= 64"); ctx->opt_skm_slices = v; }

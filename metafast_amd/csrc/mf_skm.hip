@@ -598,7 +598,7 @@ __device__ __forceinline__ uint32_t skm_pass_of(uint64_t key) {
 #define C2_FILL 3400             // claims beyond which a partition is counted again in several passes
 #define C2_QN 128                // queue entries per wave (keys): drained at 64, one push (<= 64 keys) between checks
 #define C2_LH 128                // bins of the workgroup's dropped-count histogram (a cut with thr >= C2_LH is made after the kernel)
-#define C2_ITEMS 896             // item entries per wave: 64 records x 10 items + two (wide) steps of padding (the read-ahead of the last step runs past them, unused)
+#define C2_ITEMS 896             // item entries per wave: 64 records x 10 items + two steps of padding (the read-ahead of the last step runs past them, unused) + the dummy area of the item stores
 #define C2_W 2                   // k-mers per item
 static constexpr size_t C2_LDS = (size_t)C2_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8) + 2 * C2_LH * 4 + 32;
 static_assert(C2_LDS <= 80 * 1024, "two workgroups per CU");
@@ -724,7 +724,9 @@ __device__ __forceinline__ void c2_drain(const c2_wave &L, uint32_t &qn, uint32_
 // the previous one).  An item is up to TWO consecutive k-mers of one record: with four, the last item of a record is half
 // empty on average and a step's instructions (VALU and LDS alike cost the same for 8 live lanes as for 64) ran at 71 %
 // occupancy; with two at 93 %.  Item entry (16 bits): [0,2) k-mers in the item (0 = the padding after the list), [4,10)
-// record slot, [10,15) funnel-shift amount, [15] the item starts in the record's second word.
+// record slot, [10,16) = 63 - 4c for the record's item c: its low five bits are the funnel-shift amount, bit 15 says that the
+// item starts in the record's FIRST word (c < 8) -- one field that falls by 4 from item to item, so the entries of a record
+// are e0, e0 - 0x1000, e0 - 0x2000 ... and the list is written without a branch per item (k_skm_count).
 template <int K>
 __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t &it, skm_v4 &W, uint32_t &it1, uint32_t &qn,
                                         uint32_t &won_acc, uint32_t *part_over, uint32_t P, uint32_t pass) {
@@ -736,7 +738,7 @@ __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t 
     unsigned long long q;                                                  // (VOP3 takes no 32-bit literal on gfx950: the bound sits in an SGPR)
     asm("v_cmp_lt_u32_e64 %0, %2, %1" : "=s"(q) : "v"(it), "s"(0x7FFFu));
     // two k-mers span 2K + 2 <= 64 bits from the item's first base: two funnel shifts over three words
-    const uint32_t A = skm_sel(W.x, W.y, q), B = skm_sel(W.y, W.z, q), C = skm_sel(W.z, W.w, q);
+    const uint32_t A = skm_sel(W.y, W.x, q), B = skm_sel(W.z, W.y, q), C = skm_sel(W.w, W.z, q);      // (q: first word)
     const uint32_t hr = __builtin_amdgcn_alignbit(A, B, sa), lr = __builtin_amdgcn_alignbit(B, C, sa);
     uint32_t fh[2], fl[2], ch[2], cl[2];
     fh[0] = hr >> sh; fl[0] = __builtin_amdgcn_alignbit(hr, lr, sh);
@@ -812,110 +814,9 @@ __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t 
     it = it1; W = W_n; it1 = it2;
 }
 
-// ---- the same step, TWO items per lane (items i0 + lane and i0 + 64 + lane): four probes, two record reads and two item
-// reads in flight behind ONE wait, the loop / queue / EXEC bookkeeping once per 256 k-mers instead of once per 128.
-template <int K>
-__device__ __forceinline__ void c2_item_keys(uint32_t it, const skm_v4 &W, uint64_t (&key)[2], uint32_t (&s)[2], unsigned long long (&live)[2],
-                                             uint32_t P, uint32_t pass) {
-    constexpr int sh = 64 - 2 * K;
-    constexpr int nb = 2 * K - 34;
-    const uint32_t nk = it & 3u;
-    const uint32_t sa = it >> 10;
-    unsigned long long q;
-    asm("v_cmp_lt_u32_e64 %0, %2, %1" : "=s"(q) : "v"(it), "s"(0x7FFFu));
-    const uint32_t A = skm_sel(W.x, W.y, q), B = skm_sel(W.y, W.z, q), C = skm_sel(W.z, W.w, q);
-    const uint32_t hr = __builtin_amdgcn_alignbit(A, B, sa), lr = __builtin_amdgcn_alignbit(B, C, sa);
-    uint32_t fh[2], fl[2], ch[2], cl[2];
-    fh[0] = hr >> sh; fl[0] = __builtin_amdgcn_alignbit(hr, lr, sh);
-    { const uint32_t Vh = __builtin_amdgcn_alignbit(hr, lr, 30), Vl = lr << 2; fh[1] = Vh >> sh; fl[1] = __builtin_amdgcn_alignbit(Vh, Vl, sh); }
-    uint32_t rh, rl;
-    {
-        const uint32_t H = c2_swap_pairs(__builtin_bitreverse32(~fl[0])), Lo = c2_swap_pairs(__builtin_bitreverse32(~fh[0]));
-        rh = H >> sh;
-        rl = __builtin_amdgcn_alignbit(H, Lo, sh);
-    }
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        if (u) {
-            rl = __builtin_amdgcn_alignbit(rh, rl, 2);
-            rh = (rh >> 2) | (((~fl[u]) & 3u) << nb);
-        }
-        const bool lt = (((uint64_t)fh[u] << 32) | fl[u]) < (((uint64_t)rh << 32) | rl);
-        ch[u] = lt ? fh[u] : rh;
-        cl[u] = lt ? fl[u] : rl;
-    }
-    live[0] = c2_gt<0>(nk); live[1] = c2_gt<1>(nk);
-#pragma unroll
-    for (int u = 0; u < 2; u++) {
-        key[u] = ((uint64_t)ch[u] << 32) | cl[u];
-        s[u] = c2_slot(ch[u], cl[u]);
-    }
-    if (P > 1u) {
-#pragma unroll
-        for (int u = 0; u < 2; u++) live[u] &= c2_lt_u32((skm_pass_of(key[u]) & (P - 1u)) ^ pass, 1u);
-    }
-}
-template <int K>
-__device__ __forceinline__ void c2_step_wide(const c2_wave &L, uint32_t i0, uint32_t (&it)[2], skm_v4 (&W)[2], uint32_t (&it1)[2], uint32_t &qn,
-                                             uint32_t &won_acc, uint32_t *part_over, uint32_t P, uint32_t pass) {
-    const uint32_t lane = (uint32_t)mf_lane();
-    uint64_t key[4], ret[4]; uint32_t s[4], ka[4]; unsigned long long live[4];
-    {
-        uint64_t k2[2]; uint32_t s2[2]; unsigned long long l2[2];
-        c2_item_keys<K>(it[0], W[0], k2, s2, l2, P, pass);
-        key[0] = k2[0]; key[1] = k2[1]; s[0] = s2[0]; s[1] = s2[1]; live[0] = l2[0]; live[1] = l2[1];
-        c2_item_keys<K>(it[1], W[1], k2, s2, l2, P, pass);
-        key[2] = k2[0]; key[3] = k2[1]; s[2] = s2[0]; s[3] = s2[1]; live[2] = l2[0]; live[3] = l2[1];
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) ka[u] = L.tk0 + 8u * s[u];
-    uint32_t it2[2]; skm_v4 Wn[2]; unsigned long long save;
-    const uint32_t ia2 = L.items0 + 2u * (i0 + 256u + lane);
-    const uint32_t ra0 = L.rb0 | (it1[0] & 0x3F0u), ra1 = L.rb0 | (it1[1] & 0x3F0u);
-    asm volatile("s_mov_b64 %8, exec\n\tds_read_u16 %4, %9\n\tds_read_u16 %5, %9 offset:128\n\tds_read_b128 %6, %10\n\tds_read_b128 %7, %11\n\t"
-                 "s_mov_b64 exec, %12\n\tds_cmpst_rtn_b64 %0, %16, %20, %21\n\t"
-                 "s_mov_b64 exec, %13\n\tds_cmpst_rtn_b64 %1, %17, %20, %22\n\t"
-                 "s_mov_b64 exec, %14\n\tds_cmpst_rtn_b64 %2, %18, %20, %23\n\t"
-                 "s_mov_b64 exec, %15\n\tds_cmpst_rtn_b64 %3, %19, %20, %24\n\t"
-                 "s_mov_b64 exec, %8\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(ret[0]), "=&v"(ret[1]), "=&v"(ret[2]), "=&v"(ret[3]), "=&v"(it2[0]), "=&v"(it2[1]), "=&v"(Wn[0]), "=&v"(Wn[1]), "=&s"(save)
-                 : "v"(ia2), "v"(ra0), "v"(ra1), "s"(live[0]), "s"(live[1]), "s"(live[2]), "s"(live[3]), "v"(ka[0]), "v"(ka[1]), "v"(ka[2]), "v"(ka[3]),
-                   "v"(MF_EMPTY), "v"(key[0]), "v"(key[1]), "v"(key[2]), "v"(key[3])
-                 : "memory");
-    unsigned long long won[4], ok[4], coll[4]; uint32_t aa[4];
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        won[u] = live[u] & c2_eq_u64(ret[u], MF_EMPTY);
-        ok[u] = won[u] | (live[u] & c2_eq_u64(ret[u], key[u]));
-        coll[u] = live[u] & ~ok[u];
-        aa[u] = L.tc0 + 4u * s[u];
-    }
-    const uint32_t one = 1u;
-    asm volatile("s_mov_b64 %0, exec\n\t"
-                 "s_mov_b64 exec, %1\n\tds_add_u32 %5, %9\n\t"
-                 "s_mov_b64 exec, %2\n\tds_add_u32 %6, %9\n\t"
-                 "s_mov_b64 exec, %3\n\tds_add_u32 %7, %9\n\t"
-                 "s_mov_b64 exec, %4\n\tds_add_u32 %8, %9\n\t"
-                 "s_mov_b64 exec, %0"
-                 : "=&s"(save)
-                 : "s"(ok[0]), "s"(ok[1]), "s"(ok[2]), "s"(ok[3]), "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(one)
-                 : "memory");
-    won_acc += (uint32_t)__popcll(won[0]) + (uint32_t)__popcll(won[1]) + (uint32_t)__popcll(won[2]) + (uint32_t)__popcll(won[3]);
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-        if (coll[u] != 0ull) {
-            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(coll[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)coll[u], qn));
-            c2_push64(coll[u], L.qk0 + 8u * at, key[u]);
-            qn += (uint32_t)__popcll(coll[u]);
-            while (qn >= 64u) c2_drain(L, qn, won_acc, part_over);       // (then qn < 64: + one push <= C2_QN)
-        }
-    }
-    it[0] = it1[0]; it[1] = it1[1]; W[0] = Wn[0]; W[1] = Wn[1]; it1[0] = it2[0]; it1[1] = it2[1];
-}
-
 // PROF: cycle counters per phase (diagnostics, option ablate & 32; s_memtime perturbs the kernel by about a tenth)
 #define C2_TICK(i) do { if (PROF) { const long long t__ = clock64(); prof[i] += (unsigned long long)(t__ - tlast); tlast = t__; } } while (0)
-template <int K, bool PROF, bool WIDE = false>
+template <int K, bool PROF>
 __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart,
                                                            const uint32_t *__restrict__ plen, uint32_t np,
                                                            const uint64_t *__restrict__ toff, uint64_t *__restrict__ tkeys,
@@ -1030,39 +931,37 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                 Pk.x = x1 >> 1; Pk.y = __builtin_amdgcn_alignbit(x1, x0, 1); Pk.z = __builtin_amdgcn_alignbit(x0, y1, 1); Pk.w = __builtin_amdgcn_alignbit(y1, y0, 1);
                 *reinterpret_cast<__attribute__((address_space(3))) skm_v4 *>((uintptr_t)(L.rb0 + 16u * lane)) = Pk;
             }
+            {   // the record's items: entry c = e0 - c * 0x1000 (two k-mers; see c2_step), lanes without an item c write to
+                // their dummy slot -- no branch per item; a last item of ONE k-mer is written again afterwards
+                static_assert(C2_W == 2 && C2_ITEMS >= 640 + 128 + 64 + 10, "item list layout");
+                const uint32_t e0 = 2u | (lane << 4) | (63u << 10);
+                const uint32_t ia = L.items0 + 2u * ioff, dummy = L.items0 + 2u * (uint32_t)(C2_ITEMS - 74) + 2u * lane;
 #pragma unroll
-            for (int c = 0; c < 20 / C2_W; c++) {
-                // item c starts at bit 4c+1 of the parked record: funnel shift (32 - (4c+1)) & 31, second word from c = 8
-                if ((uint32_t)c < nch) {
-                    const uint32_t left = r - (uint32_t)(C2_W * c);
-                    const uint32_t e = (left < (uint32_t)C2_W ? left : (uint32_t)C2_W) | (lane << 4) | ((uint32_t)((31 - 2 * C2_W * c) & 31) << 10) | ((uint32_t)((2 * C2_W * c + 1) >> 5) << 15);
-                    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (ioff + (uint32_t)c))) = (uint16_t)e;
+                for (int c = 0; c < 10; c++) {
+                    const uint32_t addr = (uint32_t)c < nch ? ia : dummy;
+                    const uint32_t e = e0 - (uint32_t)c * 0x1000u;
+                    asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(addr), "v"(e), "n"(2 * c) : "memory");
+                }
+                if (r & 1u) {
+                    const uint32_t e = e0 - (nch - 1u) * 0x1000u - 1u;
+                    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(ia + 2u * (nch - 1u))) = (uint16_t)e;
                 }
             }
             // padding after the list: items without k-mers for the idle lanes of the last step (the step after
             // that is only read ahead, never used)
             {
-                const uint32_t z = 0u;      // (u32 stores: NI may be odd -> two u16 stores per 64 entries; WIDE pads twice as far)
+                const uint32_t z = 0u;
 #pragma unroll
-                for (int t = 0; t < (WIDE ? 4 : 2); t++)
+                for (int t = 0; t < 2; t++)
                     *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (NI + 64u * (uint32_t)t + lane))) = (uint16_t)z;
             }
             __builtin_amdgcn_wave_barrier();
-            if (WIDE) {
-                uint32_t it[2], it1[2]; skm_v4 W[2];
-                asm volatile("ds_read_u16 %0, %4\n\tds_read_u16 %1, %4 offset:128\n\tds_read_u16 %2, %4 offset:256\n\tds_read_u16 %3, %4 offset:384\n\ts_waitcnt lgkmcnt(0)"
-                             : "=&v"(it[0]), "=&v"(it[1]), "=&v"(it1[0]), "=&v"(it1[1]) : "v"(L.items0 + 2u * lane) : "memory");
-                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(W[0]), "=&v"(W[1]) : "v"(L.rb0 | (it[0] & 0x3F0u)), "v"(L.rb0 | (it[1] & 0x3F0u)) : "memory");
-                C2_TICK(1);
-                for (uint32_t i0 = 0; i0 < NI; i0 += 128) c2_step_wide<K>(L, i0, it, W, it1, qn, won_acc, part_over, P, pass);      // wave-uniform
-            } else {
             uint32_t it, it1; skm_v4 W;
             // (LDS operations of one wave execute in order: the reads see the stores above without a wait in between)
             asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(it), "=&v"(it1) : "v"(L.items0 + 2u * lane) : "memory");
             asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(W) : "v"(L.rb0 | (it & 0x3F0u)) : "memory");
             C2_TICK(1);                                                         // round set-up (incl. the wait for the records)
             for (uint32_t i0 = 0; i0 < NI; i0 += 64) c2_step<K>(L, i0, it, W, it1, qn, won_acc, part_over, P, pass);      // wave-uniform
-            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
             __builtin_amdgcn_wave_barrier();
             C2_TICK(2);                                                         // steps (with the drains inside them)
@@ -1464,10 +1363,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             mf_ktimer t(ctx, "k_skm_count");
 #define SKM_COUNT_ARGS bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2], p0, (uint64_t)tb[b], kthr, &scal[7], \
                        (unsigned int *)&scal[8], dhist.p, c2p.p, (uint64_t)tmax
-            if (c2prof) {
-                if (ctx->opt_count_variant == 1) k_skm_count<(K == 31 ? 31 : 20), true, true><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
-                else k_skm_count<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
-            } else if (K == 31 && ctx->opt_count_variant == 1) k_skm_count<(K == 31 ? 31 : 20), false, true><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
+            if (c2prof) k_skm_count<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
             else k_skm_count<K, false><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
 #undef SKM_COUNT_ARGS
         }
@@ -1551,11 +1447,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     // them in a small LDS histogram: a cut above C2_LH - 1 is made afterwards (mf_count_skm)
     const int kthr = thr < C2_LH ? thr : -1;
     MF_TRY(skm_set_lds(k_skm_count<K, false>, C2_LDS));
-    if (K == 31) {
-        MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), true>, C2_LDS));
-        MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), true, true>, C2_LDS));
-        MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), false, true>, C2_LDS));
-    }
+    if (K == 31) MF_TRY(skm_set_lds(k_skm_count<(K == 31 ? 31 : 20), true>, C2_LDS));
     // Slices (HBM budget): the records of a run are about a third of the reads' bytes per radix level, two levels ping-pong.
     // Reads, table and index have to fit beside them.  Option skm_slices forces a number (tests); arena_cap_gb stands in for
     // a smaller device.

@@ -61,7 +61,8 @@ _SIGS = {
     "mf_dcc_pairs_complete": (i32, [vp, vp, u64]),
     "mf_dcc_merge": (i32, [vp, vp, u64, pu64]),
     "mf_dcc_stats_fill": (i32, [vp, vp]),
-    "mf_dcc_classify": (i32, [vp, vp, u64, u64, u64, i32, i32, i32, pu64, pu64]),
+    "mf_dcc_classify": (i32, [vp, vp, u64, vp, u64, u64, i32, i32, i32, pu64, pu64]),
+    "mf_dcc_world": (i32, [vp]),
     "mf_dcc_kept_fill": (i32, [vp, vp]),
     "mf_dcc_members": (i32, [vp, pu64]),
     "mf_dcc_members_fill": (i32, [vp, vp, vp]),
@@ -463,7 +464,7 @@ class DistCutter:
         base = np.ascontiguousarray(base, dtype=np.uint32)
         h = C.c_void_p()
         _check(lib().mf_dcc_create(ctx.h, shard.h, rank, world, base.ctypes.data, C.byref(h)))
-        self.h, self.world = h, world
+        self.h, self.world, self.rank = h, world, rank
 
     def close(self):
         if getattr(self, "h", None) and _lib is not None and getattr(self.ctx, "h", None):
@@ -510,9 +511,11 @@ class DistCutter:
     def stats_fill(self, d_out):
         _check(lib().mf_dcc_stats_fill(self.h, d_out))
 
-    def classify(self, d_stats, n, own_first, own_n, b1, b2, thr):
+    def classify(self, d_stats, n, seg_first, own_n, b1, b2, thr, rank):
+        """seg_first: first record of every rank (world + 1 entries) -> (kept, oversize) components of the level over ALL ranks"""
+        seg = np.ascontiguousarray(seg_first, dtype=np.uint64)
         a, b = C.c_uint64(), C.c_uint64()
-        _check(lib().mf_dcc_classify(self.h, d_stats, n, own_first, own_n, b1, b2, thr, C.byref(a), C.byref(b)))
+        _check(lib().mf_dcc_classify(self.h, d_stats, n, seg.ctypes.data, int(seg[rank]), own_n, b1, b2, thr, C.byref(a), C.byref(b)))
         return a.value, b.value
 
     def kept_fill(self, d_out):

@@ -10,6 +10,7 @@ rank working on its shard (distributed_components); the per-sample feature vecto
 Bray-Curtis matrix.  torch is used for device memory and torch.distributed only.
 """
 import os
+import sys
 import time
 
 import numpy as np
@@ -145,16 +146,27 @@ class TorchComm:
 
     def __init__(self):
         self.rank, self.world = _world()
+        self.stats = dict(collectives=0, bytes_in=0, seconds=0.0)     # what a step exchanged (bench.py reports it)
+
+    def _account(self, t0, nbytes_in):
+        if torch.cuda.is_available():
+            torch.cuda.current_stream().synchronize()
+        self.stats["collectives"] += 1
+        self.stats["bytes_in"] += int(nbytes_in)
+        self.stats["seconds"] += time.perf_counter() - t0
 
     def all_gather_ints(self, vals):
         """small host vectors (same length on every rank) -> int64 ndarray [world, len]"""
         if self.world == 1 and not _force():
             return np.asarray([vals], dtype=np.int64)
+        t0 = time.perf_counter()
         dev = "cpu" if dist.get_backend() == "gloo" else "cuda"
         t = torch.tensor(list(vals), dtype=torch.int64, device=dev)
         out = torch.empty(self.world * t.numel(), dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(out, t)
-        return out.cpu().numpy().reshape(self.world, -1)
+        res = out.cpu().numpy().reshape(self.world, -1)
+        self._account(t0, out.numel() * 8)
+        return res
 
     def all_gather(self, t, sizes):
         """1-D tensors, sizes[r] elements on rank r (known to all) -> their concatenation in rank order"""
@@ -163,7 +175,10 @@ class TorchComm:
             return t
         if t.is_cuda and dist.get_backend() == "gloo":
             return self.all_gather(t.cpu(), sizes).to(t.device)
-        return _gather_sized(t, sizes, self.rank, self.world)
+        t0 = time.perf_counter()
+        out = _gather_sized(t, sizes, self.rank, self.world)
+        self._account(t0, out.numel() * out.element_size())
+        return out
 
     def all_reduce_min(self, t):
         if self.world == 1 and not _force():
@@ -171,7 +186,9 @@ class TorchComm:
         if t.is_cuda and dist.get_backend() == "gloo":
             return self.all_reduce_min(t.cpu()).to(t.device)
         if t.numel():
+            t0 = time.perf_counter()
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            self._account(t0, t.numel() * t.element_size())
         return t
 
     def all_to_all(self, t, matrix):
@@ -183,8 +200,10 @@ class TorchComm:
             return t
         if t.is_cuda and dist.get_backend() == "gloo":         # (tests: staged through the host, the same call below)
             return self.all_to_all(t.cpu(), matrix).to(t.device)
+        t0 = time.perf_counter()
         out = torch.empty(sum(recv), dtype=t.dtype, device=t.device)
         dist.all_to_all_single(out, t.contiguous(), recv, send)
+        self._account(t0, out.numel() * out.element_size())
         return out
 
 
@@ -261,13 +280,26 @@ def _i64(n, device):
     return torch.empty(max(int(n), 1), dtype=torch.int64, device=device)
 
 
+class DistAbort(L.MetafastError):
+    """a rank could not do its part of the sharded cutter; EVERY rank raises this at the same point of the protocol (the status
+    rides on the integer gathers), so that all of them can take the replicated path together instead of one rank raising
+    while its peers wait inside a collective"""
+
+
 def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=None, info=None):
     """Component cutter with every rank owning a shard of the cutter table (include/metafast_hip.h, "A9-A11 on several
-    GPUs").  shard: this rank's Context.count_device_shard of all samples' unitigs.  Returns the components: the same
-    object on every rank, identical to cut_components on the whole table (ComponentsBuilder.splitStrategy,
-    src/algo/ComponentsBuilder.java:24-32)."""
+    GPUs").  shard: this rank's Context.count_device_shard of all samples' unitigs (None: the count failed here -- the
+    ranks then raise DistAbort together).  Returns the components: the same object on every rank, identical to
+    cut_components on the whole table (ComponentsBuilder.splitStrategy, src/algo/ComponentsBuilder.java:24-32).
+
+    Collectives: 1 + 3 once (shard sizes; query counts, queries, answers), then per threshold level 2 integer gathers (half
+    pairs per destination + the level before's oversize count; records per rank) + 1 all-to-all (half pairs) + 2 all-gathers (completed pairs; per-component
+    records) -- from the gathered records EVERY rank derives all kept components and the number of oversize ones itself
+    (round 2: three more collectives per level for lists every rank could compute) --, and 2 + 1 + 1 at the end (members'
+    k-mers and roots, their count, the components' smallest k-mers)."""
     W, me = comm.world, comm.rank
     t0, w0 = time.perf_counter(), getattr(comm, "waited", 0.0)
+    err = []                                 # the first library error on this rank: announced with the next integer gather
 
     def mark(name):
         nonlocal t0, w0
@@ -280,70 +312,101 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
     def sync():
         torch.cuda.current_stream().synchronize()
 
-    ns = comm.all_gather_ints([len(shard)])[:, 0]
+    def call(fn, default=None):
+        """a library call that may fail (memory on ONE rank, a capacity limit): after the first failure this rank only keeps the
+        collectives going (buffers of the agreed sizes, contents irrelevant) until the next integer gather tells everybody"""
+        if err:
+            return default
+        try:
+            return fn()
+        except L.MetafastError as e:
+            err.append(e)
+            return default
+
+    def gather_ints(vals, n):
+        """all_gather_ints with the status in front; vals: callable -> n integers"""
+        v = call(lambda: [int(x) for x in vals()], None)
+        m = comm.all_gather_ints([0 if err else 1] + (v if v is not None else [0] * n))
+        if not m[:, 0].all():
+            bad = [int(r) for r in np.nonzero(m[:, 0] == 0)[0]]
+            raise DistAbort("sharded component cutter: rank(s) %s failed%s" % (bad, (": %s" % err[0]) if err else ""))
+        return m[:, 1:]
+
+    if shard is None:
+        err.append(L.MetafastError("no shard"))
+    ns = gather_ints(lambda: [len(shard)], 1)[:, 0]
     base = np.concatenate([[0], np.cumsum(ns)])
     if int(base[-1]) >= 0xFFFFFFFF:
-        raise L.MetafastError("components: more than 2^32 vertices over all ranks is not supported")
-    D = L.DistCutter(ctx, shard, me, W, base)
-    # ---- neighbours in other shards
-    qm = comm.all_gather_ints(D.queries())
-    nq = int(qm[me].sum())
-    q = _i64(2 * nq, device); sync()
-    D.queries_fill(q.data_ptr())
-    rq = comm.all_to_all(q[:2 * nq], 2 * qm); sync()
-    na = int(rq.numel()) // 2
-    a = _i64(2 * na, device); sync()
-    D.answer(rq.data_ptr(), na, a.data_ptr())
-    ra = comm.all_to_all(a[:2 * na], 2 * qm.T); sync()
-    D.set_answers(ra.data_ptr(), nq)
-    del q, rq, a, ra
-    mark("cutter_adjacency")
-    # ---- threshold levels
-    kept, levels, per_level = [], 0, []
-    for thr in range(1, 1 << 16):
-        pm = comm.all_gather_ints(D.level_local())
-        nsend = int(pm[me].sum())
-        hp = _i64(nsend, device); sync()
-        D.pairs_fill(hp.data_ptr())
-        rp = comm.all_to_all(hp[:nsend], pm); sync()
-        nr = int(rp.numel())
-        if nr:
-            rp = rp.contiguous()
-            D.pairs_complete(rp.data_ptr(), nr)
-        allp = comm.all_gather(rp, pm.sum(axis=0)); sync()
-        n_stats = D.merge(allp.data_ptr(), int(allp.numel()))
-        st = _i64(2 * n_stats, device); sync()
-        D.stats_fill(st.data_ptr())
-        sm = comm.all_gather_ints([n_stats])[:, 0]
-        alls = comm.all_gather(st[:2 * n_stats], 2 * sm); sync()
-        n_kept, n_big = D.classify(alls.data_ptr(), int(alls.numel()) // 2, int(sm[:me].sum()), n_stats, b1, b2, thr)
-        kb = _i64(2 * n_kept, device); sync()
-        D.kept_fill(kb.data_ptr())
-        km = comm.all_gather_ints([n_kept, n_big])
-        allk = comm.all_gather(kb[:2 * n_kept], 2 * km[:, 0]).cpu().numpy()
-        if allk.size:
-            r = allk.reshape(-1, 2)
-            kept.append((r[:, 0] & 0xFFFFFFFF, (r[:, 0] >> 32) & 0xFFFFFFFF, r[:, 1], np.full(len(r), thr, dtype=np.int32)))
-        levels = thr
-        per_level.append((int(allp.numel()), int(sm.sum()), int(km[:, 0].sum()), int(km[:, 1].sum())))
-        if int(km[:, 1].sum()) == 0:
-            break
-    mark("cutter_levels")
-    # ---- members of the kept components, everywhere
-    nm = D.members()
-    mk = _i64(nm, device); mg = torch.empty(max(nm, 1), dtype=torch.int32, device=device); sync()
-    D.members_fill(mk.data_ptr(), mg.data_ptr())
-    mm = comm.all_gather_ints([nm])[:, 0]
-    allmk = comm.all_gather(mk[:nm], mm); allmg = comm.all_gather(mg[:nm], mm); sync()
-    cat = (lambda i, dt: np.concatenate([x[i] for x in kept]).astype(dt)) if kept else (lambda i, dt: np.zeros(0, dtype=dt))
-    roots = cat(0, np.uint32)
-    mn = _i64(len(roots), device); sync()
-    D.minkeys(roots, mn.data_ptr())
-    mn = comm.all_reduce_min(mn[:len(roots)]).cpu().numpy().astype(np.uint64)
-    comps = D.finish(allmk.data_ptr(), allmg.data_ptr(), int(allmk.numel()), roots, cat(1, np.uint32), cat(2, np.int64), cat(3, np.int32), mn)
-    if info is not None:
-        info.update(levels=levels, per_level=per_level, shard=int(ns[me]), vertices=int(base[-1]), queries=nq, members=int(allmk.numel()))
-    D.close()
+        raise L.MetafastError("components: more than 2^32 vertices over all ranks is not supported")      # (every rank sees the same total)
+    D = call(lambda: L.DistCutter(ctx, shard, me, W, base))
+    try:
+        # ---- neighbours in other shards
+        qm = gather_ints(lambda: D.queries(), W)
+        nq = int(qm[me].sum())
+        q = _i64(2 * nq, device); sync()
+        call(lambda: D.queries_fill(q.data_ptr()))
+        rq = comm.all_to_all(q[:2 * nq], 2 * qm); sync()
+        na = int(rq.numel()) // 2
+        a = _i64(2 * na, device); sync()
+        call(lambda: D.answer(rq.data_ptr(), na, a.data_ptr()))
+        ra = comm.all_to_all(a[:2 * na], 2 * qm.T); sync()
+        call(lambda: D.set_answers(ra.data_ptr(), nq))
+        del q, rq, a, ra
+        mark("cutter_adjacency")
+        # ---- threshold levels
+        kept, levels, per_level = [], 0, []
+        n_big = -1
+        for thr in range(1, 1 << 16):
+            # (the gather that opens a level also closes the one before: it carries that level's oversize count -- the same on
+            # every rank -- and the status of the calls since the last gather, so all ranks leave the loop, or abort, together)
+            pm = gather_ints(lambda: [n_big] + ([int(x) for x in D.level_local()] if n_big else [0] * W), W + 1)
+            if int(pm[me][0]) == 0:
+                break
+            pm = pm[:, 1:]
+            nsend = int(pm[me].sum())
+            hp = _i64(nsend, device); sync()
+            call(lambda: D.pairs_fill(hp.data_ptr()))
+            rp = comm.all_to_all(hp[:nsend], pm); sync()
+            nr = int(rp.numel())
+            if nr:
+                rp = rp.contiguous()
+                call(lambda: D.pairs_complete(rp.data_ptr(), nr))
+            allp = comm.all_gather(rp, pm.sum(axis=0)); sync()
+            n_stats = call(lambda: D.merge(allp.data_ptr(), int(allp.numel())), 0)
+            sm = gather_ints(lambda: [n_stats], 1)[:, 0]
+            st = _i64(2 * n_stats, device); sync()
+            call(lambda: D.stats_fill(st.data_ptr()))
+            alls = comm.all_gather(st[:2 * n_stats], 2 * sm); sync()
+            seg = np.concatenate([[0], np.cumsum(sm)])
+            n_kept, n_big = call(lambda: D.classify(alls.data_ptr(), int(alls.numel()) // 2, seg, n_stats, b1, b2, thr, me), (0, 0))
+            kb = _i64(2 * n_kept, device); sync()
+            call(lambda: D.kept_fill(kb.data_ptr()))
+            allk = kb[:2 * n_kept].cpu().numpy()
+            if allk.size:
+                r = allk.reshape(-1, 2)
+                r = r[np.argsort(r[:, 0] & 0xFFFFFFFF, kind="stable")]        # by root: the order every rank agrees on
+                kept.append((r[:, 0] & 0xFFFFFFFF, (r[:, 0] >> 32) & 0xFFFFFFFF, r[:, 1], np.full(len(r), thr, dtype=np.int32)))
+            levels = thr
+            per_level.append((int(allp.numel()), int(sm.sum()), int(n_kept), int(n_big)))
+        mark("cutter_levels")
+        # ---- members of the kept components, everywhere
+        nm = call(lambda: D.members(), 0)
+        mm = gather_ints(lambda: [nm], 1)[:, 0]
+        mk = _i64(nm, device); mg = torch.empty(max(nm, 1), dtype=torch.int32, device=device); sync()
+        call(lambda: D.members_fill(mk.data_ptr(), mg.data_ptr()))
+        allmk = comm.all_gather(mk[:nm], mm); allmg = comm.all_gather(mg[:nm], mm); sync()
+        cat = (lambda i, dt: np.concatenate([x[i] for x in kept]).astype(dt)) if kept else (lambda i, dt: np.zeros(0, dtype=dt))
+        roots = cat(0, np.uint32)
+        mn = _i64(len(roots), device); sync()
+        call(lambda: D.minkeys(roots, mn.data_ptr()))
+        mn = comm.all_reduce_min(mn[:len(roots)]).cpu().numpy().astype(np.uint64)
+        comps = call(lambda: D.finish(allmk.data_ptr(), allmg.data_ptr(), int(allmk.numel()), roots, cat(1, np.uint32), cat(2, np.int64), cat(3, np.int32), mn))
+        gather_ints(lambda: [len(comps)], 1)          # (the last status: every rank has its components, or all raise)
+        if info is not None:
+            info.update(levels=levels, per_level=per_level, shard=int(ns[me]), vertices=int(base[-1]), queries=nq, members=int(allmk.numel()))
+    finally:
+        if D is not None:
+            D.close()
     mark("cutter_members")
     return comps
 
@@ -365,6 +428,7 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
             t0 = t1
 
     goods, seqss, hists, n_occ, n_distinct = [], [], [], 0, 0
+    comm_stats = dict(collectives=0, bytes_in=0, seconds=0.0)
     for si, (d_bases, d_offsets, n_reads, n_bases) in enumerate(samples):
         if si:
             # several samples on this rank: the previous sample's lookup index (3-6 times its table) is not needed again before
@@ -401,9 +465,26 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
         allb, allo, ns, nbt = gather_sequences(sb, so)
         torch.cuda.current_stream().synchronize()
         mark("exchange_unitigs")
-        cutter = ctx.count_device_shard(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l, rank, world)
+        comm = TorchComm()
+        try:
+            cutter = ctx.count_device_shard(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l, rank, world)
+        except L.MetafastError:
+            cutter = None                    # (e.g. a partition too rich for the shard path on this rank: the ranks agree below)
         mark("cutter_count")
-        comps = distributed_components(ctx, TorchComm(), cutter, k, b1, b2, device=device, timings=timings)
+        try:
+            comps = distributed_components(ctx, comm, cutter, k, b1, b2, device=device, timings=timings)
+        except DistAbort as e:
+            # all ranks are here together: the replicated cutter instead (every rank counts all unitigs and cuts all components)
+            print("[metafast_amd] %s -- every rank builds the whole cutter table" % e, file=sys.stderr)
+            if cutter is not None:
+                cutter.close()
+            ctx.set_option("union_samples", int(comm.all_gather_ints([len(goods)]).sum()))
+            try:
+                cutter = ctx.count_device(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l)
+            finally:
+                ctx.set_option("union_samples", 0)
+            comps = ctx.cut_components(cutter, b1, b2)
+        comm_stats = comm.stats
         t0 = time.perf_counter()
     else:
         # (world sizes that are not a power of two, k < 20: every rank builds the whole cutter table and all components)
@@ -431,7 +512,7 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
     matrix = L.bray_curtis(vecs) if vecs.shape[1] else np.zeros((vecs.shape[0], vecs.shape[0]))
     mark("features_matrix")
     return dict(goods=goods, seqss=seqss, cutter=cutter, comps=comps, vecs_local=vecs_local, breadths=breadths, vecs=vecs,
-                matrix=matrix, n_occ=n_occ, n_distinct=n_distinct, hists=hists)
+                matrix=matrix, n_occ=n_occ, n_distinct=n_distinct, hists=hists, comm=comm_stats)
 
 
 def run_sample(ctx, d_bases, d_offsets, n_reads, n_bases, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda",

@@ -79,6 +79,44 @@ def test_exchanges_world2(tmp_path):
         assert np.load(tmp_path / f"n{rank}.npy").tolist() == [a0.sum(), a1.sum(), 100000, 100050, f0.sum(), f1.sum(), 100, 200100]
 
 
+def _worker4(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from metafast_amd import pipeline as P
+    comm = P.TorchComm()
+    # matrix[src][dst]: non-uniform, rank 2 neither sends nor receives anything, rank 3 only sends
+    m = np.array([[0, 5, 0, 2], [1, 0, 0, 7], [0, 0, 0, 0], [4, 3, 0, 0]])
+    send = torch.arange(int(m[rank].sum()), dtype=torch.int64) + 1000 * rank
+    got = comm.all_to_all(send, m)
+    sizes = [3, 0, 4, 1]                                                     # an all-gather with an EMPTY contribution (rank 1)
+    ag = comm.all_gather(torch.full((sizes[rank],), rank, dtype=torch.int32), sizes)
+    ints = comm.all_gather_ints([rank, 1 if rank != 2 else 0])
+    mn = comm.all_reduce_min(torch.tensor([10 + rank, 10 - rank], dtype=torch.int64))
+    seqs = ["ACGTACGTAC"[: 4 + rank]] * (rank % 2)                           # ranks 0 and 2 have NO unitigs
+    bases = torch.from_numpy(np.frombuffer("".join(seqs).encode(), dtype=np.uint8).copy())
+    offs = torch.tensor(np.concatenate([[0], np.cumsum([len(x) for x in seqs])]), dtype=torch.int64)
+    allb, allo, ns, nb = P.gather_sequences(bases, offs)
+    np.save(os.path.join(out_dir, f"q{rank}.npy"), np.array(got.tolist() + [-1] + ag.tolist() + [-1] + ints.reshape(-1).tolist() + [-1] + mn.tolist()
+                                                             + [-1, ns, nb] + allo.tolist() + [comm.stats["collectives"]], dtype=np.int64))
+    dist.destroy_process_group()
+
+
+def test_exchanges_world4_nonuniform_and_empty_ranks(tmp_path):
+    world = 4
+    mp.spawn(_worker4, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    m = np.array([[0, 5, 0, 2], [1, 0, 0, 7], [0, 0, 0, 0], [4, 3, 0, 0]])
+    for rank in range(world):
+        want = []
+        for src in range(world):                                             # what src sent to `rank`: the slice of its payload behind the earlier destinations
+            o = int(m[src][:rank].sum())
+            want += [1000 * src + o + i for i in range(int(m[src][rank]))]
+        want += [-1] + [0, 0, 0, 2, 2, 2, 2, 3] + [-1] + [0, 1, 1, 1, 2, 0, 3, 1] + [-1] + [10, 7] + [-1, 2, 12, 0, 5, 12]
+        got = np.load(tmp_path / f"q{rank}.npy").tolist()
+        assert got[:-1] == want, (rank, got, want)
+        assert got[-1] >= 4                                                  # (the exchanges were counted)
+
+
 def test_single_process_paths():
     from metafast_amd import pipeline as P
     t = torch.arange(5)

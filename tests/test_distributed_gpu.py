@@ -107,7 +107,7 @@ def test_rccl_path_world1(oracle, tmp_path):
 
 
 # ---- the sharded cutter with W virtual ranks in one process (threads; pipeline.ThreadComm stands in for RCCL) ----
-def _virtual_ranks(world, inputs, b1, b2, k=31, b=1, l=100):
+def _virtual_ranks(world, inputs, b1, b2, k=31, b=1, l=100, fail_rank=None, fail_at=None):
     """inputs: (bases, offsets) host arrays of the samples; their unitigs are what every rank has after the all-gather of
     pipeline.run_samples -> per rank (components export, info)"""
     import threading
@@ -141,7 +141,21 @@ def _virtual_ranks(world, inputs, b1, b2, k=31, b=1, l=100):
             ctx = L.Context(0)
             shard = ctx.count_device_shard(allb.data_ptr(), allo.data_ptr(), int(allo.numel()) - 1, nb, k, l, rank, world)
             info = {}
-            comps = P.distributed_components(ctx, comm, shard, k, b1, b2, info=info)
+            if rank == fail_rank and fail_at == "shard":
+                shard = None                                     # (the count failed on this rank)
+            if rank == fail_rank and fail_at == "merge":         # (a library call in the middle of a level fails on this rank only)
+                real = L.DistCutter.merge
+
+                def merge_fails_on_one_rank(self, *a):
+                    if self.rank == fail_rank:
+                        raise L.MetafastError("injected failure")
+                    return real(self, *a)
+                L.DistCutter.merge = merge_fails_on_one_rank
+            try:
+                comps = P.distributed_components(ctx, comm, shard, k, b1, b2, info=info)
+            except P.DistAbort as e:
+                out[rank] = ("abort", str(e))
+                return
             info["shard_len"] = len(shard)
             out[rank] = (comps.export(), info)
         except BaseException as e:          # (a rank that dies must not leave the others waiting at the barrier)
@@ -189,6 +203,23 @@ def test_sharded_cutter_virtual_ranks(oracle, world):
         assert info["levels"] == 6
     assert sum(i["shard_len"] for _, i in res) == res[0][1]["vertices"]
     assert all(i["shard_len"] > 0 for _, i in res)
+
+
+@pytest.mark.parametrize("fail_at", ["shard", "merge"])
+def test_sharded_cutter_ranks_abort_together(fail_at):
+    """one rank cannot do its part (its shard count failed / a call in the middle of a level fails): EVERY rank leaves the
+    protocol with DistAbort at the same gather -- nobody is left waiting inside a collective (pipeline.run_samples then takes
+    the replicated cutter on all ranks)"""
+    from util import branchy_reads
+    inputs = [branchy_reads(rs, genome_seed=7, n=6000) for rs in (107, 117)]
+    from metafast_amd import lib as L
+    real = L.DistCutter.merge
+    try:
+        res = _virtual_ranks(4, inputs, 100, 1000, fail_rank=2, fail_at=fail_at)
+    finally:
+        L.DistCutter.merge = real
+    assert all(r[0] == "abort" for r in res), res
+    assert all("rank(s) [2] failed" in r[1] for r in res)
 
 
 @pytest.mark.skipif(not os.environ.get("MF_TRY_RCCL_2RANKS"), reason="two RCCL ranks on ONE device: RCCL refuses duplicate GPUs on most builds (opt-in: MF_TRY_RCCL_2RANKS=1)")

@@ -56,6 +56,7 @@ for n in ([N] if os.environ.get('MF_SIM_SHARDED_ONLY') else sorted({1, 2, 4, N})
     print(f"union of {n}: {ns} unitigs, {nb} bases, cutter k-mers {nk}, components {nc}: cutter count {1e3*(t1-t0):.1f} ms, components {1e3*(t2-t1):.1f} ms", flush=True)
 
 # ---- (b) sharded: N virtual ranks, every rank has all unitigs (the all-gather) and counts the k-mers it owns
+ctx.trim(); torch.cuda.empty_cache()      # (the first context's arena still holds what the samples needed)
 group = P.ThreadGroup(N)
 res = [None] * N
 def work(rank):
