@@ -125,9 +125,10 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             uint32_t R;
             const uint32_t rbase = mf_wave_excl_scan((uint32_t)__popc(remote), &R);
             uint32_t idx[8];
-            // (Tried in round 3: the first probes of all eight -- or four -- neighbours in flight behind one wait, the rest in a
-            // wave-uniform loop.  119 / 137 VGPRs instead of 81 take a wave per SIMD away, and every lane then reads for all
-            // eight neighbours whether it wants them or not: k_ut_flags 29.2 ms against 26.4 with the per-neighbour loops below.)
+            // (Tried in round 3: the first probes of eight, four or two neighbours in flight behind one wait, the rest in a
+            // wave-uniform loop.  137 / 119 / 109 VGPRs instead of 81 take a wave per SIMD away, and every lane then reads for all
+            // neighbours of a batch whether it wants them or not: k_ut_flags 29.2 ms (four at a time) / 28.3 (two) against 26.2 with
+            // the per-neighbour loops below -- profiles/r03f_bench_100M_batched_lookups.json, r03j_bench_100M_flags_batch2.json.)
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) {
                 const uint64_t c = cs[i]; const uint32_t ph = phs[i];
