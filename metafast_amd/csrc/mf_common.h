@@ -131,9 +131,18 @@ struct mf_index {                 // open-addressed table in HBM: 16-byte slots 
     uint32_t part_bits = 0;
     uint64_t *dir = nullptr; size_t dir_bytes = 0;
     uint32_t skm_k = 0;           // != 0: partitions are MINIMIZER partitions of k-mers of this length (mf_skm_ph), else mf_phash
+    // COMPACT partitioned form (round 3; what mf_table_ensure_index builds for a partitioned table): 4-byte slots
+    // (12-bit tag of the key's hash << 20 | position of the key inside its partition), 0xFFFFFFFF = empty; a tag match is
+    // confirmed against the dense key array, the value is read from the dense count array.  8 bytes of index per key at
+    // load <= 0.5 instead of 32 (16-byte slots): the build writes a quarter, and a whole probe sequence sits in one 64-byte
+    // line.  dir has TWO words per partition: (first slot << 6) | log2(region slots), first entry of the partition in the table.
+    int compact = 0;
+    const uint64_t *keys = nullptr; const uint16_t *counts = nullptr;
 };
-struct mf_index_view { const void *slots; uint64_t mask; const uint64_t *dir; uint32_t part_bits, skm_k; };
-static inline mf_index_view mf_view(const mf_index &ix) { return mf_index_view{ix.slots, ix.cap - 1, ix.dir, ix.part_bits, ix.skm_k}; }
+#define MF_CIDX_EMPTY 0xFFFFFFFFu
+#define MF_CIDX_REL_BITS 20
+struct mf_index_view { const void *slots; uint64_t mask; const uint64_t *dir; uint32_t part_bits, skm_k; int compact; const uint64_t *keys; const uint16_t *counts; };
+static inline mf_index_view mf_view(const mf_index &ix) { return mf_index_view{ix.slots, ix.cap - 1, ix.dir, ix.part_bits, ix.skm_k, ix.compact, ix.keys, ix.counts}; }
 struct mf_table {
     mf_ctx *ctx = nullptr;
     int k = 0;
@@ -368,6 +377,23 @@ int mf_sort_kmers_by_comp(mf_ctx *ctx, const uint32_t *d_comp, const uint64_t *d
                           uint64_t *d_out);
 // ph: the key's partition hash if the caller has it already (minimizer partitions only), see mf_index_find
 __device__ __forceinline__ bool mf_index_find_ph(const mf_index_view &ix, uint64_t key, uint32_t ph, uint32_t *idx, uint32_t *val) {
+    if (ix.compact) {
+        const uint64_t h = mf_phash(key);
+        const uint64_t part = ix.skm_k ? (uint64_t)(ph >> (32 - ix.part_bits)) : (h >> (64 - ix.part_bits));
+        const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(&ix.dir[2 * part]);
+        const uint32_t *__restrict__ reg = reinterpret_cast<const uint32_t *>(ix.slots) + (d.x >> 6);
+        const uint32_t rmask = (1u << (uint32_t)(d.x & 63ull)) - 1u, hs = mf_pslot(h), tag = hs >> MF_CIDX_REL_BITS;
+        uint32_t s = hs & rmask;
+        for (;;) {
+            const uint32_t v = reg[s];
+            if (v == MF_CIDX_EMPTY) return false;
+            if ((v >> MF_CIDX_REL_BITS) == tag) {
+                const uint64_t i = d.y + (uint64_t)(v & ((1u << MF_CIDX_REL_BITS) - 1u));
+                if (ix.keys[i] == key) { *idx = (uint32_t)i; *val = ix.counts ? (uint32_t)ix.counts[i] : 0u; return true; }
+            }
+            s = (s + 1u) & rmask;
+        }
+    }
     const mf_slot *__restrict__ slots = reinterpret_cast<const mf_slot *>(ix.slots);
     uint64_t base = 0, rmask = ix.mask, s;
     if (ix.part_bits) {

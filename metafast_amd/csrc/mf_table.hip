@@ -76,7 +76,7 @@ __global__ void k_index_region_sizes(const uint64_t *__restrict__ part_off, uint
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= np) return;
     uint64_t c = part_off[p + 1] - part_off[p];
-    if (c >= (1ull << 30)) { atomicAdd(n_big + 2, 1u); c = 1; }  // (a region of 2^31 slots: the caller builds the generic index)
+    if (c >= (1ull << MF_CIDX_REL_BITS) - 1ull) { atomicAdd(n_big + 2, 1u); c = 1; }  // (a position inside the partition has 20 bits: the caller builds the generic index)
     const uint64_t want = 2 * c + 1;        // load <= 0.5: most probes are for absent neighbours, and a miss walks to the end of its cluster
     uint32_t S = 2;
     while (S < want) S <<= 1;
@@ -86,19 +86,31 @@ __global__ void k_index_region_sizes(const uint64_t *__restrict__ part_off, uint
     if (S > 8192u) biglist[np - 1u - atomicAdd(n_big + 4, 1u)] = p;
     else if (S > MF_IDX_WAVE_SLOTS) biglist[atomicAdd(n_big, 1u)] = p;
 }
-__global__ void k_index_dir_pack(const uint64_t *__restrict__ roff, const uint32_t *__restrict__ sz, uint32_t np, uint64_t *__restrict__ dir) {
+__global__ void k_index_dir_pack(const uint64_t *__restrict__ roff, const uint32_t *__restrict__ sz, const uint64_t *__restrict__ part_off, uint32_t np,
+                                 uint64_t *__restrict__ dir) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < np) dir[p] = (roff[p] << 6) | (uint64_t)(31 - __clz(sz[p]));
+    if (p < np) { dir[2 * (size_t)p] = (roff[p] << 6) | (uint64_t)(31 - __clz(sz[p])); dir[2 * (size_t)p + 1] = part_off[p]; }
+}
+// slot of entry i of partition [lo, ..): tag of the key's hash | position inside the partition (the keys of a table are distinct:
+// the first free slot from the home slot on is taken)
+__device__ __forceinline__ void mf_cidx_insert(uint32_t *reg, uint32_t rmask, uint64_t key, uint32_t rel) {
+    const uint32_t hs = mf_pslot(mf_phash(key));
+    const uint32_t v = ((hs >> MF_CIDX_REL_BITS) << MF_CIDX_REL_BITS) | rel;
+    uint32_t s = hs & rmask;
+    for (;;) {
+        if (atomicCAS(&reg[s], MF_CIDX_EMPTY, v) == MF_CIDX_EMPTY) break;
+        s = (s + 1u) & rmask;
+    }
 }
 // TEAM = 64: a wave per partition (4 regions per block), skips the large ones; TEAM = 256: the block per LISTED partition
 template <int TEAM>
-__global__ __launch_bounds__(256) void k_index_build_part(mf_slot *__restrict__ slots, const uint64_t *__restrict__ dir, const uint64_t *__restrict__ keys,
-                                                          const uint16_t *__restrict__ vals, const uint64_t *__restrict__ part_off,
-                                                          uint32_t np, const uint32_t *__restrict__ biglist, const unsigned int *__restrict__ n_big) {
+__global__ __launch_bounds__(256) void k_index_build_part(uint32_t *__restrict__ slots, const uint64_t *__restrict__ dir, const uint64_t *__restrict__ keys,
+                                                          const uint64_t *__restrict__ part_off, uint32_t np, const uint32_t *__restrict__ biglist,
+                                                          const unsigned int *__restrict__ n_big) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TEAMS = 256 / TEAM;
     const int team = threadIdx.x / TEAM, tl = threadIdx.x % TEAM;
-    mf_slot *reg = reinterpret_cast<mf_slot *>(smem) + (size_t)team * MF_IDX_WAVE_SLOTS;     // (TEAM 256: team == 0, the whole buffer)
+    uint32_t *reg = reinterpret_cast<uint32_t *>(smem) + (size_t)team * MF_IDX_WAVE_SLOTS;     // (TEAM 256: team == 0, the whole buffer)
     auto sync = [&]() {
         if (TEAM == 64) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
         else __syncthreads();
@@ -107,54 +119,33 @@ __global__ __launch_bounds__(256) void k_index_build_part(mf_slot *__restrict__ 
     const uint32_t count = TEAM == 64 ? np : *n_big;
     for (uint32_t it = blockIdx.x * TEAMS + team; it < count; it += nteams) {   // team-uniform
         const uint32_t p = TEAM == 64 ? it : biglist[it];
-        const uint64_t d = dir[p];
+        const uint64_t d = dir[2 * (size_t)p];
         const uint32_t S = 1u << (uint32_t)(d & 63ull), rmask = S - 1;
         if (TEAM == 64 && S > MF_IDX_WAVE_SLOTS) continue;
-        for (uint32_t j = tl; j < S; j += TEAM) { ulonglong2 e; e.x = MF_EMPTY; e.y = 0; *reinterpret_cast<ulonglong2 *>(&reg[j]) = e; }
+        for (uint32_t j = tl; j < S; j += TEAM) reg[j] = MF_CIDX_EMPTY;
         sync();
-        const uint64_t lo = part_off[p], hi = part_off[p + 1];
-        for (uint64_t i = lo + tl; i < hi; i += TEAM) {
-            const uint64_t key = keys[i];
-            const uint64_t aux = (uint64_t)(uint32_t)i | ((uint64_t)(vals ? vals[i] : 0) << 32);
-            uint32_t s = mf_pslot(mf_phash(key)) & rmask;
-            for (;;) {
-                unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&reg[s].key), (unsigned long long)MF_EMPTY,
-                                                   (unsigned long long)key);
-                if (old == MF_EMPTY) { *reinterpret_cast<uint64_t *>(&reg[s].idx) = aux; break; }
-                s = (s + 1) & rmask;
-            }
-        }
+        const uint64_t lo = part_off[p], n_here = part_off[p + 1] - lo;
+        for (uint64_t i = tl; i < n_here; i += TEAM) mf_cidx_insert(reg, rmask, keys[lo + i], (uint32_t)i);
         sync();
-        mf_slot *dst = slots + (d >> 6);
-        for (uint32_t j = tl; j < S; j += TEAM) *reinterpret_cast<ulonglong2 *>(&dst[j]) = *reinterpret_cast<const ulonglong2 *>(&reg[j]);
+        uint32_t *dst = slots + (d >> 6);
+        for (uint32_t j = tl; j < S; j += TEAM) dst[j] = reg[j];
         sync();
     }
 }
 // regions too large for LDS: one workgroup per listed partition (biglist from the back) clears its region in HBM and
 // inserts with global atomics
-__global__ __launch_bounds__(256) void k_index_build_huge(mf_slot *__restrict__ slots, const uint64_t *__restrict__ dir, const uint64_t *__restrict__ keys,
-                                                          const uint16_t *__restrict__ vals, const uint64_t *__restrict__ part_off,
-                                                          uint32_t np, const uint32_t *__restrict__ biglist, uint32_t n_huge) {
+__global__ __launch_bounds__(256) void k_index_build_huge(uint32_t *__restrict__ slots, const uint64_t *__restrict__ dir, const uint64_t *__restrict__ keys,
+                                                          const uint64_t *__restrict__ part_off, uint32_t np, const uint32_t *__restrict__ biglist, uint32_t n_huge) {
     for (uint32_t it = blockIdx.x; it < n_huge; it += gridDim.x) {
         const uint32_t p = biglist[np - 1u - it];
-        const uint64_t d = dir[p];
-        const uint64_t S = 1ull << (d & 63ull), rmask = S - 1;
-        mf_slot *reg = slots + (d >> 6);
-        for (uint64_t j = threadIdx.x; j < S; j += blockDim.x) { ulonglong2 e; e.x = MF_EMPTY; e.y = 0; *reinterpret_cast<ulonglong2 *>(&reg[j]) = e; }
+        const uint64_t d = dir[2 * (size_t)p];
+        const uint32_t S = 1u << (uint32_t)(d & 63ull), rmask = S - 1u;
+        uint32_t *reg = slots + (d >> 6);
+        for (uint32_t j = threadIdx.x; j < S; j += blockDim.x) reg[j] = MF_CIDX_EMPTY;
         __threadfence();
         __syncthreads();
-        const uint64_t lo = part_off[p], hi = part_off[p + 1];
-        for (uint64_t i = lo + threadIdx.x; i < hi; i += blockDim.x) {
-            const uint64_t key = keys[i];
-            const uint64_t aux = (uint64_t)(uint32_t)i | ((uint64_t)(vals ? vals[i] : 0) << 32);
-            uint64_t s = mf_pslot(mf_phash(key)) & rmask;
-            for (;;) {
-                unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&reg[s].key), (unsigned long long)MF_EMPTY,
-                                                   (unsigned long long)key);
-                if (old == MF_EMPTY) { *reinterpret_cast<uint64_t *>(&reg[s].idx) = aux; break; }
-                s = (s + 1) & rmask;
-            }
-        }
+        const uint64_t lo = part_off[p], n_here = part_off[p + 1] - lo;
+        for (uint64_t i = threadIdx.x; i < n_here; i += blockDim.x) mf_cidx_insert(reg, rmask, keys[lo + i], (uint32_t)i);
         __syncthreads();
     }
 }
@@ -302,11 +293,11 @@ int mf_table_ensure_index(mf_table *t) {
         mf_buf<uint32_t> biglist; MF_TRY(biglist.alloc(ctx, np));
         mf_buf<uint64_t> roff; MF_TRY(roff.alloc(ctx, (size_t)np + 1));
         mf_buf<uint64_t> scal; MF_TRY(scal.alloc(ctx, 4));            // [0] total slots, [1] number of large regions, [2] oversized partitions, [3] HBM-built regions
-        mf_buf<uint64_t> dir; MF_TRY(dir.alloc(ctx, np));
+        mf_buf<uint64_t> dir; MF_TRY(dir.alloc(ctx, (size_t)2 * np));      // (region, first entry) per partition
         MF_HIP(hipMemsetAsync(scal.p, 0, 32, ctx->stream));
         k_index_region_sizes<<<(np + 255) / 256, 256, 0, ctx->stream>>>(t->d_part_off, np, sz.p, biglist.p, (unsigned int *)&scal.p[1]);
         MF_TRY(mf_scan<1>(ctx, sz.p, roff.p, np, &scal.p[0]));
-        k_index_dir_pack<<<(np + 255) / 256, 256, 0, ctx->stream>>>(roff.p, sz.p, np, dir.p);
+        k_index_dir_pack<<<(np + 255) / 256, 256, 0, ctx->stream>>>(roff.p, sz.p, t->d_part_off, np, dir.p);
         uint64_t hs[4];
         MF_HIP(hipMemcpyAsync(hs, scal.p, 32, hipMemcpyDeviceToHost, ctx->stream));
         MF_HIP(hipStreamSynchronize(ctx->stream));
@@ -314,29 +305,28 @@ int mf_table_ensure_index(mf_table *t) {
         const uint64_t cap = hs[0];
         const uint32_t n_big = (uint32_t)hs[1], n_huge = (uint32_t)hs[3];
         void *p = nullptr;
-        MF_TRY(mf_alloc(ctx, cap * sizeof(mf_slot), &p));
+        MF_TRY(mf_alloc(ctx, cap * sizeof(uint32_t), &p));
         {
             mf_ktimer tm(ctx, "k_index_build_part");
-            const size_t lds = (size_t)4 * MF_IDX_WAVE_SLOTS * sizeof(mf_slot);
-            MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_index_build_part<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            const unsigned grid = (unsigned)std::min<uint64_t>((np + 3) / 4, (uint64_t)ctx->n_cu * 2);
-            k_index_build_part<64><<<grid, 256, lds, ctx->stream>>>((mf_slot *)p, dir.p, t->d_keys, t->d_counts, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1]);
+            const size_t lds = (size_t)4 * MF_IDX_WAVE_SLOTS * sizeof(uint32_t);
+            const unsigned grid = (unsigned)std::min<uint64_t>((np + 3) / 4, (uint64_t)ctx->n_cu * 8);
+            k_index_build_part<64><<<grid, 256, lds, ctx->stream>>>((uint32_t *)p, dir.p, t->d_keys, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1]);
             if (n_big) {      // regions of up to 8192 slots (the counting pass cannot produce partitions of more than 4096 keys)
-                const size_t lds2 = (size_t)8192 * sizeof(mf_slot);
-                MF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_index_build_part<256>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-                k_index_build_part<256><<<(unsigned)std::min<uint32_t>(n_big, (uint32_t)ctx->n_cu), 256, lds2, ctx->stream>>>((mf_slot *)p, dir.p, t->d_keys, t->d_counts, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1]);
+                const size_t lds2 = (size_t)8192 * sizeof(uint32_t);
+                k_index_build_part<256><<<(unsigned)std::min<uint32_t>(n_big, (uint32_t)ctx->n_cu * 2), 256, lds2, ctx->stream>>>((uint32_t *)p, dir.p, t->d_keys, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1]);
             }
             if (n_huge)
-                k_index_build_huge<<<(unsigned)std::min<uint32_t>(n_huge, (uint32_t)ctx->n_cu * 4), 256, 0, ctx->stream>>>((mf_slot *)p, dir.p, t->d_keys, t->d_counts, t->d_part_off, np, biglist.p, n_huge);
+                k_index_build_huge<<<(unsigned)std::min<uint32_t>(n_huge, (uint32_t)ctx->n_cu * 4), 256, 0, ctx->stream>>>((uint32_t *)p, dir.p, t->d_keys, t->d_part_off, np, biglist.p, n_huge);
         }
         MF_HIP(hipGetLastError());
         MF_HIP(hipStreamSynchronize(ctx->stream));          // (biglist / scal are released below)
         t->index.slots = p; t->index.cap = cap; t->index.part_bits = (uint32_t)t->part_bits;
         t->index.skm_k = t->part_skm ? (uint32_t)t->k : 0u;
+        t->index.compact = 1; t->index.keys = t->d_keys; t->index.counts = t->d_counts;
         t->index.dir_bytes = dir.bytes(); t->index.dir = dir.take();
-        t->index_bytes = cap * sizeof(mf_slot);
+        t->index_bytes = cap * sizeof(uint32_t);
         if (ctx->opt_verbose) fprintf(stderr, "[mf] index: %u partitions, %llu slots for %llu keys (%u large regions), %.2f GB\n", np,
-                                      (unsigned long long)cap, (unsigned long long)t->n, n_big, cap * 16 / 1e9);
+                                      (unsigned long long)cap, (unsigned long long)t->n, n_big, cap * 4 / 1e9);
         return MF_OK;
     }
     return mf_index_build(ctx, t->d_keys, t->d_counts, t->n, &t->index, &t->index_bytes);
