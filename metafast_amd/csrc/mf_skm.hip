@@ -50,9 +50,39 @@ template <int K> struct skm_word {
     uint32_t cut;         // positions where a run starts
 };
 
+// the second half of the scan: minimizer hash of each of the word's 32 k-mers from its M-mers' hashes, run starts
+template <int K>
+__device__ __forceinline__ void skm_scan_tail(skm_word<K> &S, uint32_t (&hs)[skm_word<K>::NM], uint32_t m) {
+    constexpr int W = skm_word<K>::W, NM = skm_word<K>::NM;
+    // sliding-window minimum over W M-mers with three-input minima (v_min3_u32): spans of 3, then of 9, then two (or
+    // three) overlapping spans: 118 instructions for W = 17 instead of 214 with doubling
+    static_assert(W >= 3 && W <= 18, "window");
+    auto min3 = [](uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; };
+#pragma unroll
+    for (int i = 0; i + 2 < NM; i++) hs[i] = min3(hs[i], hs[i + 1], hs[i + 2]);                 // hs[i] = min of M-mers i .. i+2
+    if (W >= 9) {
+#pragma unroll
+        for (int i = 0; i + 8 < NM; i++) hs[i] = min3(hs[i], hs[i + 3], hs[i + 6]);             // i .. i+8
+#pragma unroll
+        for (int j = 0; j < 32; j++) S.mh[j] = hs[j] < hs[j + W - 9] ? hs[j] : hs[j + W - 9];
+    } else {
+        constexpr int D = W - 3 < 3 ? W - 3 : 3;
+#pragma unroll
+        for (int j = 0; j < 32; j++) S.mh[j] = min3(hs[j], hs[j + D], hs[j + W - 3]);
+    }
+    // bit j: the k-mer at j has the minimizer of the one before it.  Built from the top with compare + add-with-carry (two
+    // instructions per position instead of compare, select, or)
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 31; j >= 1; j--)
+        asm("v_cmp_eq_u32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(S.mh[j]), "v"(S.mh[j - 1]) : "vcc");
+    const uint32_t same = acc << 1;
+    S.cut = m & ~(same & (m << 1));
+}
+
 template <int K>
 __device__ __forceinline__ void skm_scan_word(skm_word<K> &S, const uint8_t *__restrict__ bases, uint64_t n_bases, uint64_t w, uint32_t m) {
-    constexpr int W = skm_word<K>::W, NM = skm_word<K>::NM, M = MF_SKM_M;
+    constexpr int NM = skm_word<K>::NM, M = MF_SKM_M;
     // four unconditional 16-byte loads (a guarded `cond ? p[i] : zero` compiles to sixteen predicated dword loads); chunks
     // that start beyond the buffer are re-pointed at the first one and zeroed afterwards
     const uint64_t b0 = w * 32;
@@ -71,26 +101,39 @@ __device__ __forceinline__ void skm_scan_word(skm_word<K> &S, const uint8_t *__r
         r = (i == 0) ? mf_mmer_rc(f) : ((r >> 2) | ((3u - (f & 3u)) << (2 * M - 2)));
         hs[i] = mf_mmer_hash(f < r ? f : r);
     }
-    // sliding-window minimum over W M-mers with three-input minima (v_min3_u32): spans of 3, then of 9, then two (or
-    // three) overlapping spans: 118 instructions for W = 17 instead of 214 with doubling
-    static_assert(W >= 3 && W <= 18, "window");
-    auto min3 = [](uint32_t a, uint32_t b, uint32_t c) { const uint32_t m = a < b ? a : b; return m < c ? m : c; };
+    skm_scan_tail<K>(S, hs, m);
+}
+// The same scan with the HALO taken from the next lane: a word's 32 k-mers need the M-mers of 48 positions and 64 bases, the
+// last 16 / 32 of which are the next word's first ones -- which the next lane computes anyway.  v_mov_b32_dpp wave_shl:1 hands
+// them over (18 moves instead of two 16-byte loads, their decoding and 16 M-mer hashes: ~170 of the scan's ~900 instructions).
+// Lane 63 has no next lane: the caller gives it no k-mers of its own (it scans the word that lane 0 of the wave's NEXT batch
+// owns), a wave covers 63 words.
+__device__ __forceinline__ uint32_t skm_from_next_lane(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+}
+template <int K>
+__device__ __forceinline__ void skm_scan_word_halo(skm_word<K> &S, const uint8_t *__restrict__ bases, uint64_t n_bases, uint64_t w, uint32_t m) {
+    constexpr int NM = skm_word<K>::NM, M = MF_SKM_M;
+    const uint64_t b0 = w * 32;
+    const uint4 *p = reinterpret_cast<const uint4 *>(bases + (b0 < n_bases ? b0 : 0));
+    const bool in1 = b0 + 16 < n_bases;
+    const uint4 c0 = p[0], c1 = p[in1 ? 1 : 0];
+    S.D[0] = b0 < n_bases ? mf_dec16(c0) : 0u; S.D[1] = in1 ? mf_dec16(c1) : 0u;
+    S.D[2] = skm_from_next_lane(S.D[0]); S.D[3] = skm_from_next_lane(S.D[1]);
+    S.valid = m;
+    uint32_t hs[NM];
+    uint32_t r = 0;
 #pragma unroll
-    for (int i = 0; i + 2 < NM; i++) hs[i] = min3(hs[i], hs[i + 1], hs[i + 2]);                 // hs[i] = min of M-mers i .. i+2
-    if (W >= 9) {
-#pragma unroll
-        for (int i = 0; i + 8 < NM; i++) hs[i] = min3(hs[i], hs[i + 3], hs[i + 6]);             // i .. i+8
-#pragma unroll
-        for (int j = 0; j < 32; j++) S.mh[j] = hs[j] < hs[j + W - 9] ? hs[j] : hs[j + W - 9];
-    } else {
-        constexpr int D = W - 3 < 3 ? W - 3 : 3;
-#pragma unroll
-        for (int j = 0; j < 32; j++) S.mh[j] = min3(hs[j], hs[j + D], hs[j + W - 3]);
+    for (int i = 0; i < 32; i++) {
+        const int q = i >> 4, o = i & 15;       // bases i .. i+M-1 start in dword q at base offset o
+        const uint32_t top = o ? __builtin_amdgcn_alignbit(S.D[q], S.D[q + 1], 32 - 2 * o) : S.D[q];
+        const uint32_t f = top >> (32 - 2 * M);
+        r = (i == 0) ? mf_mmer_rc(f) : ((r >> 2) | ((3u - (f & 3u)) << (2 * M - 2)));
+        hs[i] = mf_mmer_hash(f < r ? f : r);
     }
-    uint32_t same = 0;
 #pragma unroll
-    for (int j = 1; j < 32; j++) same |= (S.mh[j] == S.mh[j - 1]) ? (1u << j) : 0u;
-    S.cut = m & ~(same & (m << 1));
+    for (int i = 32; i < NM; i++) hs[i] = skm_from_next_lane(hs[i - 32]);
+    skm_scan_tail<K>(S, hs, m);
 }
 
 // lane-wise m ? b : a as ONE v_cndmask.  Written in C++ (`c ? x[2i+1] : x[2i]`) hipcc turns the select between two
@@ -371,12 +414,15 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
     uint2 *rl = reinterpret_cast<uint2 *>(wbase + 64 * 16 + 64 * 8);            // [SKM_LCAP + 1] (minimizer hash, lane << 5 | position); the last one: dummy
     const uint64_t wlo = (uint64_t)blockIdx.x * words_per_block;
     const uint64_t whi = wlo + words_per_block < n_words ? wlo + words_per_block : n_words;
-    for (uint64_t wb = wlo; wb < whi; wb += blockDim.x) {          // wave-uniform: all lanes reach skm_stage_insert together
-        const uint64_t w = wb + threadIdx.x;
-        const uint32_t m = w < whi ? vmask[w] : 0u;
+    // a wave takes 63 words per batch: lane 63 only provides lane 62's halo (skm_scan_word_halo), the word it scans is lane 0's
+    // of the wave's next batch
+    const uint64_t wstep = (uint64_t)(blockDim.x >> 6) * 63u;
+    for (uint64_t wb = wlo; wb < whi; wb += wstep) {          // wave-uniform: all lanes reach skm_stage_insert together
+        const uint64_t w = wb + (uint64_t)(threadIdx.x >> 6) * 63u + lane;
+        const uint32_t m = (lane < 63u && w < whi) ? vmask[w] : 0u;
         if (__ballot(m != 0u) == 0ull) continue;
         skm_word<K> S;
-        skm_scan_word<K>(S, bases, n_bases, w < n_words ? w : 0, m);
+        skm_scan_word_halo<K>(S, bases, n_bases, w < n_words ? w : 0, m);
         uint32_t cut = S.cut;
         bool fast = FAST;
         uint32_t NR = 0, roff = 0;

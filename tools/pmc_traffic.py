@@ -31,26 +31,26 @@ for n, v in res.items():
 # optional SQ passes (tools/pmc_bench.sh <tag> <reads> a/b ...): how busy the vector ALUs and the LDS pipe were while the kernel ran.
 # Summed over the chip a counter of "cycles something was active" is compared with GRBM_GUI_ACTIVE (summed over the 8 XCDs) x 32
 # CUs per XCD -- the normalisation that reproduces round 2's hand-derived 51 % / 36 % for k_skm_count.
-sq = {}
 for letter in ("a", "b"):
     f = os.path.join(tag + "_" + letter, "p_counter_collection.csv")
     if not os.path.exists(f):
         continue
+    sq = {}                                              # (per pass: both carry GRBM_GUI_ACTIVE)
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
         sq.setdefault(name, {}).setdefault(r["Counter_Name"], 0.0)
         sq[name][r["Counter_Name"]] += float(r["Counter_Value"])
-for n, c in sq.items():
-    gui = c.get("GRBM_GUI_ACTIVE", 0.0) * 32.0
-    if n in final and gui > 0:
-        if "SQ_ACTIVE_INST_VALU" in c:
-            final[n]["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] / gui, 3)
-        if "SQ_LDS_IDX_ACTIVE" in c:
-            final[n]["lds_busy"] = round(c["SQ_LDS_IDX_ACTIVE"] / gui, 3)
-        if c.get("SQ_LDS_IDX_ACTIVE"):
-            final[n]["lds_bank_conflict"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 3)
-        for k2 in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
-            if k2 in c:
-                final[n][k2] = c[k2]
+    for n, c in sq.items():
+        gui = c.get("GRBM_GUI_ACTIVE", 0.0) * 32.0
+        if n in final and gui > 0:
+            if "SQ_ACTIVE_INST_VALU" in c:
+                final[n]["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] / gui, 3)
+            if "SQ_LDS_IDX_ACTIVE" in c:
+                final[n]["lds_busy"] = round(c["SQ_LDS_IDX_ACTIVE"] / gui, 3)
+            if c.get("SQ_LDS_IDX_ACTIVE"):
+                final[n]["lds_bank_conflict"] = round(c.get("SQ_LDS_BANK_CONFLICT", 0.0) / c["SQ_LDS_IDX_ACTIVE"], 3)
+            for k2 in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS"):
+                if k2 in c:
+                    final[n][k2] = c[k2]
 json.dump(final, open(out, "w"), indent=1, sort_keys=True)
 print(json.dumps({k: v["hbm_GB"] for k, v in final.items()}, indent=0))
