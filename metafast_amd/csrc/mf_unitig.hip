@@ -225,6 +225,10 @@ __global__ __launch_bounds__(64 * UT_J_WAVES) void k_ut_contract(const uint64_t 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
+// (Round 3 tried k_ut_links + k_ut_contract as ONE pass per partition -- the wave that owns a partition stages its info bytes in
+// LDS, computes the links from them and contracts the chains it has just computed, start nodes through a bit array: 17.5 ms
+// against 8.5 + 5.4.  The links are latency-bound random reads that want the streaming kernel's full occupancy more than they
+// want the LDS copy; profiles/r03o_bench_100M_fused_links_contract.json.)
 // tables without minimizer partitions: one hop per word
 __global__ void k_ut_jump_plain(const uint64_t *__restrict__ node, uint64_t n_nodes, uint64_t *__restrict__ jump) {
     const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
