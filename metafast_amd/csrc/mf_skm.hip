@@ -111,6 +111,9 @@ __device__ __forceinline__ void skm_scan_word(skm_word<K> &S, const uint8_t *__r
 __device__ __forceinline__ uint32_t skm_from_next_lane(uint32_t v) {
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
 }
+__device__ __forceinline__ uint32_t skm_from_prev_lane(uint32_t v) {          // (lane 0: 0)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+}
 template <int K>
 __device__ __forceinline__ void skm_scan_word_halo(skm_word<K> &S, const uint8_t *__restrict__ bases, uint64_t n_bases, uint64_t w, uint32_t m) {
     constexpr int NM = skm_word<K>::NM, M = MF_SKM_M;
@@ -174,16 +177,18 @@ __device__ __forceinline__ void skm_next_run(const skm_word<K> &S, uint32_t &cut
 
 // the record of the run [s, s+len): its len+K-1 bases left-aligned, the remaining bits zero, digit bits, k-mer count
 template <int K>
-__device__ __forceinline__ skm_rec skm_make_rec(const uint32_t (&D)[4], uint32_t s, uint32_t len, uint32_t digits) {
+__device__ __forceinline__ skm_rec skm_make_rec(const uint32_t (&D)[4], uint32_t s, uint32_t len, uint32_t digits, uint32_t D4 = 0u) {
+    // D4: bases 64 .. 79 from the word's start (a run that goes on into the next word, k_skm_scatter)
     const uint32_t o = (2u * s) & 31u;
     const unsigned long long q = __ballot(s >= 16u);
-    const uint32_t E0 = skm_sel(D[0], D[1], q), E1 = skm_sel(D[1], D[2], q), E2 = skm_sel(D[2], D[3], q), E3 = skm_sel(D[3], 0u, q);
+    // (a run from s < 16 may need base 64, the first of D4; one from s >= 16 ends by base 79: the caller bounds its length)
+    const uint32_t E0 = skm_sel(D[0], D[1], q), E1 = skm_sel(D[1], D[2], q), E2 = skm_sel(D[2], D[3], q), E3 = skm_sel(D[3], D4, q), E4 = skm_sel(D4, 0u, q);
     uint32_t T0 = E0, T1 = E1, T2 = E2, T3 = E3;
     if (o) {
         T0 = __builtin_amdgcn_alignbit(E0, E1, 32u - o);
         T1 = __builtin_amdgcn_alignbit(E1, E2, 32u - o);
         T2 = __builtin_amdgcn_alignbit(E2, E3, 32u - o);
-        T3 = E3 << o;
+        T3 = __builtin_amdgcn_alignbit(E3, E4, 32u - o);
     }
     const int kb = 2 * (int)(len + K - 1);                 // bits to keep (<= 100)
     auto keep = [](uint32_t v, int bits) { return bits >= 32 ? v : (bits <= 0 ? 0u : (v & ~(0xFFFFFFFFu >> bits))); };
@@ -392,6 +397,11 @@ __device__ __forceinline__ void skm_stage_flush_all(const skm_stage &L, skm_rec 
 // is over the 32 POSITIONS, so the hash is a fixed register, and lanes without a run at that position write to a dummy
 // slot --; then lane l takes the runs l, l + 64, l + 128, l + 192 of the list: one four-wide iteration per 256 runs (237 on
 // average per batch).  Rare batches (a run longer than RMAX that must be cut, more runs than the list holds) take the per-lane loop.
+// RUNS GO ON ACROSS WORD BOUNDARIES here: a word used to start a new run whatever its first k-mer's minimizer -- a quarter of
+// all records began at a word boundary.  Now a lane whose first k-mer continues the previous lane's last run (same minimizer
+// hash, both valid: the same read) hands the head of its word over to that run, as far as the run's RMAX allows (`ext`
+// k-mers; the rest of the head becomes a run of its own), and the lane that owns the run builds the record from its own 64
+// bases + the next lane's (parked) -- 1.75e9 -> ~1.35e9 records at 100 M reads: less to write, to split and to unpack.
 #define SKM_LCAP 384               // run descriptors per wave and batch
 #define SKM_FAST_WAVE_BYTES (64 * 16 + 64 * 8 + (SKM_LCAP + 1) * 8)
 template <int K, bool DYN, bool FAST>
@@ -410,7 +420,7 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
     const uint32_t lane = (uint32_t)mf_lane();
     unsigned char *wbase = smem + ((skm_stage_bytes(nd) + 15) & ~(size_t)15) + (size_t)(threadIdx.x >> 6) * SKM_FAST_WAVE_BYTES;
     uint4 *pd = reinterpret_cast<uint4 *>(wbase);                               // [64] the words' bases
-    uint2 *pc = reinterpret_cast<uint2 *>(wbase + 64 * 16);                     // [64] (run starts, valid starts)
+    uint2 *pc = reinterpret_cast<uint2 *>(wbase + 64 * 16);                     // [64] (positions where a run stops, k-mers of the word's head that belong to the previous lane's run)
     uint2 *rl = reinterpret_cast<uint2 *>(wbase + 64 * 16 + 64 * 8);            // [SKM_LCAP + 1] (minimizer hash, lane << 5 | position); the last one: dummy
     const uint64_t wlo = (uint64_t)blockIdx.x * words_per_block;
     const uint64_t whi = wlo + words_per_block < n_words ? wlo + words_per_block : n_words;
@@ -425,7 +435,7 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
         skm_scan_word_halo<K>(S, bases, n_bases, w < n_words ? w : 0, m);
         uint32_t cut = S.cut;
         bool fast = FAST;
-        uint32_t NR = 0, roff = 0;
+        uint32_t NR = 0, roff = 0, cutf = cut, ext = 0;
         if (FAST) {
             // a run of more than RMAX k-mers (RMAX continuation positions in a row) has to be cut: the per-lane loop does that
             constexpr int R = skm_word<K>::RMAX;
@@ -433,19 +443,34 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
             const uint32_t z = ~(cut | ~S.valid);
             const uint32_t z2 = z & (z >> 1), z4 = z2 & (z2 >> 2), z8 = z4 & (z4 >> 4), z16 = z8 & (z8 >> 8);
             const uint32_t zr = R == 16 ? z16 : (R == 17 ? (z16 & (z >> 16)) : (R == 18 ? (z16 & (z2 >> 16)) : (R == 19 ? (z16 & (z2 >> 16) & (z >> 18)) : (z16 & (z4 >> 16)))));
-            roff = mf_wave_excl_scan((uint32_t)__popc(cut), &NR);
+            // the head of this word joins the previous lane's last run?  (zr == 0 everywhere, or the batch takes the other path: then
+            // the previous lane's last run starts at its highest cut and is at most R k-mers long inside its word)
+            const uint32_t pcut = skm_from_prev_lane(cut), pvalid = skm_from_prev_lane(S.valid), pm31 = skm_from_prev_lane(S.mh[31]);
+            const bool cont = (S.valid & 1u) && (pvalid >> 31) && S.mh[0] == pm31;
+            const uint32_t hstop = (cut & ~1u) | ~S.valid;
+            const uint32_t h = hstop ? (uint32_t)__builtin_ctz(hstop) : 32u;
+            const uint32_t tail = pcut ? (uint32_t)__builtin_clz(pcut) + 1u : 32u;           // k-mers of that run in the previous word
+            // (the owner builds the record from bases 0 .. 79 of its word: the last base of the run, 32 + ext + K - 2, must be one of them)
+            constexpr uint32_t XMAX = 49 - K < R ? (uint32_t)(49 - K) : (uint32_t)R;
+            uint32_t allowed = tail < (uint32_t)R ? (uint32_t)R - tail : 0u;
+            if (allowed > XMAX) allowed = XMAX;
+            // (only in the one-pass form: with exact output ranges -- small inputs, the retry after an overflow -- the histogram
+            // pass has counted a run per word start, and the ranges must be filled exactly)
+            ext = (DYN && cont) ? (h < allowed ? h : allowed) : 0u;
+            cutf = ext ? ((cut & ~1u) | (ext < h ? (1u << ext) : 0u)) : cut;
+            roff = mf_wave_excl_scan((uint32_t)__popc(cutf), &NR);
             fast = __ballot(zr != 0u) == 0ull && NR <= (uint32_t)SKM_LCAP;
         }
         if (FAST && fast) {
             pd[lane] = make_uint4(S.D[0], S.D[1], S.D[2], S.D[3]);
-            pc[lane] = make_uint2(cut, S.valid);
+            pc[lane] = make_uint2(cutf | ~S.valid, ext);                 // (positions where a run stops, k-mers handed to the previous lane's run)
             {
                 const uint32_t l0 = mf_lds_addr(rl), dummy = l0 + 8u * (uint32_t)SKM_LCAP;
                 uint32_t at = l0 + 8u * roff;
                 const uint32_t tagl = lane << 5;
 #pragma unroll
                 for (int j = 0; j < 32; j++) {
-                    const uint32_t bit = (cut >> j) & 1u;
+                    const uint32_t bit = (cutf >> j) & 1u;
                     const uint32_t addr = bit ? at : dummy;
                     const uint32_t v1 = tagl | (uint32_t)j;
                     asm volatile("ds_write2_b32 %0, %1, %2 offset1:1" :: "v"(addr), "v"(S.mh[j]), "v"(v1) : "memory");
@@ -463,12 +488,14 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
                     const uint2 de = rl[pend[b] ? g : 0u];
                     const uint32_t src = (de.y >> 5) & 63u, s0 = de.y & 31u;
                     const uint4 Dw = pd[src]; const uint2 cv = pc[src];
-                    const uint32_t stop = (cv.x | ~cv.y) & ~((2u << s0) - 1u);
+                    const uint4 Dn = pd[(src + 1u) & 63u]; const uint2 cn = pc[(src + 1u) & 63u];        // (a run's lane is <= 62)
+                    const uint32_t stop = cv.x & ~((2u << s0) - 1u);
                     const uint32_t e = stop ? (uint32_t)__builtin_ctz(stop) : 32u;
+                    const uint32_t len = e - s0 + (e == 32u ? cn.y : 0u);                                // + the head of the next word
                     const uint32_t DD[4] = {Dw.x, Dw.y, Dw.z, Dw.w};
                     uint32_t digits;
                     skm_route(de.x, bits1, d[b], digits);
-                    rec[b] = skm_make_rec<K>(DD, s0, e - s0, digits);
+                    rec[b] = skm_make_rec<K>(DD, s0, len, digits, Dn.z);
                     if (!pend[b] || d[b] < dlo || d[b] >= dhi) { pend[b] = false; d[b] = 0; rec[b] = make_ulonglong2(~0ull, ~0ull); }
                 }
                 skm_stage_insert<DYN>(L, out, d, rec, pend, Dy);
