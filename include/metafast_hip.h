@@ -128,6 +128,20 @@ int mf_table_lookup(mf_table *t, const uint64_t *keys, uint64_t n, int32_t *valu
  * a rank that holds several samples' tables drops each index between the sample's seq-builder and features steps. */
 int mf_table_drop_index(mf_table *t);
 
+/* ---- NO-REFERENCE EXTENSION: 32 <= k <= 63 ----------------------------------------------------
+ * The reference rejects k > 31 (src/tools/KmersCounterMain.java:66-73: one Java long per k-mer); BASELINE.json's config 4 has a
+ * k = 63 leg.  These entry points replace nothing and take part in no parity claim: canonical counts of 2k-bit k-mers (two
+ * 64-bit words, first base most significant, canonical = the smaller of the k-mer and its reverse complement, counts saturate
+ * at 32767, reads shorter than max(k, min_read_len) give nothing) -- the k <= 31 definitions carried over; checked against
+ * oracle/mf_oracle.c:or_count_wide (unsigned __int128).  Input as for mf_count_device. */
+typedef struct mf_wtable mf_wtable;
+int  mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t n_bases, int k,
+                          int min_read_len, mf_wtable **out);
+void mf_wtable_destroy(mf_wtable *t);
+int  mf_wtable_stats(const mf_wtable *t, uint64_t *n_distinct, uint64_t *n_occ, int *k);
+/* ascending k-mers as (high word, low word) + counts; NULL arrays: only *n */
+int  mf_wtable_export(const mf_wtable *t, uint64_t *keys_hi, uint64_t *keys_lo, uint16_t *counts, uint64_t capacity, uint64_t *n);
+
 /* ---- A5/A6  .kmers.bin / .stat.txt --------------------------------------------------- */
 /* replaces IOUtils.printKmers (src/io/IOUtils.java:45-71; KmersCounterMain.java:99): 10-byte
  * big-endian records (int64 k-mer, int16 count) for count > threshold, ascending key order;

@@ -33,6 +33,10 @@ _SIGS = {
     "mf_ctx_reset_timers": (i32, [vp]),
     "mf_count_reads": (i32, [vp, C.POINTER(cp), i32, i32, i32, pvp]),
     "mf_table_drop_index": (i32, [vp]),
+    "mf_count_wide_device": (i32, [vp, vp, vp, u64, u64, i32, i32, pvp]),
+    "mf_wtable_destroy": (None, [vp]),
+    "mf_wtable_stats": (i32, [vp, pu64, pu64, C.POINTER(C.c_int)]),
+    "mf_wtable_export": (i32, [vp, vp, vp, vp, u64, pu64]),
     "mf_count_reads_above": (i32, [vp, C.POINTER(cp), i32, i32, i32, i32, pvp, pu64]),
     "mf_count_device": (i32, [vp, vp, vp, u64, u64, i32, i32, pvp]),
     "mf_count_device_above": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, pvp, pu64]),
@@ -203,6 +207,20 @@ class Context:
         _check(lib().mf_count_device(self.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k,
                                      min_read_len, C.byref(t)))
         return Table(self, t)
+
+    def count_wide_device(self, d_bases, d_offsets, n_reads, n_bases, k, min_read_len=0):
+        """NO-REFERENCE EXTENSION, 32 <= k <= 63 (mf_wide.hip) -> dict(hi, lo, counts: ascending 2k-bit k-mers; n_occ)"""
+        t = C.c_void_p()
+        _check(lib().mf_count_wide_device(self.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k, min_read_len, C.byref(t)))
+        try:
+            n, occ, kk = C.c_uint64(), C.c_uint64(), C.c_int()
+            _check(lib().mf_wtable_stats(t, C.byref(n), C.byref(occ), C.byref(kk)))
+            hi = np.empty(n.value, dtype=np.uint64); lo = np.empty(n.value, dtype=np.uint64); cnt = np.empty(n.value, dtype=np.uint16)
+            m = C.c_uint64()
+            _check(lib().mf_wtable_export(t, hi.ctypes.data, lo.ctypes.data, cnt.ctypes.data, n.value, C.byref(m)))
+            return dict(hi=hi, lo=lo, counts=cnt, n_occ=occ.value, k=kk.value)
+        finally:
+            lib().mf_wtable_destroy(t)
 
     def count_device_above(self, d_bases, d_offsets, n_reads, n_bases, k, threshold, min_read_len=0):
         """count, keeping only the k-mers with count > threshold (what the k-mer counter hands on, IOUtils.printKmers);

@@ -1047,3 +1047,51 @@ int or_cpu_baseline_file(const char *fasta, int k, int threads, int bcut, const 
     free(hist); free(c.b.sh); free(th); free(c.line); fclose(c.f);
     return 0;
 }
+
+/* ---- NO-REFERENCE EXTENSION: canonical k-mer counts for 32 <= k <= 63 (the reference rejects k > 31,
+ * src/tools/KmersCounterMain.java:66-73).  The k <= 31 definitions (ShortKmer: first base most significant, A0 G1 C2 T3,
+ * canonical = min(fw, rc); Long2ShortHashMap.addAndBound: saturation at 32767; loadReads: reads shorter than max(k, minLen)
+ * give nothing) on 2k-bit numbers.  Checker of metafast_amd/csrc/mf_wide.hip only. ---- */
+typedef unsigned __int128 or_u128;
+static int or_cmp_u128(const void *a, const void *b) {
+    const or_u128 x = *(const or_u128 *)a, y = *(const or_u128 *)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+/* *n_out distinct k-mers into hi[], lo[], cnt[] (ascending; arrays of capacity cap); returns 0, or -1 if cap is too small */
+int or_count_wide(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k, int min_len, uint64_t *hi, uint64_t *lo,
+                  int32_t *cnt, uint64_t cap, uint64_t *n_out, uint64_t *n_occ_out) {
+    uint64_t n_occ = 0;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const uint64_t len = offsets[r + 1] - offsets[r];
+        if (len >= (uint64_t)k && (int64_t)len >= (int64_t)min_len) n_occ += len - (uint64_t)k + 1;
+    }
+    or_u128 *all = (or_u128 *)malloc((n_occ ? n_occ : 1) * sizeof(or_u128));
+    if (!all) return -2;
+    const or_u128 mask = k == 64 ? ~(or_u128)0 : (((or_u128)1 << (2 * k)) - 1);
+    uint64_t m = 0;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const uint64_t s = offsets[r], len = offsets[r + 1] - s;
+        if (len < (uint64_t)k || (int64_t)len < (int64_t)min_len) continue;
+        or_u128 fw = 0, rc = 0;
+        for (uint64_t i = 0; i < len; i++) {
+            const int c = nuc_code(bases[s + i]);
+            fw = ((fw << 2) | (or_u128)c) & mask;
+            rc = (rc >> 2) | ((or_u128)(3 - c) << (2 * k - 2));
+            if (i + 1 >= (uint64_t)k) all[m++] = fw < rc ? fw : rc;
+        }
+    }
+    qsort(all, m, sizeof(or_u128), or_cmp_u128);
+    uint64_t nd = 0;
+    for (uint64_t i = 0; i < m;) {
+        uint64_t j = i;
+        while (j < m && all[j] == all[i]) j++;
+        if (nd >= cap) { free(all); return -1; }
+        hi[nd] = (uint64_t)(all[i] >> 64); lo[nd] = (uint64_t)all[i];
+        cnt[nd] = (int32_t)((j - i) > 32767 ? 32767 : (j - i));
+        nd++;
+        i = j;
+    }
+    free(all);
+    *n_out = nd; *n_occ_out = m;
+    return 0;
+}

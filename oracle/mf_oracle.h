@@ -102,6 +102,10 @@ int       or_features_reads(const or_comps *c, const uint8_t *bases, const uint6
 
 /* ---- A13 Bray-Curtis (src/tools/DistanceMatrixCalculatorMain.java:140-152) ---- */
 int       or_bray_curtis(const int64_t *vecs, int n_samples, int n_comp, double *out);
+/* NO-REFERENCE EXTENSION (the reference rejects k > 31): canonical counts of 2k-bit k-mers, 32 <= k <= 63, ascending
+ * (hi, lo); checker of metafast_amd/csrc/mf_wide.hip only */
+int       or_count_wide(const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k, int min_len, uint64_t *hi, uint64_t *lo,
+                        int32_t *cnt, uint64_t cap, uint64_t *n_out, uint64_t *n_occ_out);
 
 /* ---- helpers exposed for tests ---- */
 uint64_t  or_revcomp(uint64_t kmer, int k);                  /* itmo!/utils/KmerUtils.java:12-22 */

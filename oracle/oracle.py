@@ -45,6 +45,7 @@ def lib():
     sig("or_table_new", vp)
     sig("or_table_free", None, vp)
     sig("or_count_buffer", i32, vp, vp, vp, u64, i32, i32)
+    sig("or_count_wide", i32, vp, vp, u64, i32, i32, vp, vp, vp, u64, vp, vp)
     sig("or_count_files", i32, vp, C.POINTER(cp), i32, i32, i32)
     sig("or_table_size", u64, vp)
     sig("or_table_export", u64, vp, i32, vp, vp, u64)
@@ -322,6 +323,18 @@ def heatmap_order(matrix):
                 dist[i][bi] = dist[bi][i] = between(g1, group(nodes[i]))
         count -= 1
     return group(root)
+
+
+def count_wide(bases, offsets, k, min_len=0):
+    """NO-REFERENCE EXTENSION (32 <= k <= 63; the reference rejects k > 31): -> (hi, lo, counts, n_occ), ascending 2k-bit k-mers"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    cap = max(int(len(bases)), 1)
+    hi = np.empty(cap, dtype=np.uint64); lo = np.empty(cap, dtype=np.uint64); cnt = np.empty(cap, dtype=np.int32)
+    n = C.c_uint64(); n_occ = C.c_uint64()
+    _check(lib().or_count_wide(bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, k, min_len, hi.ctypes.data, lo.ctypes.data,
+                               cnt.ctypes.data, cap, C.byref(n), C.byref(n_occ)))
+    return hi[:n.value].copy(), lo[:n.value].copy(), cnt[:n.value].copy(), n_occ.value
 
 
 def revcomp(kmer, k):

@@ -1,0 +1,93 @@
+"""NO-REFERENCE EXTENSION: canonical k-mer counts for 32 <= k <= 63 (metafast_amd/csrc/mf_wide.hip).  The reference rejects
+k > 31 (src/tools/KmersCounterMain.java:66-73), so this is no parity test against the reference: the checker is the oracle's
+own 128-bit restatement of the k <= 31 definitions (oracle/mf_oracle.c: or_count_wide), itself checked here against the
+reference-pinned 64-bit oracle through an identity at k = 31 -> 32 (a 32-mer's two 31-mers)."""
+import numpy as np
+import pytest
+
+
+def _reads(rng, n, lo, hi, genome=4000, err=0.01):
+    g = rng.integers(0, 4, genome)
+    g[100:180] = 0                                            # poly-A: key 0, saturation
+    g[300:340] = np.tile([0, 3], 20)                          # (AT)n: reverse-complement palindromes at even k
+    al = np.frombuffer(b"AGCT", dtype=np.uint8)
+    seqs = []
+    for _ in range(n):
+        L = int(rng.integers(lo, hi + 1))
+        s = int(rng.integers(0, genome - L))
+        r = g[s:s + L].copy()
+        flip = rng.random(L) < err
+        r[flip] = rng.integers(0, 4, int(flip.sum()))
+        if rng.random() < 0.5:
+            r = 3 - r[::-1]
+        seqs.append(al[r])
+    bases = np.concatenate(seqs)
+    off = np.concatenate([[0], np.cumsum([len(s) for s in seqs])]).astype(np.uint64)
+    return bases, off
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [32, 33, 40, 47, 62, 63])
+def test_wide_counts_match_the_128bit_oracle(gpu_ctx, oracle, k):
+    from util import to_device
+    rng = np.random.default_rng(k)
+    bases, off = _reads(rng, 40000, 20, 160)                  # ragged: many reads shorter than k
+    db, do = to_device(bases, off)
+    for min_len in (0, 100):
+        got = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), len(off) - 1, len(bases), k, min_len)
+        hi, lo, cnt, n_occ = oracle.count_wide(bases, off, k, min_len)
+        assert got["n_occ"] == n_occ > 0 and got["k"] == k
+        assert np.array_equal(got["hi"], hi) and np.array_equal(got["lo"], lo)
+        assert np.array_equal(got["counts"].astype(np.int32), cnt)
+        assert cnt.max() > 1000
+    # saturation at 32767 and key 0 (poly-A), the all-T reads fold onto it
+    pa = np.concatenate([np.full(700 * 120, ord("A"), dtype=np.uint8), np.full(300 * 120, ord("T"), dtype=np.uint8)])
+    po = (np.arange(1001) * 120).astype(np.uint64)
+    db, do = to_device(pa, po)
+    got = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), 1000, len(pa), k, 0)
+    hi, lo, cnt, n_occ = oracle.count_wide(pa, po, k, 0)
+    assert got["n_occ"] == n_occ == 1000 * (120 - k + 1) and len(cnt) == 1 and cnt[0] == 32767
+    assert got["hi"].tolist() == [0] and got["lo"].tolist() == [0] and got["counts"].tolist() == [32767]
+
+
+def test_wide_oracle_agrees_with_the_pinned_oracle_at_the_seam(oracle):
+    """the 128-bit restatement is tied to the reference-pinned 64-bit oracle: every 32-mer occurrence contributes its first
+    31-mer, so per read (len >= 32) the multiset of canonical 31-mers of starts 0 .. len-32 is determined by the 32-mers"""
+    rng = np.random.default_rng(5)
+    bases, off = _reads(rng, 300, 32, 90, genome=2000, err=0.0)
+    hi, lo, cnt, n_occ = oracle.count_wide(bases, off, 32, 0)
+    assert (hi == 0).all() and n_occ == int(sum(int(off[i + 1] - off[i]) - 31 for i in range(len(off) - 1)))
+    # expand the 32-mer table into the canonical 31-mers of (prefix of fw) -- needs the orientation, so recount per occurrence
+    code = np.zeros(256, dtype=np.uint64)
+    for ch, c in zip(b"AGCT", range(4)):
+        code[ch] = c
+    want = {}
+    for i in range(len(off) - 1):
+        c = code[bases[int(off[i]):int(off[i + 1])]]
+        for s in range(len(c) - 31):
+            fw = 0
+            for b in c[s:s + 32]:
+                fw = (fw << 2) | int(b)
+            rc = 0
+            for b in c[s:s + 32][::-1]:
+                rc = (rc << 2) | (3 - int(b))
+            x = min(fw, rc)
+            want[x] = want.get(x, 0) + 1
+    keys = np.array(sorted(want), dtype=np.uint64)
+    assert np.array_equal(lo, keys) and np.array_equal(cnt, np.array([min(want[int(x)], 32767) for x in keys], dtype=np.int32))
+    # ... and the plain-Python recount's 31-mer half against the pinned oracle's table
+    t = oracle.Table().count_buffer(bases, off, 31)
+    k31 = {}
+    for i in range(len(off) - 1):
+        c = code[bases[int(off[i]):int(off[i + 1])]]
+        for s in range(len(c) - 30):
+            fw = 0
+            for b in c[s:s + 31]:
+                fw = (fw << 2) | int(b)
+            rc = 0
+            for b in c[s:s + 31][::-1]:
+                rc = (rc << 2) | (3 - int(b))
+            x = min(fw, rc)
+            k31[x] = k31.get(x, 0) + 1
+    ok, ov = t.export()
+    assert np.array_equal(ok, np.array(sorted(k31), dtype=np.uint64)) and np.array_equal(ov, np.array([k31[int(x)] for x in ok]))
