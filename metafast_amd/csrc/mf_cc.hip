@@ -46,10 +46,11 @@ __global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ ke
 }
 
 // the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
-template <int MODE>
+template <int MODE, int KT = 0>
 __global__ __launch_bounds__(64 * NB_WAVES) void k_cc_adjacency_part(mf_index_view ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
-                                                                   uint32_t np, int k, uint32_t *__restrict__ nbr) {
+                                                                   uint32_t np, int k_rt, uint32_t *__restrict__ nbr) {
     __shared__ nb_lds S;
+    const int k = KT ? KT : k_rt;
     nb_for_each<MODE>(ix, keys, part_off, 0u, np, k, S, 0, 0u, [&](uint64_t v, uint64_t, const uint32_t (&idx)[8], uint32_t, uint32_t, bool have) {
         if (!have) return;
         uint4 *o = reinterpret_cast<uint4 *>(nbr + v * 8);
@@ -392,8 +393,14 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             if (t->index.skm_k && t->index.part_bits && t->d_part_off && !ctx->opt_nbr_global && (n >> t->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
                 const uint32_t np = 1u << t->part_bits;
                 const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
-                k_cc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
-                k_cc_adjacency_part<2><<<(unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16), 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
+                const unsigned grid2 = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16);
+                if (k == 31) {
+                    k_cc_adjacency_part<1, 31><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
+                    k_cc_adjacency_part<2, 31><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
+                } else {
+                    k_cc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
+                    k_cc_adjacency_part<2><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
+                }
             } else
             k_cc_adjacency<<<cgrid(n), 256, 0, st>>>(mf_view(t->index), t->d_keys, n, k, nbr.p);
         }

@@ -83,10 +83,11 @@ __global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
 }
 
 // the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
-template <int MODE>
+// KT: k as a compile-time constant (0: from A.k) -- every shift of the minimizer scan and of the neighbours becomes an immediate
+template <int MODE, int KT = 0>
 __global__ __launch_bounds__(64 * NB_WAVES) void k_ut_flags_part(mf_index_view ix, ut_arrays A, const uint64_t *__restrict__ part_off, uint32_t np) {
     __shared__ nb_lds S;
-    const int k = A.k;
+    const int k = KT ? KT : A.k;
     nb_for_each<MODE>(ix, A.gk, part_off, 0u, np, k, S, 0, 0u, [&](uint64_t i, uint64_t x, const uint32_t (&idx)[8], uint32_t flip, uint32_t, bool have) {
         if (!have) return;
         uint32_t rcode = UT_CODE_NONE, lcode = UT_CODE_NONE, ridx = UT_NONE, lidx = UT_NONE, ror = 0, lor = 0;
@@ -458,8 +459,14 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
             if (g->index.skm_k && g->index.part_bits && g->d_part_off && !ctx->opt_nbr_global && (n >> g->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
                 const uint32_t np = 1u << g->part_bits;
                 const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
-                k_ut_flags_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
-                k_ut_flags_part<2><<<(unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16), 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);      // partitions of 353 .. 1408 keys: a workgroup each
+                const unsigned grid2 = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16);      // partitions of 353 .. 1408 keys: a workgroup each
+                if (k == 31) {
+                    k_ut_flags_part<1, 31><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
+                    k_ut_flags_part<2, 31><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
+                } else {
+                    k_ut_flags_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
+                    k_ut_flags_part<2><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
+                }
             } else
             k_ut_flags<<<grid_for(n), 256, 0, st>>>(mf_view(g->index), A);
         }
