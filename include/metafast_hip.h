@@ -267,6 +267,14 @@ int  mf_dcc_members_fill(mf_dcc *d, void *d_kmers, void *d_roots);
 /* smallest member k-mer of each kept component among this rank's k-mers (0x7FFF...F: none) -> d_min u64[n_kept];
  * the caller takes the minimum over the ranks (it breaks ties in the components' order) */
 int  mf_dcc_minkeys(mf_dcc *d, const uint32_t *kept_root, uint64_t n_kept, void *d_min);
+/* The same members grouped by component: 8 bytes per member on the wire -- k-mers u64[n_members], sorted by component, and
+ * (root u32, count u32) runs [n_runs] -- instead of 12; mf_dcc_finish_grouped takes ALL ranks' k-mers (rank order) and runs
+ * (rank order) */
+int  mf_dcc_members_grouped(mf_dcc *d, uint64_t *n_members, uint64_t *n_runs);
+int  mf_dcc_members_grouped_fill(mf_dcc *d, void *d_kmers, void *d_runs);
+int  mf_dcc_finish_grouped(mf_dcc *d, const void *d_kmers, uint64_t n_members, const void *d_runs, uint64_t n_runs,
+                           const uint32_t *kept_root, const uint32_t *kept_size, const int64_t *kept_weight,
+                           const int32_t *kept_thr, const uint64_t *kept_minkey, uint64_t n_kept, mf_comps **out);
 /* ALL ranks' members + all levels' kept components (host arrays) -> components, ordered as above */
 int  mf_dcc_finish(mf_dcc *d, const void *d_kmers, const void *d_roots, uint64_t n_members, const uint32_t *kept_root,
                    const uint32_t *kept_size, const int64_t *kept_weight, const int32_t *kept_thr,

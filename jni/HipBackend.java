@@ -62,6 +62,11 @@ public final class HipBackend {
     public static native void dccKeptFill(long dcc, long dKept);
     public static native long dccMembers(long dcc);
     public static native void dccMembersFill(long dcc, long dKmers, long dRoots);
+    /** {members, runs}: the members sorted by component -- 8 bytes each on the wire + one (root, count) record per component */
+    public static native long[] dccMembersGrouped(long dcc);
+    public static native void dccMembersGroupedFill(long dcc, long dKmers, long dRuns);
+    public static native long dccFinishGrouped(long dcc, long dKmers, long nMembers, long dRuns, long nRuns, int[] keptRoot, int[] keptSize,
+                                               long[] keptWeight, int[] keptThr, long[] keptMinkey);
     public static native void dccMinkeys(long dcc, int[] keptRoot, long dMin);
     /** -> components handle (List&lt;ConnectedComponent&gt;), the same on every rank */
     public static native long dccFinish(long dcc, long dKmers, long dRoots, long nMembers, int[] keptRoot, int[] keptSize, long[] keptWeight,

@@ -207,12 +207,38 @@ JNIEXPORT jlong JNICALL Java_io_HipBackend_dccMembers(JNIEnv *e, jclass, jlong d
     return (jlong)n;
 }
 JNIEXPORT void JNICALL Java_io_HipBackend_dccMembersFill(JNIEnv *e, jclass, jlong dcc, jlong dKmers, jlong dRoots) { if (mf_dcc_members_fill(DCC(dcc), DEV(dKmers), DEV(dRoots)) < 0) raise(e); }
+// { members, runs }: this rank's members sorted by component (8 bytes each on the wire) + one (root, count) record per component
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_dccMembersGrouped(JNIEnv *e, jclass, jlong dcc) {
+    uint64_t r[2] = {0, 0};
+    if (mf_dcc_members_grouped(DCC(dcc), &r[0], &r[1]) < 0) { raise(e); return nullptr; }
+    return longs(e, r, 2);
+}
+JNIEXPORT void JNICALL Java_io_HipBackend_dccMembersGroupedFill(JNIEnv *e, jclass, jlong dcc, jlong dKmers, jlong dRuns) {
+    if (mf_dcc_members_grouped_fill(DCC(dcc), DEV(dKmers), DEV(dRuns)) < 0) raise(e);
+}
 JNIEXPORT void JNICALL Java_io_HipBackend_dccMinkeys(JNIEnv *e, jclass, jlong dcc, jintArray keptRoot, jlong dMin) {
     const jsize n = e->GetArrayLength(keptRoot);
     jint *g = e->GetIntArrayElements(keptRoot, nullptr);
     const int rc = mf_dcc_minkeys(DCC(dcc), (const uint32_t *)g, (uint64_t)n, DEV(dMin));
     e->ReleaseIntArrayElements(keptRoot, g, JNI_ABORT);
     if (rc < 0) raise(e);
+}
+JNIEXPORT jlong JNICALL Java_io_HipBackend_dccFinishGrouped(JNIEnv *e, jclass, jlong dcc, jlong dKmers, jlong nMembers, jlong dRuns, jlong nRuns, jintArray keptRoot,
+                                                            jintArray keptSize, jlongArray keptWeight, jintArray keptThr, jlongArray keptMinkey) {
+    const jsize n = e->GetArrayLength(keptRoot);
+    if (e->GetArrayLength(keptSize) != n || e->GetArrayLength(keptWeight) != n || e->GetArrayLength(keptThr) != n || e->GetArrayLength(keptMinkey) != n) {
+        bad_length(e, "dccFinishGrouped: the kept arrays must have one entry per component");
+        return 0;
+    }
+    jint *g = e->GetIntArrayElements(keptRoot, nullptr), *sz = e->GetIntArrayElements(keptSize, nullptr), *th = e->GetIntArrayElements(keptThr, nullptr);
+    jlong *w = e->GetLongArrayElements(keptWeight, nullptr), *mk = e->GetLongArrayElements(keptMinkey, nullptr);
+    mf_comps *c = nullptr;
+    const int rc = mf_dcc_finish_grouped(DCC(dcc), DEV(dKmers), (uint64_t)nMembers, DEV(dRuns), (uint64_t)nRuns, (const uint32_t *)g, (const uint32_t *)sz, (const int64_t *)w,
+                                         (const int32_t *)th, (const uint64_t *)mk, (uint64_t)n, &c);
+    e->ReleaseIntArrayElements(keptRoot, g, JNI_ABORT); e->ReleaseIntArrayElements(keptSize, sz, JNI_ABORT); e->ReleaseIntArrayElements(keptThr, th, JNI_ABORT);
+    e->ReleaseLongArrayElements(keptWeight, w, JNI_ABORT); e->ReleaseLongArrayElements(keptMinkey, mk, JNI_ABORT);
+    if (rc < 0) { raise(e); return 0; }
+    return (jlong)(intptr_t)c;
 }
 JNIEXPORT jlong JNICALL Java_io_HipBackend_dccFinish(JNIEnv *e, jclass, jlong dcc, jlong dKmers, jlong dRoots, jlong nMembers, jintArray keptRoot, jintArray keptSize,
                                                      jlongArray keptWeight, jintArray keptThr, jlongArray keptMinkey) {

@@ -669,6 +669,7 @@ struct mf_dcc {
     uint64_t nstat = 0, nkept_owned = 0; int level = 0;
     mf_buf<uint32_t> touched; mf_buf<uint2> hp; std::vector<uint64_t> xstart;     // [n] global roots this rank contributes to; [nx] half pairs; [world + 1] cross edges by rank
     mf_buf<dcc_kept_rec> keptbuf;
+    mf_buf<uint64_t> gmk; mf_buf<uint2> gruns; uint64_t n_runs = 0;        // members grouped by component: k-mers, (root, count) runs
     mf_buf<uint64_t> dseg; mf_buf<uint32_t> dbase;         // [world + 1] on the device: first record of every rank (per level), first vertex of every rank
 };
 
@@ -1215,6 +1216,68 @@ extern "C" int mf_dcc_members_fill(mf_dcc *D, void *d_keys, void *d_roots) {
     MF_HIP(hipStreamSynchronize(st));
     return MF_OK;
 }
+// The members grouped by component: 8 bytes per member on the wire (the k-mer) + one (root, count) record per component and rank,
+// instead of 12 bytes per member (k-mer + root): the all-gather of the members is the largest exchange of the sharded cutter
+// (2.6 GB per rank at 8 x 50 M reads).  mf_dcc_members_grouped sorts this rank's members by root; the receiver expands the runs
+// of all ranks back to one root per member (mf_dcc_finish_grouped).
+__global__ void k_dcc_run_flags(const uint32_t *__restrict__ g, uint64_t n, uint32_t *__restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || g[i] != g[i - 1]) ? 1u : 0u;
+}
+__global__ void k_dcc_run_heads(const uint32_t *__restrict__ g, const uint32_t *__restrict__ flag, const uint64_t *__restrict__ idx, uint64_t n, uint64_t n_runs,
+                                uint2 *__restrict__ runs, uint64_t *__restrict__ start) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) { const uint64_t j = idx[i]; runs[j].x = g[i]; start[j] = i; }
+}
+__global__ void k_dcc_run_counts(const uint64_t *__restrict__ start, uint64_t n_runs, uint64_t n, uint2 *__restrict__ runs) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_runs) runs[j].y = (uint32_t)((j + 1 < n_runs ? start[j + 1] : n) - start[j]);
+}
+__global__ void k_dcc_run_lens(const uint2 *__restrict__ runs, uint64_t n_runs, uint32_t *__restrict__ len) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n_runs) len[j] = runs[j].y;
+}
+__global__ void k_dcc_run_expand(const uint2 *__restrict__ runs, const uint64_t *__restrict__ off, uint64_t n_runs, uint32_t *__restrict__ roots) {
+    // one wave per run
+    const uint64_t j = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (j >= n_runs) return;
+    const uint32_t g = runs[j].x, c = runs[j].y;
+    const uint64_t o = off[j];
+    for (uint32_t i = (uint32_t)mf_lane(); i < c; i += 64) roots[o + i] = g;
+}
+extern "C" int mf_dcc_members_grouped(mf_dcc *D, uint64_t *n_members, uint64_t *n_runs) {
+    if (!D || !n_members || !n_runs) return mf_set_error("mf_dcc_members_grouped: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    *n_members = D->nm; *n_runs = D->n_runs = 0;
+    if (!D->nm) return MF_OK;
+    mf_buf<uint32_t> sg, flag; mf_buf<uint64_t> idx, start, tot;
+    MF_TRY(sg.alloc(ctx, D->nm)); MF_TRY(D->gmk.alloc(ctx, D->nm)); MF_TRY(flag.alloc(ctx, D->nm)); MF_TRY(idx.alloc(ctx, D->nm + 1)); MF_TRY(tot.alloc(ctx, 1));
+    MF_TRY(mf_sort_u32_u64(ctx, D->mg.p, D->mk.p, D->nm, 32, sg.p, D->gmk.p));
+    k_dcc_run_flags<<<cgrid(D->nm), 256, 0, st>>>(sg.p, D->nm, flag.p);
+    MF_TRY(mf_scan<1>(ctx, flag.p, idx.p, D->nm, tot.p));
+    uint64_t nr = 0;
+    MF_HIP(hipMemcpyAsync(&nr, tot.p, 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    MF_TRY(D->gruns.alloc(ctx, nr)); MF_TRY(start.alloc(ctx, nr));
+    k_dcc_run_heads<<<cgrid(D->nm), 256, 0, st>>>(sg.p, flag.p, idx.p, D->nm, nr, D->gruns.p, start.p);
+    k_dcc_run_counts<<<cgrid(nr), 256, 0, st>>>(start.p, nr, D->nm, D->gruns.p);
+    MF_HIP(hipStreamSynchronize(st));
+    *n_runs = D->n_runs = nr;
+    return MF_OK;
+}
+extern "C" int mf_dcc_members_grouped_fill(mf_dcc *D, void *d_kmers, void *d_runs) {
+    if (!D || (D->nm && (!d_kmers || !d_runs))) return mf_set_error("mf_dcc_members_grouped_fill: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    if (D->nm) {
+        if (!D->gmk.p) return mf_set_error("mf_dcc_members_grouped_fill: call mf_dcc_members_grouped first");
+        MF_HIP(hipMemcpyAsync(d_kmers, D->gmk.p, D->nm * 8, hipMemcpyDeviceToDevice, st));
+        MF_HIP(hipMemcpyAsync(d_runs, D->gruns.p, D->n_runs * 8, hipMemcpyDeviceToDevice, st));
+    }
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
 // smallest member k-mer of each kept component among THIS rank's vertices (DCC_NOKEY: none here) -> d_out u64[n_kept];
 // the caller takes the minimum over the ranks
 __global__ void k_dcc_minkeys(const uint32_t *__restrict__ g, uint64_t n, const unsigned long long *__restrict__ gmin, unsigned long long *__restrict__ out) {
@@ -1243,6 +1306,30 @@ __global__ void k_dcc_slot_map(const uint32_t *__restrict__ g, uint32_t n, uint3
 __global__ void k_dcc_member_slots(const uint32_t *__restrict__ mg, uint64_t n, const uint32_t *__restrict__ map, uint32_t *__restrict__ comp) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) comp[i] = map[mg[i]];
+}
+// ALL ranks' grouped members (k-mers in rank order, each rank's sorted by component; the ranks' (root, count) runs in the same
+// order) -> mf_dcc_finish on the expanded roots
+extern "C" int mf_dcc_finish(mf_dcc *D, const void *d_keys, const void *d_roots, uint64_t nm, const uint32_t *kept_root, const uint32_t *kept_size,
+                             const int64_t *kept_weight, const int32_t *kept_thr, const uint64_t *minkey, uint64_t n_kept, mf_comps **out);
+extern "C" int mf_dcc_finish_grouped(mf_dcc *D, const void *d_keys, uint64_t nm, const void *d_runs, uint64_t n_runs, const uint32_t *kept_root,
+                                     const uint32_t *kept_size, const int64_t *kept_weight, const int32_t *kept_thr, const uint64_t *minkey, uint64_t n_kept,
+                                     mf_comps **out) {
+    if (!D || !out || (nm && (!d_keys || !d_runs))) return mf_set_error("mf_dcc_finish_grouped: NULL argument");
+    mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    MF_HIP(hipSetDevice(ctx->device));
+    mf_buf<uint32_t> roots, len; mf_buf<uint64_t> off, tot;
+    MF_TRY(roots.alloc(ctx, nm ? nm : 1));
+    if (n_runs) {
+        MF_TRY(len.alloc(ctx, n_runs)); MF_TRY(off.alloc(ctx, n_runs + 1)); MF_TRY(tot.alloc(ctx, 1));
+        k_dcc_run_lens<<<cgrid(n_runs), 256, 0, st>>>((const uint2 *)d_runs, n_runs, len.p);
+        MF_TRY(mf_scan<1>(ctx, len.p, off.p, n_runs, tot.p));
+        uint64_t total = 0;
+        MF_HIP(hipMemcpyAsync(&total, tot.p, 8, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+        if (total != nm) return mf_set_error("mf_dcc_finish_grouped: the runs describe %llu members, %llu were passed", (unsigned long long)total, (unsigned long long)nm);
+        k_dcc_run_expand<<<cgrid(n_runs * 64), 256, 0, st>>>((const uint2 *)d_runs, off.p, n_runs, roots.p);
+    } else if (nm) return mf_set_error("mf_dcc_finish_grouped: members without runs");
+    return mf_dcc_finish(D, d_keys, roots.p, nm, kept_root, kept_size, kept_weight, kept_thr, minkey, n_kept, out);
 }
 extern "C" int mf_dcc_finish(mf_dcc *D, const void *d_keys, const void *d_roots, uint64_t nm, const uint32_t *kept_root, const uint32_t *kept_size,
                              const int64_t *kept_weight, const int32_t *kept_thr, const uint64_t *minkey, uint64_t n_kept, mf_comps **out) {

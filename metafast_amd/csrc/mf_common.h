@@ -373,6 +373,8 @@ int mf_sort_pairs(mf_ctx *ctx, const uint64_t *d_keys_in, const uint16_t *d_vals
                   uint16_t *d_vals_out);
 int mf_sort_u32_pairs(mf_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_vals_in, uint64_t n, int bits, uint32_t *d_keys_out,
                       uint32_t *d_vals_out);
+int mf_sort_u32_u64(mf_ctx *ctx, const uint32_t *d_keys_in, const uint64_t *d_vals_in, uint64_t n, int bits, uint32_t *d_keys_out,
+                    uint64_t *d_vals_out);
 int mf_sort_kmers_by_comp(mf_ctx *ctx, const uint32_t *d_comp, const uint64_t *d_kmers, uint64_t n, int key_bits, uint32_t n_comps,
                           uint64_t *d_out);
 // ph: the key's partition hash if the caller has it already (minimizer partitions only), see mf_index_find

@@ -52,3 +52,17 @@ int mf_sort_u32_pairs(mf_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_
     MF_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tb, d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, 0u, eb, ctx->stream));
     return MF_OK;
 }
+
+// (u32 key, u64 value) pairs, ascending keys of `bits` bits (stable): the members of the sharded cutter grouped by component
+int mf_sort_u32_u64(mf_ctx *ctx, const uint32_t *d_keys_in, const uint64_t *d_vals_in, uint64_t n, int bits, uint32_t *d_keys_out,
+                    uint64_t *d_vals_out) {
+    if (!n) return MF_OK;
+    MF_HIP(hipSetDevice(ctx->device));
+    size_t tb = 0;
+    const unsigned eb = (unsigned)std::min(32, std::max(1, bits));
+    MF_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, 0u, eb, ctx->stream));
+    mf_buf<uint8_t> tmp; MF_TRY(tmp.alloc(ctx, tb + 1));
+    MF_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tb, d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, 0u, eb, ctx->stream));
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    return MF_OK;
+}

@@ -67,6 +67,9 @@ _SIGS = {
     "mf_dcc_stats_fill": (i32, [vp, vp]),
     "mf_dcc_classify": (i32, [vp, vp, u64, vp, u64, u64, i32, i32, i32, pu64, pu64]),
     "mf_dcc_world": (i32, [vp]),
+    "mf_dcc_members_grouped": (i32, [vp, pu64, pu64]),
+    "mf_dcc_members_grouped_fill": (i32, [vp, vp, vp]),
+    "mf_dcc_finish_grouped": (i32, [vp, vp, u64, vp, u64, vp, vp, vp, vp, vp, u64, pvp]),
     "mf_dcc_kept_fill": (i32, [vp, vp]),
     "mf_dcc_members": (i32, [vp, pu64]),
     "mf_dcc_members_fill": (i32, [vp, vp, vp]),
@@ -546,6 +549,24 @@ class DistCutter:
 
     def members_fill(self, d_keys, d_roots):
         _check(lib().mf_dcc_members_fill(self.h, d_keys, d_roots))
+
+    def members_grouped(self):
+        """-> (members, runs): this rank's members sorted by component, 8 B each + one (root, count) record per component"""
+        n, r = C.c_uint64(), C.c_uint64()
+        _check(lib().mf_dcc_members_grouped(self.h, C.byref(n), C.byref(r)))
+        return n.value, r.value
+
+    def members_grouped_fill(self, d_keys, d_runs):
+        _check(lib().mf_dcc_members_grouped_fill(self.h, d_keys, d_runs))
+
+    def finish_grouped(self, d_keys, nm, d_runs, n_runs, roots, sizes, weights, thrs, minkeys):
+        roots = np.ascontiguousarray(roots, dtype=np.uint32); sizes = np.ascontiguousarray(sizes, dtype=np.uint32)
+        weights = np.ascontiguousarray(weights, dtype=np.int64); thrs = np.ascontiguousarray(thrs, dtype=np.int32)
+        minkeys = np.ascontiguousarray(minkeys, dtype=np.uint64)
+        c = C.c_void_p()
+        _check(lib().mf_dcc_finish_grouped(self.h, d_keys, nm, d_runs, n_runs, roots.ctypes.data, sizes.ctypes.data, weights.ctypes.data,
+                                           thrs.ctypes.data, minkeys.ctypes.data, len(roots), C.byref(c)))
+        return Comps(self.ctx, c)
 
     def minkeys(self, roots, d_out):
         roots = np.ascontiguousarray(roots, dtype=np.uint32)

@@ -390,17 +390,20 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
             per_level.append((int(allp.numel()), int(sm.sum()), int(n_kept), int(n_big)))
         mark("cutter_levels")
         # ---- members of the kept components, everywhere
-        nm = call(lambda: D.members(), 0)
-        mm = gather_ints(lambda: [nm], 1)[:, 0]
-        mk = _i64(nm, device); mg = torch.empty(max(nm, 1), dtype=torch.int32, device=device); sync()
-        call(lambda: D.members_fill(mk.data_ptr(), mg.data_ptr()))
-        allmk = comm.all_gather(mk[:nm], mm); allmg = comm.all_gather(mg[:nm], mm); sync()
+        # ---- members of the kept components, everywhere: 8 bytes per member (the k-mers, sorted by component on the rank) + one
+        # (root, count) record per component and rank
+        nm, nr = call(lambda: D.members_grouped(), (0, 0))
+        mm = gather_ints(lambda: [nm, nr], 2)
+        mk = _i64(nm, device); mr = _i64(nr, device); sync()
+        call(lambda: D.members_grouped_fill(mk.data_ptr(), mr.data_ptr()))
+        allmk = comm.all_gather(mk[:nm], mm[:, 0]); allmr = comm.all_gather(mr[:nr], mm[:, 1]); sync()
         cat = (lambda i, dt: np.concatenate([x[i] for x in kept]).astype(dt)) if kept else (lambda i, dt: np.zeros(0, dtype=dt))
         roots = cat(0, np.uint32)
         mn = _i64(len(roots), device); sync()
         call(lambda: D.minkeys(roots, mn.data_ptr()))
         mn = comm.all_reduce_min(mn[:len(roots)]).cpu().numpy().astype(np.uint64)
-        comps = call(lambda: D.finish(allmk.data_ptr(), allmg.data_ptr(), int(allmk.numel()), roots, cat(1, np.uint32), cat(2, np.int64), cat(3, np.int32), mn))
+        comps = call(lambda: D.finish_grouped(allmk.data_ptr(), int(allmk.numel()), allmr.data_ptr(), int(allmr.numel()), roots, cat(1, np.uint32),
+                                              cat(2, np.int64), cat(3, np.int32), mn))
         gather_ints(lambda: [len(comps)], 1)          # (the last status: every rank has its components, or all raise)
         if info is not None:
             info.update(levels=levels, per_level=per_level, shard=int(ns[me]), vertices=int(base[-1]), queries=nq, members=int(allmk.numel()))
