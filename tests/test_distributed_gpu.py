@@ -24,6 +24,10 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(0)
 dist.init_process_group(os.environ["MF_BACKEND"], rank=rank, world_size=world, **({"device_id": torch.device("cuda", 0)} if os.environ["MF_BACKEND"] == "nccl" else {}))
 ctx = L.Context(0, stream=torch.cuda.current_stream())
+if os.environ.get("MF_TEST_FAIL_SHARD_RANK") == str(rank):        # (this rank's shard count fails: the ranks must fall back TOGETHER)
+    def no_shard(*a, **k):
+        raise L.MetafastError("injected: the shard count failed on this rank")
+    ctx.count_device_shard = no_shard
 spg = int(os.environ.get("MF_SPG", "1"))
 def samples():
     for j in range(spg):
@@ -86,6 +90,15 @@ def _same(got, want):
 def test_two_ranks_one_gpu_gloo(oracle, tmp_path):
     """pipeline.run_samples across two ranks (one sample each): both ranks get the oracle's components and 2 x 2 matrix"""
     res = _run(2, "gloo", tmp_path)
+    want = _oracle_pipeline(oracle, tmp_path, [107, 117])
+    for r in res:
+        _same(r, want)
+
+
+def test_two_ranks_fall_back_together_when_one_shard_count_fails(oracle, tmp_path):
+    """rank 1 cannot count its shard: both ranks leave the sharded cutter at the same gather (DistAbort), build the whole
+    cutter table each (the replicated path) and still end with the oracle's components and matrix"""
+    res = _run(2, "gloo", tmp_path, extra_env={"MF_TEST_FAIL_SHARD_RANK": "1"})
     want = _oracle_pipeline(oracle, tmp_path, [107, 117])
     for r in res:
         _same(r, want)
