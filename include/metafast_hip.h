@@ -60,6 +60,9 @@ int  mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t value);
 int  mf_ctx_synchronize(mf_ctx *ctx);
 /* Release cached workspace back to the driver. */
 int  mf_ctx_trim(mf_ctx *ctx);
+/* ... only `want` bytes of it, smallest idle regions first (a host that shares the device with the library and is short of
+ * memory: a region the library has to allocate again costs about 35 ms per GiB).  *freed may be NULL. */
+int  mf_ctx_trim_bytes(mf_ctx *ctx, uint64_t want, uint64_t *freed);
 /* Per-kernel HIP-event timings accumulated while option "profile"=1.
  * Returns number of launches of `kernel` since the last reset; *total_ms = summed duration. */
 int64_t mf_ctx_kernel_time(mf_ctx *ctx, const char *kernel, double *total_ms);

@@ -66,6 +66,7 @@ struct mf_ctx {
     int64_t opt_sr_piece = 8 << 20, opt_sr_slack = 1 << 20;
     void *pin_pool = nullptr; size_t pin_pool_bytes = 0;           // pinned staging chunks of the streaming reader (lazy, kept)
     int64_t opt_skm_slices = 0;    // digit-range slices of a counting run (0 = as many as the HBM budget asks for)
+    int64_t opt_skm_shared = 1;    // slices behind one level 1 over all digits: 0 never, 1 when it fits, 2 whenever a run is sliced
     int64_t opt_arena_cap_gb = 0;  // pretend the device has this much memory when the slices are chosen (0 = what it has)
     int64_t opt_skm_batches = 0;   // partitions are counted + gathered in this many batches (0 = auto); tests force small values
     int64_t opt_union_samples = 0;     // hint: the sequences of the next count are the unitigs of this many samples (they share k-mers: partitions are planned twice as large from 4 on)
@@ -103,18 +104,21 @@ struct mf_ktimer {
 
 template <typename T> struct mf_buf {   // RAII workspace buffer
     mf_ctx *ctx = nullptr; T *p = nullptr; size_t n = 0;
+    bool owned = true;                   // false: a view of somebody else's buffer (borrow), never released here
     mf_buf() {}
     mf_buf(const mf_buf &) = delete;
     mf_buf &operator=(const mf_buf &) = delete;
     ~mf_buf() { reset(); }
     int alloc(mf_ctx *c, size_t count) {
-        reset(); ctx = c; n = count;
+        reset(); ctx = c; n = count; owned = true;
         void *q = nullptr;
         int r = mf_alloc(c, (count ? count : 1) * sizeof(T), &q);
         p = (T *)q;
         return r;
     }
-    void reset() { if (p) mf_release(ctx, p, (n ? n : 1) * sizeof(T)); p = nullptr; n = 0; }
+    void reset() { if (p && owned) mf_release(ctx, p, (n ? n : 1) * sizeof(T)); p = nullptr; n = 0; owned = true; }
+    void borrow(mf_ctx *c, T *q, size_t count) { reset(); ctx = c; p = q; n = count; owned = false; }
+    void swap(mf_buf &o) { std::swap(ctx, o.ctx); std::swap(p, o.p); std::swap(n, o.n); std::swap(owned, o.owned); }
     T *take() { T *q = p; p = nullptr; return q; }   // ownership moves to the caller (who releases with mf_release)
     size_t bytes() const { return (n ? n : 1) * sizeof(T); }
 };

@@ -53,6 +53,31 @@ extern "C" int mf_ctx_trim(mf_ctx *ctx) {
     return MF_OK;
 }
 
+// ... only as many as it takes to hand `want` bytes back, smallest regions first: a region costs its next user 35 ms per GiB
+// of hipMalloc (150 GiB: 5 s), so a caller that is short of a gigabyte should not make the arena drop its 100 GB record
+// buffers.  *freed (may be NULL) = bytes given back (less than `want` when there were not enough idle regions).
+extern "C" int mf_ctx_trim_bytes(mf_ctx *ctx, uint64_t want, uint64_t *freed) {
+    if (freed) *freed = 0;
+    if (!ctx) return MF_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    uint64_t got = 0;
+    while (got < want) {
+        int best = -1;
+        for (size_t i = 0; i < ctx->regions.size(); i++) {
+            auto &r = ctx->regions[i];
+            if (r.free_spans.size() == 1 && r.free_spans[0].off == 0 && r.free_spans[0].sz == r.size && (best < 0 || r.size < ctx->regions[best].size)) best = (int)i;
+        }
+        if (best < 0) break;
+        hipFree(ctx->regions[best].base);
+        got += ctx->regions[best].size;
+        ctx->arena_bytes -= ctx->regions[best].size;
+        ctx->regions.erase(ctx->regions.begin() + best);
+    }
+    if (freed) *freed = got;
+    return MF_OK;
+}
+
 extern "C" void mf_ctx_destroy(mf_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
@@ -93,6 +118,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "skm_batches") ctx->opt_skm_batches = v;
     else if (s == "skm_slices") { if (v < 0 || v > 64 || (v & (v - 1))) return mf_set_error("skm_slices must be 0 or a power of two <= 64"); ctx->opt_skm_slices = v; }
     else if (s == "arena_cap_gb") ctx->opt_arena_cap_gb = v;
+    else if (s == "skm_shared") ctx->opt_skm_shared = v;
     else if (s == "stream_reader") ctx->opt_stream_reader = v;
     else if (s == "stream_piece_bytes") ctx->opt_sr_piece = v;
     else if (s == "stream_slack_bytes") ctx->opt_sr_slack = v;
@@ -111,12 +137,17 @@ extern "C" int mf_ctx_synchronize(mf_ctx *ctx) {
 
 // ---- workspace arena ----
 static const size_t MF_ALIGN = 256;
-static bool arena_take(mf_ctx *ctx, size_t bytes, void **out) {
+// spare_big: leave the idle record buffers of huge samples (a free span of >= 48 GiB, four times the request or more)
+// alone.  Something small and long-lived carved out of one -- a table, an index -- pins it: the next sample's level-1
+// buffer then needs a new region, the device is full, everything idle goes back to the driver, and the 126 GB region is
+// allocated again at 35 ms per GiB (8 samples x 200 M reads at k = 21 on one GPU spent 3 s of an 8 s step there).
+static bool arena_take(mf_ctx *ctx, size_t bytes, void **out, bool spare_big) {
     // best fit over all regions
     int br = -1, bs = -1; size_t best = ~(size_t)0;
     for (size_t r = 0; r < ctx->regions.size(); r++)
         for (size_t s = 0; s < ctx->regions[r].free_spans.size(); s++) {
             size_t sz = ctx->regions[r].free_spans[s].sz;
+            if (spare_big && sz >= ((size_t)48 << 30) && sz / 4 >= bytes) continue;
             if (sz >= bytes && sz < best) { best = sz; br = (int)r; bs = (int)s; }
         }
     if (br < 0) return false;
@@ -129,22 +160,39 @@ static bool arena_take(mf_ctx *ctx, size_t bytes, void **out) {
 }
 int mf_alloc(mf_ctx *ctx, size_t bytes, void **out) {
     bytes = (bytes + MF_ALIGN - 1) & ~(MF_ALIGN - 1);
-    if (arena_take(ctx, bytes, out)) return MF_OK;
+    if (arena_take(ctx, bytes, out, true)) return MF_OK;
     // new region: small requests share 256 MiB regions, large ones get their own
     size_t rsz = bytes < ((size_t)256 << 20) ? ((size_t)256 << 20) : bytes;
+    if (bytes >= ((size_t)1 << 30)) {
+        // ... with up to 3 % of slack: the next sample's buffer of this kind is a few megabytes larger or smaller, and a region
+        // that is a hair too small is a region allocated twice
+        const size_t gran = (size_t)1 << (63 - __builtin_clzll((unsigned long long)bytes) - 5);
+        rsz = (bytes + gran - 1) & ~(gran - 1);
+    }
     void *p = nullptr;
     hipError_t e = hipMalloc(&p, rsz);
     if (e != hipSuccess && rsz != bytes) { (void)hipGetLastError(); rsz = bytes; e = hipMalloc(&p, rsz); }
     if (e != hipSuccess) {
         (void)hipGetLastError();
-        mf_ctx_trim(ctx);                       // return idle regions and retry once
-        e = hipMalloc(&p, rsz);
-        if (e != hipSuccess) { (void)hipGetLastError(); return mf_set_error("hipMalloc(%zu bytes) failed: %s", rsz, hipGetErrorString(e)); }
+        if (arena_take(ctx, bytes, out, false)) return MF_OK;       // (rather a pinned big region than a dropped one)
+        // idle regions go back to the driver, the smallest first and only as many as it takes
+        if (ctx->opt_verbose) fprintf(stderr, "[mf] arena: hipMalloc(%.1f GB) failed with %.1f GB idle: giving idle regions back\n", rsz / 1e9, mf_arena_idle(ctx) / 1e9);
+        for (;;) {
+            uint64_t got = 0;
+            mf_ctx_trim_bytes(ctx, 1, &got);
+            if (!got) break;
+            e = hipMalloc(&p, rsz);
+            if (e == hipSuccess) break;
+            (void)hipGetLastError();
+        }
+        if (e != hipSuccess) return mf_set_error("hipMalloc(%zu bytes) failed: %s", rsz, hipGetErrorString(e));
     }
+    if (ctx->opt_verbose && rsz >= ((size_t)1 << 30))
+        fprintf(stderr, "[mf] arena: new region of %.1f GB (request %.1f GB; arena %.1f GB, idle %.1f GB)\n", rsz / 1e9, bytes / 1e9, ctx->arena_bytes / 1e9, mf_arena_idle(ctx) / 1e9);
     mf_ctx::region R; R.base = (char *)p; R.size = rsz; R.free_spans.push_back({0, rsz});
     ctx->regions.push_back(R);
     ctx->arena_bytes += rsz;
-    if (!arena_take(ctx, bytes, out)) return mf_set_error("arena: internal error");
+    if (!arena_take(ctx, bytes, out, false)) return mf_set_error("arena: internal error");
     return MF_OK;
 }
 // bytes the arena holds but nobody uses (they can serve the next request without a hipMalloc)

@@ -567,7 +567,8 @@ __global__ void k_skm_dir(const uint64_t *__restrict__ blockstart, const uint32_
 __global__ __launch_bounds__(1024) void k_skm_split(const skm_rec *__restrict__ in, const uint64_t *__restrict__ pstart,
                                                     const uint32_t *__restrict__ plen, uint32_t np, int shift, int bits,
                                                     skm_rec *__restrict__ out, uint64_t *__restrict__ ostart, uint32_t *__restrict__ olen,
-                                                    uint32_t *__restrict__ oocc, unsigned long long *__restrict__ n_valid) {
+                                                    uint32_t *__restrict__ oocc, unsigned long long *__restrict__ n_valid, uint64_t rebase) {
+    // rebase: `in` is a buffer shared by several slices (skm_shared) and `out` belongs to this slice: its regions start at 0
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ uint32_t scratch[17];
     const int nd = 1 << bits;
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(1024) void k_skm_split(const skm_rec *__restrict__ 
     for (uint32_t p = blockIdx.x; p < np; p += gridDim.x) {
         const uint64_t start = pstart[p];
         const uint32_t len = plen[p];
-        const uint64_t obase = start + (uint64_t)p * (uint64_t)(SKM_LINE * nd);   // room for per-digit padding
+        const uint64_t obase = start - rebase + (uint64_t)p * (uint64_t)(SKM_LINE * nd);   // room for per-digit padding
         for (int i = threadIdx.x; i < nd; i += blockDim.x) { L.ctr[i] = 0; occ[i] = 0; }
         __syncthreads();
         const skm_rec *src = in + start;
@@ -1230,6 +1231,18 @@ struct skm_acc {
     uint32_t np_total = 0;
 };
 #define MF_SKM_NOMEM 2             /* skm_slice: a record buffer did not fit -- the caller tries again with more slices */
+// Level 1 of a run that is counted in slices, done ONCE for all the run's digits (round 3): round 2's slices each scanned the reads
+// again for their own digits because two sliced record buffers were budgeted -- at 380 M reads k_skm_scatter was 412 ms of a
+// 970 ms sample.  One full level-1 buffer + one slice-sized buffer for the following levels fit as well (57 GB of reads +
+// 87 GB + 87 / S GB), and the reads are scanned once; the slices then differ only in which level-1 partitions they split and count.
+struct skm_shared {
+    uint32_t lo = 0, hi = 0;           // the run's level-1 digits
+    bool ready = false;
+    mf_buf<skm_rec> buf; mf_buf<uint64_t> pstart; mf_buf<uint32_t> plen, pocc;
+    std::vector<uint64_t> h_pstart;    // (host copy: where the digit regions start, for the slices' buffer sizes)
+    unsigned long long cap = 0;
+    void clear() { buf.reset(); pstart.reset(); plen.reset(); pocc.reset(); h_pstart.clear(); ready = false; cap = 0; }
+};
 // One SLICE of the run: the records whose level-1 digit lies in [dlo, dhi) go through scatter, split and count.  A run is one
 // slice unless the records do not fit next to the reads (300 M reads and more): then the reads are scanned once per slice
 // and only a 1 / S share of the records exists at any time.  Partitions are numbered by digit, so slice after slice fills
@@ -1237,9 +1250,11 @@ struct skm_acc {
 template <int K>
 static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words,
                      uint64_t n_occ, const std::vector<int> &lv, unsigned long long *scal, int kthr, uint32_t dlo, uint32_t dhi,
-                     uint32_t slice, uint32_t n_slices, skm_acc &A) {
+                     uint32_t slice, uint32_t n_slices, skm_acc &A, skm_shared *SH = nullptr) {
     hipStream_t st = ctx->stream;
     const int bits1 = lv[0], nd1 = 1 << bits1;
+    // (SH: level 1 covers all of the run's digits and is done by the first slice; dlo / dhi then only say which regions this slice takes)
+    const uint32_t l1lo = SH ? SH->lo : dlo, l1hi = SH ? SH->hi : dhi;
     int total_bits = 0; for (int b : lv) total_bits += b;
     int G = ctx->opt_l1_blocks > 0 ? (int)ctx->opt_l1_blocks : ctx->n_cu;
     {
@@ -1273,37 +1288,37 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
     // minimizer pass just to count (k_skm_hist over everything costs 17 ms of 300 at 100 M reads).  If a region turns out
     // too small the level is repeated with exact ranges.  skm_dyn: 0 never, 1 auto, 2 always (tests).
     bool dyn = !l1_only && (ctx->opt_skm_dyn == 2 || (ctx->opt_skm_dyn == 1 && n_words >= (1ull << 24)));
-    for (int attempt = dyn ? 0 : 1; attempt < 2; attempt++) {
+    for (int attempt = dyn ? 0 : 1; attempt < 2 && !(SH && SH->ready); attempt++) {
         const bool D = attempt == 0;
         const int stride = D ? (ctx->opt_skm_dyn == 2 ? 3 : 16) : 1;
         mf_buf<uint32_t> blockhist; MF_TRY(blockhist.alloc(ctx, (size_t)nd1 * G));
         mf_buf<uint32_t> blockocc; if (l1_only) MF_TRY(blockocc.alloc(ctx, (size_t)nd1 * G));
         {
             mf_ktimer t(ctx, D ? "k_skm_hist_sample" : "k_skm_hist");
-            k_skm_hist<K><<<G, 1024, (size_t)nd1 * 8, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockhist.p, blockocc.p, G, stride, dlo, dhi);
+            k_skm_hist<K><<<G, 1024, (size_t)nd1 * 8, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockhist.p, blockocc.p, G, stride, l1lo, l1hi);
         }
         MF_DBG(ctx, "k_skm_hist");
         if (D) {
             mf_buf<uint32_t> rsize; MF_TRY(rsize.alloc(ctx, np));
             mf_buf<uint64_t> rstart; MF_TRY(rstart.alloc(ctx, (size_t)np + 1));
             mf_buf<unsigned long long> gcur; MF_TRY(gcur.alloc(ctx, np));
-            k_skm_region_sizes<<<(nd1 + 255) / 256, 256, 0, st>>>(blockhist.p, G, nd1, (uint32_t)stride, rsize.p, dlo, dhi);
+            k_skm_region_sizes<<<(nd1 + 255) / 256, 256, 0, st>>>(blockhist.p, G, nd1, (uint32_t)stride, rsize.p, l1lo, l1hi);
             MF_TRY(mf_scan<1>(ctx, rsize.p, rstart.p, np, (uint64_t *)&scal[1]));
             MF_HIP(hipMemcpyAsync(gcur.p, rstart.p, (size_t)np * 8, hipMemcpyDeviceToDevice, st));
             MF_HIP(hipMemsetAsync(&scal[5], 0, 8, st));
             MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
             MF_HIP(hipStreamSynchronize(st));
-            if (bufA.alloc(ctx, std::max<unsigned long long>(cap + (uint64_t)G * SKM_CH, final_cap(cap))) != MF_OK) return MF_SKM_NOMEM;
+            if (bufA.alloc(ctx, std::max<unsigned long long>(cap + (uint64_t)G * SKM_CH, SH ? 0ull : final_cap(cap))) != MF_OK) return MF_SKM_NOMEM;
             skm_dyn Dy; Dy.gcur = gcur.p; Dy.rend = rstart.p + 1; Dy.overflow = (unsigned int *)&scal[5]; Dy.dump = cap;
             {
                 mf_ktimer t(ctx, "k_skm_scatter");
                 if (fast_lds) {
                     MF_TRY(skm_set_lds(k_skm_scatter<K, true, true>, fast_lds));
-                    k_skm_scatter<K, true, true><<<G, 1024, fast_lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, bufA.p, Dy, dlo, dhi);
+                    k_skm_scatter<K, true, true><<<G, 1024, fast_lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, bufA.p, Dy, l1lo, l1hi);
                 } else {
                     const size_t lds = skm_stage_bytes(nd1);
                     MF_TRY(skm_set_lds(k_skm_scatter<K, true, false>, lds));
-                    k_skm_scatter<K, true, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, bufA.p, Dy, dlo, dhi);
+                    k_skm_scatter<K, true, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, bufA.p, Dy, l1lo, l1hi);
                 }
             }
             MF_DBG(ctx, "k_skm_scatter");
@@ -1320,22 +1335,42 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         MF_TRY(mf_scan<SKM_LINE>(ctx, blockhist.p, blockstart.p, (uint64_t)nd1 * G, (uint64_t *)&scal[1]));
         MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
         MF_HIP(hipStreamSynchronize(st));                       // padded number of records
-        if (bufA.alloc(ctx, final_cap(cap)) != MF_OK) return MF_SKM_NOMEM;
+        if (bufA.alloc(ctx, SH ? cap : final_cap(cap)) != MF_OK) return MF_SKM_NOMEM;
         {
             mf_ktimer t(ctx, "k_skm_scatter");
             if (fast_lds) {
                 MF_TRY(skm_set_lds(k_skm_scatter<K, false, true>, fast_lds));
-                k_skm_scatter<K, false, true><<<G, 1024, fast_lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p, skm_dyn(), dlo, dhi);
+                k_skm_scatter<K, false, true><<<G, 1024, fast_lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p, skm_dyn(), l1lo, l1hi);
             } else {
                 const size_t lds = skm_stage_bytes(nd1);
                 MF_TRY(skm_set_lds(k_skm_scatter<K, false, false>, lds));
-                k_skm_scatter<K, false, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p, skm_dyn(), dlo, dhi);
+                k_skm_scatter<K, false, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, blockstart.p, G, bufA.p, skm_dyn(), l1lo, l1hi);
             }
         }
         MF_DBG(ctx, "k_skm_scatter");
         k_skm_dir<<<(nd1 + 255) / 256, 256, 0, st>>>(blockstart.p, blockocc.p, G, nd1, pstart.p, plen.p, pocc.p);
     }
 
+    uint64_t rebase = 0;
+    if (SH) {
+        if (!SH->ready) {
+            // the first slice has made level 1 for all of them
+            SH->buf.swap(bufA); SH->pstart.swap(pstart); SH->plen.swap(plen); SH->pocc.swap(pocc);
+            SH->cap = cap;
+            SH->h_pstart.resize(nd1);
+            MF_HIP(hipMemcpyAsync(SH->h_pstart.data(), SH->pstart.p, (size_t)nd1 * 8, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            SH->ready = true;
+        }
+        // this slice's view: the shared buffer, its own copy of the directory (the levels swap it away), and as many records
+        // as its digit regions span
+        bufA.borrow(ctx, SH->buf.p, SH->buf.n);
+        MF_TRY(pstart.alloc(ctx, np)); MF_TRY(plen.alloc(ctx, np)); MF_TRY(pocc.alloc(ctx, np));
+        MF_HIP(hipMemcpyAsync(pstart.p, SH->pstart.p, (size_t)nd1 * 8, hipMemcpyDeviceToDevice, st));
+        MF_HIP(hipMemcpyAsync(plen.p, SH->plen.p, (size_t)nd1 * 4, hipMemcpyDeviceToDevice, st));
+        rebase = SH->h_pstart[dlo];
+        cap = (dhi < (uint32_t)nd1 ? SH->h_pstart[dhi] : SH->cap) - rebase;
+    }
     MF_HIP(hipMemsetAsync(&scal[6], 0, 8, st));           // [6] records without padding ([7] distinct k-mers before the cut: whole run)
     const unsigned long long cap_l1 = cap, cap_last = final_cap(cap);
     if (dlo != 0 || dhi != (uint32_t)nd1) {
@@ -1345,7 +1380,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         MF_HIP(hipMemcpyAsync(ps.p, pstart.p + dlo, (size_t)np * 8, hipMemcpyDeviceToDevice, st));
         MF_HIP(hipMemcpyAsync(pl.p, plen.p + dlo, (size_t)np * 4, hipMemcpyDeviceToDevice, st));
         MF_HIP(hipMemcpyAsync(po.p, pocc.p + dlo, (size_t)np * 4, hipMemcpyDeviceToDevice, st));
-        std::swap(pstart.p, ps.p); std::swap(pstart.n, ps.n); std::swap(plen.p, pl.p); std::swap(plen.n, pl.n); std::swap(pocc.p, po.p); std::swap(pocc.n, po.n);
+        pstart.swap(ps); plen.swap(pl); pocc.swap(po);
     }
     int used = 0;
     mf_buf<skm_rec> spare;                                // the buffer a level has read from: the next level writes into it
@@ -1356,7 +1391,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         if (np2 > 0xFFFFFFF0ull) return mf_set_error("too many partitions");
         const bool last = li + 1 == lv.size();
         mf_buf<skm_rec> bufB;
-        if (spare.p && spare.n >= cap2) { std::swap(bufB.p, spare.p); std::swap(bufB.n, spare.n); std::swap(bufB.ctx, spare.ctx); }
+        if (spare.p && spare.n >= cap2) bufB.swap(spare);
         else if (bufB.alloc(ctx, std::max<unsigned long long>(cap2, cap_last)) != MF_OK) {
             if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: no room for %.1f GB of level-%zu records (arena %.1f GB): %s\n", cap2 * 16 / 1e9, li + 1, ctx->arena_bytes / 1e9, mf_last_error());
             return MF_SKM_NOMEM;
@@ -1370,14 +1405,13 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             MF_TRY(skm_set_lds(k_skm_split, lds));
             mf_ktimer t(ctx, "k_skm_split");
             k_skm_split<<<grid, 1024, lds, st>>>(bufA.p, pstart.p, plen.p, np, SKM_DIGIT_BITS - used - bits, bits, bufB.p, ostart.p, olen.p, oocc.p,
-                                                 li == 1 ? &scal[6] : nullptr);
+                                                 li == 1 ? &scal[6] : nullptr, li == 1 ? rebase : 0);
         }
         MF_DBG(ctx, "k_skm_split");
-        std::swap(bufA.p, bufB.p); std::swap(bufA.n, bufB.n); std::swap(bufA.ctx, bufB.ctx);
-        if (!last) { spare.reset(); std::swap(spare.p, bufB.p); std::swap(spare.n, bufB.n); std::swap(spare.ctx, bufB.ctx); }
-        std::swap(pstart.p, ostart.p); std::swap(pstart.n, ostart.n);
-        std::swap(plen.p, olen.p); std::swap(plen.n, olen.n);
-        if (last) { std::swap(pocc.p, oocc.p); std::swap(pocc.n, oocc.n); }
+        bufA.swap(bufB);
+        if (!last && bufB.owned) { spare.reset(); spare.swap(bufB); }        // (a borrowed level-1 buffer is the other slices' input too)
+        pstart.swap(ostart); plen.swap(olen);
+        if (last) pocc.swap(oocc);
         cap = cap2; np = (uint32_t)np2; used += bits;
     }
 
@@ -1474,14 +1508,13 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             uint64_t want = dused + d_b + (uint64_t)std::min<double>((double)rest_cap, (double)rest_cap * ratio * 1.12 + 4096.0);
             if (want < dused + d_b) want = dused + d_b;
             mf_buf<uint64_t> nk; mf_buf<uint16_t> nc;
-            MF_TRY(nk.alloc(ctx, want)); MF_TRY(nc.alloc(ctx, want));
+            if (nk.alloc(ctx, want) != MF_OK || nc.alloc(ctx, want) != MF_OK) return MF_SKM_NOMEM;
             if (dused) {
                 MF_HIP(hipMemcpyAsync(nk.p, dk.p, dused * 8, hipMemcpyDeviceToDevice, st));
                 MF_HIP(hipMemcpyAsync(nc.p, dc.p, dused * 2, hipMemcpyDeviceToDevice, st));
                 MF_HIP(hipStreamSynchronize(st));
             }
-            std::swap(dk.p, nk.p); std::swap(dk.n, nk.n); std::swap(dk.ctx, nk.ctx);
-            std::swap(dc.p, nc.p); std::swap(dc.n, nc.n); std::swap(dc.ctx, nc.ctx);
+            dk.swap(nk); dc.swap(nc);
             dcap = want;
         }
         {
@@ -1525,11 +1558,17 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     // Reads, table and index have to fit beside them.  Option skm_slices forces a number (tests); arena_cap_gb stands in for
     // a smaller device.
     uint32_t S = 1;
+    // shared: the slices share ONE level 1 over all digits (skm_shared) instead of scanning the reads once each.  It needs
+    // the whole level-1 buffer + the slice-sized buffers of the following levels beside the growing table, which is tried
+    // when what is free right now says so (option skm_shared: 0 never, 1 auto, 2 whenever there are slices); if it then
+    // does not fit after all, the level-1 buffer is kept for a second try with twice the slices before the run goes back
+    // to slices that scan for themselves.
+    bool shared = false;
     if (lv.size() >= 2) {
+        size_t fr = 0, tot = 0;
+        MF_HIP(hipMemGetInfo(&fr, &tot));
         if (ctx->opt_skm_slices > 0) S = (uint32_t)ctx->opt_skm_slices;
         else {
-            size_t fr = 0, tot = 0;
-            MF_HIP(hipMemGetInfo(&fr, &tot));
             double budget = (ctx->opt_arena_cap_gb > 0 ? (double)ctx->opt_arena_cap_gb * 1e9 : (double)tot * 0.92) - (double)n_bases * 1.15 - 8e9;
             const double table = (double)n_occ * 0.14 * 26.0;       // (distinct k-mers that survive ~ a seventh of the occurrences) x (entry + index)
             budget -= std::min(table, budget * 0.5);
@@ -1537,13 +1576,36 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             while (S < 64 && recs / S > budget) S *= 2;
         }
         while (S > 1 && (uint32_t)nd1 / S < 4) S /= 2;
+        if (S > 1 && ctx->opt_skm_shared == 2) shared = true;
+        else if (S > 1 && ctx->opt_skm_shared == 1 && ctx->opt_arena_cap_gb <= 0) {
+            // free now (the reads are already resident) - the table (the k-mers that survive the cut; it is sized from the first
+            // batch's ratio, so it rarely grows twice) - room for a batch of temporary lists (they adapt: more batches)
+            const double avail = ((double)fr + (double)mf_arena_idle(ctx)) * 0.96 - (double)n_occ * (kthr >= 1 ? 0.04 : 0.10) * 10.0 * 1.3 - (double)tot * 0.05;
+            // records: a minimizer run is (K - M + 2) / 2 k-mers long where reads and the record format do not cut it shorter
+            const double run = std::min<double>((K - MF_SKM_M + 2) / 2.0, (double)skm_word<K>::RMAX) * 0.78;
+            const double full = (double)n_occ / run * 16.0 * 1.10;
+            const double nb = lv.size() >= 3 ? 2.0 : 1.0;
+            auto need = [&](uint32_t s2) { return full * (1.0 + nb * 1.15 / s2); };
+            uint32_t S2 = ctx->opt_skm_slices > 0 ? S : 2;                   // (a forced number of slices stays)
+            // (beyond 16 slices a split launch has too few partitions to fill the device: then the slices scan for themselves)
+            while (ctx->opt_skm_slices <= 0 && S2 < 16 && need(S2) > avail) S2 *= 2;
+            while (S2 > 1 && (uint32_t)nd1 / S2 < 4) S2 /= 2;
+            if (S2 > 1 && need(S2) <= avail) { shared = true; S = S2; }
+            if (ctx->opt_verbose)
+                fprintf(stderr, "[mf] skm: free %.1f GB + idle %.1f GB -> %.1f GB for records; one level 1 = %.1f GB + %.1f GB per slice at %u slices: %s\n", fr / 1e9,
+                        mf_arena_idle(ctx) / 1e9, avail / 1e9, full / 1e9, (need(S2) - full) / 1e9, S2, shared ? "shared" : "every slice scans");
+        }
     }
     // a shard of the table only (mf_count_device_shard): the owner's digits, sliced like a whole run
     const uint32_t W = (uint32_t)std::max(ctx->own_world, 1);
     if (W > 1 && (uint32_t)nd1 < W) return mf_set_error("count (shard): %d level-1 digits for %u ranks", nd1, W);
     const uint32_t own_lo = (uint32_t)((uint64_t)nd1 * (uint32_t)ctx->own_rank / W), own_hi = (uint32_t)((uint64_t)nd1 * ((uint32_t)ctx->own_rank + 1) / W);
     while (S > 1 && (own_hi - own_lo) / S < 1) S /= 2;
-    for (;; S *= 2) {
+    if (S == 1) shared = false;
+    skm_shared SH; SH.lo = own_lo; SH.hi = own_hi;
+    const uint32_t S_own = S;
+    int shared_tries = 0;
+    for (;;) {
         skm_acc A;
         A.np_total = (uint32_t)(1ull << (total_bits + 1));      // partitions of the table: two per counting partition
         MF_TRY(A.doff.alloc(ctx, (size_t)A.np_total + 1));
@@ -1553,7 +1615,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
         int rc = MF_OK;
         for (uint32_t sl = 0; sl < S && rc == MF_OK; sl++)
             rc = skm_slice<K>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, kthr, own_lo + (uint32_t)((uint64_t)(own_hi - own_lo) * sl / S),
-                              own_lo + (uint32_t)((uint64_t)(own_hi - own_lo) * (sl + 1) / S), sl, S, A);
+                              own_lo + (uint32_t)((uint64_t)(own_hi - own_lo) * (sl + 1) / S), sl, S, A, shared ? &SH : nullptr);
         if (rc == MF_OK && W > 1) {
             // the other ranks' partitions are empty here: offsets 0 before the owner's range, the table's size after it
             const uint32_t pb0 = (uint32_t)(((uint64_t)own_lo * A.np_total) >> bits1), pb1 = (uint32_t)(((uint64_t)own_hi * A.np_total) >> bits1);
@@ -1565,8 +1627,20 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             if (!A.dused) MF_HIP(hipMemsetAsync(A.doff.p, 0, ((size_t)A.np_total + 1) * 8, st));
         }
         if (rc == MF_SKM_NOMEM) {
-            if (lv.size() >= 2 && S < 64 && (own_hi - own_lo) / (2 * S) >= 1 && (W > 1 || (uint32_t)nd1 / (2 * S) >= 4)) {
+            const bool can_double = lv.size() >= 2 && S < 64 && (own_hi - own_lo) / (2 * S) >= 1 && (W > 1 || (uint32_t)nd1 / (2 * S) >= 4);
+            if (shared && SH.ready && can_double && shared_tries++ < 2) {
+                if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: %u slice(s) behind a shared level 1 do not fit, trying %u\n", S, 2 * S);
+                S *= 2;
+                continue;
+            }
+            if (shared) {
+                if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: a shared level 1 does not fit, every slice scans for itself\n");
+                shared = false; SH.clear(); S = S_own;
+                continue;
+            }
+            if (can_double) {
                 if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: %u slice(s) do not fit, trying %u\n", S, 2 * S);
+                S *= 2;
                 continue;
             }
             return MF_SKM_FALLBACK;
@@ -1581,9 +1655,12 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             for (int i = 0; i < 7; i++) fprintf(stderr, "[mf] k_skm_count wave cycles: %-14s %5.1f %%\n", nm[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
         }
         const uint64_t n_dist = A.dused;
+        SH.clear();
+        // (the record buffers stay in the arena for the next sample: hipMalloc costs 35 ms per GiB, 5 s for a 150 GiB level 1;
+        // a host that needs the memory asks with mf_ctx_trim_bytes)
         if (ctx->opt_verbose)
-            fprintf(stderr, "[mf] count(skm): n_occ=%llu records=%llu slices=%u levels=%zu bits=%d distinct=%llu\n", (unsigned long long)n_occ,
-                    A.n_records, S, lv.size(), total_bits, (unsigned long long)n_dist);
+            fprintf(stderr, "[mf] count(skm): n_occ=%llu records=%llu slices=%u%s levels=%zu bits=%d distinct=%llu\n", (unsigned long long)n_occ,
+                    A.n_records, S, shared ? " (one level 1)" : "", lv.size(), total_bits, (unsigned long long)n_dist);
         const size_t kb = A.dk.bytes(), cb = A.dc.bytes();       // (capacity: may be a little larger than n_dist)
         MF_TRY(mf_table_adopt(ctx, K, n_dist, n_occ, A.dk.take(), kb, A.dc.take(), cb, out));
         {

@@ -28,6 +28,7 @@ _SIGS = {
     "mf_ctx_set_option": (i32, [vp, cp, i64]),
     "mf_ctx_synchronize": (i32, [vp]),
     "mf_ctx_trim": (i32, [vp]),
+    "mf_ctx_trim_bytes": (i32, [vp, u64, C.POINTER(C.c_uint64)]),
     "mf_ctx_kernel_time": (i64, [vp, cp, C.POINTER(C.c_double)]),
     "mf_ctx_kernel_report": (i32, [vp, cp, u64]),
     "mf_ctx_reset_timers": (i32, [vp]),
@@ -169,8 +170,15 @@ class Context:
     def synchronize(self):
         _check(lib().mf_ctx_synchronize(self.h))
 
-    def trim(self):
-        _check(lib().mf_ctx_trim(self.h))
+    def trim(self, want_bytes=None):
+        """give idle workspace back to the driver: all of it, or (want_bytes) the smallest idle regions until that much is free
+        again -- returns the bytes given back in that case"""
+        if want_bytes is None:
+            _check(lib().mf_ctx_trim(self.h))
+            return None
+        got = C.c_uint64(0)
+        _check(lib().mf_ctx_trim_bytes(self.h, int(want_bytes), C.byref(got)))
+        return int(got.value)
 
     def reset_timers(self):
         _check(lib().mf_ctx_reset_timers(self.h))

@@ -414,6 +414,22 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
     return comps
 
 
+def _with_room(ctx, fn):
+    """fn() allocates torch tensors beside the library's workspace arena.  When the device is full of idle arena regions
+    (samples of hundreds of millions of reads leave 100 GB record buffers cached), hand some back and try again: small
+    regions first, because the library pays 35 ms per GiB for a region it has to allocate again."""
+    oom = getattr(torch, "OutOfMemoryError", RuntimeError)
+    for want in (2 << 30, 16 << 30, None):
+        try:
+            return fn()
+        except oom as e:
+            if "out of memory" not in str(e).lower():
+                raise
+            ctx.synchronize()
+            ctx.trim(want)
+    return fn()
+
+
 def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda", timings=None):
     """This rank's samples (KmersCounterForManyFilesMain.java:80-108 loops over all libraries: with more samples than GPUs a
     rank takes several, one after the other), joined with the other ranks' for the cutter and the matrix.
@@ -459,8 +475,8 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
     if len(views) == 1:
         sb, so = parts_b[0], device_tensor(views[0]["offsets"], (views[0]["n"] + 1) * 8, device).view(torch.int64)
     else:
-        sb = torch.cat(parts_b) if parts_b else torch.zeros(0, dtype=torch.uint8, device=device)
-        so = torch.cat(parts_o + [torch.tensor([nb], dtype=torch.int64, device=device)])
+        sb = _with_room(ctx, lambda: torch.cat(parts_b) if parts_b else torch.zeros(0, dtype=torch.uint8, device=device))
+        so = _with_room(ctx, lambda: torch.cat(parts_o + [torch.tensor([nb], dtype=torch.int64, device=device)]))
     rank, world = _world()
     sharded = (world > 1 or _force()) and k >= 20 and world & (world - 1) == 0 and world <= 64 and not os.environ.get("MF_REPLICATED_CUTTER")
     if sharded:

@@ -23,7 +23,7 @@ def _check(ctx, oracle, bases, off, k, min_len=0, thr=-1):
 
 
 def _reset(ctx):
-    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0), ("skm_dyn", 1), ("skm_slices", 0), ("arena_cap_gb", 0)):
+    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0), ("skm_dyn", 1), ("skm_slices", 0), ("skm_shared", 1), ("arena_cap_gb", 0)):
         ctx.set_option(name, v)
 
 
@@ -220,11 +220,14 @@ def test_skm_lookup_filter_two_levels(gpu_ctx, oracle):
         _reset(gpu_ctx)
 
 
+@pytest.mark.parametrize("shared", [2, 0])
 @pytest.mark.parametrize("slices,dyn", [(2, 1), (4, 2), (8, 0)])
-def test_skm_digit_range_slices(gpu_ctx, oracle, slices, dyn):
-    """a run cut into digit-range slices (what a sample with more records than HBM takes: BASELINE config 5): the reads are
-    scanned once per slice, every slice counts its share of the level-1 digits; same table, same order, same tallies"""
+def test_skm_digit_range_slices(gpu_ctx, oracle, slices, dyn, shared):
+    """a run cut into digit-range slices (what a sample with more records than HBM takes: BASELINE config 5): every slice
+    counts its share of the level-1 digits, behind one level 1 over all digits (shared = 2) or scanning the reads for its own
+    digits (0: what is left when the whole level-1 buffer does not fit); same table, same order, same tallies"""
     _reset(gpu_ctx)
+    gpu_ctx.set_option("skm_shared", shared)
     rng = np.random.default_rng(79)
     b, o = genome_reads(rng, 300_000, 60_000, 150, err=0.004)
     try:
@@ -260,6 +263,11 @@ def test_skm_three_levels(gpu_ctx, oracle):
             assert t.records()[1] == 16
             t2 = _check(gpu_ctx, oracle, b, o, 21)             # again on the same context: the arena's idle buffers are re-used
             assert t2.records()[1] == 16
+        for shared, slices in ((2, 4), (0, 2), (1, 8)):        # ... in slices: behind one level 1, scanning per slice, as it fits
+            gpu_ctx.set_option("skm_slices", slices)
+            gpu_ctx.set_option("skm_shared", shared)
+            assert _check(gpu_ctx, oracle, b, o, 31).records()[0] == t.records()[0]
+            _check(gpu_ctx, oracle, b, o, 21)
     finally:
         _reset(gpu_ctx)
 
@@ -333,21 +341,55 @@ def test_long_sequences(gpu_ctx, oracle):
         _reset(gpu_ctx)
 
 
-@pytest.mark.parametrize("world", [2, 8])
-def test_shard_tables_partition_the_table(gpu_ctx, oracle, world):
-    """mf_count_device_shard: the ranks' shards are disjoint and together the oracle's table, counts included"""
+@pytest.mark.parametrize("world,slices,shared", [(2, 0, 1), (8, 0, 1), (2, 4, 2), (4, 2, 0)])
+def test_shard_tables_partition_the_table(gpu_ctx, oracle, world, slices, shared):
+    """mf_count_device_shard: the ranks' shards are disjoint and together the oracle's table, counts included; also when a
+    rank counts its digits in slices (behind one level 1 over its digits / every slice scanning the reads)"""
+    _reset(gpu_ctx)
     rng = np.random.default_rng(77)
     bases, offsets = genome_reads(rng, 30000, 4000, 150, err=0.01)
     db, do = to_device(bases, offsets)
     want_k, want_c = oracle.Table().count_buffer(bases, offsets, 31).export()
     keys, cnts = [], []
-    for r in range(world):
-        t = gpu_ctx.count_device_shard(db.data_ptr(), do.data_ptr(), len(offsets) - 1, len(bases), 31, 0, r, world)
-        kk, cc = t.export()
-        assert len(kk) > 0
-        keys.append(kk); cnts.append(cc)
-    allk = np.concatenate(keys); order = np.argsort(allk, kind="stable")
-    assert len(np.unique(allk)) == len(allk)
-    assert np.array_equal(allk[order], want_k) and np.array_equal(np.concatenate(cnts)[order].astype(np.int32), want_c)
-    with pytest.raises(Exception):
-        gpu_ctx.count_device_shard(db.data_ptr(), do.data_ptr(), len(offsets) - 1, len(bases), 31, 0, 0, 3)
+    try:
+        if slices:
+            gpu_ctx.set_option("part_target", 64); gpu_ctx.set_option("skm_slices", slices); gpu_ctx.set_option("skm_shared", shared)
+        for r in range(world):
+            t = gpu_ctx.count_device_shard(db.data_ptr(), do.data_ptr(), len(offsets) - 1, len(bases), 31, 0, r, world)
+            kk, cc = t.export()
+            assert len(kk) > 0
+            keys.append(kk); cnts.append(cc)
+        allk = np.concatenate(keys); order = np.argsort(allk, kind="stable")
+        assert len(np.unique(allk)) == len(allk)
+        assert np.array_equal(allk[order], want_k) and np.array_equal(np.concatenate(cnts)[order].astype(np.int32), want_c)
+        with pytest.raises(Exception):
+            gpu_ctx.count_device_shard(db.data_ptr(), do.data_ptr(), len(offsets) - 1, len(bases), 31, 0, 0, 3)
+    finally:
+        _reset(gpu_ctx)
+
+
+def test_trim_bytes_gives_back_the_smallest_idle_regions(gpu_ctx, oracle):
+    """mf_ctx_trim_bytes: a host short of memory gets idle workspace back without the arena dropping everything; counting
+    afterwards still works (the regions are allocated again)"""
+    import torch
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(5)
+    b, o = genome_reads(rng, 100_000, 20_000, 150, err=0.004)
+    _check(gpu_ctx, oracle, b, o, 31)
+    gpu_ctx.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    got = gpu_ctx.trim(1)                                   # one region is enough
+    assert got >= 1
+    assert torch.cuda.mem_get_info()[0] >= free0 + got - (64 << 20)
+    got_all = gpu_ctx.trim(1 << 60)                         # more than there is: everything idle, no error
+    assert got_all >= 0 and gpu_ctx.trim(1 << 20) == 0
+    _check(gpu_ctx, oracle, b, o, 31)
+    # the pipeline's retry: an allocation that fails with the device full of idle regions succeeds after a partial trim
+    from metafast_amd import pipeline as P
+    calls = []
+    def alloc():
+        calls.append(1)
+        if len(calls) == 1:
+            raise torch.OutOfMemoryError("HIP out of memory (injected)")
+        return torch.zeros(16, device="cuda")
+    assert P._with_room(gpu_ctx, alloc).numel() == 16 and len(calls) == 2
