@@ -66,6 +66,7 @@ struct mf_ctx {
     int64_t opt_sr_piece = 8 << 20, opt_sr_slack = 1 << 20;
     void *pin_pool = nullptr; size_t pin_pool_bytes = 0;           // pinned staging chunks of the streaming reader (lazy, kept)
     int64_t opt_skm_slices = 0;    // digit-range slices of a counting run (0 = as many as the HBM budget asks for)
+    int64_t opt_skm_dedupe = 1;    // k_skm_count: identical records of a unit are counted once, with their multiplicity (0 = every record for itself)
     int64_t opt_skm_shared = 1;    // slices behind one level 1 over all digits: 0 never, 1 when it fits, 2 whenever a run is sliced
     int64_t opt_arena_cap_gb = 0;  // pretend the device has this much memory when the slices are chosen (0 = what it has)
     int64_t opt_skm_batches = 0;   // partitions are counted + gathered in this many batches (0 = auto); tests force small values

@@ -671,10 +671,11 @@ __device__ __forceinline__ uint32_t skm_pass_of(uint64_t key) {
                                  // = three workgroups per CU instead of two, but an 80-VGPR budget: 54 ms against 45.)
 #define C2_FILL 3400             // claims beyond which a partition is counted again in several passes
 #define C2_QN 128                // queue entries per wave (keys): drained at 64, one push (<= 64 keys) between checks
-#define C2_LH 128                // bins of the workgroup's dropped-count histogram (a cut with thr >= C2_LH is made after the kernel)
-#define C2_ITEMS 896             // item entries per wave: 64 records x 10 items + two steps of padding (the read-ahead of the last step runs past them, unused) + the dummy area of the item stores
+#define C2_LH 64                 // bins of the workgroup's dropped-count histogram (a cut with thr >= C2_LH is made after the kernel)
+#define C2_ITEMS 848             // item entries per wave: 64 records x 10 items + two steps of padding (the read-ahead of the last step runs past them, unused) + the dummy area of the item stores
 #define C2_W 2                   // k-mers per item
-static constexpr size_t C2_LDS = (size_t)C2_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8) + 2 * C2_LH * 4 + 32;
+#define C2_DD 4                  // records per thread of a unit whose identical records are counted once (k_skm_count): units of up to C2_DD * SKM_CT records
+static constexpr size_t C2_LDS = (size_t)C2_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8 + C2_QN * 2) + 2 * C2_LH * 4 + 32;
 static_assert(C2_LDS <= 80 * 1024, "two workgroups per CU");
 
 __device__ __forceinline__ uint32_t c2_swap_pairs(uint32_t x) {                 // exchanges the two bits of every base
@@ -690,7 +691,7 @@ __device__ __forceinline__ uint32_t c2_slot(uint32_t hi, uint32_t lo) {
     return (t >> 11) & (uint32_t)(C2_SLOTS - 1);
 }
 struct c2_wave {                 // LDS byte addresses of this wave's private areas + the table
-    uint32_t tk0, tc0, rb0, items0, qk0;
+    uint32_t tk0, tc0, rb0, items0, qk0, qw0;
 };
 // ---- lane masks straight from the compare (a C++ bool that meets __ballot costs a v_cndmask + v_cmp round trip per use)
 __device__ __forceinline__ unsigned long long c2_eq_u64(uint64_t a, uint64_t b) {
@@ -754,10 +755,9 @@ __device__ __forceinline__ void c2_drain(const c2_wave &L, uint32_t &qn, uint32_
     const uint32_t c = qn < 64u ? qn : 64u;
     qn -= c;
     unsigned long long pend = c2_lt_u32(lane, c);
-    uint64_t key;
-    asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(key) : "v"(L.qk0 + 8u * (qn + lane)) : "memory");   // (idle lanes: an in-range entry)
+    uint64_t key; uint32_t one;                                                  // (one: the weight of the key's record)
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_u16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(key), "=&v"(one) : "v"(L.qk0 + 8u * (qn + lane)), "v"(L.qw0 + 2u * (qn + lane)) : "memory");   // (idle lanes: an in-range entry)
     uint32_t s = (c2_slot((uint32_t)(key >> 32), (uint32_t)key) + 1u) & mask;
-    const uint32_t one = 1u;
     for (uint32_t probes = 0; pend != 0ull; probes += 4) {
         if (probes >= 256u && ((probes & 255u) == 0u)) {
             if (probes > (uint32_t)C2_SLOTS) { if (lane == 0) *part_over = 1u; break; }
@@ -866,8 +866,9 @@ __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t 
         coll[u] = live[u] & ~ok[u];
         aa[u] = L.tc0 + 4u * s[u];
     }
-    // ---- count updates of this step (nothing to wait for)
-    const uint32_t one = 1u;
+    // ---- count updates of this step (nothing to wait for): + the weight of the item's record (the low half of the parked
+    // record's last word: the number of identical records it stands for)
+    const uint32_t one = W.w & 0xFFFFu;
     asm volatile("s_mov_b64 %0, exec\n\t"
                  "s_mov_b64 exec, %1\n\tds_add_u32 %3, %5\n\t"
                  "s_mov_b64 exec, %2\n\tds_add_u32 %4, %5\n\t"
@@ -881,6 +882,7 @@ __device__ __forceinline__ void c2_step(const c2_wave &L, uint32_t i0, uint32_t 
         if (coll[u] != 0ull) {
             const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(coll[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)coll[u], qn));
             c2_push64(coll[u], L.qk0 + 8u * at, key[u]);
+            c2_push16(coll[u], L.qw0 + 2u * at, one);
             qn += (uint32_t)__popcll(coll[u]);
             while (qn >= 64u) c2_drain(L, qn, won_acc, part_over);       // (then qn < 64: + one push <= C2_QN)
         }
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                                                            unsigned int *__restrict__ overflow, uint32_t p0, uint64_t tbase, int thr,
                                                            unsigned long long *__restrict__ n_all,
                                                            unsigned int *__restrict__ n_redo, unsigned long long *__restrict__ drop_hist,
-                                                           unsigned long long *__restrict__ prof_out, uint64_t tcap) {
+                                                           unsigned long long *__restrict__ prof_out, uint64_t tcap, uint32_t dedupe) {
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = PROF ? clock64() : 0;
     // partitions [p0, np); slice of p in tkeys / tcnt starts at toff[p] - tbase; thr >= 0: entries with count <= thr are
     // dropped and tallied in drop_hist[count] (thr < C2_LH); *n_all += distinct k-mers before the cut.
@@ -914,7 +916,8 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     uint32_t *tc = reinterpret_cast<uint32_t *>(tk + C2_SLOTS);           // [C2_SLOTS]
     uint16_t *items_all = reinterpret_cast<uint16_t *>(tc + C2_SLOTS);    // [waves][C2_ITEMS]
     uint64_t *qk_all = reinterpret_cast<uint64_t *>(items_all + (SKM_CT / 64) * C2_ITEMS);   // [waves][C2_QN]
-    uint32_t *lhist = reinterpret_cast<uint32_t *>(qk_all + (SKM_CT / 64) * C2_QN);          // [C2_LH] dropped counts, committed
+    uint16_t *qw_all = reinterpret_cast<uint16_t *>(qk_all + (SKM_CT / 64) * C2_QN);         // [waves][C2_QN] the queued keys' weights
+    uint32_t *lhist = reinterpret_cast<uint32_t *>(qw_all + (SKM_CT / 64) * C2_QN);          // [C2_LH] dropped counts, committed
     uint32_t *lhist_try = lhist + C2_LH;                                                     // [C2_LH] ... of the running attempt at a partition
     uint32_t (*pflags)[2] = reinterpret_cast<uint32_t (*)[2]>(lhist_try + C2_LH);            // [parity][1] part_over
     uint32_t &out_cursor = lhist_try[C2_LH + 4], &blk_claims = lhist_try[C2_LH + 6];
@@ -923,6 +926,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     L.rb0 = mf_lds_addr(rbuf_all + wave * 64);
     L.items0 = mf_lds_addr(items_all + wave * C2_ITEMS);
     L.qk0 = mf_lds_addr(qk_all + wave * C2_QN);
+    L.qw0 = mf_lds_addr(qw_all + wave * C2_QN);
     uint32_t qn = 0, won_acc = 0;                                               // wave-uniform
     unsigned long long all_acc = 0;                                             // per wave: distinct k-mers of its share of the tables
     uint32_t ones_acc = 0;                                                      // per wave: dropped entries with count 1
@@ -957,90 +961,207 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     uint64_t start = c2_uniform64(dc.start);
     uint32_t len = (uint32_t)__builtin_amdgcn_readfirstlane((int)dc.len);
     uint64_t o = c2_uniform64(dc.toff0) - tbase; uint32_t room = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dc.toff1 - dc.toff0));
-    // the first round of a unit is in registers before the unit starts; every further round is fetched while
-    // the round before it is worked on
-    skm_rec R0 = load_rec(start, mine, len);
+    // ---- identical records are counted once (round 3).  A minimizer partition of deeply sequenced reads holds the same
+    // super-k-mer many times over (the same stretch of a genome read again and again: 100 M reads of the benchmark's community
+    // have 27 % distinct records, holding 27 % of the k-mers).  A unit of up to C2_DD * SKM_CT records therefore goes through
+    // the (empty) k-mer table once as RECORDS: a 64-bit compare-and-swap of (fingerprint, index in the unit) claims a slot;
+    // a record that finds its fingerprint there fetches the claimant (L2: the unit has just been read) and, if the two are
+    // the same bases, adds itself to the slot's weight and drops out.  The claimants take their weights, hand the slots
+    // back, and only they (and the records whose slot was taken by somebody else) are dealt out as items, their weight in the
+    // parked record's last word (c2_step adds it instead of 1).  Two more workgroup barriers per unit; exact, because a
+    // record only drops out after a full comparison with the record that counts for it.
+    auto load4 = [&](uint64_t first, uint32_t n, skm_rec (&R)[C2_DD]) {
+#pragma unroll
+        for (int i = 0; i < C2_DD; i++) R[i] = load_rec(first, (uint32_t)i * (uint32_t)SKM_CT + mine, n);
+    };
+    // the record as the steps want it: shifted right by one bit, bases only; `low` = k-mers << 16 | weight
+    auto park = [&](const skm_rec &c, uint32_t low, uint32_t slot) {
+        const uint32_t x1 = (uint32_t)(c.x >> 32), x0 = (uint32_t)c.x, y1 = (uint32_t)(c.y >> 32), y0 = (uint32_t)c.y & 0xF0000000u;
+        skm_v4 Pk;
+        Pk.x = x1 >> 1; Pk.y = __builtin_amdgcn_alignbit(x1, x0, 1); Pk.z = __builtin_amdgcn_alignbit(x0, y1, 1); Pk.w = __builtin_amdgcn_alignbit(y1, y0, 1) | low;
+        *reinterpret_cast<__attribute__((address_space(3))) skm_v4 *>((uintptr_t)(L.rb0 + 16u * slot)) = Pk;
+    };
+    // one round of a wave: the records parked in its slots (lane = slot, r = the slot's k-mers) are dealt out as items of two
+    // k-mers and inserted; false: nothing to do
+    auto run_round = [&](uint32_t r, uint32_t *part_over, uint32_t P, uint32_t pass) {
+        const uint32_t nch = (r + (uint32_t)(C2_W - 1)) / (uint32_t)C2_W;
+        uint32_t NI;
+        const uint32_t ioff = mf_wave_excl_scan(nch, &NI);
+        if (NI == 0) return;                                                // wave-uniform
+        {   // the record's items: entry c = e0 - c * 0x1000 (two k-mers; see c2_step), lanes without an item c write to
+            // their dummy slot -- no branch per item; a last item of ONE k-mer is written again afterwards
+            static_assert(C2_W == 2 && C2_ITEMS >= 640 + 128 + 64 + 10, "item list layout");
+            const uint32_t e0 = 2u | (lane << 4) | (63u << 10);
+            const uint32_t ia = L.items0 + 2u * ioff, dummy = L.items0 + 2u * (uint32_t)(C2_ITEMS - 74) + 2u * lane;
+#pragma unroll
+            for (int c = 0; c < 10; c++) {
+                const uint32_t addr = (uint32_t)c < nch ? ia : dummy;
+                const uint32_t e = e0 - (uint32_t)c * 0x1000u;
+                asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(addr), "v"(e), "n"(2 * c) : "memory");
+            }
+            if (r & 1u) {
+                const uint32_t e = e0 - (nch - 1u) * 0x1000u - 1u;
+                *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(ia + 2u * (nch - 1u))) = (uint16_t)e;
+            }
+        }
+        // padding after the list: items without k-mers for the idle lanes of the last step (the step after
+        // that is only read ahead, never used)
+        {
+            const uint32_t z = 0u;
+#pragma unroll
+            for (int t = 0; t < 2; t++)
+                *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (NI + 64u * (uint32_t)t + lane))) = (uint16_t)z;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t it, it1; skm_v4 W;
+        // (LDS operations of one wave execute in order: the reads see the stores above without a wait in between)
+        asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(it), "=&v"(it1) : "v"(L.items0 + 2u * lane) : "memory");
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(W) : "v"(L.rb0 | (it & 0x3F0u)) : "memory");
+        C2_TICK(1);                                                         // round set-up (incl. the wait for the records)
+        for (uint32_t i0 = 0; i0 < NI; i0 += 64) c2_step<K>(L, i0, it, W, it1, qn, won_acc, part_over, P, pass);      // wave-uniform
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
+        __builtin_amdgcn_wave_barrier();
+        C2_TICK(2);                                                         // steps (with the drains inside them)
+    };
+    // the records of a unit's first C2_DD rounds are in registers before the unit starts (fetched while the unit before it
+    // is worked on); a longer unit fetches every further round while the round before it is worked on
+    skm_rec R[C2_DD];
+    load4(start, len, R);
+    // (a directory entry lives in VGPRs only while its loads are in flight: once landed it moves to SGPRs)
+    struct sdirent { uint64_t start, o; uint32_t len, room; };
+    auto to_scalar = [&](const dirent &d) -> sdirent {
+        sdirent q; q.start = c2_uniform64(d.start); q.o = c2_uniform64(d.toff0) - tbase;
+        q.len = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.len); q.room = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(d.toff1 - d.toff0));
+        return q;
+    };
     dirent dn = {0, 0, 0, 0};
     if (ui + gridDim.x < nu) dn = load_dir(ui + gridDim.x);
     // (settled before the loop: a load still pending on entry would make the compiler wait at the loop's top -- behind the
     // directory loads it has just issued there -- on every iteration)
-    asm volatile("" :: "v"(R0.x), "v"(R0.y), "v"(dn.start), "v"(dn.toff0), "v"(dn.toff1), "v"(dn.len));
+    asm volatile("" :: "v"(R[0].x), "v"(R[0].y), "v"(R[1].x), "v"(R[1].y), "v"(R[2].x), "v"(R[2].y), "v"(R[3].x), "v"(R[3].y),
+                       "v"(dn.start), "v"(dn.toff0), "v"(dn.toff1), "v"(dn.len));
+    static_assert(C2_DD == 4, "the settle lists name R[0..3]");
+    sdirent sn = to_scalar(dn);                                                 // the next unit
     __syncthreads();
     uint32_t parity = 0;
     for (;;) {
         const uint32_t un = ui + gridDim.x, unn = un + gridDim.x;
         dirent dnn = {0, 0, 0, 0};
         if (unn < nu) dnn = load_dir(unn);
-        skm_rec cur = R0;
-        const uint64_t start_n = c2_uniform64(dn.start);
-        const uint32_t len_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)dn.len);
-        if (un < nu) R0 = load_rec(start_n, mine, len_n);                      // next unit
-        C2_TICK(0);                                                             // unit top: directory, record prefetch
+        const uint64_t start_n = sn.start;
+        const uint32_t len_n = sn.len;
+        sdirent snn = {0, 0, 0, 0};                                             // the unit after the next (from dnn, once it has landed)
+        C2_TICK(0);                                                             // unit top: directory
+        // ---- identical records of the unit: weights wl[i] (0: no record, or counted by another one)
+        const bool fast = dedupe != 0u && len <= (uint32_t)(C2_DD * SKM_CT);
+        uint32_t wl[C2_DD] = {0u, 0u, 0u, 0u};
+        if (fast) {
+            constexpr uint64_t YM = ~(((1ull << SKM_DIGIT_BITS) - 1ull) << 6);  // (the digit bits say where a record went, not what it holds)
+            uint32_t sa[C2_DD], st[C2_DD];                                      // slot address; 1: claimed the slot, 2: found its fingerprint there
+            uint64_t ret[C2_DD];
+#pragma unroll
+            for (int i = 0; i < C2_DD; i++) {
+                const bool have = skm_rec_valid(R[i]) && skm_rec_n(R[i]) != 0u;
+                wl[i] = have ? 1u : 0u; st[i] = 0; sa[i] = L.tk0; ret[i] = 0;
+                if (have) {
+                    const uint64_t ym = R[i].y & YM;
+                    uint32_t h = ((uint32_t)(R[i].x >> 32) * 0x85EBCA6Bu) ^ ((uint32_t)R[i].x * 0xC2B2AE35u) ^ ((uint32_t)(ym >> 32) * 0x27D4EB2Fu) ^ ((uint32_t)ym * 0x165667B1u);
+                    h ^= h >> 15; h *= 0x9E3779B1u; h ^= h >> 13;
+                    sa[i] = L.tk0 + 8u * (h & (uint32_t)(C2_SLOTS - 1));
+                    const uint64_t word = (1ull << 32) | (uint64_t)(((h >> 11) << 11) | ((uint32_t)i * (uint32_t)SKM_CT + mine));
+                    asm volatile("ds_cmpst_rtn_b64 %0, %1, %2, %3" : "=&v"(ret[i]) : "v"(sa[i]), "v"(MF_EMPTY), "v"(word) : "memory");
+                    st[i] = h >> 11;                                            // (the fingerprint, until the answer is in)
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            static_assert(C2_DD * SKM_CT <= 2048, "index in the unit: 11 bits");
+            skm_rec G[C2_DD];
+#pragma unroll
+            for (int i = 0; i < C2_DD; i++) {
+                const uint32_t fp = st[i];
+                st[i] = 0;
+                if (wl[i]) {
+                    if (ret[i] == MF_EMPTY) st[i] = 1;
+                    else if (((uint32_t)ret[i] >> 11) == fp) st[i] = 2;
+                }
+                G[i] = SENT;
+                if (st[i] == 2) G[i] = load_rec(start, (uint32_t)ret[i] & 2047u, len);          // the claimant
+            }
+#pragma unroll
+            for (int i = 0; i < C2_DD; i++) {
+                if (st[i] == 2 && G[i].x == R[i].x && ((G[i].y ^ R[i].y) & YM) == 0ull) {
+                    const uint32_t one = 1u;
+                    asm volatile("ds_add_u32 %0, %1 offset:4" :: "v"(sa[i]), "v"(one) : "memory");
+                    wl[i] = 0;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            c2_barrier();                                                       // ---- every record has claimed, added itself or stays as it is
+#pragma unroll
+            for (int i = 0; i < C2_DD; i++) {
+                if (st[i] == 1) {
+                    uint64_t v;
+                    asm volatile("ds_wrxchg_rtn_b64 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(sa[i]), "v"(MF_EMPTY) : "memory");
+                    wl[i] = (uint32_t)(v >> 32);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            c2_barrier();                                                       // ---- the table is empty again
+        }
+        C2_TICK(6);
         // A unit with more distinct k-mers than the table takes (a heavy minimizer: low-complexity sequence between many
         // different flanks) is counted again in P = 4, 16, 64 passes over its records, pass i inserting the k-mers with
         // skm_pass_of(key) mod P = i; the passes append to the same slices.  More than 64 passes: the global overflow flag,
         // and the caller falls back to the k-mer path.  What a failed attempt tallied is not committed.
         uint32_t P = 1, pass = 0, ones_try = 0, all_try = 0;
+        bool have_cur = true;                                                   // R holds THIS unit's records (not yet the next unit's)
         for (;;) {
         P = (uint32_t)__builtin_amdgcn_readfirstlane((int)P); pass = (uint32_t)__builtin_amdgcn_readfirstlane((int)pass);      // (uniform: say so)
         uint32_t *part_over = &pflags[parity][1];
-        if (P > 1u) cur = load_rec(start, mine, len);
-        for (uint32_t rb = 0; rb < len; rb += (uint32_t)SKM_CT) {
-            if (rb && c2_lds_u32(part_over)) break;                             // (abandoned)
-            // hipcc waits with vmcnt(0) at the first use of a loaded register, i.e. for EVERY load in flight.  This round's
-            // records (loaded a round ago) are "used" here, BEFORE the next round's load goes out: the wait the compiler puts
-            // in front of this statement finds them landed, and nothing further down waits for the prefetch (with the use
-            // after the prefetch every round sat out a full HBM round trip: profiles/r03_count_vmcnt.txt).
-            asm volatile("" :: "v"(cur.x), "v"(cur.y));
-            skm_rec nxt = SENT;
-            if (rb + (uint32_t)SKM_CT < len) nxt = load_rec(start, rb + (uint32_t)SKM_CT + mine, len);      // the round after this one
-            const uint32_t r = skm_rec_valid(cur) ? skm_rec_n(cur) : 0u;
-            const uint32_t nch = (r + (uint32_t)(C2_W - 1)) / (uint32_t)C2_W;
-            uint32_t NI;
-            const uint32_t ioff = mf_wave_excl_scan(nch, &NI);
-            if (NI == 0) { cur = nxt; continue; }                               // wave-uniform
-            {   // park the record shifted right by one bit (bases only)
-                const uint32_t x1 = (uint32_t)(cur.x >> 32), x0 = (uint32_t)cur.x, y1 = (uint32_t)(cur.y >> 32), y0 = (uint32_t)cur.y & 0xF0000000u;
-                skm_v4 Pk;
-                Pk.x = x1 >> 1; Pk.y = __builtin_amdgcn_alignbit(x1, x0, 1); Pk.z = __builtin_amdgcn_alignbit(x0, y1, 1); Pk.w = __builtin_amdgcn_alignbit(y1, y0, 1);
-                *reinterpret_cast<__attribute__((address_space(3))) skm_v4 *>((uintptr_t)(L.rb0 + 16u * lane)) = Pk;
-            }
-            {   // the record's items: entry c = e0 - c * 0x1000 (two k-mers; see c2_step), lanes without an item c write to
-                // their dummy slot -- no branch per item; a last item of ONE k-mer is written again afterwards
-                static_assert(C2_W == 2 && C2_ITEMS >= 640 + 128 + 64 + 10, "item list layout");
-                const uint32_t e0 = 2u | (lane << 4) | (63u << 10);
-                const uint32_t ia = L.items0 + 2u * ioff, dummy = L.items0 + 2u * (uint32_t)(C2_ITEMS - 74) + 2u * lane;
+        const bool fetch_next = pass + 1u == P && un < nu;                      // (the pass that is meant to be the unit's last)
+        // One loop of rounds for both kinds of unit.  A unit whose identical records have been told apart parks its surviving
+        // records 64 to a round (wave by wave: `total` of them in this wave, numbered in the order i, lane); any other unit
+        // parks round after round of its records as they come, each lane its own.
+        uint32_t total = 0;
+        if (fast) {
+            if (!have_cur) { load4(start, len, R); have_cur = true; }          // (the pass before fetched the next unit and then overflowed)
 #pragma unroll
-                for (int c = 0; c < 10; c++) {
-                    const uint32_t addr = (uint32_t)c < nch ? ia : dummy;
-                    const uint32_t e = e0 - (uint32_t)c * 0x1000u;
-                    asm volatile("ds_write_b16 %0, %1 offset:%2" :: "v"(addr), "v"(e), "n"(2 * c) : "memory");
-                }
-                if (r & 1u) {
-                    const uint32_t e = e0 - (nch - 1u) * 0x1000u - 1u;
-                    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(ia + 2u * (nch - 1u))) = (uint16_t)e;
-                }
-            }
-            // padding after the list: items without k-mers for the idle lanes of the last step (the step after
-            // that is only read ahead, never used)
-            {
-                const uint32_t z = 0u;
+            for (int i = 0; i < C2_DD; i++) total += (uint32_t)__popcll(__ballot(wl[i] != 0u));
+            if (total == 0 && fetch_next) { load4(start_n, len_n, R); have_cur = false; }
+        } else if (!have_cur) { R[0] = load_rec(start, mine, len); have_cur = true; }      // (any other unit: R[0] this round, R[1] the next)
+        const uint32_t n_rounds = fast ? (total + 63u) >> 6 : (len + (uint32_t)SKM_CT - 1u) / (uint32_t)SKM_CT;
+        for (uint32_t rr = 0; rr < n_rounds; rr++) {
+            if (rr && c2_lds_u32(part_over)) break;                             // (abandoned)
+            uint32_t r;
+            if (fast) {
+                uint32_t before = 0;
 #pragma unroll
-                for (int t = 0; t < 2; t++)
-                    *reinterpret_cast<__attribute__((address_space(3))) uint16_t *>((uintptr_t)(L.items0 + 2u * (NI + 64u * (uint32_t)t + lane))) = (uint16_t)z;
+                for (int i = 0; i < C2_DD; i++) {
+                    const unsigned long long m = __ballot(wl[i] != 0u);
+                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, before));
+                    before += (uint32_t)__popcll(m);
+                    if (wl[i] != 0u && (pos >> 6) == rr) park(R[i], (skm_rec_n(R[i]) << 16) | wl[i], pos & 63u);
+                }
+                if (rr + 1u == n_rounds && fetch_next) { load4(start_n, len_n, R); have_cur = false; }      // (R has been parked: the next unit's records)
+                __builtin_amdgcn_wave_barrier();
+                uint32_t w3;
+                asm volatile("ds_read_b32 %0, %1 offset:12\n\ts_waitcnt lgkmcnt(0)" : "=v"(w3) : "v"(L.rb0 + 16u * lane) : "memory");
+                r = lane < total - rr * 64u ? (w3 >> 16) & 63u : 0u;
+            } else {
+                // hipcc waits with vmcnt(0) at the first use of a loaded register, i.e. for EVERY load in flight.  This round's
+                // records (loaded a round ago) are "used" here, BEFORE the next round's load goes out: the wait the compiler puts
+                // in front of this statement finds them landed, and nothing further down waits for the prefetch (with the use
+                // after the prefetch every round sat out a full HBM round trip: profiles/r03_count_vmcnt.txt).
+                asm volatile("" :: "v"(R[0].x), "v"(R[0].y));
+                r = skm_rec_valid(R[0]) ? skm_rec_n(R[0]) : 0u;
+                park(R[0], (r << 16) | 1u, lane);
+                if (rr + 1u < n_rounds) R[0] = load_rec(start, (rr + 1u) * (uint32_t)SKM_CT + mine, len);      // the round after this one
+                else if (fetch_next) { load4(start_n, len_n, R); have_cur = false; }                            // ... or the next unit
+                else have_cur = false;
             }
-            __builtin_amdgcn_wave_barrier();
-            uint32_t it, it1; skm_v4 W;
-            // (LDS operations of one wave execute in order: the reads see the stores above without a wait in between)
-            asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %2 offset:128\n\ts_waitcnt lgkmcnt(0)" : "=&v"(it), "=&v"(it1) : "v"(L.items0 + 2u * lane) : "memory");
-            asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(W) : "v"(L.rb0 | (it & 0x3F0u)) : "memory");
-            C2_TICK(1);                                                         // round set-up (incl. the wait for the records)
-            for (uint32_t i0 = 0; i0 < NI; i0 += 64) c2_step<K>(L, i0, it, W, it1, qn, won_acc, part_over, P, pass);      // wave-uniform
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // items / rbuf are rewritten in the next round
-            __builtin_amdgcn_wave_barrier();
-            C2_TICK(2);                                                         // steps (with the drains inside them)
-            cur = nxt;
+            run_round(r, part_over, P, pass);
         }
+        if (!fast) have_cur = false;                                            // (R[0] has moved on, or the pass was abandoned on the way)
         while (qn) c2_drain(L, qn, won_acc, part_over);                        // wave-uniform
         // a crowded table probes slowly: past C2_FILL claims the unit is counted in (more) passes
         if (won_acc) { if (lane == 0) atomicAdd(&blk_claims, won_acc); won_acc = 0; }
@@ -1050,10 +1171,12 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         C2_TICK(4);                                                             // waiting for the other waves
         const bool over = c2_lds_u32(part_over) != 0u || c2_lds_u32(&blk_claims) > (uint32_t)C2_FILL;
         if (threadIdx.x == 0) pflags[parity ^ 1u][1] = 0;                      // for the next pass / unit
-        // the next unit's first round and the directory entries read ahead have been in flight for a whole unit: settle them
+        // the next unit's records and the directory entries read ahead have been in flight for a whole unit: settle them
         // here, while only loads are outstanding -- once the stores below are in flight as well, the counter no longer tells
         // loads from stores and the first use of these registers would wait for the stores' acknowledgements too
-        asm volatile("" :: "v"(R0.x), "v"(R0.y), "v"(dn.start), "v"(dn.toff0), "v"(dn.toff1), "v"(dn.len), "v"(dnn.start), "v"(dnn.toff0), "v"(dnn.toff1), "v"(dnn.len));
+        asm volatile("" :: "v"(R[0].x), "v"(R[0].y), "v"(R[1].x), "v"(R[1].y), "v"(R[2].x), "v"(R[2].y), "v"(R[3].x), "v"(R[3].y),
+                           "v"(dnn.start), "v"(dnn.toff0), "v"(dnn.toff1), "v"(dnn.len));
+        snn = to_scalar(dnn);
         // ---- compaction: every wave sweeps ITS eighth of the table (consecutive slots, lane = slot: conflict-free),
         // 8 chunks of 64 in flight: keys are read and reset with one exchange, the counts of the occupied slots likewise.
         // (Claim lists -- visit only the slots that were won -- cost a list append per key slot in the hot loop and four
@@ -1146,9 +1269,8 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         if (threadIdx.x == 0) { dcount[p0 + ui] = out_cursor; out_cursor = 0; }
         if (un >= nu) break;
         ui = un; start = start_n; len = len_n;
-        o = c2_uniform64(dn.toff0) - tbase;
-        room = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(dn.toff1 - dn.toff0));
-        dn = dnn;
+        o = sn.o; room = sn.room;
+        sn = snn;
     }
     {   // distinct k-mers before the cut: one atomic per wave
         if (lane == 0 && n_all && all_acc) atomicAdd(n_all, all_acc);
@@ -1469,7 +1591,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             MF_HIP(hipMemsetAsync(&scal[8], 0, 8, st));
             mf_ktimer t(ctx, "k_skm_count");
 #define SKM_COUNT_ARGS bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2], p0, (uint64_t)tb[b], kthr, &scal[7], \
-                       (unsigned int *)&scal[8], dhist.p, c2p.p, (uint64_t)tmax
+                       (unsigned int *)&scal[8], dhist.p, c2p.p, (uint64_t)tmax, (uint32_t)(ctx->opt_skm_dedupe != 0)
             if (c2prof) k_skm_count<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
             else k_skm_count<K, false><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
 #undef SKM_COUNT_ARGS
@@ -1692,8 +1814,11 @@ int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const ui
     int rc = MF_SKM_FALLBACK;
     switch (k) {
 #define SKM_CASE(KK) case KK: rc = skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, thr, n_all, out); break;
+#ifndef MF_SKM_ONLY_K31              /* (a quick look at one instantiation's code: hipcc -DMF_SKM_ONLY_K31 -S) */
         SKM_CASE(20) SKM_CASE(21) SKM_CASE(22) SKM_CASE(23) SKM_CASE(24) SKM_CASE(25)
-        SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29) SKM_CASE(30) SKM_CASE(31)
+        SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29) SKM_CASE(30)
+#endif
+        SKM_CASE(31)
 #undef SKM_CASE
         default: return MF_SKM_FALLBACK;
     }
