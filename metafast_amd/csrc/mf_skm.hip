@@ -921,6 +921,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     uint32_t *lhist_try = lhist + C2_LH;                                                     // [C2_LH] ... of the running attempt at a partition
     uint32_t (*pflags)[2] = reinterpret_cast<uint32_t (*)[2]>(lhist_try + C2_LH);            // [parity][1] part_over
     uint32_t &out_cursor = lhist_try[C2_LH + 4], &blk_claims = lhist_try[C2_LH + 6];
+    uint32_t &dd_gone = lhist_try[C2_LH + 5], &dd_all = lhist_try[C2_LH + 7];                // records that dropped out / that were looked at, of the last such unit
     c2_wave L;
     L.tk0 = mf_lds_addr(tk); L.tc0 = mf_lds_addr(tc);
     L.rb0 = mf_lds_addr(rbuf_all + wave * 64);
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     // the table is cleared ONCE; after that every partition leaves it clean (its compaction clears the slots it claimed)
     for (uint32_t i = threadIdx.x; i < (uint32_t)C2_SLOTS; i += (uint32_t)SKM_CT) { tk[i] = MF_EMPTY; tc[i] = 0; }
     for (uint32_t i = threadIdx.x; i < 2u * (uint32_t)C2_LH; i += (uint32_t)SKM_CT) lhist[i] = 0;
-    if (threadIdx.x == 0) { out_cursor = 0; blk_claims = 0; pflags[0][0] = pflags[0][1] = pflags[1][0] = pflags[1][1] = 0; }
+    if (threadIdx.x == 0) { out_cursor = 0; blk_claims = 0; dd_gone = 0; dd_all = 0; pflags[0][0] = pflags[0][1] = pflags[1][0] = pflags[1][1] = 0; }
     const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
     const uint32_t mine = (lane >> 3) * 64u + wave * 8u + (lane & 7u);          // this lane's record within a round of 512
     const uint32_t nu = np - p0;                                                // unit u = partition p0 + u
@@ -950,9 +951,11 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     // Directory entries are fetched TWO units ahead, with VECTOR loads: a scalar load (what hipcc makes of a uniform
     // address) is counted in lgkmcnt, and the next LDS wait would sit out its whole memory latency (and hipcc spilt the
     // scalars to VGPR lanes at once, with a wait after every load).  `vz` is a zero the compiler cannot see through.
-    uint32_t vz; asm("v_mov_b32 %0, 0" : "=v"(vz));
+    // (made anew for every entry: a register that lives across the unit loop is one the allocator may spill, and a reload from
+    // scratch waits with vmcnt(0), i.e. for the compaction's stores to be acknowledged -- 13 % of the wave cycles at the loop's top)
     struct dirent { uint64_t start, toff0, toff1; uint32_t len; };
     auto load_dir = [&](uint32_t u) -> dirent {
+        uint32_t vz; asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
         dirent d; const uint32_t i = p0 + u + vz;
         d.start = pstart[i]; d.len = plen[i]; d.toff0 = toff[i]; d.toff1 = toff[i + 1];
         return d;
@@ -1026,6 +1029,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     // the records of a unit's first C2_DD rounds are in registers before the unit starts (fetched while the unit before it
     // is worked on); a longer unit fetches every further round while the round before it is worked on
     skm_rec R[C2_DD];
+    uint32_t dd_skip = 0;                                                       // wave-uniform: units still to go without looking for identical records
     load4(start, len, R);
     // (a directory entry lives in VGPRs only while its loads are in flight: once landed it moves to SGPRs)
     struct sdirent { uint64_t start, o; uint32_t len, room; };
@@ -1053,7 +1057,10 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         sdirent snn = {0, 0, 0, 0};                                             // the unit after the next (from dnn, once it has landed)
         C2_TICK(0);                                                             // unit top: directory
         // ---- identical records of the unit: weights wl[i] (0: no record, or counted by another one)
-        const bool fast = dedupe != 0u && len <= (uint32_t)(C2_DD * SKM_CT);
+        // (reads without depth have nothing to tell apart: where fewer than a quarter of a unit's records dropped out, the next
+        // 15 units of this workgroup go without the search; dedupe & 4: never skip -- tests)
+        const bool fast = dedupe != 0u && len <= (uint32_t)(C2_DD * SKM_CT) && dd_skip == 0u;
+        if (dd_skip) dd_skip--;
         uint32_t wl[C2_DD] = {0u, 0u, 0u, 0u};
         if (fast) {
             constexpr uint64_t YM = ~(((1ull << SKM_DIGIT_BITS) - 1ull) << 6);  // (the digit bits say where a record went, not what it holds)
@@ -1065,8 +1072,10 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                 wl[i] = have ? 1u : 0u; st[i] = 0; sa[i] = L.tk0; ret[i] = 0;
                 if (have) {
                     const uint64_t ym = R[i].y & YM;
-                    uint32_t h = ((uint32_t)(R[i].x >> 32) * 0x85EBCA6Bu) ^ ((uint32_t)R[i].x * 0xC2B2AE35u) ^ ((uint32_t)(ym >> 32) * 0x27D4EB2Fu) ^ ((uint32_t)ym * 0x165667B1u);
-                    h ^= h >> 15; h *= 0x9E3779B1u; h ^= h >> 13;
+                    // (full-rate instructions and one multiply: what two different records share here only costs them their chance)
+                    uint32_t h = (uint32_t)(R[i].x >> 32) ^ __builtin_amdgcn_alignbit((uint32_t)R[i].x, (uint32_t)R[i].x, 11)
+                                 ^ __builtin_amdgcn_alignbit((uint32_t)(ym >> 32), (uint32_t)(ym >> 32), 21) ^ __builtin_amdgcn_alignbit((uint32_t)ym, (uint32_t)ym, 5);
+                    h ^= h >> 16; h *= 0x9E3779B1u; h ^= h >> 15;
                     sa[i] = L.tk0 + 8u * (h & (uint32_t)(C2_SLOTS - 1));
                     const uint64_t word = (1ull << 32) | (uint64_t)(((h >> 11) << 11) | ((uint32_t)i * (uint32_t)SKM_CT + mine));
                     asm volatile("ds_cmpst_rtn_b64 %0, %1, %2, %3" : "=&v"(ret[i]) : "v"(sa[i]), "v"(MF_EMPTY), "v"(word) : "memory");
@@ -1085,7 +1094,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                     else if (((uint32_t)ret[i] >> 11) == fp) st[i] = 2;
                 }
                 G[i] = SENT;
-                if (st[i] == 2) G[i] = load_rec(start, (uint32_t)ret[i] & 2047u, len);          // the claimant
+                if (st[i] == 2) G[i] = (dedupe & 2u) ? R[i] : load_rec(start, (uint32_t)ret[i] & 2047u, len);          // the claimant (dedupe & 2: timing experiment, not exact)
             }
 #pragma unroll
             for (int i = 0; i < C2_DD; i++) {
@@ -1095,8 +1104,18 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                     wl[i] = 0;
                 }
             }
+            {   // how many dropped out (the next units' decision)
+                uint32_t gone = 0, all = 0;
+#pragma unroll
+                for (int i = 0; i < C2_DD; i++) { gone += (uint32_t)__popcll(__ballot(st[i] == 2 && wl[i] == 0u)); all += (uint32_t)__popcll(__ballot(st[i] != 0u || wl[i] != 0u)); }
+                if (lane == 0) { atomicAdd(&dd_gone, gone); atomicAdd(&dd_all, all); }
+            }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             c2_barrier();                                                       // ---- every record has claimed, added itself or stays as it is
+            {
+                const uint32_t gone = c2_lds_u32(&dd_gone), all = c2_lds_u32(&dd_all);
+                if (gone * 4u < all && !(dedupe & 4u)) dd_skip = 15;
+            }
 #pragma unroll
             for (int i = 0; i < C2_DD; i++) {
                 if (st[i] == 1) {
@@ -1107,8 +1126,9 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             c2_barrier();                                                       // ---- the table is empty again
+            if (threadIdx.x == 0) { dd_gone = 0; dd_all = 0; }                  // (read by everybody before this barrier; added to again a unit later)
         }
-        C2_TICK(6);
+        C2_TICK(7);                                                             // identical records
         // A unit with more distinct k-mers than the table takes (a heavy minimizer: low-complexity sequence between many
         // different flanks) is counted again in P = 4, 16, 64 passes over its records, pass i inserting the k-mers with
         // skm_pass_of(key) mod P = i; the passes append to the same slices.  More than 64 passes: the global overflow flag,
@@ -1127,9 +1147,9 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
             if (!have_cur) { load4(start, len, R); have_cur = true; }          // (the pass before fetched the next unit and then overflowed)
 #pragma unroll
             for (int i = 0; i < C2_DD; i++) total += (uint32_t)__popcll(__ballot(wl[i] != 0u));
-            if (total == 0 && fetch_next) { load4(start_n, len_n, R); have_cur = false; }
         } else if (!have_cur) { R[0] = load_rec(start, mine, len); have_cur = true; }      // (any other unit: R[0] this round, R[1] the next)
         const uint32_t n_rounds = fast ? (total + 63u) >> 6 : (len + (uint32_t)SKM_CT - 1u) / (uint32_t)SKM_CT;
+        if (n_rounds == 0 && fetch_next) { load4(start_n, len_n, R); have_cur = false; }      // (nothing to park: the next unit's records now)
         for (uint32_t rr = 0; rr < n_rounds; rr++) {
             if (rr && c2_lds_u32(part_over)) break;                             // (abandoned)
             uint32_t r;
@@ -1591,7 +1611,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             MF_HIP(hipMemsetAsync(&scal[8], 0, 8, st));
             mf_ktimer t(ctx, "k_skm_count");
 #define SKM_COUNT_ARGS bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2], p0, (uint64_t)tb[b], kthr, &scal[7], \
-                       (unsigned int *)&scal[8], dhist.p, c2p.p, (uint64_t)tmax, (uint32_t)(ctx->opt_skm_dedupe != 0)
+                       (unsigned int *)&scal[8], dhist.p, c2p.p, (uint64_t)tmax, (uint32_t)ctx->opt_skm_dedupe
             if (c2prof) k_skm_count<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
             else k_skm_count<K, false><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
 #undef SKM_COUNT_ARGS
@@ -1772,9 +1792,9 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             unsigned long long h[8];
             MF_HIP(hipMemcpyAsync(h, A.c2p.p, 64, hipMemcpyDeviceToHost, st));
             MF_HIP(hipStreamSynchronize(st));
-            unsigned long long tot = 0; for (int i = 0; i < 7; i++) tot += h[i];
-            static const char *nm[7] = {"partition top", "round set-up", "steps", "last drains", "barrier 1", "compaction", "barrier 2"};
-            for (int i = 0; i < 7; i++) fprintf(stderr, "[mf] k_skm_count wave cycles: %-14s %5.1f %%\n", nm[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
+            unsigned long long tot = 0; for (int i = 0; i < 8; i++) tot += h[i];
+            static const char *nm[8] = {"partition top", "round set-up", "steps", "last drains", "barrier 1", "compaction", "barrier 2", "same records"};
+            for (int i = 0; i < 8; i++) fprintf(stderr, "[mf] k_skm_count wave cycles: %-14s %5.1f %%\n", nm[i], 100.0 * (double)h[i] / (double)(tot ? tot : 1));
         }
         const uint64_t n_dist = A.dused;
         SH.clear();

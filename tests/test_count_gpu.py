@@ -23,7 +23,7 @@ def _check(ctx, oracle, bases, off, k, min_len=0, thr=-1):
 
 
 def _reset(ctx):
-    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0), ("skm_dyn", 1), ("skm_slices", 0), ("skm_shared", 1), ("arena_cap_gb", 0)):
+    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0), ("skm_dyn", 1), ("skm_slices", 0), ("skm_shared", 1), ("skm_dedupe", 1), ("arena_cap_gb", 0)):
         ctx.set_option(name, v)
 
 
@@ -393,3 +393,29 @@ def test_trim_bytes_gives_back_the_smallest_idle_regions(gpu_ctx, oracle):
             raise torch.OutOfMemoryError("HIP out of memory (injected)")
         return torch.zeros(16, device="cuda")
     assert P._with_room(gpu_ctx, alloc).numel() == 16 and len(calls) == 2
+
+
+@pytest.mark.parametrize("dedupe", [5, 1, 0])
+def test_skm_identical_records_counted_once(gpu_ctx, oracle, dedupe):
+    """k_skm_count tells identical records of a unit apart and inserts their k-mers once, with the multiplicity (5: always,
+    1: unless a unit shows no repeats, 0: never): very deep reads (each record ~300 times), reads without repeats, counts
+    that saturate, units of more than 2048 records and units counted in several passes -- the same tables"""
+    _reset(gpu_ctx)
+    rng = np.random.default_rng(404)
+    try:
+        gpu_ctx.set_option("skm_dedupe", dedupe)
+        deep_b, deep_o = genome_reads(rng, 6_000, 120_000, 150, err=0.002)           # 3000-fold
+        flat_b, flat_o = genome_reads(rng, 3_000_000, 20_000, 150, err=0.0)          # 1-fold: nothing repeats
+        for pt in (3072, 256, 16384):                                                 # units of ~1750, ~150 and ~9000 records
+            gpu_ctx.set_option("part_target", pt)
+            for k in (31, 21):
+                _check(gpu_ctx, oracle, deep_b, deep_o, k)
+            _check(gpu_ctx, oracle, flat_b, flat_o, 31)
+        # one read 40 000 times: counts saturate at 32767 (NumUtils.addAndBound), weights beyond 16 bits never form
+        one = genome_reads(rng, 400, 1, 150, err=0.0)[0]
+        b = np.tile(one, 40_000); o = np.arange(40_001, dtype=np.uint64) * 150
+        gpu_ctx.set_option("part_target", 3072)
+        t = _check(gpu_ctx, oracle, b, o, 31)
+        assert t.export()[1].max() == 32767
+    finally:
+        _reset(gpu_ctx)

@@ -61,6 +61,7 @@ while time.time() < t_end:
     ctx.set_option("skm", int(rng.choice([1, 1, 0]))); ctx.set_option("skm_dyn", int(rng.choice([0, 1, 2])))
     ctx.set_option("part_target", int(rng.choice([1, 16, 128, 3072])))
     ctx.set_option("skm_slices", int(rng.choice([0, 0, 2, 4]))); ctx.set_option("skm_shared", int(rng.choice([0, 1, 2])))
+    ctx.set_option("skm_dedupe", int(rng.choice([0, 1, 5, 5])))
     tag = f"it={it} k={k} reads={len(o)-1} bases={len(b)} min_len={min_len} thr={thr} l={l} b1={b1} b2={b2}"
     tb, to = to_device(b, o)
     gt = ctx.count_device(tb.data_ptr(), to.data_ptr(), len(o) - 1, int(o[-1]), k, min_len)
