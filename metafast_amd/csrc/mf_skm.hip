@@ -941,9 +941,14 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     uint32_t ui = blockIdx.x;
     if (ui >= nu) return;
     // (an address select between the record and a sentinel object would turn the load into a flat load from scratch)
+    // (a uniform base and a 32-bit lane offset: the load takes its address from an SGPR pair + one VGPR, and no 64-bit lane
+    // addresses live across the unit loop)
     auto load_rec = [&](uint64_t first, uint32_t j, uint32_t n) -> skm_rec {
         const bool ok = j < n;
-        const uint4 w = reinterpret_cast<const uint4 *>(recs)[ok ? first + j : 0];
+        const uint4 *const base = reinterpret_cast<const uint4 *>(recs) + (n ? first : 0ull);
+        uint32_t jj = ok ? j : 0u;
+        asm volatile("" : "+v"(jj));                       // (the address is made here, not ahead of time and kept -- or spilt -- until here)
+        const uint4 w = base[jj];
         skm_rec v = make_ulonglong2(((uint64_t)w.y << 32) | w.x, ((uint64_t)w.w << 32) | w.z);
         if (!ok) v = SENT;
         return v;
@@ -973,6 +978,19 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     // back, and only they (and the records whose slot was taken by somebody else) are dealt out as items, their weight in the
     // parked record's last word (c2_step adds it instead of 1).  Two more workgroup barriers per unit; exact, because a
     // record only drops out after a full comparison with the record that counts for it.
+    // the same load in two halves: the raw words now, the record (or the sentinel) when they are wanted -- nothing looks at the
+    // loaded registers in between
+    auto load_raw = [&](uint64_t first, uint32_t j, uint32_t n) -> uint4 {
+        const uint4 *const base = reinterpret_cast<const uint4 *>(recs) + (n ? first : 0ull);
+        uint32_t jj = j < n ? j : 0u;
+        asm volatile("" : "+v"(jj));
+        return base[jj];
+    };
+    auto from_raw = [&](const uint4 &w, uint32_t j, uint32_t n) -> skm_rec {
+        skm_rec v = make_ulonglong2(((uint64_t)w.y << 32) | w.x, ((uint64_t)w.w << 32) | w.z);
+        if (!(j < n)) v = SENT;
+        return v;
+    };
     auto load4 = [&](uint64_t first, uint32_t n, skm_rec (&R)[C2_DD]) {
 #pragma unroll
         for (int i = 0; i < C2_DD; i++) R[i] = load_rec(first, (uint32_t)i * (uint32_t)SKM_CT + mine, n);
@@ -1051,7 +1069,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     for (;;) {
         const uint32_t un = ui + gridDim.x, unn = un + gridDim.x;
         dirent dnn = {0, 0, 0, 0};
-        if (unn < nu) dnn = load_dir(unn);
+        bool dnn_asked = false;
         const uint64_t start_n = sn.start;
         const uint32_t len_n = sn.len;
         sdirent snn = {0, 0, 0, 0};                                             // the unit after the next (from dnn, once it has landed)
@@ -1059,7 +1077,8 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         // ---- identical records of the unit: weights wl[i] (0: no record, or counted by another one)
         // (reads without depth have nothing to tell apart: where fewer than a quarter of a unit's records dropped out, the next
         // 15 units of this workgroup go without the search; dedupe & 4: never skip -- tests)
-        const bool fast = dedupe != 0u && len <= (uint32_t)(C2_DD * SKM_CT) && dd_skip == 0u;
+        // A unit of more than C2_DD * SKM_CT records: the search covers its first records, the others follow round by round.
+        const bool fast = dedupe != 0u && dd_skip == 0u;
         if (dd_skip) dd_skip--;
         uint32_t wl[C2_DD] = {0u, 0u, 0u, 0u};
         if (fast) {
@@ -1143,45 +1162,62 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         // records 64 to a round (wave by wave: `total` of them in this wave, numbered in the order i, lane); any other unit
         // parks round after round of its records as they come, each lane its own.
         uint32_t total = 0;
+        constexpr uint32_t DDN = (uint32_t)(C2_DD * SKM_CT);
         if (fast) {
             if (!have_cur) { load4(start, len, R); have_cur = true; }          // (the pass before fetched the next unit and then overflowed)
 #pragma unroll
             for (int i = 0; i < C2_DD; i++) total += (uint32_t)__popcll(__ballot(wl[i] != 0u));
-        } else if (!have_cur) { R[0] = load_rec(start, mine, len); have_cur = true; }      // (any other unit: R[0] this round, R[1] the next)
-        const uint32_t n_rounds = fast ? (total + 63u) >> 6 : (len + (uint32_t)SKM_CT - 1u) / (uint32_t)SKM_CT;
-        if (n_rounds == 0 && fetch_next) { load4(start_n, len_n, R); have_cur = false; }      // (nothing to park: the next unit's records now)
-        for (uint32_t rr = 0; rr < n_rounds; rr++) {
-            if (rr && c2_lds_u32(part_over)) break;                             // (abandoned)
-            uint32_t r;
-            if (fast) {
-                uint32_t before = 0;
+        } else if (!have_cur) { R[0] = load_rec(start, mine, len); have_cur = true; }      // (any other unit: R[0] is the round's record)
+        // rounds of surviving records, then rounds of the records as they come (from record `plain0` on)
+        const uint32_t n_dense = fast ? (total + 63u) >> 6 : 0u;
+        const uint32_t plain0 = fast ? DDN : 0u;
+        const uint32_t n_plain = len > plain0 ? (len - plain0 + (uint32_t)SKM_CT - 1u) / (uint32_t)SKM_CT : 0u;
+        const uint32_t n_rounds = n_dense + n_plain;
+        bool gave_up = false;
+        for (uint32_t rr = 0; rr < n_dense; rr++) {
+            if (rr && c2_lds_u32(part_over)) { gave_up = true; break; }        // (abandoned)
+            uint32_t before = 0;
 #pragma unroll
-                for (int i = 0; i < C2_DD; i++) {
-                    const unsigned long long m = __ballot(wl[i] != 0u);
-                    const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, before));
-                    before += (uint32_t)__popcll(m);
-                    if (wl[i] != 0u && (pos >> 6) == rr) park(R[i], (skm_rec_n(R[i]) << 16) | wl[i], pos & 63u);
-                }
-                if (rr + 1u == n_rounds && fetch_next) { load4(start_n, len_n, R); have_cur = false; }      // (R has been parked: the next unit's records)
-                __builtin_amdgcn_wave_barrier();
-                uint32_t w3;
-                asm volatile("ds_read_b32 %0, %1 offset:12\n\ts_waitcnt lgkmcnt(0)" : "=v"(w3) : "v"(L.rb0 + 16u * lane) : "memory");
-                r = lane < total - rr * 64u ? (w3 >> 16) & 63u : 0u;
-            } else {
-                // hipcc waits with vmcnt(0) at the first use of a loaded register, i.e. for EVERY load in flight.  This round's
-                // records (loaded a round ago) are "used" here, BEFORE the next round's load goes out: the wait the compiler puts
-                // in front of this statement finds them landed, and nothing further down waits for the prefetch (with the use
-                // after the prefetch every round sat out a full HBM round trip: profiles/r03_count_vmcnt.txt).
-                asm volatile("" :: "v"(R[0].x), "v"(R[0].y));
-                r = skm_rec_valid(R[0]) ? skm_rec_n(R[0]) : 0u;
-                park(R[0], (r << 16) | 1u, lane);
-                if (rr + 1u < n_rounds) R[0] = load_rec(start, (rr + 1u) * (uint32_t)SKM_CT + mine, len);      // the round after this one
-                else if (fetch_next) { load4(start_n, len_n, R); have_cur = false; }                            // ... or the next unit
-                else have_cur = false;
+            for (int i = 0; i < C2_DD; i++) {
+                const unsigned long long m = __ballot(wl[i] != 0u);
+                const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, before));
+                before += (uint32_t)__popcll(m);
+                if (wl[i] != 0u && (pos >> 6) == rr) park(R[i], (skm_rec_n(R[i]) << 16) | wl[i], pos & 63u);
             }
+            __builtin_amdgcn_wave_barrier();
+            uint32_t w3;
+            asm volatile("ds_read_b32 %0, %1 offset:12\n\ts_waitcnt lgkmcnt(0)" : "=v"(w3) : "v"(L.rb0 + 16u * lane) : "memory");
+            run_round(lane < total - rr * 64u ? (w3 >> 16) & 63u : 0u, part_over, P, pass);
+        }
+        if (fast && n_plain != 0u && !gave_up) R[0] = load_rec(start, plain0 + mine, len);      // (a long unit's other records; waited for on the spot)
+        for (uint32_t rr = 0; rr < n_plain && !gave_up; rr++) {
+            if ((rr || n_dense) && c2_lds_u32(part_over)) break;                // (abandoned)
+            // hipcc waits with vmcnt(0) at the first use of a loaded register, i.e. for EVERY load in flight.  This round's
+            // records (loaded a round ago) are "used" here, BEFORE the next round's load goes out: the wait the compiler puts
+            // in front of this statement finds them landed, and nothing further down waits for the prefetch (with the use
+            // after the prefetch every round sat out a full HBM round trip: profiles/r03_count_vmcnt.txt).
+            asm volatile("" :: "v"(R[0].x), "v"(R[0].y));
+            const uint32_t r = skm_rec_valid(R[0]) ? skm_rec_n(R[0]) : 0u;
+            park(R[0], (r << 16) | 1u, lane);
+            if (rr + 1u < n_plain) R[0] = load_rec(start, plain0 + (rr + 1u) * (uint32_t)SKM_CT + mine, len);      // the round after this one
             run_round(r, part_over, P, pass);
         }
-        if (!fast) have_cur = false;                                            // (R[0] has moved on, or the pass was abandoned on the way)
+        if (n_plain) have_cur = false;                                          // (R[0] has moved on, or the pass was abandoned on the way)
+        // ---- the next unit's records and the directory entry after it, in ONE place and in straight-line code: they are in
+        // flight during the drains, the wait for the other waves and the compaction, and are settled after it.  (Asked for
+        // inside the round loops, the compiler joined the loaded registers with the loop's own copies of R right behind the
+        // loads -- a copy is a use, and a use waits for the load: every unit sat out an HBM round trip before its first step.)
+        // The raw words go into registers of their own (T) and become R only where they are settled: R is carried around the
+        // pass loop and the unit loop, and where the loaded registers were R themselves the compiler copied them into R's loop
+        // registers right behind the loads.
+        uint4 T[C2_DD];
+#pragma unroll
+        for (int i = 0; i < C2_DD; i++) T[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (fetch_next) {
+#pragma unroll
+            for (int i = 0; i < C2_DD; i++) T[i] = load_raw(start_n, (uint32_t)i * (uint32_t)SKM_CT + mine, len_n);
+        }
+        if (!dnn_asked) { if (unn < nu) dnn = load_dir(unn); dnn_asked = true; }
         while (qn) c2_drain(L, qn, won_acc, part_over);                        // wave-uniform
         // a crowded table probes slowly: past C2_FILL claims the unit is counted in (more) passes
         if (won_acc) { if (lane == 0) atomicAdd(&blk_claims, won_acc); won_acc = 0; }
@@ -1191,12 +1227,6 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         C2_TICK(4);                                                             // waiting for the other waves
         const bool over = c2_lds_u32(part_over) != 0u || c2_lds_u32(&blk_claims) > (uint32_t)C2_FILL;
         if (threadIdx.x == 0) pflags[parity ^ 1u][1] = 0;                      // for the next pass / unit
-        // the next unit's records and the directory entries read ahead have been in flight for a whole unit: settle them
-        // here, while only loads are outstanding -- once the stores below are in flight as well, the counter no longer tells
-        // loads from stores and the first use of these registers would wait for the stores' acknowledgements too
-        asm volatile("" :: "v"(R[0].x), "v"(R[0].y), "v"(R[1].x), "v"(R[1].y), "v"(R[2].x), "v"(R[2].y), "v"(R[3].x), "v"(R[3].y),
-                           "v"(dnn.start), "v"(dnn.toff0), "v"(dnn.toff1), "v"(dnn.len));
-        snn = to_scalar(dnn);
         // ---- compaction: every wave sweeps ITS eighth of the table (consecutive slots, lane = slot: conflict-free),
         // 8 chunks of 64 in flight: keys are read and reset with one exchange, the counts of the occupied slots likewise.
         // (Claim lists -- visit only the slots that were won -- cost a list append per key slot in the hot loop and four
@@ -1264,6 +1294,16 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         }
         }
         qn = 0;
+        // the records and the directory entries read ahead are settled HERE: behind the compaction (they had the drains, the
+        // barrier and the sweep to land; what is still outstanding now are the sweep's last stores)
+        asm volatile("" :: "v"(T[0].x), "v"(T[0].w), "v"(T[1].x), "v"(T[1].w), "v"(T[2].x), "v"(T[2].w), "v"(T[3].x), "v"(T[3].w),
+                           "v"(dnn.start), "v"(dnn.toff0), "v"(dnn.toff1), "v"(dnn.len));
+        snn = to_scalar(dnn);
+        if (fetch_next) {
+#pragma unroll
+            for (int i = 0; i < C2_DD; i++) R[i] = from_raw(T[i], (uint32_t)i * (uint32_t)SKM_CT + mine, len_n);
+            have_cur = false;
+        }
         C2_TICK(5);                                                             // compaction
         c2_barrier();                                                           // ---- B2: the table is clean, the cursors final
         C2_TICK(6);
@@ -1280,10 +1320,14 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
             if (threadIdx.x == 0 && n_redo && P == 4u) atomicAdd(n_redo, 1u);    // (statistics: units counted in several passes)
         } else if (++pass == P) {
             done = true;
-            ones_acc += ones_try; all_acc += all_try;
+            // (wave-uniform sums, and told so: in SGPRs they cost nothing across the unit loop, as VGPRs the allocator spilt them to
+            // scratch at the loop's top -- a reload waits with vmcnt(0) for the compaction's stores)
+            ones_acc = (uint32_t)__builtin_amdgcn_readfirstlane((int)(ones_acc + ones_try)); all_acc = c2_uniform64(all_acc + all_try);
             if (thr >= 2) for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) { const uint32_t v = lhist_try[i]; if (v) { atomicAdd(&lhist[i], v); lhist_try[i] = 0; } }
         }
-        if (done) break;
+        // (said to be uniform: behind an exit the compiler takes for divergent, everything the loop hands on -- the directory
+        // entries read ahead among it -- is kept in VGPRs, six more across the unit loop)
+        if (__builtin_amdgcn_readfirstlane((int)done)) break;
         c2_barrier();                                                           // (the cursors / the tallies are reset before the next pass appends)
         }
         if (threadIdx.x == 0) { dcount[p0 + ui] = out_cursor; out_cursor = 0; }
