@@ -1227,6 +1227,16 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         C2_TICK(4);                                                             // waiting for the other waves
         const bool over = c2_lds_u32(part_over) != 0u || c2_lds_u32(&blk_claims) > (uint32_t)C2_FILL;
         if (threadIdx.x == 0) pflags[parity ^ 1u][1] = 0;                      // for the next pass / unit
+        // the records and the directory entries read ahead are settled HERE, before the compaction's stores go out (they had the drains
+        // and the wait for the other waves to land): behind the stores the wait would be for the stores' acknowledgements too
+        asm volatile("" :: "v"(T[0].x), "v"(T[0].w), "v"(T[1].x), "v"(T[1].w), "v"(T[2].x), "v"(T[2].w), "v"(T[3].x), "v"(T[3].w),
+                           "v"(dnn.start), "v"(dnn.toff0), "v"(dnn.toff1), "v"(dnn.len));
+        snn = to_scalar(dnn);
+        if (fetch_next) {
+#pragma unroll
+            for (int i = 0; i < C2_DD; i++) R[i] = from_raw(T[i], (uint32_t)i * (uint32_t)SKM_CT + mine, len_n);
+            have_cur = false;
+        }
         // ---- compaction: every wave sweeps ITS eighth of the table (consecutive slots, lane = slot: conflict-free),
         // 8 chunks of 64 in flight: keys are read and reset with one exchange, the counts of the occupied slots likewise.
         // (Claim lists -- visit only the slots that were won -- cost a list append per key slot in the hot loop and four
@@ -1253,19 +1263,27 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
 #pragma unroll
             for (int i = 0; i < NCH; i++) have[i] = ~c2_eq_u64(ck[i], MF_EMPTY) & __builtin_amdgcn_ballot_w64(true);
             if (!over) {
+                // (straight-line code: eight chunks of branches -- is there a cut, did anything drop, is anything kept -- cost more
+                // than the work they skipped; the cut is one signed compare, count > thr, which holds for every entry when thr = -1)
                 uint32_t nkeep = 0, nhave = 0;
+                unsigned long long odd = 0ull;                                  // chunks with dropped entries of a count other than 1
 #pragma unroll
                 for (int i = 0; i < NCH; i++) {
-                    if (cc[i] > (uint32_t)MF_MAX_COUNT) cc[i] = (uint32_t)MF_MAX_COUNT;
-                    keep[i] = thr >= 0 ? (have[i] & c2_lt_u32((uint32_t)thr, cc[i])) : have[i];
+                    asm("v_min_u32 %0, %0, %1" : "+v"(cc[i]) : "s"((uint32_t)MF_MAX_COUNT));
+                    unsigned long long gt;
+                    asm("v_cmp_gt_i32_e64 %0, %1, %2" : "=s"(gt) : "v"(cc[i]), "s"(thr));
+                    keep[i] = have[i] & gt;
+                    const unsigned long long drop = have[i] & ~gt;
+                    const unsigned long long d1 = drop & c2_lt_u32(cc[i], 2u);       // (count 1: nearly all of them)
+                    ones_try += (uint32_t)__popcll(d1);
+                    odd |= drop & ~d1;
                     nkeep += (uint32_t)__popcll(keep[i]); nhave += (uint32_t)__popcll(have[i]);
-                    if (thr >= 0) {
-                        const unsigned long long drop = have[i] & ~keep[i];
-                        if (drop != 0ull) {
-                            const unsigned long long d1 = drop & c2_lt_u32(cc[i], 2u);       // (count 1: nearly all of them)
-                            ones_try += (uint32_t)__popcll(d1);
-                            if ((drop & ~d1) != 0ull && ((drop & ~d1) >> lane) & 1ull) atomicAdd(&lhist_try[cc[i]], 1u);
-                        }
+                }
+                if (odd != 0ull) {                                              // (rare with the usual cut at 1: never)
+#pragma unroll
+                    for (int i = 0; i < NCH; i++) {
+                        const unsigned long long dx = have[i] & ~keep[i] & ~c2_lt_u32(cc[i], 2u);
+                        if ((dx >> lane) & 1ull) atomicAdd(&lhist_try[cc[i]], 1u);
                     }
                 }
                 all_try += nhave;
@@ -1281,29 +1299,23 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                     }
                 }
                 else {
+                    // the kept entries of a chunk go out under the chunk's lane mask (EXEC is switched around the two stores: a
+                    // C++ `if` on the lane's bit is a compare, a saved EXEC and a branch per chunk)
+                    uint64_t *const kb = tkeys + o; uint16_t *const cb = tcnt + o;
 #pragma unroll
                     for (int i = 0; i < NCH; i++) {
-                        if (keep[i] != 0ull) {
-                            const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(keep[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)keep[i], wb));
-                            if ((keep[i] >> lane) & 1ull) { tkeys[o + at] = ck[i]; tcnt[o + at] = (uint16_t)cc[i]; }
-                            wb += (uint32_t)__popcll(keep[i]);
-                        }
+                        const uint32_t at = __builtin_amdgcn_mbcnt_hi((uint32_t)(keep[i] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)keep[i], wb));
+                        const uint64_t ka = (uint64_t)(uintptr_t)(kb + at), ca = (uint64_t)(uintptr_t)(cb + at);
+                        unsigned long long save;
+                        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tglobal_store_dwordx2 %2, %3, off\n\tglobal_store_short %4, %5, off\n\ts_mov_b64 exec, %0"
+                                     : "=&s"(save) : "s"(keep[i]), "v"(ka), "v"(ck[i]), "v"(ca), "v"(cc[i]) : "memory");
+                        wb += (uint32_t)__popcll(keep[i]);
                     }
                 }
             }
         }
         }
         qn = 0;
-        // the records and the directory entries read ahead are settled HERE: behind the compaction (they had the drains, the
-        // barrier and the sweep to land; what is still outstanding now are the sweep's last stores)
-        asm volatile("" :: "v"(T[0].x), "v"(T[0].w), "v"(T[1].x), "v"(T[1].w), "v"(T[2].x), "v"(T[2].w), "v"(T[3].x), "v"(T[3].w),
-                           "v"(dnn.start), "v"(dnn.toff0), "v"(dnn.toff1), "v"(dnn.len));
-        snn = to_scalar(dnn);
-        if (fetch_next) {
-#pragma unroll
-            for (int i = 0; i < C2_DD; i++) R[i] = from_raw(T[i], (uint32_t)i * (uint32_t)SKM_CT + mine, len_n);
-            have_cur = false;
-        }
         C2_TICK(5);                                                             // compaction
         c2_barrier();                                                           // ---- B2: the table is clean, the cursors final
         C2_TICK(6);
