@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     // the records of a unit's first C2_DD rounds are in registers before the unit starts (fetched while the unit before it
     // is worked on); a longer unit fetches every further round while the round before it is worked on
     skm_rec R[C2_DD];
-    uint32_t dd_skip = 0;                                                       // wave-uniform: units still to go without looking for identical records
+    uint32_t dd_skip = 0, dd_seen = 0;                                          // wave-uniform: units still to go without looking for identical records; units that looked
     load4(start, len, R);
     // (a directory entry lives in VGPRs only while its loads are in flight: once landed it moves to SGPRs)
     struct sdirent { uint64_t start, o; uint32_t len, room; };
@@ -1123,7 +1123,8 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                     wl[i] = 0;
                 }
             }
-            {   // how many dropped out (the next units' decision)
+            const bool dd_look = (dd_seen++ & 3u) == 0u;                        // (every fourth such unit is looked at)
+            if (dd_look) {   // how many dropped out (the next units' decision)
                 uint32_t gone = 0, all = 0;
 #pragma unroll
                 for (int i = 0; i < C2_DD; i++) { gone += (uint32_t)__popcll(__ballot(st[i] == 2 && wl[i] == 0u)); all += (uint32_t)__popcll(__ballot(st[i] != 0u || wl[i] != 0u)); }
@@ -1131,7 +1132,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             c2_barrier();                                                       // ---- every record has claimed, added itself or stays as it is
-            {
+            if (dd_look) {
                 const uint32_t gone = c2_lds_u32(&dd_gone), all = c2_lds_u32(&dd_all);
                 if (gone * 4u < all && !(dedupe & 4u)) dd_skip = 15;
             }
@@ -1145,7 +1146,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             c2_barrier();                                                       // ---- the table is empty again
-            if (threadIdx.x == 0) { dd_gone = 0; dd_all = 0; }                  // (read by everybody before this barrier; added to again a unit later)
+            if (dd_look && threadIdx.x == 0) { dd_gone = 0; dd_all = 0; }       // (read by everybody before this barrier; added to again a unit later)
         }
         C2_TICK(7);                                                             // identical records
         // A unit with more distinct k-mers than the table takes (a heavy minimizer: low-complexity sequence between many

@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 timeout -k 5 900 python -m pytest tests/test_count_gpu.py -x -q -m gpu 2>&1 | tail -3
-timeout -k 5 200 python3 tools/fuzz.py 120 45 2>&1 | tail -n 1
+timeout -k 5 200 python3 tools/fuzz.py 120 46 2>&1 | tail -n 1
 for dd in 1 1; do
 MF_OPTIONS=skm_dedupe=$dd timeout -k 5 300 python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/r03s_bench_dd$dd.json 2> gpurun_out/r03s_bench.err
 python3 - <<'PY'
@@ -9,4 +9,3 @@ d=json.loads(open("gpurun_out/r03s_bench_dd1.json").read().strip().splitlines()[
 print(d["ms_per_step"], "count", d["kernels"]["k_skm_count"]["ms_per_step"])
 PY
 done
-MF_VERBOSE=1 timeout -k 5 600 python3 tools/count_ab.py 100000000 31 3072:skm_dedupe=1:ablate=32 2>&1 | grep "part_target\|wave cycles" | awk '!seen[$0]++' | tail -9
