@@ -119,7 +119,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "skm_slices") { if (v < 0 || v > 64 || (v & (v - 1))) return mf_set_error("skm_slices must be 0 or a power of two <= 64"); ctx->opt_skm_slices = v; }
     else if (s == "arena_cap_gb") ctx->opt_arena_cap_gb = v;
     else if (s == "skm_shared") ctx->opt_skm_shared = v;
-    else if (s == "skm_dedupe") ctx->opt_skm_dedupe = v;
+    else if (s == "skm_dedupe") { if (v != 0 && v != 1 && v != 5) return mf_set_error("skm_dedupe must be 0, 1 or 5"); ctx->opt_skm_dedupe = v; }
     else if (s == "stream_reader") ctx->opt_stream_reader = v;
     else if (s == "stream_piece_bytes") ctx->opt_sr_piece = v;
     else if (s == "stream_slack_bytes") ctx->opt_sr_slack = v;

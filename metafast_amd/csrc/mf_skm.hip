@@ -1113,7 +1113,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                     else if (((uint32_t)ret[i] >> 11) == fp) st[i] = 2;
                 }
                 G[i] = SENT;
-                if (st[i] == 2) G[i] = (dedupe & 2u) ? R[i] : load_rec(start, (uint32_t)ret[i] & 2047u, len);          // the claimant (dedupe & 2: timing experiment, not exact)
+                if (st[i] == 2) G[i] = load_rec(start, (uint32_t)ret[i] & 2047u, len);          // the claimant
             }
 #pragma unroll
             for (int i = 0; i < C2_DD; i++) {
@@ -1159,6 +1159,9 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         P = (uint32_t)__builtin_amdgcn_readfirstlane((int)P); pass = (uint32_t)__builtin_amdgcn_readfirstlane((int)pass);      // (uniform: say so)
         uint32_t *part_over = &pflags[parity][1];
         const bool fetch_next = pass + 1u == P && un < nu;                      // (the pass that is meant to be the unit's last)
+        // (Tried: the survivors DEALT evenly over the eight waves through the parked-record area before the barrier that ends the
+        // search, so that every unit is one round of equal shares -- 34.2 ms per step round-robin, 34.5 in blocks, against 31.7
+        // with every wave parking its own survivors: waves in lock step want the same unit of the CU at the same time.)
         // One loop of rounds for both kinds of unit.  A unit whose identical records have been told apart parks its surviving
         // records 64 to a round (wave by wave: `total` of them in this wave, numbered in the order i, lane); any other unit
         // parks round after round of its records as they come, each lane its own.
