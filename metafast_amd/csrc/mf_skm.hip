@@ -1136,13 +1136,22 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                 const uint32_t gone = c2_lds_u32(&dd_gone), all = c2_lds_u32(&dd_all);
                 if (gone * 4u < all && !(dedupe & 4u)) dd_skip = 15;
             }
-#pragma unroll
-            for (int i = 0; i < C2_DD; i++) {
-                if (st[i] == 1) {
-                    uint64_t v;
-                    asm volatile("ds_wrxchg_rtn_b64 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v) : "v"(sa[i]), "v"(MF_EMPTY) : "memory");
-                    wl[i] = (uint32_t)(v >> 32);
-                }
+            {   // the claimants take their weights and hand the slots back: four exchanges under their lane masks, ONE wait
+                static_assert(C2_DD == 4, "four exchanges");
+                const unsigned long long m0 = __ballot(st[0] == 1), m1 = __ballot(st[1] == 1), m2 = __ballot(st[2] == 1), m3 = __ballot(st[3] == 1);
+                uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0; unsigned long long save;
+                asm volatile("s_mov_b64 %4, exec\n\t"
+                             "s_mov_b64 exec, %5\n\tds_wrxchg_rtn_b64 %0, %9, %13\n\t"
+                             "s_mov_b64 exec, %6\n\tds_wrxchg_rtn_b64 %1, %10, %13\n\t"
+                             "s_mov_b64 exec, %7\n\tds_wrxchg_rtn_b64 %2, %11, %13\n\t"
+                             "s_mov_b64 exec, %8\n\tds_wrxchg_rtn_b64 %3, %12, %13\n\t"
+                             "s_mov_b64 exec, %4\n\ts_waitcnt lgkmcnt(0)"
+                             : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "=&s"(save)
+                             : "s"(m0), "s"(m1), "s"(m2), "s"(m3), "v"(sa[0]), "v"(sa[1]), "v"(sa[2]), "v"(sa[3]), "v"(MF_EMPTY) : "memory");
+                if (st[0] == 1) wl[0] = (uint32_t)(v0 >> 32);
+                if (st[1] == 1) wl[1] = (uint32_t)(v1 >> 32);
+                if (st[2] == 1) wl[2] = (uint32_t)(v2 >> 32);
+                if (st[3] == 1) wl[3] = (uint32_t)(v3 >> 32);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             c2_barrier();                                                       // ---- the table is empty again
