@@ -1227,8 +1227,13 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
 #pragma unroll
         for (int i = 0; i < C2_DD; i++) T[i] = make_uint4(0u, 0u, 0u, 0u);
         if (fetch_next) {
+            // (a unit that will not search for identical records takes its rounds one by one: only the first is read ahead)
+            const bool next_fast = dedupe != 0u && dd_skip == 0u;
+            T[0] = load_raw(start_n, mine, len_n);
+            if (next_fast) {
 #pragma unroll
-            for (int i = 0; i < C2_DD; i++) T[i] = load_raw(start_n, (uint32_t)i * (uint32_t)SKM_CT + mine, len_n);
+                for (int i = 1; i < C2_DD; i++) T[i] = load_raw(start_n, (uint32_t)i * (uint32_t)SKM_CT + mine, len_n);
+            }
         }
         if (!dnn_asked) { if (unn < nu) dnn = load_dir(unn); dnn_asked = true; }
         while (qn) c2_drain(L, qn, won_acc, part_over);                        // wave-uniform
