@@ -231,7 +231,7 @@ def main():
         r = P.run_samples(ctx, samples(), k=k, b=1, l=100, b1=args.b1, b2=args.b2, device=device, timings=timings)
         nrec, rbytes = r["goods"][0].records()
         stats = dict(n_occ=r["n_occ"], n_distinct=r["n_distinct"], n_good=sum(len(g) for g in r["goods"]), n_unitigs=sum(len(q) for q in r["seqss"]),
-                     n_cutter=len(r["cutter"]), n_components=len(r["comps"]), n_reads=n_reads * spg, n_bases=n_bases * spg,
+                     n_cutter=len(r["cutter"]), n_cutter_occ=int(r["cutter"].occurrences()), n_components=len(r["comps"]), n_reads=n_reads * spg, n_bases=n_bases * spg,
                      n_records=nrec * spg, record_bytes=rbytes, n_singletons=int(sum(int(h[1]) for h in r["hists"])))
         for x in r["goods"] + r["seqss"] + [r["cutter"], r["comps"]]:
             x.close()
@@ -277,7 +277,7 @@ def main():
             if ab:
                 # a kernel that covers the sample in ONE launch is priced on that launch; one that works through the sample
                 # in batches (k_skm_count, k_gather) on all its launches of a step, the small cutter-table
-                # launches included (slightly pessimistic)
+                # launches included (k_skm_count's roofline counts that launch's units too, below)
                 lps = n / max(args.steps, 1)
                 ms_sample = mx if lps <= 2.5 else per_step_ms
                 kern[name]["sample_ms"] = round(ms_sample, 4)
@@ -301,10 +301,16 @@ def main():
                 # kernel reads that stream as super-k-mer records (2.3 B per occurrence) and writes only the k-mers that
                 # pass the cut, so the bytes it really moves (`bytes_moved_GB`, what `traffic` measures) are a quarter
                 # of the figure the survey prices the step at.
-                surv = 8.0 * stats["n_occ"] + 12.0 * stats["n_distinct"]
+                # The launch time is that of ALL the kernel's launches of a step, so the units are all theirs too: the sample's
+                # occurrences and distinct k-mers + those of the cutter table's own launch (the unitigs' k-mers, a few percent).
+                lps_ = kern[name]["launches"] / max(args.steps, 1)
+                cut_occ, cut_dist = (stats.get("n_cutter_occ", 0), stats["n_cutter"]) if lps_ > 2.5 else (0, 0)
+                surv = 8.0 * (stats["n_occ"] + cut_occ) + 12.0 * (stats["n_distinct"] + cut_dist)
                 moved, t_s = kern[name]["algorithmic_GB"], kern[name]["sample_ms"] / 1e3
                 r.update(achieved=round(surv / 1e9 / t_s, 1), frac=round(surv / 1e9 / t_s / HBM_PEAK_GBS, 4),
                          algorithmic_GB=round(surv / 1e9, 4), priced_as="SURVEY 8(d) K3, LDS-resident: 8 B/occurrence + 12 B/distinct k-mer",
+                         units=dict(occurrences=int(stats["n_occ"] + cut_occ), distinct=int(stats["n_distinct"] + cut_dist),
+                                    of_the_cutter_table=dict(occurrences=int(cut_occ), distinct=int(cut_dist))),
                          bytes_moved_GB=moved, achieved_on_bytes_moved=kern[name]["GBps"],
                          frac_on_bytes_moved=round(kern[name]["GBps"] / HBM_PEAK_GBS, 4))
                 # What binds it: LDS atomics and instruction issue, not HBM.  LDS-operation roofline beside the HBM-priced one:
