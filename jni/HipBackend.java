@@ -16,6 +16,9 @@ public final class HipBackend {
     public static native long[] countReadsAbove(long ctx, String[] files, int k, int minSeqLen, int threshold);
     /** releases the table's lookup index until it is needed again (several libraries per GPU) */
     public static native void tableDropIndex(long table);
+    /** mf_ctx_trim_bytes: idle workspace back to the driver, smallest regions first, until `want` bytes are free again; the bytes given back
+     *  (a JVM that keeps device buffers of its own beside the library asks for what it is short of, not for everything) */
+    public static native long ctxTrimBytes(long ctx, long want);
     /** hm.size() */
     public static native long tableSize(long table);
     /** IOUtils.printKmers (src/io/IOUtils.java:45): returns the number of good k-mers written */

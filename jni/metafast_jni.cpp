@@ -60,6 +60,12 @@ JNIEXPORT jlongArray JNICALL Java_io_HipBackend_countReadsAbove(JNIEnv *e, jclas
     e->SetLongArrayRegion(r, 0, 2, v);
     return r;
 }
+JNIEXPORT jlong JNICALL Java_io_HipBackend_ctxTrimBytes(JNIEnv *e, jclass, jlong ctx, jlong want) {
+    uint64_t freed = 0;
+    if (want < 0) { e->ThrowNew(e->FindClass("java/lang/IllegalArgumentException"), "ctxTrimBytes: negative size"); return 0; }
+    if (mf_ctx_trim_bytes((mf_ctx *)(intptr_t)ctx, (uint64_t)want, &freed) < 0) { raise(e); return 0; }
+    return (jlong)freed;
+}
 JNIEXPORT void JNICALL Java_io_HipBackend_tableDropIndex(JNIEnv *e, jclass, jlong table) {
     if (mf_table_drop_index((mf_table *)(intptr_t)table) < 0) raise(e);
 }
