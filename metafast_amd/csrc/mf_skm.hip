@@ -13,8 +13,10 @@
 //   S2 k_skm_scatter  the minimizer scan (again, where S1 ran over everything), records built and radix-partitioned through
 //                     64-byte LDS staging lines; one-pass form: regions reserved chunk by chunk during the scatter
 //   S3 k_skm_split    further levels: the digit is read from the record (22 digit bits travel with it)
-//   S4 k_skm_count    one partition per 512-thread workgroup: every wave deals its records out as items of <= 4 k-mers
-//                     -> open-addressed count table in LDS -> compacted (key,count) slices; a batch of partitions at a time
+//   S4 k_skm_count    one partition per 512-thread workgroup: identical records are told apart first (a pass of the records
+//                     through the empty table: the k-mers of a record that occurs n times are inserted once, with weight n);
+//                     every wave deals the surviving records out as items of <= 2 k-mers -> open-addressed count table in
+//                     LDS -> compacted (key,count) slices; a batch of partitions at a time
 //      k_gather       slices of the batch -> dense arrays, grouped by partition (the HBM index is built partition by
 //                     partition, mf_table.hip)
 //
