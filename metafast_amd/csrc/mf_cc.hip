@@ -1052,7 +1052,7 @@ extern "C" int mf_dcc_merge(mf_dcc *D, const void *d_pairs, uint64_t n, uint64_t
     if (!D || !n_stats || (n && !d_pairs)) return mf_set_error("mf_dcc_merge: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
     MF_HIP(hipSetDevice(ctx->device));
-    if (D->level == 0 || n * 48 > D->n_total) {                           // (random writes: only worth it when few ids occur)
+    if (D->level == 0 || (n * 48 > D->n_total && !ctx->opt_dcc_sparse)) {                           // (random writes: only worth it when few ids occur)
         if (D->n_total) { mf_ktimer tm_(ctx, "k_dcc_iota"); k_dcc_iota<<<cgrid(D->n_total), 256, 0, st>>>(D->pg.p, D->gsize.p, D->gweight.p, D->n_total); }
     } else {
         mf_ktimer tm_(ctx, "k_dcc_iota");
@@ -1143,6 +1143,13 @@ __global__ void k_dcc_report(const dcc_stat *__restrict__ s, uint64_t n, const u
     if (sz <= b2) { const uint32_t at = atomicAdd(&cnt[0], 1u); kept[at].g = g; kept[at].size = sz; kept[at].weight = gweight[g]; }
     else atomicAdd(&cnt[1], 1u);
 }
+// size / weight of every root the level's records name go back to zero, the other ranks' roots included: the next level's sparse
+// set-up (mf_dcc_merge) resets only the ends of ITS pairs and this rank's own fragment roots, and a component that by then lives on
+// one other rank without a cross edge would be added on top of what its root summed up at this level (k_dcc_report reads every rank's)
+__global__ void k_dcc_clear(const dcc_stat *__restrict__ s, uint64_t n, uint32_t *__restrict__ gsize, unsigned long long *__restrict__ gweight) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { gsize[s[i].g] = 0; gweight[s[i].g] = 0; }
+}
 __global__ void k_dcc_cross_next(uint8_t *__restrict__ xalive, const uint32_t *__restrict__ xv, const uint16_t *__restrict__ xval, uint64_t nx,
                                  const uint8_t *__restrict__ alive_after, uint32_t next_thr) {
     const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1182,6 +1189,7 @@ extern "C" int mf_dcc_classify(mf_dcc *D, const void *d_stats, uint64_t n, const
                                                  (uint32_t)b1, (uint32_t)b2, (uint32_t)(thr + 1), &D->ctr.p[2], D->mk.p, D->mg.p, D->gmin.p);
     }
     if (D->nx) { mf_ktimer tm_(ctx, "k_dcc_cross_next"); k_dcc_cross_next<<<cgrid(D->nx), 256, 0, st>>>(D->xalive.p, D->xv.p, D->xval.p, D->nx, D->alive.p, (uint32_t)(thr + 1)); }
+    if (n) k_dcc_clear<<<cgrid(n), 256, 0, st>>>((const dcc_stat *)d_stats, n, D->gsize.p, D->gweight.p);      // (after the last reader, k_dcc_apply)
     unsigned int c[4];
     MF_HIP(hipMemcpyAsync(c, &D->ctr.p[2], 12, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));

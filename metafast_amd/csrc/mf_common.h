@@ -72,6 +72,10 @@ struct mf_ctx {
     int64_t opt_skm_batches = 0;   // partitions are counted + gathered in this many batches (0 = auto); tests force small values
     int64_t opt_union_samples = 0;     // hint: the sequences of the next count are the unitigs of this many samples (they share k-mers: partitions are planned twice as large from 4 on)
     int own_rank = 0, own_world = 1;   // mf_count_device_shard: only the k-mers this rank owns (level-1 digits [nd1 * rank / world, nd1 * (rank + 1) / world)) are counted
+    int64_t opt_skm_pilot = 1;     // reads: a few level-1 digit regions are counted first to measure distinct k-mers per occurrence; the later levels are planned from it (0 = plan from the occurrences alone)
+    int64_t opt_skm_unit_distinct = 2200;   // ... so that a counting unit is expected to hold at most this many distinct k-mers (the LDS table takes C2_FILL = 3400 claims)
+    double last_pilot_rho = -1.0;  // what the last pilot measured (diagnostics; < 0: none ran)
+    int64_t opt_dcc_sparse = 0;    // sharded cutter, levels after the first: 1 = always the sparse set-up of the arrays over all vertex ids (tests)
     int64_t opt_nbr_global = 0;    // 1: neighbour lookups of the graph kernels through the HBM index only (A/B of mf_nbr.h)
     int64_t opt_scatter_fast = 1;  // k_skm_scatter: runs dealt evenly over the lanes through LDS where the level leaves room (0 = never)
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero

@@ -22,7 +22,7 @@
 #include <vector>
 
 int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
-                 int k, const std::vector<int> &lv, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out);
+                 int k, const std::vector<int> &lv, bool adaptive, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out);
 
 // =============================================================================================
 // K0: valid-start bitmap
@@ -672,7 +672,8 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
             if (slv.size() == 3 && Bc <= 2 * MF_MAX_DIGIT_BITS + 1 && (n_occ >> (2 * MF_MAX_DIGIT_BITS)) <= 4 * target)
                 slv = {MF_MAX_DIGIT_BITS, MF_MAX_DIGIT_BITS};
         }
-        int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, slv, scal.p, thr, n_all, out);
+        // (reads: the plan is provisional -- a pilot measures the distinct k-mers per occurrence and sets the later levels, mf_skm.hip)
+        int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, slv, ctx->opt_l1_bits < 0 && !assembled, scal.p, thr, n_all, out);
         if (rc != MF_SKM_FALLBACK) return rc;
     }
     if (ctx->own_world > 1) return mf_set_error("mf_count_device_shard: the input does not suit the minimizer-partition path");

@@ -125,6 +125,9 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "stream_slack_bytes") ctx->opt_sr_slack = v;
     else if (s == "skm_dyn") ctx->opt_skm_dyn = v;
     else if (s == "nbr_global") ctx->opt_nbr_global = v;
+    else if (s == "dcc_sparse") ctx->opt_dcc_sparse = v;
+    else if (s == "skm_pilot") ctx->opt_skm_pilot = v;
+    else if (s == "skm_unit_distinct") { if (v < 64 || v > 3400) return mf_set_error("skm_unit_distinct out of [64,3400]"); ctx->opt_skm_unit_distinct = v; }
     else if (s == "union_samples") ctx->opt_union_samples = v;
     else return mf_set_error("unknown option '%s'", name);
     return MF_OK;

@@ -1187,7 +1187,6 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         const uint32_t n_dense = fast ? (total + 63u) >> 6 : 0u;
         const uint32_t plain0 = fast ? DDN : 0u;
         const uint32_t n_plain = len > plain0 ? (len - plain0 + (uint32_t)SKM_CT - 1u) / (uint32_t)SKM_CT : 0u;
-        const uint32_t n_rounds = n_dense + n_plain;
         bool gave_up = false;
         for (uint32_t rr = 0; rr < n_dense; rr++) {
             if (rr && c2_lds_u32(part_over)) { gave_up = true; break; }        // (abandoned)
@@ -1437,6 +1436,109 @@ template <typename KF> static int skm_set_lds(KF kern, size_t bytes) {
     return MF_OK;
 }
 
+// =============================================================================================
+// The PILOT (round 4): distinct k-mers per occurrence, measured before the levels after the first are planned.
+// What a counting unit costs is decided by its DISTINCT k-mers (the LDS table takes C2_FILL claims; a unit beyond that is
+// counted again in 4, 16, 64 passes), and a plan made from the number of occurrences alone has one sequencing depth in mind: with
+// the benchmark's 7.4 occurrences per distinct k-mer built in, the same 100 M reads drawn from a pool sixteen times as large
+// (5-fold instead of 83-fold depth, 3.4 occurrences per distinct k-mer) had every second unit counted in four passes -- 362 ms
+// instead of 32.  The reference's map does not care: it doubles when it is full (Long2ShortHashMap.java:191-214).
+// Once level 1 stands, the records of a few of its digit regions whose NEXT digits are among the smallest `nsel` values -- that
+// is: a few hundred would-be units an eighth of the planned size, each with ALL the occurrences of its k-mers -- are copied out
+// (two small passes over <= 8 regions: histogram, scatter) and counted with the counting kernel itself; nothing is kept but the
+// number of distinct k-mers.  ~2 M occurrences, five small launches and one round trip to the host (0.2 ms at 100 M reads).
+// =============================================================================================
+#define SKM_PILOT_CH 8192          // records of a region per workgroup
+__global__ __launch_bounds__(256) void k_skm_pilot(const skm_rec *__restrict__ recs, const uint64_t *__restrict__ pstart, const uint32_t *__restrict__ plen,
+                                                   const uint32_t *__restrict__ regions, int shift, uint32_t nsel, uint32_t *__restrict__ cnt,
+                                                   uint32_t *__restrict__ occ, const uint64_t *__restrict__ ostart, uint32_t *__restrict__ cur,
+                                                   skm_rec *__restrict__ out) {
+    // ostart == nullptr: histogram pass (cnt / occ [region][digit]: records, k-mers); else: the records go to out[ostart[bin] + ...]
+    extern __shared__ uint32_t sh[];                                    // [2 * nsel] (histogram pass)
+    const uint32_t rg = blockIdx.y, d1 = regions[rg];
+    const uint64_t start = pstart[d1];
+    const uint32_t len = plen[d1];
+    const uint32_t j0 = blockIdx.x * (uint32_t)SKM_PILOT_CH;
+    if (j0 >= len) return;
+    const uint32_t j1 = min(len, j0 + (uint32_t)SKM_PILOT_CH);
+    const bool hist = ostart == nullptr;
+    if (hist) { for (uint32_t i = threadIdx.x; i < 2u * nsel; i += blockDim.x) sh[i] = 0; __syncthreads(); }
+    for (uint32_t j = j0 + threadIdx.x; j < j1; j += blockDim.x) {
+        const skm_rec v = recs[start + j];
+        if (!skm_rec_valid(v)) continue;
+        const uint32_t d = skm_rec_digits(v) >> shift;
+        if (d >= nsel) continue;
+        if (hist) { atomicAdd(&sh[d], 1u); atomicAdd(&sh[nsel + d], skm_rec_n(v)); }
+        else { const uint32_t at = atomicAdd(&cur[rg * nsel + d], 1u); out[ostart[rg * nsel + d] + at] = v; }
+    }
+    if (hist) {
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nsel; i += blockDim.x) {
+            if (sh[i]) { atomicAdd(&cnt[rg * nsel + i], sh[i]); atomicAdd(&occ[rg * nsel + i], sh[nsel + i]); }
+        }
+    }
+}
+__global__ void k_skm_pilot_dir(const uint32_t *__restrict__ cnt, uint32_t n, uint32_t *__restrict__ plen) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) plen[i] = (cnt[i] + 3u) & ~3u;
+}
+// -> *rho = distinct k-mers per occurrence among the sampled units (< 0: nothing sampled); bufA / pstart / plen: level 1 (indexed by digit)
+template <int K>
+static int skm_pilot(mf_ctx *ctx, const skm_rec *bufA, const uint64_t *pstart, const uint32_t *plen, uint32_t dlo, uint32_t dhi, uint64_t n_occ, int nd1,
+                     int bits_planned, int kthr, double *rho) {
+    hipStream_t st = ctx->stream;
+    *rho = -1.0;
+    if (dhi <= dlo) return MF_OK;
+    const uint32_t R = std::min<uint32_t>(8u, dhi - dlo);
+    const int pb = std::min((int)SKM_DIGIT_BITS, bits_planned + 3);                       // would-be units an eighth of the planned size
+    const double per_unit = (double)n_occ / (double)nd1 / (double)(1u << pb);            // occurrences of one of them
+    uint32_t nsel = (uint32_t)std::min<double>((double)(1u << pb), std::max(1.0, std::ceil(2.5e6 / (per_unit * R))));
+    if (nsel > 2048u) nsel = 2048u;
+    const uint32_t nb = R * nsel;
+    std::vector<uint32_t> h_reg(R);
+    for (uint32_t i = 0; i < R; i++) h_reg[i] = dlo + (uint32_t)(((uint64_t)(2 * i + 1) * (dhi - dlo)) / (2 * R));      // spread over the slice's digits
+    std::vector<uint32_t> h_len(nd1);
+    mf_buf<uint32_t> reg, cnt, occ, cur, uplen, dcount; mf_buf<uint64_t> ostart, toff; mf_buf<unsigned long long> ps;
+    MF_TRY(reg.alloc(ctx, R)); MF_TRY(cnt.alloc(ctx, (size_t)3 * nb)); MF_TRY(uplen.alloc(ctx, nb)); MF_TRY(dcount.alloc(ctx, nb));
+    MF_TRY(ostart.alloc(ctx, (size_t)nb + 1)); MF_TRY(toff.alloc(ctx, (size_t)nb + 1)); MF_TRY(ps.alloc(ctx, 24));
+    uint32_t *const d_cnt = cnt.p, *const d_occ = cnt.p + nb, *const d_cur = cnt.p + 2 * (size_t)nb;
+    MF_HIP(hipMemcpyAsync(reg.p, h_reg.data(), (size_t)R * 4, hipMemcpyHostToDevice, st));
+    MF_HIP(hipMemsetAsync(cnt.p, 0, (size_t)3 * nb * 4, st));
+    MF_HIP(hipMemsetAsync(ps.p, 0, 24 * 8, st));
+    // (a region's length is not known on the host: the grid covers the longest a region can be, 4 x the mean)
+    const uint64_t mean_len = std::max<uint64_t>(1, n_occ / (uint64_t)nd1 / 4);          // (records >= occurrences / 20; 4 is generous)
+    const unsigned gx = (unsigned)std::min<uint64_t>(65535, (4 * mean_len + SKM_PILOT_CH - 1) / SKM_PILOT_CH + 1);
+    const int shift = SKM_DIGIT_BITS - pb;
+    mf_ktimer tm(ctx, "k_skm_pilot");
+    k_skm_pilot<<<dim3(gx, R), 256, (size_t)2 * nsel * 4, st>>>(bufA, pstart, plen, reg.p, shift, nsel, d_cnt, d_occ, nullptr, nullptr, nullptr);
+    k_skm_pilot_dir<<<(nb + 255) / 256, 256, 0, st>>>(d_cnt, nb, uplen.p);
+    MF_TRY(mf_scan<1>(ctx, uplen.p, ostart.p, nb, (uint64_t *)&ps.p[0]));
+    MF_TRY(mf_scan<1>(ctx, d_occ, toff.p, nb, (uint64_t *)&ps.p[1]));
+    unsigned long long tot[2] = {0, 0};
+    MF_HIP(hipMemcpyAsync(tot, ps.p, 16, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    if (!tot[0] || !tot[1]) return MF_OK;
+    mf_buf<skm_rec> pr; mf_buf<uint64_t> tkeys; mf_buf<uint16_t> tcnt;
+    if (pr.alloc(ctx, tot[0] + 4) != MF_OK || tkeys.alloc(ctx, tot[1]) != MF_OK || tcnt.alloc(ctx, tot[1]) != MF_OK) return MF_OK;      // (no room: no pilot)
+    MF_HIP(hipMemsetAsync(pr.p, 0xFF, (tot[0] + 4) * sizeof(skm_rec), st));               // padding = sentinels
+    k_skm_pilot<<<dim3(gx, R), 256, 0, st>>>(bufA, pstart, plen, reg.p, shift, nsel, nullptr, nullptr, ostart.p, d_cur, pr.p);
+    {
+        const unsigned grid = (unsigned)std::min<uint64_t>(nb, (uint64_t)ctx->n_cu * 2);
+        // ps: [2] overflow [3] distinct before the cut [4] units redone [8..24) diagnostics
+        k_skm_count<K, false><<<grid, SKM_CT, C2_LDS, st>>>(pr.p, ostart.p, uplen.p, nb, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&ps.p[2], 0u, (uint64_t)0, kthr,
+                                                         &ps.p[3], (unsigned int *)&ps.p[4], nullptr, &ps.p[8], (uint64_t)tot[1], (uint32_t)ctx->opt_skm_dedupe);
+    }
+    unsigned long long res[3] = {0, 0, 0};
+    MF_HIP(hipMemcpyAsync(res, &ps.p[2], 24, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    MF_HIP(hipGetLastError());
+    *rho = (res[0] & 0xFFFFFFFFull) ? 1.0 : (double)res[1] / (double)tot[1];              // (a unit beyond 64 passes at an eighth of the size: plan as fine as it gets)
+    if (ctx->opt_verbose)
+        fprintf(stderr, "[mf] skm pilot: %u would-be units of %u regions (2^%d per region): %llu records, %llu occurrences, %llu distinct k-mers = %.4f per occurrence, %llu unit(s) redone\n",
+                nb, R, pb, tot[0], tot[1], res[1], *rho, res[2] & 0xFFFFFFFFull);
+    return MF_OK;
+}
+
 // lv: digit bits per level (lv[0] = level 1).  Returns MF_OK and *out, or MF_SKM_FALLBACK (nothing allocated) when the
 // input does not suit this path (a partition too rich for the LDS table, too many levels, not enough memory).
 // what the slices of one run add up to: the dense table (grouped by partition, slice after slice = partition order), the
@@ -1467,8 +1569,9 @@ struct skm_shared {
 // the dense table in the same order as a single pass would.
 template <int K>
 static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words,
-                     uint64_t n_occ, const std::vector<int> &lv, unsigned long long *scal, int kthr, uint32_t dlo, uint32_t dhi,
-                     uint32_t slice, uint32_t n_slices, skm_acc &A, skm_shared *SH = nullptr) {
+                     uint64_t n_occ, std::vector<int> &lv, unsigned long long *scal, int kthr, uint32_t dlo, uint32_t dhi,
+                     uint32_t slice, uint32_t n_slices, skm_acc &A, skm_shared *SH = nullptr, bool last_of_shared = false, bool *plan_open = nullptr) {
+    // *plan_open: the levels after the first are still to be planned (skm_pilot): lv[1..] may change in here, once
     hipStream_t st = ctx->stream;
     const int bits1 = lv[0], nd1 = 1 << bits1;
     // (SH: level 1 covers all of the run's digits and is done by the first slice; dlo / dhi then only say which regions this slice takes)
@@ -1495,7 +1598,11 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
     // adds padding), so the third level re-uses the first level's buffer instead of asking for a third one that is a few
     // megabytes too large for it (at 200 M reads, k = 21 a buffer is 125 GB: there is no room for three, and a second
     // sample would find the arena's idle regions just too small again).
+    const bool open = plan_open && *plan_open;
+    bool headroom = open;
     auto final_cap = [&](unsigned long long c1) {
+        // (plan still open: room for the padding of whatever the pilot decides -- at most 2 x n_occ / 1100 partitions of 4 records each)
+        if (headroom) return c1 + n_occ / 128 + (unsigned long long)nd1 * SKM_LINE * (1ull << MF_MAX_DIGIT_BITS);
         if (lv.size() < 3) return c1;
         unsigned long long c = c1, p = (unsigned long long)nd1;
         for (size_t li = 1; li < lv.size(); li++) { c += p * SKM_LINE * (1ull << lv[li]); p <<= lv[li]; }
@@ -1589,7 +1696,28 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         rebase = SH->h_pstart[dlo];
         cap = (dhi < (uint32_t)nd1 ? SH->h_pstart[dhi] : SH->cap) - rebase;
     }
+    if (open) {
+        // ---- the pilot: distinct k-mers per occurrence -> the levels after the first
+        *plan_open = false;
+        double rho = -1.0;
+        MF_TRY(skm_pilot<K>(ctx, bufA.p, pstart.p, plen.p, dlo, dhi, n_occ, nd1, total_bits - bits1, kthr, &rho));
+        ctx->last_pilot_rho = rho;
+        if (rho > 0.0) {
+            const double want_units = (double)n_occ * rho / (double)std::max<int64_t>(64, ctx->opt_skm_unit_distinct);
+            int Bc = 0; while (Bc < 30 && (double)(1ull << Bc) < want_units) Bc++;
+            const int r = std::max(1, std::min(Bc - bits1, std::min((int)SKM_DIGIT_BITS, 30 - bits1)));
+            if (ctx->opt_verbose) fprintf(stderr, "[mf] skm pilot: %.4f distinct k-mers per occurrence -> %d bits after level 1 (planned from the occurrences alone: %d)\n", rho, r, total_bits - bits1);
+            lv.resize(1);
+            if (r <= MF_MAX_DIGIT_BITS) lv.push_back(r); else { lv.push_back((r + 1) / 2); lv.push_back(r / 2); }
+            total_bits = 0; for (int b : lv) total_bits += b;
+        }
+    }
+    if (!A.doff.p) {                                      // (the first slice of the run, now that the plan stands)
+        A.np_total = (uint32_t)(1ull << (total_bits + 1)); // partitions of the table: two per counting partition
+        MF_TRY(A.doff.alloc(ctx, (size_t)A.np_total + 1));
+    }
     MF_HIP(hipMemsetAsync(&scal[6], 0, 8, st));           // [6] records without padding ([7] distinct k-mers before the cut: whole run)
+    headroom = false;
     const unsigned long long cap_l1 = cap, cap_last = final_cap(cap);
     if (dlo != 0 || dhi != (uint32_t)nd1) {
         // the slice's digits only: the directory of the following levels starts at digit dlo
@@ -1627,7 +1755,10 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         }
         MF_DBG(ctx, "k_skm_split");
         bufA.swap(bufB);
-        if (!last && bufB.owned) { spare.reset(); spare.swap(bufB); }        // (a borrowed level-1 buffer is the other slices' input too)
+        if (!last && bufB.owned) { spare.reset(); spare.swap(bufB); }        // (a borrowed level-1 buffer is the other slices' input too ...
+        else if (!last && SH && last_of_shared && bufB.p == SH->buf.p) {    // ... unless this is the run's last slice: its third level writes there)
+            bufB.reset(); spare.reset(); spare.swap(SH->buf); SH->ready = false;
+        }
         pstart.swap(ostart); plen.swap(olen);
         if (last) pocc.swap(oocc);
         cap = cap2; np = (uint32_t)np2; used += bits;
@@ -1762,8 +1893,9 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
 // input does not suit this path (a partition too rich for the LDS table, too many levels, not enough memory).
 template <int K>
 static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words,
-                   uint64_t n_occ, const std::vector<int> &lv, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
+                   uint64_t n_occ, const std::vector<int> &lv0, bool adaptive, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
     hipStream_t st = ctx->stream;
+    std::vector<int> lv = lv0;                 // (the levels after the first may change once the pilot has measured the reads' depth)
     const int bits1 = lv[0], nd1 = 1 << bits1;
     int total_bits = 0; for (int b : lv) total_bits += b;
     if (total_bits > 30 || total_bits - bits1 > SKM_DIGIT_BITS) return MF_SKM_FALLBACK;      // (the table gets total_bits + 1 partition bits)
@@ -1823,17 +1955,19 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     skm_shared SH; SH.lo = own_lo; SH.hi = own_hi;
     const uint32_t S_own = S;
     int shared_tries = 0;
+    // ---- the PILOT (round 4, skm_pilot below): the plan the caller made sizes the counting units by OCCURRENCES; what a unit costs
+    // is decided by its DISTINCT k-mers.  The first slice measures them once its level 1 stands and re-plans the later levels.
+    bool plan_open = adaptive && ctx->opt_skm_pilot != 0 && lv.size() >= 2 && W == 1;
     for (;;) {
-        skm_acc A;
-        A.np_total = (uint32_t)(1ull << (total_bits + 1));      // partitions of the table: two per counting partition
-        MF_TRY(A.doff.alloc(ctx, (size_t)A.np_total + 1));
+        skm_acc A;                                              // (A.np_total, A.doff: set by the first slice, once the plan stands)
         if (kthr >= 0) { MF_TRY(A.dhist.alloc(ctx, (size_t)MF_MAX_COUNT + 1)); MF_HIP(hipMemsetAsync(A.dhist.p, 0, A.dhist.bytes(), st)); }
         MF_TRY(A.c2p.alloc(ctx, 16)); MF_HIP(hipMemsetAsync(A.c2p.p, 0, 128, st));     // [0,8) phase cycles (profiling build), [8,16) overflow diagnostics
         MF_HIP(hipMemsetAsync(&scal[7], 0, 8, st));
         int rc = MF_OK;
         for (uint32_t sl = 0; sl < S && rc == MF_OK; sl++)
             rc = skm_slice<K>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, kthr, own_lo + (uint32_t)((uint64_t)(own_hi - own_lo) * sl / S),
-                              own_lo + (uint32_t)((uint64_t)(own_hi - own_lo) * (sl + 1) / S), sl, S, A, shared ? &SH : nullptr);
+                              own_lo + (uint32_t)((uint64_t)(own_hi - own_lo) * (sl + 1) / S), sl, S, A, shared ? &SH : nullptr, sl + 1 == S, &plan_open);
+        total_bits = 0; for (int b : lv) total_bits += b;
         if (rc == MF_OK && W > 1) {
             // the other ranks' partitions are empty here: offsets 0 before the owner's range, the table's size after it
             const uint32_t pb0 = (uint32_t)(((uint64_t)own_lo * A.np_total) >> bits1), pb1 = (uint32_t)(((uint64_t)own_hi * A.np_total) >> bits1);
@@ -1905,11 +2039,12 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     }
 }
 
+// adaptive: the plan was made from the number of occurrences alone -- the levels after the first may be re-planned from a pilot
 int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
-                 int k, const std::vector<int> &lv, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
+                 int k, const std::vector<int> &lv, bool adaptive, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
     int rc = MF_SKM_FALLBACK;
     switch (k) {
-#define SKM_CASE(KK) case KK: rc = skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, scal, thr, n_all, out); break;
+#define SKM_CASE(KK) case KK: rc = skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, adaptive, scal, thr, n_all, out); break;
 #ifndef MF_SKM_ONLY_K31              /* (a quick look at one instantiation's code: hipcc -DMF_SKM_ONLY_K31 -S) */
         SKM_CASE(20) SKM_CASE(21) SKM_CASE(22) SKM_CASE(23) SKM_CASE(24) SKM_CASE(25)
         SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29) SKM_CASE(30)

@@ -360,6 +360,8 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
             # (the gather that opens a level also closes the one before: it carries that level's oversize count -- the same on
             # every rank -- and the status of the calls since the last gather, so all ranks leave the loop, or abort, together)
             pm = gather_ints(lambda: [n_big] + ([int(x) for x in D.level_local()] if n_big else [0] * W), W + 1)
+            if len(set(int(x) for x in pm[:, 0])) != 1:         # (every rank derives the count from the same gathered records)
+                raise DistAbort("sharded component cutter: the ranks disagree on a level's oversize components: %s" % [int(x) for x in pm[:, 0]])
             if int(pm[me][0]) == 0:
                 break
             pm = pm[:, 1:]

@@ -120,7 +120,7 @@ def test_rccl_path_world1(oracle, tmp_path):
 
 
 # ---- the sharded cutter with W virtual ranks in one process (threads; pipeline.ThreadComm stands in for RCCL) ----
-def _virtual_ranks(world, inputs, b1, b2, k=31, b=1, l=100, fail_rank=None, fail_at=None):
+def _virtual_ranks(world, inputs, b1, b2, k=31, b=1, l=100, fail_rank=None, fail_at=None, options=None):
     """inputs: (bases, offsets) host arrays of the samples; their unitigs are what every rank has after the all-gather of
     pipeline.run_samples -> per rank (components export, info)"""
     import threading
@@ -152,6 +152,8 @@ def _virtual_ranks(world, inputs, b1, b2, k=31, b=1, l=100, fail_rank=None, fail
             torch.cuda.set_device(0)
             comm = P.ThreadComm(group, rank)
             ctx = L.Context(0)
+            for name, val in (options or {}).items():
+                ctx.set_option(name, val)
             shard = ctx.count_device_shard(allb.data_ptr(), allo.data_ptr(), int(allo.numel()) - 1, nb, k, l, rank, world)
             info = {}
             if rank == fail_rank and fail_at == "shard":
@@ -292,3 +294,22 @@ def test_sharded_cutter_small_graph_many_ranks(oracle):
     for comps, info in res:
         assert [(a, w, t) for a, w, t, _ in comps] == [(a, w, t) for a, w, t, _ in want]
         assert all(np.array_equal(np.sort(g[3]), np.sort(x[3])) for g, x in zip(comps, want))
+
+
+@pytest.mark.parametrize("seed", [107, 211, 307])
+def test_sharded_cutter_sparse_setup_every_level(oracle, seed):
+    """after the first level the arrays over all vertex ids are reset only where this level's pairs and this rank's own
+    fragment roots touch them (option dcc_sparse forces that path at every level).  Small graphs over 8 ranks leave remnants of an
+    oversize component that live on ONE rank, some of them under the root that summed up the whole component a level earlier:
+    every rank must still see the owner's size for them (no stale sums), i.e. agree on the kept list and leave the level loop
+    together -- and end with the oracle's components."""
+    from util import branchy_reads
+    inputs = [branchy_reads(seed, genome_seed=7, n=2500), branchy_reads(seed + 10, genome_seed=7, n=2500)]
+    want = _oracle_components(oracle, inputs, 20, 300)
+    res = _virtual_ranks(8, inputs, 20, 300, options={"dcc_sparse": 1})
+    assert len(want) > 0
+    for comps, info in res:
+        assert not isinstance(comps, str), (comps, info)
+        assert [(a, w, t) for a, w, t, _ in comps] == [(a, w, t) for a, w, t, _ in want]
+        assert all(np.array_equal(np.sort(g[3]), np.sort(x[3])) for g, x in zip(comps, want))
+    assert max(i["levels"] for _, i in res) >= 2
