@@ -162,7 +162,10 @@ def main():
     ap.add_argument("--samples-per-gpu", type=int, default=1, help="samples a rank processes one after the other (BASELINE config 5: 4)")
     ap.add_argument("--read-len", type=int, default=150)
     ap.add_argument("-k", type=int, default=31)
-    ap.add_argument("--genome-scale", type=int, default=1_000_000, help="pool genome length scale in bp")
+    ap.add_argument("--genome-scale", "--pool-scale", dest="genome_scale", type=int, default=1_000_000,
+                    help="pool genome length scale in bp (1000000: the 350 Mbp pool of BASELINE configs 2-4 = 83-fold depth at 100 M reads; "
+                         "5700000: the 2 Gbp pool of config 5; 16000000: 5-fold depth at 100 M reads)")
+    ap.add_argument("--sub-rate", type=float, default=0.005, help="substitution errors per base (0.005: configs 2-4; 0.01: config 5)")
     ap.add_argument("--cpu-sample-reads", type=int, default=8_000_000, help="reads of the with-reader CPU baseline (FASTA file)")
     ap.add_argument("--cpu-count-only-reads", type=int, default=4_000_000, help="reads of the parser-free CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -206,7 +209,8 @@ def main():
     torch.cuda.synchronize()
     spg = max(1, args.samples_per_gpu)
     gen_s = [0.0]
-    ctx.synth_reads_device(SEED, rank * spg, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr())
+    sub16k = int(round(args.sub_rate * 16384))
+    ctx.synth_reads_device(SEED, rank * spg, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr(), sub16k)
     torch.cuda.synchronize()
 
     def samples():
@@ -216,7 +220,7 @@ def main():
             if spg > 1:
                 torch.cuda.synchronize()
                 g0 = time.perf_counter()
-                ctx.synth_reads_device(SEED, rank * spg + j, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr())
+                ctx.synth_reads_device(SEED, rank * spg + j, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr(), sub16k)
                 torch.cuda.synchronize()
                 gen_s[0] += time.perf_counter() - g0        # (taken out of the timed region again: data generation is not the path)
             yield bases, offsets, n_reads, n_bases
@@ -336,7 +340,8 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{world * spg} sample(s) x {n_reads} synthetic {rl} bp reads, k={k}, {spg} sample(s) per GPU, "
                                    f"count+unitigs+components+features (b=1 l=100 b1={args.b1} b2={args.b2})",
-                       "reads_per_gpu": n_reads, "read_len": rl, "k": k, "genome_scale_bp": args.genome_scale},
+                       "reads_per_gpu": n_reads, "read_len": rl, "k": k, "genome_scale_bp": args.genome_scale,
+                       "substitutions_per_base": round(sub16k / 16384, 5)},
             "roofline": roof(dom),
             "roofline_hash_count": roof("k_skm_count" if "k_skm_count" in kern else "k_count"),
             "cpu_baseline": cpu,

@@ -317,6 +317,12 @@ int  mf_synth_reads_device(mf_ctx *ctx, uint64_t seed, int sample, uint64_t firs
                            int read_len, uint64_t genome_scale_bp, void *d_bases, void *d_offsets);
 int  mf_synth_reads_host(uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads, int read_len,
                          uint64_t genome_scale_bp, uint8_t *bases, uint64_t *offsets);
+/* the same with the substitution rate as a parameter: sub_per_16384 substitutions per 16384 bases (82 = the 0.5 % above,
+ * 164 = 1 %: BASELINE.json config 5, "generator scaled: pool 2 Gbp, error 1 %") */
+int  mf_synth_reads_device_ex(mf_ctx *ctx, uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads,
+                              int read_len, uint64_t genome_scale_bp, int sub_per_16384, void *d_bases, void *d_offsets);
+int  mf_synth_reads_host_ex(uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads, int read_len,
+                            uint64_t genome_scale_bp, int sub_per_16384, uint8_t *bases, uint64_t *offsets);
 
 #ifdef __cplusplus
 }

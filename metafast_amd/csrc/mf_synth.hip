@@ -5,7 +5,8 @@
 //           2 % of every genome is a copy of a stretch of another pool member (shared repeats)
 //  sample s uses genomes (32 s + j) mod 128, j = 0..63 (neighbouring samples share 32 genomes) with
 //           log-normal-like abundances: exponent = Irwin-Hall(4 x 16 bit) * 2.164 / sigma, 2^x piecewise linear
-//  read     genome by abundance x length, uniform start, strand flip p = 1/2, substitutions p = 82/16384 (0.5 %)
+//  read     genome by abundance x length, uniform start, strand flip p = 1/2, substitutions p = 82/16384 (0.5 %;
+//           the _ex entry points take the numerator: 164 = 1 %, BASELINE config 5)
 //  alphabet reference coding A0 G1 C2 T3, complement = 3 - c; no N
 #include "mf_common.h"
 
@@ -18,6 +19,7 @@ struct mf_synth_tables {
     uint64_t cum[MF_SYNTH_NS + 1];
     uint32_t member[MF_SYNTH_NS];
     uint64_t seed_pool, seed_reads;
+    uint32_t sub_thr, pad_;                 // substitution when a 14-bit draw < sub_thr
 };
 
 __host__ __device__ __forceinline__ uint64_t mf_splitmix64(uint64_t x) {
@@ -58,12 +60,14 @@ __host__ __device__ __forceinline__ void mf_synth_read(const mf_synth_tables &T,
         if ((i & 3) == 0) e = mf_splitmix64(s0 + 16 + (uint64_t)(i >> 2));
         uint32_t x = (uint32_t)(e >> (16 * (i & 3))) & 0xFFFFu;
         uint32_t c = flip ? 3u - mf_synth_base(T, g, start + (uint64_t)(L - 1 - i)) : mf_synth_base(T, g, start + (uint64_t)i);
-        if ((x >> 2) < 82u) c = (c + 1u + (x & 3u) % 3u) & 3u;
+        if ((x >> 2) < T.sub_thr) c = (c + 1u + (x & 3u) % 3u) & 3u;
         out[i] = (uint8_t)("AGCT"[c]);
     }
 }
 
-static int mf_synth_make_tables(uint64_t seed, int sample, int read_len, uint64_t scale, mf_synth_tables *T) {
+static int mf_synth_make_tables(uint64_t seed, int sample, int read_len, uint64_t scale, int sub_per_16384, mf_synth_tables *T) {
+    if (sub_per_16384 < 0 || sub_per_16384 > 16384) return mf_set_error("mf_synth: substitutions per 16384 bases out of [0,16384]");
+    T->sub_thr = (uint32_t)sub_per_16384; T->pad_ = 0;
     if (scale < 64 || (scale / 2) < (uint64_t)read_len) return mf_set_error("mf_synth: genome_scale_bp too small for read_len");
     if (scale > (1ull << 24)) return mf_set_error("mf_synth: genome_scale_bp too large");
     T->seed_pool = mf_splitmix64(seed ^ 0x504F4F4CULL);                                  // "POOL"
@@ -115,13 +119,13 @@ __global__ void k_synth_reads(const mf_synth_tables *__restrict__ T, uint64_t fi
     mf_synth_read(S, first_read + r, L, bases + r * (uint64_t)L);
 }
 
-extern "C" int mf_synth_reads_device(mf_ctx *ctx, uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads,
-                                     int read_len, uint64_t genome_scale_bp, void *d_bases, void *d_offsets) {
+extern "C" int mf_synth_reads_device_ex(mf_ctx *ctx, uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads,
+                                        int read_len, uint64_t genome_scale_bp, int sub_per_16384, void *d_bases, void *d_offsets) {
     if (!ctx || !d_bases || !d_offsets) return mf_set_error("mf_synth_reads_device: NULL argument");
     if (read_len < 1 || read_len > 100000) return mf_set_error("mf_synth: bad read_len");
     MF_HIP(hipSetDevice(ctx->device));
     mf_synth_tables T;
-    MF_TRY(mf_synth_make_tables(seed, sample, read_len, genome_scale_bp, &T));
+    MF_TRY(mf_synth_make_tables(seed, sample, read_len, genome_scale_bp, sub_per_16384, &T));
     mf_buf<mf_synth_tables> dT; MF_TRY(dT.alloc(ctx, 1));
     MF_HIP(hipMemcpyAsync(dT.p, &T, sizeof T, hipMemcpyHostToDevice, ctx->stream));
     if (n_reads) {
@@ -136,16 +140,26 @@ extern "C" int mf_synth_reads_device(mf_ctx *ctx, uint64_t seed, int sample, uin
     return MF_OK;
 }
 
-extern "C" int mf_synth_reads_host(uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads, int read_len,
-                                   uint64_t genome_scale_bp, uint8_t *bases, uint64_t *offsets) {
+extern "C" int mf_synth_reads_device(mf_ctx *ctx, uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads,
+                                     int read_len, uint64_t genome_scale_bp, void *d_bases, void *d_offsets) {
+    return mf_synth_reads_device_ex(ctx, seed, sample, first_read, n_reads, read_len, genome_scale_bp, 82, d_bases, d_offsets);
+}
+
+extern "C" int mf_synth_reads_host_ex(uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads, int read_len,
+                                      uint64_t genome_scale_bp, int sub_per_16384, uint8_t *bases, uint64_t *offsets) {
     if (!bases || !offsets) return mf_set_error("mf_synth_reads_host: NULL argument");
     if (read_len < 1 || read_len > 100000) return mf_set_error("mf_synth: bad read_len");
     mf_synth_tables T;
-    MF_TRY(mf_synth_make_tables(seed, sample, read_len, genome_scale_bp, &T));
+    MF_TRY(mf_synth_make_tables(seed, sample, read_len, genome_scale_bp, sub_per_16384, &T));
     for (uint64_t r = 0; r < n_reads; r++) {
         offsets[r] = r * (uint64_t)read_len;
         mf_synth_read(T, first_read + r, read_len, bases + r * (uint64_t)read_len);
     }
     offsets[n_reads] = n_reads * (uint64_t)read_len;
     return MF_OK;
+}
+
+extern "C" int mf_synth_reads_host(uint64_t seed, int sample, uint64_t first_read, uint64_t n_reads, int read_len,
+                                   uint64_t genome_scale_bp, uint8_t *bases, uint64_t *offsets) {
+    return mf_synth_reads_host_ex(seed, sample, first_read, n_reads, read_len, genome_scale_bp, 82, bases, offsets);
 }

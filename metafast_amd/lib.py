@@ -97,6 +97,8 @@ _SIGS = {
     "mf_bray_curtis": (i32, [vp, i32, i32, vp]),
     "mf_synth_reads_device": (i32, [vp, u64, i32, u64, u64, i32, u64, vp, vp]),
     "mf_synth_reads_host": (i32, [u64, i32, u64, u64, i32, u64, vp, vp]),
+    "mf_synth_reads_device_ex": (i32, [vp, u64, i32, u64, u64, i32, u64, i32, vp, vp]),
+    "mf_synth_reads_host_ex": (i32, [u64, i32, u64, u64, i32, u64, i32, vp, vp]),
 }
 
 
@@ -306,9 +308,10 @@ class Context:
                                  _opt(vec_path), _opt(breadth_path)))
 
     # ---- synthetic reads ----
-    def synth_reads_device(self, seed, sample, first_read, n_reads, read_len, genome_scale_bp, d_bases, d_offsets):
-        _check(lib().mf_synth_reads_device(self.h, seed, sample, first_read, n_reads, read_len, genome_scale_bp,
-                                           C.c_void_p(d_bases), C.c_void_p(d_offsets)))
+    def synth_reads_device(self, seed, sample, first_read, n_reads, read_len, genome_scale_bp, d_bases, d_offsets, sub_per_16384=82):
+        """sub_per_16384: substitutions per 16384 bases (82 = 0.5 %, the benchmark's; 164 = 1 %, BASELINE config 5)"""
+        _check(lib().mf_synth_reads_device_ex(self.h, seed, sample, first_read, n_reads, read_len, genome_scale_bp, sub_per_16384,
+                                              C.c_void_p(d_bases), C.c_void_p(d_offsets)))
 
 
 class Table:
@@ -599,9 +602,9 @@ def bray_curtis(vecs):
     return out
 
 
-def synth_reads_host(seed, sample, first_read, n_reads, read_len, genome_scale_bp):
+def synth_reads_host(seed, sample, first_read, n_reads, read_len, genome_scale_bp, sub_per_16384=82):
     bases = np.empty(n_reads * read_len, dtype=np.uint8)
     off = np.empty(n_reads + 1, dtype=np.uint64)
-    _check(lib().mf_synth_reads_host(seed, sample, first_read, n_reads, read_len, genome_scale_bp,
-                                     bases.ctypes.data, off.ctypes.data))
+    _check(lib().mf_synth_reads_host_ex(seed, sample, first_read, n_reads, read_len, genome_scale_bp, sub_per_16384,
+                                        bases.ctypes.data, off.ctypes.data))
     return bases, off

@@ -23,7 +23,7 @@ def _check(ctx, oracle, bases, off, k, min_len=0, thr=-1):
 
 
 def _reset(ctx):
-    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0), ("skm_dyn", 1), ("skm_slices", 0), ("skm_shared", 1), ("skm_dedupe", 1), ("arena_cap_gb", 0)):
+    for name, v in (("l1_bits", -1), ("l2_bits", -1), ("part_target", 3072), ("scatter_staged", 1), ("l1_blocks", 0), ("skm", 1), ("skm_batches", 0), ("skm_dyn", 1), ("skm_slices", 0), ("skm_shared", 1), ("skm_dedupe", 1), ("arena_cap_gb", 0), ("skm_pilot", 1), ("skm_unit_distinct", 2200)):
         ctx.set_option(name, v)
 
 
@@ -419,3 +419,38 @@ def test_skm_identical_records_counted_once(gpu_ctx, oracle, dedupe):
         assert t.export()[1].max() == 32767
     finally:
         _reset(gpu_ctx)
+
+
+@pytest.mark.parametrize("scale,sub16k", [(16_000_000, 82), (1_000_000, 82), (40_000, 164)])
+def test_depth_independent_plan_against_the_oracle(gpu_ctx, oracle, scale, sub16k):
+    """1 M reads through the AUTOMATIC plan at three sequencing depths -- 0.05-fold (pool scale 16 M: every
+    k-mer nearly distinct, 8 x the distinct k-mers per occurrence the occurrence-based plan has in mind), 0.8-fold, and 20-fold with
+    1 % substitutions -- bit-identical to the oracle, with the pilot in the loop (its kernel shows up in the timers) and the
+    cut inside the kernels equal to filtering afterwards."""
+    from metafast_amd import lib as L
+    _reset(gpu_ctx)
+    gpu_ctx.set_option("profile", 1)
+    gpu_ctx.reset_timers()
+    n = 1_000_000
+    b, o = L.synth_reads_host(0x4D45544146415354, 3, 0, n, 150, scale, sub16k)
+    tb, to = to_device(b, o)
+    t = gpu_ctx.count_device(tb.data_ptr(), to.data_ptr(), n, int(o[-1]), 31, 0)
+    assert "k_skm_pilot" in gpu_ctx.kernel_report()
+    gk, gc = t.export()
+    ot = oracle.Table().count_buffer(b, o, 31)
+    ok, ov = ot.export()
+    assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+    assert t.occurrences() == n * 120
+    t2, n_all = gpu_ctx.count_device_above(tb.data_ptr(), to.data_ptr(), n, int(o[-1]), 31, 1)
+    assert n_all == len(gk)
+    k2, c2 = t2.export()
+    keep = gc > 1
+    assert np.array_equal(k2, gk[keep]) and np.array_equal(c2, gc[keep])
+    h = t2.hist()
+    assert int(h.sum()) == len(gk) and int(h[1]) == int((gc == 1).sum())
+    gpu_ctx.set_option("skm_pilot", 0)                      # the plan from the occurrences alone: the same table
+    t3 = gpu_ctx.count_device(tb.data_ptr(), to.data_ptr(), n, int(o[-1]), 31, 0)
+    gpu_ctx.set_option("skm_pilot", 1)
+    k3, c3 = t3.export()
+    assert np.array_equal(k3, gk) and np.array_equal(c3, gc)
+    gpu_ctx.set_option("profile", 0)
