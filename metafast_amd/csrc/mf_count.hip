@@ -22,7 +22,7 @@
 #include <vector>
 
 int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
-                 int k, const std::vector<int> &lv, bool adaptive, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out);
+                 int k, const std::vector<int> &lv, bool adaptive, int table_bits, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out);
 
 // =============================================================================================
 // K0: valid-start bitmap
@@ -664,6 +664,11 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
         std::vector<int> slv = lv;
         if (ctx->opt_l1_bits < 0) {
             int Bc = B > 0 ? B - 1 : 0;
+            // (assembled sequences: nearly every k-mer distinct, and the table's partitions are planned small for the graph kernels --
+            // 256 occurrences -- where the counting kernel pays four workgroup barriers and a sweep of its LDS table per unit: it
+            // counts EIGHT table partitions as one unit (~2000 distinct k-mers, k_gather_split_n cuts them apart); the cutter-table
+            // launch of the benchmark cost 13 x the sample's time per occurrence with units of two)
+            if (assembled) Bc = std::max(0, B - (int)ctx->opt_unit_parts_long);
             if (ctx->own_world > 1) { int lw = 0; while ((1 << lw) < ctx->own_world) lw++; if (Bc < lw) Bc = lw; }
             slv.clear();
             const int levels = std::max(1, (Bc + MF_MAX_DIGIT_BITS - 1) / MF_MAX_DIGIT_BITS);
@@ -673,7 +678,8 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
                 slv = {MF_MAX_DIGIT_BITS, MF_MAX_DIGIT_BITS};
         }
         // (reads: the plan is provisional -- a pilot measures the distinct k-mers per occurrence and sets the later levels, mf_skm.hip)
-        int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, slv, ctx->opt_l1_bits < 0 && !assembled, scal.p, thr, n_all, out);
+        int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, slv, ctx->opt_l1_bits < 0 && !assembled,
+                              ctx->opt_l1_bits < 0 && assembled ? B : 0, scal.p, thr, n_all, out);
         if (rc != MF_SKM_FALLBACK) return rc;
     }
     if (ctx->own_world > 1) return mf_set_error("mf_count_device_shard: the input does not suit the minimizer-partition path");

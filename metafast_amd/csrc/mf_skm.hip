@@ -677,7 +677,7 @@ __device__ __forceinline__ uint32_t skm_pass_of(uint64_t key) {
 #define C2_ITEMS 848             // item entries per wave: 64 records x 10 items + two steps of padding (the read-ahead of the last step runs past them, unused) + the dummy area of the item stores
 #define C2_W 2                   // k-mers per item
 #define C2_DD 4                  // records per thread of a unit whose identical records are counted once (k_skm_count): units of up to C2_DD * SKM_CT records
-static constexpr size_t C2_LDS = (size_t)C2_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8 + C2_QN * 2) + 2 * C2_LH * 4 + 32;
+static constexpr size_t C2_LDS = (size_t)C2_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8 + C2_QN * 2) + 2 * C2_LH * 4 + 48;
 static_assert(C2_LDS <= 80 * 1024, "two workgroups per CU");
 
 __device__ __forceinline__ uint32_t c2_swap_pairs(uint32_t x) {                 // exchanges the two bits of every base
@@ -902,7 +902,13 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                                                            unsigned int *__restrict__ overflow, uint32_t p0, uint64_t tbase, int thr,
                                                            unsigned long long *__restrict__ n_all,
                                                            unsigned int *__restrict__ n_redo, unsigned long long *__restrict__ drop_hist,
-                                                           unsigned long long *__restrict__ prof_out, uint64_t tcap, uint32_t dedupe) {
+                                                           unsigned long long *__restrict__ prof_out, uint64_t tcap, uint32_t dedupe,
+                                                           unsigned int *__restrict__ unit_ctr) {
+    // unit_ctr != nullptr (zero at launch): units are handed out as the workgroups get to them (round 4).  A workgroup's first three
+    // units are blockIdx.x + {0, 1, 2} x gridDim.x; every further one is claimed from the counter THREE units ahead -- the directory entry
+    // of a unit is asked for two units ahead, and the claim passes through LDS behind a barrier of the unit before that.  With the
+    // fixed stride a workgroup's 1024 units add up to a total that differs by a few per cent from workgroup to workgroup (heavy
+    // minimizers counted in several passes among them), and a launch ends when the slowest is done.
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long tlast = PROF ? clock64() : 0;
     // partitions [p0, np); slice of p in tkeys / tcnt starts at toff[p] - tbase; thr >= 0: entries with count <= thr are
     // dropped and tallied in drop_hist[count] (thr < C2_LH); *n_all += distinct k-mers before the cut.
@@ -924,6 +930,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     uint32_t (*pflags)[2] = reinterpret_cast<uint32_t (*)[2]>(lhist_try + C2_LH);            // [parity][1] part_over
     uint32_t &out_cursor = lhist_try[C2_LH + 4], &blk_claims = lhist_try[C2_LH + 6];
     uint32_t &dd_gone = lhist_try[C2_LH + 5], &dd_all = lhist_try[C2_LH + 7];                // records that dropped out / that were looked at, of the last such unit
+    uint32_t &claim = lhist_try[C2_LH + 8];                                                  // the unit claimed for three units ahead (unit_ctr)
     c2_wave L;
     L.tk0 = mf_lds_addr(tk); L.tc0 = mf_lds_addr(tc);
     L.rb0 = mf_lds_addr(rbuf_all + wave * 64);
@@ -1059,7 +1066,8 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         return q;
     };
     dirent dn = {0, 0, 0, 0};
-    if (ui + gridDim.x < nu) dn = load_dir(ui + gridDim.x);
+    uint32_t un = ui + gridDim.x, unn = ui + 2u * gridDim.x;                   // the next unit, and the one after it
+    if (un < nu) dn = load_dir(un);
     // (settled before the loop: a load still pending on entry would make the compiler wait at the loop's top -- behind the
     // directory loads it has just issued there -- on every iteration)
     asm volatile("" :: "v"(R[0].x), "v"(R[0].y), "v"(R[1].x), "v"(R[1].y), "v"(R[2].x), "v"(R[2].y), "v"(R[3].x), "v"(R[3].y),
@@ -1069,7 +1077,8 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     __syncthreads();
     uint32_t parity = 0;
     for (;;) {
-        const uint32_t un = ui + gridDim.x, unn = un + gridDim.x;
+        uint32_t claimed = 0; bool claim_pending = false;
+        if (unit_ctr && threadIdx.x == 0) { claimed = atomicAdd(unit_ctr, 1u); claim_pending = true; }      // (in flight until the unit's first barrier B1)
         dirent dnn = {0, 0, 0, 0};
         bool dnn_asked = false;
         const uint64_t start_n = sn.start;
@@ -1242,6 +1251,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         if (won_acc) { if (lane == 0) atomicAdd(&blk_claims, won_acc); won_acc = 0; }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the LDS operations of the asm blocks are invisible to hipcc's waitcnt pass
         C2_TICK(3);                                                             // last drains
+        if (claim_pending) { claim = 3u * gridDim.x + claimed; claim_pending = false; }
         c2_barrier();                                                           // ---- B1: every insert of the pass is done
         C2_TICK(4);                                                             // waiting for the other waves
         const bool over = c2_lds_u32(part_over) != 0u || c2_lds_u32(&blk_claims) > (uint32_t)C2_FILL;
@@ -1363,7 +1373,8 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         }
         if (threadIdx.x == 0) { dcount[p0 + ui] = out_cursor; out_cursor = 0; }
         if (un >= nu) break;
-        ui = un; start = start_n; len = len_n;
+        ui = un; un = unn; unn = unit_ctr ? c2_lds_u32(&claim) : unn + gridDim.x;
+        start = start_n; len = len_n;
         o = sn.o; room = sn.room;
         sn = snn;
     }
@@ -1415,6 +1426,75 @@ __global__ __launch_bounds__(256) void k_gather_split(const uint64_t *__restrict
             dfine[2 * (size_t)p + 1] = dbase + o + front;
             if (p + 1 == np) dfine[2 * (size_t)np] = dbase + coff[np];
         }
+    }
+}
+// The same with every counting partition cut in 2^S table partitions, S = 0 ... 4 (round 4): what the counting kernel likes --
+// units of ~2000 distinct k-mers, it pays four workgroup barriers and a sweep of its table per unit -- and what the graph kernels
+// like -- ~170 k-mers per table partition, their LDS lookup table takes 352 -- are further apart than a factor of two for
+// assembled sequences (the cutter's input: nearly every k-mer distinct, 256 occurrences per table partition) and for shallow
+// reads (most distinct k-mers survive the cut).  Two passes over a partition's entries: the bins (the next S bits of each
+// k-mer's partition hash) are counted and parked in LDS, then every entry goes to its bin's range; partitions of more than
+// GS_CAP entries (counted in several passes: rare) hash twice instead.
+#define GS_CAP 4096
+template <int K>
+__global__ __launch_bounds__(256) void k_gather_split_n(const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnt,
+                                                        const uint64_t *__restrict__ pstart, const uint32_t *__restrict__ dcount,
+                                                        const uint64_t *__restrict__ coff, uint32_t np, uint64_t *__restrict__ dk,
+                                                        uint16_t *__restrict__ dc, uint32_t p0, uint64_t sbase, uint64_t *__restrict__ dfine,
+                                                        uint64_t dbase, int bit, int S) {
+    // bit: position of the lowest of the S bits in the partition hash; dfine[(p << S) + b]: first entry of table partition b of p
+    __shared__ uint8_t bins_all[4][GS_CAP];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    uint8_t *const bins = bins_all[wave];
+    const uint32_t nb = 1u << S, bmask = nb - 1u;
+    for (uint32_t p = p0 + blockIdx.x * 4u + wave; p < np; p += gridDim.x * 4u) {
+        const uint64_t s = pstart[p] - sbase, o = coff[p];
+        const uint32_t d = dcount[p];
+        const bool park = d <= (uint32_t)GS_CAP;
+        uint32_t start[16];                                                 // wave-uniform
+#pragma unroll
+        for (int b = 0; b < 16; b++) start[b] = 0;
+        for (uint32_t j0 = 0; j0 < d; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const bool have = j < d;
+            const uint64_t key = have ? keys[s + j] : 0ull;
+            const uint32_t bin = (mf_skm_ph(key, K) >> bit) & bmask;
+            if (park && have) bins[j] = (uint8_t)bin;
+#pragma unroll
+            for (int b = 0; b < 16; b++)
+                if ((uint32_t)b < nb) start[b] += (uint32_t)__popcll(__ballot(have && bin == (uint32_t)b));
+        }
+        {   // counts -> first entries
+            uint32_t acc = 0;
+#pragma unroll
+            for (int b = 0; b < 16; b++) { const uint32_t c = start[b]; start[b] = acc; acc += c; }
+        }
+        if (lane < nb) {
+            uint32_t mine = 0;
+#pragma unroll
+            for (int b = 0; b < 16; b++) if (lane == (uint32_t)b) mine = start[b];
+            dfine[((size_t)p << S) + lane] = dbase + o + mine;
+        }
+        if (lane == 0 && p + 1 == np) dfine[(size_t)np << S] = dbase + coff[np];
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t j0 = 0; j0 < d; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const bool have = j < d;
+            const uint64_t key = have ? keys[s + j] : 0ull;
+            const uint16_t c = have ? cnt[s + j] : (uint16_t)0;
+            const uint32_t bin = park ? (have ? (uint32_t)bins[j] : 0u) : ((mf_skm_ph(key, K) >> bit) & bmask);
+            uint32_t pos = 0;
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                if ((uint32_t)b < nb) {
+                    const unsigned long long m = __ballot(have && bin == (uint32_t)b);
+                    if (bin == (uint32_t)b) pos = start[b] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    start[b] += (uint32_t)__popcll(m);
+                }
+            }
+            if (have) { dk[o + pos] = key; dc[o + pos] = c; }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 __global__ void k_skm_add_base(uint64_t *__restrict__ v, uint64_t n, uint64_t base) {
@@ -1485,9 +1565,9 @@ __global__ void k_skm_pilot_dir(const uint32_t *__restrict__ cnt, uint32_t n, ui
 // -> *rho = distinct k-mers per occurrence among the sampled units (< 0: nothing sampled); bufA / pstart / plen: level 1 (indexed by digit)
 template <int K>
 static int skm_pilot(mf_ctx *ctx, const skm_rec *bufA, const uint64_t *pstart, const uint32_t *plen, uint32_t dlo, uint32_t dhi, uint64_t n_occ, int nd1,
-                     int bits_planned, int kthr, double *rho) {
+                     int bits_planned, int kthr, double *rho, double *kept) {
     hipStream_t st = ctx->stream;
-    *rho = -1.0;
+    *rho = -1.0; *kept = -1.0;
     if (dhi <= dlo) return MF_OK;
     const uint32_t R = std::min<uint32_t>(8u, dhi - dlo);
     const int pb = std::min((int)SKM_DIGIT_BITS, bits_planned + 3);                       // would-be units an eighth of the planned size
@@ -1526,16 +1606,19 @@ static int skm_pilot(mf_ctx *ctx, const skm_rec *bufA, const uint64_t *pstart, c
         const unsigned grid = (unsigned)std::min<uint64_t>(nb, (uint64_t)ctx->n_cu * 2);
         // ps: [2] overflow [3] distinct before the cut [4] units redone [8..24) diagnostics
         k_skm_count<K, false><<<grid, SKM_CT, C2_LDS, st>>>(pr.p, ostart.p, uplen.p, nb, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&ps.p[2], 0u, (uint64_t)0, kthr,
-                                                         &ps.p[3], (unsigned int *)&ps.p[4], nullptr, &ps.p[8], (uint64_t)tot[1], (uint32_t)ctx->opt_skm_dedupe);
+                                                         &ps.p[3], (unsigned int *)&ps.p[4], nullptr, &ps.p[8], (uint64_t)tot[1], (uint32_t)ctx->opt_skm_dedupe, nullptr);
     }
-    unsigned long long res[3] = {0, 0, 0};
-    MF_HIP(hipMemcpyAsync(res, &ps.p[2], 24, hipMemcpyDeviceToHost, st));
+    MF_TRY(mf_scan<1>(ctx, dcount.p, ostart.p, nb, (uint64_t *)&ps.p[5]));                // [5] k-mers that survive the cut
+    unsigned long long res[4] = {0, 0, 0, 0};
+    MF_HIP(hipMemcpyAsync(res, &ps.p[2], 32, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
     MF_HIP(hipGetLastError());
-    *rho = (res[0] & 0xFFFFFFFFull) ? 1.0 : (double)res[1] / (double)tot[1];              // (a unit beyond 64 passes at an eighth of the size: plan as fine as it gets)
+    const bool over = (res[0] & 0xFFFFFFFFull) != 0;
+    *rho = over ? 1.0 : (double)res[1] / (double)tot[1];              // (a unit beyond 64 passes at an eighth of the size: plan as fine as it gets)
+    if (!over) *kept = (double)res[3] / (double)tot[1];
     if (ctx->opt_verbose)
-        fprintf(stderr, "[mf] skm pilot: %u would-be units of %u regions (2^%d per region): %llu records, %llu occurrences, %llu distinct k-mers = %.4f per occurrence, %llu unit(s) redone\n",
-                nb, R, pb, tot[0], tot[1], res[1], *rho, res[2] & 0xFFFFFFFFull);
+        fprintf(stderr, "[mf] skm pilot: %u would-be units of %u regions (2^%d per region): %llu records, %llu occurrences, %llu distinct k-mers = %.4f per occurrence (%llu kept), %llu unit(s) redone\n",
+                nb, R, pb, tot[0], tot[1], res[1], *rho, res[3], res[2] & 0xFFFFFFFFull);
     return MF_OK;
 }
 
@@ -1549,6 +1632,8 @@ struct skm_acc {
     mf_buf<unsigned long long> dhist, c2p;
     unsigned long long n_records = 0, cap_l1 = 0;
     uint32_t np_total = 0;
+    int split_bits = 1;                    // table partitions per counting partition = 2^split_bits (k_gather_split / k_gather_split_n)
+    int table_bits = 0;                    // the caller's wish for the table (0: one bit more than the counting plan)
 };
 #define MF_SKM_NOMEM 2             /* skm_slice: a record buffer did not fit -- the caller tries again with more slices */
 // Level 1 of a run that is counted in slices, done ONCE for all the run's digits (round 3): round 2's slices each scanned the reads
@@ -1696,11 +1781,12 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         rebase = SH->h_pstart[dlo];
         cap = (dhi < (uint32_t)nd1 ? SH->h_pstart[dhi] : SH->cap) - rebase;
     }
+    bool split_from_pilot = false;
     if (open) {
         // ---- the pilot: distinct k-mers per occurrence -> the levels after the first
         *plan_open = false;
-        double rho = -1.0;
-        MF_TRY(skm_pilot<K>(ctx, bufA.p, pstart.p, plen.p, dlo, dhi, n_occ, nd1, total_bits - bits1, kthr, &rho));
+        double rho = -1.0, kept = -1.0;
+        MF_TRY(skm_pilot<K>(ctx, bufA.p, pstart.p, plen.p, dlo, dhi, n_occ, nd1, total_bits - bits1, kthr, &rho, &kept));
         ctx->last_pilot_rho = rho;
         if (rho > 0.0) {
             const double want_units = (double)n_occ * rho / (double)std::max<int64_t>(64, ctx->opt_skm_unit_distinct);
@@ -1710,10 +1796,20 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             lv.resize(1);
             if (r <= MF_MAX_DIGIT_BITS) lv.push_back(r); else { lv.push_back((r + 1) / 2); lv.push_back(r / 2); }
             total_bits = 0; for (int b : lv) total_bits += b;
+            if (kthr >= 0 && kept >= 0.0 && !A.doff.p) {
+                // the table holds the k-mers that survive the cut: as many table partitions per counting unit as keep a partition
+                // within the graph kernels' LDS lookup table (mf_nbr.h: 352 keys; 100 M reads of the benchmark: 343 per unit -> 2 x 172)
+                const double per_unit = (double)n_occ * kept / (double)(1ull << total_bits);
+                int sb = 0; while (sb < 4 && per_unit / (double)(1 << sb) > (double)ctx->opt_part_good) sb++;
+                A.split_bits = sb; split_from_pilot = true;
+                if (ctx->opt_verbose) fprintf(stderr, "[mf] skm pilot: %.4f k-mers per occurrence survive the cut: %.0f per counting unit -> %d table partition(s) per unit\n", kept, per_unit, 1 << sb);
+            }
         }
     }
     if (!A.doff.p) {                                      // (the first slice of the run, now that the plan stands)
-        A.np_total = (uint32_t)(1ull << (total_bits + 1)); // partitions of the table: two per counting partition
+        if (!split_from_pilot) A.split_bits = A.table_bits > 0 ? std::max(0, std::min(4, A.table_bits - total_bits)) : 1;
+        if (total_bits + A.split_bits > 30) A.split_bits = 30 - total_bits;
+        A.np_total = (uint32_t)(1ull << (total_bits + A.split_bits));      // partitions of the table: 2^split_bits per counting partition
         MF_TRY(A.doff.alloc(ctx, (size_t)A.np_total + 1));
     }
     MF_HIP(hipMemsetAsync(&scal[6], 0, 8, st));           // [6] records without padding ([7] distinct k-mers before the cut: whole run)
@@ -1815,10 +1911,10 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         if (p0 == p1) continue;
         {
             const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);      // resident workgroups
-            MF_HIP(hipMemsetAsync(&scal[8], 0, 8, st));
+            MF_HIP(hipMemsetAsync(&scal[8], 0, 16, st));                     // ([8] units redone, [9] the unit counter)
             mf_ktimer t(ctx, "k_skm_count");
 #define SKM_COUNT_ARGS bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2], p0, (uint64_t)tb[b], kthr, &scal[7], \
-                       (unsigned int *)&scal[8], dhist.p, c2p.p, (uint64_t)tmax, (uint32_t)ctx->opt_skm_dedupe
+                       (unsigned int *)&scal[8], dhist.p, c2p.p, (uint64_t)tmax, (uint32_t)ctx->opt_skm_dedupe, (ctx->opt_skm_dynq ? (unsigned int *)&scal[9] : nullptr)
             if (c2prof) k_skm_count<(K == 31 ? 31 : 20), true><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
             else k_skm_count<K, false><<<grid, SKM_CT, C2_LDS, st>>>(SKM_COUNT_ARGS);
 #undef SKM_COUNT_ARGS
@@ -1869,8 +1965,12 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         {
             const unsigned grid = (unsigned)std::min<uint64_t>(((uint64_t)(p1 - p0) + 3) / 4, (uint64_t)ctx->n_cu * 32);
             mf_ktimer t(ctx, "k_gather");
-            k_gather_split<K><<<grid, 256, 0, st>>>(tkeys.p, tcnt.p, toff.p, dcount.p, coff.p, p1, dk.p + dused, dc.p + dused, p0, (uint64_t)tb[b],
-                                                    doffp, dused, 31 - total_bits);
+            if (A.split_bits == 1)
+                k_gather_split<K><<<grid, 256, 0, st>>>(tkeys.p, tcnt.p, toff.p, dcount.p, coff.p, p1, dk.p + dused, dc.p + dused, p0, (uint64_t)tb[b],
+                                                        doffp, dused, 31 - total_bits);
+            else
+                k_gather_split_n<K><<<grid, 256, 0, st>>>(tkeys.p, tcnt.p, toff.p, dcount.p, coff.p, p1, dk.p + dused, dc.p + dused, p0, (uint64_t)tb[b],
+                                                          doffp, dused, std::min(31, 32 - total_bits - A.split_bits), A.split_bits);
         }
         MF_DBG(ctx, "k_gather");
         dused += d_b;
@@ -1893,7 +1993,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
 // input does not suit this path (a partition too rich for the LDS table, too many levels, not enough memory).
 template <int K>
 static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words,
-                   uint64_t n_occ, const std::vector<int> &lv0, bool adaptive, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
+                   uint64_t n_occ, const std::vector<int> &lv0, bool adaptive, int table_bits, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
     hipStream_t st = ctx->stream;
     std::vector<int> lv = lv0;                 // (the levels after the first may change once the pilot has measured the reads' depth)
     const int bits1 = lv[0], nd1 = 1 << bits1;
@@ -1960,6 +2060,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     bool plan_open = adaptive && ctx->opt_skm_pilot != 0 && lv.size() >= 2 && W == 1;
     for (;;) {
         skm_acc A;                                              // (A.np_total, A.doff: set by the first slice, once the plan stands)
+        A.table_bits = table_bits;
         if (kthr >= 0) { MF_TRY(A.dhist.alloc(ctx, (size_t)MF_MAX_COUNT + 1)); MF_HIP(hipMemsetAsync(A.dhist.p, 0, A.dhist.bytes(), st)); }
         MF_TRY(A.c2p.alloc(ctx, 16)); MF_HIP(hipMemsetAsync(A.c2p.p, 0, 128, st));     // [0,8) phase cycles (profiling build), [8,16) overflow diagnostics
         MF_HIP(hipMemsetAsync(&scal[7], 0, 8, st));
@@ -2029,8 +2130,8 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             }
             (*out)->record_bytes = 16;
         }
-        if (total_bits + 1 <= 30) {
-            (*out)->part_bits = total_bits + 1;
+        if (total_bits + A.split_bits <= 30) {
+            (*out)->part_bits = total_bits + A.split_bits;
             (*out)->part_skm = 1;
             (*out)->part_off_bytes = A.doff.bytes();
             (*out)->d_part_off = A.doff.take();
@@ -2040,11 +2141,12 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
 }
 
 // adaptive: the plan was made from the number of occurrences alone -- the levels after the first may be re-planned from a pilot
+// table_bits: partition bits the caller wants the TABLE to have (0: one more than the counting plan's)
 int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
-                 int k, const std::vector<int> &lv, bool adaptive, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
+                 int k, const std::vector<int> &lv, bool adaptive, int table_bits, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
     int rc = MF_SKM_FALLBACK;
     switch (k) {
-#define SKM_CASE(KK) case KK: rc = skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, adaptive, scal, thr, n_all, out); break;
+#define SKM_CASE(KK) case KK: rc = skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, adaptive, table_bits, scal, thr, n_all, out); break;
 #ifndef MF_SKM_ONLY_K31              /* (a quick look at one instantiation's code: hipcc -DMF_SKM_ONLY_K31 -S) */
         SKM_CASE(20) SKM_CASE(21) SKM_CASE(22) SKM_CASE(23) SKM_CASE(24) SKM_CASE(25)
         SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29) SKM_CASE(30)
