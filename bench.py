@@ -152,6 +152,114 @@ def cpu_baseline(bases, offsets, n_reads, rl, k, args):
                 reference_java=_reference_java(hb[: m2 * rl], ho, k, cores))
 
 
+def _write_fasta(bases_dev, m, rl, path):
+    """the first m reads of a sample in HBM -> a FASTA file (">r", one line per read), in pieces of 2 M reads"""
+    with open(path, "wb") as f:
+        for lo in range(0, m, 2_000_000):
+            hi = min(m, lo + 2_000_000)
+            hb = bases_dev[lo * rl: hi * rl].cpu().numpy()
+            rec = np.empty((hi - lo, rl + 4), dtype=np.uint8)       # ">r\n" + bases + "\n"
+            rec[:, 0], rec[:, 1], rec[:, 2], rec[:, rl + 3] = ord(">"), ord("r"), 10, 10
+            rec[:, 3:rl + 3] = hb.reshape(hi - lo, rl)
+            rec.tofile(f)
+    return os.path.getsize(path)
+
+
+def _log_steps(log_path):
+    """seconds per tool run from the time stamps of the driver's log ("dd-MMM-yy  HH:mm:ss,SSS  DEBUG  Running tool X")"""
+    import datetime, re
+    marks = []
+    try:
+        for ln in open(log_path, errors="replace"):
+            m = re.match(r"(\d\d-\w+-\d\d\s+\d\d:\d\d:\d\d),(\d\d\d)\s+\w+\s+(.*)", ln)
+            if not m:
+                continue
+            t = datetime.datetime.strptime(m.group(1), "%d-%b-%y  %H:%M:%S").timestamp() + int(m.group(2)) / 1e3
+            marks.append((t, m.group(3)))
+    except OSError:
+        return {}
+    steps, cur = {}, None
+    for t, msg in marks:
+        if msg.startswith("Running tool "):
+            if cur:
+                steps[cur[1]] = round(steps.get(cur[1], 0.0) + t - cur[0], 3)
+            cur = (t, msg[len("Running tool "):].strip())
+    if cur and marks:
+        steps[cur[1]] = round(steps.get(cur[1], 0.0) + marks[-1][0] - cur[0], 3)
+    return steps
+
+
+def end_to_end_and_cli(ctx, n_reads, rl, k, args, device, sample0):
+    """"end-to-end k-mers/s (including file read + H2D) is a separate line".  Two figures, never `value`:
+    end_to_end -- the first --e2e-reads reads of the benchmark sample as a FASTA file (written untimed, page cache) through
+                  mf_count_reads_above (read + parse + H2D + count) -> unitigs -> cutter -> components -> features -> matrix,
+                  the reference's path with its reader in it (src/io/IOUtils.java:772-803, src/io/ReadsDispatcher.java:34-53);
+    cli        -- `metafast.sh -k K -i a.fa b.fa -w <workDir>` on two samples of --cli-reads reads each: the drop-in a user runs,
+                  every step through the reference's files (kmers/*.kmers.bin, sequences/*.seq.fasta, components.bin,
+                  features/*.vec, matrices/...), process start and device set-up included; seconds per tool from the workDir's log."""
+    import shutil, subprocess, tempfile
+    from metafast_amd import pipeline as P
+    out = {}
+    td = tempfile.mkdtemp(prefix="mf_e2e_", dir=os.environ.get("MF_TMPDIR"))
+    sub16k = int(round(args.sub_rate * 16384))
+    try:
+        # (run BEFORE the benchmark sample exists: the drop-in's child process then meets the device as a user's would -- after the
+        # 100 M-read steps its first kernels waited 0.9 s for memory this process had used to be cleared for it)
+        mm = max(min(args.e2e_reads, n_reads), min(args.cli_reads, n_reads))
+        bases = torch.zeros(mm * rl + 64, dtype=torch.uint8, device=device)
+        offs = torch.zeros(mm + 1, dtype=torch.int64, device=device)
+        ctx.synth_reads_device(SEED, sample0, 0, mm, rl, args.genome_scale, bases.data_ptr(), offs.data_ptr(), sub16k)      # = the first reads of the benchmark sample
+        torch.cuda.synchronize()
+        m = min(args.e2e_reads, n_reads)
+        fa = os.path.join(td, "e2e.fa")
+        size = _write_fasta(bases, m, rl, fa)
+        best = None
+        for _ in range(2):                                # (second pass: arena warm, as in a run over many samples)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            r = P.run_samples(ctx, [(fa,)], k=k, b=1, l=100, b1=args.b1, b2=args.b2, device=device)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            occ = r["n_occ"]
+            for x in r["goods"] + r["seqss"] + [r["cutter"], r["comps"]]:
+                x.close()
+            best = dt if best is None else min(best, dt)
+        out["end_to_end"] = dict(value=round(occ / best, 1), unit="k-mers/s", reads=m, fasta_GB=round(size / 1e9, 3), seconds=round(best, 4),
+                                 fasta_GBps=round(size / 1e9 / best, 2),
+                                 what="FASTA file (page cache) -> read + parse + H2D + count + unitigs + cutter + components + features + matrix, one process, tables stay in HBM")
+        os.remove(fa)
+        # ---- the drop-in command line on two samples
+        mc = min(args.cli_reads, n_reads)
+        files = []
+        f0 = os.path.join(td, "sample_a.fa")
+        _write_fasta(bases, mc, rl, f0)
+        files.append(f0)
+        ctx.synth_reads_device(SEED, sample0 + 1, 0, mc, rl, args.genome_scale, bases.data_ptr(), offs.data_ptr(), sub16k)
+        torch.cuda.synchronize()
+        f1 = os.path.join(td, "sample_b.fa")
+        size2 = _write_fasta(bases, mc, rl, f1)
+        files.append(f1)
+        del bases, offs
+        # (nothing is handed back to the driver here: VRAM a process frees is cleared when the next process gets it -- 35 ms per GiB
+        # inside the child's hipMalloc, 0.9 s of its first count -- and the child fits beside this process: ~10 of the 288 GB)
+        wd = os.path.join(td, "wd")
+        t0 = time.perf_counter()
+        p = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", str(k), "-i", *files, "-w", wd], capture_output=True, text=True, cwd=td)
+        dt = time.perf_counter() - t0
+        if os.environ.get("MF_IO_TIMING"):
+            print("\n".join(ln for ln in p.stderr.splitlines() if ln.startswith("[mf]")), file=sys.stderr)
+        occ2 = 2 * mc * (rl - k + 1)
+        if p.returncode == 0:
+            out["cli"] = dict(value=round(occ2 / dt, 1), unit="k-mers/s", samples=2, reads_per_sample=mc, fasta_GB=round(2 * size2 / 1e9, 3), seconds=round(dt, 3),
+                              step_seconds=_log_steps(os.path.join(wd, "log")),
+                              what="metafast.sh -k %d -i a.fa b.fa -w wd: matrix-builder, every step through the reference's files, process start included" % k)
+        else:
+            out["cli"] = dict(error=p.stderr[-400:])
+    finally:
+        shutil.rmtree(td, ignore_errors=True)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -169,6 +277,9 @@ def main():
     ap.add_argument("--cpu-sample-reads", type=int, default=8_000_000, help="reads of the with-reader CPU baseline (FASTA file)")
     ap.add_argument("--cpu-count-only-reads", type=int, default=4_000_000, help="reads of the parser-free CPU baseline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end line (FASTA file -> matrix)")
+    ap.add_argument("--cli-reads", type=int, default=20_000_000, help="reads per sample of the metafast.sh line (two samples)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end / cli keys")
     ap.add_argument("--b1", type=int, default=1000)
     ap.add_argument("--b2", type=int, default=10000)
     args = ap.parse_args()
@@ -201,8 +312,17 @@ def main():
         name, val = kv.split("=")
         ctx.set_option(name, int(val))
 
-    # ---- synthetic sample of this rank, generated in HBM (untimed) ----
     n_reads, rl, k = args.reads, args.read_len, args.k
+    spg = max(1, args.samples_per_gpu)
+    e2e = {}
+    if not args.no_end_to_end and world == 1:
+        try:
+            e2e = end_to_end_and_cli(ctx, n_reads, rl, k, args, device, rank * spg)
+        except Exception as ex:                       # (never costs the headline line)
+            e2e = {"end_to_end": {"error": repr(ex)[:300]}, "cli": {"error": "not run"}}
+        ctx.reset_timers()
+
+    # ---- synthetic sample of this rank, generated in HBM (untimed) ----
     n_bases = n_reads * rl
     bases = torch.zeros(n_bases + 64, dtype=torch.uint8, device=device)
     offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
@@ -330,6 +450,7 @@ def main():
         cpu = None
         if not args.no_cpu_baseline and world == 1:       # reported at N=1 only
             cpu = cpu_baseline(bases, offsets, n_reads, rl, k, args)
+
         out = {
             "metric": "k-mers/s counted+graphed at k=31, 150 bp reads",
             "value": round(total_occ * args.steps / elapsed, 1),
@@ -345,6 +466,8 @@ def main():
             "roofline": roof(dom),
             "roofline_hash_count": roof("k_skm_count" if "k_skm_count" in kern else "k_count"),
             "cpu_baseline": cpu,
+            "end_to_end": e2e.get("end_to_end"),
+            "cli": e2e.get("cli"),
             "stats": stats,
             # the sharded cutter's exchanges on rank 0 (world > 1): collectives per step, bytes received per step, seconds inside
             # them (each timed with a stream synchronisation on both sides; not measurable on this pool's 1-GPU boxes)

@@ -184,7 +184,22 @@ struct Env {
     string start_ts;
 };
 static mf_ctx *ctx_of(Env &e, const Args &a) {
-    if (!e.ctx) check(mf_ctx_create(a.geti("device", 0), a.geti("available-processors", (int)sysconf(_SC_NPROCESSORS_ONLN)), &e.ctx));
+    if (!e.ctx) {
+        check(mf_ctx_create(a.geti("device", 0), a.geti("available-processors", (int)sysconf(_SC_NPROCESSORS_ONLN)), &e.ctx));
+        // the steps of one run hand their results on through the reference's files; what a step has just written stays in HBM for the
+        // step that loads it next (a quarter of the device's memory at most; MF_FILE_CACHE=0 switches it off)
+        const char *fc = getenv("MF_FILE_CACHE");
+        check(mf_ctx_set_option(e.ctx, "file_cache", fc ? atoll(fc) : -1));
+        if (const char *mo = getenv("MF_OPTIONS")) {                      // library options for A/B runs: MF_OPTIONS=name=value,name=value
+            string all(mo); size_t i = 0;
+            while (i < all.size()) {
+                size_t j = all.find(',', i); if (j == string::npos) j = all.size();
+                const string kv = all.substr(i, j - i); const size_t q = kv.find('=');
+                if (q != string::npos) check(mf_ctx_set_option(e.ctx, kv.substr(0, q).c_str(), atoll(kv.c_str() + q + 1)));
+                i = j + 1;
+            }
+        }
+    }
     return e.ctx;
 }
 static vector<const char *> cptrs(const vector<string> &v) { vector<const char *> p; for (auto &s : v) p.push_back(s.c_str()); return p; }
@@ -712,7 +727,13 @@ static vector<PV> tool_inputs(const string &tool, const Args &a, const string &w
     return v;
 }
 
+static double since_start() {
+    static struct timespec t0 = [] { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t; }();
+    struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
+    return (t.tv_sec - t0.tv_sec) + (t.tv_nsec - t0.tv_nsec) * 1e-9;
+}
 int main(int argc, char **argv) {
+    since_start();
     string tool;
     Args a = parse_args(argc, argv, &tool);
     if (a.has("version")) { printf("MetaFast (MI355X HIP hot path) %s\n", mf_version()); return 0; }
@@ -978,11 +999,19 @@ int main(int argc, char **argv) {
         logmsg("INFO", "heatmap image (dist_matrix_<date>_heatmap.png) is not rendered by the HIP path");
         if (finished(5)) return done();
     }
-    if (e.ctx) mf_ctx_destroy(e.ctx);
-    if (!finish.empty()) return 0;                      // (a run cut short by --finish leaves no SUCCESS, :377-379)
-    props_write(wd + "/out.properties", outs);
-    touch(wd + "/SUCCESS");
+    const double t_work = since_start();
+    if (e.ctx) mf_ctx_synchronize(e.ctx);
+    if (finish.empty()) {                               // (a run cut short by --finish leaves no SUCCESS, :377-379)
+        props_write(wd + "/out.properties", outs);
+        touch(wd + "/SUCCESS");
+    }
     if (g_logfile) fclose(g_logfile);
     if (g_logfile2) fclose(g_logfile2);
-    return 0;
+    if (getenv("MF_IO_TIMING")) fprintf(stderr, "[mf] driver: %.3f s until the last step was done\n", t_work);
+    // every output is written and closed.  Handing hundreds of megabytes of pinned memory and the arena's regions back one by one, and
+    // the HIP runtime's own shutdown after that, cost 0.2 s; the process ends here and the driver reclaims them with it
+    // (MF_CLEAN_EXIT=1: the long way, for leak checkers)
+    fflush(nullptr);
+    if (getenv("MF_CLEAN_EXIT")) { if (e.ctx) mf_ctx_destroy(e.ctx); return 0; }
+    _exit(0);
 }

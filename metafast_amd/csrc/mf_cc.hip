@@ -494,6 +494,7 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
 
 extern "C" void mf_comps_destroy(mf_comps *c) {
     if (!c) return;
+    if (--c->refs > 0) return;
     if (c->d_kmers) mf_release(c->ctx, c->d_kmers, c->kmers_bytes);
     if (c->d_comp) mf_release(c->ctx, c->d_comp, c->comp_bytes);
     if (c->index.slots) mf_release(c->ctx, c->index.slots, c->index_bytes);

@@ -64,6 +64,8 @@ struct mf_ctx {
     int64_t opt_skm_dyn = 1;       // one-pass level-1 scatter with sampled region sizes: 0 never, 1 auto (large inputs), 2 always
     int64_t opt_stream_reader = 1; // plain FASTA/FASTQ files go through the pinned, double-buffered streaming reader (mf_io.hip)
     int64_t opt_sr_piece = 8 << 20, opt_sr_slack = 1 << 20;
+    double t_hipmalloc = 0; uint64_t n_hipmalloc = 0, b_hipmalloc = 0;   // seconds / calls / bytes inside hipMalloc (diagnostics: MF_IO_TIMING)
+    bool pin_pool_pinned = false;                                  // (hipHostMalloc'ed; else plain page-aligned host memory, option host_pinned = 0)
     void *pin_pool = nullptr; size_t pin_pool_bytes = 0;           // pinned staging chunks of the streaming reader (lazy, kept)
     int64_t opt_skm_slices = 0;    // digit-range slices of a counting run (0 = as many as the HBM budget asks for)
     int64_t opt_skm_dedupe = 1;    // k_skm_count: identical records of a unit are counted once, with their multiplicity (0 = every record for itself)
@@ -78,6 +80,8 @@ struct mf_ctx {
     int64_t opt_part_good = 220;   // ... and a TABLE partition at most this many k-mers that survive the cut (the graph kernels' LDS lookup table takes 352, mf_nbr.h)
     int64_t opt_unit_parts_long = 3;   // assembled sequences: log2 of the table partitions counted as one unit (k_gather_split_n cuts them apart)
     double last_pilot_rho = -1.0;  // what the last pilot measured (diagnostics; < 0: none ran)
+    int64_t opt_host_pinned = 0;   // staging buffers of the file readers / writers: 1 = hipHostMalloc (0.16 - 0.29 s per GB to get, 0.1 s to give back), 0 = plain host memory (copies to and from it run at the same 56 GB/s on this platform: tools/pin_alloc.hip)
+    int64_t opt_file_cache_gb = 0; // > 0: tables / components written to files stay in HBM (up to this many GB) and are handed out when the same file is loaded again
     int64_t opt_dcc_sparse = 0;    // sharded cutter, levels after the first: 1 = always the sparse set-up of the arrays over all vertex ids (tests)
     int64_t opt_nbr_global = 0;    // 1: neighbour lookups of the graph kernels through the HBM index only (A/B of mf_nbr.h)
     int64_t opt_scatter_fast = 1;  // k_skm_scatter: runs dealt evenly over the lanes through LDS where the level leaves room (0 = never)
@@ -87,6 +91,7 @@ struct mf_ctx {
     struct span { size_t off, sz; };
     struct region { char *base; size_t size; std::vector<span> free_spans; };   // free_spans sorted by offset
     std::vector<region> regions;
+    std::vector<struct mf_file_entry *> file_cache; size_t file_cache_bytes = 0; uint64_t file_cache_clock = 0;   // (mf_io.hip)
     size_t arena_bytes = 0;
     // timers
     std::vector<mf_timer_rec> pending;
@@ -157,6 +162,7 @@ struct mf_index_view { const void *slots; uint64_t mask; const uint64_t *dir; ui
 static inline mf_index_view mf_view(const mf_index &ix) { return mf_index_view{ix.slots, ix.cap - 1, ix.dir, ix.part_bits, ix.skm_k, ix.compact, ix.keys, ix.counts}; }
 struct mf_table {
     mf_ctx *ctx = nullptr;
+    int refs = 1;                 // handles on this table (mf_table_destroy lets go of one): the file cache of the context holds one for a table it keeps
     int k = 0;
     uint64_t n = 0;               // distinct k-mers
     uint64_t n_occ = 0;           // occurrences fed in
@@ -187,6 +193,7 @@ struct mf_seqs {
 };
 struct mf_comps {
     mf_ctx *ctx = nullptr;
+    int refs = 1;                 // (as mf_table::refs)
     int k = 0;
     uint64_t n = 0, n_kmers = 0;
     // per-component records on the host in final order; the member lists (offsets / kmers) are
@@ -200,6 +207,15 @@ struct mf_comps {
     mf_index index; size_t index_bytes = 0;
 };
 
+// ---- files this process has just written, kept as the objects they were written from (option file_cache, mf_io.hip): the next step of a
+// matrix-builder run asks for the file and gets the table / the components that are still in HBM
+struct mf_file_entry {
+    std::string path; uint64_t size = 0; int64_t mtime_ns = 0;
+    mf_table *t = nullptr; int thr = -1;       // every record of the file has count > thr
+    mf_comps *c = nullptr;
+    size_t bytes = 0; uint64_t stamp = 0;
+};
+void mf_file_cache_clear(mf_ctx *ctx);
 int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, mf_index *out,
                    size_t *bytes);
 int mf_table_ensure_index(mf_table *t);

@@ -1,5 +1,7 @@
 // mf_ctx.hip -- context, workspace cache, HIP-event kernel timers, options.
 #include "mf_common.h"
+#include <time.h>
+#include <stdlib.h>
 
 static thread_local char g_err[1024] = "";
 
@@ -17,6 +19,7 @@ extern "C" const char *mf_version(void) { return "metafast_hip 0.1 (gfx950)"; }
 extern "C" int mf_ctx_create(int device, int host_threads, mf_ctx **out) {
     if (!out) return mf_set_error("mf_ctx_create: out is NULL");
     *out = nullptr;
+    struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0)
@@ -34,6 +37,10 @@ extern "C" int mf_ctx_create(int device, int host_threads, mf_ctx **out) {
     if (se != hipSuccess) { delete c; return mf_set_error("hipStreamCreate failed: %s", hipGetErrorString(se)); }
     c->own_stream = true;
     *out = c;
+    if (getenv("MF_IO_TIMING")) {
+        struct timespec ts1; clock_gettime(CLOCK_MONOTONIC, &ts1);
+        fprintf(stderr, "[mf] ctx_create: %.3f s (HIP runtime start, device %d, %d CUs)\n", (ts1.tv_sec - ts0.tv_sec) + (ts1.tv_nsec - ts0.tv_nsec) * 1e-9, device, c->n_cu);
+    }
     return MF_OK;
 }
 
@@ -82,11 +89,12 @@ extern "C" void mf_ctx_destroy(mf_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    mf_file_cache_clear(ctx);
     for (auto &r : ctx->regions) hipFree(r.base);
     ctx->regions.clear();
     for (auto &r : ctx->pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : ctx->event_pool) hipEventDestroy(ev);
-    if (ctx->pin_pool) hipHostFree(ctx->pin_pool);
+    if (ctx->pin_pool) { if (ctx->pin_pool_pinned) hipHostFree(ctx->pin_pool); else free(ctx->pin_pool); }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -126,7 +134,13 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "skm_dyn") ctx->opt_skm_dyn = v;
     else if (s == "nbr_global") ctx->opt_nbr_global = v;
     else if (s == "dcc_sparse") ctx->opt_dcc_sparse = v;
+    else if (s == "file_cache") {                       // GB; -1: a quarter of the device's memory
+        if (v < 0) { size_t fr = 0, tot = 0; MF_HIP(hipSetDevice(ctx->device)); MF_HIP(hipMemGetInfo(&fr, &tot)); v = (int64_t)(tot >> 32); }
+        ctx->opt_file_cache_gb = v;
+        if (!v) mf_file_cache_clear(ctx);
+    }
     else if (s == "skm_pilot") ctx->opt_skm_pilot = v;
+    else if (s == "host_pinned") ctx->opt_host_pinned = v;
     else if (s == "skm_dynq") ctx->opt_skm_dynq = v;
     else if (s == "part_good") { if (v < 16 || v > 4096) return mf_set_error("part_good out of [16,4096]"); ctx->opt_part_good = v; }
     else if (s == "unit_parts_long") { if (v < 0 || v > 4) return mf_set_error("unit_parts_long out of [0,4]"); ctx->opt_unit_parts_long = v; }
@@ -177,11 +191,17 @@ int mf_alloc(mf_ctx *ctx, size_t bytes, void **out) {
         rsz = (bytes + gran - 1) & ~(gran - 1);
     }
     void *p = nullptr;
+    struct timespec ta; clock_gettime(CLOCK_MONOTONIC, &ta);
     hipError_t e = hipMalloc(&p, rsz);
     if (e != hipSuccess && rsz != bytes) { (void)hipGetLastError(); rsz = bytes; e = hipMalloc(&p, rsz); }
+    { struct timespec tb; clock_gettime(CLOCK_MONOTONIC, &tb); ctx->t_hipmalloc += (tb.tv_sec - ta.tv_sec) + (tb.tv_nsec - ta.tv_nsec) * 1e-9; ctx->n_hipmalloc++; ctx->b_hipmalloc += rsz; }
     if (e != hipSuccess) {
         (void)hipGetLastError();
         if (arena_take(ctx, bytes, out, false)) return MF_OK;       // (rather a pinned big region than a dropped one)
+        if (!ctx->file_cache.empty()) {                             // (objects kept for files that may be loaded again: a convenience, gone first)
+            mf_file_cache_clear(ctx);
+            if (arena_take(ctx, bytes, out, true)) return MF_OK;
+        }
         // idle regions go back to the driver, the smallest first and only as many as it takes
         if (ctx->opt_verbose) fprintf(stderr, "[mf] arena: hipMalloc(%.1f GB) failed with %.1f GB idle: giving idle regions back\n", rsz / 1e9, mf_arena_idle(ctx) / 1e9);
         for (;;) {

@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <chrono>
+#include <climits>
 #include <fcntl.h>
 #include <string>
 #include <sys/stat.h>
@@ -40,6 +41,78 @@ static int read_whole_file(const char *path, std::vector<char> &buf) {
     fclose(f);
     return MF_OK;
 }
+// ---- MF_IO_TIMING=1: one line per file-level call with the seconds of its phases (diagnostics of the drop-in path: tools/cli_rate.py)
+struct io_timer {
+    bool on; double t0 = 0, tl = 0; std::string msg;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    explicit io_timer(const char *what) {
+        static const bool env = getenv("MF_IO_TIMING") != nullptr;
+        on = env;
+        if (on) { t0 = tl = now(); msg = std::string("[mf] ") + what + ":"; }
+    }
+    void lap(const char *name) { if (!on) return; const double t = now(); char b[96]; snprintf(b, sizeof b, " %s %.3f s,", name, t - tl); msg += b; tl = t; }
+    ~io_timer() { if (on) fprintf(stderr, "%s total %.3f s\n", msg.c_str(), now() - t0); }
+};
+
+// ---- the context's file cache (option file_cache = GB it may hold; the metafast.sh driver switches it on).  matrix-builder runs its
+// steps in ONE process and every step reads what the step before has just written: seq-builder-many the .kmers.bin files of
+// kmer-counter-many, features-calculator the same files again and components.bin once per sample (DistanceMatrixBuilderMain.java:
+// 108-170 wires the steps through their output files).  The files are written as the reference writes them; the table / the
+// components they were written FROM stay in HBM under (real path, size, mtime), and a load of that file hands out another handle on
+// the same object (mf_table::refs) instead of reading, decoding, sorting and partitioning 10 bytes per k-mer again -- 1.3 of the
+// 3.8 s of `metafast.sh -i` on 2 x 20 M reads.  Least recently used entries go when the budget is exceeded, all of them when the
+// arena cannot serve an allocation (mf_alloc).
+static bool file_identity(const char *path, std::string &real, uint64_t &size, int64_t &mtime_ns) {
+    char buf[PATH_MAX];
+    if (!realpath(path, buf)) return false;
+    struct stat st;
+    if (stat(buf, &st) != 0) return false;
+    real = buf; size = (uint64_t)st.st_size; mtime_ns = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
+    return true;
+}
+static void file_cache_drop(mf_ctx *ctx, size_t i) {
+    mf_file_entry *e = ctx->file_cache[i];
+    ctx->file_cache.erase(ctx->file_cache.begin() + (long)i);
+    ctx->file_cache_bytes -= e->bytes;
+    if (e->t) mf_table_destroy(e->t);
+    if (e->c) mf_comps_destroy(e->c);
+    delete e;
+}
+void mf_file_cache_clear(mf_ctx *ctx) { while (!ctx->file_cache.empty()) file_cache_drop(ctx, ctx->file_cache.size() - 1); }
+static void file_cache_put(mf_ctx *ctx, const char *path, mf_table *t, int thr, mf_comps *c) {
+    if (ctx->opt_file_cache_gb <= 0) return;
+    std::string real; uint64_t size; int64_t mt;
+    if (!file_identity(path, real, size, mt)) return;
+    for (size_t i = 0; i < ctx->file_cache.size(); i++) if (ctx->file_cache[i]->path == real) { file_cache_drop(ctx, i); break; }
+    const size_t bytes = t ? t->keys_bytes + t->counts_bytes + t->part_off_bytes : c->kmers_bytes + c->comp_bytes;
+    const size_t budget = (size_t)ctx->opt_file_cache_gb << 30;
+    if (bytes > budget) return;
+    while (!ctx->file_cache.empty() && ctx->file_cache_bytes + bytes > budget) {
+        size_t old = 0;
+        for (size_t i = 1; i < ctx->file_cache.size(); i++) if (ctx->file_cache[i]->stamp < ctx->file_cache[old]->stamp) old = i;
+        file_cache_drop(ctx, old);
+    }
+    mf_file_entry *e = new mf_file_entry();
+    e->path = real; e->size = size; e->mtime_ns = mt; e->t = t; e->thr = thr; e->c = c; e->bytes = bytes; e->stamp = ++ctx->file_cache_clock;
+    if (t) t->refs++;
+    if (c) c->refs++;
+    ctx->file_cache.push_back(e);
+    ctx->file_cache_bytes += bytes;
+}
+static mf_file_entry *file_cache_get(mf_ctx *ctx, const char *path) {
+    if (ctx->file_cache.empty()) return nullptr;
+    std::string real; uint64_t size; int64_t mt;
+    if (!file_identity(path, real, size, mt)) return nullptr;
+    for (size_t i = 0; i < ctx->file_cache.size(); i++) {
+        mf_file_entry *e = ctx->file_cache[i];
+        if (e->path != real) continue;
+        if (e->size != size || e->mtime_ns != mt) { file_cache_drop(ctx, i); return nullptr; }      // (somebody else wrote the file since)
+        e->stamp = ++ctx->file_cache_clock;
+        return e;
+    }
+    return nullptr;
+}
+
 static bool ends_with_nocase(const std::string &s, const char *suf) {
     size_t m = strlen(suf);
     if (m > s.size()) return false;
@@ -228,7 +301,9 @@ struct raw_file {            // uninitialised heap buffer (std::vector would zer
     char *p = nullptr; size_t n = 0;
     ~raw_file() { free(p); }
     const char *data() const { return p; }
+    char *data() { return p; }
     size_t size() const { return n; }
+    bool alloc_bytes(size_t m) { free(p); p = (char *)malloc(m ? m : 1); n = p ? m : 0; return p != nullptr; }
 };
 static int read_file_parallel(const char *path, raw_file &buf, int threads) {
     int fd = open(path, O_RDONLY);
@@ -461,6 +536,7 @@ static size_t sr_record_start(const char *b, size_t n, size_t from, bool file_st
     }
     return n;
 }
+static int ensure_pin_pool(mf_ctx *ctx, size_t want);
 static int stream_file_to_device(mf_ctx *ctx, const char *path, int fmt, sr_file &out) {
     int fd = open(path, O_RDONLY);
     if (fd < 0) return mf_set_error("can't open '%s'", path);
@@ -480,13 +556,16 @@ static int stream_file_to_device(mf_ctx *ctx, const char *path, int fmt, sr_file
         qoff = parse_fastq_pass(head.data(), head.size(), path, 0, 0, tmp);
         if (qoff < 0) { close(fd); return head.size() < fsize ? 1 : qoff; }      // (cut mid-record: let the whole-file reader decide)
     }
-    if (ctx->pin_pool_bytes < (size_t)2 * W * chunk) {
-        if (ctx->pin_pool) { hipHostFree(ctx->pin_pool); ctx->pin_pool = nullptr; ctx->pin_pool_bytes = 0; }
-        const size_t want = (size_t)2 * std::min<size_t>((size_t)std::max(ctx->host_threads, 1), 64) * chunk;
-        if (hipHostMalloc(&ctx->pin_pool, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->pin_pool = nullptr; close(fd); return 1; }
-        ctx->pin_pool_bytes = want;
+    {
+        io_timer tm("stream reader set-up");
+        if (ctx->pin_pool_bytes < (size_t)2 * W * chunk) {
+            const size_t want = (size_t)2 * std::min<size_t>((size_t)std::max(ctx->host_threads, 1), 64) * chunk;
+            if (ensure_pin_pool(ctx, want) != MF_OK) { close(fd); return 1; }
+            tm.lap("staging pool");
+        }
+        if (out.dev.alloc(ctx, np * chunk) != MF_OK) { close(fd); return 1; }
+        tm.lap("device buffer");
     }
-    if (out.dev.alloc(ctx, np * chunk) != MF_OK) { close(fd); return 1; }
     out.pieces.assign(np, sr_piece());
     std::atomic<size_t> next{0};
     std::atomic<int> state{0};                       // 0 ok, 1 = use the whole-file reader, < 0 = error
@@ -624,6 +703,11 @@ static int count_reads_impl(mf_ctx *ctx, const char *const *files, int nfiles, i
     MF_TRY(load_reads_to_device(ctx, files, nfiles, db, doff, &nr, &nb, &tp, &th));
     const double t2 = now();
     int rc = mf_count_core(ctx, db.p, doff.p, nr, nb, k, min_read_len, out, threshold < 0 ? -1 : threshold, n_distinct_all);
+    {
+        static const bool env = getenv("MF_IO_TIMING") != nullptr;
+        if (env) fprintf(stderr, "[mf] count_reads (%d file(s), %llu reads): read+parse+H2D %.3f s, offsets+compaction %.3f s, count %.3f s (hipMalloc so far: %llu calls, %.1f GB, %.3f s)\n", nfiles, (unsigned long long)nr, tp, th, now() - t2,
+                         (unsigned long long)ctx->n_hipmalloc, ctx->b_hipmalloc / 1e9, ctx->t_hipmalloc);
+    }
     if (ctx->opt_verbose)
         fprintf(stderr, "[mf] count_reads: read+parse %.3f s, offsets+H2D %.3f s, count %.3f s (%llu reads, %llu bases, %d host threads)\n",
                 tp, th, now() - t2, (unsigned long long)nr, (unsigned long long)nb, ctx->host_threads);
@@ -686,26 +770,80 @@ __global__ void k_counts_minus_one(uint16_t *__restrict__ c, uint64_t n) {
     if (i < n) c[i] = (uint16_t)(c[i] - 1);
 }
 int mf_table_select_sorted(const mf_table *t, int threshold, mf_buf<uint64_t> &sk, mf_buf<uint16_t> &sc, uint64_t *n);
+// ---- bytes in HBM / in host memory -> a file, fast.  The file-level seams write what the reference writes (10 bytes per k-mer,
+// 8 per component member, FASTA text): hundreds of megabytes per sample that used to go through one pageable buffer and one
+// fwrite (3.5 GB/s: 0.2 s per .kmers.bin of a 20 M-read sample).  Here: slots of the context's pinned pool, a D2H copy per slot,
+// and a pwrite per slot on a thread of its own while the next slot's copy runs (the page cache takes ~2 GB/s per thread).
+static int ensure_pin_pool(mf_ctx *ctx, size_t want) {
+    if (ctx->pin_pool_bytes >= want) return MF_OK;
+    if (ctx->pin_pool) { if (ctx->pin_pool_pinned) hipHostFree(ctx->pin_pool); else free(ctx->pin_pool); ctx->pin_pool = nullptr; ctx->pin_pool_bytes = 0; }
+    if (ctx->opt_host_pinned) {
+        if (hipHostMalloc(&ctx->pin_pool, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->pin_pool = nullptr; return mf_set_error("no pinned host memory (%zu bytes)", want); }
+        ctx->pin_pool_pinned = true;
+    } else {
+        // (plain memory, untouched: the threads that fill it take the page faults, in parallel)
+        if (posix_memalign(&ctx->pin_pool, 2 << 20, want) != 0) { ctx->pin_pool = nullptr; return mf_set_error("no host memory (%zu bytes)", want); }
+        ctx->pin_pool_pinned = false;
+    }
+    ctx->pin_pool_bytes = want;
+    return MF_OK;
+}
+static int pwrite_all(int fd, const void *p, size_t n, off_t off) {
+    const char *q = (const char *)p;
+    while (n) { const ssize_t w = pwrite(fd, q, n, off); if (w <= 0) return -1; q += w; n -= (size_t)w; off += w; }
+    return 0;
+}
+static int device_to_file(mf_ctx *ctx, const void *d_src, size_t bytes, int fd, off_t file_off, const char *path) {
+    if (!bytes) return MF_OK;
+    const size_t SLOT = (size_t)16 << 20;
+    MF_TRY(ensure_pin_pool(ctx, 8 * SLOT));
+    const size_t nslot = std::min<size_t>(ctx->pin_pool_bytes / SLOT, 24);
+    std::vector<std::thread> wr(nslot);
+    std::atomic<int> bad{0};
+    size_t i = 0;
+    for (size_t at = 0; at < bytes; at += SLOT, i++) {
+        const size_t s = i % nslot, m = std::min(SLOT, bytes - at);
+        if (wr[s].joinable()) wr[s].join();
+        char *h = (char *)ctx->pin_pool + s * SLOT;
+        if (hipMemcpyAsync(h, (const char *)d_src + at, m, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) { bad = 2; break; }
+        wr[s] = std::thread([=, &bad]() { if (pwrite_all(fd, h, m, file_off + (off_t)at) != 0) bad = 1; });
+    }
+    for (auto &t : wr) if (t.joinable()) t.join();
+    if (bad == 2) return mf_set_error("device copy failed while writing '%s'", path);
+    if (bad) return mf_set_error("can't write '%s'", path);
+    return MF_OK;
+}
+// host memory -> file, the ranges written by up to 16 threads
+static int host_to_file(const char *data, size_t bytes, int fd, off_t file_off, const char *path) {
+    if (!bytes) return MF_OK;
+    const size_t T = std::min<size_t>(16, (bytes + ((size_t)8 << 20) - 1) / ((size_t)8 << 20));
+    std::vector<std::thread> th; std::atomic<int> bad{0};
+    for (size_t t = 0; t < T; t++) {
+        const size_t lo = bytes * t / T, hi = bytes * (t + 1) / T;
+        th.emplace_back([=, &bad]() { if (pwrite_all(fd, data + lo, hi - lo, file_off + (off_t)lo) != 0) bad = 1; });
+    }
+    for (auto &x : th) x.join();
+    if (bad) return mf_set_error("can't write '%s'", path);
+    return MF_OK;
+}
 // n sorted (k-mer, count) pairs in HBM -> 10-byte big-endian records in `path`
 static int write_records_file(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_cnts, uint64_t n, const char *path) {
-    FILE *f = fopen(path, "wb");
-    if (!f) return mf_set_error("can't write '%s'", path);
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return mf_set_error("can't write '%s'", path);
+    int rc = MF_OK;
     if (n) {
-        // records are encoded in HBM and come down in slabs of 2^22 records (40 MB)
-        const uint64_t SLAB = 1ull << 22;
+        // records are encoded in HBM, 2^25 at a time (320 MB), and stream down through the pinned slots
+        const uint64_t SLAB = 1ull << 25;
         mf_buf<uint32_t> enc;
-        if (enc.alloc(ctx, (std::min(n, SLAB) * 10 + 3) / 4 + 1) != MF_OK) { fclose(f); return -1; }
-        std::vector<uint8_t> host(std::min(n, SLAB) * 10 + 4);
-        for (uint64_t i = 0; i < n; i += SLAB) {
+        if (enc.alloc(ctx, (std::min(n, SLAB) * 10 + 3) / 4 + 1) != MF_OK) { close(fd); return -1; }
+        for (uint64_t i = 0; i < n && rc == MF_OK; i += SLAB) {
             const uint64_t m = std::min(SLAB, n - i);
             k_records_encode<<<(unsigned)((m + REC_PER_BLOCK - 1) / REC_PER_BLOCK), REC_PER_BLOCK, 0, ctx->stream>>>(d_keys + i, d_cnts + i, m, enc.p);
-            if (hipMemcpyAsync(host.data(), enc.p, m * 10, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipStreamSynchronize(ctx->stream) != hipSuccess) { fclose(f); return mf_set_error("write_kmers: device copy failed"); }
-            if (fwrite(host.data(), 10, m, f) != m) { fclose(f); return mf_set_error("can't write '%s'", path); }
+            rc = device_to_file(ctx, enc.p, m * 10, fd, (off_t)(i * 10), path);
         }
     }
-    fclose(f);
-    return MF_OK;
+    if (close(fd) != 0 && rc == MF_OK) rc = mf_set_error("can't write '%s'", path);
+    return rc;
 }
 int mf_table_select_filtered_sorted(const mf_table *t, int threshold, mf_table *filter, int filter_threshold, mf_buf<uint64_t> &sk, mf_buf<uint16_t> &sc,
                                     uint64_t *n);
@@ -723,10 +861,21 @@ extern "C" int mf_table_write_kmers_filtered(const mf_table *t, int threshold, m
 extern "C" int mf_table_write_kmers(const mf_table *t, int threshold, const char *kmers_bin, const char *stat_txt, uint64_t *n_good) {
     if (!t || !kmers_bin) return mf_set_error("mf_table_write_kmers: NULL argument");
     mf_ctx *ctx = t->ctx;
+    io_timer tm("write_kmers");
     uint64_t n = 0;
     mf_buf<uint64_t> sk; mf_buf<uint16_t> sc;
     MF_TRY(mf_table_select_sorted(t, threshold, sk, sc, &n));
+    tm.lap("select+sort");
     MF_TRY(write_records_file(ctx, sk.p, sc.p, n, kmers_bin));
+    tm.lap("encode+D2H+write");
+    if (ctx->opt_file_cache_gb > 0) {
+        // the table the file was written from stays: itself when it holds exactly the records of the file (the cut was made while
+        // counting, mf_count_reads_above), a filtered copy otherwise
+        mf_table *keep = const_cast<mf_table *>(t); bool mine = false;
+        if (!(t->owns_arrays && n == t->n)) { keep = nullptr; if (mf_table_filter(t, threshold, &keep) == MF_OK) mine = true; else keep = nullptr; }
+        if (keep) { file_cache_put(ctx, kmers_bin, keep, threshold, nullptr); if (mine) mf_table_destroy(keep); }
+        tm.lap("cache");
+    }
     FILE *f = nullptr;
     if (stat_txt) {
         std::vector<uint64_t> hist;
@@ -749,6 +898,17 @@ extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nf
     if (!ctx || !out || (nfiles && !files)) return mf_set_error("mf_table_load_kmers: NULL argument");
     *out = nullptr;
     MF_HIP(hipSetDevice(ctx->device));
+    io_timer tm("load_kmers");
+    if (nfiles == 1) {
+        mf_file_entry *e = file_cache_get(ctx, files[0]);
+        if (e && e->t && e->t->k == k) {
+            // (the file's records all have count > e->thr: a threshold at or below that keeps every one of them -- the same table)
+            if (freq_threshold <= e->thr) { e->t->refs++; *out = e->t; tm.lap("resident"); return MF_OK; }
+            const int rc = mf_table_filter(e->t, freq_threshold, out);
+            tm.lap("resident, filtered");
+            return rc;
+        }
+    }
     std::vector<raw_file> raws((size_t)nfiles);
     uint64_t total = 0;
     for (int i = 0; i < nfiles; i++) {
@@ -756,6 +916,7 @@ extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nf
         if (raws[(size_t)i].size() % 10) return mf_set_error("Can't load k-mers file '%s': size is not a multiple of the 10-byte record", files[i]);
         total += raws[(size_t)i].size() / 10;
     }
+    tm.lap("read");
     mf_buf<uint64_t> dk; mf_buf<uint16_t> dc;
     MF_TRY(dk.alloc(ctx, total)); MF_TRY(dc.alloc(ctx, total));
     uint64_t at = 0;
@@ -768,6 +929,7 @@ extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nf
         MF_HIP(hipStreamSynchronize(ctx->stream));
         at += m;
     }
+    tm.lap("H2D+decode");
     // keep the records with freq > freq_threshold (encoded as freq + 1 > 0)
     mf_table *all = nullptr;
     {
@@ -777,6 +939,7 @@ extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nf
     k_counts_minus_one<<<(unsigned)((all->n + 255) / 256 + 1), 256, 0, ctx->stream>>>(all->d_counts, all->n);
     int rc = mf_table_from_device_pairs(ctx, all->d_keys, all->d_counts, all->n, k, out);
     const hipError_t se = hipStreamSynchronize(ctx->stream);
+    tm.lap("filter+partition");
     mf_table_destroy(all);                                  // (on every path: the synchronise used to return past it)
     if (se != hipSuccess) return mf_set_error("hipStreamSynchronize failed: %s", hipGetErrorString(se));
     return rc;
@@ -789,21 +952,54 @@ extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nf
 // TextUtils.printWithLineLimit (itmo!/utils/TextUtils.java:35-45): 70 columns
 extern "C" int mf_seqs_write_fasta(const mf_seqs *s, const char *path) {
     if (!s || !path) return mf_set_error("mf_seqs_write_fasta: NULL argument");
+    io_timer tm("write_fasta");
     std::vector<uint8_t> b; std::vector<uint64_t> o; std::vector<int32_t> a, lo, hi;
     MF_TRY(mf_seqs_to_host(s, b, o, a, lo, hi));
-    FILE *f = fopen(path, "w");
-    if (!f) return mf_set_error("can't write '%s'", path);
-    for (uint64_t i = 0; i < s->n; i++) {
-        uint64_t len = o[i + 1] - o[i];
-        fprintf(f, ">%llu length=%llu av_weight=%d min_weight=%d max_weight=%d\n", (unsigned long long)(i + 1), (unsigned long long)len,
-                a[i], lo[i], hi[i]);
-        const uint8_t *q = b.data() + o[i];
-        uint64_t j = 0;
-        while ((j + 1) * 70 < len) { fwrite(q + j * 70, 1, 70, f); fputc('\n', f); j++; }
-        fwrite(q + j * 70, 1, len - j * 70, f); fputc('\n', f);
+    tm.lap("D2H+order");
+    // the text is made by up to 32 threads, each for a range of sequences (sizes first, then the bytes), and written in one go
+    const uint64_t n = s->n;
+    const int T = (int)std::max<uint64_t>(1, std::min<uint64_t>(32, n / 4096 + 1));
+    std::vector<uint64_t> tsize((size_t)T + 1, 0);
+    auto hdr = [&](uint64_t i, char *buf) {
+        return (size_t)snprintf(buf, 128, ">%llu length=%llu av_weight=%d min_weight=%d max_weight=%d\n", (unsigned long long)(i + 1), (unsigned long long)(o[i + 1] - o[i]), a[i], lo[i], hi[i]);
+    };
+    auto body = [&](uint64_t len) { return len + (len ? (len - 1) / 70 : 0) + 1; };      // 70 columns, the last line never empty (an empty sequence: one empty line)
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                char buf[128]; uint64_t sz = 0;
+                for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) sz += hdr(i, buf) + body(o[i + 1] - o[i]);
+                tsize[(size_t)t + 1] = sz;
+            });
+        for (auto &x : th) x.join();
     }
-    fclose(f);
-    return MF_OK;
+    for (int t = 0; t < T; t++) tsize[(size_t)t + 1] += tsize[(size_t)t];
+    raw_file text;
+    if (!text.alloc_bytes(tsize[(size_t)T] + 1)) return mf_set_error("out of memory writing '%s'", path);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                char *w = text.data() + tsize[(size_t)t];
+                for (uint64_t i = n * t / T; i < n * (t + 1) / T; i++) {
+                    w += hdr(i, w);                                  // (snprintf's terminating 0 is overwritten by what follows; one spare byte at the end)
+                    const uint64_t len = o[i + 1] - o[i];
+                    const uint8_t *q = b.data() + o[i];
+                    uint64_t j = 0;
+                    while ((j + 1) * 70 < len) { memcpy(w, q + j * 70, 70); w += 70; *w++ = '\n'; j++; }
+                    memcpy(w, q + j * 70, len - j * 70); w += len - j * 70; *w++ = '\n';
+                }
+            });
+        for (auto &x : th) x.join();
+    }
+    tm.lap("text");
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return mf_set_error("can't write '%s'", path);
+    int rc = host_to_file(text.data(), tsize[(size_t)T], fd, 0, path);
+    if (close(fd) != 0 && rc == MF_OK) rc = mf_set_error("can't write '%s'", path);
+    tm.lap("write");
+    return rc;
 }
 // SeqBuilderMain.runImpl (src/tools/SeqBuilderMain.java:78-160)
 extern "C" int mf_build_unitigs(mf_ctx *ctx, mf_table *t, int k, int freq_threshold, int min_len, const char *seq_fasta,
@@ -821,7 +1017,10 @@ extern "C" int mf_build_unitigs(mf_ctx *ctx, mf_table *t, int k, int freq_thresh
         fclose(f);
     }
     mf_seqs *s = nullptr;
-    MF_TRY(mf_build_unitigs_device(ctx, t, freq_threshold, min_len, &s));
+    {
+        io_timer tm("build_unitigs (device)");
+        MF_TRY(mf_build_unitigs_device(ctx, t, freq_threshold, min_len, &s));
+    }
     int rc = mf_seqs_write_fasta(s, seq_fasta);
     if (n_seq) *n_seq = s->n;
     mf_seqs_destroy(s);
@@ -832,25 +1031,61 @@ extern "C" int mf_build_unitigs(mf_ctx *ctx, mf_table *t, int k, int freq_thresh
 // A11 components files
 // ---------------------------------------------------------------------------------------------
 // ConnectedComponent.saveComponents (src/structures/ConnectedComponent.java:80-93); stat file ComponentsBuilder.java:146-152
+// (the file image is made in HBM -- the members sorted per component as the reference's writer finds them, byte-swapped, the 12-byte
+// headers spliced in -- and streams down through the pinned slots: 0.33 -> 0.05 s for the components of 2 x 20 M reads)
+int mf_sort_kmers_by_comp(mf_ctx *ctx, const uint32_t *d_comp, const uint64_t *d_kmers, uint64_t n, int key_bits, uint32_t n_comps, uint64_t *d_out);
+__global__ __launch_bounds__(256) void k_comps_encode(const uint64_t *__restrict__ kmers, const uint64_t *__restrict__ koff, const uint64_t *__restrict__ foff,
+                                                      const long long *__restrict__ weights, uint32_t n_comp, uint32_t *__restrict__ raw) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) raw[0] = __builtin_bswap32(n_comp);
+    for (uint32_t c = blockIdx.x; c < n_comp; c += gridDim.x) {
+        const uint64_t w0 = foff[c] / 4, k0 = koff[c], sz = koff[c + 1] - k0;
+        if (threadIdx.x == 0) {
+            const unsigned long long w = (unsigned long long)weights[c];
+            raw[w0] = __builtin_bswap32((uint32_t)sz); raw[w0 + 1] = __builtin_bswap32((uint32_t)(w >> 32)); raw[w0 + 2] = __builtin_bswap32((uint32_t)w);
+        }
+        for (uint64_t j = threadIdx.x; j < sz; j += blockDim.x) {
+            const uint64_t x = kmers[k0 + j];
+            raw[w0 + 3 + 2 * j] = __builtin_bswap32((uint32_t)(x >> 32)); raw[w0 + 4 + 2 * j] = __builtin_bswap32((uint32_t)x);
+        }
+    }
+}
 extern "C" int mf_comps_write(const mf_comps *cc, const char *components_bin, const char *stat_txt) {
     if (!cc || !components_bin) return mf_set_error("mf_comps_write: NULL argument");
     mf_comps *c = const_cast<mf_comps *>(cc);
-    MF_TRY(mf_comps_materialize(c));
-    FILE *f = fopen(components_bin, "wb");
-    if (!f) return mf_set_error("can't write '%s'", components_bin);
-    uint8_t b[12];
-    be_put(b, c->n, 4); fwrite(b, 1, 4, f);
-    std::vector<uint64_t> buf;
-    for (uint64_t i = 0; i < c->n; i++) {
-        be_put(b, c->sizes[i], 4); be_put(b + 4, (uint64_t)c->weights[i], 8); fwrite(b, 1, 12, f);
-        uint64_t lo = c->offsets[i], hi = c->offsets[i + 1];
-        buf.resize(hi - lo);
-        for (uint64_t j = lo; j < hi; j++) buf[j - lo] = __builtin_bswap64(c->kmers[j]);
-        if (hi > lo) fwrite(buf.data(), 8, buf.size(), f);
+    mf_ctx *ctx = c->ctx;
+    io_timer tm("write_components");
+    if (c->n >= 0xFFFFFFFFull) return mf_set_error("components: too many components for the file format");
+    MF_HIP(hipSetDevice(ctx->device));
+    const uint64_t n = c->n, nk = c->n_kmers;
+    std::vector<uint64_t> koff(n + 1, 0), foff(n + 1, 0);
+    foff[0] = 4;
+    for (uint64_t i = 0; i < n; i++) { koff[i + 1] = koff[i] + c->sizes[i]; foff[i + 1] = foff[i] + 12 + 8 * c->sizes[i]; }
+    if (koff[n] != nk) return mf_set_error("components: sizes do not add up to the member list");
+    const uint64_t total = foff[n];
+    mf_buf<uint32_t> raw; MF_TRY(raw.alloc(ctx, total / 4 + 1));
+    if (n) {
+        mf_buf<uint64_t> sorted, dko, dfo; mf_buf<long long> dw;
+        MF_TRY(sorted.alloc(ctx, std::max<uint64_t>(nk, 1))); MF_TRY(dko.alloc(ctx, n + 1)); MF_TRY(dfo.alloc(ctx, n + 1)); MF_TRY(dw.alloc(ctx, n));
+        if (nk) MF_TRY(mf_sort_kmers_by_comp(ctx, c->d_comp, c->d_kmers, nk, 2 * (c->k > 0 ? c->k : 32), (uint32_t)std::max<uint64_t>(n, 1), sorted.p));
+        MF_HIP(hipMemcpyAsync(dko.p, koff.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        MF_HIP(hipMemcpyAsync(dfo.p, foff.data(), (n + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        MF_HIP(hipMemcpyAsync(dw.p, c->weights.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        k_comps_encode<<<(unsigned)std::min<uint64_t>(n, 65535), 256, 0, ctx->stream>>>(sorted.p, dko.p, dfo.p, dw.p, (uint32_t)n, raw.p);
+        MF_HIP(hipStreamSynchronize(ctx->stream));
+    } else {
+        const uint32_t zero = 0;
+        MF_HIP(hipMemcpyAsync(raw.p, &zero, 4, hipMemcpyHostToDevice, ctx->stream));
+        MF_HIP(hipStreamSynchronize(ctx->stream));
     }
-    fclose(f);
+    tm.lap("image");
+    const int fd = open(components_bin, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (fd < 0) return mf_set_error("can't write '%s'", components_bin);
+    int rc = device_to_file(ctx, raw.p, total, fd, 0, components_bin);
+    if (close(fd) != 0 && rc == MF_OK) rc = mf_set_error("can't write '%s'", components_bin);
+    MF_TRY(rc);
+    tm.lap("write");
     if (stat_txt) {
-        f = fopen(stat_txt, "w");
+        FILE *f = fopen(stat_txt, "w");
         if (!f) return mf_set_error("can't write '%s'", stat_txt);
         fprintf(f, "# component.no\tcomponent.size\tcomponent.weight\tusedFreqThreshold\n");
         for (uint64_t i = 0; i < c->n; i++)
@@ -875,6 +1110,10 @@ __global__ __launch_bounds__(256) void k_comps_decode(const uint32_t *__restrict
 extern "C" int mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps **out) {
     if (!ctx || !components_bin || !out) return mf_set_error("mf_comps_load: NULL argument");
     *out = nullptr;
+    io_timer tm("load_components");
+    if (mf_file_entry *e = file_cache_get(ctx, components_bin)) {
+        if (e->c) { e->c->refs++; *out = e->c; tm.lap("resident"); return MF_OK; }
+    }
     raw_file buf;
     if (read_file_parallel(components_bin, buf, ctx->host_threads) < 0) return mf_set_error("Can't load components: file not found (%s)", components_bin);
     const uint8_t *p = (const uint8_t *)buf.data();
@@ -926,8 +1165,12 @@ extern "C" int mf_cut_components(mf_ctx *ctx, mf_table *cutter, int k, int b1, i
     if (cutter->n == 0)                                                          // ComponentCutterMain.java:84-86
         return mf_set_error("No sequences were found in input files! The following steps will be useless");
     mf_comps *c = nullptr;
-    MF_TRY(mf_cut_components_device(ctx, cutter, b1, b2, &c));
+    {
+        io_timer tm("cut_components (device)");
+        MF_TRY(mf_cut_components_device(ctx, cutter, b1, b2, &c));
+    }
     int rc = mf_comps_write(c, components_bin, stat_txt);
+    if (rc == MF_OK) file_cache_put(ctx, components_bin, nullptr, 0, c);
     if (n_comp) *n_comp = c->n;
     mf_comps_destroy(c);
     return rc;
@@ -1019,7 +1262,14 @@ static int write_features_files(const std::vector<int64_t> &vec, const std::vect
     if (breadth_path) {
         FILE *f = fopen(breadth_path, "w");
         if (!f) return mf_set_error("Can't write vector to file %s", breadth_path);
-        for (double v : br) fprintf(f, "%s\n", java_double(v).c_str());
+        // (Double.toString by trial: up to 17 snprintf + strtod round trips per value -- made by up to 16 threads)
+        const size_t n = br.size(), T = std::max<size_t>(1, std::min<size_t>(16, n / 1024));
+        std::vector<std::string> part(T);
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < T; t++)
+            th.emplace_back([&, t]() { std::string &o = part[t]; for (size_t i = n * t / T; i < n * (t + 1) / T; i++) { o += java_double(br[i]); o.push_back('\n'); } });
+        for (auto &x : th) x.join();
+        for (auto &o : part) fwrite(o.data(), 1, o.size(), f);
         fclose(f);
     }
     return MF_OK;

@@ -66,3 +66,17 @@ int mf_sort_u32_u64(mf_ctx *ctx, const uint32_t *d_keys_in, const uint64_t *d_va
     MF_HIP(hipStreamSynchronize(ctx->stream));
     return MF_OK;
 }
+
+// (u64 key, u32 value) pairs, ascending keys of `bits` bits (stable)
+int mf_sort_u64_u32(mf_ctx *ctx, const uint64_t *d_keys_in, const uint32_t *d_vals_in, uint64_t n, int bits, uint64_t *d_keys_out, uint32_t *d_vals_out) {
+    if (!n) return MF_OK;
+    if (n >= (1ull << 32)) return mf_set_error("sort: more than 2^32 entries is not supported");
+    MF_HIP(hipSetDevice(ctx->device));
+    size_t tb = 0;
+    const unsigned eb = (unsigned)std::min(64, std::max(1, bits));
+    MF_HIP(rocprim::radix_sort_pairs(nullptr, tb, d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, 0u, eb, ctx->stream));
+    mf_buf<uint8_t> tmp; MF_TRY(tmp.alloc(ctx, tb ? tb : 1));
+    MF_HIP(rocprim::radix_sort_pairs((void *)tmp.p, tb, d_keys_in, d_keys_out, d_vals_in, d_vals_out, (size_t)n, 0u, eb, ctx->stream));
+    MF_HIP(hipStreamSynchronize(ctx->stream));
+    return MF_OK;
+}

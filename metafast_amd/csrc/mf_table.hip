@@ -241,6 +241,7 @@ int mf_table_adopt(mf_ctx *ctx, int k, uint64_t n, uint64_t n_occ, uint64_t *d_k
 
 extern "C" void mf_table_destroy(mf_table *t) {
     if (!t) return;
+    if (--t->refs > 0) return;                              // (another handle on the same table: the context's file cache, or a load that hit it)
     if (t->owns_arrays && t->d_keys) mf_release(t->ctx, t->d_keys, t->keys_bytes);
     if (t->owns_arrays && t->d_counts) mf_release(t->ctx, t->d_counts, t->counts_bytes);
     if (t->owns_arrays && t->index.slots) mf_release(t->ctx, t->index.slots, t->index_bytes);       // (an alias borrows the index too)

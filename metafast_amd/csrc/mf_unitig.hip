@@ -635,35 +635,52 @@ extern "C" int mf_seqs_device_view(const mf_seqs *s, const void **d_bases, const
 }
 
 // host copy in deterministic order (canonical start k-mer, strand)
+// the sequences in their output order (ascending oriented start k-mer), made in HBM: sort of (start k-mer, index), the lengths in that
+// order, their prefix sums, a gather of the bases (a wave per sequence) -- the host sorted and gathered 3e5 sequences in 0.1 s
+int mf_sort_u64_u32(mf_ctx *ctx, const uint64_t *d_keys_in, const uint32_t *d_vals_in, uint64_t n, int bits, uint64_t *d_keys_out, uint32_t *d_vals_out);
+__global__ void k_seq_iota(uint32_t *__restrict__ v, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+__global__ void k_seq_ordered_meta(const uint32_t *__restrict__ order, const uint64_t *__restrict__ off, const int32_t *__restrict__ a, const int32_t *__restrict__ mn,
+                                   const int32_t *__restrict__ mx, uint64_t n, uint32_t *__restrict__ len, int32_t *__restrict__ oa, int32_t *__restrict__ omn,
+                                   int32_t *__restrict__ omx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = order[i];
+    len[i] = (uint32_t)(off[j + 1] - off[j]); oa[i] = a[j]; omn[i] = mn[j]; omx[i] = mx[j];
+}
+__global__ __launch_bounds__(256) void k_seq_gather(const uint32_t *__restrict__ order, const uint64_t *__restrict__ off, const uint64_t *__restrict__ noff,
+                                                    const uint8_t *__restrict__ bases, uint64_t n, uint8_t *__restrict__ out) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (i >= n) return;
+    const uint32_t j = order[i];
+    const uint64_t src = off[j], len = off[j + 1] - src, dst = noff[i];
+    for (uint64_t t = threadIdx.x & 63u; t < len; t += 64) out[dst + t] = bases[src + t];
+}
 int mf_seqs_to_host(const mf_seqs *s, std::vector<uint8_t> &bases, std::vector<uint64_t> &off, std::vector<int32_t> &avg,
                     std::vector<int32_t> &mn, std::vector<int32_t> &mx) {
     mf_ctx *ctx = s->ctx;
     MF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
     const uint64_t n = s->n;
-    std::vector<uint8_t> hb(s->n_bases); std::vector<uint64_t> ho(n + 1, 0), hkey(n);
-    std::vector<int32_t> ha(n), hmn(n), hmx(n);
-    if (n) {
-        MF_HIP(hipMemcpyAsync(hb.data(), s->d_bases, s->n_bases, hipMemcpyDeviceToHost, ctx->stream));
-        MF_HIP(hipMemcpyAsync(ho.data(), s->d_offsets, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
-        MF_HIP(hipMemcpyAsync(hkey.data(), s->d_startkey, n * 8, hipMemcpyDeviceToHost, ctx->stream));
-        MF_HIP(hipMemcpyAsync(ha.data(), s->d_avg, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        MF_HIP(hipMemcpyAsync(hmn.data(), s->d_min, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        MF_HIP(hipMemcpyAsync(hmx.data(), s->d_max, n * 4, hipMemcpyDeviceToHost, ctx->stream));
-        MF_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    std::vector<uint64_t> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return hkey[a] < hkey[b]; });
     bases.resize(s->n_bases); off.assign(n + 1, 0); avg.resize(n); mn.resize(n); mx.resize(n);
-    uint64_t pos = 0;
-    for (uint64_t i = 0; i < n; i++) {
-        uint64_t j = order[i], len = ho[j + 1] - ho[j];
-        off[i] = pos;
-        memcpy(bases.data() + pos, hb.data() + ho[j], len);
-        pos += len;
-        avg[i] = ha[j]; mn[i] = hmn[j]; mx[i] = hmx[j];
-    }
-    off[n] = pos;
+    if (!n) return MF_OK;
+    if (n >= (1ull << 32)) return mf_set_error("sequences: more than 2^32 is not supported");
+    mf_buf<uint32_t> idx, order, len; mf_buf<uint64_t> skey, noff, tot; mf_buf<int32_t> oa, omn, omx; mf_buf<uint8_t> ob;
+    MF_TRY(idx.alloc(ctx, n)); MF_TRY(order.alloc(ctx, n)); MF_TRY(len.alloc(ctx, n)); MF_TRY(skey.alloc(ctx, n)); MF_TRY(noff.alloc(ctx, n + 1)); MF_TRY(tot.alloc(ctx, 1));
+    MF_TRY(oa.alloc(ctx, n)); MF_TRY(omn.alloc(ctx, n)); MF_TRY(omx.alloc(ctx, n)); MF_TRY(ob.alloc(ctx, s->n_bases + 1));
+    k_seq_iota<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(idx.p, n);
+    MF_TRY(mf_sort_u64_u32(ctx, s->d_startkey, idx.p, n, 64, skey.p, order.p));
+    k_seq_ordered_meta<<<(unsigned)((n + 255) / 256), 256, 0, st>>>(order.p, s->d_offsets, s->d_avg, s->d_min, s->d_max, n, len.p, oa.p, omn.p, omx.p);
+    MF_TRY(mf_scan<1>(ctx, len.p, noff.p, n, tot.p));
+    k_seq_gather<<<(unsigned)((n * 64 + 255) / 256), 256, 0, st>>>(order.p, s->d_offsets, noff.p, s->d_bases, n, ob.p);
+    if (s->n_bases) MF_HIP(hipMemcpyAsync(bases.data(), ob.p, s->n_bases, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemcpyAsync(off.data(), noff.p, (n + 1) * 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemcpyAsync(avg.data(), oa.p, n * 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemcpyAsync(mn.data(), omn.p, n * 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemcpyAsync(mx.data(), omx.p, n * 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
     return MF_OK;
 }
 extern "C" int mf_seqs_export(const mf_seqs *s, uint8_t *bases, uint64_t *offsets, int32_t *avg, int32_t *mn, int32_t *mx) {

@@ -435,7 +435,8 @@ def _with_room(ctx, fn):
 def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda", timings=None):
     """This rank's samples (KmersCounterForManyFilesMain.java:80-108 loops over all libraries: with more samples than GPUs a
     rank takes several, one after the other), joined with the other ranks' for the cutter and the matrix.
-    samples: iterable of (d_bases, d_offsets, n_reads, n_bases) -- torch tensors in HBM (ASCII bases, int64 offsets); it may
+    samples: iterable of (d_bases, d_offsets, n_reads, n_bases) -- torch tensors in HBM (ASCII bases, int64 offsets) -- or of
+    tuples of file names (FASTA / FASTQ / .gz / .bz2 / .binq: the library reads, parses and uploads them); it may
     be a generator that produces a sample only when it is asked for (the reads of one sample at a time in HBM).
     The global sample order is rank-major: rank 0's samples, then rank 1's, ...  Returns a dict of results."""
     t0 = time.perf_counter()
@@ -450,14 +451,20 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
 
     goods, seqss, hists, n_occ, n_distinct = [], [], [], 0, 0
     comm_stats = dict(collectives=0, bytes_in=0, seconds=0.0)
-    for si, (d_bases, d_offsets, n_reads, n_bases) in enumerate(samples):
+    for si, sample in enumerate(samples):
         if si:
             # several samples on this rank: the previous sample's lookup index (3-6 times its table) is not needed again before
             # its feature vector, where it is rebuilt (mf_table_drop_index) -- 4 samples of > 2^32 distinct k-mers each
             # (BASELINE config 5) fit one GPU's HBM this way
             goods[-1].drop_index()
         # kmer-counter: k-mers with count > b go on (IOUtils.printKmers); the others are dropped inside the counting kernels
-        good, nd = ctx.count_device_above(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, k, b)
+        if isinstance(sample[0], (str, bytes, os.PathLike)):
+            # a sample handed over as its read files (IOUtils.loadReads, src/io/IOUtils.java:772-803: all files of a library into one
+            # table): read + parse + H2D inside the library (mf_count_reads_above)
+            good, nd = ctx.count_reads_above([os.fspath(f) for f in sample], k, b)
+        else:
+            d_bases, d_offsets, n_reads, n_bases = sample
+            good, nd = ctx.count_device_above(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, k, b)
         # ... and the histogram of ALL counts, dropped k-mers included (the .stat.txt of IOUtils.printKmers, src/io/IOUtils.java:45-71)
         hists.append(good.hist())
         mark("count")

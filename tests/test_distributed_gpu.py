@@ -21,9 +21,10 @@ import numpy as np, torch, torch.distributed as dist
 from util import branchy_reads, to_device
 from metafast_amd import lib as L, pipeline as P
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(0)
-dist.init_process_group(os.environ["MF_BACKEND"], rank=rank, world_size=world, **({"device_id": torch.device("cuda", 0)} if os.environ["MF_BACKEND"] == "nccl" else {}))
-ctx = L.Context(0, stream=torch.cuda.current_stream())
+dev = int(os.environ.get("MF_DEVICE", "0"))                      # (one GPU box: every rank on cuda:0; a multi-GPU box: LOCAL_RANK)
+torch.cuda.set_device(dev)
+dist.init_process_group(os.environ["MF_BACKEND"], rank=rank, world_size=world, **({"device_id": torch.device("cuda", dev)} if os.environ["MF_BACKEND"] == "nccl" else {}))
+ctx = L.Context(dev, stream=torch.cuda.current_stream())
 if os.environ.get("MF_TEST_FAIL_SHARD_RANK") == str(rank):        # (this rank's shard count fails: the ranks must fall back TOGETHER)
     def no_shard(*a, **k):
         raise L.MetafastError("injected: the shard count failed on this rank")
@@ -34,10 +35,10 @@ def samples():
         b, o = branchy_reads(107 + 10 * (rank * spg + j), genome_seed=7, n=6000)
         db, do = to_device(b, o)
         yield db, do, len(o) - 1, len(b)
-r = P.run_samples(ctx, samples(), k=31, b=1, l=100, b1=100, b2=1000)
+r = P.run_samples(ctx, samples(), k=31, b=1, l=100, b1=100, b2=1000, device=torch.device("cuda", dev))
 comps = r["comps"].export()
 out = dict(components=[[int(a), int(w), int(t)] for a, w, t, _ in comps], members=[[int(x) for x in km] for _, _, _, km in comps],
-           vecs=r["vecs"].tolist(), matrix=r["matrix"].tolist())
+           vecs=r["vecs"].tolist(), matrix=r["matrix"].tolist(), comm={k: float(v) for k, v in r["comm"].items()})
 json.dump(out, open(os.path.join(os.environ["MF_OUT"], f"rank{rank}.json"), "w"))
 dist.destroy_process_group()
 '''
@@ -51,11 +52,21 @@ def _free_port():
     return p
 
 
-def _run(world, backend, tmp_path, spg=1, extra_env=None):
+def _n_gpus():
+    """GPUs of this box, without initialising one in the pytest process (device_count() does not, on this image)"""
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+def _run(world, backend, tmp_path, spg=1, extra_env=None, one_gpu_per_rank=False):
     port = _free_port()
     procs = []
     for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+        dev = str(rank) if one_gpu_per_rank else "0"
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=dev, MF_DEVICE=dev, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    MF_ROOT=ROOT, MF_OUT=str(tmp_path), MF_BACKEND=backend, MF_SPG=str(spg), HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, "-c", WORKER], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     for p in procs:
@@ -313,3 +324,33 @@ def test_sharded_cutter_sparse_setup_every_level(oracle, seed):
         assert [(a, w, t) for a, w, t, _ in comps] == [(a, w, t) for a, w, t, _ in want]
         assert all(np.array_equal(np.sort(g[3]), np.sort(x[3])) for g, x in zip(comps, want))
     assert max(i["levels"] for _, i in res) >= 2
+
+
+# ---- a box with more than one GPU tests itself (this pool's boxes have one: the tests below skip there) ----
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs (RCCL over xGMI with one rank per GPU)")
+@pytest.mark.parametrize("spg", [1, 2])
+def test_two_ranks_two_gpus_rccl(oracle, tmp_path, spg):
+    """one rank per GPU over RCCL: the sharded cutter's all-to-all / all-gathers between two devices, against the oracle's pipeline
+    (KmersCounterForManyFilesMain.java:80-108 + ComponentCutterMain.java:78-114 on all samples)"""
+    res = _run(2, "nccl", tmp_path, spg=spg, one_gpu_per_rank=True)
+    want = _oracle_pipeline(oracle, tmp_path, [107 + 10 * i for i in range(2 * spg)])
+    for r in res:
+        _same(r, want)
+        assert r["comm"]["collectives"] > 0 and r["comm"]["bytes_in"] > 0
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs")
+def test_bench_two_gpus_under_the_launcher():
+    """bench.py exactly as the driver launches it for N = 2 (the launcher starts before anything touches a GPU; the ranks are its
+    child processes): one JSON line, n_gpus = 2, the sharded cutter's collectives counted, weak scaling (50 M-read config scaled down)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--reads", "5000000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:3]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["comm"]["collectives_per_step"] > 0 and d["comm"]["MB_received_per_step"] > 0
+    assert d["stats"]["n_occ"] == 5000000 * 120 and "cutter_adjacency" in d["stage_ms_per_step"]

@@ -18,9 +18,17 @@ for s in range(ns):
     files.append(path)
     print(path, os.path.getsize(path) / 1e9, "GB", flush=True)
 wd = "/tmp/mf_cli_wd"
+os.environ["MF_IO_TIMING"] = "1"
+for variant in os.environ.get("MF_VARIANTS", "").split(";"):        # MF_VARIANTS="a=1,b=2;c=3": one extra run per MF_OPTIONS value (the last run is the default)
+    if not variant:
+        continue
+    subprocess.run(["rm", "-rf", wd])
+    t0 = time.perf_counter()
+    r = subprocess.run([os.path.join(root, "metafast.sh"), "-k", "31", "-i", *files, "-w", wd], capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, MF_OPTIONS=variant))
+    print("MF_OPTIONS=%s: exit %d total %.2f s" % (variant, r.returncode, time.perf_counter() - t0))
+    print("\n".join(l for l in r.stderr.splitlines() if "set-up" in l or "count_reads (1" in l or "driver" in l))
 subprocess.run(["rm", "-rf", wd])
 t0 = time.perf_counter()
-os.environ["MF_IO_TIMING"] = "1"
 r = subprocess.run([os.path.join(root, "metafast.sh"), "-k", "31", "-i", *files, "-w", wd, "-v"], capture_output=True, text=True, cwd="/tmp")
 t1 = time.perf_counter()
 print("exit", r.returncode, "total %.2f s" % (t1 - t0))
