@@ -445,6 +445,10 @@ static string run_heatmap_maker(Env &e, const Args &a, const string &matrix_path
     const size_t fn = rows[0].size();
     if (fn > rows.size()) die("Can't parse matrix, columns' number > rows' number");
     for (size_t i = 0; i < fn; i++) if (rows[i].size() != fn) die("Can't parse matrix, columns' number is different for different rows");
+    for (size_t i = fn; i < rows.size(); i++)                                                                                // HeatMapMakerMain.java:204-209 (white space is no token)
+        for (auto &cell : rows[i]) if (cell.find_first_not_of(" \t\f") != string::npos) die("Can't parse matrix, too much rows");
+    // (an empty first line: the reference indexes dataArray[0][0] of a 0 x 0 array there, :214 -- an exception, i.e. a failed run)
+    if (fn == 0) die("Can't parse matrix, the first line of %s is empty", matrix_path.c_str());
     const bool with_names = rows[0][0] == "#";
     const int n = (int)fn - (with_names ? 1 : 0);
     vector<string> names;
@@ -487,6 +491,9 @@ static vector<HostComp> read_components(const string &path) {       // Connected
     vector<unsigned char> b = slurp(path);
     if (b.size() < 4) die("Can't load components from %s", path.c_str());
     size_t pos = 0; uint64_t n = be_read(&b[0], 4); pos = 4;
+    // (every component has its 12-byte header at least: a count the file cannot hold is a wrong file, not 2^32 empty components to
+    // allocate for -- found by the sanitizer build, tests/test_host_sanitized_cpu.py)
+    if (4 + 12 * n > b.size()) die("Can't load components from %s", path.c_str());
     vector<HostComp> cs((size_t)n);
     for (auto &cp : cs) {
         if (pos + 12 > b.size()) die("Can't load components from %s", path.c_str());

@@ -113,396 +113,7 @@ static mf_file_entry *file_cache_get(mf_ctx *ctx, const char *path) {
     return nullptr;
 }
 
-static bool ends_with_nocase(const std::string &s, const char *suf) {
-    size_t m = strlen(suf);
-    if (m > s.size()) return false;
-    for (size_t i = 0; i < m; i++) if (tolower((unsigned char)s[s.size() - m + i]) != suf[i]) return false;
-    return true;
-}
-static void be_put(uint8_t *p, uint64_t v, int nb) { for (int i = 0; i < nb; i++) p[i] = (uint8_t)(v >> (8 * (nb - 1 - i))); }
-static uint64_t be_get(const uint8_t *p, int nb) { uint64_t v = 0; for (int i = 0; i < nb; i++) v = (v << 8) | p[i]; return v; }
-
-// ---------------------------------------------------------------------------------------------
-// A1 readers
-// ---------------------------------------------------------------------------------------------
-// growable byte buffer WITHOUT value-initialisation (a std::vector would zero gigabytes before every parse)
-struct byte_buf {
-    uint8_t *p = nullptr; size_t n = 0, cap = 0;
-    bool ext = false;                // p is somebody else's fixed region (a pinned staging chunk): never reallocated or freed
-    byte_buf() {}
-    void use_external(uint8_t *q, size_t c) { if (!ext) free(p); p = q; n = 0; cap = c; ext = true; }
-    byte_buf(const byte_buf &) = delete;
-    byte_buf &operator=(const byte_buf &) = delete;
-    byte_buf(byte_buf &&o) noexcept : p(o.p), n(o.n), cap(o.cap), ext(o.ext) { o.p = nullptr; o.n = o.cap = 0; o.ext = false; }
-    byte_buf &operator=(byte_buf &&o) noexcept { if (!ext) free(p); p = o.p; n = o.n; cap = o.cap; ext = o.ext; o.p = nullptr; o.n = o.cap = 0; o.ext = false; return *this; }
-    ~byte_buf() { if (!ext) free(p); }
-    void reserve(size_t c) { if (c > cap && !ext) { p = (uint8_t *)realloc(p, c); cap = c; } }     // (an external region is as large as its input)
-    uint8_t *grow(size_t add) { if (n + add > cap) reserve(std::max(cap * 2, n + add + 4096)); return p + n; }   // room for `add` more bytes
-    void push_back(uint8_t c) { *grow(1) = c; n++; }
-    size_t size() const { return n; }
-    bool empty() const { return n == 0; }
-    void resize(size_t m) { n = m; }                 // shrink only
-    const uint8_t *data() const { return p; }
-};
-struct read_batch {
-    byte_buf bases;                  // upper-case ACGT
-    std::vector<uint64_t> offsets;   // [n+1]
-    read_batch() { offsets.push_back(0); }
-    void end_read() { offsets.push_back(bases.size()); }
-    void drop_read() { bases.resize(offsets.back()); }
-};
-// byte -> base (DnaTools.fromChar, itmo!/dna/DnaTools.java:46-64; IUPAC codes: first listed choice, see nucleotide_of),
-// 0xFE = N/n (the whole read is skipped), 0xFF = not a nucleotide
-struct base_lut {
-    uint8_t t[256];
-    base_lut() {
-        for (int c = 0; c < 256; c++) t[c] = 0xFF;
-        const char *from = "ACGTacgtRrYyMmKkSsWwHhBbVvDd", *to = "ACGTACGTGGTTAAGGGGAAAAGGAAAA";
-        for (int i = 0; from[i]; i++) t[(unsigned char)from[i]] = (uint8_t)to[i];
-        t['N'] = t['n'] = 0xFE;
-    }
-};
-static const base_lut BASE_LUT;
-// one text line at a time; BufferedReader.readLine semantics (\n, \r or \r\n)
-struct line_reader {
-    const char *b; size_t n, pos;
-    bool next(const char **ln, size_t *len) {
-        if (pos >= n) return false;
-        size_t s = pos, e = s;
-        while (e < n && b[e] != '\n' && b[e] != '\r') e++;
-        *ln = b + s; *len = e - s;
-        if (e < n) e += (b[e] == '\r' && e + 1 < n && b[e + 1] == '\n') ? 2 : 1;
-        pos = e;
-        return true;
-    }
-};
-// DnaTools.fromChar (itmo!/dna/DnaTools.java:46-64).  IUPAC codes: the reference picks one of the allowed bases at RANDOM
-// (:66-117); this implementation takes the first one listed there, which is one of the reference's possible outcomes.
-static int nucleotide_of(int c) {
-    switch (c) {
-    case 'A': case 'a': return 'A'; case 'C': case 'c': return 'C'; case 'G': case 'g': return 'G'; case 'T': case 't': return 'T';
-    case 'R': case 'r': return 'G'; case 'Y': case 'y': return 'T'; case 'M': case 'm': return 'A'; case 'K': case 'k': return 'G';
-    case 'S': case 's': return 'G'; case 'W': case 'w': return 'A'; case 'H': case 'h': return 'A'; case 'B': case 'b': return 'G';
-    case 'V': case 'v': return 'A'; case 'D': case 'd': return 'A';
-    default: return -1;
-    }
-}
-// FastaReader (itmo!/io/readers/FastaReader.java:53-104): records = concatenation of the non-comment lines between
-// '>'/';' lines; a record containing N/n is skipped
-static int parse_fasta(const char *data, size_t size, const char *path, read_batch &rb) {
-    size_t pos = 0;
-    bool have = false, has_n = false;
-    int bad = -1;
-    for (;;) {
-        // one line: [ln, ln+len), BufferedReader.readLine line ends (\n, \r\n; a lone \r also ends a line)
-        bool got = pos < size;
-        const char *ln = data + pos; size_t len = 0;
-        if (got) {
-            const char *nl = (const char *)memchr(ln, '\n', size - pos);
-            size_t e = nl ? (size_t)(nl - data) : size;
-            len = e - pos;
-            pos = nl ? e + 1 : size;
-            if (len && ln[len - 1] == '\r') len--;
-            if (len && memchr(ln, '\r', len)) {            // rare: lone CR inside -> let the generic reader split it
-                line_reader lr{data, size, (size_t)(ln - data)};
-                const char *l2; size_t n2;
-                lr.next(&l2, &n2);
-                len = n2; pos = lr.pos;
-            }
-        }
-        bool comment = got && len > 0 && (ln[0] == '>' || ln[0] == ';');
-        if (!got || comment) {
-            if (have) {
-                if (has_n) rb.drop_read();
-                else if (bad >= 0) return mf_set_error("Incorrect nucleotide char: \"%c\" (%s)", bad, path);
-                else rb.end_read();
-            }
-            have = has_n = false; bad = -1;
-            if (!got) break;
-            continue;
-        }
-        uint8_t *w = rb.bases.grow(len);
-        size_t k = 0;
-        for (size_t i = 0; i < len; i++) {
-            uint8_t b = BASE_LUT.t[(unsigned char)ln[i]];
-            if (b >= 0xFE) { if (b == 0xFE) has_n = true; else if (bad < 0) bad = (unsigned char)ln[i]; continue; }
-            w[k++] = b;
-        }
-        rb.bases.n += k;
-        if (len) have = true;
-    }
-    return MF_OK;
-}
-// FastqReader (itmo!/io/readers/FastqReader.java:53-115) + quality sniffing (ReadersUtils.java:63-77: Illumina +64 on the
-// first 1000 records, any char outside [64,126] -> Sanger +33) + phred-0 drop (FastaReaderFromXQSource.java:66-70)
-static int fastq_line(line_reader &lr, const char *path, const char **ln, size_t *len) {   // 1 = line, 0 = EOF
-    do { if (!lr.next(ln, len)) return 0; } while (*len == 0);
-    if ((*ln)[0] != '@' && (*ln)[0] != '+') return mf_set_error("Unknown structure of fastq file! (%s)", path);
-    if (!lr.next(ln, len)) return mf_set_error("Unexpected end of file. File is corrupted/Format mismatch. (%s)", path);
-    return 1;
-}
-// pass 0: quality sniffing only (returns the offset, 64 or 33); pass 1: parse [data, data+size) with `offset`
-static int parse_fastq_pass(const char *data, size_t size, const char *path, int pass, int offset, read_batch &rb) {
-    line_reader lr{data, size, 0};
-    const char *d, *q; size_t dl, ql;
-    long rec = 0;
-    for (;;) {
-        int g = fastq_line(lr, path, &d, &dl);
-        if (g < 0) return g;
-        if (!g) break;
-        g = fastq_line(lr, path, &q, &ql);
-        if (g < 0) return g;
-        if (!g) return mf_set_error("Unexpected end of file. File is corrupted/Format mismatch. (%s)", path);
-        if (dl != ql) return mf_set_error("Bad DnaQ record: length of chars and quality is not the same. (%s)", path);
-        bool good = true;
-        for (size_t i = 0; i < dl; i++) {
-            int c = (unsigned char)d[i];
-            if (c == 'N' || c == 'n' || c == '.') { good = false; continue; }
-            int b = nucleotide_of(c);
-            if (b < 0) return mf_set_error("Incorrect nucleotide char: \"%c\" (%s)", c, path);
-            int qc = (unsigned char)q[i];
-            if (pass == 0) { if (qc < 64 || qc > 126) return 33; }
-            else {
-                if (qc < offset || qc > 126) return mf_set_error("Invalid quality code char: \"%c\" char code = %d (%s)", qc, qc, path);
-                if (qc == offset) good = false;
-                rb.bases.push_back((uint8_t)b);
-            }
-        }
-        if (pass == 1) { if (good) rb.end_read(); else rb.drop_read(); }
-        if (pass == 0 && ++rec >= 1000) break;
-    }
-    return pass == 0 ? 64 : MF_OK;
-}
-// .binq (BinqReader.java:52-88 + FastaReaderFromXQSource.java:62-76): records of a 4-byte big-endian length followed by one byte
-// per base, nucleotide in bits 0-1 (A0 G1 C2 T3), phred in bits 2-7; bytes of 255 before a record are padding; a read with a
-// phred-0 base is dropped (that is how N is stored)
-static int parse_binq(const char *b, size_t n, const char *path, read_batch &rb) {
-    const unsigned char *u = (const unsigned char *)b;
-    size_t pos = 0;
-    for (;;) {
-        while (pos < n && u[pos] == 255) pos++;
-        if (pos >= n) return MF_OK;
-        if (pos + 4 > n) return mf_set_error("Unexpected end of file %s", path);
-        const size_t len = ((size_t)u[pos] << 24) | ((size_t)u[pos + 1] << 16) | ((size_t)u[pos + 2] << 8) | (size_t)u[pos + 3];
-        pos += 4;
-        if (pos + len > n) return mf_set_error("Unexpected end of file %s", path);
-        bool good = true;
-        uint8_t *dst = rb.bases.grow(len);
-        for (size_t i = 0; i < len; i++) { const unsigned v = u[pos + i]; dst[i] = (uint8_t)"AGCT"[v & 3u]; good &= (v >> 2) != 0; }
-        pos += len;
-        if (good) { rb.bases.n += len; rb.end_read(); }
-    }
-}
-// ---- parallel host parsing: the file is cut at record starts, each host thread parses its piece with the serial
-// parser above (so the semantics are the serial ones by construction), pieces are concatenated in order.
-// The reference parses serially under a monitor (src/io/ReadersDispatcher.java:34-53) -- its Amdahl limit; here the
-// parser has to keep a 40 GB/s PCIe link busy. ----
-struct raw_file {            // uninitialised heap buffer (std::vector would zero 15 GB serially first)
-    char *p = nullptr; size_t n = 0;
-    ~raw_file() { free(p); }
-    const char *data() const { return p; }
-    char *data() { return p; }
-    size_t size() const { return n; }
-    bool alloc_bytes(size_t m) { free(p); p = (char *)malloc(m ? m : 1); n = p ? m : 0; return p != nullptr; }
-};
-static int read_file_parallel(const char *path, raw_file &buf, int threads) {
-    int fd = open(path, O_RDONLY);
-    if (fd < 0) return mf_set_error("can't open '%s'", path);
-    struct stat st;
-    if (fstat(fd, &st) != 0) { close(fd); return mf_set_error("can't stat '%s'", path); }
-    const size_t n = (size_t)st.st_size;
-    buf.p = (char *)malloc(n ? n : 1); buf.n = n;
-    if (!buf.p) { close(fd); return mf_set_error("out of host memory reading '%s'", path); }
-    int T = (int)std::min<size_t>((size_t)std::max(threads, 1), n / (16u << 20) + 1);
-    std::vector<std::thread> th;
-    std::vector<int> ok(T, 1);
-    for (int t = 0; t < T; t++)
-        th.emplace_back([&, t]() {
-            size_t lo = n * t / T, hi = n * (t + 1) / T;
-            while (lo < hi) { ssize_t r = pread(fd, buf.p + lo, hi - lo, (off_t)lo); if (r <= 0) { ok[t] = 0; break; } lo += (size_t)r; }
-        });
-    for (auto &x : th) x.join();
-    close(fd);
-    for (int t = 0; t < T; t++) if (!ok[t]) return mf_set_error("short read on '%s'", path);
-    return MF_OK;
-}
-// start of the first record at or after `pos` (or n): FASTA = a line starting with '>' or ';';
-// FASTQ = a line starting with '@' whose second-next line starts with '+' (a quality line may start with '@' too,
-// but then the line two below it is a sequence line)
-static size_t next_record_start(const char *b, size_t n, size_t pos, int fmt) {
-    if (pos == 0) return 0;
-    while (pos < n) {
-        const void *nl = memchr(b + pos, '\n', n - pos);
-        if (!nl) return n;
-        pos = (size_t)((const char *)nl - b) + 1;
-        if (pos >= n) return n;
-        if (fmt == 1) { if (b[pos] == '>' || b[pos] == ';') return pos; }
-        else if (b[pos] == '@') {
-            const void *l1 = memchr(b + pos, '\n', n - pos);
-            if (!l1) return n;
-            size_t p2 = (size_t)((const char *)l1 - b) + 1;
-            const void *l2 = p2 < n ? memchr(b + p2, '\n', n - p2) : nullptr;
-            if (!l2) return n;
-            size_t p3 = (size_t)((const char *)l2 - b) + 1;
-            if (p3 < n && b[p3] == '+') return pos;
-        }
-    }
-    return n;
-}
-static int parse_buffer_parallel(const raw_file &buf, int fmt, const char *path, int threads, std::vector<read_batch> &out_parts) {
-    const char *b = buf.data();
-    const size_t n = buf.size();
-    int offset = 64;
-    if (fmt == 2) { read_batch tmp; offset = parse_fastq_pass(b, n, path, 0, 0, tmp); if (offset < 0) return offset; }
-    int T = (int)std::min<size_t>((size_t)std::max(threads, 1), n / (4u << 20) + 1);
-    // a FASTQ file with empty lines, or a file without '\n' line ends, is parsed serially (cut points would be unsafe)
-    if (T > 1 && !memchr(b, '\n', std::min<size_t>(n, 1u << 20))) T = 1;
-    if (T > 1 && fmt == 2 && (memmem(b, n, "\n\n", 2) || memmem(b, n, "\n\r\n", 3))) T = 1;
-    std::vector<size_t> cut(T + 1, n);
-    cut[0] = 0;
-    for (int t = 1; t < T; t++) cut[t] = next_record_start(b, n, n * t / T, fmt);
-    for (int t = 1; t <= T; t++) if (cut[t] < cut[t - 1]) cut[t] = cut[t - 1];
-    std::vector<read_batch> parts(T);
-    std::vector<int> rc(T, MF_OK);
-    std::vector<std::string> err(T);
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; t++)
-        th.emplace_back([&, t]() {
-            parts[t].bases.reserve(cut[t + 1] - cut[t]);
-            rc[t] = fmt == 1 ? parse_fasta(b + cut[t], cut[t + 1] - cut[t], path, parts[t])
-                             : parse_fastq_pass(b + cut[t], cut[t + 1] - cut[t], path, 1, offset, parts[t]);
-            if (rc[t] < 0) err[t] = mf_last_error();         // thread-local message -> carry it to the caller
-        });
-    for (auto &x : th) x.join();
-    for (int t = 0; t < T; t++) if (rc[t] < 0) return mf_set_error("%s", err[t].c_str());
-    for (auto &p : parts) out_parts.push_back(std::move(p));      // pieces stay separate: they go to the device one by one
-    return MF_OK;
-}
-// .gz inputs (FastaGZReader.java:22-30, FastqGZReader.java:24-32: a GZIPInputStream over the file, which also reads
-// CONCATENATED gzip members): the compressed file is read whole, inflated into one host buffer (zlib; one stream cannot be
-// inflated in parallel) and then parsed by the same parallel parser as a plain file.
-static int inflate_gz(const raw_file &in, raw_file &out, const char *path) {
-    z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, 15 + 32) != Z_OK) return mf_set_error("zlib: inflateInit2 failed");
-    size_t cap = std::max<size_t>(in.n * 5, (size_t)1 << 20), have = 0, fed = 0;
-    out.p = (char *)malloc(cap);
-    if (!out.p) { inflateEnd(&zs); return mf_set_error("out of host memory inflating '%s'", path); }
-    int ret = Z_OK;
-    for (;;) {
-        if (zs.avail_in == 0 && fed < in.n) {
-            const size_t chunk = std::min<size_t>(in.n - fed, (size_t)1 << 30);
-            zs.next_in = (Bytef *)(in.p + fed); zs.avail_in = (uInt)chunk; fed += chunk;
-        }
-        if (have == cap) {
-            cap *= 2;
-            char *np = (char *)realloc(out.p, cap);
-            if (!np) { inflateEnd(&zs); return mf_set_error("out of host memory inflating '%s'", path); }
-            out.p = np;
-        }
-        const size_t room = std::min<size_t>(cap - have, (size_t)1 << 30);
-        zs.next_out = (Bytef *)(out.p + have); zs.avail_out = (uInt)room;
-        ret = inflate(&zs, Z_NO_FLUSH);
-        have += room - zs.avail_out;
-        if (ret == Z_STREAM_END) {
-            if (zs.avail_in == 0 && fed == in.n) break;          // end of the last member
-            if (inflateReset(&zs) != Z_OK) { ret = Z_DATA_ERROR; break; }      // next member of a concatenated file
-            continue;
-        }
-        if (ret == Z_BUF_ERROR && zs.avail_in == 0 && fed == in.n) { ret = Z_DATA_ERROR; break; }   // truncated stream
-        if (ret != Z_OK && ret != Z_BUF_ERROR) break;
-    }
-    inflateEnd(&zs);
-    if (ret != Z_STREAM_END) return mf_set_error("Not in GZIP format or corrupt stream: '%s'", path);
-    out.n = have;
-    return MF_OK;
-}
-// .bz2 inputs (FastaBZ2Reader.java:26-30, FastqBZ2Reader: Hadoop's BZip2Codec, which reads concatenated streams): libbz2 is
-// loaded at run time (the build image carries libbz2.so.1.0 but not its header; the four entry points and bz_stream below are
-// the library's stable public ABI since 1.0).
-struct mf_bz_stream {
-    char *next_in; unsigned int avail_in, total_in_lo32, total_in_hi32;
-    char *next_out; unsigned int avail_out, total_out_lo32, total_out_hi32;
-    void *state; void *(*bzalloc)(void *, int, int); void (*bzfree)(void *, void *); void *opaque;
-};
-static int inflate_bz2(const raw_file &in, raw_file &out, const char *path) {
-    static void *lib = nullptr;
-    typedef int (*init_fn)(mf_bz_stream *, int, int); typedef int (*step_fn)(mf_bz_stream *);
-    static init_fn bz_init = nullptr; static step_fn bz_step = nullptr, bz_end = nullptr;
-    if (!lib) {
-        for (const char *n : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) if ((lib = dlopen(n, RTLD_NOW))) break;
-        if (lib) {
-            bz_init = (init_fn)dlsym(lib, "BZ2_bzDecompressInit"); bz_step = (step_fn)dlsym(lib, "BZ2_bzDecompress"); bz_end = (step_fn)dlsym(lib, "BZ2_bzDecompressEnd");
-        }
-    }
-    if (!lib || !bz_init || !bz_step || !bz_end) return mf_set_error("bzip2 input needs libbz2 at run time (not found): '%s'", path);
-    size_t cap = std::max<size_t>(in.n * 6, (size_t)1 << 20), have = 0, fed = 0;
-    out.p = (char *)malloc(cap);
-    if (!out.p) return mf_set_error("out of host memory inflating '%s'", path);
-    mf_bz_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (bz_init(&zs, 0, 0) != 0) return mf_set_error("bzip2: init failed");
-    int ret = 0;                              // BZ_OK 0, BZ_STREAM_END 4
-    for (;;) {
-        if (zs.avail_in == 0 && fed < in.n) {
-            const size_t chunk = std::min<size_t>(in.n - fed, (size_t)1 << 30);
-            zs.next_in = in.p + fed; zs.avail_in = (unsigned int)chunk; fed += chunk;
-        }
-        if (have == cap) {
-            cap *= 2;
-            char *np = (char *)realloc(out.p, cap);
-            if (!np) { bz_end(&zs); return mf_set_error("out of host memory inflating '%s'", path); }
-            out.p = np;
-        }
-        const size_t room = std::min<size_t>(cap - have, (size_t)1 << 30);
-        zs.next_out = out.p + have; zs.avail_out = (unsigned int)room;
-        const unsigned int in_before = zs.avail_in;
-        ret = bz_step(&zs);
-        have += room - zs.avail_out;
-        if (ret == 4) {
-            if (zs.avail_in == 0 && fed == in.n) break;                    // end of the last stream
-            bz_end(&zs);
-            char *ni = zs.next_in; unsigned int ai = zs.avail_in;
-            memset(&zs, 0, sizeof zs);
-            if (bz_init(&zs, 0, 0) != 0) return mf_set_error("bzip2: init failed");
-            zs.next_in = ni; zs.avail_in = ai;                             // next stream of a concatenated file
-            continue;
-        }
-        if (ret != 0) break;
-        if (zs.avail_in == 0 && fed == in.n && room == zs.avail_out && in_before == 0) { ret = -7; break; }   // truncated
-    }
-    bz_end(&zs);
-    if (ret != 4) return mf_set_error("Not in BZIP2 format or corrupt stream: '%s'", path);
-    out.n = have;
-    return MF_OK;
-}
-// ReadersUtils.detectFileFormat (itmo!/io/ReadersUtils.java:27-54): ".gz" / ".bz2" is stripped first, then the format extension.
-// .binq: the reference's own binary read format, parsed serially.
-static int parse_reads_file(const char *path, int threads, std::vector<read_batch> &parts) {
-    std::string p(path);
-    int fmt = 0;
-    bool gz = false, bz = false;
-    if (ends_with_nocase(p, ".gz")) { gz = true; p.resize(p.size() - 3); }
-    if (ends_with_nocase(p, ".bz2")) { bz = true; p.resize(p.size() - 4); }
-    if (ends_with_nocase(p, ".binq")) fmt = 3;
-    else if (ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq")) fmt = 2;
-    else if (ends_with_nocase(p, ".fasta") || ends_with_nocase(p, ".fa") || ends_with_nocase(p, ".fn") || ends_with_nocase(p, ".fna")) fmt = 1;
-    if (!fmt) return mf_set_error("Can't detect file format for file '%s'", path);
-    raw_file buf;
-    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
-    if (gz || bz) {
-        raw_file packed;
-        MF_TRY(read_file_parallel(path, packed, threads));
-        MF_TRY(gz ? inflate_gz(packed, buf, path) : inflate_bz2(packed, buf, path));
-    } else MF_TRY(read_file_parallel(path, buf, threads));
-    const double t1 = now();
-    int rc;
-    if (fmt == 3) { read_batch rb; rc = parse_binq(buf.data(), buf.size(), path, rb); if (rc == MF_OK) parts.push_back(std::move(rb)); }
-    else rc = parse_buffer_parallel(buf, fmt, path, threads, parts);
-    if (getenv("MF_IO_TIMING")) fprintf(stderr, "[mf] %s: read %.3f s, parse %.3f s\n", path, t1 - t0, now() - t1);
-    return rc;
-}
+#include "mf_parse.h"   // the host-side parsers (plain C++: also built under ASan / UBSan, tests/test_host_sanitized_cpu.py)
 
 // ---- streaming reader for plain FASTA / FASTQ files: constant host memory, PCIe busy while the host parses --------------
 // The file is cut into pieces of SR_PIECE bytes (ends moved to the next record start, at most SR_SLACK further).  Up to 64
@@ -515,27 +126,6 @@ static int parse_reads_file(const char *path, int threads, std::vector<read_batc
 struct sr_piece { uint64_t dev_off = 0, n_bases = 0; std::vector<uint64_t> offsets; };
 struct sr_file { mf_buf<uint8_t> dev; std::vector<sr_piece> pieces; };
 // first record start at a buffer position >= from (the byte before it is a '\n', or it is the file's first byte), or n
-static size_t sr_record_start(const char *b, size_t n, size_t from, bool file_start, int fmt) {
-    if (from == 0 && file_start) return 0;
-    size_t pos = from ? from - 1 : 0;
-    while (pos < n) {
-        const void *nl = memchr(b + pos, '\n', n - pos);
-        if (!nl) return n;
-        pos = (size_t)((const char *)nl - b) + 1;
-        if (pos >= n) return n;
-        if (fmt == 1) { if (b[pos] == '>' || b[pos] == ';') return pos; }
-        else if (b[pos] == '@') {
-            const void *l1 = memchr(b + pos, '\n', n - pos);
-            if (!l1) return n;
-            const size_t p2 = (size_t)((const char *)l1 - b) + 1;
-            const void *l2 = p2 < n ? memchr(b + p2, '\n', n - p2) : nullptr;
-            if (!l2) return n;
-            const size_t p3 = (size_t)((const char *)l2 - b) + 1;
-            if (p3 < n && b[p3] == '+') return pos;
-        }
-    }
-    return n;
-}
 static int ensure_pin_pool(mf_ctx *ctx, size_t want);
 static int stream_file_to_device(mf_ctx *ctx, const char *path, int fmt, sr_file &out) {
     int fd = open(path, O_RDONLY);
@@ -1118,25 +708,12 @@ extern "C" int mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps *
     if (read_file_parallel(components_bin, buf, ctx->host_threads) < 0) return mf_set_error("Can't load components: file not found (%s)", components_bin);
     const uint8_t *p = (const uint8_t *)buf.data();
     const size_t n = buf.size();
-    size_t pos = 4;
-    if (n < 4) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
-    const uint64_t cnt = be_get(p, 4);
-    // every component has at least its 12-byte header: a count the file cannot hold is a wrong file, not a reason to
-    // allocate 2 x 8 x cnt bytes (std::bad_alloc must not cross the C boundary)
-    if (4 + 12 * cnt > n) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
     std::unique_ptr<mf_comps, void (*)(mf_comps *)> C(new mf_comps(), [](mf_comps *c) { mf_comps_destroy(c); });
+    std::vector<uint64_t> foff, koff;
+    MF_TRY(comps_walk_headers(p, n, C->sizes, C->weights, foff, koff));          // (the host walks the headers only)
+    const uint64_t cnt = C->sizes.size();
     C->ctx = ctx; C->k = 0; C->n = cnt;
-    std::vector<uint64_t> foff(cnt + 1, 0), koff(cnt + 1, 0);
-    for (uint64_t i = 0; i < cnt; i++) {
-        if (pos + 12 > n) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
-        const uint64_t sz = be_get(p + pos, 4);
-        C->weights.push_back((int64_t)be_get(p + pos + 4, 8));
-        pos += 12;
-        if (pos + 8 * sz > n) return mf_set_error("Can't load components: file corrupted or format mismatch! Do you set a wrong file?");
-        foff[i] = pos; koff[i + 1] = koff[i] + sz;
-        pos += 8 * sz;
-        C->sizes.push_back(sz); C->thr.push_back(0);
-    }
+    C->thr.assign(cnt, 0);
     const uint64_t nk = koff[cnt];
     if (nk >= 0xFFFFFFFFull) return mf_set_error("components: too many k-mers");
     C->n_kmers = nk;
