@@ -215,19 +215,20 @@ __global__ void k_cc_members(uint8_t *__restrict__ alive, const uint32_t *__rest
                              uint32_t b2, uint32_t next_thr, const uint32_t *__restrict__ keptslot,
                              const uint64_t *__restrict__ slot_off, uint32_t *__restrict__ slot_fill, uint32_t comp_base,
                              unsigned long long *__restrict__ minkey, uint64_t *__restrict__ members,
-                             uint32_t *__restrict__ member_comp) {
+                             uint32_t *__restrict__ member_comp, unsigned int *__restrict__ n_alive) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool put = false;
+    bool put = false, stays = false;
     uint32_t slot = 0; uint64_t key = 0;
     if (v < n && alive[v]) {
         const uint32_t r = parent[v];
         const uint32_t s = csize[r];
-        if (s > b2) { if ((uint32_t)vals[v] < next_thr) alive[v] = 0; }
+        if (s > b2) { if ((uint32_t)vals[v] < next_thr) alive[v] = 0; else stays = true; }
         else {
             alive[v] = 0;
             if (s >= b1) { put = true; slot = keptslot[r]; key = keys[v]; }
         }
     }
+    if (n_alive) { const unsigned long long sm = __ballot(stays); if (sm && mf_lane() == 0) atomicAdd(n_alive, (unsigned int)__popcll(sm)); }
     // positions in the member lists: one cursor atomic per distinct component and wave (see k_cc_flatten_stats)
     unsigned long long todo = __ballot(put);
     const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
@@ -431,7 +432,7 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
                 mf_ktimer tm(ctx, "k_cc_members");
                 k_cc_members<<<cgrid(n), 256, 0, st>>>(alive.p, root.p, csize.p, t->d_counts, t->d_keys, n, (uint32_t)b1, (uint32_t)b2,
                                                        (uint32_t)(thr + 1), keptslot.p, slot_off.p, slot_fill.p, (uint32_t)recs.size(),
-                                                       k_minkey.p, lv->members.p, lv->comp.p);
+                                                       k_minkey.p, lv->members.p, lv->comp.p, ctx->opt_verbose ? &counters.p[3] : nullptr);
             }
             if (nkept) {
                 std::vector<uint32_t> hs(nkept); std::vector<unsigned long long> hw(nkept), hm(nkept);
@@ -444,8 +445,11 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             }
             total_k += nkm;
             levels.push_back(std::move(lv));
-            if (ctx->opt_verbose)
-                fprintf(stderr, "[mf] components: thr=%d kept=%u (%u k-mers) big=%u\n", thr, nkept, nkm, nbig);
+            if (ctx->opt_verbose) {
+                unsigned int na = 0;
+                MF_HIP(hipMemcpy(&na, &counters.p[3], 4, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[mf] components: thr=%d kept=%u (%u k-mers) big=%u, %u of %llu vertices go on to the next level\n", thr, nkept, nkm, nbig, na, (unsigned long long)n);
+            }
             if (!nbig) break;
             if (thr > MF_MAX_COUNT) return mf_set_error("components: threshold loop did not terminate");
         }
