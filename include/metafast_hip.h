@@ -128,7 +128,10 @@ int mf_table_device_view(const mf_table *t, const void **d_keys, const void **d_
 int mf_table_lookup(mf_table *t, const uint64_t *keys, uint64_t n, int32_t *values);
 /* Releases the table's lookup index (built on first use by the unitig builder, the features step and mf_table_lookup; rebuilt
  * when it is needed again).  The reference keeps one map per library alive at a time (KmersCounterForManyFilesMain.java:80-108);
- * a rank that holds several samples' tables drops each index between the sample's seq-builder and features steps. */
+ * a rank that holds several samples' tables drops each index between the sample's seq-builder and features steps.
+ * Safe whenever no library call on this table is running (one calling thread): the views of a table that the library makes for
+ * itself (a cut that keeps every entry) live inside the call that made them; a handle that came out of the context's file cache
+ * (option file_cache: the same table under several handles, mf_table::refs) rebuilds the index when its next user needs it. */
 int mf_table_drop_index(mf_table *t);
 
 /* ---- NO-REFERENCE EXTENSION: 32 <= k <= 63 ----------------------------------------------------

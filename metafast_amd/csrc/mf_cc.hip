@@ -122,14 +122,17 @@ __global__ __launch_bounds__(256) void k_cc_hook_tile(const uint32_t *__restrict
         parent[base + i] = (uint32_t)base + r;
     }
 }
-// the edges that leave the tile of their larger end
-__global__ void k_cc_hook(const uint32_t *__restrict__ nbr, const uint8_t *__restrict__ alive, uint32_t *parent, uint64_t n) {
+// the edges that leave the tile of their larger end.  list != nullptr (a SPARSE level, below): the vertices list[0 .. n) only, ALL their
+// edges to smaller alive vertices (no tile pass ran)
+__global__ void k_cc_hook(const uint32_t *__restrict__ nbr, const uint8_t *__restrict__ alive, uint32_t *parent, uint64_t n, const uint32_t *__restrict__ list) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n || !alive[v]) return;
+    if (v >= n) return;
+    if (list) v = list[v];
+    else if (!alive[v]) return;
     const uint4 *q = reinterpret_cast<const uint4 *>(nbr + v * 8);
     uint4 a = q[0], b = q[1];
     uint32_t nb[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    const uint32_t tile0 = (uint32_t)v & ~(uint32_t)(CC_TILE - 1);
+    const uint32_t tile0 = list ? (uint32_t)v : (uint32_t)v & ~(uint32_t)(CC_TILE - 1);
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         uint32_t u = nb[j];
@@ -153,10 +156,9 @@ __global__ __launch_bounds__(256) void k_cc_flatten_stats(const uint8_t *__restr
                                                           uint32_t *__restrict__ root, const uint16_t *__restrict__ vals,
                                                           uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight, uint64_t n) {
     constexpr uint32_t HS = 2 * CC_TILE;
-    __shared__ uint32_t hk[HS], hr[HS], hs[HS];
-    __shared__ unsigned long long hw[HS];
+    __shared__ uint32_t hk[HS], hr[HS], hs[HS], hs2[HS], hw[HS], hw2[HS];      // (weights of one tile: <= 1024 x 32767 < 2^32; 48 KiB: three workgroups per CU)
     const uint64_t base = (uint64_t)blockIdx.x * CC_TILE;
-    for (uint32_t i = threadIdx.x; i < HS; i += blockDim.x) { hk[i] = CC_NONE; hs[i] = 0; hw[i] = 0; }
+    for (uint32_t i = threadIdx.x; i < HS; i += blockDim.x) { hk[i] = CC_NONE; hs[i] = 0; hw[i] = 0; hs2[i] = 0; hw2[i] = 0; }
     __syncthreads();
     uint32_t slot[CC_TILE / 256];
 #pragma unroll
@@ -173,32 +175,108 @@ __global__ __launch_bounds__(256) void k_cc_flatten_stats(const uint8_t *__restr
         }
         slot[j] = s;
         atomicAdd(&hs[s], 1u);
-        atomicAdd(&hw[s], (unsigned long long)vals[v]);
+        atomicAdd(&hw[s], (uint32_t)vals[v]);
+    }
+    __syncthreads();
+    // (distinct PARENT values -> their roots.  The finds of k_cc_hook leave the vertices of a tile pointing at many different ancestors
+    // of ONE root -- a hundred or so per tile for the giant component -- and one pair of atomics per parent value put 2.7e7 of them on
+    // the giant root's two counters at the union of 8 x 200 M reads' unitigs: 544 ms of serialised same-address atomics, 88 % of that
+    // shape's components stage (round 3 read it as "a hundred threshold levels"; there are five).  The sums are therefore added up
+    // once more in LDS, by ROOT, and a tile touches a root's counters once.)
+    uint32_t myroot[HS / 256];
+#pragma unroll
+    for (int j = 0; j < (int)(HS / 256); j++) {
+        const uint32_t i = (uint32_t)j * 256u + threadIdx.x;
+        uint32_t r = hk[i];
+        myroot[j] = CC_NONE;
+        if (r == CC_NONE) continue;
+        for (;;) { const uint32_t p = parent[r]; if (p == r) break; r = p; }
+        hr[i] = r; myroot[j] = r;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < HS; i += blockDim.x) hk[i] = CC_NONE;      // (the parent values have done their job: hk becomes the table of roots)
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < (int)(HS / 256); j++) {
+        if (myroot[j] == CC_NONE) continue;
+        const uint32_t i = (uint32_t)j * 256u + threadIdx.x, key = myroot[j];
+        uint32_t s = (key * 0x9E3779B1u) >> (32 - 11);
+        for (;;) {
+            const uint32_t old = atomicCAS(&hk[s], CC_NONE, key);
+            if (old == CC_NONE || old == key) break;
+            s = (s + 1) & (HS - 1);
+        }
+        atomicAdd(&hs2[s], hs[i]);
+        atomicAdd(&hw2[s], hw[i]);
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < HS; i += blockDim.x) {
-        uint32_t r = hk[i];
+        const uint32_t r = hk[i];
         if (r == CC_NONE) continue;
-        for (;;) { const uint32_t p = parent[r]; if (p == r) break; r = p; }
-        hr[i] = r;
-        atomicAdd(&csize[r], hs[i]);
-        atomicAdd(&cweight[r], hw[i]);
+        atomicAdd(&csize[r], hs2[i]);
+        atomicAdd(&cweight[r], (unsigned long long)hw2[i]);
     }
-    __syncthreads();
 #pragma unroll
     for (int j = 0; j < CC_TILE / 256; j++) {
         const uint64_t v = base + (uint32_t)j * 256u + threadIdx.x;
         if (slot[j] != CC_NONE) root[v] = hr[slot[j]];
     }
 }
+// ---- SPARSE levels (round 4).  After the first threshold level or two only the vertices of the oversize components that reach the next
+// threshold are left -- 29 %, 1.4 %, 0.08 % of the union of 8 x 50 M reads' unitigs at levels 3, 4, 5; the union of 8 x 200 M reads goes
+// through about a hundred levels, most of them on a sliver of the graph -- while the dense kernels above visit all n vertices five times
+// per level to find out that they are dead (961 ms of that shape's 4.3 s step).  k_cc_members therefore lists the survivors, and once
+// fewer than a third are left a level runs on the list: set-up, hook (every edge to a smaller alive vertex), size / weight per root
+// with the lanes of a wave that share a root adding up first, classification, members -- all launched over the list.
+__global__ __launch_bounds__(256) void k_cc_list_alive(const uint8_t *__restrict__ alive, uint64_t n, unsigned int *__restrict__ cursor, uint32_t *__restrict__ list) {
+    __shared__ uint32_t scratch[18];
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool a = v < n && alive[v];
+    const uint32_t at = mf_block_reserve(cursor, a ? 1u : 0u, scratch);
+    if (a) list[at] = (uint32_t)v;
+}
+__global__ void k_ccs_init(const uint32_t *__restrict__ list, uint64_t m, uint32_t *__restrict__ parent, uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t v = list[i];
+    parent[v] = v; csize[v] = 0; cweight[v] = 0;
+}
+__global__ void k_ccs_stats(const uint32_t *__restrict__ list, uint64_t m, const uint32_t *__restrict__ parent, uint32_t *__restrict__ root, const uint16_t *__restrict__ vals,
+                            uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool have = i < m;
+    uint32_t v = 0, r = 0; unsigned long long w = 0;
+    if (have) {
+        v = list[i]; r = v;
+        for (;;) { const uint32_t p = parent[r]; if (p == r) break; r = p; }        // (read-only: the forest is final)
+        root[v] = r; w = vals[v];
+    }
+    // the lanes of a wave mostly share a root (the list is in table order): one pair of atomics per distinct root and wave
+    unsigned long long todo = __ballot(have);
+    for (int round = 0; round < 6 && todo; round++) {                   // wave-uniform
+        const int lead = __ffsll((long long)todo) - 1;
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)r, lead);
+        const bool in = have && r == r0;
+        const unsigned long long grp = __ballot(in);
+        unsigned long long sw = in ? w : 0ull;
+        for (int d = 32; d >= 1; d >>= 1) sw += __shfl_xor(sw, d, 64);
+        if ((int)mf_lane() == lead) { atomicAdd(&csize[r0], (uint32_t)__popcll(grp)); atomicAdd(&cweight[r0], sw); }
+        if (in) have = false;
+        todo &= ~grp;
+    }
+    if (have) { atomicAdd(&csize[r], 1u); atomicAdd(&cweight[r], w); }
+}
 // per root: classify; kept roots get a slot in the kept list (SoA: root / size / weight / smallest k-mer)
 struct cc_kept_arrays { uint32_t *root; uint32_t *size; unsigned long long *weight; unsigned long long *minkey; };
 __global__ void k_cc_classify(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ parent,
                               const uint32_t *__restrict__ csize, const unsigned long long *__restrict__ cweight, uint64_t n,
                               uint32_t b1, uint32_t b2, uint32_t *__restrict__ keptslot, cc_kept_arrays K,
-                              unsigned int *__restrict__ counters /* [0]=kept comps [1]=kept kmers [2]=big comps */) {
+                              unsigned int *__restrict__ counters /* [0]=kept comps [1]=kept kmers [2]=big comps */, const uint32_t *__restrict__ list) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= n || !alive[v] || parent[v] != (uint32_t)v) return;
+    if (v >= n) return;
+    if (list) v = list[v];
+    else if (!alive[v]) return;
+    if (parent[v] != (uint32_t)v) return;
     uint32_t s = csize[v];
     if (s < b1) return;
     if (s <= b2) {
@@ -215,11 +293,16 @@ __global__ void k_cc_members(uint8_t *__restrict__ alive, const uint32_t *__rest
                              uint32_t b2, uint32_t next_thr, const uint32_t *__restrict__ keptslot,
                              const uint64_t *__restrict__ slot_off, uint32_t *__restrict__ slot_fill, uint32_t comp_base,
                              unsigned long long *__restrict__ minkey, uint64_t *__restrict__ members,
-                             uint32_t *__restrict__ member_comp, unsigned int *__restrict__ n_alive) {
+                             uint32_t *__restrict__ member_comp, unsigned int *__restrict__ n_alive, const uint32_t *__restrict__ list,
+                             uint32_t *__restrict__ next_list) {
+    // list != nullptr: the vertices list[0 .. n); next_list (may be nullptr): the vertices that stay alive are appended, *n_alive = how many
+    __shared__ uint32_t scratch[18];
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool put = false, stays = false;
     uint32_t slot = 0; uint64_t key = 0;
-    if (v < n && alive[v]) {
+    const bool mine = v < n;
+    if (mine && list) v = list[v];
+    if (mine && alive[v]) {
         const uint32_t r = parent[v];
         const uint32_t s = csize[r];
         if (s > b2) { if ((uint32_t)vals[v] < next_thr) alive[v] = 0; else stays = true; }
@@ -228,7 +311,10 @@ __global__ void k_cc_members(uint8_t *__restrict__ alive, const uint32_t *__rest
             if (s >= b1) { put = true; slot = keptslot[r]; key = keys[v]; }
         }
     }
-    if (n_alive) { const unsigned long long sm = __ballot(stays); if (sm && mf_lane() == 0) atomicAdd(n_alive, (unsigned int)__popcll(sm)); }
+    {
+        const uint32_t at = mf_block_reserve(n_alive, stays ? 1u : 0u, scratch);       // (one atomic per workgroup)
+        if (stays && next_list) next_list[at] = (uint32_t)v;
+    }
     // positions in the member lists: one cursor atomic per distinct component and wave (see k_cc_flatten_stats)
     unsigned long long todo = __ballot(put);
     const uint64_t lt_mask = (1ull << mf_lane()) - 1ull;
@@ -406,18 +492,30 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             k_cc_adjacency<<<cgrid(n), 256, 0, st>>>(mf_view(t->index), t->d_keys, n, k, nbr.p);
         }
         MF_HIP(hipMemsetAsync(alive.p, 1, n, st));
+        // the survivors of a level, listed for the next one (sparse levels: see k_ccs_init); [cur] is read, [cur ^ 1] written
+        mf_buf<uint32_t> alist[2];
+        uint64_t m = n;                     // alive vertices of the level at hand
+        bool sparse = false;                // the level runs on alist[cur]
+        int cur = 0;
         for (int thr = 1;; thr++) {
             MF_HIP(hipMemsetAsync(counters.p, 0, 16, st));
+            const uint32_t *L = sparse ? alist[cur].p : nullptr;
+            const uint64_t span = sparse ? m : n;                              // threads of the per-vertex kernels
             {
                 mf_ktimer tm(ctx, "k_cc_hook");
-                k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(nbr.p, alive.p, parent.p, csize.p, cweight.p, n);
-                k_cc_hook<<<cgrid(n), 256, 0, st>>>(nbr.p, alive.p, parent.p, n);
+                if (sparse) {
+                    if (m) k_ccs_init<<<cgrid(m), 256, 0, st>>>(L, m, parent.p, csize.p, cweight.p);
+                    if (m) k_cc_hook<<<cgrid(m), 256, 0, st>>>(nbr.p, alive.p, parent.p, m, L);
+                } else {
+                    k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(nbr.p, alive.p, parent.p, csize.p, cweight.p, n);
+                    k_cc_hook<<<cgrid(n), 256, 0, st>>>(nbr.p, alive.p, parent.p, n, nullptr);
+                }
             }
             {
                 mf_ktimer tm(ctx, "k_cc_stats");
-                k_cc_flatten_stats<<<cgrid(n, CC_TILE), 256, 0, st>>>(alive.p, parent.p, root.p, t->d_counts, csize.p, cweight.p, n);
-                k_cc_classify<<<cgrid(n), 256, 0, st>>>(alive.p, root.p, csize.p, cweight.p, n, (uint32_t)b1, (uint32_t)b2, keptslot.p, K,
-                                                        counters.p);
+                if (sparse) { if (m) k_ccs_stats<<<cgrid(m), 256, 0, st>>>(L, m, parent.p, root.p, t->d_counts, csize.p, cweight.p); }
+                else k_cc_flatten_stats<<<cgrid(n, CC_TILE), 256, 0, st>>>(alive.p, parent.p, root.p, t->d_counts, csize.p, cweight.p, n);
+                if (span) k_cc_classify<<<cgrid(span), 256, 0, st>>>(alive.p, root.p, csize.p, cweight.p, span, (uint32_t)b1, (uint32_t)b2, keptslot.p, K, counters.p, L);
             }
             unsigned int cnt[4];
             MF_HIP(hipMemcpyAsync(cnt, counters.p, 16, hipMemcpyDeviceToHost, st));
@@ -428,12 +526,25 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             lv->n = nkm;
             MF_TRY(mf_scan<1>(ctx, k_size.p, slot_off.p, (uint64_t)nkept, tot.p));      // (multi-block: nkept reaches millions)
             MF_HIP(hipMemsetAsync(slot_fill.p, 0, (size_t)(nkept ? nkept : 1) * 4, st));
+            // the survivors are listed from the level on where the list pays: it can hold a third of the vertices (a dense level
+            // that leaves more behind writes no list, and the next level is dense again)
+            const uint64_t lcap = std::max<uint64_t>(n / 3, 1);
+            const bool want_list = nbig != 0 && ctx->opt_cc_sparse != 0;
+            uint32_t *NL = nullptr;
+            if (want_list) {
+                const uint64_t need = std::min<uint64_t>(sparse ? m : n, sparse ? m : lcap);
+                if (alist[cur ^ 1].n < need) { alist[cur ^ 1].reset(); MF_TRY(alist[cur ^ 1].alloc(ctx, need)); }
+                NL = alist[cur ^ 1].p;
+            }
             {
                 mf_ktimer tm(ctx, "k_cc_members");
-                k_cc_members<<<cgrid(n), 256, 0, st>>>(alive.p, root.p, csize.p, t->d_counts, t->d_keys, n, (uint32_t)b1, (uint32_t)b2,
-                                                       (uint32_t)(thr + 1), keptslot.p, slot_off.p, slot_fill.p, (uint32_t)recs.size(),
-                                                       k_minkey.p, lv->members.p, lv->comp.p, ctx->opt_verbose ? &counters.p[3] : nullptr);
+                // (a dense level whose survivors may not fit the list counts them first: no list is written, see below)
+                if (span) k_cc_members<<<cgrid(span), 256, 0, st>>>(alive.p, root.p, csize.p, t->d_counts, t->d_keys, span, (uint32_t)b1, (uint32_t)b2,
+                                                                    (uint32_t)(thr + 1), keptslot.p, slot_off.p, slot_fill.p, (uint32_t)recs.size(),
+                                                                    k_minkey.p, lv->members.p, lv->comp.p, &counters.p[3], L, sparse ? NL : nullptr);
             }
+            unsigned int na = 0;
+            MF_HIP(hipMemcpyAsync(&na, &counters.p[3], 4, hipMemcpyDeviceToHost, st));
             if (nkept) {
                 std::vector<uint32_t> hs(nkept); std::vector<unsigned long long> hw(nkept), hm(nkept);
                 MF_HIP(hipMemcpyAsync(hs.data(), k_size.p, (size_t)nkept * 4, hipMemcpyDeviceToHost, st));
@@ -442,16 +553,21 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
                 MF_HIP(hipStreamSynchronize(st));
                 for (uint32_t i = 0; i < nkept; i++)
                     recs.push_back({hs[i], (int64_t)hw[i], thr, hm[i], (uint32_t)recs.size()});
-            }
+            } else MF_HIP(hipStreamSynchronize(st));
             total_k += nkm;
             levels.push_back(std::move(lv));
-            if (ctx->opt_verbose) {
-                unsigned int na = 0;
-                MF_HIP(hipMemcpy(&na, &counters.p[3], 4, hipMemcpyDeviceToHost));
-                fprintf(stderr, "[mf] components: thr=%d kept=%u (%u k-mers) big=%u, %u of %llu vertices go on to the next level\n", thr, nkept, nkm, nbig, na, (unsigned long long)n);
-            }
+            if (ctx->opt_verbose)
+                fprintf(stderr, "[mf] components: thr=%d (%s, %llu vertices) kept=%u (%u k-mers) big=%u, %u vertices go on to the next level\n", thr, sparse ? "sparse" : "dense",
+                        (unsigned long long)(sparse ? m : n), nkept, nkm, nbig, na);
             if (!nbig) break;
             if (thr > MF_MAX_COUNT) return mf_set_error("components: threshold loop did not terminate");
+            if (sparse) { cur ^= 1; m = na; }
+            else if ((uint64_t)na <= lcap && ctx->opt_cc_sparse) {
+                // the dense level did not write the list (its size was not known): one pass over the alive flags does
+                MF_HIP(hipMemsetAsync(&counters.p[3], 0, 4, st));
+                k_cc_list_alive<<<cgrid(n), 256, 0, st>>>(alive.p, n, &counters.p[3], NL);
+                sparse = true; cur ^= 1; m = na;
+            }
         }
     }
     // final order: ConnectedComponent.compareTo (src/structures/ConnectedComponent.java:125-136): thr asc, weight desc,
@@ -950,7 +1066,7 @@ extern "C" int mf_dcc_level_local(mf_dcc *D, uint64_t *counts) {
     if (n) {
         mf_ktimer tm(ctx, "k_cc_hook");
         k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, D->csize.p, D->cweight.p, n);
-        k_cc_hook<<<cgrid(n), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, n);
+        k_cc_hook<<<cgrid(n), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, n, nullptr);
     }
     if (n) {
         mf_ktimer tm(ctx, "k_cc_stats");

@@ -134,6 +134,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "skm_dyn") ctx->opt_skm_dyn = v;
     else if (s == "nbr_global") ctx->opt_nbr_global = v;
     else if (s == "dcc_sparse") ctx->opt_dcc_sparse = v;
+    else if (s == "cc_sparse") ctx->opt_cc_sparse = v;
     else if (s == "file_cache") {                       // GB; -1: a quarter of the device's memory
         if (v < 0) { size_t fr = 0, tot = 0; MF_HIP(hipSetDevice(ctx->device)); MF_HIP(hipMemGetInfo(&fr, &tot)); v = (int64_t)(tot >> 32); }
         ctx->opt_file_cache_gb = v;

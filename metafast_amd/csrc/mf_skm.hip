@@ -1077,6 +1077,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     __syncthreads();
     uint32_t parity = 0;
     for (;;) {
+        bool abandon = false;
         uint32_t claimed = 0; bool claim_pending = false;
         if (unit_ctr && threadIdx.x == 0) { claimed = atomicAdd(unit_ctr, 1u); claim_pending = true; }      // (in flight until the unit's first barrier B1)
         dirent dnn = {0, 0, 0, 0};
@@ -1356,7 +1357,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
             ones_try = 0; all_try = 0; pass = 0;
             if (threadIdx.x == 0) out_cursor = 0;
             if (thr >= 0) for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) lhist_try[i] = 0;
-            if (P >= (uint32_t)SKM_MAX_PASSES) { if (threadIdx.x == 0) atomicExch(overflow, 1u); done = true; }
+            if (P >= (uint32_t)SKM_MAX_PASSES) { if (threadIdx.x == 0) atomicExch(overflow, 1u); done = true; abandon = true; }
             P *= 4u;
             if (threadIdx.x == 0 && n_redo && P == 4u) atomicAdd(n_redo, 1u);    // (statistics: units counted in several passes)
         } else if (++pass == P) {
@@ -1372,6 +1373,9 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         c2_barrier();                                                           // (the cursors / the tallies are reset before the next pass appends)
         }
         if (threadIdx.x == 0) { dcount[p0 + ui] = out_cursor; out_cursor = 0; }
+        // (a unit beyond SKM_MAX_PASSES: the run is void -- the host sees the flag and takes the k-mer path -- and this workgroup stops
+        // here: the registers that were to hold the next unit's records still hold this one's)
+        if (__builtin_amdgcn_readfirstlane((int)abandon)) break;
         if (un >= nu) break;
         ui = un; un = unn; unn = unit_ctr ? c2_lds_u32(&claim) : unn + gridDim.x;
         start = start_n; len = len_n;
@@ -1771,6 +1775,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             MF_HIP(hipMemcpyAsync(SH->h_pstart.data(), SH->pstart.p, (size_t)nd1 * 8, hipMemcpyDeviceToHost, st));
             MF_HIP(hipStreamSynchronize(st));
             SH->ready = true;
+            if (l1lo == 0 && l1hi == (uint32_t)nd1 && n_occ) { ctx->last_l1_per_occ = (double)SH->cap / (double)n_occ; ctx->last_l1_k = K; }
         }
         // this slice's view: the shared buffer, its own copy of the directory (the levels swap it away), and as many records
         // as its digit regions span

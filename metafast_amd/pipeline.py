@@ -301,6 +301,12 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
     t0, w0 = time.perf_counter(), getattr(comm, "waited", 0.0)
     err = []                                 # the first library error on this rank: announced with the next integer gather
 
+    def buf(n, _device=None):
+        """an exchange buffer of n int64; on a rank whose library call has failed it is ZEROED: the rank keeps the collectives going with
+        buffers of the agreed sizes until the next status gather, and what its healthy peers read from them meanwhile must be in-range
+        indices and ranks, not whatever the allocator left there"""
+        return torch.zeros(max(int(n), 1), dtype=torch.int64, device=device) if err else _i64(n, device)
+
     def mark(name):
         nonlocal t0, w0
         if timings is not None:
@@ -343,11 +349,11 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
         # ---- neighbours in other shards
         qm = gather_ints(lambda: D.queries(), W)
         nq = int(qm[me].sum())
-        q = _i64(2 * nq, device); sync()
+        q = buf(2 * nq, device); sync()
         call(lambda: D.queries_fill(q.data_ptr()))
         rq = comm.all_to_all(q[:2 * nq], 2 * qm); sync()
         na = int(rq.numel()) // 2
-        a = _i64(2 * na, device); sync()
+        a = buf(2 * na, device); sync()
         call(lambda: D.answer(rq.data_ptr(), na, a.data_ptr()))
         ra = comm.all_to_all(a[:2 * na], 2 * qm.T); sync()
         call(lambda: D.set_answers(ra.data_ptr(), nq))
@@ -366,7 +372,7 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
                 break
             pm = pm[:, 1:]
             nsend = int(pm[me].sum())
-            hp = _i64(nsend, device); sync()
+            hp = buf(nsend, device); sync()
             call(lambda: D.pairs_fill(hp.data_ptr()))
             rp = comm.all_to_all(hp[:nsend], pm); sync()
             nr = int(rp.numel())
@@ -376,12 +382,12 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
             allp = comm.all_gather(rp, pm.sum(axis=0)); sync()
             n_stats = call(lambda: D.merge(allp.data_ptr(), int(allp.numel())), 0)
             sm = gather_ints(lambda: [n_stats], 1)[:, 0]
-            st = _i64(2 * n_stats, device); sync()
+            st = buf(2 * n_stats, device); sync()
             call(lambda: D.stats_fill(st.data_ptr()))
             alls = comm.all_gather(st[:2 * n_stats], 2 * sm); sync()
             seg = np.concatenate([[0], np.cumsum(sm)])
             n_kept, n_big = call(lambda: D.classify(alls.data_ptr(), int(alls.numel()) // 2, seg, n_stats, b1, b2, thr, me), (0, 0))
-            kb = _i64(2 * n_kept, device); sync()
+            kb = buf(2 * n_kept, device); sync()
             call(lambda: D.kept_fill(kb.data_ptr()))
             allk = kb[:2 * n_kept].cpu().numpy()
             if allk.size:
@@ -396,12 +402,12 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
         # (root, count) record per component and rank
         nm, nr = call(lambda: D.members_grouped(), (0, 0))
         mm = gather_ints(lambda: [nm, nr], 2)
-        mk = _i64(nm, device); mr = _i64(nr, device); sync()
+        mk = buf(nm, device); mr = buf(nr, device); sync()
         call(lambda: D.members_grouped_fill(mk.data_ptr(), mr.data_ptr()))
         allmk = comm.all_gather(mk[:nm], mm[:, 0]); allmr = comm.all_gather(mr[:nr], mm[:, 1]); sync()
         cat = (lambda i, dt: np.concatenate([x[i] for x in kept]).astype(dt)) if kept else (lambda i, dt: np.zeros(0, dtype=dt))
         roots = cat(0, np.uint32)
-        mn = _i64(len(roots), device); sync()
+        mn = buf(len(roots), device); sync()
         call(lambda: D.minkeys(roots, mn.data_ptr()))
         mn = comm.all_reduce_min(mn[:len(roots)]).cpu().numpy().astype(np.uint64)
         comps = call(lambda: D.finish_grouped(allmk.data_ptr(), int(allmk.numel()), allmr.data_ptr(), int(allmr.numel()), roots, cat(1, np.uint32),
