@@ -83,6 +83,7 @@ struct mf_ctx {
     double last_l1_per_occ = 0; int last_l1_k = 0;   // records (with padding) of the last run's level 1 per k-mer occurrence, for k = last_l1_k: the next sample's buffers are planned with it  // what the last pilot measured (diagnostics; < 0: none ran)
     int64_t opt_host_pinned = 0;   // staging buffers of the file readers / writers: 1 = hipHostMalloc (0.16 - 0.29 s per GB to get, 0.1 s to give back), 0 = plain host memory (copies to and from it run at the same 56 GB/s on this platform: tools/pin_alloc.hip)
     int64_t opt_file_cache_gb = 0; // > 0: tables / components written to files stay in HBM (up to this many GB) and are handed out when the same file is loaded again
+    int64_t opt_wide_passes = 0;   // mf_count_wide_device: passes over the reads, each for one prefix class of the canonical k-mers (0 = as many as the memory asks for; tests force a number)
     int64_t opt_cc_sparse = 1;     // component cutter: threshold levels that few vertices reach run on a list of them (0: every level visits all vertices)
     int64_t opt_dcc_sparse = 0;    // sharded cutter, levels after the first: 1 = always the sparse set-up of the arrays over all vertex ids (tests)
     int64_t opt_nbr_global = 0;    // 1: neighbour lookups of the graph kernels through the HBM index only (A/B of mf_nbr.h)

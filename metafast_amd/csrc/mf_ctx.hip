@@ -135,6 +135,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "nbr_global") ctx->opt_nbr_global = v;
     else if (s == "dcc_sparse") ctx->opt_dcc_sparse = v;
     else if (s == "cc_sparse") ctx->opt_cc_sparse = v;
+    else if (s == "wide_passes") { if (v < 0 || v > 65536 || (v & (v - 1))) return mf_set_error("wide_passes must be 0 or a power of two <= 65536"); ctx->opt_wide_passes = v; }
     else if (s == "file_cache") {                       // GB; -1: a quarter of the device's memory
         if (v < 0) { size_t fr = 0, tot = 0; MF_HIP(hipSetDevice(ctx->device)); MF_HIP(hipMemGetInfo(&fr, &tot)); v = (int64_t)(tot >> 32); }
         ctx->opt_file_cache_gb = v;

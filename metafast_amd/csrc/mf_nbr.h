@@ -17,7 +17,7 @@
 #define NB_WAVES 4                 // waves (= partitions in flight) per workgroup
 #define NB_NONE 0xFFFFFFFFu
 
-#define NB_RQ 128                  // remote requests a wave collects per 64 k-mers (more: looked up on the spot)
+#define NB_RQ 96                   // remote requests a wave collects per 64 k-mers (more: looked up on the spot); 96: 26 KiB of LDS per workgroup = six per CU (128: five)
 struct nb_lds {
     uint64_t key[NB_WAVES][NB_SLOTS]; uint64_t rq_key[NB_WAVES][NB_RQ];
     uint32_t rq_ph[NB_WAVES][NB_RQ]; uint32_t rq_idx[NB_WAVES][NB_RQ];

@@ -10,6 +10,8 @@
 // device-wide LSD radix sort (rocPRIM, low word then high word) orders them, run lengths are the counts.  32 bytes of HBM per
 // k-mer occurrence twice over -- the super-k-mer machinery of mf_skm.hip (16-byte records of <= 50 bases) does not carry 63-mers.
 #include <cstring>
+#include <memory>
+#include <vector>
 #include <rocprim/rocprim.hpp>
 #include "mf_common.h"
 #include "mf_count_dev.h"
@@ -48,15 +50,20 @@ __global__ void k_wide_popc(const uint32_t *__restrict__ vmask, uint64_t n_words
 }
 struct wide128 { uint64_t hi, lo; };
 __device__ __forceinline__ bool wide_less(const wide128 &a, const wide128 &b) { return a.hi < b.hi || (a.hi == b.hi && a.lo < b.lo); }
-// one thread per 32-position word: rolls the forward and the reverse-complement k-mer over the word's valid starts
+// one thread per 32-position word: rolls the forward and the reverse-complement k-mer over the word's valid starts.
+// PASSES (round 4): a sample of 200 M reads has 1.8e10 63-mers -- 32 bytes each, twice over, and more than the 2^32 entries the
+// sort takes.  With pbits > 0 only the k-mers whose canonical value starts with the bits `pass` take part: ascending passes append
+// ascending runs, i.e. the same table.  COUNT: the k-mers of the pass per word (-> wcnt) instead of the k-mers themselves.
+template <bool COUNT>
 __global__ __launch_bounds__(256) void k_wide_kmers(const uint8_t *__restrict__ bases, uint64_t n_bases, const uint32_t *__restrict__ vmask,
                                                     const uint64_t *__restrict__ woff, uint64_t n_words, int k, uint64_t *__restrict__ out_hi,
-                                                    uint64_t *__restrict__ out_lo) {
+                                                    uint64_t *__restrict__ out_lo, int pbits, uint32_t pass, uint32_t *__restrict__ wcnt) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
     uint32_t m = vmask[w];
-    if (!m) return;
-    uint64_t o = woff[w];
+    if (!m) { if (COUNT) wcnt[w] = 0; return; }
+    uint64_t o = COUNT ? 0 : woff[w];
+    uint32_t mine = 0;
     const int hb = 2 * k - 64;                                                   // bits of the k-mer in the high word (0 .. 62)
     const uint64_t hmask = hb >= 64 ? ~0ull : ((1ull << hb) - 1ull);
     const int first = __builtin_ctz(m), last = 31 - __builtin_clz(m);
@@ -74,10 +81,16 @@ __global__ __launch_bounds__(256) void k_wide_kmers(const uint8_t *__restrict__ 
             const uint32_t pos = (uint32_t)(p - (uint64_t)k + 1 - w * 32);        // start of the k-mer that ends at p
             if (pos < 32u && ((m >> pos) & 1u)) {
                 const wide128 &cn = wide_less(rc, fw) ? rc : fw;
-                out_hi[o] = cn.hi; out_lo[o] = cn.lo; o++;
+                bool in = true;
+                if (pbits) {                                                     // the top pbits of the 2k-bit number
+                    const uint64_t top = hb >= pbits ? cn.hi >> (hb - pbits) : ((hb ? cn.hi << (pbits - hb) : 0ull) | (cn.lo >> (64 - (pbits - hb))));
+                    in = (uint32_t)top == pass;
+                }
+                if (in) { if (COUNT) mine++; else { out_hi[o] = cn.hi; out_lo[o] = cn.lo; o++; } }
             }
         }
     }
+    if (COUNT) wcnt[w] = mine;
 }
 __global__ void k_wide_flags(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n, uint32_t *__restrict__ flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -125,42 +138,89 @@ extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void
     if (hipMemcpyAsync(&n_occ, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
     t->n_occ = n_occ;
     if (!n_occ) return MF_OK;
-    if (n_occ >= (1ull << 32)) return fail(mf_set_error("mf_count_wide_device: more than 2^32 k-mer occurrences is not supported on this path"));
-    mf_buf<uint64_t> h0, l0, h1, l1;
-    if (h0.alloc(ctx, n_occ) < 0 || l0.alloc(ctx, n_occ) < 0 || h1.alloc(ctx, n_occ) < 0 || l1.alloc(ctx, n_occ) < 0) return fail(MF_ERR);
-    {
-        mf_ktimer tm(ctx, "k_wide_kmers");
-        k_wide_kmers<<<wgrid(n_words), 256, 0, st>>>((const uint8_t *)d_bases, n_bases, vmask.p, woff.p, n_words, k, h0.p, l0.p);
+    // passes: each takes the k-mers whose canonical value starts with its number (pbits bits).  A pass must stay under 2^32 occurrences
+    // (the sort) and under a quarter of the device (four 8-byte arrays + the sort's scratch per occurrence); canonical k-mers crowd the low
+    // prefixes (the smaller of two strands), hence two bits of margin.  Option wide_passes forces a number (tests).
+    int pbits = 0;
+    if (ctx->opt_wide_passes > 0) { while ((1 << pbits) < ctx->opt_wide_passes && pbits < 16) pbits++; }
+    else {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: hipMemGetInfo failed"));
+        // (every pass rolls over all the reads again -- 0.19 s per pass at 200 M reads --, so as few as fit: 2^31 occurrences = 64 GB of
+        // key arrays + the sort's scratch.  The most crowded prefix class of canonical k-mers holds about twice its share: one bit of margin.)
+        const uint64_t per_pass = std::min<uint64_t>(1ull << 31, std::max<uint64_t>(1ull << 20, (uint64_t)(((double)fr + (double)mf_arena_idle(ctx)) * 0.6 / 44.0)));
+        while (pbits < 16 && (n_occ >> pbits) > per_pass) pbits++;
+        if (pbits) pbits = std::min(16, pbits + 1);
     }
-    {   // ascending (hi, lo): LSD -- by the low word, then (stable) by the high word's 2k - 64 bits
-        mf_ktimer tm(ctx, "k_wide_sort");
-        size_t t1 = 0, t2 = 0;
-        const unsigned hb = (unsigned)std::max(1, 2 * k - 64);
-        if (rocprim::radix_sort_pairs(nullptr, t1, l0.p, l1.p, h0.p, h1.p, (size_t)n_occ, 0u, 64u, st) != hipSuccess ||
-            rocprim::radix_sort_pairs(nullptr, t2, h1.p, h0.p, l1.p, l0.p, (size_t)n_occ, 0u, hb, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: sort set-up failed"));
-        mf_buf<uint8_t> tmp;
-        if (tmp.alloc(ctx, std::max(t1, t2) + 1) < 0) return fail(MF_ERR);
-        if (rocprim::radix_sort_pairs((void *)tmp.p, t1, l0.p, l1.p, h0.p, h1.p, (size_t)n_occ, 0u, 64u, st) != hipSuccess ||
-            rocprim::radix_sort_pairs((void *)tmp.p, t2, h1.p, h0.p, l1.p, l0.p, (size_t)n_occ, 0u, hb, st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: sort failed: %s", hipGetErrorString(hipGetLastError())));
+    const uint32_t n_pass = 1u << pbits;
+    struct piece { mf_buf<uint64_t> hi, lo; mf_buf<uint16_t> cnt; uint64_t n = 0; };
+    std::vector<std::unique_ptr<piece>> pieces;
+    uint64_t nd_total = 0, occ_seen = 0;
+    for (uint32_t pass = 0; pass < n_pass; pass++) {
+        uint64_t n_p = n_occ;
+        if (pbits) {
+            {
+                mf_ktimer tm(ctx, "k_wide_kmers");
+                k_wide_kmers<true><<<wgrid(n_words), 256, 0, st>>>((const uint8_t *)d_bases, n_bases, vmask.p, nullptr, n_words, k, nullptr, nullptr, pbits, pass, wcnt.p);
+            }
+            if (mf_scan<1>(ctx, wcnt.p, woff.p, n_words, tot.p) < 0) return fail(MF_ERR);
+            if (hipMemcpyAsync(&n_p, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
+        }
+        occ_seen += n_p;
+        if (!n_p) continue;
+        if (n_p >= (1ull << 32)) return fail(mf_set_error("mf_count_wide_device: a pass of more than 2^32 k-mer occurrences (option wide_passes: more passes)"));
+        mf_buf<uint64_t> h0, l0, h1, l1;
+        if (h0.alloc(ctx, n_p) < 0 || l0.alloc(ctx, n_p) < 0 || h1.alloc(ctx, n_p) < 0 || l1.alloc(ctx, n_p) < 0) return fail(MF_ERR);
+        {
+            mf_ktimer tm(ctx, "k_wide_kmers");
+            k_wide_kmers<false><<<wgrid(n_words), 256, 0, st>>>((const uint8_t *)d_bases, n_bases, vmask.p, woff.p, n_words, k, h0.p, l0.p, pbits, pass, nullptr);
+        }
+        {   // ascending (hi, lo): LSD -- by the low word, then (stable) by the high word's 2k - 64 bits
+            mf_ktimer tm(ctx, "k_wide_sort");
+            size_t t1 = 0, t2 = 0;
+            const unsigned hb = (unsigned)std::max(1, 2 * k - 64);
+            if (rocprim::radix_sort_pairs(nullptr, t1, l0.p, l1.p, h0.p, h1.p, (size_t)n_p, 0u, 64u, st) != hipSuccess ||
+                rocprim::radix_sort_pairs(nullptr, t2, h1.p, h0.p, l1.p, l0.p, (size_t)n_p, 0u, hb, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: sort set-up failed"));
+            mf_buf<uint8_t> tmp;
+            if (tmp.alloc(ctx, std::max(t1, t2) + 1) < 0) return fail(MF_ERR);
+            if (rocprim::radix_sort_pairs((void *)tmp.p, t1, l0.p, l1.p, h0.p, h1.p, (size_t)n_p, 0u, 64u, st) != hipSuccess ||
+                rocprim::radix_sort_pairs((void *)tmp.p, t2, h1.p, h0.p, l1.p, l0.p, (size_t)n_p, 0u, hb, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: sort failed: %s", hipGetErrorString(hipGetLastError())));
+        }
+        h1.reset(); l1.reset();
+        // run lengths
+        mf_buf<uint32_t> flag; mf_buf<uint64_t> idx;
+        if (flag.alloc(ctx, n_p) < 0 || idx.alloc(ctx, n_p + 1) < 0) return fail(MF_ERR);
+        k_wide_flags<<<wgrid(n_p), 256, 0, st>>>(h0.p, l0.p, n_p, flag.p);
+        if (mf_scan<1>(ctx, flag.p, idx.p, n_p, tot.p) < 0) return fail(MF_ERR);
+        uint64_t nd = 0;
+        if (hipMemcpyAsync(&nd, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
+        auto pc = std::make_unique<piece>();
+        mf_buf<uint64_t> start;
+        if (pc->hi.alloc(ctx, nd) < 0 || pc->lo.alloc(ctx, nd) < 0 || pc->cnt.alloc(ctx, nd) < 0 || start.alloc(ctx, nd) < 0) return fail(MF_ERR);
+        {
+            mf_ktimer tm(ctx, "k_wide_runs");
+            k_wide_heads<<<wgrid(n_p), 256, 0, st>>>(h0.p, l0.p, flag.p, idx.p, n_p, pc->hi.p, pc->lo.p, start.p);
+            k_wide_counts<<<wgrid(nd), 256, 0, st>>>(start.p, nd, n_p, pc->cnt.p);
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
+        pc->n = nd; nd_total += nd;
+        pieces.push_back(std::move(pc));
     }
-    h1.reset(); l1.reset();
-    // run lengths
-    mf_buf<uint32_t> flag; mf_buf<uint64_t> idx;
-    if (flag.alloc(ctx, n_occ) < 0 || idx.alloc(ctx, n_occ + 1) < 0) return fail(MF_ERR);
-    k_wide_flags<<<wgrid(n_occ), 256, 0, st>>>(h0.p, l0.p, n_occ, flag.p);
-    if (mf_scan<1>(ctx, flag.p, idx.p, n_occ, tot.p) < 0) return fail(MF_ERR);
-    uint64_t nd = 0;
-    if (hipMemcpyAsync(&nd, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
-    mf_buf<uint64_t> start;
-    if (t->hi.alloc(ctx, nd) < 0 || t->lo.alloc(ctx, nd) < 0 || t->cnt.alloc(ctx, nd) < 0 || start.alloc(ctx, nd) < 0) return fail(MF_ERR);
-    {
-        mf_ktimer tm(ctx, "k_wide_runs");
-        k_wide_heads<<<wgrid(n_occ), 256, 0, st>>>(h0.p, l0.p, flag.p, idx.p, n_occ, t->hi.p, t->lo.p, start.p);
-        k_wide_counts<<<wgrid(nd), 256, 0, st>>>(start.p, nd, n_occ, t->cnt.p);
+    if (occ_seen != n_occ) return fail(mf_set_error("mf_count_wide_device: internal error, the passes saw %llu of %llu k-mers", (unsigned long long)occ_seen, (unsigned long long)n_occ));
+    if (pieces.size() == 1) { t->hi.swap(pieces[0]->hi); t->lo.swap(pieces[0]->lo); t->cnt.swap(pieces[0]->cnt); }
+    else if (nd_total) {
+        if (t->hi.alloc(ctx, nd_total) < 0 || t->lo.alloc(ctx, nd_total) < 0 || t->cnt.alloc(ctx, nd_total) < 0) return fail(MF_ERR);
+        uint64_t at = 0;
+        for (auto &pc : pieces) {
+            if (!pc->n) continue;
+            if (hipMemcpyAsync(t->hi.p + at, pc->hi.p, pc->n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess || hipMemcpyAsync(t->lo.p + at, pc->lo.p, pc->n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+                hipMemcpyAsync(t->cnt.p + at, pc->cnt.p, pc->n * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: copy failed"));
+            at += pc->n;
+        }
+        if (hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
     }
-    if (hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
-    t->n = nd;
+    t->n = nd_total;
     return MF_OK;
 }
 extern "C" void mf_wtable_destroy(mf_wtable *t) { delete t; }

@@ -50,6 +50,52 @@ def test_wide_counts_match_the_128bit_oracle(gpu_ctx, oracle, k):
     assert got["hi"].tolist() == [0] and got["lo"].tolist() == [0] and got["counts"].tolist() == [32767]
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,passes", [(32, 4), (33, 16), (47, 64), (63, 8)])
+def test_wide_counts_in_passes(gpu_ctx, oracle, k, passes):
+    """a 200 M-read sample has 1.8e10 63-mers, more than one sort takes (2^32 entries, 32 bytes each twice over): the
+    reads are counted in passes, one per prefix class of the canonical k-mers, and the ascending passes append to the same table.
+    Forced pass counts (option wide_passes) on ragged reads: identical to the one-pass table and to the 128-bit oracle."""
+    from util import to_device
+    rng = np.random.default_rng(100 + k)
+    bases, off = _reads(rng, 30000, 20, 160)
+    db, do = to_device(bases, off)
+    hi, lo, cnt, n_occ = oracle.count_wide(bases, off, k, 0)
+    try:
+        gpu_ctx.set_option("wide_passes", passes)
+        got = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), len(off) - 1, len(bases), k, 0)
+    finally:
+        gpu_ctx.set_option("wide_passes", 0)
+    assert got["n_occ"] == n_occ
+    assert np.array_equal(got["hi"], hi) and np.array_equal(got["lo"], lo) and np.array_equal(got["counts"].astype(np.int32), cnt)
+
+
+@pytest.mark.gpu
+def test_wide_counts_at_20M_reads_k63(gpu_ctx):
+    """k = 63 beyond toy size (no oracle at this size: properties): 20 M synthetic reads = 1.76e9 63-mers, counted in the automatic
+    number of passes and in 32 forced ones -- the same table; occurrences = reads x 88; ascending distinct keys; the counts add up
+    (no key saturates at this depth except through the generator's repeats: sum(min(c, 32767)) <= occurrences, = where none does)"""
+    import torch
+    n, rl, k = 20_000_000, 150, 63
+    bases = torch.zeros(n * rl + 64, dtype=torch.uint8, device="cuda")
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    gpu_ctx.synth_reads_device(0x4D45544146415354, 0, 0, n, rl, 1_000_000, bases.data_ptr(), offsets.data_ptr())
+    torch.cuda.synchronize()
+    a = gpu_ctx.count_wide_device(bases.data_ptr(), offsets.data_ptr(), n, n * rl, k, 0)
+    assert a["n_occ"] == n * (rl - k + 1)
+    hi, lo, c = a["hi"], a["lo"], a["counts"].astype(np.int64)
+    assert ((hi[1:] > hi[:-1]) | ((hi[1:] == hi[:-1]) & (lo[1:] > lo[:-1]))).all()          # strictly ascending 126-bit keys
+    assert (hi < (1 << 62)).all() and int(c.min()) >= 1
+    sat = int((c == 32767).sum())
+    assert int(c.sum()) <= a["n_occ"] and (sat > 0 or int(c.sum()) == a["n_occ"])
+    try:
+        gpu_ctx.set_option("wide_passes", 32)
+        b = gpu_ctx.count_wide_device(bases.data_ptr(), offsets.data_ptr(), n, n * rl, k, 0)
+    finally:
+        gpu_ctx.set_option("wide_passes", 0)
+    assert np.array_equal(b["hi"], hi) and np.array_equal(b["lo"], lo) and np.array_equal(b["counts"].astype(np.int64), c)
+
+
 def test_wide_oracle_agrees_with_the_pinned_oracle_at_the_seam(oracle):
     """the 128-bit restatement is tied to the reference-pinned 64-bit oracle: every 32-mer occurrence contributes its first
     31-mer, so per read (len >= 32) the multiset of canonical 31-mers of starts 0 .. len-32 is determined by the 32-mers"""
