@@ -143,6 +143,74 @@ def test_200M_reads_k21_graph_properties(gpu_ctx):
     assert info["n_unitigs"] > 1000 and info["n_components"] > 100
 
 
+def test_config4_union_of_8_samples_k21(gpu_ctx):
+    """BASELINE config 4's k = 21 leg as it is specified: EIGHT samples x 200 M reads (MF_SHAPES_UNION_READS overrides), one after the
+    other on this GPU through pipeline.run_samples, the cutter table and the components over the union of all eight samples' unitigs
+    (ComponentCutterMain.java:78-114), one feature vector per sample, the 8 x 8 matrix.  No oracle at 2.08e11 k-mers: the
+    size-independent properties -- occurrences, components inside the window, pairwise disjoint, closed under the 8-neighbour
+    relation inside the cutter table at their threshold, weight = sum of the cutter's values, every sample's vec[c] = the sum of ITS
+    counts over the component, the matrix = Bray-Curtis of the vectors (symmetric, zero diagonal, samples that share genomes closer
+    than those that do not)."""
+    import gc
+    import torch
+    from metafast_amd import lib as L, pipeline as P
+    from test_fullsize_gpu import _neighbours
+    k, S = 21, 8
+    n = int(os.environ.get("MF_SHAPES_UNION_READS", "200000000"))
+    gc.collect(); gpu_ctx.trim(); torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    if free < n * 1250:
+        pytest.skip("needs %.0f GB of free HBM, %.0f GB are free" % (n * 1250 / 1e9, free / 1e9))
+    bases = torch.zeros(n * RL + 64, dtype=torch.uint8, device="cuda")
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+
+    def samples():
+        for j in range(S):
+            torch.cuda.synchronize()
+            gpu_ctx.synth_reads_device(SEED, j, 0, n, RL, 1_000_000, bases.data_ptr(), offsets.data_ptr())
+            torch.cuda.synchronize()
+            yield bases, offsets, n, n * RL
+
+    r = P.run_samples(gpu_ctx, samples(), k=k, b=1, l=100, b1=1000, b2=10000)
+    del bases, offsets
+    assert r["n_occ"] == S * n * (RL - k + 1) and len(r["goods"]) == S and r["vecs"].shape[0] == S
+    comps, cutter = r["comps"], r["cutter"]
+    cs = comps.export()
+    assert len(cs) > 1000 and r["vecs"].shape[1] == len(cs)
+    sizes = np.array([c[0] for c in cs])
+    assert sizes.min() >= 1000 and sizes.max() <= 10000 and all(len(c[3]) == c[0] for c in cs)
+    thrs = [c[2] for c in cs]
+    assert thrs == sorted(thrs) and max(thrs) >= 2                          # ConnectedComponent.compareTo: threshold first; oversize components were re-split
+    allk = np.concatenate([c[3] for c in cs])
+    owner = np.repeat(np.arange(len(cs)), sizes)
+    order = np.argsort(allk, kind="stable")
+    allk, owner = allk[order], owner[order]
+    assert np.all(allk[1:] != allk[:-1])
+    rng = np.random.default_rng(4)
+    picks = [int(x) for x in rng.choice(len(cs), size=24, replace=False)] + [len(cs) - 1]      # (the last one: the highest threshold)
+    for ci in picks:
+        size, weight, thr, km = cs[ci]
+        val = cutter.lookup(km).astype(np.int64)
+        assert val.min() >= thr and weight == val.sum()
+        nb = _neighbours(km[:200], k)
+        present = cutter.lookup(nb.reshape(-1)).astype(np.int64).reshape(nb.shape) >= thr
+        pos = np.searchsorted(allk, nb).clip(max=len(allk) - 1)
+        assert np.array_equal(present, (allk[pos] == nb) & (owner[pos] == ci))
+    cutter.drop_index()
+    for si in (0, 3, 7):                                                     # a sample's vector = ITS counts over the components' k-mers
+        good = r["goods"][si]
+        for ci in picks[:8]:
+            sv = good.lookup(cs[ci][3]).astype(np.int64)
+            assert r["vecs"][si][ci] == sv[sv > 0].sum()
+        good.drop_index()
+    m = r["matrix"]
+    assert m.shape == (S, S) and np.allclose(m, m.T) and np.all(np.diag(m) == 0) and np.abs(m - L.bray_curtis(r["vecs"])).max() <= 1e-12
+    # (the generator: sample s draws from genomes 32 s .. 32 s + 63 of 128 -- neighbours share half their genomes, samples two apart none)
+    assert m[0, 1] < m[0, 2] and m[3, 4] < m[3, 5] and 0 < m[0, 1] < 1
+    for x in r["goods"] + r["seqss"] + [cutter, comps]:
+        x.close()
+
+
 @pytest.mark.parametrize("k", [21, 20])
 def test_pipeline_against_the_oracle_k21_k20(gpu_ctx, oracle, tmp_path, k):
     _samples_against_the_oracle(gpu_ctx, oracle, tmp_path, S=2, k=k, b=1, l=100, b1=500, b2=5000, n=1_000_000, min_thr=3)

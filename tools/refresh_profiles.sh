@@ -4,7 +4,7 @@
 # profiles/traffic_100M.json: roofline.traffic and roofline.bound come from it, nothing is edited by hand), then the bench line again with it
 TAG=$1
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -o p -- python3 bench.py --no-cpu-baseline > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_rocprof.err
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/${TAG}_stats -o p -- python3 bench.py --no-cpu-baseline --no-end-to-end > gpurun_out/${TAG}_bench_under_rocprof.json 2> gpurun_out/${TAG}_rocprof.err
 timeout -k 5 300 tools/pmc_bench.sh ${TAG} 100000000 c FETCH_SIZE
 timeout -k 5 300 tools/pmc_bench.sh ${TAG} 100000000 d WRITE_SIZE
 timeout -k 5 300 tools/pmc_bench.sh ${TAG} 100000000 a "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS"
