@@ -403,7 +403,7 @@ def main():
                 # in batches (k_skm_count, k_gather) on all its launches of a step, the small cutter-table
                 # launches included (k_skm_count's roofline counts that launch's units too, below)
                 lps = n / max(args.steps, 1)
-                ms_sample = mx if lps <= 2.5 else per_step_ms
+                ms_sample = mx if lps <= 2.5 and name != "k_skm_count" else per_step_ms      # (the hash-count kernel: ALL its launches of a step, always)
                 kern[name]["sample_ms"] = round(ms_sample, 4)
                 kern[name]["algorithmic_GB"] = round(ab / 1e9, 4)
                 kern[name]["GBps"] = round(ab / 1e9 / (ms_sample / 1e3), 1) if ms_sample > 0 else None
@@ -413,7 +413,8 @@ def main():
         def roof(name):
             if not name or name not in kern or not kern[name].get("GBps"):
                 return None
-            tr = TRAFFIC.get(name)
+            # (the timers carry the names of the stages' kernels; the counters those of the functions that ran: the partition-local forms)
+            tr = TRAFFIC.get(name) or TRAFFIC.get({"k_ut_flags": "k_ut_flags_part", "k_cc_adjacency": "k_cc_adjacency_part", "k_gather": "k_gather_split"}.get(name, name))
             # traffic: HBM gigabytes per launch (set) from the committed rocprofv3 --pmc passes of this same workload
             # (profiles/traffic_100M.json; null for other workloads), raw counters beside it
             r = dict(kernel=name, bound=bound_from_counters(tr, kern[name]["sample_ms"]) or BOUND.get(name, "hbm"), achieved=kern[name]["GBps"], peak=HBM_PEAK_GBS, unit="GB/s",
@@ -427,8 +428,7 @@ def main():
                 # of the figure the survey prices the step at.
                 # The launch time is that of ALL the kernel's launches of a step, so the units are all theirs too: the sample's
                 # occurrences and distinct k-mers + those of the cutter table's own launch (the unitigs' k-mers, a few percent).
-                lps_ = kern[name]["launches"] / max(args.steps, 1)
-                cut_occ, cut_dist = (stats.get("n_cutter_occ", 0), stats["n_cutter"]) if lps_ > 2.5 else (0, 0)
+                cut_occ, cut_dist = stats.get("n_cutter_occ", 0), stats["n_cutter"]      # (the cutter table's launch is in the time: its units are in the bytes)
                 surv = 8.0 * (stats["n_occ"] + cut_occ) + 12.0 * (stats["n_distinct"] + cut_dist)
                 moved, t_s = kern[name]["algorithmic_GB"], kern[name]["sample_ms"] / 1e3
                 r.update(achieved=round(surv / 1e9 / t_s, 1), frac=round(surv / 1e9 / t_s / HBM_PEAK_GBS, 4),
