@@ -125,6 +125,9 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             uint32_t R;
             const uint32_t rbase = mf_wave_excl_scan((uint32_t)__popc(remote), &R);
             uint32_t idx[8];
+            // (Tried in round 4: two slots per LDS read -- ds_read_b128, an odd home slot skipping the pair's first -- so that the loop, which
+            // runs as long as the slowest of the wave's lanes probes, makes half the trips: k_ut_flags 26.7 -> 30.0 ms, k_cc_adjacency 5.8 ->
+            // 6.6: four more registers across the loop and two compares per trip where most lanes need one trip.)
             // (Tried in round 3: the first probes of eight, four or two neighbours in flight behind one wait, the rest in a
             // wave-uniform loop.  137 / 119 / 109 VGPRs instead of 81 take a wave per SIMD away, and every lane then reads for all
             // neighbours of a batch whether it wants them or not: k_ut_flags 29.2 ms (four at a time) / 28.3 (two) against 26.2 with
