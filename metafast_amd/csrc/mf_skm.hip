@@ -1572,9 +1572,9 @@ __global__ void k_skm_pilot_dir(const uint32_t *__restrict__ cnt, uint32_t n, ui
 // -> *rho = distinct k-mers per occurrence among the sampled units (< 0: nothing sampled); bufA / pstart / plen: level 1 (indexed by digit)
 template <int K>
 static int skm_pilot(mf_ctx *ctx, const skm_rec *bufA, const uint64_t *pstart, const uint32_t *plen, uint32_t dlo, uint32_t dhi, uint64_t n_occ, int nd1,
-                     int bits_planned, int kthr, double *rho, double *kept) {
+                     int bits_planned, int kthr, double *rho, double *kept, double *rec_per_occ) {
     hipStream_t st = ctx->stream;
-    *rho = -1.0; *kept = -1.0;
+    *rho = -1.0; *kept = -1.0; *rec_per_occ = 0.0;
     if (dhi <= dlo) return MF_OK;
     const uint32_t R = std::min<uint32_t>(8u, dhi - dlo);
     const int pb = std::min((int)SKM_DIGIT_BITS, bits_planned + 3);                       // would-be units an eighth of the planned size
@@ -1623,6 +1623,7 @@ static int skm_pilot(mf_ctx *ctx, const skm_rec *bufA, const uint64_t *pstart, c
     const bool over = (res[0] & 0xFFFFFFFFull) != 0;
     *rho = over ? 1.0 : (double)res[1] / (double)tot[1];              // (a unit beyond 64 passes at an eighth of the size: plan as fine as it gets)
     if (!over) *kept = (double)res[3] / (double)tot[1];
+    *rec_per_occ = (double)tot[0] / (double)tot[1];                    // (padded to fours per would-be unit: a few per cent high)
     if (ctx->opt_verbose)
         fprintf(stderr, "[mf] skm pilot: %u would-be units of %u regions (2^%d per region): %llu records, %llu occurrences, %llu distinct k-mers = %.4f per occurrence (%llu kept), %llu unit(s) redone\n",
                 nb, R, pb, tot[0], tot[1], res[1], *rho, res[3], res[2] & 0xFFFFFFFFull);
@@ -1793,11 +1794,15 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
     if (open) {
         // ---- the pilot: distinct k-mers per occurrence -> the levels after the first
         *plan_open = false;
-        double rho = -1.0, kept = -1.0;
-        MF_TRY(skm_pilot<K>(ctx, bufA.p, pstart.p, plen.p, dlo, dhi, n_occ, nd1, total_bits - bits1, kthr, &rho, &kept));
+        double rho = -1.0, kept = -1.0, rpo = 0.0;
+        MF_TRY(skm_pilot<K>(ctx, bufA.p, pstart.p, plen.p, dlo, dhi, n_occ, nd1, total_bits - bits1, kthr, &rho, &kept, &rpo));
         ctx->last_pilot_rho = rho;
         if (rho > 0.0) {
-            const double want_units = (double)n_occ * rho / (double)std::max<int64_t>(64, ctx->opt_skm_unit_distinct);
+            double want_units = (double)n_occ * rho / (double)std::max<int64_t>(64, ctx->opt_skm_unit_distinct);
+            // ... and a unit's RECORDS should fit the search for identical ones (its first C2_DD * SKM_CT = 2048 records go through the
+            // table as records, the rest is inserted as it comes): 380 M reads at 315-fold depth planned by distinct k-mers alone had
+            // 3170 records per unit and lost 6 % of k_skm_count to the records the search did not see
+            if (ctx->opt_skm_dedupe) want_units = std::max(want_units, (double)n_occ * rpo / (double)ctx->opt_skm_unit_records);
             int Bc = 0; while (Bc < 30 && (double)(1ull << Bc) < want_units) Bc++;
             const int r = std::max(1, std::min(Bc - bits1, std::min((int)SKM_DIGIT_BITS, 30 - bits1)));
             if (ctx->opt_verbose) fprintf(stderr, "[mf] skm pilot: %.4f distinct k-mers per occurrence -> %d bits after level 1 (planned from the occurrences alone: %d)\n", rho, r, total_bits - bits1);

@@ -59,15 +59,15 @@ def _gather_sized(t, sizes, rank, world):
     threshold levels of the cutter issue hundreds.  Otherwise: one broadcast per rank into its slice of the pre-sized buffer
     (exactly the sum of the sizes on the wire, nothing padded)."""
     tot, mx = sum(sizes), max(sizes) if sizes else 0
-    buf = torch.empty(max(tot, 1), dtype=t.dtype, device=t.device)
+    buf = _alloc(lambda: torch.empty(max(tot, 1), dtype=t.dtype, device=t.device))
     if not tot:
         return buf[:0]
     if len(set(sizes)) == 1:
         dist.all_gather_into_tensor(buf[:tot], t.contiguous())
     elif mx * world <= tot + tot // 8 + 4096:
-        inp = torch.empty(mx, dtype=t.dtype, device=t.device)
+        inp = _alloc(lambda: torch.empty(mx, dtype=t.dtype, device=t.device))
         inp[:t.numel()] = t
-        pad = torch.empty(mx * world, dtype=t.dtype, device=t.device)
+        pad = _alloc(lambda: torch.empty(mx * world, dtype=t.dtype, device=t.device))
         dist.all_gather_into_tensor(pad, inp)
         at = 0
         for r, n in enumerate(sizes):
@@ -85,6 +85,15 @@ def _gather_sized(t, sizes, rank, world):
     return buf[:tot]
 
 
+# torch allocations of the exchange helpers go through this hook: run_samples points it at _with_room (the library's arena may hold all
+# of the device in idle regions -- 4 x 380 M reads: 42 MB free when the gathered unitigs wanted 264 MB), anybody else gets a plain call
+_ALLOC = [lambda fn: fn()]
+
+
+def _alloc(fn):
+    return _ALLOC[0](fn)
+
+
 def gather_sequences(bases, offsets):
     """bases: uint8[n_bases], offsets: int64[n+1] of this rank's unitigs -> concatenation over all ranks
     (rank order), offsets rebased; the result has 64 bytes of slack after the last base."""
@@ -92,8 +101,8 @@ def gather_sequences(bases, offsets):
     parts_o = all_gather_ragged(offsets)
     nb = sum(int(p.numel()) for p in parts_b)
     ns = sum(int(p.numel()) - 1 for p in parts_o)
-    allb = torch.zeros(nb + 64, dtype=torch.uint8, device=bases.device)
-    allo = torch.zeros(ns + 1, dtype=torch.int64, device=bases.device)
+    allb = _alloc(lambda: torch.zeros(nb + 64, dtype=torch.uint8, device=bases.device))
+    allo = _alloc(lambda: torch.zeros(ns + 1, dtype=torch.int64, device=bases.device))
     pb = po = 0
     for b, o in zip(parts_b, parts_o):
         n = int(o.numel()) - 1
@@ -201,7 +210,7 @@ class TorchComm:
         if t.is_cuda and dist.get_backend() == "gloo":         # (tests: staged through the host, the same call below)
             return self.all_to_all(t.cpu(), matrix).to(t.device)
         t0 = time.perf_counter()
-        out = torch.empty(sum(recv), dtype=t.dtype, device=t.device)
+        out = _alloc(lambda: torch.empty(sum(recv), dtype=t.dtype, device=t.device))
         dist.all_to_all_single(out, t.contiguous(), recv, send)
         self._account(t0, out.numel() * out.element_size())
         return out
@@ -277,7 +286,7 @@ class ThreadComm:
 
 
 def _i64(n, device):
-    return torch.empty(max(int(n), 1), dtype=torch.int64, device=device)
+    return _alloc(lambda: torch.empty(max(int(n), 1), dtype=torch.int64, device=device))
 
 
 class DistAbort(L.MetafastError):
@@ -305,7 +314,7 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
         """an exchange buffer of n int64; on a rank whose library call has failed it is ZEROED: the rank keeps the collectives going with
         buffers of the agreed sizes until the next status gather, and what its healthy peers read from them meanwhile must be in-range
         indices and ranks, not whatever the allocator left there"""
-        return torch.zeros(max(int(n), 1), dtype=torch.int64, device=device) if err else _i64(n, device)
+        return _alloc(lambda: torch.zeros(max(int(n), 1), dtype=torch.int64, device=device)) if err else _i64(n, device)
 
     def mark(name):
         nonlocal t0, w0
@@ -457,6 +466,7 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
 
     goods, seqss, hists, n_occ, n_distinct = [], [], [], 0, 0
     comm_stats = dict(collectives=0, bytes_in=0, seconds=0.0)
+    _ALLOC[0] = lambda fn: _with_room(ctx, fn)
     for si, sample in enumerate(samples):
         if si:
             # several samples on this rank: the previous sample's lookup index (3-6 times its table) is not needed again before

@@ -26,7 +26,7 @@ for variant in os.environ.get("MF_VARIANTS", "").split(";"):        # MF_VARIANT
     t0 = time.perf_counter()
     r = subprocess.run([os.path.join(root, "metafast.sh"), "-k", "31", "-i", *files, "-w", wd], capture_output=True, text=True, cwd="/tmp", env=dict(os.environ, MF_OPTIONS=variant))
     print("MF_OPTIONS=%s: exit %d total %.2f s" % (variant, r.returncode, time.perf_counter() - t0))
-    print("\n".join(l for l in r.stderr.splitlines() if "set-up" in l or "count_reads (1" in l or "driver" in l))
+    print("\n".join(l for l in r.stderr.splitlines() if "write_" in l or "count_reads (1" in l or "driver" in l))
 subprocess.run(["rm", "-rf", wd])
 t0 = time.perf_counter()
 r = subprocess.run([os.path.join(root, "metafast.sh"), "-k", "31", "-i", *files, "-w", wd, "-v"], capture_output=True, text=True, cwd="/tmp")
