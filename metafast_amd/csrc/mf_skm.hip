@@ -12,13 +12,16 @@
 //      k_scan         region starts / exact output ranges (padded to whole 64-byte lines)
 //   S2 k_skm_scatter  the minimizer scan (again, where S1 ran over everything), records built and radix-partitioned through
 //                     64-byte LDS staging lines; one-pass form: regions reserved chunk by chunk during the scatter
+//      skm_pilot      (reads) a few hundred would-be units of level 1 are copied out and counted: distinct k-mers per occurrence
+//                     and the share that survives the cut decide the bits of the following levels and the table partitions per
+//                     unit -- the plan assumes no sequencing depth
 //   S3 k_skm_split    further levels: the digit is read from the record (22 digit bits travel with it)
-//   S4 k_skm_count    one partition per 512-thread workgroup: identical records are told apart first (a pass of the records
-//                     through the empty table: the k-mers of a record that occurs n times are inserted once, with weight n);
-//                     every wave deals the surviving records out as items of <= 2 k-mers -> open-addressed count table in
-//                     LDS -> compacted (key,count) slices; a batch of partitions at a time
-//      k_gather       slices of the batch -> dense arrays, grouped by partition (the HBM index is built partition by
-//                     partition, mf_table.hip)
+//   S4 k_skm_count    one counting unit per 512-thread workgroup at a time, units claimed from a counter three ahead: identical
+//                     records are told apart first (a pass of the records through the empty table: the k-mers of a record that
+//                     occurs n times are inserted once, with weight n); every wave deals the surviving records out as items of
+//                     <= 2 k-mers -> open-addressed count table in LDS -> compacted (key,count) slices; a batch of units at a time
+//      k_gather       slices of the batch -> dense arrays, every unit cut into 2^s table partitions by the next bits of the
+//                     partition hash (the HBM index is built partition by partition, mf_table.hip)
 //
 // A partition holds ALL occurrences of its k-mers, so the counts are exact; only the grouping of the dense table
 // differs from mf_count.hip (by minimizer partition instead of by hash partition).  If a partition has more distinct
