@@ -26,6 +26,16 @@ SAN = ["-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize
 ENV = dict(os.environ, ASAN_OPTIONS="exitcode=99:detect_leaks=0:abort_on_error=0", UBSAN_OPTIONS="exitcode=99:halt_on_error=1:print_stacktrace=1")
 
 
+_CWD = [None]
+
+
+@pytest.fixture(autouse=True)
+def _scratch_cwd(tmp_path):
+    _CWD[0] = str(tmp_path)
+    yield
+    _CWD[0] = None
+
+
 @pytest.fixture(scope="module")
 def binaries():
     if not shutil.which("g++"):
@@ -47,6 +57,7 @@ def binaries():
 
 def _run(cmd, **kw):
     kw.setdefault("input", "y\n")             # (a used workDir asks "rewrite them?")
+    kw.setdefault("cwd", _CWD[0])              # (a tool run without -w makes ./workDir: not in the repository)
     r = subprocess.run(cmd, capture_output=True, text=True, errors="replace", env=ENV, timeout=120, **kw)
     assert r.returncode in (0, 1), "exit %s\n%s\n%s" % (r.returncode, " ".join(map(str, cmd)), (r.stdout + r.stderr)[-3000:])
     return r
@@ -251,5 +262,5 @@ def test_driver_options_properties_and_matrices(binaries, tmp_path):
     for args in (["-t"], ["-t", "nonsense"], ["-k"], ["-k", "x", "-i"], ["-i", "a.fa", "-i", "b.fa", "-k", "31", "-w", str(tmp_path / "g")], ["--work-dir"], ["-t", "view"],
                  ["-t", "view", "-k", "99", "--kmers-file", "/nonexistent"], ["-h"], ["--help-all"], ["-t", "kmer-counter", "-k", "0", "-i", golden, "-w", str(tmp_path / "g2")],
                  ["-m", "4G", "-ea", "-Xmx1g", "--tools"], ["", "", ""], ["-w", str(tmp_path / "g3"), "-s", "nonsense", "-i", golden], ["-t", "dist-matrix-calculator", "--features", golden, "-w", str(tmp_path / "g4")]):
-        r = subprocess.run([cli, *args], capture_output=True, text=True, errors="replace", env=ENV, timeout=60, input="")
+        r = subprocess.run([cli, *args], capture_output=True, text=True, errors="replace", env=ENV, timeout=60, input="", cwd=str(tmp_path))
         assert r.returncode in (0, 1), (args, r.returncode, (r.stdout + r.stderr)[-2000:])
