@@ -414,7 +414,14 @@ __device__ __forceinline__ bool mf_index_find_ph(const mf_index_view &ix, uint64
     if (ix.compact) {
         const uint64_t h = mf_phash(key);
         const uint64_t part = ix.skm_k ? (uint64_t)(ph >> (32 - ix.part_bits)) : (h >> (64 - ix.part_bits));
+#if defined(NB_ABLATE) && (NB_ABLATE & 4)
+        const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(&ix.dir[2 * (part & 4095)]);
+#else
         const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(&ix.dir[2 * part]);
+#endif
+#if defined(NB_ABLATE) && (NB_ABLATE & 8)
+        if (d.x != 12345ull) return false;
+#endif
         const uint32_t *__restrict__ reg = reinterpret_cast<const uint32_t *>(ix.slots) + (d.x >> 6);
         const uint32_t rmask = (1u << (uint32_t)(d.x & 63ull)) - 1u, hs = mf_pslot(h), tag = hs >> MF_CIDX_REL_BITS;
         uint32_t s = hs & rmask;

@@ -5,23 +5,31 @@
 // 16-byte reads per k-mer, each pulling in a whole line: round 1 measured 169 GB fetched for 38 GB asked (k_ut_flags) and
 // 60 GB for 10 GB (k_cc_adjacency).  But a table that comes out of the counting pass is ordered by MINIMIZER partition,
 // and nine neighbours in ten share their k-mer's minimizer, i.e. its partition -- a few hundred k-mers that sit next to
-// each other in the table.  So: one wave per partition.  It reads the partition's keys (coalesced), builds a small
-// open-addressed table of them in LDS (512 slots: 8-byte key + 2-byte position), and looks the neighbours up there; only a
+// each other in the table.  So: one wave per partition.  It reads the partition's keys (coalesced) into LDS, builds a small
+// open-addressed index of them there (1024 two-byte slots: tag + position), and looks the neighbours up there; only a
 // neighbour whose own minimizer differs (its partition hash says so before any memory is touched) goes to the HBM index.
 // Partitions larger than NB_CAP keys use the HBM index for everything.
 #pragma once
 #include "mf_common.h"
 #ifdef __HIPCC__
-#define NB_SLOTS 512
-#define NB_CAP 352                 // keys of a partition that go into the LDS table (load <= 0.69)
+#ifndef NB_ABLATE
+#define NB_ABLATE 0
+#endif
+#define NB_SLOTS 1024               // 16-bit slots of a wave's index (tag | position): load <= 0.34, on average half of that
+#define NB_CAP 352                 // keys of a partition that go into LDS
 #define NB_WAVES 4                 // waves (= partitions in flight) per workgroup
 #define NB_NONE 0xFFFFFFFFu
 
 #define NB_RQ 96                   // remote requests a wave collects per 64 k-mers (more: looked up on the spot); 96: 26 KiB of LDS per workgroup = six per CU (128: five)
+// The LDS table of a partition is its keys IN TABLE ORDER plus an open-addressed index of 16-bit slots, slot = tag (the hash bits
+// after the home slot's) | position: a lookup of a k-mer that is not there -- three neighbours in four -- ends at the first empty
+// slot without reading a key, and a key is read only behind a matching tag.  (Until round 4 the slots held the keys themselves, 512
+// of them at load <= 0.69: every trip of a probe loop an 8-byte read and two 64-bit compares, and the loops ran ~5 trips because a
+// wave probes as long as the slowest of its lanes.)
 struct nb_lds {
-    uint64_t key[NB_WAVES][NB_SLOTS]; uint64_t rq_key[NB_WAVES][NB_RQ];
+    uint64_t key[NB_WAVES][NB_CAP]; uint64_t rq_key[NB_WAVES][NB_RQ];
     uint32_t rq_ph[NB_WAVES][NB_RQ]; uint32_t rq_idx[NB_WAVES][NB_RQ];
-    uint16_t pos[NB_WAVES][NB_SLOTS];
+    uint32_t slot[NB_WAVES][NB_SLOTS / 2];                                  // two slots a word (LDS compare-and-swap works on words)
 };
 
 // neighbour i of x: i = 2*nuc (append nuc on the right) or 2*nuc+1 (prepend nuc on the left); *ph = its partition hash
@@ -60,16 +68,27 @@ __device__ __forceinline__ uint64_t nb_neighbour_mn(uint64_t x, uint64_t rcx, in
 // partition hash): neighbours that other ranks own are not looked up, emit gets their numbers in `foreign` (8 bits).
 #define NB_BIGCAP (NB_CAP * NB_WAVES)
 __device__ __forceinline__ uint32_t nb_hash(uint64_t key) { return ((uint32_t)key ^ (uint32_t)(key >> 29)) * 0x9E3779B1u; }
+// the canonical INTERIOR of a k-mer: its middle k-2 bases or their reverse complement, whichever is smaller (rcx = mf_revcomp(x, k))
+__device__ __forceinline__ uint64_t nb_interior(uint64_t x, uint64_t rcx, int k) {
+    const uint64_t WM = (1ull << (2 * k - 4)) - 1ull;
+    const uint64_t w = (x >> 2) & WM, rw = (rcx >> 2) & WM;
+    return w < rw ? w : rw;
+}
 template <int MODE, typename F>
 __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
                                             uint32_t p_lo, uint32_t np, int k, nb_lds &S, int lw, uint32_t me, F &&emit) {
     constexpr bool BIG = MODE == 2;
     constexpr uint32_t SLOTS = BIG ? (uint32_t)(NB_SLOTS * NB_WAVES) : (uint32_t)NB_SLOTS;
-    constexpr int HSHIFT = BIG ? 21 : 23;                                   // 11 / 9 slot bits
+    constexpr int HSHIFT = BIG ? 20 : 22;                                   // 12 / 10 slot bits
+    constexpr int POSBITS = BIG ? 11 : 9;                                   // NB_BIGCAP <= 2047, NB_CAP <= 511: a position is never all ones,
+    constexpr uint32_t POSMASK = (1u << POSBITS) - 1u;                      // so no entry looks like an empty slot (0xFFFF)
+    constexpr int TSHIFT = HSHIFT - (16 - POSBITS);                         // 5 / 7 tag bits, the hash bits below the slot's
+    constexpr uint32_t TAGMASK = (1u << (16 - POSBITS)) - 1u;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t first = BIG ? blockIdx.x : blockIdx.x * NB_WAVES + wave, stride = BIG ? gridDim.x : gridDim.x * NB_WAVES;
     const uint64_t kmask = (1ull << (2 * k)) - 1;
-    uint64_t *hk = BIG ? &S.key[0][0] : S.key[wave]; uint16_t *hp = BIG ? &S.pos[0][0] : S.pos[wave];
+    uint64_t *hk = BIG ? &S.key[0][0] : S.key[wave]; uint32_t *hw = BIG ? &S.slot[0][0] : S.slot[wave];
+    const uint16_t *hs = reinterpret_cast<const uint16_t *>(hw);
     uint64_t *rk = S.rq_key[wave]; uint32_t *rp = S.rq_ph[wave], *ri = S.rq_idx[wave];
     const uint32_t tl = BIG ? threadIdx.x : lane, tn = BIG ? (uint32_t)(64 * NB_WAVES) : 64u;      // the team that builds the table
     // (wave level: the barrier builtin orders nothing by itself -- pair it with a wavefront-scope fence so that the LDS hand-offs
@@ -85,15 +104,20 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
         if (MODE == 2 && !mid) continue;
         const bool local = BIG || n <= (uint32_t)NB_CAP;
         if (local) {
-            for (uint32_t s = tl; s < SLOTS; s += tn) hk[s] = MF_EMPTY;
+            for (uint32_t s = tl; s < SLOTS / 2; s += tn) hw[s] = 0xFFFFFFFFu;
             team_sync();
             for (uint32_t j = tl; j < n; j += tn) {
                 const uint64_t x = keys[lo + j];
-                uint32_t s = nb_hash(x) >> HSHIFT;
+                hk[j] = x;
+                const uint32_t h = nb_hash(nb_interior(x, mf_revcomp(x, k), k));
+                const uint32_t ent = (((h >> TSHIFT) & TAGMASK) << POSBITS) | j;
+                uint32_t s = h >> HSHIFT;
                 for (;;) {                                                  // (keys of a table are distinct)
-                    const unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&hk[s]), (unsigned long long)MF_EMPTY, (unsigned long long)x);
-                    if (old == (unsigned long long)MF_EMPTY) { hp[s] = (uint16_t)j; break; }
-                    s = (s + 1u) & (SLOTS - 1u);
+                    uint32_t *w = &hw[s >> 1];
+                    const uint32_t sh = (s & 1u) * 16u;
+                    const uint32_t old = __atomic_load_n(w, __ATOMIC_RELAXED);
+                    if (((old >> sh) & 0xFFFFu) != 0xFFFFu) { s = (s + 1u) & (SLOTS - 1u); continue; }
+                    if (atomicCAS(w, old, (old & ~(0xFFFFu << sh)) | (ent << sh)) == old) break;      // (lost: the word's other half changed, or this one -- look again)
                 }
             }
             team_sync();
@@ -101,7 +125,7 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
         for (uint32_t j0 = BIG ? wave * 64u : 0u; j0 < n; j0 += BIG ? (uint32_t)(64 * NB_WAVES) : 64u) {      // wave-uniform
             const uint32_t j = j0 + lane;
             const bool have = j < n;
-            const uint64_t x = have ? keys[lo + j] : 0ull;
+            const uint64_t x = have ? (local ? hk[j] : keys[lo + j]) : 0ull;       // (the copy in LDS: the table is read once)
             uint32_t m_nf = 0, m_nl = 0, m_own = 0;
             mf_skm_nbr_mins(x, k, &m_nf, &m_nl, &m_own);
             // Pass 1: which neighbours live in another partition (about one in ten)?  Those are REQUESTS for the HBM index --
@@ -133,23 +157,47 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             // neighbours of a batch whether it wants them or not: k_ut_flags 29.2 ms (four at a time) / 28.3 (two) against 26.2 with
             // the per-neighbour loops below -- profiles/r03f_bench_100M_batched_lookups.json, r03j_bench_100M_flags_batch2.json.)
 #pragma unroll
-            for (uint32_t i = 0; i < 8; i++) {
-                const uint64_t c = cs[i]; const uint32_t ph = phs[i];
-                idx[i] = NB_NONE;
-                if (have && !((foreign >> i) & 1u)) {
-                    if (!((remote >> i) & 1u)) {
-                        uint32_t s = nb_hash(c) >> HSHIFT;
+            for (uint32_t i = 0; i < 8; i++) idx[i] = NB_NONE;
+#if !(NB_ABLATE & 1)
+            if (local) {
+                // the four neighbours of a side differ in ONE base at an end: they share their interior (k-2)-mer, the index is
+                // hashed on it, so ONE walk from the interior's home slot to the next empty slot meets all of them.  A key K met
+                // on the way is neighbour c of the side if its other k-1 bases are x's: K = y (forward) or K = rc(y).
+                const uint64_t LM = kmask >> 2, WM = kmask >> 4;
+                const uint32_t nloc = ~(remote | foreign);
+#pragma unroll
+                for (uint32_t side = 0; side < 2; side++) {
+                    if (have && (nloc & (0x55u << side))) {
+                        const uint64_t w = side ? (x >> 4) : (x & WM), rw = side ? (rcx & WM) : (rcx >> 4);
+                        const uint64_t pa = side ? (rcx & LM) : (x & LM);          // against K >> 2: K = y (right side) / K = rc(y) (left side)
+                        const uint64_t pb = side ? (x >> 2) : (rcx >> 2);          // against K & LM: K = rc(y) (right side) / K = y (left side)
+                        const uint32_t h = nb_hash(w < rw ? w : rw), tag = (h >> TSHIFT) & TAGMASK;
+                        uint32_t s = h >> HSHIFT;
                         for (;;) {
-                            const uint64_t v = hk[s];
-                            if (v == c) { idx[i] = (uint32_t)lo + (uint32_t)hp[s]; break; }
-                            if (v == MF_EMPTY) break;
+                            const uint32_t v = hs[s];
+                            if (v == 0xFFFFu) break;
+                            if ((v >> POSBITS) == tag) {
+                                const uint64_t K = hk[v & POSMASK];
+                                uint32_t c = 4u;
+                                if ((K >> 2) == pa) c = ((uint32_t)K & 3u) ^ (side ? 3u : 0u);
+                                else if ((K & LM) == pb) c = (uint32_t)(K >> (2 * k - 2)) ^ (side ? 0u : 3u);
+                                const uint32_t at = (uint32_t)lo + (v & POSMASK);
+#pragma unroll
+                                for (uint32_t q = 0; q < 4; q++)
+                                    if (c == q && ((nloc >> (2 * q + side)) & 1u)) idx[2 * q + side] = at;
+                            }
                             s = (s + 1u) & (SLOTS - 1u);
                         }
-                    } else {
-                        const uint32_t at = rbase + (uint32_t)__popc(remote & ((1u << i) - 1u));
-                        if (at < (uint32_t)NB_RQ) { rk[at] = c; rp[at] = ph; }
-                        else { uint32_t ii, val; if (mf_index_find_ph(ix, c, mf_remix32(ph), &ii, &val)) idx[i] = ii; }
                     }
+                }
+            }
+#endif
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) {
+                if ((remote >> i) & 1u) {
+                    const uint32_t at = rbase + (uint32_t)__popc(remote & ((1u << i) - 1u));
+                    if (at < (uint32_t)NB_RQ) { rk[at] = cs[i]; rp[at] = phs[i]; }
+                    else { uint32_t ii, val; if (mf_index_find_ph(ix, cs[i], mf_remix32(phs[i]), &ii, &val)) idx[i] = ii; }
                 }
             }
             if (R) {
@@ -157,7 +205,11 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                 const uint32_t Rl = R < (uint32_t)NB_RQ ? R : (uint32_t)NB_RQ;
                 for (uint32_t r = lane; r < Rl; r += 64) {
                     uint32_t ii, val;
+#if NB_ABLATE & 2
+                    ri[r] = (rk[r] == 12345ull && rp[r] == 77u) ? 5u : NB_NONE;
+#else
                     ri[r] = mf_index_find_ph(ix, rk[r], mf_remix32(rp[r]), &ii, &val) ? ii : NB_NONE;
+#endif
                 }
                 wave_sync();
 #pragma unroll
