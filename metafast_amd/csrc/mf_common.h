@@ -409,19 +409,24 @@ int mf_sort_u32_u64(mf_ctx *ctx, const uint32_t *d_keys_in, const uint64_t *d_va
                     uint64_t *d_vals_out);
 int mf_sort_kmers_by_comp(mf_ctx *ctx, const uint32_t *d_comp, const uint64_t *d_kmers, uint64_t n, int key_bits, uint32_t n_comps,
                           uint64_t *d_out);
+// the canonical INTERIOR of a k-mer: its middle k-2 bases or their reverse complement, whichever is smaller (rcx = mf_revcomp(x, k)).
+// The four k-mers that extend a (k-1)-mer on one side share it, and so do their reverse complements: an index hashed on the interior
+// keeps the four neighbours of a side in ONE probe sequence (mf_nbr.h, mf_index_walk_side).
+__host__ __device__ __forceinline__ uint64_t mf_interior(uint64_t x, uint64_t rcx, int k) {
+    const uint64_t WM = (1ull << (2 * k - 4)) - 1ull;
+    const uint64_t w = (x >> 2) & WM, rw = (rcx >> 2) & WM;
+    return w < rw ? w : rw;
+}
+// what the compact index of a table hashes for home slot and tag: the interior for minimizer partitions of k-mers (skm_k = k), else the key
+__host__ __device__ __forceinline__ uint64_t mf_cidx_hkey(uint64_t key, uint32_t skm_k) {
+    return skm_k >= 3u ? mf_interior(key, mf_revcomp(key, (int)skm_k), (int)skm_k) : key;
+}
 // ph: the key's partition hash if the caller has it already (minimizer partitions only), see mf_index_find
 __device__ __forceinline__ bool mf_index_find_ph(const mf_index_view &ix, uint64_t key, uint32_t ph, uint32_t *idx, uint32_t *val) {
     if (ix.compact) {
-        const uint64_t h = mf_phash(key);
+        const uint64_t h = mf_phash(mf_cidx_hkey(key, ix.skm_k));
         const uint64_t part = ix.skm_k ? (uint64_t)(ph >> (32 - ix.part_bits)) : (h >> (64 - ix.part_bits));
-#if defined(NB_ABLATE) && (NB_ABLATE & 4)
-        const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(&ix.dir[2 * (part & 4095)]);
-#else
         const ulonglong2 d = *reinterpret_cast<const ulonglong2 *>(&ix.dir[2 * part]);
-#endif
-#if defined(NB_ABLATE) && (NB_ABLATE & 8)
-        if (d.x != 12345ull) return false;
-#endif
         const uint32_t *__restrict__ reg = reinterpret_cast<const uint32_t *>(ix.slots) + (d.x >> 6);
         const uint32_t rmask = (1u << (uint32_t)(d.x & 63ull)) - 1u, hs = mf_pslot(h), tag = hs >> MF_CIDX_REL_BITS;
         uint32_t s = hs & rmask;
@@ -451,6 +456,90 @@ __device__ __forceinline__ bool mf_index_find_ph(const mf_index_view &ix, uint64
         if (raw.x == MF_EMPTY) return false;
         s = (s + 1) & rmask;
     }
+}
+// (the two halves of mf_index_walk_side for a compact index: the directory entry of the partition, then the probe sequence -- a
+// caller with other work to do issues the first, does the work, and walks when the entry has arrived)
+__device__ __forceinline__ ulonglong2 mf_index_side_dir(const mf_index_view &ix, uint32_t ph) {
+    return *reinterpret_cast<const ulonglong2 *>(&ix.dir[2 * (uint64_t)(ph >> (32 - ix.part_bits))]);
+}
+#ifndef MF_WALK_CAND
+#define MF_WALK_CAND 2
+#endif
+// hs: the interior's slot hash (home slot = hs & region mask, tag = its top bits)
+__device__ __forceinline__ uint32_t mf_index_side_hs(uint64_t pa, uint64_t pb, int k) {
+    const uint64_t WM = (1ull << (2 * k - 4)) - 1ull;
+    const uint64_t wa = pa & WM, wb = pb >> 2;           // the shared interior and its reverse complement
+    return mf_pslot(mf_phash(wa < wb ? wa : wb));
+}
+__device__ __forceinline__ uint32_t mf_index_side_home(const mf_index_view &ix, const ulonglong2 d, uint32_t hs) {
+    return (reinterpret_cast<const uint32_t *>(ix.slots) + (d.x >> 6))[hs & ((1u << (uint32_t)(d.x & 63ull)) - 1u)];
+}
+// v0: the home slot's word (mf_index_side_home), read by the caller ahead of time
+__device__ __forceinline__ void mf_index_walk_side_v(const mf_index_view &ix, const ulonglong2 d, uint32_t hs, uint32_t v0, uint64_t pa, uint64_t pb, uint32_t side, uint32_t want,
+                                                     int k, uint32_t (&out)[4]) {
+    const uint64_t LM = (1ull << (2 * k - 2)) - 1ull;
+    out[0] = out[1] = out[2] = out[3] = 0xFFFFFFFFu;
+    const uint32_t *__restrict__ reg = reinterpret_cast<const uint32_t *>(ix.slots) + (d.x >> 6);
+    const uint32_t rmask = (1u << (uint32_t)(d.x & 63ull)) - 1u, tag = hs >> MF_CIDX_REL_BITS;
+    // the probe sequence first (its slots sit next to each other: one line, seldom two), the keys behind the matching tags
+    // afterwards and TOGETHER: two memory latencies per lookup, not one per slot and one per key in turn
+    constexpr uint32_t NC = MF_WALK_CAND;                 // keys read together
+    uint32_t s = hs & rmask, nc = 0, cand[NC];
+#pragma unroll
+    for (uint32_t q = 0; q < NC; q++) cand[q] = 0u;
+    auto resolve = [&]() {
+        uint64_t K[NC];
+#pragma unroll
+        for (uint32_t q = 0; q < NC; q++) K[q] = q < nc ? ix.keys[d.y + (uint64_t)cand[q]] : ~0ull;
+#pragma unroll
+        for (uint32_t q = 0; q < NC; q++) {
+            if (q >= nc) continue;
+            uint32_t c = 4u;
+            if ((K[q] >> 2) == pa) c = ((uint32_t)K[q] & 3u) ^ (side ? 3u : 0u);
+            else if ((K[q] & LM) == pb) c = (uint32_t)(K[q] >> (2 * k - 2)) ^ (side ? 0u : 3u);
+            if (c < 4u && ((want >> c) & 1u)) {
+                const uint32_t at = (uint32_t)(d.y + (uint64_t)cand[q]);
+#pragma unroll
+                for (uint32_t r = 0; r < 4; r++) if (c == r) out[r] = at;
+            }
+        }
+        nc = 0;
+    };
+    for (uint32_t v = v0; v != MF_CIDX_EMPTY;) {
+        if ((v >> MF_CIDX_REL_BITS) == tag) {
+            const uint32_t rel = v & ((1u << MF_CIDX_REL_BITS) - 1u);
+#pragma unroll
+            for (uint32_t q = 0; q < NC; q++) if (nc == q) cand[q] = rel;
+            if (++nc == NC) resolve();
+        }
+        s = (s + 1u) & rmask;
+        v = reg[s];
+    }
+    if (nc) resolve();
+}
+__device__ __forceinline__ void mf_index_walk_side_d(const mf_index_view &ix, const ulonglong2 d, uint64_t pa, uint64_t pb, uint32_t side, uint32_t want, int k, uint32_t (&out)[4]) {
+    const uint32_t hs = mf_index_side_hs(pa, pb, k);
+    mf_index_walk_side_v(ix, d, hs, mf_index_side_home(ix, d, hs), pa, pb, side, want, k, out);
+}
+// The neighbours of ONE side of a k-mer x in one probe sequence (minimizer-partitioned tables of k-mers).  The four k-mers y_c
+// share k-1 bases with x: pa = what (K >> 2) of a stored key K is if K is y_c on the right side (x's last k-1 bases) or rc(y_c) on the
+// left (rc(x)'s last k-1 bases); pb = what K's low k-1 bases are if K is rc(y_c) on the right / y_c on the left.  side 0: right
+// (y_c = x[1..] + c), 1: left (y_c = c + x[..k-2]).  want: bit c set = look for neighbour c; ph: the partition hash they share (callers
+// group by minimizer).  out[c] = table index or 0xFFFFFFFF.
+__device__ __forceinline__ void mf_index_walk_side(const mf_index_view &ix, uint32_t ph, uint64_t pa, uint64_t pb, uint32_t side, uint32_t want, int k, uint32_t (&out)[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0xFFFFFFFFu;
+    if (!ix.compact) {                                   // (a table with an oversized partition has the generic index: one lookup per neighbour)
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) {
+            if (!((want >> c) & 1u)) continue;
+            const uint64_t y = side ? (((uint64_t)c << (2 * k - 2)) | pb) : ((pa << 2) | c);
+            const uint64_t r = side ? ((pa << 2) | (3u - c)) : (pb | ((uint64_t)(3u - c) << (2 * k - 2)));
+            uint32_t ii, val;
+            if (mf_index_find_ph(ix, y < r ? y : r, ph, &ii, &val)) out[c] = ii;
+        }
+        return;
+    }
+    mf_index_walk_side_d(ix, mf_index_side_dir(ix, ph), pa, pb, side, want, k, out);
 }
 __device__ __forceinline__ bool mf_index_find(const mf_index_view &ix, uint64_t key, uint32_t *idx, uint32_t *val) {
     return mf_index_find_ph(ix, key, ix.skm_k ? mf_skm_ph(key, (int)ix.skm_k) : 0u, idx, val);

@@ -20,15 +20,17 @@
 #define NB_WAVES 4                 // waves (= partitions in flight) per workgroup
 #define NB_NONE 0xFFFFFFFFu
 
-#define NB_RQ 96                   // remote requests a wave collects per 64 k-mers (more: looked up on the spot); 96: 26 KiB of LDS per workgroup = six per CU (128: five)
+#define NB_RQ 64                   // remote requests a wave collects per 64 k-mers (more: looked up on the spot); a request is the neighbours of ONE side that share
+                                   // a minimizer (24 bytes): half a request per k-mer; 25 KiB of LDS per workgroup = six per CU
 // The LDS table of a partition is its keys IN TABLE ORDER plus an open-addressed index of 16-bit slots, slot = tag (the hash bits
 // after the home slot's) | position: a lookup of a k-mer that is not there -- three neighbours in four -- ends at the first empty
 // slot without reading a key, and a key is read only behind a matching tag.  (Until round 4 the slots held the keys themselves, 512
 // of them at load <= 0.69: every trip of a probe loop an 8-byte read and two 64-bit compares, and the loops ran ~5 trips because a
 // wave probes as long as the slowest of its lanes.)
 struct nb_lds {
-    uint64_t key[NB_WAVES][NB_CAP]; uint64_t rq_key[NB_WAVES][NB_RQ];
-    uint32_t rq_ph[NB_WAVES][NB_RQ]; uint32_t rq_idx[NB_WAVES][NB_RQ];
+    uint64_t key[NB_WAVES][NB_CAP];
+    uint64_t rq_pa[NB_WAVES][NB_RQ], rq_pb[NB_WAVES][NB_RQ];               // a request: the two patterns of a side (mf_index_walk_side); then its four answers
+    uint32_t rq_mn[NB_WAVES][NB_RQ], rq_meta[NB_WAVES][NB_RQ];              // the minimizer hash its neighbours share; side | wanted neighbours << 1
     uint32_t slot[NB_WAVES][NB_SLOTS / 2];                                  // two slots a word (LDS compare-and-swap works on words)
 };
 
@@ -89,7 +91,7 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     uint64_t *hk = BIG ? &S.key[0][0] : S.key[wave]; uint32_t *hw = BIG ? &S.slot[0][0] : S.slot[wave];
     const uint16_t *hs = reinterpret_cast<const uint16_t *>(hw);
-    uint64_t *rk = S.rq_key[wave]; uint32_t *rp = S.rq_ph[wave], *ri = S.rq_idx[wave];
+    uint64_t *qa = S.rq_pa[wave], *qb = S.rq_pb[wave]; uint32_t *qm = S.rq_mn[wave], *qt = S.rq_meta[wave];
     const uint32_t tl = BIG ? threadIdx.x : lane, tn = BIG ? (uint32_t)(64 * NB_WAVES) : 64u;      // the team that builds the table
     // (wave level: the barrier builtin orders nothing by itself -- pair it with a wavefront-scope fence so that the LDS hand-offs
     // between lanes are ordered by contract, not by what the alias analysis happens to keep)
@@ -122,7 +124,8 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             }
             team_sync();
         }
-        for (uint32_t j0 = BIG ? wave * 64u : 0u; j0 < n; j0 += BIG ? (uint32_t)(64 * NB_WAVES) : 64u) {      // wave-uniform
+        constexpr uint32_t JSTEP = BIG ? (uint32_t)(64 * NB_WAVES) : 64u;
+        for (uint32_t j0 = BIG ? wave * 64u : 0u; j0 < n; j0 += JSTEP) {      // wave-uniform
             const uint32_t j = j0 + lane;
             const bool have = j < n;
             const uint64_t x = have ? (local ? hk[j] : keys[lo + j]) : 0ull;       // (the copy in LDS: the table is read once)
@@ -134,20 +137,36 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             // ms).  So the wave collects them in LDS, looks them up 64 at a time, one request per lane, and hands the
             // answers back through LDS.
             uint32_t remote = 0, foreign = 0, flip = 0;
-            uint64_t cs[8]; uint32_t phs[8];                                // (kept: the eight neighbours cost ~60 instructions each)
+            uint32_t phs[8];
             const uint64_t rcx = mf_revcomp(x, k);
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) {
                 uint64_t y;
-                cs[i] = nb_neighbour_mn(x, rcx, k, kmask, i, m_nf, m_nl, &y, &phs[i]);       // phs: minimizer hashes, re-mixed only where a partition hash is needed
-                flip |= (cs[i] != y) ? (1u << i) : 0u;
+                const uint64_t cn = nb_neighbour_mn(x, rcx, k, kmask, i, m_nf, m_nl, &y, &phs[i]);       // phs: minimizer hashes, re-mixed only where a partition hash is needed
+                flip |= (cn != y) ? (1u << i) : 0u;
                 // the same minimizer = the same partition; another minimizer that lands in this partition all the same (one in
                 // 2^part_bits) is simply looked up through the index
                 if (have && lw && (mf_remix32(phs[i]) >> (32 - lw)) != me) foreign |= 1u << i;
                 else if (have && !(local && phs[i] == m_own)) remote |= 1u << i;
             }
+            // Requests.  The remote neighbours of a side that share their minimizer -- all four when x's own minimizer was its first /
+            // last M-mer, the usual case -- are ONE request: one directory entry, one probe sequence (the index is hashed on the
+            // interior the four share).  A side whose remote neighbours have different minimizers asks for each of them alone.
+            uint32_t lead[2], grouped = 0, nreq = 0;
+#pragma unroll
+            for (uint32_t side = 0; side < 2; side++) {
+                const uint32_t rem = (remote >> side) & 0x55u;
+                lead[side] = 0;
+                bool same = true;
+#pragma unroll
+                for (int c = 3; c >= 0; c--) if ((rem >> (2 * c)) & 1u) lead[side] = phs[2 * c + side];
+#pragma unroll
+                for (uint32_t c = 0; c < 4; c++) if (((rem >> (2 * c)) & 1u) && phs[2 * c + side] != lead[side]) same = false;
+                if (same) grouped |= 1u << side;
+                nreq += rem ? (same ? 1u : (uint32_t)__popc(rem)) : 0u;
+            }
             uint32_t R;
-            const uint32_t rbase = mf_wave_excl_scan((uint32_t)__popc(remote), &R);
+            const uint32_t rbase = mf_wave_excl_scan(nreq, &R);
             uint32_t idx[8];
             // (Tried in round 4: two slots per LDS read -- ds_read_b128, an odd home slot skipping the pair's first -- so that the loop, which
             // runs as long as the slowest of the wave's lanes probes, makes half the trips: k_ut_flags 26.7 -> 30.0 ms, k_cc_adjacency 5.8 ->
@@ -158,6 +177,46 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             // the per-neighbour loops below -- profiles/r03f_bench_100M_batched_lookups.json, r03j_bench_100M_flags_batch2.json.)
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) idx[i] = NB_NONE;
+            {
+                const uint64_t LM = kmask >> 2;
+                uint32_t at = rbase;
+#pragma unroll
+                for (uint32_t side = 0; side < 2; side++) {
+                    const uint32_t rem = (remote >> side) & 0x55u;
+                    if (!rem) continue;
+                    const uint64_t pa = side ? (rcx & LM) : (x & LM), pb = side ? (x >> 2) : (rcx >> 2);
+                    uint32_t want4 = 0;
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; c++) want4 |= ((rem >> (2 * c)) & 1u) << c;
+                    if ((grouped >> side) & 1u) {
+                        if (at < (uint32_t)NB_RQ) { qa[at] = pa; qb[at] = pb; qm[at] = lead[side]; qt[at] = side | (want4 << 1); }
+                        else {                                                   // (no room: looked up on the spot)
+                            uint32_t o4[4];
+                            mf_index_walk_side(ix, mf_remix32(lead[side]), pa, pb, side, want4, k, o4);
+#pragma unroll
+                            for (uint32_t c = 0; c < 4; c++) if ((want4 >> c) & 1u) idx[2 * c + side] = o4[c];
+                        }
+                        at++;
+                    } else {
+#pragma unroll
+                        for (uint32_t c = 0; c < 4; c++) {
+                            if (!((want4 >> c) & 1u)) continue;
+                            if (at < (uint32_t)NB_RQ) { qa[at] = pa; qb[at] = pb; qm[at] = phs[2 * c + side]; qt[at] = side | (1u << (c + 1)); }
+                            else { uint32_t o4[4]; mf_index_walk_side(ix, mf_remix32(phs[2 * c + side]), pa, pb, side, 1u << c, k, o4); idx[2 * c + side] = o4[c]; }
+                            at++;
+                        }
+                    }
+                }
+            }
+            // lane r takes request r (NB_RQ = 64: one each).  Its directory entry -- the first of the two or three dependent reads of a
+            // lookup -- is asked for HERE and used after the local walks below: one memory latency of every batch behind LDS work.
+            static_assert(NB_RQ <= 64, "one request per lane");
+            const uint32_t Rl = R < (uint32_t)NB_RQ ? R : (uint32_t)NB_RQ;
+            ulonglong2 dent = make_ulonglong2(0ull, 0ull);
+            if (R) {
+                wave_sync();
+                if (lane < Rl && ix.compact) dent = mf_index_side_dir(ix, mf_remix32(qm[lane]));
+            }
 #if !(NB_ABLATE & 1)
             if (local) {
                 // the four neighbours of a side differ in ONE base at an end: they share their interior (k-2)-mer, the index is
@@ -192,32 +251,32 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                 }
             }
 #endif
-#pragma unroll
-            for (uint32_t i = 0; i < 8; i++) {
-                if ((remote >> i) & 1u) {
-                    const uint32_t at = rbase + (uint32_t)__popc(remote & ((1u << i) - 1u));
-                    if (at < (uint32_t)NB_RQ) { rk[at] = cs[i]; rp[at] = phs[i]; }
-                    else { uint32_t ii, val; if (mf_index_find_ph(ix, cs[i], mf_remix32(phs[i]), &ii, &val)) idx[i] = ii; }
-                }
-            }
             if (R) {
-                wave_sync();
-                const uint32_t Rl = R < (uint32_t)NB_RQ ? R : (uint32_t)NB_RQ;
-                for (uint32_t r = lane; r < Rl; r += 64) {
-                    uint32_t ii, val;
+                if (lane < Rl) {
+                    uint32_t o4[4];
+                    const uint32_t meta = qt[lane];
 #if NB_ABLATE & 2
-                    ri[r] = (rk[r] == 12345ull && rp[r] == 77u) ? 5u : NB_NONE;
+                    o4[0] = o4[1] = o4[2] = o4[3] = (qa[lane] == 12345ull && dent.x == 77ull) ? 5u : NB_NONE;
 #else
-                    ri[r] = mf_index_find_ph(ix, rk[r], mf_remix32(rp[r]), &ii, &val) ? ii : NB_NONE;
+                    if (ix.compact) mf_index_walk_side_d(ix, dent, qa[lane], qb[lane], meta & 1u, meta >> 1, k, o4);
+                    else mf_index_walk_side(ix, mf_remix32(qm[lane]), qa[lane], qb[lane], meta & 1u, meta >> 1, k, o4);
 #endif
+                    uint32_t *ans = reinterpret_cast<uint32_t *>(&qa[lane]), *ans2 = reinterpret_cast<uint32_t *>(&qb[lane]);      // (the request has been read: its answers take its place)
+                    ans[0] = o4[0]; ans[1] = o4[1]; ans2[0] = o4[2]; ans2[1] = o4[3];
                 }
                 wave_sync();
+                uint32_t at = rbase;
 #pragma unroll
-                for (uint32_t i = 0; i < 8; i++) {
-                    if ((remote >> i) & 1u) {
-                        const uint32_t at = rbase + (uint32_t)__popc(remote & ((1u << i) - 1u));
-                        if (at < (uint32_t)NB_RQ) idx[i] = ri[at];
+                for (uint32_t side = 0; side < 2; side++) {
+                    const uint32_t rem = (remote >> side) & 0x55u;
+                    if (!rem) continue;
+#pragma unroll
+                    for (uint32_t c = 0; c < 4; c++) {
+                        if (!((rem >> (2 * c)) & 1u)) continue;
+                        if (at < (uint32_t)NB_RQ) idx[2 * c + side] = c < 2 ? reinterpret_cast<const uint32_t *>(&qa[at])[c] : reinterpret_cast<const uint32_t *>(&qb[at])[c - 2];
+                        if (!((grouped >> side) & 1u)) at++;
                     }
+                    if ((grouped >> side) & 1u) at++;
                 }
                 wave_sync();
             }

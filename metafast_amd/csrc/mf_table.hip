@@ -93,8 +93,8 @@ __global__ void k_index_dir_pack(const uint64_t *__restrict__ roff, const uint32
 }
 // slot of entry i of partition [lo, ..): tag of the key's hash | position inside the partition (the keys of a table are distinct:
 // the first free slot from the home slot on is taken)
-__device__ __forceinline__ void mf_cidx_insert(uint32_t *reg, uint32_t rmask, uint64_t key, uint32_t rel) {
-    const uint32_t hs = mf_pslot(mf_phash(key));
+__device__ __forceinline__ void mf_cidx_insert(uint32_t *reg, uint32_t rmask, uint64_t key, uint32_t rel, uint32_t skm_k) {
+    const uint32_t hs = mf_pslot(mf_phash(mf_cidx_hkey(key, skm_k)));
     const uint32_t v = ((hs >> MF_CIDX_REL_BITS) << MF_CIDX_REL_BITS) | rel;
     uint32_t s = hs & rmask;
     for (;;) {
@@ -106,7 +106,7 @@ __device__ __forceinline__ void mf_cidx_insert(uint32_t *reg, uint32_t rmask, ui
 template <int TEAM>
 __global__ __launch_bounds__(256) void k_index_build_part(uint32_t *__restrict__ slots, const uint64_t *__restrict__ dir, const uint64_t *__restrict__ keys,
                                                           const uint64_t *__restrict__ part_off, uint32_t np, const uint32_t *__restrict__ biglist,
-                                                          const unsigned int *__restrict__ n_big) {
+                                                          const unsigned int *__restrict__ n_big, uint32_t skm_k) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int TEAMS = 256 / TEAM;
     const int team = threadIdx.x / TEAM, tl = threadIdx.x % TEAM;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_index_build_part(uint32_t *__restrict__
         for (uint32_t j = tl; j < S; j += TEAM) reg[j] = MF_CIDX_EMPTY;
         sync();
         const uint64_t lo = part_off[p], n_here = part_off[p + 1] - lo;
-        for (uint64_t i = tl; i < n_here; i += TEAM) mf_cidx_insert(reg, rmask, keys[lo + i], (uint32_t)i);
+        for (uint64_t i = tl; i < n_here; i += TEAM) mf_cidx_insert(reg, rmask, keys[lo + i], (uint32_t)i, skm_k);
         sync();
         uint32_t *dst = slots + (d >> 6);
         for (uint32_t j = tl; j < S; j += TEAM) dst[j] = reg[j];
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void k_index_build_part(uint32_t *__restrict__
 // regions too large for LDS: one workgroup per listed partition (biglist from the back) clears its region in HBM and
 // inserts with global atomics
 __global__ __launch_bounds__(256) void k_index_build_huge(uint32_t *__restrict__ slots, const uint64_t *__restrict__ dir, const uint64_t *__restrict__ keys,
-                                                          const uint64_t *__restrict__ part_off, uint32_t np, const uint32_t *__restrict__ biglist, uint32_t n_huge) {
+                                                          const uint64_t *__restrict__ part_off, uint32_t np, const uint32_t *__restrict__ biglist, uint32_t n_huge, uint32_t skm_k) {
     for (uint32_t it = blockIdx.x; it < n_huge; it += gridDim.x) {
         const uint32_t p = biglist[np - 1u - it];
         const uint64_t d = dir[2 * (size_t)p];
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_index_build_huge(uint32_t *__restrict__
         __threadfence();
         __syncthreads();
         const uint64_t lo = part_off[p], n_here = part_off[p + 1] - lo;
-        for (uint64_t i = threadIdx.x; i < n_here; i += blockDim.x) mf_cidx_insert(reg, rmask, keys[lo + i], (uint32_t)i);
+        for (uint64_t i = threadIdx.x; i < n_here; i += blockDim.x) mf_cidx_insert(reg, rmask, keys[lo + i], (uint32_t)i, skm_k);
         __syncthreads();
     }
 }
@@ -305,24 +305,25 @@ int mf_table_ensure_index(mf_table *t) {
         if (hs[2]) return mf_index_build(ctx, t->d_keys, t->d_counts, t->n, &t->index, &t->index_bytes);
         const uint64_t cap = hs[0];
         const uint32_t n_big = (uint32_t)hs[1], n_huge = (uint32_t)hs[3];
+        const uint32_t skm_k = t->part_skm ? (uint32_t)t->k : 0u;              // (minimizer partitions: home slot and tag from the key's interior, mf_cidx_hkey)
         void *p = nullptr;
         MF_TRY(mf_alloc(ctx, cap * sizeof(uint32_t), &p));
         {
             mf_ktimer tm(ctx, "k_index_build_part");
             const size_t lds = (size_t)4 * MF_IDX_WAVE_SLOTS * sizeof(uint32_t);
             const unsigned grid = (unsigned)std::min<uint64_t>((np + 3) / 4, (uint64_t)ctx->n_cu * 8);
-            k_index_build_part<64><<<grid, 256, lds, ctx->stream>>>((uint32_t *)p, dir.p, t->d_keys, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1]);
+            k_index_build_part<64><<<grid, 256, lds, ctx->stream>>>((uint32_t *)p, dir.p, t->d_keys, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1], skm_k);
             if (n_big) {      // regions of up to 8192 slots (the counting pass cannot produce partitions of more than 4096 keys)
                 const size_t lds2 = (size_t)8192 * sizeof(uint32_t);
-                k_index_build_part<256><<<(unsigned)std::min<uint32_t>(n_big, (uint32_t)ctx->n_cu * 2), 256, lds2, ctx->stream>>>((uint32_t *)p, dir.p, t->d_keys, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1]);
+                k_index_build_part<256><<<(unsigned)std::min<uint32_t>(n_big, (uint32_t)ctx->n_cu * 2), 256, lds2, ctx->stream>>>((uint32_t *)p, dir.p, t->d_keys, t->d_part_off, np, biglist.p, (const unsigned int *)&scal.p[1], skm_k);
             }
             if (n_huge)
-                k_index_build_huge<<<(unsigned)std::min<uint32_t>(n_huge, (uint32_t)ctx->n_cu * 4), 256, 0, ctx->stream>>>((uint32_t *)p, dir.p, t->d_keys, t->d_part_off, np, biglist.p, n_huge);
+                k_index_build_huge<<<(unsigned)std::min<uint32_t>(n_huge, (uint32_t)ctx->n_cu * 4), 256, 0, ctx->stream>>>((uint32_t *)p, dir.p, t->d_keys, t->d_part_off, np, biglist.p, n_huge, skm_k);
         }
         MF_HIP(hipGetLastError());
         MF_HIP(hipStreamSynchronize(ctx->stream));          // (biglist / scal are released below)
         t->index.slots = p; t->index.cap = cap; t->index.part_bits = (uint32_t)t->part_bits;
-        t->index.skm_k = t->part_skm ? (uint32_t)t->k : 0u;
+        t->index.skm_k = skm_k;
         t->index.compact = 1; t->index.keys = t->d_keys; t->index.counts = t->d_counts;
         t->index.dir_bytes = dir.bytes(); t->index.dir = dir.take();
         t->index_bytes = cap * sizeof(uint32_t);
