@@ -47,6 +47,7 @@ __global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ ke
 
 // the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
 template <int MODE, int KT = 0>
+__attribute__((amdgpu_waves_per_eu(KT == 31 ? 6 : 5, 8)))         // (as k_ut_flags_part, mf_unitig.hip: no scratch, checked by the build)
 __global__ __launch_bounds__(64 * NB_WAVES) void k_cc_adjacency_part(mf_index_view ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
                                                                    uint32_t np, int k_rt, uint32_t *__restrict__ nbr) {
     __shared__ nb_lds S;

@@ -476,9 +476,10 @@ __device__ __forceinline__ uint32_t mf_index_side_home(const mf_index_view &ix, 
 }
 // v0: the home slot's word (mf_index_side_home), read by the caller ahead of time
 __device__ __forceinline__ void mf_index_walk_side_v(const mf_index_view &ix, const ulonglong2 d, uint32_t hs, uint32_t v0, uint64_t pa, uint64_t pb, uint32_t side, uint32_t want,
-                                                     int k, uint32_t (&out)[4]) {
+                                                     int k, uint32_t (&out)[4], uint32_t *rev) {
     const uint64_t LM = (1ull << (2 * k - 2)) - 1ull;
     out[0] = out[1] = out[2] = out[3] = 0xFFFFFFFFu;
+    uint32_t rv = 0;
     const uint32_t *__restrict__ reg = reinterpret_cast<const uint32_t *>(ix.slots) + (d.x >> 6);
     const uint32_t rmask = (1u << (uint32_t)(d.x & 63ull)) - 1u, tag = hs >> MF_CIDX_REL_BITS;
     // the probe sequence first (its slots sit next to each other: one line, seldom two), the keys behind the matching tags
@@ -494,13 +495,19 @@ __device__ __forceinline__ void mf_index_walk_side_v(const mf_index_view &ix, co
 #pragma unroll
         for (uint32_t q = 0; q < NC; q++) {
             if (q >= nc) continue;
-            uint32_t c = 4u;
-            if ((K[q] >> 2) == pa) c = ((uint32_t)K[q] & 3u) ^ (side ? 3u : 0u);
-            else if ((K[q] & LM) == pb) c = (uint32_t)(K[q] >> (2 * k - 2)) ^ (side ? 0u : 3u);
-            if (c < 4u && ((want >> c) & 1u)) {
-                const uint32_t at = (uint32_t)(d.y + (uint64_t)cand[q]);
+            // the neighbour itself (K >> 2 == pa on the right side, K's low bases == pb on the left) or its reverse complement; a
+            // palindrome is both and counts as itself
+            const bool ma = (K[q] >> 2) == pa, mb = (K[q] & LM) == pb;
+            const uint32_t ca = ((uint32_t)K[q] & 3u) ^ (side ? 3u : 0u), cb = (uint32_t)(K[q] >> (2 * k - 2)) ^ (side ? 0u : 3u);
+            const bool fwd = side ? mb : ma;
+            if ((ma || mb)) {
+                const uint32_t c = fwd ? (side ? cb : ca) : (side ? ca : cb);
+                if ((want >> c) & 1u) {
+                    const uint32_t at = (uint32_t)(d.y + (uint64_t)cand[q]);
 #pragma unroll
-                for (uint32_t r = 0; r < 4; r++) if (c == r) out[r] = at;
+                    for (uint32_t r = 0; r < 4; r++) if (c == r) out[r] = at;
+                    rv = (rv & ~(1u << c)) | ((fwd ? 0u : 1u) << c);
+                }
             }
         }
         nc = 0;
@@ -516,18 +523,22 @@ __device__ __forceinline__ void mf_index_walk_side_v(const mf_index_view &ix, co
         v = reg[s];
     }
     if (nc) resolve();
+    *rev = rv;
 }
-__device__ __forceinline__ void mf_index_walk_side_d(const mf_index_view &ix, const ulonglong2 d, uint64_t pa, uint64_t pb, uint32_t side, uint32_t want, int k, uint32_t (&out)[4]) {
+__device__ __forceinline__ void mf_index_walk_side_d(const mf_index_view &ix, const ulonglong2 d, uint64_t pa, uint64_t pb, uint32_t side, uint32_t want, int k, uint32_t (&out)[4],
+                                                     uint32_t *rev) {
     const uint32_t hs = mf_index_side_hs(pa, pb, k);
-    mf_index_walk_side_v(ix, d, hs, mf_index_side_home(ix, d, hs), pa, pb, side, want, k, out);
+    mf_index_walk_side_v(ix, d, hs, mf_index_side_home(ix, d, hs), pa, pb, side, want, k, out, rev);
 }
 // The neighbours of ONE side of a k-mer x in one probe sequence (minimizer-partitioned tables of k-mers).  The four k-mers y_c
 // share k-1 bases with x: pa = what (K >> 2) of a stored key K is if K is y_c on the right side (x's last k-1 bases) or rc(y_c) on the
 // left (rc(x)'s last k-1 bases); pb = what K's low k-1 bases are if K is rc(y_c) on the right / y_c on the left.  side 0: right
 // (y_c = x[1..] + c), 1: left (y_c = c + x[..k-2]).  want: bit c set = look for neighbour c; ph: the partition hash they share (callers
-// group by minimizer).  out[c] = table index or 0xFFFFFFFF.
-__device__ __forceinline__ void mf_index_walk_side(const mf_index_view &ix, uint32_t ph, uint64_t pa, uint64_t pb, uint32_t side, uint32_t want, int k, uint32_t (&out)[4]) {
+// group by minimizer).  out[c] = table index or 0xFFFFFFFF; *rev: bit c set = the table holds neighbour c as its reverse complement.
+__device__ __forceinline__ void mf_index_walk_side(const mf_index_view &ix, uint32_t ph, uint64_t pa, uint64_t pb, uint32_t side, uint32_t want, int k, uint32_t (&out)[4],
+                                                   uint32_t *rev) {
     out[0] = out[1] = out[2] = out[3] = 0xFFFFFFFFu;
+    *rev = 0;
     if (!ix.compact) {                                   // (a table with an oversized partition has the generic index: one lookup per neighbour)
 #pragma unroll
         for (uint32_t c = 0; c < 4; c++) {
@@ -535,11 +546,11 @@ __device__ __forceinline__ void mf_index_walk_side(const mf_index_view &ix, uint
             const uint64_t y = side ? (((uint64_t)c << (2 * k - 2)) | pb) : ((pa << 2) | c);
             const uint64_t r = side ? ((pa << 2) | (3u - c)) : (pb | ((uint64_t)(3u - c) << (2 * k - 2)));
             uint32_t ii, val;
-            if (mf_index_find_ph(ix, y < r ? y : r, ph, &ii, &val)) out[c] = ii;
+            if (mf_index_find_ph(ix, y < r ? y : r, ph, &ii, &val)) { out[c] = ii; if (r < y) *rev |= 1u << c; }
         }
         return;
     }
-    mf_index_walk_side_d(ix, mf_index_side_dir(ix, ph), pa, pb, side, want, k, out);
+    mf_index_walk_side_d(ix, mf_index_side_dir(ix, ph), pa, pb, side, want, k, out, rev);
 }
 __device__ __forceinline__ bool mf_index_find(const mf_index_view &ix, uint64_t key, uint32_t *idx, uint32_t *val) {
     return mf_index_find_ph(ix, key, ix.skm_k ? mf_skm_ph(key, (int)ix.skm_k) : 0u, idx, val);

@@ -48,17 +48,7 @@ __device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, uint64_t rcx, int k
 __device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, int k, uint64_t kmask, uint32_t i, uint32_t m_nf, uint32_t m_nl, uint64_t *oriented, uint32_t *ph) {
     return nb_neighbour(x, mf_revcomp(x, k), k, kmask, i, m_nf, m_nl, oriented, ph);
 }
-// the same with the neighbour's minimizer hash instead of its partition hash (= mf_remix32 of it: two quarter-rate multiplies
-// that only the tenth of the neighbours in other partitions needs)
-__device__ __forceinline__ uint64_t nb_neighbour_mn(uint64_t x, uint64_t rcx, int k, uint64_t kmask, uint32_t i, uint32_t m_nf, uint32_t m_nl, uint64_t *oriented, uint32_t *mn) {
-    const uint32_t nuc = i >> 1;
-    uint64_t y, r;
-    if (i & 1u) { y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2)); r = ((rcx << 2) | (uint64_t)(3u - nuc)) & kmask; *mn = mf_skm_mn_left(y, k, m_nl); }
-    else { y = ((x << 2) | nuc) & kmask; r = (rcx >> 2) | ((uint64_t)(3u - nuc) << (2 * k - 2)); *mn = mf_skm_mn_right(y, m_nf); }
-    *oriented = y;
-    return y < r ? y : r;
-}
-// Calls emit(j, x, idx[8], canonical != oriented [8 bits], foreign [8 bits], have) for every k-mer j of the table (lanes past
+// Calls emit(j, x, idx[8], flip [8 bits: the table holds neighbour i, where found, as its reverse complement], foreign [8 bits], have) for every k-mer j of the table (lanes past
 // the end of a partition call it with have = false); idx[i] = table index of neighbour i or NB_NONE.
 // MODE 0: one wave per partition, partitions dealt round-robin to the waves of the grid; a partition of more than NB_CAP keys
 //         looks everything up in the HBM index.
@@ -139,11 +129,16 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             uint32_t remote = 0, foreign = 0, flip = 0;
             uint32_t phs[8];
             const uint64_t rcx = mf_revcomp(x, k);
+            constexpr uint32_t MM = (1u << (2 * MF_SKM_M)) - 1u;
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) {
-                uint64_t y;
-                const uint64_t cn = nb_neighbour_mn(x, rcx, k, kmask, i, m_nf, m_nl, &y, &phs[i]);       // phs: minimizer hashes, re-mixed only where a partition hash is needed
-                flip |= (cn != y) ? (1u << i) : 0u;
+                // the neighbour's minimizer hash from x's minima and the ONE M-mer it has that x has not: its last (right side: x's last
+                // M-1 bases + the new one) or its first (left side); re-mixed only where a partition hash is needed.  (Neither the
+                // neighbour nor its canonical form is built here: a walk compares stored keys with x's own k-1 bases.)
+                const uint32_t nuc = i >> 1;
+                const uint32_t f = (i & 1u) ? (((uint32_t)(x >> (2 * (k - MF_SKM_M) + 2)) & (MM >> 2)) | (nuc << (2 * MF_SKM_M - 2))) : ((((uint32_t)x << 2) | nuc) & MM);
+                const uint32_t r = mf_mmer_rc(f), h = mf_mmer_hash(f < r ? f : r), mo = (i & 1u) ? m_nl : m_nf;
+                phs[i] = h < mo ? h : mo;
                 // the same minimizer = the same partition; another minimizer that lands in this partition all the same (one in
                 // 2^part_bits) is simply looked up through the index
                 if (have && lw && (mf_remix32(phs[i]) >> (32 - lw)) != me) foreign |= 1u << i;
@@ -191,10 +186,10 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                     if ((grouped >> side) & 1u) {
                         if (at < (uint32_t)NB_RQ) { qa[at] = pa; qb[at] = pb; qm[at] = lead[side]; qt[at] = side | (want4 << 1); }
                         else {                                                   // (no room: looked up on the spot)
-                            uint32_t o4[4];
-                            mf_index_walk_side(ix, mf_remix32(lead[side]), pa, pb, side, want4, k, o4);
+                            uint32_t o4[4], rv;
+                            mf_index_walk_side(ix, mf_remix32(lead[side]), pa, pb, side, want4, k, o4, &rv);
 #pragma unroll
-                            for (uint32_t c = 0; c < 4; c++) if ((want4 >> c) & 1u) idx[2 * c + side] = o4[c];
+                            for (uint32_t c = 0; c < 4; c++) if ((want4 >> c) & 1u) { idx[2 * c + side] = o4[c]; flip |= ((rv >> c) & 1u) << (2 * c + side); }
                         }
                         at++;
                     } else {
@@ -202,7 +197,7 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                         for (uint32_t c = 0; c < 4; c++) {
                             if (!((want4 >> c) & 1u)) continue;
                             if (at < (uint32_t)NB_RQ) { qa[at] = pa; qb[at] = pb; qm[at] = phs[2 * c + side]; qt[at] = side | (1u << (c + 1)); }
-                            else { uint32_t o4[4]; mf_index_walk_side(ix, mf_remix32(phs[2 * c + side]), pa, pb, side, 1u << c, k, o4); idx[2 * c + side] = o4[c]; }
+                            else { uint32_t o4[4], rv; mf_index_walk_side(ix, mf_remix32(phs[2 * c + side]), pa, pb, side, 1u << c, k, o4, &rv); idx[2 * c + side] = o4[c]; flip |= ((rv >> c) & 1u) << (2 * c + side); }
                             at++;
                         }
                     }
@@ -237,13 +232,14 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
                             if (v == 0xFFFFu) break;
                             if ((v >> POSBITS) == tag) {
                                 const uint64_t K = hk[v & POSMASK];
-                                uint32_t c = 4u;
-                                if ((K >> 2) == pa) c = ((uint32_t)K & 3u) ^ (side ? 3u : 0u);
-                                else if ((K & LM) == pb) c = (uint32_t)(K >> (2 * k - 2)) ^ (side ? 0u : 3u);
+                                // K is the neighbour itself or its reverse complement (a palindrome is both and counts as itself)
+                                const bool ma = (K >> 2) == pa, mb = (K & LM) == pb, fwd = side ? mb : ma;
+                                const uint32_t ca = ((uint32_t)K & 3u) ^ (side ? 3u : 0u), cb = (uint32_t)(K >> (2 * k - 2)) ^ (side ? 0u : 3u);
+                                const uint32_t c = (ma || mb) ? (fwd ? (side ? cb : ca) : (side ? ca : cb)) : 4u;
                                 const uint32_t at = (uint32_t)lo + (v & POSMASK);
 #pragma unroll
                                 for (uint32_t q = 0; q < 4; q++)
-                                    if (c == q && ((nloc >> (2 * q + side)) & 1u)) idx[2 * q + side] = at;
+                                    if (c == q && ((nloc >> (2 * q + side)) & 1u)) { idx[2 * q + side] = at; flip = (flip & ~(1u << (2 * q + side))) | ((fwd ? 0u : 1u) << (2 * q + side)); }
                             }
                             s = (s + 1u) & (SLOTS - 1u);
                         }
@@ -253,16 +249,16 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
 #endif
             if (R) {
                 if (lane < Rl) {
-                    uint32_t o4[4];
+                    uint32_t o4[4], rv = 0;
                     const uint32_t meta = qt[lane];
 #if NB_ABLATE & 2
                     o4[0] = o4[1] = o4[2] = o4[3] = (qa[lane] == 12345ull && dent.x == 77ull) ? 5u : NB_NONE;
 #else
-                    if (ix.compact) mf_index_walk_side_d(ix, dent, qa[lane], qb[lane], meta & 1u, meta >> 1, k, o4);
-                    else mf_index_walk_side(ix, mf_remix32(qm[lane]), qa[lane], qb[lane], meta & 1u, meta >> 1, k, o4);
+                    if (ix.compact) mf_index_walk_side_d(ix, dent, qa[lane], qb[lane], meta & 1u, meta >> 1, k, o4, &rv);
+                    else mf_index_walk_side(ix, mf_remix32(qm[lane]), qa[lane], qb[lane], meta & 1u, meta >> 1, k, o4, &rv);
 #endif
                     uint32_t *ans = reinterpret_cast<uint32_t *>(&qa[lane]), *ans2 = reinterpret_cast<uint32_t *>(&qb[lane]);      // (the request has been read: its answers take its place)
-                    ans[0] = o4[0]; ans[1] = o4[1]; ans2[0] = o4[2]; ans2[1] = o4[3];
+                    ans[0] = o4[0]; ans[1] = o4[1]; ans2[0] = o4[2]; ans2[1] = o4[3]; qt[lane] = rv;
                 }
                 wave_sync();
                 uint32_t at = rbase;
@@ -273,7 +269,10 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
 #pragma unroll
                     for (uint32_t c = 0; c < 4; c++) {
                         if (!((rem >> (2 * c)) & 1u)) continue;
-                        if (at < (uint32_t)NB_RQ) idx[2 * c + side] = c < 2 ? reinterpret_cast<const uint32_t *>(&qa[at])[c] : reinterpret_cast<const uint32_t *>(&qb[at])[c - 2];
+                        if (at < (uint32_t)NB_RQ) {
+                            idx[2 * c + side] = c < 2 ? reinterpret_cast<const uint32_t *>(&qa[at])[c] : reinterpret_cast<const uint32_t *>(&qb[at])[c - 2];
+                            flip |= ((qt[at] >> c) & 1u) << (2 * c + side);
+                        }
                         if (!((grouped >> side) & 1u)) at++;
                     }
                     if ((grouped >> side) & 1u) at++;

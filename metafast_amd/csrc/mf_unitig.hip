@@ -85,10 +85,11 @@ __global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
 // the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
 // KT: k as a compile-time constant (0: from A.k) -- every shift of the minimizer scan and of the neighbours becomes an immediate
 template <int MODE, int KT = 0>
-// (five waves per SIMD instead of the four that the 99 registers of the plain build allow: the kernel waits for memory two thirds of its
-// time, 24.5 ms with four waves, 20.6 with five.  The Makefile checks that this costs NO scratch: a build of this kernel that spilled hung.)
+// (six waves per SIMD for k = 31 where the plain build's 85 registers allow five: the kernel waits for memory two thirds of its time,
+// every wave more hides some of it -- 24.5 ms with four, 20.6 with five.  The Makefile checks that the limit costs NO scratch
+// (check_resources.py): a build of this kernel that spilled hung on the GPU.)
 #ifndef NB_NOFORCE
-__attribute__((amdgpu_waves_per_eu(KT == 31 ? 5 : 4, 8)))
+__attribute__((amdgpu_waves_per_eu(KT == 31 ? 6 : 5, 8)))
 #endif
 __global__ __launch_bounds__(64 * NB_WAVES) void k_ut_flags_part(mf_index_view ix, ut_arrays A, const uint64_t *__restrict__ part_off, uint32_t np) {
     __shared__ nb_lds S;
