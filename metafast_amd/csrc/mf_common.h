@@ -153,7 +153,8 @@ struct mf_index {                 // open-addressed table in HBM: 16-byte slots 
     uint64_t *dir = nullptr; size_t dir_bytes = 0;
     uint32_t skm_k = 0;           // != 0: partitions are MINIMIZER partitions of k-mers of this length (mf_skm_ph), else mf_phash
     // COMPACT partitioned form (round 3; what mf_table_ensure_index builds for a partitioned table): 4-byte slots
-    // (12-bit tag of the key's hash << 20 | position of the key inside its partition), 0xFFFFFFFF = empty; a tag match is
+    // (12-bit tag << 20 | position of the key inside its partition; home slot and tag from the hash of the key -- of the key's canonical
+    // INTERIOR for minimizer partitions, mf_cidx_hkey, so that the four neighbours of a side share a probe sequence), 0xFFFFFFFF = empty; a tag match is
     // confirmed against the dense key array, the value is read from the dense count array.  8 bytes of index per key at
     // load <= 0.5 instead of 32 (16-byte slots): the build writes a quarter, and a whole probe sequence sits in one 64-byte
     // line.  dir has TWO words per partition: (first slot << 6) | log2(region slots), first entry of the partition in the table.
