@@ -186,11 +186,10 @@ __global__ __launch_bounds__(1024) void k_ut_links(ut_arrays A) {
 #define UT_J_WAVES 4
 __global__ __launch_bounds__(64 * UT_J_WAVES) void k_ut_contract(const uint64_t *__restrict__ node, const uint64_t *__restrict__ part_off, uint32_t np,
                                                                  uint64_t *__restrict__ jump) {
-    __shared__ uint32_t sg[UT_J_WAVES][UT_J_MAXN];          // successor (global node id)
     __shared__ uint32_t pj[UT_J_WAVES][UT_J_MAXN];          // local pointer (low 16 bits) | hops (high 16 bits)
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     const uint32_t gw = blockIdx.x * UT_J_WAVES + wave, nw = gridDim.x * UT_J_WAVES;
-    uint32_t *S = sg[wave], *P = pj[wave];
+    uint32_t *P = pj[wave];
     for (uint32_t p = gw; p < np; p += nw) {
         const uint64_t lo = part_off[p], hi = part_off[p + 1];
         const uint32_t m = (uint32_t)(hi - lo) * 2u;                       // oriented nodes [2 lo, 2 hi)
@@ -205,7 +204,6 @@ __global__ __launch_bounds__(64 * UT_J_WAVES) void k_ut_contract(const uint64_t 
         }
         for (uint32_t j = lane; j < m; j += 64) {
             const uint32_t g = (uint32_t)node[f0 + j];
-            S[j] = g;
             const bool inside = g != UT_NONE && (uint64_t)g >= f0 && (uint64_t)g < f0 + m;
             P[j] = inside ? ((g - (uint32_t)f0) | (1u << 16)) : j;          // the last inside node of a chain points at itself, 0 hops
         }
@@ -226,7 +224,8 @@ __global__ __launch_bounds__(64 * UT_J_WAVES) void k_ut_contract(const uint64_t 
         }
         for (uint32_t j = lane; j < m; j += 64) {
             const uint32_t a = P[j], e = a & 0xFFFFu, h = (a >> 16) & 0x7FFFu;
-            const uint32_t g = S[e];
+            const uint32_t g = (uint32_t)node[f0 + e];                     // (the chain's last inside node: its word was read a moment ago -- a cache hit;
+                                                                            //  a copy of the successors in LDS cost the kernel three of its eight waves per SIMD)
             jump[f0 + j] = g == UT_NONE ? ((uint64_t)((uint32_t)f0 + e) | ((uint64_t)h << 32) | UT_J_END) : ((uint64_t)g | ((uint64_t)(h + 1u) << 32));
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
