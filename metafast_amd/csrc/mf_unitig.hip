@@ -131,38 +131,47 @@ __device__ __forceinline__ uint32_t ut_left_node(const ut_arrays &A, uint32_t i,
     return o ? ut_node(A, A.ridx[i], ((info >> 6) & 1u) ^ 1u) : ut_node(A, A.lidx[i], (info >> 7) & 1u);
 }
 
+// One thread per K-MER, both of its oriented nodes: the successor of x and the predecessor of rc(x) are the same table entry, so the two
+// nodes want the same two info bytes of other k-mers -- the kernel's uncoalesced reads, and what bounds it (a thread per node read
+// each of them twice: 8.5 ms; the pair of node words is one 16-byte store).
 __global__ __launch_bounds__(1024) void k_ut_links(ut_arrays A) {
-    uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool is_start = false;
-    if (f < 2 * A.n) {
-        uint32_t i = (uint32_t)(f >> 1), o = (uint32_t)(f & 1);
-        uint8_t info = A.info[i];
-        uint32_t succ = UT_NONE;
-        if (!(o == 1 && A.pal && A.pal[i])) {         // strand 1 of a palindrome is not a node of its own (see ut_node)
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool st0 = false, st1 = false;
+    if (i < A.n) {
+        const uint8_t info = A.info[i];
+        const bool pal_i = A.pal && A.pal[i];
+        const bool ru = ut_r_unique(info, 0), lu = ut_l_unique(info, 0);
+        uint32_t ri = 0, li = 0;
+        uint8_t iR = 0, iL = 0;
+        bool palR = false, palL = false;
+        if (ru) { ri = A.ridx[i]; iR = A.info[ri]; palR = A.pal && A.pal[ri]; }
+        if (lu) { li = A.lidx[i]; iL = A.info[li]; palL = A.pal && A.pal[li]; }
+        const uint32_t ror = (info >> 6) & 1u, lor = (info >> 7) & 1u;
+        // strand 0: right neighbour (ridx, ror), left neighbour (lidx, lor); a palindrome is referred to on strand 0 (ut_node)
+        uint32_t succ0 = UT_NONE, succ1 = UT_NONE;
+        if (ru) { const uint32_t sd = palR ? 0u : ror; if (ut_l_unique(iR, sd)) succ0 = ri * 2u + sd; }
+        { bool has_in = false; if (lu) has_in = ut_r_unique(iL, palL ? 0u : lor); st0 = !has_in; }
+        // strand 1 (not a node of its own for a palindrome): right neighbour = rc(left neighbour of x) = (lidx, !lor), left = (ridx, !ror)
+        if (!pal_i) {
+            if (lu) { const uint32_t sd = palL ? 0u : (lor ^ 1u); if (ut_l_unique(iL, sd)) succ1 = li * 2u + sd; }
             bool has_in = false;
-            if (ut_r_unique(info, o)) {
-                uint32_t g = ut_right_node(A, i, o, info);
-                if (ut_l_unique(A.info[g >> 1], g & 1u)) succ = g;
-            }
-            if (ut_l_unique(info, o)) {
-                uint32_t h = ut_left_node(A, i, o, info);
-                has_in = ut_r_unique(A.info[h >> 1], h & 1u);
-            }
-            is_start = !has_in;
+            if (ru) has_in = ut_r_unique(iR, palR ? 0u : (ror ^ 1u));
+            st1 = !has_in;
         }
-        {   // (the walks used to read succ[], keys[] and counts[]: three random lines per hop)
-            const uint64_t x = A.gk[i];
-            const uint32_t last = o ? 3u - (uint32_t)((x >> (2 * A.k - 2)) & 3ull) : (uint32_t)(x & 3ull);
-            A.node[f] = (uint64_t)succ | ((uint64_t)A.gv[i] << 32) | ((uint64_t)last << 48);
-        }
+        // (the walks used to read succ[], keys[] and counts[]: three random lines per hop)
+        const uint64_t x = A.gk[i];
+        const uint64_t cnt = (uint64_t)A.gv[i] << 32;
+        const uint64_t w0 = (uint64_t)succ0 | cnt | ((x & 3ull) << 48);
+        const uint64_t w1 = (uint64_t)succ1 | cnt | ((uint64_t)(3u - (uint32_t)((x >> (2 * A.k - 2)) & 3ull)) << 48);
+        *reinterpret_cast<ulonglong2 *>(&A.node[2 * i]) = make_ulonglong2(w0, w1);
     }
     // block-aggregated append of the start nodes: ONE global atomic per 1024-thread workgroup (a per-wave atomic on the
     // single cursor serialises at ~12 ns each and cost 126 ms on 7.2e8 nodes)
     __shared__ uint32_t wave_base[16];
     __shared__ uint32_t block_base;
-    unsigned long long b = __ballot(is_start);
+    const unsigned long long b0 = __ballot(st0), b1 = __ballot(st1);
     const int wave = threadIdx.x >> 6;
-    if (mf_lane() == 0) wave_base[wave] = (uint32_t)__popcll(b);
+    if (mf_lane() == 0) wave_base[wave] = (uint32_t)(__popcll(b0) + __popcll(b1));
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t acc = 0;
@@ -170,7 +179,10 @@ __global__ __launch_bounds__(1024) void k_ut_links(ut_arrays A) {
         block_base = acc ? atomicAdd(A.n_starts, acc) : 0u;
     }
     __syncthreads();
-    if (is_start) A.starts[block_base + wave_base[wave] + (uint32_t)__popcll(b & ((1ull << mf_lane()) - 1ull))] = (uint32_t)f;
+    const unsigned long long below = (1ull << mf_lane()) - 1ull;
+    const uint32_t base = block_base + wave_base[wave];
+    if (st0) A.starts[base + (uint32_t)__popcll(b0 & below)] = (uint32_t)(2 * i);
+    if (st1) A.starts[base + (uint32_t)__popcll(b0) + (uint32_t)__popcll(b1 & below)] = (uint32_t)(2 * i + 1);
 }
 
 // U2b k_ut_contract: jump words.  A walk that reads one node word per hop misses the cache on nearly every hop (measured:
@@ -477,7 +489,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         }
         {
             mf_ktimer tm(ctx, "k_ut_links");
-            k_ut_links<<<grid_for(2 * n, 1024), 1024, 0, st>>>(A);
+            k_ut_links<<<grid_for(n, 1024), 1024, 0, st>>>(A);
         }
         mf_buf<uint64_t> jump;
         if ((rc = jump.alloc(ctx, 2 * n)) < 0) break;
