@@ -74,11 +74,21 @@ __device__ __forceinline__ uint32_t cc_find(uint32_t *parent, uint32_t x) {
 // solves its TILE of consecutive vertices in LDS (the edges with both ends inside: about five in six), writes every
 // vertex's tile root to parent[], and only the edges that leave the tile go through the union-find in HBM (k_cc_hook).
 #define CC_TILE 1024
+#define CC_LEDGE 2048               // edges that leave a tile, collected in LDS (more: the tile is left to the per-vertex kernel, ecount[1])
+// edges != nullptr: the edges from this tile's vertices to SMALLER tiles -- one in six, the ones the tile cannot join in LDS -- go to a
+// list (edges[0 .. ecount[0]), block-aggregated), for k_cc_hook_edges: a thread per listed edge.  (The per-vertex kernel that used to
+// find them again read the whole adjacency a second time and ran its union-finds with one lane in six busy: 5.5 ms for a sixth of the
+// edges where this kernel takes 1.4 for the rest.)
 __global__ __launch_bounds__(256) void k_cc_hook_tile(const uint32_t *__restrict__ nbr, const uint8_t *__restrict__ alive, uint32_t *__restrict__ parent,
-                                                      uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight, uint64_t n) {
+                                                      uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight, uint64_t n,
+                                                      uint2 *__restrict__ edges, unsigned long long *__restrict__ ecount, uint64_t ecap) {
     __shared__ uint32_t lp[CC_TILE];
     __shared__ uint8_t la[CC_TILE];
+    __shared__ uint2 le[CC_LEDGE];
+    __shared__ uint32_t ln;
+    __shared__ unsigned long long lbase;
     const uint64_t base = (uint64_t)blockIdx.x * CC_TILE;
+    if (threadIdx.x == 0) ln = 0;
     for (uint32_t i = threadIdx.x; i < CC_TILE; i += blockDim.x) {
         lp[i] = i;
         const uint8_t al = base + i < n ? alive[base + i] : 0;
@@ -104,7 +114,12 @@ __global__ __launch_bounds__(256) void k_cc_hook_tile(const uint32_t *__restrict
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const uint32_t u = nb[j];
-            if (u == CC_NONE || u >= (uint32_t)v || u < (uint32_t)base || !la[u - (uint32_t)base]) continue;
+            if (u == CC_NONE || u >= (uint32_t)v) continue;
+            if (u < (uint32_t)base) {
+                if (edges) { const uint32_t e = atomicAdd(&ln, 1u); if (e < (uint32_t)CC_LEDGE) le[e] = make_uint2((uint32_t)v, u); }
+                continue;
+            }
+            if (!la[u - (uint32_t)base]) continue;
             uint32_t ra = i, rb = u - (uint32_t)base;
             for (;;) {
                 ra = find_l(ra); rb = find_l(rb);
@@ -122,12 +137,39 @@ __global__ __launch_bounds__(256) void k_cc_hook_tile(const uint32_t *__restrict
         for (;;) { const uint32_t p = lp[r]; if (p == r) break; r = p; }
         parent[base + i] = (uint32_t)base + r;
     }
+    if (edges) {
+        const uint32_t cnt = ln < (uint32_t)CC_LEDGE ? ln : (uint32_t)CC_LEDGE;         // (ln: final since the barrier above)
+        if (threadIdx.x == 0) {
+            lbase = cnt ? atomicAdd(ecount, (unsigned long long)cnt) : 0ull;
+            if (ln > (uint32_t)CC_LEDGE || (cnt && lbase + cnt > ecap)) atomicAdd(ecount + 1, 1ull);      // the list is incomplete: k_cc_hook runs
+        }
+        __syncthreads();
+        for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) if (lbase + e < ecap) edges[lbase + e] = le[e];
+    }
+}
+// a thread per listed edge (v, u), u in a smaller tile than v: alive[v] is known, alive[u] is looked at here
+__global__ void k_cc_hook_edges(const uint2 *__restrict__ edges, const unsigned long long *__restrict__ ecount, uint64_t ecap, const uint8_t *__restrict__ alive, uint32_t *parent) {
+    const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long ne = ecount[0] < ecap ? ecount[0] : ecap;
+    if (e >= ne) return;
+    const uint2 ed = edges[e];
+    if (!alive[ed.y]) return;
+    uint32_t ra = ed.x, rb = ed.y;
+    for (;;) {
+        ra = cc_find(parent, ra); rb = cc_find(parent, rb);
+        if (ra == rb) break;
+        if (ra < rb) { const uint32_t t = ra; ra = rb; rb = t; }
+        if (atomicCAS(&parent[ra], ra, rb) == ra) break;            // hook larger root under smaller
+    }
 }
 // the edges that leave the tile of their larger end.  list != nullptr (a SPARSE level, below): the vertices list[0 .. n) only, ALL their
 // edges to smaller alive vertices (no tile pass ran)
-__global__ void k_cc_hook(const uint32_t *__restrict__ nbr, const uint8_t *__restrict__ alive, uint32_t *parent, uint64_t n, const uint32_t *__restrict__ list) {
+// unless: the counters of an edge list (k_cc_hook_tile): the kernel has nothing to do when the list is complete (unless[1] == 0)
+__global__ void k_cc_hook(const uint32_t *__restrict__ nbr, const uint8_t *__restrict__ alive, uint32_t *parent, uint64_t n, const uint32_t *__restrict__ list,
+                          const unsigned long long *__restrict__ unless) {
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= n) return;
+    if (unless && unless[1] == 0ull) return;
     if (list) v = list[v];
     else if (!alive[v]) return;
     const uint4 *q = reinterpret_cast<const uint4 *>(nbr + v * 8);
@@ -475,6 +517,10 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
         MF_TRY(k_root.alloc(ctx, max_kept)); MF_TRY(k_size.alloc(ctx, max_kept)); MF_TRY(k_weight.alloc(ctx, max_kept));
         MF_TRY(k_minkey.alloc(ctx, max_kept)); MF_TRY(slot_off.alloc(ctx, max_kept + 1)); MF_TRY(slot_fill.alloc(ctx, max_kept));
         MF_TRY(tot.alloc(ctx, 1));
+        // the edges that leave their tile (k_cc_hook_tile): room for one per two vertices, 4 bytes per vertex beside the adjacency's 32
+        mf_buf<uint2> edges; mf_buf<unsigned long long> ecount;
+        const uint64_t ecap = n / 2 + 1024;
+        MF_TRY(edges.alloc(ctx, ecap)); MF_TRY(ecount.alloc(ctx, 2));
         cc_kept_arrays K; K.root = k_root.p; K.size = k_size.p; K.weight = k_weight.p; K.minkey = k_minkey.p;
         {
             mf_ktimer tm(ctx, "k_cc_adjacency");
@@ -506,10 +552,12 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
                 mf_ktimer tm(ctx, "k_cc_hook");
                 if (sparse) {
                     if (m) k_ccs_init<<<cgrid(m), 256, 0, st>>>(L, m, parent.p, csize.p, cweight.p);
-                    if (m) k_cc_hook<<<cgrid(m), 256, 0, st>>>(nbr.p, alive.p, parent.p, m, L);
+                    if (m) k_cc_hook<<<cgrid(m), 256, 0, st>>>(nbr.p, alive.p, parent.p, m, L, nullptr);
                 } else {
-                    k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(nbr.p, alive.p, parent.p, csize.p, cweight.p, n);
-                    k_cc_hook<<<cgrid(n), 256, 0, st>>>(nbr.p, alive.p, parent.p, n, nullptr);
+                    MF_HIP(hipMemsetAsync(ecount.p, 0, 16, st));
+                    k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(nbr.p, alive.p, parent.p, csize.p, cweight.p, n, edges.p, ecount.p, ecap);
+                    k_cc_hook_edges<<<cgrid(ecap), 256, 0, st>>>(edges.p, ecount.p, ecap, alive.p, parent.p);
+                    k_cc_hook<<<cgrid(n), 256, 0, st>>>(nbr.p, alive.p, parent.p, n, nullptr, ecount.p);      // (only if the list overflowed)
                 }
             }
             {
@@ -1066,8 +1114,8 @@ extern "C" int mf_dcc_level_local(mf_dcc *D, uint64_t *counts) {
     const uint64_t n = D->n;
     if (n) {
         mf_ktimer tm(ctx, "k_cc_hook");
-        k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, D->csize.p, D->cweight.p, n);
-        k_cc_hook<<<cgrid(n), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, n, nullptr);
+        k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, D->csize.p, D->cweight.p, n, nullptr, nullptr, 0);
+        k_cc_hook<<<cgrid(n), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, n, nullptr, nullptr);
     }
     if (n) {
         mf_ktimer tm(ctx, "k_cc_stats");
