@@ -824,6 +824,7 @@ struct mf_dcc {
     uint32_t n = 0, n_total = 0; std::vector<uint32_t> base;
     mf_buf<uint32_t> nbr, parent, root, csize, groot;        // [8n] local neighbour ids; [n]; [n]; [n]; [n] global root of a LOCAL ROOT
     mf_buf<unsigned long long> cweight; mf_buf<uint8_t> alive;
+    mf_buf<uint2> edges; mf_buf<unsigned long long> ecount; uint64_t ecap = 0;      // the edges that leave their tile (k_cc_hook_tile)
     mf_buf<unsigned int> ctr;                                // [64] counters
     // queries (16 bytes: key, source = vertex*8 + neighbour number) grouped by owner
     std::vector<uint64_t> qoff;                              // [world + 1]
@@ -977,6 +978,7 @@ extern "C" int mf_dcc_create(mf_ctx *ctx, mf_table *shard, int rank, int world, 
     D->n = (uint32_t)shard->n; D->n_total = base[world]; D->base.assign(base, base + world + 1);
     const size_t n1 = D->n ? D->n : 1;
     MF_TRY(D->nbr.alloc(ctx, n1 * 8)); MF_TRY(D->parent.alloc(ctx, n1)); MF_TRY(D->root.alloc(ctx, n1)); MF_TRY(D->csize.alloc(ctx, n1));
+    D->ecap = n1 / 2 + 1024; MF_TRY(D->edges.alloc(ctx, D->ecap)); MF_TRY(D->ecount.alloc(ctx, 2));
     MF_TRY(D->groot.alloc(ctx, n1)); MF_TRY(D->cweight.alloc(ctx, n1)); MF_TRY(D->alive.alloc(ctx, n1)); MF_TRY(D->ctr.alloc(ctx, 64));
     MF_TRY(D->qcur.alloc(ctx, 64)); MF_TRY(D->mk.alloc(ctx, n1)); MF_TRY(D->mg.alloc(ctx, n1)); MF_TRY(D->touched.alloc(ctx, n1));
     D->xstart.assign(world + 1, 0);
@@ -1114,8 +1116,10 @@ extern "C" int mf_dcc_level_local(mf_dcc *D, uint64_t *counts) {
     const uint64_t n = D->n;
     if (n) {
         mf_ktimer tm(ctx, "k_cc_hook");
-        k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, D->csize.p, D->cweight.p, n, nullptr, nullptr, 0);
-        k_cc_hook<<<cgrid(n), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, n, nullptr, nullptr);
+        MF_HIP(hipMemsetAsync(D->ecount.p, 0, 16, st));
+        k_cc_hook_tile<<<cgrid(n, CC_TILE), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, D->csize.p, D->cweight.p, n, D->edges.p, D->ecount.p, D->ecap);
+        k_cc_hook_edges<<<cgrid(D->ecap), 256, 0, st>>>(D->edges.p, D->ecount.p, D->ecap, D->alive.p, D->parent.p);
+        k_cc_hook<<<cgrid(n), 256, 0, st>>>(D->nbr.p, D->alive.p, D->parent.p, n, nullptr, D->ecount.p);      // (only if the list overflowed)
     }
     if (n) {
         mf_ktimer tm(ctx, "k_cc_stats");
