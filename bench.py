@@ -388,7 +388,7 @@ def main():
 
     if rank == 0:
         global TRAFFIC
-        if n_reads == 100_000_000 and rl == 150 and k == 31:
+        if n_reads == 100_000_000 and rl == 150 and k == 31 and args.genome_scale == 1_000_000 and args.sub_rate == 0.005 and spg == 1:      # (the workload the counters were collected on)
             TRAFFIC = _load_traffic()
         rep = ctx.kernel_report()          # name -> (launches, total ms) from HIP events on the launch stream
         kern = {}
