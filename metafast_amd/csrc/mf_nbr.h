@@ -9,6 +9,13 @@
 // open-addressed index of them there (1024 two-byte slots: tag + position), and looks the neighbours up there; only a
 // neighbour whose own minimizer differs (its partition hash says so before any memory is touched) goes to the HBM index.
 // Partitions larger than NB_CAP keys use the HBM index for everything.
+//
+// ONE WALK PER SIDE.  The four k-mers that extend x on one side differ in one base at an end: they share their interior
+// (k-2)-mer, and so do their reverse complements.  Both indexes -- the one in LDS and the table's in HBM (mf_cidx_hkey) -- take
+// home slot and tag from the hash of the CANONICAL INTERIOR, so one probe sequence from that home slot to the next empty slot
+// meets all four; a stored key K is neighbour c of the side if its other k-1 bases are x's (K >> 2 == pa or K's low k-1 bases
+// == pb, mf_index_walk_side), and which of the two says on which strand the table holds it.  Neither a neighbour nor a canonical
+// form is built anywhere.
 #pragma once
 #include "mf_common.h"
 #ifdef __HIPCC__
@@ -54,7 +61,7 @@ __device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, int k, uint64_t kma
 //         looks everything up in the HBM index.
 // MODE 1 + MODE 2 (two launches, together = MODE 0's result): 12 % of the benchmark's good k-mers sit in partitions of
 //         353 .. 1408 keys, and their 8 lookups each were HALF of all probes that went to HBM.  MODE 1 leaves those partitions
-//         out; MODE 2 takes only them, one WORKGROUP per partition: the four waves' LDS tables together (2048 slots) hold the
+//         out; MODE 2 takes only them, one WORKGROUP per partition: the four waves' LDS tables together (4096 slots) hold the
 //         partition, the waves share its k-mers.
 // With lw > 0 the table is rank `me`'s SHARD of a larger one (mf_count_device_shard; owner of a k-mer = top lw bits of its
 // partition hash): neighbours that other ranks own are not looked up, emit gets their numbers in `foreign` (8 bits).
@@ -121,11 +128,10 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             const uint64_t x = have ? (local ? hk[j] : keys[lo + j]) : 0ull;       // (the copy in LDS: the table is read once)
             uint32_t m_nf = 0, m_nl = 0, m_own = 0;
             mf_skm_nbr_mins(x, k, &m_nf, &m_nl, &m_own);
-            // Pass 1: which neighbours live in another partition (about one in ten)?  Those are REQUESTS for the HBM index --
-            // a directory entry, then a slot: two dependent cache misses.  Looked up where they arise they cost the wave
-            // eight such round trips per 64 k-mers with six lanes in 64 busy (ablation, 100 M reads: 25 of the kernel's 39
-            // ms).  So the wave collects them in LDS, looks them up 64 at a time, one request per lane, and hands the
-            // answers back through LDS.
+            // Pass 1: which neighbours live in another partition (about one in ten)?  Those become REQUESTS for the HBM index -- a
+            // directory entry, a slot, a key: dependent cache misses.  Looked up where they arise they cost the wave eight such round
+            // trips per 64 k-mers with six lanes in 64 busy (ablation in round 2, 100 M reads: 25 of the kernel's 39 ms).  So the wave
+            // collects them in LDS, looks them up together, one request per lane, and hands the answers back through LDS.
             uint32_t remote = 0, foreign = 0, flip = 0;
             uint32_t phs[8];
             const uint64_t rcx = mf_revcomp(x, k);
@@ -163,13 +169,10 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             uint32_t R;
             const uint32_t rbase = mf_wave_excl_scan(nreq, &R);
             uint32_t idx[8];
-            // (Tried in round 4: two slots per LDS read -- ds_read_b128, an odd home slot skipping the pair's first -- so that the loop, which
-            // runs as long as the slowest of the wave's lanes probes, makes half the trips: k_ut_flags 26.7 -> 30.0 ms, k_cc_adjacency 5.8 ->
-            // 6.6: four more registers across the loop and two compares per trip where most lanes need one trip.)
-            // (Tried in round 3: the first probes of eight, four or two neighbours in flight behind one wait, the rest in a
-            // wave-uniform loop.  137 / 119 / 109 VGPRs instead of 81 take a wave per SIMD away, and every lane then reads for all
-            // neighbours of a batch whether it wants them or not: k_ut_flags 29.2 ms (four at a time) / 28.3 (two) against 26.2 with
-            // the per-neighbour loops below -- profiles/r03f_bench_100M_batched_lookups.json, r03j_bench_100M_flags_batch2.json.)
+            // (Tried on the per-neighbour probe loops this code had until round 4: two slots per LDS read, k_ut_flags 26.7 -> 30.0 ms; the
+            // first probes of eight / four / two neighbours in flight behind one wait, 29.2 / 28.3 against 26.2 -- registers, i.e. waves per
+            // SIMD, each time: profiles/r03f_bench_100M_batched_lookups.json, r03j_bench_100M_flags_batch2.json.  And on this code: the next
+            // batch's minimizer scan behind the home slot's read, 24.35 against 24.5 ms at four waves.)
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) idx[i] = NB_NONE;
             {
