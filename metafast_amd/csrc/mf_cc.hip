@@ -268,16 +268,9 @@ __global__ __launch_bounds__(256) void k_cc_flatten_stats(const uint8_t *__restr
 // ---- SPARSE levels (round 4).  After the first threshold level or two only the vertices of the oversize components that reach the next
 // threshold are left -- 29 %, 1.4 %, 0.08 % of the union of 8 x 50 M reads' unitigs at levels 3, 4, 5; the union of 8 x 200 M reads goes
 // through about a hundred levels, most of them on a sliver of the graph -- while the dense kernels above visit all n vertices five times
-// per level to find out that they are dead (961 ms of that shape's 4.3 s step).  k_cc_members therefore lists the survivors, and once
-// fewer than a third are left a level runs on the list: set-up, hook (every edge to a smaller alive vertex), size / weight per root
+// per level to find out that they are dead (961 ms of that shape's 4.3 s step).  k_cc_members therefore lists the survivors (a dense level as far as
+// a list of n / 3 has room), and once fewer than a third are left a level runs on the list: set-up, hook (every edge to a smaller alive vertex), size / weight per root
 // with the lanes of a wave that share a root adding up first, classification, members -- all launched over the list.
-__global__ __launch_bounds__(256) void k_cc_list_alive(const uint8_t *__restrict__ alive, uint64_t n, unsigned int *__restrict__ cursor, uint32_t *__restrict__ list) {
-    __shared__ uint32_t scratch[18];
-    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool a = v < n && alive[v];
-    const uint32_t at = mf_block_reserve(cursor, a ? 1u : 0u, scratch);
-    if (a) list[at] = (uint32_t)v;
-}
 __global__ void k_ccs_init(const uint32_t *__restrict__ list, uint64_t m, uint32_t *__restrict__ parent, uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
@@ -337,8 +330,9 @@ __global__ void k_cc_members(uint8_t *__restrict__ alive, const uint32_t *__rest
                              const uint64_t *__restrict__ slot_off, uint32_t *__restrict__ slot_fill, uint32_t comp_base,
                              unsigned long long *__restrict__ minkey, uint64_t *__restrict__ members,
                              uint32_t *__restrict__ member_comp, unsigned int *__restrict__ n_alive, const uint32_t *__restrict__ list,
-                             uint32_t *__restrict__ next_list) {
-    // list != nullptr: the vertices list[0 .. n); next_list (may be nullptr): the vertices that stay alive are appended, *n_alive = how many
+                             uint32_t *__restrict__ next_list, uint32_t next_cap) {
+    // list != nullptr: the vertices list[0 .. n); next_list (may be nullptr): the vertices that stay alive are appended as far as it has
+    // room (next_cap; the caller uses the list only if all of them fitted), *n_alive = how many
     __shared__ uint32_t scratch[18];
     uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool put = false, stays = false;
@@ -356,7 +350,7 @@ __global__ void k_cc_members(uint8_t *__restrict__ alive, const uint32_t *__rest
     }
     {
         const uint32_t at = mf_block_reserve(n_alive, stays ? 1u : 0u, scratch);       // (one atomic per workgroup)
-        if (stays && next_list) next_list[at] = (uint32_t)v;
+        if (stays && next_list && at < next_cap) next_list[at] = (uint32_t)v;
     }
     // positions in the member lists: one cursor atomic per distinct component and wave (see k_cc_flatten_stats)
     unsigned long long todo = __ballot(put);
@@ -587,10 +581,10 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             }
             {
                 mf_ktimer tm(ctx, "k_cc_members");
-                // (a dense level whose survivors may not fit the list counts them first: no list is written, see below)
+                // (a dense level writes the list as far as it has room and counts the survivors: the list stands if they all fitted)
                 if (span) k_cc_members<<<cgrid(span), 256, 0, st>>>(alive.p, root.p, csize.p, t->d_counts, t->d_keys, span, (uint32_t)b1, (uint32_t)b2,
                                                                     (uint32_t)(thr + 1), keptslot.p, slot_off.p, slot_fill.p, (uint32_t)recs.size(),
-                                                                    k_minkey.p, lv->members.p, lv->comp.p, &counters.p[3], L, sparse ? NL : nullptr);
+                                                                    k_minkey.p, lv->members.p, lv->comp.p, &counters.p[3], L, NL, (uint32_t)std::min<uint64_t>(sparse ? m : lcap, 0xFFFFFFFFull));
             }
             unsigned int na = 0;
             MF_HIP(hipMemcpyAsync(&na, &counters.p[3], 4, hipMemcpyDeviceToHost, st));
@@ -611,12 +605,7 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             if (!nbig) break;
             if (thr > MF_MAX_COUNT) return mf_set_error("components: threshold loop did not terminate");
             if (sparse) { cur ^= 1; m = na; }
-            else if ((uint64_t)na <= lcap && ctx->opt_cc_sparse) {
-                // the dense level did not write the list (its size was not known): one pass over the alive flags does
-                MF_HIP(hipMemsetAsync(&counters.p[3], 0, 4, st));
-                k_cc_list_alive<<<cgrid(n), 256, 0, st>>>(alive.p, n, &counters.p[3], NL);
-                sparse = true; cur ^= 1; m = na;
-            }
+            else if ((uint64_t)na <= lcap && NL) { sparse = true; cur ^= 1; m = na; }      // (the dense level's list holds all its survivors)
         }
     }
     // final order: ConnectedComponent.compareTo (src/structures/ConnectedComponent.java:125-136): thr asc, weight desc,
