@@ -52,6 +52,14 @@ const char *mf_version(void);
  * side parsers; GPU parallelism is fixed by the device. */
 int  mf_ctx_create(int device, int host_threads, mf_ctx **out);
 void mf_ctx_destroy(mf_ctx *ctx);
+/* Devices this process sees (no context is made).  The reference's drivers loop over all libraries in one process
+ * (src/tools/KmersCounterForManyFilesMain.java:80-108, SeqBuilderForManyFilesMain.java:82-94, FeaturesCalculatorMain.java:137-162);
+ * a host that wants one library per GPU makes one context per device, each driven by a thread of its own. */
+int  mf_device_count(void);
+int  mf_ctx_device(const mf_ctx *ctx);
+/* A context is used by ONE thread at a time; HIP's current device belongs to the thread, so a thread other than the one that made
+ * the context calls this before its first call on it. */
+int  mf_ctx_bind_thread(mf_ctx *ctx);
 /* Use an existing HIP stream (hipStream_t as void*) for all launches instead of the ctx-owned one;
  * NULL = the device's default (null) stream. The caller keeps ownership. */
 int  mf_ctx_set_stream(mf_ctx *ctx, void *hip_stream);
@@ -305,6 +313,20 @@ int mf_features_reads_device(mf_ctx *ctx, mf_comps *c, const void *d_bases, cons
                              uint64_t n_bases, int k, int threshold, int64_t *vec, double *breadth);
 int mf_features_reads(mf_ctx *ctx, const char *components_bin, const char *const *files, int nfiles, int k, int threshold,
                       const char *vec_path, const char *breadth_path);
+
+/* --selected (FeaturesCalculatorMain.java:55-57 the parameter, :113-116 selected = IOUtils.loadKmers(selectedKmers, 0, ...),
+ * :193-203 its use in buildAndPrintVector): with a table of selected k-mers only the component k-mers with
+ * selected.getWithZero(kmer) > 0 enter vec[c], kmersFound AND kmersCount, so breadth[c] = found / (selected k-mers of c) and a
+ * component without a selected k-mer gets 0.0 / 0.0 = NaN ("NaN" in the .breadth file, Double.toString).  `selected` is a table of
+ * the same context, e.g. mf_table_load_kmers(ctx, files, n, 0, k, &selected); NULL = no selection (the calls above). */
+int mf_features_device_selected(mf_ctx *ctx, mf_comps *c, const mf_table *sample, mf_table *selected, int threshold,
+                                int64_t *vec, double *breadth);
+int mf_features_selected(mf_ctx *ctx, const char *components_bin, const char *kmers_bin, int k, int threshold, mf_table *selected,
+                         const char *vec_path, const char *breadth_path);
+int mf_features_reads_device_selected(mf_ctx *ctx, mf_comps *c, const void *d_bases, const void *d_offsets, uint64_t n_reads,
+                                      uint64_t n_bases, int k, mf_table *selected, int threshold, int64_t *vec, double *breadth);
+int mf_features_reads_selected(mf_ctx *ctx, const char *components_bin, const char *const *files, int nfiles, int k, int threshold,
+                               mf_table *selected, const char *vec_path, const char *breadth_path);
 
 /* ---- A13  Bray-Curtis ---------------------------------------------------------------- */
 /* replaces DistanceMatrixCalculatorMain.brayCurtisDistance (src/tools/DistanceMatrixCalculatorMain.java:

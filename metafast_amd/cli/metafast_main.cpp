@@ -18,10 +18,13 @@
 #include <cstdlib>
 #include <cstring>
 #include <ctime>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <set>
 #include <string>
 #include <sys/stat.h>
+#include <thread>
 #include <unistd.h>
 #include <vector>
 #include "../../include/metafast_hip.h"
@@ -32,9 +35,12 @@ using std::vector;
 // ------------------------------------------------------------------------------------------------ utilities
 static bool g_verbose = false;
 static FILE *g_logfile = nullptr, *g_logfile2 = nullptr;      // <workDir>/log and <workDir>/logs/log_<ts> (identical)
+static std::mutex g_log_mutex;                                // (the per-device workers of a step log too)
+static bool g_workers_active = false;                         // other threads are inside library calls: die() must not run static destructors under them
 static void logmsg(const char *level, const char *fmt, ...) {
     char buf[4096];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    std::lock_guard<std::mutex> lock(g_log_mutex);
     bool debug = !strcmp(level, "DEBUG");
     if (!debug || g_verbose) fprintf(stderr, "%s: %s\n", level, buf);
     if (g_logfile || g_logfile2) {                          // "%d{dd-MMM-yy  HH:mm:ss,SSS}  %-5p  %m%n" (Tool.java:700)
@@ -48,6 +54,7 @@ static void logmsg(const char *level, const char *fmt, ...) {
     char buf[4096];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
     logmsg("ERROR", "%s", buf);
+    if (g_workers_active) { fflush(nullptr); _exit(1); }
     exit(1);                                            // Tool.java:450-463: ExecutionFailedException -> exit code 1
 }
 static void check(int rc) { if (rc < 0) die("%s", mf_last_error()); }
@@ -127,7 +134,7 @@ static const OptDef OPTS[] = {
     {"output-format", "", false, false}, {"heatmap-file", "", false, false}, {"newMatrix-file", "", false, false},
     {"without-renumbering", "wr", false, true}, {"colors-file", "col", false, false}, {"invert-colors", "", false, true},
     {"kmers-file", "kf", false, false}, {"output-file", "o", false, false}, {"split", "", false, true}, {"long", "", false, true},
-    {"use-reads-for-calculating-features", "", false, true}, {"device", "", false, false},
+    {"use-reads-for-calculating-features", "", false, true}, {"device", "", false, false}, {"devices", "", false, false},
     {"positiveReads", "pos", true, false}, {"negativeReads", "neg", true, false}, {"filter-kmers", "", true, false}, {"max-thresh", "", false, false},
 };
 // `ctx_i` says what -i means for the selected tool
@@ -177,30 +184,81 @@ static Args parse_args(int argc, char **argv, string *tool_out) {
 }
 
 // ------------------------------------------------------------------------------------------------ tools
+// Devices.  The reference's drivers loop over all libraries in one process (KmersCounterForManyFilesMain.java:80-108,
+// SeqBuilderForManyFilesMain.java:82-94, FeaturesCalculatorMain.java:137-162): here `--devices a,b,...` (default: every device the process
+// sees; `--device n` = one) names the GPUs, every entry gets a context of its own, and the three per-library steps deal their libraries
+// round-robin to one worker thread per entry (library i -> entry i mod D, in every step: what entry d wrote in kmer-counter-many is
+// still in ITS HBM when seq-builder-many and features-calculator ask for the file, `file_cache`).  The steps need no exchange -- the
+// files are the interchange --, component-cutter joins all libraries (ComponentCutterMain.java:78-114) on entry 0 from the .seq.fasta
+// files.  An entry may name a device twice (--devices 0,0: two contexts, two streams on one GPU).
 struct Env {
-    mf_ctx *ctx = nullptr;
+    vector<int> devs;                           // --devices
+    vector<mf_ctx *> ctxs;                      // one per entry, made by the first thread that needs it
     string work_dir;
     bool cont = false;
     string start_ts;
 };
+static thread_local int t_slot = 0;             // the entry of Env::devs the calling thread works for
+static void parse_devices(Env &e, const Args &a) {
+    if (!e.devs.empty()) return;
+    if (a.has("devices")) {
+        const string v = a.get("devices");
+        size_t i = 0;
+        while (i <= v.size()) {
+            size_t j = v.find(',', i); if (j == string::npos) j = v.size();
+            const string tok = v.substr(i, j - i);
+            char *end = nullptr; const long d = strtol(tok.c_str(), &end, 10);
+            if (tok.empty() || *end || d < 0) die("Can't parse --devices '%s' (a comma-separated list of device numbers)", v.c_str());
+            e.devs.push_back((int)d);
+            i = j + 1;
+        }
+    } else if (a.has("device")) e.devs.push_back(a.geti("device", 0));
+    else { const int n = mf_device_count(); for (int d = 0; d < std::max(1, n); d++) e.devs.push_back(d); }
+    e.ctxs.assign(e.devs.size(), nullptr);
+}
 static mf_ctx *ctx_of(Env &e, const Args &a) {
-    if (!e.ctx) {
-        check(mf_ctx_create(a.geti("device", 0), a.geti("available-processors", (int)sysconf(_SC_NPROCESSORS_ONLN)), &e.ctx));
+    parse_devices(e, a);
+    mf_ctx *&ctx = e.ctxs[(size_t)t_slot];
+    if (!ctx) {
+        // (-p/--available-processors: the host-side parsers' threads, shared out over the entries that work side by side)
+        const int procs = a.geti("available-processors", (int)sysconf(_SC_NPROCESSORS_ONLN));
+        check(mf_ctx_create(e.devs[(size_t)t_slot], std::max(1, procs / (int)e.devs.size()), &ctx));
         // the steps of one run hand their results on through the reference's files; what a step has just written stays in HBM for the
-        // step that loads it next (a quarter of the device's memory at most; MF_FILE_CACHE=0 switches it off)
+        // step that loads it next (a quarter of the device's memory at most -- shared out over the entries that name the same device;
+        // MF_FILE_CACHE=0 switches it off)
         const char *fc = getenv("MF_FILE_CACHE");
-        check(mf_ctx_set_option(e.ctx, "file_cache", fc ? atoll(fc) : -1));
+        int same = 0; for (int d : e.devs) same += d == e.devs[(size_t)t_slot];
+        check(mf_ctx_set_option(ctx, "file_cache", fc ? atoll(fc) : -(int64_t)same));
         if (const char *mo = getenv("MF_OPTIONS")) {                      // library options for A/B runs: MF_OPTIONS=name=value,name=value
             string all(mo); size_t i = 0;
             while (i < all.size()) {
                 size_t j = all.find(',', i); if (j == string::npos) j = all.size();
                 const string kv = all.substr(i, j - i); const size_t q = kv.find('=');
-                if (q != string::npos) check(mf_ctx_set_option(e.ctx, kv.substr(0, q).c_str(), atoll(kv.c_str() + q + 1)));
+                if (q != string::npos) check(mf_ctx_set_option(ctx, kv.substr(0, q).c_str(), atoll(kv.c_str() + q + 1)));
                 i = j + 1;
             }
         }
     }
-    return e.ctx;
+    return ctx;
+}
+// a per-library step: item i is done by the worker of entry i mod D (entry 0 = the calling thread)
+static void for_each_library(Env &e, const Args &a, size_t n, const std::function<void(size_t)> &fn) {
+    parse_devices(e, a);
+    const size_t D = std::min(e.devs.size(), n);
+    if (D <= 1) { for (size_t i = 0; i < n; i++) fn(i); return; }
+    logmsg("DEBUG", "%zu libraries on %zu device contexts", n, D);
+    g_workers_active = true;
+    vector<std::thread> th;
+    for (size_t d = 1; d < D; d++)
+        th.emplace_back([&, d]() {
+            t_slot = (int)d;
+            if (e.ctxs[d]) check(mf_ctx_bind_thread(e.ctxs[d]));           // (made by the worker of an earlier step: HIP's device is per thread)
+            for (size_t i = d; i < n; i += D) fn(i);
+            if (e.ctxs[d]) mf_ctx_synchronize(e.ctxs[d]);
+        });
+    for (size_t i = 0; i < n; i += D) fn(i);
+    for (auto &t : th) t.join();
+    g_workers_active = false;
 }
 static vector<const char *> cptrs(const vector<string> &v) { vector<const char *> p; for (auto &s : v) p.push_back(s.c_str()); return p; }
 static void check_k(int k) {                                                 // KmersCounterMain.java:66-73
@@ -246,19 +304,21 @@ static vector<string> run_kmer_counter_many(Env &e, const Args &a, vector<string
     std::sort(files.begin(), files.end());
     string out_dir = a.get("output-dir", wd + "/kmers"), stats_dir = a.get("stats-dir", wd + "/stats");
     mkdirs(wd + "/sub-counter");
-    vector<string> outs;
     auto ends = [](const string &s, const char *x) { return s.size() >= 3 && s.compare(s.size() - 3, 3, x) == 0; };
+    vector<vector<string>> libs;                                             // :80-108, one entry per library
     for (size_t i = 0; i < files.size();) {
         string n = library_name(files[i]);
         bool pair = i + 1 < files.size() && ((ends(n, "_r1") && ends(library_name(files[i + 1]), "_r2")) || (ends(n, "_R1") && ends(library_name(files[i + 1]), "_R2")));
-        vector<string> fs(files.begin() + i, files.begin() + i + (pair ? 2 : 1));
-        outs.push_back(run_kmer_counter(e, a, fs, k, b, out_dir, stats_dir));
+        libs.emplace_back(files.begin() + i, files.begin() + i + (pair ? 2 : 1));
         i += pair ? 2 : 1;
     }
+    vector<string> outs(libs.size());
+    for_each_library(e, a, libs.size(), [&](size_t i) { outs[i] = run_kmer_counter(e, a, libs[i], k, b, out_dir, stats_dir); });
     return outs;
 }
 // seq-builder (src/tools/SeqBuilderMain.java:78-160)
-static string run_seq_builder(Env &e, const Args &a, const vector<string> &files, int k, int b, int bp, int l, const string &wd, const string &out_dir) {
+static string run_seq_builder(Env &e, const Args &a, const vector<string> &files, int k, int b, int bp, int l, const string &wd, const string &out_dir,
+                              bool write_distribution = true) {
     if (files.empty()) die("Mandatory option --k-mers is not set");
     mf_ctx *ctx = ctx_of(e, a);
     mf_table *t = nullptr;
@@ -280,12 +340,22 @@ static string run_seq_builder(Env &e, const Args &a, const vector<string> &files
     string fasta = out_dir + "/" + base + (files.size() > 1 ? "+" : "") + ".seq.fasta";
     string distr = wd + "/distribution";
     uint64_t nseq = 0;
-    check(mf_build_unitigs(ctx, t, k, b, l, fasta.c_str(), distr.c_str(), &nseq));
+    check(mf_build_unitigs(ctx, t, k, b, l, fasta.c_str(), write_distribution ? distr.c_str() : nullptr, &nseq));
     logmsg("INFO", "%s sequences found", group_digits(nseq).c_str());
     if (nseq == 0) logmsg("WARN", "No sequences were found! Perhaps you should decrease --min-seq-len or --maximal-bad-frequency values");
     logmsg("INFO", "Sequences printed to %s", fasta.c_str());
     mf_table_destroy(t);
     return fasta;
+}
+// seq-builder-many (src/tools/SeqBuilderForManyFilesMain.java:82-94): one seq-builder per k-mers file, all in <wd>/sub-builder.  Every one of
+// them writes sub-builder/distribution (SeqBuilderMain.java:98), so the file a run leaves behind is the LAST library's; with several
+// device contexts at work only that one writes it.
+static vector<string> run_seq_builder_many(Env &e, const Args &a, const vector<string> &kmers, int k, int b, int bp, int l, const string &wd, const string &out_dir) {
+    vector<string> fs(kmers.size());
+    parse_devices(e, a);
+    const bool par = std::min(e.devs.size(), kmers.size()) > 1;
+    for_each_library(e, a, kmers.size(), [&](size_t i) { fs[i] = run_seq_builder(e, a, {kmers[i]}, k, b, bp, l, wd + "/sub-builder", out_dir, !par || i + 1 == kmers.size()); });
+    return fs;
 }
 // component-cutter (src/tools/ComponentCutterMain.java:78-114)
 static string run_component_cutter(Env &e, const Args &a, const vector<string> &files, int k, int l, int b1, int b2, const string &wd, const string &comp_file) {
@@ -312,28 +382,41 @@ static string run_component_cutter(Env &e, const Args &a, const vector<string> &
 static vector<string> run_features(Env &e, const Args &a, const string &comp_file, const vector<string> &reads, const vector<string> &kmers,
                                    int k, int thr, const string &wd) {
     if (comp_file.empty()) die("Mandatory option --components-file is not set");
-    if (a.has("selected")) die("--selected is not supported by the HIP path");
     if (kmers.empty() && reads.empty()) die("No input files: pass reads (-i) or k-mers files (-ka)");
-    mf_ctx *ctx = ctx_of(e, a);
+    parse_devices(e, a);
     string out_dir = wd + "/vectors";
     mkdirs(out_dir);
-    vector<string> vecs;
+    // --selected (FeaturesCalculatorMain.java:55-57, 113-116): selected = IOUtils.loadKmers(selectedKmers, 0, ...), one table per device context
+    const vector<string> sel_files = a.list("selected");
+    vector<mf_table *> sel(e.devs.size(), nullptr);
+    auto selected = [&]() -> mf_table * {
+        if (sel_files.empty()) return nullptr;
+        mf_table *&t = sel[(size_t)t_slot];
+        if (!t) { auto fp = cptrs(sel_files); check(mf_table_load_kmers(ctx_of(e, a), fp.data(), (int)fp.size(), 0, k, &t)); }
+        return t;
+    };
     // reads files first, one vector per FILE, then k-mers files (FeaturesCalculatorMain.java:117-162)
-    for (auto &rf : reads) {
-        string base = library_name(rf);
-        string vec = out_dir + "/" + base + ".vec", br = out_dir + "/" + base + ".breadth";
-        const char *fs[1] = {rf.c_str()};
-        check(mf_features_reads(ctx, comp_file.c_str(), fs, 1, k, thr, vec.c_str(), br.c_str()));
-        logmsg("INFO", "Features for file %s printed to %s", basename_of(rf).c_str(), vec.c_str());
-        vecs.push_back(vec);
-    }
-    for (auto &kf : kmers) {
-        string base = remove_ext(basename_of(kf), {".kmers.bin"});
-        string vec = out_dir + "/" + base + ".vec", br = out_dir + "/" + base + ".breadth";
-        check(mf_features(ctx, comp_file.c_str(), kf.c_str(), k, thr, vec.c_str(), br.c_str()));
-        logmsg("INFO", "Features for file %s printed to %s", basename_of(kf).c_str(), vec.c_str());
-        vecs.push_back(vec);
-    }
+    vector<string> vecs(reads.size() + kmers.size());
+    for_each_library(e, a, vecs.size(), [&](size_t i) {
+        mf_ctx *ctx = ctx_of(e, a);
+        if (i < reads.size()) {
+            const string &rf = reads[i];
+            string base = library_name(rf);
+            string vec = out_dir + "/" + base + ".vec", br = out_dir + "/" + base + ".breadth";
+            const char *fs[1] = {rf.c_str()};
+            check(mf_features_reads_selected(ctx, comp_file.c_str(), fs, 1, k, thr, selected(), vec.c_str(), br.c_str()));
+            logmsg("INFO", "Features for file %s printed to %s", basename_of(rf).c_str(), vec.c_str());
+            vecs[i] = vec;
+        } else {
+            const string &kf = kmers[i - reads.size()];
+            string base = remove_ext(basename_of(kf), {".kmers.bin"});
+            string vec = out_dir + "/" + base + ".vec", br = out_dir + "/" + base + ".breadth";
+            check(mf_features_selected(ctx, comp_file.c_str(), kf.c_str(), k, thr, selected(), vec.c_str(), br.c_str()));
+            logmsg("INFO", "Features for file %s printed to %s", basename_of(kf).c_str(), vec.c_str());
+            vecs[i] = vec;
+        }
+    });
+    for (mf_table *t : sel) if (t) mf_table_destroy(t);
     return vecs;
 }
 // Double.toString (what Java's "%s" prints for a double): shortest digits that round-trip, decimal notation in [1e-3, 1e7)
@@ -747,7 +830,7 @@ int main(int argc, char **argv) {
     if (a.has("tools")) { printf("Available tools:\n%s", TOOLS_TEXT); return 0; }
     if (a.has("help") || a.has("help-all")) {
         printf("Usage: metafast.sh [-t <tool>] [options]\n\nTools:\n%s\nLaunch options: -w/--work-dir <dir>  -p/--available-processors <n>  -c/--continue  --force  "
-               "-s/--start <step>  -f/--finish <step>  -v/--verbose  --device <n>\nTool options follow the reference (see SURVEY.md 8(b1)).\n", TOOLS_TEXT);
+               "-s/--start <step>  -f/--finish <step>  -v/--verbose  --devices <a,b,...> (default: all; the per-library steps run one library per device)  --device <n>\nTool options follow the reference (see SURVEY.md 8(b1)).\n", TOOLS_TEXT);
         return 0;
     }
     static const char *KNOWN[] = {"kmer-counter", "kmer-counter-many", "seq-builder", "seq-builder-many", "component-cutter", "features-calculator",
@@ -834,11 +917,7 @@ int main(int argc, char **argv) {
         int b = a.geti("maximal-bad-frequency", 1), bp = a.has("bottom-cut-percent") ? a.geti("bottom-cut-percent", 0) : -1, l = a.geti("sequence-len", 100);
         string out_dir = a.get("output-dir", wd + "/sequences");
         if (tool == "seq-builder") outs = {PV::file("output-file", run_seq_builder(e, a, a.list("k-mers"), k, b, bp, l, wd, out_dir))};
-        else {
-            vector<string> fs;
-            for (auto &f : a.list("k-mers")) fs.push_back(run_seq_builder(e, a, {f}, k, b, bp, l, wd + "/sub-builder", out_dir));
-            outs = {PV::files("output-files", fs)};
-        }
+        else outs = {PV::files("output-files", run_seq_builder_many(e, a, a.list("k-mers"), k, b, bp, l, wd, out_dir))};
     } else if (tool == "component-cutter") {
         const int b1 = a.geti("min-component-size", 1000), b2 = a.geti("max-component-size", 10000);
         string cf = run_component_cutter(e, a, a.list("sequences"), k, a.geti("min-seq-len", 100), b1, b2, wd, a.get("components-file", wd + "/components.bin"));
@@ -941,7 +1020,7 @@ int main(int argc, char **argv) {
             if (i + 1 < 6) { unlink((dirs[i + 1] + "/SUCCESS").c_str()); unlink((dirs[i + 1] + "/in.properties").c_str()); }
             return true;
         };
-        auto done = [&]() { if (e.ctx) mf_ctx_destroy(e.ctx); return 0; };
+        auto done = [&]() { for (mf_ctx *c : e.ctxs) if (c) mf_ctx_destroy(c); return 0; };
         vector<string> kmers, seqs, vecs;
         // 1 kmer-counter-many
         const string stats_dir = a.get("stats-dir", d1 + "/stats");
@@ -957,7 +1036,7 @@ int main(int argc, char **argv) {
         run_as_step(STEPS[1], d2, {PV("k", k), PV::files("k-mers", kmers), PV("maximal-bad-frequency", b), bp >= 0 ? PV("bottom-cut-percent", bp) : PV::null("bottom-cut-percent"),
                                    PV("sequence-len", l), PV::file("output-dir", d2 + "/sequences")},
                     start, force,
-                    [&]() { for (auto &f : kmers) seqs.push_back(run_seq_builder(e, a, {f}, k, b, bp, l, d2 + "/sub-builder", d2 + "/sequences"));
+                    [&]() { seqs = run_seq_builder_many(e, a, kmers, k, b, bp, l, d2, d2 + "/sequences");
                             return vector<PV>{PV::files("output-files", seqs)}; },
                     [&](const Props &o) { seqs = props_list(o, "output-files"); });
         describe(d2 + "/sequences", "Directory with FASTA files - paths from reads for every library");
@@ -974,7 +1053,7 @@ int main(int argc, char **argv) {
         // 4 features-calculator
         const vector<string> none;
         run_as_step(STEPS[3], d4, {PV("k", k), PV::file("components-file", comp), PV::files("reads", use_reads ? reads : none), PV::files("kmers", use_reads ? none : kmers),
-                                   PV::null("selected"), PV("threshold", 0)},
+                                   a.has("selected") ? PV::files("selected", a.list("selected")) : PV::null("selected"), PV("threshold", 0)},
                     start, force,
                     [&]() { vecs = use_reads ? run_features(e, a, comp, reads, {}, k, 0, d4) : run_features(e, a, comp, {}, kmers, k, 0, d4);
                             return vector<PV>{PV::files("features-files", vecs), PV::file("features-dir", d4 + "/vectors")}; },
@@ -1007,7 +1086,7 @@ int main(int argc, char **argv) {
         if (finished(5)) return done();
     }
     const double t_work = since_start();
-    if (e.ctx) mf_ctx_synchronize(e.ctx);
+    for (mf_ctx *c : e.ctxs) if (c) mf_ctx_synchronize(c);
     if (finish.empty()) {                               // (a run cut short by --finish leaves no SUCCESS, :377-379)
         props_write(wd + "/out.properties", outs);
         touch(wd + "/SUCCESS");
@@ -1019,6 +1098,6 @@ int main(int argc, char **argv) {
     // the HIP runtime's own shutdown after that, cost 0.2 s; the process ends here and the driver reclaims them with it
     // (MF_CLEAN_EXIT=1: the long way, for leak checkers)
     fflush(nullptr);
-    if (getenv("MF_CLEAN_EXIT")) { if (e.ctx) mf_ctx_destroy(e.ctx); return 0; }
+    if (getenv("MF_CLEAN_EXIT")) { for (mf_ctx *c : e.ctxs) if (c) mf_ctx_destroy(c); return 0; }
     _exit(0);
 }

@@ -47,7 +47,7 @@ __global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ ke
 
 // the same for a table with minimizer partitions: partition-local lookups (mf_nbr.h)
 template <int MODE, int KT = 0>
-__attribute__((amdgpu_waves_per_eu(KT == 31 ? 6 : 5, 8)))         // (as k_ut_flags_part, mf_unitig.hip: no scratch, checked by the build)
+__attribute__((amdgpu_waves_per_eu(KT ? 6 : 5, 8)))         // (as k_ut_flags_part, mf_unitig.hip: no scratch, checked by the build)
 __global__ __launch_bounds__(64 * NB_WAVES) void k_cc_adjacency_part(mf_index_view ix, const uint64_t *__restrict__ keys, const uint64_t *__restrict__ part_off,
                                                                    uint32_t np, int k_rt, uint32_t *__restrict__ nbr) {
     __shared__ nb_lds S;
@@ -388,7 +388,7 @@ __global__ void k_cc_remap(uint32_t *__restrict__ comp, uint64_t n, const uint32
 // ---- features: one thread per sample record ----
 __global__ void k_features(mf_index_view ix, const uint32_t *__restrict__ comp_of,
                            const uint64_t *__restrict__ keys, const uint16_t *__restrict__ cnts, uint64_t n, int threshold,
-                           unsigned long long *__restrict__ vec, unsigned int *__restrict__ found) {
+                           const uint8_t *__restrict__ sel, unsigned long long *__restrict__ vec, unsigned int *__restrict__ found) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
@@ -396,6 +396,7 @@ __global__ void k_features(mf_index_view ix, const uint32_t *__restrict__ comp_o
         if (c <= threshold) continue;                       // value > threshold (buildAndPrintVector :196-199)
         uint32_t idx, val;
         if (!mf_index_find(ix, keys[i], &idx, &val)) continue;   // hm.contains(kmer) (KmersPresenceWorker :583-587)
+        if (sel && !sel[idx]) continue;                     // selected.getWithZero(kmer) > 0 (:193)
         uint32_t comp = comp_of[idx];
         atomicAdd(&vec[comp], (unsigned long long)c);
         atomicAdd(&found[comp], 1u);
@@ -406,13 +407,13 @@ __global__ void k_features(mf_index_view ix, const uint32_t *__restrict__ comp_o
 // lists are a few percent of a sample's table: 3e7 probes instead of 3.6e8, and no index over the components).  The
 // k-mers of a component are contiguous, so a wave mostly adds to ONE component: wave-level sum, one atomic. ----
 __global__ void k_features_rev(mf_index_view ix, const uint64_t *__restrict__ ckeys, const uint32_t *__restrict__ comp_of, uint64_t nk,
-                               int threshold, unsigned long long *__restrict__ vec, unsigned int *__restrict__ found) {
+                               int threshold, const uint8_t *__restrict__ sel, unsigned long long *__restrict__ vec, unsigned int *__restrict__ found) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t comp = 0xFFFFFFFFu, val = 0, hit = 0;
     if (j < nk) {
         uint32_t idx, v;
         comp = comp_of[j];
-        if (mf_index_find(ix, ckeys[j], &idx, &v) && (int)v > threshold) { val = v; hit = 1; }
+        if ((!sel || sel[j]) && mf_index_find(ix, ckeys[j], &idx, &v) && (int)v > threshold) { val = v; hit = 1; }
     }
     const uint32_t first = __shfl(comp, 0, 64);
     if (__ballot(comp != first) == 0ull) {
@@ -426,13 +427,13 @@ __global__ void k_features_rev(mf_index_view ix, const uint64_t *__restrict__ ck
 
 // features from per-k-mer occurrence counters (reads mode): same reduction as k_features_rev
 __global__ void k_features_occ(const unsigned long long *__restrict__ occ, const uint32_t *__restrict__ comp_of, uint64_t nk,
-                               int threshold, unsigned long long *__restrict__ vec, unsigned int *__restrict__ found) {
+                               int threshold, const uint8_t *__restrict__ sel, unsigned long long *__restrict__ vec, unsigned int *__restrict__ found) {
     const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t comp = 0xFFFFFFFFu, hit = 0; unsigned long long val = 0;
     if (j < nk) {
         comp = comp_of[j];
         const unsigned long long v = occ[j];
-        if ((long long)v > (long long)threshold) { val = v; hit = 1; }
+        if ((!sel || sel[j]) && (long long)v > (long long)threshold) { val = v; hit = 1; }
     }
     const uint32_t first = __shfl(comp, 0, 64);
     if (__ballot(comp != first) == 0ull) {
@@ -442,6 +443,25 @@ __global__ void k_features_occ(const unsigned long long *__restrict__ occ, const
         atomicAdd(&vec[comp], val);
         atomicAdd(&found[comp], 1u);
     }
+}
+
+// --selected (FeaturesCalculatorMain.java:55-57, 115-117, 193): sel[j] = 1 iff component k-mer j has a value > 0 in the table of
+// selected k-mers (selected.getWithZero(kmer) > 0); selcnt[c] = such k-mers of component c (kmersCount, the breadth's denominator)
+__global__ void k_features_select(mf_index_view ix, const uint64_t *__restrict__ ckeys, const uint32_t *__restrict__ comp_of, uint64_t nk,
+                                  uint8_t *__restrict__ sel, unsigned int *__restrict__ selcnt) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t comp = 0xFFFFFFFFu, hit = 0;
+    if (j < nk) {
+        uint32_t idx, v;
+        comp = comp_of[j];
+        hit = mf_index_find(ix, ckeys[j], &idx, &v) && (int)v > 0;
+        sel[j] = (uint8_t)hit;
+    }
+    const uint32_t first = __shfl(comp, 0, 64);
+    if (__ballot(comp != first) == 0ull) {
+        const uint32_t tot = (uint32_t)__popcll(__ballot(hit != 0));
+        if (mf_lane() == 0 && tot) atomicAdd(&selcnt[first], tot);
+    } else if (hit) atomicAdd(&selcnt[comp], 1u);
 }
 
 static inline unsigned cgrid(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
@@ -488,6 +508,7 @@ int mf_comps_materialize(mf_comps *C) {
 }
 
 extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2, mf_comps **out) {
+    mf_range rng_("mf:components");
     if (!ctx || !t || !out) return mf_set_error("mf_cut_components_device: NULL argument");
     *out = nullptr;
     MF_HIP(hipSetDevice(ctx->device));
@@ -522,13 +543,15 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
                 const uint32_t np = 1u << t->part_bits;
                 const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
                 const unsigned grid2 = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16);
-                if (k == 31) {
-                    k_cc_adjacency_part<1, 31><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
-                    k_cc_adjacency_part<2, 31><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
-                } else {
-                    k_cc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
-                    k_cc_adjacency_part<2><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
+#define CC_ADJ_K(KK) case KK: k_cc_adjacency_part<1, KK><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p); \
+                              k_cc_adjacency_part<2, KK><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p); break;
+                switch (k) {                                                    // (k as a compile-time constant: see k_ut_flags_part's dispatch, mf_unitig.hip)
+                    CC_ADJ_K(21) CC_ADJ_K(23) CC_ADJ_K(25) CC_ADJ_K(27) CC_ADJ_K(29) CC_ADJ_K(31)
+                    default:
+                        k_cc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
+                        k_cc_adjacency_part<2><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
                 }
+#undef CC_ADJ_K
             } else
             k_cc_adjacency<<<cgrid(n), 256, 0, st>>>(mf_view(t->index), t->d_keys, n, k, nbr.p);
         }
@@ -690,12 +713,46 @@ int mf_comps_from_host(mf_ctx *ctx, int k, const std::vector<uint64_t> &sizes, c
     return MF_OK;
 }
 
-extern "C" int mf_features_device(mf_ctx *ctx, mf_comps *c, const mf_table *sample, int threshold, int64_t *vec, double *breadth) {
+// the selection of --selected on the component k-mers: mask per k-mer + count per component (host); selected == NULL: no mask
+static int features_selection(mf_ctx *ctx, mf_comps *c, mf_table *selected, mf_buf<uint8_t> &mask, std::vector<unsigned int> &selcnt) {
+    if (!selected) return MF_OK;
+    if (selected->ctx != ctx) return mf_set_error("features: the table of selected k-mers belongs to another context");
+    hipStream_t st = ctx->stream;
+    mf_buf<unsigned int> dcnt;
+    MF_TRY(mask.alloc(ctx, c->n_kmers ? c->n_kmers : 1)); MF_TRY(dcnt.alloc(ctx, c->n));
+    MF_HIP(hipMemsetAsync(mask.p, 0, c->n_kmers ? c->n_kmers : 1, st));
+    MF_HIP(hipMemsetAsync(dcnt.p, 0, c->n * 4, st));
+    if (selected->n && c->n_kmers) {
+        MF_TRY(mf_table_ensure_index(selected));
+        mf_ktimer tm(ctx, "k_features_select");
+        k_features_select<<<cgrid(c->n_kmers), 256, 0, st>>>(mf_view(selected->index), c->d_kmers, c->d_comp, c->n_kmers, mask.p, dcnt.p);
+    }
+    selcnt.resize(c->n);
+    MF_HIP(hipMemcpyAsync(selcnt.data(), dcnt.p, c->n * 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
+// breadth[i] = ((double) kmersFound) / kmersCount (:203); with --selected kmersCount counts the selected k-mers only and a
+// component without any gives 0.0 / 0.0 = NaN, as the Java division does
+static void features_breadth(const mf_comps *c, const std::vector<unsigned int> &hf, const std::vector<unsigned int> *selcnt, int threshold, double *breadth) {
+    for (uint64_t i = 0; i < c->n; i++) {
+        const uint64_t cnt = selcnt ? (uint64_t)(*selcnt)[i] : c->sizes[i];
+        // a negative threshold makes absent k-mers (value 0) count as found (value > threshold)
+        const double f = threshold < 0 ? (double)cnt : (double)hf[i];
+        breadth[i] = f / (double)cnt;
+    }
+}
+
+extern "C" int mf_features_device_selected(mf_ctx *ctx, mf_comps *c, const mf_table *sample, mf_table *selected, int threshold,
+                                           int64_t *vec, double *breadth) {
+    mf_range rng_("mf:features");
     if (!ctx || !c || !sample || !vec) return mf_set_error("mf_features_device: NULL argument");
     MF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint64_t nc = c->n;
     if (!nc) return MF_OK;
+    mf_buf<uint8_t> mask; std::vector<unsigned int> selcnt;
+    MF_TRY(features_selection(ctx, c, selected, mask, selcnt));
     mf_buf<unsigned long long> dvec; mf_buf<unsigned int> dfound;
     MF_TRY(dvec.alloc(ctx, nc)); MF_TRY(dfound.alloc(ctx, nc));
     MF_HIP(hipMemsetAsync(dvec.p, 0, nc * 8, st));
@@ -705,38 +762,38 @@ extern "C" int mf_features_device(mf_ctx *ctx, mf_comps *c, const mf_table *samp
         if (sample->index.slots || c->n_kmers < sample->n) {
             MF_TRY(mf_table_ensure_index(const_cast<mf_table *>(sample)));
             mf_ktimer tm(ctx, "k_features");
-            k_features_rev<<<cgrid(c->n_kmers), 256, 0, st>>>(mf_view(sample->index), c->d_kmers, c->d_comp, c->n_kmers, threshold, dvec.p, dfound.p);
+            k_features_rev<<<cgrid(c->n_kmers), 256, 0, st>>>(mf_view(sample->index), c->d_kmers, c->d_comp, c->n_kmers, threshold, mask.p, dvec.p, dfound.p);
         } else {          // ... or the components
             if (!c->index.slots) MF_TRY(mf_index_build(ctx, c->d_kmers, nullptr, c->n_kmers, &c->index, &c->index_bytes));
             unsigned grid = (unsigned)std::min<uint64_t>((sample->n + 255) / 256, 65536);
             mf_ktimer tm(ctx, "k_features");
             k_features<<<grid, 256, 0, st>>>(mf_view(c->index), c->d_comp, sample->d_keys,
-                                             sample->d_counts, sample->n, threshold, dvec.p, dfound.p);
+                                             sample->d_counts, sample->n, threshold, mask.p, dvec.p, dfound.p);
         }
     }
     std::vector<unsigned int> hf(nc);
     MF_HIP(hipMemcpyAsync(vec, dvec.p, nc * 8, hipMemcpyDeviceToHost, st));
     MF_HIP(hipMemcpyAsync(hf.data(), dfound.p, nc * 4, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
-    if (breadth)
-        for (uint64_t i = 0; i < nc; i++) {
-            uint64_t cnt = c->sizes[i];
-            // a negative threshold makes absent k-mers (value 0) count as found (value > threshold)
-            double f = threshold < 0 ? (double)cnt : (double)hf[i];
-            breadth[i] = f / (double)cnt;                    // ((double) kmersFound) / kmersCount :203
-        }
+    if (breadth) features_breadth(c, hf, selected ? &selcnt : nullptr, threshold, breadth);
     return MF_OK;
+}
+extern "C" int mf_features_device(mf_ctx *ctx, mf_comps *c, const mf_table *sample, int threshold, int64_t *vec, double *breadth) {
+    return mf_features_device_selected(ctx, c, sample, nullptr, threshold, vec, breadth);
 }
 
 int mf_presence_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k,
                      const mf_index &index, unsigned long long *d_occ);
-extern "C" int mf_features_reads_device(mf_ctx *ctx, mf_comps *c, const void *d_bases, const void *d_offsets, uint64_t n_reads,
-                                        uint64_t n_bases, int k, int threshold, int64_t *vec, double *breadth) {
+extern "C" int mf_features_reads_device_selected(mf_ctx *ctx, mf_comps *c, const void *d_bases, const void *d_offsets, uint64_t n_reads,
+                                                 uint64_t n_bases, int k, mf_table *selected, int threshold, int64_t *vec, double *breadth) {
+    mf_range rng_("mf:features_reads");
     if (!ctx || !c || !vec) return mf_set_error("mf_features_reads_device: NULL argument");
     MF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint64_t nc = c->n;
     if (!nc) return MF_OK;
+    mf_buf<uint8_t> mask; std::vector<unsigned int> selcnt;
+    MF_TRY(features_selection(ctx, c, selected, mask, selcnt));
     mf_buf<unsigned long long> dvec, occ; mf_buf<unsigned int> dfound;
     MF_TRY(dvec.alloc(ctx, nc)); MF_TRY(dfound.alloc(ctx, nc)); MF_TRY(occ.alloc(ctx, c->n_kmers));
     MF_HIP(hipMemsetAsync(dvec.p, 0, nc * 8, st));
@@ -746,19 +803,18 @@ extern "C" int mf_features_reads_device(mf_ctx *ctx, mf_comps *c, const void *d_
         if (!c->index.slots) MF_TRY(mf_index_build(ctx, c->d_kmers, nullptr, c->n_kmers, &c->index, &c->index_bytes));   // hm.put(kmer, 0) :99-103
         MF_TRY(mf_presence_core(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, c->index, occ.p));
         mf_ktimer tm(ctx, "k_features");
-        k_features_occ<<<cgrid(c->n_kmers), 256, 0, st>>>(occ.p, c->d_comp, c->n_kmers, threshold, dvec.p, dfound.p);
+        k_features_occ<<<cgrid(c->n_kmers), 256, 0, st>>>(occ.p, c->d_comp, c->n_kmers, threshold, mask.p, dvec.p, dfound.p);
     }
     std::vector<unsigned int> hf(nc);
     MF_HIP(hipMemcpyAsync(vec, dvec.p, nc * 8, hipMemcpyDeviceToHost, st));
     MF_HIP(hipMemcpyAsync(hf.data(), dfound.p, nc * 4, hipMemcpyDeviceToHost, st));
     MF_HIP(hipStreamSynchronize(st));
-    if (breadth)
-        for (uint64_t i = 0; i < nc; i++) {
-            const uint64_t cnt = c->sizes[i];
-            const double f = threshold < 0 ? (double)cnt : (double)hf[i];
-            breadth[i] = f / (double)cnt;
-        }
+    if (breadth) features_breadth(c, hf, selected ? &selcnt : nullptr, threshold, breadth);
     return MF_OK;
+}
+extern "C" int mf_features_reads_device(mf_ctx *ctx, mf_comps *c, const void *d_bases, const void *d_offsets, uint64_t n_reads,
+                                        uint64_t n_bases, int k, int threshold, int64_t *vec, double *breadth) {
+    return mf_features_reads_device_selected(ctx, c, d_bases, d_offsets, n_reads, n_bases, k, nullptr, threshold, vec, breadth);
 }
 
 // DistanceMatrixCalculatorMain.brayCurtisDistance :140-152.  Both sums are exact integers < 2^53 in double

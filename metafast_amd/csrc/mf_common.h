@@ -119,6 +119,16 @@ struct mf_ktimer {
     ~mf_ktimer();
 };
 
+// RAII roctx range around one stage of the path (count / unitigs / components / features and the file seams): what the reference
+// prints as Timer lines at debug level (src/tools/KmersCounterMain.java:76,79; src/algo/ComponentsBuilder.java:60,88) shows up as
+// named ranges in `rocprofv3 --marker-trace`.  The marker library (librocprofiler-sdk-roctx) is looked up at run time, once, when
+// a profiler is attached (ROCP_TOOL_LIBRARIES set) or MF_ROCTX=1; otherwise a range costs one predictable branch.
+struct mf_range {
+    bool on;
+    explicit mf_range(const char *name);
+    ~mf_range();
+};
+
 template <typename T> struct mf_buf {   // RAII workspace buffer
     mf_ctx *ctx = nullptr; T *p = nullptr; size_t n = 0;
     bool owned = true;                   // false: a view of somebody else's buffer (borrow), never released here

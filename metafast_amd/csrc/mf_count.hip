@@ -863,6 +863,7 @@ int mf_presence_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offs
 
 extern "C" int mf_count_device(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads,
                                uint64_t n_bases, int k, int min_read_len, mf_table **out) {
+    mf_range rng_("mf:count");
     if (!ctx || !out) return mf_set_error("mf_count_device: NULL argument");
     *out = nullptr;
     return mf_count_core(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, min_read_len, out, -1, nullptr);
@@ -871,6 +872,7 @@ extern "C" int mf_count_device(mf_ctx *ctx, const void *d_bases, const void *d_o
 // log2(world) bits).  The table has the partitions of the whole table; the other ranks' partitions are empty.
 extern "C" int mf_count_device_shard(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t n_bases, int k,
                                      int min_read_len, int rank, int world, mf_table **out) {
+    mf_range rng_("mf:count_shard");
     if (!ctx || !out) return mf_set_error("mf_count_device_shard: NULL argument");
     *out = nullptr;
     if (world < 1 || world > 64 || (world & (world - 1)) || rank < 0 || rank >= world)
@@ -883,6 +885,7 @@ extern "C" int mf_count_device_shard(mf_ctx *ctx, const void *d_bases, const voi
 extern "C" int mf_count_device_above(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads,
                                      uint64_t n_bases, int k, int min_read_len, int threshold, mf_table **out,
                                      uint64_t *n_distinct_all) {
+    mf_range rng_("mf:count");
     if (!ctx || !out) return mf_set_error("mf_count_device_above: NULL argument");
     *out = nullptr;
     return mf_count_core(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, min_read_len, out,

@@ -14,6 +14,43 @@ int mf_set_error(const char *fmt, ...) {
 }
 
 extern "C" const char *mf_last_error(void) { return g_err; }
+
+// ---- roctx ranges (mf_range) ----
+#include <dlfcn.h>
+#include <mutex>
+static int (*g_roctx_push)(const char *) = nullptr;
+static int (*g_roctx_pop)(void) = nullptr;
+static bool roctx_ready() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *want = getenv("MF_ROCTX");
+        if (want ? atoi(want) == 0 : getenv("ROCP_TOOL_LIBRARIES") == nullptr) return;
+        void *h = nullptr;
+        for (const char *n : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!h) return;
+        g_roctx_push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+        g_roctx_pop = (int (*)(void))dlsym(h, "roctxRangePop");
+        if (!g_roctx_push || !g_roctx_pop) g_roctx_push = nullptr;
+    });
+    return g_roctx_push != nullptr;
+}
+mf_range::mf_range(const char *name) : on(roctx_ready()) { if (on) g_roctx_push(name); }
+mf_range::~mf_range() { if (on) g_roctx_pop(); }
+
+// devices this process can see (what `--devices` of the driver defaults to); no context is made
+extern "C" int mf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+// HIP's current device is a property of the calling THREAD: a context made on one thread and then used from another (the driver's
+// per-device workers take turns over the steps of a run) is bound to the new thread first.  One calling thread at a time per context.
+extern "C" int mf_ctx_bind_thread(mf_ctx *ctx) {
+    if (!ctx) return mf_set_error("ctx is NULL");
+    MF_HIP(hipSetDevice(ctx->device));
+    return MF_OK;
+}
+extern "C" int mf_ctx_device(const mf_ctx *ctx) { return ctx ? ctx->device : mf_set_error("ctx is NULL"); }
 extern "C" const char *mf_version(void) { return "metafast_hip 0.1 (gfx950)"; }
 
 extern "C" int mf_ctx_create(int device, int host_threads, mf_ctx **out) {
@@ -136,8 +173,8 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "dcc_sparse") ctx->opt_dcc_sparse = v;
     else if (s == "cc_sparse") ctx->opt_cc_sparse = v;
     else if (s == "wide_passes") { if (v < 0 || v > 65536 || (v & (v - 1))) return mf_set_error("wide_passes must be 0 or a power of two <= 65536"); ctx->opt_wide_passes = v; }
-    else if (s == "file_cache") {                       // GB; -1: a quarter of the device's memory
-        if (v < 0) { size_t fr = 0, tot = 0; MF_HIP(hipSetDevice(ctx->device)); MF_HIP(hipMemGetInfo(&fr, &tot)); v = (int64_t)(tot >> 32); }
+    else if (s == "file_cache") {                       // GB; -1: a quarter of the device's memory, -n: an n-th of that (n contexts share the device)
+        if (v < 0) { size_t fr = 0, tot = 0; MF_HIP(hipSetDevice(ctx->device)); MF_HIP(hipMemGetInfo(&fr, &tot)); v = std::max<int64_t>(1, (int64_t)(tot >> 32) / -v); }
         ctx->opt_file_cache_gb = v;
         if (!v) mf_file_cache_clear(ctx);
     }

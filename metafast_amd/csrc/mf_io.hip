@@ -313,6 +313,7 @@ extern "C" int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles,
 // KmersCounterMain.runImpl (src/tools/KmersCounterMain.java:77-99): loadReads, then printKmers keeps value > threshold
 extern "C" int mf_count_reads_above(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, int threshold, mf_table **out,
                                     uint64_t *n_distinct_all) {
+    mf_range rng_("mf:count_reads(files)");
     if (n_distinct_all) *n_distinct_all = 0;
     return count_reads_impl(ctx, files, nfiles, k, min_read_len, threshold, out, n_distinct_all, "mf_count_reads_above");
 }
@@ -454,6 +455,7 @@ extern "C" int mf_table_write_kmers_filtered(const mf_table *t, int threshold, m
     return MF_OK;
 }
 extern "C" int mf_table_write_kmers(const mf_table *t, int threshold, const char *kmers_bin, const char *stat_txt, uint64_t *n_good) {
+    mf_range rng_("mf:write_kmers(file)");
     if (!t || !kmers_bin) return mf_set_error("mf_table_write_kmers: NULL argument");
     mf_ctx *ctx = t->ctx;
     io_timer tm("write_kmers");
@@ -490,6 +492,7 @@ extern "C" int mf_table_write_kmers(const mf_table *t, int threshold, const char
 // occurs in several files gets the (saturating) sum
 int mf_table_from_device_pairs(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, int k, mf_table **out);
 extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nfiles, int freq_threshold, int k, mf_table **out) {
+    mf_range rng_("mf:load_kmers(file)");
     if (!ctx || !out || (nfiles && !files)) return mf_set_error("mf_table_load_kmers: NULL argument");
     *out = nullptr;
     MF_HIP(hipSetDevice(ctx->device));
@@ -499,7 +502,12 @@ extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nf
         if (e && e->t && e->t->k == k) {
             // (the file's records all have count > e->thr: a threshold at or below that keeps every one of them -- the same table)
             if (freq_threshold <= e->thr) { e->t->refs++; *out = e->t; tm.lap("resident"); return MF_OK; }
-            const int rc = mf_table_filter(e->t, freq_threshold, out);
+            // (the filter allocates, and an allocation the arena cannot serve empties the file cache -- mf_alloc --, which would hand the
+            // cached table's arrays back while the filter still reads them: hold a handle of our own across the call, and do not
+            // touch `e` after it)
+            mf_table *src = e->t; src->refs++;
+            const int rc = mf_table_filter(src, freq_threshold, out);
+            mf_table_destroy(src);
             tm.lap("resident, filtered");
             return rc;
         }
@@ -599,6 +607,7 @@ extern "C" int mf_seqs_write_fasta(const mf_seqs *s, const char *path) {
 // SeqBuilderMain.runImpl (src/tools/SeqBuilderMain.java:78-160)
 extern "C" int mf_build_unitigs(mf_ctx *ctx, mf_table *t, int k, int freq_threshold, int min_len, const char *seq_fasta,
                                 const char *distribution, uint64_t *n_seq) {
+    mf_range rng_("mf:seq_builder(files)");
     if (!ctx || !t || !seq_fasta) return mf_set_error("mf_build_unitigs: NULL argument");
     if (k != t->k) return mf_set_error("mf_build_unitigs: k=%d but the table was built with k=%d", k, t->k);
     if (distribution) {                                         // stat[min(value,1023)]++, lines "i stat[i]" for i=1..1023 (:84-98,170-176)
@@ -703,6 +712,7 @@ __global__ __launch_bounds__(256) void k_comps_decode(const uint32_t *__restrict
     }
 }
 extern "C" int mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps **out) {
+    mf_range rng_("mf:load_components(file)");
     if (!ctx || !components_bin || !out) return mf_set_error("mf_comps_load: NULL argument");
     *out = nullptr;
     io_timer tm("load_components");
@@ -737,11 +747,15 @@ extern "C" int mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps *
     }
     C->host_ready = false;             // (member lists on the host: built from the device arrays when somebody asks)
     *out = C.release();
+    // (features-calculator loads the same components.bin once per library, FeaturesCalculatorMain.java:82 is one load for all of them: a context
+    // that did not write the file -- the driver's workers on the other devices -- keeps what it has just decoded)
+    file_cache_put(ctx, components_bin, nullptr, 0, *out);
     return MF_OK;
 }
 // ComponentCutterMain.runImpl :92-108
 extern "C" int mf_cut_components(mf_ctx *ctx, mf_table *cutter, int k, int b1, int b2, const char *components_bin,
                                  const char *stat_txt, uint64_t *n_comp) {
+    mf_range rng_("mf:component_cutter(files)");
     if (!ctx || !cutter || !components_bin) return mf_set_error("mf_cut_components: NULL argument");
     if (k != cutter->k) return mf_set_error("mf_cut_components: k=%d but the table was built with k=%d", k, cutter->k);
     if (cutter->n == 0)                                                          // ComponentCutterMain.java:84-86
@@ -793,8 +807,8 @@ static std::string java_double(double d) {
 }
 static int write_features_files(const std::vector<int64_t> &vec, const std::vector<double> &br, const char *vec_path, const char *breadth_path);
 // FeaturesCalculatorMain.runImpl reads branch (:117-131): the files of ONE library
-extern "C" int mf_features_reads(mf_ctx *ctx, const char *components_bin, const char *const *files, int nfiles, int k, int threshold,
-                                 const char *vec_path, const char *breadth_path) {
+extern "C" int mf_features_reads_selected(mf_ctx *ctx, const char *components_bin, const char *const *files, int nfiles, int k, int threshold,
+                                          mf_table *selected, const char *vec_path, const char *breadth_path) {
     if (!ctx || !components_bin || (nfiles && !files)) return mf_set_error("mf_features_reads: NULL argument");
     mf_comps *c = nullptr;
     MF_TRY(mf_comps_load(ctx, components_bin, &c));
@@ -803,14 +817,18 @@ extern "C" int mf_features_reads(mf_ctx *ctx, const char *components_bin, const 
     uint64_t nr = 0, nb = 0;
     int rc = load_reads_to_device(ctx, files, nfiles, db, doff, &nr, &nb, nullptr, nullptr);
     std::vector<int64_t> vec(c->n); std::vector<double> br(c->n);
-    if (rc == MF_OK) rc = mf_features_reads_device(ctx, c, db.p, doff.p, nr, nb, k, threshold, vec.data(), br.data());
+    if (rc == MF_OK) rc = mf_features_reads_device_selected(ctx, c, db.p, doff.p, nr, nb, k, selected, threshold, vec.data(), br.data());
     if (rc == MF_OK) rc = write_features_files(vec, br, vec_path, breadth_path);
     mf_comps_destroy(c);
     return rc;
 }
+extern "C" int mf_features_reads(mf_ctx *ctx, const char *components_bin, const char *const *files, int nfiles, int k, int threshold,
+                                 const char *vec_path, const char *breadth_path) {
+    return mf_features_reads_selected(ctx, components_bin, files, nfiles, k, threshold, nullptr, vec_path, breadth_path);
+}
 // FeaturesCalculatorMain.runImpl kmers-file branch (:137-162) + buildAndPrintVector output (:217-230)
-extern "C" int mf_features(mf_ctx *ctx, const char *components_bin, const char *kmers_bin, int k, int threshold,
-                           const char *vec_path, const char *breadth_path) {
+extern "C" int mf_features_selected(mf_ctx *ctx, const char *components_bin, const char *kmers_bin, int k, int threshold, mf_table *selected,
+                                    const char *vec_path, const char *breadth_path) {
     if (!ctx || !components_bin || !kmers_bin) return mf_set_error("mf_features: NULL argument");
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
@@ -825,13 +843,17 @@ extern "C" int mf_features(mf_ctx *ctx, const char *components_bin, const char *
     if (rc < 0) { mf_comps_destroy(c); return rc; }
     const double t2 = now();
     std::vector<int64_t> vec(c->n); std::vector<double> br(c->n);
-    rc = mf_features_device(ctx, c, t, threshold, vec.data(), br.data());
+    rc = mf_features_device_selected(ctx, c, t, selected, threshold, vec.data(), br.data());
     const double t3 = now();
     if (rc == MF_OK) rc = write_features_files(vec, br, vec_path, breadth_path);
     if (getenv("MF_IO_TIMING")) fprintf(stderr, "[mf] features: components %.3f s, k-mers file %.3f s, features %.3f s, output %.3f s\n", t1 - t0, t2 - t1, t3 - t2, now() - t3);
     mf_table_destroy(t);
     mf_comps_destroy(c);
     return rc;
+}
+extern "C" int mf_features(mf_ctx *ctx, const char *components_bin, const char *kmers_bin, int k, int threshold,
+                           const char *vec_path, const char *breadth_path) {
+    return mf_features_selected(ctx, components_bin, kmers_bin, k, threshold, nullptr, vec_path, breadth_path);
 }
 // buildAndPrintVector output (:217-230): one long per line / one Double.toString per line
 static int write_features_files(const std::vector<int64_t> &vec, const std::vector<double> &br, const char *vec_path, const char *breadth_path) {

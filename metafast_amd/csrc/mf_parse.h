@@ -410,15 +410,16 @@ struct mf_bz_stream {
     void *state; void *(*bzalloc)(void *, int, int); void (*bzfree)(void *, void *); void *opaque;
 };
 static int inflate_bz2(const raw_file &in, raw_file &out, const char *path) {
-    static void *lib = nullptr;
     typedef int (*init_fn)(mf_bz_stream *, int, int); typedef int (*step_fn)(mf_bz_stream *);
+    static void *lib = nullptr;
     static init_fn bz_init = nullptr; static step_fn bz_step = nullptr, bz_end = nullptr;
-    if (!lib) {
+    static std::once_flag once;               // (contexts on several threads may meet their first .bz2 file together)
+    std::call_once(once, [] {
         for (const char *n : {"libbz2.so.1.0", "libbz2.so.1", "libbz2.so"}) if ((lib = dlopen(n, RTLD_NOW))) break;
         if (lib) {
             bz_init = (init_fn)dlsym(lib, "BZ2_bzDecompressInit"); bz_step = (step_fn)dlsym(lib, "BZ2_bzDecompress"); bz_end = (step_fn)dlsym(lib, "BZ2_bzDecompressEnd");
         }
-    }
+    });
     if (!lib || !bz_init || !bz_step || !bz_end) return mf_set_error("bzip2 input needs libbz2 at run time (not found): '%s'", path);
     size_t cap = std::max<size_t>(in.n * 6, (size_t)1 << 20), have = 0, fed = 0;
     out.p = (char *)malloc(cap);

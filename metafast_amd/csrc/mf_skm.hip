@@ -1082,6 +1082,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     for (;;) {
         bool abandon = false;
         uint32_t claimed = 0; bool claim_pending = false;
+        uint32_t next_claim = 0; bool claim_latched = false;                      // the claim as every wave read it behind B1 of the first pass
         if (unit_ctr && threadIdx.x == 0) { claimed = atomicAdd(unit_ctr, 1u); claim_pending = true; }      // (in flight until the unit's first barrier B1)
         dirent dnn = {0, 0, 0, 0};
         bool dnn_asked = false;
@@ -1259,6 +1260,10 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         c2_barrier();                                                           // ---- B1: every insert of the pass is done
         C2_TICK(4);                                                             // waiting for the other waves
         const bool over = c2_lds_u32(part_over) != 0u || c2_lds_u32(&blk_claims) > (uint32_t)C2_FILL;
+        // (the claim is read HERE, one barrier behind thread 0's write and at least one -- B2 of this unit, or the barriers of
+        // its further passes -- before thread 0 writes the next unit's; read at the bottom of the unit loop, a wave that lagged behind B2
+        // could have met the newer value when the search for identical records is off and nothing else separates the two)
+        if (unit_ctr && !claim_latched) { next_claim = c2_lds_u32(&claim); claim_latched = true; }
         if (threadIdx.x == 0) pflags[parity ^ 1u][1] = 0;                      // for the next pass / unit
         // the records and the directory entries read ahead are settled HERE, before the compaction's stores go out (they had the drains
         // and the wait for the other waves to land): behind the stores the wait would be for the stores' acknowledgements too
@@ -1380,7 +1385,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         // here: the registers that were to hold the next unit's records still hold this one's)
         if (__builtin_amdgcn_readfirstlane((int)abandon)) break;
         if (un >= nu) break;
-        ui = un; un = unn; unn = unit_ctr ? c2_lds_u32(&claim) : unn + gridDim.x;
+        ui = un; un = unn; unn = unit_ctr ? next_claim : unn + gridDim.x;
         start = start_n; len = len_n;
         o = sn.o; room = sn.room;
         sn = snn;

@@ -89,7 +89,8 @@ template <int MODE, int KT = 0>
 // every wave more hides some of it -- 24.5 ms with four, 20.6 with five.  The Makefile checks that the limit costs NO scratch
 // (check_resources.py): a build of this kernel that spilled hung on the GPU.)
 #ifndef NB_NOFORCE
-__attribute__((amdgpu_waves_per_eu(KT == 31 ? 6 : 5, 8)))
+// (k = 25 and k = 29 need 12 bytes of scratch per lane at six waves -- the build's check refused them --: five there, as the generic build)
+__attribute__((amdgpu_waves_per_eu((KT == 0 || KT == 25 || KT == 29) ? 5 : 6, 8)))
 #endif
 __global__ __launch_bounds__(64 * NB_WAVES) void k_ut_flags_part(mf_index_view ix, ut_arrays A, const uint64_t *__restrict__ part_off, uint32_t np) {
     __shared__ nb_lds S;
@@ -421,6 +422,7 @@ __global__ void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
 static inline unsigned grid_for(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
 extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_threshold, int min_len, mf_seqs **out) {
+    mf_range rng_("mf:unitigs");
     if (!ctx || !t || !out) return mf_set_error("mf_build_unitigs_device: NULL argument");
     *out = nullptr;
     MF_HIP(hipSetDevice(ctx->device));
@@ -477,13 +479,17 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
                 const uint32_t np = 1u << g->part_bits;
                 const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
                 const unsigned grid2 = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16);      // partitions of 353 .. 1408 keys: a workgroup each
-                if (k == 31) {
-                    k_ut_flags_part<1, 31><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
-                    k_ut_flags_part<2, 31><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
-                } else {
-                    k_ut_flags_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
-                    k_ut_flags_part<2><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
+                // k as a compile-time constant for the k values users run (round 5: 31 alone was specialised, and k = 21 -- BASELINE config 4 --
+                // and the CAMI example's 23, Example.md:18-21, paid 2.8 x per k-mer in the generic build); any other k: the generic one
+#define UT_FLAGS_K(KK) case KK: k_ut_flags_part<1, KK><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np); \
+                                k_ut_flags_part<2, KK><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np); break;
+                switch (k) {
+                    UT_FLAGS_K(21) UT_FLAGS_K(23) UT_FLAGS_K(25) UT_FLAGS_K(27) UT_FLAGS_K(29) UT_FLAGS_K(31)
+                    default:
+                        k_ut_flags_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
+                        k_ut_flags_part<2><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
                 }
+#undef UT_FLAGS_K
             } else
             k_ut_flags<<<grid_for(n), 256, 0, st>>>(mf_view(g->index), A);
         }

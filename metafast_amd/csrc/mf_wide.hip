@@ -113,6 +113,7 @@ static unsigned wgrid(uint64_t n, unsigned bs = 256) { return (unsigned)std::min
 
 extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len,
                                     mf_wtable **out) {
+    mf_range rng_("mf:count_wide");
     if (!ctx || !out) return mf_set_error("mf_count_wide_device: NULL argument");
     *out = nullptr;
     if (k < 32 || k > 63) return mf_set_error("mf_count_wide_device: 32 <= k <= 63 (k <= 31: mf_count_device)");

@@ -94,7 +94,14 @@ _SIGS = {
     "mf_features_reads_device": (i32, [vp, vp, vp, vp, u64, u64, i32, i32, vp, vp]),
     "mf_features_reads": (i32, [vp, cp, C.POINTER(cp), i32, i32, i32, cp, cp]),
     "mf_features": (i32, [vp, cp, cp, i32, i32, cp, cp]),
+    "mf_features_device_selected": (i32, [vp, vp, vp, vp, i32, vp, vp]),
+    "mf_features_selected": (i32, [vp, cp, cp, i32, i32, vp, cp, cp]),
+    "mf_features_reads_device_selected": (i32, [vp, vp, vp, vp, u64, u64, i32, vp, i32, vp, vp]),
+    "mf_features_reads_selected": (i32, [vp, cp, C.POINTER(cp), i32, i32, i32, vp, cp, cp]),
     "mf_bray_curtis": (i32, [vp, i32, i32, vp]),
+    "mf_device_count": (i32, []),
+    "mf_ctx_device": (i32, [vp]),
+    "mf_ctx_bind_thread": (i32, [vp]),
     "mf_synth_reads_device": (i32, [vp, u64, i32, u64, u64, i32, u64, vp, vp]),
     "mf_synth_reads_host": (i32, [u64, i32, u64, u64, i32, u64, vp, vp]),
     "mf_synth_reads_device_ex": (i32, [vp, u64, i32, u64, u64, i32, u64, i32, vp, vp]),
@@ -283,29 +290,32 @@ class Context:
         return Comps(self, c)
 
     # ---- A12 ----
-    def features(self, comps, sample_table, threshold=0):
+    def features(self, comps, sample_table, threshold=0, selected=None):
+        """selected: Table of the --selected k-mers (FeaturesCalculatorMain.java:113-116, 193) or None"""
         n = comps.stats()[0]
         vec = np.zeros(n, dtype=np.int64)
         br = np.zeros(n, dtype=np.float64)
-        _check(lib().mf_features_device(self.h, comps.h, sample_table.h, threshold, vec.ctypes.data, br.ctypes.data))
+        _check(lib().mf_features_device_selected(self.h, comps.h, sample_table.h, selected.h if selected is not None else None,
+                                                 threshold, vec.ctypes.data, br.ctypes.data))
         return vec, br
 
-    def features_reads(self, comps, d_bases, d_offsets, n_reads, n_bases, k, threshold=0):
+    def features_reads(self, comps, d_bases, d_offsets, n_reads, n_bases, k, threshold=0, selected=None):
         """features of a sample straight from its reads in HBM (--use-reads-for-calculating-features): 64-bit counts"""
         n = comps.stats()[0]
         vec = np.zeros(n, dtype=np.int64)
         br = np.zeros(n, dtype=np.float64)
-        _check(lib().mf_features_reads_device(self.h, comps.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k,
-                                              threshold, vec.ctypes.data, br.ctypes.data))
+        _check(lib().mf_features_reads_device_selected(self.h, comps.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k,
+                                                       selected.h if selected is not None else None, threshold,
+                                                       vec.ctypes.data, br.ctypes.data))
         return vec, br
 
-    def features_reads_files(self, components_bin, files, k, threshold, vec_path, breadth_path):
-        _check(lib().mf_features_reads(self.h, os.fsencode(components_bin), _cfiles(files), len(files), k, threshold,
-                                       _opt(vec_path), _opt(breadth_path)))
+    def features_reads_files(self, components_bin, files, k, threshold, vec_path, breadth_path, selected=None):
+        _check(lib().mf_features_reads_selected(self.h, os.fsencode(components_bin), _cfiles(files), len(files), k, threshold,
+                                                selected.h if selected is not None else None, _opt(vec_path), _opt(breadth_path)))
 
-    def features_files(self, components_bin, kmers_bin, k, threshold, vec_path, breadth_path):
-        _check(lib().mf_features(self.h, os.fsencode(components_bin), os.fsencode(kmers_bin), k, threshold,
-                                 _opt(vec_path), _opt(breadth_path)))
+    def features_files(self, components_bin, kmers_bin, k, threshold, vec_path, breadth_path, selected=None):
+        _check(lib().mf_features_selected(self.h, os.fsencode(components_bin), os.fsencode(kmers_bin), k, threshold,
+                                          selected.h if selected is not None else None, _opt(vec_path), _opt(breadth_path)))
 
     # ---- synthetic reads ----
     def synth_reads_device(self, seed, sample, first_read, n_reads, read_len, genome_scale_bp, d_bases, d_offsets, sub_per_16384=82):

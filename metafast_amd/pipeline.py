@@ -11,6 +11,7 @@ Bray-Curtis matrix.  torch is used for device memory and torch.distributed only.
 """
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -87,11 +88,14 @@ def _gather_sized(t, sizes, rank, world):
 
 # torch allocations of the exchange helpers go through this hook: run_samples points it at _with_room (the library's arena may hold all
 # of the device in idle regions -- 4 x 380 M reads: 42 MB free when the gathered unitigs wanted 264 MB), anybody else gets a plain call
-_ALLOC = [lambda fn: fn()]
+# -- per THREAD (pipeline.ThreadComm runs several ranks as threads, each with a context of its own that only its thread may touch), and only
+# for the duration of that thread's run_samples call
+_TLS = threading.local()
 
 
 def _alloc(fn):
-    return _ALLOC[0](fn)
+    hook = getattr(_TLS, "alloc", None)
+    return hook(fn) if hook is not None else fn()
 
 
 def gather_sequences(bases, offsets):
@@ -448,6 +452,16 @@ def _with_room(ctx, fn):
 
 
 def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda", timings=None):
+    """_run_samples with the exchange helpers' allocations of THIS thread going through _with_room(ctx, .) while it runs"""
+    prev = getattr(_TLS, "alloc", None)
+    _TLS.alloc = lambda fn: _with_room(ctx, fn)
+    try:
+        return _run_samples(ctx, samples, k=k, b=b, l=l, b1=b1, b2=b2, device=device, timings=timings)
+    finally:
+        _TLS.alloc = prev
+
+
+def _run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda", timings=None):
     """This rank's samples (KmersCounterForManyFilesMain.java:80-108 loops over all libraries: with more samples than GPUs a
     rank takes several, one after the other), joined with the other ranks' for the cutter and the matrix.
     samples: iterable of (d_bases, d_offsets, n_reads, n_bases) -- torch tensors in HBM (ASCII bases, int64 offsets) -- or of
@@ -466,7 +480,6 @@ def run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda"
 
     goods, seqss, hists, n_occ, n_distinct = [], [], [], 0, 0
     comm_stats = dict(collectives=0, bytes_in=0, seconds=0.0)
-    _ALLOC[0] = lambda fn: _with_room(ctx, fn)
     for si, sample in enumerate(samples):
         if si:
             # several samples on this rank: the previous sample's lookup index (3-6 times its table) is not needed again before

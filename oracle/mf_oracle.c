@@ -745,23 +745,33 @@ or_comps *or_comps_load(const char *components_bin) {
 /* ------------------------------------------------------------------ */
 /* FeaturesCalculatorMain.runImpl :97-103 (hm.put(kmer,0)), :137-162 (resetValues +
  * calculatePresenceForKmers -> KmersPresenceWorker :577-588), buildAndPrintVector :169-236 */
+/* buildAndPrintVector :186-206, the per-component loop: with --selected (:55-57, :113-116) only the k-mers with
+ * selected.getWithZero(kmer) > 0 take part -- in the sum, in kmersFound and in kmersCount (0.0 / 0.0 = NaN when none is) */
+static void build_vector(const or_comps *c, const or_table *hm, int threshold, const or_table *selected, int64_t *vec, double *breadth) {
+    for (uint64_t i = 0; i < c->n; i++) {
+        int64_t kmers = 0, cnt = 0, found = 0;
+        for (uint64_t j = 0; j < c->a[i].nk; j++) {
+            if (selected == NULL || get_with_zero(selected, c->a[i].kmers[j]) > 0) {
+                int64_t value = get_with_zero(hm, c->a[i].kmers[j]);
+                if (value > threshold) { kmers += value; found++; }
+                cnt++;
+            }
+        }
+        vec[i] = kmers;
+        if (breadth) breadth[i] = (double)found / (double)cnt;
+    }
+}
 int or_features(const or_comps *c, const or_table *sample, int threshold, int64_t *vec, double *breadth) {
+    return or_features_selected(c, sample, threshold, NULL, vec, breadth);
+}
+int or_features_selected(const or_comps *c, const or_table *sample, int threshold, const or_table *selected, int64_t *vec, double *breadth) {
     or_table *hm = or_table_new();
     for (uint64_t i = 0; i < c->n; i++)
         for (uint64_t j = 0; j < c->a[i].nk; j++) table_put(hm, c->a[i].kmers[j], 0);
     for (uint64_t i = 0; i < sample->cap; i++)                        /* every record of the .kmers.bin */
         if (sample->keys[i] != EMPTY_KEY && or_table_get(hm, sample->keys[i]) != -1)
             table_add_bound(hm, sample->keys[i], sample->vals[i], INT64_MAX);
-    for (uint64_t i = 0; i < c->n; i++) {
-        int64_t kmers = 0, cnt = 0, found = 0;
-        for (uint64_t j = 0; j < c->a[i].nk; j++) {
-            int64_t value = get_with_zero(hm, c->a[i].kmers[j]);
-            if (value > threshold) { kmers += value; found++; }
-            cnt++;
-        }
-        vec[i] = kmers;
-        if (breadth) breadth[i] = (double)found / (double)cnt;
-    }
+    build_vector(c, hm, threshold, selected, vec, breadth);
     or_table_free(hm);
     return 0;
 }
@@ -771,6 +781,10 @@ int or_features(const or_comps *c, const or_table *sample, int threshold, int64_
  * adds 1 for every k-mer of every read that is a component k-mer; then buildAndPrintVector as above */
 int or_features_reads(const or_comps *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k, int threshold,
                       int64_t *vec, double *breadth) {
+    return or_features_reads_selected(c, bases, offsets, n_reads, k, threshold, NULL, vec, breadth);
+}
+int or_features_reads_selected(const or_comps *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k, int threshold,
+                               const or_table *selected, int64_t *vec, double *breadth) {
     if (k < 1 || k > 31) return fail("k must be in [1,31]");
     or_table *hm = or_table_new();
     for (uint64_t i = 0; i < c->n; i++)
@@ -794,16 +808,7 @@ int or_features_reads(const or_comps *c, const uint8_t *bases, const uint64_t *o
             if (or_table_get(hm, sk_canon(km)) != -1) table_add_bound(hm, sk_canon(km), 1, INT64_MAX);
         }
     }
-    for (uint64_t i = 0; i < c->n; i++) {
-        int64_t kmers = 0, cnt = 0, found = 0;
-        for (uint64_t j = 0; j < c->a[i].nk; j++) {
-            int64_t value = get_with_zero(hm, c->a[i].kmers[j]);
-            if (value > threshold) { kmers += value; found++; }
-            cnt++;
-        }
-        vec[i] = kmers;
-        if (breadth) breadth[i] = (double)found / (double)cnt;
-    }
+    build_vector(c, hm, threshold, selected, vec, breadth);
     or_table_free(hm);
     return 0;
 }

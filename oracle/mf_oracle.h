@@ -100,6 +100,13 @@ int       or_features(const or_comps *c, const or_table *sample, int threshold,
 int       or_features_reads(const or_comps *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
                             int k, int threshold, int64_t *vec, double *breadth);
 
+/* --selected (FeaturesCalculatorMain.java:55-57, 113-116, 193-203): `selected` = the table IOUtils.loadKmers(selectedKmers, 0, ..)
+ * gives (or_load_kmers with freq_threshold 0); NULL = no selection */
+int       or_features_selected(const or_comps *c, const or_table *sample, int threshold, const or_table *selected,
+                               int64_t *vec, double *breadth);
+int       or_features_reads_selected(const or_comps *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads,
+                                     int k, int threshold, const or_table *selected, int64_t *vec, double *breadth);
+
 /* ---- A13 Bray-Curtis (src/tools/DistanceMatrixCalculatorMain.java:140-152) ---- */
 int       or_bray_curtis(const int64_t *vecs, int n_samples, int n_comp, double *out);
 /* NO-REFERENCE EXTENSION (the reference rejects k > 31): canonical counts of 2k-bit k-mers, 32 <= k <= 63, ascending

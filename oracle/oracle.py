@@ -70,6 +70,8 @@ def lib():
     sig("or_comps_load", vp, cp)
     sig("or_features", i32, vp, vp, i32, vp, vp)
     sig("or_features_reads", i32, vp, vp, vp, u64, i32, i32, vp, vp)
+    sig("or_features_selected", i32, vp, vp, i32, vp, vp, vp)
+    sig("or_features_reads_selected", i32, vp, vp, vp, u64, i32, i32, vp, vp, vp)
     sig("or_bray_curtis", i32, vp, i32, i32, vp)
     sig("or_revcomp", u64, u64, i32)
     sig("or_canonical", u64, u64, i32)
@@ -241,23 +243,25 @@ class Comps:
         _check(lib().or_comps_write(self.h, os.fsencode(components_bin),
                                     os.fsencode(stat_txt) if stat_txt else None))
 
-    def features(self, sample_table, threshold=0):
+    def features(self, sample_table, threshold=0, selected=None):
+        """selected: Table of the --selected k-mers (FeaturesCalculatorMain.java:113-116) or None"""
         n = len(self)
         vec = np.zeros(n, dtype=np.int64)
         br = np.zeros(n, dtype=np.float64)
-        _check(lib().or_features(self.h, sample_table.h, threshold, vec.ctypes.data, br.ctypes.data))
+        _check(lib().or_features_selected(self.h, sample_table.h, threshold, selected.h if selected is not None else None,
+                                          vec.ctypes.data, br.ctypes.data))
         return vec, br
 
 
-def features_from_reads(comps, bases, offsets, k, threshold=0):
+def features_from_reads(comps, bases, offsets, k, threshold=0, selected=None):
     """FeaturesCalculatorMain --reads branch: occurrences of the component k-mers in the reads (long counts)"""
     bases = np.ascontiguousarray(bases, dtype=np.uint8)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
     n = len(comps)
     vec = np.zeros(n, dtype=np.int64)
     br = np.zeros(n, dtype=np.float64)
-    _check(lib().or_features_reads(comps.h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, k, threshold,
-                                   vec.ctypes.data, br.ctypes.data))
+    _check(lib().or_features_reads_selected(comps.h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, k, threshold,
+                                            selected.h if selected is not None else None, vec.ctypes.data, br.ctypes.data))
     return vec, br
 
 

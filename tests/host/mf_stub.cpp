@@ -24,5 +24,9 @@ int mf_build_unitigs(mf_ctx *, mf_table *, int, int, int, const char *, const ch
 int mf_cut_components(mf_ctx *, mf_table *, int, int, int, const char *, const char *, uint64_t *) { return MF_ERR; }
 int mf_features(mf_ctx *, const char *, const char *, int, int, const char *, const char *) { return MF_ERR; }
 int mf_features_reads(mf_ctx *, const char *, const char *const *, int, int, int, const char *, const char *) { return MF_ERR; }
+int mf_features_selected(mf_ctx *, const char *, const char *, int, int, mf_table *, const char *, const char *) { return MF_ERR; }
+int mf_features_reads_selected(mf_ctx *, const char *, const char *const *, int, int, int, mf_table *, const char *, const char *) { return MF_ERR; }
+int mf_device_count(void) { return 2; }             /* (two entries: the driver's per-device workers run, and stop at mf_ctx_create) */
+int mf_ctx_bind_thread(mf_ctx *) { return MF_ERR; }
 int mf_bray_curtis(const int64_t *, int, int, double *) { return MF_ERR; }
 }

@@ -38,6 +38,21 @@ def test_scratch_in_a_lookup_kernel_fails_the_build(tmp_path):
     assert other.returncode == 0
 
 
+def test_the_guard_fails_closed(tmp_path):
+    """a missing ScratchSize field, or a translation unit that should hold a lookup kernel and reports none, is a failed
+    check -- not a passed one"""
+    rep = [ln for ln in _report("_Z15k_ut_flags_partILi1ELi31EEv13mf_index_view9ut_arraysPKmj", 0) if "ScratchSize" not in ln]
+    r = _run(rep, tmp_path)
+    assert r.returncode == 1 and "no 'ScratchSize [bytes/lane]' remark" in r.stderr
+    src = tmp_path / "mf_unitig.err"                  # (the unit is recognised by its file name)
+    src.write_text("\n".join(_report("_Z11k_ut_linksPKm", 0)) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(CSRC, "check_resources.py"), str(src), str(tmp_path / "o.res")], capture_output=True, text=True)
+    assert r.returncode == 1 and "k_ut_flags_part" in r.stderr
+    src.write_text("\n".join(_report("_Z15k_ut_flags_partILi1ELi31EEv13mf_index_view9ut_arraysPKmj", 0)) + "\n")
+    r = subprocess.run([sys.executable, os.path.join(CSRC, "check_resources.py"), str(src), str(tmp_path / "o.res")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_the_library_in_the_tree_was_built_without_scratch_in_them():
     reports = glob.glob(os.path.join(CSRC, "build", "*.res"))
     if not reports:                                   # (a tree whose library came prebuilt: nothing to look at)

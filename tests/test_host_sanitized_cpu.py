@@ -43,7 +43,7 @@ def binaries():
     os.makedirs(BUILD, exist_ok=True)
     ph, cli = os.path.join(BUILD, "parse_harness"), os.path.join(BUILD, "metafast_san")
     jobs = [(ph, [os.path.join(HOST, "parse_harness.cpp")], ["-lz", "-ldl", "-lpthread"], [os.path.join(ROOT, "metafast_amd", "csrc", "mf_parse.h")]),
-            (cli, [os.path.join(ROOT, "metafast_amd", "cli", "metafast_main.cpp"), os.path.join(HOST, "mf_stub.cpp")], [], [])]
+            (cli, [os.path.join(ROOT, "metafast_amd", "cli", "metafast_main.cpp"), os.path.join(HOST, "mf_stub.cpp")], ["-lpthread"], [])]
     for out, srcs, libs, deps in jobs:
         newest = max(os.path.getmtime(f) for f in srcs + deps)
         if os.path.exists(out) and os.path.getmtime(out) >= newest:
@@ -240,7 +240,9 @@ def test_components_and_kmers_files(binaries, tmp_path):
 def test_driver_options_properties_and_matrices(binaries, tmp_path):
     _, cli = binaries
     rng = np.random.default_rng(14)
-    golden = os.path.join(ROOT, "tests", "golden", "ref_test_data", "meta_test_matrix.txt")
+    # (a copy: heatmap-maker writes <input>_renumbered.txt NEXT TO its input by default, and the golden directory is tracked)
+    golden = str(tmp_path / "meta_test_matrix.txt")
+    shutil.copyfile(os.path.join(ROOT, "tests", "golden", "ref_test_data", "meta_test_matrix.txt"), golden)
     wd = tmp_path / "hm"
     assert _run([cli, "-t", "heatmap-maker", "-i", golden, "-w", str(wd)]).returncode == 0
     text = open(golden, "rb").read()
@@ -261,6 +263,9 @@ def test_driver_options_properties_and_matrices(binaries, tmp_path):
     # command lines: unknown tools and options, options without their value, repeated and empty ones; GPU steps stop at the stub with exit 1
     for args in (["-t"], ["-t", "nonsense"], ["-k"], ["-k", "x", "-i"], ["-i", "a.fa", "-i", "b.fa", "-k", "31", "-w", str(tmp_path / "g")], ["--work-dir"], ["-t", "view"],
                  ["-t", "view", "-k", "99", "--kmers-file", "/nonexistent"], ["-h"], ["--help-all"], ["-t", "kmer-counter", "-k", "0", "-i", golden, "-w", str(tmp_path / "g2")],
-                 ["-m", "4G", "-ea", "-Xmx1g", "--tools"], ["", "", ""], ["-w", str(tmp_path / "g3"), "-s", "nonsense", "-i", golden], ["-t", "dist-matrix-calculator", "--features", golden, "-w", str(tmp_path / "g4")]):
+                 ["-m", "4G", "-ea", "-Xmx1g", "--tools"], ["", "", ""], ["-w", str(tmp_path / "g3"), "-s", "nonsense", "-i", golden], ["-t", "dist-matrix-calculator", "--features", golden, "-w", str(tmp_path / "g4")],
+                 ["-i", "a.fa", "b.fa", "c.fa", "--devices", "0,1,0", "-w", str(tmp_path / "g5")], ["-i", "a.fa", "--devices", "0,,1", "-w", str(tmp_path / "g6")],
+                 ["-i", "a.fa", "--devices", "x", "-w", str(tmp_path / "g7")], ["-i", "a.fa", "--devices", "-w", str(tmp_path / "g8")],
+                 ["-t", "features-calculator", "-k", "31", "-cm", golden, "-ka", golden, "--selected", golden, "--devices", "0,1", "-w", str(tmp_path / "g9")]):
         r = subprocess.run([cli, *args], capture_output=True, text=True, errors="replace", env=ENV, timeout=60, input="", cwd=str(tmp_path))
         assert r.returncode in (0, 1), (args, r.returncode, (r.stdout + r.stderr)[-2000:])
