@@ -43,6 +43,7 @@ typedef struct mf_table mf_table;  /* canonical k-mer -> saturating count (BigLo
 typedef struct mf_seqs  mf_seqs;   /* unitigs with weights (Deque<Sequence>)                */
 typedef struct mf_comps mf_comps;  /* connected components (List<ConnectedComponent>)       */
 typedef struct mf_dcc   mf_dcc;    /* one rank's part of the distributed component cutter   */
+typedef struct mf_reads mf_reads;  /* the reads of a list of files, in HBM (NamedSource<Dna>) */
 
 const char *mf_last_error(void);
 const char *mf_version(void);
@@ -96,6 +97,16 @@ int mf_count_reads(mf_ctx *ctx, const char *const *files, int nfiles, int k, int
  * k-mers before the cut (the "k-mers found" log line, KmersCounterMain.java:101-103). */
 int mf_count_reads_above(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, int threshold,
                          mf_table **out, uint64_t *n_distinct_all);
+/* The readers alone: ReadersUtils.readDnaLazy (itmo!/io/ReadersUtils.java:81-102) over a list of files -- FastaReader.java:53-104,
+ * FastqReader.java:53-115 + FastaReaderFromXQSource.java:66-70, their .gz / .bz2 forms, BinqReader.java -- into the (bases, offsets)
+ * layout mf_count_device takes (upper-case A / C / G / T; reads with N or a phred-0 base are not there).  Plain FASTA / FASTQ files
+ * are parsed on the device (option "device_parse", mf_dparse.hip); the files that parser is not sure about, and every error, go
+ * through the host readers. */
+int  mf_reads_load(mf_ctx *ctx, const char *const *files, int nfiles, mf_reads **out);
+void mf_reads_destroy(mf_reads *r);
+int  mf_reads_stats(const mf_reads *r, uint64_t *n_reads, uint64_t *n_bases);
+int  mf_reads_device_view(const mf_reads *r, const void **d_bases, const void **d_offsets);
+int  mf_reads_export(const mf_reads *r, uint8_t *bases, uint64_t *offsets);      /* bases[n_bases], offsets[n_reads + 1] */
 /* Same, for reads already resident in HBM: d_bases = concatenated ASCII bases (ACGT, either case,
  * no N), d_offsets = uint64[n_reads+1] with offsets[0]=0, offsets[n_reads]=n_bases.  d_bases must
  * be 16-byte aligned and readable up to the next multiple of 16 bytes.  This is the device half of

@@ -82,6 +82,8 @@ struct mf_ctx {
     int64_t opt_skm_unit_records = 2000;   // ... and at most this many super-k-mer records (the identical-record search of k_skm_count covers 2048)
     double last_pilot_rho = -1.0;
     double last_l1_per_occ = 0; int last_l1_k = 0;   // records (with padding) of the last run's level 1 per k-mer occurrence, for k = last_l1_k: the next sample's buffers are planned with it  // what the last pilot measured (diagnostics; < 0: none ran)
+    int64_t opt_device_parse = 1;  // plain FASTA / FASTQ files are parsed on the device (mf_dparse.hip); files it is not sure about go to the host readers
+    int64_t opt_device_parse_min = 1 << 20;   // ... from this size on (bytes): a small file is not worth the kernels' launches
     int64_t opt_host_pinned = 0;   // staging buffers of the file readers / writers: 1 = hipHostMalloc (0.16 - 0.29 s per GB to get, 0.1 s to give back), 0 = plain host memory (copies to and from it run at the same 56 GB/s on this platform: tools/pin_alloc.hip)
     int64_t opt_file_cache_gb = 0; // > 0: tables / components written to files stay in HBM (up to this many GB) and are handed out when the same file is loaded again
     int64_t opt_wide_passes = 0;   // mf_count_wide_device: passes over the reads, each for one prefix class of the canonical k-mers (0 = as many as the memory asks for; tests force a number)
@@ -206,6 +208,12 @@ struct mf_seqs {
     uint64_t *d_startkey = nullptr;  // oriented start k-mer per sequence (for deterministic ordering)
     size_t bases_bytes = 0, offsets_bytes = 0, w_bytes = 0, sk_bytes = 0;
 };
+struct mf_reads {                 // the reads of a list of files, as the readers hand them on (mf_reads_load)
+    mf_ctx *ctx = nullptr;
+    uint64_t n = 0, n_bases = 0;
+    uint8_t *d_bases = nullptr; uint64_t *d_offsets = nullptr;
+    size_t bases_bytes = 0, offsets_bytes = 0;
+};
 struct mf_comps {
     mf_ctx *ctx = nullptr;
     int refs = 1;                 // (as mf_table::refs)
@@ -231,6 +239,8 @@ struct mf_file_entry {
     size_t bytes = 0; uint64_t stamp = 0;
 };
 void mf_file_cache_clear(mf_ctx *ctx);
+int mf_ensure_pin_pool(mf_ctx *ctx, size_t want);
+int mf_dparse_file(mf_ctx *ctx, const char *path, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases);
 int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, mf_index *out,
                    size_t *bytes);
 int mf_table_ensure_index(mf_table *t);

@@ -126,7 +126,6 @@ static mf_file_entry *file_cache_get(mf_ctx *ctx, const char *path) {
 struct sr_piece { uint64_t dev_off = 0, n_bases = 0; std::vector<uint64_t> offsets; };
 struct sr_file { mf_buf<uint8_t> dev; std::vector<sr_piece> pieces; };
 // first record start at a buffer position >= from (the byte before it is a '\n', or it is the file's first byte), or n
-static int ensure_pin_pool(mf_ctx *ctx, size_t want);
 static int stream_file_to_device(mf_ctx *ctx, const char *path, int fmt, sr_file &out) {
     int fd = open(path, O_RDONLY);
     if (fd < 0) return mf_set_error("can't open '%s'", path);
@@ -150,7 +149,7 @@ static int stream_file_to_device(mf_ctx *ctx, const char *path, int fmt, sr_file
         io_timer tm("stream reader set-up");
         if (ctx->pin_pool_bytes < (size_t)2 * W * chunk) {
             const size_t want = (size_t)2 * std::min<size_t>((size_t)std::max(ctx->host_threads, 1), 64) * chunk;
-            if (ensure_pin_pool(ctx, want) != MF_OK) { close(fd); return 1; }
+            if (mf_ensure_pin_pool(ctx, want) != MF_OK) { close(fd); return 1; }
             tm.lap("staging pool");
         }
         if (out.dev.alloc(ctx, np * chunk) != MF_OK) { close(fd); return 1; }
@@ -216,6 +215,10 @@ static int stream_file_to_device(mf_ctx *ctx, const char *path, int fmt, sr_file
     return 0;
 }
 
+__global__ void k_offsets_rebase(const uint64_t *__restrict__ in, uint64_t n, uint64_t add, uint64_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] + add;
+}
 // files -> (bases, offsets) in HBM (the layout mf_count_device takes); all files of the call form ONE read set
 static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfiles, mf_buf<uint8_t> &db, mf_buf<uint64_t> &doff,
                                 uint64_t *n_reads, uint64_t *n_bases, double *t_parse, double *t_h2d) {
@@ -223,8 +226,12 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
     const double t0 = now();
     MF_HIP(hipSetDevice(ctx->device));
     // every file becomes a list of pieces: bases either already in HBM (streaming reader) or still on the host
-    struct piece { const uint8_t *dev = nullptr; const uint8_t *host = nullptr; uint64_t n_bases = 0; const std::vector<uint64_t> *offsets = nullptr; };
+    // (dev_offsets: a file the DEVICE parsed, mf_dparse.hip -- its offsets are in HBM too; n_reads says how many)
+    struct piece { const uint8_t *dev = nullptr; const uint8_t *host = nullptr; uint64_t n_bases = 0; const std::vector<uint64_t> *offsets = nullptr;
+                   const uint64_t *dev_offsets = nullptr; uint64_t n_reads = 0; };
     std::vector<piece> pieces;
+    struct dp_file { mf_buf<uint8_t> b; mf_buf<uint64_t> o; };
+    std::vector<std::unique_ptr<dp_file>> dparsed;
     std::vector<std::unique_ptr<sr_file>> streamed;
     std::vector<std::unique_ptr<std::vector<read_batch>>> parsed;
     for (int i = 0; i < nfiles; i++) {
@@ -233,6 +240,20 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
         if (ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq")) fmt = 2;
         else if (ends_with_nocase(p, ".fasta") || ends_with_nocase(p, ".fa") || ends_with_nocase(p, ".fn") || ends_with_nocase(p, ".fna")) fmt = 1;
         struct stat st;
+        if (fmt && ctx->opt_device_parse && stat(files[i], &st) == 0 && (size_t)st.st_size >= (size_t)ctx->opt_device_parse_min) {
+            auto df = std::make_unique<dp_file>();
+            uint64_t r = 0, b = 0;
+            const int rc = mf_dparse_file(ctx, files[i], fmt, df->b, df->o, &r, &b);
+            if (rc < 0) return rc;
+            if (rc == 0) {
+                if (nfiles == 1) { db.swap(df->b); doff.swap(df->o); *n_reads = r; *n_bases = b; if (t_parse) *t_parse = now() - t0; if (t_h2d) *t_h2d = 0; return MF_OK; }
+                piece P; P.dev = df->b.p; P.n_bases = b; P.dev_offsets = df->o.p; P.n_reads = r;
+                pieces.push_back(P);
+                dparsed.push_back(std::move(df));
+                continue;
+            }
+            // (1: a file the device parser is not sure about -- the host readers below take it, with the reference's error messages)
+        }
         if (fmt && ctx->opt_stream_reader && stat(files[i], &st) == 0 && (size_t)st.st_size >= (size_t)std::max<int64_t>(ctx->opt_sr_piece, 4096) / 2) {
             auto sf = std::make_unique<sr_file>();
             const int rc = stream_file_to_device(ctx, files[i], fmt, *sf);
@@ -252,7 +273,7 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
     // pieces -> one (bases, offsets) pair in HBM: bases piece by piece, offsets rebased on the host
     uint64_t nb = 0, nr = 0;
     std::vector<uint64_t> pb(pieces.size()), pr(pieces.size());
-    for (size_t t = 0; t < pieces.size(); t++) { pb[t] = nb; pr[t] = nr; nb += pieces[t].n_bases; nr += pieces[t].offsets->size() - 1; }
+    for (size_t t = 0; t < pieces.size(); t++) { pb[t] = nb; pr[t] = nr; nb += pieces[t].n_bases; nr += pieces[t].offsets ? pieces[t].offsets->size() - 1 : pieces[t].n_reads; }
     // (not a std::vector: value-initialising 160 MB of offsets for 20 M reads on one thread cost 35 ms of a 0.14 s load; the threads below
     // touch the pages as they fill them)
     raw_file offsets_buf;
@@ -265,6 +286,7 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
         for (int w = 0; w < T; w++)
             th.emplace_back([&, w]() {
                 for (size_t t = (size_t)w; t < pieces.size(); t += (size_t)T) {
+                    if (!pieces[t].offsets) continue;                             // (offsets in HBM: rebased there, below)
                     const std::vector<uint64_t> &o = *pieces[t].offsets;
                     for (size_t i = 1; i < o.size(); i++) offsets[pr[t] + i] = o[i] + pb[t];
                 }
@@ -277,10 +299,55 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
             MF_HIP(hipMemcpyAsync(db.p + pb[t], pieces[t].dev ? (const void *)pieces[t].dev : (const void *)pieces[t].host, pieces[t].n_bases,
                                   pieces[t].dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
     MF_HIP(hipMemcpyAsync(doff.p, offsets, (nr + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+    for (size_t t = 0; t < pieces.size(); t++)
+        if (pieces[t].dev_offsets && pieces[t].n_reads)
+            k_offsets_rebase<<<(unsigned)((pieces[t].n_reads + 255) / 256), 256, 0, ctx->stream>>>(pieces[t].dev_offsets + 1, pieces[t].n_reads, pb[t], doff.p + pr[t] + 1);
     MF_HIP(hipStreamSynchronize(ctx->stream));
     *n_reads = nr; *n_bases = nb;
     if (t_parse) *t_parse = t1 - t0;
     if (t_h2d) *t_h2d = now() - t1;
+    return MF_OK;
+}
+
+// ReadersUtils.readDnaLazy for a list of files (itmo!/io/ReadersUtils.java:81-102): the reads the readers hand on, in HBM
+extern "C" int mf_reads_load(mf_ctx *ctx, const char *const *files, int nfiles, mf_reads **out) {
+    mf_range rng_("mf:reads_load(files)");
+    if (!ctx || !out || (nfiles && !files)) return mf_set_error("mf_reads_load: NULL argument");
+    *out = nullptr;
+    mf_buf<uint8_t> db; mf_buf<uint64_t> doff;
+    uint64_t nr = 0, nb = 0;
+    MF_TRY(load_reads_to_device(ctx, files, nfiles, db, doff, &nr, &nb, nullptr, nullptr));
+    mf_reads *R = new mf_reads();
+    R->ctx = ctx; R->n = nr; R->n_bases = nb;
+    R->bases_bytes = db.bytes(); R->offsets_bytes = doff.bytes();
+    R->d_bases = db.take(); R->d_offsets = doff.take();
+    *out = R;
+    return MF_OK;
+}
+extern "C" void mf_reads_destroy(mf_reads *r) {
+    if (!r) return;
+    if (r->d_bases) mf_release(r->ctx, r->d_bases, r->bases_bytes);
+    if (r->d_offsets) mf_release(r->ctx, r->d_offsets, r->offsets_bytes);
+    delete r;
+}
+extern "C" int mf_reads_stats(const mf_reads *r, uint64_t *n_reads, uint64_t *n_bases) {
+    if (!r) return mf_set_error("reads handle is NULL");
+    if (n_reads) *n_reads = r->n;
+    if (n_bases) *n_bases = r->n_bases;
+    return MF_OK;
+}
+extern "C" int mf_reads_device_view(const mf_reads *r, const void **d_bases, const void **d_offsets) {
+    if (!r) return mf_set_error("reads handle is NULL");
+    if (d_bases) *d_bases = r->d_bases;
+    if (d_offsets) *d_offsets = r->d_offsets;
+    return MF_OK;
+}
+extern "C" int mf_reads_export(const mf_reads *r, uint8_t *bases, uint64_t *offsets) {
+    if (!r) return mf_set_error("reads handle is NULL");
+    MF_HIP(hipSetDevice(r->ctx->device));
+    if (bases && r->n_bases) MF_HIP(hipMemcpyAsync(bases, r->d_bases, r->n_bases, hipMemcpyDeviceToHost, r->ctx->stream));
+    if (offsets) MF_HIP(hipMemcpyAsync(offsets, r->d_offsets, (r->n + 1) * 8, hipMemcpyDeviceToHost, r->ctx->stream));
+    MF_HIP(hipStreamSynchronize(r->ctx->stream));
     return MF_OK;
 }
 
@@ -369,7 +436,7 @@ int mf_table_select_sorted(const mf_table *t, int threshold, mf_buf<uint64_t> &s
 // 8 per component member, FASTA text): hundreds of megabytes per sample that used to go through one pageable buffer and one
 // fwrite (3.5 GB/s: 0.2 s per .kmers.bin of a 20 M-read sample).  Here: slots of the context's pinned pool, a D2H copy per slot,
 // and a pwrite per slot on a thread of its own while the next slot's copy runs (the page cache takes ~2 GB/s per thread).
-static int ensure_pin_pool(mf_ctx *ctx, size_t want) {
+int mf_ensure_pin_pool(mf_ctx *ctx, size_t want) {
     if (ctx->pin_pool_bytes >= want) return MF_OK;
     if (ctx->pin_pool) { if (ctx->pin_pool_pinned) hipHostFree(ctx->pin_pool); else free(ctx->pin_pool); ctx->pin_pool = nullptr; ctx->pin_pool_bytes = 0; }
     if (ctx->opt_host_pinned) {
@@ -391,7 +458,7 @@ static int pwrite_all(int fd, const void *p, size_t n, off_t off) {
 static int device_to_file(mf_ctx *ctx, const void *d_src, size_t bytes, int fd, off_t file_off, const char *path) {
     if (!bytes) return MF_OK;
     const size_t SLOT = (size_t)16 << 20;
-    MF_TRY(ensure_pin_pool(ctx, 8 * SLOT));
+    MF_TRY(mf_ensure_pin_pool(ctx, 8 * SLOT));
     const size_t nslot = std::min<size_t>(ctx->pin_pool_bytes / SLOT, 24);
     std::vector<std::thread> wr(nslot);
     std::atomic<int> bad{0};

@@ -99,6 +99,11 @@ _SIGS = {
     "mf_features_reads_device_selected": (i32, [vp, vp, vp, vp, u64, u64, i32, vp, i32, vp, vp]),
     "mf_features_reads_selected": (i32, [vp, cp, C.POINTER(cp), i32, i32, i32, vp, cp, cp]),
     "mf_bray_curtis": (i32, [vp, i32, i32, vp]),
+    "mf_reads_load": (i32, [vp, C.POINTER(cp), i32, pvp]),
+    "mf_reads_destroy": (None, [vp]),
+    "mf_reads_stats": (i32, [vp, pu64, pu64]),
+    "mf_reads_device_view": (i32, [vp, pvp, pvp]),
+    "mf_reads_export": (i32, [vp, vp, vp]),
     "mf_device_count": (i32, []),
     "mf_ctx_device": (i32, [vp]),
     "mf_ctx_bind_thread": (i32, [vp]),
@@ -207,6 +212,20 @@ class Context:
         return out
 
     # ---- A1-A4 ----
+    def load_reads(self, files):
+        """the readers alone (ReadersUtils.readDnaLazy): -> (bases uint8[], offsets uint64[n + 1]) on the host"""
+        h = C.c_void_p()
+        _check(lib().mf_reads_load(self.h, _cfiles(files), len(files), C.byref(h)))
+        try:
+            n, nb = C.c_uint64(), C.c_uint64()
+            _check(lib().mf_reads_stats(h, C.byref(n), C.byref(nb)))
+            bases = np.empty(nb.value, dtype=np.uint8)
+            off = np.empty(n.value + 1, dtype=np.uint64)
+            _check(lib().mf_reads_export(h, bases.ctypes.data, off.ctypes.data))
+            return bases, off
+        finally:
+            lib().mf_reads_destroy(h)
+
     def count_reads(self, files, k, min_read_len=0):
         """IOUtils.loadReads (src/io/IOUtils.java:772-803)"""
         t = C.c_void_p()

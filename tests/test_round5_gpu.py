@@ -37,9 +37,9 @@ def _result_files(wd):
         for p in sorted(d.iterdir()):
             if p.is_file() and p.name not in ("in.properties", "out.properties", "SUCCESS"):
                 out[sub + "/" + p.name] = p.read_bytes()
-    mats = sorted((wd / "matrices").glob("dist_matrix_*_original_order.txt"))
-    assert len(mats) == 1
-    out["matrix"] = mats[0].read_bytes()
+    mats = sorted((wd / "matrices").glob("dist_matrix_*_original_order.txt"))       # (one per run of the step, named by its start time)
+    assert len(mats) >= 1
+    out["matrix"] = mats[-1].read_bytes()
     return out
 
 
@@ -83,6 +83,7 @@ def _devices_case(oracle, tmp_path, devices):
     # --continue from features-calculator on the many-context run: the workers meet contexts made for nothing before (fresh process)
     r = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", str(k), "-b", str(b), "-l", str(l), "-b1", str(b1), "-b2", str(b2), "-i", *files, "-w", str(many),
                         "--devices", devices, "-c", "-s", "features-calculator"], capture_output=True, text=True, timeout=900, cwd=tmp_path)
+
     assert r.returncode == 0, r.stderr[-3000:]
     m2 = _result_files(many)
     for name in a:
@@ -103,8 +104,9 @@ def test_cli_two_gpus(oracle, tmp_path):
     _devices_case(oracle, tmp_path, "0,1")
 
 
-def test_cli_default_is_every_visible_device(tmp_path):
+def test_cli_default_is_every_visible_device(gpu_ctx, tmp_path):
     """without --device(s) the driver takes every device the process sees (mf_device_count)"""
+    # (gpu_ctx first: torch must have initialised ITS HIP runtime before the library initialises the system's -- the second one to start finds no device)
     import torch
     from metafast_amd import lib as L
     assert L.lib().mf_device_count() == torch.cuda.device_count()
@@ -248,3 +250,138 @@ def test_pipeline_against_the_oracle_other_k(gpu_ctx, oracle, tmp_path, k):
     """k = 25, 27, 29: compile-time-k neighbour kernels (25 and 29 at five waves per SIMD, the others at six); 22: the generic build"""
     from test_shapes_gpu import _samples_against_the_oracle
     _samples_against_the_oracle(gpu_ctx, oracle, tmp_path, S=2, k=k, b=1, l=100, b1=500, b2=5000, n=600_000, min_thr=2)
+
+
+# ---- the device parser (mf_dparse.hip) against the oracle's readers ----
+def _fa_text(rng, n_rec, wrap, crlf=False, n_rate=0.0, lower=False, iupac=False, comments=False, lead_seq=False, empty_lines=False, no_final_nl=False):
+    nl = b"\r\n" if crlf else b"\n"
+    al = b"ACGT" + (b"acgt" if lower else b"") + (b"RYMKSWHBVDrymkswhbvd" if iupac else b"")
+    out = []
+    if lead_seq:
+        out.append(bytes(np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, size=37)]) + nl)
+    for i in range(n_rec):
+        if comments and i % 7 == 3:
+            out.append(b";a comment > with ; marks" + nl)
+        out.append(b">read_%d some description N n . @ +" % i + nl)
+        ln = int(rng.integers(0, 260))
+        s = np.frombuffer(al, dtype=np.uint8)[rng.integers(0, len(al), size=ln)].copy()
+        if n_rate and rng.random() < n_rate and ln:
+            s[int(rng.integers(0, ln))] = ord("N") if rng.random() < 0.5 else ord("n")
+        s = s.tobytes()
+        w = wrap if wrap else max(ln, 1)
+        for j in range(0, max(ln, 1), w):
+            out.append(s[j:j + w] + nl)
+        if empty_lines and i % 11 == 5:
+            out.append(nl)
+    t = b"".join(out)
+    if no_final_nl and t.endswith(nl):
+        t = t[:-len(nl)]
+    return t
+
+
+def _fq_text(rng, n_rec, crlf=False, n_rate=0.0, phred0_rate=0.0, qoff=33, odd_headers=False, no_final_nl=False, lower=False):
+    nl = b"\r\n" if crlf else b"\n"
+    out = []
+    for i in range(n_rec):
+        ln = int(rng.integers(1, 260))
+        al = b"ACGTacgt" if lower else b"ACGT"
+        s = np.frombuffer(al, dtype=np.uint8)[rng.integers(0, len(al), size=ln)].copy()
+        q = rng.integers(qoff + 1, min(qoff + 42, 127), size=ln).astype(np.uint8)
+        if n_rate and rng.random() < n_rate:
+            s[int(rng.integers(0, ln))] = int(rng.choice([ord("N"), ord("n"), ord(".")]))
+        if phred0_rate and rng.random() < phred0_rate:
+            q[int(rng.integers(0, ln))] = qoff
+        if odd_headers and i % 5 == 2:
+            q[0] = ord("@") if qoff < 64 else q[0]                      # a quality line that starts with '@'
+        out.append((b"+odd%d" if odd_headers and i % 9 == 4 else b"@r%d") % i + nl + s.tobytes() + nl + (b"@again" if odd_headers and i % 4 == 1 else b"+") + nl + q.tobytes() + nl)
+    t = b"".join(out)
+    if no_final_nl:
+        t = t[:-len(nl)]
+    return t
+
+
+def _same_reads(ctx, oracle, path):
+    """device parser == host parser == the oracle's reader, byte for byte; -> whether the device parser took the file"""
+    ob, oo = oracle.read_file(str(path))
+    ctx.set_option("device_parse", 0)
+    hb, ho = ctx.load_reads([str(path)])
+    ctx.set_option("device_parse", 1)
+    ctx.reset_timers()
+    db, do = ctx.load_reads([str(path)])
+    took = ctx.kernel_time("k_dparse")[0] > 0
+    assert np.array_equal(ho, oo) and np.array_equal(hb, ob), "host parser != oracle"
+    assert np.array_equal(do, oo), (path, len(do), len(oo), np.flatnonzero(do[:min(len(do), len(oo))] != oo[:min(len(do), len(oo))])[:5])
+    assert np.array_equal(db, ob), (path, np.flatnonzero(db != ob)[:5])
+    return took
+
+
+def test_device_parser_fasta_and_fastq(gpu_ctx, oracle, tmp_path):
+    rng = np.random.default_rng(21)
+    gpu_ctx.set_option("profile", 1)
+    gpu_ctx.set_option("device_parse_min_bytes", 1)
+    try:
+        cases = []
+        for i, kw in enumerate([dict(wrap=0), dict(wrap=70), dict(wrap=60, crlf=True), dict(wrap=0, n_rate=0.05), dict(wrap=80, n_rate=0.2, lower=True, iupac=True),
+                                dict(wrap=0, comments=True, lead_seq=True), dict(wrap=70, empty_lines=True, comments=True), dict(wrap=0, no_final_nl=True),
+                                dict(wrap=0, crlf=True, no_final_nl=True, n_rate=0.1), dict(wrap=13, lead_seq=True, n_rate=0.3)]):
+            for n_rec in (1, 3, 40, 5000):
+                p = tmp_path / ("a%d_%d.fa" % (i, n_rec))
+                p.write_bytes(_fa_text(rng, n_rec, **kw))
+                cases.append(p)
+        for i, kw in enumerate([dict(), dict(crlf=True), dict(n_rate=0.1), dict(phred0_rate=0.1), dict(qoff=64, phred0_rate=0.05, n_rate=0.05), dict(odd_headers=True),
+                                dict(no_final_nl=True), dict(crlf=True, no_final_nl=True, n_rate=0.2), dict(lower=True, n_rate=0.02)]):
+            for n_rec in (1, 2, 50, 5000):
+                p = tmp_path / ("q%d_%d.fq" % (i, n_rec))
+                p.write_bytes(_fq_text(rng, n_rec, **kw))
+                cases.append(p)
+        took = sum(_same_reads(gpu_ctx, oracle, p) for p in cases)
+        assert took == len(cases), (took, len(cases))                        # (every one of these is a file the device parser is sure about)
+        # chunk borders: records, header lines and CRLF pairs that straddle the 4 KB tiles and the 256 KB chunks
+        big = tmp_path / "big.fa"
+        big.write_bytes(_fa_text(rng, 40000, 0, n_rate=0.01) + _fa_text(rng, 20000, 61, crlf=True, n_rate=0.02, comments=True))
+        assert _same_reads(gpu_ctx, oracle, big)
+        bigq = tmp_path / "big.fastq"
+        bigq.write_bytes(_fq_text(rng, 30000, n_rate=0.02, phred0_rate=0.02) )
+        assert _same_reads(gpu_ctx, oracle, bigq)
+        # two files in one call (a paired library): the device pieces are joined in HBM
+        ob1, oo1 = oracle.read_file(str(big)); ob2, oo2 = oracle.read_file(str(bigq))
+        b, o = gpu_ctx.load_reads([str(big), str(bigq)])
+        assert np.array_equal(b, np.concatenate([ob1, ob2])) and np.array_equal(o, np.concatenate([oo1, oo2[1:] + oo1[-1]]))
+    finally:
+        gpu_ctx.set_option("profile", 0)
+        gpu_ctx.set_option("device_parse_min_bytes", 1 << 20)
+
+
+def test_device_parser_steps_back(gpu_ctx, oracle, tmp_path):
+    """files the device parser is not sure about go to the host readers: same reads as the oracle, or the reference's error"""
+    from metafast_amd import lib as L
+    rng = np.random.default_rng(22)
+    gpu_ctx.set_option("profile", 1)
+    gpu_ctx.set_option("device_parse_min_bytes", 1)
+    try:
+        good_fa = _fa_text(rng, 300, 0)
+        good_fq = _fq_text(rng, 300)
+        odd = {"lone_cr.fa": good_fa.replace(b"\n>read_7 ", b"\r>read_7 ", 1), "lone_cr_in_header.fa": good_fa.replace(b"read_9 some", b"read_9\rACGT", 1),
+               "empty_lines.fq": good_fq.replace(b"\n@r20\n", b"\n\n@r20\n", 1), "leading_empty.fq": b"\n" + good_fq, "crlf_empty.fq": good_fq.replace(b"\n@r30\n", b"\n\r\n@r30\n", 1)}
+        for name, text in odd.items():
+            p = tmp_path / name
+            p.write_bytes(text)
+            assert not _same_reads(gpu_ctx, oracle, p), name                  # (same reads, made by the host parser)
+        bad = {"bad_char.fa": good_fa.replace(b"\nA", b"\nJ", 1), "bad_char.fq": good_fq.replace(b"\nA", b"\n#", 1), "truncated.fq": good_fq[: len(good_fq) // 2],
+               "lengths.fq": good_fq.replace(b"\n+\n", b"\n+\nI", 1), "structure.fq": good_fq.replace(b"\n@r5\n", b"\nr5\n", 1), "bad_qual.fq": good_fq[:-2] + b"\x1f\n"}
+        for name, text in bad.items():
+            p = tmp_path / name
+            p.write_bytes(text)
+            msgs = []
+            for dp in (0, 1):
+                gpu_ctx.set_option("device_parse", dp)
+                with pytest.raises(L.MetafastError) as e:
+                    gpu_ctx.load_reads([str(p)])
+                msgs.append(str(e.value))
+            assert msgs[0] == msgs[1], (name, msgs)                            # (the host reader's message either way)
+            with pytest.raises(Exception):
+                oracle.read_file(str(p))
+    finally:
+        gpu_ctx.set_option("device_parse", 1)
+        gpu_ctx.set_option("profile", 0)
+        gpu_ctx.set_option("device_parse_min_bytes", 1 << 20)

@@ -57,6 +57,15 @@ while time.time() < t_end:
     (make_fastq if fq else make_fasta)(path)
     k = int(rng.choice([5, 15, 21, 31])); ml = int(rng.choice([0, 0, 50]))
     ok, ov = O.Table().count_files([path], k, ml).export()
+    # the device parser (mf_dparse.hip) against the oracle's reader: the reads themselves, byte for byte (a file it is not sure about goes
+    # through the host readers inside the same call)
+    ctx.set_option("device_parse", 1); ctx.set_option("device_parse_min_bytes", 1)
+    ob, oo = O.read_file(path)
+    gb, go = ctx.load_reads([path])
+    assert np.array_equal(go, oo) and np.array_equal(gb, ob), f"it={it} {path}: device parser"
+    gk, gc = ctx.count_reads([path], k, ml).export()
+    assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov), f"it={it} {path} k={k} min_len={ml} device parser"
+    ctx.set_option("device_parse", 0)
     for sr, piece, slack in ((1, int(rng.choice([4096, 8192, 65536])), int(rng.choice([1024, 4096, 32768]))), (0, 8 << 20, 1 << 20)):
         ctx.set_option("stream_reader", sr); ctx.set_option("stream_piece_bytes", piece); ctx.set_option("stream_slack_bytes", slack)
         gk, gc = ctx.count_reads([path], k, ml).export()
