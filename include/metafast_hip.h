@@ -272,7 +272,8 @@ int  mf_dcc_set_answers(mf_dcc *d, const void *d_answers, uint64_t n);
  * pairs (edges to fragments of HIGHER ranks) for each owner, then the half pairs themselves */
 int  mf_dcc_level_local(mf_dcc *d, uint64_t *counts);
 int  mf_dcc_pairs_fill(mf_dcc *d, void *d_pairs);
-/* owner side, in place: half pairs -> (own fragment root, other fragment root), global ids */
+/* owner side, in place: half pairs -> (own fragment root, other fragment root), global ids.  An entry (0xFFFFFFFF, 0xFFFFFFFF) is no pair: it is
+ * skipped here and by mf_dcc_merge, so that exchanges of a fixed capacity can pad their slices instead of announcing their sizes first. */
 int  mf_dcc_pairs_complete(mf_dcc *d, void *d_pairs, uint64_t n);
 /* ALL ranks' completed pairs -> global root of each own fragment; *n_stats = components this rank has vertices of, then
  * its share of each: 16-byte records (global root u32, size u32, weight u64) */

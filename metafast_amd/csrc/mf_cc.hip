@@ -1194,10 +1194,13 @@ extern "C" int mf_dcc_pairs_fill(mf_dcc *D, void *d_out) {
     MF_HIP(hipStreamSynchronize(st));
     return MF_OK;
 }
+// (round 5) exchanges of a fixed capacity fill their unused room with the pair (DCC_NO_PAIR, DCC_NO_PAIR), which no kernel takes: the sizes of
+// a level's exchanges then need no integer gather (metafast_amd/pipeline.py: distributed_components).  Vertex ids stay below 2^32 - 1.
+#define DCC_NO_PAIR 0xFFFFFFFFu
 // (c) owner side: (own vertex u, other root) -> (own root of u, other root), in place
 __global__ void k_dcc_pairs_complete(uint2 *__restrict__ p, uint64_t n, const uint32_t *__restrict__ root, uint32_t mybase) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i].x = mybase + root[p[i].x];
+    if (i < n && p[i].x != DCC_NO_PAIR) p[i].x = mybase + root[p[i].x];
 }
 extern "C" int mf_dcc_pairs_complete(mf_dcc *D, void *d_pairs, uint64_t n) {
     if (!D || (n && !d_pairs)) return mf_set_error("mf_dcc_pairs_complete: NULL argument");
@@ -1215,7 +1218,7 @@ __global__ void k_dcc_iota(uint32_t *__restrict__ p, uint32_t *__restrict__ gs, 
 }
 __global__ void k_dcc_init_pairs(const uint2 *__restrict__ pr, uint64_t n, uint32_t *__restrict__ p, uint32_t *__restrict__ gs, unsigned long long *__restrict__ gw) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || pr[i].x == DCC_NO_PAIR) return;
     const uint32_t a = pr[i].x, b = pr[i].y;
     p[a] = a; gs[a] = 0; gw[a] = 0;
     p[b] = b; gs[b] = 0; gw[b] = 0;
@@ -1229,7 +1232,7 @@ __global__ void k_dcc_init_roots(const uint8_t *__restrict__ alive, const uint32
 }
 __global__ void k_dcc_hook_pairs(const uint2 *__restrict__ pr, uint64_t n, uint32_t *parent) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || pr[i].x == DCC_NO_PAIR) return;
     uint32_t ra = pr[i].x, rb = pr[i].y;
     for (;;) {
         ra = cc_find(parent, ra); rb = cc_find(parent, rb);

@@ -181,6 +181,8 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "skm_pilot") ctx->opt_skm_pilot = v;
     else if (s == "device_parse") ctx->opt_device_parse = v;
     else if (s == "device_parse_min_bytes") ctx->opt_device_parse_min = v;
+    else if (s == "device_parse_piece_bytes") ctx->opt_device_parse_piece = v;
+    else if (s == "device_parse_threads") ctx->opt_device_parse_threads = v;
     else if (s == "host_pinned") ctx->opt_host_pinned = v;
     else if (s == "skm_dynq") ctx->opt_skm_dynq = v;
     else if (s == "part_good") { if (v < 16 || v > 4096) return mf_set_error("part_good out of [16,4096]"); ctx->opt_part_good = v; }

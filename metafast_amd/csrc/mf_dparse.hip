@@ -533,11 +533,14 @@ __global__ void k_dp_set_u64(uint64_t *p, uint64_t v) { *p = v; }
 // ---------------------------------------------------------------------------------------------
 int mf_ensure_pin_pool(mf_ctx *ctx, size_t want);
 // the file's bytes to d_raw as they are: W threads pread 8 MB pieces into their two staging chunks and copy them up
+// (copies from a mapping of the page cache instead of pread + staging were measured: 11 GB/s whatever the number of threads -- the runtime stages
+// a pageable source through its own buffers on the calling thread, page fault by page fault; gpurun_out/r05d_upload_rate.txt)
 static int dp_upload(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_raw) {
-    const size_t PIECE = (size_t)8 << 20;
+    const size_t PIECE = (size_t)std::max<int64_t>(ctx->opt_device_parse_piece, 1 << 16);
     const size_t np = (fsize + PIECE - 1) / PIECE;
-    const int W = (int)std::min<size_t>(std::min<size_t>((size_t)std::max(ctx->host_threads, 1), 32), np);
-    if (mf_ensure_pin_pool(ctx, (size_t)2 * std::min<size_t>((size_t)std::max(ctx->host_threads, 1), 32) * PIECE) != MF_OK) return 1;
+    const size_t WMAX = (size_t)std::min<int64_t>(std::max<int64_t>(ctx->opt_device_parse_threads, 1), std::max(ctx->host_threads, 1));
+    const int W = (int)std::min<size_t>(WMAX, np);
+    if (mf_ensure_pin_pool(ctx, (size_t)2 * WMAX * PIECE) != MF_OK) return 1;
     std::atomic<size_t> next{0};
     std::atomic<int> state{0};
     std::vector<std::thread> th;
@@ -674,7 +677,7 @@ int mf_dparse_file(mf_ctx *ctx, const char *path, int fmt, mf_buf<uint8_t> &base
     const uint64_t nr = h_tot[0], nbases = h_tot[1];
     MF_TRY(bases.alloc(ctx, nbases + 64)); MF_TRY(offsets.alloc(ctx, nr + 1));
     {
-        mf_ktimer tm(ctx, "k_dparse");
+        mf_ktimer tm(ctx, "k_dparse_emit");                        // (only a file the device parser has accepted gets here)
         MF_HIP(hipMemsetAsync(rec_place.p + n_rec, 0xFF, 8, st));
         k_dp_set_u64<<<1, 1, 0, st>>>(offsets.p + nr, nbases);
         if (fmt == 1) {

@@ -437,7 +437,7 @@ int mf_table_select_sorted(const mf_table *t, int threshold, mf_buf<uint64_t> &s
 // fwrite (3.5 GB/s: 0.2 s per .kmers.bin of a 20 M-read sample).  Here: slots of the context's pinned pool, a D2H copy per slot,
 // and a pwrite per slot on a thread of its own while the next slot's copy runs (the page cache takes ~2 GB/s per thread).
 int mf_ensure_pin_pool(mf_ctx *ctx, size_t want) {
-    if (ctx->pin_pool_bytes >= want) return MF_OK;
+    if (ctx->pin_pool_bytes >= want && ctx->pin_pool_pinned == (ctx->opt_host_pinned != 0)) return MF_OK;
     if (ctx->pin_pool) { if (ctx->pin_pool_pinned) hipHostFree(ctx->pin_pool); else free(ctx->pin_pool); ctx->pin_pool = nullptr; ctx->pin_pool_bytes = 0; }
     if (ctx->opt_host_pinned) {
         if (hipHostMalloc(&ctx->pin_pool, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); ctx->pin_pool = nullptr; return mf_set_error("no pinned host memory (%zu bytes)", want); }

@@ -220,6 +220,20 @@ class TorchComm:
         return out
 
 
+    def all_to_all_v(self, t, send, recv):
+        """all_to_all where a rank knows only ITS OWN split sizes: send[d] elements go to rank d, recv[s] come from rank s"""
+        send, recv = [int(x) for x in send], [int(x) for x in recv]
+        if self.world == 1 and not _force():
+            return t
+        if t.is_cuda and dist.get_backend() == "gloo":
+            return self.all_to_all_v(t.cpu(), send, recv).to(t.device)
+        t0 = time.perf_counter()
+        out = _alloc(lambda: torch.empty(sum(recv), dtype=t.dtype, device=t.device))
+        dist.all_to_all_single(out, t.contiguous(), recv, send)
+        self._account(t0, out.numel() * out.element_size())
+        return out
+
+
 class ThreadGroup:
     """W virtual ranks inside ONE process (one thread each, all on the same GPU): the distributed cutter end to end on a
     1-GPU box -- tests and tools/sim_union.py.  serial=True lets only one rank compute at a time (clean per-rank timings)."""
@@ -235,6 +249,7 @@ class ThreadComm:
     def __init__(self, group, rank):
         self.g, self.rank, self.world = group, rank, group.world
         self.waited = 0.0            # seconds spent waiting for the other ranks (not this rank's work)
+        self.stats = dict(collectives=0, bytes_in=0)          # (as TorchComm.stats: what the protocol exchanged)
         if group.turn:
             group.turn.acquire()
 
@@ -267,6 +282,8 @@ class ThreadComm:
         if torch.cuda.is_available():
             torch.cuda.synchronize()
         self.exchange = getattr(self, "exchange", 0.0) + (time.perf_counter() - t0) - (self.waited - w0)
+        self.stats["collectives"] += 1
+        self.stats["bytes_in"] += int(out.numel() * out.element_size()) if torch.is_tensor(out) else int(out.nbytes)
         return out
 
     def all_gather_ints(self, vals):
@@ -285,6 +302,19 @@ class ThreadComm:
             for r in range(self.world):
                 o = int(sum(matrix[r][:self.rank]))
                 out.append(parts[r][o:o + int(matrix[r][self.rank])])
+            return torch.cat(out)
+        return self._timed(f)
+
+
+    def all_to_all_v(self, t, send, recv):
+        def f():
+            parts = self._exchange((t, [int(x) for x in send]))
+            out = []
+            for r in range(self.world):
+                pt, ps = parts[r]
+                o = int(sum(ps[:self.rank]))
+                assert ps[self.rank] == int(recv[r]), "all_to_all_v: rank %d sends %d, rank %d expects %d" % (r, ps[self.rank], self.rank, int(recv[r]))
+                out.append(pt[o:o + ps[self.rank]])
             return torch.cat(out)
         return self._timed(f)
 
@@ -372,33 +402,115 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
         call(lambda: D.set_answers(ra.data_ptr(), nq))
         del q, rq, a, ra
         mark("cutter_adjacency")
-        # ---- threshold levels
+        # ---- threshold levels (ComponentsBuilder.java:86-150)
+        # Round 5: the sizes of a level's exchanges ride IN BAND where the level before bounds them.
+        #  * per-component records: every rank's slice has the capacity 2 x its count of the level before + 1024 and says its real
+        #    count in the slice's first record (a count beyond the capacity -- components can split -- is answered by ONE more
+        #    all-gather with the sizes everybody has just read): the integer gather of round 4 is gone from every level but the first;
+        #  * half pairs: a cross edge only ever dies, so a level's counts are bounded by the level before's.  Once a level's pairs are
+        #    few (MF_DCC_INBAND_MAX, 2^20 = 8 MB over all ranks: the latency of a collective then costs more than the padding), the
+        #    all-to-all and the all-gather of the pairs keep the split sizes of the last level that was counted, unused room is filled
+        #    with a pair no kernel takes (0xFFFFFFFF, 0xFFFFFFFF), and the status every rank owes its peers travels in the slices' first
+        #    element: no integer gather at all, 3 collectives per level (5 in round 4), and the host reads the result of a collective
+        #    twice per level (the status, the records' counts) where it read it five times.
+        inband_max = int(os.environ.get("MF_DCC_INBAND_MAX", str(1 << 20)))
+        stat_mul, stat_add = (int(x) for x in os.environ.get("MF_DCC_STATS_ROOM", "2,1024").split(","))      # (tests: "0,0" makes every level overflow its room)
+        SENT = -1                                                    # int64 view of the pair (0xFFFFFFFF, 0xFFFFFFFF)
         kept, levels, per_level = [], 0, []
         n_big = -1
-        for thr in range(1, 1 << 16):
-            # (the gather that opens a level also closes the one before: it carries that level's oversize count -- the same on
-            # every rank -- and the status of the calls since the last gather, so all ranks leave the loop, or abort, together)
-            pm = gather_ints(lambda: [n_big] + ([int(x) for x in D.level_local()] if n_big else [0] * W), W + 1)
-            if len(set(int(x) for x in pm[:, 0])) != 1:         # (every rank derives the count from the same gathered records)
-                raise DistAbort("sharded component cutter: the ranks disagree on a level's oversize components: %s" % [int(x) for x in pm[:, 0]])
-            if int(pm[me][0]) == 0:
-                break
-            pm = pm[:, 1:]
-            nsend = int(pm[me].sum())
-            hp = buf(nsend, device); sync()
-            call(lambda: D.pairs_fill(hp.data_ptr()))
-            rp = comm.all_to_all(hp[:nsend], pm); sync()
-            nr = int(rp.numel())
-            if nr:
-                rp = rp.contiguous()
-                call(lambda: D.pairs_complete(rp.data_ptr(), nr))
-            allp = comm.all_gather(rp, pm.sum(axis=0)); sync()
-            n_stats = call(lambda: D.merge(allp.data_ptr(), int(allp.numel())), 0)
-            sm = gather_ints(lambda: [n_stats], 1)[:, 0]
-            st = buf(2 * n_stats, device); sync()
+        cap_send = cap_recv = cap_tot = None                         # split sizes of the last COUNTED level: to each rank / from each rank / every rank's total
+        prev_nstat = None                                            # every rank's record count of the level before
+        host_reads = 0
+
+        def stats_exchange(n_stats):
+            """all ranks' per-component records, rank order, contiguous; -> (tensor, counts per rank)"""
+            nonlocal host_reads
+            if prev_nstat is None:                                   # (the first level: nothing bounds the counts yet)
+                sm = gather_ints(lambda: [n_stats], 1)[:, 0]
+                st = buf(2 * n_stats, device); sync()
+                call(lambda: D.stats_fill(st.data_ptr()))
+                alls = comm.all_gather(st[:2 * n_stats], 2 * sm); sync()
+                host_reads += 1
+                return alls, sm
+            caps = [stat_mul * int(x) + stat_add for x in prev_nstat]
+            st = buf(2 * max(n_stats, 1), device); sync()
             call(lambda: D.stats_fill(st.data_ptr()))
-            alls = comm.all_gather(st[:2 * n_stats], 2 * sm); sync()
+            mine = _alloc(lambda: torch.zeros(2 * (caps[me] + 1), dtype=torch.int64, device=device))
+            mine[0] = -1 if err else n_stats                         # (a failed rank says so here)
+            m = min(n_stats, caps[me]) if not err else 0
+            mine[2:2 + 2 * m] = st[:2 * m]
+            allg = comm.all_gather(mine, [2 * (c + 1) for c in caps]); sync()
+            starts = np.concatenate([[0], np.cumsum([2 * (c + 1) for c in caps])])
+            sm = allg[torch.as_tensor(starts[:-1], device=allg.device)].cpu().numpy(); host_reads += 1
+            if (sm < 0).any():
+                raise DistAbort("sharded component cutter: rank(s) %s failed%s" % ([int(r) for r in np.nonzero(sm < 0)[0]], (": %s" % err[0]) if err else ""))
+            if any(int(sm[r]) > caps[r] for r in range(W)):          # (rare: a level that splits one component into thousands) -- the sizes are known now
+                alls = comm.all_gather(st[:2 * n_stats], 2 * sm); sync()
+                return alls, sm
+            alls = torch.cat([allg[int(starts[r]) + 2: int(starts[r]) + 2 + 2 * int(sm[r])] for r in range(W)]) if int(sm.sum()) else allg[:0]
+            return alls, sm
+
+        for thr in range(1, 1 << 16):
+            inband = cap_tot is not None and int(np.sum(cap_tot)) <= inband_max and n_big > 0
+            mode = "in-band" if inband else "counted"
+            if not inband:
+                # (the gather that opens a counted level also closes the one before: it carries that level's oversize count -- the same on
+                # every rank -- and the status of the calls since the last gather, so all ranks leave the loop, or abort, together)
+                pm = gather_ints(lambda: [n_big] + ([int(x) for x in D.level_local()] if n_big else [0] * W), W + 1)
+                host_reads += 1
+                if len(set(int(x) for x in pm[:, 0])) != 1:         # (every rank derives the count from the same gathered records)
+                    raise DistAbort("sharded component cutter: the ranks disagree on a level's oversize components: %s" % [int(x) for x in pm[:, 0]])
+                if int(pm[me][0]) == 0:
+                    break
+                pm = pm[:, 1:]
+                nsend = int(pm[me].sum())
+                hp = buf(nsend, device); sync()
+                call(lambda: D.pairs_fill(hp.data_ptr()))
+                rp = comm.all_to_all(hp[:nsend], pm); sync()
+                nr = int(rp.numel())
+                if nr:
+                    rp = rp.contiguous()
+                    call(lambda: D.pairs_complete(rp.data_ptr(), nr))
+                allp = comm.all_gather(rp, pm.sum(axis=0)); sync()
+                cap_send, cap_recv, cap_tot = pm[me].copy(), pm[:, me].copy(), pm.sum(axis=0)
+            else:
+                cnt = call(lambda: [int(x) for x in D.level_local()], [0] * W)
+                nsend = int(sum(cnt))
+                hp = buf(nsend, device); sync()
+                call(lambda: D.pairs_fill(hp.data_ptr()))
+                send = [int(c) + 1 for c in cap_send]               # (one status element in front of every slice)
+                out = _alloc(lambda: torch.full((sum(send),), SENT, dtype=torch.int64, device=device))
+                so, po = 0, 0
+                for d in range(W):
+                    c = cnt[d] if not err else 0
+                    if c > int(cap_send[d]):
+                        err.append(L.MetafastError("sharded component cutter: %d half pairs for rank %d, %d at the level before" % (c, d, int(cap_send[d]))))
+                        c = 0
+                    out[so] = 0 if err else 1
+                    if c:
+                        out[so + 1: so + 1 + c] = hp[po: po + c]
+                    so += send[d]; po += cnt[d]
+                if err:                                              # (a failure found while filling: every slice says so)
+                    so = 0
+                    for d in range(W):
+                        out[so] = 0; so += send[d]
+                recv = [int(c) + 1 for c in cap_recv]
+                rp = comm.all_to_all_v(out, send, recv); sync()
+                heads = np.concatenate([[0], np.cumsum(recv)])[:-1]
+                ht = torch.as_tensor(heads, device=rp.device)
+                status = rp[ht].cpu().numpy(); host_reads += 1
+                if not (status == 1).all():
+                    raise DistAbort("sharded component cutter: rank(s) %s failed%s" % ([int(r) for r in np.nonzero(status != 1)[0]], (": %s" % err[0]) if err else ""))
+                rp = rp.contiguous()
+                rp[ht] = SENT                                        # (the status elements become pairs nobody takes)
+                nr = int(rp.numel())
+                call(lambda: D.pairs_complete(rp.data_ptr(), nr))
+                allp = comm.all_gather(rp, [int(c) + W for c in cap_tot]); sync()
+            n_stats = call(lambda: D.merge(allp.data_ptr(), int(allp.numel())), 0)
+            alls, sm = stats_exchange(n_stats)
+            prev_nstat = sm
             seg = np.concatenate([[0], np.cumsum(sm)])
+            alls = alls.contiguous()
             n_kept, n_big = call(lambda: D.classify(alls.data_ptr(), int(alls.numel()) // 2, seg, n_stats, b1, b2, thr, me), (0, 0))
             kb = buf(2 * n_kept, device); sync()
             call(lambda: D.kept_fill(kb.data_ptr()))
@@ -408,7 +520,9 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
                 r = r[np.argsort(r[:, 0] & 0xFFFFFFFF, kind="stable")]        # by root: the order every rank agrees on
                 kept.append((r[:, 0] & 0xFFFFFFFF, (r[:, 0] >> 32) & 0xFFFFFFFF, r[:, 1], np.full(len(r), thr, dtype=np.int32)))
             levels = thr
-            per_level.append((int(allp.numel()), int(sm.sum()), int(n_kept), int(n_big)))
+            per_level.append((int(allp.numel()), int(sm.sum()), int(n_kept), int(n_big), mode))
+            if inband and n_big == 0:
+                break                                                # (every rank has derived the same count from the same records; the members' gather below carries the status)
         mark("cutter_levels")
         # ---- members of the kept components, everywhere
         # ---- members of the kept components, everywhere: 8 bytes per member (the k-mers, sorted by component on the rank) + one
@@ -427,7 +541,8 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
                                               cat(2, np.int64), cat(3, np.int32), mn))
         gather_ints(lambda: [len(comps)], 1)          # (the last status: every rank has its components, or all raise)
         if info is not None:
-            info.update(levels=levels, per_level=per_level, shard=int(ns[me]), vertices=int(base[-1]), queries=nq, members=int(allmk.numel()))
+            info.update(levels=levels, per_level=per_level, shard=int(ns[me]), vertices=int(base[-1]), queries=nq, members=int(allmk.numel()), host_reads_in_levels=host_reads,
+                        collectives=int(comm.stats["collectives"]), MB_received=round(comm.stats["bytes_in"] / 1e6, 2))
     finally:
         if D is not None:
             D.close()

@@ -231,6 +231,25 @@ def test_sharded_cutter_virtual_ranks(oracle, world):
     assert all(i["shard_len"] > 0 for _, i in res)
 
 
+@pytest.mark.parametrize("inband_max,room", [("0", "2,1024"), (str(1 << 40), "2,1024"), (str(1 << 40), "0,0")])
+def test_sharded_cutter_exchange_sizes_in_band(oracle, monkeypatch, inband_max, room):
+    """round 5: a level's exchange sizes ride in band where the level before bounds them (pipeline.distributed_components).  Forced off
+    (every level counts its half pairs with an integer gather), forced on from level 2 (padded slices, the status in the slices' first
+    element), and with no room at all for the per-component records (every level answers with the second, exactly sized all-gather):
+    the oracle's components every time"""
+    from util import branchy_reads
+    monkeypatch.setenv("MF_DCC_INBAND_MAX", inband_max)
+    monkeypatch.setenv("MF_DCC_STATS_ROOM", room)
+    inputs = [branchy_reads(rs, genome_seed=7, n=6000) for rs in [107, 117, 127, 137]]
+    want = _oracle_components(oracle, inputs, 100, 1000)
+    res = _virtual_ranks(4, inputs, 100, 1000)
+    for comps, info in res:
+        assert [(a, w, t) for a, w, t, _ in comps] == [(a, w, t) for a, w, t, _ in want]
+        assert all(np.array_equal(np.sort(g[3]), np.sort(x[3])) for g, x in zip(comps, want))
+        modes = [lv[4] for lv in info["per_level"]]
+        assert modes == ["counted"] * 6 if inband_max == "0" else modes == ["counted"] + ["in-band"] * 5, modes
+
+
 @pytest.mark.parametrize("fail_at", ["shard", "merge"])
 def test_sharded_cutter_ranks_abort_together(fail_at):
     """one rank cannot do its part (its shard count failed / a call in the middle of a level fails): EVERY rank leaves the
@@ -246,6 +265,30 @@ def test_sharded_cutter_ranks_abort_together(fail_at):
         L.DistCutter.merge = real
     assert all(r[0] == "abort" for r in res), res
     assert all("rank(s) [2] failed" in r[1] for r in res)
+
+
+def test_sharded_cutter_ranks_abort_together_in_an_in_band_level():
+    """the same with the failure in a level whose sizes ride in band (level 3: the status travels in the slices of the all-to-all / in the
+    records' first entry)"""
+    from util import branchy_reads
+    from metafast_amd import lib as L
+    inputs = [branchy_reads(rs, genome_seed=7, n=6000) for rs in (107, 117, 127, 137)]
+    for which in ("merge", "level_local"):
+        real = getattr(L.DistCutter, which)
+        calls = {}
+
+        def fails_at_level_3(self, *a, _real=real):
+            calls[self.rank] = calls.get(self.rank, 0) + 1
+            if self.rank == 1 and calls[self.rank] == 3:
+                raise L.MetafastError("injected failure")
+            return _real(self, *a)
+        setattr(L.DistCutter, which, fails_at_level_3)
+        try:
+            res = _virtual_ranks(4, inputs, 100, 1000)
+        finally:
+            setattr(L.DistCutter, which, real)
+        assert all(r[0] == "abort" for r in res), (which, res)
+        assert all("rank(s) [1] failed" in r[1] for r in res), (which, res)
 
 
 @pytest.mark.skipif(not os.environ.get("MF_TRY_RCCL_2RANKS"), reason="two RCCL ranks on ONE device: RCCL refuses duplicate GPUs on most builds (opt-in: MF_TRY_RCCL_2RANKS=1)")

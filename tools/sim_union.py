@@ -73,6 +73,7 @@ def work(rank):
             shard = c2.count_device_shard(allb.data_ptr(), allo.data_ptr(), ns, nb, k, 100, rank, N)
             torch.cuda.synchronize(); tm["cutter_count"] = time.perf_counter() - t0
             info = {}
+            comm.stats = dict(collectives=0, bytes_in=0)
             comps = P.distributed_components(c2, comm, shard, k, 1000, 10000, timings=tm, info=info)
             info["components"] = len(comps); info["exchange_ms"] = round(1e3 * comm.exchange, 1); comm.exchange = 0.0
             comps.close(); shard.close()
@@ -92,5 +93,9 @@ for r, x in enumerate(res):
 tm, info, rep_k = res[0]
 print("    rank 0 kernels:", {kk: (v[0], round(v[1], 1)) for kk, v in sorted(rep_k.items(), key=lambda kv: -kv[1][1])[:30]})
 stages = sorted({kk for x in res for kk in x[0]})
+lv = res[0][1]["per_level"]
+print("    per level (pairs gathered, records gathered, kept, oversize, how the sizes travelled):", lv)
+print(f"    exchanges of rank 0: {res[0][1]['collectives']} collectives ({len(lv)} levels: {sum(1 for x in lv if x[4] == 'in-band')} with their sizes in band = 3 collectives each, "
+      f"the others 4, the first 5), {res[0][1]['MB_received']} MB received, the host read a collective's result {res[0][1]['host_reads_in_levels']} times inside the levels")
 print("sharded, max over ranks:", {kk: round(1e3 * max(x[0][kk] for x in res), 1) for kk in stages},
       "sum of the maxima", round(1e3 * sum(max(x[0][kk] for x in res) for kk in stages), 1), "ms (exchanges: memory copies here)")
