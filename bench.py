@@ -37,6 +37,16 @@ def _load_traffic():
         return {}
 
 
+def _load_other_shapes():
+    """the hash-count kernel's roofline fraction on the workloads that are NOT the headline one (the north star's sentence is about
+    the kernel, not one sample): lines of this same bench.py run by tools/other_shapes.sh on the GPU box and committed as
+    profiles/hash_count_other_shapes.json -- builder-run profiles, labelled as such in the line"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "hash_count_other_shapes.json")))
+    except Exception:
+        return None
+
+
 TRAFFIC = {}
 # what limits a kernel when no counters of this workload are at hand (other shapes than the headline one)
 BOUND = {"k_skm_count": "lds+valu", "k_skm_scatter": "valu", "k_skm_hist": "valu"}
@@ -244,6 +254,8 @@ def end_to_end_and_cli(ctx, n_reads, rl, k, args, device, sample0):
         # inside the child's hipMalloc, 0.9 s of its first count -- and the child fits beside this process: ~10 of the 288 GB)
         wd = os.path.join(td, "wd")
         t0 = time.perf_counter()
+        # (the driver's default: every device the process sees, one context each -- `devices` says how many that was; on a one-GPU box the
+        # two samples are counted one after the other)
         p = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", str(k), "-i", *files, "-w", wd], capture_output=True, text=True, cwd=td)
         dt = time.perf_counter() - t0
         if os.environ.get("MF_IO_TIMING"):
@@ -251,6 +263,7 @@ def end_to_end_and_cli(ctx, n_reads, rl, k, args, device, sample0):
         occ2 = 2 * mc * (rl - k + 1)
         if p.returncode == 0:
             out["cli"] = dict(value=round(occ2 / dt, 1), unit="k-mers/s", samples=2, reads_per_sample=mc, fasta_GB=round(2 * size2 / 1e9, 3), seconds=round(dt, 3),
+                              devices=min(2, max(1, torch.cuda.device_count())),
                               step_seconds=_log_steps(os.path.join(wd, "log")),
                               what="metafast.sh -k %d -i a.fa b.fa -w wd: matrix-builder, every step through the reference's files, process start included" % k)
         else:
@@ -464,11 +477,15 @@ def main():
                        "reads_per_gpu": n_reads, "read_len": rl, "k": k, "genome_scale_bp": args.genome_scale,
                        "substitutions_per_base": round(sub16k / 16384, 5)},
             "roofline": roof(dom),
-            "roofline_hash_count": roof("k_skm_count" if "k_skm_count" in kern else "k_count"),
+            "roofline_hash_count": (lambda r: (r.update(other_shapes=_load_other_shapes()) or r) if isinstance(r, dict) and world == 1 else r)(
+                roof("k_skm_count" if "k_skm_count" in kern else "k_count")),
             "cpu_baseline": cpu,
             "end_to_end": e2e.get("end_to_end"),
             "cli": e2e.get("cli"),
             "stats": stats,
+            # counting runs that threw their slices away and started over with more because a buffer found no place in the arena (8 x 200 M reads
+            # at k = 21 on one GPU did in round 4 until the temporary lists were halved): 0 on every committed shape
+            "slice_restarts": ctx.stat("slice_restarts"),
             # the sharded cutter's exchanges on rank 0 (world > 1): collectives per step, bytes received per step, seconds inside
             # them (each timed with a stream synchronisation on both sides; not measurable on this pool's 1-GPU boxes)
             "comm": {"collectives_per_step": round(comm_acc.get("collectives", 0) / max(args.steps, 1), 1),

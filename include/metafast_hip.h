@@ -78,6 +78,10 @@ int64_t mf_ctx_kernel_time(mf_ctx *ctx, const char *kernel, double *total_ms);
 /* Writes "name\tlaunches\ttotal_ms\tmax_launch_ms\n" lines for every timed kernel into buf (NUL-terminated). */
 int  mf_ctx_kernel_report(mf_ctx *ctx, char *buf, uint64_t cap);
 int  mf_ctx_reset_timers(mf_ctx *ctx);
+/* Counters and gauges by name: "slice_restarts" (counting runs that threw their slices away and started over with more because a
+ * buffer found no place in HBM), "device_parsed_files" / "device_parser_stepped_back" (read files the device parser took / left to
+ * the host readers), "hipmalloc_calls", "hipmalloc_bytes", "arena_bytes", "arena_idle_bytes".  < 0: unknown name. */
+int64_t mf_ctx_stat(mf_ctx *ctx, const char *name);
 
 /* ---- A1-A4  reads -> canonical k-mer counts ---------------------------------------- */
 /* replaces IOUtils.loadReads (src/io/IOUtils.java:772-803), called from

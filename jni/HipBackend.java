@@ -36,6 +36,12 @@ public final class HipBackend {
     public static native void features(long ctx, String componentsBin, String kmersBin, int k, int threshold, String vec, String breadth);
     /** FeaturesCalculatorMain.runImpl reads branch (:117-131, --use-reads-for-calculating-features) */
     public static native void featuresReads(long ctx, String componentsBin, String[] files, int k, int threshold, String vec, String breadth);
+    /** the same two with --selected (FeaturesCalculatorMain.java:55-57, 113-116, 193): selected = loadKmers(selectedKmers, 0, k), 0 = none */
+    public static native void featuresSelected(long ctx, String componentsBin, String kmersBin, int k, int threshold, long selected, String vec, String breadth);
+    public static native void featuresReadsSelected(long ctx, String componentsBin, String[] files, int k, int threshold, long selected, String vec, String breadth);
+    /** GPUs this JVM sees; one context per device, each used by one thread at a time (ctxBindThread: a thread other than the one that made the context) */
+    public static native int deviceCount();
+    public static native void ctxBindThread(long ctx);
     /** DistanceMatrixCalculatorMain.brayCurtisDistance (:140) for all pairs: row-major nSamples x nSamples */
     public static native double[] brayCurtis(long[] vecs, int nSamples, int nComp);
     /** the .stat.txt rows of IOUtils.printKmers (src/io/IOUtils.java:45-71) of a table counted with the cut inside the counting pass: hist[count] */

@@ -118,6 +118,21 @@ JNIEXPORT void JNICALL Java_io_HipBackend_featuresReads(JNIEnv *e, jclass, jlong
     utf_array f(e, files);
     if (mf_features_reads((mf_ctx *)(intptr_t)ctx, c.p, f.p.data(), (int)f.p.size(), k, threshold, v.p, b.p) < 0) raise(e);
 }
+// --selected (FeaturesCalculatorMain.java:55-57, 113-116, 193): `selected` = the handle loadKmers(selectedKmers, 0, k) returned, 0 = none
+JNIEXPORT void JNICALL Java_io_HipBackend_featuresSelected(JNIEnv *e, jclass, jlong ctx, jstring componentsBin, jstring kmersBin, jint k, jint threshold,
+                                                           jlong selected, jstring vec, jstring breadth) {
+    utf c(e, componentsBin), kb(e, kmersBin), v(e, vec), b(e, breadth);
+    if (mf_features_selected((mf_ctx *)(intptr_t)ctx, c.p, kb.p, k, threshold, (mf_table *)(intptr_t)selected, v.p, b.p) < 0) raise(e);
+}
+JNIEXPORT void JNICALL Java_io_HipBackend_featuresReadsSelected(JNIEnv *e, jclass, jlong ctx, jstring componentsBin, jobjectArray files, jint k,
+                                                                jint threshold, jlong selected, jstring vec, jstring breadth) {
+    utf c(e, componentsBin), v(e, vec), b(e, breadth);
+    utf_array f(e, files);
+    if (mf_features_reads_selected((mf_ctx *)(intptr_t)ctx, c.p, f.p.data(), (int)f.p.size(), k, threshold, (mf_table *)(intptr_t)selected, v.p, b.p) < 0) raise(e);
+}
+// devices this process sees: a host that wants one library per GPU makes one context per device and drives each from a thread of its own
+JNIEXPORT jint JNICALL Java_io_HipBackend_deviceCount(JNIEnv *, jclass) { return (jint)mf_device_count(); }
+JNIEXPORT void JNICALL Java_io_HipBackend_ctxBindThread(JNIEnv *e, jclass, jlong ctx) { if (mf_ctx_bind_thread((mf_ctx *)(intptr_t)ctx) < 0) raise(e); }
 JNIEXPORT jdoubleArray JNICALL Java_io_HipBackend_brayCurtis(JNIEnv *e, jclass, jlongArray vecs, jint nSamples, jint nComp) {
     jlong *v = e->GetLongArrayElements(vecs, nullptr);
     std::vector<double> m((size_t)nSamples * (size_t)nSamples);

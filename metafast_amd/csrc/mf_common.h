@@ -83,7 +83,7 @@ struct mf_ctx {
     double last_pilot_rho = -1.0;
     double last_l1_per_occ = 0; int last_l1_k = 0;   // records (with padding) of the last run's level 1 per k-mer occurrence, for k = last_l1_k: the next sample's buffers are planned with it  // what the last pilot measured (diagnostics; < 0: none ran)
     int64_t opt_device_parse = 1;  // plain FASTA / FASTQ files are parsed on the device (mf_dparse.hip); files it is not sure about go to the host readers
-    int64_t opt_device_parse_piece = 8 << 20, opt_device_parse_threads = 32;   // upload: piece size and host threads (each owns two staging chunks of a piece)
+    int64_t opt_device_parse_piece = 16 << 20, opt_device_parse_threads = 16;   // upload: piece size and host threads (each owns two staging chunks of a piece)
     int64_t opt_device_parse_min = 1 << 20;   // ... from this size on (bytes): a small file is not worth the kernels' launches
     int64_t opt_host_pinned = 0;   // staging buffers of the file readers / writers: 1 = hipHostMalloc (0.16 - 0.29 s per GB to get, 0.1 s to give back), 0 = plain host memory (copies to and from it run at the same 56 GB/s on this platform: tools/pin_alloc.hip)
     int64_t opt_file_cache_gb = 0; // > 0: tables / components written to files stay in HBM (up to this many GB) and are handed out when the same file is loaded again
@@ -100,6 +100,9 @@ struct mf_ctx {
     std::vector<region> regions;
     std::vector<struct mf_file_entry *> file_cache; size_t file_cache_bytes = 0; uint64_t file_cache_clock = 0;   // (mf_io.hip)
     size_t arena_bytes = 0;
+    // counters a host can read (mf_ctx_stat): counting runs that started their slices over because a buffer found no place (mf_skm.hip);
+    // read files the device parser took / handed to the host readers (mf_dparse.hip)
+    uint64_t n_slice_restarts = 0, n_dparse_files = 0, n_dparse_stepped_back = 0;
     // timers
     std::vector<mf_timer_rec> pending;
     std::vector<hipEvent_t> event_pool;

@@ -194,6 +194,19 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     return MF_OK;
 }
 
+// counters and gauges of the context, by name (-1: unknown name)
+extern "C" int64_t mf_ctx_stat(mf_ctx *ctx, const char *name) {
+    if (!ctx || !name) return mf_set_error("mf_ctx_stat: NULL argument");
+    const std::string s(name);
+    if (s == "slice_restarts") return (int64_t)ctx->n_slice_restarts;
+    if (s == "device_parsed_files") return (int64_t)ctx->n_dparse_files;
+    if (s == "device_parser_stepped_back") return (int64_t)ctx->n_dparse_stepped_back;
+    if (s == "hipmalloc_calls") return (int64_t)ctx->n_hipmalloc;
+    if (s == "hipmalloc_bytes") return (int64_t)ctx->b_hipmalloc;
+    if (s == "arena_bytes") return (int64_t)ctx->arena_bytes;
+    if (s == "arena_idle_bytes") return (int64_t)mf_arena_idle(ctx);
+    return mf_set_error("mf_ctx_stat: unknown name '%s'", name);
+}
 extern "C" int mf_ctx_synchronize(mf_ctx *ctx) {
     if (!ctx) return mf_set_error("ctx is NULL");
     MF_HIP(hipStreamSynchronize(ctx->stream));

@@ -245,6 +245,7 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
             uint64_t r = 0, b = 0;
             const int rc = mf_dparse_file(ctx, files[i], fmt, df->b, df->o, &r, &b);
             if (rc < 0) return rc;
+            if (rc == 0) ctx->n_dparse_files++; else ctx->n_dparse_stepped_back++;
             if (rc == 0) {
                 if (nfiles == 1) { db.swap(df->b); doff.swap(df->o); *n_reads = r; *n_bases = b; if (t_parse) *t_parse = now() - t0; if (t_h2d) *t_h2d = 0; return MF_OK; }
                 piece P; P.dev = df->b.p; P.n_bases = b; P.dev_offsets = df->o.p; P.n_reads = r;

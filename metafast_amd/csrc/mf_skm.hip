@@ -2101,6 +2101,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             if (!A.dused) MF_HIP(hipMemsetAsync(A.doff.p, 0, ((size_t)A.np_total + 1) * 8, st));
         }
         if (rc == MF_SKM_NOMEM) {
+            ctx->n_slice_restarts++;                             // (what was counted so far is thrown away: mf_ctx_stat "slice_restarts", bench.py reports it)
             const bool can_double = lv.size() >= 2 && S < 64 && (own_hi - own_lo) / (2 * S) >= 1 && (W > 1 || (uint32_t)nd1 / (2 * S) >= 4);
             if (shared && SH.ready && can_double && shared_tries++ < 2) {
                 if (ctx->opt_verbose) fprintf(stderr, "[mf] skm: %u slice(s) behind a shared level 1 do not fit, trying %u\n", S, 2 * S);

@@ -104,6 +104,7 @@ _SIGS = {
     "mf_reads_stats": (i32, [vp, pu64, pu64]),
     "mf_reads_device_view": (i32, [vp, pvp, pvp]),
     "mf_reads_export": (i32, [vp, vp, vp]),
+    "mf_ctx_stat": (i64, [vp, cp]),
     "mf_device_count": (i32, []),
     "mf_ctx_device": (i32, [vp]),
     "mf_ctx_bind_thread": (i32, [vp]),
@@ -196,6 +197,13 @@ class Context:
 
     def reset_timers(self):
         _check(lib().mf_ctx_reset_timers(self.h))
+
+    def stat(self, name):
+        """counters and gauges of the context: slice_restarts, device_parsed_files, device_parser_stepped_back, hipmalloc_calls, ..."""
+        v = lib().mf_ctx_stat(self.h, name.encode())
+        if v < 0:
+            raise MetafastError(lib().mf_last_error().decode(errors="replace"))
+        return int(v)
 
     def kernel_time(self, name):
         ms = C.c_double()

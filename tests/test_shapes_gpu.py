@@ -171,8 +171,11 @@ def test_config4_union_of_8_samples_k21(gpu_ctx):
             torch.cuda.synchronize()
             yield bases, offsets, n, n * RL
 
+    restarts0 = gpu_ctx.stat("slice_restarts")
     r = P.run_samples(gpu_ctx, samples(), k=k, b=1, l=100, b1=1000, b2=10000)
     del bases, offsets
+    # (250 of the 288 GB are in use here: no counting run may have thrown its slices away and started over for want of a PLACE in the arena)
+    assert gpu_ctx.stat("slice_restarts") == restarts0
     assert r["n_occ"] == S * n * (RL - k + 1) and len(r["goods"]) == S and r["vecs"].shape[0] == S
     comps, cutter = r["comps"], r["cutter"]
     cs = comps.export()
