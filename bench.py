@@ -227,7 +227,7 @@ def end_to_end_and_cli(ctx, n_reads, rl, k, args, device, sample0):
         for _ in range(2):                                # (second pass: arena warm, as in a run over many samples)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            r = P.run_samples(ctx, [(fa,)], k=k, b=1, l=100, b1=args.b1, b2=args.b2, device=device)
+            r = P.run_samples(ctx, [(fa,)], k=k, b=args.bad_freq, l=args.min_len, b1=args.b1, b2=args.b2, device=device)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             occ = r["n_occ"]
@@ -254,16 +254,18 @@ def end_to_end_and_cli(ctx, n_reads, rl, k, args, device, sample0):
         # inside the child's hipMalloc, 0.9 s of its first count -- and the child fits beside this process: ~10 of the 288 GB)
         wd = os.path.join(td, "wd")
         t0 = time.perf_counter()
-        # (the driver's default: every device the process sees, one context each -- `devices` says how many that was; on a one-GPU box the
-        # two samples are counted one after the other)
-        p = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", str(k), "-i", *files, "-w", wd], capture_output=True, text=True, cwd=td)
+        # (the driver's default: every device the process sees, and two contexts on a device where two libraries fit side by side -- one library's
+        # files are read and written while the other one is counted; `devices` / `contexts` say what the run used)
+        p = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", str(k), "-i", *files, "-w", wd, "-v"], capture_output=True, text=True, cwd=td)
         dt = time.perf_counter() - t0
+        import re
+        mctx = re.search(r"libraries on (\d+) device contexts", p.stderr)
         if os.environ.get("MF_IO_TIMING"):
             print("\n".join(ln for ln in p.stderr.splitlines() if ln.startswith("[mf]")), file=sys.stderr)
         occ2 = 2 * mc * (rl - k + 1)
         if p.returncode == 0:
             out["cli"] = dict(value=round(occ2 / dt, 1), unit="k-mers/s", samples=2, reads_per_sample=mc, fasta_GB=round(2 * size2 / 1e9, 3), seconds=round(dt, 3),
-                              devices=min(2, max(1, torch.cuda.device_count())),
+                              devices=min(2, max(1, torch.cuda.device_count())), contexts=int(mctx.group(1)) if mctx else 1,
                               step_seconds=_log_steps(os.path.join(wd, "log")),
                               what="metafast.sh -k %d -i a.fa b.fa -w wd: matrix-builder, every step through the reference's files, process start included" % k)
         else:
@@ -293,6 +295,8 @@ def main():
     ap.add_argument("--e2e-reads", type=int, default=16_000_000, help="reads of the end-to-end line (FASTA file -> matrix)")
     ap.add_argument("--cli-reads", type=int, default=20_000_000, help="reads per sample of the metafast.sh line (two samples)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the end_to_end / cli keys")
+    ap.add_argument("-b", dest="bad_freq", type=int, default=1, help="maximal bad frequency (1: the reference's default; 5: the CAMI example, Example.md:18-21)")
+    ap.add_argument("-l", dest="min_len", type=int, default=100, help="minimal sequence length (100: default; 1200: the CAMI example)")
     ap.add_argument("--b1", type=int, default=1000)
     ap.add_argument("--b2", type=int, default=10000)
     args = ap.parse_args()
@@ -365,7 +369,7 @@ def main():
         torch.cuda.synchronize()
 
     def step(timings=None):
-        r = P.run_samples(ctx, samples(), k=k, b=1, l=100, b1=args.b1, b2=args.b2, device=device, timings=timings)
+        r = P.run_samples(ctx, samples(), k=k, b=args.bad_freq, l=args.min_len, b1=args.b1, b2=args.b2, device=device, timings=timings)
         nrec, rbytes = r["goods"][0].records()
         stats = dict(n_occ=r["n_occ"], n_distinct=r["n_distinct"], n_good=sum(len(g) for g in r["goods"]), n_unitigs=sum(len(q) for q in r["seqss"]),
                      n_cutter=len(r["cutter"]), n_cutter_occ=int(r["cutter"].occurrences()), n_components=len(r["comps"]), n_reads=n_reads * spg, n_bases=n_bases * spg,
@@ -473,7 +477,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": f"{world * spg} sample(s) x {n_reads} synthetic {rl} bp reads, k={k}, {spg} sample(s) per GPU, "
-                                   f"count+unitigs+components+features (b=1 l=100 b1={args.b1} b2={args.b2})",
+                                   f"count+unitigs+components+features (b={args.bad_freq} l={args.min_len} b1={args.b1} b2={args.b2})",
                        "reads_per_gpu": n_reads, "read_len": rl, "k": k, "genome_scale_bp": args.genome_scale,
                        "substitutions_per_base": round(sub16k / 16384, 5)},
             "roofline": roof(dom),

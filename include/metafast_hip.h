@@ -57,6 +57,7 @@ void mf_ctx_destroy(mf_ctx *ctx);
  * (src/tools/KmersCounterForManyFilesMain.java:80-108, SeqBuilderForManyFilesMain.java:82-94, FeaturesCalculatorMain.java:137-162);
  * a host that wants one library per GPU makes one context per device, each driven by a thread of its own. */
 int  mf_device_count(void);
+int  mf_device_memory(int device, uint64_t *total_bytes);
 int  mf_ctx_device(const mf_ctx *ctx);
 /* A context is used by ONE thread at a time; HIP's current device belongs to the thread, so a thread other than the one that made
  * the context calls this before its first call on it. */

@@ -213,7 +213,22 @@ static void parse_devices(Env &e, const Args &a) {
             i = j + 1;
         }
     } else if (a.has("device")) e.devs.push_back(a.geti("device", 0));
-    else { const int n = mf_device_count(); for (int d = 0; d < std::max(1, n); d++) e.devs.push_back(d); }
+    else {
+        const int n = std::max(1, mf_device_count());
+        for (int d = 0; d < n; d++) e.devs.push_back(d);
+        // Two contexts per device where the libraries are small next to its memory: while one library's files are read and written (the page
+        // cache takes 9 GB/s, a sample's .kmers.bin is as large as a third of its reads) the device counts the other one's.  A library needs
+        // about 8 x its read file in HBM at the peak of its count (reads + two record buffers + lists + table + index); two of the largest
+        // must fit in 0.8 of the device.  MF_CONTEXTS_PER_DEVICE=1 (or an explicit --devices / --device) switches it off.
+        size_t largest = 0, nlib = 0;
+        for (const char *opt : {"reads", "k-mers", "kmers"})
+            for (auto &f : a.list(opt)) { struct stat st; if (stat(f.c_str(), &st) == 0) { largest = std::max(largest, (size_t)st.st_size); nlib++; } }
+        const char *cpd = getenv("MF_CONTEXTS_PER_DEVICE");
+        uint64_t hbm = 0;
+        bool two = cpd ? atoi(cpd) >= 2 : false;
+        if (!cpd && nlib >= 2 * (size_t)n && mf_device_memory(0, &hbm) == MF_OK && hbm > 0 && (double)largest * 8.0 * 2.0 < 0.8 * (double)hbm) two = true;
+        if (two) for (int d = 0; d < n; d++) e.devs.push_back(d);
+    }
     e.ctxs.assign(e.devs.size(), nullptr);
 }
 static mf_ctx *ctx_of(Env &e, const Args &a) {
@@ -830,7 +845,7 @@ int main(int argc, char **argv) {
     if (a.has("tools")) { printf("Available tools:\n%s", TOOLS_TEXT); return 0; }
     if (a.has("help") || a.has("help-all")) {
         printf("Usage: metafast.sh [-t <tool>] [options]\n\nTools:\n%s\nLaunch options: -w/--work-dir <dir>  -p/--available-processors <n>  -c/--continue  --force  "
-               "-s/--start <step>  -f/--finish <step>  -v/--verbose  --devices <a,b,...> (default: all; the per-library steps run one library per device)  --device <n>\nTool options follow the reference (see SURVEY.md 8(b1)).\n", TOOLS_TEXT);
+               "-s/--start <step>  -f/--finish <step>  -v/--verbose  --devices <a,b,...> (default: every visible device, twice where two libraries fit side by side; the per-library steps run one library per entry)  --device <n>\nTool options follow the reference (see SURVEY.md 8(b1)).\n", TOOLS_TEXT);
         return 0;
     }
     static const char *KNOWN[] = {"kmer-counter", "kmer-counter-many", "seq-builder", "seq-builder-many", "component-cutter", "features-calculator",

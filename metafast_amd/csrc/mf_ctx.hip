@@ -43,6 +43,14 @@ extern "C" int mf_device_count(void) {
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
     return n;
 }
+// bytes of device memory (no context is made): what a host sizes its per-device concurrency by
+extern "C" int mf_device_memory(int device, uint64_t *total_bytes) {
+    if (!total_bytes) return mf_set_error("mf_device_memory: NULL argument");
+    hipDeviceProp_t prop;
+    MF_HIP(hipGetDeviceProperties(&prop, device));
+    *total_bytes = (uint64_t)prop.totalGlobalMem;
+    return MF_OK;
+}
 // HIP's current device is a property of the calling THREAD: a context made on one thread and then used from another (the driver's
 // per-device workers take turns over the steps of a run) is bound to the new thread first.  One calling thread at a time per context.
 extern "C" int mf_ctx_bind_thread(mf_ctx *ctx) {

@@ -1871,6 +1871,38 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
                                                  li == 1 ? &scal[6] : nullptr, li == 1 ? rebase : 0);
         }
         MF_DBG(ctx, "k_skm_split");
+        if (ctx->opt_verbose >= 2 && last) {
+            // What a ONE-pass split would have to cope with ("measure, do not argue"): its sub-partitions would be sized from a
+            // SAMPLE of the records (every 16th tile, as level 1 is) plus slack, and a record that finds its sub-partition full goes to an overflow
+            // list.  From the exact sizes at hand: the records that overflow, in expectation over the sample (n' ~ Binomial(n, 1/16) as a normal
+            // deviate, capacity = 16 n' (1 + slack) + 64), at 6 / 12 / 25 / 50 % slack.
+            std::vector<uint32_t> h(np2);
+            MF_HIP(hipMemcpyAsync(h.data(), olen.p, np2 * 4, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            double tot = 0, tot2 = 0, mx = 0;
+            for (uint32_t v : h) { tot += v; tot2 += (double)v * v; mx = std::max(mx, (double)v); }
+            const double mean = tot / (double)np2, sd = std::sqrt(std::max(0.0, tot2 / (double)np2 - mean * mean));
+            const double slack[4] = {0.06, 0.12, 0.25, 0.50};
+            double over[4] = {0, 0, 0, 0}, parts[4] = {0, 0, 0, 0}, room[4] = {0, 0, 0, 0};
+            for (uint32_t v : h) {
+                const double n = v, mu = n / 16.0, sg = std::sqrt(n / 16.0 * 15.0 / 16.0);
+                for (int q = 0; q < 4; q++) {
+                    // overflow = n - cap(n') where cap = 16 n' (1 + s) + 64; integrate over n' = mu + z sg on a grid of z
+                    double e = 0, pr = 0, rm = 0;
+                    for (int zi = -40; zi <= 40; zi++) {
+                        const double z = zi * 0.1, w = std::exp(-0.5 * z * z) * 0.1 / 2.5066282746;
+                        const double cap = std::max(0.0, 16.0 * (mu + z * sg) * (1.0 + slack[q]) + 64.0);
+                        if (n > cap) { e += w * (n - cap); pr += w; }
+                        rm += w * cap;
+                    }
+                    over[q] += e; parts[q] += pr; room[q] += rm;
+                }
+            }
+            fprintf(stderr, "[mf] skm split, one-pass what-if: %llu sub-partitions of %.0f records on average (sd %.0f, largest %.0f); sized from a 1/16 sample + slack:\n", (unsigned long long)np2, mean, sd, mx);
+            for (int q = 0; q < 4; q++)
+                fprintf(stderr, "[mf]     slack %2.0f %%: %.3f %% of the records overflow (%.0f records in %.0f sub-partitions), the regions take %.2f x the records\n", slack[q] * 100.0,
+                        100.0 * over[q] / std::max(tot, 1.0), over[q], parts[q], room[q] / std::max(tot, 1.0));
+        }
         bufA.swap(bufB);
         if (!last && bufB.owned) { spare.reset(); spare.swap(bufB); }        // (a borrowed level-1 buffer is the other slices' input too ...
         else if (!last && SH && last_of_shared && bufB.p == SH->buf.p) {    // ... unless this is the run's last slice: its third level writes there)

@@ -106,6 +106,7 @@ _SIGS = {
     "mf_reads_export": (i32, [vp, vp, vp]),
     "mf_ctx_stat": (i64, [vp, cp]),
     "mf_device_count": (i32, []),
+    "mf_device_memory": (i32, [i32, pu64]),
     "mf_ctx_device": (i32, [vp]),
     "mf_ctx_bind_thread": (i32, [vp]),
     "mf_synth_reads_device": (i32, [vp, u64, i32, u64, u64, i32, u64, vp, vp]),

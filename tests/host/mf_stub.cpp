@@ -28,5 +28,6 @@ int mf_features_selected(mf_ctx *, const char *, const char *, int, int, mf_tabl
 int mf_features_reads_selected(mf_ctx *, const char *, const char *const *, int, int, int, mf_table *, const char *, const char *) { return MF_ERR; }
 int mf_device_count(void) { return 2; }             /* (two entries: the driver's per-device workers run, and stop at mf_ctx_create) */
 int mf_ctx_bind_thread(mf_ctx *) { return MF_ERR; }
+int mf_device_memory(int, uint64_t *t) { if (t) *t = (uint64_t)288 << 30; return MF_OK; }
 int mf_bray_curtis(const int64_t *, int, int, double *) { return MF_ERR; }
 }

@@ -117,11 +117,16 @@ def test_cli_default_is_every_visible_device(gpu_ctx, tmp_path):
         p = tmp_path / ("d%d.fa" % s)
         _write_fasta(p, s, 5000)
         files.append(str(p))
+    # two small libraries: every visible device, and two contexts on each where two libraries fit side by side (one GPU: 2 contexts on it)
     r = _run_cli(tmp_path, tmp_path / "wd", files, ["-v"])
-    if torch.cuda.device_count() >= 2:
-        assert "2 libraries on 2 device contexts" in r.stderr
-    else:
-        assert "device contexts" not in r.stderr
+    assert "2 libraries on 2 device contexts" in r.stderr
+    env = dict(os.environ, MF_CONTEXTS_PER_DEVICE="1")
+    r = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", "21", "-l", "60", "-b1", "40", "-b2", "2000", "-i", *files, "-w", str(tmp_path / "wd1"), "-v"],
+                       capture_output=True, text=True, timeout=300, cwd=tmp_path, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert ("2 libraries on 2 device contexts" in r.stderr) == (torch.cuda.device_count() >= 2)
+    a, b = _result_files(tmp_path / "wd"), _result_files(tmp_path / "wd1")
+    assert a == b
     r = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-i", *files, "-w", str(tmp_path / "wd2"), "--devices", "0,99"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
     assert r.returncode == 1 and "device 99 out of range" in r.stderr
 
