@@ -26,6 +26,7 @@
 #include <unistd.h>
 #include <sys/stat.h>
 #include <atomic>
+#include <mutex>
 #include <thread>
 
 #define DP_T 256                           // threads per workgroup
@@ -535,7 +536,11 @@ int mf_ensure_pin_pool(mf_ctx *ctx, size_t want);
 // the file's bytes to d_raw as they are: W threads pread 8 MB pieces into their two staging chunks and copy them up
 // (copies from a mapping of the page cache instead of pread + staging were measured: 11 GB/s whatever the number of threads -- the runtime stages
 // a pageable source through its own buffers on the calling thread, page fault by page fault; gpurun_out/r05d_upload_rate.txt)
-static int dp_upload(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_raw) {
+// (one upload at a time per DEVICE: two contexts of a process that share a device -- the driver's two-contexts-per-device mode -- would halve each
+// other's PCIe rate and finish together; taking turns, the first one is counting and writing while the second one's bytes cross)
+static std::mutex g_upload_mutex[64];
+int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_raw) {
+    std::lock_guard<std::mutex> turn(g_upload_mutex[(unsigned)ctx->device & 63u]);
     const size_t PIECE = (size_t)std::max<int64_t>(ctx->opt_device_parse_piece, 1 << 16);
     const size_t np = (fsize + PIECE - 1) / PIECE;
     const size_t WMAX = (size_t)std::min<int64_t>(std::max<int64_t>(ctx->opt_device_parse_threads, 1), std::max(ctx->host_threads, 1));
@@ -595,7 +600,7 @@ int mf_dparse_file(mf_ctx *ctx, const char *path, int fmt, mf_buf<uint8_t> &base
     const uint64_t nc = (n + DP_CHUNK - 1) / DP_CHUNK;
     mf_buf<uint8_t> raw;
     if (raw.alloc(ctx, nc * DP_CHUNK + 64) != MF_OK) { close(fd); return 1; }
-    int rc = dp_upload(ctx, fd, n, raw.p);
+    int rc = mf_upload_file(ctx, fd, n, raw.p);
     close(fd);
     if (rc != 0) return rc;
     const double t1 = now();

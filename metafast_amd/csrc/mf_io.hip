@@ -113,7 +113,8 @@ static mf_file_entry *file_cache_get(mf_ctx *ctx, const char *path) {
     return nullptr;
 }
 
-#include "mf_parse.h"   // the host-side parsers (plain C++: also built under ASan / UBSan, tests/test_host_sanitized_cpu.py)
+#include "mf_parse.h"
+#include <sys/mman.h>   // the host-side parsers (plain C++: also built under ASan / UBSan, tests/test_host_sanitized_cpu.py)
 
 // ---- streaming reader for plain FASTA / FASTQ files: constant host memory, PCIe busy while the host parses --------------
 // The file is cut into pieces of SR_PIECE bytes (ends moved to the next record start, at most SR_SLACK further).  Up to 64
@@ -580,22 +581,36 @@ extern "C" int mf_table_load_kmers(mf_ctx *ctx, const char *const *files, int nf
             return rc;
         }
     }
-    std::vector<raw_file> raws((size_t)nfiles);
+    // the files' bytes go to HBM as they are (staged pieces, mf_upload_file) and are decoded there: no host copy of a file is made
+    std::vector<int> fds((size_t)nfiles, -1);
+    std::vector<size_t> fsz((size_t)nfiles, 0);
+    struct closer { std::vector<int> &f; ~closer() { for (int d : f) if (d >= 0) close(d); } } closer_{fds};
     uint64_t total = 0;
     for (int i = 0; i < nfiles; i++) {
-        MF_TRY(read_file_parallel(files[i], raws[(size_t)i], ctx->host_threads));
-        if (raws[(size_t)i].size() % 10) return mf_set_error("Can't load k-mers file '%s': size is not a multiple of the 10-byte record", files[i]);
-        total += raws[(size_t)i].size() / 10;
+        fds[(size_t)i] = open(files[i], O_RDONLY);
+        struct stat stf;
+        if (fds[(size_t)i] < 0 || fstat(fds[(size_t)i], &stf) != 0) return mf_set_error("can't open '%s'", files[i]);
+        fsz[(size_t)i] = (size_t)stf.st_size;
+        if (fsz[(size_t)i] % 10) return mf_set_error("Can't load k-mers file '%s': size is not a multiple of the 10-byte record", files[i]);
+        total += fsz[(size_t)i] / 10;
     }
-    tm.lap("read");
     mf_buf<uint64_t> dk; mf_buf<uint16_t> dc;
     MF_TRY(dk.alloc(ctx, total)); MF_TRY(dc.alloc(ctx, total));
     uint64_t at = 0;
     for (int i = 0; i < nfiles; i++) {
-        const uint64_t m = raws[(size_t)i].size() / 10;
+        const uint64_t m = fsz[(size_t)i] / 10;
         if (!m) continue;
         mf_buf<uint32_t> raw; MF_TRY(raw.alloc(ctx, (m * 10 + 3) / 4 + 1));
-        MF_HIP(hipMemcpyAsync(raw.p, raws[(size_t)i].data(), m * 10, hipMemcpyHostToDevice, ctx->stream));
+        int urc = mf_upload_file(ctx, fds[(size_t)i], m * 10, reinterpret_cast<uint8_t *>(raw.p));
+        if (urc == 1) {                                   // (no staging memory: the whole file through one host buffer)
+            raw_file rf;
+            MF_TRY(read_file_parallel(files[i], rf, ctx->host_threads));
+            if (rf.size() != m * 10) return mf_set_error("short read on '%s'", files[i]);
+            MF_HIP(hipMemcpyAsync(raw.p, rf.data(), m * 10, hipMemcpyHostToDevice, ctx->stream));
+            MF_HIP(hipStreamSynchronize(ctx->stream));
+            urc = 0;
+        }
+        if (urc < 0) return urc;
         k_records_decode<<<(unsigned)((m + REC_PER_BLOCK - 1) / REC_PER_BLOCK), REC_PER_BLOCK, 0, ctx->stream>>>(raw.p, m, freq_threshold, dk.p + at, dc.p + at);
         MF_HIP(hipStreamSynchronize(ctx->stream));
         at += m;
@@ -787,13 +802,24 @@ extern "C" int mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps *
     if (mf_file_entry *e = file_cache_get(ctx, components_bin)) {
         if (e->c) { e->c->refs++; *out = e->c; tm.lap("resident"); return MF_OK; }
     }
-    raw_file buf;
-    if (read_file_parallel(components_bin, buf, ctx->host_threads) < 0) return mf_set_error("Can't load components: file not found (%s)", components_bin);
-    const uint8_t *p = (const uint8_t *)buf.data();
-    const size_t n = buf.size();
+    // The host only walks the component headers (one every 12 + 8 x size bytes): through a mapping of the file, which touches one page per
+    // component; the file's bytes themselves go to HBM in staged pieces (mf_upload_file) and are decoded there.  (Reading the whole file into
+    // a host buffer first cost 80 - 140 ms for 0.24 GB: first-touch page faults, the copy, and giving the pages back.)
+    const int fd = open(components_bin, O_RDONLY);
+    struct stat stc;
+    if (fd < 0 || fstat(fd, &stc) != 0) { if (fd >= 0) close(fd); return mf_set_error("Can't load components: file not found (%s)", components_bin); }
+    struct fd_closer { int f; ~fd_closer() { close(f); } } fdc{fd};
+    const size_t n = (size_t)stc.st_size;
+    void *map = n ? mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0) : nullptr;
+    raw_file buf;                                         // (only where the file cannot be mapped)
+    if (n && map == MAP_FAILED) { map = nullptr; if (read_file_parallel(components_bin, buf, ctx->host_threads) < 0) return mf_set_error("Can't load components: file not found (%s)", components_bin); }
+    struct unmapper { void *m; size_t n; ~unmapper() { if (m) munmap(m, n); } } um{map, n};
+    tm.lap("open");
+    const uint8_t *p = map ? (const uint8_t *)map : (const uint8_t *)buf.data();
     std::unique_ptr<mf_comps, void (*)(mf_comps *)> C(new mf_comps(), [](mf_comps *c) { mf_comps_destroy(c); });
     std::vector<uint64_t> foff, koff;
     MF_TRY(comps_walk_headers(p, n, C->sizes, C->weights, foff, koff));          // (the host walks the headers only)
+    tm.lap("headers");
     const uint64_t cnt = C->sizes.size();
     C->ctx = ctx; C->k = 0; C->n = cnt;
     C->thr.assign(cnt, 0);
@@ -807,11 +833,18 @@ extern "C" int mf_comps_load(mf_ctx *ctx, const char *components_bin, mf_comps *
     if (nk) {
         mf_buf<uint32_t> raw; MF_TRY(raw.alloc(ctx, n / 4 + 2));
         mf_buf<uint64_t> dfo, dko; MF_TRY(dfo.alloc(ctx, cnt + 1)); MF_TRY(dko.alloc(ctx, cnt + 1));
-        MF_HIP(hipMemcpyAsync(raw.p, p, n, hipMemcpyHostToDevice, ctx->stream));
+        int urc = map ? mf_upload_file(ctx, fd, n, reinterpret_cast<uint8_t *>(raw.p)) : 1;
+        if (urc < 0) return urc;
+        if (urc == 1) {                                   // (no staging memory / no mapping: one pageable copy)
+            if (!buf.p && read_file_parallel(components_bin, buf, ctx->host_threads) < 0) return mf_set_error("Can't load components: file not found (%s)", components_bin);
+            MF_HIP(hipMemcpyAsync(raw.p, buf.data(), n, hipMemcpyHostToDevice, ctx->stream));
+        }
         MF_HIP(hipMemcpyAsync(dfo.p, foff.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
         MF_HIP(hipMemcpyAsync(dko.p, koff.data(), (cnt + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+        tm.lap("alloc+H2D");
         k_comps_decode<<<(unsigned)std::min<uint64_t>(cnt, 65535), 256, 0, ctx->stream>>>(raw.p, dfo.p, dko.p, (uint32_t)cnt, C->d_kmers, C->d_comp);
         MF_HIP(hipStreamSynchronize(ctx->stream));
+        tm.lap("decode");
     }
     C->host_ready = false;             // (member lists on the host: built from the device arrays when somebody asks)
     *out = C.release();
