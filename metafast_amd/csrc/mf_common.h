@@ -67,6 +67,7 @@ struct mf_ctx {
     double t_hipmalloc = 0; uint64_t n_hipmalloc = 0, b_hipmalloc = 0;   // seconds / calls / bytes inside hipMalloc (diagnostics: MF_IO_TIMING)
     bool pin_pool_pinned = false;                                  // (hipHostMalloc'ed; else plain page-aligned host memory, option host_pinned = 0)
     void *pin_pool = nullptr; size_t pin_pool_bytes = 0;           // pinned staging chunks of the streaming reader (lazy, kept)
+    void *up_pool = nullptr; size_t up_pool_bytes = 0; bool up_pool_pinned = false;   // staging chunks of mf_upload_file (mf_dparse.hip): small and PINNED (lazy, kept)
     int64_t opt_skm_slices = 0;    // digit-range slices of a counting run (0 = as many as the HBM budget asks for)
     int64_t opt_skm_dedupe = 1;    // k_skm_count: identical records of a unit are counted once, with their multiplicity (0 = every record for itself)
     int64_t opt_skm_shared = 1;    // slices behind one level 1 over all digits: 0 never, 1 when it fits, 2 whenever a run is sliced
@@ -83,7 +84,7 @@ struct mf_ctx {
     double last_pilot_rho = -1.0;
     double last_l1_per_occ = 0; int last_l1_k = 0;   // records (with padding) of the last run's level 1 per k-mer occurrence, for k = last_l1_k: the next sample's buffers are planned with it  // what the last pilot measured (diagnostics; < 0: none ran)
     int64_t opt_device_parse = 1;  // plain FASTA / FASTQ files are parsed on the device (mf_dparse.hip); files it is not sure about go to the host readers
-    int64_t opt_device_parse_piece = 16 << 20, opt_device_parse_threads = 16;   // upload: piece size and host threads (each owns two staging chunks of a piece)
+    int64_t opt_device_parse_piece = 8 << 20, opt_device_parse_threads = 8;   // upload: piece size and host threads (each owns two staging chunks of a piece)
     int64_t opt_device_parse_min = 1 << 20;   // ... from this size on (bytes): a small file is not worth the kernels' launches
     int64_t opt_host_pinned = 0;   // staging buffers of the file readers / writers: 1 = hipHostMalloc (0.16 - 0.29 s per GB to get, 0.1 s to give back), 0 = plain host memory (copies to and from it run at the same 56 GB/s on this platform: tools/pin_alloc.hip)
     int64_t opt_file_cache_gb = 0; // > 0: tables / components written to files stay in HBM (up to this many GB) and are handed out when the same file is loaded again

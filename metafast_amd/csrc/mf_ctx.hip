@@ -140,6 +140,7 @@ extern "C" void mf_ctx_destroy(mf_ctx *ctx) {
     for (auto &r : ctx->pending) { hipEventDestroy(r.a); hipEventDestroy(r.b); }
     for (auto ev : ctx->event_pool) hipEventDestroy(ev);
     if (ctx->pin_pool) { if (ctx->pin_pool_pinned) hipHostFree(ctx->pin_pool); else free(ctx->pin_pool); }
+    if (ctx->up_pool) { if (ctx->up_pool_pinned) hipHostFree(ctx->up_pool); else free(ctx->up_pool); }
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -545,14 +545,27 @@ int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_raw) {
     const size_t np = (fsize + PIECE - 1) / PIECE;
     const size_t WMAX = (size_t)std::min<int64_t>(std::max<int64_t>(ctx->opt_device_parse_threads, 1), std::max(ctx->host_threads, 1));
     const int W = (int)std::min<size_t>(WMAX, np);
-    if (mf_ensure_pin_pool(ctx, (size_t)2 * WMAX * PIECE) != MF_OK) return 1;
+    // staging: two chunks per thread, PINNED (the copies are then true DMA from where pread has put the bytes; from plain memory the runtime
+    // stages every byte a second time).  128 MB by default: hipHostMalloc takes ~30 ms for them once per context, and a short process -- the
+    // drop-in's -- is still ahead (first load of a 3 GB file 0.102 s against 0.116 - 0.135 s with plain chunks of any size: profiles/r05j_upload_rate.txt).
+    const size_t want = (size_t)2 * WMAX * PIECE;
+    if (ctx->up_pool_bytes < want) {
+        if (ctx->up_pool) { if (ctx->up_pool_pinned) hipHostFree(ctx->up_pool); else free(ctx->up_pool); ctx->up_pool = nullptr; ctx->up_pool_bytes = 0; }
+        if (hipHostMalloc(&ctx->up_pool, want, hipHostMallocDefault) == hipSuccess) ctx->up_pool_pinned = true;
+        else {
+            (void)hipGetLastError();
+            ctx->up_pool = nullptr; ctx->up_pool_pinned = false;
+            if (posix_memalign(&ctx->up_pool, 2 << 20, want) != 0) { ctx->up_pool = nullptr; return 1; }
+        }
+        ctx->up_pool_bytes = want;
+    }
     std::atomic<size_t> next{0};
     std::atomic<int> state{0};
     std::vector<std::thread> th;
     for (int w = 0; w < W; w++)
         th.emplace_back([&, w]() {
             (void)hipSetDevice(ctx->device);
-            uint8_t *pin[2] = {(uint8_t *)ctx->pin_pool + (size_t)(2 * w) * PIECE, (uint8_t *)ctx->pin_pool + (size_t)(2 * w + 1) * PIECE};
+            uint8_t *pin[2] = {(uint8_t *)ctx->up_pool + (size_t)(2 * w) * PIECE, (uint8_t *)ctx->up_pool + (size_t)(2 * w + 1) * PIECE};
             hipEvent_t ev[2]; bool busy[2] = {false, false};
             (void)hipEventCreateWithFlags(&ev[0], hipEventDisableTiming); (void)hipEventCreateWithFlags(&ev[1], hipEventDisableTiming);
             int cur = 0;

@@ -12,21 +12,23 @@ out[:, :3] = np.frombuffer(b">r\n", dtype=np.uint8); out[:, 3:153] = b.reshape(n
 out.tofile(path); del out
 sz = os.path.getsize(path)
 import ctypes as C
-for name, opts in (("8 MB x 32", dict(device_parse_piece_bytes=8 << 20, device_parse_threads=32)), ("4 MB x 32", dict(device_parse_piece_bytes=4 << 20, device_parse_threads=32)),
-                   ("8 MB x 16", dict(device_parse_piece_bytes=8 << 20, device_parse_threads=16)), ("16 MB x 16", dict(device_parse_piece_bytes=16 << 20, device_parse_threads=16)),
-                   ("4 MB x 64", dict(device_parse_piece_bytes=4 << 20, device_parse_threads=64)), ("2 MB x 64", dict(device_parse_piece_bytes=2 << 20, device_parse_threads=64)),
-                   ("pinned 4 MB x 16", dict(host_pinned=1, device_parse_piece_bytes=4 << 20, device_parse_threads=16)),
+ctx.close()
+for name, opts in (("16 MB x 16", dict(device_parse_piece_bytes=16 << 20, device_parse_threads=16)), ("8 MB x 16", dict(device_parse_piece_bytes=8 << 20, device_parse_threads=16)),
+                   ("8 MB x 12", dict(device_parse_piece_bytes=8 << 20, device_parse_threads=12)), ("8 MB x 8", dict(device_parse_piece_bytes=8 << 20, device_parse_threads=8)),
+                   ("4 MB x 16", dict(device_parse_piece_bytes=4 << 20, device_parse_threads=16)), ("4 MB x 8", dict(device_parse_piece_bytes=4 << 20, device_parse_threads=8)),
+                   ("16 MB x 8", dict(device_parse_piece_bytes=16 << 20, device_parse_threads=8)),
                    ("pinned 8 MB x 8", dict(host_pinned=1, device_parse_piece_bytes=8 << 20, device_parse_threads=8)),
-                   ("host parser", dict(host_pinned=0, device_parse=0))):
-    ctx.set_option("device_parse", 1)
+                   ("host parser", dict(device_parse=0))):
+    ctx = L.Context(0, stream=torch.cuda.current_stream())        # (a context of its own: the FIRST load pays for the staging pool's pages, as a short process does)
     for k, v in opts.items():
         ctx.set_option(k, v)
-    best = 1e9
+    ts = []
     for rep in range(3):
         h = C.c_void_p()
         t0 = time.perf_counter()
         L._check(L.lib().mf_reads_load(ctx.h, L._cfiles([path]), 1, C.byref(h)))
         ctx.synchronize()
-        best = min(best, time.perf_counter() - t0)
+        ts.append(time.perf_counter() - t0)
         L.lib().mf_reads_destroy(h)
-    print(f"{name:14s}: {sz/1e9:.2f} GB FASTA -> reads in HBM in {best:.3f} s = {sz/best/1e9:.1f} GB/s", flush=True)
+    print(f"{name:16s}: {sz/1e9:.2f} GB FASTA -> reads in HBM: first load {ts[0]:.3f} s = {sz/ts[0]/1e9:.1f} GB/s, then {min(ts[1:]):.3f} s = {sz/min(ts[1:])/1e9:.1f} GB/s", flush=True)
+    ctx.close()
