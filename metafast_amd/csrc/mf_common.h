@@ -365,7 +365,9 @@ __device__ __forceinline__ uint32_t mf_block_reserve(unsigned int *counter, uint
 // Consecutive k-mers of a read mostly share it, so a read is cut into a few super-k-mers (runs of k-mers with one
 // minimizer) that travel through the radix passes as ONE 16-byte record instead of 8 bytes per k-mer, and graph
 // neighbours mostly live in the same partition.  Orientation-independent: rc(x) has the reverse-complemented M-mers.
-#define MF_SKM_M 15
+#ifndef MF_SKM_M
+#define MF_SKM_M 15          // (an experimental build may set another length: make EXTRA="-DMF_SKM_M=13" -- then only k <= 29 takes the super-k-mer path)
+#endif
 #define MF_SKM_MIN_K 20           // shorter k: too few M-mers per k-mer for runs worth packing -> one-record-per-k-mer path
 #define MF_SKM_BASES 50           // bases a record can hold: x = bases 0..31, y = bases 32..49 | 22 digit bits | 6-bit k-mer count
 __device__ __forceinline__ uint32_t mf_mmer_rc(uint32_t f) {      // reverse complement of a 2*MF_SKM_M-bit M-mer

@@ -2203,9 +2203,14 @@ int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const ui
 #define SKM_CASE(KK) case KK: rc = skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, adaptive, table_bits, scal, thr, n_all, out); break;
 #ifndef MF_SKM_ONLY_K31              /* (a quick look at one instantiation's code: hipcc -DMF_SKM_ONLY_K31 -S) */
         SKM_CASE(20) SKM_CASE(21) SKM_CASE(22) SKM_CASE(23) SKM_CASE(24) SKM_CASE(25)
-        SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29) SKM_CASE(30)
+        SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29)
+#if MF_SKM_M >= 15
+        SKM_CASE(30)
 #endif
+#endif
+#if MF_SKM_M >= 15
         SKM_CASE(31)
+#endif
 #undef SKM_CASE
         default: return MF_SKM_FALLBACK;
     }
