@@ -36,7 +36,7 @@ __global__ void k_cc_adjacency(mf_index_view ix, const uint64_t *__restrict__ ke
     for (uint32_t nuc = 0; nuc < 4; nuc++) {
         uint32_t idx, val;
         uint64_t y = ((x << 2) | nuc) & kmask;
-        out[2 * nuc] = mf_index_find_ph(ix, mf_canon(y, k), ix.skm_k ? mf_skm_ph_right(y, m_nf) : 0u, &idx, &val) ? idx : CC_NONE;
+        out[2 * nuc] = mf_index_find_ph(ix, mf_canon(y, k), ix.skm_k ? mf_skm_ph_right(y, k, m_nf) : 0u, &idx, &val) ? idx : CC_NONE;
         y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2));
         out[2 * nuc + 1] = mf_index_find_ph(ix, mf_canon(y, k), ix.skm_k ? mf_skm_ph_left(y, k, m_nl) : 0u, &idx, &val) ? idx : CC_NONE;
     }

@@ -365,33 +365,44 @@ __device__ __forceinline__ uint32_t mf_block_reserve(unsigned int *counter, uint
 // Consecutive k-mers of a read mostly share it, so a read is cut into a few super-k-mers (runs of k-mers with one
 // minimizer) that travel through the radix passes as ONE 16-byte record instead of 8 bytes per k-mer, and graph
 // neighbours mostly live in the same partition.  Orientation-independent: rc(x) has the reverse-complemented M-mers.
-#ifndef MF_SKM_M
-#define MF_SKM_M 15          // (an experimental build may set another length: make EXTRA="-DMF_SKM_M=13" -- then only k <= 29 takes the super-k-mer path)
+// The minimizer length follows k (round 5): M = 13 for k <= 25, M = 15 above.  A k-mer has k - M + 1 M-mers; the fewer, the shorter the runs of
+// k-mers that share a minimizer (more records per k-mer occurrence) and the more often a graph neighbour lives in another partition (2 in
+// k - M + 2: 25 % at k = 21 with M = 15, 20 % with M = 13 -- tools/nbr_locality.py, profiles/r05h_nbr_locality.txt).  Measured on 50 M reads,
+// whole step (profiles/r05m_minimizer_length.txt): k = 21: 148.9 -> 127.6 ms, k = 23: 126.2 -> 117.7, k = 25: 116.6 -> 105.5 with M = 13; k = 27:
+// 99.6 -> 101.2, k = 29: 95.1 -> 102.5 (too few distinct M-mers per partition: units overflow the LDS table and are counted in several
+// passes); M = 11 loses everywhere (k_skm_count 68 - 125 ms instead of 20).  -DMF_SKM_M=<n> fixes one length for every k (experiments).
+#ifdef MF_SKM_M
+__host__ __device__ constexpr int mf_skm_m(int) { return MF_SKM_M; }
+#else
+__host__ __device__ constexpr int mf_skm_m(int k) { return k <= 25 ? 13 : 15; }
 #endif
 #define MF_SKM_MIN_K 20           // shorter k: too few M-mers per k-mer for runs worth packing -> one-record-per-k-mer path
 #define MF_SKM_BASES 50           // bases a record can hold: x = bases 0..31, y = bases 32..49 | 22 digit bits | 6-bit k-mer count
-__device__ __forceinline__ uint32_t mf_mmer_rc(uint32_t f) {      // reverse complement of a 2*MF_SKM_M-bit M-mer
+__device__ __forceinline__ uint32_t mf_mmer_rc(uint32_t f, int M) {      // reverse complement of a 2 M-bit M-mer
     uint32_t r = __brev(~f);
     r = ((r & 0xAAAAAAAAu) >> 1) | ((r & 0x55555555u) << 1);
-    return r >> (32 - 2 * MF_SKM_M);
+    return r >> (32 - 2 * M);
 }
 // The seed keeps low-complexity M-mers away from the bottom of the order: with a plain multiply A..A hashes to 0, the
 // global minimum, so EVERY k-mer that touches a poly-A / poly-T stretch would meet in one partition (hundreds of thousands
 // of distinct k-mers in real reads: the LDS table overflows).  0x051E6720 puts all 38 canonical repeats of period 1-3
-// (homopolymers, di- and trinucleotide microsatellites) above the 77th percentile, so they are almost never the minimum.
+// (homopolymers, di- and trinucleotide microsatellites) of length 15 above the 77th percentile, 0x00B9107F those of length 13 above the
+// 73rd (with the 15-mers' seed the worst 13-mer repeat sits at the 2nd percentile), so they are almost never the minimum.
 // (No xor-shift after the multiply: the hash only ORDERS the M-mers, and the order is decided by the well-mixed top bits.)
-__device__ __forceinline__ uint32_t mf_mmer_hash(uint32_t canon) { return (canon ^ 0x051E6720u) * 0x9E3779B1u; }
+__host__ __device__ constexpr uint32_t mf_mmer_seed(int M) { return M == 13 ? 0x00B9107Fu : 0x051E6720u; }
+__device__ __forceinline__ uint32_t mf_mmer_hash(uint32_t canon, int M) { return (canon ^ mf_mmer_seed(M)) * 0x9E3779B1u; }
 // minimizer hash -> partition hash (the minimum of several uniform values is not uniform: mix again)
 __device__ __forceinline__ uint32_t mf_remix32(uint32_t h) { h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; return h ^ (h >> 16); }
 __device__ __forceinline__ uint32_t mf_skm_ph(uint64_t key, int k) {
-    const uint32_t mm = (1u << (2 * MF_SKM_M)) - 1u;
-    uint32_t f = (uint32_t)(key >> (2 * (k - MF_SKM_M))) & mm, r = mf_mmer_rc(f);
-    uint32_t best = mf_mmer_hash(f < r ? f : r);
-    for (int j = k - MF_SKM_M - 1; j >= 0; j--) {
+    const int M = mf_skm_m(k);
+    const uint32_t mm = (1u << (2 * M)) - 1u;
+    uint32_t f = (uint32_t)(key >> (2 * (k - M))) & mm, r = mf_mmer_rc(f, M);
+    uint32_t best = mf_mmer_hash(f < r ? f : r, M);
+    for (int j = k - M - 1; j >= 0; j--) {
         const uint32_t b = (uint32_t)(key >> (2 * j)) & 3u;
         f = ((f << 2) | b) & mm;
-        r = (r >> 2) | ((3u - b) << (2 * MF_SKM_M - 2));
-        const uint32_t h = mf_mmer_hash(f < r ? f : r);
+        r = (r >> 2) | ((3u - b) << (2 * M - 2));
+        const uint32_t h = mf_mmer_hash(f < r ? f : r, M);
         best = h < best ? h : best;
     }
     return mf_remix32(best);
@@ -400,15 +411,16 @@ __device__ __forceinline__ uint32_t mf_skm_ph(uint64_t key, int k) {
 // smallest M-mer hash of x without its first M-mer (right neighbours drop it) and without its last (left neighbours).
 // (*own: the k-mer's own minimizer hash, before the re-mix: equal minimizer hashes mean equal partitions)
 __device__ __forceinline__ void mf_skm_nbr_mins(uint64_t x, int k, uint32_t *no_first, uint32_t *no_last, uint32_t *own = nullptr) {
-    const uint32_t mm = (1u << (2 * MF_SKM_M)) - 1u;
-    uint32_t f = (uint32_t)(x >> (2 * (k - MF_SKM_M))) & mm, r = mf_mmer_rc(f);
-    uint32_t h = mf_mmer_hash(f < r ? f : r);
+    const int M = mf_skm_m(k);
+    const uint32_t mm = (1u << (2 * M)) - 1u;
+    uint32_t f = (uint32_t)(x >> (2 * (k - M))) & mm, r = mf_mmer_rc(f, M);
+    uint32_t h = mf_mmer_hash(f < r ? f : r, M);
     uint32_t a = 0xFFFFFFFFu, b = h;
-    for (int j = k - MF_SKM_M - 1; j >= 0; j--) {
+    for (int j = k - M - 1; j >= 0; j--) {
         const uint32_t c = (uint32_t)(x >> (2 * j)) & 3u;
         f = ((f << 2) | c) & mm;
-        r = (r >> 2) | ((3u - c) << (2 * MF_SKM_M - 2));
-        h = mf_mmer_hash(f < r ? f : r);
+        r = (r >> 2) | ((3u - c) << (2 * M - 2));
+        h = mf_mmer_hash(f < r ? f : r, M);
         a = h < a ? h : a;
         if (j > 0) b = h < b ? h : b;
     }
@@ -417,17 +429,19 @@ __device__ __forceinline__ void mf_skm_nbr_mins(uint64_t x, int k, uint32_t *no_
 }
 // partition hash of the neighbour y = x[1..]+c (right) / c+x[..k-2] (left) from the matching minimum of x
 // (_mn: the neighbour's minimizer hash itself; the partition hash is its re-mix)
-__device__ __forceinline__ uint32_t mf_skm_mn_right(uint64_t y, uint32_t no_first_of_x) {
-    const uint32_t f = (uint32_t)y & ((1u << (2 * MF_SKM_M)) - 1u), r = mf_mmer_rc(f);
-    const uint32_t h = mf_mmer_hash(f < r ? f : r);
+__device__ __forceinline__ uint32_t mf_skm_mn_right(uint64_t y, int k, uint32_t no_first_of_x) {
+    const int M = mf_skm_m(k);
+    const uint32_t f = (uint32_t)y & ((1u << (2 * M)) - 1u), r = mf_mmer_rc(f, M);
+    const uint32_t h = mf_mmer_hash(f < r ? f : r, M);
     return h < no_first_of_x ? h : no_first_of_x;
 }
 __device__ __forceinline__ uint32_t mf_skm_mn_left(uint64_t y, int k, uint32_t no_last_of_x) {
-    const uint32_t f = (uint32_t)(y >> (2 * (k - MF_SKM_M))) & ((1u << (2 * MF_SKM_M)) - 1u), r = mf_mmer_rc(f);
-    const uint32_t h = mf_mmer_hash(f < r ? f : r);
+    const int M = mf_skm_m(k);
+    const uint32_t f = (uint32_t)(y >> (2 * (k - M))) & ((1u << (2 * M)) - 1u), r = mf_mmer_rc(f, M);
+    const uint32_t h = mf_mmer_hash(f < r ? f : r, M);
     return h < no_last_of_x ? h : no_last_of_x;
 }
-__device__ __forceinline__ uint32_t mf_skm_ph_right(uint64_t y, uint32_t no_first_of_x) { return mf_remix32(mf_skm_mn_right(y, no_first_of_x)); }
+__device__ __forceinline__ uint32_t mf_skm_ph_right(uint64_t y, int k, uint32_t no_first_of_x) { return mf_remix32(mf_skm_mn_right(y, k, no_first_of_x)); }
 __device__ __forceinline__ uint32_t mf_skm_ph_left(uint64_t y, int k, uint32_t no_last_of_x) { return mf_remix32(mf_skm_mn_left(y, k, no_last_of_x)); }
 struct mf_slot { uint64_t key; uint32_t idx; uint32_t val; };
 // ascending (key, value) order (mf_sort.hip); select + sort of a table's entries with count > threshold (mf_table.hip)

@@ -48,7 +48,7 @@ __device__ __forceinline__ uint64_t nb_neighbour(uint64_t x, uint64_t rcx, int k
     const uint32_t nuc = i >> 1;
     uint64_t y, r;
     if (i & 1u) { y = (x >> 2) | ((uint64_t)nuc << (2 * k - 2)); r = ((rcx << 2) | (uint64_t)(3u - nuc)) & kmask; *ph = mf_skm_ph_left(y, k, m_nl); }
-    else { y = ((x << 2) | nuc) & kmask; r = (rcx >> 2) | ((uint64_t)(3u - nuc) << (2 * k - 2)); *ph = mf_skm_ph_right(y, m_nf); }
+    else { y = ((x << 2) | nuc) & kmask; r = (rcx >> 2) | ((uint64_t)(3u - nuc) << (2 * k - 2)); *ph = mf_skm_ph_right(y, k, m_nf); }
     *oriented = y;
     return y < r ? y : r;
 }
@@ -135,15 +135,16 @@ __device__ __forceinline__ void nb_for_each(const mf_index_view &ix, const uint6
             uint32_t remote = 0, foreign = 0, flip = 0;
             uint32_t phs[8];
             const uint64_t rcx = mf_revcomp(x, k);
-            constexpr uint32_t MM = (1u << (2 * MF_SKM_M)) - 1u;
+            const int M = mf_skm_m(k);
+            const uint32_t MM = (1u << (2 * M)) - 1u;
 #pragma unroll
             for (uint32_t i = 0; i < 8; i++) {
                 // the neighbour's minimizer hash from x's minima and the ONE M-mer it has that x has not: its last (right side: x's last
                 // M-1 bases + the new one) or its first (left side); re-mixed only where a partition hash is needed.  (Neither the
                 // neighbour nor its canonical form is built here: a walk compares stored keys with x's own k-1 bases.)
                 const uint32_t nuc = i >> 1;
-                const uint32_t f = (i & 1u) ? (((uint32_t)(x >> (2 * (k - MF_SKM_M) + 2)) & (MM >> 2)) | (nuc << (2 * MF_SKM_M - 2))) : ((((uint32_t)x << 2) | nuc) & MM);
-                const uint32_t r = mf_mmer_rc(f), h = mf_mmer_hash(f < r ? f : r), mo = (i & 1u) ? m_nl : m_nf;
+                const uint32_t f = (i & 1u) ? (((uint32_t)(x >> (2 * (k - M) + 2)) & (MM >> 2)) | (nuc << (2 * M - 2))) : ((((uint32_t)x << 2) | nuc) & MM);
+                const uint32_t r = mf_mmer_rc(f, M), h = mf_mmer_hash(f < r ? f : r, M), mo = (i & 1u) ? m_nl : m_nf;
                 phs[i] = h < mo ? h : mo;
                 // the same minimizer = the same partition; another minimizer that lands in this partition all the same (one in
                 // 2^part_bits) is simply looked up through the index

@@ -46,7 +46,7 @@ __device__ __forceinline__ uint32_t skm_rec_digits(const skm_rec &r) { return (u
 // one lane = one 32-position word of the base stream: minimizer hash of each of its 32 k-mers, run starts
 // =============================================================================================
 template <int K> struct skm_word {
-    static constexpr int W = K - MF_SKM_M + 1;          // M-mers per k-mer
+    static constexpr int W = K - mf_skm_m(K) + 1;       // M-mers per k-mer
     static constexpr int NM = 31 + W;                   // M-mers of the word's 32 k-mers
     static constexpr int RMAX = (MF_SKM_BASES - (K - 1)) < 20 ? (MF_SKM_BASES - (K - 1)) : 20;   // k-mers per record (<= 10 items of 2 in k_skm_count)
     uint32_t D[4];        // 64 bases from the word's first position, 2 bits each, first base in the top bits of D[0]
@@ -87,7 +87,7 @@ __device__ __forceinline__ void skm_scan_tail(skm_word<K> &S, uint32_t (&hs)[skm
 
 template <int K>
 __device__ __forceinline__ void skm_scan_word(skm_word<K> &S, const uint8_t *__restrict__ bases, uint64_t n_bases, uint64_t w, uint32_t m) {
-    constexpr int NM = skm_word<K>::NM, M = MF_SKM_M;
+    constexpr int NM = skm_word<K>::NM, M = mf_skm_m(K);
     // four unconditional 16-byte loads (a guarded `cond ? p[i] : zero` compiles to sixteen predicated dword loads); chunks
     // that start beyond the buffer are re-pointed at the first one and zeroed afterwards
     const uint64_t b0 = w * 32;
@@ -103,8 +103,8 @@ __device__ __forceinline__ void skm_scan_word(skm_word<K> &S, const uint8_t *__r
         const int q = i >> 4, o = i & 15;       // bases i .. i+M-1 start in dword q at base offset o
         const uint32_t top = o ? __builtin_amdgcn_alignbit(S.D[q], S.D[q + 1 < 4 ? q + 1 : 3], 32 - 2 * o) : S.D[q];
         const uint32_t f = top >> (32 - 2 * M);
-        r = (i == 0) ? mf_mmer_rc(f) : ((r >> 2) | ((3u - (f & 3u)) << (2 * M - 2)));
-        hs[i] = mf_mmer_hash(f < r ? f : r);
+        r = (i == 0) ? mf_mmer_rc(f, M) : ((r >> 2) | ((3u - (f & 3u)) << (2 * M - 2)));
+        hs[i] = mf_mmer_hash(f < r ? f : r, M);
     }
     skm_scan_tail<K>(S, hs, m);
 }
@@ -121,7 +121,7 @@ __device__ __forceinline__ uint32_t skm_from_prev_lane(uint32_t v) {          //
 }
 template <int K>
 __device__ __forceinline__ void skm_scan_word_halo(skm_word<K> &S, const uint8_t *__restrict__ bases, uint64_t n_bases, uint64_t w, uint32_t m) {
-    constexpr int NM = skm_word<K>::NM, M = MF_SKM_M;
+    constexpr int NM = skm_word<K>::NM, M = mf_skm_m(K);
     const uint64_t b0 = w * 32;
     const uint4 *p = reinterpret_cast<const uint4 *>(bases + (b0 < n_bases ? b0 : 0));
     const bool in1 = b0 + 16 < n_bases;
@@ -136,8 +136,8 @@ __device__ __forceinline__ void skm_scan_word_halo(skm_word<K> &S, const uint8_t
         const int q = i >> 4, o = i & 15;       // bases i .. i+M-1 start in dword q at base offset o
         const uint32_t top = o ? __builtin_amdgcn_alignbit(S.D[q], S.D[q + 1], 32 - 2 * o) : S.D[q];
         const uint32_t f = top >> (32 - 2 * M);
-        r = (i == 0) ? mf_mmer_rc(f) : ((r >> 2) | ((3u - (f & 3u)) << (2 * M - 2)));
-        hs[i] = mf_mmer_hash(f < r ? f : r);
+        r = (i == 0) ? mf_mmer_rc(f, M) : ((r >> 2) | ((3u - (f & 3u)) << (2 * M - 2)));
+        hs[i] = mf_mmer_hash(f < r ? f : r, M);
     }
 #pragma unroll
     for (int i = 32; i < NM; i++) hs[i] = skm_from_next_lane(hs[i - 32]);
@@ -2085,7 +2085,7 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
             // batch's ratio, so it rarely grows twice) - room for a batch of temporary lists (they adapt: more batches)
             const double avail = ((double)fr + (double)mf_arena_idle(ctx)) * 0.96 - (double)n_occ * (kthr >= 1 ? 0.04 : 0.10) * 10.0 * 1.3 - (double)tot * 0.05;
             // records: a minimizer run is (K - M + 2) / 2 k-mers long where reads and the record format do not cut it shorter
-            const double run = std::min<double>((K - MF_SKM_M + 2) / 2.0, (double)skm_word<K>::RMAX) * 0.78;
+            const double run = std::min<double>((K - mf_skm_m(K) + 2) / 2.0, (double)skm_word<K>::RMAX) * 0.78;
             const double full = (double)n_occ / run * 16.0 * 1.10;
             const double nb = lv.size() >= 3 ? 2.0 : 1.0;
             auto need = [&](uint32_t s2) { return full * (1.0 + nb * 1.15 / s2); };
@@ -2194,23 +2194,24 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     }
 }
 
+// (a k-mer length whose window of M-mers the scan is not built for -- 3 <= k - M + 1 <= 17: the sliding minimum and the halo of 16 M-mers a
+// lane takes from the next one -- goes to the one-record-per-k-mer path)
+template <int K, typename... A> static int skm_run_if(A &&... a) {
+    if constexpr (K - mf_skm_m(K) + 1 >= 3 && K - mf_skm_m(K) + 1 <= 17) return skm_run<K>(std::forward<A>(a)...);
+    else return MF_SKM_FALLBACK;
+}
 // adaptive: the plan was made from the number of occurrences alone -- the levels after the first may be re-planned from a pilot
 // table_bits: partition bits the caller wants the TABLE to have (0: one more than the counting plan's)
 int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
                  int k, const std::vector<int> &lv, bool adaptive, int table_bits, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
     int rc = MF_SKM_FALLBACK;
     switch (k) {
-#define SKM_CASE(KK) case KK: rc = skm_run<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, adaptive, table_bits, scal, thr, n_all, out); break;
+#define SKM_CASE(KK) case KK: rc = skm_run_if<KK>(ctx, d_bases, n_bases, vmask, n_words, n_occ, lv, adaptive, table_bits, scal, thr, n_all, out); break;
 #ifndef MF_SKM_ONLY_K31              /* (a quick look at one instantiation's code: hipcc -DMF_SKM_ONLY_K31 -S) */
         SKM_CASE(20) SKM_CASE(21) SKM_CASE(22) SKM_CASE(23) SKM_CASE(24) SKM_CASE(25)
-        SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29)
-#if MF_SKM_M >= 15
-        SKM_CASE(30)
+        SKM_CASE(26) SKM_CASE(27) SKM_CASE(28) SKM_CASE(29) SKM_CASE(30)
 #endif
-#endif
-#if MF_SKM_M >= 15
         SKM_CASE(31)
-#endif
 #undef SKM_CASE
         default: return MF_SKM_FALLBACK;
     }

@@ -60,7 +60,7 @@ __global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
         uint64_t ry = mf_revcomp(y, k);
         uint64_t c = y < ry ? y : ry;
         uint32_t idx, val;
-        if (mf_index_find_ph(ix, c, ix.skm_k ? mf_skm_ph_right(y, m_nf) : 0u, &idx, &val)) {
+        if (mf_index_find_ph(ix, c, ix.skm_k ? mf_skm_ph_right(y, k, m_nf) : 0u, &idx, &val)) {
             if (rcode == UT_CODE_NONE) { rcode = nuc; ridx = idx; ror = (c != y); }
             else rcode = UT_CODE_MANY;
         }
