@@ -370,7 +370,7 @@ __device__ __forceinline__ uint32_t mf_block_reserve(unsigned int *counter, uint
 // k - M + 2: 25 % at k = 21 with M = 15, 20 % with M = 13 -- tools/nbr_locality.py, profiles/r05h_nbr_locality.txt).  Measured on 50 M reads,
 // whole step (profiles/r05m_minimizer_length.txt): k = 21: 148.9 -> 127.6 ms, k = 23: 126.2 -> 117.7, k = 25: 116.6 -> 105.5 with M = 13; k = 27:
 // 99.6 -> 101.2, k = 29: 95.1 -> 102.5 (too few distinct M-mers per partition: units overflow the LDS table and are counted in several
-// passes); M = 11 loses everywhere (k_skm_count 68 - 125 ms instead of 20).  -DMF_SKM_M=<n> fixes one length for every k (experiments).
+// passes); M = 11 loses everywhere (k_skm_count 68 - 125 ms instead of 20); M = 14 is within 1.6 % of 15 for k = 27 ... 30.  -DMF_SKM_M=<n> fixes one length for every k (experiments).
 #ifdef MF_SKM_M
 __host__ __device__ constexpr int mf_skm_m(int) { return MF_SKM_M; }
 #else
