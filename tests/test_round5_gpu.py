@@ -393,3 +393,28 @@ def test_device_parser_steps_back(gpu_ctx, oracle, tmp_path):
         gpu_ctx.set_option("device_parse", 1)
         gpu_ctx.set_option("profile", 0)
         gpu_ctx.set_option("device_parse_min_bytes", 1 << 20)
+
+
+@pytest.mark.parametrize("k", [21, 23, 25])
+def test_low_complexity_reads_with_the_short_minimizer(gpu_ctx, oracle, k):
+    """k <= 25 takes 13-mers as minimizers (mf_skm_m), with their own hash seed: homopolymer and microsatellite stretches between random flanks --
+    thousands of distinct k-mers around a few low-complexity M-mers -- are counted exactly (heavy partitions in several passes or through the
+    k-mer path), and lookups find them"""
+    rng = np.random.default_rng(100 + k)
+    n_reads = 30000
+    lut = np.frombuffer(b"AGCT", dtype=np.uint8)
+    fl = lut[rng.integers(0, 4, size=(n_reads, 90))]
+    units = [b"A", b"T", b"AC", b"AG", b"ACG", b"AAT", b"C", b"GT"]
+    mids = np.stack([np.frombuffer((units[i % len(units)] * 30)[:24], dtype=np.uint8) for i in range(n_reads)])
+    arr = np.concatenate([fl[:, :45], mids, fl[:, 45:]], axis=1)
+    b = np.concatenate([arr.reshape(-1), np.zeros(64, dtype=np.uint8)])
+    o = np.arange(n_reads + 1, dtype=np.uint64) * np.uint64(arr.shape[1])
+    from util import to_device
+    tb, to = to_device(b[: n_reads * arr.shape[1]], o)
+    t = gpu_ctx.count_device(tb.data_ptr(), to.data_ptr(), n_reads, int(o[-1]), k, 0)
+    gk, gc = t.export()
+    ok, ov = oracle.Table().count_buffer(b[: n_reads * arr.shape[1]], o, k).export()
+    assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+    pick = rng.choice(len(ok), size=3000, replace=False)
+    got = t.lookup(np.concatenate([ok[pick], rng.integers(0, 1 << (2 * k), size=300, dtype=np.uint64) | np.uint64(1 << 62)]))
+    assert np.array_equal(got[:3000], ov[pick]) and np.all(got[3000:] == -1)
