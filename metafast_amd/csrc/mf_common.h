@@ -80,7 +80,7 @@ struct mf_ctx {
     int64_t opt_skm_dynq = 1;      // k_skm_count: units handed out from a counter as the workgroups get to them (0: fixed stride)
     int64_t opt_part_good = 220;   // ... and a TABLE partition at most this many k-mers that survive the cut (the graph kernels' LDS lookup table takes 352, mf_nbr.h)
     int64_t opt_unit_parts_long = 3;   // assembled sequences: log2 of the table partitions counted as one unit (k_gather_split_n cuts them apart)
-    int64_t opt_skm_unit_records = 2000;   // ... and at most this many super-k-mer records (the identical-record search of k_skm_count covers 2048)
+    int64_t opt_skm_unit_records = 0;      // ... and at most this many super-k-mer records (the identical-record search of k_skm_count covers 2048); 0: 2000 for k >= 25, 4000 below (short k-mers make short records: mf_skm.hip)
     double last_pilot_rho = -1.0;
     double last_l1_per_occ = 0; int last_l1_k = 0;   // records (with padding) of the last run's level 1 per k-mer occurrence, for k = last_l1_k: the next sample's buffers are planned with it  // what the last pilot measured (diagnostics; < 0: none ran)
     int64_t opt_device_parse = 1;  // plain FASTA / FASTQ files are parsed on the device (mf_dparse.hip); files it is not sure about go to the host readers

@@ -196,7 +196,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "skm_dynq") ctx->opt_skm_dynq = v;
     else if (s == "part_good") { if (v < 16 || v > 4096) return mf_set_error("part_good out of [16,4096]"); ctx->opt_part_good = v; }
     else if (s == "unit_parts_long") { if (v < 0 || v > 4) return mf_set_error("unit_parts_long out of [0,4]"); ctx->opt_unit_parts_long = v; }
-    else if (s == "skm_unit_records") { if (v < 64 || v > (1 << 20)) return mf_set_error("skm_unit_records out of [64,2^20]"); ctx->opt_skm_unit_records = v; }
+    else if (s == "skm_unit_records") { if (v != 0 && (v < 64 || v > (1 << 20))) return mf_set_error("skm_unit_records out of [64,2^20] (0: by k)"); ctx->opt_skm_unit_records = v; }
     else if (s == "skm_unit_distinct") { if (v < 64 || v > 3400) return mf_set_error("skm_unit_distinct out of [64,3400]"); ctx->opt_skm_unit_distinct = v; }
     else if (s == "union_samples") ctx->opt_union_samples = v;
     else return mf_set_error("unknown option '%s'", name);

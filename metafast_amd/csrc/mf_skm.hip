@@ -1810,7 +1810,12 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             // ... and a unit's RECORDS should fit the search for identical ones (its first C2_DD * SKM_CT = 2048 records go through the
             // table as records, the rest is inserted as it comes): 380 M reads at 315-fold depth planned by distinct k-mers alone had
             // 3170 records per unit and lost 6 % of k_skm_count to the records the search did not see
-            if (ctx->opt_skm_dedupe) want_units = std::max(want_units, (double)n_occ * rpo / (double)ctx->opt_skm_unit_records);
+            // (round 5: a record of short k-mers holds few of them -- 4.8 per record at k = 21, 8.4 at k = 31 -- and 2000 such records are a small unit:
+            // more than half of k_skm_count is per-unit overhead (profiles/r05k_count_phase_cycles.txt).  50 M reads, k_skm_count / the whole step in
+            // ms with 2000 and with 4000 records: k = 21 20.2 -> 16.5 / 129.9 -> 125.7, k = 23 19.8 -> 15.7 / 118.0 -> 114.2, 200 M reads at k = 21
+            // 87.1 -> 70.0 / 375.9 -> 358.7; k = 25, 27, 31: no difference -- the distinct k-mers bound those.  profiles/r05t_unit_records_sweep.txt)
+            const int64_t unit_records = ctx->opt_skm_unit_records > 0 ? ctx->opt_skm_unit_records : (K >= 25 ? 2000 : 4000);
+            if (ctx->opt_skm_dedupe) want_units = std::max(want_units, (double)n_occ * rpo / (double)unit_records);
             int Bc = 0; while (Bc < 30 && (double)(1ull << Bc) < want_units) Bc++;
             const int r = std::max(1, std::min(Bc - bits1, std::min((int)SKM_DIGIT_BITS, 30 - bits1)));
             if (ctx->opt_verbose) fprintf(stderr, "[mf] skm pilot: %.4f distinct k-mers per occurrence -> %d bits after level 1 (planned from the occurrences alone: %d)\n", rho, r, total_bits - bits1);

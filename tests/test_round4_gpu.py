@@ -11,7 +11,7 @@ from util import to_device
 pytestmark = pytest.mark.gpu
 
 SEED = 0x4D45544146415354
-DEFAULTS = dict(skm_pilot=1, skm_unit_distinct=2200, skm_unit_records=2000, part_good=220, unit_parts_long=3, skm_dynq=1, cc_sparse=1,
+DEFAULTS = dict(skm_pilot=1, skm_unit_distinct=2200, skm_unit_records=0, part_good=220, unit_parts_long=3, skm_dynq=1, cc_sparse=1,
                 skm_batches=0, l1_bits=-1, l2_bits=-1, file_cache=0)
 
 
