@@ -161,6 +161,7 @@ class Context:
         _check(lib().mf_ctx_create(device, host_threads or (os.cpu_count() or 1), C.byref(h)))
         self.h = h
         self.device = device
+        self.stream_handle = None                     # the raw stream the library launches on when the caller gave one (else: its own)
         if stream is not None:
             self.set_stream(stream)
 
@@ -179,6 +180,7 @@ class Context:
         """stream: a raw hipStream_t (int), or a torch.cuda.Stream"""
         raw = getattr(stream, "cuda_stream", stream)
         _check(lib().mf_ctx_set_stream(self.h, C.c_void_p(int(raw) if raw else None)))
+        self.stream_handle = int(raw) if raw else 0
 
     def set_option(self, name, value):
         _check(lib().mf_ctx_set_option(self.h, name.encode(), int(value)))

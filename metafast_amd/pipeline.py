@@ -358,8 +358,14 @@ def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=N
             timings[name] = timings.get(name, 0.0) + (t1 - t0) - (w1 - w0)      # (virtual ranks: the others' turns are not this rank's time)
             t0, w0 = t1, w1
 
+    # torch fills the exchange buffers on ITS current stream, the library reads and writes them on the context's: a stream synchronisation stands
+    # between the two -- unless they are the same stream (bench.py, run_samples' callers: the context was made with torch's current stream), where
+    # the order is the stream's own (round 5: eight host waits per threshold level less)
+    same_stream = getattr(ctx, "stream_handle", None) is not None and torch.cuda.is_available() and ctx.stream_handle == int(torch.cuda.current_stream().cuda_stream)
+
     def sync():
-        torch.cuda.current_stream().synchronize()
+        if not same_stream:
+            torch.cuda.current_stream().synchronize()
 
     def call(fn, default=None):
         """a library call that may fail (memory on ONE rank, a capacity limit): after the first failure this rank only keeps the
