@@ -1366,8 +1366,11 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
             if (threadIdx.x == 0) out_cursor = 0;
             if (thr >= 0) for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) lhist_try[i] = 0;
             if (P >= (uint32_t)SKM_MAX_PASSES) { if (threadIdx.x == 0) atomicExch(overflow, 1u); done = true; abandon = true; }
-            P *= 4u;
-            if (threadIdx.x == 0 && n_redo && P == 4u) atomicAdd(n_redo, 1u);    // (statistics: units counted in several passes)
+#ifndef C2_PASS_MULT
+#define C2_PASS_MULT 4u          /* passes of a unit that overflowed its table: x 4 each time (x 2 measured in round 5: profiles/r05x_pass_mult.txt) */
+#endif
+            P *= C2_PASS_MULT;
+            if (threadIdx.x == 0 && n_redo && P == C2_PASS_MULT) atomicAdd(n_redo, 1u);    // (statistics: units counted in several passes)
         } else if (++pass == P) {
             done = true;
             // (wave-uniform sums, and told so: in SGPRs they cost nothing across the unit loop, as VGPRs the allocator spilt them to
