@@ -1367,7 +1367,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
             if (thr >= 0) for (uint32_t i = threadIdx.x; i < (uint32_t)C2_LH; i += (uint32_t)SKM_CT) lhist_try[i] = 0;
             if (P >= (uint32_t)SKM_MAX_PASSES) { if (threadIdx.x == 0) atomicExch(overflow, 1u); done = true; abandon = true; }
 #ifndef C2_PASS_MULT
-#define C2_PASS_MULT 4u          /* passes of a unit that overflowed its table: x 4 each time (x 2 measured in round 5: profiles/r05x_pass_mult.txt) */
+#define C2_PASS_MULT 4u          /* passes of a unit that overflowed its table: x 4 each time (x 2 measured in round 5: no difference -- 1209 of 2^20 units are redone at all; both unit bounds, distinct k-mers and records, ask for 2^20 units on the benchmark: profiles/r05x_pass_mult.txt) */
 #endif
             P *= C2_PASS_MULT;
             if (threadIdx.x == 0 && n_redo && P == C2_PASS_MULT) atomicAdd(n_redo, 1u);    // (statistics: units counted in several passes)
