@@ -222,7 +222,12 @@ static void parse_devices(Env &e, const Args &a) {
         // must fit in 0.8 of the device.  MF_CONTEXTS_PER_DEVICE=1 (or an explicit --devices / --device) switches it off.
         size_t largest = 0, nlib = 0;
         for (const char *opt : {"reads", "k-mers", "kmers"})
-            for (auto &f : a.list(opt)) { struct stat st; if (stat(f.c_str(), &st) == 0) { largest = std::max(largest, (size_t)st.st_size); nlib++; } }
+            for (auto &f : a.list(opt)) {
+                struct stat st;
+                if (stat(f.c_str(), &st) != 0) continue;
+                const size_t packed = ends_with_ci(f, ".gz") || ends_with_ci(f, ".bz2") ? 5 : 1;      // (compressed reads: about five times their size once inflated)
+                largest = std::max(largest, (size_t)st.st_size * packed); nlib++;
+            }
         const char *cpd = getenv("MF_CONTEXTS_PER_DEVICE");
         uint64_t hbm = 0;
         bool two = cpd ? atoi(cpd) >= 2 : false;
