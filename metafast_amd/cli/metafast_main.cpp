@@ -11,6 +11,7 @@
 // "rewrite them?" prompt, log + logs/log_<ts>, output_description.txt), so that a Java run can continue a workDir this
 // program wrote and the other way round.  Errors: message on stderr, exit 1.
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <cmath>
 #include <cstdarg>
@@ -36,7 +37,7 @@ using std::vector;
 static bool g_verbose = false;
 static FILE *g_logfile = nullptr, *g_logfile2 = nullptr;      // <workDir>/log and <workDir>/logs/log_<ts> (identical)
 static std::mutex g_log_mutex;                                // (the per-device workers of a step log too)
-static bool g_workers_active = false;                         // other threads are inside library calls: die() must not run static destructors under them
+static std::atomic<bool> g_workers_active{false};                         // other threads are inside library calls: die() must not run static destructors under them
 static void logmsg(const char *level, const char *fmt, ...) {
     char buf[4096];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
