@@ -76,7 +76,11 @@ struct mf_ctx {
     int64_t opt_union_samples = 0;     // hint: the sequences of the next count are the unitigs of this many samples (they share k-mers: partitions are planned twice as large from 4 on)
     int own_rank = 0, own_world = 1;   // mf_count_device_shard: only the k-mers this rank owns (level-1 digits [nd1 * rank / world, nd1 * (rank + 1) / world)) are counted
     int64_t opt_skm_pilot = 1;     // reads: a few level-1 digit regions are counted first to measure distinct k-mers per occurrence; the later levels are planned from it (0 = plan from the occurrences alone)
-    int64_t opt_skm_unit_distinct = 2200;   // ... so that a counting unit is expected to hold at most this many distinct k-mers (the LDS table takes C2_FILL = 3400 claims)
+    #ifdef SKM_BIG_UNITS
+    int64_t opt_skm_unit_distinct = 4400;
+#else
+    int64_t opt_skm_unit_distinct = 2200;
+#endif   // ... so that a counting unit is expected to hold at most this many distinct k-mers (the LDS table takes C2_FILL = 3400 claims)
     int64_t opt_skm_dynq = 1;      // k_skm_count: units handed out from a counter as the workgroups get to them (0: fixed stride)
     int64_t opt_part_good = 220;   // ... and a TABLE partition at most this many k-mers that survive the cut (the graph kernels' LDS lookup table takes 352, mf_nbr.h)
     int64_t opt_unit_parts_long = 3;   // assembled sequences: log2 of the table partitions counted as one unit (k_gather_split_n cuts them apart)

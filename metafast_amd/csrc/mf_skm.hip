@@ -36,7 +36,15 @@ typedef uint32_t skm_v4 __attribute__((ext_vector_type(4)));
 #define SKM_LINE 4                 // records per 64-byte staging line
 #define SKM_QCAP 16
 #define SKM_DIGIT_BITS 22          // digit bits stored in a record (levels after the first)
+#ifdef SKM_BIG_UNITS              /* experiment (round 5): ONE workgroup of 1024 threads per CU with a table of 8192 slots -- units twice as large, half as many.
+                                     Correct (77 parity tests) and SLOWER: k_skm_count 25.9 -> 27.9 ms on the benchmark, 34.9 -> 39.2 without the search for
+                                     identical records, 61.1 -> 77.7 at 5-fold depth, 16.5 -> 18.4 at k = 21 (profiles/r05y_big_units.txt): sixteen waves wait
+                                     longer at a unit's barriers than eight, and a CU with one workgroup has nothing to run while that one compacts.  Not built in. */
+#define SKM_CT 1024
+#else
 #define SKM_CT 512                 // threads of k_skm_count
+#endif
+#define SKM_NW (SKM_CT / 64)       // its waves
 
 __device__ __forceinline__ bool skm_rec_valid(const skm_rec &r) { return ((uint32_t)r.y & 63u) != 63u; }
 __device__ __forceinline__ uint32_t skm_rec_n(const skm_rec &r) { return (uint32_t)r.y & 63u; }
@@ -672,16 +680,24 @@ __device__ __forceinline__ uint32_t skm_pass_of(uint64_t key) {
 // The all-counts histogram of IOUtils.printKmers (src/io/IOUtils.java:45-71, the .stat.txt file) needs the entries the
 // cut drops: their counts (<= thr) are tallied here (count 1 by ballot, the others in a small LDS histogram).
 // =============================================================================================
+#ifdef SKM_BIG_UNITS
+#define C2_SLOTS 8192
+#define C2_FILL 6800
+#define C2_WG_PER_CU 1
+#else
+#define C2_WG_PER_CU 2
 #define C2_SLOTS 4096            // table slots: at the planned ~800 distinct k-mers per partition the table is 1/5 full.  (2048 slots
                                  // = three workgroups per CU instead of two, but an 80-VGPR budget: 54 ms against 45.)
 #define C2_FILL 3400             // claims beyond which a partition is counted again in several passes
+#endif
 #define C2_QN 128                // queue entries per wave (keys): drained at 64, one push (<= 64 keys) between checks
 #define C2_LH 64                 // bins of the workgroup's dropped-count histogram (a cut with thr >= C2_LH is made after the kernel)
 #define C2_ITEMS 848             // item entries per wave: 64 records x 10 items + two steps of padding (the read-ahead of the last step runs past them, unused) + the dummy area of the item stores
 #define C2_W 2                   // k-mers per item
+#define DD_BITS (SKM_CT > 512 ? 12 : 11)   // bits of a record's index in its unit (the search for identical records: C2_DD * SKM_CT records)
 #define C2_DD 4                  // records per thread of a unit whose identical records are counted once (k_skm_count): units of up to C2_DD * SKM_CT records
 static constexpr size_t C2_LDS = (size_t)C2_SLOTS * 12 + (size_t)SKM_CT * 16 + (size_t)(SKM_CT / 64) * (C2_ITEMS * 2 + C2_QN * 8 + C2_QN * 2) + 2 * C2_LH * 4 + 48;
-static_assert(C2_LDS <= 80 * 1024, "two workgroups per CU");
+static_assert(C2_LDS <= 160 * 1024 / C2_WG_PER_CU, "workgroups per CU");
 
 __device__ __forceinline__ uint32_t c2_swap_pairs(uint32_t x) {                 // exchanges the two bits of every base
     return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
@@ -948,7 +964,7 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
     for (uint32_t i = threadIdx.x; i < 2u * (uint32_t)C2_LH; i += (uint32_t)SKM_CT) lhist[i] = 0;
     if (threadIdx.x == 0) { out_cursor = 0; blk_claims = 0; dd_gone = 0; dd_all = 0; pflags[0][0] = pflags[0][1] = pflags[1][0] = pflags[1][1] = 0; }
     const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
-    const uint32_t mine = (lane >> 3) * 64u + wave * 8u + (lane & 7u);          // this lane's record within a round of 512
+    const uint32_t mine = (lane >> 3) * (uint32_t)(SKM_NW * 8) + wave * 8u + (lane & 7u);          // this lane's record within a round of SKM_CT
     const uint32_t nu = np - p0;                                                // unit u = partition p0 + u
     uint32_t ui = blockIdx.x;
     if (ui >= nu) return;
@@ -1112,13 +1128,13 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                                  ^ __builtin_amdgcn_alignbit((uint32_t)(ym >> 32), (uint32_t)(ym >> 32), 21) ^ __builtin_amdgcn_alignbit((uint32_t)ym, (uint32_t)ym, 5);
                     h ^= h >> 16; h *= 0x9E3779B1u; h ^= h >> 15;
                     sa[i] = L.tk0 + 8u * (h & (uint32_t)(C2_SLOTS - 1));
-                    const uint64_t word = (1ull << 32) | (uint64_t)(((h >> 11) << 11) | ((uint32_t)i * (uint32_t)SKM_CT + mine));
+                    const uint64_t word = (1ull << 32) | (uint64_t)(((h >> DD_BITS) << DD_BITS) | ((uint32_t)i * (uint32_t)SKM_CT + mine));
                     asm volatile("ds_cmpst_rtn_b64 %0, %1, %2, %3" : "=&v"(ret[i]) : "v"(sa[i]), "v"(MF_EMPTY), "v"(word) : "memory");
-                    st[i] = h >> 11;                                            // (the fingerprint, until the answer is in)
+                    st[i] = h >> DD_BITS;                                       // (the fingerprint, until the answer is in)
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            static_assert(C2_DD * SKM_CT <= 2048, "index in the unit: 11 bits");
+            static_assert(C2_DD * SKM_CT <= (1 << DD_BITS), "index in the unit");
             skm_rec G[C2_DD];
 #pragma unroll
             for (int i = 0; i < C2_DD; i++) {
@@ -1126,10 +1142,10 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
                 st[i] = 0;
                 if (wl[i]) {
                     if (ret[i] == MF_EMPTY) st[i] = 1;
-                    else if (((uint32_t)ret[i] >> 11) == fp) st[i] = 2;
+                    else if (((uint32_t)ret[i] >> DD_BITS) == fp) st[i] = 2;
                 }
                 G[i] = SENT;
-                if (st[i] == 2) G[i] = load_rec(start, (uint32_t)ret[i] & 2047u, len);          // the claimant
+                if (st[i] == 2) G[i] = load_rec(start, (uint32_t)ret[i] & ((1u << DD_BITS) - 1u), len);          // the claimant
             }
 #pragma unroll
             for (int i = 0; i < C2_DD; i++) {
@@ -1281,11 +1297,11 @@ __global__ __launch_bounds__(SKM_CT, 4) void k_skm_count(const skm_rec *__restri
         // dependent LDS round trips per 64 entries here; with the table 2/5 full the sweep is cheaper on both counts.)
         {
             constexpr int NCH = 8;                                      // chunks in flight
-            static_assert(C2_SLOTS % (8 * 64 * NCH) == 0, "sweep: whole groups of eight chunks per wave");
+            static_assert(C2_SLOTS % (SKM_NW * 64 * NCH) == 0, "sweep: whole groups of eight chunks per wave");
 #pragma unroll 1
-            for (uint32_t g = 0; g < (uint32_t)(C2_SLOTS / (8 * 64 * NCH)); g++) {
+            for (uint32_t g = 0; g < (uint32_t)(C2_SLOTS / (SKM_NW * 64 * NCH)); g++) {
             uint64_t ck[NCH]; uint32_t cc[NCH]; unsigned long long have[NCH], keep[NCH];
-            const uint32_t sl0 = wave * (uint32_t)(C2_SLOTS / 8) + g * (uint32_t)(64 * NCH) + lane;
+            const uint32_t sl0 = wave * (uint32_t)(C2_SLOTS / SKM_NW) + g * (uint32_t)(64 * NCH) + lane;
             const uint32_t ka0 = L.tk0 + 8u * sl0, ca0 = L.tc0 + 4u * sl0;
             const uint64_t E = MF_EMPTY; const uint32_t zero = 0u;
             // (the counters of ALL lanes: an exchange costs the same for 8 lanes as for 64)
@@ -1621,7 +1637,7 @@ static int skm_pilot(mf_ctx *ctx, const skm_rec *bufA, const uint64_t *pstart, c
     MF_HIP(hipMemsetAsync(pr.p, 0xFF, (tot[0] + 4) * sizeof(skm_rec), st));               // padding = sentinels
     k_skm_pilot<<<dim3(gx, R), 256, 0, st>>>(bufA, pstart, plen, reg.p, shift, nsel, nullptr, nullptr, ostart.p, d_cur, pr.p);
     {
-        const unsigned grid = (unsigned)std::min<uint64_t>(nb, (uint64_t)ctx->n_cu * 2);
+        const unsigned grid = (unsigned)std::min<uint64_t>(nb, (uint64_t)ctx->n_cu * C2_WG_PER_CU);
         // ps: [2] overflow [3] distinct before the cut [4] units redone [8..24) diagnostics
         k_skm_count<K, false><<<grid, SKM_CT, C2_LDS, st>>>(pr.p, ostart.p, uplen.p, nb, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&ps.p[2], 0u, (uint64_t)0, kthr,
                                                          &ps.p[3], (unsigned int *)&ps.p[4], nullptr, &ps.p[8], (uint64_t)tot[1], (uint32_t)ctx->opt_skm_dedupe, nullptr);
@@ -1817,7 +1833,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             // more than half of k_skm_count is per-unit overhead (profiles/r05k_count_phase_cycles.txt).  50 M reads, k_skm_count / the whole step in
             // ms with 2000 and with 4000 records: k = 21 20.2 -> 16.5 / 129.9 -> 125.7, k = 23 19.8 -> 15.7 / 118.0 -> 114.2, 200 M reads at k = 21
             // 87.1 -> 70.0 / 375.9 -> 358.7; k = 25, 27, 31: no difference -- the distinct k-mers bound those.  profiles/r05t_unit_records_sweep.txt)
-            const int64_t unit_records = ctx->opt_skm_unit_records > 0 ? ctx->opt_skm_unit_records : (K >= 25 ? 2000 : 4000);
+            const int64_t unit_records = ctx->opt_skm_unit_records > 0 ? ctx->opt_skm_unit_records : (K >= 25 ? 2000 : 4000) * (SKM_CT / 512);
             if (ctx->opt_skm_dedupe) want_units = std::max(want_units, (double)n_occ * rpo / (double)unit_records);
             int Bc = 0; while (Bc < 30 && (double)(1ull << Bc) < want_units) Bc++;
             const int r = std::max(1, std::min(Bc - bits1, std::min((int)SKM_DIGIT_BITS, 30 - bits1)));
@@ -1971,7 +1987,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         const uint32_t p0 = (uint32_t)std::min<uint64_t>((uint64_t)b * PB, np), p1 = (uint32_t)std::min<uint64_t>((uint64_t)(b + 1) * PB, np);
         if (p0 == p1) continue;
         {
-            const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * 2);      // resident workgroups
+            const unsigned grid = (unsigned)std::min<uint64_t>(p1 - p0, (uint64_t)ctx->n_cu * C2_WG_PER_CU);      // resident workgroups
             MF_HIP(hipMemsetAsync(&scal[8], 0, 16, st));                     // ([8] units redone, [9] the unit counter)
             mf_ktimer t(ctx, "k_skm_count");
 #define SKM_COUNT_ARGS bufA.p, pstart.p, plen.p, p1, toff.p, tkeys.p, tcnt.p, dcount.p, (unsigned int *)&scal[2], p0, (uint64_t)tb[b], kthr, &scal[7], \
