@@ -455,6 +455,7 @@ int mf_sort_u32_pairs(mf_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_
                       uint32_t *d_vals_out);
 int mf_sort_u32_u64(mf_ctx *ctx, const uint32_t *d_keys_in, const uint64_t *d_vals_in, uint64_t n, int bits, uint32_t *d_keys_out,
                     uint64_t *d_vals_out);
+int mf_sort_u64_u64(mf_ctx *ctx, const uint64_t *d_keys_in, const uint64_t *d_vals_in, uint64_t n, int bits, uint64_t *d_keys_out, uint64_t *d_vals_out);
 int mf_sort_kmers_by_comp(mf_ctx *ctx, const uint32_t *d_comp, const uint64_t *d_kmers, uint64_t n, int key_bits, uint32_t n_comps,
                           uint64_t *d_out);
 // the canonical INTERIOR of a k-mer: its middle k-2 bases or their reverse complement, whichever is smaller (rcx = mf_revcomp(x, k)).

@@ -418,3 +418,27 @@ def test_low_complexity_reads_with_the_short_minimizer(gpu_ctx, oracle, k):
     pick = rng.choice(len(ok), size=3000, replace=False)
     got = t.lookup(np.concatenate([ok[pick], rng.integers(0, 1 << (2 * k), size=300, dtype=np.uint64) | np.uint64(1 << 62)]))
     assert np.array_equal(got[:3000], ov[pick]) and np.all(got[3000:] == -1)
+
+
+@pytest.mark.parametrize("kind,kt,vt", [(0, np.uint64, np.uint16), (1, np.uint32, np.uint32), (2, np.uint32, np.uint64), (3, np.uint64, np.uint32), (4, np.uint64, np.uint64)])
+def test_radix_sort_kernels(gpu_ctx, kind, kt, vt):
+    """mf_sort.hip (hand-written since round 5): stable, ascending by the low `bits` key bits and by nothing above them, for every (key, value)
+    width the file seams use, at sizes around the kernels' borders (a wave's 4096 elements, a workgroup's 16384, one and several passes)"""
+    import ctypes as C
+    from metafast_amd import lib as L
+    fn = L.lib().mf_debug_sort
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(40 + kind)
+    kbits = 8 * np.dtype(kt).itemsize
+    for n in (1, 63, 64, 65, 4095, 4096, 4097, 16384, 16385, 100_003, 3_000_017):
+        for bits in sorted({1, 5, 8, 9, 21, kbits - 2, kbits}):
+            # few distinct keys (long runs of equal ones: stability), or all bits random; bits above `bits` set on purpose
+            keys = rng.integers(0, 1 << min(bits, 12), size=n, dtype=np.uint64) if rng.random() < 0.4 else rng.integers(0, 1 << 63, size=n, dtype=np.uint64) >> np.uint64(63 - min(bits, 62))
+            junk = rng.integers(0, 1 << 63, size=n, dtype=np.uint64) << np.uint64(bits) if bits < kbits else np.zeros(n, dtype=np.uint64)
+            keys = ((keys & np.uint64((1 << bits) - 1)) | junk).astype(kt)
+            vals = np.arange(n, dtype=np.uint64).astype(vt) if np.dtype(vt).itemsize >= 4 else (np.arange(n) % 65521).astype(vt)
+            ko, vo = np.empty_like(keys), np.empty_like(vals)
+            assert fn(gpu_ctx.h, kind, keys.ctypes.data, vals.ctypes.data, n, bits, ko.ctypes.data, vo.ctypes.data) == 0
+            order = np.argsort(keys.astype(np.uint64) & np.uint64((1 << bits) - 1), kind="stable")
+            assert np.array_equal(ko, keys[order]) and np.array_equal(vo, vals[order]), (kind, n, bits)
