@@ -4,72 +4,118 @@
 // writes ascending k-mers so that files can be compared byte for byte.  Not on the timed step.
 //
 // Round 5: hand-written for wave64 (rounds 1-4 called rocPRIM's device radix sort here).  One pass per 8 key bits:
-//   k_rs_count    a WAVE owns RS_WAVE consecutive elements; it counts their digits in LDS (one ds_add per element) and writes its 256
-//                 counters digit-major: hist[digit][wave]
-//   mf_scan       exclusive prefix over hist in that order = where each wave's elements of each digit go
-//   k_rs_scatter  the wave walks its elements again, 64 at a time: the lanes that hold the same digit find each other with eight ballots
-//                 (one per digit bit), a lane's place is its digit's running cursor + the number of such lanes below it; the lowest one
-//                 moves the cursor on.  Stable by construction: waves own consecutive ranges, rounds go forward, lanes ascend.
-// 8 + 2 (K + V) bytes per element and pass.  Everything of a call is on ctx->stream.  (About 2.5 x the time of rocPRIM's onesweep sort, whose
-// workgroups sort tiles of 7 680 elements in LDS before they write: off the timed step that is +14 ms for components.bin's member order and
-// a few ms per .kmers.bin; the no-reference k = 32..63 path, which sorts every k-mer OCCURRENCE twice per pass, keeps the library sort: 9.1 s
-// against 13.5 s for 200 M reads at k = 63, profiles/r05aa_sort.txt.)
+//   k_rs_count    a workgroup owns RS_BLOCK consecutive elements; it counts their digits in LDS and writes its 256 counters digit-major:
+//                 hist[digit][workgroup]
+//   mf_scan       exclusive prefix over hist in that order = where each workgroup's elements of each digit go
+//   k_rs_scatter  the workgroup orders its elements a tile of 4096 at a time in LDS (stable: waves own consecutive ranges, rounds go forward,
+//                 lanes ascend; the lanes of a round that hold the same digit find each other with eight ballots) and writes the tile out in
+//                 runs of equal digits: consecutive threads, consecutive places.
+// 8 + 2 (K + V) bytes per element and pass.  Everything of a call is on ctx->stream.  Measured (profiles/r05ad_sort_rate.txt, 1e8 elements):
+// (k-mer, count) 62 bits 8.9 ms = 11.2 G elements/s; (u64, u64) 64 bits 9.8 ms (the library's keys-only sort of the same: 8.8 ms).
 #include <cstring>
 #include "mf_common.h"
 
-#define RS_T 256                       // threads per workgroup
-#define RS_WAVE 4096                   // elements a wave owns
-#define RS_BLOCK (RS_WAVE * (RS_T / 64))
+#define RS_T 256                       // threads per workgroup (4 waves)
+#define RS_R 16                        // rounds of 64 elements a wave takes per tile
+#define RS_TILE (RS_T * RS_R)          // 4096 elements: what a workgroup orders in LDS at a time
+#define RS_TILES 4                     // tiles per workgroup
+#define RS_BLOCK (RS_TILE * RS_TILES)  // 16384 consecutive elements a workgroup owns
 
 template <typename K>
-__global__ __launch_bounds__(RS_T) void k_rs_count(const K *__restrict__ keys, uint64_t n, int shift, uint32_t dmask, uint32_t *__restrict__ hist, uint64_t n_waves) {
-    __shared__ uint32_t cnt[RS_T / 64][256];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t i = lane; i < 256u; i += 64u) cnt[wave][i] = 0;
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t gw = (uint64_t)blockIdx.x * (RS_T / 64) + wave;
-    const uint64_t e0 = gw * RS_WAVE;
-    if (gw < n_waves) {
-        const uint64_t e1 = e0 + RS_WAVE < n ? e0 + RS_WAVE : n;
-        for (uint64_t e = e0 + lane; e < e1; e += 64) atomicAdd(&cnt[wave][(uint32_t)(keys[e] >> shift) & dmask], 1u);
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t d = lane; d < 256u; d += 64u) hist[(uint64_t)d * n_waves + gw] = cnt[wave][d];
-    }
+__global__ __launch_bounds__(RS_T) void k_rs_count(const K *__restrict__ keys, uint64_t n, int shift, uint32_t dmask, uint32_t *__restrict__ hist, uint64_t n_blocks) {
+    __shared__ uint32_t cnt[256];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t e0 = (uint64_t)blockIdx.x * RS_BLOCK;
+    const uint64_t e1 = e0 + RS_BLOCK < n ? e0 + RS_BLOCK : n;
+    for (uint64_t e = e0 + threadIdx.x; e < e1; e += RS_T) atomicAdd(&cnt[(uint32_t)(keys[e] >> shift) & dmask], 1u);
+    __syncthreads();
+    hist[(uint64_t)threadIdx.x * n_blocks + blockIdx.x] = cnt[threadIdx.x];
 }
 
+// A tile of 4096 elements in wave-major order (wave w holds elements w * 1024 + round * 64 + lane): every lane ranks its elements among the
+// wave's earlier ones of the same digit (eight ballots find the lanes of a round that share it, a running counter per wave and digit carries
+// the rounds before), the counters of the four waves are put in digit order, the tile is written digit-sorted into LDS and leaves it in runs:
+// consecutive threads write consecutive places.
 template <typename K, typename V>
 __global__ __launch_bounds__(RS_T) void k_rs_scatter(const K *__restrict__ keys, const V *__restrict__ vals, uint64_t n, int shift, uint32_t dmask, const uint64_t *__restrict__ offs,
-                                                     uint64_t n_waves, K *__restrict__ keys_out, V *__restrict__ vals_out) {
-    __shared__ uint32_t cur[RS_T / 64][256];            // (places are < 2^32: the callers refuse more entries)
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint64_t gw = (uint64_t)blockIdx.x * (RS_T / 64) + wave;
-    if (gw >= n_waves) return;
-    for (uint32_t d = lane; d < 256u; d += 64u) cur[wave][d] = (uint32_t)offs[(uint64_t)d * n_waves + gw];
-    __builtin_amdgcn_wave_barrier();
-    const uint64_t e0 = gw * RS_WAVE;
-    const uint64_t e1 = e0 + RS_WAVE < n ? e0 + RS_WAVE : n;
+                                                     uint64_t n_blocks, K *__restrict__ keys_out, V *__restrict__ vals_out) {
+    __shared__ K lk[RS_TILE];
+    __shared__ V lv[RS_TILE];
+    __shared__ uint32_t wcnt[RS_T / 64][256];           // per wave and digit: elements so far in this tile; then: where the wave's run of the digit starts in the tile
+    __shared__ uint32_t toff[256], gcur[256], tot[256];
+    __shared__ uint32_t scratch[17];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u, tid = threadIdx.x;
+    gcur[tid] = (uint32_t)offs[(uint64_t)tid * n_blocks + blockIdx.x];      // (places are < 2^32: the callers refuse more entries)
+    for (int w = 0; w < RS_T / 64; w++) wcnt[w][tid] = 0;
+    __syncthreads();
     const unsigned long long below = lane ? (~0ull >> (64u - lane)) : 0ull;
-    for (uint64_t eb = e0; eb < e1; eb += 64) {
-        const uint64_t e = eb + lane;
-        const bool have = e < e1;
-        K key = 0; V val = V();
-        if (have) { key = keys[e]; val = vals[e]; }
-        const uint32_t d = (uint32_t)(key >> shift) & dmask;
-        unsigned long long peers = __ballot(have);
+    const uint64_t b0 = (uint64_t)blockIdx.x * RS_BLOCK;
+    for (int t = 0; t < RS_TILES; t++) {
+        const uint64_t t0 = b0 + (uint64_t)t * RS_TILE;
+        if (t0 >= n) break;                                                  // (uniform)
+        K key[RS_R]; V val[RS_R]; uint32_t rank[RS_R];
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const unsigned long long m = __ballot((d >> b) & 1u);
-            peers &= ((d >> b) & 1u) ? m : ~m;
+        for (int r = 0; r < RS_R; r++) {
+            const uint64_t e = t0 + (uint64_t)wave * (64 * RS_R) + (uint64_t)r * 64 + lane;
+            const bool have = e < n;
+            key[r] = 0; val[r] = V();
+            if (have) { key[r] = keys[e]; val[r] = vals[e]; }
         }
-        if (have) {
-            const uint32_t lower = (uint32_t)__popcll(peers & below);
-            // (every peer reads the cursor before the lowest of them moves it: the LDS operations of a wave keep their order; atomics so that
-            // the compiler keeps every one of them a real LDS access)
-            const uint32_t at = __atomic_load_n(&cur[wave][d], __ATOMIC_RELAXED) + lower;
-            keys_out[at] = key; vals_out[at] = val;
-            if (lower == 0u) __atomic_store_n(&cur[wave][d], at + (uint32_t)__popcll(peers), __ATOMIC_RELAXED);
+#pragma unroll
+        for (int r = 0; r < RS_R; r++) {
+            const uint64_t e = t0 + (uint64_t)wave * (64 * RS_R) + (uint64_t)r * 64 + lane;
+            const bool have = e < n;
+            const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
+            unsigned long long peers = __ballot(have);
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const unsigned long long m = __ballot((d >> b) & 1u);
+                peers &= ((d >> b) & 1u) ? m : ~m;
+            }
+            rank[r] = 0xFFFFFFFFu;
+            if (have) {
+                const uint32_t lower = (uint32_t)__popcll(peers & below);
+                // (every peer reads the counter before the lowest of them moves it: the LDS operations of a wave keep their order)
+                const uint32_t c = __atomic_load_n(&wcnt[wave][d], __ATOMIC_RELAXED);
+                rank[r] = c + lower;
+                if (lower == 0u) __atomic_store_n(&wcnt[wave][d], c + (uint32_t)__popcll(peers), __ATOMIC_RELAXED);
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        {   // thread d: the digit's elements in this tile, wave by wave -> where each wave's run starts
+            uint32_t c[RS_T / 64], sum = 0;
+            for (int w = 0; w < RS_T / 64; w++) { c[w] = wcnt[w][tid]; sum += c[w]; }
+            uint32_t all;
+            const uint32_t ex = mf_block_excl_scan(sum, scratch, &all);
+            toff[tid] = ex; tot[tid] = sum;
+            uint32_t at = ex;
+            for (int w = 0; w < RS_T / 64; w++) { wcnt[w][tid] = at; at += c[w]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RS_R; r++) {
+            if (rank[r] != 0xFFFFFFFFu) {
+                const uint32_t d = (uint32_t)(key[r] >> shift) & dmask;
+                const uint32_t s = wcnt[wave][d] + rank[r];
+                lk[s] = key[r]; lv[s] = val[r];
+            }
+        }
+        __syncthreads();
+        const uint64_t left = n - t0;
+        const uint32_t cnt = left < RS_TILE ? (uint32_t)left : (uint32_t)RS_TILE;
+#pragma unroll 4
+        for (uint32_t s = tid; s < cnt; s += RS_T) {
+            const K k = lk[s];
+            const uint32_t d = (uint32_t)(k >> shift) & dmask;
+            const uint32_t at = gcur[d] + (s - toff[d]);
+            keys_out[at] = k; vals_out[at] = lv[s];
+        }
+        __syncthreads();
+        gcur[tid] += tot[tid];
+        for (int w = 0; w < RS_T / 64; w++) wcnt[w][tid] = 0;
+        __syncthreads();
     }
 }
 
@@ -81,23 +127,24 @@ static int rs_sort(mf_ctx *ctx, const K *d_keys_in, const V *d_vals_in, uint64_t
     MF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int passes = std::max(1, (std::min<int>(bits, (int)sizeof(K) * 8) + 7) / 8);
-    const uint64_t n_waves = (n + RS_WAVE - 1) / RS_WAVE;
-    const unsigned grid = (unsigned)((n_waves + (RS_T / 64) - 1) / (RS_T / 64));
-    mf_buf<uint32_t> hist; MF_TRY(hist.alloc(ctx, 256 * n_waves));
-    mf_buf<uint64_t> offs; MF_TRY(offs.alloc(ctx, 256 * n_waves + 1));
+    const uint64_t n_blocks = (n + RS_BLOCK - 1) / RS_BLOCK;
+    const unsigned grid = (unsigned)n_blocks;
+    mf_buf<uint32_t> hist; MF_TRY(hist.alloc(ctx, 256 * n_blocks));
+    mf_buf<uint64_t> offs; MF_TRY(offs.alloc(ctx, 256 * n_blocks + 1));
     mf_buf<uint64_t> tot; MF_TRY(tot.alloc(ctx, 2));
     mf_buf<K> tk; mf_buf<V> tv;
     if (passes > 1) { MF_TRY(tk.alloc(ctx, n)); MF_TRY(tv.alloc(ctx, n)); }
     // the last pass must land in the caller's buffers: with an even number of passes the first one goes to the temporaries
     const K *src_k = d_keys_in; const V *src_v = d_vals_in;
+    mf_ktimer tm(ctx, "k_radix_sort");
     for (int p = 0; p < passes; p++) {
         const bool to_out = ((passes - 1 - p) & 1) == 0;
         K *dst_k = to_out ? d_keys_out : tk.p; V *dst_v = to_out ? d_vals_out : tv.p;
         const int left = std::min<int>(bits, (int)sizeof(K) * 8) - 8 * p;                  // (bits above `bits` take no part in the order)
         const uint32_t dmask = left >= 8 ? 255u : (1u << left) - 1u;
-        k_rs_count<K><<<grid, RS_T, 0, st>>>(src_k, n, 8 * p, dmask, hist.p, n_waves);
-        MF_TRY(mf_scan<1>(ctx, hist.p, offs.p, 256 * n_waves, tot.p));
-        k_rs_scatter<K, V><<<grid, RS_T, 0, st>>>(src_k, src_v, n, 8 * p, dmask, offs.p, n_waves, dst_k, dst_v);
+        k_rs_count<K><<<grid, RS_T, 0, st>>>(src_k, n, 8 * p, dmask, hist.p, n_blocks);
+        MF_TRY(mf_scan<1>(ctx, hist.p, offs.p, 256 * n_blocks, tot.p));
+        k_rs_scatter<K, V><<<grid, RS_T, 0, st>>>(src_k, src_v, n, 8 * p, dmask, offs.p, n_blocks, dst_k, dst_v);
         src_k = dst_k; src_v = dst_v;
     }
     MF_HIP(hipGetLastError());

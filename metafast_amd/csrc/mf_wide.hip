@@ -7,12 +7,11 @@
 // reverse complement), counts saturate at 32767, reads shorter than max(k, min_len) give nothing.
 //
 // Not the hot path: one rolling pass over the reads writes the canonical k-mer of every valid start (two 64-bit words), a
-// device-wide LSD radix sort (rocPRIM, low word then high word) orders them, run lengths are the counts.  32 bytes of HBM per
+// device-wide LSD radix sort (mf_sort.hip, low word then high word) orders them, run lengths are the counts.  32 bytes of HBM per
 // k-mer occurrence twice over -- the super-k-mer machinery of mf_skm.hip (16-byte records of <= 50 bases) does not carry 63-mers.
 #include <cstring>
 #include <memory>
 #include <vector>
-#include <rocprim/rocprim.hpp>
 #include "mf_common.h"
 #include "mf_count_dev.h"
 
@@ -178,15 +177,8 @@ extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void
         }
         {   // ascending (hi, lo): LSD -- by the low word, then (stable) by the high word's 2k - 64 bits
             mf_ktimer tm(ctx, "k_wide_sort");
-            size_t t1 = 0, t2 = 0;
-            const unsigned hb = (unsigned)std::max(1, 2 * k - 64);
-            if (rocprim::radix_sort_pairs(nullptr, t1, l0.p, l1.p, h0.p, h1.p, (size_t)n_p, 0u, 64u, st) != hipSuccess ||
-                rocprim::radix_sort_pairs(nullptr, t2, h1.p, h0.p, l1.p, l0.p, (size_t)n_p, 0u, hb, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: sort set-up failed"));
-            mf_buf<uint8_t> tmp;
-            if (tmp.alloc(ctx, std::max(t1, t2) + 1) < 0) return fail(MF_ERR);
-            if (rocprim::radix_sort_pairs((void *)tmp.p, t1, l0.p, l1.p, h0.p, h1.p, (size_t)n_p, 0u, 64u, st) != hipSuccess ||
-                rocprim::radix_sort_pairs((void *)tmp.p, t2, h1.p, h0.p, l1.p, l0.p, (size_t)n_p, 0u, hb, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: sort failed: %s", hipGetErrorString(hipGetLastError())));
+            const int hb = std::max(1, 2 * k - 64);
+            if (mf_sort_u64_u64(ctx, l0.p, h0.p, n_p, 64, l1.p, h1.p) < 0 || mf_sort_u64_u64(ctx, h1.p, l1.p, n_p, hb, h0.p, l0.p) < 0) return fail(MF_ERR);
         }
         h1.reset(); l1.reset();
         // run lengths

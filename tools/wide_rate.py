@@ -25,5 +25,5 @@ for it in range(2):
     L.lib().mf_wtable_destroy(t)
     res.append(dict(seconds=round(dt, 3), n_occ=occ.value, n_distinct=nd.value, kmers_per_s=round(occ.value / dt, 1),
                     kernels={kk_: round(v[1], 1) for kk_, v in ctx.kernel_report().items()}))
-print(json.dumps(dict(what="NO-REFERENCE EXTENSION: canonical %d-mer counts of one sample of %d synthetic 150 bp reads on one MI355X (mf_count_wide_device: prefix passes, rocPRIM sort per pass)" % (k, n),
+print(json.dumps(dict(what="NO-REFERENCE EXTENSION: canonical %d-mer counts of one sample of %d synthetic 150 bp reads on one MI355X (mf_count_wide_device: prefix passes, mf_sort.hip radix sort per pass)" % (k, n),
                       reads=n, k=k, runs=res)))
