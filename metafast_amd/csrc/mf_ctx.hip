@@ -181,7 +181,11 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "nbr_global") ctx->opt_nbr_global = v;
     else if (s == "dcc_sparse") ctx->opt_dcc_sparse = v;
     else if (s == "cc_sparse") ctx->opt_cc_sparse = v;
-    else if (s == "wide_passes") { if (v < 0 || v > 65536 || (v & (v - 1))) return mf_set_error("wide_passes must be 0 or a power of two <= 65536"); ctx->opt_wide_passes = v; }
+    else if (s == "wide_finish") ctx->opt_wide_finish = v ? 1 : 0;
+    else if (s == "wide_big_bucket") { if (v < 1 || v > 256) return mf_set_error("wide_big_bucket must be in [1, 256]"); ctx->opt_wide_big_bucket = v; }
+    else if (s == "wide_ablate") ctx->opt_wide_ablate = v;
+    else if (s == "wide_distinct") { if (v < 1 || v > 704) return mf_set_error("wide_distinct must be in [1, 704]"); ctx->opt_wide_distinct = v; }
+    else if (s == "wide_passes") { if (v < 0 || v > 65536) return mf_set_error("wide_passes must be in [0, 65536]"); ctx->opt_wide_passes = v; }
     else if (s == "file_cache") {                       // GB; -1: a quarter of the device's memory, -n: an n-th of that (n contexts share the device)
         if (v < 0) { size_t fr = 0, tot = 0; MF_HIP(hipSetDevice(ctx->device)); MF_HIP(hipMemGetInfo(&fr, &tot)); v = std::max<int64_t>(1, (int64_t)(tot >> 32) / -v); }
         ctx->opt_file_cache_gb = v;
@@ -208,6 +212,8 @@ extern "C" int64_t mf_ctx_stat(mf_ctx *ctx, const char *name) {
     if (!ctx || !name) return mf_set_error("mf_ctx_stat: NULL argument");
     const std::string s(name);
     if (s == "slice_restarts") return (int64_t)ctx->n_slice_restarts;
+    if (s == "wide_big_entries") return (int64_t)ctx->n_wide_big;
+    if (s == "wide_hashed_entries") return (int64_t)ctx->n_wide_hashed;
     if (s == "device_parsed_files") return (int64_t)ctx->n_dparse_files;
     if (s == "device_parser_stepped_back") return (int64_t)ctx->n_dparse_stepped_back;
     if (s == "hipmalloc_calls") return (int64_t)ctx->n_hipmalloc;

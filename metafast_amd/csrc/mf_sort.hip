@@ -119,14 +119,15 @@ __global__ __launch_bounds__(RS_T) void k_rs_scatter(const K *__restrict__ keys,
     }
 }
 
-// in -> out, ascending by the low `bits` key bits, stable.  tmp_k / tmp_v: n elements each (needed when more than one pass is made)
+// in -> out, ascending by the `bits` key bits from bit `first_bit` up, stable.  tmp_k / tmp_v: n elements each (needed when more than one pass is made)
 template <typename K, typename V>
-static int rs_sort(mf_ctx *ctx, const K *d_keys_in, const V *d_vals_in, uint64_t n, int bits, K *d_keys_out, V *d_vals_out) {
+static int rs_sort(mf_ctx *ctx, const K *d_keys_in, const V *d_vals_in, uint64_t n, int bits, K *d_keys_out, V *d_vals_out, int first_bit = 0) {
     if (!n) return MF_OK;
     if (n >= (1ull << 32)) return mf_set_error("sort: more than 2^32 entries is not supported");
     MF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const int passes = std::max(1, (std::min<int>(bits, (int)sizeof(K) * 8) + 7) / 8);
+    bits = std::min<int>(bits, (int)sizeof(K) * 8 - first_bit);
+    const int passes = std::max(1, (bits + 7) / 8);
     const uint64_t n_blocks = (n + RS_BLOCK - 1) / RS_BLOCK;
     const unsigned grid = (unsigned)n_blocks;
     mf_buf<uint32_t> hist; MF_TRY(hist.alloc(ctx, 256 * n_blocks));
@@ -140,11 +141,11 @@ static int rs_sort(mf_ctx *ctx, const K *d_keys_in, const V *d_vals_in, uint64_t
     for (int p = 0; p < passes; p++) {
         const bool to_out = ((passes - 1 - p) & 1) == 0;
         K *dst_k = to_out ? d_keys_out : tk.p; V *dst_v = to_out ? d_vals_out : tv.p;
-        const int left = std::min<int>(bits, (int)sizeof(K) * 8) - 8 * p;                  // (bits above `bits` take no part in the order)
+        const int left = bits - 8 * p;                                                       // (bits above the range take no part in the order)
         const uint32_t dmask = left >= 8 ? 255u : (1u << left) - 1u;
-        k_rs_count<K><<<grid, RS_T, 0, st>>>(src_k, n, 8 * p, dmask, hist.p, n_blocks);
+        k_rs_count<K><<<grid, RS_T, 0, st>>>(src_k, n, first_bit + 8 * p, dmask, hist.p, n_blocks);
         MF_TRY(mf_scan<1>(ctx, hist.p, offs.p, 256 * n_blocks, tot.p));
-        k_rs_scatter<K, V><<<grid, RS_T, 0, st>>>(src_k, src_v, n, 8 * p, dmask, offs.p, n_blocks, dst_k, dst_v);
+        k_rs_scatter<K, V><<<grid, RS_T, 0, st>>>(src_k, src_v, n, first_bit + 8 * p, dmask, offs.p, n_blocks, dst_k, dst_v);
         src_k = dst_k; src_v = dst_v;
     }
     MF_HIP(hipGetLastError());
@@ -189,6 +190,12 @@ int mf_sort_u64_u32(mf_ctx *ctx, const uint64_t *d_keys_in, const uint32_t *d_va
 // (u64 key, u64 value) pairs (mf_wide.hip: the two words of a 2k-bit k-mer, sorted word by word)
 int mf_sort_u64_u64(mf_ctx *ctx, const uint64_t *d_keys_in, const uint64_t *d_vals_in, uint64_t n, int bits, uint64_t *d_keys_out, uint64_t *d_vals_out) {
     return rs_sort<uint64_t, uint64_t>(ctx, d_keys_in, d_vals_in, n, std::min(64, std::max(1, bits)), d_keys_out, d_vals_out);
+}
+
+// ... by the key bits [first_bit, first_bit + bits) alone (mf_wide.hip: the leading bits of a 2k-bit k-mer; the rest is ordered in LDS)
+int mf_sort_u64_u64_range(mf_ctx *ctx, const uint64_t *d_keys_in, const uint64_t *d_vals_in, uint64_t n, int first_bit, int bits, uint64_t *d_keys_out, uint64_t *d_vals_out) {
+    if (first_bit < 0 || first_bit > 63 || bits < 1) return mf_set_error("sort: bits [%d, %d + %d) of a 64-bit key", first_bit, first_bit, bits);
+    return rs_sort<uint64_t, uint64_t>(ctx, d_keys_in, d_vals_in, n, bits, d_keys_out, d_vals_out, first_bit);
 }
 
 // test hook (not part of the ABI, tests/test_round5_gpu.py): sorts host arrays with the kernels above.  kind: 0 = (u64, u16), 1 = (u32, u32), 2 = (u32, u64),

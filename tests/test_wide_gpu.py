@@ -6,10 +6,10 @@ import numpy as np
 import pytest
 
 
-def _reads(rng, n, lo, hi, genome=4000, err=0.01):
+def _reads(rng, n, lo, hi, genome=4000, err=0.01, polya=80):
     g = rng.integers(0, 4, genome)
-    g[100:180] = 0                                            # poly-A: key 0, saturation
-    g[300:340] = np.tile([0, 3], 20)                          # (AT)n: reverse-complement palindromes at even k
+    g[100:100 + polya] = 0                                            # poly-A: key 0, saturation
+    g[600:640] = np.tile([0, 3], 20)                          # (AT)n: reverse-complement palindromes at even k
     al = np.frombuffer(b"AGCT", dtype=np.uint8)
     seqs = []
     for _ in range(n):
@@ -94,6 +94,41 @@ def test_wide_counts_at_20M_reads_k63(gpu_ctx):
     finally:
         gpu_ctx.set_option("wide_passes", 0)
     assert np.array_equal(b["hi"], hi) and np.array_equal(b["lo"], lo) and np.array_equal(b["counts"].astype(np.int64), c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [32, 41, 47, 48, 63])
+def test_wide_buckets_small_and_large(gpu_ctx, oracle, k):
+    """Round 5: radix passes over the leading 32 bits only, the order inside those buckets made in LDS (k_wide_finish): buckets of <= 256 entries by
+    walking them, larger ones through a hash table in LDS (distinct k-mers + counts, written back as runs); a bucket of more than 704 distinct
+    k-mers is gathered, sorted with the full radix sort and put back (or, when such buckets hold more than a quarter of a pass, the whole pass is).
+    A genome at depth ~10 with a long poly-A stretch: mostly small buckets + a few large ones; the limits lowered by option drive every route;
+    wide_finish = 0 is the 16-pass sort of round 4.  One table, the oracle's."""
+    from util import to_device
+    rng = np.random.default_rng(500 + k)
+    bases, off = _reads(rng, 30000, 60, 160, genome=300000, err=0.005, polya=400)
+    db, do = to_device(bases, off)
+    hi, lo, cnt, n_occ = oracle.count_wide(bases, off, k, 0)
+    assert 2 < cnt.mean() < 50 and cnt.max() > 256
+    seen = []
+    for opts in ({}, {"wide_distinct": 4}, {"wide_big_bucket": 2}, {"wide_big_bucket": 2, "wide_distinct": 1}, {"wide_big_bucket": 1, "wide_distinct": 8, "wide_passes": 3},
+                 {"wide_finish": 0}, {"wide_passes": 5}):
+        before = gpu_ctx.stat("wide_big_entries"), gpu_ctx.stat("wide_hashed_entries")
+        try:
+            for o, v in opts.items():
+                gpu_ctx.set_option(o, v)
+            got = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), len(off) - 1, len(bases), k, 0)
+        finally:
+            for o, v in (("wide_big_bucket", 256), ("wide_distinct", 704), ("wide_finish", 1), ("wide_passes", 0)):
+                gpu_ctx.set_option(o, v)
+        assert got["n_occ"] == n_occ
+        assert np.array_equal(got["hi"], hi) and np.array_equal(got["lo"], lo) and np.array_equal(got["counts"].astype(np.int32), cnt), opts
+        seen.append((gpu_ctx.stat("wide_big_entries") - before[0], gpu_ctx.stat("wide_hashed_entries") - before[1]))
+    assert seen[0][0] == 0 and 256 < seen[0][1] < n_occ // 4, seen          # the poly-A bucket(s) through the hash table, nothing sorted aside
+    assert 0 < seen[1][0] < n_occ // 4, seen                               # ... sorted aside
+    assert seen[2][0] == 0 and seen[2][1] > n_occ // 2, seen               # nearly every bucket through the hash table
+    assert seen[3][0] > n_occ // 4, seen                                   # nearly every bucket refused by the table: the whole-pass sort
+    assert seen[5] == (0, 0), seen
 
 
 def test_wide_oracle_agrees_with_the_pinned_oracle_at_the_seam(oracle):

@@ -8,7 +8,7 @@ from metafast_amd import lib as L
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000_000
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 63
 rl = 150
-ctx = L.Context(0, stream=torch.cuda.current_stream()); ctx.set_option("profile", 1)
+ctx = L.Context(0, stream=torch.cuda.current_stream()); ctx.set_option("profile", 1); ctx.set_option("verbose", int(os.environ.get("MF_VERBOSE", "0"))); ctx.set_option("wide_ablate", int(os.environ.get("MF_WIDE_DEBUG", "0")))
 bases = torch.zeros(n * rl + 64, dtype=torch.uint8, device="cuda"); offsets = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
 ctx.synth_reads_device(0x4D45544146415354, 0, 0, n, rl, 1_000_000, bases.data_ptr(), offsets.data_ptr())
 torch.cuda.synchronize()
@@ -25,5 +25,5 @@ for it in range(2):
     L.lib().mf_wtable_destroy(t)
     res.append(dict(seconds=round(dt, 3), n_occ=occ.value, n_distinct=nd.value, kmers_per_s=round(occ.value / dt, 1),
                     kernels={kk_: round(v[1], 1) for kk_, v in ctx.kernel_report().items()}))
-print(json.dumps(dict(what="NO-REFERENCE EXTENSION: canonical %d-mer counts of one sample of %d synthetic 150 bp reads on one MI355X (mf_count_wide_device: prefix passes, mf_sort.hip radix sort per pass)" % (k, n),
+print(json.dumps(dict(what="NO-REFERENCE EXTENSION: canonical %d-mer counts of one sample of %d synthetic 150 bp reads on one MI355X (mf_count_wide_device: class-range passes, radix passes over the leading 32 bits, buckets ordered in LDS)" % (k, n),
                       reads=n, k=k, runs=res)))
