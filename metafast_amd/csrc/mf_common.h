@@ -94,7 +94,7 @@ struct mf_ctx {
     int64_t opt_file_cache_gb = 0; // > 0: tables / components written to files stay in HBM (up to this many GB) and are handed out when the same file is loaded again
     int64_t opt_wide_finish = 1;   // mf_count_wide_device: radix passes over the leading 32 bits + the order inside the buckets in LDS (0: radix passes over all 2k bits)
     int64_t opt_wide_big_bucket = 256;   // ... buckets of more entries than this (<= 256) go through the LDS hash table instead of the walk (tests lower it)
-    int64_t opt_wide_distinct = 704;     // ... buckets of more distinct k-mers than this (<= 704) are sorted aside (tests lower it)
+    int64_t opt_wide_distinct = 1280;    // ... buckets of more distinct k-mers than this (<= 1280) are sorted aside (tests lower it)
     int64_t opt_wide_ablate = 0;         // ... TIMING ONLY, wrong tables: 1 = large buckets skipped, 2 = the representatives' walk skipped
     int64_t opt_wide_passes = 0;   // mf_count_wide_device: passes over the reads, each for one prefix class of the canonical k-mers (0 = as many as the memory asks for; tests force a number)
     int64_t opt_cc_sparse = 1;     // component cutter: threshold levels that few vertices reach run on a list of them (0: every level visits all vertices)
@@ -460,6 +460,7 @@ int mf_sort_u32_pairs(mf_ctx *ctx, const uint32_t *d_keys_in, const uint32_t *d_
 int mf_sort_u32_u64(mf_ctx *ctx, const uint32_t *d_keys_in, const uint64_t *d_vals_in, uint64_t n, int bits, uint32_t *d_keys_out,
                     uint64_t *d_vals_out);
 int mf_sort_u64_u64(mf_ctx *ctx, const uint64_t *d_keys_in, const uint64_t *d_vals_in, uint64_t n, int bits, uint64_t *d_keys_out, uint64_t *d_vals_out);
+int mf_sort_u64_u64_pingpong(mf_ctx *ctx, uint64_t *k0, uint64_t *v0, uint64_t n, int first_bit, int bits, uint64_t *k1, uint64_t *v1, int *in_second);
 int mf_sort_u64_u64_range(mf_ctx *ctx, const uint64_t *d_keys_in, const uint64_t *d_vals_in, uint64_t n, int first_bit, int bits, uint64_t *d_keys_out, uint64_t *d_vals_out);
 int mf_sort_kmers_by_comp(mf_ctx *ctx, const uint32_t *d_comp, const uint64_t *d_kmers, uint64_t n, int key_bits, uint32_t n_comps,
                           uint64_t *d_out);

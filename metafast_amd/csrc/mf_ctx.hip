@@ -184,7 +184,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "wide_finish") ctx->opt_wide_finish = v ? 1 : 0;
     else if (s == "wide_big_bucket") { if (v < 1 || v > 256) return mf_set_error("wide_big_bucket must be in [1, 256]"); ctx->opt_wide_big_bucket = v; }
     else if (s == "wide_ablate") ctx->opt_wide_ablate = v;
-    else if (s == "wide_distinct") { if (v < 1 || v > 704) return mf_set_error("wide_distinct must be in [1, 704]"); ctx->opt_wide_distinct = v; }
+    else if (s == "wide_distinct") { if (v < 1 || v > 1280) return mf_set_error("wide_distinct must be in [1, 1280]"); ctx->opt_wide_distinct = v; }
     else if (s == "wide_passes") { if (v < 0 || v > 65536) return mf_set_error("wide_passes must be in [0, 65536]"); ctx->opt_wide_passes = v; }
     else if (s == "file_cache") {                       // GB; -1: a quarter of the device's memory, -n: an n-th of that (n contexts share the device)
         if (v < 0) { size_t fr = 0, tot = 0; MF_HIP(hipSetDevice(ctx->device)); MF_HIP(hipMemGetInfo(&fr, &tot)); v = std::max<int64_t>(1, (int64_t)(tot >> 32) / -v); }
@@ -218,6 +218,7 @@ extern "C" int64_t mf_ctx_stat(mf_ctx *ctx, const char *name) {
     if (s == "device_parser_stepped_back") return (int64_t)ctx->n_dparse_stepped_back;
     if (s == "hipmalloc_calls") return (int64_t)ctx->n_hipmalloc;
     if (s == "hipmalloc_bytes") return (int64_t)ctx->b_hipmalloc;
+    if (s == "hipmalloc_us") return (int64_t)(ctx->t_hipmalloc * 1e6);
     if (s == "arena_bytes") return (int64_t)ctx->arena_bytes;
     if (s == "arena_idle_bytes") return (int64_t)mf_arena_idle(ctx);
     return mf_set_error("mf_ctx_stat: unknown name '%s'", name);

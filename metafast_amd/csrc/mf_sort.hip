@@ -120,8 +120,11 @@ __global__ __launch_bounds__(RS_T) void k_rs_scatter(const K *__restrict__ keys,
 }
 
 // in -> out, ascending by the `bits` key bits from bit `first_bit` up, stable.  tmp_k / tmp_v: n elements each (needed when more than one pass is made)
+// pingpong != nullptr: no temporaries -- the input arrays are written too (d_keys_in / d_vals_in must be writable) and *pingpong says where the
+// result is: 0 = in d_keys_out / d_vals_out, 1 = back in the input arrays (an even number of passes).
 template <typename K, typename V>
-static int rs_sort(mf_ctx *ctx, const K *d_keys_in, const V *d_vals_in, uint64_t n, int bits, K *d_keys_out, V *d_vals_out, int first_bit = 0) {
+static int rs_sort(mf_ctx *ctx, const K *d_keys_in, const V *d_vals_in, uint64_t n, int bits, K *d_keys_out, V *d_vals_out, int first_bit = 0, int *pingpong = nullptr) {
+    if (pingpong) *pingpong = 0;
     if (!n) return MF_OK;
     if (n >= (1ull << 32)) return mf_set_error("sort: more than 2^32 entries is not supported");
     MF_HIP(hipSetDevice(ctx->device));
@@ -134,13 +137,13 @@ static int rs_sort(mf_ctx *ctx, const K *d_keys_in, const V *d_vals_in, uint64_t
     mf_buf<uint64_t> offs; MF_TRY(offs.alloc(ctx, 256 * n_blocks + 1));
     mf_buf<uint64_t> tot; MF_TRY(tot.alloc(ctx, 2));
     mf_buf<K> tk; mf_buf<V> tv;
-    if (passes > 1) { MF_TRY(tk.alloc(ctx, n)); MF_TRY(tv.alloc(ctx, n)); }
+    if (passes > 1 && !pingpong) { MF_TRY(tk.alloc(ctx, n)); MF_TRY(tv.alloc(ctx, n)); }
     // the last pass must land in the caller's buffers: with an even number of passes the first one goes to the temporaries
     const K *src_k = d_keys_in; const V *src_v = d_vals_in;
     mf_ktimer tm(ctx, "k_radix_sort");
     for (int p = 0; p < passes; p++) {
-        const bool to_out = ((passes - 1 - p) & 1) == 0;
-        K *dst_k = to_out ? d_keys_out : tk.p; V *dst_v = to_out ? d_vals_out : tv.p;
+        const bool to_out = pingpong ? (p & 1) == 0 : ((passes - 1 - p) & 1) == 0;
+        K *dst_k = to_out ? d_keys_out : (pingpong ? const_cast<K *>(d_keys_in) : tk.p); V *dst_v = to_out ? d_vals_out : (pingpong ? const_cast<V *>(d_vals_in) : tv.p);
         const int left = bits - 8 * p;                                                       // (bits above the range take no part in the order)
         const uint32_t dmask = left >= 8 ? 255u : (1u << left) - 1u;
         k_rs_count<K><<<grid, RS_T, 0, st>>>(src_k, n, first_bit + 8 * p, dmask, hist.p, n_blocks);
@@ -148,6 +151,7 @@ static int rs_sort(mf_ctx *ctx, const K *d_keys_in, const V *d_vals_in, uint64_t
         k_rs_scatter<K, V><<<grid, RS_T, 0, st>>>(src_k, src_v, n, first_bit + 8 * p, dmask, offs.p, n_blocks, dst_k, dst_v);
         src_k = dst_k; src_v = dst_v;
     }
+    if (pingpong) *pingpong = (passes & 1) ? 0 : 1;
     MF_HIP(hipGetLastError());
     MF_HIP(hipStreamSynchronize(st));
     return MF_OK;
@@ -196,6 +200,14 @@ int mf_sort_u64_u64(mf_ctx *ctx, const uint64_t *d_keys_in, const uint64_t *d_va
 int mf_sort_u64_u64_range(mf_ctx *ctx, const uint64_t *d_keys_in, const uint64_t *d_vals_in, uint64_t n, int first_bit, int bits, uint64_t *d_keys_out, uint64_t *d_vals_out) {
     if (first_bit < 0 || first_bit > 63 || bits < 1) return mf_set_error("sort: bits [%d, %d + %d) of a 64-bit key", first_bit, first_bit, bits);
     return rs_sort<uint64_t, uint64_t>(ctx, d_keys_in, d_vals_in, n, bits, d_keys_out, d_vals_out, first_bit);
+}
+// ... without temporaries: the two pairs of arrays are each other's ping-pong; *in_second = 1 when the result is in (k1, v1), 0 when it is back in (k0, v0)
+int mf_sort_u64_u64_pingpong(mf_ctx *ctx, uint64_t *k0, uint64_t *v0, uint64_t n, int first_bit, int bits, uint64_t *k1, uint64_t *v1, int *in_second) {
+    if (first_bit < 0 || first_bit > 63 || bits < 1 || !in_second) return mf_set_error("sort: bits [%d, %d + %d) of a 64-bit key", first_bit, first_bit, bits);
+    int back = 0;
+    const int rc = rs_sort<uint64_t, uint64_t>(ctx, k0, v0, n, bits, k1, v1, first_bit, &back);
+    *in_second = back ? 0 : 1;
+    return rc;
 }
 
 // test hook (not part of the ABI, tests/test_round5_gpu.py): sorts host arrays with the kernels above.  kind: 0 = (u64, u16), 1 = (u32, u32), 2 = (u32, u64),

@@ -6,13 +6,13 @@
 // Same definitions as for k <= 31, on 2k-bit numbers: first base most significant (A0 G1 C2 T3), canonical = min(forward,
 // reverse complement), counts saturate at 32767, reads shorter than max(k, min_len) give nothing.
 //
-// Not the hot path.  Round 5 (200 M reads at k = 63: 9.1 s -> 2.8 s):
+// Not the hot path.  Round 5 (200 M reads at k = 63: 9.1 s -> 1.98 s):
 //   k_wide_kmers<true>   the k-mers per class (top 10 bits of the canonical value): the host cuts the class range into passes of about equal size
-//                        that fit the device (48 bytes per occurrence) and the sort (< 2^31 entries);
+//                        that fit the device (36 bytes per occurrence) and the sort (< 2^32 entries);
 //   k_wide_kmers<false>  the canonical k-mers of a pass's classes, two 64-bit words each, through an LDS stage (bases packed 2 bits in LDS, no
 //                        warm-up of k - 1 bases, no byte loads in the loop);
 //   mf_sort.hip          radix passes over the LEADING 32 bits only (4 of the 16 passes a full sort of 2k = 126 bits takes);
-//   k_wide_finish        the order inside the buckets of equal leading bits, in LDS;
+//   k_wide_finish, k_wide_big  the order inside the buckets of equal leading bits, in LDS;
 //   k_wide_flags/heads/counts  run lengths = counts.
 #include <cstring>
 #include <memory>
@@ -26,8 +26,8 @@ struct mf_wtable {
     mf_ctx *ctx = nullptr;
     int k = 0;
     uint64_t n = 0, n_occ = 0;
-    mf_buf<uint64_t> hi, lo;          // ascending (hi, lo)
-    mf_buf<uint16_t> cnt;
+    struct piece { mf_buf<uint64_t> hi, lo; mf_buf<uint16_t> cnt; uint64_t n = 0; };     // ascending (hi, lo) inside a piece, and piece after piece
+    std::vector<std::unique_ptr<piece>> pieces;   // (one per pass: no second copy of a 74 GB table, and none of the 8 ms per GB a first hipMalloc of it takes)
 };
 
 __global__ void k_wide_mask_init(uint32_t *__restrict__ vmask, uint64_t n_words) {
@@ -168,53 +168,56 @@ __global__ __launch_bounds__(WG_T) void k_wide_kmers(const uint8_t *__restrict__
 
 // ---- order inside the leading-bits buckets (round 5) ----
 // After the radix passes over the leading WF_BITS bits of the 2k-bit numbers, equal leading bits sit together ("buckets": a few distinct k-mers and
-// their repeats).  A workgroup takes WF_TILE entries + the WF_BIG that follow into LDS, numbers the buckets (a scan over the bucket heads) and
-// orders the buckets that START in its tile -- the remaining 2k - WF_BITS bits never go through HBM again (12 of 16 radix passes saved at k = 63):
-//   <= WF_BIG entries: every entry looks its k-mer up in a hash table of the tile (a slot holds the index of the first entry that came with the
-//     k-mer, its "representative"; the keys stay where they are) and takes a number among its equals; only the representatives walk their bucket
-//     and count the entries below them (walking with every entry cost 8 x as much on abundant k-mers: 552 -> 66 ms per 4.4e9 entries without
-//     the walk, profiles/r05ah_finish_ablation.txt); place = bucket start + entries below + number among equals;
-//   more (abundant k-mers and their error variants; a bucket may run over many tiles): the workgroup streams the bucket through a second hash
-//     table in LDS (the tile's own arrays, done with by then) -- distinct k-mers and their counts --, ranks the distinct k-mers and writes the runs;
-//   more than `dlimit` distinct k-mers in one bucket (low-complexity reads): put on a list -- the host gathers those buckets, sorts them with the
-//     full radix sort and puts them back (or sorts the whole pass, if they hold more than a quarter of it).
+// their repeats) -- the remaining 2k - WF_BITS bits never go through HBM again (12 of 16 radix passes saved at k = 63):
+//   k_wide_finish      a workgroup takes WF_TILE entries + the WF_BIG that follow into LDS, numbers the buckets (a scan over the bucket heads) and
+//                      orders the buckets of <= WF_BIG entries that START in its tile: every entry looks its k-mer up in a hash table of the tile (a
+//                      slot holds the index of the first entry that came with the k-mer, its "representative"; the keys stay where they are) and takes
+//                      a number among its equals; only the representatives look at their bucket, and only at its other representatives (a bitmap),
+//                      adding up the counts of the smaller ones; place = bucket start + entries below + number among equals.  (Walking the bucket
+//                      with every entry: 552 ms per 4.4e9 entries, 66 ms of it not the walk, profiles/r05ah_finish_ablation.txt.)  Larger buckets
+//                      (abundant k-mers and their error variants: 40 % of the entries at 200 M reads, 616 entries and 90 distinct k-mers on
+//                      average) go on a list;
+//   k_wide_big<64>     ONE WAVE per listed bucket (no workgroup barriers, 12 buckets in flight per CU): streams the bucket -- it may run over many
+//                      tiles -- through a hash table of 512 slots in LDS (distinct k-mers and counts), ranks the distinct k-mers, writes the runs;
+//                      more than 320 distinct k-mers: on to the next list;
+//   k_wide_big<256>    the same with a workgroup and 2048 slots; more than `dlimit` (<= 1280) distinct k-mers (low-complexity reads): the last list --
+//                      the host gathers those buckets, sorts them with the full radix sort and puts them back (or sorts the whole pass, if they
+//                      hold more than a quarter of it).
 #define WF_BITS 32
 #define WF_T 256
-#define WF_PER 5
-#define WF_N (WF_T * WF_PER)          // 1280 entries in LDS
+#define WF_PER 3
+#define WF_N (WF_T * WF_PER)          // 768 entries in LDS
 #define WF_BIG 256
-#define WF_TILE (WF_N - WF_BIG)       // 1024
-#define WF_TAB 2048                   // slots of the tile's table (<= WF_N distinct k-mers)
-#define WF_SLOTS 1024                 // slots of the large buckets' table (in l_hi / l_lo / bstart)
-#define WF_DMAX 704                   // distinct k-mers it takes (+ 256 in flight < WF_SLOTS)
-#define WF_LIST 512                   // large buckets a tile can own
+#define WF_TILE (WF_N - WF_BIG)       // 512
+#define WF_TAB 1024                   // slots of the tile's table (<= WF_N distinct k-mers)
+#define WF_LIST 256                   // large buckets a tile can own (512 / 2)
 #define WF_LOCK 0xFFFFFFFFu
 #define WF_EMPTY 0xFFFFFFFFu
 __device__ __forceinline__ uint32_t wide_hash(const wide128 &x) { return (uint32_t)((x.lo * 0x9E3779B97F4A7C15ull ^ x.hi * 0xC2B2AE3D27D4EB4Full) >> 40); }
-__global__ __launch_bounds__(WF_T) void k_wide_finish(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n, int hb, uint32_t big, uint32_t dlimit, int dbg,
-                                                      uint64_t *__restrict__ ohi, uint64_t *__restrict__ olo, unsigned long long *__restrict__ big_start,
-                                                      unsigned int *__restrict__ n_big, unsigned long long *__restrict__ n_hashed) {
+__global__ __launch_bounds__(WF_T) void k_wide_finish(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n, int hb_tb, uint32_t big, int dbg,
+                                                      uint64_t *__restrict__ ohi, uint64_t *__restrict__ olo, unsigned long long *__restrict__ tile_big, uint32_t tile_cap,
+                                                      uint32_t *__restrict__ tile_cnt) {
     __shared__ uint64_t l_hi[WF_N], l_lo[WF_N];
-    __shared__ uint32_t bstart[WF_N + 1];
-    __shared__ uint32_t tab[WF_TAB], ecnt[WF_N], reps[WF_N];
-    __shared__ uint16_t occ[WF_DMAX + WF_T], mybig[WF_LIST];
+    __shared__ uint32_t bstart[WF_N + 1], tab[WF_TAB], ecnt[WF_N], reps[WF_N], repbits[WF_N / 32];
+    __shared__ uint16_t mybig[WF_LIST];
     __shared__ uint32_t scratch[17];
-    __shared__ uint32_t s_cont0, s_open, s_nbig, s_nreps, s_ndist, s_nocc, s_stop;
-    __shared__ unsigned long long s_end;
-    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    __shared__ uint32_t s_cont0, s_open, s_nbig, s_nreps;
+    const int hb = hb_tb & 255, tb = hb_tb >> 8;                                  // bits of the k-mer in the high word; leading bits the array is ascending in
+    const uint32_t tid = threadIdx.x;
     const uint64_t base = (uint64_t)blockIdx.x * WF_TILE;
     const uint32_t cnt = (uint32_t)(n - base < WF_TILE ? n - base : WF_TILE), N = (uint32_t)(n - base < WF_N ? n - base : WF_N);
     for (uint32_t i = tid; i < N; i += WF_T) { l_hi[i] = hi[base + i]; l_lo[i] = lo[base + i]; }
     for (uint32_t i = tid; i < WF_TAB; i += WF_T) tab[i] = WF_EMPTY;
     for (uint32_t i = tid; i < WF_N; i += WF_T) ecnt[i] = 0;
+    if (tid < WF_N / 32) repbits[tid] = 0;
     if (tid == 0) { s_nbig = 0; s_nreps = 0; }
     __syncthreads();
-    auto pre = [&](uint32_t i) { const wide128 x = {l_hi[i], l_lo[i]}; return wide_class(x, hb, WF_BITS); };
+    auto pre = [&](uint32_t i) { const wide128 x = {l_hi[i], l_lo[i]}; return wide_class(x, hb, tb); };
     if (tid == 0) {
         const wide128 p = {base ? hi[base - 1] : 0ull, base ? lo[base - 1] : 0ull};
-        s_cont0 = base && wide_class(p, hb, WF_BITS) == pre(0);
+        s_cont0 = base && wide_class(p, hb, tb) == pre(0);
         const wide128 q = {base + N < n ? hi[base + N] : 0ull, base + N < n ? lo[base + N] : 0ull};
-        s_open = base + N < n && wide_class(q, hb, WF_BITS) == pre(N - 1);
+        s_open = base + N < n && wide_class(q, hb, tb) == pre(N - 1);
     }
     // bucket numbers: entry i of thread t's run [t * WF_PER, ..) is a head when its leading bits differ from the entry before (entry 0 always)
     uint32_t heads = 0, hm = 0;
@@ -240,11 +243,8 @@ __global__ __launch_bounds__(WF_T) void k_wide_finish(const uint64_t *__restrict
         if ((hm >> j) & 1u) b++;                                                 // entry i is in bucket b - 1
         const uint32_t me = b - 1, s = bstart[me], e = bstart[me + 1];
         if (s >= cnt || (me == 0 && s_cont0)) continue;                          // another tile's bucket
-        if (e - s > big || (me == n_buckets - 1 && s_open)) {
-            if (i == s) {
-                const uint32_t q = atomicAdd(&s_nbig, 1u);
-                if (q < WF_LIST) mybig[q] = (uint16_t)s; else big_start[atomicAdd(n_big, 1u)] = base + s;
-            }
+        if (e - s > big || (me == n_buckets - 1 && s_open)) {                    // (open: it runs on past what is in LDS, i.e. more than WF_BIG entries)
+            if (i == s) mybig[atomicAdd(&s_nbig, 1u)] = (uint16_t)s;             // (at most WF_TILE / 2 of them: big >= 1)
             continue;
         }
         const wide128 x = {l_hi[i], l_lo[i]};
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(WF_T) void k_wide_finish(const uint64_t *__restrict
             uint32_t v = __hip_atomic_load(&tab[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (v == WF_EMPTY) {
                 v = atomicCAS(&tab[h], WF_EMPTY, i);
-                if (v == WF_EMPTY) { rep = i; reps[atomicAdd(&s_nreps, 1u)] = (me << 16) | i; break; }
+                if (v == WF_EMPTY) { rep = i; reps[atomicAdd(&s_nreps, 1u)] = (me << 16) | i; atomicOr(&repbits[i >> 5], 1u << (i & 31u)); break; }
             }
             if (l_hi[v] == x.hi && l_lo[v] == x.lo) { rep = v; break; }
             h = (h + 1) & (WF_TAB - 1);
@@ -262,94 +262,170 @@ __global__ __launch_bounds__(WF_T) void k_wide_finish(const uint64_t *__restrict
         my_at[j] = s + atomicAdd(&ecnt[rep], 1u);
     }
     __syncthreads();
-    // the representatives: entries of the bucket below them.  ecnt[] becomes that number
-    const uint32_t nreps = s_nreps;
+    // the representatives: the entries of the bucket below them = the counts of the bucket's smaller representatives (a bucket of 200 repeats of
+    // 3 k-mers costs 3 x 3 comparisons, not 3 x 200).  ecnt[]: count in the low half, that number in the high half
+    const uint32_t nreps = s_nreps, nbig = (dbg & 1) ? 0u : s_nbig;
+    if (tid == 0) tile_cnt[blockIdx.x] = nbig;                                     // (no list with one cursor: 2.3e6 atomics on one address per pass)
     if (!(dbg & 2)) for (uint32_t r = tid; r < nreps; r += WF_T) {
         const uint32_t i = reps[r] & 0xFFFFu, me = reps[r] >> 16, s = bstart[me], e = bstart[me + 1];
         const wide128 x = {l_hi[i], l_lo[i]};
         uint32_t below = 0;
-        for (uint32_t o = s; o < e; o++) { const wide128 y = {l_hi[o], l_lo[o]}; below += wide_less(y, x) ? 1u : 0u; }
-        ecnt[i] = below;
+        const uint32_t w0 = s >> 5, w1 = (e - 1) >> 5;
+        for (uint32_t w = w0; w <= w1; w++) {
+            uint32_t m = repbits[w];
+            if (w == w0) m &= ~0u << (s & 31u);
+            if (w == w1 && (e & 31u)) m &= (1u << (e & 31u)) - 1u;
+            while (m) {
+                const uint32_t o = w * 32 + (uint32_t)__builtin_ctz(m);
+                m &= m - 1;
+                const wide128 y = {l_hi[o], l_lo[o]};
+                if (wide_less(y, x)) below += ecnt[o] & 0xFFFFu;
+            }
+        }
+        ecnt[i] = (below << 16) | (ecnt[i] & 0xFFFFu);
     }
     __syncthreads();
 #pragma unroll
     for (uint32_t j = 0; j < WF_PER; j++) {
         if (my_rep[j] == WF_EMPTY) continue;
         const uint32_t i = i0 + j;
-        const uint64_t at = base + my_at[j] + ecnt[my_rep[j]];
+        const uint64_t at = base + my_at[j] + (ecnt[my_rep[j]] >> 16);
         ohi[at] = l_hi[i]; olo[at] = l_lo[i];
     }
+    for (uint32_t q = tid; q < nbig; q += WF_T) tile_big[(uint64_t)blockIdx.x * tile_cap + q] = base + mybig[q];       // (nbig <= tile_cap = (WF_TILE - 1) / (big + 1) + 1)
+}
+// the tiles' large buckets as one list
+__global__ void k_wide_big_list(const unsigned long long *__restrict__ tile_big, uint32_t tile_cap, const uint32_t *__restrict__ tile_cnt, const uint64_t *__restrict__ toff,
+                                uint64_t n_tiles, unsigned long long *__restrict__ list) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t c = tile_cnt[t];
+    for (uint32_t q = 0; q < c; q++) list[toff[t] + q] = tile_big[t * tile_cap + q];
+}
+
+// One workgroup of T threads (T = 64: one wave) per listed bucket: tcnt[] 0 = free, WF_LOCK = being written, else the count of the k-mer in the slot.
+// stats: 128 stripes of 16 words (a stripe per cache line: 1.1e7 buckets adding to ONE line cost more than the kernel), [0] entries, [1] buckets,
+// [2] the largest, [3] distinct k-mers (summed)
+template <int T, int SLOTS>
+__global__ __launch_bounds__(T) void k_wide_big(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n, int hb_tb, const unsigned long long *__restrict__ list,
+                                                uint32_t dlimit, uint64_t *__restrict__ ohi, uint64_t *__restrict__ olo, unsigned long long *__restrict__ over_list,
+                                                unsigned int *__restrict__ n_over, unsigned long long *__restrict__ stats, int dbg) {
+    constexpr int DCAP = SLOTS * 7 / 8;                                              // dlimit + 2 T <= DCAP: the table never fills
+    __shared__ uint64_t t_hi[SLOTS], t_lo[SLOTS];
+    __shared__ uint32_t tcnt[SLOTS];
+    __shared__ uint64_t d_hi[DCAP], d_lo[DCAP];                                      // the distinct k-mers side by side (the ranking loop reads them in step, no slot numbers in between) ...
+    __shared__ uint32_t d_cnt[DCAP];                                                 // ... and their counts; later: where the run of the k-mer of rank r starts
+    __shared__ uint16_t order[DCAP];                                                 // rank -> place in d_hi / d_lo
+    __shared__ uint32_t s_ndist, s_nocc, s_stop;
+    __shared__ unsigned long long s_end;
+    const int hb = hb_tb & 255, tb = hb_tb >> 8;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t start = list[blockIdx.x];
+    for (uint32_t i = tid; i < SLOTS; i += T) tcnt[i] = 0;
+    if (tid == 0) { s_ndist = 0; s_nocc = 0; s_stop = 0; s_end = n; }
+    const wide128 first = {hi[start], lo[start]};
+    const uint32_t p = wide_class(first, hb, tb);
+    wide128 cur[2], nxt[2];
+    auto fetch = [&](wide128 *x, uint64_t pos) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) { const uint64_t e = pos + (uint64_t)c * T + tid; x[c].hi = 0; x[c].lo = 0; if (e < n) { x[c].hi = hi[e]; x[c].lo = lo[e]; } }
+    };
+    fetch(cur, start);
     __syncthreads();
-    // the large buckets this tile owns, one after the other: bstart[] becomes the table's counters (0: free, WF_LOCK: being written), l_hi / l_lo its keys
-    const uint32_t nbig = (dbg & 1) ? 0u : (s_nbig < WF_LIST ? s_nbig : WF_LIST);
-    uint32_t *tcnt = bstart;
-    for (uint32_t q = 0; q < nbig; q++) {
-        const uint64_t start = base + mybig[q];
-        for (uint32_t i = tid; i < WF_SLOTS; i += WF_T) tcnt[i] = 0;
-        if (tid == 0) { s_ndist = 0; s_nocc = 0; s_stop = 0; s_end = n; }
-        const wide128 first = {hi[start], lo[start]};
-        const uint32_t p = wide_class(first, hb, WF_BITS);
-        __syncthreads();
-        bool over = false;
-        for (uint64_t pos = start;; pos += WF_T) {
-            const uint64_t e = pos + tid;
-            wide128 x = {0, 0};
-            bool same = false;
-            if (e < n) { x.hi = hi[e]; x.lo = lo[e]; same = wide_class(x, hb, WF_BITS) == p; }
+    for (uint64_t pos = start;; pos += 2 * T) {                                      // two entries per thread, and the next two on their way
+        fetch(nxt, pos + 2 * T);
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const uint64_t e = pos + (uint64_t)c * T + tid;
+            const bool same = e < n && wide_class(cur[c], hb, tb) == p;
             if (!same) { if (e < n) atomicMin(&s_end, (unsigned long long)e); s_stop = 1; }
-            uint32_t slot = wide_hash(x) & (WF_SLOTS - 1);
-            bool done = !same;
+            uint32_t slot = wide_hash(cur[c]) & (SLOTS - 1);
+            bool done = !same || (dbg & 16);
+            // the lanes of a wave that hold the k-mer of its first lane (twice: the first of the rest) send ONE of them with their number -- most of a
+            // large bucket is one abundant k-mer, and 64 lanes adding to one LDS word take turns (50 of 108 ms were the inserts, r05ar)
+            uint32_t weight = 1;
+            bool led = false;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const unsigned long long act = __ballot(!done && !led);
+                if (!act) break;                                                     // (uniform)
+                const int leader = __ffsll((long long)act) - 1;
+                const uint64_t lh = (uint64_t)__shfl((unsigned long long)cur[c].hi, leader), ll = (uint64_t)__shfl((unsigned long long)cur[c].lo, leader);
+                const bool eq = !done && !led && cur[c].hi == lh && cur[c].lo == ll;
+                const unsigned long long m = __ballot(eq);
+                if (eq) { if ((int)(tid & 63u) == leader) { weight = (uint32_t)__popcll(m); led = true; } else done = true; }
+            }
             while (!done) {
-                const uint32_t c = __hip_atomic_load(&tcnt[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (c == 0) {
+                const uint32_t v = __hip_atomic_load(&tcnt[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (v == 0) {
                     if (atomicCAS(&tcnt[slot], 0u, WF_LOCK) == 0u) {
-                        l_hi[slot] = x.hi; l_lo[slot] = x.lo;
-                        __hip_atomic_store(&tcnt[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        t_hi[slot] = cur[c].hi; t_lo[slot] = cur[c].lo;
+                        __hip_atomic_store(&tcnt[slot], weight, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                         atomicAdd(&s_ndist, 1u);
                         done = true;
                     }
-                } else if (c != WF_LOCK) {
-                    if (l_hi[slot] == x.hi && l_lo[slot] == x.lo) { atomicAdd(&tcnt[slot], 1u); done = true; }
-                    else slot = (slot + 1) & (WF_SLOTS - 1);
+                } else if (v != WF_LOCK) {
+                    if (t_hi[slot] == cur[c].hi && t_lo[slot] == cur[c].lo) { atomicAdd(&tcnt[slot], weight); done = true; }
+                    else slot = (slot + 1) & (SLOTS - 1);
                 }
             }
-            __syncthreads();
-            const uint32_t nd = s_ndist, stop = s_stop;
-            __syncthreads();
-            if (nd > dlimit) { over = true; break; }                                 // (dlimit + 256 < WF_SLOTS: the table never fills)
-            if (stop) break;
-        }
-        if (over) { if (tid == 0) big_start[atomicAdd(n_big, 1u)] = start; __syncthreads(); continue; }
-        const uint64_t len = s_end - start;
-        for (uint32_t i = tid; i < WF_SLOTS; i += WF_T) if (tcnt[i]) occ[atomicAdd(&s_nocc, 1u)] = (uint16_t)i;
-        __syncthreads();
-        const uint32_t D = s_nocc;
-        if (tid == 0) atomicAdd(n_hashed, (unsigned long long)len);
-        for (uint32_t a = wave; a < D; a += WF_T / 64) {                             // a wave per distinct k-mer: the entries before it, then its run
-            const uint32_t sa = occ[a];
-            const wide128 x = {l_hi[sa], l_lo[sa]};
-            unsigned long long before = 0;
-            for (uint32_t o = lane; o < D; o += 64) { const uint32_t so = occ[o]; const wide128 y = {l_hi[so], l_lo[so]}; if (wide_less(y, x)) before += tcnt[so]; }
-            for (int d = 32; d; d >>= 1) before += __shfl_xor(before, d);
-            const uint64_t c = tcnt[sa], at = start + before;
-            for (uint64_t j = lane; j < c; j += 64) { ohi[at + j] = x.hi; olo[at + j] = x.lo; }
         }
         __syncthreads();
+        const uint32_t nd = s_ndist, stop = s_stop;
+        __syncthreads();
+        if (nd > dlimit) { if (tid == 0) over_list[atomicAdd(n_over, 1u)] = start; return; }     // (uniform)
+        if (stop) break;
+        cur[0] = nxt[0]; cur[1] = nxt[1];
+    }
+    // (a bucket that ends inside the first of the two chunks: the second chunk's entries are another bucket's and were not taken -- the array is
+    // ascending in the leading bits)
+    const uint64_t len = s_end - start;
+    for (uint32_t i = tid; i < SLOTS; i += T) {
+        const uint32_t c = tcnt[i];
+        if (c) { const uint32_t a = atomicAdd(&s_nocc, 1u); d_hi[a] = t_hi[i]; d_lo[a] = t_lo[i]; d_cnt[a] = c; }
+    }
+    __syncthreads();
+    const uint32_t D = s_nocc;
+    if (tid == 0) { unsigned long long *sp = stats + 16 * (blockIdx.x & 127u); atomicAdd(sp, (unsigned long long)len); atomicAdd(sp + 1, 1ull); atomicMax(sp + 2, (unsigned long long)len); atomicAdd(sp + 3, (unsigned long long)D); }
+    // every distinct k-mer: how many distinct k-mers and how many entries are below it
+    uint32_t my_rank[DCAP / T], my_before[DCAP / T];
+#pragma unroll
+    for (uint32_t c = 0; c < DCAP / T; c++) {
+        const uint32_t a = tid + c * T;
+        my_rank[c] = 0; my_before[c] = 0;
+        if (a >= D || (dbg & 8)) continue;
+        const wide128 xk = {d_hi[a], d_lo[a]};
+        uint32_t rk = 0, bf = 0;
+#pragma unroll 4
+        for (uint32_t o = 0; o < D; o++) { const wide128 y = {d_hi[o], d_lo[o]}; const uint32_t cy = d_cnt[o]; if (wide_less(y, xk)) { rk++; bf += cy; } }
+        my_rank[c] = rk; my_before[c] = bf;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t c = 0; c < DCAP / T; c++) if (tid + c * T < D) { order[my_rank[c]] = (uint16_t)(tid + c * T); d_cnt[my_rank[c]] = my_before[c]; }
+    __syncthreads();
+    // the bucket in order: entry j is the k-mer of the last rank whose run starts at or before j
+    if (!(dbg & 4)) for (uint64_t j = tid; j < len; j += T) {
+        uint32_t lo_r = 0, hi_r = D;                                                    // the answer is in [lo_r, hi_r)
+        while (hi_r - lo_r > 1) { const uint32_t mid = (lo_r + hi_r) >> 1; if ((uint64_t)d_cnt[mid] <= j) lo_r = mid; else hi_r = mid; }
+        const uint32_t a = order[lo_r];
+        ohi[start + j] = d_hi[a]; olo[start + j] = d_lo[a];
     }
 }
 // the extent of a listed bucket: the first entry after `start` with other leading bits (the array is ascending in them)
-__global__ void k_wide_big_extent(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n, int hb, const uint64_t *__restrict__ start, uint32_t n_big,
+__global__ void k_wide_big_extent(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n, int hb_tb, const uint64_t *__restrict__ start, uint32_t n_big,
                                   uint32_t *__restrict__ len) {
+    const int hb = hb_tb & 255, tb = hb_tb >> 8;
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_big) return;
     const uint64_t s = start[j];
     const wide128 x = {hi[s], lo[s]};
-    const uint32_t p = wide_class(x, hb, WF_BITS);
+    const uint32_t p = wide_class(x, hb, tb);
     uint64_t a = s + 1, b = n;                                                    // the answer is in [a, b]
     while (a < b) {
         const uint64_t mid = a + ((b - a) >> 1);
         const wide128 y = {hi[mid], lo[mid]};
-        if (wide_class(y, hb, WF_BITS) == p) a = mid + 1; else b = mid;
+        if (wide_class(y, hb, tb) == p) a = mid + 1; else b = mid;
     }
     len[j] = (uint32_t)(a - s);
 }
@@ -400,7 +476,7 @@ extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void
     const uint64_t n_words = (n_bases + 31) / 32;
     const int hb = 2 * k - 64;
     mf_buf<uint32_t> vmask; mf_buf<unsigned long long> chist, cursor; mf_buf<uint64_t> tot;
-    if (vmask.alloc(ctx, n_words) < 0 || chist.alloc(ctx, (1u << WG_CB) + 2) < 0 || cursor.alloc(ctx, 2) < 0 || tot.alloc(ctx, 2) < 0) return fail(MF_ERR);
+    if (vmask.alloc(ctx, n_words) < 0 || chist.alloc(ctx, (1u << WG_CB) + 2) < 0 || cursor.alloc(ctx, 8) < 0 || tot.alloc(ctx, 2) < 0) return fail(MF_ERR);
     const unsigned gen_grid = (unsigned)std::min<uint64_t>((n_words + WG_T - 1) / WG_T, (uint64_t)ctx->n_cu * 8);
     std::vector<unsigned long long> h_class(1u << WG_CB);
     {
@@ -419,22 +495,24 @@ extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void
     for (unsigned long long c : h_class) n_occ += c;
     t->n_occ = n_occ;
     if (!n_occ) return MF_OK;
-    // passes: each takes the k-mers of a range of classes (the top WG_CB bits of the canonical value), as many classes as fit: under 2^31
-    // occurrences (the sort) and 48 bytes of device memory per occurrence (two pairs of 8-byte arrays + the sort's temporaries; the run-length
-    // arrays reuse them).  Option wide_passes: about that many passes (tests).
+    // passes: each takes the k-mers of a range of classes (the top WG_CB bits of the canonical value), as many classes as fit: under 4e9
+    // occurrences (the sort) and 36 bytes of device memory per occurrence (two pairs of 8-byte arrays that are each other's ping-pong in the
+    // sort; the run-length arrays take the place of one pair).  Option wide_passes: about that many passes (tests).
     uint64_t per_pass;
     if (ctx->opt_wide_passes > 0) per_pass = std::max<uint64_t>(1, (n_occ + (uint64_t)ctx->opt_wide_passes - 1) / (uint64_t)ctx->opt_wide_passes);
     else {
         size_t fr = 0, total = 0;
         if (hipMemGetInfo(&fr, &total) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: hipMemGetInfo failed"));
-        per_pass = std::min<uint64_t>(1ull << 31, std::max<uint64_t>(1ull << 20, (uint64_t)(((double)fr + (double)mf_arena_idle(ctx)) * 0.6 / 48.0)));
+        per_pass = std::min<uint64_t>(4000000000ull, std::max<uint64_t>(1ull << 20, (uint64_t)(((double)fr + (double)mf_arena_idle(ctx)) * 0.6 / 36.0)));
     }
     const uint64_t target = (n_occ + (n_occ + per_pass - 1) / per_pass - 1) / ((n_occ + per_pass - 1) / per_pass);   // passes of about equal size
-    struct piece { mf_buf<uint64_t> hi, lo; mf_buf<uint16_t> cnt; uint64_t n = 0; };
-    std::vector<std::unique_ptr<piece>> pieces;
+    typedef mf_wtable::piece piece;
+    std::vector<std::unique_ptr<piece>> &pieces = t->pieces;
     uint64_t nd_total = 0, occ_seen = 0;
+    // the leading bits the radix passes order: 32 -- or the high word's 24 .. 31 bits alone (k = 44 .. 47: a pass over a few bits of the low word saved)
+    const int tb = (hb >= 24 && hb < WF_BITS) ? hb : WF_BITS, hb_tb = hb | (tb << 8);
     const uint32_t big = (uint32_t)std::min<int64_t>(WF_BIG, std::max<int64_t>(1, ctx->opt_wide_big_bucket));
-    const uint32_t dlimit = (uint32_t)std::min<int64_t>(WF_DMAX, std::max<int64_t>(1, ctx->opt_wide_distinct));
+    const uint32_t dlimit = (uint32_t)std::min<int64_t>(1280, std::max<int64_t>(1, ctx->opt_wide_distinct));
     for (uint32_t c0 = 0; c0 < (1u << WG_CB);) {
         uint32_t c1 = c0;
         uint64_t n_p = 0;
@@ -448,69 +526,100 @@ extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void
         if (h0.alloc(ctx, n_p) < 0 || l0.alloc(ctx, n_p) < 0 || h1.alloc(ctx, n_p) < 0 || l1.alloc(ctx, n_p) < 0) return fail(MF_ERR);
         {
             mf_ktimer tm(ctx, "k_wide_kmers");
-            if (hipMemsetAsync(cursor.p, 0, 16, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: memset failed"));
+            if (hipMemsetAsync(cursor.p, 0, 8, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: memset failed"));
             k_wide_kmers<false><<<gen_grid, WG_T, 0, st>>>((const uint8_t *)d_bases, n_bases, vmask.p, n_words, k, cfirst, c1, nullptr, h0.p, l0.p, cursor.p);
         }
-        // ascending (hi, lo).  (h0, l0) -> (h1, l1)
+        // ascending (hi, lo).  a: the pair of arrays that holds the pass, b: the other pair (the sorts write both: no temporaries)
+        uint64_t *ah = h0.p, *al = l0.p, *bh = h1.p, *bl = l1.p;
+        auto swap_ab = [&]() { std::swap(ah, bh); std::swap(al, bl); };
+        auto sort_hi = [&](int first, int bits) { int sec = 0; if (mf_sort_u64_u64_pingpong(ctx, ah, al, n_p, first, bits, bh, bl, &sec) < 0) return MF_ERR; if (sec) swap_ab(); return MF_OK; };
+        auto sort_lo = [&](int first, int bits) { int sec = 0; if (mf_sort_u64_u64_pingpong(ctx, al, ah, n_p, first, bits, bl, bh, &sec) < 0) return MF_ERR; if (sec) swap_ab(); return MF_OK; };
         bool sorted = false;
+        unsigned int nlist[3] = {0, 0, 0};
+        unsigned long long hstat[4] = {0, 0, 0, 0};                                      // the large buckets: entries, buckets, the largest, distinct k-mers
         if (ctx->opt_wide_finish) {
             mf_ktimer tm(ctx, "k_wide_sort");
             // radix passes over the leading WF_BITS bits alone (stable LSD: the low word's share of them first), then the order inside the buckets in LDS
-            mf_buf<unsigned long long> bigs; mf_buf<unsigned int> n_big;
-            const uint64_t big_cap = n_p / big + 2;                      // (a listed bucket holds more than `big` entries)
-            if (bigs.alloc(ctx, big_cap) < 0 || n_big.alloc(ctx, 1) < 0) return fail(MF_ERR);
-            if (hb >= WF_BITS) { if (mf_sort_u64_u64_range(ctx, h0.p, l0.p, n_p, hb - WF_BITS, WF_BITS, h1.p, l1.p) < 0) return fail(MF_ERR); }
+            const uint64_t n_tiles = (n_p + WF_TILE - 1) / WF_TILE;
+            const uint32_t tile_cap = (WF_TILE - 1) / (big + 1) + 1;                  // (a listed bucket holds more than `big` entries and starts in the tile)
+            mf_buf<unsigned long long> tile_big, bigs, wstats; mf_buf<unsigned int> n_big; mf_buf<uint32_t> tile_cnt; mf_buf<uint64_t> tile_off;
+            if (tile_big.alloc(ctx, n_tiles * tile_cap) < 0 || tile_cnt.alloc(ctx, n_tiles) < 0 || tile_off.alloc(ctx, n_tiles + 1) < 0 || n_big.alloc(ctx, 1) < 0 || wstats.alloc(ctx, 128 * 16) < 0) return fail(MF_ERR);
+            if (hipMemsetAsync(wstats.p, 0, 128 * 16 * 8, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: memset failed"));
+            if (hb >= tb) { if (sort_hi(hb - tb, tb) < 0) return fail(MF_ERR); }
             else {
-                if (mf_sort_u64_u64_range(ctx, l0.p, h0.p, n_p, 64 - (WF_BITS - hb), WF_BITS - hb, l1.p, h1.p) < 0) return fail(MF_ERR);
-                if (hb) { if (mf_sort_u64_u64_range(ctx, h1.p, l1.p, n_p, 0, hb, h0.p, l0.p) < 0) return fail(MF_ERR); h0.swap(h1); l0.swap(l1); }
+                if (sort_lo(64 - (tb - hb), tb - hb) < 0) return fail(MF_ERR);
+                if (hb && sort_hi(0, hb) < 0) return fail(MF_ERR);
             }
-            // (h1, l1): ascending in the leading bits -> (h0, l0): ascending
+            // a: ascending in the leading bits -> b: ascending
+            mf_buf<unsigned long long> list2, list3;
+            unsigned int nb1 = 0, nb2 = 0, nb = 0;
+            auto fetch = [&](unsigned int *v) { return hipMemcpyAsync(v, n_big.p, 4, hipMemcpyDeviceToHost, st) == hipSuccess && hipMemsetAsync(n_big.p, 0, 4, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess; };
             if (hipMemsetAsync(n_big.p, 0, 4, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: memset failed"));
             { mf_ktimer tf(ctx, "k_wide_finish");
-            k_wide_finish<<<(unsigned)((n_p + WF_TILE - 1) / WF_TILE), WF_T, 0, st>>>(h1.p, l1.p, n_p, hb, big, dlimit, (int)ctx->opt_wide_ablate, h0.p, l0.p, bigs.p, n_big.p, cursor.p + 1); }
-            unsigned int nb = 0;
-            if (hipMemcpyAsync(&nb, n_big.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
+            k_wide_finish<<<(unsigned)n_tiles, WF_T, 0, st>>>(ah, al, n_p, hb_tb, big, (int)ctx->opt_wide_ablate, bh, bl, tile_big.p, tile_cap, tile_cnt.p); }
+            if (mf_scan<1>(ctx, tile_cnt.p, tile_off.p, n_tiles, tot.p) < 0) return fail(MF_ERR);
+            { uint64_t v = 0;
+              if (hipMemcpyAsync(&v, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
+              nb1 = (unsigned int)v; }
+            if (nb1) {
+                if (bigs.alloc(ctx, nb1) < 0 || list2.alloc(ctx, nb1) < 0) return fail(MF_ERR);
+                { mf_ktimer tf(ctx, "k_wide_big");
+                k_wide_big_list<<<wgrid(n_tiles), 256, 0, st>>>(tile_big.p, tile_cap, tile_cnt.p, tile_off.p, n_tiles, bigs.p);
+                k_wide_big<64, 512><<<nb1, 64, 0, st>>>(ah, al, n_p, hb_tb, bigs.p, std::min<uint32_t>(dlimit, 320u), bh, bl, list2.p, n_big.p, wstats.p, (int)ctx->opt_wide_ablate); }
+                if (!fetch(&nb2)) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
+            }
+            if (nb2) {
+                if (list3.alloc(ctx, nb2) < 0) return fail(MF_ERR);
+                { mf_ktimer tf(ctx, "k_wide_big2");
+                k_wide_big<256, 2048><<<nb2, 256, 0, st>>>(ah, al, n_p, hb_tb, list2.p, dlimit, bh, bl, list3.p, n_big.p, wstats.p, (int)ctx->opt_wide_ablate); }
+                if (!fetch(&nb)) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
+            }
             sorted = true;
             if (nb) {
-                if ((uint64_t)nb > big_cap) return fail(mf_set_error("mf_count_wide_device: internal error, %u large buckets among %llu k-mers", nb, (unsigned long long)n_p));
-                mf_buf<uint64_t> bs, bs2, toff, th0, tl0, th1, tl1; mf_buf<uint32_t> blen, dummy, dummy2;
-                if (bs.alloc(ctx, nb) < 0 || bs2.alloc(ctx, nb) < 0 || toff.alloc(ctx, (uint64_t)nb + 1) < 0 || blen.alloc(ctx, nb) < 0 || dummy.alloc(ctx, nb) < 0 || dummy2.alloc(ctx, nb) < 0) return fail(MF_ERR);
+                mf_buf<uint64_t> bs, toff, th0, tl0, th1, tl1; mf_buf<uint32_t> blen, dummy, dummy2;
+                if (bs.alloc(ctx, nb) < 0 || toff.alloc(ctx, (uint64_t)nb + 1) < 0 || blen.alloc(ctx, nb) < 0 || dummy.alloc(ctx, nb) < 0 || dummy2.alloc(ctx, nb) < 0) return fail(MF_ERR);
                 if (hipMemsetAsync(dummy.p, 0, (size_t)nb * 4, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: memset failed"));
-                if (mf_sort_u64_u32(ctx, (const uint64_t *)bigs.p, dummy.p, nb, 33, bs.p, dummy2.p) < 0) return fail(MF_ERR);
-                k_wide_big_extent<<<wgrid(nb), 256, 0, st>>>(h1.p, l1.p, n_p, hb, bs.p, nb, blen.p);
+                if (mf_sort_u64_u32(ctx, (const uint64_t *)list3.p, dummy.p, nb, 33, bs.p, dummy2.p) < 0) return fail(MF_ERR);
+                k_wide_big_extent<<<wgrid(nb), 256, 0, st>>>(ah, al, n_p, hb_tb, bs.p, nb, blen.p);
                 if (mf_scan<1>(ctx, blen.p, toff.p, nb, tot.p) < 0) return fail(MF_ERR);
                 uint64_t big_total = 0;
                 if (hipMemcpyAsync(&big_total, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
                 ctx->n_wide_big += big_total;
-                if (big_total > n_p / 4) { sorted = false; h0.swap(h1); l0.swap(l1); }          // too many for a side sort: all of the pass below, (h0, l0) again the input
+                if (big_total > n_p / 4) sorted = false;                              // too many for a side sort: all of the pass below (a still holds it)
                 else {
                     if (th0.alloc(ctx, big_total) < 0 || tl0.alloc(ctx, big_total) < 0 || th1.alloc(ctx, big_total) < 0 || tl1.alloc(ctx, big_total) < 0) return fail(MF_ERR);
-                    k_wide_big_move<false><<<wgrid(big_total), 256, 0, st>>>(bs.p, toff.p, nb, big_total, h1.p, l1.p, th0.p, tl0.p);
+                    k_wide_big_move<false><<<wgrid(big_total), 256, 0, st>>>(bs.p, toff.p, nb, big_total, ah, al, th0.p, tl0.p);
                     if (mf_sort_u64_u64(ctx, tl0.p, th0.p, big_total, 64, tl1.p, th1.p) < 0) return fail(MF_ERR);
                     if (hb) { if (mf_sort_u64_u64(ctx, th1.p, tl1.p, big_total, hb, th0.p, tl0.p) < 0) return fail(MF_ERR); } else { th0.swap(th1); tl0.swap(tl1); }
-                    k_wide_big_move<true><<<wgrid(big_total), 256, 0, st>>>(bs.p, toff.p, nb, big_total, th0.p, tl0.p, h0.p, l0.p);
+                    k_wide_big_move<true><<<wgrid(big_total), 256, 0, st>>>(bs.p, toff.p, nb, big_total, th0.p, tl0.p, bh, bl);
                     if (hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
                 }
             }
+            {
+                std::vector<unsigned long long> hs(128 * 16);
+                if (hipMemcpyAsync(hs.data(), wstats.p, hs.size() * 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
+                for (int i = 0; i < 128; i++) { hstat[0] += hs[16 * i]; hstat[1] += hs[16 * i + 1]; hstat[2] = std::max(hstat[2], hs[16 * i + 2]); hstat[3] += hs[16 * i + 3]; }
+            }
+            nlist[0] = nb1; nlist[1] = nb2; nlist[2] = nb;
+            if (sorted) swap_ab();
         }
         if (!sorted) {   // LSD over all 2k bits -- by the low word, then (stable) by the high word's 2k - 64 bits
             mf_ktimer tm(ctx, "k_wide_sort");
-            if (mf_sort_u64_u64(ctx, l0.p, h0.p, n_p, 64, l1.p, h1.p) < 0) return fail(MF_ERR);
-            if (hb) { if (mf_sort_u64_u64(ctx, h1.p, l1.p, n_p, hb, h0.p, l0.p) < 0) return fail(MF_ERR); } else { h0.swap(h1); l0.swap(l1); }
+            if (sort_lo(0, 64) < 0 || (hb && sort_hi(0, hb) < 0)) return fail(MF_ERR);
         }
+        if (ah != h0.p) { h0.swap(h1); l0.swap(l1); }                                  // (h0, l0): the ascending pass
         h1.reset(); l1.reset();
         // run lengths
         mf_buf<uint32_t> flag; mf_buf<uint64_t> idx;
         if (flag.alloc(ctx, n_p) < 0 || idx.alloc(ctx, n_p + 1) < 0) return fail(MF_ERR);
         k_wide_flags<<<wgrid(n_p), 256, 0, st>>>(h0.p, l0.p, n_p, flag.p);
         if (mf_scan<1>(ctx, flag.p, idx.p, n_p, tot.p) < 0) return fail(MF_ERR);
-        uint64_t nd = 0; unsigned long long emitted_hashed[2] = {0, 0};
-        unsigned long long &emitted = emitted_hashed[0];
-        if (hipMemcpyAsync(&nd, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(emitted_hashed, cursor.p, 16, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        uint64_t nd = 0; unsigned long long emitted = 0;
+        if (hipMemcpyAsync(&nd, tot.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(&emitted, cursor.p, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
             hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
-        ctx->n_wide_hashed += emitted_hashed[1];
-        if (ctx->opt_verbose) fprintf(stderr, "[mf] count_wide: classes [%u, %u): %llu k-mers, %llu distinct; %llu in buckets of more than %u entries (hash table)\n", cfirst, c1,
-                                      (unsigned long long)n_p, (unsigned long long)nd, emitted_hashed[1], big);
+        ctx->n_wide_hashed += hstat[0];
+        if (ctx->opt_verbose) fprintf(stderr, "[mf] count_wide: classes [%u, %u): %llu k-mers, %llu distinct; %llu in %llu buckets of more than %u entries (hash table; the largest %llu entries, %.1f distinct k-mers on average; lists: %u -> %u -> %u)\n", cfirst, c1,
+                                      (unsigned long long)n_p, (unsigned long long)nd, hstat[0], hstat[1], big, hstat[2], hstat[1] ? (double)hstat[3] / (double)hstat[1] : 0.0, nlist[0], nlist[1], nlist[2]);
         if (emitted != n_p) return fail(mf_set_error("mf_count_wide_device: internal error, a pass wrote %llu of %llu k-mers", emitted, (unsigned long long)n_p));
         auto pc = std::make_unique<piece>();
         mf_buf<uint64_t> start;
@@ -525,18 +634,6 @@ extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void
         pieces.push_back(std::move(pc));
     }
     if (occ_seen != n_occ) return fail(mf_set_error("mf_count_wide_device: internal error, the passes saw %llu of %llu k-mers", (unsigned long long)occ_seen, (unsigned long long)n_occ));
-    if (pieces.size() == 1) { t->hi.swap(pieces[0]->hi); t->lo.swap(pieces[0]->lo); t->cnt.swap(pieces[0]->cnt); }
-    else if (nd_total) {
-        if (t->hi.alloc(ctx, nd_total) < 0 || t->lo.alloc(ctx, nd_total) < 0 || t->cnt.alloc(ctx, nd_total) < 0) return fail(MF_ERR);
-        uint64_t at = 0;
-        for (auto &pc : pieces) {
-            if (!pc->n) continue;
-            if (hipMemcpyAsync(t->hi.p + at, pc->hi.p, pc->n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess || hipMemcpyAsync(t->lo.p + at, pc->lo.p, pc->n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess ||
-                hipMemcpyAsync(t->cnt.p + at, pc->cnt.p, pc->n * 2, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: copy failed"));
-            at += pc->n;
-        }
-        if (hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
-    }
     t->n = nd_total;
     return MF_OK;
 }
@@ -556,8 +653,13 @@ extern "C" int mf_wtable_export(const mf_wtable *t, uint64_t *keys_hi, uint64_t 
     if (capacity < t->n) return mf_set_error("mf_wtable_export: capacity %llu < %llu entries", (unsigned long long)capacity, (unsigned long long)t->n);
     if (!t->n) return MF_OK;
     MF_HIP(hipSetDevice(t->ctx->device));
-    if (keys_hi) MF_HIP(hipMemcpy(keys_hi, t->hi.p, t->n * 8, hipMemcpyDeviceToHost));
-    if (keys_lo) MF_HIP(hipMemcpy(keys_lo, t->lo.p, t->n * 8, hipMemcpyDeviceToHost));
-    if (counts) MF_HIP(hipMemcpy(counts, t->cnt.p, t->n * 2, hipMemcpyDeviceToHost));
+    uint64_t at = 0;
+    for (auto &pc : t->pieces) {
+        if (!pc->n) continue;
+        if (keys_hi) MF_HIP(hipMemcpy(keys_hi + at, pc->hi.p, pc->n * 8, hipMemcpyDeviceToHost));
+        if (keys_lo) MF_HIP(hipMemcpy(keys_lo + at, pc->lo.p, pc->n * 8, hipMemcpyDeviceToHost));
+        if (counts) MF_HIP(hipMemcpy(counts + at, pc->cnt.p, pc->n * 2, hipMemcpyDeviceToHost));
+        at += pc->n;
+    }
     return MF_OK;
 }

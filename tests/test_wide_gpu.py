@@ -100,7 +100,7 @@ def test_wide_counts_at_20M_reads_k63(gpu_ctx):
 @pytest.mark.parametrize("k", [32, 41, 47, 48, 63])
 def test_wide_buckets_small_and_large(gpu_ctx, oracle, k):
     """Round 5: radix passes over the leading 32 bits only, the order inside those buckets made in LDS (k_wide_finish): buckets of <= 256 entries by
-    walking them, larger ones through a hash table in LDS (distinct k-mers + counts, written back as runs); a bucket of more than 704 distinct
+    walking them, larger ones through a hash table in LDS (distinct k-mers + counts, written back as runs); a bucket of more than 1280 distinct
     k-mers is gathered, sorted with the full radix sort and put back (or, when such buckets hold more than a quarter of a pass, the whole pass is).
     A genome at depth ~10 with a long poly-A stretch: mostly small buckets + a few large ones; the limits lowered by option drive every route;
     wide_finish = 0 is the 16-pass sort of round 4.  One table, the oracle's."""
@@ -119,7 +119,7 @@ def test_wide_buckets_small_and_large(gpu_ctx, oracle, k):
                 gpu_ctx.set_option(o, v)
             got = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), len(off) - 1, len(bases), k, 0)
         finally:
-            for o, v in (("wide_big_bucket", 256), ("wide_distinct", 704), ("wide_finish", 1), ("wide_passes", 0)):
+            for o, v in (("wide_big_bucket", 256), ("wide_distinct", 1280), ("wide_finish", 1), ("wide_passes", 0)):
                 gpu_ctx.set_option(o, v)
         assert got["n_occ"] == n_occ
         assert np.array_equal(got["hi"], hi) and np.array_equal(got["lo"], lo) and np.array_equal(got["counts"].astype(np.int32), cnt), opts

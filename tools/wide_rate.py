@@ -24,6 +24,7 @@ for it in range(2):
     L._check(L.lib().mf_wtable_stats(t, C.byref(nd), C.byref(occ), C.byref(kk)))
     L.lib().mf_wtable_destroy(t)
     res.append(dict(seconds=round(dt, 3), n_occ=occ.value, n_distinct=nd.value, kmers_per_s=round(occ.value / dt, 1),
+                    hipmalloc=dict(calls=ctx.stat('hipmalloc_calls'), GB=round(ctx.stat('hipmalloc_bytes') / 1e9, 1), seconds=round(ctx.stat('hipmalloc_us') / 1e6, 3)),
                     kernels={kk_: round(v[1], 1) for kk_, v in ctx.kernel_report().items()}))
 print(json.dumps(dict(what="NO-REFERENCE EXTENSION: canonical %d-mer counts of one sample of %d synthetic 150 bp reads on one MI355X (mf_count_wide_device: class-range passes, radix passes over the leading 32 bits, buckets ordered in LDS)" % (k, n),
                       reads=n, k=k, runs=res)))
