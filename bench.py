@@ -47,6 +47,19 @@ def _load_other_shapes():
         return None
 
 
+def _load_extension_k63():
+    """NO-REFERENCE EXTENSION, not part of the metric: canonical 63-mer counts of one 200 M-read sample (BASELINE config 4's k = 63 leg, counts only),
+    the second run of tools/wide_rate.py on the GPU box, committed as profiles/r05at_wide_200M_k63.json -- a builder-run profile, labelled as such"""
+    try:
+        r = json.load(open(os.path.join(ROOT, "profiles", "r05at_wide_200M_k63.json")))
+        run = r["runs"][-1]
+        return {"label": "NO-REFERENCE EXTENSION (the reference stops at k = 31); builder-run profile profiles/r05at_wide_200M_k63.json, not measured by this run",
+                "k": r["k"], "reads": r["reads"], "seconds": run["seconds"], "kmers_per_s": run["kmers_per_s"], "n_distinct": run["n_distinct"],
+                "kernel_ms": run["kernels"]}
+    except Exception:
+        return None
+
+
 TRAFFIC = {}
 # what limits a kernel when no counters of this workload are at hand (other shapes than the headline one)
 BOUND = {"k_skm_count": "lds+valu", "k_skm_scatter": "valu", "k_skm_hist": "valu"}
@@ -487,6 +500,7 @@ def main():
             "end_to_end": e2e.get("end_to_end"),
             "cli": e2e.get("cli"),
             "stats": stats,
+            "extension_k63": _load_extension_k63() if world == 1 else None,
             # counting runs that threw their slices away and started over with more because a buffer found no place in the arena (8 x 200 M reads
             # at k = 21 on one GPU did in round 4 until the temporary lists were halved): 0 on every committed shape
             "slice_restarts": ctx.stat("slice_restarts"),
