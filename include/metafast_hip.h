@@ -171,6 +171,10 @@ void mf_wtable_destroy(mf_wtable *t);
 int  mf_wtable_stats(const mf_wtable *t, uint64_t *n_distinct, uint64_t *n_occ, int *k);
 /* ascending k-mers as (high word, low word) + counts; NULL arrays: only *n */
 int  mf_wtable_export(const mf_wtable *t, uint64_t *keys_hi, uint64_t *keys_lo, uint16_t *counts, uint64_t capacity, uint64_t *n);
+/* the table where it is: it lies in HBM in *n_pieces pieces (one per pass over the reads), ascending inside a piece and piece after piece;
+ * piece i: device pointers to its high words, low words (uint64) and counts (uint16), *n entries.  Valid until mf_wtable_destroy. */
+int  mf_wtable_pieces(const mf_wtable *t, uint32_t *n_pieces);
+int  mf_wtable_piece_view(const mf_wtable *t, uint32_t i, const void **d_keys_hi, const void **d_keys_lo, const void **d_counts, uint64_t *n);
 
 /* ---- A5/A6  .kmers.bin / .stat.txt --------------------------------------------------- */
 /* replaces IOUtils.printKmers (src/io/IOUtils.java:45-71; KmersCounterMain.java:99): 10-byte

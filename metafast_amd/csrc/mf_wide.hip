@@ -645,6 +645,21 @@ extern "C" int mf_wtable_stats(const mf_wtable *t, uint64_t *n_distinct, uint64_
     if (k) *k = t->k;
     return MF_OK;
 }
+extern "C" int mf_wtable_pieces(const mf_wtable *t, uint32_t *n_pieces) {
+    if (!t || !n_pieces) return mf_set_error("mf_wtable_pieces: NULL argument");
+    *n_pieces = (uint32_t)t->pieces.size();
+    return MF_OK;
+}
+extern "C" int mf_wtable_piece_view(const mf_wtable *t, uint32_t i, const void **d_keys_hi, const void **d_keys_lo, const void **d_counts, uint64_t *n) {
+    if (!t || !n) return mf_set_error("mf_wtable_piece_view: NULL argument");
+    if (i >= t->pieces.size()) return mf_set_error("mf_wtable_piece_view: piece %u of %zu", i, t->pieces.size());
+    const auto &pc = *t->pieces[i];
+    if (d_keys_hi) *d_keys_hi = pc.hi.p;
+    if (d_keys_lo) *d_keys_lo = pc.lo.p;
+    if (d_counts) *d_counts = pc.cnt.p;
+    *n = pc.n;
+    return MF_OK;
+}
 // ascending 2k-bit k-mers as (high word, low word), counts; capacity in entries (NULL arrays: only *n)
 extern "C" int mf_wtable_export(const mf_wtable *t, uint64_t *keys_hi, uint64_t *keys_lo, uint16_t *counts, uint64_t capacity, uint64_t *n) {
     if (!t || !n) return mf_set_error("mf_wtable_export: NULL argument");

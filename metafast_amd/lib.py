@@ -38,6 +38,8 @@ _SIGS = {
     "mf_wtable_destroy": (None, [vp]),
     "mf_wtable_stats": (i32, [vp, pu64, pu64, C.POINTER(C.c_int)]),
     "mf_wtable_export": (i32, [vp, vp, vp, vp, u64, pu64]),
+    "mf_wtable_pieces": (i32, [vp, C.POINTER(C.c_uint32)]),
+    "mf_wtable_piece_view": (i32, [vp, C.c_uint32, pvp, pvp, pvp, pu64]),
     "mf_count_reads_above": (i32, [vp, C.POINTER(cp), i32, i32, i32, i32, pvp, pu64]),
     "mf_count_device": (i32, [vp, vp, vp, u64, u64, i32, i32, pvp]),
     "mf_count_device_above": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, pvp, pu64]),
@@ -272,6 +274,12 @@ class Context:
         finally:
             lib().mf_wtable_destroy(t)
 
+    def count_wide_table(self, d_bases, d_offsets, n_reads, n_bases, k, min_read_len=0):
+        """NO-REFERENCE EXTENSION, 32 <= k <= 63: the table left in HBM -> WideTable (pieces(): device pointers)"""
+        t = C.c_void_p()
+        _check(lib().mf_count_wide_device(self.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k, min_read_len, C.byref(t)))
+        return WideTable(self, t)
+
     def count_device_above(self, d_bases, d_offsets, n_reads, n_bases, k, threshold, min_read_len=0):
         """count, keeping only the k-mers with count > threshold (what the k-mer counter hands on, IOUtils.printKmers);
         -> (Table of the kept k-mers, number of distinct k-mers before the cut)"""
@@ -352,6 +360,36 @@ class Context:
         """sub_per_16384: substitutions per 16384 bases (82 = 0.5 %, the benchmark's; 164 = 1 %, BASELINE config 5)"""
         _check(lib().mf_synth_reads_device_ex(self.h, seed, sample, first_read, n_reads, read_len, genome_scale_bp, sub_per_16384,
                                               C.c_void_p(d_bases), C.c_void_p(d_offsets)))
+
+
+class WideTable:
+    """NO-REFERENCE EXTENSION: canonical counts of 2k-bit k-mers (32 <= k <= 63) in HBM, in ascending pieces"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def close(self):
+        if self.h:
+            lib().mf_wtable_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def stats(self):
+        n, occ, kk = C.c_uint64(), C.c_uint64(), C.c_int()
+        _check(lib().mf_wtable_stats(self.h, C.byref(n), C.byref(occ), C.byref(kk)))
+        return n.value, occ.value, kk.value
+
+    def pieces(self):
+        """[(d_hi, d_lo, d_counts, n)]: raw device pointers of every piece (uint64, uint64, uint16)"""
+        m = C.c_uint32()
+        _check(lib().mf_wtable_pieces(self.h, C.byref(m)))
+        out = []
+        for i in range(m.value):
+            a, b, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
+            _check(lib().mf_wtable_piece_view(self.h, i, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
+            out.append((a.value or 0, b.value or 0, c.value or 0, n.value))
+        return out
 
 
 class Table:
