@@ -92,6 +92,7 @@ struct mf_ctx {
     int64_t opt_device_parse_min = 1 << 20;   // ... from this size on (bytes): a small file is not worth the kernels' launches
     int64_t opt_host_pinned = 0;   // staging buffers of the file readers / writers: 1 = hipHostMalloc (0.16 - 0.29 s per GB to get, 0.1 s to give back), 0 = plain host memory (copies to and from it run at the same 56 GB/s on this platform: tools/pin_alloc.hip)
     int64_t opt_file_cache_gb = 0; // > 0: tables / components written to files stay in HBM (up to this many GB) and are handed out when the same file is loaded again
+    int64_t opt_ut_double_after = 4;   // unitigs: walks still under way after this many chunked rounds (32, 128, 512, 4096 jumps) double the jump words instead (tests: 1)
     int64_t opt_wide_finish = 1;   // mf_count_wide_device: radix passes over the leading 32 bits + the order inside the buckets in LDS (0: radix passes over all 2k bits)
     int64_t opt_wide_big_bucket = 256;   // ... buckets of more entries than this (<= 256) go through the LDS hash table instead of the walk (tests lower it)
     int64_t opt_wide_distinct = 1280;    // ... buckets of more distinct k-mers than this (<= 1280) are sorted aside (tests lower it)
@@ -111,7 +112,7 @@ struct mf_ctx {
     size_t arena_bytes = 0;
     // counters a host can read (mf_ctx_stat): counting runs that started their slices over because a buffer found no place (mf_skm.hip);
     // read files the device parser took / handed to the host readers (mf_dparse.hip)
-    uint64_t n_slice_restarts = 0, n_dparse_files = 0, n_dparse_stepped_back = 0, n_wide_big = 0, n_wide_hashed = 0;
+    uint64_t n_slice_restarts = 0, n_dparse_files = 0, n_dparse_stepped_back = 0, n_wide_big = 0, n_wide_hashed = 0, n_ut_doubled = 0;
     // timers
     std::vector<mf_timer_rec> pending;
     std::vector<hipEvent_t> event_pool;

@@ -283,6 +283,52 @@ __global__ void k_ut_walk1(ut_arrays A, const ut_item *__restrict__ items, uint3
     if (going) { W.cont[c].node = f; W.cont[c].slot = slot; W.cont[c].dist = d; }
 }
 
+// ---- U3b: long paths (round 5) ----
+// A walk is a chain of dependent loads, ~0.7 us per jump: a unitig of 1e6 k-mers -- what the reference's own example parameters (-k 23 -b 5
+// -l 1200, /root/reference/Example.md:18-21) leave of an abundant genome -- kept ONE lane busy for 108 ms, and once more for the segment cuts
+// (profiles/r05v_shape_cami_example_k23_b5_l1200.json: k_ut_walk1 108 ms + k_ut_segments 92 ms of a 297 ms step).  When walks are still under
+// way after the rounds of 32, 128, 512 and 4096 jumps, the jump words are doubled instead (Wyllie's list ranking) -- over the ENTRY nodes only,
+// the nodes some jump lands on (one in ~6): EJ[i] = entry (or, END, the path's last node) | distance << 32 | END << 63.  Five synchronous rounds
+// give words that span exactly 32 jumps (kept: the segment cuts walk them); further rounds run in place (a word is always a true statement
+// "t is d nodes ahead") until every unfinished walk reads its end in one load.
+#define UTD_END (1ull << 63)
+__global__ void k_utd_mark(const uint64_t *__restrict__ jump, uint64_t n_nodes, uint32_t *__restrict__ flag) {
+    const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_nodes) return;
+    const uint64_t w = jump[f];
+    if (!(w & UT_J_END)) flag[(uint32_t)w] = 1u;
+}
+__global__ void k_utd_mark_items(const ut_item *__restrict__ items, uint32_t n_items, uint32_t *__restrict__ flag) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_items) flag[items[t].node] = 1u;
+}
+__global__ void k_utd_build(const uint64_t *__restrict__ jump, const uint32_t *__restrict__ flag, const uint64_t *__restrict__ idx, uint64_t n_nodes,
+                            uint64_t *__restrict__ ej, uint32_t *__restrict__ ent_node) {
+    const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_nodes || !flag[f]) return;
+    const uint64_t i = idx[f], w = jump[f], hops = (w >> 32) & 0x7FFFull;
+    ent_node[i] = (uint32_t)f;
+    ej[i] = (w & UT_J_END) ? ((uint64_t)(uint32_t)w | (hops << 32) | UTD_END) : (idx[(uint32_t)w] | (hops << 32));
+}
+// out[i] = in[i] followed by in[its target] (in == out: in place)
+__global__ void k_utd_double(const uint64_t *in, uint64_t *out, uint64_t n_ent) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ent) return;
+    const uint64_t a = in[i];
+    if (a & UTD_END) { if (out != in) out[i] = a; return; }
+    const uint64_t b = in[(uint32_t)a];
+    out[i] = (uint64_t)(uint32_t)b | ((((a >> 32) & 0x7FFFFFFFull) + ((b >> 32) & 0x7FFFFFFFull)) << 32) | (b & UTD_END);
+}
+// the unfinished walks: the end of the path, if the word of the walk's node says it already; *n_open: the others
+__global__ void k_utd_finish(const ut_item *__restrict__ items, uint32_t n_items, const uint64_t *__restrict__ idx, const uint64_t *__restrict__ ej, ut_walk_out W) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_items) return;
+    const ut_item it = items[t];
+    const uint64_t a = ej[idx[it.node]];
+    if (a & UTD_END) { W.end_node[it.slot] = (uint32_t)a; W.end_dist[it.slot] = it.dist + (uint32_t)((a >> 32) & 0x7FFFFFFFull); }
+    else atomicAdd(W.n_cont, 1u);
+}
+
 // PASS 0: equal-case arbitration (atomicMin of the start node id per start k-mer), count candidates
 // PASS 1: emit: path id from a cursor, pstart / plen / pkey per path (a palindromic start gives two paths)
 struct ut_paths {
@@ -361,6 +407,36 @@ __global__ void k_ut_segments(ut_arrays A, const uint32_t *__restrict__ pstart, 
         }
     }
     seg[idx] = cur;
+}
+// ... over the 32-jump words of U3b when they exist: 32 x fewer dependent loads per path
+__global__ void k_ut_segments_far(ut_arrays A, const uint32_t *__restrict__ pstart, uint32_t np, const uint64_t *__restrict__ segoff, ut_seg *__restrict__ seg,
+                                  const uint64_t *__restrict__ idx, const uint64_t *__restrict__ ej32, const uint32_t *__restrict__ ent_node) {
+    const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pid >= np) return;
+    uint64_t at = segoff[pid];
+    uint32_t f = pstart[pid], d = 0, last = 0;
+    ut_seg cur; cur.node = f; cur.pid = pid; cur.dist = 0; cur.stop = 0xFFFFFFFFu;
+    uint64_t i = 0;
+    for (bool first = true;; first = false) {
+        if (first) {                                             // (a start node is nobody's target: its own jump word leads to the first entry)
+            const uint64_t w = A.jump[f];
+            if (w & UT_J_END) break;
+            d += (uint32_t)(w >> 32) & 0x7FFFu;
+            f = (uint32_t)w;
+            i = idx[f];
+        } else {
+            const uint64_t a = ej32[i];
+            if (a & UTD_END) break;
+            d += (uint32_t)((a >> 32) & 0x7FFFFFFFull);
+            i = (uint32_t)a;
+            f = ent_node[i];
+        }
+        if (d - last >= UT_SEG) {
+            cur.stop = d; seg[at++] = cur;
+            cur.node = f; cur.dist = d; cur.stop = 0xFFFFFFFFu; last = d;
+        }
+    }
+    seg[at] = cur;
 }
 __global__ void k_ut_walk2(ut_arrays A, const ut_seg *__restrict__ seg, uint64_t n_seg, ut_out O, unsigned long long *__restrict__ wsum) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -518,6 +594,8 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         mf_buf<uint32_t> end_node, end_dist;
         if ((rc = end_node.alloc(ctx, n_starts)) < 0 || (rc = end_dist.alloc(ctx, n_starts)) < 0) break;
         int rounds = 0;
+        mf_buf<uint64_t> d_idx, d_ej32; mf_buf<uint32_t> d_ent;                 // U3b (long paths): node -> entry, the 32-jump words, entry -> node
+        int doubled = 0;
         if (n_starts) {
             mf_buf<ut_item> contA, contB;
             if ((rc = contA.alloc(ctx, n_starts)) < 0) break;
@@ -535,6 +613,48 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
                 if (!n_cont) break;
                 if (!contB.p && (rc = contB.alloc(ctx, n_cont)) < 0) break;
                 hipMemsetAsync(&ctr.p[2], 0, 4, st);
+                if (rounds >= (int)ctx->opt_ut_double_after && A.jump) {
+                    // U3b: still walking after the chunked rounds -- double the jump words over the entry nodes (if there is room: else the walks go on)
+                    ut_item *items = (rounds & 1) ? contA.p : contB.p;
+                    const uint64_t nn = 2 * n;
+                    mf_buf<uint32_t> flag; mf_buf<uint64_t> etot, ejA, ejB;
+                    uint64_t n_ent = 0;
+                    bool ok = flag.alloc(ctx, nn) == MF_OK && d_idx.alloc(ctx, nn + 1) == MF_OK && etot.alloc(ctx, 1) == MF_OK;
+                    if (ok) {
+                        mf_ktimer tm(ctx, "k_ut_double");
+                        hipMemsetAsync(flag.p, 0, nn * 4, st);
+                        k_utd_mark<<<grid_for(nn), 256, 0, st>>>(A.jump, nn, flag.p);
+                        k_utd_mark_items<<<grid_for(n_cont), 256, 0, st>>>(items, n_cont, flag.p);
+                        ok = mf_scan<1>(ctx, flag.p, d_idx.p, nn, etot.p) == MF_OK && hipMemcpyAsync(&n_ent, etot.p, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                             hipStreamSynchronize(st) == hipSuccess;
+                    }
+                    ok = ok && n_ent && ejA.alloc(ctx, n_ent) == MF_OK && ejB.alloc(ctx, n_ent) == MF_OK && d_ej32.alloc(ctx, n_ent) == MF_OK && d_ent.alloc(ctx, n_ent) == MF_OK;
+                    if (ok) {
+                        mf_ktimer tm(ctx, "k_ut_double");
+                        k_utd_build<<<grid_for(nn), 256, 0, st>>>(A.jump, flag.p, d_idx.p, nn, ejA.p, d_ent.p);
+                        uint64_t *cur = ejA.p, *oth = ejB.p;
+                        for (int r = 0; r < 5; r++) { k_utd_double<<<grid_for(n_ent), 256, 0, st>>>(cur, oth, n_ent); std::swap(cur, oth); }
+                        hipMemcpyAsync(d_ej32.p, cur, n_ent * 8, hipMemcpyDeviceToDevice, st);
+                        unsigned int open = n_cont;
+                        for (int r = 5; open && r < 40; r += 3) {               // (three rounds in place, then a look; isolated cycles never settle: nobody walks them)
+                            for (int q = 0; q < 3; q++) k_utd_double<<<grid_for(n_ent), 256, 0, st>>>(cur, cur, n_ent);
+                            hipMemsetAsync(&ctr.p[2], 0, 4, st);
+                            k_utd_finish<<<grid_for(n_cont), 256, 0, st>>>(items, n_cont, d_idx.p, cur, W);
+                            if (hipMemcpyAsync(&open, &ctr.p[2], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                                rc = mf_set_error("unitigs: walk failed: %s", hipGetErrorString(hipGetLastError())); break;
+                            }
+                        }
+                        if (rc < 0) break;
+                        if (open) { rc = mf_set_error("unitigs: internal error, %u walks without an end after the doubling rounds", open); break; }
+                        doubled = 1; ctx->n_ut_doubled++;
+                        if (ctx->opt_verbose) fprintf(stderr, "[mf] unitigs: %u walks still under way after %d rounds: jump words doubled over %llu entry nodes of %llu\n", n_cont, rounds,
+                                                      (unsigned long long)n_ent, (unsigned long long)nn);
+                        break;
+                    }
+                    (void)hipGetLastError();
+                    d_idx.reset(); d_ej32.reset(); d_ent.reset();                // (no room: the walks go on jump by jump)
+                    hipMemsetAsync(&ctr.p[2], 0, 4, st);
+                }
                 ut_item *in = (rounds & 1) ? contA.p : contB.p;
                 W.cont = (rounds & 1) ? contB.p : contA.p;
                 {
@@ -601,7 +721,8 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
             hipMemsetAsync(wmax.p, 0, (size_t)np * 4, st);
             {
                 mf_ktimer tm(ctx, "k_ut_segments");
-                k_ut_segments<<<grid_for(np, 64), 64, 0, st>>>(A, pstart.p, np, segoff.p, seg.p);
+                if (doubled) k_ut_segments_far<<<grid_for(np, 64), 64, 0, st>>>(A, pstart.p, np, segoff.p, seg.p, d_idx.p, d_ej32.p, d_ent.p);
+                else k_ut_segments<<<grid_for(np, 64), 64, 0, st>>>(A, pstart.p, np, segoff.p, seg.p);
             }
             {
                 mf_ktimer tm(ctx, "k_ut_walk2");

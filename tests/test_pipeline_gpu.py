@@ -77,6 +77,37 @@ def test_unitigs_cycles_and_homopolymers(gpu_ctx, oracle):
         _check_unitigs(gpu_ctx, oracle, b, o, k, 0, k)
 
 
+@pytest.mark.parametrize("k,b,l", [(31, 1, 100), (23, 5, 1200), (21, 0, 21)])
+def test_unitigs_long_paths_double_the_jump_words(gpu_ctx, oracle, k, b, l):
+    """Round 5: a walk is a chain of dependent loads; a unitig of 1e5 .. 1e6 k-mers (what -k 23 -b 5 -l 1200, the reference's example
+    parameters, leave of an abundant genome) kept one lane busy for the whole kernel.  Walks still under way after the chunked rounds double the
+    jump words over the entry nodes (mf_unitig.hip U3b) and the segment cuts walk the 32-jump words.  An error-free genome of 200 kb at depth
+    22: one path of 2e5 k-mers -- the doubling runs by itself (stat unitig_doublings), gives the oracle's sequences, and so does the walk with the
+    doubling put off (ut_double_after = 64) and brought forward to the first round (1); the small branchy / cyclic cases with it brought forward."""
+    rng = np.random.default_rng(900 + k)
+    bs, o = genome_reads(rng, 200_000, 30_000, 150, err=0.0)
+    before = gpu_ctx.stat("unitig_doublings")
+    gs, got = _check_unitigs(gpu_ctx, oracle, bs, o, k, b, l)
+    assert gpu_ctx.stat("unitig_doublings") == before + 1 and max(len(s[0]) for s in got) > 50_000
+    ref = _norm_seqs(got)
+    for after in (64, 1):
+        try:
+            gpu_ctx.set_option("ut_double_after", after)
+            t = gpu_count(gpu_ctx, bs, o, k)
+            assert _norm_seqs(gpu_ctx.build_unitigs(t, b, l).export()) == ref
+            if after == 1 and k == 31:
+                for seed in (7, 9):
+                    bb, oo = branchy_reads(seed)
+                    _check_unitigs(gpu_ctx, oracle, bb, oo, 31, 1, 100)
+                cyc = "ACGTTGCATGCCGATAGGCTTAACCGGATATCCGGTTAAGC"
+                bb, oo = pack_reads([cyc * 3, "A" * 80, "ACGT" * 30, "AATT" * 30, cyc[3:] + cyc[:20]])
+                for kk in (7, 8, 12):
+                    _check_unitigs(gpu_ctx, oracle, bb, oo, kk, 0, kk)
+        finally:
+            gpu_ctx.set_option("ut_double_after", 4)
+    assert gpu_ctx.stat("unitig_doublings") >= before + 2
+
+
 def _check_components(ctx, oracle, cutter_gpu, cutter_or, k, b1, b2):
     gc = ctx.cut_components(cutter_gpu, b1, b2)
     oc = oracle.cut_components(cutter_or, k, b1, b2)
