@@ -81,7 +81,9 @@ int  mf_ctx_kernel_report(mf_ctx *ctx, char *buf, uint64_t cap);
 int  mf_ctx_reset_timers(mf_ctx *ctx);
 /* Counters and gauges by name: "slice_restarts" (counting runs that threw their slices away and started over with more because a
  * buffer found no place in HBM), "device_parsed_files" / "device_parser_stepped_back" (read files the device parser took / left to
- * the host readers), "hipmalloc_calls", "hipmalloc_bytes", "arena_bytes", "arena_idle_bytes".  < 0: unknown name. */
+ * the host readers), "unitig_doublings" (unitig runs whose long paths went through the doubled jump words), "wide_hashed_entries" /
+ * "wide_big_entries" (k = 32..63: entries of large buckets ordered through the LDS hash tables / sorted aside), "hipmalloc_calls",
+ * "hipmalloc_bytes", "hipmalloc_us", "arena_bytes", "arena_idle_bytes".  < 0: unknown name. */
 int64_t mf_ctx_stat(mf_ctx *ctx, const char *name);
 
 /* ---- A1-A4  reads -> canonical k-mer counts ---------------------------------------- */
