@@ -112,7 +112,7 @@ struct mf_ctx {
     size_t arena_bytes = 0;
     // counters a host can read (mf_ctx_stat): counting runs that started their slices over because a buffer found no place (mf_skm.hip);
     // read files the device parser took / handed to the host readers (mf_dparse.hip)
-    uint64_t n_slice_restarts = 0, n_dparse_files = 0, n_dparse_stepped_back = 0, n_wide_big = 0, n_wide_hashed = 0, n_ut_doubled = 0;
+    uint64_t n_slice_restarts = 0, n_dparse_files = 0, n_dparse_stepped_back = 0, n_wide_big = 0, n_wide_hashed = 0, n_ut_doubled = 0, n_pilots = 0;
     // timers
     std::vector<mf_timer_rec> pending;
     std::vector<hipEvent_t> event_pool;

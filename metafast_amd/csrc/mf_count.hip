@@ -628,7 +628,11 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     uint64_t target = (uint64_t)ctx->opt_part_target;
     // (assembled: long sequences, or a caller that filters by length -- ComponentCutterMain.java:81 is the one that does --, or
     // the pipeline's hint; at low coverage unitigs are short, and partitions planned for reads then hold 4000 distinct k-mers)
-    const bool assembled = n_bases / n_reads >= (uint64_t)(8 * k) || min_len > 0 || ctx->opt_union_samples > 0 || ctx->own_world > 1;
+    // (round 5: length alone says "assembled" only where no pilot will look at the input: 250-base reads at k = 25 .. 31 are "long sequences"
+    // by the 8 k rule, were planned as unitigs -- 2^23 units of 200 records, three radix levels -- and took 387 ms where 150-base reads of the
+    // same volume take 130 (profiles/r05az_probe_shapes.txt); the pilot measures what the rule guesses: distinct k-mers per occurrence)
+    const bool pilot_looks = ctx->opt_skm && k >= MF_SKM_MIN_K && ctx->opt_skm_pilot != 0 && ctx->opt_l1_bits < 0;
+    const bool assembled = (n_bases / n_reads >= (uint64_t)(8 * k) && !pilot_looks) || min_len > 0 || ctx->opt_union_samples > 0 || ctx->own_world > 1;
     if (assembled && target > (uint64_t)ctx->opt_part_target_long) target = (uint64_t)ctx->opt_part_target_long;
     // (a shard of the union of many samples' unitigs: the samples share most of their k-mers -- 0.36 distinct per occurrence at 8
     // samples --, and it is the DISTINCT k-mers of a partition that must fit the LDS tables)

@@ -213,6 +213,7 @@ extern "C" int64_t mf_ctx_stat(mf_ctx *ctx, const char *name) {
     if (!ctx || !name) return mf_set_error("mf_ctx_stat: NULL argument");
     const std::string s(name);
     if (s == "slice_restarts") return (int64_t)ctx->n_slice_restarts;
+    if (s == "pilot_runs") return (int64_t)ctx->n_pilots;
     if (s == "unitig_doublings") return (int64_t)ctx->n_ut_doubled;
     if (s == "wide_big_entries") return (int64_t)ctx->n_wide_big;
     if (s == "wide_hashed_entries") return (int64_t)ctx->n_wide_hashed;

@@ -1823,7 +1823,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         *plan_open = false;
         double rho = -1.0, kept = -1.0, rpo = 0.0;
         MF_TRY(skm_pilot<K>(ctx, bufA.p, pstart.p, plen.p, dlo, dhi, n_occ, nd1, total_bits - bits1, kthr, &rho, &kept, &rpo));
-        ctx->last_pilot_rho = rho;
+        ctx->last_pilot_rho = rho; ctx->n_pilots++;
         if (rho > 0.0) {
             double want_units = (double)n_occ * rho / (double)std::max<int64_t>(64, ctx->opt_skm_unit_distinct);
             // ... and a unit's RECORDS should fit the search for identical ones (its first C2_DD * SKM_CT = 2048 records go through the

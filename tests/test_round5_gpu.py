@@ -420,6 +420,28 @@ def test_low_complexity_reads_with_the_short_minimizer(gpu_ctx, oracle, k):
     assert np.array_equal(got[:3000], ov[pick]) and np.all(got[3000:] == -1)
 
 
+@pytest.mark.parametrize("k,read_len", [(31, 250), (25, 250), (21, 400)])
+def test_long_reads_are_planned_by_the_pilot(gpu_ctx, oracle, k, read_len):
+    """Round 5: reads of 8 k bases or more were taken for assembled sequences by their length alone (no pilot, units planned for all-distinct
+    k-mers: 250-base reads at k = 25 ran 2.6 x slower than 150-base reads of the same volume, profiles/r05az_probe_shapes.txt).  Now the pilot
+    looks at them like at any reads (stat pilot_runs); sequences that come with a length filter (the cutter's input) are still planned as
+    assembled.  Counts equal the oracle's either way."""
+    from util import genome_reads, to_device
+    rng = np.random.default_rng(40 + k)
+    b, o = genome_reads(rng, 2_000_000, 30_000_000 // read_len, read_len, err=0.005)        # (3e7 bases: enough for a plan of two radix levels)
+    tb, to = to_device(b, o)
+    ok, ov = oracle.Table().count_buffer(b, o, k).export()
+    before = gpu_ctx.stat("pilot_runs")
+    t = gpu_ctx.count_device(tb.data_ptr(), to.data_ptr(), len(o) - 1, int(o[-1]), k, 0)
+    gk, gc = t.export()
+    assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+    assert gpu_ctx.stat("pilot_runs") == before + 1
+    t2 = gpu_ctx.count_device(tb.data_ptr(), to.data_ptr(), len(o) - 1, int(o[-1]), k, read_len)        # (a length filter: the cutter's call)
+    gk, gc = t2.export()
+    assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov)
+    assert gpu_ctx.stat("pilot_runs") == before + 1
+
+
 @pytest.mark.parametrize("kind,kt,vt", [(0, np.uint64, np.uint16), (1, np.uint32, np.uint32), (2, np.uint32, np.uint64), (3, np.uint64, np.uint32), (4, np.uint64, np.uint64)])
 def test_radix_sort_kernels(gpu_ctx, kind, kt, vt):
     """mf_sort.hip (hand-written since round 5): stable, ascending by the low `bits` key bits and by nothing above them, for every (key, value)
