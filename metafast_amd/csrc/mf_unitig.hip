@@ -288,9 +288,10 @@ __global__ void k_ut_walk1(ut_arrays A, const ut_item *__restrict__ items, uint3
 // -l 1200, /root/reference/Example.md:18-21) leave of an abundant genome -- kept ONE lane busy for 108 ms, and once more for the segment cuts
 // (profiles/r05v_shape_cami_example_k23_b5_l1200.json: k_ut_walk1 108 ms + k_ut_segments 92 ms of a 297 ms step).  When walks are still under
 // way after the rounds of 32, 128, 512 and 4096 jumps, the jump words are doubled instead (Wyllie's list ranking) -- over the ENTRY nodes only,
-// the nodes some jump lands on (one in ~6): EJ[i] = entry (or, END, the path's last node) | distance << 32 | END << 63.  Five synchronous rounds
-// give words that span exactly 32 jumps (kept: the segment cuts walk them); further rounds run in place (a word is always a true statement
-// "t is d nodes ahead") until every unfinished walk reads its end in one load.
+// the nodes some jump lands on (one in ~6): EJ[i] = entry (or, END, the path's last node) | distance << 32 | END << 63.  The rounds run in place
+// (a word is always a true statement "t is d nodes ahead"; every round at least doubles what a word spans) until every unfinished walk reads
+// its end in one load, and on until every entry does: the segment cuts (U5) are then made by the entries themselves -- the first entry in
+// every stretch of UT_SEG nodes of an emitted path, found with one atomicMin per entry -- instead of one more walk per path.
 #define UTD_END (1ull << 63)
 __global__ void k_utd_mark(const uint64_t *__restrict__ jump, uint64_t n_nodes, uint32_t *__restrict__ flag) {
     const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -334,6 +335,7 @@ __global__ void k_utd_finish(const ut_item *__restrict__ items, uint32_t n_items
 struct ut_paths {
     uint32_t *eqmin;      // [n]
     uint32_t *pstart;     // [n_paths] start node
+    uint32_t *pend;       // [n_paths] last node (nullptr: not wanted)
     uint32_t *plen;       // [n_paths] length in nt
     uint64_t *pkey;       // [n_paths] canonical start k-mer * 2 + strand
     unsigned int *cursor;
@@ -369,6 +371,7 @@ __global__ void k_ut_ends(ut_arrays A, ut_paths P, const uint32_t *__restrict__ 
     const uint32_t pid = mf_block_reserve(P.cursor, take, rs_scratch);        // (one atomic per workgroup: 2e5 per-wave atomics on the cursor cost 2.4 ms a pass)
     if (PASS == 1 && take) {
         P.pstart[pid] = s;
+        if (P.pend) { P.pend[pid] = end_node[t]; if (twice) P.pend[pid + 1] = end_node[t]; }
         P.plen[pid] = (uint32_t)len_nt;
         P.pkey[pid] = stc * 2ull + (uint64_t)(s & 1u);
         if (twice) { P.pstart[pid + 1] = s; P.plen[pid + 1] = (uint32_t)len_nt; P.pkey[pid + 1] = stc * 2ull + 1ull; }
@@ -408,35 +411,46 @@ __global__ void k_ut_segments(ut_arrays A, const uint32_t *__restrict__ pstart, 
     }
     seg[idx] = cur;
 }
-// ... over the 32-jump words of U3b when they exist: 32 x fewer dependent loads per path
-__global__ void k_ut_segments_far(ut_arrays A, const uint32_t *__restrict__ pstart, uint32_t np, const uint64_t *__restrict__ segoff, ut_seg *__restrict__ seg,
-                                  const uint64_t *__restrict__ idx, const uint64_t *__restrict__ ej32, const uint32_t *__restrict__ ent_node) {
+// ... with the doubled jump words of U3b: no walk.  pid_of_end[last node of an emitted path] = its path (the first of the two when a path is
+// written twice: they follow each other and share the start node); slot b of a path = the first entry at a distance in [b, b + 1) x UT_SEG
+__global__ void k_utd_path_ends(const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ pend, uint32_t np, const uint64_t *__restrict__ segoff,
+                                uint32_t *__restrict__ pid_of_end, unsigned long long *__restrict__ seg_min) {
     const uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x;
     if (pid >= np) return;
-    uint64_t at = segoff[pid];
-    uint32_t f = pstart[pid], d = 0, last = 0;
-    ut_seg cur; cur.node = f; cur.pid = pid; cur.dist = 0; cur.stop = 0xFFFFFFFFu;
-    uint64_t i = 0;
-    for (bool first = true;; first = false) {
-        if (first) {                                             // (a start node is nobody's target: its own jump word leads to the first entry)
-            const uint64_t w = A.jump[f];
-            if (w & UT_J_END) break;
-            d += (uint32_t)(w >> 32) & 0x7FFFu;
-            f = (uint32_t)w;
-            i = idx[f];
-        } else {
-            const uint64_t a = ej32[i];
-            if (a & UTD_END) break;
-            d += (uint32_t)((a >> 32) & 0x7FFFFFFFull);
-            i = (uint32_t)a;
-            f = ent_node[i];
-        }
-        if (d - last >= UT_SEG) {
-            cur.stop = d; seg[at++] = cur;
-            cur.node = f; cur.dist = d; cur.stop = 0xFFFFFFFFu; last = d;
-        }
-    }
-    seg[at] = cur;
+    atomicMin(&pid_of_end[pend[pid]], pid);
+    seg_min[segoff[pid]] = (unsigned long long)pstart[pid];                       // (distance 0: the start node, nobody's target)
+}
+__global__ void k_utd_cuts(const uint64_t *__restrict__ ej, const uint32_t *__restrict__ ent_node, uint64_t n_ent, const uint32_t *__restrict__ pid_of_end,
+                           const uint32_t *__restrict__ pstart, const uint32_t *__restrict__ plen, uint32_t np, int k, const uint64_t *__restrict__ segoff,
+                           unsigned long long *__restrict__ seg_min) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_ent) return;
+    const uint64_t a = ej[i];
+    if (!(a & UTD_END)) return;                                                  // (an isolated cycle)
+    const uint32_t pid = pid_of_end[(uint32_t)a];
+    if (pid == UT_NONE) return;                                                  // a path that is not written
+    const uint32_t hops = plen[pid] - (uint32_t)k, dte = (uint32_t)((a >> 32) & 0x7FFFFFFFull);     // start -> last node; this entry -> last node
+    const uint32_t d = hops - dte;
+    const unsigned long long v = ((unsigned long long)d << 32) | ent_node[i];
+    atomicMin(&seg_min[segoff[pid] + d / UT_SEG], v);
+    if (pid + 1 < np && pstart[pid + 1] == pstart[pid]) atomicMin(&seg_min[segoff[pid + 1] + d / UT_SEG], v);       // the path's second copy
+}
+__global__ void k_utd_seg_fill(const unsigned long long *__restrict__ seg_min, uint64_t n_seg, const uint64_t *__restrict__ segoff, uint32_t np, ut_seg *__restrict__ seg) {
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_seg) return;
+    const unsigned long long v = seg_min[q];
+    if (v == ~0ull) return;                                                      // (seg[q].node stays UT_NONE: an unused entry)
+    uint32_t lo = 0, hi = np;                                                    // the path of slot q: the last one with segoff <= q
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (segoff[mid] <= q) lo = mid; else hi = mid; }
+    ut_seg sg; sg.node = (uint32_t)v; sg.pid = lo; sg.dist = (uint32_t)(v >> 32); sg.stop = 0xFFFFFFFFu;
+    for (uint64_t r = q + 1; r < segoff[lo + 1]; r++) { const unsigned long long w = seg_min[r]; if (w != ~0ull) { sg.stop = (uint32_t)(w >> 32); break; } }
+    seg[q] = sg;
+}
+__global__ void k_utd_max(const uint32_t *__restrict__ v, uint32_t n, unsigned int *__restrict__ out) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t x = t < n ? v[t] : 0u;
+    for (int d = 32; d; d >>= 1) { const uint32_t y = __shfl_xor(x, d); x = y > x ? y : x; }
+    if ((threadIdx.x & 63u) == 0 && x) atomicMax(out, x);
 }
 __global__ void k_ut_walk2(ut_arrays A, const ut_seg *__restrict__ seg, uint64_t n_seg, ut_out O, unsigned long long *__restrict__ wsum) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -594,7 +608,8 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         mf_buf<uint32_t> end_node, end_dist;
         if ((rc = end_node.alloc(ctx, n_starts)) < 0 || (rc = end_dist.alloc(ctx, n_starts)) < 0) break;
         int rounds = 0;
-        mf_buf<uint64_t> d_idx, d_ej32; mf_buf<uint32_t> d_ent;                 // U3b (long paths): node -> entry, the 32-jump words, entry -> node
+        mf_buf<uint64_t> d_ej; mf_buf<uint32_t> d_ent;                          // U3b (long paths): the doubled jump words of the entry nodes, entry -> node
+        uint64_t d_n_ent = 0;
         int doubled = 0;
         if (n_starts) {
             mf_buf<ut_item> contA, contB;
@@ -617,7 +632,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
                     // U3b: still walking after the chunked rounds -- double the jump words over the entry nodes (if there is room: else the walks go on)
                     ut_item *items = (rounds & 1) ? contA.p : contB.p;
                     const uint64_t nn = 2 * n;
-                    mf_buf<uint32_t> flag; mf_buf<uint64_t> etot, ejA, ejB;
+                    mf_buf<uint32_t> flag; mf_buf<uint64_t> etot, d_idx;
                     uint64_t n_ent = 0;
                     bool ok = flag.alloc(ctx, nn) == MF_OK && d_idx.alloc(ctx, nn + 1) == MF_OK && etot.alloc(ctx, 1) == MF_OK;
                     if (ok) {
@@ -628,31 +643,39 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
                         ok = mf_scan<1>(ctx, flag.p, d_idx.p, nn, etot.p) == MF_OK && hipMemcpyAsync(&n_ent, etot.p, 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
                              hipStreamSynchronize(st) == hipSuccess;
                     }
-                    ok = ok && n_ent && ejA.alloc(ctx, n_ent) == MF_OK && ejB.alloc(ctx, n_ent) == MF_OK && d_ej32.alloc(ctx, n_ent) == MF_OK && d_ent.alloc(ctx, n_ent) == MF_OK;
+                    ok = ok && n_ent && d_ej.alloc(ctx, n_ent) == MF_OK && d_ent.alloc(ctx, n_ent) == MF_OK;
                     if (ok) {
                         mf_ktimer tm(ctx, "k_ut_double");
-                        k_utd_build<<<grid_for(nn), 256, 0, st>>>(A.jump, flag.p, d_idx.p, nn, ejA.p, d_ent.p);
-                        uint64_t *cur = ejA.p, *oth = ejB.p;
-                        for (int r = 0; r < 5; r++) { k_utd_double<<<grid_for(n_ent), 256, 0, st>>>(cur, oth, n_ent); std::swap(cur, oth); }
-                        hipMemcpyAsync(d_ej32.p, cur, n_ent * 8, hipMemcpyDeviceToDevice, st);
+                        k_utd_build<<<grid_for(nn), 256, 0, st>>>(A.jump, flag.p, d_idx.p, nn, d_ej.p, d_ent.p);
                         unsigned int open = n_cont;
-                        for (int r = 5; open && r < 40; r += 3) {               // (three rounds in place, then a look; isolated cycles never settle: nobody walks them)
-                            for (int q = 0; q < 3; q++) k_utd_double<<<grid_for(n_ent), 256, 0, st>>>(cur, cur, n_ent);
+                        int done_rounds = 0;
+                        for (; open && done_rounds < 40; done_rounds += 3) {      // (three rounds, then a look; isolated cycles never settle: nobody walks them)
+                            for (int q = 0; q < 3; q++) k_utd_double<<<grid_for(n_ent), 256, 0, st>>>(d_ej.p, d_ej.p, n_ent);
                             hipMemsetAsync(&ctr.p[2], 0, 4, st);
-                            k_utd_finish<<<grid_for(n_cont), 256, 0, st>>>(items, n_cont, d_idx.p, cur, W);
+                            k_utd_finish<<<grid_for(n_cont), 256, 0, st>>>(items, n_cont, d_idx.p, d_ej.p, W);
                             if (hipMemcpyAsync(&open, &ctr.p[2], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
                                 rc = mf_set_error("unitigs: walk failed: %s", hipGetErrorString(hipGetLastError())); break;
                             }
                         }
                         if (rc < 0) break;
                         if (open) { rc = mf_set_error("unitigs: internal error, %u walks without an end after the doubling rounds", open); break; }
-                        doubled = 1; ctx->n_ut_doubled++;
-                        if (ctx->opt_verbose) fprintf(stderr, "[mf] unitigs: %u walks still under way after %d rounds: jump words doubled over %llu entry nodes of %llu\n", n_cont, rounds,
-                                                      (unsigned long long)n_ent, (unsigned long long)nn);
+                        // ... and on until EVERY entry of a path knows its end (2^rounds >= the longest path): the segment cuts need them all
+                        unsigned int longest = 0;
+                        hipMemsetAsync(&ctr.p[2], 0, 4, st);
+                        k_utd_max<<<grid_for(n_starts), 256, 0, st>>>(end_dist.p, n_starts, &ctr.p[2]);
+                        if (hipMemcpyAsync(&longest, &ctr.p[2], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
+                            rc = mf_set_error("unitigs: walk failed: %s", hipGetErrorString(hipGetLastError())); break;
+                        }
+                        int need = 1; while (need < 32 && (1ull << need) < (unsigned long long)longest + 2ull) need++;
+                        for (; done_rounds < need + 1; done_rounds++) k_utd_double<<<grid_for(n_ent), 256, 0, st>>>(d_ej.p, d_ej.p, n_ent);
+                        hipMemsetAsync(&ctr.p[2], 0, 4, st);
+                        doubled = 1; ctx->n_ut_doubled++; d_n_ent = n_ent;
+                        if (ctx->opt_verbose) fprintf(stderr, "[mf] unitigs: %u walks still under way after %d rounds: jump words doubled over %llu entry nodes of %llu in %d rounds (longest path %u nodes)\n",
+                                                      n_cont, rounds, (unsigned long long)n_ent, (unsigned long long)nn, done_rounds, longest + 1);
                         break;
                     }
                     (void)hipGetLastError();
-                    d_idx.reset(); d_ej32.reset(); d_ent.reset();                // (no room: the walks go on jump by jump)
+                    d_ej.reset(); d_ent.reset();                                 // (no room: the walks go on jump by jump)
                     hipMemsetAsync(&ctr.p[2], 0, 4, st);
                 }
                 ut_item *in = (rounds & 1) ? contA.p : contB.p;
@@ -669,7 +692,7 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if ((rc = eqmin.alloc(ctx, n)) < 0) break;
         k_fill_u32<<<std::min(grid_for(n), 65536u), 256, 0, st>>>(eqmin.p, n, UT_NONE);
         hipMemsetAsync(ctr.p, 0, 4, st);
-        ut_paths P; P.eqmin = eqmin.p; P.pstart = nullptr; P.plen = nullptr; P.pkey = nullptr; P.cursor = ctr.p;
+        ut_paths P; P.eqmin = eqmin.p; P.pstart = nullptr; P.pend = nullptr; P.plen = nullptr; P.pkey = nullptr; P.cursor = ctr.p;
         if (n_starts) {
             mf_ktimer tm(ctx, "k_ut_ends");
             k_ut_ends<0><<<grid_for(n_starts, 1024), 1024, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
@@ -678,10 +701,10 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         if (hipMemcpyAsync(&ncand, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
             rc = mf_set_error("unitigs: ends pass failed"); break;
         }
-        mf_buf<uint32_t> plen, pstart; mf_buf<uint64_t> pkey;
-        if ((rc = plen.alloc(ctx, ncand)) < 0 || (rc = pkey.alloc(ctx, ncand)) < 0 || (rc = pstart.alloc(ctx, ncand)) < 0) break;
+        mf_buf<uint32_t> plen, pstart, pend; mf_buf<uint64_t> pkey;
+        if ((rc = plen.alloc(ctx, ncand)) < 0 || (rc = pkey.alloc(ctx, ncand)) < 0 || (rc = pstart.alloc(ctx, ncand)) < 0 || (doubled && (rc = pend.alloc(ctx, ncand)) < 0)) break;
         hipMemsetAsync(ctr.p, 0, 4, st);
-        P.plen = plen.p; P.pkey = pkey.p; P.pstart = pstart.p;
+        P.plen = plen.p; P.pkey = pkey.p; P.pstart = pstart.p; P.pend = doubled ? pend.p : nullptr;
         if (n_starts) {
             mf_ktimer tm(ctx, "k_ut_ends");
             k_ut_ends<1><<<grid_for(n_starts, 1024), 1024, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
@@ -721,8 +744,16 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
             hipMemsetAsync(wmax.p, 0, (size_t)np * 4, st);
             {
                 mf_ktimer tm(ctx, "k_ut_segments");
-                if (doubled) k_ut_segments_far<<<grid_for(np, 64), 64, 0, st>>>(A, pstart.p, np, segoff.p, seg.p, d_idx.p, d_ej32.p, d_ent.p);
-                else k_ut_segments<<<grid_for(np, 64), 64, 0, st>>>(A, pstart.p, np, segoff.p, seg.p);
+                if (doubled) {
+                    mf_buf<uint32_t> pid_of_end; mf_buf<unsigned long long> seg_min;
+                    if ((rc = pid_of_end.alloc(ctx, 2 * n)) < 0 || (rc = seg_min.alloc(ctx, n_seg)) < 0) break;
+                    hipMemsetAsync(pid_of_end.p, 0xFF, 2 * n * 4, st);
+                    hipMemsetAsync(seg_min.p, 0xFF, n_seg * 8, st);
+                    k_utd_path_ends<<<grid_for(np), 256, 0, st>>>(pstart.p, pend.p, np, segoff.p, pid_of_end.p, seg_min.p);
+                    k_utd_cuts<<<grid_for(d_n_ent), 256, 0, st>>>(d_ej.p, d_ent.p, d_n_ent, pid_of_end.p, pstart.p, plen.p, np, k, segoff.p, seg_min.p);
+                    k_utd_seg_fill<<<grid_for(n_seg), 256, 0, st>>>(seg_min.p, n_seg, segoff.p, np, seg.p);
+                    if (hipStreamSynchronize(st) != hipSuccess) { rc = mf_set_error("unitigs: cuts failed: %s", hipGetErrorString(hipGetLastError())); break; }
+                } else k_ut_segments<<<grid_for(np, 64), 64, 0, st>>>(A, pstart.p, np, segoff.p, seg.p);
             }
             {
                 mf_ktimer tm(ctx, "k_ut_walk2");
