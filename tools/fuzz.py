@@ -15,6 +15,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 O.build()
 ctx = L.Context(0, stream=torch.cuda.current_stream())
+for kv in filter(None, os.environ.get("MF_OPTIONS", "").split(",")):      # e.g. MF_OPTIONS=ut_double_after=1: the long-path route of the unitigs on every case
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 AL = np.frombuffer(b"ACGT", dtype=np.uint8)
 COMP = np.zeros(256, dtype=np.uint8)
 for a, b in zip(b"ACGT", b"TGCA"):
