@@ -1,0 +1,333 @@
+// mf_inflate.h -- DEFLATE (RFC 1951) in gzip members (RFC 1952), whole buffers in memory, host code.
+//
+// Why: reads arrive as .fastq.gz.  A gzip stream inflates on ONE thread, and that thread is the whole kmer-counter step for a compressed
+// library (tools/gz_rate.py: 2.2 of 2.3 s for 5 M reads through zlib's inflate(), 0.34 GB/s of FASTA; the reference reads through
+// java.util.zip.GZIPInputStream -- zlib as well -- FastaGZReader.java / FastqGZReader.java).  zlib's decoder is written for streaming: a state
+// machine that can stop after any byte of input or output.  With the whole member in memory none of that is needed: a 64-bit bit buffer refilled
+// by one unaligned load, one table look-up per symbol or pair of literals (12 bits for literals / lengths, 8 for distances, sub-tables behind them), copies in
+// 8-byte steps, and bounds checked once per symbol against slack at both ends.
+//
+// Nothing depends on this decoder being right: gunzip() returns false on ANYTHING it does not like -- a malformed header, an invalid code, a
+// distance beyond the output, a CRC-32 or length that does not match the member's trailer -- and the caller (mf_parse.h: inflate_gz) then
+// inflates the file with zlib, which also words the error for a corrupt file.  tests/test_inflate_cpu.py drives both against Python's zlib.
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+#include <zlib.h>
+
+namespace mfz {
+
+struct entry { uint16_t val; uint8_t len; uint8_t op; };   // len: bits to take; op: see below; val: literal / base / sub-table offset
+enum : uint8_t { OP_LIT = 0x80, OP_EOB = 0x40, OP_SUB = 0x20, OP_BAD = 0x10 };   // else: op = number of extra bits (0 .. 13), val = base
+// OP_LIT | 1: TWO literals (val = first | second << 8, len = the bits of both codes): reads are literals mostly -- quality strings, bases that
+// repeat nothing within 32 KB -- and a base costs 2 .. 3 bits, so one look-up of 12 bits often holds two symbols (build_table, kind 0)
+
+static const uint16_t LEN_BASE[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+static const uint8_t LEN_EXTRA[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+static const uint16_t DIST_BASE[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+static const uint8_t DIST_EXTRA[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+
+#define MFZ_LBITS 12
+#define MFZ_DBITS 8
+#define MFZ_LTAB (1 << MFZ_LBITS)
+#define MFZ_DTAB (1 << MFZ_DBITS)
+#define MFZ_LTAB_MAX (MFZ_LTAB + 288 * 8)       // primary + the sub-tables (<= 2^(15 - 12) entries behind any primary slot that needs one)
+#define MFZ_DTAB_MAX (MFZ_DTAB + 32 * 128)
+
+static inline uint32_t rev_bits(uint32_t code, int len) {
+    uint32_t r = 0;
+    for (int i = 0; i < len; i++) { r = (r << 1) | (code & 1u); code >>= 1; }
+    return r;
+}
+// kind 0: literal / length alphabet, 1: distances, 2: the code-length alphabet (7-bit table, symbols as literals).  false: over-subscribed or
+// (but for one lone distance code, which zlib allows too) incomplete code lengths, or a symbol that does not exist.
+static bool build_table(const uint8_t *lens, int n, int kind, int pbits, entry *tab, int tab_max) {
+    int count[16] = {0};
+    for (int i = 0; i < n; i++) count[lens[i]]++;
+    if (count[0] == n) {                                                     // no code at all: every look-up is an error (a block of literals only: no distances)
+        for (int i = 0; i < (1 << pbits); i++) tab[i] = entry{0, 1, OP_BAD};
+        return kind == 1;
+    }
+    long left = 1;
+    for (int l = 1; l <= 15; l++) { left = (left << 1) - count[l]; if (left < 0) return false; }
+    const bool incomplete = left > 0;
+    if (incomplete && !(kind == 1 && n - count[0] == 1)) return false;
+    uint32_t next[16]; next[0] = 0; next[1] = 0;
+    for (int l = 1; l < 15; l++) next[l + 1] = (next[l] + (uint32_t)count[l]) << 1;
+    auto make = [&](int sym, int len) {
+        entry e; e.len = (uint8_t)len;
+        if (kind == 2) { e.val = (uint16_t)sym; e.op = OP_LIT; }
+        else if (kind == 0) {
+            if (sym < 256) { e.val = (uint16_t)sym; e.op = OP_LIT; }
+            else if (sym == 256) { e.val = 0; e.op = OP_EOB; }
+            else if (sym <= 285) { e.val = LEN_BASE[sym - 257]; e.op = LEN_EXTRA[sym - 257]; }
+            else { e.val = 0; e.op = OP_BAD; }
+        } else {
+            if (sym < 30) { e.val = DIST_BASE[sym]; e.op = DIST_EXTRA[sym]; } else { e.val = 0; e.op = OP_BAD; }
+        }
+        return e;
+    };
+    const int psize = 1 << pbits;
+    for (int i = 0; i < psize; i++) tab[i] = entry{0, 1, OP_BAD};            // (slots no code reaches: an incomplete distance code)
+    // pass 1: the longest code behind every primary slot that needs a sub-table
+    uint8_t sub_bits[MFZ_LTAB];                                              // (pbits <= MFZ_LBITS)
+    memset(sub_bits, 0, (size_t)psize);
+    uint32_t code_of[320];
+    {
+        uint32_t nx[16]; memcpy(nx, next, sizeof nx);
+        for (int s = 0; s < n; s++) {
+            const int l = lens[s];
+            if (!l) continue;
+            const uint32_t r = rev_bits(nx[l]++, l);
+            code_of[s] = r;
+            if (l > pbits) { uint8_t &b = sub_bits[r & (uint32_t)(psize - 1)]; if (l - pbits > b) b = (uint8_t)(l - pbits); }
+        }
+    }
+    int used = psize;
+    for (int i = 0; i < psize; i++)
+        if (sub_bits[i]) {
+            if (used + (1 << sub_bits[i]) > tab_max) return false;
+            tab[i] = entry{(uint16_t)used, sub_bits[i], OP_SUB};             // len: bits of the sub-table's index
+            for (int j = 0; j < (1 << sub_bits[i]); j++) tab[used + j] = entry{0, 1, OP_BAD};
+            used += 1 << sub_bits[i];
+        }
+    for (int s = 0; s < n; s++) {
+        const int l = lens[s];
+        if (!l) continue;
+        const uint32_t r = code_of[s];
+        if (l <= pbits) { const entry e = make(s, l); for (uint32_t i = r; i < (uint32_t)psize; i += 1u << l) tab[i] = e; }
+        else {
+            const entry &P = tab[r & (uint32_t)(psize - 1)];
+            const int sb = P.len, rest = l - pbits;
+            const entry e = make(s, rest);                                   // (the primary bits are taken when the pointer is followed)
+            for (uint32_t i = r >> pbits; i < (1u << sb); i += 1u << rest) tab[P.val + i] = e;
+        }
+    }
+    if (kind == 0) {
+        // pairs of literals: slot i = code of literal a in its low bits; if the bits above hold all of a second literal's code, the slot decodes both
+        static thread_local entry single[MFZ_LTAB];
+        memcpy(single, tab, sizeof(entry) * (size_t)psize);
+        for (int i = 0; i < psize; i++) {
+            const entry a = single[i];
+            if (a.op != OP_LIT || a.len >= pbits) continue;
+            const entry b = single[(uint32_t)i >> a.len];
+            if (b.op != OP_LIT || a.len + b.len > pbits) continue;
+            tab[i] = entry{(uint16_t)(a.val | (b.val << 8)), (uint8_t)(a.len + b.len), (uint8_t)(OP_LIT | 1)};
+        }
+    }
+    return true;
+}
+
+struct out_buf {
+    uint8_t *p = nullptr; size_t n = 0, cap = 0;
+    bool reserve(size_t more) {                                              // room for `more` bytes behind n
+        if (n + more <= cap) return true;
+        size_t c = cap ? cap : ((size_t)1 << 20);
+        while (c < n + more) c += c / 2;
+        uint8_t *q = (uint8_t *)realloc(p, c);
+        if (!q) return false;
+        p = q; cap = c;
+        return true;
+    }
+};
+
+static inline uint64_t load64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static inline void store64(uint8_t *p, uint64_t v) { memcpy(p, &v, 8); }
+static inline void store16(uint8_t *p, uint16_t v) { memcpy(p, &v, 2); }
+
+// One raw DEFLATE stream from in[pos ..) (the caller guarantees 16 readable bytes behind in + n) appended to out; *pos: the first byte
+// after the stream.  false: anything irregular.
+static bool inflate_raw(const uint8_t *in, size_t n, size_t *pos, out_buf &out) {
+    const uint8_t *p = in + *pos, *const end = in + n;
+    uint64_t buf = 0; int cnt = 0;
+    const size_t out_start = out.n;                                           // (distances may not reach before the member's first byte)
+    static thread_local entry lt[MFZ_LTAB_MAX], dt[MFZ_DTAB_MAX];
+    static thread_local entry fixed_lt[MFZ_LTAB_MAX], fixed_dt[MFZ_DTAB_MAX];
+    static thread_local bool fixed_ready = false;
+#define MFZ_REFILL() do { buf |= load64(p) << cnt; p += (63 - cnt) >> 3; cnt |= 56; } while (0)
+#define MFZ_OVERRUN() ((size_t)(p - in) > n + (size_t)(cnt >> 3))           /* bits taken from beyond the input's end */
+    for (;;) {
+        MFZ_REFILL();
+        const int final_block = (int)(buf & 1u), type = (int)((buf >> 1) & 3u);
+        buf >>= 3; cnt -= 3;
+        if (type == 0) {                                                     // stored: to the byte boundary, LEN, ~LEN, bytes
+            const int drop = cnt & 7;
+            buf >>= drop; cnt -= drop;
+            p -= cnt >> 3; buf = 0; cnt = 0;                                 // (back to the first unused byte)
+            if (p + 4 > end) return false;
+            const uint32_t len = (uint32_t)p[0] | ((uint32_t)p[1] << 8), nlen = (uint32_t)p[2] | ((uint32_t)p[3] << 8);
+            if ((len ^ nlen) != 0xFFFFu) return false;
+            p += 4;
+            if ((size_t)(end - p) < len) return false;
+            if (!out.reserve((size_t)len + 512)) return false;
+            memcpy(out.p + out.n, p, len);
+            out.n += len; p += len;
+        } else if (type == 3) return false;
+        else {
+            const entry *L, *D;
+            if (type == 1) {
+                if (!fixed_ready) {
+                    uint8_t ll[288], dl[32];
+                    for (int i = 0; i < 144; i++) ll[i] = 8;
+                    for (int i = 144; i < 256; i++) ll[i] = 9;
+                    for (int i = 256; i < 280; i++) ll[i] = 7;
+                    for (int i = 280; i < 288; i++) ll[i] = 8;
+                    for (int i = 0; i < 32; i++) dl[i] = 5;
+                    if (!build_table(ll, 288, 0, MFZ_LBITS, fixed_lt, MFZ_LTAB_MAX) || !build_table(dl, 32, 1, MFZ_DBITS, fixed_dt, MFZ_DTAB_MAX)) return false;
+                    fixed_ready = true;
+                }
+                L = fixed_lt; D = fixed_dt;
+            } else {
+                const int hlit = (int)(buf & 31u) + 257, hdist = (int)((buf >> 5) & 31u) + 1, hclen = (int)((buf >> 10) & 15u) + 4;
+                buf >>= 14; cnt -= 14;
+                if (hlit > 286 || hdist > 30) return false;
+                static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                uint8_t cl[19] = {0};
+                for (int i = 0; i < hclen; i++) {
+                    if (cnt < 3) MFZ_REFILL();
+                    cl[order[i]] = (uint8_t)(buf & 7u); buf >>= 3; cnt -= 3;
+                }
+                entry ct[128];
+                if (!build_table(cl, 19, 2, 7, ct, 128)) return false;
+                uint8_t lens[288 + 32];
+                int i = 0;
+                while (i < hlit + hdist) {
+                    if (cnt < 7 + 7) MFZ_REFILL();
+                    const entry e = ct[buf & 127u];
+                    if (e.op != OP_LIT) return false;
+                    buf >>= e.len; cnt -= e.len;
+                    const int sym = e.val;
+                    if (sym < 16) lens[i++] = (uint8_t)sym;
+                    else {
+                        int rep; uint8_t v = 0;
+                        if (sym == 16) { if (!i) return false; v = lens[i - 1]; rep = 3 + (int)(buf & 3u); buf >>= 2; cnt -= 2; }
+                        else if (sym == 17) { rep = 3 + (int)(buf & 7u); buf >>= 3; cnt -= 3; }
+                        else { rep = 11 + (int)(buf & 127u); buf >>= 7; cnt -= 7; }
+                        if (i + rep > hlit + hdist) return false;
+                        while (rep--) lens[i++] = v;
+                    }
+                }
+                if (MFZ_OVERRUN()) return false;
+                if (lens[256] == 0) return false;                             // no end-of-block code
+                if (!build_table(lens, hlit, 0, MFZ_LBITS, lt, MFZ_LTAB_MAX) || !build_table(lens + hlit, hdist, 1, MFZ_DBITS, dt, MFZ_DTAB_MAX)) return false;
+                L = lt; D = dt;
+            }
+            // the symbols of the block
+            for (;;) {
+                if (out.cap - out.n < 1024) { if (!out.reserve((size_t)1 << 20)) return false; }
+                uint8_t *o = out.p + out.n, *const o_lim = out.p + out.cap - 600;       // (a symbol writes <= 258 + 7 bytes; checked every 256 literals at most)
+                bool eob = false;
+                while (o < o_lim) {
+                    if ((size_t)(p - in) > n + 8) return false;                // far beyond the input: a stream without an end
+                    MFZ_REFILL();
+                    entry e = L[buf & (MFZ_LTAB - 1)];
+                    if (e.op & OP_SUB) { buf >>= MFZ_LBITS; cnt -= MFZ_LBITS; e = L[e.val + (buf & ((1u << e.len) - 1u))]; }
+                    buf >>= e.len; cnt -= e.len;
+                    if (e.op & OP_LIT) {
+                        // one or two literals per look-up, up to four look-ups per refill (15 + 3 x 12 bits <= 56)
+                        store16(o, e.val); o += 1 + (e.op & 1);
+                        entry f = L[buf & (MFZ_LTAB - 1)];
+                        if (f.op & OP_LIT) {
+                            buf >>= f.len; cnt -= f.len; store16(o, f.val); o += 1 + (f.op & 1);
+                            f = L[buf & (MFZ_LTAB - 1)];
+                            if (f.op & OP_LIT) {
+                                buf >>= f.len; cnt -= f.len; store16(o, f.val); o += 1 + (f.op & 1);
+                                f = L[buf & (MFZ_LTAB - 1)];
+                                if (f.op & OP_LIT) { buf >>= f.len; cnt -= f.len; store16(o, f.val); o += 1 + (f.op & 1); }
+                            }
+                        }
+                        continue;
+                    }
+                    if (e.op & (OP_EOB | OP_BAD | OP_SUB)) { if (e.op & OP_EOB) { eob = true; break; } return false; }
+                    const uint32_t len = e.val + (uint32_t)(buf & ((1u << e.op) - 1u));
+                    buf >>= e.op; cnt -= e.op;
+                    if (cnt < 32) MFZ_REFILL();
+                    entry d = D[buf & (MFZ_DTAB - 1)];
+                    if (d.op & OP_SUB) { buf >>= MFZ_DBITS; cnt -= MFZ_DBITS; d = D[d.val + (buf & ((1u << d.len) - 1u))]; }
+                    buf >>= d.len; cnt -= d.len;
+                    if (d.op & (OP_LIT | OP_EOB | OP_BAD | OP_SUB)) return false;
+                    const uint32_t dist = d.val + (uint32_t)(buf & ((1u << d.op) - 1u));
+                    buf >>= d.op; cnt -= d.op;
+                    if ((size_t)dist > (size_t)(o - (out.p + out_start))) return false;
+                    const uint8_t *s = o - dist;
+                    uint8_t *const o_end = o + len;
+                    if (dist >= 8) { do { store64(o, load64(s)); o += 8; s += 8; } while (o < o_end); }
+                    else if (dist == 1) { const uint64_t v = 0x0101010101010101ull * s[0]; do { store64(o, v); o += 8; } while (o < o_end); }
+                    else { do { *o++ = *s++; } while (o < o_end); }
+                    o = o_end;
+                }
+                out.n = (size_t)(o - out.p);
+                if (eob) break;
+            }
+            if (MFZ_OVERRUN()) return false;
+        }
+        if (final_block) break;
+    }
+    // back to the byte after the last one a bit was taken from
+    p -= cnt >> 3;
+    if (p > end) return false;
+    *pos = (size_t)(p - in);
+    return true;
+#undef MFZ_REFILL
+#undef MFZ_OVERRUN
+}
+
+// CRC-32 of a large buffer on several threads (zlib's crc32 + crc32_combine)
+static uint32_t crc32_parallel(const uint8_t *p, size_t n, int threads) {
+    const size_t T = (size_t)std::max(1, std::min<int>(threads, (int)(n / ((size_t)8 << 20)) + 1));
+    if (T == 1) {
+        uLong c = crc32(0L, Z_NULL, 0);
+        for (size_t at = 0; at < n; at += (size_t)1 << 30) c = crc32(c, p + at, (uInt)std::min<size_t>(n - at, (size_t)1 << 30));
+        return (uint32_t)c;
+    }
+    std::vector<uLong> part(T);
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < T; t++)
+        th.emplace_back([&, t]() {
+            const size_t lo = n * t / T, hi = n * (t + 1) / T;
+            uLong c = crc32(0L, Z_NULL, 0);
+            for (size_t at = lo; at < hi; at += (size_t)1 << 30) c = crc32(c, p + at, (uInt)std::min<size_t>(hi - at, (size_t)1 << 30));
+            part[t] = c;
+        });
+    for (auto &x : th) x.join();
+    uLong c = part[0];
+    for (size_t t = 1; t < T; t++) c = crc32_combine(c, part[t], (z_off_t)(n * (t + 1) / T - n * t / T));
+    return (uint32_t)c;
+}
+
+// A file of one or more gzip members, whole in memory with 16 readable bytes behind in + n -> *out_p (malloc), *out_n.  false (nothing
+// allocated is left behind): the caller inflates with zlib instead.
+static bool gunzip(const uint8_t *in, size_t n, int threads, char **out_p, size_t *out_n) {
+    out_buf out;
+    if (!out.reserve(std::max<size_t>(n * 5, (size_t)1 << 20))) return false;
+    size_t pos = 0;
+    bool ok = n > 0;
+    while (ok && pos < n) {
+        // member header (RFC 1952)
+        if (n - pos < 18 || in[pos] != 0x1F || in[pos + 1] != 0x8B || in[pos + 2] != 8) { ok = false; break; }
+        const uint8_t flg = in[pos + 3];
+        if (flg & 0xE0) { ok = false; break; }
+        size_t q = pos + 10;
+        if (flg & 4) { if (q + 2 > n) { ok = false; break; } const size_t xl = (size_t)in[q] | ((size_t)in[q + 1] << 8); q += 2 + xl; }
+        if (flg & 8) { while (q < n && in[q]) q++; q++; }
+        if (flg & 16) { while (q < n && in[q]) q++; q++; }
+        if (flg & 2) q += 2;
+        if (q >= n) { ok = false; break; }
+        const size_t member_start = out.n;
+        if (!inflate_raw(in, n, &q, out)) { ok = false; break; }
+        if (q + 8 > n) { ok = false; break; }
+        const uint32_t want_crc = (uint32_t)in[q] | ((uint32_t)in[q + 1] << 8) | ((uint32_t)in[q + 2] << 16) | ((uint32_t)in[q + 3] << 24);
+        const uint32_t want_len = (uint32_t)in[q + 4] | ((uint32_t)in[q + 5] << 8) | ((uint32_t)in[q + 6] << 16) | ((uint32_t)in[q + 7] << 24);
+        if ((uint32_t)(out.n - member_start) != want_len) { ok = false; break; }
+        if (crc32_parallel(out.p + member_start, out.n - member_start, threads) != want_crc) { ok = false; break; }
+        pos = q + 8;
+    }
+    if (!ok) { free(out.p); return false; }
+    *out_p = (char *)out.p; *out_n = out.n;
+    return true;
+}
+
+}   // namespace mfz

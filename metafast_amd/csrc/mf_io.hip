@@ -1010,3 +1010,25 @@ static int write_features_files(const std::vector<int64_t> &vec, const std::vect
     }
     return MF_OK;
 }
+
+// test hook (not part of the ABI; tests/test_inflate_cpu.py): the image of a gzip file -> its content through the whole-buffer decoder alone (mode 1:
+// MF_ERR where it refuses), through zlib alone (0), or in the product's order (2).  *out: malloc'd, mf_debug_free
+extern "C" int mf_debug_gunzip(const void *in, uint64_t n, int mode, void **out, uint64_t *out_n) {
+    if (!out || !out_n || (!in && n)) return mf_set_error("mf_debug_gunzip: NULL argument");
+    raw_file packed, plain;
+    packed.p = (char *)malloc(n + 64); packed.n = n;
+    if (!packed.p) return mf_set_error("out of host memory");
+    if (n) memcpy(packed.p, in, n);
+    memset(packed.p + n, 0, 64);
+    int rc = MF_OK;
+    if (mode == 1) {
+        char *q = nullptr; size_t m = 0;
+        if (!mfz::gunzip(reinterpret_cast<const uint8_t *>(packed.p), n, 4, &q, &m)) return mf_set_error("mf_debug_gunzip: the whole-buffer decoder refuses this input");
+        plain.p = q; plain.n = m;
+    } else rc = mode == 0 ? inflate_gz_zlib(packed, plain, "(memory)") : inflate_gz(packed, plain, "(memory)", 4);
+    if (rc < 0) return rc;
+    *out = plain.p; *out_n = plain.n;
+    plain.p = nullptr;
+    return MF_OK;
+}
+extern "C" void mf_debug_free(void *p) { free(p); }

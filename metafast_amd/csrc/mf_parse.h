@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <algorithm>
+#include "mf_inflate.h"
 #include <atomic>
 #include <cmath>
 #include <cstdlib>
@@ -295,8 +296,9 @@ static int read_file_parallel(const char *path, raw_file &buf, int threads) {
     struct stat st;
     if (fstat(fd, &st) != 0) { close(fd); return mf_set_error("can't stat '%s'", path); }
     const size_t n = (size_t)st.st_size;
-    buf.p = (char *)malloc(n ? n : 1); buf.n = n;
+    buf.p = (char *)malloc(n + 64); buf.n = n;                 // (64 readable bytes behind the file: mf_inflate.h loads eight at a time)
     if (!buf.p) { close(fd); return mf_set_error("out of host memory reading '%s'", path); }
+    memset(buf.p + n, 0, 64);
     int T = (int)std::min<size_t>((size_t)std::max(threads, 1), n / (16u << 20) + 1);
     std::vector<std::thread> th;
     std::vector<int> ok(T, 1);
@@ -365,7 +367,7 @@ static int parse_buffer_parallel(const raw_file &buf, int fmt, const char *path,
 // .gz inputs (FastaGZReader.java:22-30, FastqGZReader.java:24-32: a GZIPInputStream over the file, which also reads
 // CONCATENATED gzip members): the compressed file is read whole, inflated into one host buffer (zlib; one stream cannot be
 // inflated in parallel) and then parsed by the same parallel parser as a plain file.
-static int inflate_gz(const raw_file &in, raw_file &out, const char *path) {
+static int inflate_gz_zlib(const raw_file &in, raw_file &out, const char *path) {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, 15 + 32) != Z_OK) return mf_set_error("zlib: inflateInit2 failed");
@@ -400,6 +402,16 @@ static int inflate_gz(const raw_file &in, raw_file &out, const char *path) {
     if (ret != Z_STREAM_END) return mf_set_error("Not in GZIP format or corrupt stream: '%s'", path);
     out.n = have;
     return MF_OK;
+}
+// the whole-buffer decoder first (mf_inflate.h: about three times zlib's pace; it checks every member's CRC-32 and length); whatever it does not
+// like -- and every corrupt file, for the wording of the error -- goes through zlib.  MF_FAST_INFLATE=0 in the environment: zlib only
+static int inflate_gz(const raw_file &in, raw_file &out, const char *path, int threads = 8) {
+    static const bool fast = !(getenv("MF_FAST_INFLATE") && atoi(getenv("MF_FAST_INFLATE")) == 0);
+    if (fast) {
+        char *q = nullptr; size_t m = 0;
+        if (mfz::gunzip(reinterpret_cast<const uint8_t *>(in.p), in.n, threads, &q, &m)) { free(out.p); out.p = q; out.n = m; return MF_OK; }
+    }
+    return inflate_gz_zlib(in, out, path);
 }
 // .bz2 inputs (FastaBZ2Reader.java:26-30, FastqBZ2Reader: Hadoop's BZip2Codec, which reads concatenated streams): libbz2 is
 // loaded at run time (the build image carries libbz2.so.1.0 but not its header; the four entry points and bz_stream below are
@@ -479,7 +491,7 @@ static int parse_reads_file(const char *path, int threads, std::vector<read_batc
     if (gz || bz) {
         raw_file packed;
         MF_TRY(read_file_parallel(path, packed, threads));
-        MF_TRY(gz ? inflate_gz(packed, buf, path) : inflate_bz2(packed, buf, path));
+        MF_TRY(gz ? inflate_gz(packed, buf, path, threads) : inflate_bz2(packed, buf, path));
     } else MF_TRY(read_file_parallel(path, buf, threads));
     const double t1 = now();
     int rc;

@@ -1,0 +1,155 @@
+"""mf_inflate.h (round 5): the whole-buffer DEFLATE / gzip decoder the compressed-input readers try first (FastaGZReader.java / FastqGZReader.java read
+through java.util.zip.GZIPInputStream).  Host code: runs without a GPU.  Against Python's zlib on every kind of block (stored, fixed, dynamic), every
+level, long distances, sub-table codes (skewed alphabets), concatenated members, header fields, empty members -- and on damaged files, where it must
+refuse (the product then lets zlib word the error)."""
+import ctypes as C
+import gzip
+import io
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def gunzip():
+    from metafast_amd import lib as L
+    lib = L.lib()
+    fn = lib.mf_debug_gunzip
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_char_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    lib.mf_debug_free.restype = None
+    lib.mf_debug_free.argtypes = [C.c_void_p]
+
+    def run(data, mode):
+        out, n = C.c_void_p(), C.c_uint64()
+        rc = fn(data, len(data), mode, C.byref(out), C.byref(n))
+        if rc != 0:
+            return None
+        try:
+            return C.string_at(out, n.value)
+        finally:
+            lib.mf_debug_free(out)
+    return run
+
+
+def _gz(data, level=6, **kw):
+    b = io.BytesIO()
+    with gzip.GzipFile(fileobj=b, mode="wb", compresslevel=level, **kw) as f:
+        f.write(data)
+    return b.getvalue()
+
+
+def _corpus():
+    rng = np.random.default_rng(7)
+    dna = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 3_000_000)].tobytes()
+    fq = b"".join(b"@read_%d\n" % i + dna[i * 150:(i + 1) * 150] + b"\n+\n" + bytes(rng.integers(33, 74, 150, dtype=np.uint8)) + b"\n" for i in range(12000))
+    skew = bytes(np.minimum(rng.geometric(0.02, 400_000), 255).astype(np.uint8))           # long codes: sub-tables behind the 11-bit table
+    rep = (b"abcdefghij" * 7 + b"Z") * 30000                                                # matches at many distances, lengths up to 258
+    return {"empty": b"", "one": b"A", "dna": dna, "fastq": fq, "random": bytes(rng.integers(0, 256, 500_000, dtype=np.uint8)), "skewed": skew, "repeats": rep,
+            "zeros": bytes(2_000_000), "far": dna[:40000] + bytes(rng.integers(0, 256, 31000, dtype=np.uint8)) + dna[:40000]}
+
+
+def test_every_block_kind_and_level(gunzip):
+    for name, data in _corpus().items():
+        for level in (0, 1, 2, 4, 6, 9):
+            z = _gz(data, level)
+            assert gunzip(z, 1) == data, (name, level)
+            assert gunzip(z, 2) == data and gunzip(z, 0) == data
+        # fixed-Huffman blocks and raw strategies
+        for strategy in (zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+            co = zlib.compressobj(6, zlib.DEFLATED, 31, 9, strategy)
+            z = co.compress(data) + co.flush()
+            assert gunzip(z, 1) == data, (name, strategy)
+        # many small blocks (a flush after every piece)
+        co = zlib.compressobj(5, zlib.DEFLATED, 31)
+        z = b"".join(co.compress(data[i:i + 7001]) + co.flush(zlib.Z_FULL_FLUSH if (i // 7001) % 2 else zlib.Z_SYNC_FLUSH) for i in range(0, len(data), 7001)) + co.flush()
+        assert gunzip(z, 1) == data, name
+
+
+def test_members_and_header_fields(gunzip):
+    c = _corpus()
+    parts = [c["fastq"][:100000], b"", c["dna"][:50000], c["one"], c["repeats"][:300000]]
+    z = b"".join(_gz(p, lv) for p, lv in zip(parts, (1, 6, 9, 0, 3)))
+    assert gunzip(z, 1) == b"".join(parts)
+    # FNAME, mtime; FEXTRA + FCOMMENT + FHCRC by hand
+    z = _gz(parts[0], 6, filename="reads_1.fastq", mtime=12345)
+    assert gunzip(z, 1) == parts[0]
+    raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+    body = raw.compress(parts[2]) + raw.flush()
+    hdr = bytes([0x1F, 0x8B, 8, 4 | 8 | 16 | 2, 0, 0, 0, 0, 0, 255]) + (5).to_bytes(2, "little") + b"EXTRA" + b"name\0" + b"a comment\0" + b"\x12\x34"
+    z = hdr + body + zlib.crc32(parts[2]).to_bytes(4, "little") + (len(parts[2]) & 0xFFFFFFFF).to_bytes(4, "little")
+    assert gunzip(z, 1) == parts[2]
+
+
+def test_damaged_files_are_refused(gunzip):
+    c = _corpus()
+    data = c["fastq"][:400000]
+    z = bytearray(_gz(data, 6))
+    assert gunzip(bytes(z), 1) == data
+    rng = np.random.default_rng(3)
+    refused = 0
+    for _ in range(300):
+        y = bytearray(z)
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            y[int(rng.integers(0, len(y)))] ^= 1 << int(rng.integers(0, 8))                # one flipped bit anywhere
+        elif kind == 1:
+            del y[int(rng.integers(1, len(y))):]                                           # truncated
+        elif kind == 2:
+            at = int(rng.integers(10, len(y) - 8)); y[at:at + 4] = bytes(rng.integers(0, 256, 4, dtype=np.uint8))
+        else:
+            y += bytes(rng.integers(1, 256, int(rng.integers(1, 40)), dtype=np.uint8))      # garbage behind the member
+        got = gunzip(bytes(y), 1)
+        if got is None:
+            refused += 1
+        else:
+            assert got == data, kind                                                       # (a flipped header byte -- mtime, OS -- changes nothing)
+        # the product's order never returns anything but what zlib returns
+        try:
+            want = gzip.decompress(bytes(y))
+        except Exception:
+            want = None
+        both = gunzip(bytes(y), 2)
+        assert both == want or (want is None and both is None) or (kind == 3 and both is None), kind
+    assert refused > 150
+    for bad in (b"", b"\x1f", b"\x1f\x8b\x08", b"not a gzip file at all, just text\n" * 10):
+        assert gunzip(bad, 1) is None
+
+
+def test_random_streams(gunzip):
+    """many small streams of random shape: alphabets of 1 .. 256 symbols with flat, geometric and two-level distributions (code lengths up to 15:
+    sub-tables; pairs of short codes), runs, copies at random distances, every level and strategy, stored / fixed / dynamic blocks mixed by flushes"""
+    rng = np.random.default_rng(2024)
+    for it in range(1500):
+        n = int(rng.integers(0, 30000))
+        k = int(rng.integers(1, 257))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            a = rng.integers(0, k, n)
+        elif kind == 1:
+            a = np.minimum(rng.geometric(float(rng.uniform(0.01, 0.6)), n) - 1, k - 1)
+        elif kind == 2:
+            a = np.where(rng.random(n) < 0.97, rng.integers(0, min(k, 4), n), rng.integers(0, k, n))
+        else:
+            a = np.repeat(rng.integers(0, k, n // 50 + 1), rng.integers(1, 120, n // 50 + 1))[:n]
+        data = bytearray(a.astype(np.uint8).tobytes())
+        for _ in range(int(rng.integers(0, 6))):                                           # copies: matches at chosen distances
+            if len(data) > 600:
+                L0 = int(rng.integers(3, 300)); src = int(rng.integers(0, len(data) - L0)); dst = int(rng.integers(0, len(data) - L0))
+                data[dst:dst + L0] = data[src:src + L0]
+        data = bytes(data)
+        level = int(rng.integers(0, 10))
+        strategy = int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED]))
+        co = zlib.compressobj(level, zlib.DEFLATED, 31, int(rng.integers(1, 10)), strategy)
+        cut = int(rng.integers(0, len(data) + 1))
+        z = co.compress(data[:cut]) + (co.flush(zlib.Z_SYNC_FLUSH) if rng.random() < 0.5 else b"") + co.compress(data[cut:]) + co.flush()
+        assert gunzip(z, 1) == data, (it, n, k, kind, level, strategy)
+
+
+def test_large_member_in_parallel_crc(gunzip):
+    rng = np.random.default_rng(11)
+    dna = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, 60_000_000)].tobytes()
+    z = _gz(dna, 1)
+    assert gunzip(z, 1) == dna
