@@ -12,8 +12,12 @@
 // inflates the file with zlib, which also words the error for a corrupt file.  tests/test_inflate_cpu.py drives both against Python's zlib.
 #pragma once
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 #include <zlib.h>
@@ -298,9 +302,342 @@ static uint32_t crc32_parallel(const uint8_t *p, size_t n, int threads) {
     return (uint32_t)c;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// ONE member on SEVERAL threads.  A DEFLATE stream has no index, but its blocks can be found: a thread given a place in the middle of the file
+// tries every bit position for the start of a dynamic block -- a header whose three Huffman codes are complete, symbols that decode to the
+// block's end, a sane header behind it -- and decodes from there WITHOUT the 32 KB of output that came before: output elements are 16 bits
+// wide, and what a match copies from before the thread's start is written as 256 + position in that unknown window.  Afterwards the windows are
+// handed from piece to piece (the last 32 KB of each, a short serial pass) and every piece replaces its markers and lands in its place, with
+// its CRC-32.  Each piece must END exactly where the next one was found to START, the last block must end at the member's trailer, and CRC-32
+// and length must match: anything else is false, and the caller falls back to one thread.  (pugz, Kerbiriou & Chikhi 2019, is this idea for
+// FASTQ; rapidgzip, Knespel & Brunst 2023, the general form.)  Files of several members (bgzip, `cat a.gz b.gz`) stay on one thread.
+struct bitrd {
+    const uint8_t *in; size_t n; const uint8_t *p; uint64_t buf; int cnt;
+    void seek(size_t bit) { const size_t b = bit >> 3; const int s = (int)(bit & 7); buf = (uint64_t)in[b] >> s; cnt = 8 - s; p = in + b + 1; }
+    size_t pos() const { return (size_t)(p - in) * 8 - (size_t)cnt; }
+    void refill() { buf |= load64(p) << cnt; p += (63 - cnt) >> 3; cnt |= 56; }
+    void take(int k) { buf >>= k; cnt -= k; }
+    bool beyond() const { return (size_t)(p - in) > n + 8; }                   // (the caller's 64 readable bytes behind the input cover this much)
+};
+// the header of a dynamic block behind its three first bits -> the two tables
+static bool read_dynamic(bitrd &r, entry *lt, entry *dt) {
+    r.refill();
+    const int hlit = (int)(r.buf & 31u) + 257, hdist = (int)((r.buf >> 5) & 31u) + 1, hclen = (int)((r.buf >> 10) & 15u) + 4;
+    r.take(14);
+    if (hlit > 286 || hdist > 30) return false;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t cl[19] = {0};
+    for (int i = 0; i < hclen; i++) { if (r.cnt < 3) r.refill(); cl[order[i]] = (uint8_t)(r.buf & 7u); r.take(3); }
+    entry ct[128];
+    if (!build_table(cl, 19, 2, 7, ct, 128)) return false;
+    uint8_t lens[288 + 32];
+    int i = 0;
+    while (i < hlit + hdist) {
+        if (r.cnt < 14) r.refill();
+        const entry e = ct[r.buf & 127u];
+        if (e.op != OP_LIT) return false;
+        r.take(e.len);
+        const int sym = e.val;
+        if (sym < 16) lens[i++] = (uint8_t)sym;
+        else {
+            int rep; uint8_t v = 0;
+            if (sym == 16) { if (!i) return false; v = lens[i - 1]; rep = 3 + (int)(r.buf & 3u); r.take(2); }
+            else if (sym == 17) { rep = 3 + (int)(r.buf & 7u); r.take(3); }
+            else { rep = 11 + (int)(r.buf & 127u); r.take(7); }
+            if (i + rep > hlit + hdist) return false;
+            while (rep--) lens[i++] = v;
+        }
+        if (r.beyond()) return false;
+    }
+    if (lens[256] == 0) return false;
+    return build_table(lens, hlit, 0, MFZ_LBITS, lt, MFZ_LTAB_MAX) && build_table(lens + hlit, hdist, 1, MFZ_DBITS, dt, MFZ_DTAB_MAX);
+}
+static bool fixed_tables(const entry **L, const entry **D) {
+    static thread_local entry flt[MFZ_LTAB_MAX], fdt[MFZ_DTAB_MAX];
+    static thread_local bool ready = false;
+    if (!ready) {
+        uint8_t ll[288], dl[32];
+        for (int i = 0; i < 144; i++) ll[i] = 8;
+        for (int i = 144; i < 256; i++) ll[i] = 9;
+        for (int i = 256; i < 280; i++) ll[i] = 7;
+        for (int i = 280; i < 288; i++) ll[i] = 8;
+        for (int i = 0; i < 32; i++) dl[i] = 5;
+        if (!build_table(ll, 288, 0, MFZ_LBITS, flt, MFZ_LTAB_MAX) || !build_table(dl, 32, 1, MFZ_DBITS, fdt, MFZ_DTAB_MAX)) return false;
+        ready = true;
+    }
+    *L = flt; *D = fdt;
+    return true;
+}
+// does a dynamic block start at this bit?  (header, every symbol to the end of the block, the header of what follows)
+static bool block_starts_at(const uint8_t *in, size_t n, size_t bit, entry *lt, entry *dt, entry *lt2, entry *dt2) {
+    bitrd r{in, n, nullptr, 0, 0};
+    r.seek(bit); r.refill();
+    if ((r.buf & 7u) != 4u) return false;                                      // not final, dynamic
+    r.take(3);
+    if (!read_dynamic(r, lt, dt)) return false;
+    size_t produced = 0;
+    for (uint32_t syms = 0;; syms++) {
+        if (syms > (1u << 22) || r.beyond()) return false;
+        r.refill();
+        entry e = lt[r.buf & (MFZ_LTAB - 1)];
+        if (e.op & OP_SUB) { r.take(MFZ_LBITS); e = lt[e.val + (r.buf & ((1u << e.len) - 1u))]; }
+        r.take(e.len);
+        if (e.op & OP_LIT) { produced += 1 + (e.op & 1); continue; }
+        if (e.op & OP_EOB) break;
+        if (e.op & (OP_BAD | OP_SUB)) return false;
+        r.take(e.op);
+        if (r.cnt < 32) r.refill();
+        entry d = dt[r.buf & (MFZ_DTAB - 1)];
+        if (d.op & OP_SUB) { r.take(MFZ_DBITS); d = dt[d.val + (r.buf & ((1u << d.len) - 1u))]; }
+        r.take(d.len);
+        if (d.op & (OP_LIT | OP_EOB | OP_BAD | OP_SUB)) return false;
+        r.take(d.op);
+        produced += 3;
+    }
+    if (produced < 64 || r.pos() > n * 8) return false;                        // (a block of next to nothing: not where pieces are cut)
+    r.refill();
+    const uint32_t type = (uint32_t)(r.buf >> 1) & 3u;
+    if (type == 3) return false;
+    if (type == 2) { r.take(3); return read_dynamic(r, lt2, dt2); }
+    if (type == 0) {
+        r.take(3); r.take(r.cnt & 7);
+        const uint8_t *q = r.p - (r.cnt >> 3);
+        if (q + 4 > in + n) return false;
+        return (((uint32_t)q[0] | ((uint32_t)q[1] << 8)) ^ ((uint32_t)q[2] | ((uint32_t)q[3] << 8))) == 0xFFFFu;
+    }
+    return true;
+}
+static size_t find_block(const uint8_t *in, size_t n, size_t from_bit, size_t to_bit) {       // the first bit in [from, to) where a block starts; SIZE_MAX: none
+    static thread_local entry a[MFZ_LTAB_MAX], b[MFZ_DTAB_MAX], c[MFZ_LTAB_MAX], d[MFZ_DTAB_MAX];
+    for (size_t bit = from_bit; bit < to_bit && (bit >> 3) + 8 < n; bit++) {
+        const uint64_t w = load64(in + (bit >> 3)) >> (bit & 7);
+        if ((w & 7u) != 4u || ((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) continue;
+        if (block_starts_at(in, n, bit, a, b, c, d)) return bit;
+    }
+    return (size_t)-1;
+}
+struct marked_out {
+    uint16_t *p = nullptr; size_t n = 0, cap = 0;
+    ~marked_out() { free(p); }
+    bool reserve(size_t more) {
+        if (n + more <= cap) return true;
+        size_t c = cap ? cap : ((size_t)1 << 20);
+        while (c < n + more) c += c / 2;
+        uint16_t *q = (uint16_t *)realloc(p, c * 2);
+        if (!q) return false;
+        p = q; cap = c;
+        return true;
+    }
+};
+// blocks from bit `start` until one would start at `stop` (-> *end_bit = stop) or the final block has ended (-> *final_seen, *end_bit behind it).
+// first: nothing precedes `start` (a distance beyond the output is an error); else such distances become markers 256 + window position
+static bool inflate_piece(const uint8_t *in, size_t n, size_t start, size_t stop, bool first, marked_out &out, size_t *end_bit, bool *final_seen) {
+    static thread_local entry lt[MFZ_LTAB_MAX], dt[MFZ_DTAB_MAX];
+    bitrd r{in, n, nullptr, 0, 0};
+    r.seek(start);
+    *final_seen = false;
+    for (;;) {
+        const size_t at = r.pos();
+        if (at == stop) { *end_bit = at; return true; }
+        if (at > stop) return false;
+        r.refill();
+        const int final_block = (int)(r.buf & 1u), type = (int)((r.buf >> 1) & 3u);
+        r.take(3);
+        if (type == 3) return false;
+        if (type == 0) {
+            r.take(r.cnt & 7);
+            const uint8_t *q = r.p - (r.cnt >> 3);
+            if (q + 4 > in + n) return false;
+            const uint32_t len = (uint32_t)q[0] | ((uint32_t)q[1] << 8), nlen = (uint32_t)q[2] | ((uint32_t)q[3] << 8);
+            if ((len ^ nlen) != 0xFFFFu) return false;
+            q += 4;
+            if ((size_t)(in + n - q) < len) return false;
+            if (!out.reserve((size_t)len + 1024)) return false;
+            for (uint32_t i = 0; i < len; i++) out.p[out.n + i] = q[i];
+            out.n += len;
+            r.seek((size_t)(q + len - in) * 8);
+        } else {
+            const entry *L, *D;
+            if (type == 1) { if (!fixed_tables(&L, &D)) return false; }
+            else { if (!read_dynamic(r, lt, dt)) return false; L = lt; D = dt; }
+            for (bool eob = false; !eob;) {
+                if (out.cap - out.n < 2048 && !out.reserve((size_t)1 << 20)) return false;
+                uint16_t *o = out.p + out.n, *const o_lim = out.p + out.cap - 600;
+                while (o < o_lim) {
+                    if (r.beyond()) return false;
+                    r.refill();
+                    entry e = L[r.buf & (MFZ_LTAB - 1)];
+                    if (e.op & OP_SUB) { r.take(MFZ_LBITS); e = L[e.val + (r.buf & ((1u << e.len) - 1u))]; }
+                    r.take(e.len);
+                    if (e.op & OP_LIT) {
+                        o[0] = (uint16_t)(e.val & 255u); o[1] = (uint16_t)(e.val >> 8); o += 1 + (e.op & 1);
+                        for (int more = 0; more < 3; more++) {
+                            const entry f = L[r.buf & (MFZ_LTAB - 1)];
+                            if (!(f.op & OP_LIT)) break;
+                            r.take(f.len);
+                            o[0] = (uint16_t)(f.val & 255u); o[1] = (uint16_t)(f.val >> 8); o += 1 + (f.op & 1);
+                        }
+                        continue;
+                    }
+                    if (e.op & OP_EOB) { eob = true; break; }
+                    if (e.op & (OP_BAD | OP_SUB)) return false;
+                    const uint32_t len = e.val + (uint32_t)(r.buf & ((1u << e.op) - 1u));
+                    r.take(e.op);
+                    if (r.cnt < 32) r.refill();
+                    entry d = D[r.buf & (MFZ_DTAB - 1)];
+                    if (d.op & OP_SUB) { r.take(MFZ_DBITS); d = D[d.val + (r.buf & ((1u << d.len) - 1u))]; }
+                    r.take(d.len);
+                    if (d.op & (OP_LIT | OP_EOB | OP_BAD | OP_SUB)) return false;
+                    const uint32_t dist = d.val + (uint32_t)(r.buf & ((1u << d.op) - 1u));
+                    r.take(d.op);
+                    const size_t have = (size_t)(o - out.p);
+                    uint32_t j = 0;
+                    if ((size_t)dist > have) {                                 // (part of) the source lies before this piece
+                        if (first) return false;
+                        const uint32_t before = (uint32_t)std::min<size_t>(len, (size_t)dist - have);
+                        const uint32_t w0 = 32768u - (uint32_t)((size_t)dist - have);          // window position of the first source element
+                        for (; j < before; j++) o[j] = (uint16_t)(256u + w0 + j);
+                    }
+                    if (dist >= len && j == 0) memcpy(o, o - dist, (size_t)len * 2);
+                    else for (; j < len; j++) o[j] = *(o + j - dist);
+                    o += len;
+                }
+                out.n = (size_t)(o - out.p);
+            }
+            if (r.pos() > n * 8) return false;
+        }
+        if (final_block) { *final_seen = true; *end_bit = r.pos(); return true; }
+    }
+}
+// a member's raw stream in [d0, n - 8) on `threads` threads, appended to out.  false: one thread has to do it
+static bool inflate_parallel(const uint8_t *in, size_t n, size_t d0, int threads, out_buf &out, uint32_t *crc_out, size_t piece_min) {
+    // (not more: every piece in flight holds its output twice over in 16-bit elements, and memory touched for the first time costs more than
+    // decoding it -- 0.5 s per GB on this pool's boxes, whatever the number of threads: tools/page_fault_rate.cpp)
+    const size_t T = (size_t)std::max(2, std::min(threads, 32));
+    const size_t body = n - 8 - d0;
+    const bool dbg = getenv("MF_INFLATE_DEBUG") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_0 = now();
+    double t_dec = 0, t_win = 0, t_res = 0;
+    const size_t piece = std::max<size_t>(piece_min, std::min<size_t>(body / (T * 4) + 1, (size_t)8 << 20));
+    const size_t np0 = (body + piece - 1) / piece;
+    if (np0 < 2) return false;
+    // where the pieces start: piece i at the first block found at or behind d0 + i * piece (none found before the next one's place: no cut there)
+    std::vector<size_t> found(np0, (size_t)-1);
+    found[0] = d0 * 8;
+    {
+        std::atomic<size_t> next{1};
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < std::min(T, np0); t++)
+            th.emplace_back([&]() { for (;;) { const size_t i = next++; if (i >= np0) break; found[i] = find_block(in, n - 8, (d0 + i * piece) * 8, (d0 + std::min(body, (i + 1) * piece)) * 8); } });
+        for (auto &x : th) x.join();
+    }
+    std::vector<size_t> starts;
+    for (size_t i = 0; i < np0; i++) if (found[i] != (size_t)-1) starts.push_back(found[i]);
+    const size_t np = starts.size();
+    if (np < 2) return false;
+    const double t_find = now() - t_0;
+    // waves of pieces: decode (parallel), hand the windows on (serial), resolve the markers into place with a CRC each (parallel)
+    std::vector<uint8_t> window(32768, 0);
+    size_t total = 0;                                                           // bytes of this member so far
+    uLong crc = crc32(0L, Z_NULL, 0);
+    const size_t out_start = out.n;
+    const size_t wave = T;
+    std::vector<marked_out> mo(std::min(wave, np));                             // (reused wave after wave: memory touched once)
+    for (auto &M : mo) if (!M.reserve(piece * 7 / 2)) return false;
+    for (size_t w0 = 0; w0 < np; w0 += wave) {
+        const size_t w1 = std::min(np, w0 + wave), m = w1 - w0;
+        for (size_t j = 0; j < m; j++) mo[j].n = 0;
+        const double t_a = now();
+        std::vector<size_t> endb(m, 0);
+        std::vector<char> ok(m, 0), fin(m, 0);
+        {
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < std::min(T, m); t++)
+                th.emplace_back([&]() {
+                    for (;;) {
+                        const size_t j = next++;
+                        if (j >= m) break;
+                        const size_t i = w0 + j;
+                        bool f = false;
+                        ok[j] = inflate_piece(in, n - 8, starts[i], i + 1 < np ? starts[i + 1] : (size_t)-1, i == 0, mo[j], &endb[j], &f) ? 1 : 0;
+                        fin[j] = f ? 1 : 0;
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+        for (size_t j = 0; j < m; j++) {
+            const size_t i = w0 + j;
+            if (!ok[j]) return false;
+            if (i + 1 < np) { if (fin[j] || endb[j] != starts[i + 1]) return false; }
+            else if (!fin[j] || (endb[j] + 7) / 8 != n - 8) return false;         // the last block ends at the trailer
+        }
+        const double t_b = now(); t_dec += t_b - t_a;
+        // windows: wins[j] = the 32 KB before piece w0 + j
+        std::vector<std::vector<uint8_t>> wins(m);
+        std::vector<size_t> offs(m);
+        size_t grow = 0;
+        for (size_t j = 0; j < m; j++) {
+            wins[j] = window;
+            offs[j] = total;
+            const marked_out &M = mo[j];
+            // markers must not reach before the member's first byte
+            const size_t known = std::min<size_t>(total, 32768);
+            std::vector<uint8_t> nw(32768, 0);
+            const size_t tail = std::min<size_t>(M.n, 32768);
+            for (size_t q = 0; q < 32768 - tail; q++) nw[q] = window[q + tail];
+            for (size_t q = 0; q < tail; q++) {
+                const uint16_t v = M.p[M.n - tail + q];
+                if (v >= 256) { const uint32_t wp = (uint32_t)v - 256u; if (wp < 32768 - known) return false; nw[32768 - tail + q] = window[wp]; }
+                else nw[32768 - tail + q] = (uint8_t)v;
+            }
+            window.swap(nw);
+            total += M.n; grow += M.n;
+        }
+        if (!out.reserve(grow + 64)) return false;
+        const double t_c = now(); t_win += t_c - t_b;
+        std::vector<uLong> crcs(m, 0);
+        std::vector<char> good(m, 1);
+        {
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < std::min(T, m); t++)
+                th.emplace_back([&]() {
+                    for (;;) {
+                        const size_t j = next++;
+                        if (j >= m) break;
+                        const marked_out &M = mo[j];
+                        uint8_t *dst = out.p + out_start + offs[j];
+                        const uint8_t *W = wins[j].data();
+                        const size_t known = std::min<size_t>(offs[j], 32768);
+                        bool g = true;
+                        for (size_t q = 0; q < M.n; q++) {
+                            const uint16_t v = M.p[q];
+                            if (v >= 256) { const uint32_t wp = (uint32_t)v - 256u; if (wp < 32768 - known) { g = false; break; } dst[q] = W[wp]; }
+                            else dst[q] = (uint8_t)v;
+                        }
+                        good[j] = g ? 1 : 0;
+                        uLong c = crc32(0L, Z_NULL, 0);
+                        for (size_t at = 0; g && at < M.n; at += (size_t)1 << 30) c = crc32(c, dst + at, (uInt)std::min<size_t>(M.n - at, (size_t)1 << 30));
+                        crcs[j] = c;
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+        for (size_t j = 0; j < m; j++) { if (!good[j]) return false; crc = crc32_combine(crc, crcs[j], (z_off_t)mo[j].n); }
+        out.n += grow;
+        t_res += now() - t_c;
+    }
+    if (dbg) fprintf(stderr, "[mf] inflate: %zu pieces of %zu bytes on %zu threads: block search %.3f s, decoding %.3f s, windows %.3f s, markers + CRC %.3f s\n", np, piece, T, t_find, t_dec, t_win, t_res);
+    *crc_out = (uint32_t)crc;
+    return true;
+}
+
 // A file of one or more gzip members, whole in memory with 16 readable bytes behind in + n -> *out_p (malloc), *out_n.  false (nothing
 // allocated is left behind): the caller inflates with zlib instead.
-static bool gunzip(const uint8_t *in, size_t n, int threads, char **out_p, size_t *out_n) {
+static bool gunzip(const uint8_t *in, size_t n, int threads, char **out_p, size_t *out_n, size_t parallel_min = (size_t)32 << 20, size_t piece_min = (size_t)2 << 20,
+                   bool *went_parallel = nullptr) {
     out_buf out;
     if (!out.reserve(std::max<size_t>(n * 5, (size_t)1 << 20))) return false;
     size_t pos = 0;
@@ -317,12 +654,20 @@ static bool gunzip(const uint8_t *in, size_t n, int threads, char **out_p, size_
         if (flg & 2) q += 2;
         if (q >= n) { ok = false; break; }
         const size_t member_start = out.n;
-        if (!inflate_raw(in, n, &q, out)) { ok = false; break; }
+        uint32_t have_crc = 0;
+        bool have = false;
+        if (pos == 0 && threads >= 2 && n - q >= parallel_min) {
+            // the file as ONE member on several threads (whatever goes wrong in there -- a second member among it -- leaves out as it was)
+            if (inflate_parallel(in, n, q, threads, out, &have_crc, piece_min)) { have = true; q = n - 8; } else out.n = member_start;
+            if (went_parallel) *went_parallel = have;
+            if (getenv("MF_INFLATE_DEBUG")) fprintf(stderr, "[mf] inflate: %zu bytes on %d threads: %s\n", n, threads, have ? "done" : "refused, one thread");
+        }
+        if (!have && !inflate_raw(in, n, &q, out)) { ok = false; break; }
         if (q + 8 > n) { ok = false; break; }
         const uint32_t want_crc = (uint32_t)in[q] | ((uint32_t)in[q + 1] << 8) | ((uint32_t)in[q + 2] << 16) | ((uint32_t)in[q + 3] << 24);
         const uint32_t want_len = (uint32_t)in[q + 4] | ((uint32_t)in[q + 5] << 8) | ((uint32_t)in[q + 6] << 16) | ((uint32_t)in[q + 7] << 24);
         if ((uint32_t)(out.n - member_start) != want_len) { ok = false; break; }
-        if (crc32_parallel(out.p + member_start, out.n - member_start, threads) != want_crc) { ok = false; break; }
+        if ((have ? have_crc : crc32_parallel(out.p + member_start, out.n - member_start, threads)) != want_crc) { ok = false; break; }
         pos = q + 8;
     }
     if (!ok) { free(out.p); return false; }

@@ -1012,7 +1012,8 @@ static int write_features_files(const std::vector<int64_t> &vec, const std::vect
 }
 
 // test hook (not part of the ABI; tests/test_inflate_cpu.py): the image of a gzip file -> its content through the whole-buffer decoder alone (mode 1:
-// MF_ERR where it refuses), through zlib alone (0), or in the product's order (2).  *out: malloc'd, mf_debug_free
+// MF_ERR where it refuses), through zlib alone (0), in the product's order (2), or through the decoder with the several-thread form forced on small
+// inputs (3: pieces of 48 KB; MF_ERR also where that form steps back to one thread).  *out: malloc'd, mf_debug_free
 extern "C" int mf_debug_gunzip(const void *in, uint64_t n, int mode, void **out, uint64_t *out_n) {
     if (!out || !out_n || (!in && n)) return mf_set_error("mf_debug_gunzip: NULL argument");
     raw_file packed, plain;
@@ -1021,10 +1022,13 @@ extern "C" int mf_debug_gunzip(const void *in, uint64_t n, int mode, void **out,
     if (n) memcpy(packed.p, in, n);
     memset(packed.p + n, 0, 64);
     int rc = MF_OK;
-    if (mode == 1) {
+    if (mode == 1 || mode == 3) {
         char *q = nullptr; size_t m = 0;
-        if (!mfz::gunzip(reinterpret_cast<const uint8_t *>(packed.p), n, 4, &q, &m)) return mf_set_error("mf_debug_gunzip: the whole-buffer decoder refuses this input");
+        bool par = false;
+        if (!mfz::gunzip(reinterpret_cast<const uint8_t *>(packed.p), n, 4, &q, &m, mode == 3 ? 0 : (size_t)32 << 20, mode == 3 ? (size_t)48 << 10 : (size_t)2 << 20, &par))
+            return mf_set_error("mf_debug_gunzip: the whole-buffer decoder refuses this input");
         plain.p = q; plain.n = m;
+        if (mode == 3 && !par) return mf_set_error("mf_debug_gunzip: the several-thread form stepped back");
     } else rc = mode == 0 ? inflate_gz_zlib(packed, plain, "(memory)") : inflate_gz(packed, plain, "(memory)", 4);
     if (rc < 0) return rc;
     *out = plain.p; *out_n = plain.n;

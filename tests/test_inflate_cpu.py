@@ -148,6 +148,49 @@ def test_random_streams(gunzip):
         assert gunzip(z, 1) == data, (it, n, k, kind, level, strategy)
 
 
+def test_one_member_on_several_threads(gunzip):
+    """the speculative form (mf_inflate.h: inflate_parallel), forced onto small inputs with pieces of 48 KB of compressed data: block starts found
+    by trying bit positions, pieces decoded without their 32 KB of history (markers), windows handed on, markers resolved.  Pieces shorter than
+    a window, stored and fixed blocks among the dynamic ones, matches that copy markers; several members: the form steps back (mode 3 says so)
+    and one thread does it."""
+    c = _corpus()
+    rng = np.random.default_rng(5)
+    ran = 0
+    for name in ("dna", "fastq", "random", "skewed", "repeats", "far", "zeros"):
+        data = c[name]
+        for level in (1, 4, 6, 9):
+            z = _gz(data, level)
+            got = gunzip(z, 3)
+            if got is not None:
+                ran += 1
+                assert got == data, (name, level)
+            assert gunzip(z, 1) == data
+        # blocks of every kind in one stream: pieces of it compressed at different levels and strategies, joined by full flushes
+        co = [zlib.compressobj(lv, zlib.DEFLATED, -15, 8, st) for lv, st in ((6, zlib.Z_DEFAULT_STRATEGY), (0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (9, zlib.Z_FILTERED))]
+        co = zlib.compressobj(6, zlib.DEFLATED, 31, 8)
+        z = b"".join(co.compress(data[i:i + 90001]) + co.flush(zlib.Z_FULL_FLUSH if (i // 90001) % 3 == 0 else zlib.Z_SYNC_FLUSH) for i in range(0, len(data), 90001)) + co.flush()
+        got = gunzip(z, 3)
+        assert got is None or got == data, name
+        assert gunzip(z, 1) == data
+    assert ran >= 12                                                                       # (compressible data gives too few pieces to cut: those ran on one thread)
+    # text with long-range repeats at random distances <= 32 KB: matches reach into the unknown window all the time
+    words = [bytes(rng.integers(97, 123, int(rng.integers(3, 40)), dtype=np.uint8)) for _ in range(3000)]
+    text = b" ".join(words[int(i)] for i in rng.integers(0, len(words), 700_000))
+    for level in (1, 6, 9):
+        z = _gz(text, level)
+        assert gunzip(z, 3) == text, level
+    # several members: not for this form
+    z = _gz(text[:2_000_000], 6) + _gz(text[2_000_000:], 6)
+    assert gunzip(z, 3) is None and gunzip(z, 1) == text and gunzip(z, 2) == text
+    # damaged: never anything but the content or a refusal
+    z = bytearray(_gz(text, 6))
+    for _ in range(40):
+        y = bytearray(z)
+        y[int(rng.integers(20, len(y) - 8))] ^= 1 << int(rng.integers(0, 8))
+        got = gunzip(bytes(y), 3)
+        assert got is None or got == text
+
+
 def test_large_member_in_parallel_crc(gunzip):
     rng = np.random.default_rng(11)
     dna = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, 60_000_000)].tobytes()

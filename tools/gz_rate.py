@@ -21,8 +21,8 @@ with open(fa, "wb") as f:
 del bases, offs
 size = os.path.getsize(fa)
 subprocess.run(["gzip", "-1", "-k", fa], check=True)
-subprocess.run(["bzip2", "-1", "-k", fa], check=True)
-for ext, dec in ((".gz", ["gzip", "-dc"]), (".bz2", ["bzip2", "-dc"]), ("", ["cat"])):
+subprocess.run(["bzip2", "-1", "-k", fa], check=True) if n <= 5_000_000 else None
+for ext, dec in ((".gz", ["gzip", "-dc"]),) + (((".bz2", ["bzip2", "-dc"]),) if n <= 5_000_000 else ()) + (("", ["cat"]),):
     f = fa + ext
     t0 = time.perf_counter(); subprocess.run(dec + [f], stdout=subprocess.DEVNULL, check=True); td_ = time.perf_counter() - t0
     wd = os.path.join(td, "wd" + ext.replace(".", "_"))
@@ -30,6 +30,8 @@ for ext, dec in ((".gz", ["gzip", "-dc"]), (".bz2", ["bzip2", "-dc"]), ("", ["ca
     p = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-t", "kmer-counter", "-k", "31", "-i", f, "-w", wd], capture_output=True, text=True, env=dict(os.environ, MF_IO_TIMING="1"))
     dt = time.perf_counter() - t0
     line = [ln for ln in p.stderr.splitlines() if "count_reads" in ln][-1:] or [p.stderr[-300:]]
+    for ln in p.stderr.splitlines():
+        if "inflate" in ln or ": read " in ln: print("      " + ln[:200])
     print("%-5s %.2f GB on disk, %.2f GB of FASTA: %s alone %.2f s = %.2f GB/s; kmer-counter %.2f s (exit %d)  %s" % (ext or "plain", os.path.getsize(f) / 1e9, size / 1e9, dec[0], td_, size / 1e9 / td_, dt, p.returncode, line[0][:200]))
 # a library of two compressed files (a paired-end sample): the two streams inflate side by side
 half = n // 2
