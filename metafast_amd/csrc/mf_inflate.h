@@ -634,10 +634,70 @@ static bool inflate_parallel(const uint8_t *in, size_t n, size_t d0, int threads
     return true;
 }
 
+// BGZF (bgzip, the blocked gzip of htslib): members of <= 64 KB whose FEXTRA field "BC" says how long each one is -- the members can be
+// counted off by their headers alone and inflate independently, every thread a run of them, each checked against its own CRC-32 and length.
+// false: not (entirely) BGZF, or anything irregular.
+static bool gunzip_bgzf(const uint8_t *in, size_t n, int threads, char **out_p, size_t *out_n) {
+    struct member { size_t at, csize; uint32_t isize; };
+    std::vector<member> ms;
+    size_t pos = 0, total = 0;
+    while (pos < n) {
+        if (n - pos < 28 || in[pos] != 0x1F || in[pos + 1] != 0x8B || in[pos + 2] != 8 || in[pos + 3] != 4) return false;      // FEXTRA and nothing else
+        const size_t xlen = (size_t)in[pos + 10] | ((size_t)in[pos + 11] << 8);
+        if (pos + 12 + xlen + 8 > n) return false;
+        size_t bsize = 0;
+        for (size_t q = pos + 12; q + 4 <= pos + 12 + xlen;) {
+            const size_t sl = (size_t)in[q + 2] | ((size_t)in[q + 3] << 8);
+            if (in[q] == 'B' && in[q + 1] == 'C' && sl == 2 && q + 6 <= pos + 12 + xlen) bsize = ((size_t)in[q + 4] | ((size_t)in[q + 5] << 8)) + 1;
+            q += 4 + sl;
+        }
+        if (bsize < 12 + xlen + 8 + 2 || pos + bsize > n) return false;
+        const uint8_t *tr = in + pos + bsize - 8;
+        const uint32_t isize = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+        if (isize > 65536) return false;
+        ms.push_back(member{pos + 12 + xlen, bsize - 12 - xlen - 8, isize});
+        total += isize; pos += bsize;
+    }
+    if (ms.size() < 2) return false;
+    uint8_t *out = (uint8_t *)malloc(total + 64);
+    if (!out) return false;
+    std::vector<size_t> off(ms.size());
+    { size_t a = 0; for (size_t i = 0; i < ms.size(); i++) { off[i] = a; a += ms[i].isize; } }
+    const size_t T = (size_t)std::max(1, std::min<int>(threads, 64));
+    std::atomic<size_t> next{0};
+    std::atomic<int> bad{0};
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < std::min(T, ms.size() / 64 + 1); t++)
+        th.emplace_back([&]() {
+            out_buf scratch;                                                  // (the decoder writes a little past what it returns: not into a neighbour's place)
+            for (;;) {
+                const size_t i0 = next.fetch_add(64);
+                if (i0 >= ms.size() || bad.load()) break;
+                for (size_t i = i0; i < std::min(ms.size(), i0 + 64); i++) {
+                    const member &m = ms[i];
+                    scratch.n = 0;
+                    size_t q = m.at;
+                    // (the member's stream must end where its trailer begins, and give what the trailer says)
+                    if (!inflate_raw(in, m.at + m.csize, &q, scratch) || q != m.at + m.csize || scratch.n != m.isize) { bad = 1; break; }
+                    const uint8_t *tr = in + m.at + m.csize;
+                    const uint32_t want = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+                    if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), scratch.p, (uInt)scratch.n) != want) { bad = 1; break; }
+                    memcpy(out + off[i], scratch.p, scratch.n);
+                }
+            }
+            free(scratch.p);
+        });
+    for (auto &x : th) x.join();
+    if (bad.load()) { free(out); return false; }
+    *out_p = (char *)out; *out_n = total;
+    return true;
+}
+
 // A file of one or more gzip members, whole in memory with 16 readable bytes behind in + n -> *out_p (malloc), *out_n.  false (nothing
 // allocated is left behind): the caller inflates with zlib instead.
 static bool gunzip(const uint8_t *in, size_t n, int threads, char **out_p, size_t *out_n, size_t parallel_min = (size_t)32 << 20, size_t piece_min = (size_t)2 << 20,
                    bool *went_parallel = nullptr) {
+    if (n >= 28 && in[3] == 4 && gunzip_bgzf(in, n, threads, out_p, out_n)) return true;
     out_buf out;
     if (!out.reserve(std::max<size_t>(n * 5, (size_t)1 << 20))) return false;
     size_t pos = 0;

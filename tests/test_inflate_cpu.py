@@ -191,6 +191,40 @@ def test_one_member_on_several_threads(gunzip):
         assert got is None or got == text
 
 
+def _bgzf(data, level=6, block=0xFF00):
+    out = []
+    for i in list(range(0, len(data), block)) + [None]:                                    # (+ the empty end-of-file block bgzip appends)
+        chunk = b"" if i is None else data[i:i + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out.append(bytes([0x1F, 0x8B, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0]) + b"BC" + (2).to_bytes(2, "little") + (bsize - 1).to_bytes(2, "little") + body +
+                   zlib.crc32(chunk).to_bytes(4, "little") + len(chunk).to_bytes(4, "little"))
+    return b"".join(out)
+
+
+def test_bgzf_members_in_parallel(gunzip):
+    """bgzip's blocked gzip: members of <= 64 KB with their length in the FEXTRA field -- counted off by the headers, inflated side by side"""
+    c = _corpus()
+    for name in ("fastq", "dna", "random", "zeros", "one", "empty"):
+        for level in (1, 6):
+            z = _bgzf(c[name], level)
+            assert gzip.decompress(z) == c[name]
+            assert gunzip(z, 1) == c[name] and gunzip(z, 2) == c[name], (name, level)
+    z = bytearray(_bgzf(c["fastq"], 6))
+    rng = np.random.default_rng(9)
+    for _ in range(60):
+        y = bytearray(z)
+        y[int(rng.integers(0, len(y)))] ^= 1 << int(rng.integers(0, 8))
+        got = gunzip(bytes(y), 1)
+        assert got is None or got == c["fastq"]
+        try:
+            want = gzip.decompress(bytes(y))
+        except Exception:
+            want = None
+        assert gunzip(bytes(y), 2) == want
+
+
 def test_large_member_in_parallel_crc(gunzip):
     rng = np.random.default_rng(11)
     dna = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, 60_000_000)].tobytes()
