@@ -257,6 +257,7 @@ int mf_ensure_pin_pool(mf_ctx *ctx, size_t want);
 // a file's bytes to HBM as they are (pread into staging chunks by several threads + hipMemcpyAsync; mf_dparse.hip): 0 ok, 1 no staging memory, < 0 error
 int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_dst);
 int mf_dparse_file(mf_ctx *ctx, const char *path, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases);
+int mf_dparse_mem(mf_ctx *ctx, const char *path, const void *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases);
 int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, mf_index *out,
                    size_t *bytes);
 int mf_table_ensure_index(mf_table *t);

@@ -539,7 +539,8 @@ int mf_ensure_pin_pool(mf_ctx *ctx, size_t want);
 // (one upload at a time per DEVICE: two contexts of a process that share a device -- the driver's two-contexts-per-device mode -- would halve each
 // other's PCIe rate and finish together; taking turns, the first one is counting and writing while the second one's bytes cross)
 static std::mutex g_upload_mutex[64];
-int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_raw) {
+// mem != nullptr: the bytes come from host memory (an inflated .gz file) instead of the file: the same staging, memcpy for pread
+static int upload_bytes(mf_ctx *ctx, int fd, const uint8_t *mem, size_t fsize, uint8_t *d_raw) {
     std::lock_guard<std::mutex> turn(g_upload_mutex[(unsigned)ctx->device & 63u]);
     const size_t PIECE = (size_t)std::max<int64_t>(ctx->opt_device_parse_piece, 1 << 16);
     const size_t np = (fsize + PIECE - 1) / PIECE;
@@ -575,7 +576,8 @@ int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_raw) {
                 const size_t lo = i * PIECE, len = std::min(PIECE, fsize - lo);
                 if (busy[cur]) { (void)hipEventSynchronize(ev[cur]); busy[cur] = false; }
                 size_t got = 0;
-                while (got < len) { const ssize_t r = pread(fd, pin[cur] + got, len - got, (off_t)(lo + got)); if (r <= 0) break; got += (size_t)r; }
+                if (mem) { memcpy(pin[cur], mem + lo, len); got = len; }
+                else while (got < len) { const ssize_t r = pread(fd, pin[cur] + got, len - got, (off_t)(lo + got)); if (r <= 0) break; got += (size_t)r; }
                 if (got != len) { state = -1; break; }
                 if (hipMemcpyAsync(d_raw + lo, pin[cur], len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipEventRecord(ev[cur], ctx->stream) != hipSuccess) { state = -2; break; }
                 busy[cur] = true;
@@ -589,32 +591,49 @@ int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_raw) {
     return 0;
 }
 
+int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_raw) { return upload_bytes(ctx, fd, nullptr, fsize, d_raw); }
+
 // one FASTA (fmt 1) / FASTQ (fmt 2) file -> (bases, offsets) in HBM.  0 = done, 1 = not a file for the device parser (the caller takes the host
 // parser: nothing was produced), < 0 = error
+// mem != nullptr: the file's content is in host memory already (mem_n bytes: a compressed file the host has inflated); path names it in messages
+static int dparse_source(mf_ctx *ctx, const char *path, const uint8_t *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases);
 int mf_dparse_file(mf_ctx *ctx, const char *path, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases) {
+    return dparse_source(ctx, path, nullptr, 0, fmt, bases, offsets, n_reads, n_bases);
+}
+int mf_dparse_mem(mf_ctx *ctx, const char *path, const void *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases) {
+    if (!mem || !mem_n) return 1;
+    return dparse_source(ctx, path, (const uint8_t *)mem, mem_n, fmt, bases, offsets, n_reads, n_bases);
+}
+static int dparse_source(mf_ctx *ctx, const char *path, const uint8_t *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases) {
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    int fd = open(path, O_RDONLY);
-    if (fd < 0) return mf_set_error("can't open '%s'", path);
-    struct stat sb;
-    if (fstat(fd, &sb) != 0) { close(fd); return mf_set_error("can't stat '%s'", path); }
-    const size_t n = (size_t)sb.st_size;
-    if (n == 0) { close(fd); return 1; }
+    int fd = -1;
+    size_t n = mem_n;
+    if (!mem) {
+        fd = open(path, O_RDONLY);
+        if (fd < 0) return mf_set_error("can't open '%s'", path);
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) { close(fd); return mf_set_error("can't stat '%s'", path); }
+        n = (size_t)sb.st_size;
+    }
+    auto shut = [&]() { if (fd >= 0) close(fd); fd = -1; };
+    if (n == 0) { shut(); return 1; }
     int qoff = 64;
     if (fmt == 2) {                                  // quality offset: the first 1000 records (ReadersUtils.java:63-77), on the host
         std::vector<char> head(std::min<size_t>(n, 4u << 20));
-        if (pread(fd, head.data(), head.size(), 0) != (ssize_t)head.size()) { close(fd); return mf_set_error("short read on '%s'", path); }
+        if (mem) memcpy(head.data(), mem, head.size());
+        else if (pread(fd, head.data(), head.size(), 0) != (ssize_t)head.size()) { shut(); return mf_set_error("short read on '%s'", path); }
         read_batch tmp;
         qoff = parse_fastq_pass(head.data(), head.size(), path, 0, 0, tmp);
-        if (qoff < 0) { close(fd); return 1; }       // (whatever it is: the host parser says it in the reference's words)
+        if (qoff < 0) { shut(); return 1; }           // (whatever it is: the host parser says it in the reference's words)
     }
     MF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint64_t nc = (n + DP_CHUNK - 1) / DP_CHUNK;
     mf_buf<uint8_t> raw;
-    if (raw.alloc(ctx, nc * DP_CHUNK + 64) != MF_OK) { close(fd); return 1; }
-    int rc = mf_upload_file(ctx, fd, n, raw.p);
-    close(fd);
+    if (raw.alloc(ctx, nc * DP_CHUNK + 64) != MF_OK) { shut(); return 1; }
+    int rc = upload_bytes(ctx, fd, mem, n, raw.p);
+    shut();
     if (rc != 0) return rc;
     const double t1 = now();
     mf_buf<unsigned int> flags; MF_TRY(flags.alloc(ctx, 4));

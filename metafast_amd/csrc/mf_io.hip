@@ -238,7 +238,9 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
     // Compressed files (a paired-end library is two .fastq.gz files, a multi-lane one eight): gzip and bzip2 streams inflate on ONE thread each --
     // 0.22 GB/s of FASTA, the whole step (tools/gz_rate.py: kmer-counter 2.87 s where `gzip -dc` alone takes 3.45 s) --, so the files of a library
     // inflate side by side, up to four at a time; they join the pieces in the order of the command line, and so do their errors.
-    struct pre_file { int rc = 1; std::unique_ptr<std::vector<read_batch>> parts; std::string err; };      // rc 1: not read ahead
+    // (round 5: what the host has inflated is FASTA / FASTQ text like any plain file's: it goes up through the staging chunks and the DEVICE parses
+    // it -- mf_dparse_mem --; host parse, pageable copies and the offsets' rebase were 0.7 of a 20 M-read file's 1.85 s)
+    struct pre_file { int rc = 1; std::unique_ptr<std::vector<read_batch>> parts; std::unique_ptr<raw_file> content; int fmt = 0; std::string err; };      // rc 1: not read ahead
     std::vector<pre_file> prep((size_t)std::max(nfiles, 0));
     {
         std::vector<int> comp;
@@ -254,8 +256,8 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
                         const size_t j = next++;
                         if (j >= comp.size()) break;
                         pre_file &P = prep[(size_t)comp[j]];
-                        P.parts = std::make_unique<std::vector<read_batch>>();
-                        const int rc = parse_reads_file(files[comp[j]], per, *P.parts);
+                        P.content = std::make_unique<raw_file>();
+                        const int rc = read_file_content(files[comp[j]], per, *P.content, &P.fmt);
                         if (rc < 0) P.err = mf_last_error();                     // (the message lives in this thread)
                         P.rc = rc < 0 ? rc : 0;
                     }
@@ -295,10 +297,35 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
             }
         }
         auto parts = std::make_unique<std::vector<read_batch>>();
-        if (prep[(size_t)i].rc != 1) {
-            if (prep[(size_t)i].rc < 0) return mf_set_error("%s", prep[(size_t)i].err.c_str());
-            parts = std::move(prep[(size_t)i].parts);
-        } else MF_TRY(parse_reads_file(files[i], ctx->host_threads, *parts));
+        {
+            pre_file &P = prep[(size_t)i];
+            if (P.rc < 0) return mf_set_error("%s", P.err.c_str());
+            if (P.rc == 1) {                                                    // (not read ahead: now)
+                P.content = std::make_unique<raw_file>();
+                const double ta = now();
+                MF_TRY(read_file_content(files[i], ctx->host_threads, *P.content, &P.fmt));
+                if (getenv("MF_IO_TIMING")) fprintf(stderr, "[mf] %s: read %.3f s\n", files[i], now() - ta);
+            }
+            const bool packed = ends_with_nocase(p, ".gz") || ends_with_nocase(p, ".bz2");
+            if (packed && (P.fmt == 1 || P.fmt == 2) && ctx->opt_device_parse && P.content->size() >= (size_t)ctx->opt_device_parse_min) {
+                auto df = std::make_unique<dp_file>();
+                uint64_t r = 0, b = 0;
+                const int rc = mf_dparse_mem(ctx, files[i], P.content->data(), P.content->size(), P.fmt, df->b, df->o, &r, &b);
+                if (rc < 0) return rc;
+                if (rc == 0) {
+                    ctx->n_dparse_files++;
+                    P.content.reset();
+                    if (nfiles == 1) { db.swap(df->b); doff.swap(df->o); *n_reads = r; *n_bases = b; if (t_parse) *t_parse = now() - t0; if (t_h2d) *t_h2d = 0; return MF_OK; }
+                    piece Q; Q.dev = df->b.p; Q.n_bases = b; Q.dev_offsets = df->o.p; Q.n_reads = r;
+                    pieces.push_back(Q);
+                    dparsed.push_back(std::move(df));
+                    continue;
+                }
+                ctx->n_dparse_stepped_back++;
+            }
+            MF_TRY(parse_file_content(*P.content, P.fmt, files[i], ctx->host_threads, *parts));
+            P.content.reset();
+        }
         for (auto &rb : *parts) pieces.push_back(piece{nullptr, rb.bases.data(), rb.bases.size(), &rb.offsets});
         parsed.push_back(std::move(parts));
     }

@@ -475,7 +475,8 @@ static int inflate_bz2(const raw_file &in, raw_file &out, const char *path) {
 }
 // ReadersUtils.detectFileFormat (itmo!/io/ReadersUtils.java:27-54): ".gz" / ".bz2" is stripped first, then the format extension.
 // .binq: the reference's own binary read format, parsed serially.
-static int parse_reads_file(const char *path, int threads, std::vector<read_batch> &parts) {
+// the file's content in memory (compressed files inflated), and its format: 1 FASTA, 2 FASTQ, 3 binq
+static int read_file_content(const char *path, int threads, raw_file &buf, int *fmt_out) {
     std::string p(path);
     int fmt = 0;
     bool gz = false, bz = false;
@@ -485,18 +486,26 @@ static int parse_reads_file(const char *path, int threads, std::vector<read_batc
     else if (ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq")) fmt = 2;
     else if (ends_with_nocase(p, ".fasta") || ends_with_nocase(p, ".fa") || ends_with_nocase(p, ".fn") || ends_with_nocase(p, ".fna")) fmt = 1;
     if (!fmt) return mf_set_error("Can't detect file format for file '%s'", path);
-    raw_file buf;
-    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    const double t0 = now();
+    *fmt_out = fmt;
     if (gz || bz) {
         raw_file packed;
         MF_TRY(read_file_parallel(path, packed, threads));
         MF_TRY(gz ? inflate_gz(packed, buf, path, threads) : inflate_bz2(packed, buf, path));
     } else MF_TRY(read_file_parallel(path, buf, threads));
+    return MF_OK;
+}
+static int parse_file_content(const raw_file &buf, int fmt, const char *path, int threads, std::vector<read_batch> &parts) {
+    if (fmt == 3) { read_batch rb; const int rc = parse_binq(buf.data(), buf.size(), path, rb); if (rc == MF_OK) parts.push_back(std::move(rb)); return rc; }
+    return parse_buffer_parallel(buf, fmt, path, threads, parts);
+}
+static int parse_reads_file(const char *path, int threads, std::vector<read_batch> &parts) {
+    raw_file buf;
+    int fmt = 0;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    MF_TRY(read_file_content(path, threads, buf, &fmt));
     const double t1 = now();
-    int rc;
-    if (fmt == 3) { read_batch rb; rc = parse_binq(buf.data(), buf.size(), path, rb); if (rc == MF_OK) parts.push_back(std::move(rb)); }
-    else rc = parse_buffer_parallel(buf, fmt, path, threads, parts);
+    const int rc = parse_file_content(buf, fmt, path, threads, parts);
     if (getenv("MF_IO_TIMING")) fprintf(stderr, "[mf] %s: read %.3f s, parse %.3f s\n", path, t1 - t0, now() - t1);
     return rc;
 }
