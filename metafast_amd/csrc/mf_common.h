@@ -92,6 +92,8 @@ struct mf_ctx {
     int64_t opt_device_parse_min = 1 << 20;   // ... from this size on (bytes): a small file is not worth the kernels' launches
     int64_t opt_host_pinned = 0;   // staging buffers of the file readers / writers: 1 = hipHostMalloc (0.16 - 0.29 s per GB to get, 0.1 s to give back), 0 = plain host memory (copies to and from it run at the same 56 GB/s on this platform: tools/pin_alloc.hip)
     int64_t opt_file_cache_gb = 0; // > 0: tables / components written to files stay in HBM (up to this many GB) and are handed out when the same file is loaded again
+    int64_t opt_gz_device_min = 32 << 20;   // .fa.gz / .fq.gz files of at least this size are inflated on many threads straight into HBM (mf_dparse_gz); tests: 0
+    int64_t opt_gz_piece = 2 << 20;         // ... in pieces of at least this many compressed bytes (tests: 65536)
     int64_t opt_ut_double_after = 4;   // unitigs: walks still under way after this many chunked rounds (32, 128, 512, 4096 jumps) double the jump words instead (tests: 1)
     int64_t opt_wide_finish = 1;   // mf_count_wide_device: radix passes over the leading 32 bits + the order inside the buckets in LDS (0: radix passes over all 2k bits)
     int64_t opt_wide_big_bucket = 256;   // ... buckets of more entries than this (<= 256) go through the LDS hash table instead of the walk (tests lower it)
@@ -112,7 +114,7 @@ struct mf_ctx {
     size_t arena_bytes = 0;
     // counters a host can read (mf_ctx_stat): counting runs that started their slices over because a buffer found no place (mf_skm.hip);
     // read files the device parser took / handed to the host readers (mf_dparse.hip)
-    uint64_t n_slice_restarts = 0, n_dparse_files = 0, n_dparse_stepped_back = 0, n_wide_big = 0, n_wide_hashed = 0, n_ut_doubled = 0, n_pilots = 0;
+    uint64_t n_slice_restarts = 0, n_dparse_files = 0, n_dparse_stepped_back = 0, n_wide_big = 0, n_wide_hashed = 0, n_ut_doubled = 0, n_pilots = 0, n_gz_device = 0;
     // timers
     std::vector<mf_timer_rec> pending;
     std::vector<hipEvent_t> event_pool;
@@ -257,6 +259,7 @@ int mf_ensure_pin_pool(mf_ctx *ctx, size_t want);
 // a file's bytes to HBM as they are (pread into staging chunks by several threads + hipMemcpyAsync; mf_dparse.hip): 0 ok, 1 no staging memory, < 0 error
 int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_dst);
 int mf_dparse_file(mf_ctx *ctx, const char *path, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases);
+int mf_dparse_gz(mf_ctx *ctx, const char *path, const void *packed, size_t packed_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases);
 int mf_dparse_mem(mf_ctx *ctx, const char *path, const void *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases);
 int mf_index_build(mf_ctx *ctx, const uint64_t *d_keys, const uint16_t *d_vals, uint64_t n, mf_index *out,
                    size_t *bytes);

@@ -181,6 +181,8 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "nbr_global") ctx->opt_nbr_global = v;
     else if (s == "dcc_sparse") ctx->opt_dcc_sparse = v;
     else if (s == "cc_sparse") ctx->opt_cc_sparse = v;
+    else if (s == "gz_device_min_bytes") ctx->opt_gz_device_min = v;
+    else if (s == "gz_piece_bytes") { if (v < 4096) return mf_set_error("gz_piece_bytes must be at least 4096"); ctx->opt_gz_piece = v; }
     else if (s == "ut_double_after") { if (v < 1 || v > 64) return mf_set_error("ut_double_after must be in [1, 64]"); ctx->opt_ut_double_after = v; }
     else if (s == "wide_finish") ctx->opt_wide_finish = v ? 1 : 0;
     else if (s == "wide_big_bucket") { if (v < 1 || v > 256) return mf_set_error("wide_big_bucket must be in [1, 256]"); ctx->opt_wide_big_bucket = v; }
@@ -213,6 +215,7 @@ extern "C" int64_t mf_ctx_stat(mf_ctx *ctx, const char *name) {
     if (!ctx || !name) return mf_set_error("mf_ctx_stat: NULL argument");
     const std::string s(name);
     if (s == "slice_restarts") return (int64_t)ctx->n_slice_restarts;
+    if (s == "gz_files_inflated_into_hbm") return (int64_t)ctx->n_gz_device;
     if (s == "pilot_runs") return (int64_t)ctx->n_pilots;
     if (s == "unitig_doublings") return (int64_t)ctx->n_ut_doubled;
     if (s == "wide_big_entries") return (int64_t)ctx->n_wide_big;

@@ -539,6 +539,19 @@ int mf_ensure_pin_pool(mf_ctx *ctx, size_t want);
 // (one upload at a time per DEVICE: two contexts of a process that share a device -- the driver's two-contexts-per-device mode -- would halve each
 // other's PCIe rate and finish together; taking turns, the first one is counting and writing while the second one's bytes cross)
 static std::mutex g_upload_mutex[64];
+static int ensure_up_pool(mf_ctx *ctx, size_t want) {
+    if (ctx->up_pool_bytes < want) {
+        if (ctx->up_pool) { if (ctx->up_pool_pinned) hipHostFree(ctx->up_pool); else free(ctx->up_pool); ctx->up_pool = nullptr; ctx->up_pool_bytes = 0; }
+        if (hipHostMalloc(&ctx->up_pool, want, hipHostMallocDefault) == hipSuccess) ctx->up_pool_pinned = true;
+        else {
+            (void)hipGetLastError();
+            ctx->up_pool = nullptr; ctx->up_pool_pinned = false;
+            if (posix_memalign(&ctx->up_pool, 2 << 20, want) != 0) { ctx->up_pool = nullptr; return 1; }
+        }
+        ctx->up_pool_bytes = want;
+    }
+    return 0;
+}
 // mem != nullptr: the bytes come from host memory (an inflated .gz file) instead of the file: the same staging, memcpy for pread
 static int upload_bytes(mf_ctx *ctx, int fd, const uint8_t *mem, size_t fsize, uint8_t *d_raw) {
     std::lock_guard<std::mutex> turn(g_upload_mutex[(unsigned)ctx->device & 63u]);
@@ -550,16 +563,7 @@ static int upload_bytes(mf_ctx *ctx, int fd, const uint8_t *mem, size_t fsize, u
     // stages every byte a second time).  128 MB by default: hipHostMalloc takes ~30 ms for them once per context, and a short process -- the
     // drop-in's -- is still ahead (first load of a 3 GB file 0.102 s against 0.116 - 0.135 s with plain chunks of any size: profiles/r05j_upload_rate.txt).
     const size_t want = (size_t)2 * WMAX * PIECE;
-    if (ctx->up_pool_bytes < want) {
-        if (ctx->up_pool) { if (ctx->up_pool_pinned) hipHostFree(ctx->up_pool); else free(ctx->up_pool); ctx->up_pool = nullptr; ctx->up_pool_bytes = 0; }
-        if (hipHostMalloc(&ctx->up_pool, want, hipHostMallocDefault) == hipSuccess) ctx->up_pool_pinned = true;
-        else {
-            (void)hipGetLastError();
-            ctx->up_pool = nullptr; ctx->up_pool_pinned = false;
-            if (posix_memalign(&ctx->up_pool, 2 << 20, want) != 0) { ctx->up_pool = nullptr; return 1; }
-        }
-        ctx->up_pool_bytes = want;
-    }
+    if (ensure_up_pool(ctx, want) != 0) return 1;
     std::atomic<size_t> next{0};
     std::atomic<int> state{0};
     std::vector<std::thread> th;
@@ -593,10 +597,80 @@ static int upload_bytes(mf_ctx *ctx, int fd, const uint8_t *mem, size_t fsize, u
 
 int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_raw) { return upload_bytes(ctx, fd, nullptr, fsize, d_raw); }
 
+// ---- a .gz file: the host inflates it piece by piece (mf_inflate.h, one member on many threads) INTO the pinned staging chunks, and the chunks go
+// up as they fill -- the inflated text is never whole in host memory (first-touch page faults on those gigabytes were a third of the load) and is
+// parsed where it lands.  1: not a file for this way (several members, BGZF, an irregular stream, more text than the buffer was sized for): the
+// caller inflates it on the host.
+static int dparse_source(mf_ctx *ctx, const char *path, const uint8_t *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases,
+                         mf_buf<uint8_t> *filled, int filled_qoff);
+struct dp_gz_sink : mfz::byte_sink {
+    mf_ctx *ctx = nullptr; uint8_t *d_raw = nullptr; size_t cap = 0;
+    std::vector<char> head;                                                    // the first bytes of the text (FASTQ: the quality offset is decided from them)
+    uint8_t *pin[64][2]; hipEvent_t ev[64][2]; bool busy[64][2]; int cur[64];
+    std::atomic<int> failed{0};
+    uint8_t *acquire(int w) override {
+        (void)hipSetDevice(ctx->device);
+        const int c = cur[w];
+        if (busy[w][c]) { (void)hipEventSynchronize(ev[w][c]); busy[w][c] = false; }
+        return pin[w][c];
+    }
+    bool commit(int w, size_t offset, size_t len) override {
+        const int c = cur[w];
+        if (offset + len > cap) return false;
+        if (offset < head.size()) memcpy(head.data() + offset, pin[w][c], std::min(len, head.size() - offset));
+        if (hipMemcpyAsync(d_raw + offset, pin[w][c], len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipEventRecord(ev[w][c], ctx->stream) != hipSuccess) { failed = 1; return false; }
+        busy[w][c] = true;
+        cur[w] = c ^ 1;
+        return true;
+    }
+};
+int mf_dparse_gz(mf_ctx *ctx, const char *path, const void *packed, size_t packed_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases) {
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    MF_HIP(hipSetDevice(ctx->device));
+    size_t fr = 0, tot = 0;
+    MF_HIP(hipMemGetInfo(&fr, &tot));
+    // room for six times the compressed bytes (reads compress three- to fivefold), a quarter of what is free at most
+    size_t cap = std::min<size_t>(packed_n * 6 + ((size_t)64 << 20), (size_t)(((double)fr + (double)mf_arena_idle(ctx)) / 4.0));
+    cap = cap / DP_CHUNK * DP_CHUNK;
+    if (cap < packed_n * 2) return 1;
+    mf_buf<uint8_t> raw;
+    if (raw.alloc(ctx, cap + 64) != MF_OK) return 1;
+    size_t total = 0;
+    dp_gz_sink sink;
+    {
+        std::lock_guard<std::mutex> turn(g_upload_mutex[(unsigned)ctx->device & 63u]);
+        const size_t PIECE = (size_t)std::max<int64_t>(ctx->opt_device_parse_piece, 1 << 16);
+        const size_t W = (size_t)std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ctx->opt_device_parse_threads, 1), std::max(ctx->host_threads, 1)), 64);
+        if (ensure_up_pool(ctx, 2 * W * PIECE) != 0) return 1;
+        sink.ctx = ctx; sink.d_raw = raw.p; sink.cap = cap; sink.workers = (int)W; sink.slot_bytes = PIECE;
+        sink.head.assign((size_t)4 << 20, 0);
+        for (size_t w = 0; w < W; w++)
+            for (int c = 0; c < 2; c++) {
+                sink.pin[w][c] = (uint8_t *)ctx->up_pool + (2 * w + (size_t)c) * PIECE; sink.busy[w][c] = false; sink.cur[w] = 0;
+                (void)hipEventCreateWithFlags(&sink.ev[w][c], hipEventDisableTiming);
+            }
+        const bool ok = mfz::gunzip_to_sink((const uint8_t *)packed, packed_n, ctx->host_threads, &sink, &total, (size_t)ctx->opt_gz_piece);
+        for (size_t w = 0; w < W; w++)
+            for (int c = 0; c < 2; c++) { if (sink.busy[w][c]) (void)hipEventSynchronize(sink.ev[w][c]); (void)hipEventDestroy(sink.ev[w][c]); }
+        if (sink.failed.load()) { (void)hipGetLastError(); return mf_set_error("H2D copy of the inflated reads failed ('%s')", path); }
+        if (!ok || total == 0) return 1;
+    }
+    int qoff = 64;
+    if (fmt == 2) {
+        read_batch tmp;
+        qoff = parse_fastq_pass(sink.head.data(), std::min(total, sink.head.size()), path, 0, 0, tmp);
+        if (qoff < 0) return 1;
+    }
+    if (getenv("MF_IO_TIMING")) fprintf(stderr, "[mf] %s: %.2f GB inflated into HBM (%.2f GB of text) in %.3f s\n", path, packed_n / 1e9, total / 1e9, now() - t0);
+    return dparse_source(ctx, path, nullptr, total, fmt, bases, offsets, n_reads, n_bases, &raw, qoff);
+}
+
 // one FASTA (fmt 1) / FASTQ (fmt 2) file -> (bases, offsets) in HBM.  0 = done, 1 = not a file for the device parser (the caller takes the host
 // parser: nothing was produced), < 0 = error
 // mem != nullptr: the file's content is in host memory already (mem_n bytes: a compressed file the host has inflated); path names it in messages
-static int dparse_source(mf_ctx *ctx, const char *path, const uint8_t *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases);
+static int dparse_source(mf_ctx *ctx, const char *path, const uint8_t *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases,
+                         mf_buf<uint8_t> *filled = nullptr, int filled_qoff = 64);
 int mf_dparse_file(mf_ctx *ctx, const char *path, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases) {
     return dparse_source(ctx, path, nullptr, 0, fmt, bases, offsets, n_reads, n_bases);
 }
@@ -604,12 +678,14 @@ int mf_dparse_mem(mf_ctx *ctx, const char *path, const void *mem, size_t mem_n, 
     if (!mem || !mem_n) return 1;
     return dparse_source(ctx, path, (const uint8_t *)mem, mem_n, fmt, bases, offsets, n_reads, n_bases);
 }
-static int dparse_source(mf_ctx *ctx, const char *path, const uint8_t *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases) {
+// filled: the content is in HBM already (mem_n bytes in *filled, which holds at least the whole chunks they span + 64: a .gz file inflated straight into it)
+static int dparse_source(mf_ctx *ctx, const char *path, const uint8_t *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases,
+                         mf_buf<uint8_t> *filled, int filled_qoff) {
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
     int fd = -1;
     size_t n = mem_n;
-    if (!mem) {
+    if (!mem && !filled) {
         fd = open(path, O_RDONLY);
         if (fd < 0) return mf_set_error("can't open '%s'", path);
         struct stat sb;
@@ -618,8 +694,8 @@ static int dparse_source(mf_ctx *ctx, const char *path, const uint8_t *mem, size
     }
     auto shut = [&]() { if (fd >= 0) close(fd); fd = -1; };
     if (n == 0) { shut(); return 1; }
-    int qoff = 64;
-    if (fmt == 2) {                                  // quality offset: the first 1000 records (ReadersUtils.java:63-77), on the host
+    int qoff = filled ? filled_qoff : 64;
+    if (fmt == 2 && !filled) {                       // quality offset: the first 1000 records (ReadersUtils.java:63-77), on the host
         std::vector<char> head(std::min<size_t>(n, 4u << 20));
         if (mem) memcpy(head.data(), mem, head.size());
         else if (pread(fd, head.data(), head.size(), 0) != (ssize_t)head.size()) { shut(); return mf_set_error("short read on '%s'", path); }
@@ -631,10 +707,13 @@ static int dparse_source(mf_ctx *ctx, const char *path, const uint8_t *mem, size
     hipStream_t st = ctx->stream;
     const uint64_t nc = (n + DP_CHUNK - 1) / DP_CHUNK;
     mf_buf<uint8_t> raw;
-    if (raw.alloc(ctx, nc * DP_CHUNK + 64) != MF_OK) { shut(); return 1; }
-    int rc = upload_bytes(ctx, fd, mem, n, raw.p);
-    shut();
-    if (rc != 0) return rc;
+    if (filled) raw.swap(*filled);
+    else {
+        if (raw.alloc(ctx, nc * DP_CHUNK + 64) != MF_OK) { shut(); return 1; }
+        const int rc = upload_bytes(ctx, fd, mem, n, raw.p);
+        shut();
+        if (rc != 0) return rc;
+    }
     const double t1 = now();
     mf_buf<unsigned int> flags; MF_TRY(flags.alloc(ctx, 4));
     mf_buf<uint64_t> totals; MF_TRY(totals.alloc(ctx, 4));

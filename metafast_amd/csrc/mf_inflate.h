@@ -311,6 +311,15 @@ static uint32_t crc32_parallel(const uint8_t *p, size_t n, int threads) {
 // its CRC-32.  Each piece must END exactly where the next one was found to START, the last block must end at the member's trailer, and CRC-32
 // and length must match: anything else is false, and the caller falls back to one thread.  (pugz, Kerbiriou & Chikhi 2019, is this idea for
 // FASTQ; rapidgzip, Knespel & Brunst 2023, the general form.)  Files of several members (bgzip, `cat a.gz b.gz`) stay on one thread.
+// where the several-thread form may put a member's bytes instead of one host buffer (mf_dparse.hip: pinned staging chunks on their way to HBM --
+// the inflated file is never whole in host memory, and first-touch page faults on it were a third of the time)
+struct byte_sink {
+    int workers = 1;                  // threads that may fill slots at the same time
+    size_t slot_bytes = 0;            // what acquire() gives
+    virtual uint8_t *acquire(int worker) = 0;                                  // a slot to fill (waits until the worker's earlier use of it is over)
+    virtual bool commit(int worker, size_t offset, size_t len) = 0;            // the slot holds bytes [offset, offset + len) of the member
+    virtual ~byte_sink() {}
+};
 struct bitrd {
     const uint8_t *in; size_t n; const uint8_t *p; uint64_t buf; int cnt;
     void seek(size_t bit) { const size_t b = bit >> 3; const int s = (int)(bit & 7); buf = (uint64_t)in[b] >> s; cnt = 8 - s; p = in + b + 1; }
@@ -510,7 +519,8 @@ static bool inflate_piece(const uint8_t *in, size_t n, size_t start, size_t stop
     }
 }
 // a member's raw stream in [d0, n - 8) on `threads` threads, appended to out.  false: one thread has to do it
-static bool inflate_parallel(const uint8_t *in, size_t n, size_t d0, int threads, out_buf &out, uint32_t *crc_out, size_t piece_min) {
+static bool inflate_parallel(const uint8_t *in, size_t n, size_t d0, int threads, out_buf &out, uint32_t *crc_out, size_t piece_min, byte_sink *sink = nullptr,
+                             size_t *sink_total = nullptr) {
     // (not more: every piece in flight holds its output twice over in 16-bit elements, and memory touched for the first time costs more than
     // decoding it -- 0.5 s per GB on this pool's boxes, whatever the number of threads: tools/page_fault_rate.cpp)
     const size_t T = (size_t)std::max(2, std::min(threads, 32));
@@ -595,42 +605,52 @@ static bool inflate_parallel(const uint8_t *in, size_t n, size_t d0, int threads
             window.swap(nw);
             total += M.n; grow += M.n;
         }
-        if (!out.reserve(grow + 64)) return false;
+        if (!sink && !out.reserve(grow + 64)) return false;
         const double t_c = now(); t_win += t_c - t_b;
-        std::vector<uLong> crcs(m, 0);
-        std::vector<char> good(m, 1);
-        {
+        if (sink) {
+            // items: a piece's output in runs of <= slot_bytes, resolved into the sink's slots; CRCs joined in order afterwards
+            struct item { size_t j, q0, len; };
+            std::vector<item> items;
+            for (size_t j = 0; j < m; j++) for (size_t q0 = 0; q0 < mo[j].n; q0 += sink->slot_bytes) items.push_back(item{j, q0, std::min(sink->slot_bytes, mo[j].n - q0)});
+            std::vector<uLong> ic(items.size(), 0);
             std::atomic<size_t> next{0};
+            std::atomic<int> bad{0};
             std::vector<std::thread> th;
-            for (size_t t = 0; t < std::min(T, m); t++)
-                th.emplace_back([&]() {
+            for (int t = 0; t < std::max(1, sink->workers); t++)
+                th.emplace_back([&, t]() {
                     for (;;) {
-                        const size_t j = next++;
-                        if (j >= m) break;
-                        const marked_out &M = mo[j];
-                        uint8_t *dst = out.p + out_start + offs[j];
-                        const uint8_t *W = wins[j].data();
-                        const size_t known = std::min<size_t>(offs[j], 32768);
+                        const size_t a = next++;
+                        if (a >= items.size() || bad.load()) break;
+                        const item &I = items[a];
+                        const marked_out &M = mo[I.j];
+                        uint8_t *dst = sink->acquire(t);
+                        if (!dst) { bad = 1; break; }
+                        const uint8_t *W = wins[I.j].data();
+                        const size_t known = std::min<size_t>(offs[I.j], 32768);
+                        const uint16_t *src = M.p + I.q0;
                         bool g = true;
-                        for (size_t q = 0; q < M.n; q++) {
-                            const uint16_t v = M.p[q];
+                        for (size_t q = 0; q < I.len; q++) {
+                            const uint16_t v = src[q];
                             if (v >= 256) { const uint32_t wp = (uint32_t)v - 256u; if (wp < 32768 - known) { g = false; break; } dst[q] = W[wp]; }
                             else dst[q] = (uint8_t)v;
                         }
-                        good[j] = g ? 1 : 0;
-                        uLong c = crc32(0L, Z_NULL, 0);
-                        for (size_t at = 0; g && at < M.n; at += (size_t)1 << 30) c = crc32(c, dst + at, (uInt)std::min<size_t>(M.n - at, (size_t)1 << 30));
-                        crcs[j] = c;
+                        if (!g) { bad = 1; break; }
+                        ic[a] = crc32(crc32(0L, Z_NULL, 0), dst, (uInt)I.len);
+                        if (!sink->commit(t, offs[I.j] + I.q0, I.len)) { bad = 1; break; }
                     }
                 });
             for (auto &x : th) x.join();
+            if (bad.load()) return false;
+            for (size_t a = 0; a < items.size(); a++) crc = crc32_combine(crc, ic[a], (z_off_t)items[a].len);
+            t_res += now() - t_c;
+            continue;
         }
-        for (size_t j = 0; j < m; j++) { if (!good[j]) return false; crc = crc32_combine(crc, crcs[j], (z_off_t)mo[j].n); }
         out.n += grow;
         t_res += now() - t_c;
     }
     if (dbg) fprintf(stderr, "[mf] inflate: %zu pieces of %zu bytes on %zu threads: block search %.3f s, decoding %.3f s, windows %.3f s, markers + CRC %.3f s\n", np, piece, T, t_find, t_dec, t_win, t_res);
     *crc_out = (uint32_t)crc;
+    if (sink_total) *sink_total = total;
     return true;
 }
 
@@ -690,6 +710,29 @@ static bool gunzip_bgzf(const uint8_t *in, size_t n, int threads, char **out_p, 
     for (auto &x : th) x.join();
     if (bad.load()) { free(out); return false; }
     *out_p = (char *)out; *out_n = total;
+    return true;
+}
+
+// ONE member on several threads straight into a sink: true and *total when all of it went there and CRC-32 and length match; false -- several
+// members, BGZF, anything irregular, a sink that refuses -- when the caller has to take the file some other way (what the sink got is void then)
+static bool gunzip_to_sink(const uint8_t *in, size_t n, int threads, byte_sink *sink, size_t *total, size_t piece_min = (size_t)2 << 20) {
+    if (n < 18 + 8 || in[0] != 0x1F || in[1] != 0x8B || in[2] != 8 || (in[3] & 0xE0)) return false;
+    const uint8_t flg = in[3];
+    size_t q = 10;
+    if (flg & 4) { const size_t xl = (size_t)in[q] | ((size_t)in[q + 1] << 8); q += 2 + xl; }
+    if (flg & 8) { while (q < n && in[q]) q++; q++; }
+    if (flg & 16) { while (q < n && in[q]) q++; q++; }
+    if (flg & 2) q += 2;
+    if (q + 8 >= n) return false;
+    out_buf none;
+    uint32_t crc = 0;
+    size_t tot = 0;
+    if (!inflate_parallel(in, n, q, threads, none, &crc, piece_min, sink, &tot)) return false;
+    const uint8_t *tr = in + n - 8;
+    const uint32_t want_crc = (uint32_t)tr[0] | ((uint32_t)tr[1] << 8) | ((uint32_t)tr[2] << 16) | ((uint32_t)tr[3] << 24);
+    const uint32_t want_len = (uint32_t)tr[4] | ((uint32_t)tr[5] << 8) | ((uint32_t)tr[6] << 16) | ((uint32_t)tr[7] << 24);
+    if ((uint32_t)tot != want_len || crc != want_crc) return false;
+    *total = tot;
     return true;
 }
 

@@ -221,6 +221,16 @@ __global__ void k_offsets_rebase(const uint64_t *__restrict__ in, uint64_t n, ui
     if (i < n) out[i] = in[i] + add;
 }
 // files -> (bases, offsets) in HBM (the layout mf_count_device takes); all files of the call form ONE read set
+// a plain-gzip FASTA / FASTQ file large enough for the several-thread inflater (mf_inflate.h: 32 MB), with the device parser on
+static bool gz_straight_to_device(mf_ctx *ctx, const char *path) {
+    std::string p(path);
+    if (!ctx->opt_device_parse || !ends_with_nocase(p, ".gz")) return false;
+    if (getenv("MF_FAST_INFLATE") && atoi(getenv("MF_FAST_INFLATE")) == 0) return false;
+    p.resize(p.size() - 3);
+    if (!(ends_with_nocase(p, ".fastq") || ends_with_nocase(p, ".fq") || ends_with_nocase(p, ".fasta") || ends_with_nocase(p, ".fa") || ends_with_nocase(p, ".fn") || ends_with_nocase(p, ".fna"))) return false;
+    struct stat st;
+    return stat(path, &st) == 0 && (int64_t)st.st_size >= ctx->opt_gz_device_min;
+}
 static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfiles, mf_buf<uint8_t> &db, mf_buf<uint64_t> &doff,
                                 uint64_t *n_reads, uint64_t *n_bases, double *t_parse, double *t_h2d) {
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -244,7 +254,11 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
     std::vector<pre_file> prep((size_t)std::max(nfiles, 0));
     {
         std::vector<int> comp;
-        for (int i = 0; i < nfiles; i++) { std::string p(files[i]); if (ends_with_nocase(p, ".gz") || ends_with_nocase(p, ".bz2")) comp.push_back(i); }
+        for (int i = 0; i < nfiles; i++) {
+            std::string p(files[i]);
+            if (gz_straight_to_device(ctx, files[i])) continue;                  // (a large .gz file takes every thread by itself, and the one upload path: in its turn below)
+            if (ends_with_nocase(p, ".gz") || ends_with_nocase(p, ".bz2")) comp.push_back(i);
+        }
         if (comp.size() >= 2) {
             std::atomic<size_t> next{0};
             const size_t T = std::min<size_t>(comp.size(), 4);
@@ -300,6 +314,26 @@ static int load_reads_to_device(mf_ctx *ctx, const char *const *files, int nfile
         {
             pre_file &P = prep[(size_t)i];
             if (P.rc < 0) return mf_set_error("%s", P.err.c_str());
+            if (P.rc == 1 && gz_straight_to_device(ctx, files[i])) {
+                // a large .fa.gz / .fq.gz: inflated on many threads into the staging chunks, parsed in HBM (mf_dparse_gz)
+                raw_file packed;
+                MF_TRY(read_file_parallel(files[i], packed, ctx->host_threads));
+                std::string inner(files[i]); inner.resize(inner.size() - 3);
+                const int gfmt = (ends_with_nocase(inner, ".fastq") || ends_with_nocase(inner, ".fq")) ? 2 : 1;
+                auto df = std::make_unique<dp_file>();
+                uint64_t r = 0, b = 0;
+                const int rc = mf_dparse_gz(ctx, files[i], packed.data(), packed.size(), gfmt, df->b, df->o, &r, &b);
+                if (rc < 0) return rc;
+                if (rc == 0) {
+                    ctx->n_dparse_files++; ctx->n_gz_device++;
+                    if (nfiles == 1) { db.swap(df->b); doff.swap(df->o); *n_reads = r; *n_bases = b; if (t_parse) *t_parse = now() - t0; if (t_h2d) *t_h2d = 0; return MF_OK; }
+                    piece Q; Q.dev = df->b.p; Q.n_bases = b; Q.dev_offsets = df->o.p; Q.n_reads = r;
+                    pieces.push_back(Q);
+                    dparsed.push_back(std::move(df));
+                    continue;
+                }
+                // (1: not a file for that way -- the host inflates it below)
+            }
             if (P.rc == 1) {                                                    // (not read ahead: now)
                 P.content = std::make_unique<raw_file>();
                 const double ta = now();

@@ -323,6 +323,47 @@ def _same_reads(ctx, oracle, path):
     return took
 
 
+def test_gz_files_inflate_into_hbm(gpu_ctx, oracle, tmp_path):
+    """Round 5 (mf_inflate.h, mf_dparse_gz): a .fa.gz / .fq.gz file is inflated by the host on many threads -- one gzip member cut into pieces at
+    block starts found by trying bit positions, pieces decoded without their 32 KB of history -- straight into the pinned staging chunks, and the
+    text is parsed in HBM.  With the limits lowered so that files of a few MB go this way (pieces of 64 KB): the oracle's reads, byte for byte;
+    FASTQ with both quality offsets; a file of two members and a BGZF file step back to the host's inflater, a damaged file fails as before."""
+    import gzip, zlib
+    rng = np.random.default_rng(31)
+    al = np.frombuffer(b"ACGT", dtype=np.uint8)
+    n = 40000
+    reads = al[rng.integers(0, 4, (n, 150))]
+    reads[rng.random((n, 150)) < 0.002] = ord("N")
+    fa = b"".join(b">read_%d some text\n" % i + reads[i].tobytes() + b"\n" for i in range(n))
+    files = {"a.fa.gz": gzip.compress(fa, 6), "b.fasta.gz": gzip.compress(fa, 1)}
+    for name, qlo in (("c.fq.gz", 33), ("d.fastq.gz", 64)):
+        q = rng.integers(qlo + 2, qlo + 41, (n, 150), dtype=np.uint8)
+        fq = b"".join(b"@r%d\n" % i + reads[i].tobytes() + b"\n+\n" + q[i].tobytes() + b"\n" for i in range(n))
+        files[name] = gzip.compress(fq, 4)
+    files["two_members.fa.gz"] = gzip.compress(fa[: len(fa) // 2], 6) + gzip.compress(fa[len(fa) // 2:], 6)
+    try:
+        gpu_ctx.set_option("gz_device_min_bytes", 0); gpu_ctx.set_option("gz_piece_bytes", 65536); gpu_ctx.set_option("device_parse_min_bytes", 1)
+        for name, blob in files.items():
+            p = tmp_path / name
+            p.write_bytes(blob)
+            ob, oo = oracle.read_file(str(p))
+            before = gpu_ctx.stat("gz_files_inflated_into_hbm")
+            db, do = gpu_ctx.load_reads([str(p)])
+            assert np.array_equal(do, oo) and np.array_equal(db, ob), name
+            assert gpu_ctx.stat("gz_files_inflated_into_hbm") == before + (0 if name.startswith("two") else 1), name
+        # two files of one library, one of them that way
+        ob1, oo1 = oracle.read_file(str(tmp_path / "a.fa.gz")); ob2, oo2 = oracle.read_file(str(tmp_path / "c.fq.gz"))
+        db, do = gpu_ctx.load_reads([str(tmp_path / "a.fa.gz"), str(tmp_path / "c.fq.gz")])
+        assert np.array_equal(db, np.concatenate([ob1, ob2])) and np.array_equal(do, np.concatenate([oo1, oo2[1:] + oo1[-1]]))
+        bad = bytearray(files["a.fa.gz"]); bad[len(bad) // 2] ^= 0x10
+        (tmp_path / "bad.fa.gz").write_bytes(bytes(bad))
+        from metafast_amd.lib import MetafastError
+        with pytest.raises(MetafastError, match="GZIP|gzip|corrupt"):
+            gpu_ctx.load_reads([str(tmp_path / "bad.fa.gz")])
+    finally:
+        gpu_ctx.set_option("gz_device_min_bytes", 32 << 20); gpu_ctx.set_option("gz_piece_bytes", 2 << 20); gpu_ctx.set_option("device_parse_min_bytes", 1 << 20)
+
+
 def test_device_parser_fasta_and_fastq(gpu_ctx, oracle, tmp_path):
     rng = np.random.default_rng(21)
     gpu_ctx.set_option("profile", 1)
