@@ -641,7 +641,8 @@ int mf_dparse_gz(mf_ctx *ctx, const char *path, const void *packed, size_t packe
     {
         std::lock_guard<std::mutex> turn(g_upload_mutex[(unsigned)ctx->device & 63u]);
         const size_t PIECE = (size_t)std::max<int64_t>(ctx->opt_device_parse_piece, 1 << 16);
-        const size_t W = (size_t)std::min<int64_t>(std::min<int64_t>(std::max<int64_t>(ctx->opt_device_parse_threads, 1), std::max(ctx->host_threads, 1)), 64);
+        // (twice the file uploader's threads: a slot is resolved AND summed -- zlib's crc32, 1.5 GB/s a thread -- before it goes up)
+        const size_t W = (size_t)std::min<int64_t>(std::min<int64_t>(2 * std::max<int64_t>(ctx->opt_device_parse_threads, 1), std::max(ctx->host_threads, 1)), 64);
         if (ensure_up_pool(ctx, 2 * W * PIECE) != 0) return 1;
         sink.ctx = ctx; sink.d_raw = raw.p; sink.cap = cap; sink.workers = (int)W; sink.slot_bytes = PIECE;
         sink.head.assign((size_t)4 << 20, 0);
