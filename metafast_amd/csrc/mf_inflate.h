@@ -645,6 +645,35 @@ static bool inflate_parallel(const uint8_t *in, size_t n, size_t d0, int threads
             t_res += now() - t_c;
             continue;
         }
+        std::vector<uLong> crcs(m, 0);
+        std::vector<char> good(m, 1);
+        {
+            std::atomic<size_t> next{0};
+            std::vector<std::thread> th;
+            for (size_t t = 0; t < std::min(T, m); t++)
+                th.emplace_back([&]() {
+                    for (;;) {
+                        const size_t j = next++;
+                        if (j >= m) break;
+                        const marked_out &M = mo[j];
+                        uint8_t *dst = out.p + out_start + offs[j];
+                        const uint8_t *W = wins[j].data();
+                        const size_t known = std::min<size_t>(offs[j], 32768);
+                        bool g = true;
+                        for (size_t q = 0; q < M.n; q++) {
+                            const uint16_t v = M.p[q];
+                            if (v >= 256) { const uint32_t wp = (uint32_t)v - 256u; if (wp < 32768 - known) { g = false; break; } dst[q] = W[wp]; }
+                            else dst[q] = (uint8_t)v;
+                        }
+                        good[j] = g ? 1 : 0;
+                        uLong c = crc32(0L, Z_NULL, 0);
+                        for (size_t at = 0; g && at < M.n; at += (size_t)1 << 30) c = crc32(c, dst + at, (uInt)std::min<size_t>(M.n - at, (size_t)1 << 30));
+                        crcs[j] = c;
+                    }
+                });
+            for (auto &x : th) x.join();
+        }
+        for (size_t j = 0; j < m; j++) { if (!good[j]) return false; crc = crc32_combine(crc, crcs[j], (z_off_t)mo[j].n); }
         out.n += grow;
         t_res += now() - t_c;
     }
