@@ -1958,6 +1958,9 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
         MF_HIP(hipMemGetInfo(&fr, &tot));
         double budget = (ctx->opt_arena_cap_gb > 0 ? (double)ctx->opt_arena_cap_gb * 1e9 : (double)tot) * 0.22;
         if (ctx->opt_arena_cap_gb <= 0) budget = std::min(budget, ((double)fr + (double)mf_arena_idle(ctx)) * 0.5);      // ... and half of what is free right now
+        // (a small sample -- the drop-in's 20 M reads -- in one batch asked for 12 GB of lists beside 10 GB of records: memory a short process
+        // pays 35 ms per GiB for when the driver has to clear it first; a batch more costs 0.7 ms)
+        if (n_occ < (1ull << 32)) budget = std::min(budget, 3e9);
         while (nbatch < 64 && nbatch * 2 <= np && (double)tall * 10.0 / nbatch > budget) nbatch *= 2;
     }
     const uint32_t PB = (np + nbatch - 1) / nbatch;
