@@ -639,7 +639,8 @@ int mf_dparse_gz(mf_ctx *ctx, const char *path, const void *packed, size_t packe
     size_t total = 0;
     dp_gz_sink sink;
     {
-        std::lock_guard<std::mutex> turn(g_upload_mutex[(unsigned)ctx->device & 63u]);
+        // (no turn-taking with the device's other contexts here, unlike mf_upload_file: the text goes up at the inflater's 4 GB/s, a tenth of what PCIe
+        // carries -- two libraries inflate side by side)
         const size_t PIECE = (size_t)std::max<int64_t>(ctx->opt_device_parse_piece, 1 << 16);
         // (twice the file uploader's threads: a slot is resolved AND summed -- zlib's crc32, 1.5 GB/s a thread -- before it goes up)
         const size_t W = (size_t)std::min<int64_t>(std::min<int64_t>(2 * std::max<int64_t>(ctx->opt_device_parse_threads, 1), std::max(ctx->host_threads, 1)), 64);

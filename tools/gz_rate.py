@@ -48,4 +48,13 @@ p = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-t", "kmer-counter", "-k
 dt = time.perf_counter() - t0
 line = [ln for ln in p.stderr.splitlines() if "count_reads" in ln][-1:] or [p.stderr[-300:]]
 print("two .gz files of one library (the same reads): kmer-counter %.2f s (exit %d)  %s" % (dt, p.returncode, line[0][:200]))
+# the drop-in on two compressed libraries (the two halves as two samples): matrix-builder, every step
+wd = os.path.join(td, "wd_two_libs")
+t0 = time.perf_counter()
+p = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", "31", "-i", fa2[0] + ".gz", fa2[1] + ".gz", "-w", wd, "--separate-libs"] if False else
+                   [os.path.join(ROOT, "metafast.sh"), "-k", "31", "-i", fa2[0] + ".gz", fa2[1] + ".gz", "-w", wd], capture_output=True, text=True, env=dict(os.environ, MF_IO_TIMING="1"))
+dt = time.perf_counter() - t0
+print("metafast.sh -k 31 -i s_1.fa.gz s_2.fa.gz (two libraries of %d reads, matrix-builder): %.2f s (exit %d)" % (half, dt, p.returncode))
+for ln in p.stderr.splitlines():
+    if "inflated into HBM" in ln or "driver:" in ln: print("      " + ln[:200])
 import shutil; shutil.rmtree(td, ignore_errors=True)
