@@ -1075,6 +1075,17 @@ static int write_features_files(const std::vector<int64_t> &vec, const std::vect
 // test hook (not part of the ABI; tests/test_inflate_cpu.py): the image of a gzip file -> its content through the whole-buffer decoder alone (mode 1:
 // MF_ERR where it refuses), through zlib alone (0), in the product's order (2), or through the decoder with the several-thread form forced on small
 // inputs (3: pieces of 48 KB; MF_ERR also where that form steps back to one thread).  *out: malloc'd, mf_debug_free
+// (mode 4: the several-thread form into a byte_sink -- what mf_dparse_gz does with pinned chunks -- here into slots of 64 KB that are copied to their place)
+struct debug_host_sink : mfz::byte_sink {
+    std::vector<std::vector<uint8_t>> slots; std::vector<uint8_t> all; std::mutex m;
+    uint8_t *acquire(int w) override { return slots[(size_t)w].data(); }
+    bool commit(int w, size_t offset, size_t len) override {
+        std::lock_guard<std::mutex> g(m);
+        if (all.size() < offset + len) all.resize(offset + len);
+        memcpy(all.data() + offset, slots[(size_t)w].data(), len);
+        return true;
+    }
+};
 extern "C" int mf_debug_gunzip(const void *in, uint64_t n, int mode, void **out, uint64_t *out_n) {
     if (!out || !out_n || (!in && n)) return mf_set_error("mf_debug_gunzip: NULL argument");
     raw_file packed, plain;
@@ -1083,6 +1094,16 @@ extern "C" int mf_debug_gunzip(const void *in, uint64_t n, int mode, void **out,
     if (n) memcpy(packed.p, in, n);
     memset(packed.p + n, 0, 64);
     int rc = MF_OK;
+    if (mode == 4) {
+        debug_host_sink sink;
+        sink.workers = 3; sink.slot_bytes = (size_t)64 << 10;
+        sink.slots.assign(3, std::vector<uint8_t>(sink.slot_bytes));
+        size_t total = 0;
+        if (!mfz::gunzip_to_sink(reinterpret_cast<const uint8_t *>(packed.p), n, 4, &sink, &total, (size_t)48 << 10)) return mf_set_error("mf_debug_gunzip: not a file for the sink");
+        if (sink.all.size() != total) return mf_set_error("mf_debug_gunzip: the sink got %zu of %zu bytes", sink.all.size(), total);
+        plain.p = (char *)malloc(total ? total : 1); plain.n = total;
+        if (total) memcpy(plain.p, sink.all.data(), total);
+    } else
     if (mode == 1 || mode == 3) {
         char *q = nullptr; size_t m = 0;
         bool par = false;

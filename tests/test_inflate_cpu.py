@@ -179,9 +179,13 @@ def test_one_member_on_several_threads(gunzip):
     for level in (1, 6, 9):
         z = _gz(text, level)
         assert gunzip(z, 3) == text, level
+    # ... and into a sink (mode 4: what mf_dparse_gz does with the pinned staging chunks): slots of 64 KB, three workers
+    for level in (1, 6):
+        assert gunzip(_gz(text, level), 4) == text, level
+    assert gunzip(_gz(c["fastq"], 6), 4) == c["fastq"]
     # several members: not for this form
     z = _gz(text[:2_000_000], 6) + _gz(text[2_000_000:], 6)
-    assert gunzip(z, 3) is None and gunzip(z, 1) == text and gunzip(z, 2) == text
+    assert gunzip(z, 3) is None and gunzip(z, 4) is None and gunzip(z, 1) == text and gunzip(z, 2) == text
     # damaged: never anything but the content or a refusal
     z = bytearray(_gz(text, 6))
     for _ in range(40):
