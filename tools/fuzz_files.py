@@ -65,6 +65,17 @@ while time.time() < t_end:
     assert np.array_equal(go, oo) and np.array_equal(gb, ob), f"it={it} {path}: device parser"
     gk, gc = ctx.count_reads([path], k, ml).export()
     assert np.array_equal(gk, ok) and np.array_equal(gc.astype(np.int32), ov), f"it={it} {path} k={k} min_len={ml} device parser"
+    # the same file gzip-compressed (round 5): inflated by mf_inflate.h -- on several threads in pieces of 16 .. 64 KB where the file gives enough
+    # of them -- into the staging chunks and parsed in HBM (mf_dparse_gz), or from the host buffer (mf_dparse_mem)
+    import gzip as _gzip
+    gzp = path + ".gz"
+    with open(path, "rb") as f, open(gzp, "wb") as g:
+        g.write(_gzip.compress(f.read(), int(rng.choice([1, 6, 9]))))
+    ctx.set_option("gz_device_min_bytes", int(rng.choice([0, 1 << 40]))); ctx.set_option("gz_piece_bytes", int(rng.choice([16384, 65536])))
+    gb, go = ctx.load_reads([gzp])
+    assert np.array_equal(go, oo) and np.array_equal(gb, ob), f"it={it} {gzp}: gz"
+    ctx.set_option("gz_device_min_bytes", 32 << 20); ctx.set_option("gz_piece_bytes", 2 << 20)
+    os.remove(gzp)
     ctx.set_option("device_parse", 0)
     for sr, piece, slack in ((1, int(rng.choice([4096, 8192, 65536])), int(rng.choice([1024, 4096, 32768]))), (0, 8 << 20, 1 << 20)):
         ctx.set_option("stream_reader", sr); ctx.set_option("stream_piece_bytes", piece); ctx.set_option("stream_slack_bytes", slack)
