@@ -234,3 +234,40 @@ def test_large_member_in_parallel_crc(gunzip):
     dna = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, 60_000_000)].tobytes()
     z = _gz(dna, 1)
     assert gunzip(z, 1) == dna
+
+
+def test_decoder_under_asan_ubsan(tmp_path):
+    """tools/inflate_sanitized.cpp: mf_inflate.h alone under AddressSanitizer + UBSan -- one thread and the several-thread form forced with 16 KB
+    pieces -- on valid, bit-flipped, truncated and overwritten gzip / BGZF files: no report, nothing but content or a refusal"""
+    import shutil, subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "inflate_sanitized"
+    r = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-o", str(exe), os.path.join(root, "tools", "inflate_sanitized.cpp"), "-lz", "-lpthread"],
+                       capture_output=True, text=True, cwd=os.path.join(root, "tools"))
+    if r.returncode != 0:
+        pytest.skip("no sanitizer runtime here: " + r.stderr[-200:])
+    rng = np.random.default_rng(17)
+    words = [bytes(rng.integers(97, 123, int(rng.integers(3, 40)), dtype=np.uint8)) for _ in range(800)]
+    text = b" ".join(words[int(i)] for i in rng.integers(0, len(words), 90000))
+    dna = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, 600_000)].tobytes()
+    files = []
+    for name, d in (("text", text), ("dna", dna), ("zero", bytes(300000))):
+        for lvl in (0, 1, 6):
+            for kind, z in (("gz", _gz(d, lvl)), ("bgzf", _bgzf(d, lvl))):
+                for v in range(7):
+                    y = bytearray(z)
+                    if v == 1:
+                        y[int(rng.integers(0, len(y)))] ^= 1 << int(rng.integers(0, 8))
+                    elif v == 2:
+                        del y[int(rng.integers(1, len(y))):]
+                    elif v == 3:
+                        at = int(rng.integers(0, max(1, len(y) - 8))); y[at:at + 6] = bytes(rng.integers(0, 256, 6, dtype=np.uint8))
+                    elif v >= 4:
+                        y[int(rng.integers(10, len(y)))] ^= 1 << int(rng.integers(0, 8))
+                    f = tmp_path / f"{name}_{lvl}_{kind}_{v}.gz"
+                    f.write_bytes(bytes(y)); files.append(str(f))
+    r = subprocess.run([str(exe)] + files, capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and "ERROR" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-2000:]
+    assert "accepted" in r.stdout
