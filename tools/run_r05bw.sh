@@ -1,0 +1,3 @@
+#!/bin/bash
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+MF_GZ_FASTQ=1 timeout -k 5 900 python3 tools/gz_rate.py 20000000 2>&1 | grep "^\.gz\|^plain\|^two\|^metafast\|inflated\|driver" | tail -8
