@@ -34,154 +34,10 @@ void or_free(void *p) { free(p); }
 
 #define SHORT_MAX 32767
 
-/* ------------------------------------------------------------------ */
-/* k-mer arithmetic                                                    */
-/* ------------------------------------------------------------------ */
-
-/* itmo!/utils/KmerUtils.java:12-22 (same bit trick at src/algo/KmerOperations.java:62-72) */
-uint64_t or_revcomp(uint64_t x, int k) {
-    x = ((x & 0x3333333333333333ULL) << 2) | ((x & 0xccccccccccccccccULL) >> 2);
-    x = ((x & 0x0f0f0f0f0f0f0f0fULL) << 4) | ((x & 0xf0f0f0f0f0f0f0f0ULL) >> 4);
-    x = ((x & 0x00ff00ff00ff00ffULL) << 8) | ((x & 0xff00ff00ff00ff00ULL) >> 8);
-    x = ((x & 0x0000ffff0000ffffULL) << 16) | ((x & 0xffff0000ffff0000ULL) >> 16);
-    x = (x << 32) | (x >> 32);
-    x = ~x;
-    return x >> (64 - 2 * k);
-}
-
-/* itmo!/dna/kmers/ShortKmer.java: fw/rc pair */
-typedef struct { uint64_t fw, rc; } skmer;
-
-static inline skmer sk_make(uint64_t kmer, int k) {          /* ShortKmer.java:19-36 */
-    skmer s; s.fw = kmer; s.rc = or_revcomp(kmer, k); return s;
-}
-static inline uint64_t sk_canon(skmer s) {                    /* ShortKmer.java:54-56 toLong */
-    return s.fw < s.rc ? s.fw : s.rc;                         /* k<=31: top bits 0, signed==unsigned */
-}
-static inline void sk_shift_right(skmer *s, int nuc, int k) { /* ShortKmer.java:68-71 */
-    uint64_t mask = (1ULL << (2 * k)) - 1;
-    s->fw = ((s->fw << 2) | (uint64_t)nuc) & mask;
-    s->rc = (s->rc >> 2) | ((uint64_t)(3 - nuc) << (2 * k - 2));
-}
-static inline void sk_shift_left(skmer *s, int nuc, int k) {  /* ShortKmer.java:89-92 */
-    uint64_t mask = (1ULL << (2 * k)) - 1;
-    s->fw = (s->fw >> 2) | ((uint64_t)nuc << (2 * k - 2));
-    s->rc = ((s->rc << 2) | (uint64_t)(3 - nuc)) & mask;
-}
-static inline int sk_nuc_at(skmer s, int i, int k) {          /* ShortKmer.java:58-61 */
-    return (int)((s.fw >> (2 * (k - 1 - i))) & 3);
-}
-uint64_t or_canonical(uint64_t kmer, int k) { return sk_canon(sk_make(kmer, k)); }
-
-/* itmo!/dna/DnaTools.java:31,46-64: A=0 G=1 C=2 T=3 */
-static const char NUC_CHARS[4] = {'A', 'G', 'C', 'T'};
-static inline int nuc_code(int c) {
-    switch (c) {
-    case 'A': case 'a': return 0;
-    case 'G': case 'g': return 1;
-    case 'C': case 'c': return 2;
-    case 'T': case 't': return 3;
-    default: return -1;
-    }
-}
-
-/* ------------------------------------------------------------------ */
-/* map  uint64 -> int64  (open addressing; stands in for                */
-/* BigLong2ShortHashMap / BigLong2LongHashMap; only the key->value      */
-/* function is restated, not the slot order)                            */
-/* ------------------------------------------------------------------ */
-#define EMPTY_KEY UINT64_MAX   /* unreachable: k<=31 keys are < 2^62 */
-
-struct or_table { uint64_t *keys; int64_t *vals; uint64_t cap, size; };
-
-static inline uint64_t mix64(uint64_t h) {
-    h ^= h >> 33; h *= 0xff51afd7ed558ccdULL; h ^= h >> 33; h *= 0xc4ceb9fe1a85ec53ULL; h ^= h >> 33;
-    return h;
-}
-static void table_alloc(or_table *t, uint64_t cap) {
-    t->cap = cap; t->size = 0;
-    t->keys = (uint64_t *)malloc(cap * sizeof(uint64_t));
-    t->vals = (int64_t *)malloc(cap * sizeof(int64_t));
-    for (uint64_t i = 0; i < cap; i++) t->keys[i] = EMPTY_KEY;
-}
-or_table *or_table_new(void) {
-    or_table *t = (or_table *)calloc(1, sizeof *t);
-    table_alloc(t, 1024);
-    return t;
-}
-void or_table_free(or_table *t) { if (t) { free(t->keys); free(t->vals); free(t); } }
-uint64_t or_table_size(const or_table *t) { return t->size; }
-
-static inline uint64_t table_pos(const or_table *t, uint64_t key) {
-    uint64_t m = t->cap - 1, p = mix64(key) & m;
-    while (t->keys[p] != EMPTY_KEY && t->keys[p] != key) p = (p + 1) & m;
-    return p;
-}
-static void table_grow(or_table *t) {
-    or_table old = *t;
-    table_alloc(t, old.cap * 2);
-    for (uint64_t i = 0; i < old.cap; i++)
-        if (old.keys[i] != EMPTY_KEY) {
-            uint64_t p = table_pos(t, old.keys[i]);
-            t->keys[p] = old.keys[i]; t->vals[p] = old.vals[i]; t->size++;
-        }
-    free(old.keys); free(old.vals);
-}
-/* Long2ShortHashMap.get :160-175 -> -1 when absent */
-int64_t or_table_get(const or_table *t, uint64_t key) {
-    uint64_t p = table_pos(t, key);
-    return t->keys[p] == key ? t->vals[p] : -1;
-}
-static void table_put(or_table *t, uint64_t key, int64_t v) {
-    uint64_t p = table_pos(t, key);
-    if (t->keys[p] == key) { t->vals[p] = v; return; }
-    t->keys[p] = key; t->vals[p] = v; t->size++;
-    if (t->size * 4 >= t->cap * 3) table_grow(t);
-}
-/* Long2ShortHashMap.addAndBound :119-157 + NumUtils.addAndBound(short,short) :21-26 */
-static void table_add_bound(or_table *t, uint64_t key, int64_t inc, int64_t bound) {
-    uint64_t p = table_pos(t, key);
-    if (t->keys[p] == key) {
-        int64_t v = t->vals[p];
-        t->vals[p] = (v > bound - inc) ? bound : v + inc;
-        return;
-    }
-    t->keys[p] = key; t->vals[p] = inc > bound ? bound : inc; t->size++;
-    if (t->size * 4 >= t->cap * 3) table_grow(t);
-}
-int or_table_add(or_table *t, uint64_t key, int inc) { table_add_bound(t, key, inc, SHORT_MAX); return 0; }
-
-static or_table *table_clone(const or_table *t) {
-    or_table *c = (or_table *)calloc(1, sizeof *c);
-    c->cap = t->cap; c->size = t->size;
-    c->keys = (uint64_t *)malloc(t->cap * sizeof(uint64_t));
-    c->vals = (int64_t *)malloc(t->cap * sizeof(int64_t));
-    memcpy(c->keys, t->keys, t->cap * sizeof(uint64_t));
-    memcpy(c->vals, t->vals, t->cap * sizeof(int64_t));
-    return c;
-}
-
-typedef struct { uint64_t key; int64_t val; } kv_t;
-static int kv_cmp(const void *a, const void *b) {
-    uint64_t x = ((const kv_t *)a)->key, y = ((const kv_t *)b)->key;
-    return x < y ? -1 : x > y;
-}
-/* all entries with val > threshold, ascending key; caller frees */
-static kv_t *table_sorted(const or_table *t, int64_t threshold, uint64_t *n_out) {
-    kv_t *a = (kv_t *)malloc((t->size + 1) * sizeof(kv_t));
-    uint64_t n = 0;
-    for (uint64_t i = 0; i < t->cap; i++)
-        if (t->keys[i] != EMPTY_KEY && t->vals[i] > threshold) { a[n].key = t->keys[i]; a[n].val = t->vals[i]; n++; }
-    qsort(a, n, sizeof(kv_t), kv_cmp);
-    *n_out = n;
-    return a;
-}
-uint64_t or_table_export(const or_table *t, int threshold, uint64_t *keys, int32_t *vals, uint64_t cap) {
-    uint64_t n; kv_t *a = table_sorted(t, threshold, &n);
-    for (uint64_t i = 0; i < n && i < cap; i++) { keys[i] = a[i].key; vals[i] = (int32_t)a[i].val; }
-    free(a);
-    return n;
-}
+#define OKEY uint64_t
+#define OKEY_BITS 64
+#define OKEY_MAXK 31
+#include "mf_oracle_core.inc"
 
 /* ------------------------------------------------------------------ */
 /* A1 readers                                                          */
@@ -339,34 +195,6 @@ int or_read_file(const char *path, uint8_t **bases, uint64_t **offsets, uint64_t
     return 0;
 }
 
-/* ------------------------------------------------------------------ */
-/* A2-A4 counting                                                      */
-/* ------------------------------------------------------------------ */
-/* ReadsLoadWorker.process (src/io/IOUtils.java:756-768) + ShortKmer.kmersOf (:104-150) */
-int or_count_buffer(or_table *t, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k, int min_len) {
-    if (k < 1 || k > 31) return fail("k must be in [1,31]");   /* KmersCounterMain.java:66-73 */
-    for (uint64_t r = 0; r < n_reads; r++) {
-        const uint8_t *s = bases + offsets[r];
-        uint64_t len = offsets[r + 1] - offsets[r];
-        if ((int64_t)len < (int64_t)min_len) continue;         /* dna.length() >= minDnaLen */
-        if (len < (uint64_t)k) continue;                       /* kmersOf: i=k-1 >= length -> empty */
-        uint64_t fw = 0;
-        for (int i = 0; i < k; i++) {
-            int c = nuc_code(s[i]);
-            if (c < 0) return fail("bad base in buffer");
-            fw = (fw << 2) | (uint64_t)c;
-        }
-        skmer km = sk_make(fw, k);
-        table_add_bound(t, sk_canon(km), 1, SHORT_MAX);
-        for (uint64_t i = (uint64_t)k; i < len; i++) {
-            int c = nuc_code(s[i]);
-            if (c < 0) return fail("bad base in buffer");
-            sk_shift_right(&km, c, k);
-            table_add_bound(t, sk_canon(km), 1, SHORT_MAX);
-        }
-    }
-    return 0;
-}
 /* IOUtils.loadReads :772-803 / run :838-865: files sequentially into one map */
 int or_count_files(or_table *t, const char *const *files, int nfiles, int k, int min_len) {
     for (int f = 0; f < nfiles; f++) {
@@ -431,272 +259,6 @@ int or_load_kmers(or_table *t, const char *const *files, int nfiles, int freq_th
     return 0;
 }
 
-/* ------------------------------------------------------------------ */
-/* A7/A8 unitigs                                                       */
-/* ------------------------------------------------------------------ */
-typedef struct { char *s; uint64_t len; int avg, mn, mx; } seq_t;
-struct or_seqs { seq_t *a; uint64_t n, cap; };
-
-/* HashMapOperations.getLeftNucleotide :13-29 */
-static int get_left(const or_table *t, skmer km, int k, int thr) {
-    int right_nuc = sk_nuc_at(km, k - 1, k), ans = -1;
-    for (int nuc = 0; nuc <= 3; nuc++) {
-        sk_shift_left(&km, nuc, k);
-        uint64_t rep = sk_canon(km);
-        sk_shift_right(&km, right_nuc, k);
-        if (or_table_get(t, rep) > thr) { if (ans > -1) return -2; ans = nuc; }
-    }
-    return ans;
-}
-/* HashMapOperations.getRightNucleotide :31-47 */
-static int get_right(const or_table *t, skmer km, int k, int thr) {
-    int left_nuc = sk_nuc_at(km, 0, k), ans = -1;
-    for (int nuc = 0; nuc <= 3; nuc++) {
-        sk_shift_right(&km, nuc, k);
-        uint64_t rep = sk_canon(km);
-        sk_shift_left(&km, left_nuc, k);
-        if (or_table_get(t, rep) > thr) { if (ans > -1) return -2; ans = nuc; }
-    }
-    return ans;
-}
-static inline int64_t get_with_zero(const or_table *t, uint64_t key) {   /* Long2ShortHashMap.getWithZero :178-183 */
-    int64_t v = or_table_get(t, key); return v == -1 ? 0 : v;
-}
-
-/* AddSequencesShiftingRightTask.processSequence :74-123 */
-/* census of the last or_build_unitigs call (tests: the 0 / 1 / 2-emission rule must be exercised):
- * [0] walks started, [1] walks of at least min_len nucleotides, [2] walks emitted */
-static uint64_t g_census[3];
-void or_unitig_census(uint64_t out[3]) { out[0] = g_census[0]; out[1] = g_census[1]; out[2] = g_census[2]; }
-static void process_sequence(const or_table *t, skmer start, int k, int thr, int min_len, or_table *used, or_seqs *out) {
-    g_census[0]++;
-    int64_t value = get_with_zero(t, sk_canon(start));
-    uint64_t cap = 256, len = 0;
-    char *sb = (char *)malloc(cap);
-    for (int i = 0; i < k; i++) sb[len++] = NUC_CHARS[sk_nuc_at(start, i, k)];   /* startKmer.toString() */
-    int64_t w = value; int mn = (int)value, mx = (int)value;
-    skmer km = start;
-    for (;;) {
-        int rn = get_right(t, km, k, thr);
-        if (rn < 0) break;
-        sk_shift_right(&km, rn, k);
-        int ln = get_left(t, km, k, thr);
-        if (ln < 0) break;                                /* km stays advanced */
-        if (len == cap) { cap *= 2; sb = (char *)realloc(sb, cap); }
-        sb[len++] = NUC_CHARS[rn];
-        value = get_with_zero(t, sk_canon(km));
-        w += value;
-        if (value < mn) mn = (int)value;
-        if (value > mx) mx = (int)value;
-    }
-    if ((int64_t)len >= (int64_t)min_len) {
-        g_census[1]++;
-        uint64_t st = sk_canon(start), en = sk_canon(km);
-        if (st > en) { free(sb); return; }
-        if (st == en) {                                   /* print only one of them */
-            if (or_table_get(used, st) != -1) { free(sb); return; }
-            table_put(used, st, 1);
-        }
-        if (out->n == out->cap) { out->cap = out->cap ? out->cap * 2 : 64; out->a = (seq_t *)realloc(out->a, out->cap * sizeof(seq_t)); }
-        g_census[2]++;
-        seq_t *q = &out->a[out->n++];
-        q->s = sb; q->len = len; q->avg = (int)(w / (int64_t)(len - (uint64_t)k + 1)); q->mn = mn; q->mx = mx;
-        return;
-    }
-    free(sb);
-}
-
-/* SequencesFinders.thresholdStrategy :13-31 + AddSequencesShiftingRightTask.run :40-71 */
-or_seqs *or_build_unitigs(const or_table *t, int k, int thr, int min_len) {
-    g_census[0] = g_census[1] = g_census[2] = 0;
-    or_seqs *out = (or_seqs *)calloc(1, sizeof *out);
-    or_table *used = or_table_new();
-    uint64_t n; kv_t *a = table_sorted(t, thr, &n);       /* value <= freqThreshold -> continue */
-    for (uint64_t i = 0; i < n; i++) {
-        skmer kf = sk_make(a[i].key, k);
-        skmer both[2]; both[0] = kf; both[1] = sk_make(kf.rc, k);   /* {kmerF, kmerF.rc()} */
-        for (int o = 0; o < 2; o++) {
-            skmer km = both[o];
-            int is_left = 0;
-            int nuc = get_left(t, km, k, thr);
-            if (nuc < 0) is_left = 1;
-            else {
-                int right_nuc = sk_nuc_at(km, k - 1, k);
-                sk_shift_left(&km, nuc, k);
-                if (get_right(t, km, k, thr) < 0) is_left = 1;
-                sk_shift_right(&km, right_nuc, k);
-            }
-            if (is_left) process_sequence(t, km, k, thr, min_len, used, out);
-        }
-    }
-    free(a); or_table_free(used);
-    return out;
-}
-void or_seqs_free(or_seqs *s) { if (!s) return; for (uint64_t i = 0; i < s->n; i++) free(s->a[i].s); free(s->a); free(s); }
-uint64_t or_seqs_count(const or_seqs *s) { return s->n; }
-uint64_t or_seqs_total_len(const or_seqs *s) { uint64_t t = 0; for (uint64_t i = 0; i < s->n; i++) t += s->a[i].len; return t; }
-int or_seqs_get(const or_seqs *s, uint64_t i, const char **seq, uint64_t *len, int *avg_w, int *min_w, int *max_w) {
-    if (i >= s->n) return fail("index");
-    *seq = s->a[i].s; *len = s->a[i].len; *avg_w = s->a[i].avg; *min_w = s->a[i].mn; *max_w = s->a[i].mx;
-    return 0;
-}
-/* Sequence.printSequences :26-37; FastaDedicatedWriter.writeData :33-49; TextUtils.printWithLineLimit :35-45 */
-int or_seqs_write_fasta(const or_seqs *s, const char *path) {
-    FILE *f = fopen(path, "w");
-    if (!f) return fail("can't write %s", path);
-    for (uint64_t i = 0; i < s->n; i++) {
-        const seq_t *q = &s->a[i];
-        fprintf(f, ">%llu length=%llu av_weight=%d min_weight=%d max_weight=%d\n",
-                (unsigned long long)(i + 1), (unsigned long long)q->len, q->avg, q->mn, q->mx);
-        uint64_t j = 0;
-        while ((j + 1) * 70 < q->len) { fwrite(q->s + j * 70, 1, 70, f); fputc('\n', f); j++; }
-        fwrite(q->s + j * 70, 1, q->len - j * 70, f); fputc('\n', f);
-    }
-    fclose(f);
-    return 0;
-}
-/* SeqBuilderMain.runImpl :84-98 + dumpStat :170-176 */
-int or_write_distribution(const or_table *t, const char *path) {
-    uint64_t stat[1024]; memset(stat, 0, sizeof stat);
-    for (uint64_t i = 0; i < t->cap; i++)
-        if (t->keys[i] != EMPTY_KEY) { int64_t v = t->vals[i]; if (v >= 1024) v = 1023; if (v >= 0) stat[v]++; }
-    FILE *f = fopen(path, "w");
-    if (!f) return fail("can't write %s", path);
-    for (int i = 1; i < 1024; i++) fprintf(f, "%d %llu\n", i, (unsigned long long)stat[i]);
-    fclose(f);
-    return 0;
-}
-/* ComponentCutterMain.runImpl :81-82 -> IOUtils.loadReads(seq files, k, minLen) */
-int or_count_seqs(or_table *t, const or_seqs *s, int k, int min_len) {
-    for (uint64_t i = 0; i < s->n; i++) {
-        uint64_t off[2] = {0, s->a[i].len};
-        int rc = or_count_buffer(t, (const uint8_t *)s->a[i].s, off, 1, k, min_len);
-        if (rc < 0) return rc;
-    }
-    return 0;
-}
-
-/* ------------------------------------------------------------------ */
-/* A10/A11 components                                                  */
-/* ------------------------------------------------------------------ */
-typedef struct {
-    uint64_t *kmers; uint64_t nk, ck;   /* ConnectedComponent.kmers (null once big) */
-    uint64_t size; int64_t weight; int thr;
-    or_table *next_hm;                  /* ConnectedComponent.nextHM */
-    uint64_t min_key;
-} comp_t;
-struct or_comps { comp_t *a; uint64_t n, cap; };
-
-static void comp_add(comp_t *c, uint64_t kmer, int64_t w) {   /* ConnectedComponent.add :70-74 */
-    if (c->nk == c->ck) { c->ck = c->ck ? c->ck * 2 : 64; c->kmers = (uint64_t *)realloc(c->kmers, c->ck * sizeof(uint64_t)); }
-    c->kmers[c->nk++] = kmer; c->size++; c->weight += w;
-}
-/* KmerOperations.possibleNeighbours :9-26 */
-static void possible_neighbours(uint64_t kmer, int k, uint64_t ans[8]) {
-    skmer go_right = sk_make(kmer, k), go_left = sk_make(kmer, k);
-    sk_shift_right(&go_right, 0, k); ans[0] = sk_canon(go_right);
-    sk_shift_left(&go_left, 0, k);   ans[1] = sk_canon(go_left);
-    for (int nuc = 1; nuc <= 3; nuc++) {
-        /* updateAt(k-1, nuc) / updateAt(0, nuc): ShortKmer.java:94-102 */
-        skmer r = sk_make((go_right.fw & ~3ULL) | (uint64_t)nuc, k);
-        ans[nuc * 2] = sk_canon(r);
-        uint64_t top = 3ULL << (2 * k - 2);
-        skmer l = sk_make((go_left.fw & ~top) | ((uint64_t)nuc << (2 * k - 2)), k);
-        ans[nuc * 2 + 1] = sk_canon(l);
-    }
-}
-/* ComponentsBuilder.bfs :220-270; hm is mutated (visited = negated value) */
-static comp_t bfs(or_table *hm, uint64_t start, int k, int b2, int thr, uint64_t **queue, uint64_t *qcap) {
-    comp_t comp; memset(&comp, 0, sizeof comp);
-    comp.thr = thr;
-    uint64_t qh = 0, qt = 0;
-#define ENQ(x) do { if (qt == *qcap) { *qcap *= 2; *queue = (uint64_t *)realloc(*queue, *qcap * sizeof(uint64_t)); } (*queue)[qt++] = (x); } while (0)
-    ENQ(start);
-    int64_t value = or_table_get(hm, start);
-    table_put(hm, start, -value);
-    comp_add(&comp, start, value);
-    int already_big = 0;
-    while (qh < qt) {
-        uint64_t kmer = (*queue)[qh++];
-        uint64_t nb[8]; possible_neighbours(kmer, k, nb);
-        for (int j = 0; j < 8; j++) {
-            uint64_t nbr = nb[j];
-            value = or_table_get(hm, nbr);
-            if (value > 0) {
-                ENQ(nbr);
-                table_put(hm, nbr, -value);
-                if (!already_big) {
-                    comp_add(&comp, nbr, value);
-                    if (comp.size > (uint64_t)b2) {
-                        already_big = 1;
-                        comp.next_hm = or_table_new();
-                        for (uint64_t q = 0; q < comp.nk; q++) {
-                            int64_t v = -or_table_get(hm, comp.kmers[q]);
-                            if (v >= thr + 1) table_put(comp.next_hm, comp.kmers[q], v);
-                        }
-                        free(comp.kmers); comp.kmers = NULL; comp.nk = comp.ck = 0;
-                    }
-                } else {
-                    if (value >= thr + 1) table_put(comp.next_hm, nbr, value);
-                    comp.size++;
-                }
-            }
-        }
-    }
-#undef ENQ
-    return comp;
-}
-static int u64_cmp(const void *a, const void *b) { uint64_t x = *(const uint64_t *)a, y = *(const uint64_t *)b; return x < y ? -1 : x > y; }
-static void comps_push(or_comps *c, comp_t x) {
-    if (c->n == c->cap) { c->cap = c->cap ? c->cap * 2 : 16; c->a = (comp_t *)realloc(c->a, c->cap * sizeof(comp_t)); }
-    c->a[c->n++] = x;
-}
-/* ConnectedComponent.compareTo :125-136 (+ min k-mer as a deterministic tie-break; the reference
- * leaves ties in discovery order, which is hash/race dependent) */
-static int comp_cmp(const void *pa, const void *pb) {
-    const comp_t *a = (const comp_t *)pa, *b = (const comp_t *)pb;
-    if (a->thr != b->thr) return a->thr < b->thr ? -1 : 1;
-    if (a->weight != b->weight) return a->weight > b->weight ? -1 : 1;
-    if (a->size != b->size) return a->size > b->size ? -1 : 1;
-    return a->min_key < b->min_key ? -1 : a->min_key > b->min_key;
-}
-/* ComponentsBuilder.findAllComponents :198-213 + run :58-153 + Task.run :162-179 */
-or_comps *or_cut_components(const or_table *t, int k, int b1, int b2) {
-    or_comps *ans = (or_comps *)calloc(1, sizeof *ans);
-    uint64_t qcap = 1 << 16; uint64_t *queue = (uint64_t *)malloc(qcap * sizeof(uint64_t));
-    /* work list of (hm, thr): first the whole map at thr=1, then each big component's nextHM at thr+1 */
-    typedef struct { or_table *hm; int thr; } work_t;
-    uint64_t wn = 0, wc = 16; work_t *work = (work_t *)malloc(wc * sizeof(work_t));
-    work[wn].hm = table_clone(t); work[wn].thr = 1; wn++;
-    while (wn) {
-        work_t w = work[--wn];
-        uint64_t n; kv_t *a = table_sorted(w.hm, 0, &n);          /* value > 0 i.e. not processed */
-        for (uint64_t i = 0; i < n; i++) {
-            if (or_table_get(w.hm, a[i].key) <= 0) continue;
-            comp_t c = bfs(w.hm, a[i].key, k, b2, w.thr, &queue, &qcap);
-            if (c.size < (uint64_t)b1) { free(c.kmers); }
-            else if (c.size <= (uint64_t)b2) {
-                qsort(c.kmers, c.nk, sizeof(uint64_t), u64_cmp);
-                c.min_key = c.kmers[0];
-                comps_push(ans, c);
-            } else {
-                if (wn == wc) { wc *= 2; work = (work_t *)realloc(work, wc * sizeof(work_t)); }
-                work[wn].hm = c.next_hm; work[wn].thr = c.thr + 1; wn++;
-            }
-        }
-        free(a); or_table_free(w.hm);
-    }
-    free(work); free(queue);
-    qsort(ans->a, ans->n, sizeof(comp_t), comp_cmp);               /* Collections.sort(ans) :144 */
-    return ans;
-}
-void or_comps_free(or_comps *c) { if (!c) return; for (uint64_t i = 0; i < c->n; i++) free(c->a[i].kmers); free(c->a); free(c); }
-uint64_t or_comps_count(const or_comps *c) { return c->n; }
-int or_comps_get(const or_comps *c, uint64_t i, uint64_t *size, int64_t *weight, int *thr, const uint64_t **kmers) {
-    if (i >= c->n) return fail("index");
-    *size = c->a[i].size; *weight = c->a[i].weight; *thr = c->a[i].thr; *kmers = c->a[i].kmers;
-    return 0;
-}
 /* ConnectedComponent.saveComponents :80-93; ComponentsBuilder.run :146-152 */
 int or_comps_write(const or_comps *c, const char *components_bin, const char *stat_txt) {
     FILE *f = fopen(components_bin, "wb");
@@ -740,78 +302,6 @@ or_comps *or_comps_load(const char *components_bin) {
     return c;
 }
 
-/* ------------------------------------------------------------------ */
-/* A12 features                                                        */
-/* ------------------------------------------------------------------ */
-/* FeaturesCalculatorMain.runImpl :97-103 (hm.put(kmer,0)), :137-162 (resetValues +
- * calculatePresenceForKmers -> KmersPresenceWorker :577-588), buildAndPrintVector :169-236 */
-/* buildAndPrintVector :186-206, the per-component loop: with --selected (:55-57, :113-116) only the k-mers with
- * selected.getWithZero(kmer) > 0 take part -- in the sum, in kmersFound and in kmersCount (0.0 / 0.0 = NaN when none is) */
-static void build_vector(const or_comps *c, const or_table *hm, int threshold, const or_table *selected, int64_t *vec, double *breadth) {
-    for (uint64_t i = 0; i < c->n; i++) {
-        int64_t kmers = 0, cnt = 0, found = 0;
-        for (uint64_t j = 0; j < c->a[i].nk; j++) {
-            if (selected == NULL || get_with_zero(selected, c->a[i].kmers[j]) > 0) {
-                int64_t value = get_with_zero(hm, c->a[i].kmers[j]);
-                if (value > threshold) { kmers += value; found++; }
-                cnt++;
-            }
-        }
-        vec[i] = kmers;
-        if (breadth) breadth[i] = (double)found / (double)cnt;
-    }
-}
-int or_features(const or_comps *c, const or_table *sample, int threshold, int64_t *vec, double *breadth) {
-    return or_features_selected(c, sample, threshold, NULL, vec, breadth);
-}
-int or_features_selected(const or_comps *c, const or_table *sample, int threshold, const or_table *selected, int64_t *vec, double *breadth) {
-    or_table *hm = or_table_new();
-    for (uint64_t i = 0; i < c->n; i++)
-        for (uint64_t j = 0; j < c->a[i].nk; j++) table_put(hm, c->a[i].kmers[j], 0);
-    for (uint64_t i = 0; i < sample->cap; i++)                        /* every record of the .kmers.bin */
-        if (sample->keys[i] != EMPTY_KEY && or_table_get(hm, sample->keys[i]) != -1)
-            table_add_bound(hm, sample->keys[i], sample->vals[i], INT64_MAX);
-    build_vector(c, hm, threshold, selected, vec, breadth);
-    or_table_free(hm);
-    return 0;
-}
-
-/* FeaturesCalculatorMain.runImpl reads branch (:117-131): hm (k-mer -> long, BigLong2LongHashMap: no saturation at 32767)
- * holds the component k-mers; IOUtils.calculatePresenceForReads / ReadsPresenceWorker.process (src/io/IOUtils.java:806-834)
- * adds 1 for every k-mer of every read that is a component k-mer; then buildAndPrintVector as above */
-int or_features_reads(const or_comps *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k, int threshold,
-                      int64_t *vec, double *breadth) {
-    return or_features_reads_selected(c, bases, offsets, n_reads, k, threshold, NULL, vec, breadth);
-}
-int or_features_reads_selected(const or_comps *c, const uint8_t *bases, const uint64_t *offsets, uint64_t n_reads, int k, int threshold,
-                               const or_table *selected, int64_t *vec, double *breadth) {
-    if (k < 1 || k > 31) return fail("k must be in [1,31]");
-    or_table *hm = or_table_new();
-    for (uint64_t i = 0; i < c->n; i++)
-        for (uint64_t j = 0; j < c->a[i].nk; j++) table_put(hm, c->a[i].kmers[j], 0);
-    for (uint64_t r = 0; r < n_reads; r++) {
-        const uint8_t *s = bases + offsets[r];
-        uint64_t len = offsets[r + 1] - offsets[r];
-        if (len < (uint64_t)k) continue;
-        uint64_t fw = 0;
-        for (int i = 0; i < k; i++) {
-            int cc = nuc_code(s[i]);
-            if (cc < 0) { or_table_free(hm); return fail("bad base in buffer"); }
-            fw = (fw << 2) | (uint64_t)cc;
-        }
-        skmer km = sk_make(fw, k);
-        if (or_table_get(hm, sk_canon(km)) != -1) table_add_bound(hm, sk_canon(km), 1, INT64_MAX);
-        for (uint64_t i = (uint64_t)k; i < len; i++) {
-            int cc = nuc_code(s[i]);
-            if (cc < 0) { or_table_free(hm); return fail("bad base in buffer"); }
-            sk_shift_right(&km, cc, k);
-            if (or_table_get(hm, sk_canon(km)) != -1) table_add_bound(hm, sk_canon(km), 1, INT64_MAX);
-        }
-    }
-    build_vector(c, hm, threshold, selected, vec, breadth);
-    or_table_free(hm);
-    return 0;
-}
 
 /* ------------------------------------------------------------------ */
 /* A13 Bray-Curtis                                                     */

@@ -17,9 +17,9 @@ _lib = None
 
 def build(force=False):
     """Compile the oracle with gcc (a few seconds)."""
-    src = os.path.join(_HERE, "mf_oracle.c")
+    srcs = [os.path.join(_HERE, f) for f in ("mf_oracle.c", "mf_oracle_wide.c", "mf_oracle_core.inc", "mf_oracle.h")]
     if (force or not os.path.exists(_LIB_PATH)
-            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+            or os.path.getmtime(_LIB_PATH) < max(os.path.getmtime(f) for f in srcs)):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return _LIB_PATH
 
@@ -75,6 +75,29 @@ def lib():
     sig("or_bray_curtis", i32, vp, i32, i32, vp)
     sig("or_revcomp", u64, u64, i32)
     sig("or_canonical", u64, u64, i32)
+    # NO-REFERENCE EXTENSION, k <= 63 (mf_oracle_wide.c: the core compiled for 128-bit keys)
+    sig("orw_last_error", cp)
+    sig("orw_table_new", vp)
+    sig("orw_table_free", None, vp)
+    sig("orw_table_size", u64, vp)
+    sig("orw_table_export", u64, vp, i32, vp, vp, u64)
+    sig("orw_table_get2", i64, vp, u64, u64)
+    sig("orw_table_add2", i32, vp, u64, u64, i32)
+    sig("orw_count_buffer", i32, vp, vp, vp, u64, i32, i32)
+    sig("orw_build_unitigs", vp, vp, i32, i32, i32)
+    sig("orw_unitig_census", None, pu64)
+    sig("orw_seqs_free", None, vp)
+    sig("orw_seqs_count", u64, vp)
+    sig("orw_seqs_total_len", u64, vp)
+    sig("orw_seqs_get", i32, vp, u64, C.POINTER(vp), pu64, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32))
+    sig("orw_count_seqs", i32, vp, vp, i32, i32)
+    sig("orw_cut_components", vp, vp, i32, i32, i32)
+    sig("orw_comps_free", None, vp)
+    sig("orw_comps_count", u64, vp)
+    sig("orw_comps_get", i32, vp, u64, pu64, C.POINTER(i64), C.POINTER(i32), C.POINTER(vp))
+    sig("orw_features_selected", i32, vp, vp, i32, vp, vp, vp)
+    sig("orw_features_reads_selected", i32, vp, vp, vp, u64, i32, i32, vp, vp, vp)
+    sig("orw_revcomp2", None, u64, u64, i32, pu64)
     sig("or_cpu_baseline_count", u64, vp, vp, u64, i32, i32, pu64)
     sig("or_cpu_baseline_file", i32, cp, i32, i32, i32, cp, pu64, C.POINTER(C.c_double))
     _lib = L
@@ -339,6 +362,178 @@ def count_wide(bases, offsets, k, min_len=0):
     _check(lib().or_count_wide(bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, k, min_len, hi.ctypes.data, lo.ctypes.data,
                                cnt.ctypes.data, cap, C.byref(n), C.byref(n_occ)))
     return hi[:n.value].copy(), lo[:n.value].copy(), cnt[:n.value].copy(), n_occ.value
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# NO-REFERENCE EXTENSION: k <= 63 (oracle/mf_oracle_wide.c = mf_oracle_core.inc compiled for unsigned __int128 keys).
+# A k-mer is a Python int on this side; arrays of k-mers are structured numpy arrays W128 (low word first).
+# ---------------------------------------------------------------------------------------------------------------------
+W128 = np.dtype([("lo", "<u8"), ("hi", "<u8")])
+
+
+def w128_to_ints(a):
+    return [(int(h) << 64) | int(l) for l, h in zip(a["lo"].tolist(), a["hi"].tolist())]
+
+
+def _wcheck(rc):
+    if rc < 0:
+        raise OracleError(lib().orw_last_error().decode())
+
+
+class WTable:
+    """Table with 128-bit keys (any k <= 63)"""
+
+    def __init__(self):
+        self.h = lib().orw_table_new()
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().orw_table_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def count_buffer(self, bases, offsets, k, min_len=0):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        _wcheck(lib().orw_count_buffer(self.h, bases.ctypes.data, offsets.ctypes.data, len(offsets) - 1, k, min_len))
+        return self
+
+    def add(self, key, inc=1):
+        key = int(key)
+        lib().orw_table_add2(self.h, key >> 64, key & 0xFFFFFFFFFFFFFFFF, int(inc))
+
+    def get(self, key):
+        key = int(key)
+        return lib().orw_table_get2(self.h, key >> 64, key & 0xFFFFFFFFFFFFFFFF)
+
+    def __len__(self):
+        return lib().orw_table_size(self.h)
+
+    def export(self, threshold=-(2 ** 31)):
+        """-> (keys W128[n] ascending, vals int32[n]) of entries with value > threshold"""
+        L = lib()
+        n = L.orw_table_export(self.h, threshold, None, None, 0)
+        keys = np.empty(n, dtype=W128)
+        vals = np.empty(n, dtype=np.int32)
+        if n:
+            L.orw_table_export(self.h, threshold, keys.ctypes.data, vals.ctypes.data, n)
+        return keys, vals
+
+    def good(self, b):
+        """the table KmersCounterMain hands on: entries with value > b (IOUtils.printKmers), as a new table"""
+        keys, vals = self.export(b)
+        g = WTable()
+        for (lo, hi), v in zip(keys.tolist(), vals.tolist()):
+            lib().orw_table_add2(g.h, hi, lo, v)
+        return g
+
+    def count_seqs(self, seqs, k, min_len):
+        _wcheck(lib().orw_count_seqs(self.h, seqs.h, k, min_len))
+        return self
+
+
+class WSeqs:
+    def __init__(self, h):
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().orw_seqs_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def __len__(self):
+        return lib().orw_seqs_count(self.h)
+
+    def get(self, i):
+        p = C.c_void_p()
+        n = C.c_uint64()
+        a, mn, mx = C.c_int(), C.c_int(), C.c_int()
+        _wcheck(lib().orw_seqs_get(self.h, i, C.byref(p), C.byref(n), C.byref(a), C.byref(mn), C.byref(mx)))
+        return C.string_at(p, n.value).decode(), a.value, mn.value, mx.value
+
+    def all(self):
+        return [self.get(i) for i in range(len(self))]
+
+
+def wide_build_unitigs(table, k, freq_threshold, min_len):
+    return WSeqs(lib().orw_build_unitigs(table.h, k, freq_threshold, min_len))
+
+
+def wide_unitig_census():
+    c = (C.c_uint64 * 3)()
+    lib().orw_unitig_census(c)
+    return int(c[0]), int(c[1]), int(c[2])
+
+
+class WComps:
+    def __init__(self, h):
+        if not h:
+            raise OracleError(lib().orw_last_error().decode())
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().orw_comps_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def __len__(self):
+        return lib().orw_comps_count(self.h)
+
+    def get(self, i):
+        """-> (size, weight, thr, kmers W128[] ascending)"""
+        sz, w, t, p = C.c_uint64(), C.c_int64(), C.c_int(), C.c_void_p()
+        _wcheck(lib().orw_comps_get(self.h, i, C.byref(sz), C.byref(w), C.byref(t), C.byref(p)))
+        n = sz.value
+        km = np.frombuffer(C.string_at(p, 16 * n), dtype=W128).copy() if n else np.empty(0, W128)
+        return n, w.value, t.value, km
+
+    def all(self):
+        return [self.get(i) for i in range(len(self))]
+
+    def features(self, sample_table, threshold=0, selected=None):
+        n = len(self)
+        vec = np.zeros(n, dtype=np.int64)
+        br = np.zeros(n, dtype=np.float64)
+        _wcheck(lib().orw_features_selected(self.h, sample_table.h, threshold, selected.h if selected is not None else None,
+                                            vec.ctypes.data, br.ctypes.data))
+        return vec, br
+
+
+def wide_cut_components(table, k, b1, b2):
+    return WComps(lib().orw_cut_components(table.h, k, b1, b2))
+
+
+def wide_revcomp(kmer, k):
+    kmer = int(kmer)
+    out = (C.c_uint64 * 2)()
+    lib().orw_revcomp2(kmer >> 64, kmer & 0xFFFFFFFFFFFFFFFF, k, out)
+    return (int(out[1]) << 64) | int(out[0])
+
+
+def run_pipeline_wide(samples, k, b=1, l=100, b1=1000, b2=10000):
+    """run_pipeline on reads in memory with 128-bit keys (any k <= 63): samples = list of (bases, offsets).
+    The steps of DistanceMatrixBuilderMain.java:88-175 exactly as run_pipeline wires them."""
+    out = []
+    for bases, offsets in samples:
+        t = WTable().count_buffer(bases, offsets, k, 0)
+        good = t.good(b)
+        seqs = wide_build_unitigs(good, k, b, l)
+        out.append(dict(table=t, good=good, seqs=seqs, n_distinct=len(t), n_good=len(good)))
+    cutter = WTable()
+    for s in out:
+        cutter.count_seqs(s["seqs"], k, l)
+    comps = wide_cut_components(cutter, k, b1, b2)
+    vecs = np.array([comps.features(s["good"], 0)[0] for s in out], dtype=np.int64).reshape(len(out), len(comps))
+    mat = bray_curtis(vecs) if len(comps) else None
+    return dict(samples=out, cutter=cutter, comps=comps, vecs=vecs, matrix=mat)
 
 
 def revcomp(kmer, k):
