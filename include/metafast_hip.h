@@ -177,6 +177,30 @@ int  mf_wtable_export(const mf_wtable *t, uint64_t *keys_hi, uint64_t *keys_lo, 
  * piece i: device pointers to its high words, low words (uint64) and counts (uint16), *n entries.  Valid until mf_wtable_destroy. */
 int  mf_wtable_pieces(const mf_wtable *t, uint32_t *n_pieces);
 int  mf_wtable_piece_view(const mf_wtable *t, uint32_t i, const void **d_keys_hi, const void **d_keys_lo, const void **d_counts, uint64_t *n);
+/* ... "counted + graphed" for 32 <= k <= 63 (round 6; mf_wgraph.hip): the rest of the path on 2k-bit k-mers, same definitions as for
+ * k <= 31 (the entry points named in brackets), checked against oracle/mf_oracle_wide.c = the pinned oracle's text compiled for 128-bit
+ * keys.  A wide table is ascending, so a k-mer's place in it is a 32-bit vertex id that orders like the k-mer: only the neighbour
+ * look-up sees 128-bit keys, everything after it is the k <= 31 machinery on ids. */
+/* [mf_count_device_above] the count with the cut count > threshold inside the pass; *n_distinct_all (may be NULL) = distinct k-mers before it */
+int  mf_count_wide_device_above(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t n_bases, int k,
+                                int min_read_len, int threshold, mf_wtable **out, uint64_t *n_distinct_all);
+/* [mf_table_filter] the entries with count > threshold as a new table */
+int  mf_wtable_filter(const mf_wtable *t, int threshold, mf_wtable **out);
+/* [mf_table_drop_index] */
+int  mf_wtable_drop_index(mf_wtable *t);
+/* [mf_build_unitigs_device] src/algo/AddSequencesShiftingRightTask.java:40-123 on 2k-bit k-mers; the result is an ordinary mf_seqs */
+int  mf_build_unitigs_wide_device(mf_ctx *ctx, mf_wtable *t, int freq_threshold, int min_len, mf_seqs **out);
+/* [mf_cut_components_device] src/algo/ComponentsBuilder.java:58-270; the cutter table = mf_count_wide_device over the unitigs with
+ * min_read_len = l.  Components ordered as for k <= 31 (thr asc, weight desc, size desc, smallest k-mer asc), k-mers ascending inside */
+typedef struct mf_wcomps mf_wcomps;
+int  mf_cut_components_wide_device(mf_ctx *ctx, mf_wtable *cutter, int b1, int b2, mf_wcomps **out);
+void mf_wcomps_destroy(mf_wcomps *c);
+int  mf_wcomps_stats(const mf_wcomps *c, uint64_t *n_comp, uint64_t *n_kmers);
+/* sizes[n], weights[n], thr[n], kmer_offsets[n + 1], the k-mers' high and low words [n_kmers]; any array may be NULL */
+int  mf_wcomps_export(const mf_wcomps *c, uint64_t *sizes, int64_t *weights, int32_t *thr, uint64_t *kmer_offsets, uint64_t *kmers_hi,
+                      uint64_t *kmers_lo);
+/* [mf_features_device] vec[c] = sum of the sample's counts > threshold over the component's k-mers, breadth[c] = found / size */
+int  mf_features_wide_device(mf_ctx *ctx, mf_wcomps *c, mf_wtable *sample, int threshold, int64_t *vec, double *breadth);
 
 /* ---- A5/A6  .kmers.bin / .stat.txt --------------------------------------------------- */
 /* replaces IOUtils.printKmers (src/io/IOUtils.java:45-71; KmersCounterMain.java:99): 10-byte

@@ -17,6 +17,7 @@
 // are disconnected, so splitting them together is the same as the reference's per-component Tasks.
 #include "mf_common.h"
 #include "mf_nbr.h"
+#include "mf_cc.h"
 #include <algorithm>
 #include <numeric>
 #include <memory>
@@ -345,7 +346,7 @@ __global__ void k_cc_members(uint8_t *__restrict__ alive, const uint32_t *__rest
         if (s > b2) { if ((uint32_t)vals[v] < next_thr) alive[v] = 0; else stays = true; }
         else {
             alive[v] = 0;
-            if (s >= b1) { put = true; slot = keptslot[r]; key = keys[v]; }
+            if (s >= b1) { put = true; slot = keptslot[r]; key = keys ? keys[v] : v; }      // (keys == nullptr: an ascending table, the vertex id stands for the k-mer)
         }
     }
     {
@@ -507,14 +508,9 @@ int mf_comps_materialize(mf_comps *C) {
     return MF_OK;
 }
 
-extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2, mf_comps **out) {
-    mf_range rng_("mf:components");
-    if (!ctx || !t || !out) return mf_set_error("mf_cut_components_device: NULL argument");
-    *out = nullptr;
-    MF_HIP(hipSetDevice(ctx->device));
+int mf_cc_build(mf_ctx *ctx, uint64_t n, int k, const uint16_t *d_counts, const uint64_t *d_keys, int b1, int b2,
+                const std::function<int(uint32_t *)> &adjacency, mf_comps **out) {
     hipStream_t st = ctx->stream;
-    const uint64_t n = t->n;
-    const int k = t->k;
     if (n >= 0xFFFFFFFFull) return mf_set_error("components: more than 2^32 vertices is not supported");
     if (b1 < 0) b1 = 0;
     struct rec { uint64_t size; int64_t weight; int32_t thr; uint64_t minkey; uint32_t temp; };
@@ -523,7 +519,6 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
     std::vector<std::unique_ptr<level_buf>> levels;
     uint64_t total_k = 0;
     if (n) {
-        MF_TRY(mf_table_ensure_index(t));
         mf_buf<uint32_t> nbr, parent, root, csize, keptslot, slot_fill, k_root, k_size; mf_buf<unsigned long long> cweight, k_weight, k_minkey;
         mf_buf<uint8_t> alive; mf_buf<unsigned int> counters; mf_buf<uint64_t> slot_off, tot;
         const uint64_t max_kept = n / (uint64_t)std::max(b1, 1) + 1;
@@ -539,21 +534,7 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
         cc_kept_arrays K; K.root = k_root.p; K.size = k_size.p; K.weight = k_weight.p; K.minkey = k_minkey.p;
         {
             mf_ktimer tm(ctx, "k_cc_adjacency");
-            if (t->index.skm_k && t->index.part_bits && t->d_part_off && !ctx->opt_nbr_global && (n >> t->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
-                const uint32_t np = 1u << t->part_bits;
-                const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
-                const unsigned grid2 = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16);
-#define CC_ADJ_K(KK) case KK: k_cc_adjacency_part<1, KK><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p); \
-                              k_cc_adjacency_part<2, KK><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p); break;
-                switch (k) {                                                    // (k as a compile-time constant: see k_ut_flags_part's dispatch, mf_unitig.hip)
-                    CC_ADJ_K(21) CC_ADJ_K(23) CC_ADJ_K(25) CC_ADJ_K(27) CC_ADJ_K(29) CC_ADJ_K(31)
-                    default:
-                        k_cc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
-                        k_cc_adjacency_part<2><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr.p);
-                }
-#undef CC_ADJ_K
-            } else
-            k_cc_adjacency<<<cgrid(n), 256, 0, st>>>(mf_view(t->index), t->d_keys, n, k, nbr.p);
+            MF_TRY(adjacency(nbr.p));
         }
         MF_HIP(hipMemsetAsync(alive.p, 1, n, st));
         // the survivors of a level, listed for the next one (sparse levels: see k_ccs_init); [cur] is read, [cur ^ 1] written
@@ -579,8 +560,8 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             }
             {
                 mf_ktimer tm(ctx, "k_cc_stats");
-                if (sparse) { if (m) k_ccs_stats<<<cgrid(m), 256, 0, st>>>(L, m, parent.p, root.p, t->d_counts, csize.p, cweight.p); }
-                else k_cc_flatten_stats<<<cgrid(n, CC_TILE), 256, 0, st>>>(alive.p, parent.p, root.p, t->d_counts, csize.p, cweight.p, n);
+                if (sparse) { if (m) k_ccs_stats<<<cgrid(m), 256, 0, st>>>(L, m, parent.p, root.p, d_counts, csize.p, cweight.p); }
+                else k_cc_flatten_stats<<<cgrid(n, CC_TILE), 256, 0, st>>>(alive.p, parent.p, root.p, d_counts, csize.p, cweight.p, n);
                 if (span) k_cc_classify<<<cgrid(span), 256, 0, st>>>(alive.p, root.p, csize.p, cweight.p, span, (uint32_t)b1, (uint32_t)b2, keptslot.p, K, counters.p, L);
             }
             unsigned int cnt[4];
@@ -605,7 +586,7 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
             {
                 mf_ktimer tm(ctx, "k_cc_members");
                 // (a dense level writes the list as far as it has room and counts the survivors: the list stands if they all fitted)
-                if (span) k_cc_members<<<cgrid(span), 256, 0, st>>>(alive.p, root.p, csize.p, t->d_counts, t->d_keys, span, (uint32_t)b1, (uint32_t)b2,
+                if (span) k_cc_members<<<cgrid(span), 256, 0, st>>>(alive.p, root.p, csize.p, d_counts, d_keys, span, (uint32_t)b1, (uint32_t)b2,
                                                                     (uint32_t)(thr + 1), keptslot.p, slot_off.p, slot_fill.p, (uint32_t)recs.size(),
                                                                     k_minkey.p, lv->members.p, lv->comp.p, &counters.p[3], L, NL, (uint32_t)std::min<uint64_t>(sparse ? m : lcap, 0xFFFFFFFFull));
             }
@@ -671,6 +652,38 @@ extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2
     if (rc < 0) { mf_comps_destroy(C); return rc; }
     *out = C;
     return MF_OK;
+}
+
+extern "C" int mf_cut_components_device(mf_ctx *ctx, mf_table *t, int b1, int b2, mf_comps **out) {
+    mf_range rng_("mf:components");
+    if (!ctx || !t || !out) return mf_set_error("mf_cut_components_device: NULL argument");
+    *out = nullptr;
+    MF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t n = t->n;
+    const int k = t->k;
+    if (n >= 0xFFFFFFFFull) return mf_set_error("components: more than 2^32 vertices is not supported");
+    if (n) MF_TRY(mf_table_ensure_index(t));
+    return mf_cc_build(ctx, n, k, t->d_counts, t->d_keys, b1, b2, [&](uint32_t *nbr) -> int {
+        {
+            if (t->index.skm_k && t->index.part_bits && t->d_part_off && !ctx->opt_nbr_global && (n >> t->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
+                const uint32_t np = 1u << t->part_bits;
+                const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
+                const unsigned grid2 = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16);
+#define CC_ADJ_K(KK) case KK: k_cc_adjacency_part<1, KK><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr); \
+                              k_cc_adjacency_part<2, KK><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr); break;
+                switch (k) {                                                    // (k as a compile-time constant: see k_ut_flags_part's dispatch, mf_unitig.hip)
+                    CC_ADJ_K(21) CC_ADJ_K(23) CC_ADJ_K(25) CC_ADJ_K(27) CC_ADJ_K(29) CC_ADJ_K(31)
+                    default:
+                        k_cc_adjacency_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr);
+                        k_cc_adjacency_part<2><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(t->index), t->d_keys, t->d_part_off, np, k, nbr);
+                }
+#undef CC_ADJ_K
+            } else
+            k_cc_adjacency<<<cgrid(n), 256, 0, st>>>(mf_view(t->index), t->d_keys, n, k, nbr);
+        }
+        return MF_OK;
+    }, out);
 }
 
 extern "C" void mf_comps_destroy(mf_comps *c) {

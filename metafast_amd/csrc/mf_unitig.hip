@@ -25,6 +25,8 @@
 // Isolated cycles have no start node and are never emitted (same as the reference).
 #include "mf_common.h"
 #include "mf_nbr.h"
+#include "mf_unitig.h"
+#include "mf_wide.h"
 #include <algorithm>
 #include <numeric>
 
@@ -33,17 +35,6 @@
 #define UT_CODE_NONE 4u
 #define UT_CODE_MANY 5u
 #define UT_WALK_CHUNK 4096
-
-struct ut_arrays {
-    const uint64_t *gk; const uint16_t *gv; uint64_t n; int k;
-    uint8_t *info; uint32_t *ridx; uint32_t *lidx;
-    uint8_t *pal;             // even k only: 1 if the k-mer equals its reverse complement (else nullptr)
-    uint64_t *node;           // per oriented node: successor on its path (low 32 bits, UT_NONE = none) | count << 32 |
-                              // last base of the oriented k-mer << 48: everything a walk needs per hop in ONE 8-byte load
-    const uint64_t *jump;     // per oriented node: where its chain leaves the node's partition + hops (k_ut_contract)
-    uint32_t *starts;         // compacted list of start nodes
-    unsigned int *n_starts;
-};
 
 __global__ void k_ut_flags(mf_index_view ix, ut_arrays A) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -135,6 +126,7 @@ __device__ __forceinline__ uint32_t ut_left_node(const ut_arrays &A, uint32_t i,
 // One thread per K-MER, both of its oriented nodes: the successor of x and the predecessor of rc(x) are the same table entry, so the two
 // nodes want the same two info bytes of other k-mers -- the kernel's uncoalesced reads, and what bounds it (a thread per node read
 // each of them twice: 8.5 ms; the pair of node words is one 16-byte store).
+template <bool W>
 __global__ __launch_bounds__(1024) void k_ut_links(ut_arrays A) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool st0 = false, st1 = false;
@@ -163,7 +155,9 @@ __global__ __launch_bounds__(1024) void k_ut_links(ut_arrays A) {
         const uint64_t x = A.gk[i];
         const uint64_t cnt = (uint64_t)A.gv[i] << 32;
         const uint64_t w0 = (uint64_t)succ0 | cnt | ((x & 3ull) << 48);
-        const uint64_t w1 = (uint64_t)succ1 | cnt | ((uint64_t)(3u - (uint32_t)((x >> (2 * A.k - 2)) & 3ull)) << 48);
+        const int fsh = 2 * A.k - 2;                         // the first base: bits [2k - 2, 2k) (W: in the high word from k = 33 on)
+        const uint32_t first = W ? (uint32_t)((fsh >= 64 ? A.ghi[i] >> (fsh - 64) : x >> fsh) & 3ull) : (uint32_t)((x >> fsh) & 3ull);
+        const uint64_t w1 = (uint64_t)succ1 | cnt | ((uint64_t)(3u - first) << 48);
         *reinterpret_cast<ulonglong2 *>(&A.node[2 * i]) = make_ulonglong2(w0, w1);
     }
     // block-aggregated append of the start nodes: ONE global atomic per 1024-thread workgroup (a per-wave atomic on the
@@ -340,7 +334,7 @@ struct ut_paths {
     uint64_t *pkey;       // [n_paths] canonical start k-mer * 2 + strand
     unsigned int *cursor;
 };
-template <int PASS>
+template <int PASS, bool W>
 __global__ void k_ut_ends(ut_arrays A, ut_paths P, const uint32_t *__restrict__ end_node, const uint32_t *__restrict__ end_dist,
                           uint32_t n_starts, int min_len) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -355,9 +349,10 @@ __global__ void k_ut_ends(ut_arrays A, ut_paths P, const uint32_t *__restrict__ 
     uint8_t info = A.info[i];
     // end k-mer: the walk stops either because R(f) < 0 (cur = f) or because the k-mer beyond f has
     // several left neighbours (cur = that k-mer): processSequence :83-92
-    uint64_t endc = A.gk[i];
-    if (ut_r_unique(info, o)) endc = A.gk[ut_right_node(A, i, o, info) >> 1];
-    stc = A.gk[s >> 1];
+    // (W: the table is ascending, a k-mer's index compares and orders like the k-mer itself)
+    uint64_t endc = W ? (uint64_t)i : A.gk[i];
+    if (ut_r_unique(info, o)) { const uint32_t e = ut_right_node(A, i, o, info) >> 1; endc = W ? (uint64_t)e : A.gk[e]; }
+    stc = W ? (uint64_t)(s >> 1) : A.gk[s >> 1];
     if (stc > endc) break;
     eq = stc == endc;
     // task.run :50-51 processes {kmerF, kmerF.rc()}: for a palindromic start k-mer these are the same oriented k-mer, so
@@ -452,6 +447,7 @@ __global__ void k_utd_max(const uint32_t *__restrict__ v, uint32_t n, unsigned i
     for (int d = 32; d; d >>= 1) { const uint32_t y = __shfl_xor(x, d); x = y > x ? y : x; }
     if ((threadIdx.x & 63u) == 0 && x) atomicMax(out, x);
 }
+template <bool W>
 __global__ void k_ut_walk2(ut_arrays A, const ut_seg *__restrict__ seg, uint64_t n_seg, ut_out O, unsigned long long *__restrict__ wsum) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_seg) return;
@@ -462,9 +458,15 @@ __global__ void k_ut_walk2(ut_arrays A, const ut_seg *__restrict__ seg, uint64_t
     const char *NUC = "AGCT";
     uint32_t f = sg.node, d = sg.dist;
     if (d == 0) {                                              // the first k-mer in full
+        if (W) {
+            const mf_u128 x = ((mf_u128)A.ghi[f >> 1] << 64) | (mf_u128)A.gk[f >> 1];
+            const mf_u128 y = (f & 1u) ? mf_wrevcomp(x, k) : x;
+            for (int j = 0; j < k - 1; j++) O.bases[base + j] = (uint8_t)NUC[(uint32_t)(y >> (2 * (k - 1 - j))) & 3u];
+        } else {
         const uint64_t x = A.gk[f >> 1];
         const uint64_t y = (f & 1u) ? mf_revcomp(x, k) : x;
         for (int j = 0; j < k - 1; j++) O.bases[base + j] = (uint8_t)NUC[(y >> (2 * (k - 1 - j))) & 3u];
+        }
     }
     // one base per hop: collected in a register and written as aligned 8-byte words (a byte store per hop is one
     // partial-line write per hop); a word is stored whole only when all its eight bytes are this segment's
@@ -511,19 +513,10 @@ __global__ void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
 
 static inline unsigned grid_for(uint64_t n, unsigned bs = 256) { return (unsigned)((n + bs - 1) / bs); }
 
-extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_threshold, int min_len, mf_seqs **out) {
-    mf_range rng_("mf:unitigs");
-    if (!ctx || !t || !out) return mf_set_error("mf_build_unitigs_device: NULL argument");
-    *out = nullptr;
-    MF_HIP(hipSetDevice(ctx->device));
+int mf_ut_build(mf_ctx *ctx, const uint64_t *gk, const uint64_t *ghi, const uint16_t *gv, uint64_t n, int k, int part_bits, const uint64_t *d_part_off,
+                int min_len, const std::function<int(const ut_arrays &)> &flags, mf_seqs **out) {
     hipStream_t st = ctx->stream;
-    const int k = t->k;
-
-    // nodes = k-mers with value > freqThreshold (task.run :46-48)
-    mf_table *g = nullptr;
-    MF_TRY(mf_table_filter_or_alias(t, freq_threshold, &g));
-    struct guard { mf_table *p; ~guard() { mf_table_destroy(p); } } gg{g};
-    const uint64_t n = g->n;
+    const bool wide = ghi != nullptr;
     mf_seqs *S = new mf_seqs();
     S->ctx = ctx; S->k = k;
     if (n == 0) {
@@ -537,65 +530,34 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
     if (n >= 0x7FFFFFFFull) { delete S; return mf_set_error("unitigs: more than 2^31 good k-mers per table is not supported"); }
     int rc = MF_OK;
     do {
-        if ((rc = mf_table_ensure_index(g)) < 0) break;
         mf_buf<uint8_t> info, pal; mf_buf<uint32_t> ridx, lidx, eqmin, starts; mf_buf<uint64_t> succ;
         mf_buf<unsigned int> ctr;
         if ((rc = info.alloc(ctx, n)) < 0 || (rc = ridx.alloc(ctx, n)) < 0 || (rc = lidx.alloc(ctx, n)) < 0 ||
             (rc = succ.alloc(ctx, 2 * n)) < 0 || (rc = starts.alloc(ctx, 2 * n)) < 0 || (rc = ctr.alloc(ctx, 4)) < 0) break;
         hipMemsetAsync(ctr.p, 0, 16, st);
         ut_arrays A;
-        A.gk = g->d_keys; A.gv = g->d_counts; A.n = n; A.k = k;
+        A.gk = gk; A.ghi = ghi; A.gv = gv; A.n = n; A.k = k;
         A.info = info.p; A.ridx = ridx.p; A.lidx = lidx.p; A.node = succ.p; A.starts = starts.p; A.n_starts = &ctr.p[1];
         A.pal = nullptr; A.jump = nullptr;
         if ((k & 1) == 0) { if ((rc = pal.alloc(ctx, n)) < 0) break; A.pal = pal.p; }   // palindromes need an even k
-        if (ctx->opt_verbose >= 2 && g->part_bits > 0 && g->d_part_off) {       // how the keys spread over the partitions (the neighbour lookup's LDS table takes NB_CAP)
-            const uint32_t npart = 1u << g->part_bits;
-            std::vector<uint64_t> po((size_t)npart + 1);
-            hipMemcpy(po.data(), g->d_part_off, po.size() * 8, hipMemcpyDeviceToHost);
-            uint64_t over = 0, nover = 0, mx = 0, b[6] = {0, 0, 0, 0, 0, 0};
-            for (uint32_t p = 0; p < npart; p++) {
-                const uint64_t c = po[p + 1] - po[p];
-                if (c > (uint64_t)NB_CAP) { over += c; nover++; }
-                mx = std::max(mx, c);
-                b[c <= 64 ? 0 : c <= 128 ? 1 : c <= 256 ? 2 : c <= 352 ? 3 : c <= 704 ? 4 : 5] += c;
-            }
-            fprintf(stderr, "[mf] unitigs: %u partitions, %.1f keys each, largest %llu; keys in partitions > %d: %.1f %% (%llu partitions); keys by partition size <=64/128/256/352/704/more: %.1f %.1f %.1f %.1f %.1f %.1f %%\n",
-                    npart, (double)n / npart, (unsigned long long)mx, NB_CAP, 100.0 * over / n, (unsigned long long)nover, 100.0 * b[0] / n, 100.0 * b[1] / n, 100.0 * b[2] / n,
-                    100.0 * b[3] / n, 100.0 * b[4] / n, 100.0 * b[5] / n);
-        }
         {
             mf_ktimer tm(ctx, "k_ut_flags");
-            if (g->index.skm_k && g->index.part_bits && g->d_part_off && !ctx->opt_nbr_global && (n >> g->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
-                const uint32_t np = 1u << g->part_bits;
-                const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
-                const unsigned grid2 = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16);      // partitions of 353 .. 1408 keys: a workgroup each
-                // k as a compile-time constant for the k values users run (round 5: 31 alone was specialised, and k = 21 -- BASELINE config 4 --
-                // and the CAMI example's 23, Example.md:18-21, paid 2.8 x per k-mer in the generic build); any other k: the generic one
-#define UT_FLAGS_K(KK) case KK: k_ut_flags_part<1, KK><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np); \
-                                k_ut_flags_part<2, KK><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np); break;
-                switch (k) {
-                    UT_FLAGS_K(21) UT_FLAGS_K(23) UT_FLAGS_K(25) UT_FLAGS_K(27) UT_FLAGS_K(29) UT_FLAGS_K(31)
-                    default:
-                        k_ut_flags_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
-                        k_ut_flags_part<2><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
-                }
-#undef UT_FLAGS_K
-            } else
-            k_ut_flags<<<grid_for(n), 256, 0, st>>>(mf_view(g->index), A);
+            if ((rc = flags(A)) < 0) break;
         }
         {
             mf_ktimer tm(ctx, "k_ut_links");
-            k_ut_links<<<grid_for(n, 1024), 1024, 0, st>>>(A);
+            if (wide) k_ut_links<true><<<grid_for(n, 1024), 1024, 0, st>>>(A);
+            else k_ut_links<false><<<grid_for(n, 1024), 1024, 0, st>>>(A);
         }
         mf_buf<uint64_t> jump;
         if ((rc = jump.alloc(ctx, 2 * n)) < 0) break;
         A.jump = jump.p;
         {
             mf_ktimer tm(ctx, "k_ut_contract");
-            if (g->part_bits > 0 && g->d_part_off) {
-                const uint32_t npart = 1u << g->part_bits;
+            if (part_bits > 0 && d_part_off) {
+                const uint32_t npart = 1u << part_bits;
                 const unsigned grid = (unsigned)std::min<uint64_t>((npart + UT_J_WAVES - 1) / UT_J_WAVES, (uint64_t)ctx->n_cu * 32);
-                k_ut_contract<<<grid, 64 * UT_J_WAVES, 0, st>>>(succ.p, g->d_part_off, npart, jump.p);
+                k_ut_contract<<<grid, 64 * UT_J_WAVES, 0, st>>>(succ.p, d_part_off, npart, jump.p);
             } else
                 k_ut_jump_plain<<<grid_for(2 * n), 256, 0, st>>>(succ.p, 2 * n, jump.p);
         }
@@ -695,7 +657,8 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         ut_paths P; P.eqmin = eqmin.p; P.pstart = nullptr; P.pend = nullptr; P.plen = nullptr; P.pkey = nullptr; P.cursor = ctr.p;
         if (n_starts) {
             mf_ktimer tm(ctx, "k_ut_ends");
-            k_ut_ends<0><<<grid_for(n_starts, 1024), 1024, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
+            if (wide) k_ut_ends<0, true><<<grid_for(n_starts, 1024), 1024, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
+            else k_ut_ends<0, false><<<grid_for(n_starts, 1024), 1024, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
         }
         unsigned int ncand = 0;
         if (hipMemcpyAsync(&ncand, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
@@ -707,7 +670,8 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
         P.plen = plen.p; P.pkey = pkey.p; P.pstart = pstart.p; P.pend = doubled ? pend.p : nullptr;
         if (n_starts) {
             mf_ktimer tm(ctx, "k_ut_ends");
-            k_ut_ends<1><<<grid_for(n_starts, 1024), 1024, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
+            if (wide) k_ut_ends<1, true><<<grid_for(n_starts, 1024), 1024, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
+            else k_ut_ends<1, false><<<grid_for(n_starts, 1024), 1024, 0, st>>>(A, P, end_node.p, end_dist.p, n_starts, min_len);
         }
         unsigned int np = 0;
         if (hipMemcpyAsync(&np, ctr.p, 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {
@@ -757,7 +721,8 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
             }
             {
                 mf_ktimer tm(ctx, "k_ut_walk2");
-                k_ut_walk2<<<grid_for(n_seg), 256, 0, st>>>(A, seg.p, n_seg, O, wsum.p);
+                if (wide) k_ut_walk2<true><<<grid_for(n_seg), 256, 0, st>>>(A, seg.p, n_seg, O, wsum.p);
+                else k_ut_walk2<false><<<grid_for(n_seg), 256, 0, st>>>(A, seg.p, n_seg, O, wsum.p);
                 k_ut_wfinal<<<grid_for(np), 256, 0, st>>>(O, wsum.p, np, k);
             }
             rounds2 = 1;
@@ -778,6 +743,59 @@ extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_thresh
     if (rc < 0) { delete S; return rc; }
     *out = S;
     return MF_OK;
+}
+
+extern "C" int mf_build_unitigs_device(mf_ctx *ctx, mf_table *t, int freq_threshold, int min_len, mf_seqs **out) {
+    mf_range rng_("mf:unitigs");
+    if (!ctx || !t || !out) return mf_set_error("mf_build_unitigs_device: NULL argument");
+    *out = nullptr;
+    MF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int k = t->k;
+
+    // nodes = k-mers with value > freqThreshold (task.run :46-48)
+    mf_table *g = nullptr;
+    MF_TRY(mf_table_filter_or_alias(t, freq_threshold, &g));
+    struct guard { mf_table *p; ~guard() { mf_table_destroy(p); } } gg{g};
+    const uint64_t n = g->n;
+    if (n && n < 0x7FFFFFFFull) MF_TRY(mf_table_ensure_index(g));
+    return mf_ut_build(ctx, g->d_keys, nullptr, g->d_counts, n, k, g->part_bits, g->d_part_off, min_len, [&](const ut_arrays &A) -> int {
+        if (ctx->opt_verbose >= 2 && g->part_bits > 0 && g->d_part_off) {       // how the keys spread over the partitions (the neighbour lookup's LDS table takes NB_CAP)
+            const uint32_t npart = 1u << g->part_bits;
+            std::vector<uint64_t> po((size_t)npart + 1);
+            hipMemcpy(po.data(), g->d_part_off, po.size() * 8, hipMemcpyDeviceToHost);
+            uint64_t over = 0, nover = 0, mx = 0, b[6] = {0, 0, 0, 0, 0, 0};
+            for (uint32_t p = 0; p < npart; p++) {
+                const uint64_t c = po[p + 1] - po[p];
+                if (c > (uint64_t)NB_CAP) { over += c; nover++; }
+                mx = std::max(mx, c);
+                b[c <= 64 ? 0 : c <= 128 ? 1 : c <= 256 ? 2 : c <= 352 ? 3 : c <= 704 ? 4 : 5] += c;
+            }
+            fprintf(stderr, "[mf] unitigs: %u partitions, %.1f keys each, largest %llu; keys in partitions > %d: %.1f %% (%llu partitions); keys by partition size <=64/128/256/352/704/more: %.1f %.1f %.1f %.1f %.1f %.1f %%\n",
+                    npart, (double)n / npart, (unsigned long long)mx, NB_CAP, 100.0 * over / n, (unsigned long long)nover, 100.0 * b[0] / n, 100.0 * b[1] / n, 100.0 * b[2] / n,
+                    100.0 * b[3] / n, 100.0 * b[4] / n, 100.0 * b[5] / n);
+        }
+        {
+            if (g->index.skm_k && g->index.part_bits && g->d_part_off && !ctx->opt_nbr_global && (n >> g->part_bits) >= 100) {      // (small partitions: the set-up per partition outweighs the local lookups)
+                const uint32_t np = 1u << g->part_bits;
+                const unsigned grid = (unsigned)std::min<uint64_t>((np + NB_WAVES - 1) / NB_WAVES, (uint64_t)ctx->n_cu * 64);
+                const unsigned grid2 = (unsigned)std::min<uint64_t>(np, (uint64_t)ctx->n_cu * 16);      // partitions of 353 .. 1408 keys: a workgroup each
+                // k as a compile-time constant for the k values users run (round 5: 31 alone was specialised, and k = 21 -- BASELINE config 4 --
+                // and the CAMI example's 23, Example.md:18-21, paid 2.8 x per k-mer in the generic build); any other k: the generic one
+#define UT_FLAGS_K(KK) case KK: k_ut_flags_part<1, KK><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np); \
+                                k_ut_flags_part<2, KK><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np); break;
+                switch (k) {
+                    UT_FLAGS_K(21) UT_FLAGS_K(23) UT_FLAGS_K(25) UT_FLAGS_K(27) UT_FLAGS_K(29) UT_FLAGS_K(31)
+                    default:
+                        k_ut_flags_part<1><<<grid, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
+                        k_ut_flags_part<2><<<grid2, 64 * NB_WAVES, 0, st>>>(mf_view(g->index), A, g->d_part_off, np);
+                }
+#undef UT_FLAGS_K
+            } else
+            k_ut_flags<<<grid_for(n), 256, 0, st>>>(mf_view(g->index), A);
+        }
+        return MF_OK;
+    }, out);
 }
 
 extern "C" void mf_seqs_destroy(mf_seqs *s) {

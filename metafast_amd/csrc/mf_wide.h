@@ -1,0 +1,58 @@
+// mf_wide.h -- NO-REFERENCE EXTENSION (32 <= k <= 63): the table of 2k-bit k-mers shared by mf_wide.hip (counting) and
+// mf_wgraph.hip (unitigs, components, features on 128-bit keys).  The reference stops at k = 31 (src/tools/KmersCounterMain.java:66-73).
+#pragma once
+#include <memory>
+#include <vector>
+#include "mf_common.h"
+
+typedef unsigned __int128 mf_u128;
+
+// A wide table is ASCENDING in (hi, lo) inside a piece and piece after piece: a k-mer's place in the table orders like the k-mer
+// itself, which is what lets the graph stages work on 32-bit vertex ids and compare ids where the k <= 31 kernels compare k-mers.
+struct mf_wtable {
+    mf_ctx *ctx = nullptr;
+    int k = 0;
+    uint64_t n = 0, n_occ = 0;
+    uint64_t n_all = 0;           // distinct k-mers before a cut inside the counting pass (mf_count_wide_device_above); else = n
+    int cut_thr = -1;             // every entry has count > cut_thr
+    struct piece { mf_buf<uint64_t> hi, lo; mf_buf<uint16_t> cnt; uint64_t n = 0; };     // ascending (hi, lo) inside a piece, and piece after piece
+    std::vector<std::unique_ptr<piece>> pieces;   // (one per pass: no second copy of a 74 GB table, and none of the 8 ms per GB a first hipMalloc of it takes)
+    // lookup index over a ONE-piece table (built on first use by the graph stages, mf_wgraph.hip): open-addressed, 8-byte slots
+    // = position (low 32 bits) | tag (the hash's high 32 bits), ~0 = empty, load <= 0.5
+    mf_buf<unsigned long long> index; uint64_t index_mask = 0;
+};
+struct mf_windex_view { const unsigned long long *slots; uint64_t mask; const uint64_t *hi, *lo; const uint16_t *cnt; uint64_t n; };
+
+int mf_wtable_flatten(mf_wtable *t);                      // all pieces into one (no-op for <= 1 piece)
+int mf_wtable_ensure_index(mf_wtable *t);                 // flatten + index
+// entries of (hi, lo, cnt)[n] with cnt > thr -> a new piece (order kept)
+int mf_wide_compact(mf_ctx *ctx, const uint64_t *hi, const uint64_t *lo, const uint16_t *cnt, uint64_t n, int thr, mf_wtable::piece &out);
+
+#ifdef __HIPCC__
+#define MF_WIDX_EMPTY 0xFFFFFFFFFFFFFFFFull
+__device__ __forceinline__ uint64_t mf_whash(uint64_t hi, uint64_t lo) { return mf_hash64(lo * 0x9E3779B97F4A7C15ull ^ hi); }
+// position of the k-mer (hi, lo) in the table or 0xFFFFFFFF
+__device__ __forceinline__ uint32_t mf_windex_find(const mf_windex_view &ix, uint64_t hi, uint64_t lo) {
+    const uint64_t h = mf_whash(hi, lo);
+    const uint32_t tag = (uint32_t)(h >> 32);
+    uint64_t s = h & ix.mask;
+    for (;;) {
+        const unsigned long long v = ix.slots[s];
+        if (v == MF_WIDX_EMPTY) return 0xFFFFFFFFu;
+        if ((uint32_t)(v >> 32) == tag) {
+            const uint32_t p = (uint32_t)v;
+            if (ix.lo[p] == lo && ix.hi[p] == hi) return p;
+        }
+        s = (s + 1) & ix.mask;
+    }
+}
+// reverse complement of a 2k-bit k-mer, 32 <= k <= 63 (A0 G1 C2 T3: complement = 3 - n)
+__device__ __forceinline__ uint64_t mf_wrev2(uint64_t x) {
+    const uint64_t y = __brevll(x);
+    return ((y & 0x5555555555555555ull) << 1) | ((y >> 1) & 0x5555555555555555ull);
+}
+__device__ __forceinline__ mf_u128 mf_wrevcomp(mf_u128 x, int k) {
+    const mf_u128 r = ((mf_u128)mf_wrev2((uint64_t)x) << 64) | (mf_u128)mf_wrev2((uint64_t)(x >> 64));
+    return (~r) >> (128 - 2 * k);
+}
+#endif

@@ -19,16 +19,9 @@
 #include <vector>
 #include "mf_common.h"
 #include "mf_count_dev.h"
+#include "mf_wide.h"
 
 int mf_sort_u64_u32(mf_ctx *ctx, const uint64_t *d_keys_in, const uint32_t *d_vals_in, uint64_t n, int bits, uint64_t *d_keys_out, uint32_t *d_vals_out);
-
-struct mf_wtable {
-    mf_ctx *ctx = nullptr;
-    int k = 0;
-    uint64_t n = 0, n_occ = 0;
-    struct piece { mf_buf<uint64_t> hi, lo; mf_buf<uint16_t> cnt; uint64_t n = 0; };     // ascending (hi, lo) inside a piece, and piece after piece
-    std::vector<std::unique_ptr<piece>> pieces;   // (one per pass: no second copy of a 74 GB table, and none of the 8 ms per GB a first hipMalloc of it takes)
-};
 
 __global__ void k_wide_mask_init(uint32_t *__restrict__ vmask, uint64_t n_words) {
     const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -459,8 +452,38 @@ __global__ void k_wide_counts(const uint64_t *__restrict__ start, uint64_t nd, u
 
 static unsigned wgrid(uint64_t n, unsigned bs = 256) { return (unsigned)std::min<uint64_t>((n + bs - 1) / bs, 0x7FFFFFFFull); }
 
-extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len,
-                                    mf_wtable **out) {
+// ---- the entries with count > thr of ascending arrays, order kept (the cut of IOUtils.printKmers, src/io/IOUtils.java:52-60, carried over) ----
+__global__ void k_wide_keep_flags(const uint16_t *__restrict__ cnt, uint64_t n, int thr, uint32_t *__restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (int)cnt[i] > thr ? 1u : 0u;
+}
+__global__ void k_wide_keep_move(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, const uint16_t *__restrict__ cnt, const uint32_t *__restrict__ flag,
+                                 const uint64_t *__restrict__ idx, uint64_t n, uint64_t *__restrict__ ohi, uint64_t *__restrict__ olo, uint16_t *__restrict__ ocnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    const uint64_t j = idx[i];
+    ohi[j] = hi[i]; olo[j] = lo[i]; ocnt[j] = cnt[i];
+}
+int mf_wide_compact(mf_ctx *ctx, const uint64_t *hi, const uint64_t *lo, const uint16_t *cnt, uint64_t n, int thr, mf_wtable::piece &out) {
+    hipStream_t st = ctx->stream;
+    mf_buf<uint32_t> flag; mf_buf<uint64_t> idx, tot;
+    MF_TRY(flag.alloc(ctx, n)); MF_TRY(idx.alloc(ctx, n + 1)); MF_TRY(tot.alloc(ctx, 1));
+    uint64_t keep = 0;
+    if (n) {
+        k_wide_keep_flags<<<wgrid(n), 256, 0, st>>>(cnt, n, thr, flag.p);
+        MF_TRY(mf_scan<1>(ctx, flag.p, idx.p, n, tot.p));
+        MF_HIP(hipMemcpyAsync(&keep, tot.p, 8, hipMemcpyDeviceToHost, st));
+        MF_HIP(hipStreamSynchronize(st));
+    }
+    MF_TRY(out.hi.alloc(ctx, keep)); MF_TRY(out.lo.alloc(ctx, keep)); MF_TRY(out.cnt.alloc(ctx, keep));
+    if (keep) k_wide_keep_move<<<wgrid(n), 256, 0, st>>>(hi, lo, cnt, flag.p, idx.p, n, out.hi.p, out.lo.p, out.cnt.p);
+    MF_HIP(hipStreamSynchronize(st));
+    out.n = keep;
+    return MF_OK;
+}
+
+static int count_wide_impl(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len, int threshold,
+                           mf_wtable **out) {
     mf_range rng_("mf:count_wide");
     if (!ctx || !out) return mf_set_error("mf_count_wide_device: NULL argument");
     *out = nullptr;
@@ -508,7 +531,7 @@ extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void
     const uint64_t target = (n_occ + (n_occ + per_pass - 1) / per_pass - 1) / ((n_occ + per_pass - 1) / per_pass);   // passes of about equal size
     typedef mf_wtable::piece piece;
     std::vector<std::unique_ptr<piece>> &pieces = t->pieces;
-    uint64_t nd_total = 0, occ_seen = 0;
+    uint64_t nd_total = 0, occ_seen = 0, n_kept = 0;
     // the leading bits the radix passes order: 32 -- or the high word's 24 .. 31 bits alone (k = 44 .. 47: a pass over a few bits of the low word saved)
     const int tb = (hb >= 24 && hb < WF_BITS) ? hb : WF_BITS, hb_tb = hb | (tb << 8);
     const uint32_t big = (uint32_t)std::min<int64_t>(WF_BIG, std::max<int64_t>(1, ctx->opt_wide_big_bucket));
@@ -631,10 +654,67 @@ extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void
         }
         if (hipStreamSynchronize(st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: %s", hipGetErrorString(hipGetLastError())));
         pc->n = nd; nd_total += nd;
+        if (threshold >= 1) {                                                            // the cut inside the pass: the uncut piece goes back to the arena
+            auto kept = std::make_unique<piece>();
+            if (mf_wide_compact(ctx, pc->hi.p, pc->lo.p, pc->cnt.p, nd, threshold, *kept) < 0) return fail(MF_ERR);
+            pc = std::move(kept);
+        }
+        n_kept += pc->n;
         pieces.push_back(std::move(pc));
     }
     if (occ_seen != n_occ) return fail(mf_set_error("mf_count_wide_device: internal error, the passes saw %llu of %llu k-mers", (unsigned long long)occ_seen, (unsigned long long)n_occ));
-    t->n = nd_total;
+    t->n = n_kept; t->n_all = nd_total;
+    if (threshold >= 1) t->cut_thr = threshold;
+    return MF_OK;
+}
+extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len,
+                                    mf_wtable **out) {
+    return count_wide_impl(ctx, d_bases, d_offsets, n_reads, n_bases, k, min_read_len, 0, out);
+}
+extern "C" int mf_count_wide_device_above(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len,
+                                          int threshold, mf_wtable **out, uint64_t *n_distinct_all) {
+    MF_TRY(count_wide_impl(ctx, d_bases, d_offsets, n_reads, n_bases, k, min_read_len, threshold, out));
+    if (n_distinct_all) *n_distinct_all = (*out)->n_all;
+    return MF_OK;
+}
+// the entries with count > threshold as a table of its own (one piece)
+extern "C" int mf_wtable_filter(const mf_wtable *t, int threshold, mf_wtable **out) {
+    if (!t || !out) return mf_set_error("mf_wtable_filter: NULL argument");
+    *out = nullptr;
+    mf_ctx *ctx = t->ctx;
+    MF_HIP(hipSetDevice(ctx->device));
+    auto nt = std::make_unique<mf_wtable>();
+    nt->ctx = ctx; nt->k = t->k; nt->n_occ = t->n_occ; nt->n_all = t->n_all; nt->cut_thr = std::max(t->cut_thr, threshold);
+    uint64_t tot = 0;
+    for (auto &pc : t->pieces) {
+        auto kept = std::make_unique<mf_wtable::piece>();
+        MF_TRY(mf_wide_compact(ctx, pc->hi.p, pc->lo.p, pc->cnt.p, pc->n, threshold, *kept));
+        tot += kept->n;
+        if (kept->n) nt->pieces.push_back(std::move(kept));
+    }
+    nt->n = tot;
+    MF_TRY(mf_wtable_flatten(nt.get()));
+    *out = nt.release();
+    return MF_OK;
+}
+int mf_wtable_flatten(mf_wtable *t) {
+    if (t->pieces.size() <= 1) return MF_OK;
+    mf_ctx *ctx = t->ctx;
+    hipStream_t st = ctx->stream;
+    auto one = std::make_unique<mf_wtable::piece>();
+    MF_TRY(one->hi.alloc(ctx, t->n)); MF_TRY(one->lo.alloc(ctx, t->n)); MF_TRY(one->cnt.alloc(ctx, t->n));
+    uint64_t at = 0;
+    for (auto &pc : t->pieces) {
+        if (!pc->n) continue;
+        MF_HIP(hipMemcpyAsync(one->hi.p + at, pc->hi.p, pc->n * 8, hipMemcpyDeviceToDevice, st));
+        MF_HIP(hipMemcpyAsync(one->lo.p + at, pc->lo.p, pc->n * 8, hipMemcpyDeviceToDevice, st));
+        MF_HIP(hipMemcpyAsync(one->cnt.p + at, pc->cnt.p, pc->n * 2, hipMemcpyDeviceToDevice, st));
+        at += pc->n;
+    }
+    MF_HIP(hipStreamSynchronize(st));
+    one->n = at;
+    t->pieces.clear();
+    t->pieces.push_back(std::move(one));
     return MF_OK;
 }
 extern "C" void mf_wtable_destroy(mf_wtable *t) { delete t; }

@@ -40,6 +40,15 @@ _SIGS = {
     "mf_wtable_export": (i32, [vp, vp, vp, vp, u64, pu64]),
     "mf_wtable_pieces": (i32, [vp, C.POINTER(C.c_uint32)]),
     "mf_wtable_piece_view": (i32, [vp, C.c_uint32, pvp, pvp, pvp, pu64]),
+    "mf_count_wide_device_above": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, pvp, pu64]),
+    "mf_wtable_filter": (i32, [vp, i32, pvp]),
+    "mf_wtable_drop_index": (i32, [vp]),
+    "mf_build_unitigs_wide_device": (i32, [vp, vp, i32, i32, pvp]),
+    "mf_cut_components_wide_device": (i32, [vp, vp, i32, i32, pvp]),
+    "mf_wcomps_destroy": (None, [vp]),
+    "mf_wcomps_stats": (i32, [vp, pu64, pu64]),
+    "mf_wcomps_export": (i32, [vp, vp, vp, vp, vp, vp, vp]),
+    "mf_features_wide_device": (i32, [vp, vp, vp, i32, vp, vp]),
     "mf_count_reads_above": (i32, [vp, C.POINTER(cp), i32, i32, i32, i32, pvp, pu64]),
     "mf_count_device": (i32, [vp, vp, vp, u64, u64, i32, i32, pvp]),
     "mf_count_device_above": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, pvp, pu64]),
@@ -280,6 +289,34 @@ class Context:
         _check(lib().mf_count_wide_device(self.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k, min_read_len, C.byref(t)))
         return WideTable(self, t)
 
+    def count_wide_above(self, d_bases, d_offsets, n_reads, n_bases, k, threshold, min_read_len=0):
+        """NO-REFERENCE EXTENSION, 32 <= k <= 63: count_wide_table with the cut count > threshold inside the pass
+        -> (WideTable, distinct k-mers before the cut)"""
+        t = C.c_void_p()
+        n_all = C.c_uint64()
+        _check(lib().mf_count_wide_device_above(self.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_reads, n_bases, k, min_read_len, threshold,
+                                                C.byref(t), C.byref(n_all)))
+        return WideTable(self, t), n_all.value
+
+    def build_unitigs_wide(self, table, freq_threshold, min_len):
+        """NO-REFERENCE EXTENSION: build_unitigs on a WideTable -> Seqs"""
+        s = C.c_void_p()
+        _check(lib().mf_build_unitigs_wide_device(self.h, table.h, freq_threshold, min_len, C.byref(s)))
+        return Seqs(self, s)
+
+    def cut_components_wide(self, cutter, b1, b2):
+        """NO-REFERENCE EXTENSION: cut_components on a WideTable -> WideComps"""
+        c = C.c_void_p()
+        _check(lib().mf_cut_components_wide_device(self.h, cutter.h, b1, b2, C.byref(c)))
+        return WideComps(self, c)
+
+    def features_wide(self, comps, sample, threshold=0):
+        n = len(comps)
+        vec = np.zeros(n, dtype=np.int64)
+        br = np.zeros(n, dtype=np.float64)
+        _check(lib().mf_features_wide_device(self.h, comps.h, sample.h, threshold, vec.ctypes.data, br.ctypes.data))
+        return vec, br
+
     def count_device_above(self, d_bases, d_offsets, n_reads, n_bases, k, threshold, min_read_len=0):
         """count, keeping only the k-mers with count > threshold (what the k-mer counter hands on, IOUtils.printKmers);
         -> (Table of the kept k-mers, number of distinct k-mers before the cut)"""
@@ -380,6 +417,22 @@ class WideTable:
         _check(lib().mf_wtable_stats(self.h, C.byref(n), C.byref(occ), C.byref(kk)))
         return n.value, occ.value, kk.value
 
+    def export(self):
+        """-> (hi, lo, counts) ascending"""
+        n = self.stats()[0]
+        hi = np.empty(n, dtype=np.uint64); lo = np.empty(n, dtype=np.uint64); cnt = np.empty(n, dtype=np.uint16)
+        m = C.c_uint64()
+        _check(lib().mf_wtable_export(self.h, hi.ctypes.data, lo.ctypes.data, cnt.ctypes.data, n, C.byref(m)))
+        return hi, lo, cnt
+
+    def filter(self, threshold):
+        t = C.c_void_p()
+        _check(lib().mf_wtable_filter(self.h, threshold, C.byref(t)))
+        return WideTable(self.ctx, t)
+
+    def drop_index(self):
+        _check(lib().mf_wtable_drop_index(self.h))
+
     def pieces(self):
         """[(d_hi, d_lo, d_counts, n)]: raw device pointers of every piece (uint64, uint64, uint16)"""
         m = C.c_uint32()
@@ -390,6 +443,36 @@ class WideTable:
             _check(lib().mf_wtable_piece_view(self.h, i, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
             out.append((a.value or 0, b.value or 0, c.value or 0, n.value))
         return out
+
+
+class WideComps:
+    """NO-REFERENCE EXTENSION: connected components of 2k-bit k-mers (32 <= k <= 63)"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def close(self):
+        if self.h:
+            lib().mf_wcomps_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def stats(self):
+        n, nk = C.c_uint64(), C.c_uint64()
+        _check(lib().mf_wcomps_stats(self.h, C.byref(n), C.byref(nk)))
+        return n.value, nk.value
+
+    def __len__(self):
+        return self.stats()[0]
+
+    def export(self):
+        """-> dict(sizes, weights, thr, offsets, hi, lo): k-mers grouped by component, ascending inside"""
+        n, nk = self.stats()
+        sizes = np.zeros(n, dtype=np.uint64); weights = np.zeros(n, dtype=np.int64); thr = np.zeros(n, dtype=np.int32)
+        off = np.zeros(n + 1, dtype=np.uint64); hi = np.zeros(nk, dtype=np.uint64); lo = np.zeros(nk, dtype=np.uint64)
+        _check(lib().mf_wcomps_export(self.h, sizes.ctypes.data, weights.ctypes.data, thr.ctypes.data, off.ctypes.data, hi.ctypes.data, lo.ctypes.data))
+        return dict(sizes=sizes, weights=weights, thr=thr, offsets=off, hi=hi, lo=lo)
 
 
 class Table:

@@ -693,6 +693,69 @@ def _run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda
                 matrix=matrix, n_occ=n_occ, n_distinct=n_distinct, hists=hists, comm=comm_stats)
 
 
+def run_samples_wide(ctx, samples, k=63, b=1, l=100, b1=1000, b2=10000, device="cuda", timings=None):
+    """NO-REFERENCE EXTENSION (the reference rejects k > 31, src/tools/KmersCounterMain.java:66-73; BASELINE config 4 names a k = 63
+    leg): the steps of _run_samples for 32 <= k <= 63 on THIS rank's samples -- counts with the cut inside the pass, unitigs, the cutter
+    table over all unitigs, components, features, matrix (mf_wide.hip, mf_wgraph.hip).  samples: (d_bases, d_offsets, n_reads, n_bases)
+    tuples of torch tensors in HBM.  One rank only: the per-sample steps need no exchange, the join of several ranks' unitigs is not
+    built for wide k-mers."""
+    t0 = time.perf_counter()
+
+    def mark(name):
+        nonlocal t0
+        if timings is not None:
+            ctx.synchronize()
+            t1 = time.perf_counter()
+            timings[name] = timings.get(name, 0.0) + (t1 - t0)
+            t0 = t1
+
+    goods, seqss, n_occ, n_distinct = [], [], 0, []
+    for si, (d_bases, d_offsets, n_reads, n_bases) in enumerate(samples):
+        if si:
+            goods[-1].drop_index()
+        good, nd = ctx.count_wide_above(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, k, b)
+        mark("count")
+        seqss.append(ctx.build_unitigs_wide(good, b, l))
+        mark("unitigs")
+        goods.append(good); n_occ += good.stats()[1]; n_distinct.append(nd)
+    if len(goods) > 1:
+        goods[-1].drop_index()
+    views = [sq.device_view() for sq in seqss]
+    if len(views) == 1:
+        v = views[0]
+        sb, so, ns, nb = v["bases"], v["offsets"], v["n"], v["n_bases"]
+        keep = None
+    else:
+        parts_b = [device_tensor(v["bases"], v["n_bases"], device) for v in views]
+        parts_o, nb = [], 0
+        for v in views:
+            parts_o.append(device_tensor(v["offsets"], (v["n"] + 1) * 8, device).view(torch.int64)[:-1] + nb)
+            nb += v["n_bases"]
+        ctx.synchronize()
+        tb = _with_room(ctx, lambda: torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=device)]))
+        to = _with_room(ctx, lambda: torch.cat(parts_o + [torch.tensor([nb], dtype=torch.int64, device=device)]))
+        torch.cuda.current_stream().synchronize()
+        keep = (tb, to)
+        sb, so, ns = tb.data_ptr(), to.data_ptr(), int(to.numel()) - 1
+    cutter = ctx.count_wide_table(sb, so, ns, nb, k, l)
+    mark("cutter_count")
+    comps = ctx.cut_components_wide(cutter, b1, b2)
+    cutter.drop_index()
+    mark("components")
+    vecs, breadths = [], []
+    for good in goods:
+        vec, br = ctx.features_wide(comps, good, 0)
+        if len(goods) > 1:
+            good.drop_index()
+        vecs.append(vec); breadths.append(br)
+    vecs = np.stack(vecs) if vecs else np.zeros((0, len(comps)), dtype=np.int64)
+    matrix = L.bray_curtis(vecs) if vecs.shape[1] else np.zeros((vecs.shape[0], vecs.shape[0]))
+    mark("features_matrix")
+    del keep
+    return dict(goods=goods, seqss=seqss, cutter=cutter, comps=comps, vecs=vecs, breadths=breadths, matrix=matrix, n_occ=n_occ,
+                n_distinct=n_distinct)
+
+
 def run_sample(ctx, d_bases, d_offsets, n_reads, n_bases, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda",
                timings=None):
     """One sample on this rank's GPU (run_samples with a single sample; the result keys of one sample)."""
