@@ -48,16 +48,78 @@ def _load_other_shapes():
 
 
 def _load_extension_k63():
-    """NO-REFERENCE EXTENSION, not part of the metric: canonical 63-mer counts of one 200 M-read sample (BASELINE config 4's k = 63 leg, counts only),
-    the second run of tools/wide_rate.py on the GPU box, committed as profiles/r05at_wide_200M_k63.json -- a builder-run profile, labelled as such"""
+    """NO-REFERENCE EXTENSION, not part of the metric: one 200 M-read sample counted + graphed at k = 63 (BASELINE config 4's k = 63 leg) =
+    the line `python bench.py -k 63 --reads 200000000` printed on the GPU box, committed as profiles/extension_k63_200M.json -- a builder-run
+    profile, labelled as such"""
     try:
-        r = json.load(open(os.path.join(ROOT, "profiles", "r05at_wide_200M_k63.json")))
-        run = r["runs"][-1]
-        return {"label": "NO-REFERENCE EXTENSION (the reference stops at k = 31); builder-run profile profiles/r05at_wide_200M_k63.json, not measured by this run",
-                "k": r["k"], "reads": r["reads"], "seconds": run["seconds"], "kmers_per_s": run["kmers_per_s"], "n_distinct": run["n_distinct"],
-                "kernel_ms": run["kernels"]}
+        r = json.load(open(os.path.join(ROOT, "profiles", "extension_k63_200M.json")))
+        return {"label": "NO-REFERENCE EXTENSION (the reference stops at k = 31); builder-run profile profiles/extension_k63_200M.json "
+                         "(python bench.py -k 63 --reads 200000000), not measured by this run",
+                "k": r["config"]["k"], "reads": r["config"]["reads_per_gpu"], "ms_per_step": r["ms_per_step"], "kmers_per_s": r["value"],
+                "stage_ms_per_step": r["stage_ms_per_step"], "stats": r["stats"], "kernel_ms_per_step": {n: v["ms_per_step"] for n, v in r["kernels"].items()}}
     except Exception:
         return None
+
+
+def main_wide(args, ctx, device, rank, world):
+    """`bench.py -k K` with 32 <= K <= 63: NO-REFERENCE EXTENSION (the reference rejects k > 31, src/tools/KmersCounterMain.java:66-73;
+    BASELINE config 4's k = 63 leg).  The same step -- count with the cut inside, unitigs, cutter table, components, features, matrix -- on
+    2k-bit k-mers (mf_wide.hip, mf_wgraph.hip), reads resident in HBM; a normal line whose metric string says what it is.  One GPU."""
+    from metafast_amd import pipeline as P
+    n_reads, rl, k = args.reads, args.read_len, args.k
+    n_bases = n_reads * rl
+    bases = torch.zeros(n_bases + 64, dtype=torch.uint8, device=device)
+    offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
+    sub16k = int(round(args.sub_rate * 16384))
+    ctx.synth_reads_device(SEED, rank, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr(), sub16k)
+    torch.cuda.synchronize()
+
+    def step(timings=None):
+        r = P.run_samples_wide(ctx, [(bases, offsets, n_reads, n_bases)], k=k, b=args.bad_freq, l=args.min_len, b1=args.b1, b2=args.b2, device=device, timings=timings)
+        stats = dict(n_occ=r["n_occ"], n_distinct=int(sum(r["n_distinct"])), n_good=int(sum(g.stats()[0] for g in r["goods"])),
+                     n_unitigs=int(sum(len(q) for q in r["seqss"])), n_cutter=int(r["cutter"].stats()[0]), n_components=len(r["comps"]),
+                     n_component_kmers=int(r["comps"].stats()[1]), n_reads=n_reads, n_bases=n_bases)
+        for x in r["goods"] + r["seqss"] + [r["cutter"], r["comps"]]:
+            x.close()
+        return stats
+
+    for _ in range(args.warmup):
+        stats = step()
+    ctx.reset_timers()
+    stage_t = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        stats = step(stage_t)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    rep = ctx.kernel_report()
+    kern = {name: dict(launches=n, ms_per_step=round(ms / max(args.steps, 1), 4), max_launch_ms=round(mx, 4)) for name, (n, ms, mx) in rep.items()}
+    # the dominant kernels move, per occurrence: k_wide_kmers 16 B written (two words), the sort 4 passes x 32 B, finish / big 32 B; priced on
+    # the bytes the passes must move at least once (16 B written + 16 B read per occurrence and sort pass) -- an HBM-bound integer path
+    dom = max(kern, key=lambda kn: kern[kn]["ms_per_step"]) if kern else None
+    roof = None
+    if dom:
+        passes = {"k_wide_sort": 4 * 32 + 32, "k_wide_kmers": 16 + 2 * rl / max(rl - k + 1, 1), "k_wide_finish": 32, "k_wide_big": 32}.get(dom)
+        if passes:
+            gb = passes * stats["n_occ"] / 1e9
+            ms = kern[dom]["ms_per_step"]
+            roof = dict(kernel=dom, bound="hbm", achieved=round(gb / (ms / 1e3), 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gb / (ms / 1e3) / HBM_PEAK_GBS, 4),
+                        launch_ms=ms, algorithmic_GB=round(gb, 3), traffic=None,
+                        priced_as="%.1f B per k-mer occurrence (the two 64-bit words of every occurrence through the passes of this stage)" % passes)
+    out = {
+        "metric": "NO-REFERENCE EXTENSION: k-mers/s counted+graphed at k=%d, %d bp reads (the reference rejects k > 31)" % (k, rl),
+        "value": round(stats["n_occ"] * args.steps / elapsed, 1), "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u128", "data": "synthetic",
+        "config": {"workload": f"1 sample x {n_reads} synthetic {rl} bp reads, k={k}, count+unitigs+components+features "
+                               f"(b={args.bad_freq} l={args.min_len} b1={args.b1} b2={args.b2})",
+                   "reads_per_gpu": n_reads, "read_len": rl, "k": k, "genome_scale_bp": args.genome_scale, "substitutions_per_base": round(sub16k / 16384, 5)},
+        "roofline": roof, "cpu_baseline": None, "stats": stats,
+        "stage_ms_per_step": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in stage_t.items()},
+        "kernels": kern,
+    }
+    return out
 
 
 TRAFFIC = {}
@@ -343,6 +405,15 @@ def main():
         ctx.set_option(name, int(val))
 
     n_reads, rl, k = args.reads, args.read_len, args.k
+    if k >= 32:
+        if world != 1:
+            raise SystemExit("bench.py -k %d: the 32 <= k <= 63 extension runs on one GPU" % k)
+        out = main_wide(args, ctx, device, rank, world)
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+        return
     spg = max(1, args.samples_per_gpu)
     e2e = {}
     if not args.no_end_to_end and world == 1:
