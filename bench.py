@@ -461,7 +461,7 @@ def main():
         for x in r["goods"] + r["seqss"] + [r["cutter"], r["comps"]]:
             x.close()
         for kk, v in r["comm"].items():
-            comm_acc[kk] = comm_acc.get(kk, 0) + v
+            comm_acc[kk] = v if isinstance(v, str) else comm_acc.get(kk, 0) + v
         return stats, r["matrix"]
 
     comm_acc = {}
@@ -577,7 +577,8 @@ def main():
             "slice_restarts": ctx.stat("slice_restarts"),
             # the sharded cutter's exchanges on rank 0 (world > 1): collectives per step, bytes received per step, seconds inside
             # them (each timed with a stream synchronisation on both sides; not measurable on this pool's 1-GPU boxes)
-            "comm": {"collectives_per_step": round(comm_acc.get("collectives", 0) / max(args.steps, 1), 1),
+            "comm": {"kind": comm_acc.get("kind"),      # the library's communicator (mf_comm): "rccl" under the launcher, "local" in a single process
+                     "collectives_per_step": round(comm_acc.get("collectives", 0) / max(args.steps, 1), 1),
                      "MB_received_per_step": round(comm_acc.get("bytes_in", 0) / max(args.steps, 1) / 1e6, 2),
                      "comm_ms_per_step": round(comm_acc.get("seconds", 0.0) / max(args.steps, 1) * 1e3, 3)},
             "stage_ms_per_step": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in stage_t.items()},

@@ -341,6 +341,70 @@ int  mf_dcc_finish(mf_dcc *d, const void *d_kmers, const void *d_roots, uint64_t
                    const uint32_t *kept_size, const int64_t *kept_weight, const int32_t *kept_thr,
                    const uint64_t *kept_minkey, uint64_t n_kept, mf_comps **out);
 
+/* ---- the exchanges of the multi-GPU path, behind this boundary (round 6; mf_comm.hip) ----------------------
+ * The reference is one JVM (ComponentCutterMain.runImpl, src/tools/ComponentCutterMain.java:78-114, joins all libraries in one map; IOUtils.run,
+ * src/io/IOUtils.java:846-862, waits for its threads on a latch).  With a library per GPU the join is an exchange.  A communicator gives every rank
+ * three primitives on buffers in HBM -- a gather of a few host integers, an all-gather and an all-to-all of slices whose sizes all ranks know --
+ * over one of three transports, and the calls below run the path's exchange steps on it (on the context's stream and workspace):
+ *   local     the ranks are THREADS of one process, a context each (metafast.sh --devices a,b,...): a rank copies its slice straight into every
+ *             peer's receive buffer (peer access over xGMI; a device-to-device copy where two ranks share a GPU) -- the direct all-gather of a
+ *             fully connected xGMI node, no ring;
+ *   rccl      one process per GPU: librccl looked up at run time; slices travel as grouped ncclSend / ncclRecv pairs;
+ *   external  the host's own primitives (MPI under a Java host; torch.distributed in this repository's tests).
+ * One calling thread per communicator; every rank makes the same calls in the same order.  MF_ERR_TOGETHER: some rank could not do its part
+ * and ALL ranks return this from the same call (mf_last_error names the ranks) -- the caller may take another route on all of them, e.g.
+ * mf_comm_gather_sequences + mf_count_device + mf_cut_components_device everywhere. */
+#define MF_ERR_TOGETHER (-2)
+typedef struct mf_comm mf_comm;
+/* n communicators for n threads of this process, out[r] for the thread that drives ctxs[r] */
+int  mf_comm_create_local(mf_ctx *const *ctxs, int n, mf_comm **out);
+/* one process per GPU: rank 0 makes an id (128 bytes) and hands it to the others by the host's own means; all ranks then create together */
+int  mf_comm_rccl_id(void *id128);
+int  mf_comm_create_rccl(mf_ctx *ctx, const void *id128, int rank, int world, mf_comm **out);
+/* the host's primitives; all sizes in bytes, known to every rank; device pointers of the context's GPU; < 0 = failure.  The library has
+ * synchronised its stream before a call and reads the result on that stream after it: the primitive returns when the data has arrived.
+ *   gather_ints(user, vals[n], n, out[world * n])                       rank r's vals at out[r * n]
+ *   all_gather(user, d_send, d_recv, bytes[world])                      rank r's bytes[r] bytes at d_recv + sum(bytes[:r]), on every rank
+ *   all_to_all(user, d_send, send_bytes[world], d_recv, recv_bytes[world])   d_send grouped by destination, d_recv by source */
+typedef struct mf_comm_ops {
+    int (*gather_ints)(void *user, const int64_t *vals, int n, int64_t *out);
+    int (*all_gather)(void *user, const void *d_send, void *d_recv, const uint64_t *bytes);
+    int (*all_to_all)(void *user, const void *d_send, const uint64_t *send_bytes, void *d_recv, const uint64_t *recv_bytes);
+} mf_comm_ops;
+int  mf_comm_create_external(mf_ctx *ctx, int rank, int world, const mf_comm_ops *ops, void *user, mf_comm **out);
+void mf_comm_destroy(mf_comm *c);
+int  mf_comm_rank(const mf_comm *c);
+int  mf_comm_world(const mf_comm *c);
+const char *mf_comm_kind(const mf_comm *c);                  /* "local" / "rccl" / "external" */
+/* "collectives", "bytes_in" (received), "us" (host time inside the exchanges) since the last reset; < 0: unknown name */
+int64_t mf_comm_stat(const mf_comm *c, const char *name);
+int  mf_comm_reset_stats(mf_comm *c);
+/* the primitives themselves (tests; hosts that have more to exchange) */
+int  mf_comm_gather_ints(mf_comm *c, const int64_t *vals, int n, int64_t *out);
+int  mf_comm_all_gather(mf_comm *c, const void *d_send, void *d_recv, const uint64_t *bytes_per_rank);
+int  mf_comm_all_to_all(mf_comm *c, const void *d_send, const uint64_t *send_bytes, void *d_recv, const uint64_t *recv_bytes);
+/* Every rank's sequences (its libraries' unitigs: the layout of mf_seqs_device_view / mf_reads_device_view) on every rank, rank after rank:
+ * IOUtils.loadReads over the .seq.fasta files of ALL libraries (src/tools/ComponentCutterMain.java:81).  The result is read with
+ * mf_reads_stats / mf_reads_device_view and freed with mf_reads_destroy. */
+int  mf_comm_gather_sequences(mf_comm *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases, mf_reads **all);
+/* One call = ComponentCutterMain.runImpl :81-108 over all ranks: the sequences are gathered, every rank counts the k-mers it owns
+ * (mf_count_device_shard) and the exchange protocol of the sharded cutter above (mf_dcc_*) runs inside: the SAME components on every rank,
+ * identical to mf_cut_components_device on the table of all sequences.  world = a power of two <= 64, 20 <= k <= 31. */
+int  mf_cut_components_sharded(mf_comm *c, const void *d_bases, const void *d_offsets, uint64_t n_seqs, uint64_t n_bases, int k, int min_len,
+                               int b1, int b2, mf_comps **out);
+/* File form, every rank: its libraries' .seq.fasta files in (nfiles may be 0), rank 0 writes components.bin and the components-stat file
+ * (ComponentCutterMain.runImpl :92-108), every rank keeps the components for the features step of its own libraries (option file_cache). */
+int  mf_cut_components_sharded_files(mf_comm *c, const char *const *seq_files, int nfiles, int k, int min_len, int b1, int b2,
+                                     const char *components_bin, const char *stat_txt, uint64_t *n_comp);
+/* ... on a shard the caller has counted (NULL: this rank has none -- all ranks return MF_ERR_TOGETHER); info (may be NULL): [0] threshold levels,
+ * [1] this rank's neighbour queries, [2] members over all ranks, [3] vertices over all ranks */
+int  mf_cut_components_of_shard(mf_comm *c, mf_table *shard, int k, int b1, int b2, mf_comps **out, uint64_t *info);
+/* The feature vectors of all ranks' samples, rank after rank, on every rank (the rows DistanceMatrixCalculatorMain reads back from the .vec files,
+ * src/tools/DistanceMatrixCalculatorMain.java:125-138): rows = this rank's int64[n_rows][n_comp] (host); all_rows (host; NULL: only the count)
+ * takes capacity_rows rows. */
+int  mf_features_allgather(mf_comm *c, const int64_t *rows, uint64_t n_rows, uint64_t n_comp, int64_t *all_rows, uint64_t capacity_rows,
+                           uint64_t *n_all_rows);
+
 /* ---- A12  features ------------------------------------------------------------------ */
 /* replaces FeaturesCalculatorMain: hm.put(kmer,0) for component k-mers (:97-103), presence pass
  * over the sample's records (IOUtils.calculatePresenceForKmers, src/io/IOUtils.java:577-597) and

@@ -81,5 +81,17 @@ public final class HipBackend {
     public static native long dccFinish(long dcc, long dKmers, long dRoots, long nMembers, int[] keptRoot, int[] keptSize, long[] keptWeight,
                                         int[] keptThr, long[] keptMinkey);
 
+    // ---- the exchanges behind the boundary (round 6): ComponentCutterMain.runImpl :78-114 over several GPUs in ONE call per rank
+    /** one communicator per context, for one worker thread per GPU of this JVM (slices are copied straight into the peers' buffers) */
+    public static native long[] commCreateLocal(long[] ctxs);
+    /** one JVM per GPU: rank 0 makes the 128-byte id, hands it to the others, all create together (RCCL) */
+    public static native byte[] commRcclId();
+    public static native long commCreateRccl(long ctx, byte[] id, int rank, int world);
+    public static native void commDestroy(long comm);
+    /** every rank: the .seq.fasta files of ITS libraries; rank 0 writes components.bin + the stat file; -> number of components */
+    public static native long cutComponentsSharded(long comm, String[] seqFiles, int k, int minSeqLen, int b1, int b2, String componentsBin, String statTxt);
+    /** the feature vectors of all ranks' libraries, rank after rank (the rows DistanceMatrixCalculatorMain reads from the .vec files) */
+    public static native long[] featuresAllgather(long comm, long[] rows, int nRows, int nComp);
+
     private HipBackend() {}
 }

@@ -278,5 +278,61 @@ JNIEXPORT jlong JNICALL Java_io_HipBackend_dccFinish(JNIEnv *e, jclass, jlong dc
     if (rc < 0) { raise(e); return 0; }
     return (jlong)(intptr_t)c;
 }
+
+// ---- the exchanges behind the boundary (round 6, mf_comm): a JVM with one worker thread per GPU makes local communicators; one JVM per GPU the
+// rccl ones (the id crosses by the host's own means -- a file, a socket).  MF_ERR_TOGETHER surfaces as the same ExecutionFailedException on
+// every rank: ComponentCutterMain can then cut on one device.
+#define COMM(x) ((mf_comm *)(intptr_t)(x))
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_commCreateLocal(JNIEnv *e, jclass, jlongArray ctxs) {
+    const jsize n = e->GetArrayLength(ctxs);
+    std::vector<jlong> h(n);
+    e->GetLongArrayRegion(ctxs, 0, n, h.data());
+    std::vector<mf_ctx *> cs(n); std::vector<mf_comm *> out(n, nullptr);
+    for (jsize i = 0; i < n; i++) cs[i] = (mf_ctx *)(intptr_t)h[i];
+    if (mf_comm_create_local(cs.data(), (int)n, out.data()) < 0) { raise(e); return nullptr; }
+    jlongArray r = e->NewLongArray(n);
+    if (!r) { for (mf_comm *c : out) mf_comm_destroy(c); return nullptr; }
+    for (jsize i = 0; i < n; i++) h[i] = (jlong)(intptr_t)out[i];
+    e->SetLongArrayRegion(r, 0, n, h.data());
+    return r;
+}
+JNIEXPORT jbyteArray JNICALL Java_io_HipBackend_commRcclId(JNIEnv *e, jclass) {
+    jbyte id[128];
+    if (mf_comm_rccl_id(id) < 0) { raise(e); return nullptr; }
+    jbyteArray r = e->NewByteArray(128);
+    if (r) e->SetByteArrayRegion(r, 0, 128, id);
+    return r;
+}
+JNIEXPORT jlong JNICALL Java_io_HipBackend_commCreateRccl(JNIEnv *e, jclass, jlong ctx, jbyteArray id, jint rank, jint world) {
+    if (e->GetArrayLength(id) != 128) { bad_length(e, "commCreateRccl: the id has 128 bytes"); return 0; }
+    jbyte b[128];
+    e->GetByteArrayRegion(id, 0, 128, b);
+    mf_comm *c = nullptr;
+    if (mf_comm_create_rccl((mf_ctx *)(intptr_t)ctx, b, rank, world, &c) < 0) { raise(e); return 0; }
+    return (jlong)(intptr_t)c;
+}
+JNIEXPORT void JNICALL Java_io_HipBackend_commDestroy(JNIEnv *, jclass, jlong comm) { mf_comm_destroy(COMM(comm)); }
+JNIEXPORT jlong JNICALL Java_io_HipBackend_cutComponentsSharded(JNIEnv *e, jclass, jlong comm, jobjectArray seqFiles, jint k, jint minLen, jint b1, jint b2, jstring componentsBin,
+                                                                jstring statTxt) {
+    utf_array f(e, seqFiles);
+    utf cb(e, componentsBin), st(e, statTxt);
+    uint64_t nc = 0;
+    if (mf_cut_components_sharded_files(COMM(comm), f.p.data(), (int)f.p.size(), k, minLen, b1, b2, cb.p, st.p, &nc) < 0) { raise(e); return 0; }
+    return (jlong)nc;
+}
+// rows: this rank's vectors, row after row; -> all ranks' rows, rank after rank
+JNIEXPORT jlongArray JNICALL Java_io_HipBackend_featuresAllgather(JNIEnv *e, jclass, jlong comm, jlongArray rows, jint nRows, jint nComp) {
+    if (nRows < 0 || nComp < 0 || e->GetArrayLength(rows) != (jsize)nRows * nComp) { bad_length(e, "featuresAllgather: rows must hold nRows x nComp values"); return nullptr; }
+    jlong *v = e->GetLongArrayElements(rows, nullptr);
+    uint64_t n_all = 0;
+    int rc = mf_features_allgather(COMM(comm), (const int64_t *)v, (uint64_t)nRows, (uint64_t)nComp, nullptr, 0, &n_all);
+    std::vector<int64_t> all(n_all * (uint64_t)nComp + 1);
+    if (rc == 0) rc = mf_features_allgather(COMM(comm), (const int64_t *)v, (uint64_t)nRows, (uint64_t)nComp, all.data(), n_all, &n_all);
+    e->ReleaseLongArrayElements(rows, v, JNI_ABORT);
+    if (rc < 0) { raise(e); return nullptr; }
+    jlongArray r = e->NewLongArray((jsize)(n_all * (uint64_t)nComp));
+    if (r) e->SetLongArrayRegion(r, 0, (jsize)(n_all * (uint64_t)nComp), (const jlong *)all.data());
+    return r;
+}
 }
 #endif

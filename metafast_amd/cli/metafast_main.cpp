@@ -379,8 +379,63 @@ static vector<string> run_seq_builder_many(Env &e, const Args &a, const vector<s
     return fs;
 }
 // component-cutter (src/tools/ComponentCutterMain.java:78-114)
+// ... with several device contexts (round 6): every entry reads the .seq.fasta files of ITS libraries (library i -> entry i mod W, as in the
+// per-library steps: the device that built them), the entries cut the components together -- every entry owns a shard of the cutter table,
+// the exchanges run inside the library over a communicator of this process's threads (mf_comm_create_local: slices copied straight into the
+// peers' buffers, over xGMI between devices) -- and entry 0 writes components.bin; every entry keeps the components for the features of
+// its libraries.  W = the largest power of two <= the entries; MF_REPLICATED_CUTTER=1, k < 20 or a single entry: entry 0 alone, as before.
+// Returns false when the entries gave up together (the caller then takes entry 0 alone).
+static bool run_component_cutter_sharded(Env &e, const Args &a, const vector<string> &files, int k, int l, int b1, int b2, const string &comp_file, const string &stat, uint64_t *nc) {
+    parse_devices(e, a);
+    size_t W = 1;
+    while (2 * W <= e.devs.size() && 2 * W <= 64) W *= 2;
+    if (W < 2 || k < 20 || getenv("MF_REPLICATED_CUTTER")) return false;
+    const int keep_slot = t_slot;
+    for (size_t d = 0; d < W; d++) { t_slot = (int)d; ctx_of(e, a); }           // (a context is made by whoever needs it first; its worker binds it below)
+    t_slot = keep_slot;
+    vector<mf_comm *> comms(W, nullptr);
+    check(mf_comm_create_local(e.ctxs.data(), (int)W, comms.data()));
+    logmsg("DEBUG", "Cutting components on %zu device contexts (sharded cutter table)", W);
+    vector<int> rcs(W, MF_OK); vector<string> errs(W); vector<uint64_t> ncs(W, 0);
+    auto work = [&](size_t d) {
+        vector<string> mine;
+        for (size_t i = d; i < files.size(); i += W) mine.push_back(files[i]);
+        auto fp = cptrs(mine);
+        rcs[d] = mf_cut_components_sharded_files(comms[d], fp.data(), (int)fp.size(), k, l, b1, b2, comp_file.c_str(), stat.c_str(), &ncs[d]);
+        if (rcs[d] < 0) errs[d] = mf_last_error();
+    };
+    g_workers_active = true;
+    vector<std::thread> th;
+    for (size_t d = 1; d < W; d++) th.emplace_back([&, d]() { t_slot = (int)d; if (mf_ctx_bind_thread(e.ctxs[d]) < 0) { rcs[d] = MF_ERR; errs[d] = mf_last_error(); } work(d); mf_ctx_synchronize(e.ctxs[d]); });
+    work(0);
+    for (auto &t : th) t.join();
+    g_workers_active = false;
+    for (mf_comm *c : comms) mf_comm_destroy(c);
+    for (size_t d = 0; d < W; d++)
+        if (rcs[d] < 0) {
+            if (rcs[d] == MF_ERR_TOGETHER) continue;
+            die("%s", errs[d].c_str());                                          // (a file that cannot be read, ...: the reference's message)
+        }
+    for (size_t d = 0; d < W; d++) if (rcs[d] == MF_ERR_TOGETHER) { logmsg("WARN", "%s -- cutting the components on one device", errs[d].c_str()); return false; }
+    *nc = ncs[0];
+    return true;
+}
 static string run_component_cutter(Env &e, const Args &a, const vector<string> &files, int k, int l, int b1, int b2, const string &wd, const string &comp_file) {
     if (files.empty()) die("Mandatory option --sequences is not set");
+    {
+        mkdirs(wd);
+        const string stat = wd + "/components-stat-" + std::to_string(b1) + "-" + std::to_string(b2) + ".txt";
+        uint64_t nc = 0;
+        logmsg("DEBUG", "Loading sequences from files...");
+        if (run_component_cutter_sharded(e, a, files, k, l, b1, b2, comp_file, stat, &nc) && nc > 0) {
+            // (no component at all: the run below repeats the step on one device and says what the reference says -- "No sequences were found" or
+            // "No components were extracted" --, a case of toy inputs)
+            logmsg("INFO", "Searching for components...");
+            logmsg("INFO", "Total %s components were found", group_digits(nc).c_str());
+            logmsg("INFO", "Components saved to %s", comp_file.c_str());
+            return comp_file;
+        }
+    }
     mf_ctx *ctx = ctx_of(e, a);
     mf_table *t = nullptr;
     auto fp = cptrs(files);

@@ -1170,6 +1170,7 @@ __global__ __launch_bounds__(256) void k_dcc_pairs_out(const uint32_t *__restric
 extern "C" int mf_dcc_level_local(mf_dcc *D, uint64_t *counts) {
     if (!D || !counts) return mf_set_error("mf_dcc_level_local: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    if (ctx->opt_dcc_test_fail / 1000 == 2 && ++ctx->dcc_test_calls[2] == ctx->opt_dcc_test_fail % 1000) return mf_set_error("injected failure (option dcc_test_fail)");
     MF_HIP(hipSetDevice(ctx->device));
     const uint64_t n = D->n;
     if (n) {
@@ -1286,6 +1287,7 @@ __global__ void k_dcc_stats_emit(const uint32_t *__restrict__ touched, uint32_t 
 extern "C" int mf_dcc_merge(mf_dcc *D, const void *d_pairs, uint64_t n, uint64_t *n_stats) {
     if (!D || !n_stats || (n && !d_pairs)) return mf_set_error("mf_dcc_merge: NULL argument");
     mf_ctx *ctx = D->ctx; hipStream_t st = ctx->stream;
+    if (ctx->opt_dcc_test_fail / 1000 == 1 && ++ctx->dcc_test_calls[1] == ctx->opt_dcc_test_fail % 1000) return mf_set_error("injected failure (option dcc_test_fail)");
     MF_HIP(hipSetDevice(ctx->device));
     if (D->level == 0 || (n * 48 > D->n_total && !ctx->opt_dcc_sparse)) {                           // (random writes: only worth it when few ids occur)
         if (D->n_total) { mf_ktimer tm_(ctx, "k_dcc_iota"); k_dcc_iota<<<cgrid(D->n_total), 256, 0, st>>>(D->pg.p, D->gsize.p, D->gweight.p, D->n_total); }

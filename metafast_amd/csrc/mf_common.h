@@ -102,6 +102,7 @@ struct mf_ctx {
     int64_t opt_wide_passes = 0;   // mf_count_wide_device: passes over the reads, each for one prefix class of the canonical k-mers (0 = as many as the memory asks for; tests force a number)
     int64_t opt_cc_sparse = 1;     // component cutter: threshold levels that few vertices reach run on a list of them (0: every level visits all vertices)
     int64_t opt_dcc_sparse = 0;    // sharded cutter, levels after the first: 1 = always the sparse set-up of the arrays over all vertex ids (tests)
+    int64_t opt_dcc_test_fail = 0; int64_t dcc_test_calls[3] = {0, 0, 0};   // tests only: which * 1000 + n makes the n-th call of mf_dcc_merge (which = 1) / mf_dcc_level_local (2) on this context fail
     int64_t opt_nbr_global = 0;    // 1: neighbour lookups of the graph kernels through the HBM index only (A/B of mf_nbr.h)
     int64_t opt_scatter_fast = 1;  // k_skm_scatter: runs dealt evenly over the lanes through LDS where the level leaves room (0 = never)
     int64_t opt_ablate = 0;        // diagnostics only (tools/prof_count.py): results are WRONG when non-zero
@@ -255,6 +256,8 @@ struct mf_file_entry {
     size_t bytes = 0; uint64_t stamp = 0;
 };
 void mf_file_cache_clear(mf_ctx *ctx);
+mf_ctx *mf_comm_ctx(mf_comm *c);                 // (mf_comm.hip)
+int mf_comm_agree(mf_comm *c, int ok);           // every rank says whether it is fine: 0 when all are, else < 0 on every rank
 int mf_ensure_pin_pool(mf_ctx *ctx, size_t want);
 // a file's bytes to HBM as they are (pread into staging chunks by several threads + hipMemcpyAsync; mf_dparse.hip): 0 ok, 1 no staging memory, < 0 error
 int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_dst);

@@ -965,6 +965,32 @@ extern "C" int mf_cut_components(mf_ctx *ctx, mf_table *cutter, int k, int b1, i
     return rc;
 }
 
+// ComponentCutterMain.runImpl :78-114 over the ranks of a communicator (mf_comm.hip): every rank reads the .seq.fasta files of ITS libraries
+// (IOUtils.loadReads :81 -- the readers' part of it), the ranks cut the components together (mf_cut_components_sharded: the same object on every
+// rank), rank 0 writes components.bin and the statistics file, and every rank keeps the components in its context's file cache: the
+// features step of a library finds them in the HBM of the device that library lives on.
+extern "C" int mf_cut_components_sharded_files(mf_comm *cm, const char *const *seq_files, int nfiles, int k, int min_len, int b1, int b2,
+                                               const char *components_bin, const char *stat_txt, uint64_t *n_comp) {
+    mf_range rng_("mf:component_cutter(files, sharded)");
+    if (!cm || !components_bin || nfiles < 0 || (nfiles && !seq_files)) return mf_set_error("mf_cut_components_sharded_files: bad argument");
+    mf_ctx *ctx = mf_comm_ctx(cm);
+    // this rank's files.  A failure here must not leave the peers waiting in the exchange: every rank says how it went first
+    mf_reads *mine = nullptr;
+    const int rc_load = nfiles ? mf_reads_load(ctx, seq_files, nfiles, &mine) : MF_OK;
+    struct rguard { mf_reads *r; ~rguard() { if (r) mf_reads_destroy(r); } } rg{mine};
+    const std::string load_err = rc_load < 0 ? mf_last_error() : "";
+    if (mf_comm_agree(cm, rc_load == MF_OK) < 0) { if (rc_load < 0) { mf_set_error("%s", load_err.c_str()); return MF_ERR; } return MF_ERR_TOGETHER; }
+    mf_comps *c = nullptr;
+    MF_TRY(mf_cut_components_sharded(cm, mine ? mine->d_bases : nullptr, mine ? mine->d_offsets : nullptr, mine ? mine->n : 0, mine ? mine->n_bases : 0, k, min_len, b1, b2, &c));
+    struct cguard { mf_comps *p; ~cguard() { mf_comps_destroy(p); } } cg{c};
+    int rc = MF_OK;
+    if (mf_comm_rank(cm) == 0) rc = mf_comps_write(c, components_bin, stat_txt);
+    if (mf_comm_agree(cm, rc == MF_OK) < 0) return rc < 0 ? rc : MF_ERR_TOGETHER;      // (also the barrier behind the write: the file exists for every rank's cache entry)
+    file_cache_put(ctx, components_bin, nullptr, 0, c);
+    if (n_comp) *n_comp = c->n;
+    return MF_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // A12 feature files
 // ---------------------------------------------------------------------------------------------

@@ -49,6 +49,24 @@ _SIGS = {
     "mf_wcomps_stats": (i32, [vp, pu64, pu64]),
     "mf_wcomps_export": (i32, [vp, vp, vp, vp, vp, vp, vp]),
     "mf_features_wide_device": (i32, [vp, vp, vp, i32, vp, vp]),
+    "mf_comm_create_local": (i32, [vp, i32, vp]),
+    "mf_comm_rccl_id": (i32, [vp]),
+    "mf_comm_create_rccl": (i32, [vp, vp, i32, i32, pvp]),
+    "mf_comm_create_external": (i32, [vp, i32, i32, vp, vp, pvp]),
+    "mf_comm_destroy": (None, [vp]),
+    "mf_comm_rank": (i32, [vp]),
+    "mf_comm_world": (i32, [vp]),
+    "mf_comm_kind": (cp, [vp]),
+    "mf_comm_stat": (i64, [vp, cp]),
+    "mf_comm_reset_stats": (i32, [vp]),
+    "mf_comm_gather_ints": (i32, [vp, vp, i32, vp]),
+    "mf_comm_all_gather": (i32, [vp, vp, vp, vp]),
+    "mf_comm_all_to_all": (i32, [vp, vp, vp, vp, vp]),
+    "mf_comm_gather_sequences": (i32, [vp, vp, vp, u64, u64, pvp]),
+    "mf_cut_components_sharded": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, i32, pvp]),
+    "mf_cut_components_sharded_files": (i32, [vp, C.POINTER(cp), i32, i32, i32, i32, i32, cp, cp, pu64]),
+    "mf_cut_components_of_shard": (i32, [vp, vp, i32, i32, i32, pvp, vp]),
+    "mf_features_allgather": (i32, [vp, vp, u64, u64, vp, u64, pu64]),
     "mf_count_reads_above": (i32, [vp, C.POINTER(cp), i32, i32, i32, i32, pvp, pu64]),
     "mf_count_device": (i32, [vp, vp, vp, u64, u64, i32, i32, pvp]),
     "mf_count_device_above": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, pvp, pu64]),
@@ -131,6 +149,12 @@ class MetafastError(RuntimeError):
     """Mirrors ExecutionFailedException (itmo!/utils/tool/Tool.java:450-463)."""
 
 
+class DistAbort(MetafastError):
+    """MF_ERR_TOGETHER: a rank could not do its part of an exchange step; EVERY rank raises this from the same call (the status rides on
+    the integer gathers), so that all of them can take another route together instead of one rank raising while its peers wait inside
+    a collective"""
+
+
 def exported_symbols():
     """Every entry point declared in include/metafast_hip.h."""
     return sorted(_SIGS)
@@ -154,7 +178,7 @@ def lib():
 
 def _check(rc):
     if rc < 0:
-        raise MetafastError(lib().mf_last_error().decode(errors="replace"))
+        raise (DistAbort if rc == -2 else MetafastError)(lib().mf_last_error().decode(errors="replace"))
     return rc
 
 
@@ -177,6 +201,10 @@ class Context:
             self.set_stream(stream)
 
     def close(self):
+        c = getattr(self, "_mf_comm", None)             # (the communicator pipeline.py made for this context)
+        if c is not None:
+            self._mf_comm = None
+            c.close()
         if getattr(self, "h", None) and _lib is not None:
             _lib.mf_ctx_destroy(self.h)
         self.h = None
@@ -192,6 +220,10 @@ class Context:
         raw = getattr(stream, "cuda_stream", stream)
         _check(lib().mf_ctx_set_stream(self.h, C.c_void_p(int(raw) if raw else None)))
         self.stream_handle = int(raw) if raw else 0
+
+    def bind_thread(self):
+        """a thread other than the one that made the context calls this before its first call on it (HIP's current device is per thread)"""
+        _check(lib().mf_ctx_bind_thread(self.h))
 
     def set_option(self, name, value):
         _check(lib().mf_ctx_set_option(self.h, name.encode(), int(value)))
@@ -442,6 +474,175 @@ class WideTable:
             a, b, c, n = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_uint64()
             _check(lib().mf_wtable_piece_view(self.h, i, C.byref(a), C.byref(b), C.byref(c), C.byref(n)))
             out.append((a.value or 0, b.value or 0, c.value or 0, n.value))
+        return out
+
+
+class Reads:
+    """sequences in HBM (bases + offsets) that the library owns: mf_reads (here: the gathered unitigs of all ranks)"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None and getattr(self.ctx, "h", None):
+            _lib.mf_reads_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def stats(self):
+        n, nb = C.c_uint64(), C.c_uint64()
+        _check(lib().mf_reads_stats(self.h, C.byref(n), C.byref(nb)))
+        return n.value, nb.value
+
+    def device_view(self):
+        b, o = C.c_void_p(), C.c_void_p()
+        _check(lib().mf_reads_device_view(self.h, C.byref(b), C.byref(o)))
+        n, nb = self.stats()
+        return dict(bases=b.value or 0, offsets=o.value or 0, n=n, n_bases=nb)
+
+    def export(self):
+        n, nb = self.stats()
+        bases = np.empty(nb, dtype=np.uint8)
+        off = np.empty(n + 1, dtype=np.uint64)
+        _check(lib().mf_reads_export(self.h, bases.ctypes.data, off.ctypes.data))
+        return bases, off
+
+
+_OPS_GATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_int64))
+_OPS_ALLGATHER = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64))
+_OPS_ALLTOALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+
+
+class _CommOps(C.Structure):
+    _fields_ = [("gather_ints", _OPS_GATHER), ("all_gather", _OPS_ALLGATHER), ("all_to_all", _OPS_ALLTOALL)]
+
+
+class Comm:
+    """mf_comm (include/metafast_hip.h): the exchanges of the multi-GPU path behind the C-ABI.  local(): one communicator per context for
+    threads of this process; rccl(): one process per GPU; external(): the caller's own primitives (torch.distributed in pipeline.py)."""
+
+    def __init__(self, ctx, h, keep=None):
+        self.ctx, self.h, self._keep = ctx, h, keep
+        self.rank, self.world = lib().mf_comm_rank(h), lib().mf_comm_world(h)
+        self.kind = lib().mf_comm_kind(h).decode()
+
+    def close(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.mf_comm_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def local(ctxs):
+        n = len(ctxs)
+        arr = (C.c_void_p * n)(*[c.h for c in ctxs])
+        out = (C.c_void_p * n)()
+        _check(lib().mf_comm_create_local(arr, n, out))
+        return [Comm(ctxs[r], C.c_void_p(out[r])) for r in range(n)]
+
+    @staticmethod
+    def rccl_id():
+        buf = C.create_string_buffer(128)
+        _check(lib().mf_comm_rccl_id(buf))
+        return buf.raw
+
+    @staticmethod
+    def rccl(ctx, id128, rank, world):
+        h = C.c_void_p()
+        _check(lib().mf_comm_create_rccl(ctx.h, C.c_char_p(bytes(id128)), rank, world, C.byref(h)))
+        return Comm(ctx, h)
+
+    @staticmethod
+    def external(ctx, rank, world, gather_ints, all_gather, all_to_all):
+        """gather_ints(list of int) -> int64 array [world, n]; all_gather(d_send, d_recv, bytes[world]); all_to_all(d_send, send_bytes[world],
+        d_recv, recv_bytes[world]) -- device pointers as ints, the data has arrived when the call returns"""
+        def _g(user, vals, n, out):
+            try:
+                m = np.asarray(gather_ints([int(vals[i]) for i in range(n)]), dtype=np.int64).reshape(-1)
+                for i in range(world * n):
+                    out[i] = int(m[i])
+                return 0
+            except Exception as e:              # (a C caller sees a status, not a Python exception)
+                print("[metafast_amd] external gather_ints failed: %r" % (e,), file=__import__("sys").stderr)
+                return -1
+
+        def _ag(user, d_send, d_recv, nb):
+            try:
+                all_gather(d_send or 0, d_recv or 0, [int(nb[r]) for r in range(world)])
+                return 0
+            except Exception as e:
+                print("[metafast_amd] external all_gather failed: %r" % (e,), file=__import__("sys").stderr)
+                return -1
+
+        def _aa(user, d_send, sb, d_recv, rb):
+            try:
+                all_to_all(d_send or 0, [int(sb[r]) for r in range(world)], d_recv or 0, [int(rb[r]) for r in range(world)])
+                return 0
+            except Exception as e:
+                print("[metafast_amd] external all_to_all failed: %r" % (e,), file=__import__("sys").stderr)
+                return -1
+        ops = _CommOps(_OPS_GATHER(_g), _OPS_ALLGATHER(_ag), _OPS_ALLTOALL(_aa))
+        h = C.c_void_p()
+        _check(lib().mf_comm_create_external(ctx.h, rank, world, C.byref(ops), None, C.byref(h)))
+        return Comm(ctx, h, keep=ops)
+
+    def stats(self):
+        return dict(collectives=int(lib().mf_comm_stat(self.h, b"collectives")), bytes_in=int(lib().mf_comm_stat(self.h, b"bytes_in")),
+                    seconds=lib().mf_comm_stat(self.h, b"us") / 1e6)
+
+    def reset_stats(self):
+        _check(lib().mf_comm_reset_stats(self.h))
+
+    def gather_ints(self, vals):
+        v = np.ascontiguousarray(vals, dtype=np.int64)
+        out = np.zeros((self.world, len(v)), dtype=np.int64)
+        _check(lib().mf_comm_gather_ints(self.h, v.ctypes.data, len(v), out.ctypes.data))
+        return out
+
+    def all_gather(self, d_send, d_recv, bytes_per_rank):
+        b = np.ascontiguousarray(bytes_per_rank, dtype=np.uint64)
+        _check(lib().mf_comm_all_gather(self.h, C.c_void_p(d_send), C.c_void_p(d_recv), b.ctypes.data))
+
+    def all_to_all(self, d_send, send_bytes, d_recv, recv_bytes):
+        sb = np.ascontiguousarray(send_bytes, dtype=np.uint64); rb = np.ascontiguousarray(recv_bytes, dtype=np.uint64)
+        _check(lib().mf_comm_all_to_all(self.h, C.c_void_p(d_send), sb.ctypes.data, C.c_void_p(d_recv), rb.ctypes.data))
+
+    def gather_sequences(self, d_bases, d_offsets, n_seqs, n_bases):
+        """every rank's sequences on every rank, rank after rank -> Reads"""
+        h = C.c_void_p()
+        _check(lib().mf_comm_gather_sequences(self.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_seqs, n_bases, C.byref(h)))
+        return Reads(self.ctx, h)
+
+    def cut_components_sharded(self, d_bases, d_offsets, n_seqs, n_bases, k, min_len, b1, b2):
+        """ComponentCutterMain.runImpl over all ranks in one call (this rank's sequences in, the same Comps on every rank out)"""
+        c = C.c_void_p()
+        _check(lib().mf_cut_components_sharded(self.h, C.c_void_p(d_bases), C.c_void_p(d_offsets), n_seqs, n_bases, k, min_len, b1, b2, C.byref(c)))
+        return Comps(self.ctx, c)
+
+    def cut_components_of_shard(self, shard, k, b1, b2):
+        """... on a shard the caller has counted (None: this rank has none; all ranks raise DistAbort) -> (Comps, info)"""
+        c = C.c_void_p()
+        info = np.zeros(4, dtype=np.uint64)
+        _check(lib().mf_cut_components_of_shard(self.h, shard.h if shard is not None else None, k, b1, b2, C.byref(c), info.ctypes.data))
+        return Comps(self.ctx, c), dict(levels=int(info[0]), queries=int(info[1]), members=int(info[2]), vertices=int(info[3]))
+
+    def features_allgather(self, rows):
+        """rows int64[n_local_samples, C] -> int64[n_all_samples, C], rank-major"""
+        rows = np.ascontiguousarray(rows, dtype=np.int64).reshape(len(rows), -1)
+        n = C.c_uint64()
+        _check(lib().mf_features_allgather(self.h, rows.ctypes.data, rows.shape[0], rows.shape[1], None, 0, C.byref(n)))
+        out = np.zeros((n.value, rows.shape[1]), dtype=np.int64)
+        _check(lib().mf_features_allgather(self.h, rows.ctypes.data, rows.shape[0], rows.shape[1], out.ctypes.data, n.value, C.byref(n)))
         return out
 
 

@@ -234,325 +234,55 @@ class TorchComm:
         return out
 
 
-class ThreadGroup:
-    """W virtual ranks inside ONE process (one thread each, all on the same GPU): the distributed cutter end to end on a
-    1-GPU box -- tests and tools/sim_union.py.  serial=True lets only one rank compute at a time (clean per-rank timings)."""
-
-    def __init__(self, world, serial=True):
-        import threading
-        self.world, self.slots = world, [None] * world
-        self.barrier = threading.Barrier(world)
-        self.turn = threading.Lock() if serial else None
+DistAbort = L.DistAbort        # (every rank raises it from the same call: see lib.DistAbort)
 
 
-class ThreadComm:
-    def __init__(self, group, rank):
-        self.g, self.rank, self.world = group, rank, group.world
-        self.waited = 0.0            # seconds spent waiting for the other ranks (not this rank's work)
-        self.stats = dict(collectives=0, bytes_in=0)          # (as TorchComm.stats: what the protocol exchanged)
-        if group.turn:
-            group.turn.acquire()
+def make_comm(ctx, device="cuda"):
+    """The communicator of this rank (mf_comm, include/metafast_hip.h): the exchange steps of the path run INSIDE the library on it.
+    One process per GPU under torch.distributed: the library's own RCCL communicator (mf_comm_create_rccl; rank 0's id travels through
+    torch's process group, which is only the rendezvous) -- or, with the gloo backend (tests: several ranks on one GPU) or MF_COMM=torch,
+    an external communicator whose three primitives are TorchComm's.  A single process: a local communicator of one rank."""
+    rank, world = _world()
+    if not (dist.is_available() and dist.is_initialized()):
+        return L.Comm.local([ctx])[0]
+    backend = dist.get_backend()
+    if backend == "nccl" and os.environ.get("MF_COMM", "rccl") != "torch":
+        ids = [L.Comm.rccl_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        return L.Comm.rccl(ctx, ids[0], rank, world)
+    tc = TorchComm()
+    dev = torch.device(device) if not isinstance(device, torch.device) else device
 
-    def done(self):
-        if self.g.turn:
-            self.g.turn.release()
+    def gather_ints(vals):
+        return tc.all_gather_ints(vals)
 
-    def _exchange(self, x):
-        g = self.g
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        g.slots[self.rank] = x
-        tw = time.perf_counter()
-        if g.turn:
-            g.turn.release()
-        try:
-            g.barrier.wait()
-            out = list(g.slots)
-            g.barrier.wait()
-        finally:
-            if g.turn:
-                g.turn.acquire()
-        self.waited += time.perf_counter() - tw
-        return out
+    def all_gather(d_send, d_recv, nbytes):
+        send = device_tensor(d_send, nbytes[rank], dev)
+        out = tc.all_gather(send, nbytes)
+        if sum(nbytes):
+            device_tensor(d_recv, sum(nbytes), dev).copy_(out)
+        torch.cuda.current_stream().synchronize()
 
-    def _timed(self, fn):
-        """self.exchange: seconds this rank spent inside the exchanges (their copies; waiting for the others excluded)"""
-        t0, w0 = time.perf_counter(), self.waited
-        out = fn()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
-        self.exchange = getattr(self, "exchange", 0.0) + (time.perf_counter() - t0) - (self.waited - w0)
-        self.stats["collectives"] += 1
-        self.stats["bytes_in"] += int(out.numel() * out.element_size()) if torch.is_tensor(out) else int(out.nbytes)
-        return out
+    def all_to_all(d_send, sb, d_recv, rb):
+        send = device_tensor(d_send, sum(sb), dev)
+        out = tc.all_to_all_v(send, sb, rb)
+        if sum(rb):
+            device_tensor(d_recv, sum(rb), dev).copy_(out)
+        torch.cuda.current_stream().synchronize()
 
-    def all_gather_ints(self, vals):
-        return self._timed(lambda: np.asarray(self._exchange([int(v) for v in vals]), dtype=np.int64).reshape(self.world, -1))
-
-    def all_gather(self, t, sizes):
-        return self._timed(lambda: torch.cat(self._exchange(t)))
-
-    def all_reduce_min(self, t):
-        return self._timed(lambda: torch.stack(self._exchange(t)).min(dim=0).values)
-
-    def all_to_all(self, t, matrix):
-        def f():
-            parts = self._exchange(t)
-            out = []
-            for r in range(self.world):
-                o = int(sum(matrix[r][:self.rank]))
-                out.append(parts[r][o:o + int(matrix[r][self.rank])])
-            return torch.cat(out)
-        return self._timed(f)
-
-
-    def all_to_all_v(self, t, send, recv):
-        def f():
-            parts = self._exchange((t, [int(x) for x in send]))
-            out = []
-            for r in range(self.world):
-                pt, ps = parts[r]
-                o = int(sum(ps[:self.rank]))
-                assert ps[self.rank] == int(recv[r]), "all_to_all_v: rank %d sends %d, rank %d expects %d" % (r, ps[self.rank], self.rank, int(recv[r]))
-                out.append(pt[o:o + ps[self.rank]])
-            return torch.cat(out)
-        return self._timed(f)
-
-
-def _i64(n, device):
-    return _alloc(lambda: torch.empty(max(int(n), 1), dtype=torch.int64, device=device))
-
-
-class DistAbort(L.MetafastError):
-    """a rank could not do its part of the sharded cutter; EVERY rank raises this at the same point of the protocol (the status
-    rides on the integer gathers), so that all of them can take the replicated path together instead of one rank raising
-    while its peers wait inside a collective"""
+    return L.Comm.external(ctx, rank, world, gather_ints, all_gather, all_to_all)
 
 
 def distributed_components(ctx, comm, shard, k, b1, b2, device="cuda", timings=None, info=None):
-    """Component cutter with every rank owning a shard of the cutter table (include/metafast_hip.h, "A9-A11 on several
-    GPUs").  shard: this rank's Context.count_device_shard of all samples' unitigs (None: the count failed here -- the
-    ranks then raise DistAbort together).  Returns the components: the same object on every rank, identical to
-    cut_components on the whole table (ComponentsBuilder.splitStrategy, src/algo/ComponentsBuilder.java:24-32).
-
-    Collectives: 1 + 3 once (shard sizes; query counts, queries, answers), then per threshold level 2 integer gathers (half
-    pairs per destination + the level before's oversize count; records per rank) + 1 all-to-all (half pairs) + 2 all-gathers (completed pairs; per-component
-    records) -- from the gathered records EVERY rank derives all kept components and the number of oversize ones itself
-    (round 2: three more collectives per level for lists every rank could compute) --, and 2 + 1 + 1 at the end (members'
-    k-mers and roots, their count, the components' smallest k-mers)."""
-    W, me = comm.world, comm.rank
-    t0, w0 = time.perf_counter(), getattr(comm, "waited", 0.0)
-    err = []                                 # the first library error on this rank: announced with the next integer gather
-
-    def buf(n, _device=None):
-        """an exchange buffer of n int64; on a rank whose library call has failed it is ZEROED: the rank keeps the collectives going with
-        buffers of the agreed sizes until the next status gather, and what its healthy peers read from them meanwhile must be in-range
-        indices and ranks, not whatever the allocator left there"""
-        return _alloc(lambda: torch.zeros(max(int(n), 1), dtype=torch.int64, device=device)) if err else _i64(n, device)
-
-    def mark(name):
-        nonlocal t0, w0
-        if timings is not None:
-            torch.cuda.synchronize()
-            t1, w1 = time.perf_counter(), getattr(comm, "waited", 0.0)
-            timings[name] = timings.get(name, 0.0) + (t1 - t0) - (w1 - w0)      # (virtual ranks: the others' turns are not this rank's time)
-            t0, w0 = t1, w1
-
-    # torch fills the exchange buffers on ITS current stream, the library reads and writes them on the context's: a stream synchronisation stands
-    # between the two -- unless they are the same stream (bench.py, run_samples' callers: the context was made with torch's current stream), where
-    # the order is the stream's own (round 5: eight host waits per threshold level less)
-    same_stream = getattr(ctx, "stream_handle", None) is not None and torch.cuda.is_available() and ctx.stream_handle == int(torch.cuda.current_stream().cuda_stream)
-
-    def sync():
-        if not same_stream:
-            torch.cuda.current_stream().synchronize()
-
-    def call(fn, default=None):
-        """a library call that may fail (memory on ONE rank, a capacity limit): after the first failure this rank only keeps the
-        collectives going (buffers of the agreed sizes, contents irrelevant) until the next integer gather tells everybody"""
-        if err:
-            return default
-        try:
-            return fn()
-        except L.MetafastError as e:
-            err.append(e)
-            return default
-
-    def gather_ints(vals, n):
-        """all_gather_ints with the status in front; vals: callable -> n integers"""
-        v = call(lambda: [int(x) for x in vals()], None)
-        m = comm.all_gather_ints([0 if err else 1] + (v if v is not None else [0] * n))
-        if not m[:, 0].all():
-            bad = [int(r) for r in np.nonzero(m[:, 0] == 0)[0]]
-            raise DistAbort("sharded component cutter: rank(s) %s failed%s" % (bad, (": %s" % err[0]) if err else ""))
-        return m[:, 1:]
-
-    if shard is None:
-        err.append(L.MetafastError("no shard"))
-    ns = gather_ints(lambda: [len(shard)], 1)[:, 0]
-    base = np.concatenate([[0], np.cumsum(ns)])
-    if int(base[-1]) >= 0xFFFFFFFF:
-        raise L.MetafastError("components: more than 2^32 vertices over all ranks is not supported")      # (every rank sees the same total)
-    D = call(lambda: L.DistCutter(ctx, shard, me, W, base))
-    try:
-        # ---- neighbours in other shards
-        qm = gather_ints(lambda: D.queries(), W)
-        nq = int(qm[me].sum())
-        q = buf(2 * nq, device); sync()
-        call(lambda: D.queries_fill(q.data_ptr()))
-        rq = comm.all_to_all(q[:2 * nq], 2 * qm); sync()
-        na = int(rq.numel()) // 2
-        a = buf(2 * na, device); sync()
-        call(lambda: D.answer(rq.data_ptr(), na, a.data_ptr()))
-        ra = comm.all_to_all(a[:2 * na], 2 * qm.T); sync()
-        call(lambda: D.set_answers(ra.data_ptr(), nq))
-        del q, rq, a, ra
-        mark("cutter_adjacency")
-        # ---- threshold levels (ComponentsBuilder.java:86-150)
-        # Round 5: the sizes of a level's exchanges ride IN BAND where the level before bounds them.
-        #  * per-component records: every rank's slice has the capacity 2 x its count of the level before + 1024 and says its real
-        #    count in the slice's first record (a count beyond the capacity -- components can split -- is answered by ONE more
-        #    all-gather with the sizes everybody has just read): the integer gather of round 4 is gone from every level but the first;
-        #  * half pairs: a cross edge only ever dies, so a level's counts are bounded by the level before's.  Once a level's pairs are
-        #    few (MF_DCC_INBAND_MAX, 2^20 = 8 MB over all ranks: the latency of a collective then costs more than the padding), the
-        #    all-to-all and the all-gather of the pairs keep the split sizes of the last level that was counted, unused room is filled
-        #    with a pair no kernel takes (0xFFFFFFFF, 0xFFFFFFFF), and the status every rank owes its peers travels in the slices' first
-        #    element: no integer gather at all, 3 collectives per level (5 in round 4), and the host reads the result of a collective
-        #    twice per level (the status, the records' counts) where it read it five times.
-        inband_max = int(os.environ.get("MF_DCC_INBAND_MAX", str(1 << 20)))
-        stat_mul, stat_add = (int(x) for x in os.environ.get("MF_DCC_STATS_ROOM", "2,1024").split(","))      # (tests: "0,0" makes every level overflow its room)
-        SENT = -1                                                    # int64 view of the pair (0xFFFFFFFF, 0xFFFFFFFF)
-        kept, levels, per_level = [], 0, []
-        n_big = -1
-        cap_send = cap_recv = cap_tot = None                         # split sizes of the last COUNTED level: to each rank / from each rank / every rank's total
-        prev_nstat = None                                            # every rank's record count of the level before
-        host_reads = 0
-
-        def stats_exchange(n_stats):
-            """all ranks' per-component records, rank order, contiguous; -> (tensor, counts per rank)"""
-            nonlocal host_reads
-            if prev_nstat is None:                                   # (the first level: nothing bounds the counts yet)
-                sm = gather_ints(lambda: [n_stats], 1)[:, 0]
-                st = buf(2 * n_stats, device); sync()
-                call(lambda: D.stats_fill(st.data_ptr()))
-                alls = comm.all_gather(st[:2 * n_stats], 2 * sm); sync()
-                host_reads += 1
-                return alls, sm
-            caps = [stat_mul * int(x) + stat_add for x in prev_nstat]
-            st = buf(2 * max(n_stats, 1), device); sync()
-            call(lambda: D.stats_fill(st.data_ptr()))
-            mine = _alloc(lambda: torch.zeros(2 * (caps[me] + 1), dtype=torch.int64, device=device))
-            mine[0] = -1 if err else n_stats                         # (a failed rank says so here)
-            m = min(n_stats, caps[me]) if not err else 0
-            mine[2:2 + 2 * m] = st[:2 * m]
-            allg = comm.all_gather(mine, [2 * (c + 1) for c in caps]); sync()
-            starts = np.concatenate([[0], np.cumsum([2 * (c + 1) for c in caps])])
-            sm = allg[torch.as_tensor(starts[:-1], device=allg.device)].cpu().numpy(); host_reads += 1
-            if (sm < 0).any():
-                raise DistAbort("sharded component cutter: rank(s) %s failed%s" % ([int(r) for r in np.nonzero(sm < 0)[0]], (": %s" % err[0]) if err else ""))
-            if any(int(sm[r]) > caps[r] for r in range(W)):          # (rare: a level that splits one component into thousands) -- the sizes are known now
-                alls = comm.all_gather(st[:2 * n_stats], 2 * sm); sync()
-                return alls, sm
-            alls = torch.cat([allg[int(starts[r]) + 2: int(starts[r]) + 2 + 2 * int(sm[r])] for r in range(W)]) if int(sm.sum()) else allg[:0]
-            return alls, sm
-
-        for thr in range(1, 1 << 16):
-            inband = cap_tot is not None and int(np.sum(cap_tot)) <= inband_max and n_big > 0
-            mode = "in-band" if inband else "counted"
-            if not inband:
-                # (the gather that opens a counted level also closes the one before: it carries that level's oversize count -- the same on
-                # every rank -- and the status of the calls since the last gather, so all ranks leave the loop, or abort, together)
-                pm = gather_ints(lambda: [n_big] + ([int(x) for x in D.level_local()] if n_big else [0] * W), W + 1)
-                host_reads += 1
-                if len(set(int(x) for x in pm[:, 0])) != 1:         # (every rank derives the count from the same gathered records)
-                    raise DistAbort("sharded component cutter: the ranks disagree on a level's oversize components: %s" % [int(x) for x in pm[:, 0]])
-                if int(pm[me][0]) == 0:
-                    break
-                pm = pm[:, 1:]
-                nsend = int(pm[me].sum())
-                hp = buf(nsend, device); sync()
-                call(lambda: D.pairs_fill(hp.data_ptr()))
-                rp = comm.all_to_all(hp[:nsend], pm); sync()
-                nr = int(rp.numel())
-                if nr:
-                    rp = rp.contiguous()
-                    call(lambda: D.pairs_complete(rp.data_ptr(), nr))
-                allp = comm.all_gather(rp, pm.sum(axis=0)); sync()
-                cap_send, cap_recv, cap_tot = pm[me].copy(), pm[:, me].copy(), pm.sum(axis=0)
-            else:
-                cnt = call(lambda: [int(x) for x in D.level_local()], [0] * W)
-                nsend = int(sum(cnt))
-                hp = buf(nsend, device); sync()
-                call(lambda: D.pairs_fill(hp.data_ptr()))
-                send = [int(c) + 1 for c in cap_send]               # (one status element in front of every slice)
-                out = _alloc(lambda: torch.full((sum(send),), SENT, dtype=torch.int64, device=device))
-                so, po = 0, 0
-                for d in range(W):
-                    c = cnt[d] if not err else 0
-                    if c > int(cap_send[d]):
-                        err.append(L.MetafastError("sharded component cutter: %d half pairs for rank %d, %d at the level before" % (c, d, int(cap_send[d]))))
-                        c = 0
-                    out[so] = 0 if err else 1
-                    if c:
-                        out[so + 1: so + 1 + c] = hp[po: po + c]
-                    so += send[d]; po += cnt[d]
-                if err:                                              # (a failure found while filling: every slice says so)
-                    so = 0
-                    for d in range(W):
-                        out[so] = 0; so += send[d]
-                recv = [int(c) + 1 for c in cap_recv]
-                rp = comm.all_to_all_v(out, send, recv); sync()
-                heads = np.concatenate([[0], np.cumsum(recv)])[:-1]
-                ht = torch.as_tensor(heads, device=rp.device)
-                status = rp[ht].cpu().numpy(); host_reads += 1
-                if not (status == 1).all():
-                    raise DistAbort("sharded component cutter: rank(s) %s failed%s" % ([int(r) for r in np.nonzero(status != 1)[0]], (": %s" % err[0]) if err else ""))
-                rp = rp.contiguous()
-                rp[ht] = SENT                                        # (the status elements become pairs nobody takes)
-                nr = int(rp.numel())
-                call(lambda: D.pairs_complete(rp.data_ptr(), nr))
-                allp = comm.all_gather(rp, [int(c) + W for c in cap_tot]); sync()
-            n_stats = call(lambda: D.merge(allp.data_ptr(), int(allp.numel())), 0)
-            alls, sm = stats_exchange(n_stats)
-            prev_nstat = sm
-            seg = np.concatenate([[0], np.cumsum(sm)])
-            alls = alls.contiguous()
-            n_kept, n_big = call(lambda: D.classify(alls.data_ptr(), int(alls.numel()) // 2, seg, n_stats, b1, b2, thr, me), (0, 0))
-            kb = buf(2 * n_kept, device); sync()
-            call(lambda: D.kept_fill(kb.data_ptr()))
-            allk = kb[:2 * n_kept].cpu().numpy()
-            if allk.size:
-                r = allk.reshape(-1, 2)
-                r = r[np.argsort(r[:, 0] & 0xFFFFFFFF, kind="stable")]        # by root: the order every rank agrees on
-                kept.append((r[:, 0] & 0xFFFFFFFF, (r[:, 0] >> 32) & 0xFFFFFFFF, r[:, 1], np.full(len(r), thr, dtype=np.int32)))
-            levels = thr
-            per_level.append((int(allp.numel()), int(sm.sum()), int(n_kept), int(n_big), mode))
-            if inband and n_big == 0:
-                break                                                # (every rank has derived the same count from the same records; the members' gather below carries the status)
-        mark("cutter_levels")
-        # ---- members of the kept components, everywhere
-        # ---- members of the kept components, everywhere: 8 bytes per member (the k-mers, sorted by component on the rank) + one
-        # (root, count) record per component and rank
-        nm, nr = call(lambda: D.members_grouped(), (0, 0))
-        mm = gather_ints(lambda: [nm, nr], 2)
-        mk = buf(nm, device); mr = buf(nr, device); sync()
-        call(lambda: D.members_grouped_fill(mk.data_ptr(), mr.data_ptr()))
-        allmk = comm.all_gather(mk[:nm], mm[:, 0]); allmr = comm.all_gather(mr[:nr], mm[:, 1]); sync()
-        cat = (lambda i, dt: np.concatenate([x[i] for x in kept]).astype(dt)) if kept else (lambda i, dt: np.zeros(0, dtype=dt))
-        roots = cat(0, np.uint32)
-        mn = buf(len(roots), device); sync()
-        call(lambda: D.minkeys(roots, mn.data_ptr()))
-        mn = comm.all_reduce_min(mn[:len(roots)]).cpu().numpy().astype(np.uint64)
-        comps = call(lambda: D.finish_grouped(allmk.data_ptr(), int(allmk.numel()), allmr.data_ptr(), int(allmr.numel()), roots, cat(1, np.uint32),
-                                              cat(2, np.int64), cat(3, np.int32), mn))
-        gather_ints(lambda: [len(comps)], 1)          # (the last status: every rank has its components, or all raise)
-        if info is not None:
-            info.update(levels=levels, per_level=per_level, shard=int(ns[me]), vertices=int(base[-1]), queries=nq, members=int(allmk.numel()), host_reads_in_levels=host_reads,
-                        collectives=int(comm.stats["collectives"]), MB_received=round(comm.stats["bytes_in"] / 1e6, 2))
-    finally:
-        if D is not None:
-            D.close()
-    mark("cutter_members")
+    """Component cutter with every rank owning a shard of the cutter table (include/metafast_hip.h, "A9-A11 on several GPUs"): since
+    round 6 the exchange protocol runs inside the library (mf_cut_components_of_shard, mf_comm.hip) on `comm` (lib.Comm).  shard: this
+    rank's Context.count_device_shard of all samples' unitigs (None: the count failed here -- the ranks then raise DistAbort
+    together).  Returns the components: the same object on every rank, identical to cut_components on the whole table
+    (ComponentsBuilder.splitStrategy, src/algo/ComponentsBuilder.java:24-32)."""
+    comps, inf = comm.cut_components_of_shard(shard, k, b1, b2)
+    if info is not None:
+        st = comm.stats()
+        info.update(inf, shard=len(shard) if shard is not None else 0, collectives=st["collectives"], MB_received=round(st["bytes_in"] / 1e6, 2))
     return comps
 
 
@@ -600,7 +330,6 @@ def _run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda
             t0 = t1
 
     goods, seqss, hists, n_occ, n_distinct = [], [], [], 0, 0
-    comm_stats = dict(collectives=0, bytes_in=0, seconds=0.0)
     for si, sample in enumerate(samples):
         if si:
             # several samples on this rank: the previous sample's lookup index (3-6 times its table) is not needed again before
@@ -625,70 +354,73 @@ def _run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda
         goods.append(good); n_occ += good.occurrences(); n_distinct += nd
     # this rank's unitigs, all samples one after the other
     views = [sq.device_view() for sq in seqss]
-    parts_b = [device_tensor(v["bases"], v["n_bases"], device) for v in views]
-    parts_o, nb = [], 0
-    for v in views:
-        parts_o.append(device_tensor(v["offsets"], (v["n"] + 1) * 8, device).view(torch.int64)[:-1] + nb)
-        nb += v["n_bases"]
     ctx.synchronize()
+    keep = None
     if len(views) == 1:
-        sb, so = parts_b[0], device_tensor(views[0]["offsets"], (views[0]["n"] + 1) * 8, device).view(torch.int64)
+        v = views[0]
+        sb, so, ns_l, nb_l = v["bases"] or 0, v["offsets"] or 0, v["n"], v["n_bases"]
     else:
-        sb = _with_room(ctx, lambda: torch.cat(parts_b) if parts_b else torch.zeros(0, dtype=torch.uint8, device=device))
-        so = _with_room(ctx, lambda: torch.cat(parts_o + [torch.tensor([nb], dtype=torch.int64, device=device)]))
-    rank, world = _world()
-    sharded = (world > 1 or _force()) and k >= 20 and world & (world - 1) == 0 and world <= 64 and not os.environ.get("MF_REPLICATED_CUTTER")
-    if sharded:
-        # every rank owns a shard of the cutter table and of the components step (distributed_components)
-        allb, allo, ns, nbt = gather_sequences(sb, so)
+        parts_b = [device_tensor(v["bases"], v["n_bases"], device) for v in views]
+        parts_o, nb_l = [], 0
+        for v in views:
+            parts_o.append(device_tensor(v["offsets"], (v["n"] + 1) * 8, device).view(torch.int64)[:-1] + nb_l)
+            nb_l += v["n_bases"]
+        tb = _with_room(ctx, lambda: torch.cat(parts_b + [torch.zeros(64, dtype=torch.uint8, device=device)]))
+        to = _with_room(ctx, lambda: torch.cat(parts_o + [torch.tensor([nb_l], dtype=torch.int64, device=device)]))
         torch.cuda.current_stream().synchronize()
-        mark("exchange_unitigs")
-        comm = TorchComm()
+        keep = (tb, to)
+        sb, so, ns_l = tb.data_ptr(), to.data_ptr(), int(to.numel()) - 1
+    rank, world = _world()
+    # the exchanges run inside the library on this rank's communicator (mf_comm): the sequences of all ranks, the sharded cutter, the rows
+    comm = getattr(ctx, "_mf_comm", None)                      # (made once per context: an RCCL communicator costs a rendezvous)
+    if comm is None or comm.h is None:
+        comm = ctx._mf_comm = make_comm(ctx, device)
+    comm.reset_stats()
+    allr = comm.gather_sequences(sb, so, ns_l, nb_l)            # every rank's unitigs on every rank (ComponentCutterMain.java:81 over all libraries)
+    av = allr.device_view()
+    del keep
+    mark("exchange_unitigs")
+    n_all = int(comm.gather_ints([len(goods)]).sum())
+    sharded = (world > 1 or _force()) and k >= 20 and world & (world - 1) == 0 and world <= 64 and not os.environ.get("MF_REPLICATED_CUTTER")
+    cutter = comps = None
+    if sharded:
+        # every rank owns a shard of the cutter table and of the components step (mf_cut_components_of_shard)
         try:
-            cutter = ctx.count_device_shard(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l, rank, world)
+            cutter = ctx.count_device_shard(av["bases"], av["offsets"], av["n"], av["n_bases"], k, l, rank, world)
         except L.MetafastError:
             cutter = None                    # (e.g. a partition too rich for the shard path on this rank: the ranks agree below)
         mark("cutter_count")
         try:
-            comps = distributed_components(ctx, comm, cutter, k, b1, b2, device=device, timings=timings)
+            comps = distributed_components(ctx, comm, cutter, k, b1, b2, device=device)
         except DistAbort as e:
             # all ranks are here together: the replicated cutter instead (every rank counts all unitigs and cuts all components)
             print("[metafast_amd] %s -- every rank builds the whole cutter table" % e, file=sys.stderr)
             if cutter is not None:
                 cutter.close()
-            ctx.set_option("union_samples", int(comm.all_gather_ints([len(goods)]).sum()))
-            try:
-                cutter = ctx.count_device(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l)
-            finally:
-                ctx.set_option("union_samples", 0)
-            comps = ctx.cut_components(cutter, b1, b2)
-        comm_stats = comm.stats
-        t0 = time.perf_counter()
-    else:
-        # (world sizes that are not a power of two, k < 20: every rank builds the whole cutter table and all components)
-        allb, allo, ns, nbt = gather_sequences(sb, so)
-        if torch.cuda.is_available():
-            torch.cuda.current_stream().synchronize()
-        mark("exchange_unitigs")
-        n_all = int(TorchComm().all_gather_ints([len(goods)]).sum())
+            cutter = None
+        mark("components")
+    if comps is None:
+        # (world sizes that are not a power of two, k < 20, a rank that could not do its part: every rank builds the whole cutter table)
         ctx.set_option("union_samples", n_all)          # (planning hint: many samples share most of their unitig k-mers)
         try:
-            cutter = ctx.count_device(allb.data_ptr(), allo.data_ptr(), ns, nbt, k, l)
+            cutter = ctx.count_device(av["bases"], av["offsets"], av["n"], av["n_bases"], k, l)
         finally:
             ctx.set_option("union_samples", 0)
         mark("cutter_count")
         comps = ctx.cut_components(cutter, b1, b2)
         mark("components")
+    allr.close()
     vecs_local, breadths = [], []
     for good in goods:
         vec, breadth = ctx.features(comps, good, 0)
         if len(goods) > 1:
             good.drop_index()
         vecs_local.append(vec); breadths.append(breadth)
-    vt = torch.from_numpy(np.stack(vecs_local) if vecs_local else np.zeros((0, len(comps)), dtype=np.int64)).to(device)
-    vecs = gather_vector_rows(vt).cpu().numpy()
+    rows = np.stack(vecs_local) if vecs_local else np.zeros((0, len(comps)), dtype=np.int64)
+    vecs = comm.features_allgather(rows)                        # north_star's all-gather of the per-sample feature vectors
     matrix = L.bray_curtis(vecs) if vecs.shape[1] else np.zeros((vecs.shape[0], vecs.shape[0]))
     mark("features_matrix")
+    comm_stats = dict(comm.stats(), kind=comm.kind)
     return dict(goods=goods, seqss=seqss, cutter=cutter, comps=comps, vecs_local=vecs_local, breadths=breadths, vecs=vecs,
                 matrix=matrix, n_occ=n_occ, n_distinct=n_distinct, hists=hists, comm=comm_stats)
 

@@ -30,4 +30,7 @@ int mf_device_count(void) { return 2; }             /* (two entries: the driver'
 int mf_ctx_bind_thread(mf_ctx *) { return MF_ERR; }
 int mf_device_memory(int, uint64_t *t) { if (t) *t = (uint64_t)288 << 30; return MF_OK; }
 int mf_bray_curtis(const int64_t *, int, int, double *) { return MF_ERR; }
+int mf_comm_create_local(mf_ctx *const *, int, mf_comm **) { return MF_ERR; }
+void mf_comm_destroy(mf_comm *) {}
+int mf_cut_components_sharded_files(mf_comm *, const char *const *, int, int, int, int, int, const char *, const char *, uint64_t *) { return MF_ERR; }
 }

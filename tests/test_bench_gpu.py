@@ -60,4 +60,5 @@ def test_bench_under_the_launcher_rccl_world1():
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-2000:]
     d = _check(p.stdout, 1)
-    assert "cutter_adjacency" in d["stage_ms_per_step"]           # the sharded cutter ran (through RCCL, one rank)
+    # the sharded cutter ran, its exchanges inside the library on the library's own RCCL communicator (one rank)
+    assert d["comm"]["kind"] == "rccl" and d["comm"]["collectives_per_step"] >= 20 and "components" in d["stage_ms_per_step"]

@@ -38,7 +38,7 @@ def samples():
 r = P.run_samples(ctx, samples(), k=31, b=1, l=100, b1=100, b2=1000, device=torch.device("cuda", dev))
 comps = r["comps"].export()
 out = dict(components=[[int(a), int(w), int(t)] for a, w, t, _ in comps], members=[[int(x) for x in km] for _, _, _, km in comps],
-           vecs=r["vecs"].tolist(), matrix=r["matrix"].tolist(), comm={k: float(v) for k, v in r["comm"].items()})
+           vecs=r["vecs"].tolist(), matrix=r["matrix"].tolist(), comm={k: (v if isinstance(v, str) else float(v)) for k, v in r["comm"].items()})
 json.dump(out, open(os.path.join(os.environ["MF_OUT"], f"rank{rank}.json"), "w"))
 dist.destroy_process_group()
 '''
@@ -130,72 +130,84 @@ def test_rccl_path_world1(oracle, tmp_path):
     _same(res[0], want)
 
 
-# ---- the sharded cutter with W virtual ranks in one process (threads; pipeline.ThreadComm stands in for RCCL) ----
-def _virtual_ranks(world, inputs, b1, b2, k=31, b=1, l=100, fail_rank=None, fail_at=None, options=None):
-    """inputs: (bases, offsets) host arrays of the samples; their unitigs are what every rank has after the all-gather of
-    pipeline.run_samples -> per rank (components export, info)"""
+# ---- the sharded cutter with W ranks as THREADS of one process, a context each on the one GPU: the library's local communicator
+# (mf_comm_create_local) -- what metafast.sh --devices a,b,... runs; on a multi-GPU box the same copies cross xGMI ----
+def _virtual_ranks(world, inputs, b1, b2, k=31, b=1, l=100, fail_rank=None, fail_at=None, options=None, one_call=False):
+    """inputs: (bases, offsets) host arrays of the samples.  one_call=False: every rank counts its shard of ALL samples' unitigs itself and
+    runs mf_cut_components_of_shard (failures can be injected: fail_at = "shard" / "merge" / "merge:3" / "level_local:3"); one_call=True:
+    rank r holds the unitigs of samples r, r + W, ... and calls mf_cut_components_sharded (gather + shard count + protocol in one call).
+    -> per rank (components export, info) or ("abort", message)"""
     import threading
     import torch
     from util import to_device
     from metafast_amd import lib as L, pipeline as P
     ctx0 = L.Context(0)
-    bs, os_, nb = [], [], 0
+    per_sample = []
     for bases, offsets in inputs:
         db, do = to_device(bases, offsets)
         t = ctx0.count_device(db.data_ptr(), do.data_ptr(), len(offsets) - 1, len(bases), k, 0)
         g = t.filter(b)
         sq = ctx0.build_unitigs(g, b, l)
         v = sq.device_view()
-        bs.append(P.device_tensor(v["bases"], v["n_bases"], "cuda").clone())
-        os_.append(P.device_tensor(v["offsets"], (v["n"] + 1) * 8, "cuda").view(torch.int64)[:-1] + nb)
-        nb += v["n_bases"]
+        per_sample.append((P.device_tensor(v["bases"], v["n_bases"], "cuda").clone(), P.device_tensor(v["offsets"], (v["n"] + 1) * 8, "cuda").view(torch.int64).clone(), v["n_bases"]))
         sq.close(); g.close(); t.close()
-    allb = torch.zeros(nb + 64, dtype=torch.uint8, device="cuda")
-    allb[:nb] = torch.cat(bs)
-    allo = torch.cat(os_ + [torch.tensor([nb], dtype=torch.int64, device="cuda")])
+
+    def cat(samples):
+        bs, os_, nb = [], [], 0
+        for sb, so, n in samples:
+            bs.append(sb); os_.append(so[:-1] + nb); nb += n
+        allb = torch.zeros(nb + 64, dtype=torch.uint8, device="cuda")
+        if bs:
+            allb[:nb] = torch.cat(bs)
+        allo = torch.cat(os_ + [torch.tensor([nb], dtype=torch.int64, device="cuda")])
+        return allb, allo, nb
+    allb, allo, nb = cat(per_sample)
+    mine = [cat(per_sample[r::world]) for r in range(world)]
     torch.cuda.synchronize()
-    group = P.ThreadGroup(world)
+    ctxs = [L.Context(0) for _ in range(world)]
+    comms = L.Comm.local(ctxs)
     out, errs = [None] * world, []
 
     def work(rank):
-        comm = None
         try:
             torch.cuda.set_device(0)
-            comm = P.ThreadComm(group, rank)
-            ctx = L.Context(0)
+            ctx, comm = ctxs[rank], comms[rank]
+            ctx.bind_thread()
             for name, val in (options or {}).items():
                 ctx.set_option(name, val)
+            if one_call:
+                mb, mo, mnb = mine[rank]
+                try:
+                    comps = comm.cut_components_sharded(mb.data_ptr(), mo.data_ptr(), int(mo.numel()) - 1, mnb, k, l, b1, b2)
+                except L.DistAbort as e:
+                    out[rank] = ("abort", str(e))
+                    return
+                out[rank] = (comps.export(), dict(comm.stats(), kind=comm.kind))
+                return
             shard = ctx.count_device_shard(allb.data_ptr(), allo.data_ptr(), int(allo.numel()) - 1, nb, k, l, rank, world)
             info = {}
             if rank == fail_rank and fail_at == "shard":
                 shard = None                                     # (the count failed on this rank)
-            if rank == fail_rank and fail_at == "merge":         # (a library call in the middle of a level fails on this rank only)
-                real = L.DistCutter.merge
-
-                def merge_fails_on_one_rank(self, *a):
-                    if self.rank == fail_rank:
-                        raise L.MetafastError("injected failure")
-                    return real(self, *a)
-                L.DistCutter.merge = merge_fails_on_one_rank
+            elif rank == fail_rank and fail_at:                  # (the n-th call of a library function inside the protocol fails on this rank only)
+                which, _, nth = fail_at.partition(":")
+                ctx.set_option("dcc_test_fail", {"merge": 1000, "level_local": 2000}[which] + int(nth or 1))
             try:
                 comps = P.distributed_components(ctx, comm, shard, k, b1, b2, info=info)
-            except P.DistAbort as e:
+            except L.DistAbort as e:
                 out[rank] = ("abort", str(e))
                 return
             info["shard_len"] = len(shard)
             out[rank] = (comps.export(), info)
-        except BaseException as e:          # (a rank that dies must not leave the others waiting at the barrier)
+        except BaseException as e:          # (a rank that dies must not leave the others waiting: the barrier gives up after a while)
             errs.append(e)
-            group.barrier.abort()
-        finally:
-            if comm:
-                comm.done()
 
     th = [threading.Thread(target=work, args=(r,)) for r in range(world)]
     for t in th:
         t.start()
     for t in th:
         t.join()
+    for c in comms:
+        c.close()
     if errs:
         raise errs[0]
     return out
@@ -231,64 +243,130 @@ def test_sharded_cutter_virtual_ranks(oracle, world):
     assert all(i["shard_len"] > 0 for _, i in res)
 
 
-@pytest.mark.parametrize("inband_max,room", [("0", "2,1024"), (str(1 << 40), "2,1024"), (str(1 << 40), "0,0")])
-def test_sharded_cutter_exchange_sizes_in_band(oracle, monkeypatch, inband_max, room):
-    """round 5: a level's exchange sizes ride in band where the level before bounds them (pipeline.distributed_components).  Forced off
-    (every level counts its half pairs with an integer gather), forced on from level 2 (padded slices, the status in the slices' first
-    element), and with no room at all for the per-component records (every level answers with the second, exactly sized all-gather):
-    the oracle's components every time"""
+@pytest.mark.parametrize("fail_at", ["shard", "merge", "merge:3", "level_local:3"])
+def test_sharded_cutter_ranks_abort_together(fail_at):
+    """one rank cannot do its part (its shard count failed / a call in the middle of a level fails -- the first level's or a later one's):
+    EVERY rank leaves mf_cut_components_of_shard with MF_ERR_TOGETHER at the same gather -- nobody is left waiting inside an exchange
+    (pipeline.run_samples then takes the replicated cutter on all ranks)"""
     from util import branchy_reads
-    monkeypatch.setenv("MF_DCC_INBAND_MAX", inband_max)
-    monkeypatch.setenv("MF_DCC_STATS_ROOM", room)
-    inputs = [branchy_reads(rs, genome_seed=7, n=6000) for rs in [107, 117, 127, 137]]
+    inputs = [branchy_reads(rs, genome_seed=7, n=6000) for rs in (107, 117, 127, 137)]
+    res = _virtual_ranks(4, inputs, 100, 1000, fail_rank=2, fail_at=fail_at)
+    assert all(r[0] == "abort" for r in res), res
+    assert all("rank(s) 2 failed" in r[1] for r in res), res
+    assert "injected failure" in res[2][1] or fail_at == "shard"          # (the failing rank also says why)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_cutter_in_one_call(oracle, world):
+    """mf_cut_components_sharded: rank r brings the unitigs of ITS samples, the call gathers them, counts the rank's shard and runs the
+    protocol -- what metafast.sh's component-cutter does per device entry: every rank ends with the oracle's components"""
+    from util import branchy_reads
+    inputs = [branchy_reads(rs, genome_seed=7, n=6000) for rs in [107, 117, 127, 137, 147]]
     want = _oracle_components(oracle, inputs, 100, 1000)
-    res = _virtual_ranks(4, inputs, 100, 1000)
+    res = _virtual_ranks(world, inputs, 100, 1000, one_call=True)
     for comps, info in res:
         assert [(a, w, t) for a, w, t, _ in comps] == [(a, w, t) for a, w, t, _ in want]
         assert all(np.array_equal(np.sort(g[3]), np.sort(x[3])) for g, x in zip(comps, want))
-        modes = [lv[4] for lv in info["per_level"]]
-        assert modes == ["counted"] * 6 if inband_max == "0" else modes == ["counted"] + ["in-band"] * 5, modes
+        assert info["kind"] == "local" and info["collectives"] > 10 and info["bytes_in"] > 0
 
 
-@pytest.mark.parametrize("fail_at", ["shard", "merge"])
-def test_sharded_cutter_ranks_abort_together(fail_at):
-    """one rank cannot do its part (its shard count failed / a call in the middle of a level fails): EVERY rank leaves the
-    protocol with DistAbort at the same gather -- nobody is left waiting inside a collective (pipeline.run_samples then takes
-    the replicated cutter on all ranks)"""
-    from util import branchy_reads
-    inputs = [branchy_reads(rs, genome_seed=7, n=6000) for rs in (107, 117)]
+def test_comm_primitives_local():
+    """the three primitives of a local communicator (4 threads, one GPU): ragged all-gather with an empty contribution, non-uniform
+    all-to-all with a rank that neither sends nor receives, integer gather; mismatched sizes are an error on every rank, not a hang"""
+    import threading
+    import torch
     from metafast_amd import lib as L
-    real = L.DistCutter.merge
-    try:
-        res = _virtual_ranks(4, inputs, 100, 1000, fail_rank=2, fail_at=fail_at)
-    finally:
-        L.DistCutter.merge = real
-    assert all(r[0] == "abort" for r in res), res
-    assert all("rank(s) [2] failed" in r[1] for r in res)
+    W = 4
+    ctxs = [L.Context(0) for _ in range(W)]
+    comms = L.Comm.local(ctxs)
+    m = np.array([[0, 5, 0, 2], [1, 0, 0, 7], [0, 0, 0, 0], [4, 3, 0, 0]])          # m[src][dst] elements of 8 bytes
+    sizes = [3, 0, 4, 1]
+    out, errs = [None] * W, []
 
-
-def test_sharded_cutter_ranks_abort_together_in_an_in_band_level():
-    """the same with the failure in a level whose sizes ride in band (level 3: the status travels in the slices of the all-to-all / in the
-    records' first entry)"""
-    from util import branchy_reads
-    from metafast_amd import lib as L
-    inputs = [branchy_reads(rs, genome_seed=7, n=6000) for rs in (107, 117, 127, 137)]
-    for which in ("merge", "level_local"):
-        real = getattr(L.DistCutter, which)
-        calls = {}
-
-        def fails_at_level_3(self, *a, _real=real):
-            calls[self.rank] = calls.get(self.rank, 0) + 1
-            if self.rank == 1 and calls[self.rank] == 3:
-                raise L.MetafastError("injected failure")
-            return _real(self, *a)
-        setattr(L.DistCutter, which, fails_at_level_3)
+    def work(r):
         try:
-            res = _virtual_ranks(4, inputs, 100, 1000)
-        finally:
-            setattr(L.DistCutter, which, real)
-        assert all(r[0] == "abort" for r in res), (which, res)
-        assert all("rank(s) [1] failed" in r[1] for r in res), (which, res)
+            torch.cuda.set_device(0)
+            ctxs[r].bind_thread()
+            c = comms[r]
+            ints = c.gather_ints([r, 10 * r])
+            send = (torch.arange(int(m[r].sum()), dtype=torch.int64, device="cuda") + 1000 * r)
+            recv = torch.full((int(m[:, r].sum()) + 1,), -7, dtype=torch.int64, device="cuda")
+            torch.cuda.synchronize()
+            c.all_to_all(send.data_ptr(), 8 * m[r], recv.data_ptr(), 8 * m[:, r])
+            ag_in = torch.full((sizes[r],), r, dtype=torch.int32, device="cuda")
+            ag_out = torch.full((sum(sizes) + 1,), -1, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            c.all_gather(ag_in.data_ptr(), ag_out.data_ptr(), [4 * x for x in sizes])
+            ctxs[r].synchronize()
+            out[r] = (ints.tolist(), recv.cpu().tolist(), ag_out.cpu().tolist(), c.stats())
+        except BaseException as e:
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(W)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    for r in range(W):
+        ints, recv, ag, st = out[r]
+        assert ints == [[0, 0], [1, 10], [2, 20], [3, 30]]
+        want = []
+        for src in range(W):
+            o = int(m[src][:r].sum())
+            want += [1000 * src + o + i for i in range(int(m[src][r]))]
+        assert recv == want + [-7]
+        assert ag == [0, 0, 0, 2, 2, 2, 2, 3, -1]
+        assert st["collectives"] == 3 and st["bytes_in"] == 8 * 8 + 8 * int(m[:, r].sum()) + 4 * sum(sizes)
+    # sizes that do not match: an error on the ranks that see it, the others are woken up -- nobody hangs
+    res = [None] * W
+
+    def bad(r):
+        torch.cuda.set_device(0)
+        ctxs[r].bind_thread()
+        buf = torch.zeros(64, dtype=torch.int64, device="cuda")
+        torch.cuda.synchronize()
+        try:
+            comms[r].all_to_all(buf.data_ptr(), [8, 8, 8, 8], buf.data_ptr() + 256, [8, 8, 8, 16 if r == 0 else 8])
+            res[r] = "ok"
+        except L.MetafastError as e:
+            res[r] = str(e)
+    th = [threading.Thread(target=bad, args=(r,)) for r in range(W)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert all(x != "ok" for x in res), res
+    for c in comms:
+        c.close()
+
+
+RCCL_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, os.environ["MF_ROOT"])
+import numpy as np, torch
+from metafast_amd import lib as L
+torch.cuda.set_device(0)
+ctx = L.Context(0)
+c = L.Comm.rccl(ctx, L.Comm.rccl_id(), 0, 1)
+a = torch.arange(1000, dtype=torch.int64, device="cuda")
+b = torch.zeros(1000, dtype=torch.int64, device="cuda"); d = torch.zeros(1000, dtype=torch.int64, device="cuda")
+torch.cuda.synchronize()
+ints = c.gather_ints([5, 6, 7]).tolist()
+c.all_gather(a.data_ptr(), b.data_ptr(), [8000])
+c.all_to_all(a.data_ptr(), [8000], d.data_ptr(), [8000])
+ctx.synchronize()
+rows = c.features_allgather(np.arange(12, dtype=np.int64).reshape(3, 4)).tolist()
+print(json.dumps(dict(kind=c.kind, ints=ints, ag=bool((a == b).all()), aa=bool((a == d).all()), rows=rows, stats=c.stats())))
+'''
+
+
+def test_comm_rccl_world1():
+    """the library's own RCCL communicator (librccl through dlopen, ncclCommInitRank, grouped send / recv) at world size 1 with MF_FORCE_DIST=1:
+    the transport really runs (more than one rank needs more than one GPU: the two-GPU tests below)"""
+    env = dict(os.environ, MF_ROOT=ROOT, MF_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", RCCL_WORKER], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])      # (RCCL prints a banner of its own on stdout)
+    assert d["kind"] == "rccl" and d["ints"] == [[5, 6, 7]] and d["ag"] and d["aa"]
+    assert d["rows"] == np.arange(12).reshape(3, 4).tolist()
+    assert d["stats"]["collectives"] >= 5 and d["stats"]["bytes_in"] >= 16000
 
 
 @pytest.mark.skipif(not os.environ.get("MF_TRY_RCCL_2RANKS"), reason="two RCCL ranks on ONE device: RCCL refuses duplicate GPUs on most builds (opt-in: MF_TRY_RCCL_2RANKS=1)")
@@ -395,5 +473,5 @@ def test_bench_two_gpus_under_the_launcher():
     assert len(lines) == 1, lines[:3]
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
-    assert d["comm"]["collectives_per_step"] > 0 and d["comm"]["MB_received_per_step"] > 0
-    assert d["stats"]["n_occ"] == 5000000 * 120 and "cutter_adjacency" in d["stage_ms_per_step"]
+    assert d["comm"]["collectives_per_step"] > 0 and d["comm"]["MB_received_per_step"] > 0 and d["comm"]["kind"] == "rccl"
+    assert d["stats"]["n_occ"] == 5000000 * 120 and "components" in d["stage_ms_per_step"]
