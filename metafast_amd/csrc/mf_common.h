@@ -78,6 +78,8 @@ struct mf_ctx {
     int64_t opt_skm_pilot = 1;     // reads: a few level-1 digit regions are counted first to measure distinct k-mers per occurrence; the later levels are planned from it (0 = plan from the occurrences alone)
     #ifdef SKM_BIG_UNITS
     int64_t opt_skm_unit_distinct = 4400;
+#elif defined(SKM_SMALL_UNITS)
+    int64_t opt_skm_unit_distinct = 1100;
 #else
     int64_t opt_skm_unit_distinct = 2200;
 #endif   // ... so that a counting unit is expected to hold at most this many distinct k-mers (the LDS table takes C2_FILL = 3400 claims)

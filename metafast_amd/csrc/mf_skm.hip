@@ -41,6 +41,8 @@ typedef uint32_t skm_v4 __attribute__((ext_vector_type(4)));
                                      identical records, 61.1 -> 77.7 at 5-fold depth, 16.5 -> 18.4 at k = 21 (profiles/r05y_big_units.txt): sixteen waves wait
                                      longer at a unit's barriers than eight, and a CU with one workgroup has nothing to run while that one compacts.  Not built in. */
 #define SKM_CT 1024
+#elif defined(SKM_SMALL_UNITS)    /* experiment (round 6): workgroups of 256 threads with a table of 2048 slots, three per CU -- units half as large, twice as many */
+#define SKM_CT 256
 #else
 #define SKM_CT 512                 // threads of k_skm_count
 #endif
@@ -684,6 +686,10 @@ __device__ __forceinline__ uint32_t skm_pass_of(uint64_t key) {
 #define C2_SLOTS 8192
 #define C2_FILL 6800
 #define C2_WG_PER_CU 1
+#elif defined(SKM_SMALL_UNITS)
+#define C2_SLOTS 2048
+#define C2_FILL 1700
+#define C2_WG_PER_CU 3
 #else
 #define C2_WG_PER_CU 2
 #define C2_SLOTS 4096            // table slots: at the planned ~800 distinct k-mers per partition the table is 1/5 full.  (2048 slots
@@ -1833,7 +1839,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             // more than half of k_skm_count is per-unit overhead (profiles/r05k_count_phase_cycles.txt).  50 M reads, k_skm_count / the whole step in
             // ms with 2000 and with 4000 records: k = 21 20.2 -> 16.5 / 129.9 -> 125.7, k = 23 19.8 -> 15.7 / 118.0 -> 114.2, 200 M reads at k = 21
             // 87.1 -> 70.0 / 375.9 -> 358.7; k = 25, 27, 31: no difference -- the distinct k-mers bound those.  profiles/r05t_unit_records_sweep.txt)
-            const int64_t unit_records = ctx->opt_skm_unit_records > 0 ? ctx->opt_skm_unit_records : (K >= 25 ? 2000 : 4000) * (SKM_CT / 512);
+            const int64_t unit_records = ctx->opt_skm_unit_records > 0 ? ctx->opt_skm_unit_records : (K >= 25 ? 2000 : 4000) * SKM_CT / 512;
             if (ctx->opt_skm_dedupe) want_units = std::max(want_units, (double)n_occ * rpo / (double)unit_records);
             int Bc = 0; while (Bc < 30 && (double)(1ull << Bc) < want_units) Bc++;
             const int r = std::max(1, std::min(Bc - bits1, std::min((int)SKM_DIGIT_BITS, 30 - bits1)));

@@ -221,7 +221,7 @@ def test_pipeline_against_the_oracle_k21_k20(gpu_ctx, oracle, tmp_path, k):
 
 def test_eight_samples_one_gpu_against_the_oracle(gpu_ctx, oracle, tmp_path):
     _samples_against_the_oracle(gpu_ctx, oracle, tmp_path, S=8, k=31, b=1, l=100, b1=1000, b2=10000,
-                                n=int(os.environ.get("MF_SHAPES_READS", "5000000")), min_thr=2)
+                                n=int(os.environ.get("MF_SHAPES_READS", "2000000")), min_thr=2)      # (5 M reads per sample: 155 of the suite's 640 s, the CPU side's; MF_SHAPES_READS=5000000 for that size)
 
 
 def _samples_against_the_oracle(gpu_ctx, oracle, tmp_path, S, k, b, l, b1, b2, n, min_thr):
