@@ -60,14 +60,18 @@ def _devices_case(oracle, tmp_path, devices):
     one = tmp_path / "wd_one"
     many = tmp_path / "wd_many"
     _run_cli(tmp_path, one, files, ["--device", "0"])
-    r = _run_cli(tmp_path, many, files, ["--devices", devices, "-v"])
+    os.environ["MF_SHARDED_CUTTER"] = "1"            # (entries on ONE device: the driver would not shard the cutter by itself)
+    try:
+        r = _run_cli(tmp_path, many, files, ["--devices", devices, "-v"])
+    finally:
+        del os.environ["MF_SHARDED_CUTTER"]
     assert "5 libraries on 2 device contexts" in r.stderr
     # round 6: the component cutter is sharded over the contexts too (mf_cut_components_sharded_files over a local communicator) -- and replicated
     # on request; all three workDirs are the same, byte for byte
     assert "Cutting components on 2 device contexts (sharded cutter table)" in r.stderr
     repl = tmp_path / "wd_repl"
     r2 = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-k", str(k), "-b", str(b), "-l", str(l), "-b1", str(b1), "-b2", str(b2), "-i", *files, "-w", str(repl),
-                         "--devices", devices, "-v"], capture_output=True, text=True, timeout=900, cwd=tmp_path, env=dict(os.environ, MF_REPLICATED_CUTTER="1"))
+                         "--devices", devices, "-v"], capture_output=True, text=True, timeout=900, cwd=tmp_path, env=dict(os.environ, MF_REPLICATED_CUTTER="1", MF_SHARDED_CUTTER="1"))
     assert r2.returncode == 0 and "sharded cutter table" not in r2.stderr, r2.stderr[-2000:]
     assert _result_files(repl)["component-cutter/components.bin"] == _result_files(many)["component-cutter/components.bin"]
     a, m = _result_files(one), _result_files(many)
