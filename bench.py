@@ -67,18 +67,32 @@ def main_wide(args, ctx, device, rank, world):
     2k-bit k-mers (mf_wide.hip, mf_wgraph.hip), reads resident in HBM; a normal line whose metric string says what it is.  One GPU."""
     from metafast_amd import pipeline as P
     n_reads, rl, k = args.reads, args.read_len, args.k
+    spg = max(1, args.samples_per_gpu)
     n_bases = n_reads * rl
     bases = torch.zeros(n_bases + 64, dtype=torch.uint8, device=device)
     offsets = torch.zeros(n_reads + 1, dtype=torch.int64, device=device)
     sub16k = int(round(args.sub_rate * 16384))
     ctx.synth_reads_device(SEED, rank, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr(), sub16k)
     torch.cuda.synchronize()
+    gen_s = [0.0]
+
+    def samples():
+        """(as in the k <= 31 run: the reads of ONE sample in HBM at a time; the generator's time is taken out of the clock again)"""
+        for j in range(spg):
+            if spg > 1:
+                torch.cuda.synchronize()
+                g0 = time.perf_counter()
+                ctx.synth_reads_device(SEED, rank * spg + j, 0, n_reads, rl, args.genome_scale, bases.data_ptr(), offsets.data_ptr(), sub16k)
+                torch.cuda.synchronize()
+                gen_s[0] += time.perf_counter() - g0
+            yield bases, offsets, n_reads, n_bases
 
     def step(timings=None):
-        r = P.run_samples_wide(ctx, [(bases, offsets, n_reads, n_bases)], k=k, b=args.bad_freq, l=args.min_len, b1=args.b1, b2=args.b2, device=device, timings=timings)
+        r = P.run_samples_wide(ctx, samples(), k=k, b=args.bad_freq, l=args.min_len, b1=args.b1, b2=args.b2, device=device, timings=timings)
         stats = dict(n_occ=r["n_occ"], n_distinct=int(sum(r["n_distinct"])), n_good=int(sum(g.stats()[0] for g in r["goods"])),
                      n_unitigs=int(sum(len(q) for q in r["seqss"])), n_cutter=int(r["cutter"].stats()[0]), n_components=len(r["comps"]),
-                     n_component_kmers=int(r["comps"].stats()[1]), n_reads=n_reads, n_bases=n_bases)
+                     n_component_kmers=int(r["comps"].stats()[1]), n_reads=n_reads * spg, n_bases=n_bases * spg, n_samples=spg,
+                     matrix_checksum=float(np.nansum(r["matrix"])))
         for x in r["goods"] + r["seqss"] + [r["cutter"], r["comps"]]:
             x.close()
         return stats
@@ -88,11 +102,14 @@ def main_wide(args, ctx, device, rank, world):
     ctx.reset_timers()
     stage_t = {}
     torch.cuda.synchronize()
+    gen_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = step(stage_t)
     torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = time.perf_counter() - t0 - gen_s[0]
+    if gen_s[0] and "count" in stage_t:
+        stage_t["count"] -= gen_s[0]
     rep = ctx.kernel_report()
     kern = {name: dict(launches=n, ms_per_step=round(ms / max(args.steps, 1), 4), max_launch_ms=round(mx, 4)) for name, (n, ms, mx) in rep.items()}
     # the dominant kernels move, per occurrence: k_wide_kmers 16 B written (two words), the sort 4 passes x 32 B, finish / big 32 B; priced on
@@ -112,7 +129,7 @@ def main_wide(args, ctx, device, rank, world):
         "value": round(stats["n_occ"] * args.steps / elapsed, 1), "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u128", "data": "synthetic",
-        "config": {"workload": f"1 sample x {n_reads} synthetic {rl} bp reads, k={k}, count+unitigs+components+features "
+        "config": {"workload": f"{spg} sample(s) x {n_reads} synthetic {rl} bp reads, k={k}, one GPU, count+unitigs+components+features "
                                f"(b={args.bad_freq} l={args.min_len} b1={args.b1} b2={args.b2})",
                    "reads_per_gpu": n_reads, "read_len": rl, "k": k, "genome_scale_bp": args.genome_scale, "substitutions_per_base": round(sub16k / 16384, 5)},
         "roofline": roof, "cpu_baseline": None, "stats": stats,

@@ -247,9 +247,28 @@ def make_comm(ctx, device="cuda"):
         return L.Comm.local([ctx])[0]
     backend = dist.get_backend()
     if backend == "nccl" and os.environ.get("MF_COMM", "rccl") != "torch":
-        ids = [L.Comm.rccl_id() if rank == 0 else None]
+        # the library's own RCCL communicator; torch's process group is the rendezvous for the id.  Whatever goes wrong on ANY rank (no librccl
+        # to be found, ncclCommInitRank refusing, a first small exchange that fails) sends ALL ranks to torch's collectives instead, together
+        ids = [None]
+        if rank == 0:
+            try:
+                ids = [L.Comm.rccl_id()]
+            except L.MetafastError as e:
+                print("[metafast_amd] no RCCL communicator of the library's own (%s): torch.distributed's collectives instead" % e, file=sys.stderr)
         dist.broadcast_object_list(ids, src=0)
-        return L.Comm.rccl(ctx, ids[0], rank, world)
+        comm, ok = None, 0
+        if ids[0] is not None:
+            try:
+                comm = L.Comm.rccl(ctx, ids[0], rank, world)
+                ok = int(comm.gather_ints([rank + 1])[:, 0].tolist() == list(range(1, world + 1)))
+            except L.MetafastError as e:
+                print("[metafast_amd] rank %d: the library's RCCL communicator failed (%s)" % (rank, e), file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            return comm
+        if comm is not None:
+            comm.close()
     tc = TorchComm()
     dev = torch.device(device) if not isinstance(device, torch.device) else device
 
