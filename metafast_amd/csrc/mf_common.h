@@ -97,6 +97,7 @@ struct mf_ctx {
     int64_t opt_gz_device_min = 32 << 20;   // .fa.gz / .fq.gz files of at least this size are inflated on many threads straight into HBM (mf_dparse_gz); tests: 0
     int64_t opt_gz_piece = 2 << 20;         // ... in pieces of at least this many compressed bytes (tests: 65536)
     int64_t opt_ut_double_after = 4;   // unitigs: walks still under way after this many chunked rounds (32, 128, 512, 4096 jumps) double the jump words instead (tests: 1)
+    int64_t opt_ut_plain_rounds = 3;   // unitigs of a table without partitions (2k-bit tables, k < 20): rounds of doubling the one-hop jump words over all nodes before the walks (0: none)
     int64_t opt_wide_finish = 1;   // mf_count_wide_device: radix passes over the leading 32 bits + the order inside the buckets in LDS (0: radix passes over all 2k bits)
     int64_t opt_wide_big_bucket = 256;   // ... buckets of more entries than this (<= 256) go through the LDS hash table instead of the walk (tests lower it)
     int64_t opt_wide_distinct = 1280;    // ... buckets of more distinct k-mers than this (<= 1280) are sorted aside (tests lower it)

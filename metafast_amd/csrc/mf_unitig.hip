@@ -250,6 +250,19 @@ __global__ void k_ut_jump_plain(const uint64_t *__restrict__ node, uint64_t n_no
     jump[f] = g == UT_NONE ? ((uint64_t)(uint32_t)f | UT_J_END) : ((uint64_t)g | (1ull << 32));
 }
 
+// ... and doubled (round 6): out[f] = in[f] followed by in[its target] -- a table without partitions (the 2k-bit tables of mf_wgraph.hip are
+// ascending, neighbours far apart) has nothing for k_ut_contract to contract, every walk paid one dependent load per NODE and a path of
+// 1e5 k-mers kept a lane busy for 50 ms, twice (200 M reads at k = 63: k_ut_walk1 34 ms + k_ut_double 185 + k_ut_segments 53).  Three rounds
+// over all nodes (a streaming read + one random 8-byte read each) make a word span up to 8 hops.
+__global__ void k_ut_jump_double(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint64_t n_nodes) {
+    const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_nodes) return;
+    const uint64_t a = in[f];
+    if (a & UT_J_END) { out[f] = a; return; }
+    const uint64_t b = in[(uint32_t)a];
+    out[f] = (uint64_t)(uint32_t)b | ((((a >> 32) & 0x7FFFull) + ((b >> 32) & 0x7FFFull)) << 32) | (b & UT_J_END);
+}
+
 // walk item: a path being followed from `start` (slot = its index in starts[]), currently at `node`, `dist` hops in
 struct ut_item { uint32_t node, slot, dist; };
 struct ut_walk_out {
@@ -558,8 +571,18 @@ int mf_ut_build(mf_ctx *ctx, const uint64_t *gk, const uint64_t *ghi, const uint
                 const uint32_t npart = 1u << part_bits;
                 const unsigned grid = (unsigned)std::min<uint64_t>((npart + UT_J_WAVES - 1) / UT_J_WAVES, (uint64_t)ctx->n_cu * 32);
                 k_ut_contract<<<grid, 64 * UT_J_WAVES, 0, st>>>(succ.p, d_part_off, npart, jump.p);
-            } else
+            } else {
                 k_ut_jump_plain<<<grid_for(2 * n), 256, 0, st>>>(succ.p, 2 * n, jump.p);
+                // (a target is a node's successor chain 2^r hops on -- or the path's last node; an isolated cycle just goes round)
+                const int rounds_j = n >= (1u << 16) ? (int)std::max<int64_t>(0, std::min<int64_t>(ctx->opt_ut_plain_rounds, 8)) : 0;
+                if (rounds_j) {
+                    mf_buf<uint64_t> tmp;
+                    if (tmp.alloc(ctx, 2 * n) == MF_OK) {
+                        for (int r = 0; r < rounds_j; r++) { k_ut_jump_double<<<grid_for(2 * n), 256, 0, st>>>(jump.p, tmp.p, 2 * n); jump.swap(tmp); }
+                        A.jump = jump.p;
+                    } else (void)hipGetLastError();
+                }
+            }
         }
         unsigned int n_starts = 0;
         if (hipMemcpyAsync(&n_starts, &ctr.p[1], 4, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) {

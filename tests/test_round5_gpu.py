@@ -109,6 +109,35 @@ def test_cli_two_contexts_on_one_gpu(gpu_ctx, oracle, tmp_path):
     _devices_case(oracle, tmp_path, "0,0")
 
 
+def test_cli_sharded_cutter_more_contexts_than_libraries(gpu_ctx, tmp_path):
+    """round 6: four contexts, two libraries -- the ranks without a library bring no sequences but own their shard of the cutter table;
+    three contexts: the cutter runs on the largest power of two of them (2); an unreadable .seq.fasta: the reference's message, no hang"""
+    files = []
+    for s in range(2):
+        p = tmp_path / ("m%d.fa" % s)
+        _write_fasta(p, s, 7000)
+        files.append(str(p))
+    one = tmp_path / "wd1"
+    _run_cli(tmp_path, one, files, ["--device", "0"])
+    want = (one / "component-cutter" / "components.bin").read_bytes()
+    assert len(want) > 16
+    os.environ["MF_SHARDED_CUTTER"] = "1"
+    try:
+        for devs, w in (("0,0,0,0", 4), ("0,0,0", 2)):
+            wd = tmp_path / ("wd_" + devs.replace(",", ""))
+            r = _run_cli(tmp_path, wd, files, ["--devices", devs, "-v"])
+            assert "Cutting components on %d device contexts (sharded cutter table)" % w in r.stderr
+            assert (wd / "component-cutter" / "components.bin").read_bytes() == want
+            assert _result_files(wd)["matrix"] == _result_files(one)["matrix"]
+        # the component-cutter alone on sequence files one of which does not exist
+        seqs = sorted(str(p) for p in (one / "seq-builder-many" / "sequences").iterdir())
+        r = subprocess.run([os.path.join(ROOT, "metafast.sh"), "-t", "component-cutter", "-k", "21", "-i", seqs[0], str(tmp_path / "nothing.seq.fasta"), "-w", str(tmp_path / "wdx"),
+                            "--devices", "0,0"], capture_output=True, text=True, timeout=300, cwd=tmp_path)
+        assert r.returncode == 1 and "nothing.seq.fasta" in r.stderr, r.stderr[-1500:]
+    finally:
+        del os.environ["MF_SHARDED_CUTTER"]
+
+
 def test_cli_two_gpus(gpu_ctx, oracle, tmp_path):
     # (gpu_ctx first, in every test of this file: torch.cuda.device_count() before torch and the library have initialised their HIP runtimes in
     # the usual order -- torch's, then the library's -- left the library without a device on the GPU box)
