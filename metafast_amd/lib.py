@@ -205,6 +205,10 @@ class Context:
         if c is not None:
             self._mf_comm = None
             c.close()
+        peer = getattr(self, "_mf_peer", None)          # (... and the peer context for the samples it overlaps)
+        if peer is not None:
+            self._mf_peer = None
+            peer.close()
         if getattr(self, "h", None) and _lib is not None:
             _lib.mf_ctx_destroy(self.h)
         self.h = None
@@ -227,6 +231,9 @@ class Context:
 
     def set_option(self, name, value):
         _check(lib().mf_ctx_set_option(self.h, name.encode(), int(value)))
+        if not hasattr(self, "options"):
+            self.options = {}
+        self.options[name] = int(value)          # (what a peer context of this one is given too: pipeline.py)
 
     def synchronize(self):
         _check(lib().mf_ctx_synchronize(self.h))
@@ -242,6 +249,9 @@ class Context:
         return int(got.value)
 
     def reset_timers(self):
+        peer = getattr(self, "_mf_peer", None)
+        if peer is not None and peer.h is not None:
+            peer.reset_timers()
         _check(lib().mf_ctx_reset_timers(self.h))
 
     def stat(self, name):
@@ -257,12 +267,18 @@ class Context:
         return int(n), float(ms.value)
 
     def kernel_report(self):
+        """name -> (launches, total ms, longest launch ms); the peer context's launches (pipeline.py: overlapped samples) are added in"""
         buf = C.create_string_buffer(1 << 16)
         _check(lib().mf_ctx_kernel_report(self.h, buf, len(buf)))
         out = {}
         for line in buf.value.decode().splitlines():
             name, n, ms, mx = line.split("\t")
             out[name] = (int(n), float(ms), float(mx))
+        peer = getattr(self, "_mf_peer", None)
+        if peer is not None and peer.h is not None:
+            for name, (n, ms, mx) in peer.kernel_report().items():
+                a = out.get(name, (0, 0.0, 0.0))
+                out[name] = (a[0] + n, a[1] + ms, max(a[2], mx))
         return out
 
     # ---- A1-A4 ----

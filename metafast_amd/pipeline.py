@@ -349,28 +349,94 @@ def _run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda
             t0 = t1
 
     goods, seqss, hists, n_occ, n_distinct = [], [], [], 0, 0
-    for si, sample in enumerate(samples):
-        if si:
-            # several samples on this rank: the previous sample's lookup index (3-6 times its table) is not needed again before
-            # its feature vector, where it is rebuilt (mf_table_drop_index) -- 4 samples of > 2^32 distinct k-mers each
-            # (BASELINE config 5) fit one GPU's HBM this way
+    # Several samples on this rank (round 6): sample i's unitigs are built while sample i + 1 is counted -- the walk / hook kernels of the
+    # graph stages are latency-bound (< 10 % VALU busy), the counting kernels issue-bound (65 - 73 %): two streams fill the device better than
+    # one.  A context is driven by one thread at a time and owns its tables, so the samples ALTERNATE between this context and a peer on the
+    # same device (made when the second sample arrives, if the device has room for a second workspace), and a sample's unitigs run in a worker
+    # thread on the sample's own context while the main thread counts the next sample on the other one.  MF_OVERLAP_SAMPLES=0: one context.
+    ctxs, running = [ctx], {}
+
+    def wait(ci):
+        w = running.pop(ci, None)
+        if w is not None:
+            w[0].join()
+            if w[1]:
+                raise w[1][0]
+
+    def unitigs_of(c, good, slot, drop):
+        def work(err):
+            try:
+                c.bind_thread()                                # (a thread of its own: HIP's current device belongs to the thread)
+                seqss[slot] = c.build_unitigs(good, b, l)
+                if drop:
+                    # several samples on this rank: the sample's lookup index (3-6 times its table) is not needed again before its feature
+                    # vector, where it is rebuilt (mf_table_drop_index) -- 4 samples of > 2^32 distinct k-mers each (BASELINE config 5) fit
+                    # one GPU's HBM this way
+                    good.drop_index()
+                c.synchronize()
+            except BaseException as e:
+                err.append(e)
+        return work
+
+    it = iter(samples)
+    sample = next(it, None)
+    si = -1
+    overlap_on = os.environ.get("MF_OVERLAP_SAMPLES", "1") != "0" and torch.cuda.is_available()
+    while sample is not None:
+        si += 1
+        if si == 1 and len(ctxs) == 1 and overlap_on:
+            peer = getattr(ctx, "_mf_peer", None)
+            if peer is None or peer.h is None:
+                free_b = torch.cuda.mem_get_info(ctx.device)[0]
+                if free_b > 1.3 * ctx.stat("arena_bytes") + (8 << 30):          # (room for a second workspace of the size the first sample needed)
+                    try:
+                        peer = L.Context(ctx.device)
+                        for name, val in getattr(ctx, "options", {}).items():
+                            peer.set_option(name, val)
+                        ctx._mf_peer = peer
+                    except L.MetafastError:
+                        peer = None
+            if peer is not None:
+                ctxs.append(peer)
+        ci = si % len(ctxs)
+        c = ctxs[ci]
+        wait(ci)                                              # (the unitigs of the sample before the last: the same context)
+        if len(ctxs) == 1 and si:
             goods[-1].drop_index()
         # kmer-counter: k-mers with count > b go on (IOUtils.printKmers); the others are dropped inside the counting kernels
         if isinstance(sample[0], (str, bytes, os.PathLike)):
             # a sample handed over as its read files (IOUtils.loadReads, src/io/IOUtils.java:772-803: all files of a library into one
             # table): read + parse + H2D inside the library (mf_count_reads_above)
-            good, nd = ctx.count_reads_above([os.fspath(f) for f in sample], k, b)
+            good, nd = c.count_reads_above([os.fspath(f) for f in sample], k, b)
         else:
             d_bases, d_offsets, n_reads, n_bases = sample
-            good, nd = ctx.count_device_above(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, k, b)
+            if c is not ctx:
+                torch.cuda.current_stream().synchronize()      # (the reads were written on torch's stream, the peer launches on its own)
+            good, nd = c.count_device_above(d_bases.data_ptr(), d_offsets.data_ptr(), n_reads, n_bases, k, b)
         # ... and the histogram of ALL counts, dropped k-mers included (the .stat.txt of IOUtils.printKmers, src/io/IOUtils.java:45-71)
         hists.append(good.hist())
+        c.synchronize()                                        # (the reads are free for the next sample from here on)
         mark("count")
-        seqss.append(ctx.build_unitigs(good, b, l))
-        if si:
-            good.drop_index()
-        mark("unitigs")
+        seqss.append(None)
         goods.append(good); n_occ += good.occurrences(); n_distinct += nd
+        work = unitigs_of(c, good, si, drop=si > 0)
+        # the next sample, now that this one's reads are free (a generator may refill the same buffer); none: this sample's unitigs run right
+        # here -- a single sample (the benchmark's step) never meets a thread
+        sample = next(it, None)
+        if sample is not None and overlap_on and (len(ctxs) > 1 or si == 0):
+            err = []
+            th = threading.Thread(target=work, args=(err,))
+            th.start()
+            running[ci] = (th, err)
+        else:
+            err = []
+            work(err)
+            if err:
+                raise err[0]
+            mark("unitigs")
+    for ci in list(running):
+        wait(ci)
+    mark("unitigs")
     # this rank's unitigs, all samples one after the other
     views = [sq.device_view() for sq in seqss]
     ctx.synchronize()
@@ -429,12 +495,30 @@ def _run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda
         comps = ctx.cut_components(cutter, b1, b2)
         mark("components")
     allr.close()
-    vecs_local, breadths = [], []
-    for good in goods:
-        vec, breadth = ctx.features(comps, good, 0)
-        if len(goods) > 1:
-            good.drop_index()
-        vecs_local.append(vec); breadths.append(breadth)
+    vecs_local, breadths = [None] * len(goods), [None] * len(goods)
+
+    def features_of(c, idx, err):
+        # (on the context that owns the samples' tables: this one or its peer -- the peer's samples in a thread of their own beside these)
+        try:
+            if c is not ctx:
+                c.bind_thread()
+            for i in idx:
+                vecs_local[i], breadths[i] = c.features(comps, goods[i], 0)
+                if len(goods) > 1:
+                    goods[i].drop_index()
+        except BaseException as e:
+            err.append(e)
+    ferr, fth = [], []
+    for c in ctxs[1:]:
+        idx = [i for i, g in enumerate(goods) if g.ctx is c]
+        if idx:
+            fth.append(threading.Thread(target=features_of, args=(c, idx, ferr)))
+            fth[-1].start()
+    features_of(ctx, [i for i, g in enumerate(goods) if g.ctx is ctx], ferr)
+    for t in fth:
+        t.join()
+    if ferr:
+        raise ferr[0]
     rows = np.stack(vecs_local) if vecs_local else np.zeros((0, len(comps)), dtype=np.int64)
     vecs = comm.features_allgather(rows)                        # north_star's all-gather of the per-sample feature vectors
     matrix = L.bray_curtis(vecs) if vecs.shape[1] else np.zeros((vecs.shape[0], vecs.shape[0]))

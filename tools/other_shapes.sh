@@ -6,7 +6,10 @@ TAG=$1
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 ONLY=${2:-}
 for spec in "dedupe_off|MF_OPTIONS=skm_dedupe=0|" "k21_50M||--reads 50000000 -k 21" "k23_50M_cami_k||--reads 50000000 -k 23" "depth_5fold||--genome-scale 16000000" \
-            "cami_example_k23_b5_l1200||--reads 50000000 -k 23 -b 5 -l 1200" "config5_as_specified||--samples-per-gpu 4 --reads 120000000 --pool-scale 5700000 --sub-rate 0.01"; do
+            "cami_example_k23_b5_l1200||--reads 50000000 -k 23 -b 5 -l 1200" "config5_as_specified|MF_OVERLAP_SAMPLES=0|--samples-per-gpu 4 --reads 120000000 --pool-scale 5700000 --sub-rate 0.01" \
+            "config5_as_specified_overlapped||--samples-per-gpu 4 --reads 120000000 --pool-scale 5700000 --sub-rate 0.01"; do
+  # (several samples per GPU: the kernel's fraction is taken with the samples one after the other -- MF_OVERLAP_SAMPLES=0 -- because kernels of two
+  # streams that run side by side stretch each other's event times; the step time that counts is the overlapped one, the line after it)
   name=${spec%%|*}; rest=${spec#*|}; envs=${rest%%|*}; args=${rest#*|}
   if [ -n "$ONLY" ] && [ "$ONLY" != "$name" ]; then continue; fi
   env $envs timeout -k 5 900 python3 bench.py $args --steps 2 --warmup 1 --no-cpu-baseline --no-end-to-end 2>/dev/null | tail -1 > gpurun_out/${TAG}_shape_${name}.json
