@@ -772,7 +772,9 @@ extern "C" int mf_features_device_selected(mf_ctx *ctx, mf_comps *c, const mf_ta
     MF_HIP(hipMemsetAsync(dfound.p, 0, nc * 4, st));
     if (sample->n && c->n_kmers) {
         // probe whichever side has an index already or is cheaper to index: the sample's table (built for the unitigs) ...
-        if (sample->index.slots || c->n_kmers < sample->n) {
+        // (components of ANOTHER context of the same device -- pipeline.py's peer context for overlapped samples --: only read here, never indexed:
+        // their index would come out of this context's workspace and two contexts' threads would race for it)
+        if (sample->index.slots || c->n_kmers < sample->n || c->ctx != ctx) {
             MF_TRY(mf_table_ensure_index(const_cast<mf_table *>(sample)));
             mf_ktimer tm(ctx, "k_features");
             k_features_rev<<<cgrid(c->n_kmers), 256, 0, st>>>(mf_view(sample->index), c->d_kmers, c->d_comp, c->n_kmers, threshold, mask.p, dvec.p, dfound.p);

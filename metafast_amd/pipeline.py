@@ -349,11 +349,14 @@ def _run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda
             t0 = t1
 
     goods, seqss, hists, n_occ, n_distinct = [], [], [], 0, 0
-    # Several samples on this rank (round 6): sample i's unitigs are built while sample i + 1 is counted -- the walk / hook kernels of the
-    # graph stages are latency-bound (< 10 % VALU busy), the counting kernels issue-bound (65 - 73 %): two streams fill the device better than
-    # one.  A context is driven by one thread at a time and owns its tables, so the samples ALTERNATE between this context and a peer on the
-    # same device (made when the second sample arrives, if the device has room for a second workspace), and a sample's unitigs run in a worker
-    # thread on the sample's own context while the main thread counts the next sample on the other one.  MF_OVERLAP_SAMPLES=0: one context.
+    # Several samples on this rank, MF_OVERLAP_SAMPLES=1 (round 6, OFF by default): sample i's unitigs are built while sample i + 1 is counted.
+    # The idea: the walk / hook kernels of the graph stages are latency-bound (< 10 % VALU busy), the counting kernels
+    # issue-bound (65 - 73 %), two streams should fill the device better than one.  A context is driven by one thread at a time and owns its
+    # tables, so the samples ALTERNATE between this context and a peer on the same device (made when the second sample arrives, if the device
+    # has room for a second workspace), and a sample's unitigs run in a worker thread on the sample's own context while the main thread counts
+    # the next sample on the other one.  MEASURED (profiles/r06z_shape_config5_*): config 5 as specified 1296.2 -> 1292.7 ms per step, 8 x 5 M
+    # reads 272 -> 254 (most of it the features of the two contexts side by side): the kernels do run side by side -- k_skm_count's event time
+    # goes from 278 to 366 ms -- and slow each other down by what the overlap hides.  Not worth a second workspace and a thread by default.
     ctxs, running = [ctx], {}
 
     def wait(ci):
@@ -381,7 +384,7 @@ def _run_samples(ctx, samples, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda
     it = iter(samples)
     sample = next(it, None)
     si = -1
-    overlap_on = os.environ.get("MF_OVERLAP_SAMPLES", "1") != "0" and torch.cuda.is_available()
+    overlap_on = os.environ.get("MF_OVERLAP_SAMPLES", "0") == "1" and torch.cuda.is_available()
     while sample is not None:
         si += 1
         if si == 1 and len(ctxs) == 1 and overlap_on:
