@@ -188,6 +188,8 @@ int  mf_count_wide_device_above(mf_ctx *ctx, const void *d_bases, const void *d_
 int  mf_wtable_filter(const mf_wtable *t, int threshold, mf_wtable **out);
 /* [mf_table_drop_index] */
 int  mf_wtable_drop_index(mf_wtable *t);
+/* [mf_table_lookup] values[i] = count of the k-mer (keys_hi[i], keys_lo[i]) or -1; builds the lookup index on first use */
+int  mf_wtable_lookup(mf_wtable *t, const uint64_t *keys_hi, const uint64_t *keys_lo, uint64_t n, int32_t *values);
 /* [mf_build_unitigs_device] src/algo/AddSequencesShiftingRightTask.java:40-123 on 2k-bit k-mers; the result is an ordinary mf_seqs */
 int  mf_build_unitigs_wide_device(mf_ctx *ctx, mf_wtable *t, int freq_threshold, int min_len, mf_seqs **out);
 /* [mf_cut_components_device] src/algo/ComponentsBuilder.java:58-270; the cutter table = mf_count_wide_device over the unitigs with

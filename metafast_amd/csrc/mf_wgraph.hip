@@ -279,6 +279,29 @@ extern "C" int mf_features_wide_device(mf_ctx *ctx, mf_wcomps *c, mf_wtable *sam
         }
     return MF_OK;
 }
+// Long2ShortHashMap.get for a batch of host k-mers (as mf_table_lookup): values[i] = count or -1
+__global__ void k_w_lookup(mf_windex_view ix, const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n, int32_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t p = ix.n ? mf_windex_find(ix, hi[i], lo[i]) : 0xFFFFFFFFu;
+    out[i] = p == 0xFFFFFFFFu ? -1 : (int32_t)ix.cnt[p];
+}
+extern "C" int mf_wtable_lookup(mf_wtable *t, const uint64_t *keys_hi, const uint64_t *keys_lo, uint64_t n, int32_t *values) {
+    if (!t || (n && (!keys_hi || !keys_lo || !values))) return mf_set_error("mf_wtable_lookup: NULL argument");
+    if (!n) return MF_OK;
+    mf_ctx *ctx = t->ctx;
+    MF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (t->n) MF_TRY(mf_wtable_ensure_index(t));
+    mf_buf<uint64_t> dh, dl; mf_buf<int32_t> dv;
+    MF_TRY(dh.alloc(ctx, n)); MF_TRY(dl.alloc(ctx, n)); MF_TRY(dv.alloc(ctx, n));
+    MF_HIP(hipMemcpyAsync(dh.p, keys_hi, n * 8, hipMemcpyHostToDevice, st));
+    MF_HIP(hipMemcpyAsync(dl.p, keys_lo, n * 8, hipMemcpyHostToDevice, st));
+    k_w_lookup<<<ggrid(n), 256, 0, st>>>(wview(t), dh.p, dl.p, n, dv.p);
+    MF_HIP(hipMemcpyAsync(values, dv.p, n * 4, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    return MF_OK;
+}
 // the table's lookup index, released (rebuilt when a graph stage needs it again): a rank that holds several samples
 extern "C" int mf_wtable_drop_index(mf_wtable *t) {
     if (!t) return mf_set_error("wide table is NULL");

@@ -43,6 +43,7 @@ _SIGS = {
     "mf_count_wide_device_above": (i32, [vp, vp, vp, u64, u64, i32, i32, i32, pvp, pu64]),
     "mf_wtable_filter": (i32, [vp, i32, pvp]),
     "mf_wtable_drop_index": (i32, [vp]),
+    "mf_wtable_lookup": (i32, [vp, vp, vp, u64, vp]),
     "mf_build_unitigs_wide_device": (i32, [vp, vp, i32, i32, pvp]),
     "mf_cut_components_wide_device": (i32, [vp, vp, i32, i32, pvp]),
     "mf_wcomps_destroy": (None, [vp]),
@@ -480,6 +481,14 @@ class WideTable:
 
     def drop_index(self):
         _check(lib().mf_wtable_drop_index(self.h))
+
+    def lookup(self, kmers):
+        """kmers: iterable of Python ints (2k-bit k-mers) -> int32 counts, -1 = absent"""
+        ks = [int(x) for x in kmers]
+        hi = np.array([x >> 64 for x in ks], dtype=np.uint64); lo = np.array([x & 0xFFFFFFFFFFFFFFFF for x in ks], dtype=np.uint64)
+        out = np.empty(len(ks), dtype=np.int32)
+        _check(lib().mf_wtable_lookup(self.h, hi.ctypes.data, lo.ctypes.data, len(ks), out.ctypes.data))
+        return out
 
     def pieces(self):
         """[(d_hi, d_lo, d_counts, n)]: raw device pointers of every piece (uint64, uint64, uint16)"""
