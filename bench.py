@@ -61,10 +61,11 @@ def _load_extension_k63():
         return None
 
 
-def main_wide(args, ctx, device, rank, world):
+def main_wide(args, ctx, device, rank, world, use_dist=False):
     """`bench.py -k K` with 32 <= K <= 63: NO-REFERENCE EXTENSION (the reference rejects k > 31, src/tools/KmersCounterMain.java:66-73;
     BASELINE config 4's k = 63 leg).  The same step -- count with the cut inside, unitigs, cutter table, components, features, matrix -- on
-    2k-bit k-mers (mf_wide.hip, mf_wgraph.hip), reads resident in HBM; a normal line whose metric string says what it is.  One GPU."""
+    2k-bit k-mers (mf_wide.hip, mf_wgraph.hip), reads resident in HBM; a normal line whose metric string says what it is.  Several GPUs: a
+    sample (or several) per rank, unitigs gathered, the cutter replicated on every rank, rows all-gathered (pipeline.run_samples_wide)."""
     from metafast_amd import pipeline as P
     n_reads, rl, k = args.reads, args.read_len, args.k
     spg = max(1, args.samples_per_gpu)
@@ -95,19 +96,35 @@ def main_wide(args, ctx, device, rank, world):
                      matrix_checksum=float(np.nansum(r["matrix"])))
         for x in r["goods"] + r["seqss"] + [r["cutter"], r["comps"]]:
             x.close()
+        comm_kind[0] = (r.get("comm") or {}).get("kind")
         return stats
+
+    comm_kind = [None]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         stats = step()
     ctx.reset_timers()
     stage_t = {}
-    torch.cuda.synchronize()
+    barrier()
     gen_s[0] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         stats = step(stage_t)
-    torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0 - gen_s[0]
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        occ = torch.tensor([float(stats["n_occ"])], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(occ, op=dist.ReduceOp.SUM)
+        elapsed = float(t.item())
+        stats["n_occ_all_ranks"] = int(occ.item())
     if gen_s[0] and "count" in stage_t:
         stage_t["count"] -= gen_s[0]
     rep = ctx.kernel_report()
@@ -126,13 +143,13 @@ def main_wide(args, ctx, device, rank, world):
                         priced_as="%.1f B per k-mer occurrence (the two 64-bit words of every occurrence through the passes of this stage)" % passes)
     out = {
         "metric": "NO-REFERENCE EXTENSION: k-mers/s counted+graphed at k=%d, %d bp reads (the reference rejects k > 31)" % (k, rl),
-        "value": round(stats["n_occ"] * args.steps / elapsed, 1), "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "value": round(stats.get("n_occ_all_ranks", stats["n_occ"]) * args.steps / elapsed, 1), "unit": "k-mers/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u128", "data": "synthetic",
-        "config": {"workload": f"{spg} sample(s) x {n_reads} synthetic {rl} bp reads, k={k}, one GPU, count+unitigs+components+features "
+        "config": {"workload": f"{world * spg} sample(s) x {n_reads} synthetic {rl} bp reads, k={k}, {spg} per GPU, count+unitigs+components+features "
                                f"(b={args.bad_freq} l={args.min_len} b1={args.b1} b2={args.b2})",
                    "reads_per_gpu": n_reads, "read_len": rl, "k": k, "genome_scale_bp": args.genome_scale, "substitutions_per_base": round(sub16k / 16384, 5)},
-        "roofline": roof, "cpu_baseline": None, "stats": stats,
+        "roofline": roof, "cpu_baseline": None, "stats": stats, "comm_kind": comm_kind[0],
         "stage_ms_per_step": {kk: round(v / max(args.steps, 1) * 1e3, 3) for kk, v in stage_t.items()},
         "kernels": kern,
     }
@@ -441,13 +458,14 @@ def main():
 
     n_reads, rl, k = args.reads, args.read_len, args.k
     if k >= 32:
-        if world != 1:
-            raise SystemExit("bench.py -k %d: the 32 <= k <= 63 extension runs on one GPU" % k)
-        out = main_wide(args, ctx, device, rank, world)
-        sys.stdout.flush()
-        os.dup2(real_stdout, 1)
-        print(json.dumps(out), flush=True)
-        os.dup2(2, 1)
+        out = main_wide(args, ctx, device, rank, world, use_dist)
+        if rank == 0:
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
+            print(json.dumps(out), flush=True)
+            os.dup2(2, 1)
+        if use_dist:
+            dist.destroy_process_group()
         return
     spg = max(1, args.samples_per_gpu)
     e2e = {}

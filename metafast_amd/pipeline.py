@@ -535,8 +535,10 @@ def run_samples_wide(ctx, samples, k=63, b=1, l=100, b1=1000, b2=10000, device="
     """NO-REFERENCE EXTENSION (the reference rejects k > 31, src/tools/KmersCounterMain.java:66-73; BASELINE config 4 names a k = 63
     leg): the steps of _run_samples for 32 <= k <= 63 on THIS rank's samples -- counts with the cut inside the pass, unitigs, the cutter
     table over all unitigs, components, features, matrix (mf_wide.hip, mf_wgraph.hip).  samples: (d_bases, d_offsets, n_reads, n_bases)
-    tuples of torch tensors in HBM.  One rank only: the per-sample steps need no exchange, the join of several ranks' unitigs is not
-    built for wide k-mers."""
+    tuples of torch tensors in HBM.  Several ranks (one process per GPU, BASELINE config 4: a sample per GPU): the per-sample steps need no
+    exchange; the unitigs of all ranks are gathered on every rank (mf_comm_gather_sequences: sequences are sequences whatever k is) and every
+    rank cuts the components of the whole cutter table itself -- the REPLICATED cutter: a sharded one is not built for wide k-mers, their
+    tables have no minimizer partitions to own --; the rows of all ranks' samples are all-gathered for the matrix (mf_features_allgather)."""
     t0 = time.perf_counter()
 
     def mark(name):
@@ -575,23 +577,38 @@ def run_samples_wide(ctx, samples, k=63, b=1, l=100, b1=1000, b2=10000, device="
         torch.cuda.current_stream().synchronize()
         keep = (tb, to)
         sb, so, ns = tb.data_ptr(), to.data_ptr(), int(to.numel()) - 1
+    rank, world = _world()
+    comm, allr = None, None
+    if world > 1 or _force():
+        comm = getattr(ctx, "_mf_comm", None)
+        if comm is None or comm.h is None:
+            comm = ctx._mf_comm = make_comm(ctx, device)
+        comm.reset_stats()
+        ctx.synchronize()
+        allr = comm.gather_sequences(sb or 0, so or 0, ns, nb)
+        av = allr.device_view()
+        sb, so, ns, nb = av["bases"], av["offsets"], av["n"], av["n_bases"]
+        mark("exchange_unitigs")
     cutter = ctx.count_wide_table(sb, so, ns, nb, k, l)
+    if allr is not None:
+        allr.close()
     mark("cutter_count")
     comps = ctx.cut_components_wide(cutter, b1, b2)
     cutter.drop_index()
     mark("components")
-    vecs, breadths = [], []
+    vecs_local, breadths = [], []
     for good in goods:
         vec, br = ctx.features_wide(comps, good, 0)
         if len(goods) > 1:
             good.drop_index()
-        vecs.append(vec); breadths.append(br)
-    vecs = np.stack(vecs) if vecs else np.zeros((0, len(comps)), dtype=np.int64)
+        vecs_local.append(vec); breadths.append(br)
+    vecs_local = np.stack(vecs_local) if vecs_local else np.zeros((0, len(comps)), dtype=np.int64)
+    vecs = comm.features_allgather(vecs_local) if comm is not None else vecs_local
     matrix = L.bray_curtis(vecs) if vecs.shape[1] else np.zeros((vecs.shape[0], vecs.shape[0]))
     mark("features_matrix")
     del keep
-    return dict(goods=goods, seqss=seqss, cutter=cutter, comps=comps, vecs=vecs, breadths=breadths, matrix=matrix, n_occ=n_occ,
-                n_distinct=n_distinct)
+    return dict(goods=goods, seqss=seqss, cutter=cutter, comps=comps, vecs=vecs, vecs_local=vecs_local, breadths=breadths, matrix=matrix, n_occ=n_occ,
+                n_distinct=n_distinct, comm=dict(comm.stats(), kind=comm.kind) if comm is not None else None)
 
 
 def run_sample(ctx, d_bases, d_offsets, n_reads, n_bases, k=31, b=1, l=100, b1=1000, b2=10000, device="cuda",

@@ -35,6 +35,17 @@ def samples():
         b, o = branchy_reads(107 + 10 * (rank * spg + j), genome_seed=7, n=6000)
         db, do = to_device(b, o)
         yield db, do, len(o) - 1, len(b)
+kk = int(os.environ.get("MF_K", "31"))
+if kk >= 32:                                                      # NO-REFERENCE EXTENSION: a sample per rank, the replicated wide cutter
+    r = P.run_samples_wide(ctx, samples(), k=kk, b=1, l=100, b1=100, b2=1000, device=torch.device("cuda", dev))
+    e = r["comps"].export()
+    off = e["offsets"].astype(int)
+    out = dict(components=[[int(a), int(w), int(t)] for a, w, t in zip(e["sizes"], e["weights"], e["thr"])],
+               members=[[(int(h) << 64) | int(l_) for h, l_ in zip(e["hi"][off[i]:off[i + 1]], e["lo"][off[i]:off[i + 1]])] for i in range(len(e["sizes"]))],
+               vecs=r["vecs"].tolist(), matrix=r["matrix"].tolist(), comm={k: (v if isinstance(v, str) else float(v)) for k, v in r["comm"].items()})
+    json.dump(out, open(os.path.join(os.environ["MF_OUT"], f"rank{rank}.json"), "w"))
+    dist.destroy_process_group()
+    sys.exit(0)
 r = P.run_samples(ctx, samples(), k=31, b=1, l=100, b1=100, b2=1000, device=torch.device("cuda", dev))
 comps = r["comps"].export()
 out = dict(components=[[int(a), int(w), int(t)] for a, w, t, _ in comps], members=[[int(x) for x in km] for _, _, _, km in comps],
@@ -121,6 +132,22 @@ def test_two_ranks_two_samples_each(oracle, tmp_path):
     want = _oracle_pipeline(oracle, tmp_path, [107, 117, 127, 137])
     for r in res:
         _same(r, want)
+
+
+@pytest.mark.parametrize("k,spg", [(47, 1), (63, 2)])
+def test_two_ranks_wide_kmers_gloo(oracle, tmp_path, k, spg):
+    """NO-REFERENCE EXTENSION over two ranks (BASELINE config 4: a sample per GPU at k = 63): unitigs gathered through the library's
+    communicator, the wide cutter replicated on both ranks, the rows all-gathered -- both ranks end with the 128-bit oracle's components and matrix"""
+    from util import branchy_reads
+    res = _run(2, "gloo", tmp_path, spg=spg, extra_env={"MF_K": str(k)})
+    samples = [branchy_reads(107 + 10 * i, genome_seed=7, n=6000) for i in range(2 * spg)]
+    w = oracle.run_pipeline_wide(samples, k, b=1, l=100, b1=100, b2=1000)
+    wc = w["comps"].all()
+    assert len(wc) >= 3
+    want = dict(components=[[a, ww, t] for a, ww, t, _ in wc], members=[oracle.w128_to_ints(km) for _, _, _, km in wc], vecs=w["vecs"].tolist(), matrix=w["matrix"].tolist())
+    for r in res:
+        _same(r, want)
+        assert r["comm"]["kind"] == "external" and r["comm"]["collectives"] >= 5
 
 
 def test_rccl_path_world1(oracle, tmp_path):
