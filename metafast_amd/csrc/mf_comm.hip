@@ -161,11 +161,8 @@ extern "C" int mf_comm_create_local(mf_ctx *const *ctxs, int n, mf_comm **out) {
         for (int b = 0; b < n; b++) {
             if (g->device[a] == g->device[b]) continue;
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, g->device[a], g->device[b]) == hipSuccess && can && hipSetDevice(g->device[a]) == hipSuccess) {
-                const hipError_t e = hipDeviceEnablePeerAccess(g->device[b], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-                else if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
-            }
+            if (hipDeviceCanAccessPeer(&can, g->device[a], g->device[b]) == hipSuccess && can && hipSetDevice(g->device[a]) == hipSuccess)
+                if (hipDeviceEnablePeerAccess(g->device[b], 0) != hipSuccess) (void)hipGetLastError();      // (already enabled, or refused: the copies then go the runtime's way)
         }
     (void)hipSetDevice(cur);
     for (int r = 0; r < n; r++) {

@@ -142,7 +142,8 @@ extern "C" int mf_build_unitigs_wide_device(mf_ctx *ctx, mf_wtable *t, int freq_
     }
     if (g->n && g->n < 0x7FFFFFFFull) MF_TRY(mf_wtable_ensure_index(g));
     const mf_windex_view ix = wview(g);
-    return mf_ut_build(ctx, ix.lo, g->n ? ix.hi : reinterpret_cast<const uint64_t *>(8), ix.cnt, g->n, g->k, 0, nullptr, min_len, [&](const ut_arrays &A) -> int {
+    // (an empty table: no high words to point at -- mf_ut_build returns its empty result before it looks)
+    return mf_ut_build(ctx, ix.lo, ix.hi, ix.cnt, g->n, g->k, 0, nullptr, min_len, [&](const ut_arrays &A) -> int {
         k_w_ut_flags<<<ggrid(A.n), 256, 0, ctx->stream>>>(ix, A);
         return MF_OK;
     }, out);

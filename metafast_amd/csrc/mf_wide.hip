@@ -664,7 +664,7 @@ static int count_wide_impl(mf_ctx *ctx, const void *d_bases, const void *d_offse
     }
     if (occ_seen != n_occ) return fail(mf_set_error("mf_count_wide_device: internal error, the passes saw %llu of %llu k-mers", (unsigned long long)occ_seen, (unsigned long long)n_occ));
     t->n = n_kept; t->n_all = nd_total;
-    if (threshold >= 1) t->cut_thr = threshold;
+    t->cut_thr = threshold >= 1 ? threshold : 0;                                  // (a counted k-mer has count >= 1 > 0)
     return MF_OK;
 }
 extern "C" int mf_count_wide_device(mf_ctx *ctx, const void *d_bases, const void *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len,
