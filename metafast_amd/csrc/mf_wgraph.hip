@@ -26,10 +26,10 @@ static inline unsigned ggrid(uint64_t n, unsigned bs = 256) { return (unsigned)s
 // ---------------------------------------------------------------------------------------------
 // index
 // ---------------------------------------------------------------------------------------------
-__global__ void k_windex_build(unsigned long long *__restrict__ slots, uint64_t mask, const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n) {
+__global__ void k_windex_build(unsigned long long *__restrict__ slots, uint64_t mask, const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n, int k) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint64_t h = mf_whash(hi[i], lo[i]);
+    const uint64_t h = mf_whash_key(((mf_u128)hi[i] << 64) | (mf_u128)lo[i], k);          // (the canonical interior's: mf_wide.h)
     const unsigned long long ent = (h & 0xFFFFFFFF00000000ull) | (unsigned long long)(uint32_t)i;
     uint64_t s = h & mask;
     for (;;) {                                               // (the keys of a table are distinct)
@@ -49,11 +49,12 @@ int mf_wtable_ensure_index(mf_wtable *t) {
     mf_ktimer tm(ctx, "k_windex_build");
     MF_HIP(hipMemsetAsync(t->index.p, 0xFF, cap * 8, ctx->stream));
     auto &pc = *t->pieces[0];
-    k_windex_build<<<ggrid(t->n), 256, 0, ctx->stream>>>(t->index.p, t->index_mask, pc.hi.p, pc.lo.p, t->n);
+    k_windex_build<<<ggrid(t->n), 256, 0, ctx->stream>>>(t->index.p, t->index_mask, pc.hi.p, pc.lo.p, t->n, t->k);
     return MF_OK;
 }
 static mf_windex_view wview(const mf_wtable *t) {
     mf_windex_view v{};
+    v.k = t->k;
     if (t->n) { auto &pc = *t->pieces[0]; v.slots = t->index.p; v.mask = t->index_mask; v.hi = pc.hi.p; v.lo = pc.lo.p; v.cnt = pc.cnt.p; v.n = t->n; }
     return v;
 }
@@ -62,25 +63,51 @@ static mf_windex_view wview(const mf_wtable *t) {
 // the eight neighbours of a vertex: idx[2 nuc] = x[1..] + nuc (right), idx[2 nuc + 1] = nuc + x[..k-2] (left), as mf_nbr.h; bit i of
 // *flip: the table holds neighbour i as its reverse complement (a palindrome counts as itself)
 // ---------------------------------------------------------------------------------------------
+// The neighbours of ONE side of x in one probe sequence (mf_index_walk_side of the k <= 31 tables on two words): the four k-mers y_c share k - 1
+// bases with x.  pa = what (K >> 2) of a stored key K is if K is y_c on the right side (x's last k - 1 bases) or rc(y_c) on the left (rc(x)'s
+// last k - 1 bases); pb = what K's low k - 1 bases are if K is rc(y_c) on the right / y_c on the left.  side 0: right (y_c = x[1..] + c), 1: left
+// (y_c = c + x[..k-2]).  out[c] = table index or 0xFFFFFFFF; bit c of the result: the table holds neighbour c as its reverse complement (a
+// palindrome is both and counts as itself).
+__device__ __forceinline__ uint32_t w_side_walk(const mf_windex_view &ix, mf_u128 x, mf_u128 rcx, int k, uint32_t side, uint32_t (&out)[4]) {
+    const mf_u128 LM = (((mf_u128)1) << (2 * k - 2)) - 1, WM = LM >> 2;
+    const mf_u128 pa = side ? (rcx & LM) : (x & LM), pb = side ? (x >> 2) : (rcx >> 2);
+    const uint64_t h = mf_whash_interior(side ? (x >> 4) : (x & WM), side ? (rcx & WM) : (rcx >> 4));      // the interior the four share, and its reverse complement
+    const uint32_t tag = (uint32_t)(h >> 32);
+    out[0] = out[1] = out[2] = out[3] = 0xFFFFFFFFu;
+    uint32_t rv = 0;
+    uint64_t s = h & ix.mask;
+    for (;;) {
+        const unsigned long long v = ix.slots[s];
+        if (v == MF_WIDX_EMPTY) break;
+        if ((uint32_t)(v >> 32) == tag) {
+            const uint32_t p = (uint32_t)v;
+            const mf_u128 K = ((mf_u128)ix.hi[p] << 64) | (mf_u128)ix.lo[p];
+            const bool ma = (K >> 2) == pa, mb = (K & LM) == pb, fwd = side ? mb : ma;
+            if (ma || mb) {
+                const uint32_t ca = ((uint32_t)K & 3u) ^ (side ? 3u : 0u), cb = (uint32_t)(K >> (2 * k - 2)) ^ (side ? 0u : 3u);
+                const uint32_t c = fwd ? (side ? cb : ca) : (side ? ca : cb);
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) if (c == q) out[q] = p;
+                rv = (rv & ~(1u << c)) | ((fwd ? 0u : 1u) << c);
+            }
+        }
+        s = (s + 1) & ix.mask;
+    }
+    return rv;
+}
+// the eight neighbours of a vertex: idx[2 nuc] = x[1..] + nuc (right), idx[2 nuc + 1] = nuc + x[..k-2] (left), as mf_nbr.h; bit i of *flip: the
+// table holds neighbour i as its reverse complement
 __device__ __forceinline__ void w_neighbours(const mf_windex_view &ix, mf_u128 x, int k, uint32_t (&idx)[8], uint32_t *flip, bool *pal) {
-    const mf_u128 kmask = (((mf_u128)1) << (2 * k)) - 1;
     const mf_u128 rcx = mf_wrevcomp(x, k);
     *pal = rcx == x;
+    uint32_t r4[4], l4[4];
+    const uint32_t rr = w_side_walk(ix, x, rcx, k, 0u, r4), rl = w_side_walk(ix, x, rcx, k, 1u, l4);
     uint32_t fl = 0;
 #pragma unroll
-    for (uint32_t nuc = 0; nuc < 4; nuc++) {
-        {   // ShortKmer.shiftRight
-            const mf_u128 y = ((x << 2) | (mf_u128)nuc) & kmask, r = (rcx >> 2) | ((mf_u128)(3u - nuc) << (2 * k - 2));
-            const mf_u128 c = y < r ? y : r;
-            idx[2 * nuc] = mf_windex_find(ix, (uint64_t)(c >> 64), (uint64_t)c);
-            if (r < y) fl |= 1u << (2 * nuc);
-        }
-        {   // ShortKmer.shiftLeft
-            const mf_u128 y = (x >> 2) | ((mf_u128)nuc << (2 * k - 2)), r = ((rcx << 2) | (mf_u128)(3u - nuc)) & kmask;
-            const mf_u128 c = y < r ? y : r;
-            idx[2 * nuc + 1] = mf_windex_find(ix, (uint64_t)(c >> 64), (uint64_t)c);
-            if (r < y) fl |= 1u << (2 * nuc + 1);
-        }
+    for (uint32_t c = 0; c < 4; c++) {
+        idx[2 * c] = r4[c]; idx[2 * c + 1] = l4[c];
+        fl |= ((rr >> c) & 1u) << (2 * c);
+        fl |= ((rl >> c) & 1u) << (2 * c + 1);
     }
     *flip = fl;
 }

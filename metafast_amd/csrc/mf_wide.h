@@ -21,7 +21,7 @@ struct mf_wtable {
     // = position (low 32 bits) | tag (the hash's high 32 bits), ~0 = empty, load <= 0.5
     mf_buf<unsigned long long> index; uint64_t index_mask = 0;
 };
-struct mf_windex_view { const unsigned long long *slots; uint64_t mask; const uint64_t *hi, *lo; const uint16_t *cnt; uint64_t n; };
+struct mf_windex_view { const unsigned long long *slots; uint64_t mask; const uint64_t *hi, *lo; const uint16_t *cnt; uint64_t n; int k; };
 
 int mf_wtable_flatten(mf_wtable *t);                      // all pieces into one (no-op for <= 1 piece)
 int mf_wtable_ensure_index(mf_wtable *t);                 // flatten + index
@@ -31,9 +31,31 @@ int mf_wide_compact(mf_ctx *ctx, const uint64_t *hi, const uint64_t *lo, const u
 #ifdef __HIPCC__
 #define MF_WIDX_EMPTY 0xFFFFFFFFFFFFFFFFull
 __device__ __forceinline__ uint64_t mf_whash(uint64_t hi, uint64_t lo) { return mf_hash64(lo * 0x9E3779B97F4A7C15ull ^ hi); }
+// reverse complement of a 2k-bit k-mer, 32 <= k <= 63 (A0 G1 C2 T3: complement = 3 - n)
+__device__ __forceinline__ uint64_t mf_wrev2(uint64_t x) {
+    const uint64_t y = __brevll(x);
+    return ((y & 0x5555555555555555ull) << 1) | ((y >> 1) & 0x5555555555555555ull);
+}
+__device__ __forceinline__ mf_u128 mf_wrevcomp(mf_u128 x, int k) {
+    const mf_u128 r = ((mf_u128)mf_wrev2((uint64_t)x) << 64) | (mf_u128)mf_wrev2((uint64_t)(x >> 64));
+    return (~r) >> (128 - 2 * k);
+}
+// The index is hashed on the k-mer's CANONICAL INTERIOR (its middle k - 2 bases or their reverse complement, whichever is smaller), as the
+// k <= 31 tables' is (mf_cidx_hkey): the four k-mers that extend a (k - 1)-mer on one side share it, and so do their reverse complements, so ONE
+// probe sequence from that home slot to the next empty slot meets all four neighbours of a side (w_side_walk, mf_wgraph.hip): two probe
+// sequences per vertex instead of eight.  h: home slot = low bits, tag = high 32 bits.
+__device__ __forceinline__ uint64_t mf_whash_interior(mf_u128 w, mf_u128 rw) {
+    const mf_u128 c = w < rw ? w : rw;
+    return mf_whash((uint64_t)(c >> 64), (uint64_t)c);
+}
+__device__ __forceinline__ uint64_t mf_whash_key(mf_u128 x, int k) {
+    const mf_u128 WM = (((mf_u128)1) << (2 * k - 4)) - 1;
+    const mf_u128 rcx = mf_wrevcomp(x, k);
+    return mf_whash_interior((x >> 2) & WM, (rcx >> 2) & WM);
+}
 // position of the k-mer (hi, lo) in the table or 0xFFFFFFFF
 __device__ __forceinline__ uint32_t mf_windex_find(const mf_windex_view &ix, uint64_t hi, uint64_t lo) {
-    const uint64_t h = mf_whash(hi, lo);
+    const uint64_t h = mf_whash_key(((mf_u128)hi << 64) | (mf_u128)lo, ix.k);
     const uint32_t tag = (uint32_t)(h >> 32);
     uint64_t s = h & ix.mask;
     for (;;) {
@@ -45,14 +67,5 @@ __device__ __forceinline__ uint32_t mf_windex_find(const mf_windex_view &ix, uin
         }
         s = (s + 1) & ix.mask;
     }
-}
-// reverse complement of a 2k-bit k-mer, 32 <= k <= 63 (A0 G1 C2 T3: complement = 3 - n)
-__device__ __forceinline__ uint64_t mf_wrev2(uint64_t x) {
-    const uint64_t y = __brevll(x);
-    return ((y & 0x5555555555555555ull) << 1) | ((y >> 1) & 0x5555555555555555ull);
-}
-__device__ __forceinline__ mf_u128 mf_wrevcomp(mf_u128 x, int k) {
-    const mf_u128 r = ((mf_u128)mf_wrev2((uint64_t)x) << 64) | (mf_u128)mf_wrev2((uint64_t)(x >> 64));
-    return (~r) >> (128 - 2 * k);
 }
 #endif
