@@ -98,6 +98,9 @@ struct mf_ctx {
     int64_t opt_gz_piece = 2 << 20;         // ... in pieces of at least this many compressed bytes (tests: 65536)
     int64_t opt_ut_double_after = 4;   // unitigs: walks still under way after this many chunked rounds (32, 128, 512, 4096 jumps) double the jump words instead (tests: 1)
     int64_t opt_ut_plain_rounds = 3;   // unitigs of a table without partitions (2k-bit tables, k < 20): rounds of doubling the one-hop jump words over all nodes before the walks (0: none)
+    int64_t opt_wide_skm = 1;      // mf_count_wide_device: super-k-mer records + LDS tables (mf_wskm.hip) instead of sorting every occurrence (0: the sort path, mf_wide.hip)
+    int64_t opt_wide_skm_min = 1 << 20;     // ... from this many k-mer occurrences on (tests: 1)
+    int64_t opt_wide_skm_unit = 4000;       // ... k-mer occurrences per counting unit (tests lower it: units that overflow the LDS table are counted in passes)
     int64_t opt_wide_finish = 1;   // mf_count_wide_device: radix passes over the leading 32 bits + the order inside the buckets in LDS (0: radix passes over all 2k bits)
     int64_t opt_wide_big_bucket = 256;   // ... buckets of more entries than this (<= 256) go through the LDS hash table instead of the walk (tests lower it)
     int64_t opt_wide_distinct = 1280;    // ... buckets of more distinct k-mers than this (<= 1280) are sorted aside (tests lower it)

@@ -23,6 +23,9 @@ struct mf_wtable {
 };
 struct mf_windex_view { const unsigned long long *slots; uint64_t mask; const uint64_t *hi, *lo; const uint16_t *cnt; uint64_t n; int k; };
 
+// the count on the record path (mf_wskm.hip): 0 = *t filled, 1 = not an input for it (the caller counts the old way), < 0 = error
+int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len, int threshold,
+                      const uint32_t *vmask, uint64_t n_words, mf_wtable *t);
 int mf_wtable_flatten(mf_wtable *t);                      // all pieces into one (no-op for <= 1 piece)
 int mf_wtable_ensure_index(mf_wtable *t);                 // flatten + index
 // entries of (hi, lo, cnt)[n] with cnt > thr -> a new piece (order kept)

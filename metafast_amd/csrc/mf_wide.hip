@@ -507,6 +507,12 @@ static int count_wide_impl(mf_ctx *ctx, const void *d_bases, const void *d_offse
         k_wide_mask_init<<<wgrid(n_words), 256, 0, st>>>(vmask.p, n_words);
         k_wide_mask_reads<<<wgrid(n_reads), 256, 0, st>>>((const uint64_t *)d_offsets, n_reads, k, min_read_len, vmask.p);
     }
+    if (ctx->opt_wide_skm) {
+        // the record path (mf_wskm.hip): super-k-mer records + LDS tables; 1 = not an input for it (tiny, no room): the sort path below
+        const int rc = mf_count_wide_skm(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, min_read_len, threshold, vmask.p, n_words, t);
+        if (rc < 0) return fail(rc);
+        if (rc == 0) return MF_OK;
+    }
     {
         mf_ktimer tm(ctx, "k_wide_kmers");
         if (hipMemsetAsync(chist.p, 0, sizeof(unsigned long long) << WG_CB, st) != hipSuccess) return fail(mf_set_error("mf_count_wide_device: memset failed"));

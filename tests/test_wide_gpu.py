@@ -6,6 +6,14 @@ import numpy as np
 import pytest
 
 
+@pytest.fixture(autouse=True)
+def _record_path_back_on(request):
+    """tests of the sort path switch the record path (round 6, option wide_skm) off: back on behind every test"""
+    yield
+    if "gpu_ctx" in request.fixturenames:
+        request.getfixturevalue("gpu_ctx").set_option("wide_skm", 1)
+
+
 def _reads(rng, n, lo, hi, genome=4000, err=0.01, polya=80):
     g = rng.integers(0, 4, genome)
     g[100:100 + polya] = 0                                            # poly-A: key 0, saturation
@@ -56,6 +64,8 @@ def test_wide_counts_in_passes(gpu_ctx, oracle, k, passes):
     """a 200 M-read sample has 1.8e10 63-mers, more than one sort takes (2^32 entries, 32 bytes each twice over): the
     reads are counted in passes, one per prefix class of the canonical k-mers, and the ascending passes append to the same table.
     Forced pass counts (option wide_passes) on ragged reads: identical to the one-pass table and to the 128-bit oracle."""
+    gpu_ctx.set_option("wide_skm", 0)          # (the sort path of mf_wide.hip: the record path of round 6 -- mf_wskm.hip -- has tests of its own below)
+
     from util import to_device
     rng = np.random.default_rng(100 + k)
     bases, off = _reads(rng, 30000, 20, 160)
@@ -104,6 +114,8 @@ def test_wide_buckets_small_and_large(gpu_ctx, oracle, k):
     k-mers is gathered, sorted with the full radix sort and put back (or, when such buckets hold more than a quarter of a pass, the whole pass is).
     A genome at depth ~10 with a long poly-A stretch: mostly small buckets + a few large ones; the limits lowered by option drive every route;
     wide_finish = 0 is the 16-pass sort of round 4.  One table, the oracle's."""
+    gpu_ctx.set_option("wide_skm", 0)          # (the sort path of mf_wide.hip: the record path of round 6 -- mf_wskm.hip -- has tests of its own below)
+
     from util import to_device
     rng = np.random.default_rng(500 + k)
     bases, off = _reads(rng, 30000, 60, 160, genome=300000, err=0.005, polya=400)
@@ -241,3 +253,40 @@ def test_wide_oracle_agrees_with_the_pinned_oracle_at_the_seam(oracle):
             k31[x] = k31.get(x, 0) + 1
     ok, ov = t.export()
     assert np.array_equal(ok, np.array(sorted(k31), dtype=np.uint64)) and np.array_equal(ov, np.array([k31[int(x)] for x in ok]))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", [32, 33, 40, 47, 62, 63])
+def test_wide_record_path_equals_sort_path(gpu_ctx, oracle, k):
+    """round 6: the count on the RECORD path (mf_wskm.hip: super-k-mer records of 32 bytes, LDS tables with two words per key) against the
+    sort path (mf_wide.hip) and the 128-bit oracle -- ragged reads with a poly-A stretch (key 0, saturation) and (AT)n palindromes, with and
+    without the cut, units small enough that some overflow the LDS table and are counted in passes, reads cut at tile borders"""
+    from util import to_device
+    rng = np.random.default_rng(700 + k)
+    bases, off = _reads(rng, 60000, 20, 220)
+    db, do = to_device(bases, off)
+    n = len(off) - 1
+    hi, lo, cnt, n_occ = oracle.count_wide(bases, off, k, 0)
+    try:
+        for unit in (4000, 300, 64):
+            gpu_ctx.set_option("wide_skm", 1); gpu_ctx.set_option("wide_skm_min", 1); gpu_ctx.set_option("wide_skm_unit", unit)
+            got = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), n, len(bases), k, 0)
+            assert got["n_occ"] == n_occ
+            assert np.array_equal(got["hi"], hi) and np.array_equal(got["lo"], lo) and np.array_equal(got["counts"].astype(np.int32), cnt), unit
+        gpu_ctx.set_option("wide_skm_unit", 4000)
+        for thr in (1, 3):
+            t, n_all = gpu_ctx.count_wide_above(db.data_ptr(), do.data_ptr(), n, len(bases), k, thr)
+            ghi, glo, gc = t.export()
+            keep = cnt > thr
+            assert n_all == len(cnt) and np.array_equal(ghi, hi[keep]) and np.array_equal(glo, lo[keep]) and np.array_equal(gc.astype(np.int32), cnt[keep])
+        gpu_ctx.set_option("wide_skm", 0)
+        old = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), n, len(bases), k, 0)
+        assert np.array_equal(old["hi"], hi) and np.array_equal(old["counts"].astype(np.int32), cnt)
+        # min_read_len, and nothing at all
+        gpu_ctx.set_option("wide_skm", 1)
+        got = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), n, len(bases), k, 150)
+        h2, l2, c2, o2 = oracle.count_wide(bases, off, k, 150)
+        assert got["n_occ"] == o2 and np.array_equal(got["hi"], h2) and np.array_equal(got["lo"], l2) and np.array_equal(got["counts"].astype(np.int32), c2)
+    finally:
+        gpu_ctx.set_option("wide_skm", 1); gpu_ctx.set_option("wide_skm_min", 1 << 20); gpu_ctx.set_option("wide_skm_unit", 4000)
+
