@@ -98,6 +98,11 @@ struct mf_ctx {
     int64_t opt_gz_piece = 2 << 20;         // ... in pieces of at least this many compressed bytes (tests: 65536)
     int64_t opt_ut_double_after = 4;   // unitigs: walks still under way after this many chunked rounds (32, 128, 512, 4096 jumps) double the jump words instead (tests: 1)
     int64_t opt_ut_plain_rounds = 3;   // unitigs of a table without partitions (2k-bit tables, k < 20): rounds of doubling the one-hop jump words over all nodes before the walks (0: none)
+    int64_t opt_stream_count = 1;  // mf_count_reads*: plain FASTA / FASTQ files are counted WHILE they cross PCIe (mf_stream.hip: upload || parse || level-1 scatter, piece by piece)
+    int64_t opt_stream_count_min = 512 << 20, opt_stream_count_piece = 256 << 20;   // ... from this many bytes of files on; bytes per piece
+    int64_t opt_stream_count_test_pct = 100;   // (tests: the digit regions get this share of what the sample says -- below 100 they overflow and the count steps back)
+    uint64_t n_streamed = 0, n_stream_stepped_back = 0;     // counts that went that way / that started that way and were done again from whole files
+    void *up_stream = nullptr;     // hipStream_t of the streamed count's uploads (lazy)
     int64_t opt_wide_skm = 1;      // mf_count_wide_device: super-k-mer records + LDS tables (mf_wskm.hip) instead of sorting every occurrence (0: the sort path, mf_wide.hip)
     int64_t opt_wide_skm_min = 1 << 20;     // ... from this many k-mer occurrences on (tests: 1)
     int64_t opt_wide_skm_unit = 4000;       // ... k-mer occurrences per counting unit (tests lower it: units that overflow the LDS table are counted in passes)

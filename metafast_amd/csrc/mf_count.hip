@@ -591,6 +591,85 @@ template <typename K> static int set_lds(K kern, size_t bytes) {
     return MF_OK;
 }
 
+// K0 as a call (the streamed count masks piece by piece): vmask[ceil(n_bases / 32)], *d_nocc += the piece's k-mer occurrences; asynchronous
+int mf_mask_reads(mf_ctx *ctx, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_len, uint32_t *vmask, unsigned long long *d_nocc) {
+    const uint64_t n_words = (n_bases + 31) / 32;
+    if (!n_words || !n_reads) return MF_OK;
+    mf_ktimer t(ctx, "k_mask");
+    k_mask_init<<<(unsigned)((n_words + 255) / 256), 256, 0, ctx->stream>>>(vmask, n_words, n_bases);
+    k_mask_reads<<<(unsigned)((n_reads + 1023) / 1024), 1024, 0, ctx->stream>>>(d_offsets, n_reads, k, min_len, vmask, d_nocc);
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+// the partition plan of a count: lv = the k-mer path's levels, slv = the super-k-mer path's (counting units), B = partition bits of the table,
+// assembled = the input is taken for assembled sequences (no pilot).  Shared by mf_count_core and the streamed count (mf_stream.hip), which plans
+// from an estimate of n_occ.
+int mf_count_plan(mf_ctx *ctx, uint64_t n_occ, uint64_t n_reads, uint64_t n_bases, int k, int min_len, std::vector<int> &lv, std::vector<int> &slv, bool &assembled, int &B) {
+    // ---- partition plan ----
+    // Partitions are sized by k-mer OCCURRENCES (the LDS table must hold a partition's distinct k-mers, and reads repeat
+    // theirs: several occurrences per distinct k-mer).  Long sequences (mean length >= 8k) are assembled ones -- the
+    // cutter's input, ComponentCutterMain.java:81 -- whose k-mers are nearly all distinct: size those by a sixth, so that
+    // a partition's index region stays a few KB and the 8 neighbour probes of a k-mer stay cache-local.
+    uint64_t target = (uint64_t)ctx->opt_part_target;
+    // (assembled: long sequences, or a caller that filters by length -- ComponentCutterMain.java:81 is the one that does --, or
+    // the pipeline's hint; at low coverage unitigs are short, and partitions planned for reads then hold 4000 distinct k-mers)
+    // (round 5: length alone says "assembled" only where no pilot will look at the input: 250-base reads at k = 25 .. 31 are "long sequences"
+    // by the 8 k rule, were planned as unitigs -- 2^23 units of 200 records, three radix levels -- and took 387 ms where 150-base reads of the
+    // same volume take 130 (profiles/r05az_probe_shapes.txt); the pilot measures what the rule guesses: distinct k-mers per occurrence)
+    const bool pilot_looks = ctx->opt_skm && k >= MF_SKM_MIN_K && ctx->opt_skm_pilot != 0 && ctx->opt_l1_bits < 0;
+    assembled = (n_bases / n_reads >= (uint64_t)(8 * k) && !pilot_looks) || min_len > 0 || ctx->opt_union_samples > 0 || ctx->own_world > 1;
+    if (assembled && target > (uint64_t)ctx->opt_part_target_long) target = (uint64_t)ctx->opt_part_target_long;
+    // (a shard of the union of many samples' unitigs: the samples share most of their k-mers -- 0.36 distinct per occurrence at 8
+    // samples --, and it is the DISTINCT k-mers of a partition that must fit the LDS tables)
+    if ((ctx->own_world >= 4 || ctx->opt_union_samples >= 4) && target == (uint64_t)ctx->opt_part_target_long) target *= 2;
+    B = ceil_log2_u64((n_occ + target - 1) / target);
+    if (ctx->own_world > 1) {                       // (a shard: every rank must own at least one level-1 digit)
+        int lw = 0; while ((1 << lw) < ctx->own_world) lw++;
+        if (B < lw) B = lw;
+        if (!ctx->opt_skm || k < MF_SKM_MIN_K) return mf_set_error("mf_count_device_shard: k >= %d needed (minimizer partitions decide the owner)", MF_SKM_MIN_K);
+    }
+    lv.clear();
+    if (ctx->opt_l1_bits >= 0) {
+        lv.push_back((int)ctx->opt_l1_bits);
+        int rest = ctx->opt_l2_bits >= 0 ? (int)ctx->opt_l2_bits : std::max(0, B - lv[0]);
+        while (rest > 0) { int b = std::min(rest, MF_MAX_DIGIT_BITS); lv.push_back(b); rest -= b; }
+    } else {
+        int levels = std::max(1, (B + MF_MAX_DIGIT_BITS - 1) / MF_MAX_DIGIT_BITS);
+        int rest = B;
+        for (int i = 0; i < levels; i++) { int b = (rest + (levels - i) - 1) / (levels - i); lv.push_back(b); rest -= b; }
+    }
+    int total_bits = 0; for (int b : lv) total_bits += b;
+    if (total_bits > 40) return mf_set_error("partition plan needs %d bits", total_bits);
+
+    // ---- the super-k-mer path's plan (mf_skm.hip) ----
+    {
+        // A third radix level costs a whole extra pass over the records (k = 21, 100 M reads: 23 bits, +96 ms).  The LDS table
+        // limits a partition's DISTINCT k-mers, the plan sizes it by occurrences: up to twice the target is tried with two
+        // full levels first (if a partition turns out too rich the call ends up on the k-mer path, with its own plan).
+        // The counting pass runs on partitions TWICE the planned size (one bit fewer): its per-partition costs (directory,
+        // barriers, the sweep of the LDS table) halve, and the gather cuts every counting partition in two by the next bit of
+        // the partition hash, so the table still has the B bits of partitions the graph kernels are planned for (k_gather_split).
+        // Forced plans (l1_bits / l2_bits: tests) are taken as the counting plan.
+        slv = lv;
+        if (ctx->opt_l1_bits < 0) {
+            int Bc = B > 0 ? B - 1 : 0;
+            // (assembled sequences: nearly every k-mer distinct, and the table's partitions are planned small for the graph kernels --
+            // 256 occurrences -- where the counting kernel pays four workgroup barriers and a sweep of its LDS table per unit: it
+            // counts EIGHT table partitions as one unit (~2000 distinct k-mers, k_gather_split_n cuts them apart); the cutter-table
+            // launch of the benchmark cost 13 x the sample's time per occurrence with units of two)
+            if (assembled) Bc = std::max(0, B - (int)ctx->opt_unit_parts_long);
+            if (ctx->own_world > 1) { int lw = 0; while ((1 << lw) < ctx->own_world) lw++; if (Bc < lw) Bc = lw; }
+            slv.clear();
+            const int levels = std::max(1, (Bc + MF_MAX_DIGIT_BITS - 1) / MF_MAX_DIGIT_BITS);
+            int rest = Bc;
+            for (int i = 0; i < levels; i++) { int b = (rest + (levels - i) - 1) / (levels - i); slv.push_back(b); rest -= b; }
+            if (slv.size() == 3 && Bc <= 2 * MF_MAX_DIGIT_BITS + 1 && (n_occ >> (2 * MF_MAX_DIGIT_BITS)) <= 4 * target)
+                slv = {MF_MAX_DIGIT_BITS, MF_MAX_DIGIT_BITS};
+        }
+    }
+    return MF_OK;
+}
+
 // thr >= 0: keep only the k-mers with count > thr (*n_all = distinct k-mers before the cut); thr < 0: keep everything
 int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases,
                   int k, int min_len, mf_table **out, int thr, uint64_t *n_all) {
@@ -620,67 +699,12 @@ int mf_count_core(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets
     MF_HIP(hipStreamSynchronize(st));
     if (n_occ == 0) return mf_table_adopt(ctx, k, 0, 0, nullptr, 0, nullptr, 0, out);
 
-    // ---- partition plan ----
-    // Partitions are sized by k-mer OCCURRENCES (the LDS table must hold a partition's distinct k-mers, and reads repeat
-    // theirs: several occurrences per distinct k-mer).  Long sequences (mean length >= 8k) are assembled ones -- the
-    // cutter's input, ComponentCutterMain.java:81 -- whose k-mers are nearly all distinct: size those by a sixth, so that
-    // a partition's index region stays a few KB and the 8 neighbour probes of a k-mer stay cache-local.
-    uint64_t target = (uint64_t)ctx->opt_part_target;
-    // (assembled: long sequences, or a caller that filters by length -- ComponentCutterMain.java:81 is the one that does --, or
-    // the pipeline's hint; at low coverage unitigs are short, and partitions planned for reads then hold 4000 distinct k-mers)
-    // (round 5: length alone says "assembled" only where no pilot will look at the input: 250-base reads at k = 25 .. 31 are "long sequences"
-    // by the 8 k rule, were planned as unitigs -- 2^23 units of 200 records, three radix levels -- and took 387 ms where 150-base reads of the
-    // same volume take 130 (profiles/r05az_probe_shapes.txt); the pilot measures what the rule guesses: distinct k-mers per occurrence)
-    const bool pilot_looks = ctx->opt_skm && k >= MF_SKM_MIN_K && ctx->opt_skm_pilot != 0 && ctx->opt_l1_bits < 0;
-    const bool assembled = (n_bases / n_reads >= (uint64_t)(8 * k) && !pilot_looks) || min_len > 0 || ctx->opt_union_samples > 0 || ctx->own_world > 1;
-    if (assembled && target > (uint64_t)ctx->opt_part_target_long) target = (uint64_t)ctx->opt_part_target_long;
-    // (a shard of the union of many samples' unitigs: the samples share most of their k-mers -- 0.36 distinct per occurrence at 8
-    // samples --, and it is the DISTINCT k-mers of a partition that must fit the LDS tables)
-    if ((ctx->own_world >= 4 || ctx->opt_union_samples >= 4) && target == (uint64_t)ctx->opt_part_target_long) target *= 2;
-    int B = ceil_log2_u64((n_occ + target - 1) / target);
-    if (ctx->own_world > 1) {                       // (a shard: every rank must own at least one level-1 digit)
-        int lw = 0; while ((1 << lw) < ctx->own_world) lw++;
-        if (B < lw) B = lw;
-        if (!ctx->opt_skm || k < MF_SKM_MIN_K) return mf_set_error("mf_count_device_shard: k >= %d needed (minimizer partitions decide the owner)", MF_SKM_MIN_K);
-    }
-    std::vector<int> lv;
-    if (ctx->opt_l1_bits >= 0) {
-        lv.push_back((int)ctx->opt_l1_bits);
-        int rest = ctx->opt_l2_bits >= 0 ? (int)ctx->opt_l2_bits : std::max(0, B - lv[0]);
-        while (rest > 0) { int b = std::min(rest, MF_MAX_DIGIT_BITS); lv.push_back(b); rest -= b; }
-    } else {
-        int levels = std::max(1, (B + MF_MAX_DIGIT_BITS - 1) / MF_MAX_DIGIT_BITS);
-        int rest = B;
-        for (int i = 0; i < levels; i++) { int b = (rest + (levels - i) - 1) / (levels - i); lv.push_back(b); rest -= b; }
-    }
+    std::vector<int> lv, slv; bool assembled = false; int B = 0;
+    MF_TRY(mf_count_plan(ctx, n_occ, n_reads, n_bases, k, min_len, lv, slv, assembled, B));
     int total_bits = 0; for (int b : lv) total_bits += b;
-    if (total_bits > 40) return mf_set_error("partition plan needs %d bits", total_bits);
 
     // ---- super-k-mer path (mf_skm.hip); falls through to the k-mer path below if the input does not suit it ----
     if (ctx->opt_skm && k >= MF_SKM_MIN_K) {
-        // A third radix level costs a whole extra pass over the records (k = 21, 100 M reads: 23 bits, +96 ms).  The LDS table
-        // limits a partition's DISTINCT k-mers, the plan sizes it by occurrences: up to twice the target is tried with two
-        // full levels first (if a partition turns out too rich the call ends up on the k-mer path, with its own plan).
-        // The counting pass runs on partitions TWICE the planned size (one bit fewer): its per-partition costs (directory,
-        // barriers, the sweep of the LDS table) halve, and the gather cuts every counting partition in two by the next bit of
-        // the partition hash, so the table still has the B bits of partitions the graph kernels are planned for (k_gather_split).
-        // Forced plans (l1_bits / l2_bits: tests) are taken as the counting plan.
-        std::vector<int> slv = lv;
-        if (ctx->opt_l1_bits < 0) {
-            int Bc = B > 0 ? B - 1 : 0;
-            // (assembled sequences: nearly every k-mer distinct, and the table's partitions are planned small for the graph kernels --
-            // 256 occurrences -- where the counting kernel pays four workgroup barriers and a sweep of its LDS table per unit: it
-            // counts EIGHT table partitions as one unit (~2000 distinct k-mers, k_gather_split_n cuts them apart); the cutter-table
-            // launch of the benchmark cost 13 x the sample's time per occurrence with units of two)
-            if (assembled) Bc = std::max(0, B - (int)ctx->opt_unit_parts_long);
-            if (ctx->own_world > 1) { int lw = 0; while ((1 << lw) < ctx->own_world) lw++; if (Bc < lw) Bc = lw; }
-            slv.clear();
-            const int levels = std::max(1, (Bc + MF_MAX_DIGIT_BITS - 1) / MF_MAX_DIGIT_BITS);
-            int rest = Bc;
-            for (int i = 0; i < levels; i++) { int b = (rest + (levels - i) - 1) / (levels - i); slv.push_back(b); rest -= b; }
-            if (slv.size() == 3 && Bc <= 2 * MF_MAX_DIGIT_BITS + 1 && (n_occ >> (2 * MF_MAX_DIGIT_BITS)) <= 4 * target)
-                slv = {MF_MAX_DIGIT_BITS, MF_MAX_DIGIT_BITS};
-        }
         // (reads: the plan is provisional -- a pilot measures the distinct k-mers per occurrence and sets the later levels, mf_skm.hip)
         int rc = mf_count_skm(ctx, d_bases, n_bases, vmask.p, n_words, n_occ, k, slv, ctx->opt_l1_bits < 0 && !assembled,
                               ctx->opt_l1_bits < 0 && assembled ? B : 0, scal.p, thr, n_all, out);

@@ -141,6 +141,7 @@ extern "C" void mf_ctx_destroy(mf_ctx *ctx) {
     for (auto ev : ctx->event_pool) hipEventDestroy(ev);
     if (ctx->pin_pool) { if (ctx->pin_pool_pinned) hipHostFree(ctx->pin_pool); else free(ctx->pin_pool); }
     if (ctx->up_pool) { if (ctx->up_pool_pinned) hipHostFree(ctx->up_pool); else free(ctx->up_pool); }
+    if (ctx->up_stream) (void)hipStreamDestroy((hipStream_t)ctx->up_stream);
     if (ctx->own_stream && ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -180,6 +181,10 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "skm_dyn") ctx->opt_skm_dyn = v;
     else if (s == "nbr_global") ctx->opt_nbr_global = v;
     else if (s == "ut_plain_rounds") ctx->opt_ut_plain_rounds = v;
+    else if (s == "stream_count") ctx->opt_stream_count = v;
+    else if (s == "stream_count_min_bytes") ctx->opt_stream_count_min = v;
+    else if (s == "stream_count_piece_bytes") ctx->opt_stream_count_piece = v;
+    else if (s == "stream_count_test_pct") ctx->opt_stream_count_test_pct = v;
     else if (s == "wide_skm") ctx->opt_wide_skm = v;
     else if (s == "wide_skm_min") ctx->opt_wide_skm_min = v;
     else if (s == "wide_skm_unit") ctx->opt_wide_skm_unit = v;
@@ -225,6 +230,8 @@ extern "C" int64_t mf_ctx_stat(mf_ctx *ctx, const char *name) {
     if (s == "unitig_doublings") return (int64_t)ctx->n_ut_doubled;
     if (s == "wide_big_entries") return (int64_t)ctx->n_wide_big;
     if (s == "wide_hashed_entries") return (int64_t)ctx->n_wide_hashed;
+    if (s == "streamed_counts") return (int64_t)ctx->n_streamed;
+    if (s == "streamed_counts_stepped_back") return (int64_t)ctx->n_stream_stepped_back;
     if (s == "device_parsed_files") return (int64_t)ctx->n_dparse_files;
     if (s == "device_parser_stepped_back") return (int64_t)ctx->n_dparse_stepped_back;
     if (s == "hipmalloc_calls") return (int64_t)ctx->n_hipmalloc;

@@ -553,8 +553,12 @@ static int ensure_up_pool(mf_ctx *ctx, size_t want) {
     return 0;
 }
 // mem != nullptr: the bytes come from host memory (an inflated .gz file) instead of the file: the same staging, memcpy for pread
-static int upload_bytes(mf_ctx *ctx, int fd, const uint8_t *mem, size_t fsize, uint8_t *d_raw) {
-    std::lock_guard<std::mutex> turn(g_upload_mutex[(unsigned)ctx->device & 63u]);
+// file_off: where in the file the fsize bytes start; up: the stream the copies go on (the streamed count, mf_stream.hip: a stream of its own, so that they
+// cross PCIe while the context's stream computes); take_turn = false: the caller holds the device's turn already
+static int upload_bytes(mf_ctx *ctx, int fd, const uint8_t *mem, size_t fsize, uint8_t *d_raw, size_t file_off = 0, hipStream_t up = nullptr, bool take_turn = true) {
+    if (!up) up = ctx->stream;
+    std::unique_lock<std::mutex> turn(g_upload_mutex[(unsigned)ctx->device & 63u], std::defer_lock);
+    if (take_turn) turn.lock();
     const size_t PIECE = (size_t)std::max<int64_t>(ctx->opt_device_parse_piece, 1 << 16);
     const size_t np = (fsize + PIECE - 1) / PIECE;
     const size_t WMAX = (size_t)std::min<int64_t>(std::max<int64_t>(ctx->opt_device_parse_threads, 1), std::max(ctx->host_threads, 1));
@@ -581,9 +585,9 @@ static int upload_bytes(mf_ctx *ctx, int fd, const uint8_t *mem, size_t fsize, u
                 if (busy[cur]) { (void)hipEventSynchronize(ev[cur]); busy[cur] = false; }
                 size_t got = 0;
                 if (mem) { memcpy(pin[cur], mem + lo, len); got = len; }
-                else while (got < len) { const ssize_t r = pread(fd, pin[cur] + got, len - got, (off_t)(lo + got)); if (r <= 0) break; got += (size_t)r; }
+                else while (got < len) { const ssize_t r = pread(fd, pin[cur] + got, len - got, (off_t)(file_off + lo + got)); if (r <= 0) break; got += (size_t)r; }
                 if (got != len) { state = -1; break; }
-                if (hipMemcpyAsync(d_raw + lo, pin[cur], len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess || hipEventRecord(ev[cur], ctx->stream) != hipSuccess) { state = -2; break; }
+                if (hipMemcpyAsync(d_raw + lo, pin[cur], len, hipMemcpyHostToDevice, up) != hipSuccess || hipEventRecord(ev[cur], up) != hipSuccess) { state = -2; break; }
                 busy[cur] = true;
                 cur ^= 1;
             }
@@ -596,6 +600,15 @@ static int upload_bytes(mf_ctx *ctx, int fd, const uint8_t *mem, size_t fsize, u
 }
 
 int mf_upload_file(mf_ctx *ctx, int fd, size_t fsize, uint8_t *d_raw) { return upload_bytes(ctx, fd, nullptr, fsize, d_raw); }
+// ---- for the streamed count (mf_stream.hip): a range of a file / a host buffer to HBM on a stream of the caller's; the device's upload turn as a lock object
+int mf_upload_range(mf_ctx *ctx, int fd, size_t file_off, size_t len, uint8_t *d_dst, hipStream_t up) { return upload_bytes(ctx, fd, nullptr, len, d_dst, file_off, up, false); }
+int mf_upload_mem(mf_ctx *ctx, const uint8_t *mem, size_t len, uint8_t *d_dst, hipStream_t up) { return upload_bytes(ctx, -1, mem, len, d_dst, 0, up, false); }
+std::mutex &mf_upload_turn(mf_ctx *ctx) { return g_upload_mutex[(unsigned)ctx->device & 63u]; }
+int mf_upload_pool(mf_ctx *ctx) {
+    const size_t PIECE = (size_t)std::max<int64_t>(ctx->opt_device_parse_piece, 1 << 16);
+    const size_t WMAX = (size_t)std::min<int64_t>(std::max<int64_t>(ctx->opt_device_parse_threads, 1), std::max(ctx->host_threads, 1));
+    return ensure_up_pool(ctx, (size_t)2 * WMAX * PIECE);
+}
 
 // ---- a .gz file: the host inflates it piece by piece (mf_inflate.h, one member on many threads) INTO the pinned staging chunks, and the chunks go
 // up as they fill -- the inflated text is never whole in host memory (first-touch page faults on those gigabytes were a third of the load) and is
@@ -675,6 +688,12 @@ static int dparse_source(mf_ctx *ctx, const char *path, const uint8_t *mem, size
                          mf_buf<uint8_t> *filled = nullptr, int filled_qoff = 64);
 int mf_dparse_file(mf_ctx *ctx, const char *path, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases) {
     return dparse_source(ctx, path, nullptr, 0, fmt, bases, offsets, n_reads, n_bases);
+}
+// the text is in HBM already (n bytes at d_raw, in a buffer of at least the whole 256 KB chunks they span + 64 bytes, which stays the caller's): a piece
+// of a file that starts and ends at record borders (mf_stream.hip).  qoff: the FASTQ quality offset the caller has decided from the file's head
+int mf_dparse_device(mf_ctx *ctx, const char *path, uint8_t *d_raw, size_t room, size_t n, int fmt, int qoff, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases) {
+    mf_buf<uint8_t> view; view.borrow(ctx, d_raw, room);
+    return dparse_source(ctx, path, nullptr, n, fmt, bases, offsets, n_reads, n_bases, &view, qoff);
 }
 int mf_dparse_mem(mf_ctx *ctx, const char *path, const void *mem, size_t mem_n, int fmt, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases) {
     if (!mem || !mem_n) return 1;

@@ -445,6 +445,7 @@ extern "C" int mf_reads_export(const mf_reads *r, uint8_t *bases, uint64_t *offs
     return MF_OK;
 }
 
+int mf_count_files_streamed(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, int thr, uint64_t *n_all, mf_table **out);
 // IOUtils.loadReads (src/io/IOUtils.java:772-803): all files into one table
 static int count_reads_impl(mf_ctx *ctx, const char *const *files, int nfiles, int k, int min_read_len, int threshold, mf_table **out,
                             uint64_t *n_distinct_all, const char *who) {
@@ -453,6 +454,12 @@ static int count_reads_impl(mf_ctx *ctx, const char *const *files, int nfiles, i
     if (k < 1) return mf_set_error("The size of k-mer must be at least 1.");
     if (k > 31) return mf_set_error("The size of k-mer must be no more than 31.");
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    {
+        // large plain FASTA / FASTQ files are counted while they cross PCIe (mf_stream.hip); 1: not that way, nothing was produced
+        const int src = mf_count_files_streamed(ctx, files, nfiles, k, min_read_len, threshold < 0 ? -1 : threshold, n_distinct_all, out);
+        if (src <= 0) return src;
+        if (n_distinct_all) *n_distinct_all = 0;
+    }
     mf_buf<uint8_t> db; mf_buf<uint64_t> doff;
     uint64_t nr = 0, nb = 0; double tp = 0, th = 0;
     MF_TRY(load_reads_to_device(ctx, files, nfiles, db, doff, &nr, &nb, &tp, &th));

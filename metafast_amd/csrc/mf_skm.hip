@@ -29,6 +29,7 @@
 #include "mf_common.h"
 #include "mf_count_dev.h"
 #include <algorithm>
+#include <memory>
 #include <vector>
 
 typedef ulonglong2 skm_rec;
@@ -309,6 +310,9 @@ struct skm_dyn {
     const uint64_t *rend;         // [nd] end of the region
     unsigned int *overflow;       // set when a region was too small (the caller repeats the level with exact ranges)
     uint64_t dump;                // a scratch chunk of this workgroup: where lines go after an overflow
+    unsigned long long *save;     // [G][nd] or null.  STREAMED level 1 (mf_stream.hip: the reads arrive piece by piece, a launch per piece): a workgroup's
+                                  // position inside its current chunk of every digit outlives the launch, so that a piece leaves a partly filled LINE per
+                                  // workgroup and digit behind, not a partly filled chunk (30 pieces x 256 workgroups x 1024 digits x 256 records = 30 GB of padding)
 };
 template <bool DYN>
 __device__ __forceinline__ uint64_t skm_take_line(const skm_stage &L, uint32_t dg, const skm_dyn &Dy) {
@@ -396,9 +400,20 @@ __device__ __forceinline__ void skm_stage_flush_all(const skm_stage &L, skm_rec 
         }
         if (DYN) {
             uint64_t pos = L.cur[d];
-            if (pos != SKM_NONE) for (; (pos & (uint64_t)(SKM_CH - 1)) != 0ull; pos++) out[pos] = SENT;
+            if (Dy.save) Dy.save[(size_t)blockIdx.x * nd + d] = pos;         // (k_skm_close_chunks pads them after the last piece)
+            else if (pos != SKM_NONE) for (; (pos & (uint64_t)(SKM_CH - 1)) != 0ull; pos++) out[pos] = SENT;
         }
     }
+}
+// after the last piece of a streamed level 1: the unused rest of every workgroup's current chunk becomes sentinels (positions in the dump
+// area -- after an overflow: the level is thrown away -- are left alone)
+__global__ void k_skm_close_chunks(const unsigned long long *__restrict__ save, uint64_t n, uint64_t cap, skm_rec *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t pos = save[i];
+    if (pos == SKM_NONE || pos >= cap) return;
+    const skm_rec SENT = make_ulonglong2(~0ull, ~0ull);
+    for (; (pos & (uint64_t)(SKM_CH - 1)) != 0ull; pos++) out[pos] = SENT;
 }
 
 // =============================================================================================
@@ -428,7 +443,10 @@ __global__ __launch_bounds__(1024) void k_skm_scatter(const uint8_t *__restrict_
     const int nd = 1 << bits1;
     skm_stage L = skm_stage_carve(smem, nd);
     if (DYN) Dy.dump += (uint64_t)blockIdx.x * SKM_CH;
-    for (int i = threadIdx.x; i < nd; i += blockDim.x) { L.cur[i] = DYN ? SKM_NONE : blockstart[(size_t)i * G + blockIdx.x]; L.ctr[i] = 0; }
+    for (int i = threadIdx.x; i < nd; i += blockDim.x) {
+        L.cur[i] = DYN ? (Dy.save ? (uint64_t)Dy.save[(size_t)blockIdx.x * nd + i] : SKM_NONE) : blockstart[(size_t)i * G + blockIdx.x];
+        L.ctr[i] = 0;
+    }
     if (threadIdx.x < 64) L.ctr[nd + threadIdx.x] = 0;
     __syncthreads();
     // FAST: this wave's parking area and run list, behind the staging area
@@ -1760,7 +1778,7 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
             MF_HIP(hipMemcpyAsync(&cap, &scal[1], 8, hipMemcpyDeviceToHost, st));
             MF_HIP(hipStreamSynchronize(st));
             if (bufA.alloc(ctx, std::max<unsigned long long>(cap + (uint64_t)G * SKM_CH, SH ? 0ull : final_cap(cap))) != MF_OK) return MF_SKM_NOMEM;
-            skm_dyn Dy; Dy.gcur = gcur.p; Dy.rend = rstart.p + 1; Dy.overflow = (unsigned int *)&scal[5]; Dy.dump = cap;
+            skm_dyn Dy; Dy.gcur = gcur.p; Dy.rend = rstart.p + 1; Dy.overflow = (unsigned int *)&scal[5]; Dy.dump = cap; Dy.save = nullptr;
             {
                 mf_ktimer t(ctx, "k_skm_scatter");
                 if (fast_lds) {
@@ -2079,7 +2097,10 @@ static int skm_slice(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, cons
 // input does not suit this path (a partition too rich for the LDS table, too many levels, not enough memory).
 template <int K>
 static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words,
-                   uint64_t n_occ, const std::vector<int> &lv0, bool adaptive, int table_bits, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out) {
+                   uint64_t n_occ, const std::vector<int> &lv0, bool adaptive, int table_bits, unsigned long long *scal, int thr, uint64_t *n_all, mf_table **out,
+                   skm_shared *pre = nullptr) {
+    // pre: level 1 stands already (a STREAMED one, skm_stream_* below: the reads are gone, d_bases == nullptr) -- whatever would scan them again
+    // ends the run with MF_SKM_FALLBACK and the caller starts over from the files
     hipStream_t st = ctx->stream;
     std::vector<int> lv = lv0;                 // (the levels after the first may change once the pilot has measured the reads' depth)
     const int bits1 = lv[0], nd1 = 1 << bits1;
@@ -2139,12 +2160,19 @@ static int skm_run(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const 
     while (S > 1 && (own_hi - own_lo) / S < 1) S /= 2;
     if (S == 1) shared = false;
     skm_shared SH; SH.lo = own_lo; SH.hi = own_hi;
+    if (pre) {
+        if (W != 1 || lv.size() < 2 || !pre->ready) return MF_SKM_FALLBACK;
+        shared = true;
+        SH.buf.swap(pre->buf); SH.pstart.swap(pre->pstart); SH.plen.swap(pre->plen); SH.pocc.swap(pre->pocc); SH.h_pstart.swap(pre->h_pstart);
+        SH.cap = pre->cap; SH.ready = true; pre->ready = false;
+    }
     const uint32_t S_own = S;
     int shared_tries = 0;
     // ---- the PILOT (round 4, skm_pilot below): the plan the caller made sizes the counting units by OCCURRENCES; what a unit costs
     // is decided by its DISTINCT k-mers.  The first slice measures them once its level 1 stands and re-plans the later levels.
     bool plan_open = adaptive && ctx->opt_skm_pilot != 0 && lv.size() >= 2 && W == 1;
     for (;;) {
+        if (pre && !(shared && SH.ready)) return MF_SKM_FALLBACK;
         skm_acc A;                                              // (A.np_total, A.doff: set by the first slice, once the plan stands)
         A.table_bits = table_bits;
         if (kthr >= 0) { MF_TRY(A.dhist.alloc(ctx, (size_t)MF_MAX_COUNT + 1)); MF_HIP(hipMemsetAsync(A.dhist.p, 0, A.dhist.bytes(), st)); }
@@ -2233,6 +2261,156 @@ template <int K, typename... A> static int skm_run_if(A &&... a) {
     if constexpr (K - mf_skm_m(K) + 1 >= 3 && K - mf_skm_m(K) + 1 <= 17) return skm_run<K>(std::forward<A>(a)...);
     else return MF_SKM_FALLBACK;
 }
+// =============================================================================================
+// STREAMED level 1 (round 6; the driver is mf_stream.hip): the reads of a library arrive piece by piece while the rest of the file is still crossing
+// PCIe.  begin: the digit regions are sized from a SAMPLE of the files (chunks spread evenly over them, parsed like a small file) and the record
+// buffer is made; piece: one launch of the one-pass scatter per piece, all pieces filling the same regions through the same cursors; finish: the
+// directory, and the run goes on behind a level 1 that "the first slice has made" (skm_shared).  A region that turns out too small, a plan without
+// a split level, anything else that would need the reads again: MF_SKM_FALLBACK, and the caller loads the files whole.
+// =============================================================================================
+struct mf_skm_stream {
+    mf_ctx *ctx = nullptr; int k = 0;
+    std::vector<int> lv; bool adaptive = false; int table_bits = 0;
+    int G = 0; size_t fast_lds = 0;
+    mf_buf<unsigned long long> scal, gcur, save;
+    mf_buf<uint64_t> rstart;
+    mf_buf<skm_rec> buf; unsigned long long cap = 0;
+    uint64_t pieces = 0;
+};
+__global__ void k_skm_region_sizes_stream(const uint32_t *__restrict__ blockhist, int Gs, int nd, double scale, uint32_t G, uint32_t pct, uint32_t *__restrict__ rsize) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nd) return;
+    uint64_t t = 0;
+    for (int b = 0; b < Gs; b++) t += blockhist[(size_t)d * Gs + b];
+    const double e = (double)t * scale;
+    // an eighth + four standard deviations of the sample's count, scaled; a partly used chunk per workgroup; the runs a piece border cuts
+    uint64_t r = (uint64_t)(e + e / 8.0 + 4.0 * sqrt((double)t + 1.0) * scale) + (uint64_t)G * SKM_CH + 16384;
+    if (pct != 100u) r = r * pct / 100u;                 // (tests: regions that overflow)
+    r = (r + SKM_CH - 1) & ~(uint64_t)(SKM_CH - 1);
+    rsize[d] = r > 0xFFFFFF00ull ? 0xFFFFFF00u : (uint32_t)r;
+}
+template <int K>
+static int skm_stream_begin(mf_skm_stream *S, const uint8_t *s_bases, uint64_t s_nbases, const uint32_t *s_vmask, uint64_t s_nwords, double scale) {
+    mf_ctx *ctx = S->ctx; hipStream_t st = ctx->stream;
+    const int bits1 = S->lv[0], nd1 = 1 << bits1;
+    int total_bits = 0; for (int b : S->lv) total_bits += b;
+    if (S->lv.size() < 2 || total_bits > 30 || total_bits - bits1 > SKM_DIGIT_BITS) return MF_SKM_FALLBACK;
+    S->G = ctx->opt_l1_blocks > 0 ? (int)ctx->opt_l1_blocks : ctx->n_cu;
+    S->fast_lds = ((skm_stage_bytes(nd1) + 15) & ~(size_t)15) + (size_t)16 * SKM_FAST_WAVE_BYTES;
+    if (S->fast_lds > (size_t)160 * 1024 || ctx->opt_scatter_fast == 0) S->fast_lds = 0;
+    int Gs = S->G;
+    { const uint64_t maxG = (s_nwords + 1023) / 1024; if ((uint64_t)Gs > maxG) Gs = (int)std::max<uint64_t>(maxG, 1); }
+    const uint64_t wpb = (s_nwords + Gs - 1) / Gs;
+    mf_buf<uint32_t> blockhist; MF_TRY(blockhist.alloc(ctx, (size_t)nd1 * Gs));
+    {
+        mf_ktimer t(ctx, "k_skm_hist_sample");
+        k_skm_hist<K><<<Gs, 1024, (size_t)nd1 * 8, st>>>(s_bases, s_nbases, s_vmask, s_nwords, wpb, bits1, blockhist.p, nullptr, Gs, 1, 0u, (uint32_t)nd1);
+    }
+    MF_TRY(S->scal.alloc(ctx, 12)); MF_HIP(hipMemsetAsync(S->scal.p, 0, S->scal.bytes(), st));
+    mf_buf<uint32_t> rsize; MF_TRY(rsize.alloc(ctx, (size_t)nd1));
+    MF_TRY(S->rstart.alloc(ctx, (size_t)nd1 + 1)); MF_TRY(S->gcur.alloc(ctx, (size_t)nd1)); MF_TRY(S->save.alloc(ctx, (size_t)S->G * nd1));
+    k_skm_region_sizes_stream<<<(nd1 + 255) / 256, 256, 0, st>>>(blockhist.p, Gs, nd1, scale, (uint32_t)S->G, (uint32_t)std::max<int64_t>(ctx->opt_stream_count_test_pct, 1), rsize.p);
+    MF_TRY(mf_scan<1>(ctx, rsize.p, S->rstart.p, (uint64_t)nd1, (uint64_t *)&S->scal.p[1]));
+    MF_HIP(hipMemcpyAsync(S->gcur.p, S->rstart.p, (size_t)nd1 * 8, hipMemcpyDeviceToDevice, st));
+    MF_HIP(hipMemsetAsync(S->save.p, 0xFF, S->save.bytes(), st));
+    MF_HIP(hipMemcpyAsync(&S->cap, &S->scal.p[1], 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    if (S->buf.alloc(ctx, S->cap + (uint64_t)S->G * SKM_CH) != MF_OK) return MF_SKM_FALLBACK;
+    if (ctx->opt_verbose) fprintf(stderr, "[mf] skm (streamed): level 1 of %d bits, regions for %.2f G records (%.1f GB) from a sample of %.1f M bases x %.1f\n", bits1, S->cap / 1e9, S->cap * 16 / 1e9, s_nbases / 1e6, scale);
+    return MF_OK;
+}
+template <int K>
+static int skm_stream_piece(mf_skm_stream *S, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words) {
+    mf_ctx *ctx = S->ctx; hipStream_t st = ctx->stream;
+    const int bits1 = S->lv[0], nd1 = 1 << bits1, G = S->G;
+    const uint64_t wpb = (n_words + G - 1) / G;
+    skm_dyn Dy; Dy.gcur = S->gcur.p; Dy.rend = S->rstart.p + 1; Dy.overflow = (unsigned int *)&S->scal.p[5]; Dy.dump = S->cap; Dy.save = S->save.p;
+    mf_ktimer t(ctx, "k_skm_scatter");
+    if (S->fast_lds) {
+        MF_TRY(skm_set_lds(k_skm_scatter<K, true, true>, S->fast_lds));
+        k_skm_scatter<K, true, true><<<G, 1024, S->fast_lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, S->buf.p, Dy, 0u, (uint32_t)nd1);
+    } else {
+        const size_t lds = skm_stage_bytes(nd1);
+        MF_TRY(skm_set_lds(k_skm_scatter<K, true, false>, lds));
+        k_skm_scatter<K, true, false><<<G, 1024, lds, st>>>(d_bases, n_bases, vmask, n_words, wpb, bits1, nullptr, G, S->buf.p, Dy, 0u, (uint32_t)nd1);
+    }
+    S->pieces++;
+    MF_HIP(hipGetLastError());
+    return MF_OK;
+}
+static int skm_cut_above(int rc, int thr, mf_table **out) {
+    if (rc == MF_OK && thr >= 0 && (*out)->cut_thr < thr) {
+        // a cut the counting kernel does not make itself (thr >= C2_LH): as a pass over the finished table
+        mf_table *all = *out, *good = nullptr;
+        rc = mf_table_filter(all, thr, &good);
+        if (rc == MF_OK) { good->n_occ = all->n_occ; good->n_records = all->n_records; good->record_bytes = all->record_bytes; }
+        mf_table_destroy(all);
+        *out = good;
+    }
+    return rc;
+}
+template <int K>
+static int skm_stream_finish(mf_skm_stream *S, uint64_t n_occ, uint64_t n_bases, int thr, uint64_t *n_all, mf_table **out) {
+    mf_ctx *ctx = S->ctx; hipStream_t st = ctx->stream;
+    const int nd1 = 1 << S->lv[0];
+    k_skm_close_chunks<<<(unsigned)(((uint64_t)S->G * nd1 + 255) / 256), 256, 0, st>>>(S->save.p, (uint64_t)S->G * nd1, S->cap, S->buf.p);
+    skm_shared pre; pre.lo = 0; pre.hi = (uint32_t)nd1;
+    MF_TRY(pre.pstart.alloc(ctx, (size_t)nd1)); MF_TRY(pre.plen.alloc(ctx, (size_t)nd1)); MF_TRY(pre.pocc.alloc(ctx, (size_t)nd1));
+    k_skm_dir_dyn<<<(nd1 + 255) / 256, 256, 0, st>>>(S->rstart.p, S->gcur.p, nd1, pre.pstart.p, pre.plen.p);
+    unsigned long long ovf = 0;
+    pre.h_pstart.resize((size_t)nd1);
+    MF_HIP(hipMemcpyAsync(&ovf, &S->scal.p[5], 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipMemcpyAsync(pre.h_pstart.data(), pre.pstart.p, (size_t)nd1 * 8, hipMemcpyDeviceToHost, st));
+    MF_HIP(hipStreamSynchronize(st));
+    if (ovf) {
+        if (ctx->opt_verbose) fprintf(stderr, "[mf] skm (streamed): a digit region sized from the sample was too small\n");
+        return MF_SKM_FALLBACK;
+    }
+    pre.buf.swap(S->buf); pre.cap = S->cap; pre.ready = true;
+    S->gcur.reset(); S->save.reset(); S->rstart.reset();
+    MF_HIP(hipMemsetAsync(S->scal.p, 0, S->scal.bytes(), st));
+    const int rc = skm_run<K>(ctx, nullptr, n_bases, nullptr, (n_bases + 31) / 32, n_occ, S->lv, S->adaptive, S->table_bits, S->scal.p, thr, n_all, out, &pre);
+    return skm_cut_above(rc, thr, out);
+}
+template <int K, typename... A> static int skm_stream_begin_if(A &&... a) {
+    if constexpr (K - mf_skm_m(K) + 1 >= 3 && K - mf_skm_m(K) + 1 <= 17) return skm_stream_begin<K>(std::forward<A>(a)...); else return MF_SKM_FALLBACK;
+}
+template <int K, typename... A> static int skm_stream_piece_if(A &&... a) {
+    if constexpr (K - mf_skm_m(K) + 1 >= 3 && K - mf_skm_m(K) + 1 <= 17) return skm_stream_piece<K>(std::forward<A>(a)...); else return MF_SKM_FALLBACK;
+}
+template <int K, typename... A> static int skm_stream_finish_if(A &&... a) {
+    if constexpr (K - mf_skm_m(K) + 1 >= 3 && K - mf_skm_m(K) + 1 <= 17) return skm_stream_finish<K>(std::forward<A>(a)...); else return MF_SKM_FALLBACK;
+}
+#ifndef MF_SKM_ONLY_K31
+#define SKM_STREAM_SWITCH(FN, ...) switch (S->k) { \
+        case 20: return FN<20>(__VA_ARGS__); case 21: return FN<21>(__VA_ARGS__); case 22: return FN<22>(__VA_ARGS__); case 23: return FN<23>(__VA_ARGS__); \
+        case 24: return FN<24>(__VA_ARGS__); case 25: return FN<25>(__VA_ARGS__); case 26: return FN<26>(__VA_ARGS__); case 27: return FN<27>(__VA_ARGS__); \
+        case 28: return FN<28>(__VA_ARGS__); case 29: return FN<29>(__VA_ARGS__); case 30: return FN<30>(__VA_ARGS__); case 31: return FN<31>(__VA_ARGS__); \
+        default: return MF_SKM_FALLBACK; }
+#else
+#define SKM_STREAM_SWITCH(FN, ...) switch (S->k) { case 31: return FN<31>(__VA_ARGS__); default: return MF_SKM_FALLBACK; }
+#endif
+// lv / adaptive / table_bits: the counting plan (mf_count_plan) made from an ESTIMATE of the occurrences; MF_SKM_FALLBACK: not this way
+int mf_skm_stream_begin(mf_ctx *ctx, int k, const std::vector<int> &lv, bool adaptive, int table_bits, const uint8_t *s_bases, uint64_t s_nbases,
+                        const uint32_t *s_vmask, uint64_t s_nwords, double scale, mf_skm_stream **out) {
+    *out = nullptr;
+    if (!ctx->opt_skm || k < MF_SKM_MIN_K || k > 31 || ctx->own_world > 1) return MF_SKM_FALLBACK;
+    std::unique_ptr<mf_skm_stream> U(new mf_skm_stream());
+    mf_skm_stream *S = U.get();
+    S->ctx = ctx; S->k = k; S->lv = lv; S->adaptive = adaptive; S->table_bits = table_bits;
+    auto go = [&]() -> int { SKM_STREAM_SWITCH(skm_stream_begin_if, S, s_bases, s_nbases, s_vmask, s_nwords, scale) };
+    const int rc = go();
+    if (rc == MF_OK) *out = U.release();
+    return rc;
+}
+int mf_skm_stream_piece(mf_skm_stream *S, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words) {
+    SKM_STREAM_SWITCH(skm_stream_piece_if, S, d_bases, n_bases, vmask, n_words)
+}
+int mf_skm_stream_finish(mf_skm_stream *S, uint64_t n_occ, uint64_t n_bases, int thr, uint64_t *n_all, mf_table **out) {
+    SKM_STREAM_SWITCH(skm_stream_finish_if, S, n_occ, n_bases, thr, n_all, out)
+}
+void mf_skm_stream_free(mf_skm_stream *S) { delete S; }
+
 // adaptive: the plan was made from the number of occurrences alone -- the levels after the first may be re-planned from a pilot
 // table_bits: partition bits the caller wants the TABLE to have (0: one more than the counting plan's)
 int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const uint32_t *vmask, uint64_t n_words, uint64_t n_occ,
@@ -2248,13 +2426,5 @@ int mf_count_skm(mf_ctx *ctx, const uint8_t *d_bases, uint64_t n_bases, const ui
 #undef SKM_CASE
         default: return MF_SKM_FALLBACK;
     }
-    if (rc == MF_OK && thr >= 0 && (*out)->cut_thr < thr) {
-        // a cut the counting kernel does not make itself (thr >= C2_LH): as a pass over the finished table
-        mf_table *all = *out, *good = nullptr;
-        rc = mf_table_filter(all, thr, &good);
-        if (rc == MF_OK) { good->n_occ = all->n_occ; good->n_records = all->n_records; good->record_bytes = all->record_bytes; }
-        mf_table_destroy(all);
-        *out = good;
-    }
-    return rc;
+    return skm_cut_above(rc, thr, out);
 }
