@@ -507,7 +507,9 @@ static int count_wide_impl(mf_ctx *ctx, const void *d_bases, const void *d_offse
         k_wide_mask_init<<<wgrid(n_words), 256, 0, st>>>(vmask.p, n_words);
         k_wide_mask_reads<<<wgrid(n_reads), 256, 0, st>>>((const uint64_t *)d_offsets, n_reads, k, min_read_len, vmask.p);
     }
-    if (ctx->opt_wide_skm) {
+    // (assembled sequences -- the cutter table's input, filtered by length: ComponentCutterMain.java:81 -- hold every k-mer once: LDS tables merge nothing,
+    // and the sort path counts the 3.9e8 k-mers of the 200 M-read sample's unitigs in 53 ms where the record path takes 144; wide_skm = 2: always)
+    if (ctx->opt_wide_skm == 2 || (ctx->opt_wide_skm && min_read_len <= 0)) {
         // the record path (mf_wskm.hip): super-k-mer records + LDS tables; 1 = not an input for it (tiny, no room): the sort path below
         const int rc = mf_count_wide_skm(ctx, (const uint8_t *)d_bases, (const uint64_t *)d_offsets, n_reads, n_bases, k, min_read_len, threshold, vmask.p, n_words, t);
         if (rc < 0) return fail(rc);

@@ -283,7 +283,7 @@ def test_wide_record_path_equals_sort_path(gpu_ctx, oracle, k):
         old = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), n, len(bases), k, 0)
         assert np.array_equal(old["hi"], hi) and np.array_equal(old["counts"].astype(np.int32), cnt)
         # min_read_len, and nothing at all
-        gpu_ctx.set_option("wide_skm", 1)
+        gpu_ctx.set_option("wide_skm", 2)          # (2: the record path for inputs filtered by length too -- by default those are taken for assembled sequences)
         got = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), n, len(bases), k, 150)
         h2, l2, c2, o2 = oracle.count_wide(bases, off, k, 150)
         assert got["n_occ"] == o2 and np.array_equal(got["hi"], h2) and np.array_equal(got["lo"], l2) and np.array_equal(got["counts"].astype(np.int32), c2)
