@@ -83,10 +83,13 @@ int  mf_ctx_reset_timers(mf_ctx *ctx);
  * buffer found no place in HBM), "device_parsed_files" / "device_parser_stepped_back" (read files the device parser took / left to
  * the host readers), "unitig_doublings" (unitig runs whose long paths went through the doubled jump words), "wide_hashed_entries" /
  * "wide_big_entries" (k = 32..63: entries of large buckets ordered through the LDS hash tables / sorted aside), "hipmalloc_calls",
- * "hipmalloc_bytes", "hipmalloc_us", "arena_bytes", "arena_idle_bytes".  < 0: unknown name. */
+ * "hipmalloc_bytes", "hipmalloc_us", "arena_bytes", "arena_idle_bytes", "streamed_counts" / "streamed_counts_stepped_back" (counts of read
+ * files that ran while the files crossed PCIe / that started so and were done again from the whole files).  < 0: unknown name. */
 int64_t mf_ctx_stat(mf_ctx *ctx, const char *name);
 
 /* ---- A1-A4  reads -> canonical k-mer counts ---------------------------------------- */
+/* (round 6: plain FASTA / FASTQ files of 512 MB and more are counted WHILE they cross PCIe -- option "stream_count", mf_stream.hip: the reference's
+ * reader feeds its workers while it reads, src/io/ReadsDispatcher.java:34-53 -- with the same table as a result) */
 /* replaces IOUtils.loadReads (src/io/IOUtils.java:772-803), called from
  * KmersCounterMain.runImpl (src/tools/KmersCounterMain.java:77) with min_read_len=0 and from
  * ComponentCutterMain.runImpl (src/tools/ComponentCutterMain.java:81) with min_read_len=l.
