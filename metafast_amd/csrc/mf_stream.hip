@@ -45,22 +45,14 @@ int mf_dparse_device(mf_ctx *ctx, const char *path, uint8_t *d_raw, size_t room,
 #define ST_WINDOW ((size_t)1 << 20)       // how far a record border is looked for behind a nominal cut
 #define ST_SAMPLE ((size_t)128 << 10)     // bytes per sample chunk
 
-// the first record start in [w, w + n) AFTER position 0 (the window begins anywhere inside a record): FASTA -- a '>' behind a line feed; FASTQ -- a
-// line that starts with '@' whose next line but one starts with '+' (a QUALITY line may start with '@' too: the line after it is then the next
-// record's '@' header and the one after that its bases, which never start with '+').  (size_t)-1: none in the window
+// the first record start in [w, w + n) AFTER position 0 (the window begins anywhere inside a record): the stream reader's cutter (mf_parse.h,
+// sr_record_start: FASTA -- a '>' or ';' behind a line feed; FASTQ -- a line that starts with '@' whose next line but one starts with '+': a QUALITY
+// line may start with '@' too, but the line after it is then the next record's '@' header and the one after that its bases, which never start
+// with '+'; it runs under ASan + UBSan in the CPU suite, tests/host/parse_harness.cpp "cuts").  (size_t)-1: none in the window
 static size_t record_start(const char *w, size_t n, int fmt) {
-    if (fmt == 1) {
-        for (size_t i = 0; i + 1 < n; i++) if (w[i] == '\n' && w[i + 1] == '>') return i + 1;
-        return (size_t)-1;
-    }
-    size_t ls[3] = {0, 0, 0};            // starts of the last three lines seen (ls[2] the newest); the window's first line is partial: skipped
-    int have = 0;
-    for (size_t i = 0; i + 1 < n; i++) {
-        if (w[i] != '\n') continue;
-        ls[0] = ls[1]; ls[1] = ls[2]; ls[2] = i + 1; have++;
-        if (have >= 3 && w[ls[0]] == '@' && w[ls[2]] == '+') return ls[0];
-    }
-    return (size_t)-1;
+    if (n < 2) return (size_t)-1;
+    const size_t r = sr_record_start(w, n, 1, false, fmt);
+    return r >= n ? (size_t)-1 : r;
 }
 // the last record start in the window (for the END of a sample chunk): searched from 3/4 of it on
 static size_t last_record_start(const char *w, size_t n, int fmt) {
