@@ -161,3 +161,36 @@ def test_streamed_count_many_pieces_reuses_the_ring(stream_ctx, tmp_path):
     t, _ = _both_ways(ctx, [fq], 31, 0)
     assert t.occurrences() > 0
     t.close()
+
+
+def test_cli_streams_its_libraries(gpu_ctx, tmp_path):
+    """metafast.sh with the streamed count on (limits lowered through MF_OPTIONS, two contexts on the GPU: each streams its library in its turn):
+    the workDir's result files are the files of a run with stream_count = 0, byte for byte"""
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from metafast_amd import lib as L
+    files = []
+    for s in range(2):
+        n, rl = 120_000, 100
+        bases, _ = L.synth_reads_host(0x4D45544146415354, s, 0, n, rl, 40000)          # (SURVEY 8(d)'s generator: shared and private pool pieces -> components)
+        p = str(tmp_path / ("lib%d.fa" % s)); _write_fasta(p, np.frombuffer(bases, dtype=np.uint8)[: n * rl].reshape(n, rl)); files.append(p)
+
+    def run(wd, opts):
+        env = dict(os.environ, MF_OPTIONS=opts)
+        cmd = [os.path.join(ROOT, "metafast.sh"), "-k", "21", "-b", "1", "-l", "60", "-b1", "40", "-b2", "2000", "-i", *files, "-w", str(wd), "--devices", "0,0", "-v"]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=tmp_path, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = {}
+        for sub in ("kmer-counter-many/kmers", "kmer-counter-many/stats", "seq-builder-many/sequences", "component-cutter", "features-calculator/vectors"):
+            for q in sorted((wd / sub).iterdir()):
+                if q.is_file() and q.name not in ("in.properties", "out.properties", "SUCCESS"):
+                    out[sub + "/" + q.name] = q.read_bytes()
+        out["matrix"] = sorted((wd / "matrices").glob("dist_matrix_*_original_order.txt"))[-1].read_bytes()
+        return out, r.stderr
+
+    whole, _ = run(tmp_path / "wd0", "stream_count=0")
+    streamed, err = run(tmp_path / "wd1", "stream_count_min_bytes=1,stream_count_piece_bytes=2097152,part_target=256,verbose=1")
+    assert err.count("streamed count (1 file(s)") == 2 and "stepped back" not in err, err[-3000:]
+    assert whole.keys() == streamed.keys()
+    for name in whole:
+        assert whole[name] == streamed[name], name
