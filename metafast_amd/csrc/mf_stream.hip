@@ -105,6 +105,7 @@ int mf_count_files_streamed(mf_ctx *ctx, const char *const *files, int nfiles, i
         ctx->up_stream = (void *)s2;
     }
     hipStream_t up = (hipStream_t)ctx->up_stream;
+    const double t01 = now();
     // (a fresh process: the pinned staging chunks take 30 ms to make -- beside the border search and the sample, not in front of them)
     int pool_rc = 0;
     std::thread pool_thread([&]() { (void)hipSetDevice(ctx->device); pool_rc = mf_upload_pool(ctx); });
@@ -155,6 +156,7 @@ int mf_count_files_streamed(mf_ctx *ctx, const char *const *files, int nfiles, i
         }
     }
     if (pieces.size() < 2) return 1;
+    const double t02 = now();
     // ---- the sample: chunks spread evenly over the files, trimmed to whole records, one after the other in a host buffer
     // (a 128th of the bytes, 64 MB at most: ~5000 sampled records per digit region at 1024 regions, and the regions get four standard deviations + an eighth)
     const size_t n_chunks = std::min<size_t>(std::min<size_t>(std::max<size_t>(total / 128 / ST_SAMPLE, 64), 512), piece_max / ST_SAMPLE);      // (it goes up into a piece's buffer)
@@ -358,7 +360,7 @@ int mf_count_files_streamed(mf_ctx *ctx, const char *const *files, int nfiles, i
     if (rc == MF_OK) ctx->n_streamed++; else if (rc == 1) ctx->n_stream_stepped_back++;
     static const bool env = getenv("MF_IO_TIMING") != nullptr;
     if (env || ctx->opt_verbose)
-        fprintf(stderr, "[mf] streamed count (%d file(s), %.2f GB, %zu pieces, sample %.1f MB): %s%s; borders + sample %.3f s (+ buffers %.3f s, pinned chunks %.3f s), upload || parse || scatter %.3f s, rest of the count %.3f s; %llu reads\n",
-                nfiles, total / 1e9, pieces.size(), s_bytes / 1e6, rc == MF_OK ? "done" : (rc == 1 ? "stepped back to whole files" : "failed"), why, t05 - t0, t07 - t05, t1 - t07, t2 - t1, now() - t2, (unsigned long long)n_reads);
+        fprintf(stderr, "[mf] streamed count (%d file(s), %.2f GB, %zu pieces, sample %.1f MB): %s%s; files + stream %.3f s, borders %.3f s, sample %.3f s (+ buffers %.3f s, pinned chunks %.3f s), upload || parse || scatter %.3f s, rest of the count %.3f s; %llu reads\n",
+                nfiles, total / 1e9, pieces.size(), s_bytes / 1e6, rc == MF_OK ? "done" : (rc == 1 ? "stepped back to whole files" : "failed"), why, t01 - t0, t02 - t01, t05 - t02, t07 - t05, t1 - t07, t2 - t1, now() - t2, (unsigned long long)n_reads);
     return rc;
 }

@@ -38,6 +38,15 @@ int mf_sort_u64_u32(mf_ctx *ctx, const uint64_t *d_keys_in, const uint32_t *d_va
 #define WC_T 1024                                  // threads of the count (one workgroup per CU: 16 waves)
 #define WC_SLOTS 4096
 #define WC_FILL 2800
+#ifndef WC_RO
+#define WC_RO 8                                    // consecutive k-mers of a thread in the passes over one class of an overflowing unit (k_wskm_count)
+#endif
+#ifndef WC_PROF
+#define WC_PROF 0                                  // (1: thread 0 of every workgroup adds up the cycles of the kernel's phases: counters[8 .. 13], printed with verbose)
+#endif
+#ifndef WC_ABL
+#define WC_ABL 0                                   // (timing experiments, results are wrong: 1 no table operations, 3 no fill counter, 4 no fence, 5 no look at the overflow flag)
+#endif
 #define WC_EMPTY 0xFFFFFFFFFFFFFFFFull
 #define WC_BUSY 0xFFFFFFFFFFFFFFFEull
 
@@ -218,6 +227,12 @@ __global__ __launch_bounds__(WC_T) void k_wskm_count(const wskm_rec *__restrict_
     __shared__ uint32_t stk_v[64], stk_b[64];
     __shared__ unsigned long long s_base;
     const uint32_t tid = threadIdx.x;
+#if WC_PROF
+    unsigned long long pc[6] = {0, 0, 0, 0, 0, 0}, pt = clock64();           // (thread 0: cycles per phase -- 0 top + clear, 1 load + scan, 2 rounds, 3 sweep + write; 4: all of them in passes after an overflow; 5: rounds)
+#define WC_TICK(i) do { if (tid == 0) { const unsigned long long n_ = clock64(); pc[i] += n_ - pt; if (!first) pc[4] += n_ - pt; pt = n_; } } while (0)
+#else
+#define WC_TICK(i) do { } while (0)
+#endif
     unsigned long long dist_acc = 0;                     // (this thread's share of the distinct k-mers: ONE atomic per wave at the end -- a wave's atomic per
                                                          // unit on one address was 1.3e8 serialised atomics of 12 ns each: 1.6 of the kernel's 1.7 s)
     for (uint32_t u = blockIdx.x; u < n_units; u += gridDim.x) {
@@ -238,59 +253,98 @@ __global__ __launch_bounds__(WC_T) void k_wskm_count(const wskm_rec *__restrict_
             if (tid == 0) { s_sp--; s_claims = 0; s_over = 0; }
             for (uint64_t c0 = a; c0 < b; c0 += WC_CH) {                          // (uniform)
                 __syncthreads();
+                WC_TICK(c0 == a ? 0 : 2);
                 if (s_over) break;                       // (uniform: read behind the barrier)
                 const uint32_t nr = (uint32_t)(b - c0 < (uint64_t)WC_CH ? b - c0 : (uint64_t)WC_CH);
-                uint32_t len = 0;
-                if (tid < nr) {
-                    const wskm_rec *rp = &recs[order[c0 + tid]];
-                    const uint4 A = *reinterpret_cast<const uint4 *>(&rp->w[0]), B = *reinterpret_cast<const uint4 *>(&rp->w[4]);
-                    *reinterpret_cast<uint4 *>(&srec[tid * 8]) = A;
-                    *reinterpret_cast<uint4 *>(&srec[tid * 8 + 4]) = B;
-                    len = B.w;
-                }
                 uint32_t T;
-                const uint32_t ex = mf_block_excl_scan(len, scratch, &T);
-                soff[tid] = ex;
-                if (tid == 0) soff[WC_CH] = T;
-                __syncthreads();
-                for (uint32_t i = tid; i < T; i += WC_T) {
+                if (first || b - a > (uint64_t)WC_CH) {
+                    uint32_t len = 0;
+                    if (tid < nr) {
+                        const wskm_rec *rp = &recs[order[c0 + tid]];
+                        const uint4 A = *reinterpret_cast<const uint4 *>(&rp->w[0]), B = *reinterpret_cast<const uint4 *>(&rp->w[4]);
+                        *reinterpret_cast<uint4 *>(&srec[tid * 8]) = A;
+                        *reinterpret_cast<uint4 *>(&srec[tid * 8 + 4]) = B;
+                        len = B.w;
+                    }
+                    const uint32_t ex = mf_block_excl_scan(len, scratch, &T);
+                    soff[tid] = ex;
+                    if (tid == 0) soff[WC_CH] = T;
+                    __syncthreads();
+                } else T = soff[WC_CH];                  // (a unit of one chunk: its records and their scan are still parked from the first pass)
+                WC_TICK(1);
+#if WC_PROF
+                if (tid == 0) pc[5] += (T + WC_T - 1) / WC_T;
+#endif
+                // A thread takes R CONSECUTIVE k-mers: it finds the record of the first (a binary search in the scan), cuts the k-mer out of the record's
+                // words (two funnelled 128-bit shifts) and reverses it for the other strand; the following ones of the same record roll in a base at a
+                // time (forward: shift left; the other strand: shift right).  R = 1 in a unit's first pass -- every k-mer goes into the table, and the
+                // inserts of a thread run one after the other: R = 2, 4, 8 there measured 679, 770, 984 ms against 647 --, R = WC_RO in the passes over
+                // ONE CLASS of an overflowing unit (half of the kernel's time: 2.5 % of the units, counted 5, 21, 85 ... times over), where most k-mers
+                // are only made, looked at and dropped.
+                const mf_u128 kmask = (~(mf_u128)0) >> (128 - 2 * k);
+                const uint32_t R = cb == 0 ? 1u : (uint32_t)WC_RO;
+                for (uint32_t g0 = tid * R; g0 < T; g0 += WC_T * R) {
                     if (*(volatile uint32_t *)&s_over) break;                   // (the table is filling up: nobody adds to it any more)
-                    uint32_t lo_r = 0, hi_r = nr;                                // the last record with soff <= i
-                    while (hi_r - lo_r > 1) { const uint32_t mid = (lo_r + hi_r) >> 1; if (soff[mid] <= i) lo_r = mid; else hi_r = mid; }
-                    const uint32_t j = i - soff[lo_r];
-                    const uint32_t *w = &srec[lo_r * 8];
-                    const uint32_t q = j >> 4, o = (j & 15u) * 2u;               // the k-mer starts at bit 32 q + o of the record's 224
-                    const mf_u128 X0 = ((mf_u128)(((uint64_t)w[q] << 32) | w[q + 1]) << 64) | (mf_u128)(((uint64_t)w[q + 2] << 32) | w[q + 3]);
-                    const mf_u128 X = o ? ((X0 << o) | (mf_u128)(w[q + 4] >> (32u - o))) : X0;      // (q <= 2: w[q + 4] is a base word, w[7] is never reached)
-                    const mf_u128 fw = X >> (128 - 2 * k);
-                    const mf_u128 rc = mf_wrevcomp(fw, k);
-                    const mf_u128 cn = fw < rc ? fw : rc;
-                    const unsigned long long hi = (unsigned long long)(cn >> 64), lo = (unsigned long long)cn;
-                    const uint2 hh = wc_hash(hi, lo);
-                    if ((hh.y & cmask) != cv) continue;
-                    uint32_t s = hh.x & (WC_SLOTS - 1);
-                    for (uint32_t probes = 0;; probes++) {
-                        if (probes >= (uint32_t)WC_SLOTS) { s_over = 1u; break; }
-                        const unsigned long long old = atomicCAS(&thi[s], WC_EMPTY, WC_BUSY);
-                        if (old == WC_EMPTY) {                                   // the slot is this k-mer's: low word first, the high word publishes it
-                            tlo[s] = lo;
-                            __threadfence_block();
-                            atomicExch(&thi[s], hi);
-                            atomicAdd(&tcnt[s], 1u);
-                            if (atomicAdd(&s_claims, 1u) + 1u > (uint32_t)WC_FILL) s_over = 1u;
-                            break;
+                    const uint32_t iend = g0 + R < T ? g0 + R : T;
+                    uint32_t lo_r = 0, hi_r = nr;                                // the last record with soff <= g0
+                    while (hi_r - lo_r > 1) { const uint32_t mid = (lo_r + hi_r) >> 1; if (soff[mid] <= g0) lo_r = mid; else hi_r = mid; }
+                    uint32_t j = g0 - soff[lo_r], rend = soff[lo_r + 1];
+                    uint32_t wb = lo_r * 8u;                                     // (the record's words: srec[wb ..])
+                    mf_u128 fw = 0, rc = 0;
+                    bool have = false;
+                    for (uint32_t i = g0; i < iend; i++, j++) {
+                        if (i >= rend) {                                         // the next record (every record holds at least one k-mer)
+                            do { lo_r++; rend = soff[lo_r + 1]; } while (rend <= i);
+                            j = 0; wb = lo_r * 8u; have = false;
                         }
-                        if (old == WC_BUSY) continue;                            // (being written: look again)
-                        if (old == hi && *(volatile unsigned long long *)&tlo[s] == lo) { atomicAdd(&tcnt[s], 1u); break; }
-                        s = (s + 1u) & (WC_SLOTS - 1);
+                        if (!have) {
+                            const uint32_t q = wb + (j >> 4), o = (j & 15u) * 2u;   // the k-mer starts at bit 32 (j / 16) + o of the record's 224
+                            const mf_u128 X0 = ((mf_u128)(((uint64_t)srec[q] << 32) | srec[q + 1]) << 64) | (mf_u128)(((uint64_t)srec[q + 2] << 32) | srec[q + 3]);
+                            const mf_u128 X = o ? ((X0 << o) | (mf_u128)(srec[q + 4] >> (32u - o))) : X0;      // (j / 16 <= 2: that word is a base word, word 7 is never reached)
+                            fw = X >> (128 - 2 * k);
+                            rc = mf_wrevcomp(fw, k);
+                            have = true;
+                        } else {
+                            const uint32_t bi = j + (uint32_t)k - 1u;            // the base that comes in
+                            const uint32_t nb = (srec[wb + (bi >> 4)] >> (30u - 2u * (bi & 15u))) & 3u;
+                            fw = ((fw << 2) | (mf_u128)nb) & kmask;
+                            rc = (rc >> 2) | ((mf_u128)(3u - nb) << (2 * k - 2));
+                        }
+                        const mf_u128 cn = fw < rc ? fw : rc;
+                        const unsigned long long hi = (unsigned long long)(cn >> 64), lo = (unsigned long long)cn;
+                        const uint2 hh = wc_hash(hi, lo);
+                        if ((hh.y & cmask) != cv) continue;
+#if WC_ABL == 1
+                        if (hh.x == 0x12345u && lo == 77ull) atomicAdd(&tcnt[hh.x & (WC_SLOTS - 1)], 1u);
+                        continue;
+#endif
+                        uint32_t s = hh.x & (WC_SLOTS - 1);
+                        for (uint32_t probes = 0;; probes++) {
+                            if (probes >= (uint32_t)WC_SLOTS) { s_over = 1u; break; }
+                            const unsigned long long old = atomicCAS(&thi[s], WC_EMPTY, WC_BUSY);
+                            if (old == WC_EMPTY) {                               // the slot is this k-mer's: low word first, the high word publishes it
+                                tlo[s] = lo;
+                                __threadfence_block();
+                                atomicExch(&thi[s], hi);
+                                atomicAdd(&tcnt[s], 1u);
+                                if (atomicAdd(&s_claims, 1u) + 1u > (uint32_t)WC_FILL) s_over = 1u;
+                                break;
+                            }
+                            if (old == WC_BUSY) continue;                        // (being written: look again)
+                            if (old == hi && *(volatile unsigned long long *)&tlo[s] == lo) { atomicAdd(&tcnt[s], 1u); break; }
+                            s = (s + 1u) & (WC_SLOTS - 1);
+                        }
                     }
                 }
             }
             __syncthreads();
+            WC_TICK(2);
             if (s_over) {                                // too many distinct k-mers for the table: the class in four
                 if (cb + 2 > 24) { if (tid == 0) atomicAdd(&counters[3], 1ull); break; }      // (2800 x 2^24 distinct k-mers in one minimizer partition: not with 2k >= 64 bits of key)
                 if (tid == 0) {
                     if (first) atomicAdd(&counters[2], 1ull);
+                    // (as many classes at once as the part of the unit seen so far asks for -- distinct k-mers found / the share of the records seen, 16 to
+                    // 256 classes -- was measured: 665 ms against 621; the estimate is too high where the k-mers repeat, and every class too many is a pass)
                     for (uint32_t c = 0; c < 4; c++) { stk_v[s_sp] = cv | (c << cb); stk_b[s_sp] = cb + 2; s_sp++; }
                 }
                 first = false;
@@ -311,8 +365,12 @@ __global__ __launch_bounds__(WC_T) void k_wskm_count(const wskm_rec *__restrict_
                     if (at < cap) { out_hi[at] = thi[s]; out_lo[at] = tlo[s]; out_cnt[at] = (uint16_t)(tcnt[s] > (uint32_t)MF_MAX_COUNT ? (uint32_t)MF_MAX_COUNT : tcnt[s]); }
                     at++;
                 }
+            WC_TICK(3);
         }
     }
+#if WC_PROF
+    if (tid == 0) for (int i = 0; i < 6; i++) atomicAdd(&counters[8 + i], pc[i]);
+#endif
     for (int d = 32; d >= 1; d >>= 1) dist_acc += __shfl_down(dist_acc, d, 64);
     if ((tid & 63u) == 0 && dist_acc) atomicAdd(&counters[1], dist_acc);
 }
@@ -330,8 +388,8 @@ __global__ void k_wskm_gather16(const uint16_t *__restrict__ src, const uint32_t
 int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len, int threshold,
                       const uint32_t *vmask, uint64_t n_words, mf_wtable *t) {
     hipStream_t st = ctx->stream;
-    mf_buf<unsigned long long> ctr; MF_TRY(ctr.alloc(ctx, 8));
-    MF_HIP(hipMemsetAsync(ctr.p, 0, 64, st));
+    mf_buf<unsigned long long> ctr; MF_TRY(ctr.alloc(ctx, 16));
+    MF_HIP(hipMemsetAsync(ctr.p, 0, 128, st));
     k_wskm_nocc<<<wsgrid(n_reads), 256, 0, st>>>(d_offsets, n_reads, k, min_read_len, &ctr.p[4]);
     unsigned long long n_occ = 0;
     MF_HIP(hipMemcpyAsync(&n_occ, &ctr.p[4], 8, hipMemcpyDeviceToHost, st));
@@ -402,6 +460,15 @@ int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_off
         ohi.reset(); olo.reset(); ocnt.reset();
         ocap = res[0] + 64;
     }
+#if WC_PROF
+    {
+        unsigned long long pc[6];
+        MF_HIP(hipMemcpy(pc, ctr.p + 8, 48, hipMemcpyDeviceToHost));
+        const double tot = (double)(pc[0] + pc[1] + pc[2] + pc[3]);
+        fprintf(stderr, "[mf] k_wskm_count workgroup cycles: top + clear %.1f %%, load + scan %.1f %%, rounds %.1f %%, sweep + write %.1f %%; in passes behind an overflow %.1f %%; %llu rounds of %d k-mers for %llu k-mers\n",
+                100.0 * pc[0] / tot, 100.0 * pc[1] / tot, 100.0 * pc[2] / tot, 100.0 * pc[3] / tot, 100.0 * pc[4] / tot, pc[5], WC_T, n_occ);
+    }
+#endif
     recs.reset(); order.reset(); uoff.reset();
     const uint64_t nk = res[0];
     if (ctx->opt_verbose) fprintf(stderr, "[mf] count_wide (records): %llu k-mers in %llu records (%.1f per record), %u units, %llu counted in several passes; %llu distinct, %llu kept\n", n_occ, n_rec,

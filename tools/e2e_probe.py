@@ -5,6 +5,8 @@ from metafast_amd import lib as L, pipeline as P
 import bench
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 16_000_000
 ctx = L.Context(0, stream=torch.cuda.current_stream())
+for kv in filter(None, os.environ.get("MF_OPTIONS", "").split(",")):
+    name, val = kv.split("="); ctx.set_option(name, int(val))
 bases = torch.zeros(n * 150 + 64, dtype=torch.uint8, device="cuda"); offs = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
 ctx.synth_reads_device(bench.SEED, 0, 0, n, 150, 1_000_000, bases.data_ptr(), offs.data_ptr(), 82)
 torch.cuda.synchronize()
