@@ -98,6 +98,7 @@ __global__ __launch_bounds__(WS_T) void k_wskm_scan(const uint8_t *__restrict__ 
     __shared__ uint32_t vw[WS_TILE / 32 + 1], sw[WS_TILE / 32 + 1];      // bitmaps: a k-mer starts here; a run starts here
     __shared__ uint32_t scratch[18];
     __shared__ unsigned long long s_base;
+    __shared__ uint8_t rl[WS_TILE];
     const uint32_t tid = threadIdx.x;
     const bool aligned = (reinterpret_cast<uintptr_t>(bases) & 15u) == 0;
     const int W = k - WS_M + 1;                          // M-mers of a k-mer (18 .. 49)
@@ -163,13 +164,17 @@ __global__ __launch_bounds__(WS_T) void k_wskm_scan(const uint8_t *__restrict__ 
             return e - p < (uint32_t)WS_RMAX ? e - p : (uint32_t)WS_RMAX;
         };
         uint32_t mine = 0;
-        for (uint32_t p = tid; p < WS_TILE; p += WS_T) mine += rec_len(p) ? 1u : 0u;
+        for (uint32_t p = tid; p < WS_TILE; p += WS_T) {  // (rec_len is 40 instructions and ran twice: its answers wait in LDS for the second round)
+            const uint32_t l = rec_len(p);
+            rl[p] = (uint8_t)l;
+            mine += l ? 1u : 0u;
+        }
         uint32_t tot;
         uint32_t at = mf_block_excl_scan(mine, scratch, &tot);
         if (tid == 0) s_base = tot ? atomicAdd(cursor, (unsigned long long)tot) : 0ull;
         __syncthreads();
         for (uint32_t p = tid; p < WS_TILE; p += WS_T) {
-            const uint32_t len = rec_len(p);
+            const uint32_t len = rl[p];                  // (written by this thread)
             if (!len) continue;
             const unsigned long long g = s_base + at;
             at++;
@@ -384,6 +389,51 @@ __global__ void k_wskm_gather16(const uint16_t *__restrict__ src, const uint32_t
     if (i < n) dst[i] = src[idx[i]];
 }
 
+// ---- the kept entries in ascending order.  The k-mers are distinct and spread evenly, so the LEADING 32 BITS nearly order them: 7.5e8 kept entries
+// of the 200 M-read sample fall into 2^32 values, 0.17 per value.  (leading bits, entry number) pairs are sorted -- 4 passes over 8 bytes instead
+// of the 16 passes over 12 bytes a full sort of 126 bits takes --, the entries are gathered in that order, and an entry finds its place inside its
+// RUN of equal leading bits by counting the run's smaller entries.  A run of more than WO_RUN entries (k-mers that share their first 16 bases by
+// the thousand: poly-A tails, satellites) goes ASIDE with its place: all bits of those entries are sorted, and the i-th smallest of them takes the i-th smallest
+// of their places -- the runs are ranges of places, and a run with smaller leading bits holds smaller k-mers.  More than an eighth of the entries aside: all
+// bits of everything are sorted (option wide_skm_lead = 0: always; 2: tests -- no room aside).
+#define WO_RUN 64
+__global__ void k_wskm_lead(const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, uint64_t n, int k, uint32_t *__restrict__ lead, uint32_t *__restrict__ idx) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const mf_u128 x = ((mf_u128)hi[i] << 64) | (mf_u128)lo[i];
+    lead[i] = (uint32_t)(x >> (2 * k - 32));
+    idx[i] = (uint32_t)i;
+}
+// hi / lo / cnt: the entries in the order of their leading bits already (gathered: the run's other entries are then neighbours in memory, not random lines)
+__global__ void k_wskm_place(const uint32_t *__restrict__ lead, const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo,
+                             const uint16_t *__restrict__ cnt, uint64_t n, uint64_t *__restrict__ ohi, uint64_t *__restrict__ olo, uint16_t *__restrict__ ocnt,
+                             unsigned int *__restrict__ side_n, uint32_t *__restrict__ side_pos, uint64_t *__restrict__ shi, uint64_t *__restrict__ slo,
+                             uint16_t *__restrict__ scnt, uint64_t scap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t t = lead[i];
+    uint64_t a = i, b = i + 1;
+    while (a > 0 && i - a < (uint64_t)WO_RUN && lead[a - 1] == t) a--;
+    while (b < n && b - i <= (uint64_t)WO_RUN && lead[b] == t) b++;
+    const uint64_t h = hi[i], l = lo[i];
+    if (b - a > (uint64_t)WO_RUN) {                                        // a long run (every entry of it sees that: a search that stops at its bound has seen WO_RUN others): aside, with its place
+        const unsigned int at = atomicAdd(side_n, 1u);
+        if ((uint64_t)at < scap) { side_pos[at] = (uint32_t)i; shi[at] = h; slo[at] = l; scnt[at] = cnt[i]; }
+        return;
+    }
+    uint64_t rank = 0;
+    for (uint64_t j = a; j < b; j++) {
+        const uint64_t h2 = hi[j], l2 = lo[j];
+        rank += (h2 < h || (h2 == h && l2 < l)) ? 1u : 0u;
+    }
+    ohi[a + rank] = h; olo[a + rank] = l; ocnt[a + rank] = cnt[i];
+}
+__global__ void k_wskm_scatter_side(const uint32_t *__restrict__ pos, const uint64_t *__restrict__ hi, const uint64_t *__restrict__ lo, const uint16_t *__restrict__ cnt, uint64_t n,
+                                    uint64_t *__restrict__ ohi, uint64_t *__restrict__ olo, uint16_t *__restrict__ ocnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint32_t p = pos[i]; ohi[p] = hi[i]; olo[p] = lo[i]; ocnt[p] = cnt[i]; }
+}
+
 // 0: *t filled (one ascending piece, the cut made); 1: not an input for this path (nothing changed); < 0: error
 int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len, int threshold,
                       const uint32_t *vmask, uint64_t n_words, mf_wtable *t) {
@@ -479,21 +529,63 @@ int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_off
     MF_TRY(pc->hi.alloc(ctx, nk)); MF_TRY(pc->lo.alloc(ctx, nk)); MF_TRY(pc->cnt.alloc(ctx, nk));
     if (nk) {
         mf_ktimer tm(ctx, "k_wskm_order");
-        mf_buf<uint32_t> i0, i1, i2; mf_buf<uint64_t> k1, k2, h1;
-        MF_TRY(i0.alloc(ctx, nk)); MF_TRY(i1.alloc(ctx, nk)); MF_TRY(k1.alloc(ctx, nk));
-        k_wskm_iota<<<wsgrid(nk), 256, 0, st>>>(i0.p, nk);
-        MF_TRY(mf_sort_u64_u32(ctx, olo.p, i0.p, nk, 64, k1.p, i1.p));
-        i0.reset();
-        const int hb = 2 * k - 64;
-        if (hb > 0) {
-            MF_TRY(h1.alloc(ctx, nk)); MF_TRY(k2.alloc(ctx, nk)); MF_TRY(i2.alloc(ctx, nk));
-            k_wskm_gather64<<<wsgrid(nk), 256, 0, st>>>(ohi.p, i1.p, nk, h1.p);
-            MF_TRY(mf_sort_u64_u32(ctx, h1.p, i1.p, nk, hb, k2.p, i2.p));
-        } else i2.swap(i1);
-        k_wskm_gather64<<<wsgrid(nk), 256, 0, st>>>(ohi.p, i2.p, nk, pc->hi.p);
-        k_wskm_gather64<<<wsgrid(nk), 256, 0, st>>>(olo.p, i2.p, nk, pc->lo.p);
-        k_wskm_gather16<<<wsgrid(nk), 256, 0, st>>>(ocnt.p, i2.p, nk, pc->cnt.p);
-        MF_HIP(hipStreamSynchronize(st));
+        // all bits of n entries sorted: by the low word carrying the entry number, then -- stable -- by the high word's 2k - 64 bits
+        auto full_order = [&](const uint64_t *shi, const uint64_t *slo, const uint16_t *scnt, uint64_t n, uint64_t *dhi, uint64_t *dlo, uint16_t *dcnt) -> int {
+            mf_buf<uint32_t> i0, i1, i2; mf_buf<uint64_t> k1, k2, h1;
+            MF_TRY(i0.alloc(ctx, n)); MF_TRY(i1.alloc(ctx, n)); MF_TRY(k1.alloc(ctx, n));
+            k_wskm_iota<<<wsgrid(n), 256, 0, st>>>(i0.p, n);
+            MF_TRY(mf_sort_u64_u32(ctx, slo, i0.p, n, 64, k1.p, i1.p));
+            i0.reset();
+            const int hb = 2 * k - 64;
+            if (hb > 0) {
+                MF_TRY(h1.alloc(ctx, n)); MF_TRY(k2.alloc(ctx, n)); MF_TRY(i2.alloc(ctx, n));
+                k_wskm_gather64<<<wsgrid(n), 256, 0, st>>>(shi, i1.p, n, h1.p);
+                MF_TRY(mf_sort_u64_u32(ctx, h1.p, i1.p, n, hb, k2.p, i2.p));
+            } else i2.swap(i1);
+            k_wskm_gather64<<<wsgrid(n), 256, 0, st>>>(shi, i2.p, n, dhi);
+            k_wskm_gather64<<<wsgrid(n), 256, 0, st>>>(slo, i2.p, n, dlo);
+            k_wskm_gather16<<<wsgrid(n), 256, 0, st>>>(scnt, i2.p, n, dcnt);
+            MF_HIP(hipStreamSynchronize(st));
+            return MF_OK;
+        };
+        bool placed = false;
+        if (ctx->opt_wide_skm_lead) {
+            mf_buf<uint32_t> l0, j0, l1, j1; mf_buf<unsigned int> side_n;
+            MF_TRY(l0.alloc(ctx, nk)); MF_TRY(j0.alloc(ctx, nk)); MF_TRY(l1.alloc(ctx, nk)); MF_TRY(j1.alloc(ctx, nk)); MF_TRY(side_n.alloc(ctx, 1));
+            MF_HIP(hipMemsetAsync(side_n.p, 0, 4, st));
+            k_wskm_lead<<<wsgrid(nk), 256, 0, st>>>(ohi.p, olo.p, nk, k, l0.p, j0.p);
+            MF_TRY(mf_sort_u32_pairs(ctx, l0.p, j0.p, nk, 32, l1.p, j1.p));
+            j0.reset();
+            // (the entries of long runs: their places in l0 -- free again --, themselves aside; room for an eighth of all, or all bits of everything are sorted)
+            const uint64_t scap = ctx->opt_wide_skm_lead == 2 ? 0 : nk / 8 + 1024;
+            mf_buf<uint64_t> shi, slo; mf_buf<uint16_t> scnt;
+            MF_TRY(shi.alloc(ctx, scap + 1)); MF_TRY(slo.alloc(ctx, scap + 1)); MF_TRY(scnt.alloc(ctx, scap + 1));
+            mf_buf<uint64_t> ghi, glo; mf_buf<uint16_t> gcnt;
+            MF_TRY(ghi.alloc(ctx, nk)); MF_TRY(glo.alloc(ctx, nk)); MF_TRY(gcnt.alloc(ctx, nk));
+            k_wskm_gather64<<<wsgrid(nk), 256, 0, st>>>(ohi.p, j1.p, nk, ghi.p);
+            k_wskm_gather64<<<wsgrid(nk), 256, 0, st>>>(olo.p, j1.p, nk, glo.p);
+            k_wskm_gather16<<<wsgrid(nk), 256, 0, st>>>(ocnt.p, j1.p, nk, gcnt.p);
+            k_wskm_place<<<wsgrid(nk), 256, 0, st>>>(l1.p, ghi.p, glo.p, gcnt.p, nk, pc->hi.p, pc->lo.p, pc->cnt.p, side_n.p, l0.p, shi.p, slo.p, scnt.p, scap);
+            unsigned int ns = 0;
+            MF_HIP(hipMemcpyAsync(&ns, side_n.p, 4, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            l1.reset(); j1.reset();
+            if ((uint64_t)ns <= scap) {
+                placed = true;
+                if (ns) {
+                    // ascending places x ascending k-mers: the runs are ranges of places, and the k-mers of a run with smaller leading bits are smaller
+                    mf_buf<uint32_t> pos, zero, dummy; mf_buf<uint64_t> thi, tlo; mf_buf<uint16_t> tcnt;
+                    MF_TRY(pos.alloc(ctx, ns)); MF_TRY(zero.alloc(ctx, ns)); MF_TRY(dummy.alloc(ctx, ns)); MF_TRY(thi.alloc(ctx, ns)); MF_TRY(tlo.alloc(ctx, ns)); MF_TRY(tcnt.alloc(ctx, ns));
+                    MF_HIP(hipMemsetAsync(zero.p, 0, (size_t)ns * 4, st));
+                    MF_TRY(mf_sort_u32_pairs(ctx, l0.p, zero.p, ns, 32, pos.p, dummy.p));
+                    MF_TRY(full_order(shi.p, slo.p, scnt.p, ns, thi.p, tlo.p, tcnt.p));
+                    k_wskm_scatter_side<<<wsgrid(ns), 256, 0, st>>>(pos.p, thi.p, tlo.p, tcnt.p, ns, pc->hi.p, pc->lo.p, pc->cnt.p);
+                    MF_HIP(hipStreamSynchronize(st));
+                }
+                if (ctx->opt_verbose) fprintf(stderr, "[mf] count_wide (records): %u of %llu kept k-mers stand in runs of more than %d with the same leading 16 bases (all their bits are sorted)\n", ns, (unsigned long long)nk, WO_RUN);
+            }
+        }
+        if (!placed) MF_TRY(full_order(ohi.p, olo.p, ocnt.p, nk, pc->hi.p, pc->lo.p, pc->cnt.p));
     }
     pc->n = nk;
     t->pieces.clear();

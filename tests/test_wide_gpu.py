@@ -279,6 +279,22 @@ def test_wide_record_path_equals_sort_path(gpu_ctx, oracle, k):
             ghi, glo, gc = t.export()
             keep = cnt > thr
             assert n_all == len(cnt) and np.array_equal(ghi, hi[keep]) and np.array_equal(glo, lo[keep]) and np.array_equal(gc.astype(np.int32), cnt[keep])
+        # the kept entries' order: by their leading 32 bits + a look at the runs of equal ones (the default), by all bits (wide_skm_lead = 0), and
+        # -- 300 k-mers that share their first 20 bases: a run too long for the look -- by all bits after all
+        gpu_ctx.set_option("wide_skm_lead", 0)
+        got = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), n, len(bases), k, 0)
+        assert np.array_equal(got["hi"], hi) and np.array_equal(got["lo"], lo) and np.array_equal(got["counts"].astype(np.int32), cnt)
+        gpu_ctx.set_option("wide_skm_lead", 1)
+        pre = np.frombuffer(b"AAAAAAAAAACCCCCCCCCC", dtype=np.uint8)
+        tails = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (300, k - 20))]
+        b2 = np.concatenate([np.concatenate([pre, t]) for t in tails] + [bases]); o2 = np.concatenate([np.arange(300, dtype=np.uint64) * np.uint64(k), off + np.uint64(300 * k)])
+        db2, do2 = to_device(b2, o2)
+        h2, l2, c2, n2 = oracle.count_wide(b2, o2, k, 0)
+        for lead in (1, 2):                         # (1: the run goes aside; 2: no room aside -- all bits of everything)
+            gpu_ctx.set_option("wide_skm_lead", lead)
+            got = gpu_ctx.count_wide_device(db2.data_ptr(), do2.data_ptr(), len(o2) - 1, len(b2), k, 0)
+            assert got["n_occ"] == n2 and np.array_equal(got["hi"], h2) and np.array_equal(got["lo"], l2) and np.array_equal(got["counts"].astype(np.int32), c2), lead
+        gpu_ctx.set_option("wide_skm_lead", 1)
         gpu_ctx.set_option("wide_skm", 0)
         old = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), n, len(bases), k, 0)
         assert np.array_equal(old["hi"], hi) and np.array_equal(old["counts"].astype(np.int32), cnt)
@@ -288,5 +304,5 @@ def test_wide_record_path_equals_sort_path(gpu_ctx, oracle, k):
         h2, l2, c2, o2 = oracle.count_wide(bases, off, k, 150)
         assert got["n_occ"] == o2 and np.array_equal(got["hi"], h2) and np.array_equal(got["lo"], l2) and np.array_equal(got["counts"].astype(np.int32), c2)
     finally:
-        gpu_ctx.set_option("wide_skm", 1); gpu_ctx.set_option("wide_skm_min", 1 << 20); gpu_ctx.set_option("wide_skm_unit", 4000)
+        gpu_ctx.set_option("wide_skm", 1); gpu_ctx.set_option("wide_skm_min", 1 << 20); gpu_ctx.set_option("wide_skm_unit", 4000); gpu_ctx.set_option("wide_skm_lead", 1)
 
