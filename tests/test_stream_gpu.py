@@ -194,3 +194,33 @@ def test_cli_streams_its_libraries(gpu_ctx, tmp_path):
     assert whole.keys() == streamed.keys()
     for name in whole:
         assert whole[name] == streamed[name], name
+
+
+def test_streamed_count_with_the_defaults_16M_reads(gpu_ctx, tmp_path):
+    """no option lowered: 16 M reads of the benchmark sample as a 2.46 GB FASTA file in 256 MB pieces (the bench's end_to_end line) -- the table of the
+    reads counted where they lie in HBM, entry for entry; 0 slice restarts, nothing stepped back"""
+    import sys, torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    ctx = gpu_ctx
+    n, rl, k = 16_000_000, 150, 31
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40e9:
+        pytest.skip("needs 40 GB of free HBM")
+    bases = torch.zeros(n * rl + 64, dtype=torch.uint8, device="cuda"); offs = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
+    ctx.synth_reads_device(bench.SEED, 0, 0, n, rl, 1_000_000, bases.data_ptr(), offs.data_ptr(), 82)
+    torch.cuda.synchronize()
+    fa = str(tmp_path / "s.fa")
+    bench._write_fasta(bases, n, rl, fa)
+    t0, all0 = ctx.count_device_above(bases.data_ptr(), offs.data_ptr(), n, n * rl, k, 1) if hasattr(ctx, "count_device_above") else (None, None)
+    before = ctx.stat("streamed_counts"), ctx.stat("streamed_counts_stepped_back"), ctx.stat("slice_restarts")
+    t1, all1 = ctx.count_reads_above([fa], k, 1)
+    assert (ctx.stat("streamed_counts"), ctx.stat("streamed_counts_stepped_back"), ctx.stat("slice_restarts")) == (before[0] + 1, before[1], before[2])
+    if t0 is None:
+        t = ctx.count_device(bases.data_ptr(), offs.data_ptr(), n, n * rl, k, 0)
+        t0 = t.filter(1); all0 = len(t); t.close()
+    assert all0 == all1 and len(t0) == len(t1) and t0.occurrences() == t1.occurrences() == n * (rl - k + 1)
+    k0, c0 = _sorted_table(t0); k1, c1 = _sorted_table(t1)
+    assert np.array_equal(k0, k1) and np.array_equal(c0, c1)
+    t0.close(); t1.close()
+    os.remove(fa)
