@@ -285,6 +285,22 @@ def _write_fasta(bases_dev, m, rl, path):
     return os.path.getsize(path)
 
 
+def _write_fastq(bases_dev, m, rl, path):
+    """the same reads as a FASTQ file ("@r", bases, "+", a line of 'I': phred 40 at offset 33)"""
+    with open(path, "wb") as f:
+        for lo in range(0, m, 2_000_000):
+            hi = min(m, lo + 2_000_000)
+            hb = bases_dev[lo * rl: hi * rl].cpu().numpy()
+            rec = np.empty((hi - lo, 2 * rl + 7), dtype=np.uint8)    # "@r\n" + bases + "\n+\n" + qualities + "\n"
+            rec[:, 0], rec[:, 1], rec[:, 2] = ord("@"), ord("r"), 10
+            rec[:, 3:rl + 3] = hb.reshape(hi - lo, rl)
+            rec[:, rl + 3], rec[:, rl + 4], rec[:, rl + 5] = 10, ord("+"), 10
+            rec[:, rl + 6:2 * rl + 6] = ord("I")
+            rec[:, 2 * rl + 6] = 10
+            rec.tofile(f)
+    return os.path.getsize(path)
+
+
 def _log_steps(log_path):
     """seconds per tool run from the time stamps of the driver's log ("dd-MMM-yy  HH:mm:ss,SSS  DEBUG  Running tool X")"""
     import datetime, re
@@ -368,6 +384,8 @@ def end_to_end_and_cli(ctx, n_reads, rl, k, args, device, sample0):
         # ---- end to end, one process (bases: still the first reads of the benchmark sample)
         fa = os.path.join(td, "e2e.fa")
         size = _write_fasta(bases, m, rl, fa)
+        fq = os.path.join(td, "e2e.fq")
+        size_q = _write_fastq(bases, m, rl, fq)
         del bases, offs
 
         def e2e_line(path, nreads, fsize, what):
@@ -385,6 +403,9 @@ def end_to_end_and_cli(ctx, n_reads, rl, k, args, device, sample0):
             return dict(value=round(occ / best, 1), unit="k-mers/s", reads=nreads, fasta_GB=round(fsize / 1e9, 3), seconds=round(best, 4), fasta_GBps=round(fsize / 1e9 / best, 2), what=what)
         out["end_to_end"] = e2e_line(fa, m, size, "FASTA file (page cache) -> read + parse + H2D + count + unitigs + cutter + components + features + matrix, one process, tables stay in HBM")
         os.remove(fa)
+        # (the same reads as FASTQ -- what a sequencer writes: twice the bytes per base across PCIe; qualities "I", nothing dropped)
+        out["end_to_end_fastq"] = e2e_line(fq, m, size_q, "as end_to_end, the same reads as a FASTQ file")
+        os.remove(fq)
         if big:
             # ... and where the metric is quoted: config 2's whole sample as ONE FASTA file (15.4 GB at 100 M reads), same call
             bases = torch.zeros(big * rl + 64, dtype=torch.uint8, device=device)
@@ -622,6 +643,7 @@ def main():
                 roof("k_skm_count" if "k_skm_count" in kern else "k_count")),
             "cpu_baseline": cpu,
             "end_to_end": e2e.get("end_to_end"),
+            "end_to_end_fastq": e2e.get("end_to_end_fastq"),
             "end_to_end_config2": e2e.get("end_to_end_config2"),
             "cli": e2e.get("cli"),
             "stats": stats,
