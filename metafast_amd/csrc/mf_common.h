@@ -105,6 +105,7 @@ struct mf_ctx {
     void *up_stream = nullptr;     // hipStream_t of the streamed count's uploads (lazy)
     int64_t opt_wide_skm = 1;      // mf_count_wide_device: super-k-mer records + LDS tables (mf_wskm.hip) instead of sorting every occurrence (0: the sort path, mf_wide.hip)
     int64_t opt_wide_skm_min = 1 << 20;     // ... from this many k-mer occurrences on (tests: 1)
+    int64_t opt_wide_skm_lazy_order = 1;    // ... the table stays in the order of the counting units until an export / the cutter asks for ascending k-mers (0: ordered at once)
     int64_t opt_wide_skm_lead = 1;          // ... the kept entries are ordered by their leading 32 bits + a look at the runs of equal ones (0: all bits are sorted; tests)
     int64_t opt_wide_skm_unit = 4000;       // ... k-mer occurrences per counting unit (tests lower it: units that overflow the LDS table are counted in passes)
     int64_t opt_wide_finish = 1;   // mf_count_wide_device: radix passes over the leading 32 bits + the order inside the buckets in LDS (0: radix passes over all 2k bits)

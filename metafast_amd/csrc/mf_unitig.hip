@@ -362,12 +362,22 @@ __global__ void k_ut_ends(ut_arrays A, ut_paths P, const uint32_t *__restrict__ 
     uint8_t info = A.info[i];
     // end k-mer: the walk stops either because R(f) < 0 (cur = f) or because the k-mer beyond f has
     // several left neighbours (cur = that k-mer): processSequence :83-92
-    // (W: the table is ascending, a k-mer's index compares and orders like the k-mer itself)
-    uint64_t endc = W ? (uint64_t)i : A.gk[i];
-    if (ut_r_unique(info, o)) { const uint32_t e = ut_right_node(A, i, o, info) >> 1; endc = W ? (uint64_t)e : A.gk[e]; }
-    stc = W ? (uint64_t)(s >> 1) : A.gk[s >> 1];
-    if (stc > endc) break;
-    eq = stc == endc;
+    // (W: two words per k-mer -- the table need not be ascending (round 6: the record path leaves it in the order of its counting units until somebody
+    // asks for the order), so the k-mers themselves are compared; the path's key is the start k-mer's PLACE in the table)
+    uint32_t ei = i;
+    if (ut_r_unique(info, o)) ei = ut_right_node(A, i, o, info) >> 1;
+    if (W) {
+        const uint32_t si = s >> 1;
+        const uint64_t eh = A.ghi[ei], el = A.gk[ei], sh = A.ghi[si], sl = A.gk[si];
+        if (sh > eh || (sh == eh && sl > el)) break;
+        eq = sh == eh && sl == el;
+        stc = (uint64_t)si;
+    } else {
+        const uint64_t endc = A.gk[ei];
+        stc = A.gk[s >> 1];
+        if (stc > endc) break;
+        eq = stc == endc;
+    }
     // task.run :50-51 processes {kmerF, kmerF.rc()}: for a palindromic start k-mer these are the same oriented k-mer, so
     // the reference walks the identical path twice and prints it twice unless the equal-case `used` set stops the second
     twice = A.pal && A.pal[s >> 1] && !eq;

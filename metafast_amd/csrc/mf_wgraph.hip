@@ -209,6 +209,7 @@ extern "C" int mf_cut_components_wide_device(mf_ctx *ctx, mf_wtable *t, int b1, 
     MF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     if (t->n >= 0xFFFFFFFFull) return mf_set_error("components: more than 2^32 vertices is not supported");
+    MF_TRY(mf_wtable_ensure_ascending(t));                // (vertex ids stand for k-mers here: members come out as ids, ties go to the smallest id)
     if (t->n) MF_TRY(mf_wtable_ensure_index(t));
     const mf_windex_view ix = wview(t);
     mf_comps *inner = nullptr;

@@ -7,14 +7,16 @@
 
 typedef unsigned __int128 mf_u128;
 
-// A wide table is ASCENDING in (hi, lo) inside a piece and piece after piece: a k-mer's place in the table orders like the k-mer
-// itself, which is what lets the graph stages work on 32-bit vertex ids and compare ids where the k <= 31 kernels compare k-mers.
+// A wide table is ASCENDING in (hi, lo) inside a piece and piece after piece -- a k-mer's place in the table then orders like the k-mer itself, which
+// is what lets the component cutter work on 32-bit vertex ids and break ties by the smallest id -- or, fresh from the record path (mf_wskm.hip), still
+// in the order of its counting units (ascending == false): mf_wtable_ensure_ascending orders it when somebody needs the order.
 struct mf_wtable {
     mf_ctx *ctx = nullptr;
     int k = 0;
     uint64_t n = 0, n_occ = 0;
     uint64_t n_all = 0;           // distinct k-mers before a cut inside the counting pass (mf_count_wide_device_above); else = n
     int cut_thr = -1;             // every entry has count > cut_thr
+    bool ascending = true;
     struct piece { mf_buf<uint64_t> hi, lo; mf_buf<uint16_t> cnt; uint64_t n = 0; };     // ascending (hi, lo) inside a piece, and piece after piece
     std::vector<std::unique_ptr<piece>> pieces;   // (one per pass: no second copy of a 74 GB table, and none of the 8 ms per GB a first hipMalloc of it takes)
     // lookup index over a ONE-piece table (built on first use by the graph stages, mf_wgraph.hip): open-addressed, 8-byte slots
@@ -26,6 +28,8 @@ struct mf_windex_view { const unsigned long long *slots; uint64_t mask; const ui
 // the count on the record path (mf_wskm.hip): 0 = *t filled, 1 = not an input for it (the caller counts the old way), < 0 = error
 int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len, int threshold,
                       const uint32_t *vmask, uint64_t n_words, mf_wtable *t);
+int mf_wide_order(mf_ctx *ctx, int k, const uint64_t *src_hi, const uint64_t *src_lo, const uint16_t *src_cnt, uint64_t nk, mf_wtable::piece *pc);
+int mf_wtable_ensure_ascending(mf_wtable *t);             // (drops an index built over the other order)
 int mf_wtable_flatten(mf_wtable *t);                      // all pieces into one (no-op for <= 1 piece)
 int mf_wtable_ensure_index(mf_wtable *t);                 // flatten + index
 // entries of (hi, lo, cnt)[n] with cnt > thr -> a new piece (order kept)

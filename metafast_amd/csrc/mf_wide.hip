@@ -701,8 +701,24 @@ extern "C" int mf_wtable_filter(const mf_wtable *t, int threshold, mf_wtable **o
         if (kept->n) nt->pieces.push_back(std::move(kept));
     }
     nt->n = tot;
+    nt->ascending = t->ascending;                         // (the cut keeps the order it finds)
     MF_TRY(mf_wtable_flatten(nt.get()));
     *out = nt.release();
+    return MF_OK;
+}
+// a table fresh from the record path: its one piece in ascending order (the index, if any, was built over the other order)
+int mf_wtable_ensure_ascending(mf_wtable *t) {
+    if (t->ascending) return MF_OK;
+    if (t->pieces.size() > 1) return mf_set_error("wide table: %zu pieces out of order", t->pieces.size());
+    if (t->pieces.size() == 1 && t->pieces[0]->n) {
+        MF_HIP(hipSetDevice(t->ctx->device));
+        auto pc = std::make_unique<mf_wtable::piece>();
+        mf_wtable::piece &old = *t->pieces[0];
+        MF_TRY(mf_wide_order(t->ctx, t->k, old.hi.p, old.lo.p, old.cnt.p, old.n, pc.get()));
+        t->pieces[0] = std::move(pc);
+        t->index.reset(); t->index_mask = 0;
+    }
+    t->ascending = true;
     return MF_OK;
 }
 int mf_wtable_flatten(mf_wtable *t) {
@@ -740,6 +756,7 @@ extern "C" int mf_wtable_pieces(const mf_wtable *t, uint32_t *n_pieces) {
 }
 extern "C" int mf_wtable_piece_view(const mf_wtable *t, uint32_t i, const void **d_keys_hi, const void **d_keys_lo, const void **d_counts, uint64_t *n) {
     if (!t || !n) return mf_set_error("mf_wtable_piece_view: NULL argument");
+    MF_TRY(mf_wtable_ensure_ascending(const_cast<mf_wtable *>(t)));     // (what the caller sees is ascending)
     if (i >= t->pieces.size()) return mf_set_error("mf_wtable_piece_view: piece %u of %zu", i, t->pieces.size());
     const auto &pc = *t->pieces[i];
     if (d_keys_hi) *d_keys_hi = pc.hi.p;
@@ -756,6 +773,7 @@ extern "C" int mf_wtable_export(const mf_wtable *t, uint64_t *keys_hi, uint64_t 
     if (capacity < t->n) return mf_set_error("mf_wtable_export: capacity %llu < %llu entries", (unsigned long long)capacity, (unsigned long long)t->n);
     if (!t->n) return MF_OK;
     MF_HIP(hipSetDevice(t->ctx->device));
+    MF_TRY(mf_wtable_ensure_ascending(const_cast<mf_wtable *>(t)));
     uint64_t at = 0;
     for (auto &pc : t->pieces) {
         if (!pc->n) continue;

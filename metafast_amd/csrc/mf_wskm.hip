@@ -434,6 +434,74 @@ __global__ void k_wskm_scatter_side(const uint32_t *__restrict__ pos, const uint
     if (i < n) { const uint32_t p = pos[i]; ohi[p] = hi[i]; olo[p] = lo[i]; ocnt[p] = cnt[i]; }
 }
 
+// nk distinct k-mers (src_hi, src_lo, src_cnt) in any order -> *pc: ascending (high, low)
+int mf_wide_order(mf_ctx *ctx, int k, const uint64_t *src_hi, const uint64_t *src_lo, const uint16_t *src_cnt, uint64_t nk, mf_wtable::piece *pc) {
+    hipStream_t st = ctx->stream;
+    MF_TRY(pc->hi.alloc(ctx, nk)); MF_TRY(pc->lo.alloc(ctx, nk)); MF_TRY(pc->cnt.alloc(ctx, nk));
+    if (nk) {
+        mf_ktimer tm(ctx, "k_wskm_order");
+        // all bits of n entries sorted: by the low word carrying the entry number, then -- stable -- by the high word's 2k - 64 bits
+        auto full_order = [&](const uint64_t *shi, const uint64_t *slo, const uint16_t *scnt, uint64_t n, uint64_t *dhi, uint64_t *dlo, uint16_t *dcnt) -> int {
+            mf_buf<uint32_t> i0, i1, i2; mf_buf<uint64_t> k1, k2, h1;
+            MF_TRY(i0.alloc(ctx, n)); MF_TRY(i1.alloc(ctx, n)); MF_TRY(k1.alloc(ctx, n));
+            k_wskm_iota<<<wsgrid(n), 256, 0, st>>>(i0.p, n);
+            MF_TRY(mf_sort_u64_u32(ctx, slo, i0.p, n, 64, k1.p, i1.p));
+            i0.reset();
+            const int hb = 2 * k - 64;
+            if (hb > 0) {
+                MF_TRY(h1.alloc(ctx, n)); MF_TRY(k2.alloc(ctx, n)); MF_TRY(i2.alloc(ctx, n));
+                k_wskm_gather64<<<wsgrid(n), 256, 0, st>>>(shi, i1.p, n, h1.p);
+                MF_TRY(mf_sort_u64_u32(ctx, h1.p, i1.p, n, hb, k2.p, i2.p));
+            } else i2.swap(i1);
+            k_wskm_gather64<<<wsgrid(n), 256, 0, st>>>(shi, i2.p, n, dhi);
+            k_wskm_gather64<<<wsgrid(n), 256, 0, st>>>(slo, i2.p, n, dlo);
+            k_wskm_gather16<<<wsgrid(n), 256, 0, st>>>(scnt, i2.p, n, dcnt);
+            MF_HIP(hipStreamSynchronize(st));
+            return MF_OK;
+        };
+        bool placed = false;
+        if (ctx->opt_wide_skm_lead) {
+            mf_buf<uint32_t> l0, j0, l1, j1; mf_buf<unsigned int> side_n;
+            MF_TRY(l0.alloc(ctx, nk)); MF_TRY(j0.alloc(ctx, nk)); MF_TRY(l1.alloc(ctx, nk)); MF_TRY(j1.alloc(ctx, nk)); MF_TRY(side_n.alloc(ctx, 1));
+            MF_HIP(hipMemsetAsync(side_n.p, 0, 4, st));
+            k_wskm_lead<<<wsgrid(nk), 256, 0, st>>>(src_hi, src_lo, nk, k, l0.p, j0.p);
+            MF_TRY(mf_sort_u32_pairs(ctx, l0.p, j0.p, nk, 32, l1.p, j1.p));
+            j0.reset();
+            // (the entries of long runs: their places in l0 -- free again --, themselves aside; room for an eighth of all, or all bits of everything are sorted)
+            const uint64_t scap = ctx->opt_wide_skm_lead == 2 ? 0 : nk / 8 + 1024;
+            mf_buf<uint64_t> shi, slo; mf_buf<uint16_t> scnt;
+            MF_TRY(shi.alloc(ctx, scap + 1)); MF_TRY(slo.alloc(ctx, scap + 1)); MF_TRY(scnt.alloc(ctx, scap + 1));
+            mf_buf<uint64_t> ghi, glo; mf_buf<uint16_t> gcnt;
+            MF_TRY(ghi.alloc(ctx, nk)); MF_TRY(glo.alloc(ctx, nk)); MF_TRY(gcnt.alloc(ctx, nk));
+            k_wskm_gather64<<<wsgrid(nk), 256, 0, st>>>(src_hi, j1.p, nk, ghi.p);
+            k_wskm_gather64<<<wsgrid(nk), 256, 0, st>>>(src_lo, j1.p, nk, glo.p);
+            k_wskm_gather16<<<wsgrid(nk), 256, 0, st>>>(src_cnt, j1.p, nk, gcnt.p);
+            k_wskm_place<<<wsgrid(nk), 256, 0, st>>>(l1.p, ghi.p, glo.p, gcnt.p, nk, pc->hi.p, pc->lo.p, pc->cnt.p, side_n.p, l0.p, shi.p, slo.p, scnt.p, scap);
+            unsigned int ns = 0;
+            MF_HIP(hipMemcpyAsync(&ns, side_n.p, 4, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            l1.reset(); j1.reset();
+            if ((uint64_t)ns <= scap) {
+                placed = true;
+                if (ns) {
+                    // ascending places x ascending k-mers: the runs are ranges of places, and the k-mers of a run with smaller leading bits are smaller
+                    mf_buf<uint32_t> pos, zero, dummy; mf_buf<uint64_t> thi, tlo; mf_buf<uint16_t> tcnt;
+                    MF_TRY(pos.alloc(ctx, ns)); MF_TRY(zero.alloc(ctx, ns)); MF_TRY(dummy.alloc(ctx, ns)); MF_TRY(thi.alloc(ctx, ns)); MF_TRY(tlo.alloc(ctx, ns)); MF_TRY(tcnt.alloc(ctx, ns));
+                    MF_HIP(hipMemsetAsync(zero.p, 0, (size_t)ns * 4, st));
+                    MF_TRY(mf_sort_u32_pairs(ctx, l0.p, zero.p, ns, 32, pos.p, dummy.p));
+                    MF_TRY(full_order(shi.p, slo.p, scnt.p, ns, thi.p, tlo.p, tcnt.p));
+                    k_wskm_scatter_side<<<wsgrid(ns), 256, 0, st>>>(pos.p, thi.p, tlo.p, tcnt.p, ns, pc->hi.p, pc->lo.p, pc->cnt.p);
+                    MF_HIP(hipStreamSynchronize(st));
+                }
+                if (ctx->opt_verbose) fprintf(stderr, "[mf] count_wide (records): %u of %llu kept k-mers stand in runs of more than %d with the same leading 16 bases (all their bits are sorted)\n", ns, (unsigned long long)nk, WO_RUN);
+            }
+        }
+        if (!placed) MF_TRY(full_order(src_hi, src_lo, src_cnt, nk, pc->hi.p, pc->lo.p, pc->cnt.p));
+    }
+    pc->n = nk;
+    return MF_OK;
+}
+
 // 0: *t filled (one ascending piece, the cut made); 1: not an input for this path (nothing changed); < 0: error
 int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_offsets, uint64_t n_reads, uint64_t n_bases, int k, int min_read_len, int threshold,
                       const uint32_t *vmask, uint64_t n_words, mf_wtable *t) {
@@ -524,68 +592,16 @@ int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_off
     if (ctx->opt_verbose) fprintf(stderr, "[mf] count_wide (records): %llu k-mers in %llu records (%.1f per record), %u units, %llu counted in several passes; %llu distinct, %llu kept\n", n_occ, n_rec,
                                   (double)n_occ / (double)n_rec, n_units, res[2], res[1], (unsigned long long)nk);
     if (nk >= (1ull << 32)) { t->n_occ = 0; return 1; }                         // (more kept k-mers than entry numbers: the old way)
-    // ascending (high, low): by the low word carrying the entry number, then -- stable -- by the high word's 2k - 64 bits
+    // The table stays in the order of the counting units (option wide_skm_lazy_order, the default) until somebody needs it ascending -- an export, the
+    // pieces' views, the component cutter (mf_wtable_ensure_ascending): unitigs and features find k-mers through the index and compare k-mers, not places,
+    // and ordering 7.5e8 kept entries is 0.2 s of the 200 M-read sample's 1.4 s.
     auto pc = std::make_unique<mf_wtable::piece>();
-    MF_TRY(pc->hi.alloc(ctx, nk)); MF_TRY(pc->lo.alloc(ctx, nk)); MF_TRY(pc->cnt.alloc(ctx, nk));
-    if (nk) {
-        mf_ktimer tm(ctx, "k_wskm_order");
-        // all bits of n entries sorted: by the low word carrying the entry number, then -- stable -- by the high word's 2k - 64 bits
-        auto full_order = [&](const uint64_t *shi, const uint64_t *slo, const uint16_t *scnt, uint64_t n, uint64_t *dhi, uint64_t *dlo, uint16_t *dcnt) -> int {
-            mf_buf<uint32_t> i0, i1, i2; mf_buf<uint64_t> k1, k2, h1;
-            MF_TRY(i0.alloc(ctx, n)); MF_TRY(i1.alloc(ctx, n)); MF_TRY(k1.alloc(ctx, n));
-            k_wskm_iota<<<wsgrid(n), 256, 0, st>>>(i0.p, n);
-            MF_TRY(mf_sort_u64_u32(ctx, slo, i0.p, n, 64, k1.p, i1.p));
-            i0.reset();
-            const int hb = 2 * k - 64;
-            if (hb > 0) {
-                MF_TRY(h1.alloc(ctx, n)); MF_TRY(k2.alloc(ctx, n)); MF_TRY(i2.alloc(ctx, n));
-                k_wskm_gather64<<<wsgrid(n), 256, 0, st>>>(shi, i1.p, n, h1.p);
-                MF_TRY(mf_sort_u64_u32(ctx, h1.p, i1.p, n, hb, k2.p, i2.p));
-            } else i2.swap(i1);
-            k_wskm_gather64<<<wsgrid(n), 256, 0, st>>>(shi, i2.p, n, dhi);
-            k_wskm_gather64<<<wsgrid(n), 256, 0, st>>>(slo, i2.p, n, dlo);
-            k_wskm_gather16<<<wsgrid(n), 256, 0, st>>>(scnt, i2.p, n, dcnt);
-            MF_HIP(hipStreamSynchronize(st));
-            return MF_OK;
-        };
-        bool placed = false;
-        if (ctx->opt_wide_skm_lead) {
-            mf_buf<uint32_t> l0, j0, l1, j1; mf_buf<unsigned int> side_n;
-            MF_TRY(l0.alloc(ctx, nk)); MF_TRY(j0.alloc(ctx, nk)); MF_TRY(l1.alloc(ctx, nk)); MF_TRY(j1.alloc(ctx, nk)); MF_TRY(side_n.alloc(ctx, 1));
-            MF_HIP(hipMemsetAsync(side_n.p, 0, 4, st));
-            k_wskm_lead<<<wsgrid(nk), 256, 0, st>>>(ohi.p, olo.p, nk, k, l0.p, j0.p);
-            MF_TRY(mf_sort_u32_pairs(ctx, l0.p, j0.p, nk, 32, l1.p, j1.p));
-            j0.reset();
-            // (the entries of long runs: their places in l0 -- free again --, themselves aside; room for an eighth of all, or all bits of everything are sorted)
-            const uint64_t scap = ctx->opt_wide_skm_lead == 2 ? 0 : nk / 8 + 1024;
-            mf_buf<uint64_t> shi, slo; mf_buf<uint16_t> scnt;
-            MF_TRY(shi.alloc(ctx, scap + 1)); MF_TRY(slo.alloc(ctx, scap + 1)); MF_TRY(scnt.alloc(ctx, scap + 1));
-            mf_buf<uint64_t> ghi, glo; mf_buf<uint16_t> gcnt;
-            MF_TRY(ghi.alloc(ctx, nk)); MF_TRY(glo.alloc(ctx, nk)); MF_TRY(gcnt.alloc(ctx, nk));
-            k_wskm_gather64<<<wsgrid(nk), 256, 0, st>>>(ohi.p, j1.p, nk, ghi.p);
-            k_wskm_gather64<<<wsgrid(nk), 256, 0, st>>>(olo.p, j1.p, nk, glo.p);
-            k_wskm_gather16<<<wsgrid(nk), 256, 0, st>>>(ocnt.p, j1.p, nk, gcnt.p);
-            k_wskm_place<<<wsgrid(nk), 256, 0, st>>>(l1.p, ghi.p, glo.p, gcnt.p, nk, pc->hi.p, pc->lo.p, pc->cnt.p, side_n.p, l0.p, shi.p, slo.p, scnt.p, scap);
-            unsigned int ns = 0;
-            MF_HIP(hipMemcpyAsync(&ns, side_n.p, 4, hipMemcpyDeviceToHost, st));
-            MF_HIP(hipStreamSynchronize(st));
-            l1.reset(); j1.reset();
-            if ((uint64_t)ns <= scap) {
-                placed = true;
-                if (ns) {
-                    // ascending places x ascending k-mers: the runs are ranges of places, and the k-mers of a run with smaller leading bits are smaller
-                    mf_buf<uint32_t> pos, zero, dummy; mf_buf<uint64_t> thi, tlo; mf_buf<uint16_t> tcnt;
-                    MF_TRY(pos.alloc(ctx, ns)); MF_TRY(zero.alloc(ctx, ns)); MF_TRY(dummy.alloc(ctx, ns)); MF_TRY(thi.alloc(ctx, ns)); MF_TRY(tlo.alloc(ctx, ns)); MF_TRY(tcnt.alloc(ctx, ns));
-                    MF_HIP(hipMemsetAsync(zero.p, 0, (size_t)ns * 4, st));
-                    MF_TRY(mf_sort_u32_pairs(ctx, l0.p, zero.p, ns, 32, pos.p, dummy.p));
-                    MF_TRY(full_order(shi.p, slo.p, scnt.p, ns, thi.p, tlo.p, tcnt.p));
-                    k_wskm_scatter_side<<<wsgrid(ns), 256, 0, st>>>(pos.p, thi.p, tlo.p, tcnt.p, ns, pc->hi.p, pc->lo.p, pc->cnt.p);
-                    MF_HIP(hipStreamSynchronize(st));
-                }
-                if (ctx->opt_verbose) fprintf(stderr, "[mf] count_wide (records): %u of %llu kept k-mers stand in runs of more than %d with the same leading 16 bases (all their bits are sorted)\n", ns, (unsigned long long)nk, WO_RUN);
-            }
-        }
-        if (!placed) MF_TRY(full_order(ohi.p, olo.p, ocnt.p, nk, pc->hi.p, pc->lo.p, pc->cnt.p));
+    if (ctx->opt_wide_skm_lazy_order) {
+        pc->hi.swap(ohi); pc->lo.swap(olo); pc->cnt.swap(ocnt);
+        t->ascending = false;
+    } else {
+        MF_TRY(mf_wide_order(ctx, k, ohi.p, olo.p, ocnt.p, nk, pc.get()));
+        t->ascending = true;
     }
     pc->n = nk;
     t->pieces.clear();
