@@ -196,6 +196,16 @@ __global__ void k_cc_hook(const uint32_t *__restrict__ nbr, const uint8_t *__res
 // few tile roots, so the tile is first grouped by parent value in an LDS hash table (size and weight summed with LDS
 // atomics); the walk to the root and the atomics on the root's two global counters then happen once per distinct parent
 // value instead of once per vertex (the giant component's counters are the hottest addresses of the whole step).
+// every alive vertex points at its root (a thread per vertex, ancestors read through the cache): k_cc_flatten_stats then finds a tile's roots in one step
+// each instead of walking up from every distinct parent value with the 12 waves per CU its LDS tables leave it
+__global__ void k_cc_compress(const uint8_t *__restrict__ alive, uint32_t *__restrict__ parent, uint64_t n) {
+    const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n || !alive[v]) return;
+    uint32_t r = parent[v];
+    if (r == (uint32_t)v) return;
+    for (;;) { const uint32_t p = parent[r]; if (p == r) break; r = p; }
+    parent[v] = r;
+}
 __global__ __launch_bounds__(256) void k_cc_flatten_stats(const uint8_t *__restrict__ alive, const uint32_t *__restrict__ parent,
                                                           uint32_t *__restrict__ root, const uint16_t *__restrict__ vals,
                                                           uint32_t *__restrict__ csize, unsigned long long *__restrict__ cweight, uint64_t n) {
@@ -561,7 +571,10 @@ int mf_cc_build(mf_ctx *ctx, uint64_t n, int k, const uint16_t *d_counts, const 
             {
                 mf_ktimer tm(ctx, "k_cc_stats");
                 if (sparse) { if (m) k_ccs_stats<<<cgrid(m), 256, 0, st>>>(L, m, parent.p, root.p, d_counts, csize.p, cweight.p); }
-                else k_cc_flatten_stats<<<cgrid(n, CC_TILE), 256, 0, st>>>(alive.p, parent.p, root.p, d_counts, csize.p, cweight.p, n);
+                else {
+                    if (ctx->opt_cc_compress) k_cc_compress<<<cgrid(n), 256, 0, st>>>(alive.p, parent.p, n);        // (5-fold depth: k_cc_stats 51 -> 42 ms)
+                    k_cc_flatten_stats<<<cgrid(n, CC_TILE), 256, 0, st>>>(alive.p, parent.p, root.p, d_counts, csize.p, cweight.p, n);
+                }
                 if (span) k_cc_classify<<<cgrid(span), 256, 0, st>>>(alive.p, root.p, csize.p, cweight.p, span, (uint32_t)b1, (uint32_t)b2, keptslot.p, K, counters.p, L);
             }
             unsigned int cnt[4];

@@ -98,6 +98,7 @@ struct mf_ctx {
     int64_t opt_gz_piece = 2 << 20;         // ... in pieces of at least this many compressed bytes (tests: 65536)
     int64_t opt_ut_double_after = 4;   // unitigs: walks still under way after this many chunked rounds (32, 128, 512, 4096 jumps) double the jump words instead (tests: 1)
     int64_t opt_ut_plain_rounds = 3;   // unitigs of a table without partitions (2k-bit tables, k < 20): rounds of doubling the one-hop jump words over all nodes before the walks (0: none)
+    int64_t opt_cc_compress = 1;   // a pass that points every vertex at its root before the components' sizes are added up (mf_cc.hip, k_cc_compress)
     int64_t opt_stream_count = 1;  // mf_count_reads*: plain FASTA / FASTQ files are counted WHILE they cross PCIe (mf_stream.hip: upload || parse || level-1 scatter, piece by piece)
     int64_t opt_stream_count_min = 512 << 20, opt_stream_count_piece = 256 << 20;   // ... from this many bytes of files on; bytes per piece
     int64_t opt_stream_count_test_pct = 100;   // (tests: the digit regions get this share of what the sample says -- below 100 they overflow and the count steps back)

@@ -181,6 +181,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "skm_dyn") ctx->opt_skm_dyn = v;
     else if (s == "nbr_global") ctx->opt_nbr_global = v;
     else if (s == "ut_plain_rounds") ctx->opt_ut_plain_rounds = v;
+    else if (s == "cc_compress") ctx->opt_cc_compress = v;
     else if (s == "stream_count") ctx->opt_stream_count = v;
     else if (s == "stream_count_min_bytes") ctx->opt_stream_count_min = v;
     else if (s == "stream_count_piece_bytes") ctx->opt_stream_count_piece = v;
