@@ -532,6 +532,96 @@ static size_t sr_record_start(const char *b, size_t n, size_t from, bool file_st
     return n;
 }
 
+// ---- the streamed count (mf_stream.hip): where the files are cut into pieces and what the sample holds.  Host work on bytes nobody has checked yet.
+#define ST_WINDOW ((size_t)1 << 20)       // how far a record border is looked for behind a nominal cut
+#define ST_SAMPLE ((size_t)128 << 10)     // bytes per sample chunk
+// the first record start in [w, w + n) AFTER position 0 (the window begins anywhere inside a record): sr_record_start's rule -- FASTA: a '>' or ';'
+// behind a line feed; FASTQ: a line that starts with '@' whose next line but one starts with '+' (a QUALITY line may start with '@' too, but the line
+// after it is then the next record's '@' header and the one after that its bases, which never start with '+').  (size_t)-1: none in the window
+static size_t st_record_start(const char *w, size_t n, int fmt) {
+    if (n < 2) return (size_t)-1;
+    const size_t r = sr_record_start(w, n, 1, false, fmt);
+    return r >= n ? (size_t)-1 : r;
+}
+// the last record start in the window (the END of a sample chunk): searched in its second half
+static size_t st_last_record_start(const char *w, size_t n, int fmt) {
+    size_t best = (size_t)-1, from = n / 2;
+    for (;;) {
+        if (from + 2 >= n) break;
+        const size_t r = st_record_start(w + from, n - from, fmt);
+        if (r == (size_t)-1) break;
+        best = from + r;
+        from = best + 1;
+    }
+    return best;
+}
+struct st_piece { int file; size_t off, len; };
+// pieces of about P bytes, every one starting and ending at a record border of its file (the first at byte 0, the last at the file's end; no small last
+// piece).  0: done; 1: a border was not found within ST_WINDOW bytes (records longer than that: assembled sequences, not reads) or a read failed
+static int st_plan_pieces(const std::vector<int> &fds, const std::vector<size_t> &sizes, int fmt, size_t P, std::vector<st_piece> &pieces, size_t *piece_max) {
+    std::vector<char> w(ST_WINDOW);
+    *piece_max = 0;
+    for (size_t i = 0; i < fds.size(); i++) {
+        const size_t n = sizes[i];
+        size_t at = 0;
+        while (at < n) {
+            size_t end = at + P;
+            if (end + P / 4 >= n) end = n;
+            else {
+                // (16 KB first: reads are a few hundred bytes, and 58 windows of 1 MB were 10 ms of preads in front of the first upload)
+                size_t r = (size_t)-1;
+                for (size_t win : {(size_t)16 << 10, ST_WINDOW}) {
+                    const size_t m = std::min(win, n - end);
+                    if (pread(fds[i], w.data(), m, (off_t)end) != (ssize_t)m) return 1;
+                    r = st_record_start(w.data(), m, fmt);
+                    if (r != (size_t)-1) break;
+                }
+                if (r == (size_t)-1) return 1;
+                end += r;
+            }
+            pieces.push_back(st_piece{(int)i, at, end - at});
+            *piece_max = std::max(*piece_max, end - at);
+            at = end;
+        }
+    }
+    return 0;
+}
+// n_chunks chunks of ST_SAMPLE bytes spread evenly over the files' bytes, each trimmed to whole records, one after the other in sample[n_chunks * ST_SAMPLE];
+// *s_bytes = what they hold.  0: done; 1: a chunk without two record starts, a read that failed, a file shorter than a chunk
+static int st_sample(const std::vector<int> &fds, const std::vector<size_t> &sizes, size_t total, int fmt, size_t n_chunks, int threads, char *sample, size_t *s_bytes) {
+    for (size_t sz : sizes) if (sz < ST_SAMPLE) return 1;
+    std::vector<size_t> s_len(n_chunks, 0);
+    std::atomic<size_t> next{0}; std::atomic<int> bad{0};
+    std::vector<std::thread> th;
+    for (int t = 0; t < std::max(1, threads); t++)
+        th.emplace_back([&]() {
+            std::vector<char> w(ST_SAMPLE);
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= n_chunks || bad.load()) break;
+                // chunk c stands at byte c / n_chunks of all the files' bytes
+                size_t g = (size_t)((double)total * ((double)c / (double)n_chunks));
+                size_t f = 0; while (f + 1 < fds.size() && g >= sizes[f]) { g -= sizes[f]; f++; }
+                if (g + ST_SAMPLE > sizes[f]) g = sizes[f] - ST_SAMPLE;
+                if (pread(fds[f], w.data(), ST_SAMPLE, (off_t)g) != (ssize_t)ST_SAMPLE) { bad = 1; break; }
+                const size_t a = g == 0 ? 0 : st_record_start(w.data(), ST_SAMPLE, fmt);
+                const size_t b = st_last_record_start(w.data(), ST_SAMPLE, fmt);
+                if (a == (size_t)-1 || b == (size_t)-1 || b <= a) { bad = 1; break; }
+                memcpy(sample + c * ST_SAMPLE, w.data() + a, b - a);
+                s_len[c] = b - a;
+            }
+        });
+    for (auto &x : th) x.join();
+    if (bad.load()) return 1;
+    size_t at = 0;
+    for (size_t c = 0; c < n_chunks; c++) {            // close the gaps
+        if (at != c * ST_SAMPLE) memmove(sample + at, sample + c * ST_SAMPLE, s_len[c]);
+        at += s_len[c];
+    }
+    *s_bytes = at;
+    return 0;
+}
+
 // ConnectedComponent.loadComponents (src/structures/ConnectedComponent.java:95-122): the component headers of a components.bin image
 // (count, then per component: size u32, weight i64, size k-mers of 8 bytes; big-endian).  foff[i] = byte offset of component i's
 // k-mers, koff = prefix sums of the sizes.  A count or a size the image cannot hold is a wrong file, not a reason to allocate for it.

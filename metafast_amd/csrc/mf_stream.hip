@@ -42,32 +42,8 @@ int mf_upload_pool(mf_ctx *ctx);
 int mf_dparse_device(mf_ctx *ctx, const char *path, uint8_t *d_raw, size_t room, size_t n, int fmt, int qoff, mf_buf<uint8_t> &bases, mf_buf<uint64_t> &offsets, uint64_t *n_reads, uint64_t *n_bases);
 
 #define ST_CHUNK ((size_t)256 << 10)      // the device parser's chunk (DP_CHUNK): the buffers hold whole chunks + 64 bytes
-#define ST_WINDOW ((size_t)1 << 20)       // how far a record border is looked for behind a nominal cut
-#define ST_SAMPLE ((size_t)128 << 10)     // bytes per sample chunk
-
-// the first record start in [w, w + n) AFTER position 0 (the window begins anywhere inside a record): the stream reader's cutter (mf_parse.h,
-// sr_record_start: FASTA -- a '>' or ';' behind a line feed; FASTQ -- a line that starts with '@' whose next line but one starts with '+': a QUALITY
-// line may start with '@' too, but the line after it is then the next record's '@' header and the one after that its bases, which never start
-// with '+'; it runs under ASan + UBSan in the CPU suite, tests/host/parse_harness.cpp "cuts").  (size_t)-1: none in the window
-static size_t record_start(const char *w, size_t n, int fmt) {
-    if (n < 2) return (size_t)-1;
-    const size_t r = sr_record_start(w, n, 1, false, fmt);
-    return r >= n ? (size_t)-1 : r;
-}
-// the last record start in the window (for the END of a sample chunk): searched from 3/4 of it on
-static size_t last_record_start(const char *w, size_t n, int fmt) {
-    size_t best = (size_t)-1, from = n / 2;
-    for (;;) {
-        const size_t r = record_start(w + from, n - from, fmt);
-        if (r == (size_t)-1) break;
-        best = from + r;
-        from = best + 1;
-        if (from + 2 >= n) break;
-    }
-    return best;
-}
-
-struct st_piece { int file; size_t off, len; };
+// (where the pieces are cut and what the sample holds is host work on bytes nobody has checked: st_record_start, st_plan_pieces, st_sample live in
+// mf_parse.h and run under ASan + UBSan in the CPU suite -- tests/host/parse_harness.cpp "stream", tests/test_host_sanitized_cpu.py)
 struct st_slot { mf_buf<uint8_t> raw; int piece = -1; bool ready = false; };
 
 // 0: done (*out), 1: not this way (nothing produced), < 0: error
@@ -118,7 +94,7 @@ int mf_count_files_streamed(mf_ctx *ctx, const char *const *files, int nfiles, i
             if (pread(fds[(size_t)i], head.data(), head.size(), 0) != (ssize_t)head.size()) return 1;
             // (the last record of the head may be cut: the sniffing reads whole lines only as far as it needs -- 1000 records)
             size_t cut = head.size(); while (cut && head[cut - 1] != '\n') cut--;
-            const size_t lr = last_record_start(head.data(), cut, 2);
+            const size_t lr = st_last_record_start(head.data(), cut, 2);
             if (lr == (size_t)-1) return 1;
             read_batch tmp;
             const int q = parse_fastq_pass(head.data(), lr, files[i], 0, 0, tmp);
@@ -129,32 +105,7 @@ int mf_count_files_streamed(mf_ctx *ctx, const char *const *files, int nfiles, i
     const size_t P = (size_t)std::max<int64_t>(ctx->opt_stream_count_piece, (int64_t)ST_WINDOW);        // (tests go down to 1 MB)
     std::vector<st_piece> pieces;
     size_t piece_max = 0;
-    {
-        std::vector<char> w(ST_WINDOW);
-        for (int i = 0; i < nfiles; i++) {
-            const size_t n = sizes[(size_t)i];
-            size_t at = 0;
-            while (at < n) {
-                size_t end = at + P;
-                if (end + P / 4 >= n) end = n;                 // (no small last piece)
-                else {
-                    // (16 KB first: reads are a few hundred bytes, and 58 windows of 1 MB were 10 ms of preads in front of the first upload)
-                    size_t r = (size_t)-1;
-                    for (size_t win : {(size_t)16 << 10, ST_WINDOW}) {
-                        const size_t m = std::min(win, n - end);
-                        if (pread(fds[(size_t)i], w.data(), m, (off_t)end) != (ssize_t)m) return 1;
-                        r = record_start(w.data(), m, fmt);
-                        if (r != (size_t)-1) break;
-                    }
-                    if (r == (size_t)-1) return 1;             // (records longer than the window: assembled sequences, not reads)
-                    end += r;
-                }
-                pieces.push_back(st_piece{i, at, end - at});
-                piece_max = std::max(piece_max, end - at);
-                at = end;
-            }
-        }
-    }
+    if (st_plan_pieces(fds, sizes, fmt, P, pieces, &piece_max) != 0) return 1;   // (records longer than the search window: assembled sequences, not reads)
     if (pieces.size() < 2) return 1;
     const double t02 = now();
     // ---- the sample: chunks spread evenly over the files, trimmed to whole records, one after the other in a host buffer
@@ -163,37 +114,8 @@ int mf_count_files_streamed(mf_ctx *ctx, const char *const *files, int nfiles, i
     std::unique_ptr<char, void (*)(void *)> sample_mem((char *)malloc(n_chunks * ST_SAMPLE), free);      // (not a vector: 64 MB of zeroes first cost 15 ms)
     char *const sample = sample_mem.get();
     if (!sample) return 1;
-    std::vector<size_t> s_len(n_chunks, 0);
-    {
-        std::atomic<size_t> next{0}; std::atomic<int> bad{0};
-        const int T = std::max(1, std::min(ctx->host_threads, 16));
-        std::vector<std::thread> th;
-        for (int t = 0; t < T; t++)
-            th.emplace_back([&]() {
-                std::vector<char> w(ST_SAMPLE);
-                for (;;) {
-                    const size_t c = next.fetch_add(1);
-                    if (c >= n_chunks || bad.load()) break;
-                    // chunk c stands at byte c / n_chunks of all the files' bytes
-                    size_t g = (size_t)((double)total * ((double)c / (double)n_chunks));
-                    int f = 0; while (f + 1 < nfiles && g >= sizes[(size_t)f]) { g -= sizes[(size_t)f]; f++; }
-                    if (g + ST_SAMPLE > sizes[(size_t)f]) g = sizes[(size_t)f] - ST_SAMPLE;
-                    if (pread(fds[(size_t)f], w.data(), ST_SAMPLE, (off_t)g) != (ssize_t)ST_SAMPLE) { bad = 1; break; }
-                    const size_t a = g == 0 ? 0 : record_start(w.data(), ST_SAMPLE, fmt);
-                    const size_t b = last_record_start(w.data(), ST_SAMPLE, fmt);
-                    if (a == (size_t)-1 || b == (size_t)-1 || b <= a) { bad = 1; break; }
-                    memcpy(sample + c * ST_SAMPLE, w.data() + a, b - a);
-                    s_len[c] = b - a;
-                }
-            });
-        for (auto &x : th) x.join();
-        if (bad.load()) return 1;
-    }
     size_t s_bytes = 0;
-    for (size_t c = 0; c < n_chunks; c++) {            // close the gaps
-        if (s_bytes != c * ST_SAMPLE) memmove(sample + s_bytes, sample + c * ST_SAMPLE, s_len[c]);
-        s_bytes += s_len[c];
-    }
+    if (st_sample(fds, sizes, total, fmt, n_chunks, std::max(1, std::min(ctx->host_threads, 16)), sample, &s_bytes) != 0) return 1;
     if (s_bytes < ST_SAMPLE) return 1;
     const double scale = (double)total / (double)s_bytes;
     // ---- buffers: the sample's text and a ring of three pieces

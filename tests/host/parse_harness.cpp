@@ -3,6 +3,7 @@
 //   parse_harness reads <file> <threads> [dump]   parse_reads_file (by extension: FASTA / FASTQ / .gz / .bz2 / .binq); dump = offsets + bases, raw
 //   parse_harness cuts <file> <fmt 1|2> <piece> <slack>   the streaming reader's record cutter at every piece boundary
 //   parse_harness comps <file>                     the header walk of a components.bin
+//   parse_harness stream <fmt> <piece> <chunks> <sample out> <file>...   the streamed count's piece plan and sample (mf_stream.hip)
 // Exit code 0 = parsed, 1 = rejected with a message (both fine); anything else is a finding (ASAN_OPTIONS=exitcode=99).
 // Test infrastructure (tests/test_host_sanitized_cpu.py); CPU only -- nothing here touches a GPU.
 #include "../../metafast_amd/csrc/mf_parse.h"
@@ -60,6 +61,30 @@ int main(int argc, char **argv) {
             if (s0 > n || e0 > n) { printf("cut beyond the window\n"); return 3; }
         }
         printf("cuts %llu fnv %016llx\n", (unsigned long long)cuts, (unsigned long long)h);
+        return 0;
+    }
+    if (mode == "stream") {
+        // parse_harness stream <fmt 1|2> <piece bytes> <chunks> <sample out> <file> [<file> ...]: the piece plan and the sample of the streamed count
+        if (argc < 7) { fprintf(stderr, "usage: parse_harness stream <fmt> <piece> <chunks> <sample out> <file>...\n"); return 2; }
+        const int fmt = atoi(argv[2]);
+        const size_t P = (size_t)atoll(argv[3]), n_chunks = (size_t)atoll(argv[4]);
+        std::vector<int> fds; std::vector<size_t> sizes; size_t total = 0;
+        for (int i = 6; i < argc; i++) {
+            const int fd = open(argv[i], O_RDONLY);
+            struct stat sb;
+            if (fd < 0 || fstat(fd, &sb) != 0) { printf("rejected: can't open %s\n", argv[i]); return 1; }
+            fds.push_back(fd); sizes.push_back((size_t)sb.st_size); total += (size_t)sb.st_size;
+        }
+        std::vector<st_piece> pieces; size_t piece_max = 0;
+        if (st_plan_pieces(fds, sizes, fmt, P, pieces, &piece_max) != 0) { printf("rejected: no piece plan\n"); return 1; }
+        for (auto &pc : pieces) printf("piece %d %zu %zu\n", pc.file, pc.off, pc.len);
+        std::vector<char> sample(n_chunks * ST_SAMPLE + 1);
+        size_t s_bytes = 0;
+        if (st_sample(fds, sizes, total, fmt, n_chunks, 4, sample.data(), &s_bytes) != 0) { printf("rejected: no sample\n"); return 1; }
+        FILE *f = fopen(argv[5], "wb");
+        if (f) { fwrite(sample.data(), 1, s_bytes, f); fclose(f); }
+        printf("sample %zu bytes, largest piece %zu\n", s_bytes, piece_max);
+        for (int fd : fds) close(fd);
         return 0;
     }
     if (mode == "comps") {

@@ -269,3 +269,67 @@ def test_driver_options_properties_and_matrices(binaries, tmp_path):
                  ["-t", "features-calculator", "-k", "31", "-cm", golden, "-ka", golden, "--selected", golden, "--devices", "0,1", "-w", str(tmp_path / "g9")]):
         r = subprocess.run([cli, *args], capture_output=True, text=True, errors="replace", env=ENV, timeout=60, input="", cwd=str(tmp_path))
         assert r.returncode in (0, 1), (args, r.returncode, (r.stdout + r.stderr)[-2000:])
+
+
+def _record_starts(blob, fq):
+    """byte offsets where a record begins: FASTA -- header / comment lines; FASTQ -- every fourth line"""
+    starts, pos, line = [], 0, 0
+    while pos < len(blob):
+        if fq:
+            if line % 4 == 0:
+                starts.append(pos)
+        elif blob[pos:pos + 1] in (b">", b";"):
+            starts.append(pos)
+        nl = blob.find(b"\n", pos)
+        if nl < 0:
+            break
+        pos = nl + 1; line += 1
+    return starts
+
+
+def test_streamed_count_piece_plan_and_sample(binaries, tmp_path):
+    """Round 6 (mf_stream.hip; the host half is st_plan_pieces / st_sample in mf_parse.h): the pieces tile every file, each one starts where a record
+    starts -- also when quality lines start with '@' or '+' --, the sample is whole records of the files; damaged files are planned or rejected cleanly"""
+    ph, _ = binaries
+    rng = np.random.default_rng(17)
+    planned = 0
+    for it in range(6):
+        fq = it % 2 == 1
+        blobs = [(_fastq(rng, 9000) if fq else _fasta(rng, 7000)) for _ in range(1 + it % 2 * (it // 2 % 2))]
+        files = []
+        for j, b in enumerate(blobs):
+            f = tmp_path / ("s%d_%d.%s" % (it, j, "fq" if fq else "fa")); f.write_bytes(b); files.append(f)
+        piece = int(rng.choice([1 << 20, (1 << 20) + 12345, 3 << 19]))
+        out = tmp_path / "sample.bin"
+        r = _run([ph, "stream", "2" if fq else "1", str(piece), "8", str(out), *map(str, files)])
+        if r.returncode == 1:
+            # (a FASTA file with a 9000-base record wrapped at 60 has no shorter lines than the window... not with these sizes: a plan is expected)
+            assert "rejected" in r.stdout
+            continue
+        planned += 1
+        pieces = [tuple(map(int, ln.split()[1:])) for ln in r.stdout.splitlines() if ln.startswith("piece ")]
+        for j, b in enumerate(blobs):
+            mine = [(o, n) for f, o, n in pieces if f == j]
+            assert mine[0][0] == 0 and sum(n for _, n in mine) == len(b) and all(mine[i][0] + mine[i][1] == mine[i + 1][0] for i in range(len(mine) - 1))
+            starts = set(_record_starts(b, fq))
+            assert all(o in starts for o, _ in mine), (it, j)
+            assert all(n >= piece for _, n in mine[:-1])
+        sample = out.read_bytes()
+        assert len(sample) > 0 and sample.endswith(b"\n")
+        # the sample: whole records of the files (every record of it is a record of some file)
+        recs = set()
+        for b in blobs:
+            st = _record_starts(b, fq) + [len(b)]
+            recs.update(b[st[i]:st[i + 1]] for i in range(len(st) - 1))
+        sst = _record_starts(sample, fq) + [len(sample)]
+        assert sst[0] == 0
+        assert all(sample[sst[i]:sst[i + 1]] in recs for i in range(len(sst) - 1)), it
+    assert planned >= 5, planned
+    # damaged files: any outcome but a sanitizer report
+    blob = _fastq(rng, 9000)
+    for j, b in enumerate(_mutations(rng, blob, 12)):
+        f = tmp_path / ("d%d.fq" % j); f.write_bytes(b)
+        _run([ph, "stream", "2", str(1 << 20), "8", str(tmp_path / "sample.bin"), str(f)])
+    for j, b in enumerate(_mutations(rng, _fasta(rng, 7000), 12)):
+        f = tmp_path / ("d%d.fa" % j); f.write_bytes(b)
+        _run([ph, "stream", "1", str(1 << 20), "8", str(tmp_path / "sample.bin"), str(f)])
