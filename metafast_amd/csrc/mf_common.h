@@ -107,8 +107,10 @@ struct mf_ctx {
     int64_t opt_wide_skm = 1;      // mf_count_wide_device: super-k-mer records + LDS tables (mf_wskm.hip) instead of sorting every occurrence (0: the sort path, mf_wide.hip)
     int64_t opt_wide_skm_min = 1 << 20;     // ... from this many k-mer occurrences on (tests: 1)
     int64_t opt_wide_skm_lazy_order = 1;    // ... the table stays in the order of the counting units until an export / the cutter asks for ascending k-mers (0: ordered at once)
+    int64_t opt_wide_skm_fine = 8;          // ... partitions of 1 / this of a unit's occurrences
+    int64_t opt_wide_skm_merge = 1;         // ... small neighbouring partitions share a counting unit (0: a unit per partition)
     int64_t opt_wide_skm_lead = 1;          // ... the kept entries are ordered by their leading 32 bits + a look at the runs of equal ones (0: all bits are sorted; tests)
-    int64_t opt_wide_skm_unit = 4000;       // ... k-mer occurrences per counting unit (tests lower it: units that overflow the LDS table are counted in passes)
+    int64_t opt_wide_skm_unit = 2400;       // ... k-mer occurrences per counting unit (tests lower it: units that overflow the LDS table are counted in passes)
     int64_t opt_wide_finish = 1;   // mf_count_wide_device: radix passes over the leading 32 bits + the order inside the buckets in LDS (0: radix passes over all 2k bits)
     int64_t opt_wide_big_bucket = 256;   // ... buckets of more entries than this (<= 256) go through the LDS hash table instead of the walk (tests lower it)
     int64_t opt_wide_distinct = 1280;    // ... buckets of more distinct k-mers than this (<= 1280) are sorted aside (tests lower it)

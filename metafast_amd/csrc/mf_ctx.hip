@@ -190,6 +190,8 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "wide_skm_min") ctx->opt_wide_skm_min = v;
     else if (s == "wide_skm_unit") ctx->opt_wide_skm_unit = v;
     else if (s == "wide_skm_lead") ctx->opt_wide_skm_lead = v;
+    else if (s == "wide_skm_merge") ctx->opt_wide_skm_merge = v;
+    else if (s == "wide_skm_fine") ctx->opt_wide_skm_fine = v;
     else if (s == "wide_skm_lazy_order") ctx->opt_wide_skm_lazy_order = v;
     else if (s == "dcc_sparse") ctx->opt_dcc_sparse = v;
     else if (s == "dcc_test_fail") { ctx->opt_dcc_test_fail = v; ctx->dcc_test_calls[1] = ctx->dcc_test_calls[2] = 0; }

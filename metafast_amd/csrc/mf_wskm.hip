@@ -194,6 +194,19 @@ __global__ void k_wskm_iota(uint32_t *__restrict__ v, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = (uint32_t)i;
 }
+// Counting units = RUNS OF WHOLE PARTITIONS of about G records: unit j starts at the first partition border at or behind record j G (a partition of
+// more than G records makes the units it covers empty but the first).  The partitions are very unequal -- 200 M reads at k = 63, 2^23 of them: 77 %
+// hold fewer than 128 records (a round of 1024 k-mers half empty, behind a table clear, two barriers' worth of scans and two sweeps of 4096 slots)
+// and 5 % hold 44 % of all records -- so small neighbours share a table (their k-mers differ: a k-mer has one partition) and large ones stay alone.
+__global__ void k_wskm_units(const uint64_t *__restrict__ poff, uint32_t np, uint64_t n_rec, uint64_t G, uint32_t nu, uint64_t *__restrict__ uoff) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nu) return;
+    const uint64_t t = (uint64_t)j * G;
+    if (j == nu || t >= n_rec) { uoff[j] = n_rec; return; }
+    uint32_t lo = 0, hi = np;                            // the first partition whose first record is at or behind t (poff[np] = n_rec >= t)
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (poff[mid] < t) lo = mid + 1; else hi = mid; }
+    uoff[j] = poff[lo];
+}
 __global__ void k_wskm_offsets(const uint32_t *__restrict__ part_sorted, uint64_t n, uint32_t np, uint64_t *__restrict__ off) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p > np) return;
@@ -519,7 +532,9 @@ int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_off
     const uint64_t n_tiles = (n_words * 32 + WS_TILE - 1) / WS_TILE;
     // partitions: units of about 4000 k-mer occurrences (a unit whose distinct k-mers do not fit the LDS table is counted in passes)
     int pbits = 0;
-    while (pbits < 28 && (n_occ >> pbits) > (uint64_t)std::max<int64_t>(256, ctx->opt_wide_skm_unit)) pbits++;
+    // (partitions of a share of a unit's occurrences where neighbours are merged into units: what is heavy because several minimizers met in it comes apart)
+    const int64_t per_part = ctx->opt_wide_skm_merge ? std::max<int64_t>(64, ctx->opt_wide_skm_unit / std::max<int64_t>(1, ctx->opt_wide_skm_fine)) : std::max<int64_t>(256, ctx->opt_wide_skm_unit);
+    while (pbits < 28 && (n_occ >> pbits) > (uint64_t)per_part) pbits++;
     // records: a run is (k - 13) / 2 k-mers long on average where reads, tiles and the record format do not cut it shorter
     uint64_t cap = n_occ / 10 + n_tiles * 4 + 4096;
     mf_buf<wskm_rec> recs; mf_buf<uint32_t> part;
@@ -543,16 +558,43 @@ int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_off
     t->n_occ = n_occ;
     if (!n_rec) { t->n = 0; t->n_all = 0; t->cut_thr = threshold >= 1 ? threshold : 0; return MF_OK; }
     // by partition
-    const uint32_t n_units = 1u << pbits;
+    const uint32_t n_parts = 1u << pbits;
+    uint32_t n_units = n_parts;
     mf_buf<uint32_t> order; mf_buf<uint64_t> uoff;
     {
         mf_buf<uint32_t> idx, part_s;
         if (idx.alloc(ctx, n_rec) != MF_OK || part_s.alloc(ctx, n_rec) != MF_OK || order.alloc(ctx, n_rec) != MF_OK) { (void)hipGetLastError(); return 1; }
-        MF_TRY(uoff.alloc(ctx, (size_t)n_units + 1));
+        mf_buf<uint64_t> poff;
+        MF_TRY(poff.alloc(ctx, (size_t)n_parts + 1));
         k_wskm_iota<<<wsgrid(n_rec), 256, 0, st>>>(idx.p, n_rec);
         if (pbits) MF_TRY(mf_sort_u32_pairs(ctx, part.p, idx.p, n_rec, pbits, part_s.p, order.p));
         else { MF_HIP(hipMemcpyAsync(order.p, idx.p, n_rec * 4, hipMemcpyDeviceToDevice, st)); MF_HIP(hipMemcpyAsync(part_s.p, part.p, n_rec * 4, hipMemcpyDeviceToDevice, st)); }
-        k_wskm_offsets<<<(n_units + 1 + 255) / 256, 256, 0, st>>>(part_s.p, n_rec, n_units, uoff.p);
+        k_wskm_offsets<<<(n_parts + 1 + 255) / 256, 256, 0, st>>>(part_s.p, n_rec, n_parts, poff.p);
+        if (ctx->opt_wide_skm_merge && pbits) {
+            // (records per unit: the unit's k-mer occurrences / the k-mers a record holds)
+            const uint64_t G = std::max<uint64_t>(8, (uint64_t)((double)std::max<int64_t>(ctx->opt_wide_skm_unit, 64) * (double)n_rec / (double)n_occ));
+            const uint64_t nu64 = (n_rec + G - 1) / G;
+            if (nu64 + 1 < (1ull << 31)) {
+                n_units = (uint32_t)nu64;
+                MF_TRY(uoff.alloc(ctx, (size_t)n_units + 1));
+                k_wskm_units<<<(n_units + 1 + 255) / 256, 256, 0, st>>>(poff.p, n_parts, n_rec, G, n_units, uoff.p);
+            }
+        }
+        if (!uoff.p) uoff.swap(poff);
+        if (ctx->opt_verbose >= 2) {                      // the units' sizes in records: how heavy the heavy ones are
+            std::vector<uint64_t> h((size_t)n_units + 1);
+            MF_HIP(hipMemcpyAsync(h.data(), uoff.p, ((size_t)n_units + 1) * 8, hipMemcpyDeviceToHost, st));
+            MF_HIP(hipStreamSynchronize(st));
+            uint64_t bins[12] = {0}, recs_in[12] = {0}, mx = 0;
+            for (uint32_t u = 0; u < n_units; u++) {
+                const uint64_t r = h[u + 1] - h[u]; mx = std::max(mx, r);
+                int b = 0; while (b < 11 && r >= (128ull << b)) b++;
+                bins[b]++; recs_in[b] += r;
+            }
+            fprintf(stderr, "[mf] count_wide (records): units by records (largest %llu):", (unsigned long long)mx);
+            for (int b = 0; b < 12; b++) fprintf(stderr, " <%llu: %llu units, %.1f %% of the records;", (unsigned long long)(128ull << b), (unsigned long long)bins[b], 100.0 * recs_in[b] / (double)n_rec);
+            fprintf(stderr, "\n");
+        }
         MF_HIP(hipStreamSynchronize(st));
     }
     part.reset();

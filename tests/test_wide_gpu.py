@@ -273,7 +273,7 @@ def test_wide_record_path_equals_sort_path(gpu_ctx, oracle, k):
             got = gpu_ctx.count_wide_device(db.data_ptr(), do.data_ptr(), n, len(bases), k, 0)
             assert got["n_occ"] == n_occ
             assert np.array_equal(got["hi"], hi) and np.array_equal(got["lo"], lo) and np.array_equal(got["counts"].astype(np.int32), cnt), unit
-        gpu_ctx.set_option("wide_skm_unit", 4000)
+        gpu_ctx.set_option("wide_skm_unit", 2400)
         for thr in (1, 3):
             t, n_all = gpu_ctx.count_wide_above(db.data_ptr(), do.data_ptr(), n, len(bases), k, thr)
             ghi, glo, gc = t.export()
@@ -304,5 +304,5 @@ def test_wide_record_path_equals_sort_path(gpu_ctx, oracle, k):
         h2, l2, c2, o2 = oracle.count_wide(bases, off, k, 150)
         assert got["n_occ"] == o2 and np.array_equal(got["hi"], h2) and np.array_equal(got["lo"], l2) and np.array_equal(got["counts"].astype(np.int32), c2)
     finally:
-        gpu_ctx.set_option("wide_skm", 1); gpu_ctx.set_option("wide_skm_min", 1 << 20); gpu_ctx.set_option("wide_skm_unit", 4000); gpu_ctx.set_option("wide_skm_lead", 1)
+        gpu_ctx.set_option("wide_skm", 1); gpu_ctx.set_option("wide_skm_min", 1 << 20); gpu_ctx.set_option("wide_skm_unit", 2400); gpu_ctx.set_option("wide_skm_lead", 1)
 
