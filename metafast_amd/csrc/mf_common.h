@@ -108,6 +108,7 @@ struct mf_ctx {
     int64_t opt_wide_skm_min = 1 << 20;     // ... from this many k-mer occurrences on (tests: 1)
     int64_t opt_wide_skm_lazy_order = 1;    // ... the table stays in the order of the counting units until an export / the cutter asks for ascending k-mers (0: ordered at once)
     int64_t opt_wide_skm_fine = 8;          // ... partitions of 1 / this of a unit's occurrences
+    int64_t opt_wide_skm_pack = 1;          // ... the records are laid out in their units' order, identical ones counted once with a weight (k_wskm_pack; 0: off, 2: order only)
     int64_t opt_wide_skm_merge = 1;         // ... small neighbouring partitions share a counting unit (0: a unit per partition)
     int64_t opt_wide_skm_lead = 1;          // ... the kept entries are ordered by their leading 32 bits + a look at the runs of equal ones (0: all bits are sorted; tests)
     int64_t opt_wide_skm_unit = 2400;       // ... k-mer occurrences per counting unit (tests lower it: units that overflow the LDS table are counted in passes)

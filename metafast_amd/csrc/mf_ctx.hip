@@ -191,6 +191,7 @@ extern "C" int mf_ctx_set_option(mf_ctx *ctx, const char *name, int64_t v) {
     else if (s == "wide_skm_unit") ctx->opt_wide_skm_unit = v;
     else if (s == "wide_skm_lead") ctx->opt_wide_skm_lead = v;
     else if (s == "wide_skm_merge") ctx->opt_wide_skm_merge = v;
+    else if (s == "wide_skm_pack") ctx->opt_wide_skm_pack = v;
     else if (s == "wide_skm_fine") ctx->opt_wide_skm_fine = v;
     else if (s == "wide_skm_lazy_order") ctx->opt_wide_skm_lazy_order = v;
     else if (s == "dcc_sparse") ctx->opt_dcc_sparse = v;

@@ -184,6 +184,8 @@ __global__ __launch_bounds__(WS_T) void k_wskm_scan(const uint8_t *__restrict__ 
                 for (int j = 0; j < 7; j++) R[j] = ws_word_at(pk, p + 16u * (uint32_t)j);
                 *reinterpret_cast<uint4 *>(&recs[g].w[0]) = make_uint4(R[0], R[1], R[2], R[3]);
                 *reinterpret_cast<uint4 *>(&recs[g].w[4]) = make_uint4(R[4], R[5], R[6], len);
+                // (the records' CONTENT as low bits of the sort key -- identical records next to each other inside their partition, for k_wskm_pack's windows -- was
+                // measured: k_wskm_count 412 -> 408 ms, k_wskm_scan 177 -> 194: the windows meet most repeats as it is)
                 part[g] = pbits ? mf_remix32(h[p]) >> (32 - pbits) : 0u;
             }
         }
@@ -278,11 +280,11 @@ __global__ __launch_bounds__(WC_T) void k_wskm_count(const wskm_rec *__restrict_
                 if (first || b - a > (uint64_t)WC_CH) {
                     uint32_t len = 0;
                     if (tid < nr) {
-                        const wskm_rec *rp = &recs[order[c0 + tid]];
+                        const wskm_rec *rp = order ? &recs[order[c0 + tid]] : &recs[c0 + tid];      // (order == nullptr: the records lie in their units' order, k_wskm_pack)
                         const uint4 A = *reinterpret_cast<const uint4 *>(&rp->w[0]), B = *reinterpret_cast<const uint4 *>(&rp->w[4]);
                         *reinterpret_cast<uint4 *>(&srec[tid * 8]) = A;
                         *reinterpret_cast<uint4 *>(&srec[tid * 8 + 4]) = B;
-                        len = B.w;
+                        len = B.w & 0xFFu;                           // (w[7] = k-mers | the records this one stands for << 8: k_wskm_pack; 0 there = 1)
                     }
                     const uint32_t ex = mf_block_excl_scan(len, scratch, &T);
                     soff[tid] = ex;
@@ -310,8 +312,9 @@ __global__ __launch_bounds__(WC_T) void k_wskm_count(const wskm_rec *__restrict_
                     uint32_t wb = lo_r * 8u;                                     // (the record's words: srec[wb ..])
                     mf_u128 fw = 0, rc = 0;
                     bool have = false;
+                    uint32_t wgt = 1u;                                           // identical records this one stands for (k_wskm_pack)
                     for (uint32_t i = g0; i < iend; i++, j++) {
-                        if (i >= rend) {                                         // the next record (every record holds at least one k-mer)
+                        if (i >= rend) {                                         // the next record (a record without k-mers -- a repeat -- has no place in the scan)
                             do { lo_r++; rend = soff[lo_r + 1]; } while (rend <= i);
                             j = 0; wb = lo_r * 8u; have = false;
                         }
@@ -322,6 +325,8 @@ __global__ __launch_bounds__(WC_T) void k_wskm_count(const wskm_rec *__restrict_
                             fw = X >> (128 - 2 * k);
                             rc = mf_wrevcomp(fw, k);
                             have = true;
+                            wgt = srec[wb + 7u] >> 8;
+                            wgt = wgt ? wgt : 1u;
                         } else {
                             const uint32_t bi = j + (uint32_t)k - 1u;            // the base that comes in
                             const uint32_t nb = (srec[wb + (bi >> 4)] >> (30u - 2u * (bi & 15u))) & 3u;
@@ -344,12 +349,12 @@ __global__ __launch_bounds__(WC_T) void k_wskm_count(const wskm_rec *__restrict_
                                 tlo[s] = lo;
                                 __threadfence_block();
                                 atomicExch(&thi[s], hi);
-                                atomicAdd(&tcnt[s], 1u);
+                                atomicAdd(&tcnt[s], wgt);
                                 if (atomicAdd(&s_claims, 1u) + 1u > (uint32_t)WC_FILL) s_over = 1u;
                                 break;
                             }
                             if (old == WC_BUSY) continue;                        // (being written: look again)
-                            if (old == hi && *(volatile unsigned long long *)&tlo[s] == lo) { atomicAdd(&tcnt[s], 1u); break; }
+                            if (old == hi && *(volatile unsigned long long *)&tlo[s] == lo) { atomicAdd(&tcnt[s], wgt); break; }
                             s = (s + 1u) & (WC_SLOTS - 1);
                         }
                     }
@@ -391,6 +396,51 @@ __global__ __launch_bounds__(WC_T) void k_wskm_count(const wskm_rec *__restrict_
 #endif
     for (int d = 32; d >= 1; d >>= 1) dist_acc += __shfl_down(dist_acc, d, 64);
     if ((tid & 63u) == 0 && dist_acc) atomicAdd(&counters[1], dist_acc);
+}
+
+// The records in the order of their partitions, IDENTICAL ONES ONCE (as the k <= 31 count does: reads of the same place give the same super-k-mers -- 21 % of
+// the 200 M-read sample's records repeat an earlier one, with 27 % of the k-mers): a window of 1024 sorted records is parked in LDS, a record that finds an
+// identical one in the window's set before it gives up its k-mers (w[7] = 0 k-mers) and the first one's weight grows (w[7] = k-mers | weight << 8).
+// Identical records have the same minimizer, so the same partition and unit: wherever the windows' borders fall, the counts stay right.  The counting
+// kernel then reads its records one after the other instead of through the sort's index.
+__global__ __launch_bounds__(1024) void k_wskm_pack(const wskm_rec *__restrict__ recs, const uint32_t *__restrict__ order, uint64_t n, uint32_t dedupe, wskm_rec *__restrict__ out) {
+    __shared__ uint32_t srec[1024 * 8];
+    __shared__ uint32_t hset[2048];
+    __shared__ uint32_t rw[1024];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 1024u + tid;
+    for (uint32_t q = tid; q < 2048u; q += 1024u) hset[q] = 0xFFFFFFFFu;
+    uint4 A = make_uint4(0, 0, 0, 0), B = A;
+    uint32_t h = 0;
+    if (i < n) {
+        const wskm_rec *rp = &recs[order[i]];
+        A = *reinterpret_cast<const uint4 *>(&rp->w[0]); B = *reinterpret_cast<const uint4 *>(&rp->w[4]);
+        *reinterpret_cast<uint4 *>(&srec[tid * 8]) = A;
+        *reinterpret_cast<uint4 *>(&srec[tid * 8 + 4]) = B;
+        h = (A.x * 0x9E3779B1u) ^ (A.y * 0x85EBCA6Bu) ^ (A.z * 0xC2B2AE35u) ^ (A.w * 0x27D4EB2Fu) ^ (B.x * 0x165667B1u) ^ (B.y * 0xD3A2646Cu) ^ (B.z * 0xFD7046C5u) ^ B.w;
+        h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    }
+    rw[tid] = 1u;
+    __syncthreads();
+    bool repeat = false;
+    if (i < n && dedupe) {
+        uint32_t sl = h & 2047u;
+        for (;;) {
+            const uint32_t old = atomicCAS(&hset[sl], 0xFFFFFFFFu, tid);
+            if (old == 0xFFFFFFFFu) break;
+            bool same = true;
+#pragma unroll
+            for (int w = 0; w < 8; w++) same &= srec[old * 8 + w] == srec[tid * 8 + w];
+            if (same) { atomicAdd(&rw[old], 1u); repeat = true; break; }
+            sl = (sl + 1u) & 2047u;
+        }
+    }
+    __syncthreads();
+    if (i < n) {
+        B.w = repeat ? 0u : ((B.w & 0xFFu) | (rw[tid] << 8));
+        *reinterpret_cast<uint4 *>(&out[i].w[0]) = A;
+        *reinterpret_cast<uint4 *>(&out[i].w[4]) = B;
+    }
 }
 
 __global__ void k_wskm_gather64(const uint64_t *__restrict__ src, const uint32_t *__restrict__ idx, uint64_t n, uint64_t *__restrict__ dst) {
@@ -598,6 +648,18 @@ int mf_count_wide_skm(mf_ctx *ctx, const uint8_t *d_bases, const uint64_t *d_off
         MF_HIP(hipStreamSynchronize(st));
     }
     part.reset();
+    // the records in their units' order, identical ones once (option wide_skm_pack: 0 -- through the sort's index, every record for itself; 1; 2 -- in order, no weights)
+    if (ctx->opt_wide_skm_pack) {
+        mf_buf<wskm_rec> packed;
+        if (packed.alloc(ctx, n_rec) == MF_OK) {
+            {
+                mf_ktimer tm(ctx, "k_wskm_pack");
+                k_wskm_pack<<<(unsigned)((n_rec + 1023) / 1024), 1024, 0, st>>>(recs.p, order.p, n_rec, ctx->opt_wide_skm_pack == 1 ? 1u : 0u, packed.p);
+            }
+            MF_HIP(hipStreamSynchronize(st));
+            recs.swap(packed); packed.reset(); order.reset();
+        } else (void)hipGetLastError();
+    }
     // count: the kept entries' number is not known before -- a room sized from the cut, and once more with the exact size if it was too small
     uint64_t ocap = std::max<uint64_t>(1 << 20, threshold >= 1 ? n_occ / 12 : (n_occ < 1000000000ull ? n_occ : n_occ / 2));
     mf_buf<uint64_t> ohi, olo; mf_buf<uint16_t> ocnt;

@@ -68,7 +68,7 @@ while time.time() < t_end:
     ctx.set_option("wide_passes", int(rng.choice([0, 0, 3, 16])))
     ctx.set_option("wide_big_bucket", int(rng.choice([256, 256, 4, 32]))); ctx.set_option("wide_distinct", int(rng.choice([1280, 1280, 8])))
     ctx.set_option("ut_double_after", int(rng.choice([4, 4, 1])))
-    ctx.set_option("wide_skm", int(rng.choice([1, 2, 2, 0]))); ctx.set_option("wide_skm_min", 1); ctx.set_option("wide_skm_lead", int(rng.choice([1, 1, 2, 0]))); ctx.set_option("wide_skm_merge", int(rng.choice([1, 1, 0]))); ctx.set_option("wide_skm_fine", int(rng.choice([1, 8, 32]))); ctx.set_option("wide_skm_unit", int(rng.choice([4000, 4000, 300, 64])))
+    ctx.set_option("wide_skm", int(rng.choice([1, 2, 2, 0]))); ctx.set_option("wide_skm_min", 1); ctx.set_option("wide_skm_lead", int(rng.choice([1, 1, 2, 0]))); ctx.set_option("wide_skm_merge", int(rng.choice([1, 1, 0]))); ctx.set_option("wide_skm_pack", int(rng.choice([1, 1, 2, 0]))); ctx.set_option("wide_skm_fine", int(rng.choice([1, 8, 32]))); ctx.set_option("wide_skm_unit", int(rng.choice([4000, 4000, 300, 64])))
     tag = f"it={it} seed={seed} k={k} reads={len(o)-1} bases={len(b)} thr={thr} l={l} b1={b1} b2={b2}"
     tb, to = to_device(b, o)
     ga, n_all = ctx.count_wide_above(tb.data_ptr(), to.data_ptr(), len(o) - 1, int(o[-1]), k, thr)
