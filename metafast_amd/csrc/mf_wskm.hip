@@ -39,7 +39,7 @@ int mf_sort_u64_u32(mf_ctx *ctx, const uint64_t *d_keys_in, const uint32_t *d_va
 #define WC_SLOTS 4096
 #define WC_FILL 2800
 #ifndef WC_RO
-#define WC_RO 8                                    // consecutive k-mers of a thread in the passes over one class of an overflowing unit (k_wskm_count)
+#define WC_RO 4                                    // consecutive k-mers of a thread in the passes over one class of an overflowing unit (k_wskm_count; 1 / 2 / 4 / 8 / 16: 422 / 410 / 404 / 413 / 439 ms)
 #endif
 #ifndef WC_PROF
 #define WC_PROF 0                                  // (1: thread 0 of every workgroup adds up the cycles of the kernel's phases: counters[8 .. 13], printed with verbose)
